@@ -1,0 +1,218 @@
+/*
+ * wga_hip.h — C-ABI of libwgahip.so: the MI355X (gfx950) engine for wgatools' CIGAR-driven hot path.
+ *
+ * Every compute entry point replaces one per-record Rust function of the reference (cited per
+ * function as /root/reference-relative file:line) with a *batched* call over many records.
+ *
+ * Conventions
+ *   - plain C, no ownership transfer: the caller allocates every input and output buffer.
+ *   - every `const T* d_*` / `T* d_*` argument is a DEVICE pointer (HBM resident).  Callers that
+ *     do not link HIP themselves (a Rust/cgo/ctypes binding) use wga_malloc/wga_memcpy_* below.
+ *   - `d_ops` must be 16-byte aligned (hipMalloc / wga_malloc guarantee 256).
+ *   - calls are asynchronous on the context's stream; wga_sync() (or a D2H copy) waits.
+ *   - return value: 0 = WGA_OK, negative = wga_status.  Per-record problems never fail the call:
+ *     they are reported in `wga_rec_diag` so the host can print the reference's message for the
+ *     first failing record in input order (reference: errors.rs:45-74, main.rs:14-21).
+ *
+ * Packed CIGAR op (u32): len << 4 | code, len < 2^28.  Codes follow BAM for the nine standard
+ * ops; the packer (wga_cigar_pack) splits longer lengths into several ops and marks the pieces of
+ * a split I / D with continuation codes so that event counts stay exact.
+ */
+#ifndef WGA_HIP_H
+#define WGA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WGA_ABI_VERSION 1
+
+/* ---- status codes (call level) ------------------------------------------------------------ */
+enum wga_status {
+  WGA_OK = 0,
+  WGA_E_INVALID_ARG = -1,
+  WGA_E_NO_DEVICE = -2,
+  WGA_E_HIP = -3, /* a HIP runtime call failed; see wga_last_error() */
+  WGA_E_OOM = -4,
+  WGA_E_TOO_SMALL = -5 /* caller buffer too small (host packer) */
+};
+
+/* ---- packed op codes ---------------------------------------------------------------------- */
+enum wga_op_code {
+  WGA_OP_M = 0,
+  WGA_OP_I = 1,
+  WGA_OP_D = 2,
+  WGA_OP_N = 3,
+  WGA_OP_S = 4,
+  WGA_OP_H = 5,
+  WGA_OP_P = 6,
+  WGA_OP_EQ = 7,
+  WGA_OP_X = 8,
+  WGA_OP_I_CONT = 9,   /* continuation of a split I: same bases, no new event */
+  WGA_OP_D_CONT = 10,  /* continuation of a split D */
+  WGA_OP_OTHER = 11    /* any other single-char op (`B`, `z`, `é`, ...): the reference accepts the
+                          token and lets each consumer decide (cigar.rs:43-56) */
+};
+#define WGA_OP_LEN_BITS 28
+#define WGA_OP_MAX_LEN ((1u << WGA_OP_LEN_BITS) - 1u)
+#define WGA_PACK_OP(len, code) (((uint32_t)(len) << 4) | (uint32_t)(code))
+
+/* ---- per-record error codes: 1:1 with the WGAError variants the hot path can raise --------- */
+enum wga_rec_err {
+  WGA_REC_OK = 0,
+  WGA_REC_CIGAR_TAG_NOT_FOUND = 1, /* errors.rs:57  "CIGAR start tag not found"            */
+  WGA_REC_CIGAR_OP_INVALID = 2,    /* errors.rs:59  "CIGAR OP `{0}` invalid"               */
+  WGA_REC_PARSE_INT = 3,           /* errors.rs:51  "Parse `{0}` Into Integer Error"       */
+  WGA_REC_INVALID_BASE = 4,        /* errors.rs:73  "Invalid Base: `{0}`"                  */
+  WGA_REC_NOM = 5,                 /* errors.rs:45  nom tag error                          */
+  WGA_REC_PANIC = 6                /* the reference panics (errors.rs:92 slice, String::insert_str
+                                      out of range at cigar.rs:507,513)                    */
+};
+
+#define WGA_NONE UINT64_MAX
+
+/* Device-side per-record diagnostics (all fields WGA_NONE when clean).  Written with atomicMin so
+ * "first in op order" / "first in reversed-sequence order" is exact. */
+typedef struct {
+  uint64_t bad_op_idx;   /* first op (index inside the record) the consumer rejects              */
+  uint64_t panic_op_idx; /* first I/D op whose insertion point lies beyond the fetched sequence  */
+  uint64_t bad_base_pos; /* first invalid base in reverse-complement order (utils.rs:85-98)      */
+} wga_rec_diag;
+
+/* = struct Cigar sans text (cigar.rs:16-29) */
+typedef struct {
+  uint64_t match, mismatch, ins_ev, ins_bp, del_ev, del_bp, inv_ins_ev, inv_ins_bp, inv_del_ev,
+      inv_del_bp, inv_ev;
+} wga_cigar_counts;
+
+/* CSR batch of n records: d_ops[d_op_off[i] .. d_op_off[i+1]) belong to record i. */
+typedef struct {
+  const uint32_t* d_ops;
+  const uint64_t* d_op_off; /* n+1 entries, d_op_off[0] == 0 */
+  const uint8_t* d_strand_neg; /* n entries, 1 = '-' (common.rs:42-48) */
+  uint64_t n_ops;              /* == d_op_off[n] (host copy, sizes the launch) */
+  uint32_t n;
+} wga_cigar_batch;
+
+typedef struct wga_ctx wga_ctx;
+
+/* ---- context / runtime plumbing ------------------------------------------------------------ */
+int wga_abi_version(void);
+const char* wga_last_error(void);
+int wga_device_count(void);
+int wga_ctx_create(int device, wga_ctx** out);
+void wga_ctx_destroy(wga_ctx*);
+/* Launch on an external stream (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL restores the context's own stream. */
+int wga_ctx_set_stream(wga_ctx*, void* hip_stream);
+/* Tunables: "expand_force_slow" (0/1) forces the u64 op-serial fallback of the expand kernel. */
+int wga_ctx_set_param(wga_ctx*, const char* name, int64_t value);
+int wga_sync(wga_ctx*);
+int wga_malloc(wga_ctx*, size_t bytes, void** d_out);
+int wga_free(wga_ctx*, void* d_ptr);
+int wga_memcpy_h2d(wga_ctx*, void* d_dst, const void* h_src, size_t bytes);
+int wga_memcpy_d2h(wga_ctx*, void* h_dst, const void* d_src, size_t bytes); /* synchronises */
+int wga_memset(wga_ctx*, void* d_dst, int byte, size_t bytes);
+
+/* ---- host: CIGAR text -> packed ops (replaces the nom tokeniser, cigar.rs:43-75,
+ *      utils.rs:69-74; driven per record by every consumer, e.g. cigar.rs:529-549) ------------
+ * `text` is the CIGAR *after* the "cg:Z:" tag.  Emits ops until the first tokeniser error, which
+ * is returned in *err (wga_rec_err) with the offending token in [*err_tok_off, +*err_tok_len).
+ * Returns WGA_OK, or WGA_E_TOO_SMALL with *n_ops = required capacity. */
+int wga_cigar_pack(const char* text, size_t len, uint32_t* ops, size_t cap, size_t* n_ops,
+                   int32_t* err, size_t* err_tok_off, size_t* err_tok_len);
+/* Upper bound of ops wga_cigar_pack can emit for `len` bytes of text. */
+size_t wga_cigar_pack_bound(const char* text, size_t len);
+
+/* ---- K1: PAF stat walk (replaces parse_paf_to_cigar, cigar.rs:629-707) ----------------------
+ * d_counts[n]; d_diag[n] (bad_op_idx set for ops other than M = X I D).
+ * d_tile_ws (optional, may be NULL): wga_tile_ws_bytes(n_ops) bytes, filled with the per-tile
+ * partial sums wga_paf2maf_expand needs to place a tile inside a long record. */
+size_t wga_tile_ws_bytes(uint64_t n_ops);
+int wga_cigar_stat(wga_ctx*, const wga_cigar_batch*, wga_cigar_counts* d_counts,
+                   wga_rec_diag* d_diag, void* d_tile_ws);
+
+/* ---- paf2maf row geometry (host logic of converter.rs:196-263 moved on device) --------------
+ * Row lengths follow String::insert_str semantics: t_row_len = t_src_len + I bases,
+ * q_row_len = q_src_len + D bases (cigar.rs:504-515).  Each record occupies
+ *   pre_t[i] | t row | pre_q[i] | q row | post[i]   bytes of the output text
+ * (pre/post = the MAF line text around the rows, maf.rs:566-581; NULL = 0).
+ * Outputs: d_t_row_off[n], d_q_row_off[n], d_rec_off[n+1] (d_rec_off[n] = total bytes). */
+int wga_paf2maf_layout(wga_ctx*, uint32_t n, const wga_cigar_counts* d_counts,
+                       const uint64_t* d_t_src_len, const uint64_t* d_q_src_len,
+                       const uint32_t* d_pre_t, const uint32_t* d_pre_q, const uint32_t* d_post,
+                       uint64_t* d_t_row_off, uint64_t* d_q_row_off, uint64_t* d_rec_off);
+
+/* ---- K2: paf2maf gap insertion (replaces parse_cigar_to_insert + cigar_unit_insert_seq,
+ *      cigar.rs:492-551, and reverse_complement, utils.rs:83-101) -----------------------------
+ * t_fa/q_fa: ungapped forward-strand sequence pools; record i uses
+ *   t_fa[t_src_off[i] .. +t_src_len[i])   and   q_fa[q_src_off[i] .. +q_src_len[i])
+ * (what faidx fetch returned, converter.rs:219-225).  For strand '-' the kernel reads the query
+ * slice reversed and complemented.  Writes the two gapped rows at d_out + d_*_row_off[i].
+ * d_counts / d_tile_ws must come from wga_cigar_stat on the same batch; d_diag is updated
+ * (panic_op_idx, bad_base_pos). */
+int wga_paf2maf_expand(wga_ctx*, const wga_cigar_batch*, const wga_cigar_counts* d_counts,
+                       const void* d_tile_ws, const uint8_t* d_t_fa, uint64_t t_fa_bytes,
+                       const uint64_t* d_t_src_off, const uint64_t* d_t_src_len,
+                       const uint8_t* d_q_fa, uint64_t q_fa_bytes, const uint64_t* d_q_src_off,
+                       const uint64_t* d_q_src_len, uint8_t* d_out, const uint64_t* d_t_row_off,
+                       const uint64_t* d_q_row_off, wga_rec_diag* d_diag);
+
+/* Copy n variable-length byte snippets: d_dst[d_dst_off[i] ..) = d_src[d_src_off[i] .. d_src_off[i+1])
+ * (used to drop the "a score=…" / "s\tname\t…" line text between the rows, maf.rs:566-581). */
+int wga_scatter_bytes(wga_ctx*, uint32_t n, const uint8_t* d_src, const uint64_t* d_src_off,
+                      uint8_t* d_dst, const uint64_t* d_dst_off);
+
+/* ---- K3: MAF column-pair walk (replaces parse_maf_seq_to_cigar + cigar_cat_ext,
+ *      cigar.rs:298-308,344-432) ---------------------------------------------------------------
+ * Record i compares d_rows[t_off[i] + j] with d_rows[q_off[i] + j] for j < cols[i]
+ * (cols = min of the two row lengths: `zip` truncates).  d_counts[n] as K1.
+ * Optional RLE for maf2paf's cg:Z: text (maf.rs:484-520): if d_runs != NULL, record i's runs are
+ * written to d_runs[d_run_off[i] ..) as (len << 4 | code) with code in {=,X,I,D}; a run longer
+ * than 2^28-1 is split into same-code pieces (the host re-merges when formatting).
+ * d_run_cnt[n] always receives the number of u32 words record i needs; call once with
+ * d_runs == NULL to size, scan on the host (or wga_exclusive_scan_u64), call again. */
+int wga_maf_pair_stat(wga_ctx*, uint32_t n, const uint8_t* d_rows, const uint64_t* d_t_off,
+                      const uint64_t* d_q_off, const uint64_t* d_cols,
+                      const uint8_t* d_strand_neg, wga_cigar_counts* d_counts,
+                      uint64_t* d_run_cnt, uint32_t* d_runs, const uint64_t* d_run_off);
+
+/* ---- K5: pafcov (replaces update_cov_vec, cigar.rs:710-741, and the per-thread array merge of
+ *      pafcov.rs:29-53) ------------------------------------------------------------------------
+ * Record i adds +1 to d_cov[cov_off[target_id[i]] + p] for every base p of its M / = ops that
+ * lies below cov_len[target_id[i]].  Implemented as a difference array: accumulate() adds the
+ * ±1 marks, finalize() turns marks into counts by an inclusive scan per target. */
+int wga_pafcov_accumulate(wga_ctx*, const wga_cigar_batch*, const uint32_t* d_target_id,
+                          const uint64_t* d_t_start, const uint64_t* d_cov_off,
+                          const uint64_t* d_cov_len, int32_t* d_cov);
+int wga_pafcov_finalize(wga_ctx*, uint32_t n_targets, const uint64_t* d_cov_off,
+                        const uint64_t* d_cov_len, int32_t* d_cov);
+
+/* ---- per-record class sums of a batch: bases in M/=/X, I, D, S and "other" (N H P ...) ops.
+ *      pafpseudo's host logic (pseudomaf.rs:147-202) needs M+X+D (target span) and the edited
+ *      query length q_len - (I+S) + D before it can place segments.  d_sums: n x 5 u64. ------- */
+typedef struct {
+  uint64_t mx, i, d, s, o;
+} wga_class_sums;
+int wga_cigar_class_sums(wga_ctx*, const wga_cigar_batch*, wga_class_sums* d_sums);
+
+/* ---- K6: pafpseudo row segments (replaces gen_pesudo_maf_by_cigar, cigar.rs:744-804, plus the
+ *      overlap trim of pseudomaf.rs:190-192) ---------------------------------------------------
+ * Record i writes its target-coordinate segment (length M+X+D, minus skip[i] leading columns)
+ * at d_out + d_dst_off[i].  base_mode = 1: bases from q_fa (reverse-complemented for '-'),
+ * 0: symbols '1' (M/=), '0' (X), '-' (D). */
+int wga_pafpseudo_fill(wga_ctx*, const wga_cigar_batch*, int base_mode, const uint8_t* d_q_fa,
+                       uint64_t q_fa_bytes, const uint64_t* d_q_src_off,
+                       const uint64_t* d_q_src_len, const uint64_t* d_skip, uint8_t* d_out,
+                       const uint64_t* d_dst_off, wga_rec_diag* d_diag);
+
+/* ---- utility: exclusive scan of n u64 values on device (d_out[n+1], d_out[n] = total) ------- */
+int wga_exclusive_scan_u64(wga_ctx*, uint32_t n, const uint64_t* d_in, uint64_t* d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WGA_HIP_H */

@@ -1,0 +1,780 @@
+/*
+ * oracle.c — CPU restatement of wgatools' CIGAR hot path.  TEST INFRASTRUCTURE ONLY
+ * (see oracle.h for the usage rule and the parity-pinning statement: README VCF golden pins the
+ * `call` walk; stat / paf2maf / maf2paf / pafcov / pafpseudo are "parity unpinned").
+ *
+ * Deliberately naive: it keeps the reference's algorithmic structure — text tokenising per
+ * consumer, String::insert_str / drain with tail memmove (quadratic), per-base coverage
+ * increments — so that it is an independent check of the scan-based GPU kernels and a faithful
+ * "port" CPU baseline.  All citations are /root/reference-relative.
+ */
+#include "oracle.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* small helpers                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+static void set_err(orc_err* e, int kind, const char* arg, size_t n) {
+  if (!e) return;
+  e->kind = kind;
+  if (n > sizeof(e->arg) - 1) n = sizeof(e->arg) - 1;
+  if (arg && n) memcpy(e->arg, arg, n);
+  e->arg[n] = 0;
+}
+
+void orc_free(void* p) { free(p); }
+
+/* errors.rs:45-74 message templates */
+void orc_err_message(const orc_err* e, char* buf, size_t cap) {
+  switch (e->kind) {
+    case ORC_OK: snprintf(buf, cap, "ok"); break;
+    case ORC_CIGAR_TAG_NOT_FOUND: snprintf(buf, cap, "CIGAR start tag not found"); break;
+    case ORC_CIGAR_OP_INVALID: snprintf(buf, cap, "CIGAR OP `%s` invalid", e->arg); break;
+    case ORC_PARSE_INT: snprintf(buf, cap, "Parse `%s` Into Integer Error", e->arg); break;
+    case ORC_INVALID_BASE: snprintf(buf, cap, "Invalid Base: `%s`", e->arg); break;
+    case ORC_NOM: /* errors.rs:45 + nom 7 Display of Error<String>: "error {:?} at: {}" */
+      snprintf(buf, cap, "Format error Tag at: %s Parse Error by rust::nom, please check", e->arg);
+      break;
+    default: snprintf(buf, cap, "panic: %s", e->arg); break;
+  }
+}
+
+static int is_digit(char c) { return c >= '0' && c <= '9'; }
+
+/* number of bytes of the UTF-8 char starting at s (chars() semantics of cst2cu, cigar.rs:45-53) */
+static size_t utf8_len(unsigned char c) {
+  if (c < 0x80) return 1;
+  if ((c >> 5) == 0x6) return 2;
+  if ((c >> 4) == 0xE) return 3;
+  if ((c >> 3) == 0x1E) return 4;
+  return 1;
+}
+
+/* One CigarStrTuple (cigar.rs:38): op token and length token. */
+typedef struct {
+  const char* len;
+  size_t len_n;
+  const char* op;
+  size_t op_n;
+} cst_t;
+
+/* parse_cigar_str_tuple, cigar.rs:59-75: empty input -> Eof error (ends fold_many1);
+ * else take_while(digit) then take_till(digit). Returns 1 if a tuple was produced. */
+static int parse_cigar_str_tuple(const char** p, const char* end, cst_t* out) {
+  if (*p == end) return 0;
+  const char* s = *p;
+  out->len = s;
+  while (s < end && is_digit(*s)) s++;
+  out->len_n = (size_t)(s - out->len);
+  out->op = s;
+  while (s < end && !is_digit(*s)) s++;
+  out->op_n = (size_t)(s - out->op);
+  *p = s;
+  return 1;
+}
+
+/* cst2cu, cigar.rs:43-56 (+ parse_str2u64, utils.rs:69-74).  The op is checked before the
+ * length. On success *op points at the single (possibly multi-byte) char. */
+static int cst2cu(const cst_t* t, const char** op, size_t* op_n, uint64_t* len, orc_err* err) {
+  if (t->op_n == 0) { /* chars.next() == None */
+    set_err(err, ORC_CIGAR_OP_INVALID, "", 0);
+    return ORC_CIGAR_OP_INVALID;
+  }
+  size_t first = utf8_len((unsigned char)t->op[0]);
+  if (first < t->op_n) { /* a second char exists */
+    set_err(err, ORC_CIGAR_OP_INVALID, t->op, t->op_n);
+    return ORC_CIGAR_OP_INVALID;
+  }
+  if (t->len_n == 0) { /* "".parse::<u64>() fails */
+    set_err(err, ORC_PARSE_INT, "", 0);
+    return ORC_PARSE_INT;
+  }
+  uint64_t v = 0;
+  for (size_t i = 0; i < t->len_n; i++) {
+    uint64_t d = (uint64_t)(t->len[i] - '0');
+    if (v > (UINT64_MAX - d) / 10) { /* u64 overflow -> parse error */
+      set_err(err, ORC_PARSE_INT, t->len, t->len_n);
+      return ORC_PARSE_INT;
+    }
+    v = v * 10 + d;
+  }
+  *op = t->op;
+  *op_n = t->op_n;
+  *len = v;
+  return ORC_OK;
+}
+
+/* tag("cg:Z:") + the From<nom::Err> conversion of errors.rs:88-96 (slices input[..10]). */
+static int strip_tag(const char** p, const char* end, orc_err* err) {
+  size_t n = (size_t)(end - *p);
+  if (n >= 5 && memcmp(*p, "cg:Z:", 5) == 0) {
+    *p += 5;
+    return ORC_OK;
+  }
+  if (n < 10) {
+    set_err(err, ORC_PANIC, "byte index 10 is out of bounds (errors.rs:92)", 46);
+    return ORC_PANIC;
+  }
+  set_err(err, ORC_NOM, *p, 10);
+  return ORC_NOM;
+}
+
+/* fold_many1 needs at least one tuple; on an empty CIGAR the Many1 error is converted through
+ * errors.rs:92 with an empty input -> the reference panics. */
+static int empty_cigar_panic(orc_err* err) {
+  set_err(err, ORC_PANIC, "byte index 10 is out of bounds (errors.rs:92)", 46);
+  return ORC_PANIC;
+}
+
+static int op_is(const char* op, size_t n, char c) { return n == 1 && op[0] == c; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* parse_paf_to_cigar, cigar.rs:629-707                                                        */
+/* ------------------------------------------------------------------------------------------ */
+int orc_parse_paf_to_cigar(const char* cg, size_t n, int strand_neg, orc_counts* out,
+                           orc_err* err) {
+  memset(out, 0, sizeof(*out));
+  if (err) err->kind = ORC_OK;
+  const char* p = cg;
+  const char* end = cg + n;
+  int inv = 0;
+  if (strand_neg) { /* :643-649 */
+    out->inv_ev = 1;
+    inv = 1;
+  }
+  int rc = strip_tag(&p, end, err); /* :652 */
+  if (rc) return rc;
+  if (p == end) return empty_cigar_panic(err);
+  cst_t t;
+  while (parse_cigar_str_tuple(&p, end, &t)) { /* :654-691 */
+    const char* op;
+    size_t op_n;
+    uint64_t len;
+    rc = cst2cu(&t, &op, &op_n, &len, err);
+    if (rc) return rc; /* first error sticks; later ops are skipped and `res?` returns it */
+    if (op_is(op, op_n, 'M') || op_is(op, op_n, '=')) {
+      out->match += len;
+    } else if (op_is(op, op_n, 'X')) {
+      out->mismatch += len;
+    } else if (op_is(op, op_n, 'I')) {
+      if (inv) {
+        out->inv_ins_ev += 1;
+        out->inv_ins_bp += len;
+      } else {
+        out->ins_ev += 1;
+        out->ins_bp += len;
+      }
+    } else if (op_is(op, op_n, 'D')) {
+      if (inv) {
+        out->inv_del_ev += 1;
+        out->inv_del_bp += len;
+      } else {
+        out->del_ev += 1;
+        out->del_bp += len;
+      }
+    } else {
+      set_err(err, ORC_CIGAR_OP_INVALID, op, op_n);
+      return ORC_CIGAR_OP_INVALID;
+    }
+  }
+  return ORC_OK;
+}
+
+/* RecStat::from, common.rs:116-140 */
+void orc_recstat_from(const orc_counts* c, orc_recstat* r) {
+  memset(r, 0, sizeof(*r));
+  r->matched = c->match;
+  r->mismatched = c->mismatch;
+  r->ins_event = c->ins_ev;
+  r->del_event = c->del_ev;
+  r->ins_size = c->ins_bp;
+  r->del_size = c->del_bp;
+  r->inv_ins_event = c->inv_ins_ev;
+  r->inv_ins_size = c->inv_ins_bp;
+  r->inv_del_event = c->inv_del_ev;
+  r->inv_del_size = c->inv_del_bp;
+  r->aligned_size = r->matched + r->mismatched + r->del_size + r->inv_del_size;
+  uint64_t query_align_size = r->matched + r->mismatched + r->ins_size + r->inv_ins_size;
+  r->inv_event = c->inv_ev;
+  if (r->inv_event != 0) { /* usize as f32 / usize as f32 */
+    r->inv_size = (float)(r->aligned_size + query_align_size) / (float)(r->inv_event + 1);
+  }
+}
+
+/* reverse_complement, utils.rs:83-101: iterates chars().rev(); first offender (from the END of
+ * the input) is reported. */
+int orc_reverse_complement(const char* in, size_t n, char* out, orc_err* err) {
+  if (err) err->kind = ORC_OK;
+  for (size_t i = 0; i < n; i++) {
+    char c = in[n - 1 - i];
+    char o;
+    switch (c) {
+      case 'A': o = 'T'; break;
+      case 'C': o = 'G'; break;
+      case 'G': o = 'C'; break;
+      case 'T': o = 'A'; break;
+      case 'N': o = 'N'; break;
+      case 'a': o = 't'; break;
+      case 'c': o = 'g'; break;
+      case 'g': o = 'c'; break;
+      case 't': o = 'a'; break;
+      case 'n': o = 'n'; break;
+      default:
+        set_err(err, ORC_INVALID_BASE, &c, 1);
+        return ORC_INVALID_BASE;
+    }
+    out[i] = o;
+  }
+  return ORC_OK;
+}
+
+/* String::insert_str(idx, "-" * count): panics when idx > len; tail memmove otherwise. */
+static int string_insert_gaps(char** s, size_t* sn, uint64_t idx, uint64_t count, orc_err* err) {
+  if (idx > *sn) {
+    set_err(err, ORC_PANIC, "String::insert_str index out of range (cigar.rs:507,513)", 56);
+    return ORC_PANIC;
+  }
+  char* ns = (char*)realloc(*s, *sn + count + 1);
+  if (!ns) abort();
+  memmove(ns + idx + count, ns + idx, *sn - idx);
+  memset(ns + idx, '-', count);
+  *s = ns;
+  *sn += count;
+  return ORC_OK;
+}
+
+/* parse_cigar_to_insert, cigar.rs:522-551, with cigar_unit_insert_seq, :492-519 */
+int orc_parse_cigar_to_insert(const char* cg, size_t n, char** t, size_t* tn, char** q, size_t* qn,
+                              orc_err* err) {
+  if (err) err->kind = ORC_OK;
+  const char* p = cg;
+  const char* end = cg + n;
+  int rc = strip_tag(&p, end, err); /* :529 */
+  if (rc) return rc;
+  if (p == end) return empty_cigar_panic(err);
+  uint64_t current_offset = 0;
+  cst_t tok;
+  while (parse_cigar_str_tuple(&p, end, &tok)) {
+    const char* op;
+    size_t op_n;
+    uint64_t len;
+    rc = cst2cu(&tok, &op, &op_n, &len, err);
+    if (rc) return rc;
+    if (op_is(op, op_n, 'M') || op_is(op, op_n, '=') || op_is(op, op_n, 'X')) {
+      current_offset += len; /* :500-503 */
+    } else if (op_is(op, op_n, 'I')) { /* :504-509 insert '-' into target */
+      rc = string_insert_gaps(t, tn, current_offset, len, err);
+      if (rc) return rc;
+      current_offset += len;
+    } else if (op_is(op, op_n, 'D')) { /* :510-515 insert '-' into query */
+      rc = string_insert_gaps(q, qn, current_offset, len, err);
+      if (rc) return rc;
+      current_offset += len;
+    } else {
+      set_err(err, ORC_CIGAR_OP_INVALID, op, op_n);
+      return ORC_CIGAR_OP_INVALID;
+    }
+  }
+  return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* MAF column pair walk                                                                        */
+/* ------------------------------------------------------------------------------------------ */
+/* cigar_cat_ext, cigar.rs:298-308 */
+static char cigar_cat_ext(char c1, char c2) {
+  if (c1 == c2) return '=';
+  if (c1 == '-') return 'I';
+  if (c2 == '-') return 'D';
+  return 'X';
+}
+/* cigar_cat_ext_caller, cigar.rs:314-328 */
+static char cigar_cat_ext_caller(char c1, char c2) {
+  if (c1 == '-') return c2 == '-' ? 'W' : 'I';
+  if (c2 == '-') return 'D';
+  return c1 == c2 ? '=' : 'X';
+}
+
+typedef struct {
+  char* s;
+  size_t n, cap;
+} sbuf;
+static void sb_push(sbuf* b, const char* s, size_t n) {
+  if (b->n + n + 1 > b->cap) {
+    size_t nc = b->cap ? b->cap * 2 : 256;
+    while (nc < b->n + n + 1) nc *= 2;
+    b->s = (char*)realloc(b->s, nc);
+    if (!b->s) abort();
+    b->cap = nc;
+  }
+  memcpy(b->s + b->n, s, n);
+  b->n += n;
+  b->s[b->n] = 0;
+}
+static void sb_printf_u64(sbuf* b, uint64_t v) {
+  char tmp[32];
+  int k = snprintf(tmp, sizeof tmp, "%llu", (unsigned long long)v);
+  sb_push(b, tmp, (size_t)k);
+}
+
+/* parse_maf_seq_to_cigar(rec, with_h = false), cigar.rs:344-432.  The rows are zipped (shorter
+ * wins) and grouped into maximal runs of equal category (itertools group_by). */
+void orc_parse_maf_seq_to_cigar(const char* t, size_t tn, const char* q, size_t qn, int strand_neg,
+                                orc_counts* out, char** cigar_text) {
+  memset(out, 0, sizeof(*out));
+  sbuf sb = {0, 0, 0};
+  sb_push(&sb, "", 0);
+  size_t cols = tn < qn ? tn : qn;
+  int inv = 0;
+  if (strand_neg) { /* :370-376 */
+    out->inv_ev = 1;
+    inv = 1;
+  }
+  size_t i = 0;
+  while (i < cols) {
+    char k = cigar_cat_ext(t[i], q[i]);
+    size_t j = i + 1;
+    while (j < cols && cigar_cat_ext(t[j], q[j]) == k) j++;
+    uint64_t len = (uint64_t)(j - i);
+    switch (k) { /* :382-408 */
+      case '=': out->match += len; break;
+      case 'I':
+        if (inv) {
+          out->inv_ins_ev += 1;
+          out->inv_ins_bp += len;
+        } else {
+          out->ins_ev += 1;
+          out->ins_bp += len;
+        }
+        break;
+      case 'D':
+        if (inv) {
+          out->inv_del_ev += 1;
+          out->inv_del_bp += len;
+        } else {
+          out->del_ev += 1;
+          out->del_bp += len;
+        }
+        break;
+      case 'X': out->mismatch += len; break;
+    }
+    sb_printf_u64(&sb, len); /* :409-410 */
+    sb_push(&sb, &k, 1);
+    i = j;
+  }
+  if (cigar_text)
+    *cigar_text = sb.s;
+  else
+    free(sb.s);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* update_cov_vec, cigar.rs:710-741                                                            */
+/* ------------------------------------------------------------------------------------------ */
+int orc_update_cov_vec(uint64_t* cov, size_t cov_len, const char* cg, size_t n, size_t start,
+                       orc_err* err) {
+  if (err) err->kind = ORC_OK;
+  const char* p = cg;
+  const char* end = cg + n;
+  int rc = strip_tag(&p, end, err);
+  if (rc) return rc;
+  if (p == end) return empty_cigar_panic(err);
+  size_t pos = start;
+  cst_t tok;
+  while (parse_cigar_str_tuple(&p, end, &tok)) {
+    const char* op;
+    size_t op_n;
+    uint64_t len;
+    rc = cst2cu(&tok, &op, &op_n, &len, err);
+    if (rc) return rc;
+    size_t length = (size_t)len;
+    if (op_is(op, op_n, 'M') || op_is(op, op_n, '=')) { /* :721-728 per-base increments */
+      for (size_t i = pos; i < pos + length; i++) {
+        if (i < cov_len) cov[i] += 1;
+      }
+      pos += length;
+    } else if (op_is(op, op_n, 'I') || op_is(op, op_n, 'S')) {
+      /* :729 nothing */
+    } else {
+      pos += length; /* :731-733 everything else (D, X, N, H, P, ...) just moves */
+    }
+  }
+  return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* gen_pesudo_maf_by_cigar, cigar.rs:744-804                                                   */
+/* ------------------------------------------------------------------------------------------ */
+static void str_push_n(char** s, size_t* sn, char c, size_t count) {
+  char* ns = (char*)realloc(*s, *sn + count + 1);
+  if (!ns) abort();
+  memset(ns + *sn, c, count);
+  *s = ns;
+  *sn += count;
+}
+
+int orc_gen_pesudo_maf_by_cigar(const char* cg, size_t n, char** q, size_t* qn, int base,
+                                orc_err* err) {
+  if (err) err->kind = ORC_OK;
+  const char* p = cg;
+  const char* end = cg + n;
+  int rc = strip_tag(&p, end, err);
+  if (rc) return rc;
+  if (p == end) return empty_cigar_panic(err);
+  size_t current_offset = 0;
+  cst_t tok;
+  while (parse_cigar_str_tuple(&p, end, &tok)) {
+    const char* op;
+    size_t op_n;
+    uint64_t len;
+    rc = cst2cu(&tok, &op, &op_n, &len, err);
+    if (rc) return rc;
+    size_t length = (size_t)len;
+    if (op_is(op, op_n, 'M') || op_is(op, op_n, '=')) { /* :760-768 */
+      if (base)
+        current_offset += length;
+      else
+        str_push_n(q, qn, '1', length);
+    } else if (op_is(op, op_n, 'I') || op_is(op, op_n, 'S')) { /* :769-776 drain */
+      if (base) {
+        if (current_offset + length > *qn || current_offset > current_offset + length) {
+          set_err(err, ORC_PANIC, "String::drain range out of bounds (cigar.rs:772)", 48);
+          return ORC_PANIC;
+        }
+        memmove(*q + current_offset, *q + current_offset + length,
+                *qn - current_offset - length);
+        *qn -= length;
+      }
+    } else if (op_is(op, op_n, 'D')) { /* :777-786 */
+      if (base) {
+        rc = string_insert_gaps(q, qn, current_offset, length, err);
+        if (rc) return rc;
+        current_offset += length;
+      } else {
+        str_push_n(q, qn, '-', length);
+      }
+    } else if (op_is(op, op_n, 'X')) { /* :787-795 */
+      if (base)
+        current_offset += length;
+      else
+        str_push_n(q, qn, '0', length);
+    } else {
+      /* :796 ignored */
+    }
+  }
+  return ORC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* cs_to_cigar, paf.rs:159-218.  Regex (:[0-9]+|\*[a-z][a-z]|[=\+\-][A-Za-z]+) restated as a   */
+/* leftmost scanner: unmatched bytes are skipped exactly like captures_iter does.              */
+/* ------------------------------------------------------------------------------------------ */
+static int is_lower(char c) { return c >= 'a' && c <= 'z'; }
+static int is_alpha(char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
+
+char* orc_cs_to_cigar(const char* cs, size_t n) {
+  sbuf sb = {0, 0, 0};
+  sb_push(&sb, "", 0);
+  char last_op = 'M';
+  uint64_t last_len = 0;
+  size_t i = 0;
+  while (i < n) {
+    char c = cs[i];
+    if (c == ':' && i + 1 < n && is_digit(cs[i + 1])) {
+      size_t j = i + 1;
+      uint64_t length = 0;
+      while (j < n && is_digit(cs[j])) length = length * 10 + (uint64_t)(cs[j++] - '0');
+      if (last_op == 'M') {
+        last_len += length;
+      } else {
+        if (last_len > 0) {
+          sb_printf_u64(&sb, last_len);
+          sb_push(&sb, &last_op, 1);
+        }
+        last_op = 'M';
+        last_len = length;
+      }
+      i = j;
+    } else if (c == '*' && i + 2 < n + 0 && is_lower(cs[i + 1]) && is_lower(cs[i + 2])) {
+      if (last_op == 'X') {
+        last_len += 1;
+      } else {
+        if (last_len > 0) {
+          sb_printf_u64(&sb, last_len);
+          sb_push(&sb, &last_op, 1);
+        }
+        last_op = 'X';
+        last_len = 1;
+      }
+      i += 3;
+    } else if ((c == '=' || c == '+' || c == '-') && i + 1 < n && is_alpha(cs[i + 1])) {
+      size_t j = i + 1;
+      while (j < n && is_alpha(cs[j])) j++;
+      uint64_t length = (uint64_t)(j - i - 1);
+      if (c == '-' || c == '+') {
+        if (last_len > 0) {
+          sb_printf_u64(&sb, last_len);
+          sb_push(&sb, &last_op, 1);
+        }
+        sb_printf_u64(&sb, length);
+        sb_push(&sb, c == '-' ? "D" : "I", 1);
+        last_len = 0;
+        last_op = 'M';
+      } /* '=' parts are matched but ignored, paf.rs:209 */
+      i = j;
+    } else {
+      i++;
+    }
+  }
+  if (last_len > 0) {
+    sb_printf_u64(&sb, last_len);
+    sb_push(&sb, &last_op, 1);
+  }
+  return sb.s;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* call (MAF), caller.rs                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+/* find_safe_chunk_boundary, caller.rs:159-219 */
+size_t orc_find_safe_chunk_boundary(const char* t, const char* q, size_t total, size_t start,
+                                    size_t chunk_size, uint64_t svlen_cutoff) {
+  size_t proposed_end = start + chunk_size < total ? start + chunk_size : total;
+  size_t current_gap_size = 0;
+  int in_sv = 0;
+  size_t sv_start = 0;
+  size_t safe_end = proposed_end;
+  for (size_t abs_pos = start; abs_pos < proposed_end; abs_pos++) {
+    char rc = t[abs_pos], qc = q[abs_pos];
+    if (rc == '-' || qc == '-') {
+      if (!in_sv) {
+        in_sv = 1;
+        sv_start = abs_pos;
+      }
+      current_gap_size += 1;
+    } else if (in_sv) {
+      if (current_gap_size >= (size_t)svlen_cutoff) {
+        if (sv_start >= start) safe_end = abs_pos;
+      }
+      in_sv = 0;
+      current_gap_size = 0;
+    }
+  }
+  if (in_sv && current_gap_size >= (size_t)svlen_cutoff) { /* :202-215 */
+    size_t end_pos = proposed_end;
+    for (size_t pos = proposed_end; pos < total; pos++) {
+      if (t[pos] != '-' && q[pos] != '-') {
+        end_pos = pos;
+        break;
+      }
+    }
+    safe_end = end_pos;
+  }
+  return safe_end;
+}
+
+/* noodles-vcf 0.43 reference/alternate base parsing upper-cases a/c/g/t/n (third-party, source
+ * not in the reference tree: unpinned). */
+static void sb_push_bases_upper(sbuf* b, const char* s, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    char c = s[i];
+    if (c >= 'a' && c <= 'z') c = (char)(c - 32);
+    sb_push(b, &c, 1);
+  }
+}
+
+/* one VCF body line in noodles-vcf 0.43 layout (README.md:332-342):
+ * CHROM POS ID(.) REF ALT QUAL(.) FILTER(.) INFO FORMAT SAMPLE */
+static void emit_vcf(sbuf* out, const char* chro, uint64_t pos, const char* ref, size_t ref_n,
+                     const char* alt, size_t alt_n, int alt_symbolic, const char* info,
+                     const char* fmt_and_sample) {
+  sb_push(out, chro, strlen(chro));
+  sb_push(out, "\t", 1);
+  sb_printf_u64(out, pos);
+  sb_push(out, "\t.\t", 3);
+  sb_push_bases_upper(out, ref, ref_n);
+  sb_push(out, "\t", 1);
+  if (alt_symbolic)
+    sb_push(out, alt, alt_n);
+  else
+    sb_push_bases_upper(out, alt, alt_n);
+  sb_push(out, "\t.\t.\t", 5);
+  if (info)
+    sb_push(out, info, strlen(info));
+  else
+    sb_push(out, ".", 1);
+  sb_push(out, "\t", 1);
+  sb_push(out, fmt_and_sample, strlen(fmt_and_sample));
+  sb_push(out, "\n", 1);
+}
+
+/* call_within_var, caller.rs:388-608 */
+int orc_call_within_var(const char* chro, const char* q_chro, const char* t, const char* q,
+                        size_t cols, uint64_t t_start, uint64_t t_end, uint64_t q_start,
+                        uint64_t q_end, int strand_neg, int if_snp, uint64_t svlen_cutoff,
+                        int if_inv, char** out, size_t* out_len) {
+  sbuf sb = {*out, *out_len, *out ? *out_len + 1 : 0};
+  if (!sb.s) sb_push(&sb, "", 0);
+  /* :411-415 gap-stripped copies */
+  char* t_ref = (char*)malloc(cols + 1);
+  char* q_ref = (char*)malloc(cols + 1);
+  size_t t_ref_n = 0, q_ref_n = 0;
+  for (size_t i = 0; i < cols; i++)
+    if (t[i] != '-') t_ref[t_ref_n++] = t[i];
+  for (size_t i = 0; i < cols; i++)
+    if (q[i] != '-') q_ref[q_ref_n++] = q[i];
+  uint64_t target_current_offset = t_start;
+  uint64_t query_current_offset = q_start;
+  char suffix = strand_neg ? 'N' : 'P';
+  char info[256], qi[512];
+  int rc = 0;
+  if (strand_neg && t_ref_n != 0 && if_inv) { /* :423-440 */
+    snprintf(info, sizeof info, "SVTYPE=INV;END=%llu", (unsigned long long)t_end);
+    snprintf(qi, sizeof qi, "GT:QI\t1|1:%s@%llu@%llu@%c", q_chro, (unsigned long long)q_start,
+             (unsigned long long)q_end, suffix);
+    emit_vcf(&sb, chro, target_current_offset + 1, t_ref, 1, "<INV>", 5, 1, info, qi);
+  }
+  const char* init_info = strand_neg ? "INV_NEST=TRUE;" : ""; /* :448-451 */
+  int after_m = 0;
+  size_t i = 0;
+  while (i < cols) { /* group_by(cigar_cat_ext_caller) :444-446 */
+    char k = cigar_cat_ext_caller(t[i], q[i]);
+    size_t j = i + 1;
+    while (j < cols && cigar_cat_ext_caller(t[j], q[j]) == k) j++;
+    uint64_t len = (uint64_t)(j - i);
+    i = j;
+    switch (k) {
+      case '=': /* :456-460 */
+        target_current_offset += len;
+        query_current_offset += len;
+        after_m = 1;
+        break;
+      case 'W': break; /* :461-463 */
+      case 'I':        /* :464-515 */
+        if (len > svlen_cutoff) {
+          if (!after_m) {
+            query_current_offset += len;
+            after_m = 0;
+            continue;
+          }
+          uint64_t ts = target_current_offset - t_start - 1;
+          uint64_t qs = query_current_offset - q_start - 1;
+          if (ts + 1 > t_ref_n || qs + len + 1 > q_ref_n) {
+            rc = ORC_PANIC;
+            goto done;
+          }
+          snprintf(info, sizeof info, "%sSVTYPE=INS;SVLEN=%llu;END=%llu", init_info,
+                   (unsigned long long)len, (unsigned long long)target_current_offset);
+          snprintf(qi, sizeof qi, "GT:QI\t1|1:%s@%llu@%llu@%c", q_chro,
+                   (unsigned long long)query_current_offset,
+                   (unsigned long long)(query_current_offset + len), suffix);
+          emit_vcf(&sb, chro, target_current_offset, t_ref + ts, 1, q_ref + qs, (size_t)len + 1, 0,
+                   info, qi);
+        }
+        query_current_offset += len;
+        after_m = 0;
+        break;
+      case 'D': /* :516-569 */
+        if (len > svlen_cutoff) {
+          if (!after_m) {
+            target_current_offset += len;
+            after_m = 0;
+            continue;
+          }
+          uint64_t ts = target_current_offset - t_start - 1;
+          uint64_t qs = query_current_offset - q_start - 1;
+          if (ts + len + 1 > t_ref_n || qs + 1 > q_ref_n) {
+            rc = ORC_PANIC;
+            goto done;
+          }
+          snprintf(info, sizeof info, "%sSVTYPE=DEL;SVLEN=%llu;END=%llu", init_info,
+                   (unsigned long long)len, (unsigned long long)(target_current_offset + len));
+          snprintf(qi, sizeof qi, "GT:QI\t1|1:%s@%llu@%llu@%c", q_chro,
+                   (unsigned long long)query_current_offset,
+                   (unsigned long long)query_current_offset, suffix);
+          emit_vcf(&sb, chro, target_current_offset, t_ref + ts, (size_t)len + 1, q_ref + qs, 1, 0,
+                   info, qi);
+        }
+        target_current_offset += len;
+        after_m = 0;
+        break;
+      case 'X': /* :570-603 */
+        if (if_snp) {
+          for (uint64_t s = 0; s < len; s++) {
+            uint64_t ts = target_current_offset - t_start;
+            uint64_t qs = query_current_offset - q_start;
+            if (ts + 1 > t_ref_n || qs + 1 > q_ref_n) {
+              rc = ORC_PANIC;
+              goto done;
+            }
+            snprintf(qi, sizeof qi, "GT:QI\t1|1:%s@%llu@%c", q_chro,
+                     (unsigned long long)query_current_offset, suffix);
+            emit_vcf(&sb, chro, target_current_offset + 1, t_ref + ts, 1, q_ref + qs, 1, 0, NULL,
+                     qi);
+            target_current_offset += 1;
+            query_current_offset += 1;
+          }
+        } else {
+          query_current_offset += len;
+          target_current_offset += len;
+        }
+        after_m = 1;
+        break;
+    }
+  }
+done:
+  free(t_ref);
+  free(q_ref);
+  *out = sb.s;
+  *out_len = sb.n;
+  return rc;
+}
+
+/* per-record chunk loop of call_var_maf, caller.rs:115-149, with create_chunk_record
+ * (:221-265: start += non-gap chars of the prefix, align_size = non-gap chars of the chunk) and
+ * the strand-aware accessors of maf.rs:433-450,468-470 applied to the chunk record. */
+int orc_call_var_maf_record(const char* chro, const char* q_chro, const char* t, const char* q,
+                            size_t cols, uint64_t t_start, uint64_t t_size_unused,
+                            uint64_t q_sline_start, uint64_t q_sline_align, uint64_t q_size,
+                            int strand_neg, int if_snp, int if_inv, uint64_t svlen_cutoff,
+                            size_t chunk_size, char** out, size_t* out_len) {
+  (void)t_size_unused;
+  (void)q_sline_align;
+  size_t total = cols;
+  size_t chunk_start = 0;
+  while (chunk_start < total) {
+    size_t safe_end =
+        orc_find_safe_chunk_boundary(t, q, total, chunk_start, chunk_size, svlen_cutoff);
+    /* create_chunk_record: naive prefix recount for every chunk (:240-251) */
+    uint64_t nt_start = t_start, nq_start = q_sline_start, nt_align = 0, nq_align = 0;
+    for (size_t i = 0; i < chunk_start; i++) {
+      if (t[i] != '-') nt_start++;
+      if (q[i] != '-') nq_start++;
+    }
+    for (size_t i = chunk_start; i < safe_end; i++) {
+      if (t[i] != '-') nt_align++;
+      if (q[i] != '-') nq_align++;
+    }
+    /* accessors on the chunk record */
+    uint64_t c_t_start = nt_start;
+    uint64_t c_t_end = nt_start + nt_align; /* maf.rs:468-470 */
+    uint64_t c_q_start, c_q_end;
+    if (strand_neg) { /* maf.rs:438-440, 448 */
+      c_q_start = q_size - nq_start - nq_align;
+      c_q_end = q_size - nq_start;
+    } else {
+      c_q_start = nq_start;
+      c_q_end = nq_start + nq_align;
+    }
+    int rc = orc_call_within_var(chro, q_chro, t + chunk_start, q + chunk_start,
+                                 safe_end - chunk_start, c_t_start, c_t_end, c_q_start, c_q_end,
+                                 strand_neg, if_snp, svlen_cutoff, if_inv, out, out_len);
+    if (rc) return rc;
+    if (safe_end == chunk_start) break; /* guard: the reference would spin forever here */
+    chunk_start = safe_end;
+  }
+  return ORC_OK;
+}

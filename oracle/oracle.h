@@ -1,0 +1,103 @@
+/*
+ * oracle.h — CPU restatement of wgatools' CIGAR hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this library; it
+ * is the checker, never the product path (the product is libwgahip.so and fails loudly without a
+ * GPU).  Every function restates one reference function, deliberately naive (same algorithmic
+ * structure, including the quadratic String::insert_str / drain behaviour), and cites the
+ * /root/reference-relative file:line it follows.
+ *
+ * PARITY PINNING.  The reference (Rust) cannot be built or run in this environment and has no
+ * unit tests.  Pinned: orc_call_within_var + orc_find_safe_chunk_boundary + orc_cigar_cat_ext_caller
+ * reproduce the only golden output in the reference repository (README.md:323-343, VCF of
+ * `wgatools call test/test.maf -s -l0`; tests/test_oracle_golden.py).  Everything else —
+ * stat, paf2maf, maf2paf, pafcov, pafpseudo — is checked only against expected outputs derived
+ * by reading the code: for those paths this oracle is **parity unpinned**.
+ */
+#ifndef WGA_ORACLE_H
+#define WGA_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* WGAError variants reachable from the hot path (errors.rs:45-74) + PANIC for the spots where
+ * the reference panics instead of returning Err. */
+enum orc_err_kind {
+  ORC_OK = 0,
+  ORC_CIGAR_TAG_NOT_FOUND = 1,
+  ORC_CIGAR_OP_INVALID = 2,
+  ORC_PARSE_INT = 3,
+  ORC_INVALID_BASE = 4,
+  ORC_NOM = 5,
+  ORC_PANIC = 6
+};
+
+typedef struct {
+  int kind;
+  char arg[64]; /* the {0} of the error message (op token, digits, base, first 10 bytes) */
+} orc_err;
+
+/* struct Cigar sans text, cigar.rs:16-29 (same field order as wga_cigar_counts) */
+typedef struct {
+  uint64_t match, mismatch, ins_ev, ins_bp, del_ev, del_bp, inv_ins_ev, inv_ins_bp, inv_del_ev,
+      inv_del_bp, inv_ev;
+} orc_counts;
+
+/* RecStat, common.rs:99-113 */
+typedef struct {
+  uint64_t aligned_size, matched, mismatched, ins_event, del_event, ins_size, del_size,
+      inv_ins_event, inv_ins_size, inv_del_event, inv_del_size, inv_event;
+  float inv_size;
+} orc_recstat;
+
+/* Formats the reference's error message (errors.rs) into buf. */
+void orc_err_message(const orc_err* e, char* buf, size_t cap);
+
+/* cigar.rs:629-707 parse_paf_to_cigar; `cg` includes the "cg:Z:" tag. */
+int orc_parse_paf_to_cigar(const char* cg, size_t n, int strand_neg, orc_counts* out, orc_err* err);
+/* common.rs:116-140 */
+void orc_recstat_from(const orc_counts* c, orc_recstat* out);
+/* utils.rs:83-101; out has n bytes */
+int orc_reverse_complement(const char* in, size_t n, char* out, orc_err* err);
+/* cigar.rs:522-551 parse_cigar_to_insert (+ cigar_unit_insert_seq :492-519).  *t / *q are
+ * malloc'd NUL-less buffers that are re-allocated as gaps are inserted. */
+int orc_parse_cigar_to_insert(const char* cg, size_t n, char** t, size_t* tn, char** q, size_t* qn,
+                              orc_err* err);
+/* cigar.rs:344-432 parse_maf_seq_to_cigar (with_h=false).  cigar_text (optional) receives a
+ * malloc'd NUL-terminated "<len><op>..." string. */
+void orc_parse_maf_seq_to_cigar(const char* t, size_t tn, const char* q, size_t qn, int strand_neg,
+                                orc_counts* out, char** cigar_text);
+/* cigar.rs:710-741 update_cov_vec */
+int orc_update_cov_vec(uint64_t* cov, size_t cov_len, const char* cg, size_t n, size_t start,
+                       orc_err* err);
+/* cigar.rs:744-804 gen_pesudo_maf_by_cigar; *q is malloc'd and edited in place */
+int orc_gen_pesudo_maf_by_cigar(const char* cg, size_t n, char** q, size_t* qn, int base,
+                                orc_err* err);
+/* paf.rs:159-218 cs_to_cigar (regex restated as a hand scanner); returns malloc'd string */
+char* orc_cs_to_cigar(const char* cs, size_t n);
+
+/* caller.rs:159-219; returns safe_end */
+size_t orc_find_safe_chunk_boundary(const char* t, const char* q, size_t total, size_t start,
+                                    size_t chunk_size, uint64_t svlen_cutoff);
+/* caller.rs:388-608 call_within_var on one chunk (rows already cut, starts already advanced).
+ * Appends VCF body lines (noodles-vcf 0.43 layout as in README.md:332-342) to *out (malloc'd,
+ * NUL-terminated, grown as needed). */
+int orc_call_within_var(const char* chro, const char* q_chro, const char* t, const char* q,
+                        size_t cols, uint64_t t_start, uint64_t t_end, uint64_t q_start,
+                        uint64_t q_end, int strand_neg, int if_snp, uint64_t svlen_cutoff,
+                        int if_inv, char** out, size_t* out_len);
+/* caller.rs:42-157 per-record driver: chunk loop + create_chunk_record (:221-265) + call. */
+int orc_call_var_maf_record(const char* chro, const char* q_chro, const char* t, const char* q,
+                            size_t cols, uint64_t t_start, uint64_t t_size_unused,
+                            uint64_t q_sline_start, uint64_t q_sline_align, uint64_t q_size,
+                            int strand_neg, int if_snp, int if_inv, uint64_t svlen_cutoff,
+                            size_t chunk_size, char** out, size_t* out_len);
+
+void orc_free(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,197 @@
+"""ctypes face of oracle/liboracle.so — the CPU checker.  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
+
+COUNT_FIELDS = ("match", "mismatch", "ins_ev", "ins_bp", "del_ev", "del_bp", "inv_ins_ev",
+                "inv_ins_bp", "inv_del_ev", "inv_del_bp", "inv_ev")
+
+
+class Err(C.Structure):
+    _fields_ = [("kind", C.c_int), ("arg", C.c_char * 64)]
+
+
+class Counts(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in COUNT_FIELDS]
+
+    def as_tuple(self):
+        return tuple(int(getattr(self, k)) for k in COUNT_FIELDS)
+
+
+class RecStat(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in (
+        "aligned_size", "matched", "mismatched", "ins_event", "del_event", "ins_size", "del_size",
+        "inv_ins_event", "inv_ins_size", "inv_del_event", "inv_del_size", "inv_event")] + [
+        ("inv_size", C.c_float)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = [os.path.join(ROOT, "oracle", f) for f in ("oracle.c", "oracle.h")]
+        if (not os.path.exists(LIB_PATH)
+                or any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH)
+                       for s in src)):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+        L = C.CDLL(LIB_PATH)
+        P, Z, U = C.c_void_p, C.c_size_t, C.c_uint64
+        L.orc_err_message.argtypes = [P, C.c_char_p, Z]
+        L.orc_parse_paf_to_cigar.argtypes = [C.c_char_p, Z, C.c_int, P, P]
+        L.orc_recstat_from.argtypes = [P, P]
+        L.orc_reverse_complement.argtypes = [C.c_char_p, Z, C.c_char_p, P]
+        L.orc_parse_cigar_to_insert.argtypes = [C.c_char_p, Z, P, P, P, P, P]
+        L.orc_parse_maf_seq_to_cigar.argtypes = [C.c_char_p, Z, C.c_char_p, Z, C.c_int, P, P]
+        L.orc_update_cov_vec.argtypes = [P, Z, C.c_char_p, Z, Z, P]
+        L.orc_gen_pesudo_maf_by_cigar.argtypes = [C.c_char_p, Z, P, P, C.c_int, P]
+        L.orc_call_var_maf_record.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, Z,
+                                              U, U, U, U, U, C.c_int, C.c_int, C.c_int, U, Z, P, P]
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_cs_to_cigar.restype = C.c_void_p
+        L.orc_cs_to_cigar.argtypes = [C.c_char_p, C.c_size_t]
+        L.orc_find_safe_chunk_boundary.restype = C.c_size_t
+        L.orc_find_safe_chunk_boundary.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_size_t,
+                                                   C.c_size_t, C.c_uint64]
+        _lib = L
+    return _lib
+
+
+class OracleError(Exception):
+    def __init__(self, kind, arg, message):
+        super().__init__(message)
+        self.kind, self.arg, self.message = kind, arg, message
+
+
+def _raise(err):
+    buf = C.create_string_buffer(256)
+    lib().orc_err_message(C.byref(err), buf, 256)
+    raise OracleError(err.kind, err.arg.decode(errors="replace"), buf.value.decode(errors="replace"))
+
+
+def parse_paf_to_cigar(cg, strand_neg):
+    """cigar.rs:629-707 -> 11-tuple in wga_cigar_counts order"""
+    cg = cg.encode() if isinstance(cg, str) else cg
+    out, err = Counts(), Err()
+    if lib().orc_parse_paf_to_cigar(cg, len(cg), int(strand_neg), C.byref(out), C.byref(err)):
+        _raise(err)
+    return out.as_tuple()
+
+
+def recstat_from(counts):
+    c = Counts(*counts)
+    r = RecStat()
+    lib().orc_recstat_from(C.byref(c), C.byref(r))
+    return r
+
+
+def reverse_complement(seq):
+    seq = seq.encode() if isinstance(seq, str) else bytes(seq)
+    out = C.create_string_buffer(len(seq) + 1)
+    err = Err()
+    if lib().orc_reverse_complement(seq, len(seq), out, C.byref(err)):
+        _raise(err)
+    return out.raw[: len(seq)]
+
+
+def _malloc_copy(b):
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    p = libc.malloc(len(b) + 1)
+    C.memmove(p, b, len(b))
+    return C.c_void_p(p)
+
+
+def parse_cigar_to_insert(cg, t_seq, q_seq):
+    """cigar.rs:522-551: returns the two gapped rows (bytes)"""
+    cg = cg.encode() if isinstance(cg, str) else cg
+    t, q = _malloc_copy(bytes(t_seq)), _malloc_copy(bytes(q_seq))
+    tn, qn = C.c_size_t(len(t_seq)), C.c_size_t(len(q_seq))
+    err = Err()
+    rc = lib().orc_parse_cigar_to_insert(cg, len(cg), C.byref(t), C.byref(tn), C.byref(q),
+                                         C.byref(qn), C.byref(err))
+    try:
+        if rc:
+            _raise(err)
+        return C.string_at(t, tn.value), C.string_at(q, qn.value)
+    finally:
+        lib().orc_free(t)
+        lib().orc_free(q)
+
+
+def parse_maf_seq_to_cigar(t_row, q_row, strand_neg):
+    """cigar.rs:344-432 -> (counts 11-tuple, cigar text)"""
+    t_row, q_row = bytes(t_row), bytes(q_row)
+    out = Counts()
+    txt = C.c_void_p()
+    lib().orc_parse_maf_seq_to_cigar(t_row, C.c_size_t(len(t_row)), q_row, C.c_size_t(len(q_row)),
+                                     int(strand_neg), C.byref(out), C.byref(txt))
+    s = C.string_at(txt).decode()
+    lib().orc_free(txt)
+    return out.as_tuple(), s
+
+
+def update_cov_vec(cov, cg, start):
+    """cigar.rs:710-741 on a numpy uint64 array (in place)"""
+    cg = cg.encode() if isinstance(cg, str) else cg
+    assert cov.dtype == np.uint64 and cov.flags.c_contiguous
+    err = Err()
+    if lib().orc_update_cov_vec(C.c_void_p(cov.ctypes.data), C.c_size_t(len(cov)), cg,
+                                C.c_size_t(len(cg)), C.c_size_t(int(start)), C.byref(err)):
+        _raise(err)
+
+
+def gen_pesudo_maf_by_cigar(cg, q_seq, base):
+    """cigar.rs:744-804 -> edited sequence (bytes)"""
+    cg = cg.encode() if isinstance(cg, str) else cg
+    q = _malloc_copy(bytes(q_seq))
+    qn = C.c_size_t(len(q_seq))
+    err = Err()
+    rc = lib().orc_gen_pesudo_maf_by_cigar(cg, C.c_size_t(len(cg)), C.byref(q), C.byref(qn),
+                                           int(base), C.byref(err))
+    try:
+        if rc:
+            _raise(err)
+        return C.string_at(q, qn.value)
+    finally:
+        lib().orc_free(q)
+
+
+def cs_to_cigar(cs):
+    cs = cs.encode() if isinstance(cs, str) else cs
+    p = lib().orc_cs_to_cigar(cs, len(cs))
+    s = C.string_at(p).decode()
+    lib().orc_free(p)
+    return s
+
+
+def find_safe_chunk_boundary(t, q, start, chunk_size, svlen_cutoff):
+    t, q = bytes(t), bytes(q)
+    return lib().orc_find_safe_chunk_boundary(t, q, len(t), start, chunk_size, svlen_cutoff)
+
+
+def call_var_maf_record(chro, q_chro, t_row, q_row, t_start, q_sline_start, q_sline_align, q_size,
+                        strand_neg, if_snp, if_inv, svlen_cutoff, chunk_size=1000000):
+    """caller.rs:115-149 + :388-608 for one MAF block -> VCF body text"""
+    t_row, q_row = bytes(t_row), bytes(q_row)
+    cols = min(len(t_row), len(q_row))
+    out = C.c_void_p()
+    out_len = C.c_size_t(0)
+    rc = lib().orc_call_var_maf_record(
+        chro.encode(), q_chro.encode(), t_row, q_row, C.c_size_t(cols), C.c_uint64(t_start),
+        C.c_uint64(0), C.c_uint64(q_sline_start), C.c_uint64(q_sline_align), C.c_uint64(q_size),
+        int(strand_neg), int(if_snp), int(if_inv), C.c_uint64(svlen_cutoff),
+        C.c_size_t(chunk_size), C.byref(out), C.byref(out_len))
+    s = C.string_at(out, out_len.value).decode() if out.value else ""
+    if out.value:
+        lib().orc_free(out)
+    if rc:
+        raise OracleError(rc, "", "call_within_var panicked")
+    return s

@@ -1,0 +1,83 @@
+"""Build helpers for the native pieces.
+
+build_hip()    libwgahip.so  — the product: HIP kernels + C-ABI for gfx950 (hipcc cross-compiles
+                               without a GPU).
+build_oracle() oracle/liboracle.so — the CPU checker (tests / smoke / cpu_baseline only).
+build_emu()    tests/emu/libwgaemu.so — the same kernel source under a SIMT emulator, used by the
+                               CPU test-suite to check kernel logic; never loaded by the product.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "wgatools_amd", "csrc")
+HIP_LIB = os.path.join(ROOT, "wgatools_amd", "libwgahip.so")
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "libwgaemu.so")
+ORACLE_LIB = os.path.join(ROOT, "oracle", "liboracle.so")
+STAGE2 = ["-DWGA_STAGE2"] if os.path.exists(os.path.join(CSRC, "wga_kernels2.h")) else []
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd, cwd=None):
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+    return r.stdout
+
+
+def _sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [
+        os.path.join(ROOT, "include", "wga_hip.h")
+    ]
+
+
+def build_hip(force=False, verbose=False):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not force and not _newer(HIP_LIB, _sources()):
+        return HIP_LIB
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: libwgahip.so cannot be built here")
+    objs = []
+    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall"] + STAGE2
+    for src, xflag in (("wga_capi.cpp", ["-x", "hip"]), ("wga_pack.cpp", [])):
+        obj = os.path.join(CSRC, src.replace(".cpp", ".o"))
+        out = _run([hipcc] + flags + xflag + ["-c", os.path.join(CSRC, src), "-o", obj])
+        if verbose and out:
+            print(out)
+        objs.append(obj)
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-o", HIP_LIB] + objs
+         + ["-Wl,-rpath,/opt/rocm/lib"])
+    return HIP_LIB
+
+
+def build_emu(force=False):
+    srcs = _sources() + [os.path.join(ROOT, "tests", "emu", "simt_emu.h")]
+    if not force and not _newer(EMU_LIB, srcs):
+        return EMU_LIB
+    _run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DWGA_EMU", "-Wall",
+          "-Wno-unknown-pragmas", "-I" + os.path.join(ROOT, "tests", "emu")] + STAGE2
+         + [os.path.join(CSRC, "wga_capi.cpp"), os.path.join(CSRC, "wga_pack.cpp"), "-o", EMU_LIB])
+    return EMU_LIB
+
+
+def build_oracle(force=False):
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle.c", "oracle.h")]
+    if not force and not _newer(ORACLE_LIB, srcs):
+        return ORACLE_LIB
+    _run(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+    return ORACLE_LIB
+
+
+if __name__ == "__main__":
+    print(build_oracle(force=True))
+    print(build_emu(force=True))
+    print(build_hip(force=True, verbose=True))

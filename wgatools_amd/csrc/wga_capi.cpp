@@ -1,0 +1,425 @@
+/*
+ * wga_capi.cpp — the C-ABI of libwgahip.so (include/wga_hip.h): context, memory plumbing and
+ * the launch logic of every kernel.  Compiled as HIP for gfx950 (product) or, with -DWGA_EMU,
+ * as plain C++ over tests/emu/simt_emu.h (CPU logic tests only).
+ */
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+#include "wga_kernels.h"
+#ifdef WGA_STAGE2
+#include "wga_kernels2.h"
+#endif
+
+struct wga_ctx {
+  int device = 0;
+  wga_stream_t own_stream = nullptr;
+  wga_stream_t stream = nullptr;
+  int expand_force_slow = 0;
+  void* scratch = nullptr;
+  size_t scratch_cap = 0;
+};
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* what, const char* detail) {
+  g_last_error = std::string(what) + (detail ? std::string(": ") + detail : std::string());
+  return code;
+}
+#define RT_CHECK(expr)                                      \
+  do {                                                      \
+    const char* _e = (expr);                                \
+    if (_e) return fail(WGA_E_HIP, #expr, _e);              \
+  } while (0)
+#define LAUNCH_CHECK()                                      \
+  do {                                                      \
+    const char* _e = rt_launch_error();                     \
+    if (_e) return fail(WGA_E_HIP, "kernel launch", _e);    \
+  } while (0)
+
+static int ctx_bind(wga_ctx* c) {
+  if (!c) return fail(WGA_E_INVALID_ARG, "null context", nullptr);
+  RT_CHECK(rt_set_device(c->device));
+  return WGA_OK;
+}
+
+/* grow-only scratch arena on the context (scan partials etc.) */
+static int ctx_scratch(wga_ctx* c, size_t bytes, void** out) {
+  if (c->scratch_cap < bytes) {
+    RT_CHECK(rt_sync(c->stream));
+    if (c->scratch) RT_CHECK(rt_free(c->scratch));
+    c->scratch = nullptr;
+    c->scratch_cap = 0;
+    size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 2;
+    RT_CHECK(rt_malloc(&c->scratch, cap));
+    c->scratch_cap = cap;
+  }
+  *out = c->scratch;
+  return WGA_OK;
+}
+
+/* exclusive scan driver shared by wga_exclusive_scan_u64 and the layout */
+template <typename F>
+static int run_scan(wga_ctx* c, F f, u32 n, u64* d_out /* n+1 */) {
+  u32 nb = (n + 1023u) / 1024u;
+  void* ws;
+  int rc = ctx_scratch(c, ((size_t)nb + 1) * sizeof(u64), &ws);
+  if (rc) return rc;
+  u64* partial = (u64*)ws;
+  if (nb) {
+    WGA_LAUNCH(k_scan_partials<F>, nb, WGA_BLOCK, c->stream, f, n, partial);
+    LAUNCH_CHECK();
+  }
+  WGA_LAUNCH(k_scan_top, 1, WGA_BLOCK, c->stream, partial, nb, d_out + n);
+  LAUNCH_CHECK();
+  if (nb) {
+    WGA_LAUNCH(k_scan_final<F>, nb, WGA_BLOCK, c->stream, f, n, (const u64*)partial, d_out);
+    LAUNCH_CHECK();
+  }
+  return WGA_OK;
+}
+
+extern "C" {
+
+int wga_abi_version(void) { return WGA_ABI_VERSION; }
+const char* wga_last_error(void) { return g_last_error.c_str(); }
+int wga_device_count(void) { return rt_device_count(); }
+
+int wga_ctx_create(int device, wga_ctx** out) {
+  if (!out) return fail(WGA_E_INVALID_ARG, "out is null", nullptr);
+  int n = rt_device_count();
+  if (n <= 0) return fail(WGA_E_NO_DEVICE, "no HIP device visible (libwgahip needs an MI355X)", nullptr);
+  if (device < 0 || device >= n) return fail(WGA_E_INVALID_ARG, "device index out of range", nullptr);
+  wga_ctx* c = new wga_ctx();
+  c->device = device;
+  const char* e = rt_set_device(device);
+  if (!e) e = rt_stream_create(&c->own_stream);
+  if (e) {
+    delete c;
+    return fail(WGA_E_HIP, "context creation", e);
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return WGA_OK;
+}
+
+void wga_ctx_destroy(wga_ctx* c) {
+  if (!c) return;
+  (void)rt_set_device(c->device);
+  (void)rt_sync(c->stream);
+  if (c->scratch) (void)rt_free(c->scratch);
+  rt_stream_destroy(c->own_stream);
+  delete c;
+}
+
+int wga_ctx_set_stream(wga_ctx* c, void* hip_stream) {
+  if (!c) return fail(WGA_E_INVALID_ARG, "null context", nullptr);
+  c->stream = hip_stream ? (wga_stream_t)hip_stream : c->own_stream;
+  return WGA_OK;
+}
+
+int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
+  if (!c || !name) return fail(WGA_E_INVALID_ARG, "null argument", nullptr);
+  if (strcmp(name, "expand_force_slow") == 0) {
+    c->expand_force_slow = value != 0;
+    return WGA_OK;
+  }
+  return fail(WGA_E_INVALID_ARG, "unknown parameter", name);
+}
+
+int wga_sync(wga_ctx* c) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  RT_CHECK(rt_sync(c->stream));
+  return WGA_OK;
+}
+int wga_malloc(wga_ctx* c, size_t bytes, void** d_out) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (!d_out) return fail(WGA_E_INVALID_ARG, "d_out is null", nullptr);
+  const char* e = rt_malloc(d_out, bytes);
+  if (e) return fail(WGA_E_OOM, "device allocation", e);
+  return WGA_OK;
+}
+int wga_free(wga_ctx* c, void* d_ptr) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (d_ptr) RT_CHECK(rt_free(d_ptr));
+  return WGA_OK;
+}
+int wga_memcpy_h2d(wga_ctx* c, void* d_dst, const void* h_src, size_t bytes) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (bytes) RT_CHECK(rt_h2d(d_dst, h_src, bytes, c->stream));
+  return WGA_OK;
+}
+int wga_memcpy_d2h(wga_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (bytes)
+    RT_CHECK(rt_d2h(h_dst, d_src, bytes, c->stream));
+  else
+    RT_CHECK(rt_sync(c->stream));
+  return WGA_OK;
+}
+int wga_memset(wga_ctx* c, void* d_dst, int byte, size_t bytes) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (bytes) RT_CHECK(rt_memset(d_dst, byte, bytes, c->stream));
+  return WGA_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+static int check_batch(const wga_cigar_batch* b) {
+  if (!b) return fail(WGA_E_INVALID_ARG, "batch is null", nullptr);
+  if (b->n && (!b->d_op_off || !b->d_strand_neg)) return fail(WGA_E_INVALID_ARG, "batch arrays null", nullptr);
+  if (b->n_ops && !b->d_ops) return fail(WGA_E_INVALID_ARG, "d_ops null", nullptr);
+  if (((uintptr_t)b->d_ops & 15u) != 0) return fail(WGA_E_INVALID_ARG, "d_ops must be 16-byte aligned", nullptr);
+  return WGA_OK;
+}
+static inline u64 n_tiles(u64 n_ops) { return (n_ops + WGA_TILE - 1) / WGA_TILE; }
+
+size_t wga_tile_ws_bytes(uint64_t n_ops) { return (size_t)(n_tiles(n_ops) * sizeof(wga_tile_sum)) + 16; }
+
+int wga_cigar_stat(wga_ctx* c, const wga_cigar_batch* b, wga_cigar_counts* d_counts,
+                   wga_rec_diag* d_diag, void* d_tile_ws) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if ((rc = check_batch(b))) return rc;
+  if (b->n == 0) return WGA_OK;
+  if (!d_counts || !d_diag) return fail(WGA_E_INVALID_ARG, "d_counts / d_diag null", nullptr);
+  RT_CHECK(rt_memset(d_counts, 0, (size_t)b->n * sizeof(wga_cigar_counts), c->stream));
+  RT_CHECK(rt_memset(d_diag, 0xFF, (size_t)b->n * sizeof(wga_rec_diag), c->stream));
+  u64 nt = n_tiles(b->n_ops);
+  if (nt == 0) return WGA_OK;
+  u32 grid = (u32)((nt + 3) / 4);
+  WGA_LAUNCH(k_cigar_stat, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off,
+             b->d_strand_neg, b->n, (u64)b->n_ops, d_counts, d_diag, (wga_tile_sum*)d_tile_ws);
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
+int wga_exclusive_scan_u64(wga_ctx* c, uint32_t n, const uint64_t* d_in, uint64_t* d_out) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (!d_out || (n && !d_in)) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  ScanPlain f;
+  f.in = (const u64*)d_in;
+  return run_scan(c, f, n, (u64*)d_out);
+}
+
+int wga_paf2maf_layout(wga_ctx* c, uint32_t n, const wga_cigar_counts* d_counts,
+                       const uint64_t* d_t_src_len, const uint64_t* d_q_src_len,
+                       const uint32_t* d_pre_t, const uint32_t* d_pre_q, const uint32_t* d_post,
+                       uint64_t* d_t_row_off, uint64_t* d_q_row_off, uint64_t* d_rec_off) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (!d_rec_off) return fail(WGA_E_INVALID_ARG, "d_rec_off null", nullptr);
+  if (n && (!d_counts || !d_t_src_len || !d_q_src_len || !d_t_row_off || !d_q_row_off))
+    return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  ScanLayout f;
+  f.counts = d_counts;
+  f.t_src_len = (const u64*)d_t_src_len;
+  f.q_src_len = (const u64*)d_q_src_len;
+  f.pre_t = d_pre_t;
+  f.pre_q = d_pre_q;
+  f.post = d_post;
+  rc = run_scan(c, f, n, (u64*)d_rec_off);
+  if (rc) return rc;
+  if (n) {
+    WGA_LAUNCH(k_layout_rows, (n + 255u) / 256u, WGA_BLOCK, c->stream, f, n, (const u64*)d_rec_off,
+               (u64*)d_t_row_off, (u64*)d_q_row_off);
+    LAUNCH_CHECK();
+  }
+  return WGA_OK;
+}
+
+int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_counts* d_counts,
+                       const void* d_tile_ws, const uint8_t* d_t_fa, uint64_t t_fa_bytes,
+                       const uint64_t* d_t_src_off, const uint64_t* d_t_src_len,
+                       const uint8_t* d_q_fa, uint64_t q_fa_bytes, const uint64_t* d_q_src_off,
+                       const uint64_t* d_q_src_len, uint8_t* d_out, const uint64_t* d_t_row_off,
+                       const uint64_t* d_q_row_off, wga_rec_diag* d_diag) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if ((rc = check_batch(b))) return rc;
+  if (b->n == 0 || b->n_ops == 0) return WGA_OK;
+  if (!d_counts || !d_tile_ws || !d_t_src_off || !d_t_src_len || !d_q_src_off || !d_q_src_len ||
+      !d_out || !d_t_row_off || !d_q_row_off || !d_diag)
+    return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  if ((t_fa_bytes && !d_t_fa) || (q_fa_bytes && !d_q_fa)) return fail(WGA_E_INVALID_ARG, "null sequence pool", nullptr);
+  ExpandArgs a;
+  a.ops = b->d_ops;
+  a.op_off = (const u64*)b->d_op_off;
+  a.strand_neg = b->d_strand_neg;
+  a.n = b->n;
+  a.n_ops = b->n_ops;
+  a.counts = d_counts;
+  a.tiles = (const wga_tile_sum*)d_tile_ws;
+  a.t_fa = d_t_fa;
+  a.t_fa_bytes = t_fa_bytes;
+  a.t_src_off = (const u64*)d_t_src_off;
+  a.t_src_len = (const u64*)d_t_src_len;
+  a.q_fa = d_q_fa;
+  a.q_fa_bytes = q_fa_bytes;
+  a.q_src_off = (const u64*)d_q_src_off;
+  a.q_src_len = (const u64*)d_q_src_len;
+  a.out = d_out;
+  a.t_row_off = (const u64*)d_t_row_off;
+  a.q_row_off = (const u64*)d_q_row_off;
+  a.diag = d_diag;
+  a.force_slow = c->expand_force_slow;
+  u64 nt = n_tiles(b->n_ops);
+  if (nt > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "batch too large for one launch", nullptr);
+  WGA_LAUNCH(k_paf2maf_expand, (u32)nt, WGA_BLOCK, c->stream, a);
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
+int wga_scatter_bytes(wga_ctx* c, uint32_t n, const uint8_t* d_src, const uint64_t* d_src_off,
+                      uint8_t* d_dst, const uint64_t* d_dst_off) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (n == 0) return WGA_OK;
+  if (!d_src || !d_src_off || !d_dst || !d_dst_off) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  WGA_LAUNCH(k_scatter_bytes, (n + 3u) / 4u, WGA_BLOCK, c->stream, n, d_src, (const u64*)d_src_off,
+             d_dst, (const u64*)d_dst_off);
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
+#ifdef WGA_STAGE2
+/* ------------------------------------------------------------------------------------------ */
+/* K3 / K5 / K6 launchers (kernels in wga_kernels2.h)                                          */
+/* ------------------------------------------------------------------------------------------ */
+int wga_maf_pair_stat(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint64_t* d_t_off,
+                      const uint64_t* d_q_off, const uint64_t* d_cols,
+                      const uint8_t* d_strand_neg, wga_cigar_counts* d_counts,
+                      uint64_t* d_run_cnt, uint32_t* d_runs, const uint64_t* d_run_off) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (n == 0) return WGA_OK;
+  if (!d_rows || !d_t_off || !d_q_off || !d_cols || !d_strand_neg || !d_counts)
+    return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  if (d_runs && !d_run_off) return fail(WGA_E_INVALID_ARG, "d_run_off null", nullptr);
+  WGA_LAUNCH(k_maf_pair_stat, (n + 3u) / 4u, WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off,
+             (const u64*)d_q_off, (const u64*)d_cols, d_strand_neg, d_counts, (u64*)d_run_cnt,
+             d_runs, (const u64*)d_run_off);
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
+int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_target_id,
+                          const uint64_t* d_t_start, const uint64_t* d_cov_off,
+                          const uint64_t* d_cov_len, int32_t* d_cov) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if ((rc = check_batch(b))) return rc;
+  if (b->n == 0 || b->n_ops == 0) return WGA_OK;
+  if (!d_target_id || !d_t_start || !d_cov_off || !d_cov_len || !d_cov)
+    return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  u64 nt = n_tiles(b->n_ops);
+  void* ws;
+  if ((rc = ctx_scratch(c, (size_t)nt * 2 * sizeof(u64), &ws))) return rc;
+  u64* tile_mv = (u64*)ws;
+  u32 grid = (u32)((nt + 3) / 4);
+  WGA_LAUNCH(k_pafcov_tiles, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off, b->n,
+             (u64)b->n_ops, tile_mv);
+  LAUNCH_CHECK();
+  WGA_LAUNCH(k_pafcov_accumulate, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off,
+             b->n, (u64)b->n_ops, (const u64*)tile_mv, d_target_id, (const u64*)d_t_start,
+             (const u64*)d_cov_off, (const u64*)d_cov_len, d_cov);
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
+int wga_pafcov_finalize(wga_ctx* c, uint32_t n_targets, const uint64_t* d_cov_off,
+                        const uint64_t* d_cov_len, int32_t* d_cov) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (n_targets == 0) return WGA_OK;
+  if (!d_cov_off || !d_cov_len || !d_cov) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  /* per target: chunk sums -> serial chunk scan (one block per target) -> chunk-local scans.
+   * The chunk grid is sized on the host from a copy of the two small per-target arrays. */
+  std::string hbuf((size_t)n_targets * 16, '\0');
+  u64* h_off = (u64*)&hbuf[0];
+  u64* h_len = h_off + n_targets;
+  RT_CHECK(rt_d2h(h_off, d_cov_off, (size_t)n_targets * 8, c->stream));
+  RT_CHECK(rt_d2h(h_len, d_cov_len, (size_t)n_targets * 8, c->stream));
+  u64 max_chunks = 0, total_chunks = 0;
+  std::string cbuf(((size_t)n_targets + 1) * 8, '\0');
+  u64* h_chunk_off = (u64*)&cbuf[0];
+  for (u32 t = 0; t < n_targets; t++) {
+    u64 nc = (h_len[t] + WGA_COV_CHUNK - 1) / WGA_COV_CHUNK;
+    h_chunk_off[t] = total_chunks;
+    total_chunks += nc;
+    if (nc > max_chunks) max_chunks = nc;
+  }
+  h_chunk_off[n_targets] = total_chunks;
+  if (total_chunks == 0) return WGA_OK;
+  if (max_chunks > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "target too long", nullptr);
+  void* ws;
+  size_t need = ((size_t)total_chunks + n_targets + 1) * 8 + 64;
+  if ((rc = ctx_scratch(c, need, &ws))) return rc;
+  u64* d_chunk_off = (u64*)ws;
+  i64* d_chunk_sum = (i64*)(d_chunk_off + n_targets + 1);
+  RT_CHECK(rt_h2d(d_chunk_off, h_chunk_off, ((size_t)n_targets + 1) * 8, c->stream));
+  RT_CHECK(rt_sync(c->stream)); /* h_chunk_off is a stack-lifetime host buffer */
+  dim3 grid((u32)max_chunks, n_targets, 1);
+  WGA_LAUNCH(k_cov_chunk_sums, grid, WGA_BLOCK, c->stream, (const u64*)d_cov_off,
+             (const u64*)d_cov_len, (const int32_t*)d_cov, (const u64*)d_chunk_off, d_chunk_sum);
+  LAUNCH_CHECK();
+  WGA_LAUNCH(k_cov_chunk_scan, n_targets, WGA_BLOCK, c->stream, (const u64*)d_chunk_off, d_chunk_sum);
+  LAUNCH_CHECK();
+  WGA_LAUNCH(k_cov_chunk_apply, grid, WGA_BLOCK, c->stream, (const u64*)d_cov_off,
+             (const u64*)d_cov_len, d_cov, (const u64*)d_chunk_off, (const i64*)d_chunk_sum);
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
+int wga_pafpseudo_fill(wga_ctx* c, const wga_cigar_batch* b, int base_mode, const uint8_t* d_q_fa,
+                       uint64_t q_fa_bytes, const uint64_t* d_q_src_off,
+                       const uint64_t* d_q_src_len, const uint64_t* d_skip, uint8_t* d_out,
+                       const uint64_t* d_dst_off, wga_rec_diag* d_diag) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if ((rc = check_batch(b))) return rc;
+  if (b->n == 0) return WGA_OK;
+  if (!d_skip || !d_out || !d_dst_off || !d_diag) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  if (base_mode && (!d_q_fa || !d_q_src_off || !d_q_src_len))
+    return fail(WGA_E_INVALID_ARG, "base mode needs the query pool", nullptr);
+  RT_CHECK(rt_memset(d_diag, 0xFF, (size_t)b->n * sizeof(wga_rec_diag), c->stream));
+  u64 nt = n_tiles(b->n_ops);
+  if (nt == 0) return WGA_OK;
+  void* ws;
+  if ((rc = ctx_scratch(c, (size_t)nt * sizeof(wga_tile_sum), &ws))) return rc;
+  wga_tile_sum* tiles = (wga_tile_sum*)ws;
+  WGA_LAUNCH(k_class_tiles, (u32)((nt + 3) / 4), WGA_BLOCK, c->stream, b->d_ops,
+             (const u64*)b->d_op_off, b->n, (u64)b->n_ops, tiles);
+  LAUNCH_CHECK();
+  PseudoArgs a;
+  a.ops = b->d_ops;
+  a.op_off = (const u64*)b->d_op_off;
+  a.strand_neg = b->d_strand_neg;
+  a.n = b->n;
+  a.n_ops = b->n_ops;
+  a.tiles = tiles;
+  a.base_mode = base_mode;
+  a.q_fa = d_q_fa;
+  a.q_fa_bytes = q_fa_bytes;
+  a.q_src_off = (const u64*)d_q_src_off;
+  a.q_src_len = (const u64*)d_q_src_len;
+  a.skip = (const u64*)d_skip;
+  a.out = d_out;
+  a.dst_off = (const u64*)d_dst_off;
+  a.diag = d_diag;
+  if (nt > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "batch too large for one launch", nullptr);
+  WGA_LAUNCH(k_pafpseudo_fill, (u32)nt, WGA_BLOCK, c->stream, a);
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+#endif /* WGA_STAGE2 */
+
+} /* extern "C" */

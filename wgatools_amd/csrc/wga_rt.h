@@ -1,0 +1,82 @@
+/*
+ * wga_rt.h — the few runtime calls the C-ABI needs, in two builds:
+ *   default : HIP (hipcc --offload-arch=gfx950); this is the product.
+ *   WGA_EMU : g++ + tests/emu/simt_emu.h; kernel-logic emulation for the CPU test-suite only.
+ */
+#ifndef WGA_RT_H
+#define WGA_RT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef WGA_EMU
+#include <stdlib.h>
+#include <string.h>
+
+#include "simt_emu.h"
+typedef void* wga_stream_t;
+#define WGA_LAUNCH(kernel, grid, block, stream, ...) \
+  emu::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
+static inline int rt_device_count() { return 1; }
+static inline const char* rt_set_device(int) { return nullptr; }
+static inline const char* rt_stream_create(wga_stream_t* s) {
+  *s = nullptr;
+  return nullptr;
+}
+static inline void rt_stream_destroy(wga_stream_t) {}
+static inline const char* rt_sync(wga_stream_t) { return nullptr; }
+static inline const char* rt_malloc(void** p, size_t n) {
+  *p = malloc(n ? n : 1);
+  return *p ? nullptr : "malloc failed";
+}
+static inline const char* rt_free(void* p) {
+  free(p);
+  return nullptr;
+}
+static inline const char* rt_h2d(void* d, const void* h, size_t n, wga_stream_t) {
+  memcpy(d, h, n);
+  return nullptr;
+}
+static inline const char* rt_d2h(void* h, const void* d, size_t n, wga_stream_t) {
+  memcpy(h, d, n);
+  return nullptr;
+}
+static inline const char* rt_memset(void* d, int v, size_t n, wga_stream_t) {
+  memset(d, v, n);
+  return nullptr;
+}
+static inline const char* rt_launch_error() { return nullptr; }
+#else
+#include <hip/hip_runtime.h>
+typedef hipStream_t wga_stream_t;
+#define WGA_LAUNCH(kernel, grid, block, stream, ...) \
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+static inline const char* rt_err(hipError_t e) { return e == hipSuccess ? nullptr : hipGetErrorString(e); }
+static inline int rt_device_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+static inline const char* rt_set_device(int d) { return rt_err(hipSetDevice(d)); }
+static inline const char* rt_stream_create(wga_stream_t* s) {
+  return rt_err(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+}
+static inline void rt_stream_destroy(wga_stream_t s) { (void)hipStreamDestroy(s); }
+static inline const char* rt_sync(wga_stream_t s) { return rt_err(hipStreamSynchronize(s)); }
+static inline const char* rt_malloc(void** p, size_t n) { return rt_err(hipMalloc(p, n ? n : 1)); }
+static inline const char* rt_free(void* p) { return rt_err(hipFree(p)); }
+static inline const char* rt_h2d(void* d, const void* h, size_t n, wga_stream_t s) {
+  return rt_err(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s));
+}
+static inline const char* rt_d2h(void* h, const void* d, size_t n, wga_stream_t s) {
+  hipError_t e = hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess) return hipGetErrorString(e);
+  return rt_err(hipStreamSynchronize(s));
+}
+static inline const char* rt_memset(void* d, int v, size_t n, wga_stream_t s) {
+  return rt_err(hipMemsetAsync(d, v, n, s));
+}
+static inline const char* rt_launch_error() { return rt_err(hipGetLastError()); }
+#endif
+
+#endif

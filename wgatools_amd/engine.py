@@ -1,0 +1,228 @@
+"""Thin object layer over the C-ABI: device arrays and one method per entry point.
+
+No computation happens here — every method forwards to libwgahip.so.  Arrays live in HBM
+(`DeviceArray`); `upload` / `numpy()` are the only host<->device copies.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+COUNTS_DTYPE = np.dtype([(k, "<u8") for k in (
+    "match", "mismatch", "ins_ev", "ins_bp", "del_ev", "del_bp", "inv_ins_ev", "inv_ins_bp",
+    "inv_del_ev", "inv_del_bp", "inv_ev")])
+DIAG_DTYPE = np.dtype([("bad_op_idx", "<u8"), ("panic_op_idx", "<u8"), ("bad_base_pos", "<u8")])
+CLASS_SUMS_DTYPE = np.dtype([(k, "<u8") for k in ("mx", "i", "d", "s", "o")])
+NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+OP_CODES = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4, "H": 5, "P": 6, "=": 7, "X": 8}
+OP_I_CONT, OP_D_CONT, OP_OTHER = 9, 10, 11
+OP_MAX_LEN = (1 << 28) - 1
+
+REC_ERR_NAMES = {0: "ok", 1: "CigarTagNotFound", 2: "CigarOpInvalid", 3: "ParseIntError",
+                 4: "InvalidBase", 5: "NomErr", 6: "panic"}
+
+
+class DeviceArray:
+    """A typed view of an HBM allocation owned by (or borrowed into) an Engine."""
+
+    def __init__(self, eng, ptr, shape, dtype, owner=True):
+        self.eng = eng
+        self.ptr = ptr
+        self.shape = tuple(shape) if not np.isscalar(shape) else (int(shape),)
+        self.dtype = np.dtype(dtype)
+        self.owner = owner
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape)) if self.shape else 1
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        self.eng._check(self.eng.lib.wga_memcpy_d2h(self.eng.ctx, out.ctypes.data, self.ptr,
+                                                    self.nbytes))
+        return out
+
+    def fill(self, byte):
+        self.eng._check(self.eng.lib.wga_memset(self.eng.ctx, self.ptr, byte, self.nbytes))
+        return self
+
+    def free(self):
+        if self.owner and self.ptr:
+            self.eng.lib.wga_free(self.eng.ctx, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _p(x):
+    """device pointer of a DeviceArray / torch tensor / int / None"""
+    if x is None:
+        return None
+    if isinstance(x, DeviceArray):
+        return x.ptr
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    return int(x)
+
+
+class Batch:
+    """A device-resident CSR batch of packed CIGARs (wga_cigar_batch)."""
+
+    def __init__(self, ops, op_off, strand_neg, n, n_ops):
+        self.ops, self.op_off, self.strand_neg = ops, op_off, strand_neg
+        self.n, self.n_ops = int(n), int(n_ops)
+        self.c = _lib.CigarBatch(_p(ops), _p(op_off), _p(strand_neg), self.n_ops, self.n)
+
+
+class Engine:
+    def __init__(self, device=0, lib=None):
+        self.lib = lib if lib is not None else _lib.load()
+        ctx = C.c_void_p()
+        rc = self.lib.wga_ctx_create(device, C.byref(ctx))
+        if rc != 0:
+            raise _lib.WgaError("wga_ctx_create failed (%d): %s" % (
+                rc, self.lib.wga_last_error().decode()))
+        self.ctx = ctx
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.wga_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise _lib.WgaError("libwgahip call failed (%d): %s" % (
+                rc, self.lib.wga_last_error().decode()))
+
+    # ---- memory -----------------------------------------------------------------------------
+    def empty(self, shape, dtype):
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) if not np.isscalar(shape) else int(shape)
+        ptr = C.c_void_p()
+        self._check(self.lib.wga_malloc(self.ctx, max(n * dt.itemsize, 16), C.byref(ptr)))
+        return DeviceArray(self, ptr.value, shape, dt)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        d = self.empty(arr.shape, arr.dtype)
+        self._check(self.lib.wga_memcpy_h2d(self.ctx, d.ptr, arr.ctypes.data, arr.nbytes))
+        self.sync()  # the host array may be a temporary
+        return d
+
+    def sync(self):
+        self._check(self.lib.wga_sync(self.ctx))
+
+    def set_stream(self, hip_stream):
+        self._check(self.lib.wga_ctx_set_stream(self.ctx, hip_stream))
+
+    def set_param(self, name, value):
+        self._check(self.lib.wga_ctx_set_param(self.ctx, name.encode(), int(value)))
+
+    # ---- host packer ------------------------------------------------------------------------
+    def pack_cigar(self, text):
+        """CIGAR text (after 'cg:Z:') -> (ops u32[], err code, (tok_off, tok_len))."""
+        if isinstance(text, str):
+            text = text.encode()
+        n = C.c_size_t()
+        err = C.c_int32()
+        eo, el = C.c_size_t(), C.c_size_t()
+        cap = max(1, text.count(b"M") + len(text))  # generous first guess
+        ops = np.empty(cap, dtype=np.uint32)
+        rc = self.lib.wga_cigar_pack(text, len(text), ops.ctypes.data, cap, C.byref(n),
+                                     C.byref(err), C.byref(eo), C.byref(el))
+        if rc == -5:  # WGA_E_TOO_SMALL
+            cap = n.value
+            ops = np.empty(cap, dtype=np.uint32)
+            rc = self.lib.wga_cigar_pack(text, len(text), ops.ctypes.data, cap, C.byref(n),
+                                         C.byref(err), C.byref(eo), C.byref(el))
+        self._check(rc)
+        return ops[: n.value].copy(), err.value, (eo.value, el.value)
+
+    def make_batch(self, ops, op_off, strand_neg):
+        """numpy CSR arrays -> device Batch"""
+        ops = np.ascontiguousarray(ops, dtype=np.uint32)
+        op_off = np.ascontiguousarray(op_off, dtype=np.uint64)
+        strand_neg = np.ascontiguousarray(strand_neg, dtype=np.uint8)
+        n = len(strand_neg)
+        assert len(op_off) == n + 1 and int(op_off[-1]) == len(ops)
+        return Batch(self.upload(ops), self.upload(op_off), self.upload(strand_neg), n, len(ops))
+
+    # ---- kernels ----------------------------------------------------------------------------
+    def tile_ws(self, n_ops):
+        return self.empty(self.lib.wga_tile_ws_bytes(int(n_ops)), np.uint8)
+
+    def cigar_stat(self, batch, counts=None, diag=None, tile_ws=None, want_tiles=True):
+        counts = counts if counts is not None else self.empty(batch.n, COUNTS_DTYPE)
+        diag = diag if diag is not None else self.empty(batch.n, DIAG_DTYPE)
+        if tile_ws is None and want_tiles:
+            tile_ws = self.tile_ws(batch.n_ops)
+        self._check(self.lib.wga_cigar_stat(self.ctx, C.byref(batch.c), _p(counts), _p(diag),
+                                            _p(tile_ws)))
+        return counts, diag, tile_ws
+
+    def cigar_class_sums(self, batch, sums=None):
+        sums = sums if sums is not None else self.empty(batch.n, CLASS_SUMS_DTYPE)
+        self._check(self.lib.wga_cigar_class_sums(self.ctx, C.byref(batch.c), _p(sums)))
+        return sums
+
+    def paf2maf_layout(self, n, counts, t_src_len, q_src_len, pre_t=None, pre_q=None, post=None,
+                       t_row_off=None, q_row_off=None, rec_off=None):
+        t_row_off = t_row_off if t_row_off is not None else self.empty(n, np.uint64)
+        q_row_off = q_row_off if q_row_off is not None else self.empty(n, np.uint64)
+        rec_off = rec_off if rec_off is not None else self.empty(n + 1, np.uint64)
+        self._check(self.lib.wga_paf2maf_layout(self.ctx, n, _p(counts), _p(t_src_len),
+                                                _p(q_src_len), _p(pre_t), _p(pre_q), _p(post),
+                                                _p(t_row_off), _p(q_row_off), _p(rec_off)))
+        return t_row_off, q_row_off, rec_off
+
+    def paf2maf_expand(self, batch, counts, tile_ws, t_fa, t_fa_bytes, t_src_off, t_src_len, q_fa,
+                       q_fa_bytes, q_src_off, q_src_len, out, t_row_off, q_row_off, diag):
+        self._check(self.lib.wga_paf2maf_expand(
+            self.ctx, C.byref(batch.c), _p(counts), _p(tile_ws), _p(t_fa), int(t_fa_bytes),
+            _p(t_src_off), _p(t_src_len), _p(q_fa), int(q_fa_bytes), _p(q_src_off), _p(q_src_len),
+            _p(out), _p(t_row_off), _p(q_row_off), _p(diag)))
+
+    def scatter_bytes(self, n, src, src_off, dst, dst_off):
+        self._check(self.lib.wga_scatter_bytes(self.ctx, n, _p(src), _p(src_off), _p(dst),
+                                               _p(dst_off)))
+
+    def exclusive_scan_u64(self, n, d_in, d_out=None):
+        d_out = d_out if d_out is not None else self.empty(n + 1, np.uint64)
+        self._check(self.lib.wga_exclusive_scan_u64(self.ctx, n, _p(d_in), _p(d_out)))
+        return d_out
+
+    def maf_pair_stat(self, n, rows, t_off, q_off, cols, strand_neg, counts=None, run_cnt=None,
+                      runs=None, run_off=None):
+        counts = counts if counts is not None else self.empty(n, COUNTS_DTYPE)
+        run_cnt = run_cnt if run_cnt is not None else self.empty(n, np.uint64)
+        self._check(self.lib.wga_maf_pair_stat(self.ctx, n, _p(rows), _p(t_off), _p(q_off),
+                                               _p(cols), _p(strand_neg), _p(counts), _p(run_cnt),
+                                               _p(runs), _p(run_off)))
+        return counts, run_cnt
+
+    def pafcov_accumulate(self, batch, target_id, t_start, cov_off, cov_len, cov):
+        self._check(self.lib.wga_pafcov_accumulate(self.ctx, C.byref(batch.c), _p(target_id),
+                                                   _p(t_start), _p(cov_off), _p(cov_len), _p(cov)))
+
+    def pafcov_finalize(self, n_targets, cov_off, cov_len, cov):
+        self._check(self.lib.wga_pafcov_finalize(self.ctx, n_targets, _p(cov_off), _p(cov_len),
+                                                 _p(cov)))
+
+    def pafpseudo_fill(self, batch, base_mode, q_fa, q_fa_bytes, q_src_off, q_src_len, skip, out,
+                       dst_off, diag=None):
+        diag = diag if diag is not None else self.empty(batch.n, DIAG_DTYPE)
+        self._check(self.lib.wga_pafpseudo_fill(self.ctx, C.byref(batch.c), int(base_mode),
+                                                _p(q_fa), int(q_fa_bytes), _p(q_src_off),
+                                                _p(q_src_len), _p(skip), _p(out), _p(dst_off),
+                                                _p(diag)))
+        return diag

@@ -1,0 +1,103 @@
+"""Synthetic PAF workloads of BASELINE.json's shapes, generated with numpy.
+
+`make_paf_batch` draws the config-2 mixture: records of ~lognormal(mean_ops, sigma 0.5) ops that
+alternate a match run (`=` or `M`, len ~ Geom(mean 24)) with an edit (X len 1: 60 %, I: 20 %,
+D: 20 %; indel len ~ Geom(mean 3) with a 1 % heavy tail U[50, 2000]); strand 50/50; target and
+query slices placed uniformly in two sequence pools of ACGT (+0.1 % N, 5 % lower-case runs).
+"""
+import numpy as np
+
+OP_M, OP_I, OP_D, OP_N, OP_S, OP_H, OP_P, OP_EQ, OP_X = range(9)
+OP_CHARS = "MIDNSHP=X"
+
+
+def make_pool(rng, nbytes, n_frac=0.001, lower_frac=0.05):
+    """uniform ACGT with a sprinkle of N and lower-case runs (exercises case + revcomp)"""
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    pool = acgt[rng.integers(0, 4, size=nbytes)]
+    if n_frac > 0 and nbytes:
+        k = int(nbytes * n_frac)
+        pool[rng.integers(0, nbytes, size=k)] = ord("N")
+    if lower_frac > 0 and nbytes:
+        run = 200
+        k = max(1, int(nbytes * lower_frac / run))
+        starts = rng.integers(0, max(1, nbytes - run), size=k)
+        for s in starts[: 20000]:
+            pool[s:s + run] |= 0x20
+    return pool
+
+
+def make_ops(rng, n_rec, mean_ops, sigma=0.5, use_m=False, min_ops=1, max_ops=None):
+    """-> ops (u32 packed), op_off (u64, n+1), per-class sums per record"""
+    mu = np.log(mean_ops) - 0.5 * sigma * sigma
+    n_ops = np.maximum(min_ops, rng.lognormal(mu, sigma, size=n_rec).astype(np.int64))
+    if max_ops is not None:
+        n_ops = np.minimum(n_ops, max_ops)
+    op_off = np.zeros(n_rec + 1, dtype=np.uint64)
+    np.cumsum(n_ops, out=op_off[1:])
+    total = int(op_off[-1])
+    idx_in_rec = np.arange(total, dtype=np.int64) - np.repeat(op_off[:-1].astype(np.int64), n_ops)
+    is_match = (idx_in_rec & 1) == 0
+    code = np.empty(total, dtype=np.uint32)
+    length = np.empty(total, dtype=np.uint32)
+    nm = int(is_match.sum())
+    code[is_match] = OP_M if use_m else OP_EQ
+    length[is_match] = rng.geometric(1.0 / 24.0, size=nm)
+    ne = total - nm
+    u = rng.random(ne)
+    ecode = np.where(u < 0.6, OP_X, np.where(u < 0.8, OP_I, OP_D)).astype(np.uint32)
+    elen = rng.geometric(1.0 / 3.0, size=ne).astype(np.uint32)
+    heavy = rng.random(ne) < 0.01
+    elen[heavy] = rng.integers(50, 2001, size=int(heavy.sum()))
+    elen[ecode == OP_X] = 1
+    if use_m:
+        ecode[ecode == OP_X] = OP_M
+    code[~is_match] = ecode
+    length[~is_match] = elen
+    ops = (length << np.uint32(4)) | code
+    return ops.astype(np.uint32), op_off, code, length
+
+
+def class_sums(code, length, op_off):
+    """per-record sums of M+=+X, I, D lengths (numpy reduceat; empty records -> 0)"""
+    n = len(op_off) - 1
+    out = {}
+    starts = op_off[:-1].astype(np.int64)
+    for name, mask in (("mx", (code == OP_M) | (code == OP_EQ) | (code == OP_X)),
+                       ("i", code == OP_I), ("d", code == OP_D)):
+        v = np.where(mask, length, 0).astype(np.uint64)
+        c = np.zeros(len(v) + 1, dtype=np.uint64)
+        np.cumsum(v, out=c[1:])
+        out[name] = c[op_off[1:].astype(np.int64)] - c[starts]
+    assert len(out["mx"]) == n
+    return out
+
+
+def make_paf_batch(seed, n_rec, mean_ops, pool_bytes, use_m=False, sigma=0.5, max_ops=None,
+                   neg_frac=0.5):
+    """A full paf2maf problem: packed CIGARs + slices into two pools (all numpy, host side)."""
+    rng = np.random.default_rng(seed)
+    ops, op_off, code, length = make_ops(rng, n_rec, mean_ops, sigma, use_m, max_ops=max_ops)
+    cs = class_sums(code, length, op_off)
+    t_len = cs["mx"] + cs["d"]
+    q_len = cs["mx"] + cs["i"]
+    need = int(max(t_len.max(initial=0), q_len.max(initial=0))) + 64
+    pool_bytes = max(int(pool_bytes), need)
+    t_pool = make_pool(rng, pool_bytes)
+    q_pool = make_pool(rng, pool_bytes)
+    t_off = (rng.random(n_rec) * (pool_bytes - t_len.astype(np.float64))).astype(np.uint64)
+    q_off = (rng.random(n_rec) * (pool_bytes - q_len.astype(np.float64))).astype(np.uint64)
+    strand = (rng.random(n_rec) < neg_frac).astype(np.uint8)
+    return dict(ops=ops, op_off=op_off, strand_neg=strand, t_pool=t_pool, q_pool=q_pool,
+                t_src_off=t_off, t_src_len=t_len.astype(np.uint64), q_src_off=q_off,
+                q_src_len=q_len.astype(np.uint64), code=code, length=length)
+
+
+def cigar_text(ops_slice):
+    """packed ops of one record -> CIGAR text (no tag)"""
+    out = []
+    for w in ops_slice.tolist():
+        c = w & 15
+        ch = OP_CHARS[c] if c < 9 else ("I" if c == 9 else "D" if c == 10 else "B")
+        out.append("%d%s" % (w >> 4, ch))
+    return "".join(out)
