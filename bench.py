@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""bench.py — the headline metric of BASELINE.json: PAF CIGAR-ops/s for `paf2maf`+`stat`.
+
+One "step" = one pass of the hot path over one HBM-resident batch of synthetic PAF records:
+  K1 wga_cigar_stat  (parse_paf_to_cigar, cigar.rs:629-707)  -> per-record counts
+  wga_paf2maf_layout (row geometry, converter.rs:237-262)
+  K2 wga_paf2maf_expand (parse_cigar_to_insert + reverse_complement, cigar.rs:492-551)
+  + a reduction of the stat totals (RCCL all-reduce over xGMI when N > 1)
+Workload at N=1 = BASELINE.json configs[1]: 100 000 records, mean CIGAR 5 kop, 2 x 50 Mb
+sequence pools.  N > 1: weak scaling — every rank owns its own shard of records (records are
+independent; real runs shard by hash(target_name)), no data-path collective.
+
+Prints ONE JSON line on rank 0.  `python bench.py` defaults to N=1, 5 steps, 2 warm-up steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy rate
+
+
+def cpu_baseline(tb, budget_s=12.0, max_records=1500):
+    """The oracle (oracle/oracle.c: reference-faithful port, text tokenising + String::insert_str
+    tail memmoves) timed on ONE host core over a bounded sample of the same batch."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as orc
+    from wgatools_amd import synth
+    recs = []
+    n = min(tb["n"], max_records)
+    for i in range(n):
+        r = synth.torch_batch_record_to_numpy(tb, i)
+        recs.append((("cg:Z:" + synth.cigar_text(r["ops"])).encode(), int(r["strand_neg"][0]),
+                     r["t_pool"].tobytes(), r["q_pool"].tobytes(), len(r["ops"])))
+    ops_done, done = 0, 0
+    t0 = time.perf_counter()
+    for cg, neg, t, q, nops in recs:
+        orc.parse_paf_to_cigar(cg, neg)                       # stat
+        if neg:
+            q = orc.reverse_complement(q)                     # paf2maf
+        orc.parse_cigar_to_insert(cg, t, q)
+        ops_done += nops
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": ops_done / dt, "unit": "ops/s", "cores": 1, "kind": "port",
+            "sample": "first %d records (%d ops) of the same batch, stat + paf2maf per record, "
+                      "%.1f s on 1 core" % (done, ops_done, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--records", type=int, default=100_000)
+    ap.add_argument("--mean-ops", type=int, default=5000)
+    ap.add_argument("--pool-mb", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", type=int, default=8, help="records spot-checked against the oracle")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from wgatools_amd import engine, pipeline, synth
+    eng = engine.Engine(local_rank)
+    seed = 0x5747415F + 2 + rank
+    tb = synth.make_paf_batch_torch(seed, args.records, args.mean_ops, args.pool_mb * 1_000_000, dev)
+    job = pipeline.Paf2MafStatJob(eng, tb)
+    job.bind_stream()
+    totals = torch.zeros(11, dtype=torch.int64, device=dev)
+
+    def step(evs=None):
+        if evs:
+            evs[0].record()
+        job.stat()
+        if evs:
+            evs[1].record()
+        job.layout()
+        if evs:
+            evs[2].record()
+        job.expand()
+        if evs:
+            evs[3].record()
+        torch.sum(job.counts, dim=0, out=totals)            # global stat totals
+        if world > 1:
+            dist.all_reduce(totals)                          # RCCL over xGMI: 88 bytes
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    nops = torch.tensor([float(job.n_ops)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nops)
+    elapsed = float(el.item())
+    total_ops = float(nops.item())
+
+    # the run only counts if every record came out clean
+    assert bool((job.diag == -1).all()), "kernel reported per-record errors on clean synthetic input"
+
+    if rank == 0:
+        k_stat = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
+        k_layout = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
+        k_expand = sum(e[2].elapsed_time(e[3]) for e in events) / args.steps
+        ab = job.algorithmic_bytes()
+        in_bytes = 4 * job.n_ops + int(tb["t_src_len"].sum()) + int(tb["q_src_len"].sum())
+        ach = ab["expand"] / (k_expand * 1e-3) / 1e9
+        result = {
+            "metric": "paf_cigar_ops_per_s (paf2maf+stat)",
+            "value": total_ops * args.steps / elapsed,
+            "unit": "ops/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: paf2maf+stat, %d records/GPU x mean %d ops "
+                            "(lognormal s=0.5; =/X/I/D mix), 2 x %d Mb pools, strand 50/50, "
+                            "HBM-resident" % (args.records, args.mean_ops, args.pool_mb),
+                "records_per_gpu": args.records, "ops_per_gpu": job.n_ops,
+                "columns_per_gpu": int((tb["mx"] + tb["i"] + tb["d"]).sum()),
+                "output_bytes_per_gpu": job.out_bytes, "sharding": "records, no data-path collective",
+            },
+            "input_GBps": in_bytes * world * args.steps / elapsed / 1e9,
+            "kernel_ms": {"k_cigar_stat": k_stat, "layout_scan": k_layout, "k_paf2maf_expand": k_expand},
+            "roofline": {
+                "kernel": "k_paf2maf_expand", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": ab["expand"],
+                "k_cigar_stat_GBps": ab["stat"] / (k_stat * 1e-3) / 1e9,
+            },
+        }
+        # parity spot check against the oracle (after the timed region)
+        if args.check:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import parity_cases as pc
+            step_idx = torch.linspace(0, tb["n"] - 1, args.check).long().tolist()
+            for i in step_idx:
+                r = synth.torch_batch_record_to_numpy(tb, i)
+                et, eq = pc.oracle_rows(r, 0)
+                gt, gq = job.record_rows(i)
+                assert gt == et and gq == eq, "record %d differs from the oracle" % i
+            result["parity_spot_check"] = "%d records bit-identical to oracle rows" % len(step_idx)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(tb)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

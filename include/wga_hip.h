@@ -105,9 +105,10 @@ const char* wga_last_error(void);
 int wga_device_count(void);
 int wga_ctx_create(int device, wga_ctx** out);
 void wga_ctx_destroy(wga_ctx*);
-/* Launch on an external stream (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream);
- * NULL restores the context's own stream. */
+/* Launch on an external stream (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream;
+ * NULL is HIP's default stream).  wga_ctx_reset_stream goes back to the context's own stream. */
 int wga_ctx_set_stream(wga_ctx*, void* hip_stream);
+int wga_ctx_reset_stream(wga_ctx*);
 /* Tunables: "expand_force_slow" (0/1) forces the u64 op-serial fallback of the expand kernel. */
 int wga_ctx_set_param(wga_ctx*, const char* name, int64_t value);
 int wga_sync(wga_ctx*);
@@ -170,15 +171,15 @@ int wga_scatter_bytes(wga_ctx*, uint32_t n, const uint8_t* d_src, const uint64_t
  *      cigar.rs:298-308,344-432) ---------------------------------------------------------------
  * Record i compares d_rows[t_off[i] + j] with d_rows[q_off[i] + j] for j < cols[i]
  * (cols = min of the two row lengths: `zip` truncates).  d_counts[n] as K1.
- * Optional RLE for maf2paf's cg:Z: text (maf.rs:484-520): if d_runs != NULL, record i's runs are
- * written to d_runs[d_run_off[i] ..) as (len << 4 | code) with code in {=,X,I,D}; a run longer
- * than 2^28-1 is split into same-code pieces (the host re-merges when formatting).
- * d_run_cnt[n] always receives the number of u32 words record i needs; call once with
- * d_runs == NULL to size, scan on the host (or wga_exclusive_scan_u64), call again. */
+ * Optional run list for maf2paf's cg:Z: text (maf.rs:484-520): d_run_cnt[n] always receives the
+ * number of runs of record i; if d_runs != NULL record i's runs are written in order to
+ * d_runs[d_run_off[i] ..) as (start_column << 3 | class), class 0 '=', 1 'I', 2 'D', 3 'X'
+ * (a run's length is the next run's start — or cols[i] — minus its own start).  Call once with
+ * d_runs == NULL to size, scan d_run_cnt (wga_exclusive_scan_u64), call again. */
 int wga_maf_pair_stat(wga_ctx*, uint32_t n, const uint8_t* d_rows, const uint64_t* d_t_off,
                       const uint64_t* d_q_off, const uint64_t* d_cols,
                       const uint8_t* d_strand_neg, wga_cigar_counts* d_counts,
-                      uint64_t* d_run_cnt, uint32_t* d_runs, const uint64_t* d_run_off);
+                      uint64_t* d_run_cnt, uint64_t* d_runs, const uint64_t* d_run_off);
 
 /* ---- K5: pafcov (replaces update_cov_vec, cigar.rs:710-741, and the per-thread array merge of
  *      pafcov.rs:29-53) ------------------------------------------------------------------------

@@ -1,4 +1,7 @@
-"""ctypes face of oracle/liboracle.so — the CPU checker.  Test infrastructure only."""
+"""ctypes face of oracle/liboracle.so — the CPU checker.
+
+Test infrastructure only: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg; never by the wgatools_amd package."""
 import ctypes as C
 import os
 import subprocess

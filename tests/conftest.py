@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
 def pytest_configure(config):
@@ -14,6 +15,7 @@ def pytest_configure(config):
 
 
 def _gpu_engine():
+    import torch  # noqa: F401  first: libwgahip.so then shares torch's HIP runtime (same SONAME)
     from wgatools_amd import build, engine, _lib
     # the product library; on the GPU box the prebuilt in-tree .so travels with the snapshot
     if not os.path.exists(build.HIP_LIB):

@@ -1,0 +1,394 @@
+"""Parity checks of the HIP path against the CPU oracle, written once and run twice:
+   * tests/test_emu_parity.py — same kernel source on the SIMT emulator (`-m "not gpu"`)
+   * tests/test_gpu_parity.py — libwgahip.so on a real MI355X (`-m gpu`), through the C-ABI.
+Bit-exact: every comparison is equality of integers / bytes.
+"""
+import numpy as np
+
+import oracle_py as orc
+from wgatools_amd import engine, synth
+
+NONE = int(engine.NONE)
+
+
+def rec_ops(b, i):
+    return b["ops"][int(b["op_off"][i]):int(b["op_off"][i + 1])]
+
+
+def rec_text(b, i):
+    return "cg:Z:" + synth.cigar_text(rec_ops(b, i))
+
+
+# ------------------------------------------------------------------------------------------------
+# K1
+# ------------------------------------------------------------------------------------------------
+def check_stat(eng, b, sample=None):
+    """wga_cigar_stat == parse_paf_to_cigar (cigar.rs:629-707) for every (sampled) record"""
+    batch = eng.make_batch(b["ops"], b["op_off"], b["strand_neg"])
+    counts, diag, _ = eng.cigar_stat(batch)
+    c, d = counts.numpy(), diag.numpy()
+    idx = range(batch.n) if sample is None else sample
+    for i in idx:
+        try:
+            exp = orc.parse_paf_to_cigar(rec_text(b, i), b["strand_neg"][i])
+            assert d["bad_op_idx"][i] == engine.NONE, (i, d[i])
+            assert tuple(int(x) for x in c[i]) == exp, (i, exp, c[i])
+        except orc.OracleError as e:
+            # the oracle rejected an op: the kernel must point at that very op
+            assert e.kind == 2
+            k = int(d["bad_op_idx"][i])
+            assert k != NONE, (i, e.message)
+            w = int(rec_ops(b, i)[k])
+            ch = synth.OP_CHARS[w & 15] if (w & 15) < 9 else "B"
+            assert e.arg == ch, (i, k, e.arg, ch)
+            # and no earlier op is rejected
+            for w2 in rec_ops(b, i)[:k].tolist():
+                assert (w2 & 15) in (0, 1, 2, 7, 8, 9, 10)
+    return counts, diag
+
+
+# ------------------------------------------------------------------------------------------------
+# K2
+# ------------------------------------------------------------------------------------------------
+def run_paf2maf(eng, b, pre=None, force_slow=0, fill=0x23):
+    """stat -> layout -> expand; returns host copies"""
+    n = len(b["strand_neg"])
+    batch = eng.make_batch(b["ops"], b["op_off"], b["strand_neg"])
+    eng.set_param("expand_force_slow", force_slow)
+    counts, diag, tws = eng.cigar_stat(batch)
+    tl, ql = eng.upload(b["t_src_len"]), eng.upload(b["q_src_len"])
+    to, qo = eng.upload(b["t_src_off"]), eng.upload(b["q_src_off"])
+    if pre is not None:
+        pt, pq, po = (eng.upload(np.asarray(x, dtype=np.uint32)) for x in pre)
+    else:
+        pt = pq = po = None
+    tro, qro, reco = eng.paf2maf_layout(n, counts, tl, ql, pt, pq, po)
+    total = int(reco.numpy()[-1])
+    out = eng.empty(total + 64, np.uint8).fill(fill)
+    tp, qp = eng.upload(b["t_pool"]), eng.upload(b["q_pool"])
+    eng.paf2maf_expand(batch, counts, tws, tp, len(b["t_pool"]), to, tl, qp, len(b["q_pool"]), qo,
+                       ql, out, tro, qro, diag)
+    eng.set_param("expand_force_slow", 0)
+    return dict(out=out.numpy(), t_row_off=tro.numpy(), q_row_off=qro.numpy(),
+                rec_off=reco.numpy(), counts=counts.numpy(), diag=diag.numpy(), total=total)
+
+
+def oracle_rows(b, i):
+    """what converter.rs:219-235 does for one record, through the oracle"""
+    t = b["t_pool"][int(b["t_src_off"][i]):int(b["t_src_off"][i] + b["t_src_len"][i])].tobytes()
+    q = b["q_pool"][int(b["q_src_off"][i]):int(b["q_src_off"][i] + b["q_src_len"][i])].tobytes()
+    if b["strand_neg"][i]:
+        q = orc.reverse_complement(q)  # may raise InvalidBase
+    return orc.parse_cigar_to_insert(rec_text(b, i), t, q)  # may raise CigarOpInvalid / panic
+
+
+def check_paf2maf(eng, b, pre=None, force_slow=0, sample=None):
+    r = run_paf2maf(eng, b, pre=pre, force_slow=force_slow)
+    out, n = r["out"], len(b["strand_neg"])
+    covered = np.zeros(len(out), dtype=bool)
+    idx = range(n) if sample is None else sample
+    for i in idx:
+        d = r["diag"][i]
+        try:
+            et, eq = oracle_rows(b, i)
+        except orc.OracleError as e:
+            if e.kind == 4:  # InvalidBase: first offender in reversed order
+                pos = int(d["bad_base_pos"])
+                assert pos != NONE, (i, e.message)
+                raw = b["q_pool"][int(b["q_src_off"][i] + b["q_src_len"][i]) - 1 - pos]
+                assert chr(raw) == e.arg, (i, pos, chr(raw), e.arg)
+            elif e.kind == 2:
+                assert int(d["bad_op_idx"]) != NONE, (i, e.message)
+            else:
+                assert e.kind == 6 and int(d["panic_op_idx"]) != NONE, (i, e.message, d)
+            continue
+        assert int(d["bad_op_idx"]) == NONE and int(d["panic_op_idx"]) == NONE and \
+            int(d["bad_base_pos"]) == NONE, (i, d)
+        to, qo = int(r["t_row_off"][i]), int(r["q_row_off"][i])
+        gt, gq = out[to:to + len(et)].tobytes(), out[qo:qo + len(eq)].tobytes()
+        if gt != et or gq != eq:
+            k = next((j for j in range(len(et)) if gt[j] != et[j]), None)
+            k2 = next((j for j in range(len(eq)) if gq[j] != eq[j]), None)
+            raise AssertionError("record %d rows differ: t@%s q@%s (neg=%d, len=%d)" % (
+                i, k, k2, b["strand_neg"][i], len(et)))
+        covered[to:to + len(et)] = True
+        covered[qo:qo + len(eq)] = True
+        # geometry: rows sit where the layout says (String::insert_str lengths)
+        assert len(et) == int(b["t_src_len"][i]) + int(r["counts"][i]["ins_bp"] + r["counts"][i]["inv_ins_bp"])
+        assert len(eq) == int(b["q_src_len"][i]) + int(r["counts"][i]["del_bp"] + r["counts"][i]["inv_del_bp"])
+    if sample is None:
+        # nothing outside the rows of clean records was touched (no stray / RMW stores)
+        clean = np.ones(n, dtype=bool)
+        for f in ("bad_op_idx", "panic_op_idx", "bad_base_pos"):
+            clean &= r["diag"][f] == engine.NONE
+        if clean.all():
+            assert (out[~covered] == 0x23).all()
+    return r
+
+
+# ------------------------------------------------------------------------------------------------
+# hand-made batches for the edge cases
+# ------------------------------------------------------------------------------------------------
+def batch_from_texts(eng, cigars, strands, t_seqs, q_seqs, pad=0):
+    """records given as text; slices are laid back to back (optionally `pad` bytes apart) in the
+    pools so that the first / last records touch the pool edges"""
+    from helpers import pack_records
+    ops, off, errs = pack_records(eng, cigars)
+    assert all(e == 0 for e in errs), errs
+    def pool(seqs):
+        offs, buf, p = [], bytearray(), 0
+        for s in seqs:
+            offs.append(p)
+            buf += s + b"N" * pad
+            p += len(s) + pad
+        if pad and buf:
+            del buf[-pad:]
+        return np.frombuffer(bytes(buf) or b"N", dtype=np.uint8).copy(), np.array(offs, dtype=np.uint64)
+    tp, to = pool(t_seqs)
+    qp, qo = pool(q_seqs)
+    return dict(ops=ops, op_off=off, strand_neg=np.array(strands, dtype=np.uint8), t_pool=tp,
+                q_pool=qp, t_src_off=to, q_src_off=qo,
+                t_src_len=np.array([len(s) for s in t_seqs], dtype=np.uint64),
+                q_src_len=np.array([len(s) for s in q_seqs], dtype=np.uint64))
+
+
+def rand_seq(rng, n, alphabet=b"ACGTacgtNn"):
+    a = np.frombuffer(alphabet, dtype=np.uint8)
+    return a[rng.integers(0, len(a), size=n)].tobytes()
+
+
+def consumption(cigar):
+    """(target bases, query bases) a CIGAR text consumes (M = X / D / I)"""
+    import re
+    t = q = 0
+    for n, op in re.findall(r"(\d+)(\D)", cigar):
+        n = int(n)
+        if op in "M=X":
+            t += n
+            q += n
+        elif op == "D":
+            t += n
+        elif op == "I":
+            q += n
+    return t, q
+
+
+def edge_case_batch(eng, seed=7):
+    """zero-length ops, 1-op records, leading/trailing indels, slices longer / shorter than the
+    CIGAR consumes, both strands, records touching both pool edges"""
+    rng = np.random.default_rng(seed)
+    cigars = [
+        "5=", "1X", "1I", "1D", "0M3=0I2X0D", "3I5=2D", "2D5=3I", "7=1X7=1X7=1X7=", "40=",
+        "16=", "15=1I", "1D15=", "17=3I17=3D17=", "1=1I1=1D1=1I1=1D1=1I1=1D", "100I", "100D",
+        "33=17I5X19D64=", "8M8I8M8D8M",
+    ]
+    strands = [i % 2 for i in range(len(cigars))]
+    t_seqs, q_seqs = [], []
+    for c in cigars:
+        t, q = consumption(c)
+        t_seqs.append(rand_seq(rng, t))
+        q_seqs.append(rand_seq(rng, q))
+    # slices longer than the CIGAR consumes (tails are appended) and shorter (rows end early)
+    extra = [("10=2I10=", 0, 27, 30), ("10=2I10=", 1, 20, 40), ("12=", 1, 5, 12), ("12=", 0, 12, 3),
+             ("4=2D4=", 1, 10, 6), ("30=", 0, 64, 64), ("30=", 1, 64, 64)]
+    for c, s, tl, ql in extra:
+        cigars.append(c)
+        strands.append(s)
+        t_seqs.append(rand_seq(rng, tl))
+        q_seqs.append(rand_seq(rng, ql))
+    return batch_from_texts(eng, cigars, strands, t_seqs, q_seqs)
+
+
+# ------------------------------------------------------------------------------------------------
+# K5 pafcov
+# ------------------------------------------------------------------------------------------------
+def sprinkle_ops(rng, b, frac=0.02, codes=(3, 4, 5, 6, 11)):
+    """replace a few ops by N/S/H/P/other (legal for pafcov / pafpseudo)"""
+    ops = b["ops"].copy()
+    k = max(1, int(len(ops) * frac))
+    idx = rng.integers(0, len(ops), k)
+    ops[idx] = (ops[idx] & ~np.uint32(15)) | rng.choice(np.array(codes, dtype=np.uint32), k)
+    nb = dict(b)
+    nb["ops"] = ops
+    return nb
+
+
+def text_any(ops_slice):
+    chars = "MIDNSHP=XIDB"
+    return "cg:Z:" + "".join("%d%s" % (w >> 4, chars[w & 15]) for w in ops_slice.tolist())
+
+
+def check_pafcov(eng, b, target_id, t_start, target_len, align=4):
+    n = len(b["strand_neg"])
+    nt = len(target_len)
+    cov_off = np.zeros(nt, dtype=np.uint64)
+    p = 0
+    for t in range(nt):
+        p = (p + align - 1) // align * align
+        cov_off[t] = p
+        p += int(target_len[t])
+    total = p + 8
+    batch = eng.make_batch(b["ops"], b["op_off"], b["strand_neg"])
+    cov = eng.empty(total, np.int32).fill(0)
+    d_off, d_len = eng.upload(cov_off), eng.upload(np.asarray(target_len, dtype=np.uint64))
+    eng.pafcov_accumulate(batch, eng.upload(np.asarray(target_id, dtype=np.uint32)),
+                          eng.upload(np.asarray(t_start, dtype=np.uint64)), d_off, d_len, cov)
+    eng.pafcov_finalize(nt, d_off, d_len, cov)
+    got = cov.numpy()
+    exp = [np.zeros(int(l), dtype=np.uint64) for l in target_len]
+    for i in range(n):
+        orc.update_cov_vec(exp[target_id[i]], text_any(rec_ops(b, i)), int(t_start[i]))
+    for t in range(nt):
+        g = got[int(cov_off[t]):int(cov_off[t]) + int(target_len[t])]
+        assert (g.astype(np.int64) == exp[t].astype(np.int64)).all(), (
+            t, np.nonzero(g.astype(np.int64) != exp[t].astype(np.int64))[0][:5])
+    return got
+
+
+# ------------------------------------------------------------------------------------------------
+# K6 pafpseudo
+# ------------------------------------------------------------------------------------------------
+def check_pafpseudo(eng, b, base_mode, skip=None):
+    n = len(b["strand_neg"])
+    batch = eng.make_batch(b["ops"], b["op_off"], b["strand_neg"])
+    sums = eng.cigar_class_sums(batch).numpy()
+    # class sums against numpy
+    code = b["ops"] & 15
+    length = (b["ops"] >> 4).astype(np.uint64)
+    cls_of = np.array([0, 1, 2, 4, 3, 4, 4, 0, 0, 1, 2, 4, 4, 4, 4, 4])
+    for ci, name in enumerate(("mx", "i", "d", "s", "o")):
+        v = np.where(cls_of[code] == ci, length, 0).astype(np.uint64)
+        c = np.concatenate([[0], np.cumsum(v)]).astype(np.uint64)
+        exp = c[b["op_off"][1:].astype(np.int64)] - c[b["op_off"][:-1].astype(np.int64)]
+        assert (sums[name] == exp).all(), name
+    skip = np.zeros(n, dtype=np.uint64) if skip is None else np.asarray(skip, dtype=np.uint64)
+    # expected segments from the oracle
+    exp_rows, errs = [], []
+    for i in range(n):
+        q = b"" if not base_mode else \
+            b["q_pool"][int(b["q_src_off"][i]):int(b["q_src_off"][i] + b["q_src_len"][i])].tobytes()
+        try:
+            if base_mode and b["strand_neg"][i]:
+                q = orc.reverse_complement(q)
+            row = orc.gen_pesudo_maf_by_cigar(text_any(rec_ops(b, i)), q, bool(base_mode))
+            exp_rows.append(row[int(skip[i]):])
+            errs.append(None)
+        except orc.OracleError as e:
+            exp_rows.append(b"")
+            errs.append(e)
+    # host geometry (pseudomaf.rs lengths): edited length minus the trimmed head
+    if base_mode:
+        seg = (b["q_src_len"].astype(np.int64) - (sums["i"] + sums["s"]).astype(np.int64)
+               + sums["d"].astype(np.int64))
+    else:
+        seg = (sums["mx"] + sums["d"]).astype(np.int64)
+    seg = np.maximum(seg - skip.astype(np.int64), 0)
+    rng = np.random.default_rng(n)
+    gaps = rng.integers(0, 20, n)
+    dst_off = np.zeros(n, dtype=np.uint64)
+    p = 3
+    for i in range(n):
+        dst_off[i] = p
+        p += int(seg[i]) + int(gaps[i])
+    out = eng.empty(p + 64, np.uint8).fill(0x23)
+    if base_mode:
+        qp = eng.upload(b["q_pool"])
+        diag = eng.pafpseudo_fill(batch, 1, qp, len(b["q_pool"]), eng.upload(b["q_src_off"]),
+                                  eng.upload(b["q_src_len"]), eng.upload(skip), out,
+                                  eng.upload(dst_off))
+    else:
+        diag = eng.pafpseudo_fill(batch, 0, None, 0, None, None, eng.upload(skip), out,
+                                  eng.upload(dst_off))
+    o, d = out.numpy(), diag.numpy()
+    covered = np.zeros(len(o), dtype=bool)
+    all_clean = True
+    for i in range(n):
+        if errs[i] is not None:
+            all_clean = False
+            if errs[i].kind == 4:
+                pos = int(d["bad_base_pos"][i])
+                assert pos != NONE
+                raw = b["q_pool"][int(b["q_src_off"][i] + b["q_src_len"][i]) - 1 - pos]
+                assert chr(raw) == errs[i].arg
+            else:
+                assert errs[i].kind == 6 and int(d["panic_op_idx"][i]) != NONE, (i, errs[i].message)
+            continue
+        assert int(d["panic_op_idx"][i]) == NONE and int(d["bad_base_pos"][i]) == NONE, (i, d[i])
+        e = exp_rows[i]
+        assert len(e) == int(seg[i]), (i, len(e), seg[i])
+        g = o[int(dst_off[i]):int(dst_off[i]) + len(e)].tobytes()
+        if g != e:
+            k = next(j for j in range(len(e)) if g[j] != e[j])
+            raise AssertionError("pseudo segment %d differs at %d: %r vs %r" % (
+                i, k, e[max(0, k - 10):k + 10], g[max(0, k - 10):k + 10]))
+        covered[int(dst_off[i]):int(dst_off[i]) + len(e)] = True
+    if all_clean:
+        assert (o[~covered] == 0x23).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# K3 MAF column pairs
+# ------------------------------------------------------------------------------------------------
+def check_maf_pair(eng, pairs, strands):
+    """pairs: list of (t_row bytes, q_row bytes)"""
+    n = len(pairs)
+    buf, t_off, q_off, cols = bytearray(b"@@@"), [], [], []
+    for t, q in pairs:
+        t_off.append(len(buf))
+        buf += t + b"@"
+        q_off.append(len(buf))
+        buf += q + b"@@"
+        cols.append(min(len(t), len(q)))
+    rows = eng.upload(np.frombuffer(bytes(buf), dtype=np.uint8))
+    d_t, d_q = eng.upload(np.array(t_off, dtype=np.uint64)), eng.upload(np.array(q_off, dtype=np.uint64))
+    d_c, d_s = eng.upload(np.array(cols, dtype=np.uint64)), eng.upload(np.array(strands, dtype=np.uint8))
+    counts, run_cnt = eng.maf_pair_stat(n, rows, d_t, d_q, d_c, d_s)
+    rc = run_cnt.numpy()
+    run_off = eng.exclusive_scan_u64(n, run_cnt)
+    ro = run_off.numpy()
+    runs = eng.empty(int(ro[-1]) + 1, np.uint64).fill(0)
+    counts, _ = eng.maf_pair_stat(n, rows, d_t, d_q, d_c, d_s, counts=counts, run_cnt=run_cnt,
+                                  runs=runs, run_off=run_off)
+    c, rr = counts.numpy(), runs.numpy()
+    for i, (t, q) in enumerate(pairs):
+        exp_counts, exp_txt = orc.parse_maf_seq_to_cigar(t, q, strands[i])
+        assert tuple(int(x) for x in c[i]) == exp_counts, (i, exp_counts, c[i])
+        mine = rr[int(ro[i]):int(ro[i + 1])]
+        starts = (mine >> np.uint64(3)).astype(np.int64).tolist() + [cols[i]]
+        txt = "".join("%d%s" % (starts[k + 1] - starts[k], "=IDX"[int(mine[k] & np.uint64(7))])
+                      for k in range(len(mine)))
+        assert txt == exp_txt, (i, txt[:80], exp_txt[:80])
+        assert int(rc[i]) == len(mine)
+
+
+# ------------------------------------------------------------------------------------------------
+# a second, linear-time expectation for long records (the C oracle's insert_str is quadratic)
+# ------------------------------------------------------------------------------------------------
+def fast_expected_rows(ops, t_seq, q_seq, neg):
+    """numpy gather formulation of converter.rs:228-235 for clean records (ops in M = X I D and
+    slices exactly as long as the CIGAR consumes).  Cross-checked against the C oracle in
+    test_emu_parity.py::test_fast_expected_matches_oracle."""
+    code = (ops & 15).astype(np.int64)
+    ln = (ops >> 4).astype(np.int64)
+    is_i = (code == 1) | (code == 9)
+    is_d = (code == 2) | (code == 10)
+    t_adv = np.where(is_i, 0, ln)
+    q_adv = np.where(is_d, 0, ln)
+    t_before = np.concatenate([[0], np.cumsum(t_adv)[:-1]])
+    q_before = np.concatenate([[0], np.cumsum(q_adv)[:-1]])
+    col_before = np.concatenate([[0], np.cumsum(ln)[:-1]])
+    L = int(ln.sum())
+    op_of_col = np.repeat(np.arange(len(ops)), ln)
+    within = np.arange(L) - col_before[op_of_col]
+    t = np.frombuffer(t_seq, dtype=np.uint8)
+    q = np.frombuffer(q_seq, dtype=np.uint8)
+    if neg:
+        comp = np.arange(256, dtype=np.uint8)
+        for a, b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
+            comp[a] = b
+        q = comp[q[::-1]]
+    ti = np.minimum(t_before[op_of_col] + within, max(len(t) - 1, 0))
+    qi = np.minimum(q_before[op_of_col] + within, max(len(q) - 1, 0))
+    t_row = np.where(is_i[op_of_col], ord("-"), t[ti] if len(t) else ord("-")).astype(np.uint8)
+    q_row = np.where(is_d[op_of_col], ord("-"), q[qi] if len(q) else ord("-")).astype(np.uint8)
+    return t_row.tobytes(), q_row.tobytes()

@@ -1,0 +1,211 @@
+"""Kernel-logic parity on the CPU: the HIP kernel source (wga_kernels*.h) compiled against the
+SIMT emulator (tests/emu) and checked against the oracle.  These run under `-m "not gpu"`; the
+same checks run on the real GPU in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from wgatools_amd import engine, synth
+
+
+@pytest.mark.parametrize("seed,n,mean,use_m", [(1, 12, 700, False), (2, 60, 40, False),
+                                               (3, 400, 3, True), (4, 2, 6000, False)])
+def test_stat_random(emu, seed, n, mean, use_m):
+    b = synth.make_paf_batch(seed, n, mean, 60000, use_m=use_m)
+    pc.check_stat(emu, b)
+
+
+def test_stat_bad_ops_and_continuations(emu):
+    """N/S/H/P/other ops are CigarOpInvalid for stat; split I/D count one event"""
+    M, I, D, N, S, H, P, EQ, X = range(9)
+    def op(l, c): return (l << 4) | c
+    recs = [
+        [op(5, EQ), op(3, N), op(2, I)],                       # bad at 1
+        [op(5, M), op(2, I), op(7, 9), op(1, D), op(4, 10), op(9, 10), op(3, X)],  # continuations
+        [op(4, S), op(5, M)],                                  # bad at 0
+        [op(1, EQ)] * 1500 + [op(2, H)] + [op(1, EQ)] * 700,   # bad op deep in a multi-tile record
+        [op(2, 11)],                                           # OTHER
+    ]
+    ops = np.array([w for r in recs for w in r], dtype=np.uint32)
+    off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+    b = dict(ops=ops, op_off=off, strand_neg=np.array([0, 1, 0, 1, 0], dtype=np.uint8))
+    batch = emu.make_batch(b["ops"], b["op_off"], b["strand_neg"])
+    counts, diag, _ = emu.cigar_stat(batch)
+    c, d = counts.numpy(), diag.numpy()
+    assert d["bad_op_idx"].tolist() == [1, int(engine.NONE), 0, 1500, 0]
+    # record 1 ('-'): 2I+7cont = one inv_ins event of 9 bp; 1D+4+9 = one inv_del event of 14 bp
+    assert tuple(int(x) for x in c[1]) == (5, 3, 0, 0, 0, 0, 1, 9, 1, 14, 1)
+
+
+def test_stat_empty(emu):
+    b = dict(ops=np.zeros(0, np.uint32), op_off=np.zeros(1, np.uint64), strand_neg=np.zeros(0, np.uint8))
+    batch = emu.make_batch(b["ops"], b["op_off"], b["strand_neg"])
+    emu.cigar_stat(batch)
+
+
+@pytest.mark.parametrize("seed,n,mean,pool,pre,use_m", [
+    (1, 12, 700, 50000, False, False), (2, 40, 60, 20000, True, False),
+    (3, 300, 3, 5000, True, True), (4, 3, 5000, 200000, False, True)])
+def test_paf2maf_random(emu, seed, n, mean, pool, pre, use_m):
+    b = synth.make_paf_batch(seed, n, mean, pool, use_m=use_m)
+    rng = np.random.default_rng(seed)
+    p = (rng.integers(0, 40, n), rng.integers(0, 40, n), rng.integers(0, 5, n)) if pre else None
+    pc.check_paf2maf(emu, b, pre=p)
+
+
+def test_paf2maf_edge_cases(emu):
+    b = pc.edge_case_batch(emu)
+    n = len(b["strand_neg"])
+    rng = np.random.default_rng(5)
+    pc.check_paf2maf(emu, b)
+    pc.check_paf2maf(emu, b, pre=(rng.integers(0, 33, n), rng.integers(0, 33, n), rng.integers(0, 3, n)))
+    pc.check_paf2maf(emu, b, force_slow=1)
+
+
+def test_paf2maf_force_slow_random(emu):
+    b = synth.make_paf_batch(5, 10, 300, 20000)
+    pc.check_paf2maf(emu, b, force_slow=1)
+
+
+def test_paf2maf_errors(emu):
+    """InvalidBase position (reverse order), CigarOpInvalid, insert_str panic"""
+    cigars = ["10=", "10=", "6M1I", "3=1D", "4=2N4="]
+    strands = [1, 1, 0, 0, 0]
+    t = [b"ACGTACGTAC", b"ACGTACGTAC", b"ACGT", b"ACGT", b"ACGTACGT"]
+    q = [b"ACGTRCGYAC", b"ACGTACGTAC", b"ACGTACG", b"AC", b"ACGTACGT"]
+    b = pc.batch_from_texts(emu, cigars, strands, t, q)
+    r = pc.check_paf2maf(emu, b)
+    d = r["diag"]
+    assert int(d["bad_base_pos"][0]) == 2          # 'Y' is hit first when scanning from the end
+    assert int(d["bad_base_pos"][1]) == int(engine.NONE)
+    assert int(d["panic_op_idx"][2]) == 1 and int(d["panic_op_idx"][3]) == 1
+    assert int(d["bad_op_idx"][4]) == 1
+
+
+def test_paf2maf_long_record_many_tiles(emu):
+    """one record over ~300 tiles (walk-back over > 256 tile summaries) next to short ones"""
+    b = synth.make_paf_batch(11, 5, 4, 1_500_000)
+    big = synth.make_paf_batch(12, 1, 300_000, 1_500_000, sigma=0.01)
+    # splice the big record in the middle
+    k = 2
+    ops = np.concatenate([b["ops"][:int(b["op_off"][k])], big["ops"], b["ops"][int(b["op_off"][k]):]])
+    lens = np.diff(b["op_off"]).astype(np.int64).tolist()
+    lens.insert(k, len(big["ops"]))
+    off = np.cumsum([0] + lens).astype(np.uint64)
+    def ins(a, v): return np.insert(a, k, v)
+    nb = dict(ops=ops, op_off=off, strand_neg=ins(b["strand_neg"], 1), t_pool=big["t_pool"],
+              q_pool=big["q_pool"],
+              t_src_off=ins(b["t_src_off"], big["t_src_off"][0]), t_src_len=ins(b["t_src_len"], big["t_src_len"][0]),
+              q_src_off=ins(b["q_src_off"], big["q_src_off"][0]), q_src_len=ins(b["q_src_len"], big["q_src_len"][0]))
+    pc.check_stat(emu, nb)
+    pc.check_paf2maf(emu, nb)
+
+
+def test_scan_and_scatter(emu):
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 5, 1024, 1025, 5000):
+        v = rng.integers(0, 1 << 40, n).astype(np.uint64)
+        got = emu.exclusive_scan_u64(n, emu.upload(v) if n else None).numpy()
+        exp = np.concatenate([[0], np.cumsum(v)]).astype(np.uint64)
+        assert (got == exp).all()
+    lens = rng.integers(0, 70, 50)
+    src_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    src = rng.integers(0, 256, int(src_off[-1])).astype(np.uint8)
+    dst_off = (np.arange(50) * 100).astype(np.uint64)
+    dst = emu.empty(5000, np.uint8).fill(0)
+    emu.scatter_bytes(50, emu.upload(src), emu.upload(src_off), dst, emu.upload(dst_off))
+    d = dst.numpy()
+    for i in range(50):
+        assert (d[i * 100:i * 100 + lens[i]] == src[int(src_off[i]):int(src_off[i + 1])]).all()
+        assert (d[i * 100 + lens[i]:(i + 1) * 100] == 0).all()
+
+
+def _cov_problem(seed, n, mean, nt):
+    rng = np.random.default_rng(seed)
+    b = pc.sprinkle_ops(rng, synth.make_paf_batch(seed, n, mean, 1000))
+    span = synth.class_sums(b["ops"] & 15, b["ops"] >> 4, b["op_off"])
+    tlen = rng.integers(200, 3000, nt)
+    tid = rng.integers(0, nt, n)
+    # some records run off the end of their target (positions >= length are ignored)
+    tstart = (rng.random(n) * tlen[tid] * 1.05).astype(np.uint64)
+    return b, tid, tstart, tlen
+
+
+@pytest.mark.parametrize("seed,n,mean,nt,align", [(1, 30, 40, 3, 4), (2, 200, 5, 7, 1), (3, 4, 3000, 2, 4)])
+def test_pafcov(emu, seed, n, mean, nt, align):
+    b, tid, tstart, tlen = _cov_problem(seed, n, mean, nt)
+    pc.check_pafcov(emu, b, tid, tstart, tlen, align=align)
+
+
+def test_pafcov_long_target(emu):
+    """a target longer than several scan chunks, with a record spanning tiles"""
+    b = synth.make_paf_batch(9, 3, 2500, 1000)
+    pc.check_pafcov(emu, b, [0, 0, 1], [10, 5000, 0], [40000, 9000])
+
+
+@pytest.mark.parametrize("base", [0, 1])
+@pytest.mark.parametrize("seed,n,mean", [(1, 20, 60), (2, 150, 4), (3, 3, 2600)])
+def test_pafpseudo(emu, base, seed, n, mean):
+    rng = np.random.default_rng(seed)
+    b = synth.make_paf_batch(seed, n, mean, 60000)
+    b = pc.sprinkle_ops(rng, b, codes=(3, 5, 6, 11))      # N H P other: ignored
+    # S consumes query like I: give those records a longer slice
+    ops = b["ops"].copy()
+    k = rng.integers(0, len(ops), max(1, len(ops) // 50))
+    ops[k] = (ops[k] & ~np.uint32(15)) | np.uint32(4)
+    b["ops"] = ops
+    code, length = ops & 15, (ops >> 4).astype(np.uint64)
+    v = np.where((code == 0) | (code == 7) | (code == 8) | (code == 1) | (code == 4), length, 0).astype(np.uint64)
+    c = np.concatenate([[0], np.cumsum(v)]).astype(np.uint64)
+    b["q_src_len"] = c[b["op_off"][1:].astype(np.int64)] - c[b["op_off"][:-1].astype(np.int64)]
+    b["q_src_off"] = (rng.random(n) * (len(b["q_pool"]) - b["q_src_len"].astype(np.float64))).astype(np.uint64)
+    skip = np.where(rng.random(n) < 0.4, rng.integers(0, 30, n), 0)
+    pc.check_pafpseudo(emu, b, base, skip=None)
+    # trimmed heads (pseudomaf.rs:190-192) — keep skip below the segment length
+    seg = synth.class_sums(code, ops >> 4, b["op_off"])
+    skip = np.minimum(skip, (seg["mx"] + seg["d"]).astype(np.int64))
+    pc.check_pafpseudo(emu, b, base, skip=skip)
+
+
+def test_pafpseudo_length_mismatch(emu):
+    """slice longer (tail kept) / shorter (panic) than the CIGAR consumes"""
+    cigars = ["5=2I3=", "5=2I3=", "4=3D4=", "10=", "8=2I", "8=1D", "3=2S1="]
+    strands = [0, 1, 1, 0, 0, 1, 0]
+    q = [b"ACGTACGTACGTTT", b"ACGTACGTACGTTT", b"ACGTAC", b"ACGTA", b"ACGTA", b"ACGTA", b"ACGTA"]
+    t = [b"A"] * 7
+    b = pc.batch_from_texts(emu, cigars, strands, t, q)
+    pc.check_pafpseudo(emu, b, 1)
+
+
+def test_maf_pair_stat(emu):
+    rng = np.random.default_rng(4)
+    pairs, strands = [], []
+    # rows produced by paf2maf itself ...
+    b = synth.make_paf_batch(21, 12, 120, 30000)
+    for i in range(12):
+        try:
+            pairs.append(pc.oracle_rows(b, i))
+            strands.append(int(b["strand_neg"][i]))
+        except Exception:
+            pass
+    # ... and free-form rows: '-'/'-' columns count as '=', case matters, unequal lengths zip
+    for L in (0, 1, 63, 64, 65, 200, 1000):
+        t = pc.rand_seq(rng, L, b"ACGTacgt--N")
+        q = pc.rand_seq(rng, L + int(rng.integers(0, 3)), b"ACGTacgt--N")
+        pairs.append((t, q))
+        strands.append(L & 1)
+    from helpers import GOLDEN, read_maf_blocks
+    import os
+    blk = read_maf_blocks(os.path.join(GOLDEN, "test.maf"))[0]
+    pairs.append((blk[0]["seq"], blk[1]["seq"]))
+    strands.append(0)
+    pc.check_maf_pair(emu, pairs, strands)
+
+
+def test_fast_expected_matches_oracle():
+    """the numpy expectation used for long records on the GPU agrees with the C oracle"""
+    b = synth.make_paf_batch(31, 25, 150, 40000)
+    for i in range(25):
+        t = b["t_pool"][int(b["t_src_off"][i]):int(b["t_src_off"][i] + b["t_src_len"][i])].tobytes()
+        q = b["q_pool"][int(b["q_src_off"][i]):int(b["q_src_off"][i] + b["q_src_len"][i])].tobytes()
+        assert pc.fast_expected_rows(pc.rec_ops(b, i), t, q, b["strand_neg"][i]) == pc.oracle_rows(b, i)

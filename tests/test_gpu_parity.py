@@ -1,0 +1,229 @@
+"""Parity of the product path — libwgahip.so on a real MI355X, called through the C-ABI —
+against the CPU oracle.  `pytest -m gpu`.  Bit-exact everywhere."""
+import os
+
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from wgatools_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- the emulator cases again, on hardware ----------------------------------------------------
+@pytest.mark.parametrize("seed,n,mean,use_m", [(1, 12, 700, False), (2, 60, 40, False),
+                                               (3, 400, 3, True), (4, 2, 6000, False),
+                                               (5, 3000, 200, False)])
+def test_stat_random(gpu, seed, n, mean, use_m):
+    pc.check_stat(gpu, synth.make_paf_batch(seed, n, mean, 60000, use_m=use_m))
+
+
+@pytest.mark.parametrize("seed,n,mean,pool,pre,use_m", [
+    (1, 12, 700, 50000, False, False), (2, 40, 60, 20000, True, False),
+    (3, 300, 3, 5000, True, True), (4, 3, 5000, 200000, False, True),
+    (6, 500, 400, 2_000_000, True, False)])
+def test_paf2maf_random(gpu, seed, n, mean, pool, pre, use_m):
+    b = synth.make_paf_batch(seed, n, mean, pool, use_m=use_m)
+    rng = np.random.default_rng(seed)
+    p = (rng.integers(0, 40, n), rng.integers(0, 40, n), rng.integers(0, 5, n)) if pre else None
+    pc.check_paf2maf(gpu, b, pre=p)
+
+
+def test_paf2maf_edge_cases(gpu):
+    b = pc.edge_case_batch(gpu)
+    n = len(b["strand_neg"])
+    rng = np.random.default_rng(5)
+    pc.check_paf2maf(gpu, b)
+    pc.check_paf2maf(gpu, b, pre=(rng.integers(0, 33, n), rng.integers(0, 33, n), rng.integers(0, 3, n)))
+    pc.check_paf2maf(gpu, b, force_slow=1)
+
+
+def test_paf2maf_errors(gpu):
+    cigars = ["10=", "10=", "6M1I", "3=1D", "4=2N4="]
+    strands = [1, 1, 0, 0, 0]
+    t = [b"ACGTACGTAC", b"ACGTACGTAC", b"ACGT", b"ACGT", b"ACGTACGT"]
+    q = [b"ACGTRCGYAC", b"ACGTACGTAC", b"ACGTACG", b"AC", b"ACGTACGT"]
+    r = pc.check_paf2maf(gpu, pc.batch_from_texts(gpu, cigars, strands, t, q))
+    d = r["diag"]
+    assert int(d["bad_base_pos"][0]) == 2 and int(d["bad_base_pos"][1]) == int(engine.NONE)
+    assert int(d["panic_op_idx"][2]) == 1 and int(d["panic_op_idx"][3]) == 1
+    assert int(d["bad_op_idx"][4]) == 1
+
+
+def test_paf2maf_force_slow(gpu):
+    pc.check_paf2maf(gpu, synth.make_paf_batch(5, 10, 300, 20000), force_slow=1)
+
+
+# ---- BASELINE configs[1] shape at a size the oracle finishes in seconds -------------------------
+def test_paf2maf_config2_reduced(gpu):
+    """2 000 records x mean 5 kop (config 2 is 100 000): stat of every record + rows of a sample"""
+    b = synth.make_paf_batch(0x5747415F + 2, 2000, 5000, 50_000_000)
+    rng = np.random.default_rng(1)
+    sample = sorted(rng.choice(2000, 60, replace=False).tolist())
+    pc.check_stat(gpu, b, sample=range(0, 2000, 7))
+    pc.check_paf2maf(gpu, b, sample=sample)
+
+
+def test_paf2maf_long_cigar_stress(gpu):
+    """>= 200 kop records (config 5 stress): linear-time numpy expectation"""
+    b = synth.make_paf_batch(77, 6, 300_000, 40_000_000, sigma=0.05)
+    r = pc.run_paf2maf(gpu, b)
+    assert (r["diag"]["panic_op_idx"] == engine.NONE).all() and (r["diag"]["bad_base_pos"] == engine.NONE).all()
+    for i in range(6):
+        t = b["t_pool"][int(b["t_src_off"][i]):int(b["t_src_off"][i] + b["t_src_len"][i])].tobytes()
+        q = b["q_pool"][int(b["q_src_off"][i]):int(b["q_src_off"][i] + b["q_src_len"][i])].tobytes()
+        et, eq = pc.fast_expected_rows(pc.rec_ops(b, i), t, q, b["strand_neg"][i])
+        to, qo = int(r["t_row_off"][i]), int(r["q_row_off"][i])
+        assert r["out"][to:to + len(et)].tobytes() == et, i
+        assert r["out"][qo:qo + len(eq)].tobytes() == eq, i
+
+
+# ---- full BASELINE configs[1] size: size-independent properties ---------------------------------
+def test_paf2maf_config2_full_size_properties(gpu):
+    """100 000 records x mean 5 kop, 2 x 50 Mb pools (15 GB of rows).  Checked on device:
+       * a checksum of checksums: per-letter byte counts of all rows == per-letter counts of all
+         source slices (complemented for '-' strand) + exactly sum(I)+sum(D) gap bytes;
+       * stat totals == class sums of the generator;
+       * 48 records spread over the batch are bit-identical to the oracle."""
+    import torch
+    from wgatools_amd import pipeline
+    dev = torch.device("cuda", 0)
+    tb = synth.make_paf_batch_torch(0x5747415F + 2, 100_000, 5000, 50_000_000, dev)
+    job = pipeline.Paf2MafStatJob(gpu, tb)
+    job.bind_stream()
+    job.out.fill_(0)
+    job.step()
+    torch.cuda.synchronize()
+    assert bool((job.diag == -1).all())
+    assert int(job.rec_off[-1]) == job.out_bytes
+    # stat totals
+    c = job.counts
+    neg = tb["strand_neg"].bool()
+    assert bool((c[:, 0] + c[:, 1] == tb["mx"]).all())
+    assert bool((c[:, 3] + c[:, 7] == tb["i"]).all()) and bool((c[:, 5] + c[:, 9] == tb["d"]).all())
+    assert bool((c[:, 10] == neg.long()).all()) and bool((c[~neg][:, 6:10] == 0).all())
+    # letter histogram of the output, in 1 GB chunks
+    hist = torch.zeros(256, dtype=torch.int64, device=dev)
+    for a in range(0, job.out_bytes, 1 << 30):
+        hist += torch.bincount(job.out[a:min(a + (1 << 30), job.out_bytes)].int(), minlength=256)
+    # expected: prefix letter counts of the pools -> per-record slice counts
+    exp = torch.zeros(256, dtype=torch.int64, device=dev)
+    comp = {ord(a): ord(b) for a, b in zip("ACGTNacgtn", "TGCANtgcan")}
+    def add(pool, off, ln, sel, complement):
+        for ch in b"ACGTNacgtn":
+            pre = torch.zeros(pool.numel() + 1, dtype=torch.int64, device=dev)
+            torch.cumsum((pool == ch).long(), 0, out=pre[1:])
+            cnt = (pre[off + ln] - pre[off])[sel].sum()
+            exp[comp[ch] if complement else ch] += cnt
+    allr = torch.ones_like(neg)
+    add(tb["t_pool"], tb["t_src_off"], tb["t_src_len"], allr, False)
+    add(tb["q_pool"], tb["q_src_off"], tb["q_src_len"], ~neg, False)
+    add(tb["q_pool"], tb["q_src_off"], tb["q_src_len"], neg, True)
+    exp[ord("-")] = int(tb["i"].sum() + tb["d"].sum())
+    assert bool((hist == exp).all()), (hist.nonzero().flatten().tolist(),
+                                        (hist - exp)[hist != exp].tolist())
+    # sample vs oracle
+    for i in torch.linspace(0, tb["n"] - 1, 48).long().tolist():
+        r = synth.torch_batch_record_to_numpy(tb, i)
+        assert job.record_rows(i) == pc.oracle_rows(r, 0), i
+
+
+def test_paf2maf_wide_tile_auto_slow_path(gpu):
+    """one tile wider than 2^31 columns (9 D ops of 2^28-1) takes the u64 fallback by itself"""
+    import torch
+    dev = torch.device("cuda", 0)
+    big = (1 << 28) - 1
+    ops = np.array([(5 << 4) | 7] + [(big << 4) | 2] * 9 + [(7 << 4) | 7], dtype=np.uint32)
+    t_len, q_len = 12 + 9 * big, 12
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    t_pool = lut[torch.randint(0, 4, (t_len,), device=dev, generator=g)]
+    q_pool = lut[torch.randint(0, 4, (q_len,), device=dev, generator=g)]
+    batch = gpu.make_batch(ops, np.array([0, len(ops)], dtype=np.uint64), np.array([0], dtype=np.uint8))
+    counts, diag, tws = gpu.cigar_stat(batch)
+    z = gpu.upload(np.zeros(1, dtype=np.uint64))
+    tl, ql = gpu.upload(np.array([t_len], dtype=np.uint64)), gpu.upload(np.array([q_len], dtype=np.uint64))
+    tro, qro, reco = gpu.paf2maf_layout(1, counts, tl, ql)
+    total = int(reco.numpy()[-1])
+    assert total == 2 * t_len
+    out = torch.full((total + 64,), 0x23, dtype=torch.uint8, device=dev)
+    gpu.paf2maf_expand(batch, counts, tws, t_pool, t_len, z, tl, q_pool, q_len, z, ql, out, tro, qro, diag)
+    gpu.sync()
+    assert bool((out[:t_len] == t_pool).all())            # D consumes the target: row == slice
+    qrow = out[t_len:2 * t_len]
+    assert bool((qrow[:5] == q_pool[:5]).all()) and bool((qrow[-7:] == q_pool[5:]).all())
+    assert bool((qrow[5:-7] == 45).all()) and bool((out[total:] == 0x23).all())
+    c = counts.numpy()[0]
+    assert int(c["del_bp"]) == 9 * big and int(c["del_ev"]) == 9 and int(c["match"]) == 12
+
+
+# ---- the other consumers ---------------------------------------------------------------------------
+def _cov_problem(seed, n, mean, nt, tmax):
+    rng = np.random.default_rng(seed)
+    b = pc.sprinkle_ops(rng, synth.make_paf_batch(seed, n, mean, 1000))
+    tlen = rng.integers(tmax // 10, tmax, nt)
+    tid = rng.integers(0, nt, n)
+    tstart = (rng.random(n) * tlen[tid] * 1.02).astype(np.uint64)
+    return b, tid, tstart, tlen
+
+
+@pytest.mark.parametrize("seed,n,mean,nt,tmax,align", [(1, 30, 40, 3, 3000, 4), (2, 200, 5, 7, 3000, 1),
+                                                        (3, 4, 3000, 2, 90000, 4), (4, 3000, 300, 16, 400000, 4)])
+def test_pafcov(gpu, seed, n, mean, nt, tmax, align):
+    b, tid, tstart, tlen = _cov_problem(seed, n, mean, nt, tmax)
+    pc.check_pafcov(gpu, b, tid, tstart, tlen, align=align)
+
+
+@pytest.mark.parametrize("base", [0, 1])
+@pytest.mark.parametrize("seed,n,mean", [(1, 20, 60), (2, 150, 4), (3, 3, 2600), (4, 400, 500)])
+def test_pafpseudo(gpu, base, seed, n, mean):
+    rng = np.random.default_rng(seed)
+    b = pc.sprinkle_ops(rng, synth.make_paf_batch(seed, n, mean, 600000), codes=(3, 5, 6, 11))
+    ops = b["ops"].copy()
+    k = rng.integers(0, len(ops), max(1, len(ops) // 50))
+    ops[k] = (ops[k] & ~np.uint32(15)) | np.uint32(4)
+    b["ops"] = ops
+    code, length = ops & 15, (ops >> 4).astype(np.uint64)
+    v = np.where((code == 0) | (code == 7) | (code == 8) | (code == 1) | (code == 4), length, 0).astype(np.uint64)
+    c = np.concatenate([[0], np.cumsum(v)]).astype(np.uint64)
+    b["q_src_len"] = c[b["op_off"][1:].astype(np.int64)] - c[b["op_off"][:-1].astype(np.int64)]
+    b["q_src_off"] = (rng.random(n) * (len(b["q_pool"]) - b["q_src_len"].astype(np.float64))).astype(np.uint64)
+    seg = synth.class_sums(code, ops >> 4, b["op_off"])
+    skip = np.where(rng.random(n) < 0.4, rng.integers(0, 30, n), 0)
+    skip = np.minimum(skip, (seg["mx"] + seg["d"]).astype(np.int64))
+    pc.check_pafpseudo(gpu, b, base, skip=None)
+    pc.check_pafpseudo(gpu, b, base, skip=skip)
+
+
+def test_pafpseudo_length_mismatch(gpu):
+    cigars = ["5=2I3=", "5=2I3=", "4=3D4=", "10=", "8=2I", "8=1D", "3=2S1="]
+    strands = [0, 1, 1, 0, 0, 1, 0]
+    q = [b"ACGTACGTACGTTT", b"ACGTACGTACGTTT", b"ACGTAC", b"ACGTA", b"ACGTA", b"ACGTA", b"ACGTA"]
+    pc.check_pafpseudo(gpu, pc.batch_from_texts(gpu, cigars, strands, [b"A"] * 7, q), 1)
+
+
+def test_maf_pair_stat(gpu):
+    rng = np.random.default_rng(4)
+    pairs, strands = [], []
+    b = synth.make_paf_batch(21, 40, 400, 300000)
+    for i in range(40):
+        pairs.append(pc.oracle_rows(b, i))
+        strands.append(int(b["strand_neg"][i]))
+    for L in (0, 1, 63, 64, 65, 200, 1000, 100000):
+        pairs.append((pc.rand_seq(rng, L, b"ACGTacgt--N"), pc.rand_seq(rng, L + int(rng.integers(0, 3)), b"ACGTacgt--N")))
+        strands.append(L & 1)
+    from helpers import GOLDEN, read_maf_blocks
+    blk = read_maf_blocks(os.path.join(GOLDEN, "test.maf"))[0]
+    pairs.append((blk[0]["seq"], blk[1]["seq"]))
+    strands.append(0)
+    pc.check_maf_pair(gpu, pairs, strands)
+
+
+def test_scan(gpu):
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 5, 1024, 1025, 5000, 3_000_000):
+        v = rng.integers(0, 1 << 40, n).astype(np.uint64)
+        got = gpu.exclusive_scan_u64(n, gpu.upload(v) if n else None).numpy()
+        assert (got == np.concatenate([[0], np.cumsum(v)]).astype(np.uint64)).all()

@@ -36,6 +36,7 @@ PROTOTYPES = {
     "wga_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "wga_ctx_destroy": (None, [vp]),
     "wga_ctx_set_stream": (C.c_int, [vp, vp]),
+    "wga_ctx_reset_stream": (C.c_int, [vp]),
     "wga_ctx_set_param": (C.c_int, [vp, C.c_char_p, C.c_int64]),
     "wga_sync": (C.c_int, [vp]),
     "wga_malloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),

@@ -116,7 +116,13 @@ void wga_ctx_destroy(wga_ctx* c) {
 
 int wga_ctx_set_stream(wga_ctx* c, void* hip_stream) {
   if (!c) return fail(WGA_E_INVALID_ARG, "null context", nullptr);
-  c->stream = hip_stream ? (wga_stream_t)hip_stream : c->own_stream;
+  c->stream = (wga_stream_t)hip_stream;
+  return WGA_OK;
+}
+
+int wga_ctx_reset_stream(wga_ctx* c) {
+  if (!c) return fail(WGA_E_INVALID_ARG, "null context", nullptr);
+  c->stream = c->own_stream;
   return WGA_OK;
 }
 
@@ -297,7 +303,7 @@ int wga_scatter_bytes(wga_ctx* c, uint32_t n, const uint8_t* d_src, const uint64
 int wga_maf_pair_stat(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint64_t* d_t_off,
                       const uint64_t* d_q_off, const uint64_t* d_cols,
                       const uint8_t* d_strand_neg, wga_cigar_counts* d_counts,
-                      uint64_t* d_run_cnt, uint32_t* d_runs, const uint64_t* d_run_off) {
+                      uint64_t* d_run_cnt, uint64_t* d_runs, const uint64_t* d_run_off) {
   int rc = ctx_bind(c);
   if (rc) return rc;
   if (n == 0) return WGA_OK;
@@ -306,7 +312,7 @@ int wga_maf_pair_stat(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint6
   if (d_runs && !d_run_off) return fail(WGA_E_INVALID_ARG, "d_run_off null", nullptr);
   WGA_LAUNCH(k_maf_pair_stat, (n + 3u) / 4u, WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off,
              (const u64*)d_q_off, (const u64*)d_cols, d_strand_neg, d_counts, (u64*)d_run_cnt,
-             d_runs, (const u64*)d_run_off);
+             (u64*)d_runs, (const u64*)d_run_off);
   LAUNCH_CHECK();
   return WGA_OK;
 }
@@ -322,15 +328,15 @@ int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* 
     return fail(WGA_E_INVALID_ARG, "null array", nullptr);
   u64 nt = n_tiles(b->n_ops);
   void* ws;
-  if ((rc = ctx_scratch(c, (size_t)nt * 2 * sizeof(u64), &ws))) return rc;
-  u64* tile_mv = (u64*)ws;
+  if ((rc = ctx_scratch(c, (size_t)nt * sizeof(wga_tile_sum), &ws))) return rc;
+  wga_tile_sum* tiles = (wga_tile_sum*)ws;
   u32 grid = (u32)((nt + 3) / 4);
-  WGA_LAUNCH(k_pafcov_tiles, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off, b->n,
-             (u64)b->n_ops, tile_mv);
+  WGA_LAUNCH(k_class_tiles, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off, b->n,
+             (u64)b->n_ops, tiles, (wga_class_sums*)nullptr);
   LAUNCH_CHECK();
   WGA_LAUNCH(k_pafcov_accumulate, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off,
-             b->n, (u64)b->n_ops, (const u64*)tile_mv, d_target_id, (const u64*)d_t_start,
-             (const u64*)d_cov_off, (const u64*)d_cov_len, d_cov);
+             b->n, (u64)b->n_ops, (const wga_tile_sum*)tiles, d_target_id, (const u64*)d_t_start,
+             (const u64*)d_cov_off, (const u64*)d_cov_len, (int*)d_cov);
   LAUNCH_CHECK();
   return WGA_OK;
 }
@@ -369,12 +375,27 @@ int wga_pafcov_finalize(wga_ctx* c, uint32_t n_targets, const uint64_t* d_cov_of
   RT_CHECK(rt_sync(c->stream)); /* h_chunk_off is a stack-lifetime host buffer */
   dim3 grid((u32)max_chunks, n_targets, 1);
   WGA_LAUNCH(k_cov_chunk_sums, grid, WGA_BLOCK, c->stream, (const u64*)d_cov_off,
-             (const u64*)d_cov_len, (const int32_t*)d_cov, (const u64*)d_chunk_off, d_chunk_sum);
+             (const u64*)d_cov_len, (const int*)d_cov, (const u64*)d_chunk_off, d_chunk_sum);
   LAUNCH_CHECK();
   WGA_LAUNCH(k_cov_chunk_scan, n_targets, WGA_BLOCK, c->stream, (const u64*)d_chunk_off, d_chunk_sum);
   LAUNCH_CHECK();
   WGA_LAUNCH(k_cov_chunk_apply, grid, WGA_BLOCK, c->stream, (const u64*)d_cov_off,
-             (const u64*)d_cov_len, d_cov, (const u64*)d_chunk_off, (const i64*)d_chunk_sum);
+             (const u64*)d_cov_len, (int*)d_cov, (const u64*)d_chunk_off, (const i64*)d_chunk_sum);
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
+int wga_cigar_class_sums(wga_ctx* c, const wga_cigar_batch* b, wga_class_sums* d_sums) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if ((rc = check_batch(b))) return rc;
+  if (b->n == 0) return WGA_OK;
+  if (!d_sums) return fail(WGA_E_INVALID_ARG, "d_sums null", nullptr);
+  RT_CHECK(rt_memset(d_sums, 0, (size_t)b->n * sizeof(wga_class_sums), c->stream));
+  u64 nt = n_tiles(b->n_ops);
+  if (nt == 0) return WGA_OK;
+  WGA_LAUNCH(k_class_tiles, (u32)((nt + 3) / 4), WGA_BLOCK, c->stream, b->d_ops,
+             (const u64*)b->d_op_off, b->n, (u64)b->n_ops, (wga_tile_sum*)nullptr, d_sums);
   LAUNCH_CHECK();
   return WGA_OK;
 }
@@ -394,10 +415,13 @@ int wga_pafpseudo_fill(wga_ctx* c, const wga_cigar_batch* b, int base_mode, cons
   u64 nt = n_tiles(b->n_ops);
   if (nt == 0) return WGA_OK;
   void* ws;
-  if ((rc = ctx_scratch(c, (size_t)nt * sizeof(wga_tile_sum), &ws))) return rc;
+  size_t tile_bytes = ((size_t)nt * sizeof(wga_tile_sum) + 63) & ~(size_t)63;
+  if ((rc = ctx_scratch(c, tile_bytes + (size_t)b->n * sizeof(wga_class_sums), &ws))) return rc;
   wga_tile_sum* tiles = (wga_tile_sum*)ws;
+  wga_class_sums* rec_sums = (wga_class_sums*)((char*)ws + tile_bytes);
+  RT_CHECK(rt_memset(rec_sums, 0, (size_t)b->n * sizeof(wga_class_sums), c->stream));
   WGA_LAUNCH(k_class_tiles, (u32)((nt + 3) / 4), WGA_BLOCK, c->stream, b->d_ops,
-             (const u64*)b->d_op_off, b->n, (u64)b->n_ops, tiles);
+             (const u64*)b->d_op_off, b->n, (u64)b->n_ops, tiles, rec_sums);
   LAUNCH_CHECK();
   PseudoArgs a;
   a.ops = b->d_ops;
@@ -406,6 +430,7 @@ int wga_pafpseudo_fill(wga_ctx* c, const wga_cigar_batch* b, int base_mode, cons
   a.n = b->n;
   a.n_ops = b->n_ops;
   a.tiles = tiles;
+  a.rec_sums = rec_sums;
   a.base_mode = base_mode;
   a.q_fa = d_q_fa;
   a.q_fa_bytes = q_fa_bytes;

@@ -443,14 +443,18 @@ __device__ __forceinline__ void merge16(u32 o[4], const u32 W[4], int pa, int pb
 
 /*
  * Emit N (<= 2^31) bytes of one gapped row to dst.  Output byte k is tile-relative column
- * c0 + k.  The row's gaps inside this range are entries [ga, gb) of the compacted gap list
- * (G_col = tile-relative start column, G_cum = exclusive prefix of gap bases; G_cum[gb] is
- * readable).  A non-gap column c reads slice index  sbase + (c - c0) - (gaps before c - gcum_a).
+ * c0 + k.  The row's events inside this range are entries [ga, gb) of a compacted list
+ * (G_col = tile-relative start column, G_cum = exclusive prefix of gap bases — an entry's gap
+ * length is G_cum[i+1]-G_cum[i], entry gb is readable — and G_adj = exclusive prefix of the
+ * source adjustment: gap bases minus skipped source bases, as wrapping u32; for paf2maf rows
+ * G_adj == G_cum).  A non-gap column c reads slice index
+ *     sbase + (c - c_org) - (adj before c - gcum_a)          (gcum_a = adj at c_org)
  * Threads tid, tid+nthreads, ... own 16-byte *address-aligned* chunks of dst.
  */
-__device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const u32* G_col, const u32* G_cum,
-                                         int ga, int gb, u32 gcum_a, u64 sbase, const RowSrc& src,
-                                         u32 tid, u32 nthreads, u64* bad_base_pos) {
+__device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, u32 c_org, const u32* G_col,
+                                         const u32* G_cum, const u32* G_adj, int ga, int gb,
+                                         u32 gcum_a, u64 sbase, const RowSrc& src, u32 tid,
+                                         u32 nthreads, u64* bad_base_pos) {
   if (N == 0) return;
   const u64 A = (u64)dst, E = A + N;
   const u64 first = A >> 4, last = (E - 1) >> 4;
@@ -474,13 +478,13 @@ __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const u32* G_co
     bool in_gap = false;
     u32 gap_end = 0, cum = gcum_a;
     if (i >= ga) {
-      u32 gs = G_col[i], gcn = G_cum[i + 1];
-      u32 gl = gcn - G_cum[i];
+      u32 gs = G_col[i];
+      u32 gl = G_cum[i + 1] - G_cum[i];
       if (c - gs < gl) {
         in_gap = true;
         gap_end = gs + gl;
       }
-      cum = gcn;
+      cum = G_adj[i + 1];
     }
     u32 o[4] = {0u, 0u, 0u, 0u};
     while (c < c_end) {
@@ -495,7 +499,7 @@ __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const u32* G_co
         u32 pe = next_gs < c_end ? next_gs : c_end;
         if (pe > c) {
           const int pa = (int)(c - cz), pb = (int)(pe - cz);
-          const i64 S = (i64)sbase + (i64)(int)(cz - c0) - (i64)(cum - gcum_a);
+          const i64 S = (i64)sbase + (i64)(int)(cz - c_org) - (i64)(int)(cum - gcum_a);
           u32 W[4], inv[4];
           load_window(src, S, pa, pb, W, inv);
           if (src.rc) { /* InvalidBase: first offender in reversed order = smallest q' index */
@@ -513,13 +517,13 @@ __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const u32* G_co
         }
         if (c < c_end) { /* c == start of gap i+1 */
           i++;
-          u32 gs = G_col[i], gcn = G_cum[i + 1];
-          u32 gl = gcn - G_cum[i];
+          u32 gs = G_col[i];
+          u32 gl = G_cum[i + 1] - G_cum[i];
           if (gl) {
             in_gap = true;
             gap_end = gs + gl;
           }
-          cum = gcn;
+          cum = G_adj[i + 1];
         }
       }
     }
@@ -544,8 +548,8 @@ __device__ __forceinline__ void emit_tail(u8* dst, u64 n, u64 sbase, const RowSr
   while (done < n) {
     u64 m = n - done;
     if (m > (1ull << 30)) m = 1ull << 30;
-    emit_row(dst + done, (u32)m, 0u, (const u32*)0, (const u32*)0, 0, 0, 0u, sbase + done, src,
-             tid, nthreads, bad_base_pos);
+    emit_row(dst + done, (u32)m, 0u, 0u, (const u32*)0, (const u32*)0, (const u32*)0, 0, 0, 0u,
+             sbase + done, src, tid, nthreads, bad_base_pos);
     done += m;
   }
 }
@@ -774,12 +778,12 @@ __global__ __launch_bounds__(256) void k_paf2maf_expand(ExpandArgs a) {
       /* rows end where the slice ends (a CIGAR that consumes more than was fetched) */
       u64 x1t = cb + seg_cols < t_row_len ? cb + seg_cols : t_row_len;
       if (x1t > cb)
-        emit_row(t_dst + cb, (u32)(x1t - cb), col_a, s_tg_col, s_tg_cum, ia, ib, icum_a, tb, ts,
-                 tid, WGA_BLOCK, bad_base);
+        emit_row(t_dst + cb, (u32)(x1t - cb), col_a, col_a, s_tg_col, s_tg_cum, s_tg_cum, ia, ib,
+                 icum_a, tb, ts, tid, WGA_BLOCK, bad_base);
       u64 x1q = cb + seg_cols < q_row_len ? cb + seg_cols : q_row_len;
       if (x1q > cb)
-        emit_row(q_dst + cb, (u32)(x1q - cb), col_a, s_qg_col, s_qg_cum, ja, jb, dcum_a, qb, qs,
-                 tid, WGA_BLOCK, bad_base);
+        emit_row(q_dst + cb, (u32)(x1q - cb), col_a, col_a, s_qg_col, s_qg_cum, s_qg_cum, ja, jb,
+                 dcum_a, qb, qs, tid, WGA_BLOCK, bad_base);
     } else {
       /* u64 fallback for tiles wider than 2^31 columns: ops are walked serially (every thread
        * redundantly), each op's columns are written block-strided, one byte per store */

@@ -1,0 +1,669 @@
+/*
+ * wga_kernels2.h — the consumers beside paf2maf/stat:
+ *   k_class_tiles          tile summaries (+ optional per-record class sums) without the stat
+ *                          counters — shared first pass of pafcov and pafpseudo
+ *   K5 k_pafcov_accumulate difference-array coverage marks (update_cov_vec, cigar.rs:710-741)
+ *      k_cov_chunk_*       per-target inclusive scan that turns marks into per-base counts
+ *   K6 k_pafpseudo_fill    target-coordinate pseudo-MAF segments (cigar.rs:744-804)
+ *   K3 k_maf_pair_stat     MAF column-pair walk (cigar.rs:298-308,344-432)
+ * Same tile decomposition and helpers as wga_kernels.h.
+ */
+#ifndef WGA_KERNELS2_H
+#define WGA_KERNELS2_H
+
+#include "wga_kernels.h"
+
+#define WGA_COV_CHUNK 4096u
+
+/* ============================================================================================ */
+/* class sums per tile (and per record)                                                         */
+/* ============================================================================================ */
+__global__ __launch_bounds__(256) void k_class_tiles(const u32* __restrict__ ops,
+                                                     const u64* __restrict__ op_off, u32 n,
+                                                     u64 n_ops, wga_tile_sum* tiles,
+                                                     wga_class_sums* rec_sums) {
+  const u32 lane = threadIdx.x & 63u;
+  const u32 wave = threadIdx.x >> 6;
+  const u64 g = (u64)blockIdx.x * 4 + wave;
+  const u64 tile_start = g * WGA_TILE;
+  if (tile_start >= n_ops) return;
+  const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
+  const u32 nt = (u32)(tile_end - tile_start);
+  u32 w[16];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    u32 base = ((u32)j * 64u + lane) * 4u;
+    if (base + 3 < nt) {
+      u32x4_a16 v = *(const u32x4_a16*)(ops + tile_start + base);
+      w[4 * j + 0] = v[0];
+      w[4 * j + 1] = v[1];
+      w[4 * j + 2] = v[2];
+      w[4 * j + 3] = v[3];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; e++) w[4 * j + e] = (base + e < nt) ? ops[tile_start + base + e] : 0u;
+    }
+  }
+  u32 r = wga_find_rec(op_off, n, tile_start);
+  u64 cur = tile_start;
+  u64 tot[5] = {0, 0, 0, 0, 0}, tail[5] = {0, 0, 0, 0, 0};
+  while (cur < tile_end) {
+    u64 re = op_off[r + 1];
+    while (re <= cur) {
+      r++;
+      re = op_off[r + 1];
+    }
+    const u64 rs = op_off[r];
+    const u64 seg_end = re < tile_end ? re : tile_end;
+    const u32 a = (u32)(cur - tile_start), b = (u32)(seg_end - tile_start);
+    u32 s[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        u32 idx = ((u32)j * 64u + lane) * 4u + (u32)e;
+        u32 op = w[4 * j + e];
+        u32 cls = op_class(op & 15u);
+        u32 l = (idx >= a && idx < b) ? (op >> 4) : 0u;
+        s[0] += cls == CLS_MX ? l : 0u;
+        s[1] += cls == CLS_I ? l : 0u;
+        s[2] += cls == CLS_D ? l : 0u;
+        s[3] += cls == CLS_S ? l : 0u;
+        s[4] += cls == CLS_O ? l : 0u;
+      }
+    }
+    u64 S[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) S[c] = wave_sum_u64((u64)s[c]);
+    if (rec_sums && lane == 0) {
+      u64* f = (u64*)(rec_sums + r);
+      if (rs >= tile_start && re <= tile_end) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) f[c] = S[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+          if (S[c]) atomicAdd(f + c, S[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+      tot[c] += S[c];
+      tail[c] = S[c];
+    }
+    cur = seg_end;
+    r++;
+  }
+  if (tiles && lane == 0) {
+    wga_tile_sum ts;
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+      ts.tot[c] = tot[c];
+      ts.tail[c] = tail[c];
+    }
+    tiles[g] = ts;
+  }
+}
+
+/* ============================================================================================ */
+/* K5: pafcov                                                                                   */
+/* ============================================================================================ */
+/* One wave per tile, 16 *consecutive* ops per lane so that a lane can walk its ops serially
+ * after one wave-level exclusive scan of the position advance.  Only M and = are counted; I and
+ * S do not move; every other op (D X N H P ...) moves without counting (cigar.rs:720-733).
+ * A covered span [pos, pos+len) becomes +1 at pos and -1 at pos+len (both only below the
+ * target length): two atomics per M/= op instead of len increments. */
+__global__ __launch_bounds__(256) void k_pafcov_accumulate(
+    const u32* __restrict__ ops, const u64* __restrict__ op_off, u32 n, u64 n_ops,
+    const wga_tile_sum* __restrict__ tiles, const u32* __restrict__ target_id,
+    const u64* __restrict__ t_start, const u64* __restrict__ cov_off,
+    const u64* __restrict__ cov_len, int* cov) {
+  const u32 lane = threadIdx.x & 63u;
+  const u32 wave = threadIdx.x >> 6;
+  const u64 g = (u64)blockIdx.x * 4 + wave;
+  const u64 tile_start = g * WGA_TILE;
+  if (tile_start >= n_ops) return;
+  const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
+  const u32 nt = (u32)(tile_end - tile_start);
+  u32 w[16];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    u32 base = lane * 16u + (u32)j * 4u;
+    if (base + 3 < nt) {
+      u32x4_a16 v = *(const u32x4_a16*)(ops + tile_start + base);
+      w[4 * j + 0] = v[0];
+      w[4 * j + 1] = v[1];
+      w[4 * j + 2] = v[2];
+      w[4 * j + 3] = v[3];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; e++) w[4 * j + e] = (base + e < nt) ? ops[tile_start + base + e] : 0u;
+    }
+  }
+  u32 r = wga_find_rec(op_off, n, tile_start);
+  u64 cur = tile_start;
+  while (cur < tile_end) {
+    u64 re = op_off[r + 1];
+    while (re <= cur) {
+      r++;
+      re = op_off[r + 1];
+    }
+    const u64 rs = op_off[r];
+    const u64 seg_end = re < tile_end ? re : tile_end;
+    const u32 a = (u32)(cur - tile_start), b = (u32)(seg_end - tile_start);
+    u64 mv = 0;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      u32 idx = lane * 16u + (u32)e;
+      u32 cls = op_class(w[e] & 15u);
+      bool moves = cls == CLS_MX || cls == CLS_D || cls == CLS_O;
+      mv += (idx >= a && idx < b && moves) ? (u64)(w[e] >> 4) : 0ull;
+    }
+    u64 inc = mv;
+    for (u32 d = 1; d < 64; d <<= 1) {
+      u64 t = __shfl_up(inc, d);
+      if (lane >= d) inc += t;
+    }
+    u64 base = 0;
+    if (rs < tile_start) { /* wave-uniform */
+      const u64 g0 = rs / WGA_TILE;
+      u64 p = 0;
+      for (u64 k = g0 + lane; k < g; k += 64) {
+        const u64* v = (k == g0) ? tiles[k].tail : tiles[k].tot;
+        p += v[CLS_MX] + v[CLS_D] + v[CLS_O];
+      }
+      base = wave_sum_u64(p);
+    }
+    const u32 tg = target_id[r];
+    const u64 coff = cov_off[tg], clen = cov_len[tg];
+    u64 pos = t_start[r] + base + (inc - mv);
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      u32 idx = lane * 16u + (u32)e;
+      if (idx >= a && idx < b) {
+        u32 code = w[e] & 15u;
+        u64 len = w[e] >> 4;
+        u32 cls = op_class(code);
+        if (code == WGA_OP_M || code == WGA_OP_EQ) {
+          if (pos < clen) {
+            atomicAdd(cov + coff + pos, 1);
+            if (pos + len < clen) atomicAdd(cov + coff + pos + len, -1);
+          }
+          pos += len;
+        } else if (cls == CLS_I || cls == CLS_S) {
+        } else {
+          pos += len;
+        }
+      }
+    }
+    cur = seg_end;
+    r++;
+  }
+}
+
+__device__ __forceinline__ u64 block_sum_u64(u64 v, u64* s_w /*[4]*/) {
+  v = wave_sum_u64(v);
+  __syncthreads();
+  if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+/* marks -> counts, per target: (1) chunk sums, (2) one block per target scans its chunk sums,
+ * (3) chunk-local inclusive scans with the carried prefix.  grid = (max chunks, targets). */
+__global__ __launch_bounds__(256) void k_cov_chunk_sums(const u64* cov_off, const u64* cov_len,
+                                                        const int* cov, const u64* chunk_off,
+                                                        i64* chunk_sum) {
+  __shared__ u64 s_w[4];
+  const u32 t = blockIdx.y;
+  const u64 c = blockIdx.x;
+  if (c >= chunk_off[t + 1] - chunk_off[t]) return; /* block-uniform */
+  const u64 len = cov_len[t];
+  const int* p = cov + cov_off[t] + c * WGA_COV_CHUNK;
+  const u64 cnt = len - c * WGA_COV_CHUNK < WGA_COV_CHUNK ? len - c * WGA_COV_CHUNK : WGA_COV_CHUNK;
+  i64 s = 0;
+  for (u32 k = threadIdx.x; k < cnt; k += WGA_BLOCK) s += p[k];
+  u64 tot = block_sum_u64((u64)s, s_w);
+  if (threadIdx.x == 0) chunk_sum[chunk_off[t] + c] = (i64)tot;
+}
+
+__global__ __launch_bounds__(256) void k_cov_chunk_scan(const u64* chunk_off, i64* chunk_sum) {
+  __shared__ u64 s_w[5];
+  const u32 t = blockIdx.x;
+  const u64 c0 = chunk_off[t], nc = chunk_off[t + 1] - c0;
+  u64 carry = 0;
+  for (u64 base = 0; base < nc; base += WGA_BLOCK) {
+    u64 i = base + threadIdx.x;
+    u64 v = i < nc ? (u64)chunk_sum[c0 + i] : 0;
+    u64 tot;
+    u64 ex = block_excl_scan_u64(v, s_w, &tot);
+    if (i < nc) chunk_sum[c0 + i] = (i64)(carry + ex);
+    carry += tot;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cov_chunk_apply(const u64* cov_off, const u64* cov_len,
+                                                         int* cov, const u64* chunk_off,
+                                                         const i64* chunk_sum) {
+  __shared__ u64 s_w[5];
+  const u32 t = blockIdx.y;
+  const u64 c = blockIdx.x;
+  if (c >= chunk_off[t + 1] - chunk_off[t]) return;
+  const u64 len = cov_len[t];
+  int* p = cov + cov_off[t] + c * WGA_COV_CHUNK;
+  const u64 cnt = len - c * WGA_COV_CHUNK < WGA_COV_CHUNK ? len - c * WGA_COV_CHUNK : WGA_COV_CHUNK;
+  u64 carry = (u64)chunk_sum[chunk_off[t] + c];
+  const bool aligned = (((u64)p) & 15ull) == 0;
+  for (u32 pass = 0; pass < WGA_COV_CHUNK / 1024u; pass++) {
+    const u32 k0 = pass * 1024u + threadIdx.x * 4u;
+    int x[4] = {0, 0, 0, 0};
+    if (aligned && k0 + 3 < cnt) {
+      u32x4_a16 v = *(const u32x4_a16*)(p + k0);
+      x[0] = (int)v[0];
+      x[1] = (int)v[1];
+      x[2] = (int)v[2];
+      x[3] = (int)v[3];
+    } else {
+      for (u32 e = 0; e < 4; e++)
+        if (k0 + e < cnt) x[e] = p[k0 + e];
+    }
+    i64 s = (i64)x[0] + x[1] + x[2] + x[3];
+    u64 tot;
+    u64 ex = block_excl_scan_u64((u64)s, s_w, &tot);
+    i64 run = (i64)(carry + ex);
+    int y[4];
+    for (u32 e = 0; e < 4; e++) {
+      run += x[e];
+      y[e] = (int)run;
+    }
+    if (aligned && k0 + 3 < cnt) {
+      u32x4_a16 v = {(u32)y[0], (u32)y[1], (u32)y[2], (u32)y[3]};
+      *(u32x4_a16*)(p + k0) = v;
+    } else {
+      for (u32 e = 0; e < 4; e++)
+        if (k0 + e < cnt) p[k0 + e] = y[e];
+    }
+    carry += tot;
+  }
+}
+
+/* ============================================================================================ */
+/* K6: pafpseudo                                                                                */
+/* ============================================================================================ */
+struct PseudoArgs {
+  const u32* ops;
+  const u64* op_off;
+  const u8* strand_neg;
+  u32 n;
+  u64 n_ops;
+  const wga_tile_sum* tiles;
+  const wga_class_sums* rec_sums;
+  int base_mode;
+  const u8* q_fa;
+  u64 q_fa_bytes;
+  const u64* q_src_off;
+  const u64* q_src_len;
+  const u64* skip;
+  u8* out;
+  const u64* dst_off;
+  wga_rec_diag* diag;
+};
+
+/* symbol mode: '1' for M/=, '0' for X, '-' for D, nothing for the rest (cigar.rs:760-796) */
+__device__ __forceinline__ u32 pseudo_symbol(u32 code) {
+  return (code == WGA_OP_M || code == WGA_OP_EQ)
+             ? 0x31313131u
+             : code == WGA_OP_X ? 0x30303030u
+                                : (code == WGA_OP_D || code == WGA_OP_D_CONT) ? 0x2D2D2D2Du : 0u;
+}
+
+/* fill N bytes whose value depends only on the op covering the column (symbol mode) */
+__device__ __forceinline__ void emit_symbols(u8* dst, u32 N, u32 c0, const u32* s_col,
+                                             const u32* s_sym, int ka, int kb, u32 tid,
+                                             u32 nthreads) {
+  if (N == 0) return;
+  const u64 A = (u64)dst, E = A + N;
+  const u64 first = A >> 4, last = (E - 1) >> 4;
+  for (u64 ch = first + tid; ch <= last; ch += nthreads) {
+    const u64 base_addr = ch << 4;
+    const u32 a0 = base_addr < A ? (u32)(A - base_addr) : 0u;
+    const u32 b0 = base_addr + 16 > E ? (u32)(E - base_addr) : 16u;
+    const u32 cz = c0 + (u32)(base_addr - A);
+    u32 c = cz + a0;
+    const u32 c_end = cz + b0;
+    int lo = ka, hi = kb; /* last op in [ka,kb) whose start column is <= c: it has length > 0 */
+    while (lo < hi) {
+      int mid = (lo + hi) >> 1;
+      if (s_col[mid] <= c)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    int k = lo - 1;
+    u32 o[4] = {0u, 0u, 0u, 0u};
+    while (c < c_end) {
+      u32 oe = s_col[k + 1];
+      u32 pe = oe < c_end ? oe : c_end;
+      if (pe > c) {
+        const u32 sym = s_sym[k];
+        const u32 W[4] = {sym, sym, sym, sym};
+        merge16(o, W, (int)(c - cz), (int)(pe - cz));
+        c = pe;
+      }
+      k++;
+    }
+    if (a0 == 0u && b0 == 16u) {
+      u32x4_a16 v = {o[0], o[1], o[2], o[3]};
+      *(u32x4_a16*)base_addr = v;
+    } else {
+      u8* p = (u8*)base_addr;
+      for (u32 j = a0; j < b0; j++) {
+        u32 d = j >> 2;
+        u32 word = d == 0 ? o[0] : d == 1 ? o[1] : d == 2 ? o[2] : o[3];
+        p[j] = (u8)(word >> (8u * (j & 3u)));
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
+  __shared__ u32 s_col[WGA_TILE + 1];   /* exclusive prefix of target columns (M = X D)          */
+  __shared__ u32 s_ev[WGA_TILE + 1];    /* exclusive count of event ops (D, I, S)                */
+  __shared__ u32 s_sym[WGA_TILE + 1];   /* symbol-mode byte of the op                            */
+  __shared__ u32 s_g_col[WGA_TILE + 1]; /* events: column                                        */
+  __shared__ u32 s_g_cum[WGA_TILE + 1]; /*         '-' bases before (D)                          */
+  __shared__ u32 s_g_adj[WGA_TILE + 1]; /*         D bases - (I+S) bases before (wrapping)       */
+  __shared__ u64 s_w[5];
+  __shared__ u64 s_red[4][4];
+
+  const u32 tid = threadIdx.x;
+  const u32 lane = tid & 63u, wave = tid >> 6;
+  const u64 g = blockIdx.x;
+  const u64 tile_start = g * WGA_TILE;
+  const u64 tile_end = tile_start + WGA_TILE < a.n_ops ? tile_start + WGA_TILE : a.n_ops;
+  const u32 nt = (u32)(tile_end - tile_start);
+  const wga_tile_sum tsum = a.tiles[g];
+  const bool fast = tsum.tot[CLS_MX] + tsum.tot[CLS_D] + tsum.tot[CLS_I] + tsum.tot[CLS_S] <=
+                    WGA_FAST_COL_LIMIT;
+
+  u32 opw[4];
+  {
+    u32 base = tid * 4u;
+    if (base + 3 < nt) {
+      u32x4_a16 v = *(const u32x4_a16*)(a.ops + tile_start + base);
+      opw[0] = v[0];
+      opw[1] = v[1];
+      opw[2] = v[2];
+      opw[3] = v[3];
+    } else {
+      for (int e = 0; e < 4; e++) opw[e] = (base + e < nt) ? a.ops[tile_start + base + e] : 0u;
+    }
+  }
+  u32 e_col[4], e_is[4], e_d[4], cls[4];
+  if (fast) {
+    u32 l[4], sl = 0, sd = 0, sis = 0, cnt = 0;
+    for (int e = 0; e < 4; e++) {
+      u32 len = opw[e] >> 4;
+      cls[e] = op_class(opw[e] & 15u);
+      l[e] = (cls[e] == CLS_MX || cls[e] == CLS_D) ? len : 0u;
+      sl += l[e];
+      sd += cls[e] == CLS_D ? len : 0u;
+      sis += (cls[e] == CLS_I || cls[e] == CLS_S) ? len : 0u;
+      cnt += (cls[e] == CLS_D || cls[e] == CLS_I || cls[e] == CLS_S) ? 1u : 0u;
+    }
+    u64 totA, totB;
+    u64 exA = block_excl_scan_u64((u64)sl | ((u64)sd << 32), s_w, &totA);
+    u64 exB = block_excl_scan_u64((u64)sis | ((u64)cnt << 32), s_w, &totB);
+    u32 x_col = (u32)exA, x_d = (u32)(exA >> 32), x_is = (u32)exB, x_cnt = (u32)(exB >> 32);
+    for (int e = 0; e < 4; e++) {
+      u32 k = tid * 4u + (u32)e;
+      e_col[e] = x_col;
+      e_is[e] = x_is;
+      e_d[e] = x_d;
+      s_col[k] = x_col;
+      s_ev[k] = x_cnt;
+      s_sym[k] = pseudo_symbol(opw[e] & 15u);
+      if (cls[e] == CLS_D || cls[e] == CLS_I || cls[e] == CLS_S) {
+        s_g_col[x_cnt] = x_col;
+        s_g_cum[x_cnt] = x_d;
+        s_g_adj[x_cnt] = x_d - x_is;
+        if (cls[e] == CLS_D)
+          x_d += opw[e] >> 4;
+        else
+          x_is += opw[e] >> 4;
+        x_cnt += 1u;
+      }
+      x_col += l[e];
+    }
+    if (tid == WGA_BLOCK - 1) {
+      s_col[WGA_TILE] = x_col;
+      s_ev[WGA_TILE] = x_cnt;
+      s_g_col[x_cnt] = x_col;
+      s_g_cum[x_cnt] = x_d;
+      s_g_adj[x_cnt] = x_d - x_is;
+    }
+  }
+  __syncthreads();
+
+  u32 r = wga_find_rec(a.op_off, a.n, tile_start);
+  u64 cur = tile_start;
+  while (cur < tile_end) {
+    u64 re = a.op_off[r + 1];
+    while (re <= cur) {
+      r++;
+      re = a.op_off[r + 1];
+    }
+    const u64 rs = a.op_off[r];
+    const u64 seg_end = re < tile_end ? re : tile_end;
+    const u32 ka = (u32)(cur - tile_start), kb = (u32)(seg_end - tile_start);
+
+    u64 b_mx = 0, b_i = 0, b_d = 0, b_s = 0;
+    if (rs < tile_start) {
+      const u64 g0 = rs / WGA_TILE;
+      u64 p_mx = 0, p_i = 0, p_d = 0, p_s = 0;
+      for (u64 k = g0 + tid; k < g; k += WGA_BLOCK) {
+        const wga_tile_sum* t = a.tiles + k;
+        const u64* v = (k == g0) ? t->tail : t->tot;
+        p_mx += v[CLS_MX];
+        p_i += v[CLS_I];
+        p_d += v[CLS_D];
+        p_s += v[CLS_S];
+      }
+      p_mx = wave_sum_u64(p_mx);
+      p_i = wave_sum_u64(p_i);
+      p_d = wave_sum_u64(p_d);
+      p_s = wave_sum_u64(p_s);
+      __syncthreads();
+      if (lane == 0) {
+        s_red[wave][0] = p_mx;
+        s_red[wave][1] = p_i;
+        s_red[wave][2] = p_d;
+        s_red[wave][3] = p_s;
+      }
+      __syncthreads();
+      for (int w2 = 0; w2 < 4; w2++) {
+        b_mx += s_red[w2][0];
+        b_i += s_red[w2][1];
+        b_d += s_red[w2][2];
+        b_s += s_red[w2][3];
+      }
+    }
+    const u64 cb = b_mx + b_d;       /* target columns of this record before the segment */
+    const u64 qb = b_mx + b_i + b_s; /* query bases consumed before it                   */
+
+    const wga_class_sums cs = a.rec_sums[r];
+    const u64 T_total = cs.mx + cs.d;          /* columns the CIGAR emits */
+    const u64 Q_total = cs.mx + cs.i + cs.s;   /* query bases it consumes */
+    RowSrc qs;
+    qs.fa = a.q_fa;
+    qs.fa_bytes = a.q_fa_bytes;
+    qs.src_off = a.base_mode ? a.q_src_off[r] : 0;
+    qs.src_len = a.base_mode ? a.q_src_len[r] : 0;
+    qs.rc = a.strand_neg[r] != 0;
+    /* edited length: String::drain / insert_str semantics (cigar.rs:769-786) */
+    const u64 row_len = a.base_mode ? qs.src_len - (cs.i + cs.s) + cs.d : T_total;
+    const u64 skip = a.skip[r];
+    u8* const dst = a.out + a.dst_off[r];
+    u64* const bad_base = (u64*)&a.diag[r].bad_base_pos;
+    u64* const panic_idx = (u64*)&a.diag[r].panic_op_idx;
+
+    if (fast) {
+      const u32 col_a = s_col[ka], seg_cols = s_col[kb] - col_a;
+      const int ea = (int)s_ev[ka], eb = (int)s_ev[kb];
+      const u32 adj_a = s_g_adj[ea];
+      if (a.base_mode) {
+        /* drain(offset..offset+len) panics past the end of the string, insert_str(offset)
+         * beyond it (cigar.rs:772,779): in slice terms, an I/S op needs q_before + len <= slice
+         * length, a D op q_before <= slice length */
+        const u32 d_a = s_g_cum[ea], is_a = d_a - adj_a;
+        for (int e = 0; e < 4; e++) {
+          u32 k = tid * 4u + (u32)e;
+          if (k >= ka && k < kb) {
+            u64 q_before = qb + (u64)(e_col[e] - col_a) - (u64)(e_d[e] - d_a) + (u64)(e_is[e] - is_a);
+            u64 len = opw[e] >> 4;
+            if ((cls[e] == CLS_I || cls[e] == CLS_S) && q_before + len > qs.src_len)
+              atomicMin(panic_idx, tile_start + k - rs);
+            if (cls[e] == CLS_D && q_before > qs.src_len) atomicMin(panic_idx, tile_start + k - rs);
+          }
+        }
+      }
+      u64 x0 = cb > skip ? cb : skip;
+      u64 x1 = cb + seg_cols < row_len ? cb + seg_cols : row_len;
+      if (x1 > x0) {
+        const u32 c_first = col_a + (u32)(x0 - cb);
+        if (a.base_mode)
+          emit_row(dst + (x0 - skip), (u32)(x1 - x0), c_first, col_a, s_g_col, s_g_cum, s_g_adj, ea,
+                   eb, adj_a, qb, qs, tid, WGA_BLOCK, bad_base);
+        else
+          emit_symbols(dst + (x0 - skip), (u32)(x1 - x0), c_first, s_col, s_sym, (int)ka, (int)kb,
+                       tid, WGA_BLOCK);
+      }
+    }
+    /* u64 fallback for tiles too wide for u32 columns: op-serial walk, every thread redundantly */
+    if (!fast) {
+      u64 x = cb, qp = qb;
+      for (u64 k = cur; k < seg_end; k++) {
+        const u32 op = a.ops[k];
+        const u32 code = op & 15u;
+        const u32 c = op_class(code);
+        const u64 len = op >> 4;
+        if (a.base_mode && tid == 0) {
+          if ((c == CLS_I || c == CLS_S) && qp + len > qs.src_len) atomicMin(panic_idx, k - rs);
+          if (c == CLS_D && qp > qs.src_len) atomicMin(panic_idx, k - rs);
+        }
+        if (c == CLS_MX || c == CLS_D) {
+          for (u64 j = tid; j < len; j += WGA_BLOCK) {
+            u64 xx = x + j;
+            if (xx >= skip && xx < row_len) {
+              u8 v;
+              if (a.base_mode)
+                v = (c == CLS_D) ? (u8)'-' : src_byte(qs, qp + j, bad_base);
+              else
+                v = (u8)(pseudo_symbol(code) & 0xFFu);
+              dst[xx - skip] = v;
+            }
+          }
+          x += len;
+        }
+        if (c == CLS_MX || c == CLS_I || c == CLS_S) qp += len;
+      }
+    }
+    /* leftover query bases beyond the CIGAR stay at the end of the edited string */
+    if (seg_end == re && a.base_mode && row_len > T_total) {
+      u64 x0 = T_total > skip ? T_total : skip;
+      if (row_len > x0)
+        emit_tail(dst + (x0 - skip), row_len - x0, Q_total + (x0 - T_total), qs, tid, WGA_BLOCK,
+                  bad_base);
+    }
+    cur = seg_end;
+    r++;
+  }
+}
+
+/* ============================================================================================ */
+/* K3: MAF column-pair walk                                                                     */
+/* ============================================================================================ */
+/* One wave per record; column c is handled by lane c % 64 so that the run boundary test needs
+ * one __shfl_up.  cigar_cat_ext (cigar.rs:298-308): equal bytes -> '=' (also '-','-', and
+ * case-sensitive), else target gap -> I, else query gap -> D, else X.  Events are run starts.
+ * Run list entry: start_col << 3 | class (0 '=', 1 I, 2 D, 3 X); lengths are differences. */
+__global__ __launch_bounds__(256) void k_maf_pair_stat(u32 n, const u8* __restrict__ rows,
+                                                       const u64* t_off, const u64* q_off,
+                                                       const u64* cols, const u8* strand_neg,
+                                                       wga_cigar_counts* counts, u64* run_cnt,
+                                                       u64* runs, const u64* run_off) {
+  const u32 lane = threadIdx.x & 63u;
+  const u64 i = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const u8* t = rows + t_off[i];
+  const u8* q = rows + q_off[i];
+  const u64 L = cols[i];
+  u64* rout = runs ? runs + run_off[i] : (u64*)0;
+  u32 ncol[4] = {0, 0, 0, 0}, nrun[4] = {0, 0, 0, 0}; /* per lane: < 2^32 for L < 2^38 */
+  u64 ncol_hi[4] = {0, 0, 0, 0};
+  u32 carry_cls = 0xFFu; /* class of the column before this iteration's lane 0 */
+  u64 run_base = 0;
+  u32 it_in_acc = 0;
+  for (u64 c0 = 0; c0 < L; c0 += 64) {
+    const u64 c = c0 + lane;
+    const bool in = c < L;
+    u32 cls = 0xFEu;
+    if (in) {
+      u8 c1 = t[c], c2 = q[c];
+      cls = (c1 == c2) ? 0u : (c1 == (u8)'-') ? 1u : (c2 == (u8)'-') ? 2u : 3u;
+    }
+    u32 prev = __shfl_up(cls, 1u);
+    if (lane == 0) prev = carry_cls;
+    const bool start = in && cls != prev;
+    if (in) {
+      ncol[0] += cls == 0u;
+      ncol[1] += cls == 1u;
+      ncol[2] += cls == 2u;
+      ncol[3] += cls == 3u;
+    }
+    if (start) {
+      nrun[0] += cls == 0u;
+      nrun[1] += cls == 1u;
+      nrun[2] += cls == 2u;
+      nrun[3] += cls == 3u;
+    }
+    const u64 m = __ballot(start);
+    if (rout && start) {
+      u64 below = m & ((1ull << lane) - 1ull);
+      rout[run_base + (u64)__popcll(below)] = (c << 3) | (u64)cls;
+    }
+    run_base += (u64)__popcll(m);
+    carry_cls = __shfl(cls, 63);
+    if (++it_in_acc == 0x40000000u) { /* keep the u32 lane counters from wrapping */
+      for (int k = 0; k < 4; k++) {
+        ncol_hi[k] += ncol[k];
+        ncol[k] = 0;
+      }
+      it_in_acc = 0;
+    }
+  }
+  u64 C[4], R[4];
+  for (int k = 0; k < 4; k++) {
+    C[k] = wave_sum_u64(ncol_hi[k] + ncol[k]);
+    R[k] = wave_sum_u64((u64)nrun[k]);
+  }
+  if (lane == 0) {
+    const bool neg = strand_neg[i] != 0;
+    wga_cigar_counts o;
+    o.match = C[0];
+    o.mismatch = C[3];
+    o.ins_ev = neg ? 0 : R[1];
+    o.ins_bp = neg ? 0 : C[1];
+    o.del_ev = neg ? 0 : R[2];
+    o.del_bp = neg ? 0 : C[2];
+    o.inv_ins_ev = neg ? R[1] : 0;
+    o.inv_ins_bp = neg ? C[1] : 0;
+    o.inv_del_ev = neg ? R[2] : 0;
+    o.inv_del_bp = neg ? C[2] : 0;
+    o.inv_ev = neg ? 1 : 0;
+    counts[i] = o;
+    if (run_cnt) run_cnt[i] = run_base;
+  }
+}
+
+#endif /* WGA_KERNELS2_H */

@@ -123,7 +123,11 @@ class Engine:
         self._check(self.lib.wga_sync(self.ctx))
 
     def set_stream(self, hip_stream):
-        self._check(self.lib.wga_ctx_set_stream(self.ctx, hip_stream))
+        """launch on this hipStream_t (0 / None = HIP's default stream)"""
+        self._check(self.lib.wga_ctx_set_stream(self.ctx, hip_stream or None))
+
+    def reset_stream(self):
+        self._check(self.lib.wga_ctx_reset_stream(self.ctx))
 
     def set_param(self, name, value):
         self._check(self.lib.wga_ctx_set_param(self.ctx, name.encode(), int(value)))

@@ -101,3 +101,87 @@ def cigar_text(ops_slice):
         ch = OP_CHARS[c] if c < 9 else ("I" if c == 9 else "D" if c == 10 else "B")
         out.append("%d%s" % (w >> 4, ch))
     return "".join(out)
+
+
+# ------------------------------------------------------------------------------------------------
+# device-side generator (torch is plumbing: it only fills HBM with synthetic input)
+# ------------------------------------------------------------------------------------------------
+def make_paf_batch_torch(seed, n_rec, mean_ops, pool_bytes, device, use_m=False, sigma=0.5,
+                         neg_frac=0.5):
+    """Same mixture as make_paf_batch, generated in HBM.  Returns a dict of torch tensors
+    (ops int32 view of the packed u32 ops, op_off/src offsets int64) plus host n_ops."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    rng = np.random.default_rng(seed)
+    mu = np.log(mean_ops) - 0.5 * sigma * sigma
+    n_ops = np.maximum(1, rng.lognormal(mu, sigma, size=n_rec).astype(np.int64))
+    op_off_h = np.zeros(n_rec + 1, dtype=np.int64)
+    np.cumsum(n_ops, out=op_off_h[1:])
+    total = int(op_off_h[-1])
+    op_off = torch.from_numpy(op_off_h).to(device)
+    rec_id = torch.repeat_interleave(torch.arange(n_rec, device=device), torch.from_numpy(n_ops).to(device))
+    idx_in_rec = torch.arange(total, device=device) - op_off[rec_id]
+    is_match = (idx_in_rec & 1) == 0
+    del idx_in_rec
+    u = torch.rand(total, device=device, generator=g)
+    code = torch.where(u < 0.6, OP_X, torch.where(u < 0.8, OP_I, OP_D)).to(torch.int32)
+    ln = torch.empty(total, device=device).geometric_(1.0 / 3.0, generator=g).to(torch.int32)
+    heavy = torch.rand(total, device=device, generator=g) < 0.01
+    hv = torch.randint(50, 2001, (total,), device=device, generator=g, dtype=torch.int32)
+    ln = torch.where(heavy, hv, ln)
+    del heavy, hv, u
+    ln = torch.where(code == OP_X, torch.ones_like(ln), ln)
+    if use_m:
+        code = torch.where(code == OP_X, torch.full_like(code, OP_M), code)
+    ml = torch.empty(total, device=device).geometric_(1.0 / 24.0, generator=g).to(torch.int32)
+    code = torch.where(is_match, torch.full_like(code, OP_M if use_m else OP_EQ), code)
+    ln = torch.where(is_match, ml, ln)
+    del ml, is_match
+    ops = (ln << 4) | code
+
+    def rec_sum(mask):
+        c = torch.zeros(total + 1, dtype=torch.int64, device=device)
+        torch.cumsum(torch.where(mask, ln, torch.zeros_like(ln)).to(torch.int64), 0, out=c[1:])
+        return c[op_off[1:]] - c[op_off[:-1]]
+    mx = rec_sum((code == OP_M) | (code == OP_EQ) | (code == OP_X))
+    si = rec_sum(code == OP_I)
+    sd = rec_sum(code == OP_D)
+    del code, ln, rec_id
+    t_len, q_len = mx + sd, mx + si
+    need = int(max(int(t_len.max()), int(q_len.max()))) + 64
+    pool_bytes = max(int(pool_bytes), need)
+
+    def pool():
+        lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+        p = lut[torch.randint(0, 4, (pool_bytes,), device=device, generator=g)]
+        k = max(1, pool_bytes // 1000)
+        p[torch.randint(0, pool_bytes, (k,), device=device, generator=g)] = ord("N")
+        run = 200
+        starts = torch.randint(0, max(1, pool_bytes - run), (max(1, pool_bytes // (20 * run)),),
+                               device=device, generator=g)
+        idx = (starts[:, None] + torch.arange(run, device=device)[None, :]).reshape(-1)
+        p[idx] |= 0x20
+        return p
+    t_pool, q_pool = pool(), pool()
+    t_off = (torch.rand(n_rec, device=device, generator=g, dtype=torch.float64)
+             * (pool_bytes - t_len).to(torch.float64)).to(torch.int64)
+    q_off = (torch.rand(n_rec, device=device, generator=g, dtype=torch.float64)
+             * (pool_bytes - q_len).to(torch.float64)).to(torch.int64)
+    strand = (torch.rand(n_rec, device=device, generator=g) < neg_frac).to(torch.uint8)
+    return dict(ops=ops.contiguous(), op_off=op_off, strand_neg=strand, t_pool=t_pool,
+                q_pool=q_pool, t_src_off=t_off, t_src_len=t_len, q_src_off=q_off, q_src_len=q_len,
+                n=n_rec, n_ops=total, mx=mx, i=si, d=sd)
+
+
+def torch_batch_record_to_numpy(tb, i):
+    """one record of a torch batch as the numpy dict make_paf_batch returns (n = 1)"""
+    a, b = int(tb["op_off"][i]), int(tb["op_off"][i + 1])
+    ops = tb["ops"][a:b].cpu().numpy().view(np.uint32)
+    to, tl = int(tb["t_src_off"][i]), int(tb["t_src_len"][i])
+    qo, ql = int(tb["q_src_off"][i]), int(tb["q_src_len"][i])
+    return dict(ops=ops, op_off=np.array([0, b - a], dtype=np.uint64),
+                strand_neg=np.array([int(tb["strand_neg"][i])], dtype=np.uint8),
+                t_pool=tb["t_pool"][to:to + tl].cpu().numpy(), q_pool=tb["q_pool"][qo:qo + ql].cpu().numpy(),
+                t_src_off=np.zeros(1, np.uint64), t_src_len=np.array([tl], dtype=np.uint64),
+                q_src_off=np.zeros(1, np.uint64), q_src_len=np.array([ql], dtype=np.uint64))
