@@ -93,6 +93,7 @@ def test_paf2maf_config2_full_size_properties(gpu):
     job = pipeline.Paf2MafStatJob(gpu, tb)
     job.bind_stream()
     job.out.fill_(0)
+    torch.cuda.synchronize()
     job.step()
     torch.cuda.synchronize()
     assert bool((job.diag == -1).all())
@@ -141,6 +142,8 @@ def test_paf2maf_wide_tile_auto_slow_path(gpu):
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
     t_pool = lut[torch.randint(0, 4, (t_len,), device=dev, generator=g)]
     q_pool = lut[torch.randint(0, 4, (q_len,), device=dev, generator=g)]
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
     batch = gpu.make_batch(ops, np.array([0, len(ops)], dtype=np.uint64), np.array([0], dtype=np.uint8))
     counts, diag, tws = gpu.cigar_stat(batch)
     z = gpu.upload(np.zeros(1, dtype=np.uint64))
@@ -149,6 +152,7 @@ def test_paf2maf_wide_tile_auto_slow_path(gpu):
     total = int(reco.numpy()[-1])
     assert total == 2 * t_len
     out = torch.full((total + 64,), 0x23, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
     gpu.paf2maf_expand(batch, counts, tws, t_pool, t_len, z, tl, q_pool, q_len, z, ql, out, tro, qro, diag)
     gpu.sync()
     assert bool((out[:t_len] == t_pool).all())            # D consumes the target: row == slice
