@@ -109,7 +109,8 @@ void wga_ctx_destroy(wga_ctx*);
  * NULL is HIP's default stream).  wga_ctx_reset_stream goes back to the context's own stream. */
 int wga_ctx_set_stream(wga_ctx*, void* hip_stream);
 int wga_ctx_reset_stream(wga_ctx*);
-/* Tunables: "expand_force_slow" (0/1) forces the u64 op-serial fallback of the expand kernel. */
+/* Tunables (test knobs): "expand_force_slow" (0/1) forces the u64 op-serial fallback of the
+ * expand kernel; "expand_no_table" (0/1) forces its binary-search event lookup. */
 int wga_ctx_set_param(wga_ctx*, const char* name, int64_t value);
 int wga_sync(wga_ctx*);
 int wga_malloc(wga_ctx*, size_t bytes, void** d_out);

@@ -50,11 +50,12 @@ def check_stat(eng, b, sample=None):
 # ------------------------------------------------------------------------------------------------
 # K2
 # ------------------------------------------------------------------------------------------------
-def run_paf2maf(eng, b, pre=None, force_slow=0, fill=0x23):
+def run_paf2maf(eng, b, pre=None, force_slow=0, fill=0x23, no_table=0):
     """stat -> layout -> expand; returns host copies"""
     n = len(b["strand_neg"])
     batch = eng.make_batch(b["ops"], b["op_off"], b["strand_neg"])
     eng.set_param("expand_force_slow", force_slow)
+    eng.set_param("expand_no_table", no_table)
     counts, diag, tws = eng.cigar_stat(batch)
     tl, ql = eng.upload(b["t_src_len"]), eng.upload(b["q_src_len"])
     to, qo = eng.upload(b["t_src_off"]), eng.upload(b["q_src_off"])
@@ -69,6 +70,7 @@ def run_paf2maf(eng, b, pre=None, force_slow=0, fill=0x23):
     eng.paf2maf_expand(batch, counts, tws, tp, len(b["t_pool"]), to, tl, qp, len(b["q_pool"]), qo,
                        ql, out, tro, qro, diag)
     eng.set_param("expand_force_slow", 0)
+    eng.set_param("expand_no_table", 0)
     return dict(out=out.numpy(), t_row_off=tro.numpy(), q_row_off=qro.numpy(),
                 rec_off=reco.numpy(), counts=counts.numpy(), diag=diag.numpy(), total=total)
 
@@ -82,8 +84,8 @@ def oracle_rows(b, i):
     return orc.parse_cigar_to_insert(rec_text(b, i), t, q)  # may raise CigarOpInvalid / panic
 
 
-def check_paf2maf(eng, b, pre=None, force_slow=0, sample=None):
-    r = run_paf2maf(eng, b, pre=pre, force_slow=force_slow)
+def check_paf2maf(eng, b, pre=None, force_slow=0, sample=None, no_table=0):
+    r = run_paf2maf(eng, b, pre=pre, force_slow=force_slow, no_table=no_table)
     out, n = r["out"], len(b["strand_neg"])
     covered = np.zeros(len(out), dtype=bool)
     idx = range(n) if sample is None else sample

@@ -60,6 +60,12 @@ def test_paf2maf_edge_cases(emu):
     pc.check_paf2maf(emu, b)
     pc.check_paf2maf(emu, b, pre=(rng.integers(0, 33, n), rng.integers(0, 33, n), rng.integers(0, 3, n)))
     pc.check_paf2maf(emu, b, force_slow=1)
+    pc.check_paf2maf(emu, b, no_table=1)
+
+
+def test_paf2maf_no_table_random(emu):
+    """binary-search event lookup (the path of tiles wider than 65536 columns)"""
+    pc.check_paf2maf(emu, synth.make_paf_batch(8, 30, 500, 60000), no_table=1)
 
 
 def test_paf2maf_force_slow_random(emu):
@@ -103,10 +109,10 @@ def test_paf2maf_long_record_many_tiles(emu):
 
 def test_scan_and_scatter(emu):
     rng = np.random.default_rng(3)
-    for n in (0, 1, 5, 1024, 1025, 5000):
+    for n in (0, 1, 5, 1024, 1025, 5000, 300000):
         v = rng.integers(0, 1 << 40, n).astype(np.uint64)
         got = emu.exclusive_scan_u64(n, emu.upload(v) if n else None).numpy()
-        exp = np.concatenate([[0], np.cumsum(v)]).astype(np.uint64)
+        exp = np.concatenate([np.zeros(1, np.uint64), np.cumsum(v, dtype=np.uint64)])
         assert (got == exp).all()
     lens = rng.integers(0, 70, 50)
     src_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
@@ -156,7 +162,7 @@ def test_pafpseudo(emu, base, seed, n, mean):
     b["ops"] = ops
     code, length = ops & 15, (ops >> 4).astype(np.uint64)
     v = np.where((code == 0) | (code == 7) | (code == 8) | (code == 1) | (code == 4), length, 0).astype(np.uint64)
-    c = np.concatenate([[0], np.cumsum(v)]).astype(np.uint64)
+    c = np.concatenate([np.zeros(1, np.uint64), np.cumsum(v, dtype=np.uint64)])
     b["q_src_len"] = c[b["op_off"][1:].astype(np.int64)] - c[b["op_off"][:-1].astype(np.int64)]
     b["q_src_off"] = (rng.random(n) * (len(b["q_pool"]) - b["q_src_len"].astype(np.float64))).astype(np.uint64)
     skip = np.where(rng.random(n) < 0.4, rng.integers(0, 30, n), 0)

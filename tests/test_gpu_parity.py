@@ -191,7 +191,7 @@ def test_pafpseudo(gpu, base, seed, n, mean):
     b["ops"] = ops
     code, length = ops & 15, (ops >> 4).astype(np.uint64)
     v = np.where((code == 0) | (code == 7) | (code == 8) | (code == 1) | (code == 4), length, 0).astype(np.uint64)
-    c = np.concatenate([[0], np.cumsum(v)]).astype(np.uint64)
+    c = np.concatenate([np.zeros(1, np.uint64), np.cumsum(v, dtype=np.uint64)])
     b["q_src_len"] = c[b["op_off"][1:].astype(np.int64)] - c[b["op_off"][:-1].astype(np.int64)]
     b["q_src_off"] = (rng.random(n) * (len(b["q_pool"]) - b["q_src_len"].astype(np.float64))).astype(np.uint64)
     seg = synth.class_sums(code, ops >> 4, b["op_off"])
@@ -230,4 +230,4 @@ def test_scan(gpu):
     for n in (0, 1, 5, 1024, 1025, 5000, 3_000_000):
         v = rng.integers(0, 1 << 40, n).astype(np.uint64)
         got = gpu.exclusive_scan_u64(n, gpu.upload(v) if n else None).numpy()
-        assert (got == np.concatenate([[0], np.cumsum(v)]).astype(np.uint64)).all()
+        assert (got == np.concatenate([np.zeros(1, np.uint64), np.cumsum(v, dtype=np.uint64)])).all()

@@ -18,6 +18,9 @@ struct wga_ctx {
   wga_stream_t own_stream = nullptr;
   wga_stream_t stream = nullptr;
   int expand_force_slow = 0;
+  int expand_no_table = 0;
+  int expand_ablate = 0;
+  void* expand_dbg = nullptr;
   void* scratch = nullptr;
   size_t scratch_cap = 0;
 };
@@ -130,6 +133,18 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return fail(WGA_E_INVALID_ARG, "null argument", nullptr);
   if (strcmp(name, "expand_force_slow") == 0) {
     c->expand_force_slow = value != 0;
+    return WGA_OK;
+  }
+  if (strcmp(name, "expand_dbg_ptr") == 0) {
+    c->expand_dbg = (void*)(uintptr_t)value;
+    return WGA_OK;
+  }
+  if (strcmp(name, "expand_ablate") == 0) {
+    c->expand_ablate = (int)value;
+    return WGA_OK;
+  }
+  if (strcmp(name, "expand_no_table") == 0) {
+    c->expand_no_table = value != 0;
     return WGA_OK;
   }
   return fail(WGA_E_INVALID_ARG, "unknown parameter", name);
@@ -256,29 +271,39 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
       !d_out || !d_t_row_off || !d_q_row_off || !d_diag)
     return fail(WGA_E_INVALID_ARG, "null array", nullptr);
   if ((t_fa_bytes && !d_t_fa) || (q_fa_bytes && !d_q_fa)) return fail(WGA_E_INVALID_ARG, "null sequence pool", nullptr);
+  u64 nt = n_tiles(b->n_ops);
+  if (nt > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "batch too large for one launch", nullptr);
+  /* pre-pass: per-record descriptors and per-tile base sums, in the context's scratch arena */
+  void* ws;
+  size_t rec_bytes = ((size_t)b->n * sizeof(wga_rec_desc) + 255) & ~(size_t)255;
+  if ((rc = ctx_scratch(c, rec_bytes + (size_t)nt * sizeof(wga_tile_base), &ws))) return rc;
+  wga_rec_desc* recs = (wga_rec_desc*)ws;
+  wga_tile_base* bases = (wga_tile_base*)((char*)ws + rec_bytes);
+  WGA_LAUNCH(k_rec_desc, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, b->n, d_counts,
+             b->d_strand_neg, (const u64*)d_t_src_off, (const u64*)d_t_src_len,
+             (const u64*)d_q_src_off, (const u64*)d_q_src_len, (const u64*)d_t_row_off,
+             (const u64*)d_q_row_off, recs);
+  LAUNCH_CHECK();
+  WGA_LAUNCH(k_tile_base, (u32)((nt + 3) / 4), WGA_BLOCK, c->stream, (const u64*)b->d_op_off,
+             (u64)b->n_ops, (const wga_tile_sum*)d_tile_ws, bases);
+  LAUNCH_CHECK();
   ExpandArgs a;
   a.ops = b->d_ops;
   a.op_off = (const u64*)b->d_op_off;
-  a.strand_neg = b->d_strand_neg;
-  a.n = b->n;
   a.n_ops = b->n_ops;
-  a.counts = d_counts;
   a.tiles = (const wga_tile_sum*)d_tile_ws;
+  a.bases = bases;
+  a.recs = recs;
   a.t_fa = d_t_fa;
   a.t_fa_bytes = t_fa_bytes;
-  a.t_src_off = (const u64*)d_t_src_off;
-  a.t_src_len = (const u64*)d_t_src_len;
   a.q_fa = d_q_fa;
   a.q_fa_bytes = q_fa_bytes;
-  a.q_src_off = (const u64*)d_q_src_off;
-  a.q_src_len = (const u64*)d_q_src_len;
   a.out = d_out;
-  a.t_row_off = (const u64*)d_t_row_off;
-  a.q_row_off = (const u64*)d_q_row_off;
   a.diag = d_diag;
   a.force_slow = c->expand_force_slow;
-  u64 nt = n_tiles(b->n_ops);
-  if (nt > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "batch too large for one launch", nullptr);
+  a.no_table = c->expand_no_table;
+  a.ablate = c->expand_ablate;
+  a.dbg = (u64*)c->expand_dbg;
   WGA_LAUNCH(k_paf2maf_expand, (u32)nt, WGA_BLOCK, c->stream, a);
   LAUNCH_CHECK();
   return WGA_OK;

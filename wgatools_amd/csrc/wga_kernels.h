@@ -59,11 +59,15 @@ __device__ __forceinline__ u32 op_class(u32 code) {
 struct wga_tile_sum {
   u64 tot[5];
   u64 tail[5];
+  u64 rec; /* record that owns the first op of the tile (saves later kernels the search) */
 };
 
 /* a 16-byte vector that only promises dword alignment (global_load_dwordx4 needs no more) */
 typedef u32 u32x4_a4 __attribute__((vector_size(16), aligned(4)));
 typedef u32 u32x4_a16 __attribute__((vector_size(16), aligned(16)));
+/* byte-aligned 16-byte access: one global_load/store_dwordx4 on gfx950 (unaligned loads measure
+ * the same as aligned ones, unaligned stores ~10 % slower: scripts/micro/unaligned_copy.hip) */
+typedef u32 u32x4_a1 __attribute__((vector_size(16), aligned(1)));
 
 __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
@@ -135,6 +139,7 @@ __global__ __launch_bounds__(256) void k_cigar_stat(const u32* __restrict__ ops,
   }
 
   u32 r = wga_find_rec(op_off, n, tile_start);
+  const u32 r_first = r;
   u64 cur = tile_start;
   u64 tot[5] = {0, 0, 0, 0, 0}, tail[5] = {0, 0, 0, 0, 0};
   while (cur < tile_end) {
@@ -227,6 +232,7 @@ __global__ __launch_bounds__(256) void k_cigar_stat(const u32* __restrict__ ops,
       ts.tot[c] = tot[c];
       ts.tail[c] = tail[c];
     }
+    ts.rec = r_first;
     tiles[g] = ts;
   }
 }
@@ -342,24 +348,35 @@ struct RowSrc {
   u64 src_off;   /* start of this record's slice in the pool */
   u64 src_len;   /* slice length as fetched */
   bool rc;       /* read reversed + complemented (utils.rs:83-101) */
+  bool safe;     /* every 20-byte window of this row lies inside the pool (rowsrc_prepare) */
+  int ablate;    /* profiling knob (see ExpandArgs) */
+  const u8* win_base; /* address of slice index sbase (rc: of the mirrored window start) */
 };
 
-/* 0x80 in every byte of y that is zero (exact: no cross-byte carries) */
-__device__ __forceinline__ u32 zero_bytes(u32 y) {
-  return ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+/* v_perm_b32: result byte k = byte sel[k] (0..7) of the 8-byte pool {hi:7..4, lo:3..0} */
+__device__ __forceinline__ u32 byte_perm(u32 hi, u32 lo, u32 sel) {
+#ifdef WGA_EMU
+  u64 pool = ((u64)hi << 32) | (u64)lo;
+  u32 r = 0;
+  for (int k = 0; k < 4; k++) r |= (u32)((pool >> (8 * ((sel >> (8 * k)) & 7u))) & 0xFFu) << (8 * k);
+  return r;
+#else
+  return __builtin_amdgcn_perm(hi, lo, sel);
+#endif
 }
 
-/* complement 4 packed bases; *valid gets 0x80 per byte that is one of ACGTNacgtn */
-__device__ __forceinline__ u32 comp4(u32 x, u32* valid) {
-  u32 low = x | 0x20202020u;
-  u32 isn = zero_bytes(low ^ 0x6E6E6E6Eu);
-  u32 v = isn | zero_bytes(low ^ 0x61616161u) | zero_bytes(low ^ 0x63636363u) |
-          zero_bytes(low ^ 0x67676767u) | zero_bytes(low ^ 0x74747474u);
-  *valid = v;
-  u32 b1 = (x >> 1) & 0x01010101u;         /* bit 1: set for C/G, clear for A/T */
-  u32 xm = 0x15151515u - b1 * 0x11u;       /* A<->T: ^0x15, C<->G: ^0x04 */
-  u32 nmask = (isn >> 7) * 0xFFu;          /* N stays N */
-  return x ^ (xm & ~nmask);
+/* Complement 4 packed bases (utils.rs:86-96) with two 8-entry byte LUTs indexed by the low
+ * THREE bits of each base — A=1 C=3 T=4 N=6 G=7 are distinct.  `fold` is the upper-case base a
+ * valid byte must equal once its case bit is cleared (0xFF for the unused indices, which no
+ * byte & 0xDF can equal), `comp` its complement.  *bad gets a non-zero byte wherever the input
+ * is not one of ACGTNacgtn. */
+__device__ __forceinline__ u32 comp4(u32 x, u32* bad) {
+  const u32 sel = x & 0x07070707u;
+  /* index:      7     6     5     4        3     2     1     0   */
+  const u32 fold = byte_perm(0x474EFF54u, 0x43FF41FFu, sel); /* G N - T | C - A - */
+  const u32 comp = byte_perm(0x434EFF41u, 0x47FF54FFu, sel); /* C N - A | G - T - */
+  *bad = (x & 0xDFDFDFDFu) ^ fold;
+  return comp | (x & 0x20202020u);
 }
 
 __device__ __forceinline__ u32 bswap32(u32 x) {
@@ -378,178 +395,478 @@ __device__ __forceinline__ u32 bytemask(int lo, int hi) {
   return mh & ~ml;
 }
 
-/* Load the 16 source bytes that map to output bytes 0..15 of a chunk: byte j <-> slice index
- * S + j (S may be negative / beyond the slice for bytes outside the piece — those are masked by
- * the caller; memory safety comes from the pool bounds check).  For rc the slice is read
- * backwards and complemented; *inv gets 0x80 flags of invalid bases (all 16 bytes). */
-__device__ __forceinline__ void load_window(const RowSrc& src, i64 S, int pa, int pb, u32 W[4],
-                                            u32 inv[4]) {
-  /* pool index of the lowest-addressed byte of the window */
-  i64 P = src.rc ? (i64)src.src_off + (i64)src.src_len - 16 - S : (i64)src.src_off + S;
-  u64 addr = (u64)src.fa + (u64)P;
-  u64 al = addr & ~3ull;
-  u32 V[4];
-  if (P >= 4 && (u64)P + 24 <= src.fa_bytes) { /* whole dword-aligned 20-byte span in the pool */
-    u32x4_a4 v = *(const u32x4_a4*)al;
-    u32 v4 = *(const u32*)(al + 16);
-    u32 sh = (u32)(addr & 3ull);
-    V[0] = alignbyte(v[1], v[0], sh);
-    V[1] = alignbyte(v[2], v[1], sh);
-    V[2] = alignbyte(v[3], v[2], sh);
-    V[3] = alignbyte(v4, v[3], sh);
+/* A 16-byte source window: output byte j of a chunk <-> slice index S + j (S may be negative /
+ * beyond the slice for bytes outside the piece — those are masked by the caller).  Split in two
+ * so that several windows can be in flight: win_issue only issues the load (ONE byte-aligned
+ * global_load_dwordx4), win_finish — for rc — reverses + complements and flags invalid bases
+ * (non-zero byte).  `off` = S - sbase is a small i32; the 64-bit part of the address is
+ * wave-uniform (RowSrc::win_base).  Rows whose slice sits >= 32 bytes inside the pool (`safe`,
+ * uniform) load unchecked; rows at a pool edge take guarded byte loads. */
+struct WinRaw {
+  u32 v[4];
+};
+
+__device__ __forceinline__ void win_issue(const RowSrc& src, u64 sbase, int off, int pa, int pb,
+                                          WinRaw& r) {
+  if (src.ablate & 2) {
+    r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0x41414141u;
+  } else if (src.safe) {
+    /* pointer arithmetic only (no integer round trip): keeps this a global_load, not flat */
+    const int sgn = src.rc ? -1 : 0; /* uniform */
+    const u8* p = src.win_base + (i64)((off ^ sgn) - sgn);
+    u32x4_a1 v = *(const u32x4_a1*)p;
+    r.v[0] = v[0];
+    r.v[1] = v[1];
+    r.v[2] = v[2];
+    r.v[3] = v[3];
   } else { /* pool edge: guarded byte loads, only for the bytes of the piece */
-    V[0] = V[1] = V[2] = V[3] = 0u;
+    const i64 S = (i64)sbase + off;
+    const i64 P = src.rc ? (i64)src.src_off + (i64)src.src_len - 16 - S : (i64)src.src_off + S;
+    u64 lo = 0, hi = 0; /* no dynamically indexed array: that would force WinRaw into scratch */
     for (int j = pa; j < pb; j++) {
       int vj = src.rc ? 15 - j : j; /* position inside the address-ordered window */
       i64 idx = P + vj;
-      u32 byte = (idx >= 0 && (u64)idx < src.fa_bytes) ? (u32)src.fa[idx] : 0u;
-      V[vj >> 2] |= byte << (8 * (vj & 3));
+      u64 byte = (idx >= 0 && (u64)idx < src.fa_bytes) ? (u64)src.fa[idx] : 0ull;
+      if (vj < 8)
+        lo |= byte << (8 * vj);
+      else
+        hi |= byte << (8 * (vj - 8));
     }
+    r.v[0] = (u32)lo;
+    r.v[1] = (u32)(lo >> 32);
+    r.v[2] = (u32)hi;
+    r.v[3] = (u32)(hi >> 32);
   }
+}
+
+__device__ __forceinline__ void win_finish(const RowSrc& src, const WinRaw& r, u32 W[4],
+                                           u32 inv[4]) {
   if (src.rc) {
-    u32 r0 = bswap32(V[3]), r1 = bswap32(V[2]), r2 = bswap32(V[1]), r3 = bswap32(V[0]);
-    u32 v0, v1, v2, v3;
-    W[0] = comp4(r0, &v0);
-    W[1] = comp4(r1, &v1);
-    W[2] = comp4(r2, &v2);
-    W[3] = comp4(r3, &v3);
-    inv[0] = ~v0 & 0x80808080u;
-    inv[1] = ~v1 & 0x80808080u;
-    inv[2] = ~v2 & 0x80808080u;
-    inv[3] = ~v3 & 0x80808080u;
+    W[0] = comp4(bswap32(r.v[3]), &inv[0]);
+    W[1] = comp4(bswap32(r.v[2]), &inv[1]);
+    W[2] = comp4(bswap32(r.v[1]), &inv[2]);
+    W[3] = comp4(bswap32(r.v[0]), &inv[3]);
   } else {
-    W[0] = V[0];
-    W[1] = V[1];
-    W[2] = V[2];
-    W[3] = V[3];
+    W[0] = r.v[0];
+    W[1] = r.v[1];
+    W[2] = r.v[2];
+    W[3] = r.v[3];
     inv[0] = inv[1] = inv[2] = inv[3] = 0u;
   }
 }
 
-__device__ __forceinline__ void merge16(u32 o[4], const u32 W[4], int pa, int pb) {
-  if (pa <= 0 && pb >= 16) {
-    o[0] = W[0];
-    o[1] = W[1];
-    o[2] = W[2];
-    o[3] = W[3];
-    return;
+/* bytes [0, n) of a 16-byte vector set: table of 17 masks, built once per block in LDS */
+__device__ __forceinline__ void build_lowmask(u32x4_a16* lm) {
+  if (threadIdx.x < 17u) {
+    u32x4_a16 m;
+    for (int d = 0; d < 4; d++) m[d] = bytemask(0, (int)threadIdx.x - 4 * d);
+    lm[threadIdx.x] = m;
   }
+}
+
+/* o = bytes [pa, pb) from W, the rest unchanged */
+__device__ __forceinline__ void merge16(u32 o[4], const u32 W[4], int pa, int pb,
+                                        const u32x4_a16* lm) {
+  const u32x4_a16 hi = lm[pb], lo = lm[pa];
 #pragma unroll
   for (int d = 0; d < 4; d++) {
-    u32 m = bytemask(pa - 4 * d, pb - 4 * d);
+    u32 m = hi[d] & ~lo[d];
     o[d] = (o[d] & ~m) | (W[d] & m);
   }
 }
+__device__ __forceinline__ void merge_dash(u32 o[4], int pa, int pb, const u32x4_a16* lm) {
+  const u32 dash[4] = {0x2D2D2D2Du, 0x2D2D2D2Du, 0x2D2D2D2Du, 0x2D2D2D2Du};
+  merge16(o, dash, pa, pb, lm);
+}
 
-/*
- * Emit N (<= 2^31) bytes of one gapped row to dst.  Output byte k is tile-relative column
- * c0 + k.  The row's events inside this range are entries [ga, gb) of a compacted list
- * (G_col = tile-relative start column, G_cum = exclusive prefix of gap bases — an entry's gap
- * length is G_cum[i+1]-G_cum[i], entry gb is readable — and G_adj = exclusive prefix of the
- * source adjustment: gap bases minus skipped source bases, as wrapping u32; for paf2maf rows
- * G_adj == G_cum).  A non-gap column c reads slice index
- *     sbase + (c - c_org) - (adj before c - gcum_a)          (gcum_a = adj at c_org)
- * Threads tid, tid+nthreads, ... own 16-byte *address-aligned* chunks of dst.
- */
-__device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, u32 c_org, const u32* G_col,
-                                         const u32* G_cum, const u32* G_adj, int ga, int gb,
-                                         u32 gcum_a, u64 sbase, const RowSrc& src, u32 tid,
-                                         u32 nthreads, u64* bad_base_pos) {
-  if (N == 0) return;
-  const u64 A = (u64)dst, E = A + N;
-  const u64 first = A >> 4, last = (E - 1) >> 4;
-  for (u64 ch = first + tid; ch <= last; ch += nthreads) {
-    const u64 base_addr = ch << 4;
-    const u32 a0 = base_addr < A ? (u32)(A - base_addr) : 0u;
-    const u32 b0 = base_addr + 16 > E ? (u32)(E - base_addr) : 16u;
-    const u32 cz = c0 + (u32)(base_addr - A); /* column of chunk byte 0 (wraps for the head) */
-    u32 c = cz + a0;
-    const u32 c_end = cz + b0;
-    /* last gap entry in [ga, gb) that starts at or before c */
-    int lo = ga, hi = gb;
-    while (lo < hi) {
-      int mid = (lo + hi) >> 1;
-      if (G_col[mid] <= c)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    int i = lo - 1;
-    bool in_gap = false;
-    u32 gap_end = 0, cum = gcum_a;
-    if (i >= ga) {
-      u32 gs = G_col[i];
-      u32 gl = G_cum[i + 1] - G_cum[i];
-      if (c - gs < gl) {
-        in_gap = true;
-        gap_end = gs + gl;
-      }
-      cum = G_adj[i + 1];
-    }
-    u32 o[4] = {0u, 0u, 0u, 0u};
-    while (c < c_end) {
-      if (in_gap) {
-        u32 pe = gap_end < c_end ? gap_end : c_end;
-        const u32 dash[4] = {0x2D2D2D2Du, 0x2D2D2D2Du, 0x2D2D2D2Du, 0x2D2D2D2Du};
-        merge16(o, dash, (int)(c - cz), (int)(pe - cz));
-        c = pe;
-        in_gap = false;
-      } else {
-        u32 next_gs = (i + 1 < gb) ? G_col[i + 1] : 0xFFFFFFFFu;
-        u32 pe = next_gs < c_end ? next_gs : c_end;
-        if (pe > c) {
-          const int pa = (int)(c - cz), pb = (int)(pe - cz);
-          const i64 S = (i64)sbase + (i64)(int)(cz - c_org) - (i64)(int)(cum - gcum_a);
-          u32 W[4], inv[4];
-          load_window(src, S, pa, pb, W, inv);
-          if (src.rc) { /* InvalidBase: first offender in reversed order = smallest q' index */
+/* InvalidBase: first offender in reversed order = smallest q' index */
+__device__ __forceinline__ void flag_bad_bases(const u32 inv[4], int pa, int pb, i64 S,
+                                               const u32x4_a16* lm, u64* bad_base_pos) {
+  const u32x4_a16 hi = lm[pb], lo = lm[pa];
+  if (((inv[0] & hi[0] & ~lo[0]) | (inv[1] & hi[1] & ~lo[1]) | (inv[2] & hi[2] & ~lo[2]) |
+       (inv[3] & hi[3] & ~lo[3])) == 0u)
+    return;
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-              u32 bad = inv[d] & bytemask(pa - 4 * d, pb - 4 * d);
-              if (bad) {
-                int j = 4 * d + ((__ffsll((unsigned long long)bad) - 1) >> 3);
-                atomicMin(bad_base_pos, (u64)(S + j));
-              }
-            }
-          }
-          merge16(o, W, pa, pb);
-          c = pe;
-        }
-        if (c < c_end) { /* c == start of gap i+1 */
-          i++;
-          u32 gs = G_col[i];
-          u32 gl = G_cum[i + 1] - G_cum[i];
-          if (gl) {
-            in_gap = true;
-            gap_end = gs + gl;
-          }
-          cum = G_adj[i + 1];
-        }
-      }
+  for (int d = 0; d < 4; d++) {
+    u32 bad = inv[d] & hi[d] & ~lo[d];
+    if (bad) {
+      int j = 4 * d + ((__ffsll((unsigned long long)bad) - 1) >> 3);
+      atomicMin(bad_base_pos, (u64)(S + j));
     }
-    if (a0 == 0u && b0 == 16u) {
-      u32x4_a16 v = {o[0], o[1], o[2], o[3]};
-      *(u32x4_a16*)base_addr = v;
-    } else { /* partial chunk at a row / tile edge: byte stores, never read-modify-write */
-      u8* p = (u8*)base_addr;
-      for (u32 j = a0; j < b0; j++) {
-        u32 d = j >> 2;
-        u32 word = d == 0 ? o[0] : d == 1 ? o[1] : d == 2 ? o[2] : o[3];
-        p[j] = (u8)(word >> (8u * (j & 3u)));
+  }
+}
+
+/* Row description shared by the emitters.  The row's events inside [c0, c0+N) are entries
+ * [ga, gb) of a compacted list (G_col = tile-relative start column, G_cum = exclusive prefix of
+ * gap bases — an entry's gap length is G_cum[i+1]-G_cum[i], entry gb is readable — and G_adj =
+ * exclusive prefix of the source adjustment: gap bases minus skipped source bases, as wrapping
+ * u32; for paf2maf rows G_adj == G_cum).  A non-gap column c reads slice index
+ *     sbase + (c - c_org) - (adj before c - gcum_a)          (gcum_a = adj at c_org) */
+struct RowDesc {
+  u32 c_org;
+  const u32* G_col;
+  const u32* G_cum;
+  const u32* G_adj;
+  int ga, gb;
+  u32 gcum_a;
+  u64 sbase;
+  const u32x4_a16* lowmask;
+  const u32* tbl; /* granule table: T[j] = events (tile-wide index) that start before granule j */
+  u32 tsh;        /* bit offset of this row's counts inside a table word */
+  u32 gsh;        /* log2 of the granule width in columns (>= 4) */
+  u32* queue;     /* WGA_QCAP words per wave */
+};
+
+/* generic piece walk of one chunk from an arbitrary state (any number of pieces) */
+__device__ __forceinline__ void emit_walk(u32 o[4], u32 c, u32 c_end, u32 cz, int i, bool in_gap,
+                                          u32 gap_end, u32 cum, const RowDesc& rd,
+                                          const RowSrc& src, u64* bad_base_pos) {
+  while (c < c_end) {
+    if (in_gap) {
+      u32 pe = gap_end < c_end ? gap_end : c_end;
+      merge_dash(o, (int)(c - cz), (int)(pe - cz), rd.lowmask);
+      c = pe;
+      in_gap = false;
+    } else {
+      u32 next_gs = (i + 1 < rd.gb) ? rd.G_col[i + 1] : 0xFFFFFFFFu;
+      u32 pe = next_gs < c_end ? next_gs : c_end;
+      if (pe > c) {
+        const int pa = (int)(c - cz), pb = (int)(pe - cz);
+        const int off = (int)(cz - rd.c_org) - (int)(cum - rd.gcum_a);
+        WinRaw raw;
+        u32 W[4], inv[4];
+        win_issue(src, rd.sbase, off, pa, pb, raw);
+        win_finish(src, raw, W, inv);
+        if (src.rc) flag_bad_bases(inv, pa, pb, (i64)rd.sbase + off, rd.lowmask, bad_base_pos);
+        merge16(o, W, pa, pb, rd.lowmask);
+        c = pe;
+      }
+      if (c < c_end) { /* c == start of entry i+1 */
+        i++;
+        u32 gs = rd.G_col[i];
+        u32 gl = rd.G_cum[i + 1] - rd.G_cum[i];
+        if (gl) {
+          in_gap = true;
+          gap_end = gs + gl;
+        }
+        cum = rd.G_adj[i + 1];
       }
     }
   }
 }
 
-/* tail of a row when the fetched slice is longer than the CIGAR consumes: plain copy */
-__device__ __forceinline__ void emit_tail(u8* dst, u64 n, u64 sbase, const RowSrc& src, u32 tid,
-                                          u32 nthreads, u64* bad_base_pos) {
+/* tell the compiler a value is wave-uniform so that it lives in SGPRs (scalar loads, no VGPRs) */
+#ifdef WGA_EMU
+#define WGA_UNI32(x) ((u32)(x))
+#define WGA_UNI64(x) ((u64)(x))
+#else
+#define WGA_UNI32(x) ((u32)__builtin_amdgcn_readfirstlane((int)(x)))
+#define WGA_UNI64(x)                                                               \
+  (((u64)(u32)__builtin_amdgcn_readfirstlane((int)((u64)(x) >> 32)) << 32) |       \
+   (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(u64)(x)))
+#endif
+
+#ifdef WGA_EMU
+#define WGA_CLOCK() 0ull
+#else
+#define WGA_CLOCK() ((u64)__builtin_amdgcn_s_memtime())
+#endif
+
+/* lanes of a wave exchange data through LDS: hardware runs them in lockstep (only the compiler
+ * must not reorder), the emulator needs a real wave barrier */
+#ifdef WGA_EMU
+#define WGA_WAVE_SYNC() emu::barrier_wait(emu::S().wave_bar[emu::flat_tid() >> 6])
+#else
+#define WGA_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
+#define WGA_TBL_SHIFT 4u                          /* granule = 16 columns */
+#define WGA_TBL_COLS 32768u                       /* widest tile the granule table covers */
+#define WGA_TBL_N (WGA_TBL_COLS >> WGA_TBL_SHIFT) /* 2048 granules (+2 sentinels) */
+#define WGA_QCAP 192u                             /* per-wave queue of complex chunks */
+
+/* Chunks are the 16-column granules of the tile-relative column space (so the granule table
+ * classifies them exactly); their output address is whatever it is — stores are byte-aligned
+ * 16-byte stores.  Only the first / last granule of a row span can be partial. */
+struct ChunkGeom {
+  u8* p;      /* address of byte 0 of the granule (may lie before the row for a head granule) */
+  u32 a0, b0; /* valid bytes [a0, b0) of the 16 */
+  u32 cz;     /* column of byte 0 */
+  u32 c, c_end;
+};
+struct RowGeom {
+  u8* base;    /* address of column 16*j0 */
+  u32 j0;      /* first granule */
+  u32 head;    /* c0 & 15 */
+  u32 nchunks; /* granules touched by [c0, c0+N) */
+  u32 last_b0; /* valid end of the last granule (1..16) */
+};
+__device__ __forceinline__ RowGeom row_geom(u8* dst, u32 N, u32 c0) {
+  RowGeom r;
+  r.head = c0 & 15u;
+  r.j0 = c0 >> 4;
+  r.base = dst - r.head; /* pointer arithmetic: stores stay global_store */
+  r.nchunks = (r.head + N + 15u) >> 4;
+  r.last_b0 = ((r.head + N - 1u) & 15u) + 1u;
+  return r;
+}
+__device__ __forceinline__ ChunkGeom chunk_geom(const RowGeom& r, u32 rel) {
+  ChunkGeom g;
+  g.p = r.base + (rel << 4);
+  g.a0 = rel == 0u ? r.head : 0u;
+  g.b0 = rel == r.nchunks - 1u ? r.last_b0 : 16u;
+  g.cz = (r.j0 + rel) << 4;
+  g.c = g.cz + g.a0;
+  g.c_end = g.cz + g.b0;
+  return g;
+}
+__device__ __forceinline__ void chunk_store(const ChunkGeom& g, const u32 o[4], int ablate = 0) {
+  if (ablate & 4) {
+    if (o[0] == 0x12345678u && o[1] == 0x9ABCDEF0u && o[3] == 7u) *(u32*)g.p = o[2];
+    return;
+  }
+  if (g.a0 == 0u && g.b0 == 16u) {
+    u32x4_a1 v = {o[0], o[1], o[2], o[3]};
+    *(u32x4_a1*)g.p = v;
+  } else { /* partial chunk at a row / tile edge: byte stores, never read-modify-write */
+    u8* p = g.p;
+    for (u32 j = g.a0; j < g.b0; j++) {
+      u32 d = j >> 2;
+      u32 word = d == 0 ? o[0] : d == 1 ? o[1] : d == 2 ? o[2] : o[3];
+      p[j] = (u8)(word >> (8u * (j & 3u)));
+    }
+  }
+}
+
+/* i = last entry in [ga, gb) whose column is <= c, or ga-1: two table reads and a walk over the
+ * entries of one granule (0..1 entries when the granule is 16 columns wide). */
+__device__ __forceinline__ int find_entry(const RowDesc& rd, u32 c) {
+  const int ga = rd.ga, gb = rd.gb;
+  const u32 j = c >> rd.gsh;
+  int k = (int)((rd.tbl[j] >> rd.tsh) & 0xFFFFu);
+  const int hi = (int)((rd.tbl[j + 1] >> rd.tsh) & 0xFFFFu);
+  while (k < hi && rd.G_col[k] <= c) k++;
+  k -= 1;
+  return k < ga ? ga - 1 : (k >= gb ? gb - 1 : k);
+}
+
+/* A chunk that touches an event boundary: copy0 | gap1 | copy1 (possibly starting inside gap0)
+ * with at most two source windows.  Split so that its loads can be in flight together with
+ * the fast path's: complex_issue looks the events up and issues the windows, complex_finish
+ * assembles and stores; more than two events inside 16 columns continue in emit_walk. */
+struct ComplexState {
+  ChunkGeom g;
+  WinRaw r0, r1;
+  u32 a1, b1, e1, b2, gs1, adj1;
+  int off0, off1, n1;
+  bool in_gap0, need0, need1, hasB;
+};
+
+__device__ __forceinline__ void complex_issue(ComplexState& st, const ChunkGeom& g, int i,
+                                              const RowDesc& rd, const RowSrc& src) {
+  const int ga = rd.ga, gb = rd.gb;
+  const u32 c = g.c, c_end = g.c_end, cz = g.cz;
+  st.g = g;
+  bool in_gap0 = false;
+  u32 gap0_end = 0, adj0 = rd.gcum_a;
+  if (i >= ga) {
+    const u32 gs0 = rd.G_col[i];
+    const u32 gl0 = rd.G_cum[i + 1] - rd.G_cum[i];
+    if (c - gs0 < gl0) {
+      in_gap0 = true;
+      gap0_end = gs0 + gl0;
+    }
+    adj0 = rd.G_adj[i + 1];
+  }
+  const int n1 = i + 1;
+  const u32 gs1 = n1 < gb ? rd.G_col[n1] : 0xFFFFFFFFu;
+  const int offz = (int)(cz - rd.c_org);
+  u32 gl1 = 0u, adj1 = adj0, gs2 = 0xFFFFFFFFu;
+  const bool hasB = gs1 < c_end;
+  if (hasB) {
+    gl1 = rd.G_cum[n1 + 1] - rd.G_cum[n1];
+    adj1 = rd.G_adj[n1 + 1];
+    if (n1 + 1 < gb) gs2 = rd.G_col[n1 + 1];
+  }
+  st.in_gap0 = in_gap0;
+  st.hasB = hasB;
+  st.n1 = n1;
+  st.gs1 = gs1;
+  st.adj1 = adj1;
+  st.a1 = in_gap0 ? (gap0_end < c_end ? gap0_end : c_end) : c; /* copy piece 0 */
+  st.b1 = hasB ? gs1 : c_end;
+  st.e1 = hasB ? (gs1 + gl1 < c_end ? gs1 + gl1 : c_end) : c_end; /* end of gap 1 */
+  st.b2 = gs2 < c_end ? gs2 : c_end;                              /* copy piece 1 */
+  st.need0 = st.b1 > st.a1;
+  st.need1 = hasB && st.b2 > st.e1;
+  st.off0 = offz - (int)(adj0 - rd.gcum_a);
+  st.off1 = offz - (int)(adj1 - rd.gcum_a);
+  if (st.need0) win_issue(src, rd.sbase, st.off0, (int)(st.a1 - cz), (int)(st.b1 - cz), st.r0);
+  if (st.need1) win_issue(src, rd.sbase, st.off1, (int)(st.e1 - cz), (int)(st.b2 - cz), st.r1);
+}
+
+__device__ __forceinline__ void complex_finish(const ComplexState& st, const RowDesc& rd,
+                                               const RowSrc& src, u64* bad_base_pos) {
+  const u32 cz = st.g.cz, c = st.g.c, c_end = st.g.c_end;
+  u32 o[4] = {0u, 0u, 0u, 0u};
+  if (st.in_gap0) merge_dash(o, (int)(c - cz), (int)(st.a1 - cz), rd.lowmask);
+  if (st.need0) {
+    u32 W[4], inv[4];
+    win_finish(src, st.r0, W, inv);
+    if (src.rc)
+      flag_bad_bases(inv, (int)(st.a1 - cz), (int)(st.b1 - cz), (i64)rd.sbase + st.off0, rd.lowmask, bad_base_pos);
+    merge16(o, W, (int)(st.a1 - cz), (int)(st.b1 - cz), rd.lowmask);
+  }
+  if (st.hasB) {
+    merge_dash(o, (int)(st.gs1 - cz), (int)(st.e1 - cz), rd.lowmask);
+    if (st.need1) {
+      u32 W[4], inv[4];
+      win_finish(src, st.r1, W, inv);
+      if (src.rc)
+        flag_bad_bases(inv, (int)(st.e1 - cz), (int)(st.b2 - cz), (i64)rd.sbase + st.off1, rd.lowmask, bad_base_pos);
+      merge16(o, W, (int)(st.e1 - cz), (int)(st.b2 - cz), rd.lowmask);
+    }
+    if (st.b2 < c_end) /* a third event inside 16 columns: rare, generic walk from there */
+      emit_walk(o, st.b2, c_end, cz, st.n1, false, 0u, st.adj1, rd, src, bad_base_pos);
+  }
+  chunk_store(st.g, o, src.ablate);
+}
+
+/*
+ * Emit N (<= 2^31) bytes of one gapped row to dst; output byte k is tile-relative column c0 + k.
+ * Threads tid, tid+nthreads, ... own 16-byte *address-aligned* chunks of dst, so a wave writes
+ * 1 KiB with one coalesced 16 B/lane store.  Two-speed: a chunk that lies inside one copy piece
+ * (or one gap) — ~4 of 5 — is finished on the spot with one source window and no masking; a
+ * chunk that touches an event boundary is pushed to the wave's LDS queue, and the queue is
+ * drained 64 chunks at a time by complex_chunk, so the expensive path always runs with full
+ * lanes instead of taxing every wave iteration.
+ */
+#define WGA_EMIT_U 2 /* chunks in flight per lane */
+
+__device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& rd,
+                                         const RowSrc& src, u32 tid, u32 nthreads,
+                                         u64* bad_base_pos) {
+  if (N == 0) return;
+  const u32 lane = tid & 63u;
+  const RowGeom rg = row_geom(dst, N, c0);
+  const int ga = rd.ga;
+  u32* const queue = rd.queue + (tid >> 6) * WGA_QCAP;
+  u32 qn = 0; /* wave-uniform queue length */
+  const u32 per_it = nthreads * WGA_EMIT_U;
+  const u32 niter = (rg.nchunks + per_it - 1) / per_it;
+  const bool head_full = rg.head == 0u, tail_full = rg.last_b0 == 16u;
+  const bool row_fast = src.safe && !(src.ablate & 32);
+#pragma nounroll
+  for (u32 it = 0; it < niter; it++) {
+    /* Fast path: a full 16-column granule that no event touches (or that lies wholly inside
+     * one gap), from a row whose windows need no bounds checks, with only valid bases.  It is
+     * written branch-free — unconditional, index-clamped LDS reads and selects, one predicated
+     * load and one predicated store per chunk — and WGA_EMIT_U chunks per lane go through it
+     * together (all lookups, then all loads, then all stores).  Everything else is deferred to
+     * the queue; complex_issue/finish handle every case. */
+    u32 rel[WGA_EMIT_U];
+    int off0[WGA_EMIT_U];
+    bool act[WGA_EMIT_U], cand[WGA_EMIT_U], wgap[WGA_EMIT_U];
+    WinRaw raw[WGA_EMIT_U];
+#pragma unroll
+    for (int u = 0; u < WGA_EMIT_U; u++) {
+      rel[u] = (it * WGA_EMIT_U + (u32)u) * nthreads + tid;
+      act[u] = rel[u] < rg.nchunks;
+      const u32 relc = act[u] ? rel[u] : 0u;
+      const u32 cz = (rg.j0 + relc) << 4;
+      const u32 jg = cz >> rd.gsh;
+      const u32 t0 = (rd.tbl[jg] >> rd.tsh) & 0xFFFFu, t1 = (rd.tbl[jg + 1] >> rd.tsh) & 0xFFFFu;
+      int i = (int)t0 - 1;
+      i = i < ga ? ga - 1 : i;
+      const bool has = i >= ga;
+      const int ic = has ? i : ga; /* always a readable index */
+      const u32 gs0 = rd.G_col[ic], cum0 = rd.G_cum[ic], cum1 = rd.G_cum[ic + 1];
+      const u32 adj1 = rd.G_adj[ic + 1];
+      const u32 gl0 = cum1 - cum0;
+      const u32 c = cz + (relc == 0u ? rg.head : 0u);
+      const bool in_gap0 = has && (c - gs0 < gl0);
+      wgap[u] = in_gap0 && (gs0 + gl0 >= cz + 16u);
+      const u32 adj0 = has ? adj1 : rd.gcum_a;
+      const bool full = (relc != 0u || head_full) && (relc != rg.nchunks - 1u || tail_full);
+      cand[u] = act[u] && full && t0 == t1 && (wgap[u] || !in_gap0) && row_fast;
+      off0[u] = (int)(cz - rd.c_org) - (int)(adj0 - rd.gcum_a);
+    }
+#pragma unroll
+    for (int u = 0; u < WGA_EMIT_U; u++)
+      if (cand[u]) win_issue(src, rd.sbase, off0[u], 0, 16, raw[u]);
+#pragma unroll
+    for (int u = 0; u < WGA_EMIT_U; u++) {
+      bool cx = act[u] && !cand[u];
+      if (cand[u]) {
+        u32 o[4], inv[4];
+        win_finish(src, raw[u], o, inv);
+        if (wgap[u]) {
+          o[0] = o[1] = o[2] = o[3] = 0x2D2D2D2Du;
+          inv[0] = inv[1] = inv[2] = inv[3] = 0u;
+        }
+        if ((inv[0] | inv[1] | inv[2] | inv[3]) == 0u) {
+          if (!(src.ablate & 4)) {
+            u32x4_a1 v = {o[0], o[1], o[2], o[3]};
+            *(u32x4_a1*)(rg.base + (rel[u] << 4)) = v;
+          }
+        } else {
+          cx = true; /* an invalid base: the complex path finds and reports it */
+        }
+      }
+      /* compact the complex chunks into the wave queue */
+      if (src.ablate & 16) cx = false;
+      const u64 m = __ballot(cx);
+      if (m) {
+        if (cx) queue[qn + (u32)__popcll(m & ((1ull << lane) - 1ull))] = rel[u];
+        qn += (u32)__popcll(m);
+      }
+    }
+    WGA_WAVE_SYNC();
+    /* drain the queue 64 chunks at a time, and whatever is left when the row ends */
+    const bool last = it + 1 >= niter;
+    while (qn >= 64u || (last && qn > 0u)) {
+      const u32 take = qn < 64u ? qn : 64u;
+      qn -= take;
+      if (lane < take) {
+        const ChunkGeom g = chunk_geom(rg, queue[qn + lane]);
+        ComplexState cst;
+        complex_issue(cst, g, find_entry(rd, g.c), rd, src);
+        complex_finish(cst, rd, src, bad_base_pos);
+      }
+      WGA_WAVE_SYNC(); /* the drained slots are rewritten by the next pushes */
+    }
+  }
+}
+
+/* finish a RowSrc: the wave-uniform 64-bit part of every window address of this row */
+__device__ __forceinline__ void rowsrc_prepare(RowSrc& s, u64 sbase) {
+  s.safe = s.src_off >= 16 && s.src_off + s.src_len + 16 <= s.fa_bytes;
+  s.win_base = s.rc ? s.fa + s.src_off + s.src_len - 16 - sbase : s.fa + s.src_off + sbase;
+}
+
+/* tail of a row when the fetched slice is longer than the CIGAR consumes: plain copy.  `zero2`
+ * = two zero words in LDS (an empty granule table), `dummy` = any readable LDS array. */
+__device__ __forceinline__ void emit_tail(u8* dst, u64 n, u64 sbase, RowSrc src,
+                                          const u32x4_a16* lowmask, u32* queue, const u32* zero2,
+                                          const u32* dummy, u32 tid, u32 nthreads,
+                                          u64* bad_base_pos) {
   u64 done = 0;
   while (done < n) {
     u64 m = n - done;
     if (m > (1ull << 30)) m = 1ull << 30;
-    emit_row(dst + done, (u32)m, 0u, 0u, (const u32*)0, (const u32*)0, (const u32*)0, 0, 0, 0u,
-             sbase + done, src, tid, nthreads, bad_base_pos);
+    RowDesc rd;
+    rd.c_org = 0u;
+    rd.G_col = rd.G_cum = rd.G_adj = dummy;
+    rd.ga = rd.gb = 0;
+    rd.gcum_a = 0u;
+    rd.sbase = sbase + done;
+    rd.lowmask = lowmask;
+    rd.tbl = zero2;
+    rd.tsh = 0u;
+    rd.gsh = 31u;
+    rd.queue = queue;
+    rowsrc_prepare(src, rd.sbase);
+    emit_row(dst + done, (u32)m, 0u, rd, src, tid, nthreads, bad_base_pos);
     done += m;
   }
 }
@@ -580,38 +897,104 @@ __device__ __forceinline__ u8 src_byte(const RowSrc& src, u64 sidx, u64* bad_bas
   return o;
 }
 
+/* Per-record geometry gathered once (k_rec_desc) so that the expand kernel fetches one compact
+ * struct per segment instead of ten scattered values; per-tile base sums of the record that
+ * continues into a tile (k_tile_base) so that it never walks tile summaries itself. */
+struct wga_rec_desc {
+  u64 t_row_off, q_row_off;
+  u64 t_src_off, t_src_len, q_src_off, q_src_len;
+  u64 I_total, D_total, L;
+  u64 neg;
+};
+struct wga_tile_base {
+  u64 mx, i, d;
+};
+
+__global__ __launch_bounds__(256) void k_rec_desc(u32 n, const wga_cigar_counts* counts,
+                                                  const u8* strand_neg, const u64* t_src_off,
+                                                  const u64* t_src_len, const u64* q_src_off,
+                                                  const u64* q_src_len, const u64* t_row_off,
+                                                  const u64* q_row_off, wga_rec_desc* out) {
+  u32 r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= n) return;
+  const wga_cigar_counts cn = counts[r];
+  wga_rec_desc d;
+  d.t_row_off = t_row_off[r];
+  d.q_row_off = q_row_off[r];
+  d.t_src_off = t_src_off[r];
+  d.t_src_len = t_src_len[r];
+  d.q_src_off = q_src_off[r];
+  d.q_src_len = q_src_len[r];
+  d.I_total = cn.ins_bp + cn.inv_ins_bp;
+  d.D_total = cn.del_bp + cn.inv_del_bp;
+  d.L = cn.match + cn.mismatch + d.I_total + d.D_total;
+  d.neg = strand_neg[r] != 0 ? 1 : 0;
+  out[r] = d;
+}
+
+/* one wave per tile: class sums of the tile's first record before the tile = tail of the tile
+ * where the record starts + totals of the tiles in between (summaries are read 64 at a time) */
+__global__ __launch_bounds__(256) void k_tile_base(const u64* op_off, u64 n_ops,
+                                                   const wga_tile_sum* tiles,
+                                                   wga_tile_base* bases) {
+  const u32 lane = threadIdx.x & 63u;
+  const u64 g = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const u64 tile_start = g * WGA_TILE;
+  if (tile_start >= n_ops) return;
+  const u64 rs = op_off[tiles[g].rec];
+  u64 p_mx = 0, p_i = 0, p_d = 0;
+  if (rs < tile_start) {
+    const u64 g0 = rs / WGA_TILE;
+    for (u64 k = g0 + lane; k < g; k += 64) {
+      const u64* v = (k == g0) ? tiles[k].tail : tiles[k].tot;
+      p_mx += v[CLS_MX];
+      p_i += v[CLS_I];
+      p_d += v[CLS_D];
+    }
+  }
+  p_mx = wave_sum_u64(p_mx);
+  p_i = wave_sum_u64(p_i);
+  p_d = wave_sum_u64(p_d);
+  if (lane == 0) {
+    wga_tile_base b;
+    b.mx = p_mx;
+    b.i = p_i;
+    b.d = p_d;
+    bases[g] = b;
+  }
+}
+
 struct ExpandArgs {
   const u32* ops;
   const u64* op_off;
-  const u8* strand_neg;
-  u32 n;
   u64 n_ops;
-  const wga_cigar_counts* counts;
   const wga_tile_sum* tiles;
+  const wga_tile_base* bases;
+  const wga_rec_desc* recs;
   const u8* t_fa;
   u64 t_fa_bytes;
-  const u64* t_src_off;
-  const u64* t_src_len;
   const u8* q_fa;
   u64 q_fa_bytes;
-  const u64* q_src_off;
-  const u64* q_src_len;
   u8* out;
-  const u64* t_row_off;
-  const u64* q_row_off;
   wga_rec_diag* diag;
   int force_slow;
+  int no_table; /* test knob: 256-column granules (the coarse-table path of very wide tiles) */
+  int ablate;   /* profiling knob: 1 = stop after phase A, 2 = no source loads, 4 = no stores */
+  u64* dbg;     /* profiling: 8 s_memtime stamps per tile (NULL: off) */
 };
 
 __global__ __launch_bounds__(256) void k_paf2maf_expand(ExpandArgs a) {
   __shared__ u32 s_col[WGA_TILE + 1];    /* tile-relative exclusive column prefix per op      */
   __shared__ u32 s_ev[WGA_TILE + 1];     /* exclusive (#I-class ops | #D-class ops << 16)     */
-  __shared__ u32 s_tg_col[WGA_TILE + 1]; /* target-row gaps (I ops): start column             */
-  __shared__ u32 s_tg_cum[WGA_TILE + 1]; /*                           gap bases before        */
-  __shared__ u32 s_qg_col[WGA_TILE + 1]; /* query-row gaps (D ops)                            */
-  __shared__ u32 s_qg_cum[WGA_TILE + 1];
+  __shared__ u32 s_tg_col[WGA_TILE + 2]; /* target-row gaps (I ops): start column             */
+  __shared__ u32 s_tg_cum[WGA_TILE + 2]; /*                           gap bases before        */
+  __shared__ u32 s_qg_col[WGA_TILE + 2]; /* query-row gaps (D ops)                            */
+  __shared__ u32 s_qg_cum[WGA_TILE + 2];
+  __shared__ u32 s_zero2[2];
   __shared__ u64 s_w[5];
-  __shared__ u64 s_red[4][3];
+  __shared__ u32x4_a16 s_lowmask[17];
+  __shared__ u32 s_tbl[WGA_TBL_N + 2];   /* entries before each 16-column granule: I | D<<16  */
+  __shared__ u32 s_queue[4 * WGA_QCAP];  /* per-wave queues of complex chunks                 */
 
   const u32 tid = threadIdx.x;
   const u32 lane = tid & 63u, wave = tid >> 6;
@@ -619,10 +1002,20 @@ __global__ __launch_bounds__(256) void k_paf2maf_expand(ExpandArgs a) {
   const u64 tile_start = g * WGA_TILE;
   const u64 tile_end = tile_start + WGA_TILE < a.n_ops ? tile_start + WGA_TILE : a.n_ops;
   const u32 nt = (u32)(tile_end - tile_start);
+  build_lowmask(s_lowmask);
+  u64 stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (a.dbg) stamp[0] = WGA_CLOCK();
 
   const wga_tile_sum tsum = a.tiles[g];
   const u64 tile_cols = tsum.tot[CLS_MX] + tsum.tot[CLS_I] + tsum.tot[CLS_D];
   const bool fast = !a.force_slow && tile_cols <= WGA_FAST_COL_LIMIT;
+  /* granule width: 16 columns unless the tile is wider than the table covers */
+  u32 gsh = a.no_table ? 8u : WGA_TBL_SHIFT;
+  while ((tile_cols >> gsh) >= WGA_TBL_N) gsh++;
+  const bool use_tbl = fast;
+  if (use_tbl)
+    for (u32 k = tid; k < WGA_TBL_N; k += WGA_BLOCK) s_tbl[k] = 0u;
+  if (tid < 2u) s_zero2[tid] = 0u;
 
   /* ---- phase A: 4 consecutive ops per thread, block scan into LDS -------------------------- */
   u32 opw[4];
@@ -638,8 +1031,8 @@ __global__ __launch_bounds__(256) void k_paf2maf_expand(ExpandArgs a) {
       for (int e = 0; e < 4; e++) opw[e] = (base + e < nt) ? a.ops[tile_start + base + e] : 0u;
     }
   }
-  u32 e_col[4], e_i[4], e_d[4], cls[4];
   if (fast) {
+    u32 cls[4];
     u32 l[4], sl = 0, si = 0, sd = 0, cnt = 0;
     for (int e = 0; e < 4; e++) {
       u32 code = opw[e] & 15u, len = opw[e] >> 4;
@@ -658,37 +1051,57 @@ __global__ __launch_bounds__(256) void k_paf2maf_expand(ExpandArgs a) {
     u32 x_col = (u32)exA, x_i = (u32)(exA >> 32), x_d = (u32)exB, x_cnt = (u32)(exB >> 32);
     for (int e = 0; e < 4; e++) {
       u32 k = tid * 4u + (u32)e;
-      e_col[e] = x_col;
-      e_i[e] = x_i;
-      e_d[e] = x_d;
       s_col[k] = x_col;
       s_ev[k] = x_cnt;
       if (cls[e] == CLS_I) {
         s_tg_col[x_cnt & 0xFFFFu] = x_col;
         s_tg_cum[x_cnt & 0xFFFFu] = x_i;
+        if (use_tbl) atomicAdd(&s_tbl[x_col >> gsh], 1u);
         x_i += opw[e] >> 4;
         x_cnt += 1u;
       } else if (cls[e] == CLS_D) {
         s_qg_col[x_cnt >> 16] = x_col;
         s_qg_cum[x_cnt >> 16] = x_d;
+        if (use_tbl) atomicAdd(&s_tbl[x_col >> gsh], 0x10000u);
         x_d += opw[e] >> 4;
         x_cnt += 0x10000u;
       }
       x_col += l[e];
     }
-    if (tid == WGA_BLOCK - 1) { /* sentinels: totals */
+    if (tid == WGA_BLOCK - 1) { /* sentinels: totals (two, so that index i+1 is always readable) */
       s_col[WGA_TILE] = x_col;
       s_ev[WGA_TILE] = x_cnt;
       s_tg_col[x_cnt & 0xFFFFu] = x_col;
       s_tg_cum[x_cnt & 0xFFFFu] = x_i;
+      s_tg_col[(x_cnt & 0xFFFFu) + 1u] = x_col;
+      s_tg_cum[(x_cnt & 0xFFFFu) + 1u] = x_i;
       s_qg_col[x_cnt >> 16] = x_col;
       s_qg_cum[x_cnt >> 16] = x_d;
+      s_qg_col[(x_cnt >> 16) + 1u] = x_col;
+      s_qg_cum[(x_cnt >> 16) + 1u] = x_d;
+    }
+    if (use_tbl) { /* per-granule counts -> exclusive prefix (tile-wide entry index) */
+      __syncthreads();
+      u32 v[WGA_TBL_N / WGA_BLOCK], sum = 0;
+      for (u32 e = 0; e < WGA_TBL_N / WGA_BLOCK; e++) {
+        v[e] = s_tbl[tid * (WGA_TBL_N / WGA_BLOCK) + e];
+        sum += v[e];
+      }
+      u64 tot;
+      u32 run = (u32)block_excl_scan_u64((u64)sum, s_w, &tot); /* both 16-bit halves <= 1024 */
+      for (u32 e = 0; e < WGA_TBL_N / WGA_BLOCK; e++) {
+        s_tbl[tid * (WGA_TBL_N / WGA_BLOCK) + e] = run;
+        run += v[e];
+      }
+      if (tid == WGA_BLOCK - 1) s_tbl[WGA_TBL_N] = s_tbl[WGA_TBL_N + 1] = run;
     }
   }
   __syncthreads();
 
+  if (a.dbg) stamp[1] = WGA_CLOCK();
+  if (a.ablate & 1) return;
   /* ---- phase B: walk the record segments of this tile ------------------------------------- */
-  u32 r = wga_find_rec(a.op_off, a.n, tile_start);
+  u32 r = WGA_UNI32((u32)tsum.rec);
   u64 cur = tile_start;
   while (cur < tile_end) {
     u64 re = a.op_off[r + 1];
@@ -700,90 +1113,75 @@ __global__ __launch_bounds__(256) void k_paf2maf_expand(ExpandArgs a) {
     const u64 seg_end = re < tile_end ? re : tile_end;
     const u32 ka = (u32)(cur - tile_start), kb = (u32)(seg_end - tile_start);
 
-    /* class sums of this record before the tile: summaries of tiles g0..g-1 (tail of g0) */
+    /* class sums of this record before the tile (only the tile's first segment can continue a
+     * record; k_tile_base worked them out) and the record's geometry (k_rec_desc) */
     u64 b_mx = 0, b_i = 0, b_d = 0;
-    if (rs < tile_start) { /* block-uniform: only the first segment can continue a record */
-      const u64 g0 = rs / WGA_TILE;
-      u64 p_mx = 0, p_i = 0, p_d = 0;
-      for (u64 k = g0 + tid; k < g; k += WGA_BLOCK) {
-        const wga_tile_sum* t = a.tiles + k;
-        const u64* v = (k == g0) ? t->tail : t->tot;
-        p_mx += v[CLS_MX];
-        p_i += v[CLS_I];
-        p_d += v[CLS_D];
-      }
-      p_mx = wave_sum_u64(p_mx);
-      p_i = wave_sum_u64(p_i);
-      p_d = wave_sum_u64(p_d);
-      __syncthreads();
-      if (lane == 0) {
-        s_red[wave][0] = p_mx;
-        s_red[wave][1] = p_i;
-        s_red[wave][2] = p_d;
-      }
-      __syncthreads();
-      for (int w2 = 0; w2 < 4; w2++) {
-        b_mx += s_red[w2][0];
-        b_i += s_red[w2][1];
-        b_d += s_red[w2][2];
-      }
+    if (rs < tile_start) {
+      const wga_tile_base tbs = a.bases[g];
+      b_mx = tbs.mx;
+      b_i = tbs.i;
+      b_d = tbs.d;
     }
     const u64 cb = b_mx + b_i + b_d; /* record-relative column of the segment start */
     const u64 tb = b_mx + b_d;       /* target bases consumed before it              */
     const u64 qb = b_mx + b_i;       /* query bases consumed before it               */
 
-    const wga_cigar_counts cn = a.counts[r];
-    const u64 I_total = cn.ins_bp + cn.inv_ins_bp, D_total = cn.del_bp + cn.inv_del_bp;
-    const u64 L = cn.match + cn.mismatch + I_total + D_total;
+    const wga_rec_desc rdsc = a.recs[r];
+    const u64 I_total = rdsc.I_total, D_total = rdsc.D_total, L = rdsc.L;
     RowSrc ts, qs;
     ts.fa = a.t_fa;
     ts.fa_bytes = a.t_fa_bytes;
-    ts.src_off = a.t_src_off[r];
-    ts.src_len = a.t_src_len[r];
+    ts.src_off = rdsc.t_src_off;
+    ts.src_len = rdsc.t_src_len;
     ts.rc = false;
+    ts.ablate = qs.ablate = a.ablate;
     qs.fa = a.q_fa;
     qs.fa_bytes = a.q_fa_bytes;
-    qs.src_off = a.q_src_off[r];
-    qs.src_len = a.q_src_len[r];
-    qs.rc = a.strand_neg[r] != 0;
+    qs.src_off = rdsc.q_src_off;
+    qs.src_len = rdsc.q_src_len;
+    qs.rc = rdsc.neg != 0;
     const u64 t_row_len = ts.src_len + I_total, q_row_len = qs.src_len + D_total;
-    u8* const t_dst = a.out + a.t_row_off[r];
-    u8* const q_dst = a.out + a.q_row_off[r];
+    u8* const t_dst = a.out + rdsc.t_row_off;
+    u8* const q_dst = a.out + rdsc.q_row_off;
     u64* const bad_base = (u64*)&a.diag[r].bad_base_pos;
     u64* const panic_idx = (u64*)&a.diag[r].panic_op_idx;
 
+    u32 col_a = 0, seg_cols = 0, icum_a = 0, dcum_a = 0;
+    int ia = 0, ib = 0, ja = 0, jb = 0;
     if (fast) {
-      const u32 col_a = s_col[ka], seg_cols = s_col[kb] - col_a;
-      const u32 eva = s_ev[ka], evb = s_ev[kb];
-      const int ia = (int)(eva & 0xFFFFu), ib = (int)(evb & 0xFFFFu);
-      const int ja = (int)(eva >> 16), jb = (int)(evb >> 16);
-      const u32 icum_a = s_tg_cum[ia], dcum_a = s_qg_cum[ja];
+      col_a = WGA_UNI32(s_col[ka]);
+      seg_cols = WGA_UNI32(s_col[kb]) - col_a;
+      const u32 eva = WGA_UNI32(s_ev[ka]), evb = WGA_UNI32(s_ev[kb]);
+      ia = (int)(eva & 0xFFFFu);
+      ib = (int)(evb & 0xFFFFu);
+      ja = (int)(eva >> 16);
+      jb = (int)(evb >> 16);
+      icum_a = WGA_UNI32(s_tg_cum[ia]);
+      dcum_a = WGA_UNI32(s_qg_cum[ja]);
 
       /* String::insert_str panics when the insertion point is beyond the string
        * (cigar.rs:507,513): an I (D) op whose target (query) consumption so far exceeds the
-       * fetched slice */
-      for (int e = 0; e < 4; e++) {
-        u32 k = tid * 4u + (u32)e;
-        if (k >= ka && k < kb) {
-          if (cls[e] == CLS_I) {
-            u64 t_before = tb + (u64)(e_col[e] - col_a) - (u64)(e_i[e] - icum_a);
-            if (t_before > ts.src_len) atomicMin(panic_idx, tile_start + k - rs);
-          } else if (cls[e] == CLS_D) {
-            u64 q_before = qb + (u64)(e_col[e] - col_a) - (u64)(e_d[e] - dcum_a);
-            if (q_before > qs.src_len) atomicMin(panic_idx, tile_start + k - rs);
+       * fetched slice.  Checked on the compact gap lists; the exact op index is only worked out
+       * (serial rescan by the detecting thread) when that ever happens. */
+      bool pan = false;
+      for (int i = ia + (int)tid; i < ib; i += (int)WGA_BLOCK)
+        pan |= tb + (u64)(s_tg_col[i] - col_a) - (u64)(s_tg_cum[i] - icum_a) > ts.src_len;
+      for (int i = ja + (int)tid; i < jb; i += (int)WGA_BLOCK)
+        pan |= qb + (u64)(s_qg_col[i] - col_a) - (u64)(s_qg_cum[i] - dcum_a) > qs.src_len;
+      if (pan) {
+        u64 tp = tb, qp = qb;
+        for (u64 k = cur; k < seg_end; k++) {
+          const u32 op = a.ops[k];
+          const u32 c = op_class(op & 15u);
+          const u64 len = op >> 4;
+          if ((c == CLS_I && tp > ts.src_len) || (c == CLS_D && qp > qs.src_len)) {
+            atomicMin(panic_idx, k - rs);
+            break;
           }
+          if (c == CLS_MX || c == CLS_D) tp += len;
+          if (c == CLS_MX || c == CLS_I) qp += len;
         }
       }
-
-      /* rows end where the slice ends (a CIGAR that consumes more than was fetched) */
-      u64 x1t = cb + seg_cols < t_row_len ? cb + seg_cols : t_row_len;
-      if (x1t > cb)
-        emit_row(t_dst + cb, (u32)(x1t - cb), col_a, col_a, s_tg_col, s_tg_cum, s_tg_cum, ia, ib,
-                 icum_a, tb, ts, tid, WGA_BLOCK, bad_base);
-      u64 x1q = cb + seg_cols < q_row_len ? cb + seg_cols : q_row_len;
-      if (x1q > cb)
-        emit_row(q_dst + cb, (u32)(x1q - cb), col_a, col_a, s_qg_col, s_qg_cum, s_qg_cum, ja, jb,
-                 dcum_a, qb, qs, tid, WGA_BLOCK, bad_base);
     } else {
       /* u64 fallback for tiles wider than 2^31 columns: ops are walked serially (every thread
        * redundantly), each op's columns are written block-strided, one byte per store */
@@ -806,13 +1204,59 @@ __global__ __launch_bounds__(256) void k_paf2maf_expand(ExpandArgs a) {
       }
     }
 
-    /* the record ends in this tile: append what the slices hold beyond the CIGAR */
-    if (seg_end == re) {
-      if (t_row_len > L) emit_tail(t_dst + L, t_row_len - L, L - I_total, ts, tid, WGA_BLOCK, bad_base);
-      if (q_row_len > L) emit_tail(q_dst + L, q_row_len - L, L - D_total, qs, tid, WGA_BLOCK, bad_base);
+    /* Row jobs through ONE emit_row site (keeps the kernel small enough for the I-cache):
+     * 0/1 = this segment of the target / query row (rows end where a short slice ends);
+     * 2/3 = once the record ends in this tile, what the slices hold beyond the CIGAR. */
+    const bool rec_ends = seg_end == re;
+    if (a.dbg && stamp[2] == 0) stamp[2] = WGA_CLOCK();
+#pragma nounroll
+    for (int job = 0; job < 4; job++) {
+      if (a.dbg && job == 1 && stamp[3] == 0) stamp[3] = WGA_CLOCK();
+      if (a.dbg && job == 2 && stamp[4] == 0) stamp[4] = WGA_CLOCK();
+      const bool is_q = (job & 1) != 0, is_tail = job >= 2;
+      if (a.ablate & 8) continue;
+      const u64 row_len = is_q ? q_row_len : t_row_len;
+      u64 x0, nbytes;
+      if (!is_tail) {
+        if (!fast) continue;
+        const u64 x1 = cb + seg_cols < row_len ? cb + seg_cols : row_len;
+        x0 = cb;
+        nbytes = x1 > cb ? x1 - cb : 0;
+      } else {
+        if (!rec_ends) continue;
+        x0 = L;
+        nbytes = row_len > L ? row_len - L : 0;
+      }
+      if (nbytes == 0) continue;
+      RowSrc src = is_q ? qs : ts;
+      u8* const dst = (is_q ? q_dst : t_dst) + x0;
+      const u64 sb0 = is_tail ? L - (is_q ? D_total : I_total) : (is_q ? qb : tb);
+      for (u64 done = 0; done < nbytes; done += (1ull << 30)) {
+        const u64 m = nbytes - done < (1ull << 30) ? nbytes - done : (1ull << 30);
+        RowDesc rd;
+        rd.c_org = is_tail ? 0u : col_a;
+        rd.G_col = is_q ? s_qg_col : s_tg_col;
+        rd.G_cum = rd.G_adj = is_q ? s_qg_cum : s_tg_cum;
+        rd.ga = is_tail ? 0 : (is_q ? ja : ia);
+        rd.gb = is_tail ? 0 : (is_q ? jb : ib);
+        rd.gcum_a = is_tail ? 0u : (is_q ? dcum_a : icum_a);
+        rd.sbase = is_tail ? sb0 + done : sb0;
+        rd.lowmask = s_lowmask;
+        rd.tbl = is_tail ? s_zero2 : s_tbl;
+        rd.tsh = (is_q && !is_tail) ? 16u : 0u;
+        rd.gsh = is_tail ? 31u : gsh;
+        rd.queue = s_queue;
+        rowsrc_prepare(src, rd.sbase);
+        emit_row(dst + done, (u32)m, is_tail ? 0u : col_a + (u32)done, rd, src, tid, WGA_BLOCK, bad_base);
+      }
     }
     cur = seg_end;
     r++;
+    stamp[6] += 1;
+  }
+  if (a.dbg && tid == 0) {
+    stamp[5] = WGA_CLOCK();
+    for (int k = 0; k < 8; k++) a.dbg[g * 8 + k] = stamp[k];
   }
 }
 

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void k_class_tiles(const u32* __restrict__ ops
     }
   }
   u32 r = wga_find_rec(op_off, n, tile_start);
+  const u32 r_first = r;
   u64 cur = tile_start;
   u64 tot[5] = {0, 0, 0, 0, 0}, tail[5] = {0, 0, 0, 0, 0};
   while (cur < tile_end) {
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256) void k_class_tiles(const u32* __restrict__ ops
       ts.tot[c] = tot[c];
       ts.tail[c] = tail[c];
     }
+    ts.rec = r_first;
     tiles[g] = ts;
   }
 }
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void k_pafcov_accumulate(
       for (int e = 0; e < 4; e++) w[4 * j + e] = (base + e < nt) ? ops[tile_start + base + e] : 0u;
     }
   }
-  u32 r = wga_find_rec(op_off, n, tile_start);
+  u32 r = (u32)tiles[g].rec;
   u64 cur = tile_start;
   while (cur < tile_end) {
     u64 re = op_off[r + 1];
@@ -319,8 +321,8 @@ __device__ __forceinline__ u32 pseudo_symbol(u32 code) {
 
 /* fill N bytes whose value depends only on the op covering the column (symbol mode) */
 __device__ __forceinline__ void emit_symbols(u8* dst, u32 N, u32 c0, const u32* s_col,
-                                             const u32* s_sym, int ka, int kb, u32 tid,
-                                             u32 nthreads) {
+                                             const u32* s_sym, int ka, int kb,
+                                             const u32x4_a16* lowmask, u32 tid, u32 nthreads) {
   if (N == 0) return;
   const u64 A = (u64)dst, E = A + N;
   const u64 first = A >> 4, last = (E - 1) >> 4;
@@ -347,7 +349,7 @@ __device__ __forceinline__ void emit_symbols(u8* dst, u32 N, u32 c0, const u32* 
       if (pe > c) {
         const u32 sym = s_sym[k];
         const u32 W[4] = {sym, sym, sym, sym};
-        merge16(o, W, (int)(c - cz), (int)(pe - cz));
+        merge16(o, W, (int)(c - cz), (int)(pe - cz), lowmask);
         c = pe;
       }
       k++;
@@ -370,13 +372,18 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
   __shared__ u32 s_col[WGA_TILE + 1];   /* exclusive prefix of target columns (M = X D)          */
   __shared__ u32 s_ev[WGA_TILE + 1];    /* exclusive count of event ops (D, I, S)                */
   __shared__ u32 s_sym[WGA_TILE + 1];   /* symbol-mode byte of the op                            */
-  __shared__ u32 s_g_col[WGA_TILE + 1]; /* events: column                                        */
-  __shared__ u32 s_g_cum[WGA_TILE + 1]; /*         '-' bases before (D)                          */
-  __shared__ u32 s_g_adj[WGA_TILE + 1]; /*         D bases - (I+S) bases before (wrapping)       */
+  __shared__ u32 s_g_col[WGA_TILE + 2]; /* events: column                                        */
+  __shared__ u32 s_g_cum[WGA_TILE + 2]; /*         '-' bases before (D)                          */
+  __shared__ u32 s_g_adj[WGA_TILE + 2]; /*         D bases - (I+S) bases before (wrapping)       */
+  __shared__ u32 s_tbl[WGA_TBL_N + 2];  /* events that start before each column granule          */
+  __shared__ u32 s_zero2[2];
   __shared__ u64 s_w[5];
   __shared__ u64 s_red[4][4];
+  __shared__ u32x4_a16 s_lowmask[17];
+  __shared__ u32 s_queue[4 * WGA_QCAP];
 
   const u32 tid = threadIdx.x;
+  build_lowmask(s_lowmask);
   const u32 lane = tid & 63u, wave = tid >> 6;
   const u64 g = blockIdx.x;
   const u64 tile_start = g * WGA_TILE;
@@ -385,6 +392,11 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
   const wga_tile_sum tsum = a.tiles[g];
   const bool fast = tsum.tot[CLS_MX] + tsum.tot[CLS_D] + tsum.tot[CLS_I] + tsum.tot[CLS_S] <=
                     WGA_FAST_COL_LIMIT;
+  u32 gsh = WGA_TBL_SHIFT;
+  while (((tsum.tot[CLS_MX] + tsum.tot[CLS_D]) >> gsh) >= WGA_TBL_N) gsh++;
+  if (fast)
+    for (u32 k = tid; k < WGA_TBL_N; k += WGA_BLOCK) s_tbl[k] = 0u;
+  if (tid < 2u) s_zero2[tid] = 0u;
 
   u32 opw[4];
   {
@@ -427,6 +439,7 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
         s_g_col[x_cnt] = x_col;
         s_g_cum[x_cnt] = x_d;
         s_g_adj[x_cnt] = x_d - x_is;
+        atomicAdd(&s_tbl[x_col >> gsh], 1u);
         if (cls[e] == CLS_D)
           x_d += opw[e] >> 4;
         else
@@ -438,14 +451,29 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
     if (tid == WGA_BLOCK - 1) {
       s_col[WGA_TILE] = x_col;
       s_ev[WGA_TILE] = x_cnt;
-      s_g_col[x_cnt] = x_col;
-      s_g_cum[x_cnt] = x_d;
-      s_g_adj[x_cnt] = x_d - x_is;
+      s_g_col[x_cnt] = s_g_col[x_cnt + 1u] = x_col;
+      s_g_cum[x_cnt] = s_g_cum[x_cnt + 1u] = x_d;
+      s_g_adj[x_cnt] = s_g_adj[x_cnt + 1u] = x_d - x_is;
+    }
+    { /* per-granule counts -> exclusive prefix */
+      __syncthreads();
+      u32 v[WGA_TBL_N / WGA_BLOCK], sum = 0;
+      for (u32 e = 0; e < WGA_TBL_N / WGA_BLOCK; e++) {
+        v[e] = s_tbl[tid * (WGA_TBL_N / WGA_BLOCK) + e];
+        sum += v[e];
+      }
+      u64 tot;
+      u32 run = (u32)block_excl_scan_u64((u64)sum, s_w, &tot);
+      for (u32 e = 0; e < WGA_TBL_N / WGA_BLOCK; e++) {
+        s_tbl[tid * (WGA_TBL_N / WGA_BLOCK) + e] = run;
+        run += v[e];
+      }
+      if (tid == WGA_BLOCK - 1) s_tbl[WGA_TBL_N] = s_tbl[WGA_TBL_N + 1] = run;
     }
   }
   __syncthreads();
 
-  u32 r = wga_find_rec(a.op_off, a.n, tile_start);
+  u32 r = (u32)tsum.rec;
   u64 cur = tile_start;
   while (cur < tile_end) {
     u64 re = a.op_off[r + 1];
@@ -500,6 +528,7 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
     qs.src_off = a.base_mode ? a.q_src_off[r] : 0;
     qs.src_len = a.base_mode ? a.q_src_len[r] : 0;
     qs.rc = a.strand_neg[r] != 0;
+    qs.ablate = 0;
     /* edited length: String::drain / insert_str semantics (cigar.rs:769-786) */
     const u64 row_len = a.base_mode ? qs.src_len - (cs.i + cs.s) + cs.d : T_total;
     const u64 skip = a.skip[r];
@@ -531,12 +560,26 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
       u64 x1 = cb + seg_cols < row_len ? cb + seg_cols : row_len;
       if (x1 > x0) {
         const u32 c_first = col_a + (u32)(x0 - cb);
-        if (a.base_mode)
-          emit_row(dst + (x0 - skip), (u32)(x1 - x0), c_first, col_a, s_g_col, s_g_cum, s_g_adj, ea,
-                   eb, adj_a, qb, qs, tid, WGA_BLOCK, bad_base);
-        else
+        if (a.base_mode) {
+          RowDesc rd;
+          rd.c_org = col_a;
+          rd.G_col = s_g_col;
+          rd.G_cum = s_g_cum;
+          rd.G_adj = s_g_adj;
+          rd.ga = ea;
+          rd.gb = eb;
+          rd.gcum_a = adj_a;
+          rd.sbase = qb;
+          rd.lowmask = s_lowmask;
+          rd.tbl = s_tbl;
+          rd.tsh = 0u;
+          rd.gsh = gsh;
+          rd.queue = s_queue;
+          rowsrc_prepare(qs, qb);
+          emit_row(dst + (x0 - skip), (u32)(x1 - x0), c_first, rd, qs, tid, WGA_BLOCK, bad_base);
+        } else
           emit_symbols(dst + (x0 - skip), (u32)(x1 - x0), c_first, s_col, s_sym, (int)ka, (int)kb,
-                       tid, WGA_BLOCK);
+                       s_lowmask, tid, WGA_BLOCK);
       }
     }
     /* u64 fallback for tiles too wide for u32 columns: op-serial walk, every thread redundantly */
@@ -572,8 +615,7 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
     if (seg_end == re && a.base_mode && row_len > T_total) {
       u64 x0 = T_total > skip ? T_total : skip;
       if (row_len > x0)
-        emit_tail(dst + (x0 - skip), row_len - x0, Q_total + (x0 - T_total), qs, tid, WGA_BLOCK,
-                  bad_base);
+        emit_tail(dst + (x0 - skip), row_len - x0, Q_total + (x0 - T_total), qs, s_lowmask, s_queue, s_zero2, s_g_col, tid, WGA_BLOCK, bad_base);
     }
     cur = seg_end;
     r++;
