@@ -73,16 +73,78 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
   return v;
 }
-__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+
+/* Inclusive scan of a u32 over the 64 lanes.  On gfx950 this is six DPP adds (row_shr 1/2/4/8
+ * inside each 16-lane row, then row_bcast:15 and row_bcast:31 across rows): no LDS crossbar, no
+ * index arithmetic — a __shfl_up formulation costs ~5x the VALU work.  Lanes that a step does
+ * not reach add the `old` operand, 0. */
+__device__ __forceinline__ u32 wave_incl_scan_u32(u32 v) {
+#ifdef WGA_EMU
+  const u32 lane = threadIdx.x & 63u;
+  for (u32 d = 1; d < 64; d <<= 1) {
+    u32 t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
   return v;
+#else
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); /* row_shr:1 */
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false); /* row_shr:2 */
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false); /* row_shr:4 */
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); /* row_shr:8 */
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); /* row_bcast:15 */
+  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); /* row_bcast:31 */
+  return v;
+#endif
 }
+/* value of lane 63 of an inclusive scan = the wave total (uniform) */
+__device__ __forceinline__ u32 wave_last_u32(u32 incl) {
+#ifdef WGA_EMU
+  return __shfl(incl, 63);
+#else
+  return (u32)__builtin_amdgcn_readlane((int)incl, 63);
+#endif
+}
+/* exact sum of 64 u32 values (up to 2^38): two 16-bit halves scanned separately */
+__device__ __forceinline__ u64 wave_sum_u32_wide(u32 v) {
+  const u32 lo = wave_last_u32(wave_incl_scan_u32(v & 0xFFFFu));
+  const u32 hi = wave_last_u32(wave_incl_scan_u32(v >> 16));
+  return ((u64)hi << 16) + (u64)lo;
+}
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) { return wave_last_u32(wave_incl_scan_u32(v)); }
 __device__ __forceinline__ u32 wave_min_u32(u32 v) {
   for (int m = 32; m >= 1; m >>= 1) {
     u32 o = __shfl_xor(v, m);
     v = o < v ? o : v;
   }
   return v;
+}
+
+/* exclusive scan of four u32 values across a 256-thread block; tot[] = block totals.
+ * s_w4: 16 words of LDS. */
+__device__ __forceinline__ void block_excl_scan4_u32(const u32 v[4], u32 ex[4], u32 tot[4],
+                                                     u32* s_w4) {
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  u32 inc[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) inc[k] = wave_incl_scan_u32(v[k]);
+  __syncthreads(); /* protect s_w4 reuse */
+  if (lane == 63u) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_w4[wave * 4 + k] = inc[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    u32 pre = 0, t = 0;
+#pragma unroll
+    for (u32 w = 0; w < 4; w++) {
+      const u32 x = s_w4[w * 4 + k];
+      pre += w < wave ? x : 0u;
+      t += x;
+    }
+    ex[k] = pre + inc[k] - v[k];
+    tot[k] = t;
+  }
 }
 
 /* Last r in [0, n] with off[r] <= x (off is non-decreasing, off[0] == 0).  Wave-uniform call:
@@ -181,8 +243,8 @@ __global__ __launch_bounds__(256) void k_cigar_stat(const u32* __restrict__ ops,
     }
     u64 S[5];
 #pragma unroll
-    for (int c = 0; c < 5; c++) S[c] = wave_sum_u64((u64)s[c]);
-    const u64 Smatch = wave_sum_u64((u64)s_match);
+    for (int c = 0; c < 5; c++) S[c] = wave_sum_u32_wide(s[c]);
+    const u64 Smatch = wave_sum_u32_wide(s_match);
     const u32 EV = wave_sum_u32(ev);
     const u32 BAD = wave_min_u32(bad);
 
@@ -732,15 +794,6 @@ __device__ __forceinline__ void complex_finish(const ComplexState& st, const Row
   chunk_store(st.g, o, src.ablate);
 }
 
-/*
- * Emit N (<= 2^31) bytes of one gapped row to dst; output byte k is tile-relative column c0 + k.
- * Threads tid, tid+nthreads, ... own 16-byte *address-aligned* chunks of dst, so a wave writes
- * 1 KiB with one coalesced 16 B/lane store.  Two-speed: a chunk that lies inside one copy piece
- * (or one gap) — ~4 of 5 — is finished on the spot with one source window and no masking; a
- * chunk that touches an event boundary is pushed to the wave's LDS queue, and the queue is
- * drained 64 chunks at a time by complex_chunk, so the expensive path always runs with full
- * lanes instead of taxing every wave iteration.
- */
 #define WGA_EMIT_U 2 /* chunks in flight per lane */
 
 __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& rd,
@@ -983,7 +1036,7 @@ struct ExpandArgs {
   u64* dbg;     /* profiling: 8 s_memtime stamps per tile (NULL: off) */
 };
 
-__global__ __launch_bounds__(256) void k_paf2maf_expand(ExpandArgs a) {
+__global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
   __shared__ u32 s_col[WGA_TILE + 1];    /* tile-relative exclusive column prefix per op      */
   __shared__ u32 s_ev[WGA_TILE + 1];     /* exclusive (#I-class ops | #D-class ops << 16)     */
   __shared__ u32 s_tg_col[WGA_TILE + 2]; /* target-row gaps (I ops): start column             */
@@ -991,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_paf2maf_expand(ExpandArgs a) {
   __shared__ u32 s_qg_col[WGA_TILE + 2]; /* query-row gaps (D ops)                            */
   __shared__ u32 s_qg_cum[WGA_TILE + 2];
   __shared__ u32 s_zero2[2];
-  __shared__ u64 s_w[5];
+  __shared__ u32 s_w4[16];
   __shared__ u32x4_a16 s_lowmask[17];
   __shared__ u32 s_tbl[WGA_TBL_N + 2];   /* entries before each 16-column granule: I | D<<16  */
   __shared__ u32 s_queue[4 * WGA_QCAP];  /* per-wave queues of complex chunks                 */
@@ -1043,12 +1096,12 @@ __global__ __launch_bounds__(256) void k_paf2maf_expand(ExpandArgs a) {
       sd += cls[e] == CLS_D ? len : 0u;
       cnt += cls[e] == CLS_I ? 1u : (cls[e] == CLS_D ? 0x10000u : 0u);
     }
-    /* one u64 block scan carries (cols | I bases << 32); a second carries (D bases | counts<<32):
-     * every component stays below 2^31 on the fast path, so the packed lanes never carry over */
-    u64 totA, totB;
-    u64 exA = block_excl_scan_u64((u64)sl | ((u64)si << 32), s_w, &totA);
-    u64 exB = block_excl_scan_u64((u64)sd | ((u64)cnt << 32), s_w, &totB);
-    u32 x_col = (u32)exA, x_i = (u32)(exA >> 32), x_d = (u32)exB, x_cnt = (u32)(exB >> 32);
+    /* exclusive prefixes of (columns, I bases, D bases, gap-op counts): every component stays
+     * below 2^31 on the fast path */
+    const u32 sv[4] = {sl, si, sd, cnt};
+    u32 sx[4], stot[4];
+    block_excl_scan4_u32(sv, sx, stot, s_w4);
+    u32 x_col = sx[0], x_i = sx[1], x_d = sx[2], x_cnt = sx[3];
     for (int e = 0; e < 4; e++) {
       u32 k = tid * 4u + (u32)e;
       s_col[k] = x_col;
@@ -1087,8 +1140,10 @@ __global__ __launch_bounds__(256) void k_paf2maf_expand(ExpandArgs a) {
         v[e] = s_tbl[tid * (WGA_TBL_N / WGA_BLOCK) + e];
         sum += v[e];
       }
-      u64 tot;
-      u32 run = (u32)block_excl_scan_u64((u64)sum, s_w, &tot); /* both 16-bit halves <= 1024 */
+      const u32 tv[4] = {sum, 0u, 0u, 0u}; /* both 16-bit halves <= 1024 */
+      u32 tx[4], ttot[4];
+      block_excl_scan4_u32(tv, tx, ttot, s_w4);
+      u32 run = tx[0];
       for (u32 e = 0; e < WGA_TBL_N / WGA_BLOCK; e++) {
         s_tbl[tid * (WGA_TBL_N / WGA_BLOCK) + e] = run;
         run += v[e];
