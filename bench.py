@@ -24,33 +24,40 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy rate
 
 
-def cpu_baseline(tb, budget_s=12.0, max_records=1500):
+def cpu_baseline(tb, budget_s=15.0, max_records=40000):
     """The oracle (oracle/oracle.c: reference-faithful port, text tokenising + String::insert_str
     tail memmoves) timed on ONE host core over a bounded sample of the same batch."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
     import oracle_py as orc
-    from wgatools_amd import synth
-    recs = []
     n = min(tb["n"], max_records)
+    op_off = tb["op_off"][: n + 1].cpu().numpy()
+    ops = tb["ops"][: int(op_off[n])].cpu().numpy().view(np.uint32)
+    t_pool, q_pool = tb["t_pool"].cpu().numpy(), tb["q_pool"].cpu().numpy()
+    to, tl = tb["t_src_off"][:n].cpu().numpy(), tb["t_src_len"][:n].cpu().numpy()
+    qo, ql = tb["q_src_off"][:n].cpu().numpy(), tb["q_src_len"][:n].cpu().numpy()
+    strand = tb["strand_neg"][:n].cpu().numpy()
+    ops_done, done, t_work = 0, 0, 0.0
+    t_start = time.perf_counter()
     for i in range(n):
-        r = synth.torch_batch_record_to_numpy(tb, i)
-        recs.append((("cg:Z:" + synth.cigar_text(r["ops"])).encode(), int(r["strand_neg"][0]),
-                     r["t_pool"].tobytes(), r["q_pool"].tobytes(), len(r["ops"])))
-    ops_done, done = 0, 0
-    t0 = time.perf_counter()
-    for cg, neg, t, q, nops in recs:
+        a, b = int(op_off[i]), int(op_off[i + 1])
+        cg = orc.ops_to_text(ops[a:b])              # input preparation: not timed
+        t = t_pool[int(to[i]):int(to[i] + tl[i])].tobytes()
+        q = q_pool[int(qo[i]):int(qo[i] + ql[i])].tobytes()
+        neg = int(strand[i])
+        t0 = time.perf_counter()
         orc.parse_paf_to_cigar(cg, neg)                       # stat
         if neg:
             q = orc.reverse_complement(q)                     # paf2maf
         orc.parse_cigar_to_insert(cg, t, q)
-        ops_done += nops
+        t_work += time.perf_counter() - t0
+        ops_done += b - a
         done += 1
-        if time.perf_counter() - t0 > budget_s:
+        if t_work > budget_s or time.perf_counter() - t_start > 4 * budget_s:
             break
-    dt = time.perf_counter() - t0
-    return {"value": ops_done / dt, "unit": "ops/s", "cores": 1, "kind": "port",
+    return {"value": ops_done / t_work, "unit": "ops/s", "cores": 1, "kind": "port",
             "sample": "first %d records (%d ops) of the same batch, stat + paf2maf per record, "
-                      "%.1f s on 1 core" % (done, ops_done, dt)}
+                      "%.1f s of oracle time on 1 core" % (done, ops_done, t_work)}
 
 
 def main():

@@ -27,6 +27,29 @@ static void set_err(orc_err* e, int kind, const char* arg, size_t n) {
 
 void orc_free(void* p) { free(p); }
 
+/* test helper (not a reference function): packed u32 ops (len << 4 | code) -> "cg:Z:" text */
+size_t orc_ops_to_text(const uint32_t* ops, size_t n, char* out, size_t cap) {
+  static const char chars[] = "MIDNSHP=XIDB";
+  size_t k = 0;
+  if (cap < 6) return 0;
+  memcpy(out, "cg:Z:", 5);
+  k = 5;
+  for (size_t i = 0; i < n; i++) {
+    if (k + 12 > cap) return 0;
+    uint32_t len = ops[i] >> 4, code = ops[i] & 15u;
+    char tmp[12];
+    int m = 0;
+    do {
+      tmp[m++] = (char)('0' + len % 10);
+      len /= 10;
+    } while (len);
+    while (m) out[k++] = tmp[--m];
+    out[k++] = chars[code < 12 ? code : 11];
+  }
+  out[k] = 0;
+  return k;
+}
+
 /* errors.rs:45-74 message templates */
 void orc_err_message(const orc_err* e, char* buf, size_t cap) {
   switch (e->kind) {

@@ -96,6 +96,8 @@ int orc_call_var_maf_record(const char* chro, const char* q_chro, const char* t,
                             size_t chunk_size, char** out, size_t* out_len);
 
 void orc_free(void* p);
+/* test helper: packed ops -> "cg:Z:..." text; returns length (0 if cap too small) */
+size_t orc_ops_to_text(const uint32_t* ops, size_t n, char* out, size_t cap);
 
 #ifdef __cplusplus
 }

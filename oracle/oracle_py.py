@@ -56,6 +56,8 @@ def lib():
         L.orc_gen_pesudo_maf_by_cigar.argtypes = [C.c_char_p, Z, P, P, C.c_int, P]
         L.orc_call_var_maf_record.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, Z,
                                               U, U, U, U, U, C.c_int, C.c_int, C.c_int, U, Z, P, P]
+        L.orc_ops_to_text.restype = Z
+        L.orc_ops_to_text.argtypes = [P, Z, C.c_char_p, Z]
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_cs_to_cigar.restype = C.c_void_p
         L.orc_cs_to_cigar.argtypes = [C.c_char_p, C.c_size_t]
@@ -198,3 +200,12 @@ def call_var_maf_record(chro, q_chro, t_row, q_row, t_start, q_sline_start, q_sl
     if rc:
         raise OracleError(rc, "", "call_within_var panicked")
     return s
+
+
+def ops_to_text(ops):
+    """packed u32 ops (numpy) -> b'cg:Z:...' (helper for large samples; not a reference function)"""
+    ops = np.ascontiguousarray(ops, dtype=np.uint32)
+    cap = 12 * len(ops) + 16
+    buf = C.create_string_buffer(cap)
+    k = lib().orc_ops_to_text(C.c_void_p(ops.ctypes.data), len(ops), buf, cap)
+    return buf.raw[:k]
