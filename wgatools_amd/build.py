@@ -69,6 +69,23 @@ def build_emu(force=False):
     return EMU_LIB
 
 
+CLI_BIN = os.path.join(ROOT, "wgatools_amd", "bin", "wgatools")
+
+
+def build_cli(force=False):
+    """the `wgatools` drop-in command line (C++ host layer over the C-ABI)"""
+    hdir = os.path.join(ROOT, "wgatools_amd", "host")
+    srcs = [os.path.join(hdir, f) for f in ("wgatools_main.cpp", "wga_host.cpp", "wga_host.hpp")]
+    lib = build_hip()
+    if not force and not _newer(CLI_BIN, srcs + [lib]):
+        return CLI_BIN
+    os.makedirs(os.path.dirname(CLI_BIN), exist_ok=True)
+    _run(["g++", "-O2", "-g", "-std=c++17", "-Wall", srcs[0], srcs[1], "-o", CLI_BIN,
+          "-L" + os.path.dirname(lib), "-lwgahip", "-lz", "-Wl,-rpath,$ORIGIN/..",
+          "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
+    return CLI_BIN
+
+
 def build_oracle(force=False):
     srcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle.c", "oracle.h")]
     if not force and not _newer(ORACLE_LIB, srcs):

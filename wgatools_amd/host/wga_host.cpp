@@ -1,0 +1,687 @@
+/*
+ * wga_host.cpp — parsers / writers of the host layer (see wga_host.hpp for the reference map).
+ */
+#include "wga_host.hpp"
+
+#include <stdio.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+
+namespace wga {
+
+void fail(const std::string& msg) { throw Error{msg}; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* I/O (utils.rs:135-246)                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+std::string read_all(const std::string* path) {
+  std::string out;
+  if (!path) {
+    if (isatty(0)) fail("Empty stdin, please add `-h` for help"); /* errors.rs:23 */
+    char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, stdin)) > 0) out.append(buf, n);
+    return out;
+  }
+  /* gzopen reads plain files transparently and inflates gzip members (MultiGzDecoder) */
+  gzFile f = gzopen(path->c_str(), "rb");
+  if (!f) fail("File path `" + *path + "` not exist"); /* errors.rs:13 */
+  gzbuffer(f, 1 << 20);
+  char buf[1 << 16];
+  int n;
+  while ((n = gzread(f, buf, sizeof buf)) > 0) out.append(buf, (size_t)n);
+  gzclose(f);
+  return out;
+}
+
+static bool ends_with(const std::string& s, const char* suf) {
+  size_t n = strlen(suf);
+  return s.size() >= n && memcmp(s.data() + s.size() - n, suf, n) == 0;
+}
+
+void Output::open(const std::string& p, bool rewrite) {
+  path = p;
+  if (p == "-") {
+    fp = stdout;
+    return;
+  }
+  struct stat st;
+  if (stat(p.c_str(), &st) == 0 && !rewrite)
+    fail("File `" + p + "` already exists, please add `-r` to rewrite it."); /* errors.rs:25 */
+  if (ends_with(p, ".bz2") || ends_with(p, ".xz"))
+    fail("IO error:bz2 / xz output is not built into this engine (plain or .gz only)");
+  if (ends_with(p, ".gz")) {
+    gz = gzopen(p.c_str(), "wb6");
+    if (!gz) fail("IO error:cannot create `" + p + "`");
+  } else {
+    fp = fopen(p.c_str(), "wb");
+    if (!fp) fail("IO error:cannot create `" + p + "`");
+  }
+}
+void Output::write(const char* p, size_t n) {
+  if (!n) return;
+  if (gz) {
+    while (n) {
+      unsigned k = n > (1u << 30) ? (1u << 30) : (unsigned)n;
+      if (gzwrite((gzFile)gz, p, k) <= 0) fail("IO error:write failed");
+      p += k;
+      n -= k;
+    }
+  } else if (fwrite(p, 1, n, fp) != n) {
+    fail("IO error:write failed");
+  }
+}
+void Output::close() {
+  if (gz) gzclose((gzFile)gz);
+  if (fp && fp != stdout) fclose(fp);
+  if (fp == stdout) fflush(stdout);
+  gz = nullptr;
+  fp = nullptr;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* numbers                                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+void append_u64(std::string& s, uint64_t v) {
+  char b[24];
+  auto r = std::to_chars(b, b + sizeof b, v);
+  s.append(b, r.ptr);
+}
+
+/* Rust's u64::from_str: optional '+', at least one digit, no overflow */
+static bool parse_u64(const std::string& s, uint64_t* out) {
+  size_t i = 0;
+  if (i < s.size() && s[i] == '+') i++;
+  if (i >= s.size()) return false;
+  uint64_t v = 0;
+  for (; i < s.size(); i++) {
+    if (s[i] < '0' || s[i] > '9') return false;
+    uint64_t d = (uint64_t)(s[i] - '0');
+    if (v > (UINT64_MAX - d) / 10) return false;
+    v = v * 10 + d;
+  }
+  *out = v;
+  return true;
+}
+
+/* ryu::Buffer::format(f32) -> pretty::format32 (ryu 1.0.14): shortest digits, then
+ *   0 <= k && kk <= 13 : digits, zeros, ".0"        0 < kk <= 13 : dddd.ddd
+ *   -6 < kk <= 0       : 0.000ddd                   else d[.ddd]e<exp>
+ * (k = decimal exponent of the last digit, kk = position of the decimal point). */
+std::string format_f32(float f) {
+  if (std::isnan(f)) return "NaN";
+  if (std::isinf(f)) return f < 0 ? "-inf" : "inf";
+  if (f == 0.0f) return std::signbit(f) ? "-0.0" : "0.0";
+  char b[64];
+  auto r = std::to_chars(b, b + sizeof b, f, std::chars_format::scientific);
+  std::string sci(b, r.ptr); /* [-]d[.ddd]e[+-]xx */
+  std::string out;
+  size_t p = 0;
+  if (sci[0] == '-') {
+    out.push_back('-');
+    p = 1;
+  }
+  size_t epos = sci.find('e', p);
+  std::string digits;
+  for (size_t i = p; i < epos; i++)
+    if (sci[i] != '.') digits.push_back(sci[i]);
+  int exp10 = atoi(sci.c_str() + epos + 1);
+  int len = (int)digits.size();
+  int k = exp10 - (len - 1);
+  int kk = len + k;
+  if (0 <= k && kk <= 13) {
+    out += digits;
+    out.append((size_t)k, '0');
+    out += ".0";
+  } else if (0 < kk && kk <= 13) {
+    out.append(digits, 0, (size_t)kk);
+    out.push_back('.');
+    out.append(digits, (size_t)kk, std::string::npos);
+  } else if (-6 < kk && kk <= 0) {
+    out += "0.";
+    out.append((size_t)(-kk), '0');
+    out += digits;
+  } else if (len == 1) {
+    out += digits;
+    out.push_back('e');
+    out += std::to_string(kk - 1);
+  } else {
+    out.push_back(digits[0]);
+    out.push_back('.');
+    out.append(digits, 1, std::string::npos);
+    out.push_back('e');
+    out += std::to_string(kk - 1);
+  }
+  return out;
+}
+
+void append_csv_field(std::string& s, const std::string& f, char delim) {
+  bool need = false;
+  for (char c : f)
+    if (c == delim || c == '"' || c == '\n' || c == '\r') {
+      need = true;
+      break;
+    }
+  if (!need) {
+    s += f;
+    return;
+  }
+  s.push_back('"');
+  for (char c : f) {
+    if (c == '"') s.push_back('"');
+    s.push_back(c);
+  }
+  s.push_back('"');
+}
+
+/* natord 1.0.9 compare(): whitespace skipped, digit runs compared numerically — left-aligned
+ * when either run starts with '0', otherwise longest run wins, then first difference */
+static bool is_ws(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); }
+int natord_compare(const std::string& a, const std::string& b) {
+  size_t i = 0, j = 0;
+  auto digit = [](const std::string& s, size_t k) { return k < s.size() && s[k] >= '0' && s[k] <= '9'; };
+  for (;;) {
+    while (i < a.size() && is_ws((unsigned char)a[i])) i++;
+    while (j < b.size() && is_ws((unsigned char)b[j])) j++;
+    bool ea = i >= a.size(), eb = j >= b.size();
+    if (ea && eb) return 0;
+    if (ea) return -1;
+    if (eb) return 1;
+    unsigned char ca = (unsigned char)a[i++], cb = (unsigned char)b[j++];
+    bool da = ca >= '0' && ca <= '9', db = cb >= '0' && cb <= '9';
+    if (da && db) {
+      if (ca == '0' || cb == '0') { /* compare_left */
+        if (ca != cb) return ca < cb ? -1 : 1;
+        for (;;) {
+          bool la = digit(a, i), lb = digit(b, j);
+          if (la && lb) {
+            if (a[i] != b[j]) return a[i] < b[j] ? -1 : 1;
+            i++;
+            j++;
+          } else if (la) {
+            return 1;
+          } else if (lb) {
+            return -1;
+          } else {
+            break;
+          }
+        }
+      } else { /* compare_right */
+        int bias = ca == cb ? 0 : (ca < cb ? -1 : 1);
+        for (;;) {
+          bool la = digit(a, i), lb = digit(b, j);
+          if (la && lb) {
+            if (bias == 0 && a[i] != b[j]) bias = a[i] < b[j] ? -1 : 1;
+            i++;
+            j++;
+          } else if (la) {
+            return 1;
+          } else if (lb) {
+            return -1;
+          } else {
+            if (bias != 0) return bias;
+            break;
+          }
+        }
+      }
+    } else if (ca != cb) {
+      return ca < cb ? -1 : 1;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* PAF (paf.rs)                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+std::vector<PafRecord> parse_paf(const std::string& text) {
+  std::vector<PafRecord> out;
+  size_t p = 0, n = text.size();
+  uint64_t recno = 0, line = 1;
+  std::vector<std::string> fields;
+  while (p < n) {
+    /* record terminators: \n, \r\n, \r; blank lines are skipped */
+    if (text[p] == '\n' || text[p] == '\r') {
+      if (text[p] == '\n') line++;
+      p++;
+      continue;
+    }
+    if (text[p] == '#') { /* comment line */
+      while (p < n && text[p] != '\n' && text[p] != '\r') p++;
+      continue;
+    }
+    size_t rec_byte = p;
+    fields.clear();
+    for (;;) {
+      std::string f;
+      if (p < n && text[p] == '"') { /* quoted field, "" = one quote */
+        p++;
+        while (p < n) {
+          if (text[p] == '"') {
+            if (p + 1 < n && text[p + 1] == '"') {
+              f.push_back('"');
+              p += 2;
+            } else {
+              p++;
+              break;
+            }
+          } else {
+            f.push_back(text[p++]);
+          }
+        }
+        while (p < n && text[p] != '\t' && text[p] != '\n' && text[p] != '\r') f.push_back(text[p++]);
+      } else {
+        size_t s = p;
+        while (p < n && text[p] != '\t' && text[p] != '\n' && text[p] != '\r') p++;
+        f.assign(text, s, p - s);
+      }
+      fields.push_back(std::move(f));
+      if (p < n && text[p] == '\t') {
+        p++;
+        continue;
+      }
+      break;
+    }
+    auto bad = [&](size_t field, const std::string& why) {
+      fail("CSV deserialize error by: CSV deserialize error: record " + std::to_string(recno) +
+           " (line: " + std::to_string(line) + ", byte: " + std::to_string(rec_byte) + "): field " +
+           std::to_string(field) + ": " + why);
+    };
+    if (fields.size() < 12)
+      fail("CSV deserialize error by: CSV deserialize error: record " + std::to_string(recno) +
+           " (line: " + std::to_string(line) + ", byte: " + std::to_string(rec_byte) +
+           "): invalid length " + std::to_string(fields.size()) + ", expected struct PafRecord with 13 elements");
+    PafRecord r;
+    auto num = [&](size_t k, uint64_t* v) {
+      if (!parse_u64(fields[k], v)) bad(k, fields[k].empty() ? "cannot parse integer from empty string"
+                                                             : "invalid digit found in string");
+    };
+    r.query_name = fields[0];
+    num(1, &r.query_length);
+    num(2, &r.query_start);
+    num(3, &r.query_end);
+    if (fields[4] == "+")
+      r.neg = false;
+    else if (fields[4] == "-")
+      r.neg = true;
+    else
+      bad(4, "unknown variant `" + fields[4] + "`, expected `+` or `-`");
+    r.target_name = fields[5];
+    num(6, &r.target_length);
+    num(7, &r.target_start);
+    num(8, &r.target_end);
+    num(9, &r.matches);
+    num(10, &r.block_length);
+    num(11, &r.mapq);
+    r.tags.assign(fields.begin() + 12, fields.end());
+    out.push_back(std::move(r));
+    recno++;
+  }
+  return out;
+}
+
+/* paf.rs:159-218; the regex (:[0-9]+|\*[a-z][a-z]|[=\+\-][A-Za-z]+) as a leftmost scanner */
+std::string cs_to_cigar(const std::string& cs) {
+  std::string cigar;
+  char last_op = 'M';
+  uint64_t last_len = 0;
+  auto flush = [&]() {
+    if (last_len > 0) {
+      append_u64(cigar, last_len);
+      cigar.push_back(last_op);
+    }
+  };
+  auto lower = [](char c) { return c >= 'a' && c <= 'z'; };
+  auto alpha = [](char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); };
+  auto dig = [](char c) { return c >= '0' && c <= '9'; };
+  size_t i = 0, n = cs.size();
+  while (i < n) {
+    char c = cs[i];
+    if (c == ':' && i + 1 < n && dig(cs[i + 1])) {
+      size_t j = i + 1;
+      uint64_t length = 0;
+      while (j < n && dig(cs[j])) length = length * 10 + (uint64_t)(cs[j++] - '0');
+      if (last_op == 'M') {
+        last_len += length;
+      } else {
+        flush();
+        last_op = 'M';
+        last_len = length;
+      }
+      i = j;
+    } else if (c == '*' && i + 2 < n && lower(cs[i + 1]) && lower(cs[i + 2])) {
+      if (last_op == 'X') {
+        last_len += 1;
+      } else {
+        flush();
+        last_op = 'X';
+        last_len = 1;
+      }
+      i += 3;
+    } else if ((c == '=' || c == '+' || c == '-') && i + 1 < n && alpha(cs[i + 1])) {
+      size_t j = i + 1;
+      while (j < n && alpha(cs[j])) j++;
+      if (c != '=') { /* '=' parts are matched but ignored, paf.rs:209 */
+        flush();
+        append_u64(cigar, (uint64_t)(j - i - 1));
+        cigar.push_back(c == '-' ? 'D' : 'I');
+        last_len = 0;
+        last_op = 'M';
+      }
+      i = j;
+    } else {
+      i++;
+    }
+  }
+  flush();
+  return cigar;
+}
+
+std::string paf_cigar_string(const PafRecord& r, int* err) {
+  *err = 0;
+  for (const auto& t : r.tags)
+    if (t.compare(0, 5, "cg:Z:") == 0) return t;
+  for (const auto& t : r.tags)
+    if (t.compare(0, 5, "cs:Z:") == 0) return "cg:Z:" + cs_to_cigar(t.substr(5));
+  *err = 1;
+  return "";
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* MAF (maf.rs)                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+static std::vector<std::string> split_ws(const std::string& line) {
+  std::vector<std::string> f;
+  size_t i = 0, n = line.size();
+  while (i < n) {
+    while (i < n && is_ws((unsigned char)line[i])) i++;
+    size_t s = i;
+    while (i < n && !is_ws((unsigned char)line[i])) i++;
+    if (i > s) f.emplace_back(line, s, i - s);
+  }
+  return f;
+}
+
+static MafSLine parse_sline(const std::string& line) { /* maf.rs:138-211 */
+  static const char* names[] = {"mode", "name", "start", "align_size", "strand", "size", "seq"};
+  std::vector<std::string> f = split_ws(line);
+  if (f.size() < 7) fail(std::string("Parse MAF error by: S-line Filed `") + names[f.size()] + "` Missing");
+  MafSLine s;
+  s.name = f[1];
+  if (!parse_u64(f[2], &s.start)) fail("Parse `" + f[2] + "` Into Integer Error");
+  if (!parse_u64(f[3], &s.align_size)) fail("Parse `" + f[3] + "` Into Integer Error");
+  if (f[4] == "+")
+    s.neg = false;
+  else if (f[4] == "-")
+    s.neg = true;
+  else
+    fail("Parse Strand `" + f[4] + "` Error");
+  if (!parse_u64(f[5], &s.size)) fail("Parse `" + f[5] + "` Into Integer Error");
+  s.seq = f[6];
+  if (f.size() > 7) fail("Parse MAF error by: Surplus Filed > 7");
+  return s;
+}
+
+std::vector<MafRecord> parse_maf(const std::string& text, std::string* header) {
+  std::vector<MafRecord> out;
+  size_t p = 0, n = text.size();
+  auto next_line = [&](std::string* line) -> bool { /* BufRead::lines: strips \n and \r\n */
+    if (p >= n) return false;
+    size_t e = text.find('\n', p);
+    size_t end = e == std::string::npos ? n : e;
+    size_t le = end;
+    if (le > p && text[le - 1] == '\r') le--;
+    line->assign(text, p, le - p);
+    p = e == std::string::npos ? n : e + 1;
+    return true;
+  };
+  std::string line;
+  if (next_line(&line) && header) *header = line; /* the first line is always the header */
+  while (next_line(&line)) {
+    if (line.empty() || line[0] != 's') continue;
+    MafRecord rec;
+    rec.slines.push_back(parse_sline(line));
+    while (next_line(&line)) {
+      if (!line.empty() && line[0] == 's')
+        rec.slines.push_back(parse_sline(line));
+      else
+        break; /* the terminating line is consumed and dropped */
+    }
+    out.push_back(std::move(rec));
+  }
+  return out;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* FASTA                                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+void Faidx::load(const std::string& path) {
+  std::string text = read_all(&path);
+  pool.clear();
+  pool.reserve(text.size());
+  contigs.clear();
+  size_t p = 0, n = text.size();
+  std::string cur;
+  uint64_t cur_off = 0;
+  bool have = false;
+  auto close = [&]() {
+    if (have) contigs[cur] = Contig{(uint64_t)pool.size() - cur_off, cur_off};
+  };
+  while (p < n) {
+    size_t e = text.find('\n', p);
+    size_t end = e == std::string::npos ? n : e;
+    size_t le = end;
+    if (le > p && text[le - 1] == '\r') le--;
+    if (le > p && text[p] == '>') {
+      close();
+      size_t s = p + 1, q = s;
+      while (q < le && !is_ws((unsigned char)text[q])) q++;
+      cur.assign(text, s, q - s);
+      cur_off = pool.size();
+      have = true;
+    } else if (have) {
+      pool.append(text, p, le - p);
+    }
+    p = e == std::string::npos ? n : e + 1;
+  }
+  close();
+}
+
+void Faidx::fetch(const std::string& name, uint64_t beg_u, uint64_t end_u, uint64_t* off,
+                  uint64_t* len) const {
+  if (beg_u > (uint64_t)INT64_MAX || end_u > (uint64_t)INT64_MAX)
+    fail("HTS library error by The given position is too large to be converted to i64");
+  auto it = contigs.find(name);
+  if (it == contigs.end()) fail("HTS library error by sequence `" + name + "` not found in the FASTA index");
+  int64_t L = (int64_t)it->second.len, beg = (int64_t)beg_u, end = (int64_t)end_u;
+  /* faidx_adjust_position (htslib), end inclusive */
+  if (end < beg) beg = end;
+  if (beg < 0)
+    beg = 0;
+  else if (L <= beg)
+    beg = L;
+  if (end < 0)
+    end = 0;
+  else if (L <= end)
+    end = L - 1;
+  int64_t n = end + 1 - beg;
+  if (n < 0) n = 0;
+  *off = it->second.pool_off + (uint64_t)beg;
+  *len = (uint64_t)n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* stat (common.rs:116-140, stat.rs)                                                           */
+/* ------------------------------------------------------------------------------------------ */
+RecStat recstat_from(const wga_cigar_counts& c) {
+  RecStat r;
+  r.matched = c.match;
+  r.mismatched = c.mismatch;
+  r.ins_event = c.ins_ev;
+  r.del_event = c.del_ev;
+  r.ins_size = c.ins_bp;
+  r.del_size = c.del_bp;
+  r.inv_ins_event = c.inv_ins_ev;
+  r.inv_ins_size = c.inv_ins_bp;
+  r.inv_del_event = c.inv_del_ev;
+  r.inv_del_size = c.inv_del_bp;
+  r.aligned_size = r.matched + r.mismatched + r.del_size + r.inv_del_size;
+  uint64_t query_align = r.matched + r.mismatched + r.ins_size + r.inv_ins_size;
+  r.inv_event = c.inv_ev;
+  if (r.inv_event != 0) r.inv_size = (float)(r.aligned_size + query_align) / (float)(r.inv_event + 1);
+  return r;
+}
+
+namespace {
+struct Statistic { /* stat.rs:27-50, field order = column order */
+  std::string ref_name;
+  uint64_t ref_size = 0, ref_start = 0;
+  std::string query_name;
+  uint64_t query_size = 0, query_start = 0, aligned_size = 0, unaligned_size = 0;
+  float identity = 0, similarity = 0;
+  uint64_t matched = 0, mismatched = 0, ins_event = 0, del_event = 0, ins_size = 0, del_size = 0,
+           inv_event = 0;
+  float inv_size = 0;
+  uint64_t inv_ins_event = 0, inv_ins_size = 0, inv_del_event = 0, inv_del_size = 0;
+};
+void add(Statistic& s, const RecStat& r) {
+  s.aligned_size += r.aligned_size;
+  s.matched += r.matched;
+  s.mismatched += r.mismatched;
+  s.ins_event += r.ins_event;
+  s.del_event += r.del_event;
+  s.ins_size += r.ins_size;
+  s.del_size += r.del_size;
+  s.inv_ins_event += r.inv_ins_event;
+  s.inv_ins_size += r.inv_ins_size;
+  s.inv_del_event += r.inv_del_event;
+  s.inv_del_size += r.inv_del_size;
+  s.inv_event += r.inv_event;
+  s.inv_size += r.inv_size;
+}
+}  // namespace
+
+std::string stat_tsv(const std::vector<StatInput>& recs, bool each) {
+  std::vector<Statistic> rows;
+  if (each) { /* split_final, stat.rs:129-164: unaligned_size stays 0 */
+    for (const auto& in : recs) {
+      Statistic s;
+      s.ref_name = in.ref_name;
+      s.ref_size = in.ref_size;
+      s.ref_start = in.ref_start;
+      s.query_name = in.query_name;
+      s.query_size = in.query_size;
+      s.query_start = in.query_start;
+      add(s, in.rs);
+      s.identity = (float)s.matched / (float)s.aligned_size;
+      s.similarity = (float)(s.matched + s.mismatched) / (float)s.aligned_size;
+      rows.push_back(std::move(s));
+    }
+  } else { /* merge_final_from_pair, stat.rs:167-223 (groups in first-appearance order; the
+              reference iterates a HashMap, i.e. in random order) */
+    std::map<std::tuple<std::string, uint64_t, std::string, uint64_t>, size_t> index;
+    for (const auto& in : recs) {
+      auto key = std::make_tuple(in.ref_name, in.ref_size, in.query_name, in.query_size);
+      auto it = index.find(key);
+      if (it == index.end()) {
+        Statistic s;
+        s.ref_name = in.ref_name;
+        s.ref_size = in.ref_size;
+        s.ref_start = in.ref_size; /* minima start from the sizes, stat.rs:186,189 */
+        s.query_name = in.query_name;
+        s.query_size = in.query_size;
+        s.query_start = in.query_size;
+        it = index.emplace(key, rows.size()).first;
+        rows.push_back(std::move(s));
+      }
+      Statistic& s = rows[it->second];
+      add(s, in.rs);
+      if (in.ref_start < s.ref_start) s.ref_start = in.ref_start;
+      if (in.query_start < s.query_start) s.query_start = in.query_start;
+    }
+    for (auto& s : rows) {
+      s.unaligned_size = s.ref_size - s.aligned_size; /* wraps like release-mode Rust */
+      s.identity = (float)s.matched / (float)s.aligned_size;
+      s.similarity = (float)(s.matched + s.mismatched) / (float)s.aligned_size;
+    }
+  }
+  std::stable_sort(rows.begin(), rows.end(), [](const Statistic& a, const Statistic& b) {
+    return natord_compare(a.ref_name, b.ref_name) < 0;
+  });
+  std::string out;
+  if (rows.empty()) return out; /* csv writes the header with the first row only */
+  out += "ref_name\tref_size\tref_start\tquery_name\tquery_size\tquery_start\taligned_size\t"
+         "unaligned_size\tidentity\tsimilarity\tmatched\tmismatched\tins_event\tdel_event\tins_size\t"
+         "del_size\tinv_event\tinv_size\tinv_ins_event\tinv_ins_size\tinv_del_event\tinv_del_size\n";
+  for (const auto& s : rows) {
+    append_csv_field(out, s.ref_name, '\t');
+    out.push_back('\t');
+    append_u64(out, s.ref_size);
+    out.push_back('\t');
+    append_u64(out, s.ref_start);
+    out.push_back('\t');
+    append_csv_field(out, s.query_name, '\t');
+    out.push_back('\t');
+    uint64_t a[] = {s.query_size, s.query_start, s.aligned_size, s.unaligned_size};
+    for (uint64_t v : a) {
+      append_u64(out, v);
+      out.push_back('\t');
+    }
+    out += format_f32(s.identity);
+    out.push_back('\t');
+    out += format_f32(s.similarity);
+    out.push_back('\t');
+    uint64_t b[] = {s.matched, s.mismatched, s.ins_event, s.del_event, s.ins_size, s.del_size, s.inv_event};
+    for (uint64_t v : b) {
+      append_u64(out, v);
+      out.push_back('\t');
+    }
+    out += format_f32(s.inv_size);
+    out.push_back('\t');
+    uint64_t c[] = {s.inv_ins_event, s.inv_ins_size, s.inv_del_event, s.inv_del_size};
+    for (int k = 0; k < 4; k++) {
+      append_u64(out, c[k]);
+      out.push_back(k == 3 ? '\n' : '\t');
+    }
+  }
+  return out;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* CIGAR error messages (errors.rs:51-60)                                                      */
+/* ------------------------------------------------------------------------------------------ */
+std::string cigar_error_message(int32_t err, const std::string& cigar, size_t tok_off, size_t tok_len) {
+  std::string tok = cigar.substr(tok_off, tok_len);
+  switch (err) {
+    case WGA_REC_CIGAR_OP_INVALID: return "CIGAR OP `" + tok + "` invalid";
+    case WGA_REC_PARSE_INT: return "Parse `" + tok + "` Into Integer Error";
+    case WGA_REC_CIGAR_TAG_NOT_FOUND: return "CIGAR start tag not found";
+    case WGA_REC_PANIC: return "panic: empty CIGAR (the reference panics in errors.rs:92)";
+    default: return "CIGAR error";
+  }
+}
+
+std::string cigar_op_token_at(const std::string& cigar, uint64_t op_idx) {
+  /* packed ops of one text op can be several (split lengths): walk like the packer does */
+  size_t p = 0, n = cigar.size();
+  uint64_t k = 0;
+  while (p < n) {
+    size_t ls = p;
+    while (p < n && cigar[p] >= '0' && cigar[p] <= '9') p++;
+    uint64_t v = 0;
+    for (size_t i = ls; i < p; i++) v = v * 10 + (uint64_t)(cigar[i] - '0');
+    size_t os = p;
+    while (p < n && !(cigar[p] >= '0' && cigar[p] <= '9')) p++;
+    uint64_t pieces = v == 0 ? 1 : (v + WGA_OP_MAX_LEN - 1) / WGA_OP_MAX_LEN;
+    if (op_idx < k + pieces) return cigar.substr(os, p - os);
+    k += pieces;
+  }
+  return "";
+}
+
+}  // namespace wga

@@ -1,0 +1,131 @@
+/*
+ * wga_host.hpp — host side of the drop-in: record types, text parsers and writers with the
+ * reference's semantics (C++ because the image has no Rust toolchain).  No compute here: the
+ * drivers in wgatools_main.cpp hand batches to libwgahip.so through include/wga_hip.h.
+ *
+ * Mirrors (reference file:line)
+ *   PafRecord / PAFReader          parser/paf.rs:13-78      (csv crate: tab, flexible, '#' comments)
+ *   get_cigar_string / cs_to_cigar parser/paf.rs:122-218
+ *   MAFSLine / MAFRecord / reader  parser/maf.rs:65-73,138-211,216-220,371-421,424-478
+ *   MAFWriter                      parser/maf.rs:543-582
+ *   faidx fetch_seq_string         rust-htslib 0.44.1 faidx (htslib faidx_fetch_seq64)  [unpinned]
+ *   RecStat::from                  parser/common.rs:116-140
+ *   Statistic / merge / split      tools/stat.rs:27-50,129-223
+ *   csv writer, ryu f32, natord    csv 1.2.2 / ryu 1.0.14 / natord 1.0.9                [unpinned]
+ */
+#ifndef WGA_HOST_HPP
+#define WGA_HOST_HPP
+
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/wga_hip.h"
+
+namespace wga {
+
+/* errors: message text of WGAError (errors.rs:8-86); thrown, caught in main, printed as
+ * "<timestamp> ERROR <msg>" on stderr, exit code 1 (main.rs:14-21, log.rs:9-31) */
+struct Error {
+  std::string msg;
+};
+[[noreturn]] void fail(const std::string& msg);
+
+/* ---- input / output (utils.rs:135-246: plain or gzip; "-" = stdin/stdout; -r to overwrite) --- */
+std::string read_all(const std::string* path); /* nullptr = stdin */
+struct Output {
+  std::string path;
+  void* gz = nullptr;
+  FILE* fp = nullptr;
+  void open(const std::string& path, bool rewrite);
+  void write(const char* p, size_t n);
+  void write(const std::string& s) { write(s.data(), s.size()); }
+  void close();
+};
+
+/* ---- PAF ------------------------------------------------------------------------------------ */
+struct PafRecord { /* paf.rs:50-65 */
+  std::string query_name;
+  uint64_t query_length = 0, query_start = 0, query_end = 0;
+  bool neg = false;
+  std::string target_name;
+  uint64_t target_length = 0, target_start = 0, target_end = 0;
+  uint64_t matches = 0, block_length = 0, mapq = 0;
+  std::vector<std::string> tags;
+};
+/* csv-crate reading: records end at \n, \r\n or \r; empty lines and lines starting with '#' are
+ * skipped; fields split on tabs with '"' quoting. */
+std::vector<PafRecord> parse_paf(const std::string& text);
+/* paf.rs:122-141: the cg:Z: tag, or the cs:Z: tag converted; "" + err=1 when neither exists */
+std::string paf_cigar_string(const PafRecord& r, int* err);
+std::string cs_to_cigar(const std::string& cs);
+
+/* ---- MAF ------------------------------------------------------------------------------------ */
+struct MafSLine { /* maf.rs:65-73 */
+  std::string name;
+  uint64_t start = 0, align_size = 0;
+  bool neg = false;
+  uint64_t size = 0;
+  std::string seq;
+};
+struct MafRecord { /* maf.rs:216-220 */
+  uint64_t score = 255;
+  std::vector<MafSLine> slines;
+  size_t query_idx = 1;
+  /* accessors of maf.rs:424-478 */
+  const MafSLine& t() const { return slines[0]; }
+  const MafSLine& q() const { return slines[query_idx]; }
+  uint64_t query_start() const { return q().neg ? q().size - q().start - q().align_size : q().start; }
+  uint64_t query_end() const { return q().neg ? q().size - q().start : q().start + q().align_size; }
+};
+/* maf.rs:25-36 + 371-421: first line is always the header; a block = maximal run of 's' lines */
+std::vector<MafRecord> parse_maf(const std::string& text, std::string* header);
+
+/* ---- FASTA index ------------------------------------------------------------------------------ */
+struct Faidx {
+  struct Contig {
+    uint64_t len, pool_off;
+  };
+  std::unordered_map<std::string, Contig> contigs;
+  std::string pool; /* all contigs, newlines stripped, case preserved */
+  void load(const std::string& path);
+  /* faidx_fetch_seq64(name, beg, end inclusive) clipping: returns (pool offset, length) */
+  void fetch(const std::string& name, uint64_t beg, uint64_t end_incl, uint64_t* off, uint64_t* len) const;
+};
+
+/* ---- formatting ------------------------------------------------------------------------------- */
+void append_u64(std::string& s, uint64_t v);
+/* ryu::Buffer::format(f32) as used by csv's serializer */
+std::string format_f32(float f);
+/* csv writer, QuoteStyle::Necessary */
+void append_csv_field(std::string& s, const std::string& f, char delim);
+/* natord::compare (natural order, digit runs numeric) */
+int natord_compare(const std::string& a, const std::string& b);
+
+/* ---- stat ------------------------------------------------------------------------------------- */
+struct RecStat { /* common.rs:99-113 */
+  uint64_t aligned_size = 0, matched = 0, mismatched = 0, ins_event = 0, del_event = 0,
+           ins_size = 0, del_size = 0, inv_ins_event = 0, inv_ins_size = 0, inv_del_event = 0,
+           inv_del_size = 0, inv_event = 0;
+  float inv_size = 0.0f;
+};
+RecStat recstat_from(const wga_cigar_counts& c); /* common.rs:116-140 */
+struct StatInput {
+  std::string ref_name, query_name;
+  uint64_t ref_size, query_size, ref_start, query_start;
+  RecStat rs;
+};
+/* stat.rs:107-223: merge by (ref,ref_size,query,query_size) or one row per record, stable natord
+ * sort by ref_name, TSV with header row (only when there is at least one row). */
+std::string stat_tsv(const std::vector<StatInput>& recs, bool each);
+
+/* error message for a tokeniser failure (errors.rs:51-60), given the CIGAR text after the tag */
+std::string cigar_error_message(int32_t err, const std::string& cigar, size_t tok_off, size_t tok_len);
+/* the op char of packed op index `idx` of a CIGAR text (for CigarOpInvalid raised by a kernel) */
+std::string cigar_op_token_at(const std::string& cigar, uint64_t op_idx);
+
+}  // namespace wga
+#endif

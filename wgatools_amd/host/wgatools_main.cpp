@@ -1,0 +1,630 @@
+/*
+ * wgatools_main.cpp — the `wgatools <subcmd>` command line for the subcommands on the CIGAR hot
+ * path, driving libwgahip.so through the C-ABI (include/wga_hip.h).  Flags, aliases, output text
+ * and error behaviour follow the reference CLI (cli.rs:20-36,39-325; main.rs:14-206;
+ * utils.rs wrap_*).  Subcommands off the hot path are not provided.
+ *
+ *   paf2maf | p2m   converter.rs:176-265      stat | st      tools/stat.rs:61-126
+ *   maf2paf | m2p   converter.rs:29-54        pafcov | pc    tools/pafcov.rs:13-83
+ */
+#include <stdio.h>
+#include <string.h>
+#include <time.h>
+
+#include <algorithm>
+
+#include "wga_host.hpp"
+
+using namespace wga;
+
+namespace {
+
+/* ---- device helper ---------------------------------------------------------------------------- */
+struct Dev {
+  wga_ctx* ctx = nullptr;
+  std::vector<void*> owned;
+  void init() {
+    if (ctx) return;
+    int rc = wga_ctx_create(0, &ctx);
+    if (rc) fail(std::string("GPU engine: ") + wga_last_error());
+  }
+  void check(int rc) {
+    if (rc) fail(std::string("GPU engine: ") + wga_last_error());
+  }
+  void* alloc(size_t bytes) {
+    void* p = nullptr;
+    check(wga_malloc(ctx, bytes ? bytes : 16, &p));
+    owned.push_back(p);
+    return p;
+  }
+  template <typename T>
+  T* upload(const T* h, size_t n) {
+    T* d = (T*)alloc(n * sizeof(T));
+    if (n) check(wga_memcpy_h2d(ctx, d, h, n * sizeof(T)));
+    return d;
+  }
+  template <typename T>
+  T* upload(const std::vector<T>& v) { return upload(v.data(), v.size()); }
+  template <typename T>
+  void download(T* h, const T* d, size_t n) { check(wga_memcpy_d2h(ctx, h, d, n * sizeof(T))); }
+  void release(void* p) {
+    auto it = std::find(owned.begin(), owned.end(), p);
+    if (it != owned.end()) owned.erase(it);
+    wga_free(ctx, p);
+  }
+  void release_all() {
+    check(wga_sync(ctx));
+    for (void* p : owned) wga_free(ctx, p);
+    owned.clear();
+  }
+  ~Dev() {
+    if (ctx) {
+      for (void* p : owned) wga_free(ctx, p);
+      wga_ctx_destroy(ctx);
+    }
+  }
+};
+
+/* a packed batch of PAF CIGARs (host side of wga_cigar_batch) */
+struct PackedBatch {
+  std::vector<uint32_t> ops;
+  std::vector<uint64_t> op_off{0};
+  std::vector<uint8_t> strand;
+  std::vector<std::string> cigars; /* text after the tag, for error messages */
+};
+
+/* Pack record r; returns "" or the reference's error message for this record. */
+std::string pack_record(const PafRecord& r, PackedBatch& b) {
+  int err = 0;
+  std::string cg = paf_cigar_string(r, &err);
+  if (err) return "CIGAR start tag not found"; /* errors.rs:57 */
+  std::string text = cg.substr(5);
+  size_t need = text.size() + 1, n = 0, eo = 0, el = 0;
+  int32_t rerr = 0;
+  size_t base = b.ops.size();
+  b.ops.resize(base + need);
+  int rc = wga_cigar_pack(text.data(), text.size(), b.ops.data() + base, need, &n, &rerr, &eo, &el);
+  if (rc == WGA_E_TOO_SMALL) { /* lengths >= 2^28 were split */
+    b.ops.resize(base + n);
+    rc = wga_cigar_pack(text.data(), text.size(), b.ops.data() + base, n, &n, &rerr, &eo, &el);
+  }
+  b.ops.resize(base + n);
+  if (rerr) {
+    b.ops.resize(base);
+    return cigar_error_message(rerr, text, eo, el);
+  }
+  b.op_off.push_back(b.ops.size());
+  b.strand.push_back(r.neg ? 1 : 0);
+  b.cigars.push_back(std::move(text));
+  return "";
+}
+
+wga_cigar_batch device_batch(Dev& d, const PackedBatch& b) {
+  wga_cigar_batch cb;
+  cb.d_ops = d.upload(b.ops);
+  cb.d_op_off = d.upload(b.op_off);
+  cb.d_strand_neg = d.upload(b.strand);
+  cb.n_ops = b.ops.size();
+  cb.n = (uint32_t)b.strand.size();
+  return cb;
+}
+
+/* ---- paf2maf (converter.rs:176-265) ------------------------------------------------------------- */
+int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::string& q_fa, Output& out) {
+  std::vector<PafRecord> recs = parse_paf(read_all(input));
+  Faidx tf, qf;
+  tf.load(t_fa);
+  qf.load(q_fa);
+  out.write("#maf version=1.6 convert_from=paf t_seq_path=" + t_fa + " q_seq_path=" + q_fa + "\n");
+  Dev d;
+  d.init();
+  uint8_t* d_tpool = d.upload((const uint8_t*)tf.pool.data(), tf.pool.size());
+  uint8_t* d_qpool = d.upload((const uint8_t*)qf.pool.data(), qf.pool.size());
+  const uint64_t kMaxOps = 64ull << 20, kMaxBytes = 6ull << 30;
+  size_t i0 = 0;
+  std::string pending_error;
+  while (i0 < recs.size() && pending_error.empty()) {
+    PackedBatch b;
+    std::vector<uint64_t> t_off, t_len, q_off, q_len;
+    std::vector<uint32_t> pre_t, pre_q, post;
+    std::string blob;
+    std::vector<uint64_t> blob_off{0};
+    uint64_t est = 0;
+    size_t i = i0;
+    for (; i < recs.size(); i++) {
+      const PafRecord& r = recs[i];
+      if (!b.strand.empty() && (b.ops.size() > kMaxOps || est > kMaxBytes)) break;
+      uint64_t to, tl, qo, ql;
+      try { /* fetch order of converter.rs:219-225: target first, then query */
+        tf.fetch(r.target_name, r.target_start, r.target_end - 1, &to, &tl);
+        qf.fetch(r.query_name, r.query_start, r.query_end - 1, &qo, &ql);
+      } catch (Error& e) {
+        pending_error = e.msg;
+        break;
+      }
+      /* reverse_complement runs before the CIGAR is looked at: an invalid base wins — the
+       * kernel reports it; tag / tokeniser errors are known now */
+      std::string perr = pack_record(r, b);
+      if (!perr.empty()) {
+        /* ... unless the query slice holds an invalid base (checked on the host: rare path) */
+        if (r.neg)
+          for (uint64_t k = ql; k-- > 0;) {
+            char c = qf.pool[qo + k];
+            if (!strchr("ACGTNacgtn", c) || c == 0) {
+              perr = std::string("Invalid Base: `") + c + "`";
+              break;
+            }
+          }
+        pending_error = perr;
+        break;
+      }
+      t_off.push_back(to);
+      t_len.push_back(tl);
+      q_off.push_back(qo);
+      q_len.push_back(ql);
+      std::string a = "a score=";
+      append_u64(a, r.mapq);
+      a += "\ns\t" + r.target_name + "\t";
+      append_u64(a, r.target_start);
+      a.push_back('\t');
+      append_u64(a, r.target_end - r.target_start);
+      a += "\t+\t";
+      append_u64(a, r.target_length);
+      a.push_back('\t');
+      std::string q = "\ns\t" + r.query_name + "\t";
+      append_u64(q, r.neg ? r.query_length - r.query_end : r.query_start); /* converter.rs:213-216 */
+      q.push_back('\t');
+      append_u64(q, r.query_end - r.query_start);
+      q += r.neg ? "\t-\t" : "\t+\t";
+      append_u64(q, r.query_length);
+      q.push_back('\t');
+      pre_t.push_back((uint32_t)a.size());
+      pre_q.push_back((uint32_t)q.size());
+      post.push_back(2);
+      blob += a;
+      blob_off.push_back(blob.size());
+      blob += q;
+      blob_off.push_back(blob.size());
+      blob += "\n\n";
+      blob_off.push_back(blob.size());
+      est += tl + ql + (tl + ql) / 4;
+    }
+    const uint32_t n = (uint32_t)b.strand.size();
+    if (n) {
+      wga_cigar_batch cb = device_batch(d, b);
+      auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
+      auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
+      void* d_tiles = d.alloc(wga_tile_ws_bytes(cb.n_ops));
+      d.check(wga_cigar_stat(d.ctx, &cb, d_counts, d_diag, d_tiles));
+      uint64_t *d_to = d.upload(t_off), *d_tl = d.upload(t_len), *d_qo = d.upload(q_off), *d_ql = d.upload(q_len);
+      uint32_t *d_pt = d.upload(pre_t), *d_pq = d.upload(pre_q), *d_po = d.upload(post);
+      auto* d_tro = (uint64_t*)d.alloc((size_t)n * 8);
+      auto* d_qro = (uint64_t*)d.alloc((size_t)n * 8);
+      auto* d_rec = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+      d.check(wga_paf2maf_layout(d.ctx, n, d_counts, d_tl, d_ql, d_pt, d_pq, d_po, d_tro, d_qro, d_rec));
+      std::vector<uint64_t> rec_off(n + 1), tro(n), qro(n);
+      d.download(rec_off.data(), d_rec, n + 1);
+      d.download(tro.data(), d_tro, n);
+      d.download(qro.data(), d_qro, n);
+      std::vector<wga_cigar_counts> counts(n);
+      d.download(counts.data(), d_counts, n);
+      auto* d_out = (uint8_t*)d.alloc(rec_off[n] + 64);
+      d.check(wga_paf2maf_expand(d.ctx, &cb, d_counts, d_tiles, d_tpool, tf.pool.size(), d_to, d_tl, d_qpool,
+                                 qf.pool.size(), d_qo, d_ql, d_out, d_tro, d_qro, d_diag));
+      /* the MAF line text around the rows: three snippets per record */
+      std::vector<uint64_t> dst(3 * (size_t)n);
+      for (uint32_t k = 0; k < n; k++) {
+        dst[3 * k] = rec_off[k];
+        dst[3 * k + 1] = tro[k] + t_len[k] + counts[k].ins_bp + counts[k].inv_ins_bp;
+        dst[3 * k + 2] = rec_off[k + 1] - 2;
+      }
+      uint8_t* d_blob = d.upload((const uint8_t*)blob.data(), blob.size());
+      uint64_t *d_boff = d.upload(blob_off), *d_dst = d.upload(dst);
+      d.check(wga_scatter_bytes(d.ctx, 3 * n, d_blob, d_boff, d_out, d_dst));
+      std::vector<wga_rec_diag> diag(n);
+      d.download(diag.data(), d_diag, n);
+      uint32_t good = n;
+      for (uint32_t k = 0; k < n; k++) {
+        const wga_rec_diag& g = diag[k];
+        if (g.bad_base_pos == WGA_NONE && g.bad_op_idx == WGA_NONE && g.panic_op_idx == WGA_NONE) continue;
+        good = k;
+        if (g.bad_base_pos != WGA_NONE) { /* utils.rs:97 */
+          char c = qf.pool[q_off[k] + q_len[k] - 1 - g.bad_base_pos];
+          pending_error = std::string("Invalid Base: `") + c + "`";
+        } else if (g.bad_op_idx < g.panic_op_idx) { /* errors.rs:59 */
+          pending_error = "CIGAR OP `" + cigar_op_token_at(b.cigars[k], g.bad_op_idx) + "` invalid";
+        } else {
+          pending_error = "panic: String::insert_str beyond the end of the fetched sequence (cigar.rs:507,513)";
+        }
+        break;
+      }
+      std::string host((size_t)rec_off[good], '\0');
+      if (rec_off[good]) d.download((uint8_t*)host.data(), d_out, rec_off[good]);
+      out.write(host);
+      /* free this batch's buffers (the pools stay) */
+      d.check(wga_sync(d.ctx));
+      while (d.owned.size() > 2) d.release(d.owned.back());
+    }
+    i0 = i;
+  }
+  out.close();
+  if (!pending_error.empty()) fail(pending_error);
+  return 0;
+}
+
+/* ---- stat (stat.rs) ----------------------------------------------------------------------------- */
+int cmd_stat_paf(const std::string* input, bool each, Output& out) {
+  std::vector<PafRecord> recs = parse_paf(read_all(input));
+  PackedBatch b;
+  for (const auto& r : recs) {
+    std::string e = pack_record(r, b);
+    if (!e.empty()) fail(e); /* buffered driver: nothing is written on error */
+  }
+  const uint32_t n = (uint32_t)b.strand.size();
+  std::vector<wga_cigar_counts> counts(n);
+  if (n) {
+    Dev d;
+    d.init();
+    wga_cigar_batch cb = device_batch(d, b);
+    auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
+    auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
+    d.check(wga_cigar_stat(d.ctx, &cb, d_counts, d_diag, nullptr));
+    std::vector<wga_rec_diag> diag(n);
+    d.download(diag.data(), d_diag, n);
+    d.download(counts.data(), d_counts, n);
+    for (uint32_t k = 0; k < n; k++)
+      if (diag[k].bad_op_idx != WGA_NONE)
+        fail("CIGAR OP `" + cigar_op_token_at(b.cigars[k], diag[k].bad_op_idx) + "` invalid");
+  }
+  std::vector<StatInput> in;
+  in.reserve(n);
+  for (uint32_t k = 0; k < n; k++) {
+    const PafRecord& r = recs[k];
+    in.push_back(StatInput{r.target_name, r.query_name, r.target_length, r.query_length, r.target_start,
+                           r.query_start, recstat_from(counts[k])});
+  }
+  out.write(stat_tsv(in, each));
+  out.close();
+  return 0;
+}
+
+/* MAF blocks -> one row buffer + offsets; runs the column-pair kernel */
+struct MafPairs {
+  std::string rows;
+  std::vector<uint64_t> t_off, q_off, cols;
+  std::vector<uint8_t> strand;
+};
+void select_query(std::vector<MafRecord>& recs, const std::string* query_name) {
+  for (auto& r : recs) {
+    if (query_name) { /* maf.rs:277-285 */
+      size_t k = 0;
+      for (; k < r.slines.size(); k++)
+        if (r.slines[k].name == *query_name) break;
+      if (k == r.slines.size()) fail("Query name:" + *query_name + " not found in MAF");
+      r.query_idx = k;
+    }
+    if (r.query_idx >= r.slines.size())
+      fail("panic: MAF block with a single s-line has no query row (maf.rs:426 index out of bounds)");
+  }
+}
+MafPairs gather_pairs(const std::vector<MafRecord>& recs) {
+  MafPairs p;
+  for (const auto& r : recs) {
+    p.t_off.push_back(p.rows.size());
+    p.rows += r.t().seq;
+    p.q_off.push_back(p.rows.size());
+    p.rows += r.q().seq;
+    p.cols.push_back(std::min(r.t().seq.size(), r.q().seq.size()));
+    p.strand.push_back(r.q().neg ? 1 : 0);
+  }
+  return p;
+}
+
+int cmd_stat_maf(const std::string* input, bool each, const std::string* query_name, Output& out) {
+  std::string header;
+  std::vector<MafRecord> recs = parse_maf(read_all(input), &header);
+  select_query(recs, query_name);
+  const uint32_t n = (uint32_t)recs.size();
+  std::vector<wga_cigar_counts> counts(n);
+  if (n) {
+    MafPairs p = gather_pairs(recs);
+    Dev d;
+    d.init();
+    auto* d_rows = d.upload((const uint8_t*)p.rows.data(), p.rows.size());
+    auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
+    auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
+    d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d.upload(p.t_off), d.upload(p.q_off), d.upload(p.cols),
+                              d.upload(p.strand), d_counts, d_cnt, nullptr, nullptr));
+    d.download(counts.data(), d_counts, n);
+  }
+  std::vector<StatInput> in;
+  for (uint32_t k = 0; k < n; k++) {
+    const MafRecord& r = recs[k];
+    in.push_back(StatInput{r.t().name, r.q().name, r.t().size, r.q().size, r.t().start, r.query_start(),
+                           recstat_from(counts[k])});
+  }
+  out.write(stat_tsv(in, each));
+  out.close();
+  return 0;
+}
+
+/* ---- maf2paf (converter.rs:29-54, maf.rs:484-520) ------------------------------------------------ */
+int cmd_maf2paf(const std::string* input, const std::string* query_name, Output& out) {
+  std::string header;
+  std::vector<MafRecord> recs = parse_maf(read_all(input), &header);
+  select_query(recs, query_name);
+  const uint32_t n = (uint32_t)recs.size();
+  std::string text;
+  if (n) {
+    MafPairs p = gather_pairs(recs);
+    Dev d;
+    d.init();
+    auto* d_rows = d.upload((const uint8_t*)p.rows.data(), p.rows.size());
+    auto *d_t = d.upload(p.t_off), *d_q = d.upload(p.q_off), *d_c = d.upload(p.cols);
+    auto* d_s = d.upload(p.strand);
+    auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
+    auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
+    d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, nullptr, nullptr));
+    auto* d_roff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+    d.check(wga_exclusive_scan_u64(d.ctx, n, d_cnt, d_roff));
+    std::vector<uint64_t> roff(n + 1);
+    d.download(roff.data(), d_roff, n + 1);
+    auto* d_runs = (uint64_t*)d.alloc((roff[n] + 1) * 8);
+    d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, d_runs, d_roff));
+    std::vector<uint64_t> runs(roff[n]);
+    if (roff[n]) d.download(runs.data(), d_runs, roff[n]);
+    std::vector<wga_cigar_counts> counts(n);
+    d.download(counts.data(), d_counts, n);
+    for (uint32_t k = 0; k < n; k++) {
+      const MafRecord& r = recs[k];
+      const wga_cigar_counts& c = counts[k];
+      uint64_t block = c.match + c.mismatch + c.ins_bp + c.inv_ins_bp + c.del_bp + c.inv_del_bp;
+      append_csv_field(text, r.q().name, '\t');
+      uint64_t a[] = {r.q().size, r.query_start(), r.query_end()};
+      for (uint64_t v : a) {
+        text.push_back('\t');
+        append_u64(text, v);
+      }
+      text += r.q().neg ? "\t-\t" : "\t+\t";
+      append_csv_field(text, r.t().name, '\t');
+      uint64_t bb[] = {r.t().size, r.t().start, r.t().start + r.t().align_size, c.match, block, 255};
+      for (uint64_t v : bb) {
+        text.push_back('\t');
+        append_u64(text, v);
+      }
+      text += "\tNM:i:";
+      append_u64(text, block - c.match);
+      text += "\tcg:Z:";
+      for (uint64_t x = roff[k]; x < roff[k + 1]; x++) {
+        uint64_t start = runs[x] >> 3, end = x + 1 < roff[k + 1] ? runs[x + 1] >> 3 : p.cols[k];
+        append_u64(text, end - start);
+        text.push_back("=IDX"[runs[x] & 7]);
+      }
+      text.push_back('\n');
+    }
+  }
+  out.write(text);
+  out.close();
+  return 0;
+}
+
+/* ---- pafcov (pafcov.rs:13-83) --------------------------------------------------------------------- */
+int cmd_pafcov(const std::string* input, Output& out) {
+  std::vector<PafRecord> recs = parse_paf(read_all(input));
+  PackedBatch b;
+  std::vector<std::string> targets; /* first-appearance order (the reference: HashMap order) */
+  std::unordered_map<std::string, uint32_t> tid;
+  std::vector<uint64_t> cov_len, t_start;
+  std::vector<uint32_t> target_id;
+  for (const auto& r : recs) {
+    std::string e = pack_record(r, b);
+    if (!e.empty()) fail(e);
+    auto it = tid.find(r.target_name);
+    if (it == tid.end()) { /* array length = target_length of the first record seen */
+      it = tid.emplace(r.target_name, (uint32_t)targets.size()).first;
+      targets.push_back(r.target_name);
+      cov_len.push_back(r.target_length);
+    }
+    target_id.push_back(it->second);
+    t_start.push_back(r.target_start);
+  }
+  const uint32_t n = (uint32_t)b.strand.size(), nt = (uint32_t)targets.size();
+  if (n) {
+    std::vector<uint64_t> cov_off(nt);
+    uint64_t total = 0;
+    for (uint32_t t = 0; t < nt; t++) {
+      cov_off[t] = total;
+      total += (cov_len[t] + 3) & ~3ull;
+    }
+    Dev d;
+    d.init();
+    wga_cigar_batch cb = device_batch(d, b);
+    auto* d_cov = (int32_t*)d.alloc((total + 4) * 4);
+    d.check(wga_memset(d.ctx, d_cov, 0, (total + 4) * 4));
+    auto *d_off = d.upload(cov_off), *d_len = d.upload(cov_len);
+    d.check(wga_pafcov_accumulate(d.ctx, &cb, d.upload(target_id), d.upload(t_start), d_off, d_len, d_cov));
+    d.check(wga_pafcov_finalize(d.ctx, nt, d_off, d_len, d_cov));
+    std::vector<int32_t> cov(total);
+    if (total) d.download(cov.data(), d_cov, total);
+    std::string text;
+    for (uint32_t t = 0; t < nt; t++) {
+      for (uint64_t pos = 0; pos < cov_len[t]; pos++) {
+        text += targets[t];
+        text.push_back('\t');
+        append_u64(text, pos);
+        text.push_back('\t');
+        append_u64(text, pos + 1);
+        text.push_back('\t');
+        append_u64(text, (uint64_t)(uint32_t)cov[cov_off[t] + pos]);
+        text.push_back('\n');
+        if (text.size() > (1u << 24)) {
+          out.write(text);
+          text.clear();
+        }
+      }
+    }
+    out.write(text);
+  }
+  out.close();
+  return 0;
+}
+
+/* ---- command line (cli.rs) -------------------------------------------------------------------------- */
+void log_error(const std::string& msg) {
+  struct timespec ts;
+  clock_gettime(CLOCK_REALTIME, &ts);
+  struct tm tmv;
+  localtime_r(&ts.tv_sec, &tmv);
+  char d[64], z[16];
+  strftime(d, sizeof d, "%Y-%m-%dT%H:%M:%S", &tmv);
+  strftime(z, sizeof z, "%z", &tmv);
+  fprintf(stderr, "%s.%09ld%.3s:%.2s ERROR %s\n", d, ts.tv_nsec, z, z + 3, msg.c_str());
+}
+
+void usage() {
+  fprintf(stderr,
+          "wgatools (MI355X engine) — subcommands on the CIGAR hot path\n"
+          "Usage: wgatools [-o OUT] [-r] [-t N] [-v] <COMMAND>\n"
+          "  paf2maf | p2m  [PAF] -g TARGET.fa -q QUERY.fa\n"
+          "  maf2paf | m2p  [MAF] [-q QUERY_NAME]\n"
+          "  stat    | st   [FILE] [-f maf|paf] [-e] [-q QUERY_NAME]\n"
+          "  pafcov  | pc   [PAF]\n");
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  try {
+    std::string outfile = "-", cmd;
+    bool rewrite = false;
+    std::vector<std::string> rest;
+    for (int i = 1; i < argc; i++) {
+      std::string a = argv[i];
+      auto val = [&](const char* name) -> std::string {
+        if (i + 1 >= argc) fail(std::string("a value is required for '") + name + "'");
+        return argv[++i];
+      };
+      if (a == "-o" || a == "--outfile")
+        outfile = val("--outfile");
+      else if (a.compare(0, 10, "--outfile=") == 0)
+        outfile = a.substr(10);
+      else if (a == "-r" || a == "--rewrite")
+        rewrite = true;
+      else if (a == "-t" || a == "--threads")
+        (void)val("--threads");
+      else if (a.size() >= 2 && a[0] == '-' && a.find_first_not_of('v', 1) == std::string::npos)
+        ; /* -v, -vv, ... logging level */
+      else if (a == "--verbose")
+        ;
+      else if (a == "-h" || a == "--help") {
+        usage();
+        return 0;
+      } else if (cmd.empty() && a[0] != '-')
+        cmd = a;
+      else
+        rest.push_back(a);
+    }
+    if (cmd.empty()) {
+      usage();
+      return 2;
+    }
+    /* hidden hooks for the CPU unit tests of the host formatters (no GPU involved) */
+    if (cmd == "__fmt_f32") {
+      for (const auto& a : rest) {
+        uint32_t bits = (uint32_t)strtoul(a.c_str(), nullptr, 16);
+        float f;
+        memcpy(&f, &bits, 4);
+        printf("%s\n", format_f32(f).c_str());
+      }
+      return 0;
+    }
+    if (cmd == "__natord") {
+      for (size_t i = 0; i + 1 < rest.size(); i += 2) printf("%d\n", natord_compare(rest[i], rest[i + 1]));
+      return 0;
+    }
+    if (cmd == "__cs2cg") {
+      for (const auto& a : rest) printf("%s\n", cs_to_cigar(a).c_str());
+      return 0;
+    }
+    if (cmd == "__parse_paf" || cmd == "__parse_maf") { /* echo the parsed records */
+      std::string text = read_all(rest.empty() ? nullptr : &rest[0]);
+      if (cmd == "__parse_paf") {
+        for (const auto& r : parse_paf(text)) {
+          printf("%s|%llu|%llu|%llu|%c|%s|%llu|%llu|%llu|%llu|%llu|%llu", r.query_name.c_str(),
+                 (unsigned long long)r.query_length, (unsigned long long)r.query_start,
+                 (unsigned long long)r.query_end, r.neg ? '-' : '+', r.target_name.c_str(),
+                 (unsigned long long)r.target_length, (unsigned long long)r.target_start,
+                 (unsigned long long)r.target_end, (unsigned long long)r.matches,
+                 (unsigned long long)r.block_length, (unsigned long long)r.mapq);
+          for (const auto& t : r.tags) printf("|%s", t.c_str());
+          printf("\n");
+        }
+      } else {
+        std::string header;
+        for (const auto& r : parse_maf(text, &header)) {
+          printf("block %zu", r.slines.size());
+          for (const auto& sl : r.slines)
+            printf(" [%s %llu %llu %c %llu %zu]", sl.name.c_str(), (unsigned long long)sl.start,
+                   (unsigned long long)sl.align_size, sl.neg ? '-' : '+', (unsigned long long)sl.size,
+                   sl.seq.size());
+          printf("\n");
+        }
+      }
+      return 0;
+    }
+    /* per-subcommand options */
+    std::string input_s, target, query, format = "maf", query_name;
+    bool has_input = false, each = false, has_qname = false;
+    for (size_t i = 0; i < rest.size(); i++) {
+      const std::string& a = rest[i];
+      auto val = [&]() -> std::string {
+        if (i + 1 >= rest.size()) fail("a value is required for '" + a + "'");
+        return rest[++i];
+      };
+      bool conv = cmd == "paf2maf" || cmd == "p2m";
+      if (a == "-g" || a == "--target")
+        target = val();
+      else if ((a == "-q" || a == "--query") && conv)
+        query = val();
+      else if (a == "-q" || a == "--query-name") {
+        query_name = val();
+        has_qname = true;
+      } else if (a == "-f" || a == "--format")
+        format = val();
+      else if (a == "-e" || a == "--each")
+        each = true;
+      else if (a[0] != '-' && !has_input) {
+        input_s = a;
+        has_input = true;
+      } else
+        fail("unexpected argument '" + a + "'");
+    }
+    const std::string* input = has_input ? &input_s : nullptr;
+    const std::string* qn = has_qname ? &query_name : nullptr;
+    Output out;
+    if (cmd == "paf2maf" || cmd == "p2m") {
+      if (target.empty() || query.empty()) fail("the following required arguments were not provided: --target --query");
+      out.open(outfile, rewrite);
+      return cmd_paf2maf(input, target, query, out);
+    }
+    if (cmd == "stat" || cmd == "st") {
+      out.open(outfile, rewrite);
+      if (format == "paf") return cmd_stat_paf(input, each, out);
+      if (format == "maf") return cmd_stat_maf(input, each, qn, out);
+      fail("format `" + format + "` is not supported by this engine (maf | paf)");
+    }
+    if (cmd == "maf2paf" || cmd == "m2p") {
+      out.open(outfile, rewrite);
+      return cmd_maf2paf(input, qn, out);
+    }
+    if (cmd == "pafcov" || cmd == "pc") {
+      out.open(outfile, rewrite);
+      return cmd_pafcov(input, out);
+    }
+    fail("subcommand `" + cmd + "` is not on the CIGAR hot path and is not provided by this engine");
+  } catch (Error& e) {
+    log_error(e.msg);
+    return 1;
+  }
+  return 0;
+}
