@@ -182,3 +182,120 @@ def test_stat_paf_matches_oracle_aggregation(cli, tmp_path):
             tot["inv_del_size"]))))
     exp.sort(key=lambda t: natkey(t[0]))   # python's sort is stable
     assert rows[1:] == [e[1] for e in exp]
+
+
+def _rust_bsearch_pos(keys, key):
+    size, left, right = len(keys), 0, len(keys)
+    while left < right:
+        mid = left + size // 2
+        if keys[mid] == key:
+            return mid
+        if keys[mid] < key:
+            left = mid + 1
+        else:
+            right = mid
+        size = right - left
+    return left
+
+
+def _expected_pseudo_files(recs, contigs, base):
+    """pseudomaf.rs:18-210 restated in Python over the oracle's gen_pesudo_maf_by_cigar"""
+    import collections
+    targets = collections.OrderedDict()
+    for r in recs:
+        targets.setdefault(r["tname"], []).append(r)
+    files = {}
+    for tname, trecs in targets.items():
+        queries = collections.OrderedDict()
+        for r in trecs:
+            lst = queries.setdefault(r["qname"], [])
+            lst.insert(_rust_bsearch_pos([x["tstart"] for x in lst], r["tstart"]), r)
+        out = [b"a score=0\n"]
+        first = True
+        target_size = 0
+        for qname, lst in queries.items():
+            first_query, last_end = True, 0
+            for r in lst:
+                target_size = r["tlen"]
+                if first:
+                    seq = contigs[tname][:target_size] if base else b"N" * target_size
+                    out.append(b"s\t%s\t0\t%d\t+\t%d\t%s\n" % (tname.encode(), target_size, target_size, seq))
+                    first = False
+                if first_query:
+                    out.append(b"s\t%s\t0\t%d\t+\t%d\t" % (qname.encode(), r["qlen"], r["qlen"]))
+                overlap = 0
+                if r["tstart"] > last_end:
+                    out.append(b"-" * (r["tstart"] - last_end))
+                else:
+                    if last_end > r["tend"]:
+                        continue
+                    overlap = last_end - r["tstart"]
+                last_end = r["tend"]
+                q = contigs[qname][r["qstart"]:r["qend"]] if base else b""
+                if base and r["strand"] == "-":
+                    q = orc.reverse_complement(q)
+                seg = orc.gen_pesudo_maf_by_cigar(r["cg"], q, base)
+                out.append(seg[overlap:])
+                first_query = False
+            out.append(b"-" * (target_size - last_end))
+            out.append(b"\n")
+        out.append(b"\n")
+        files[tname] = b"".join(out)
+    return files
+
+
+@pytest.mark.parametrize("base", [False, True])
+def test_pafpseudo_end_to_end(cli, tmp_path, base):
+    rng = np.random.default_rng(5)
+    b = synth.make_paf_batch(91, 36, 60, 60000)
+    cs = synth.class_sums(b["code"], b["length"], b["op_off"])
+    tspan = (cs["mx"] + cs["d"]).astype(np.int64)
+    tnames, qnames = ["tA", "tB", "t10"], ["q1", "q2", "q3"]
+    tsize = {"tA": 9000, "tB": 7000, "t10": 8000}
+    contigs = {q: b["q_pool"].tobytes() for q in qnames}
+    for t in tnames:
+        contigs[t] = pc.rand_seq(rng, tsize[t], b"ACGTacgtN")
+    recs, cursor = [], {}
+    for i in range(36):
+        t, q = tnames[i % 3], qnames[(i // 3) % 3]
+        cur = cursor.get((t, q), 0)
+        mode = rng.integers(0, 4)   # gap / abut / partial overlap / contained
+        start = cur + int(rng.integers(1, 60)) if mode == 0 or cur == 0 else \
+            cur if mode == 1 else max(0, cur - int(rng.integers(1, 40))) if mode == 2 else max(0, cur - int(tspan[i]) - 5)
+        end = start + int(tspan[i])
+        if end > tsize[t]:
+            continue
+        cursor[(t, q)] = max(cur, end)
+        qs = int(b["q_src_off"][i])
+        recs.append(dict(tname=t, qname=q, tlen=tsize[t], tstart=start, tend=end, qlen=len(b["q_pool"]),
+                         qstart=qs, qend=qs + int(b["q_src_len"][i]), strand="-" if b["strand_neg"][i] else "+",
+                         cg=pc.rec_text(b, i)))
+    rng.shuffle(recs)   # input order is not sorted: the sorted insertion does the work
+    paf = tmp_path / "all.paf"
+    with open(paf, "w") as f:
+        for r in recs:
+            f.write("%s\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t0\t0\t60\t%s\n" % (
+                r["qname"], r["qlen"], r["qstart"], r["qend"], r["strand"], r["tname"], r["tlen"], r["tstart"],
+                r["tend"], r["cg"]))
+    fa = tmp_path / "all.fa"
+    with open(fa, "wb") as f:
+        for name, seq in contigs.items():
+            f.write(b">" + name.encode() + b"\n")
+            for k in range(0, len(seq), 60):
+                f.write(seq[k:k + 60] + b"\n")
+    outdir = tmp_path / ("out_base" if base else "out_sym")
+    args = ["pafpseudo", str(paf), "-o", str(outdir)] + (["-f", str(fa)] if base else [])
+    rc, _, err = run(cli, *args)
+    assert rc == 0, err
+    exp = _expected_pseudo_files(recs, contigs, base)
+    assert sorted(os.listdir(outdir)) == sorted(t + ".maf" for t in exp)
+    for t, text in exp.items():
+        got = open(outdir / (t + ".maf"), "rb").read()
+        # the reference writes query rows in HashMap order: compare rows as a multiset, header first
+        assert got.split(b"\n")[:2] == text.split(b"\n")[:2]
+        assert sorted(got.split(b"\n")) == sorted(text.split(b"\n")), t
+    # the directory exists now: refuse without -r, accept with -r, honour -g
+    rc, _, err = run(cli, *args)
+    assert rc == 1 and "already exists" in err
+    rc, _, err = run(cli, *(args + ["-r", "-g", "tB"]))
+    assert rc == 0, err

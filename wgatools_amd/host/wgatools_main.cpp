@@ -9,6 +9,8 @@
  */
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#include <sys/stat.h>
 #include <time.h>
 
 #include <algorithm>
@@ -469,6 +471,210 @@ int cmd_pafcov(const std::string* input, Output& out) {
   return 0;
 }
 
+
+/* ---- pafpseudo (pseudomaf.rs:18-237) ----------------------------------------------------------------
+ * Host: grouping by target / query, insertion sort by target_start, gap / overlap / contained
+ * logic (:86-95,:147-175,:198-202).  GPU: every kept record's segment in target coordinates
+ * (gen_pesudo_maf_by_cigar + the head trim), all targets in one batch. */
+struct PseudoSeg {
+  size_t rec;        /* index into recs */
+  uint64_t gap;      /* '-' columns written before the segment */
+  uint64_t overlap;  /* leading columns dropped */
+};
+struct PseudoQuery {
+  std::string name;
+  uint64_t size = 0;
+  std::vector<size_t> recs; /* sorted by target_start */
+  std::vector<PseudoSeg> segs;
+  uint64_t tail = 0;
+};
+struct PseudoTarget {
+  std::string name;
+  std::vector<size_t> recs;
+  std::vector<PseudoQuery> queries;
+  uint64_t target_size_first = 0;
+};
+
+/* slice::binary_search_by of the Rust std the reference was built with: probe the middle, return
+ * at the first equal element [toolchain-dependent for ties: unpinned] */
+size_t rust_binary_search_pos(const std::vector<size_t>& v, const std::vector<PafRecord>& recs, uint64_t key) {
+  size_t size = v.size(), left = 0, right = size;
+  while (left < right) {
+    size_t mid = left + size / 2;
+    uint64_t probe = recs[v[mid]].target_start;
+    if (probe == key) return mid;
+    if (probe < key)
+      left = mid + 1;
+    else
+      right = mid;
+    size = right - left;
+  }
+  return left;
+}
+
+int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewrite, const std::string* fasta,
+                  const std::string* only_target) {
+  if (outdir == "-") fail("Stdout not allowed here"); /* errors.rs:37 */
+  struct stat st;
+  if (stat(outdir.c_str(), &st) != 0) {
+    std::string cmd = "mkdir -p '" + outdir + "'";
+    if (system(cmd.c_str()) != 0) fail("IO error:cannot create directory `" + outdir + "`");
+  } else {
+    if (!S_ISDIR(st.st_mode)) fail("Path `" + outdir + "` is not a dir");
+    if (!rewrite) fail("File `" + outdir + "` already exists, please add `-r` to rewrite it.");
+  }
+  std::vector<PafRecord> recs = parse_paf(read_all(input));
+  Faidx fa;
+  const bool base = fasta != nullptr;
+  if (base) fa.load(*fasta);
+  /* 1. group by target (:25-42), then by query with sorted insertion (:86-95) */
+  std::vector<PseudoTarget> targets;
+  std::unordered_map<std::string, size_t> tindex;
+  for (size_t i = 0; i < recs.size(); i++) {
+    const PafRecord& r = recs[i];
+    if (only_target && r.target_name != *only_target) continue;
+    auto it = tindex.find(r.target_name);
+    if (it == tindex.end()) {
+      it = tindex.emplace(r.target_name, targets.size()).first;
+      targets.emplace_back();
+      targets.back().name = r.target_name;
+    }
+    targets[it->second].recs.push_back(i);
+  }
+  PackedBatch b;
+  std::vector<uint64_t> q_off, q_len, skip;
+  for (auto& t : targets) {
+    std::unordered_map<std::string, size_t> qindex;
+    for (size_t i : t.recs) {
+      const PafRecord& r = recs[i];
+      auto it = qindex.find(r.query_name);
+      if (it == qindex.end()) {
+        it = qindex.emplace(r.query_name, t.queries.size()).first;
+        t.queries.emplace_back();
+        t.queries.back().name = r.query_name;
+      }
+      PseudoQuery& q = t.queries[it->second];
+      size_t pos = rust_binary_search_pos(q.recs, recs, r.target_start);
+      q.recs.insert(q.recs.begin() + (long)pos, i);
+    }
+    /* 2. walk (:108-205) */
+    uint64_t target_size = 0;
+    bool first = true;
+    for (auto& q : t.queries) {
+      uint64_t last_target_end = 0;
+      bool first_query = true;
+      for (size_t i : q.recs) {
+        const PafRecord& r = recs[i];
+        target_size = r.target_length;
+        if (first) {
+          t.target_size_first = target_size;
+          first = false;
+        }
+        if (first_query) q.size = r.query_length;
+        uint64_t overlap = 0, gap = 0;
+        if (r.target_start > last_target_end) {
+          gap = r.target_start - last_target_end;
+        } else {
+          if (last_target_end > r.target_end) continue; /* contained: dropped */
+          overlap = last_target_end - r.target_start;
+        }
+        last_target_end = r.target_end;
+        uint64_t qo = 0, ql = 0;
+        if (base) fa.fetch(q.name, r.query_start, r.query_end - 1, &qo, &ql); /* :222-225 */
+        std::string e = pack_record(r, b);
+        if (!e.empty()) fail(e);
+        q_off.push_back(qo);
+        q_len.push_back(ql);
+        skip.push_back(overlap);
+        q.segs.push_back(PseudoSeg{i, gap, overlap});
+        first_query = false;
+      }
+      if (last_target_end > target_size)
+        fail("panic: attempt to fill a negative tail (pseudomaf.rs:198 underflows)");
+      q.tail = target_size - last_target_end;
+    }
+  }
+  /* 3. GPU: class sums -> segment lengths -> fill */
+  const uint32_t n = (uint32_t)b.strand.size();
+  std::vector<uint64_t> seg_len(n), dst_off(n + 1, 0);
+  std::string segs;
+  if (n) {
+    Dev d;
+    d.init();
+    wga_cigar_batch cb = device_batch(d, b);
+    auto* d_sums = (wga_class_sums*)d.alloc((size_t)n * sizeof(wga_class_sums));
+    d.check(wga_cigar_class_sums(d.ctx, &cb, d_sums));
+    std::vector<wga_class_sums> sums(n);
+    d.download(sums.data(), d_sums, n);
+    for (uint32_t k = 0; k < n; k++) {
+      uint64_t len = base ? q_len[k] - (sums[k].i + sums[k].s) + sums[k].d : sums[k].mx + sums[k].d;
+      if (base && q_len[k] < sums[k].i + sums[k].s) len = 0; /* reported as a panic below */
+      if (skip[k] > len) fail("panic: String::drain range out of bounds (pseudomaf.rs:191)");
+      seg_len[k] = len - skip[k];
+      dst_off[k + 1] = dst_off[k] + seg_len[k];
+    }
+    auto* d_out = (uint8_t*)d.alloc(dst_off[n] + 64);
+    auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
+    uint8_t* d_pool = base ? d.upload((const uint8_t*)fa.pool.data(), fa.pool.size()) : nullptr;
+    d.check(wga_pafpseudo_fill(d.ctx, &cb, base ? 1 : 0, d_pool, fa.pool.size(), base ? d.upload(q_off) : nullptr,
+                               base ? d.upload(q_len) : nullptr, d.upload(skip), d_out, d.upload(dst_off), d_diag));
+    std::vector<wga_rec_diag> diag(n);
+    d.download(diag.data(), d_diag, n);
+    for (uint32_t k = 0; k < n; k++) {
+      if (diag[k].bad_base_pos != WGA_NONE)
+        fail(std::string("Invalid Base: `") + fa.pool[q_off[k] + q_len[k] - 1 - diag[k].bad_base_pos] + "`");
+      if (diag[k].panic_op_idx != WGA_NONE)
+        fail("panic: String::drain / insert_str beyond the end of the query sequence (cigar.rs:772,779)");
+    }
+    segs.resize(dst_off[n]);
+    if (dst_off[n]) d.download((uint8_t*)segs.data(), d_out, dst_off[n]);
+  }
+  /* 4. one file per target (:62-72, :98-209) */
+  size_t k = 0;
+  for (const auto& t : targets) {
+    Output out;
+    out.open(outdir + "/" + t.name + ".maf", true);
+    std::string text = "a score=0\n";
+    if (!t.queries.empty()) {
+      text += "s\t" + t.name + "\t0\t";
+      append_u64(text, t.target_size_first);
+      text += "\t+\t";
+      append_u64(text, t.target_size_first);
+      text.push_back('\t');
+      if (base) {
+        uint64_t o, l;
+        fa.fetch(t.name, 0, t.target_size_first - 1, &o, &l);
+        text.append(fa.pool, o, l);
+      } else {
+        text.append(t.target_size_first, 'N');
+      }
+      text.push_back('\n');
+    }
+    for (const auto& q : t.queries) {
+      text += "s\t" + q.name + "\t0\t";
+      append_u64(text, q.size);
+      text += "\t+\t";
+      append_u64(text, q.size);
+      text.push_back('\t');
+      for (const auto& sg : q.segs) {
+        text.append(sg.gap, '-');
+        text.append(segs, dst_off[k], seg_len[k]);
+        k++;
+      }
+      text.append(q.tail, '-');
+      text.push_back('\n');
+      if (text.size() > (1u << 26)) {
+        out.write(text);
+        text.clear();
+      }
+    }
+    text.push_back('\n');
+    out.write(text);
+    out.close();
+  }
+  return 0;
+}
+
 /* ---- command line (cli.rs) -------------------------------------------------------------------------- */
 void log_error(const std::string& msg) {
   struct timespec ts;
@@ -488,7 +694,8 @@ void usage() {
           "  paf2maf | p2m  [PAF] -g TARGET.fa -q QUERY.fa\n"
           "  maf2paf | m2p  [MAF] [-q QUERY_NAME]\n"
           "  stat    | st   [FILE] [-f maf|paf] [-e] [-q QUERY_NAME]\n"
-          "  pafcov  | pc   [PAF]\n");
+          "  pafcov  | pc   [PAF]\n"
+          "  pafpseudo | pp [PAF] -o OUTDIR [-f ALL.fa] [-g TARGET]\n");
 }
 
 }  // namespace
@@ -573,8 +780,9 @@ int main(int argc, char** argv) {
       return 0;
     }
     /* per-subcommand options */
-    std::string input_s, target, query, format = "maf", query_name;
-    bool has_input = false, each = false, has_qname = false;
+    std::string input_s, target, query, format = "maf", query_name, fasta;
+    bool has_input = false, each = false, has_qname = false, has_fasta = false;
+    const bool pseudo = cmd == "pafpseudo" || cmd == "pp";
     for (size_t i = 0; i < rest.size(); i++) {
       const std::string& a = rest[i];
       auto val = [&]() -> std::string {
@@ -589,6 +797,9 @@ int main(int argc, char** argv) {
       else if (a == "-q" || a == "--query-name") {
         query_name = val();
         has_qname = true;
+      } else if ((a == "-f" || a == "--fasta") && pseudo) {
+        fasta = val();
+        has_fasta = true;
       } else if (a == "-f" || a == "--format")
         format = val();
       else if (a == "-e" || a == "--each")
@@ -617,6 +828,8 @@ int main(int argc, char** argv) {
       out.open(outfile, rewrite);
       return cmd_maf2paf(input, qn, out);
     }
+    if (pseudo)
+      return cmd_pafpseudo(input, outfile, rewrite, has_fasta ? &fasta : nullptr, target.empty() ? nullptr : &target);
     if (cmd == "pafcov" || cmd == "pc") {
       out.open(outfile, rewrite);
       return cmd_pafcov(input, out);
