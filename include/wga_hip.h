@@ -182,6 +182,17 @@ int wga_maf_pair_stat(wga_ctx*, uint32_t n, const uint8_t* d_rows, const uint64_
                       const uint8_t* d_strand_neg, wga_cigar_counts* d_counts,
                       uint64_t* d_run_cnt, uint64_t* d_runs, const uint64_t* d_run_off);
 
+/* ---- K4: MAF call column walk (replaces the group_by(cigar_cat_ext_caller) scan of
+ *      call_within_var, caller.rs:444-446, and the per-column gap scans of
+ *      find_safe_chunk_boundary :173-199 / create_chunk_record :240-251) -------------------------
+ * Ordered list of maximal runs of equal caller class per record (cigar.rs:314-328), 3 u64 per
+ * run: [0] start_column << 3 | class (0 '=', 1 I, 2 D, 3 X, 4 W = both rows gapped),
+ * [1] non-gap target characters before the run, [2] non-gap query characters before it.
+ * Same two-call protocol as wga_maf_pair_stat (d_runs == NULL sizes; d_run_off counts runs). */
+int wga_maf_call_runs(wga_ctx*, uint32_t n, const uint8_t* d_rows, const uint64_t* d_t_off,
+                      const uint64_t* d_q_off, const uint64_t* d_cols, uint64_t* d_run_cnt,
+                      uint64_t* d_runs, const uint64_t* d_run_off);
+
 /* ---- K5: pafcov (replaces update_cov_vec, cigar.rs:710-741, and the per-thread array merge of
  *      pafcov.rs:29-53) ------------------------------------------------------------------------
  * Record i adds +1 to d_cov[cov_off[target_id[i]] + p] for every base p of its M / = ops that

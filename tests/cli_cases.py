@@ -1,0 +1,402 @@
+"""End-to-end drop-in cases for the `wgatools` command line, text compared byte-for-byte with
+expectations built from the oracle / SURVEY Appendix B.  Imported by test_gpu_cli.py (the real
+binary over libwgahip.so, on a GPU) and test_emu_cli.py (the same host code linked against the
+emulator build of the kernels, on CPU); each provides the `cli` fixture."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_py as orc
+import parity_cases as pc
+from helpers import GOLDEN
+from wgatools_amd import build, synth
+
+STAT_HEADER = ("ref_name\tref_size\tref_start\tquery_name\tquery_size\tquery_start\taligned_size\t"
+               "unaligned_size\tidentity\tsimilarity\tmatched\tmismatched\tins_event\tdel_event\tins_size\t"
+               "del_size\tinv_event\tinv_size\tinv_ins_event\tinv_ins_size\tinv_del_event\tinv_del_size\n")
+
+
+def run(cli, *args):
+    r = subprocess.run([cli] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return r.returncode, r.stdout, r.stderr.decode()
+
+
+def test_stat_maf_fixture(cli):
+    """Appendix B.1"""
+    rc, out, err = run(cli, "stat", os.path.join(GOLDEN, "test.maf"))
+    assert rc == 0, err
+    assert out.decode() == STAT_HEADER + ("ref.chr8\t182411202\t181469925\tquery.chr8\t183119688\t181989421\t1000\t"
+                                          "182410202\t0.99\t0.999\t990\t9\t1\t1\t8\t1\t0\t0.0\t0\t0\t0\t0\n")
+    rc, out, err = run(cli, "st", "-e", os.path.join(GOLDEN, "test.maf"))
+    assert out.decode().splitlines()[1].split("\t")[7] == "0"   # -e rows: unaligned_size = 0
+
+
+def test_maf2paf_fixture(cli):
+    """Appendix B.2"""
+    rc, out, err = run(cli, "maf2paf", os.path.join(GOLDEN, "test.maf"))
+    assert rc == 0, err
+    assert out.decode() == ("query.chr8\t183119688\t181989421\t181990428\t+\tref.chr8\t182411202\t181469925\t"
+                            "181470925\t990\t1008\t255\tNM:i:18\tcg:Z:109=1D243=1X12=1X138=1X177=1X31=1X133=8I18="
+                            "1X100=2X7=1X22=\n")
+
+
+def test_stat_paf_fixture(cli):
+    """Appendix B.3: both records share the pair (B,300,A,300)"""
+    rc, out, err = run(cli, "stat", "-f", "paf", os.path.join(GOLDEN, "testdotplot.paf"))
+    assert rc == 0, err
+    assert out.decode() == STAT_HEADER + "B\t300\t0\tA\t300\t0\t250\t50\t0.84\t0.84\t210\t0\t2\t2\t30\t30\t1\t50.0\t1\t10\t1\t10\n"
+
+
+def test_pafcov_fixture(cli):
+    """Appendix B.4"""
+    rc, out, err = run(cli, "pc", os.path.join(GOLDEN, "testdotplot.paf"))
+    assert rc == 0, err
+    lines = out.decode().splitlines()
+    assert len(lines) == 300
+    cov = np.zeros(300, dtype=int)
+    for a, b in ((0, 40), (60, 120), (130, 200), (200, 210), (220, 250)):
+        cov[a:b] = 1
+    assert lines == ["B\t%d\t%d\t%d" % (p, p + 1, cov[p]) for p in range(300)]
+
+
+def _write_paf2maf_case(tmp_path, b, mapq, bad=None):
+    t_fa, q_fa, paf = tmp_path / "t.fa", tmp_path / "q.fa", tmp_path / "in.paf"
+    def fasta(path, name, seq):
+        with open(path, "wb") as f:
+            f.write(b">" + name + b" description\n")
+            for i in range(0, len(seq), 70):
+                f.write(seq[i:i + 70] + b"\n")
+    fasta(t_fa, b"tchr", b["t_pool"].tobytes())
+    fasta(q_fa, b"qchr", b["q_pool"].tobytes())
+    n = len(b["strand_neg"])
+    with open(paf, "w") as f:
+        f.write("# synthetic\n")
+        for i in range(n):
+            cg = pc.rec_text(b, i) if bad is None or i != bad[0] else bad[1]
+            qs, ql = int(b["q_src_off"][i]), int(b["q_src_len"][i])
+            ts, tl = int(b["t_src_off"][i]), int(b["t_src_len"][i])
+            f.write("qchr\t%d\t%d\t%d\t%s\ttchr\t%d\t%d\t%d\t%d\t%d\t%d\tNM:i:0\t%s\n" % (
+                len(b["q_pool"]), qs, qs + ql, "-" if b["strand_neg"][i] else "+", len(b["t_pool"]), ts,
+                ts + tl, 0, 0, mapq[i], cg))
+    return str(t_fa), str(q_fa), str(paf)
+
+
+def _expected_maf(b, mapq, t_fa, q_fa, upto):
+    out = ["#maf version=1.6 convert_from=paf t_seq_path=%s q_seq_path=%s\n" % (t_fa, q_fa)]
+    for i in range(upto):
+        et, eq = pc.oracle_rows(b, i)
+        qs, ql = int(b["q_src_off"][i]), int(b["q_src_len"][i])
+        ts, tl = int(b["t_src_off"][i]), int(b["t_src_len"][i])
+        neg = bool(b["strand_neg"][i])
+        qstart = len(b["q_pool"]) - (qs + ql) if neg else qs
+        out.append("a score=%d\ns\ttchr\t%d\t%d\t+\t%d\t%s\ns\tqchr\t%d\t%d\t%s\t%d\t%s\n\n" % (
+            mapq[i], ts, tl, len(b["t_pool"]), et.decode(), qstart, ql, "-" if neg else "+",
+            len(b["q_pool"]), eq.decode()))
+    return "".join(out).encode()
+
+
+def test_paf2maf_end_to_end(cli, tmp_path):
+    b = synth.make_paf_batch(77, 60, 300, 200000)
+    mapq = np.random.default_rng(1).integers(0, 61, 60)
+    t_fa, q_fa, paf = _write_paf2maf_case(tmp_path, b, mapq)
+    outp = str(tmp_path / "out.maf")
+    rc, out, err = run(cli, "paf2maf", paf, "-g", t_fa, "-q", q_fa, "-o", outp)
+    assert rc == 0, err
+    assert open(outp, "rb").read() == _expected_maf(b, mapq, t_fa, q_fa, 60)
+    # alias + stdout + gz output
+    rc, out, err = run(cli, "p2m", paf, "--target", t_fa, "--query", q_fa)
+    assert rc == 0 and out == _expected_maf(b, mapq, t_fa, q_fa, 60)
+    gz = str(tmp_path / "out.maf.gz")
+    rc, _, err = run(cli, "p2m", paf, "-g", t_fa, "-q", q_fa, "-o", gz)
+    import gzip
+    assert rc == 0 and gzip.open(gz, "rb").read() == _expected_maf(b, mapq, t_fa, q_fa, 60)
+
+
+def test_paf2maf_error_is_streamed(cli, tmp_path):
+    """streaming driver: records before the failing one are written, then `ERROR <msg>`, exit 1"""
+    b = synth.make_paf_batch(78, 12, 80, 30000)
+    mapq = np.arange(12)
+    t_fa, q_fa, paf = _write_paf2maf_case(tmp_path, b, mapq, bad=(7, "cg:Z:10=3N5="))
+    rc, out, err = run(cli, "paf2maf", paf, "-g", t_fa, "-q", q_fa)
+    assert rc == 1 and err.strip().endswith("ERROR CIGAR OP `N` invalid")
+    assert out == _expected_maf(b, mapq, t_fa, q_fa, 7)
+    t_fa, q_fa, paf = _write_paf2maf_case(tmp_path, b, mapq, bad=(3, "cg:Z:10=3"))
+    rc, out, err = run(cli, "paf2maf", paf, "-g", t_fa, "-q", q_fa)
+    assert rc == 1 and err.strip().endswith("ERROR CIGAR OP `` invalid")
+    assert out == _expected_maf(b, mapq, t_fa, q_fa, 3)
+
+
+def test_stat_paf_matches_oracle_aggregation(cli, tmp_path):
+    """many records over a few (ref, query) pairs; f32 columns through the oracle's RecStat"""
+    b = synth.make_paf_batch(79, 50, 200, 100000)
+    rng = np.random.default_rng(2)
+    names = [("chr%d" % rng.integers(1, 12), "q%d" % rng.integers(0, 3)) for _ in range(50)]
+    paf = tmp_path / "s.paf"
+    with open(paf, "w") as f:
+        for i in range(50):
+            f.write("%s\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t0\t0\t60\t%s\n" % (
+                names[i][1], 5000000, int(b["q_src_off"][i]), int(b["q_src_off"][i] + b["q_src_len"][i]),
+                "-" if b["strand_neg"][i] else "+", names[i][0], 9000000, int(b["t_src_off"][i]),
+                int(b["t_src_off"][i] + b["t_src_len"][i]), pc.rec_text(b, i)))
+    rc, out, err = run(cli, "stat", "-f", "paf", str(paf))
+    assert rc == 0, err
+    rows = out.decode().splitlines()
+    assert rows[0] + "\n" == STAT_HEADER
+    # expectation: merge in first-appearance order, stable natural sort by ref name
+    import collections
+    groups = collections.OrderedDict()
+    for i in range(50):
+        c = orc.parse_paf_to_cigar(pc.rec_text(b, i), b["strand_neg"][i])
+        rs = orc.recstat_from(c)
+        groups.setdefault(names[i], []).append((rs, int(b["t_src_off"][i]), int(b["q_src_off"][i])))
+    def natkey(s):
+        import re
+        return [int(x) if x.isdigit() else x for x in re.split(r"(\d+)", s)]
+    exp = []
+    for (ref, q), lst in groups.items():
+        tot = collections.Counter()
+        inv_size = np.float32(0)
+        for rs, _, _ in lst:
+            for k, _t in rs._fields_:
+                if k != "inv_size":
+                    tot[k] += getattr(rs, k)
+            inv_size = np.float32(inv_size + np.float32(rs.inv_size))
+        al = tot["aligned_size"]
+        ident = np.float32(tot["matched"]) / np.float32(al)
+        sim = np.float32(tot["matched"] + tot["mismatched"]) / np.float32(al)
+        from test_host_cli import ryu_pretty_f32
+        exp.append((ref, "\t".join(str(x) for x in (
+            ref, 9000000, min(min(r for _, r, _ in lst), 9000000), q, 5000000, min(min(s for _, _, s in lst), 5000000),
+            al, 9000000 - al, ryu_pretty_f32(ident), ryu_pretty_f32(sim), tot["matched"], tot["mismatched"],
+            tot["ins_event"], tot["del_event"], tot["ins_size"], tot["del_size"], tot["inv_event"],
+            ryu_pretty_f32(inv_size), tot["inv_ins_event"], tot["inv_ins_size"], tot["inv_del_event"],
+            tot["inv_del_size"]))))
+    exp.sort(key=lambda t: natkey(t[0]))   # python's sort is stable
+    assert rows[1:] == [e[1] for e in exp]
+
+
+def _rust_bsearch_pos(keys, key):
+    size, left, right = len(keys), 0, len(keys)
+    while left < right:
+        mid = left + size // 2
+        if keys[mid] == key:
+            return mid
+        if keys[mid] < key:
+            left = mid + 1
+        else:
+            right = mid
+        size = right - left
+    return left
+
+
+def _expected_pseudo_files(recs, contigs, base):
+    """pseudomaf.rs:18-210 restated in Python over the oracle's gen_pesudo_maf_by_cigar"""
+    import collections
+    targets = collections.OrderedDict()
+    for r in recs:
+        targets.setdefault(r["tname"], []).append(r)
+    files = {}
+    for tname, trecs in targets.items():
+        queries = collections.OrderedDict()
+        for r in trecs:
+            lst = queries.setdefault(r["qname"], [])
+            lst.insert(_rust_bsearch_pos([x["tstart"] for x in lst], r["tstart"]), r)
+        out = [b"a score=0\n"]
+        first = True
+        target_size = 0
+        for qname, lst in queries.items():
+            first_query, last_end = True, 0
+            for r in lst:
+                target_size = r["tlen"]
+                if first:
+                    seq = contigs[tname][:target_size] if base else b"N" * target_size
+                    out.append(b"s\t%s\t0\t%d\t+\t%d\t%s\n" % (tname.encode(), target_size, target_size, seq))
+                    first = False
+                if first_query:
+                    out.append(b"s\t%s\t0\t%d\t+\t%d\t" % (qname.encode(), r["qlen"], r["qlen"]))
+                overlap = 0
+                if r["tstart"] > last_end:
+                    out.append(b"-" * (r["tstart"] - last_end))
+                else:
+                    if last_end > r["tend"]:
+                        continue
+                    overlap = last_end - r["tstart"]
+                last_end = r["tend"]
+                q = contigs[qname][r["qstart"]:r["qend"]] if base else b""
+                if base and r["strand"] == "-":
+                    q = orc.reverse_complement(q)
+                seg = orc.gen_pesudo_maf_by_cigar(r["cg"], q, base)
+                out.append(seg[overlap:])
+                first_query = False
+            out.append(b"-" * (target_size - last_end))
+            out.append(b"\n")
+        out.append(b"\n")
+        files[tname] = b"".join(out)
+    return files
+
+
+@pytest.mark.parametrize("base", [False, True])
+def test_pafpseudo_end_to_end(cli, tmp_path, base):
+    rng = np.random.default_rng(5)
+    b = synth.make_paf_batch(91, 36, 60, 60000)
+    cs = synth.class_sums(b["code"], b["length"], b["op_off"])
+    tspan = (cs["mx"] + cs["d"]).astype(np.int64)
+    tnames, qnames = ["tA", "tB", "t10"], ["q1", "q2", "q3"]
+    tsize = {"tA": 9000, "tB": 7000, "t10": 8000}
+    contigs = {q: b["q_pool"].tobytes() for q in qnames}
+    for t in tnames:
+        contigs[t] = pc.rand_seq(rng, tsize[t], b"ACGTacgtN")
+    recs, cursor = [], {}
+    for i in range(36):
+        t, q = tnames[i % 3], qnames[(i // 3) % 3]
+        cur = cursor.get((t, q), 0)
+        mode = rng.integers(0, 4)   # gap / abut / partial overlap / contained
+        start = cur + int(rng.integers(1, 60)) if mode == 0 or cur == 0 else \
+            cur if mode == 1 else max(0, cur - int(rng.integers(1, 40))) if mode == 2 else max(0, cur - int(tspan[i]) - 5)
+        end = start + int(tspan[i])
+        if end > tsize[t]:
+            continue
+        cursor[(t, q)] = max(cur, end)
+        qs = int(b["q_src_off"][i])
+        recs.append(dict(tname=t, qname=q, tlen=tsize[t], tstart=start, tend=end, qlen=len(b["q_pool"]),
+                         qstart=qs, qend=qs + int(b["q_src_len"][i]), strand="-" if b["strand_neg"][i] else "+",
+                         cg=pc.rec_text(b, i)))
+    rng.shuffle(recs)   # input order is not sorted: the sorted insertion does the work
+    paf = tmp_path / "all.paf"
+    with open(paf, "w") as f:
+        for r in recs:
+            f.write("%s\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t0\t0\t60\t%s\n" % (
+                r["qname"], r["qlen"], r["qstart"], r["qend"], r["strand"], r["tname"], r["tlen"], r["tstart"],
+                r["tend"], r["cg"]))
+    fa = tmp_path / "all.fa"
+    with open(fa, "wb") as f:
+        for name, seq in contigs.items():
+            f.write(b">" + name.encode() + b"\n")
+            for k in range(0, len(seq), 60):
+                f.write(seq[k:k + 60] + b"\n")
+    outdir = tmp_path / ("out_base" if base else "out_sym")
+    args = ["pafpseudo", str(paf), "-o", str(outdir)] + (["-f", str(fa)] if base else [])
+    rc, _, err = run(cli, *args)
+    assert rc == 0, err
+    exp = _expected_pseudo_files(recs, contigs, base)
+    assert sorted(os.listdir(outdir)) == sorted(t + ".maf" for t in exp)
+    for t, text in exp.items():
+        got = open(outdir / (t + ".maf"), "rb").read()
+        # the reference writes query rows in HashMap order: compare rows as a multiset, header first
+        assert got.split(b"\n")[:2] == text.split(b"\n")[:2]
+        assert sorted(got.split(b"\n")) == sorted(text.split(b"\n")), t
+    # the directory exists now: refuse without -r, accept with -r, honour -g
+    rc, _, err = run(cli, *args)
+    assert rc == 1 and "already exists" in err
+    rc, _, err = run(cli, *(args + ["-r", "-g", "tB"]))
+    assert rc == 0, err
+
+
+# ---- call (MAF) ------------------------------------------------------------------------------------
+VCF_HEADER = (
+    "##fileformat=VCFv4.4\n"
+    '##INFO=<ID=SVLEN,Number=A,Type=Integer,Description="Length of structural variant">\n'
+    '##INFO=<ID=SVTYPE,Number=1,Type=String,Description="Type of structural variant">\n'
+    '##INFO=<ID=END,Number=1,Type=Integer,Description="End position of the longest variant described in this record">\n'
+    '##INFO=<ID=INV_NEST,Number=1,Type=String,Description="Varations nested within inversion">\n'
+    '##FORMAT=<ID=QI,Number=1,Type=String,Description="Query informations">\n'
+    '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n'
+    "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n")
+
+
+def test_call_readme_golden(cli):
+    """README.md:323-343 — header and every SV row byte-identical; SNP rows carry QI (caller.rs:582-593,
+    the README predates it), so their first 8 columns are compared."""
+    rc, out, err = run(cli, "call", os.path.join(GOLDEN, "test.maf"), "-s", "-l0")
+    assert rc == 0, err
+    got = out.decode().splitlines()
+    golden = open(os.path.join(GOLDEN, "readme_call_test_maf_s_l0.vcf")).read().splitlines()
+    assert len(got) == len(golden)
+    for g, w in zip(got, golden):
+        if w.startswith("#") or "SVTYPE" in w:
+            assert g == w
+        else:
+            assert g.split("\t")[:8] == w.split("\t")[:8]
+            assert g.split("\t")[8] == "GT:QI"
+
+
+def _synth_maf_blocks(seed, n_blocks, cols):
+    """random gapped row pairs: match/mismatch stretches, insertions, deletions, both-gap columns,
+    adjacent I/D runs, lower-case and N bases, both strands"""
+    rng = np.random.default_rng(seed)
+    blocks = []
+    for k in range(n_blocks):
+        t, q = [], []
+        while len(t) < cols:
+            kind = rng.choice(5, p=[0.55, 0.12, 0.14, 0.14, 0.05])
+            ln = int(rng.integers(1, 40 if kind == 0 else 12))
+            alpha = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)
+            a = alpha[rng.integers(0, 9, ln)]
+            if kind == 0:
+                t += list(a); q += list(a)
+            elif kind == 1:
+                b = alpha[rng.integers(0, 9, ln)]
+                t += list(a); q += list(b)
+            elif kind == 2:
+                t += [45] * ln; q += list(a)
+            elif kind == 3:
+                t += list(a); q += [45] * ln
+            else:
+                t += [45] * ln; q += [45] * ln
+        t, q = bytes(t[:cols]), bytes(q[:cols])
+        t_al, q_al = cols - t.count(b"-"), cols - q.count(b"-")
+        blocks.append(dict(t_name="chrT%d" % (k % 3), t_start=int(rng.integers(0, 10000)), t_align=t_al, t_size=50000,
+                           q_name="qry.%d" % (k % 2), q_start=int(rng.integers(0, 10000)), q_align=q_al,
+                           q_size=40000, neg=bool(rng.integers(0, 2)), t=t, q=q))
+    return blocks
+
+
+def _write_maf(path, blocks, extra_sline=False):
+    with open(path, "wb") as f:
+        f.write(b"##maf version=1\n")
+        for b in blocks:
+            f.write(b"a score=255\n")
+            f.write(b"s\t%s\t%d\t%d\t+\t%d\t%s\n" % (b["t_name"].encode(), b["t_start"], b["t_align"], b["t_size"], b["t"]))
+            if extra_sline:
+                f.write(b"s\tother.x\t5\t%d\t+\t99999\t%s\n" % (b["t_align"], b["t"]))
+            f.write(b"s\t%s\t%d\t%d\t%s\t%d\t%s\n\n" % (b["q_name"].encode(), b["q_start"], b["q_align"],
+                                                     b"-" if b["neg"] else b"+", b["q_size"], b["q"]))
+
+
+def _expected_vcf(blocks, sample, snp, inv, svlen, chunk):
+    body = "".join(orc.call_var_maf_record(b["t_name"], b["q_name"], b["t"], b["q"], b["t_start"], b["q_start"],
+                                           b["q_align"], b["q_size"], b["neg"], snp, inv, svlen, chunk)
+                   for b in blocks)
+    return VCF_HEADER % sample + body
+
+
+@pytest.mark.parametrize("snp,inv,svlen,chunk", [(True, True, 0, 1000000), (True, False, 3, 64), (False, True, 5, 7),
+                                                 (True, True, 50, 300), (True, True, 1, 1)])
+def test_call_synthetic_blocks(cli, tmp_path, snp, inv, svlen, chunk):
+    blocks = _synth_maf_blocks(11, 7, 1500)
+    maf = tmp_path / "in.maf"
+    _write_maf(maf, blocks)
+    args = ["call", str(maf), "-l", str(svlen), "-c", str(chunk), "-n", "smp"]
+    args += ["-s"] if snp else []
+    args += ["-i"] if inv else []
+    rc, out, err = run(cli, *args)
+    assert rc == 0, err
+    assert out.decode() == _expected_vcf(blocks, "smp", snp, inv, svlen, chunk)
+
+
+def test_call_query_selection(cli, tmp_path):
+    """caller.rs:62-108: --query-name / --query-regex pick the query s-line; blocks without it are skipped"""
+    blocks = _synth_maf_blocks(5, 4, 400)
+    maf = tmp_path / "in.maf"
+    _write_maf(maf, blocks, extra_sline=True)
+    want0 = _expected_vcf([b for b in blocks if b["q_name"] == "qry.0"], "sample", True, False, 0, 1000000)
+    rc, out, err = run(cli, "c", str(maf), "-s", "-l0", "--query-name", "qry.0")
+    assert rc == 0, err
+    assert out.decode() == want0
+    rc, out, err = run(cli, "c", str(maf), "-s", "-l0", "--query-regex", r"qry\.\d")
+    assert rc == 0, err
+    assert out.decode() == _expected_vcf(blocks, "sample", True, False, 0, 1000000)
+    rc, out, err = run(cli, "c", str(maf), "-s", "-l0", "--query-name", "absent")
+    assert rc == 0 and out.decode() == VCF_HEADER % "sample"

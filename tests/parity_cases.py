@@ -364,6 +364,46 @@ def check_maf_pair(eng, pairs, strands):
 
 
 # ------------------------------------------------------------------------------------------------
+# K4 MAF column runs for `call`
+# ------------------------------------------------------------------------------------------------
+def check_maf_call_runs(eng, pairs):
+    """runs of equal cigar_cat_ext_caller class (cigar.rs:314-328, grouped as caller.rs:444-446)
+    with the non-gap target / query characters before each run (what create_chunk_record,
+    caller.rs:221-265, and the offsets of call_within_var count)."""
+    n = len(pairs)
+    buf, t_off, q_off, cols = bytearray(b"@"), [], [], []
+    for t, q in pairs:
+        t_off.append(len(buf))
+        buf += t + b"@@@"
+        q_off.append(len(buf))
+        buf += q + b"@"
+        cols.append(min(len(t), len(q)))
+    rows = eng.upload(np.frombuffer(bytes(buf), dtype=np.uint8))
+    d_t, d_q = eng.upload(np.array(t_off, dtype=np.uint64)), eng.upload(np.array(q_off, dtype=np.uint64))
+    d_c = eng.upload(np.array(cols, dtype=np.uint64))
+    run_cnt = eng.maf_call_runs(n, rows, d_t, d_q, d_c)
+    run_off = eng.exclusive_scan_u64(n, run_cnt)
+    ro = run_off.numpy()
+    runs = eng.empty(3 * int(ro[-1]) + 3, np.uint64).fill(0)
+    eng.maf_call_runs(n, rows, d_t, d_q, d_c, run_cnt=run_cnt, runs=runs, run_off=run_off)
+    rr = runs.numpy()
+    for i, (t, q) in enumerate(pairs):
+        L = cols[i]
+        ta, qa = np.frombuffer(t, dtype=np.uint8)[:L], np.frombuffer(q, dtype=np.uint8)[:L]
+        tg, qg = ta == 45, qa == 45
+        cls = np.where(tg & qg, 4, np.where(tg, 1, np.where(qg, 2, np.where(ta == qa, 0, 3))))
+        starts = np.flatnonzero(np.concatenate([[True], cls[1:] != cls[:-1]])) if L else np.zeros(0, np.int64)
+        tb = np.concatenate([[0], np.cumsum(~tg)])[starts] if L else starts
+        qb = np.concatenate([[0], np.cumsum(~qg)])[starts] if L else starts
+        mine = rr[3 * int(ro[i]):3 * int(ro[i + 1])].reshape(-1, 3)
+        assert len(mine) == len(starts), (i, len(mine), len(starts))
+        assert ((mine[:, 0] >> np.uint64(3)).astype(np.int64) == starts).all(), i
+        assert ((mine[:, 0] & np.uint64(7)).astype(np.int64) == cls[starts]).all(), i
+        assert (mine[:, 1].astype(np.int64) == tb).all(), i
+        assert (mine[:, 2].astype(np.int64) == qb).all(), i
+
+
+# ------------------------------------------------------------------------------------------------
 # a second, linear-time expectation for long records (the C oracle's insert_str is quadratic)
 # ------------------------------------------------------------------------------------------------
 def fast_expected_rows(ops, t_seq, q_seq, neg):

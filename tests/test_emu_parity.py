@@ -206,6 +206,7 @@ def test_maf_pair_stat(emu):
     pairs.append((blk[0]["seq"], blk[1]["seq"]))
     strands.append(0)
     pc.check_maf_pair(emu, pairs, strands)
+    pc.check_maf_call_runs(emu, pairs)
 
 
 def test_fast_expected_matches_oracle():

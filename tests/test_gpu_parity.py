@@ -223,6 +223,7 @@ def test_maf_pair_stat(gpu):
     pairs.append((blk[0]["seq"], blk[1]["seq"]))
     strands.append(0)
     pc.check_maf_pair(gpu, pairs, strands)
+    pc.check_maf_call_runs(gpu, pairs)
 
 
 def test_scan(gpu):

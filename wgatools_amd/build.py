@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "wgatools_amd", "csrc")
 HIP_LIB = os.path.join(ROOT, "wgatools_amd", "libwgahip.so")
 EMU_LIB = os.path.join(ROOT, "tests", "emu", "libwgaemu.so")
+CLI_EMU_BIN = os.path.join(ROOT, "tests", "emu", "wgatools_emu")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "liboracle.so")
 STAGE2 = ["-DWGA_STAGE2"] if os.path.exists(os.path.join(CSRC, "wga_kernels2.h")) else []
 
@@ -84,6 +85,20 @@ def build_cli(force=False):
           "-L" + os.path.dirname(lib), "-lwgahip", "-lz", "-Wl,-rpath,$ORIGIN/..",
           "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
     return CLI_BIN
+
+
+def build_cli_emu(force=False):
+    """tests/emu/wgatools_emu — the CLI host code linked against the emulator build of the kernels.
+    Test infrastructure: lets the CPU suite exercise the host logic end to end without a GPU."""
+    lib = build_emu(force)
+    srcs = [os.path.join(ROOT, "wgatools_amd", "host", "wgatools_main.cpp"), os.path.join(ROOT, "wgatools_amd", "host", "wga_host.cpp"),
+            os.path.join(ROOT, "wgatools_amd", "host", "wga_host.hpp"), lib]
+    if not force and not _newer(CLI_EMU_BIN, srcs):
+        return CLI_EMU_BIN
+    _run(["g++", "-O1", "-g", "-std=c++17", "-Wall", os.path.join(ROOT, "wgatools_amd", "host", "wgatools_main.cpp"),
+          os.path.join(ROOT, "wgatools_amd", "host", "wga_host.cpp"), "-o", CLI_EMU_BIN, "-L" + os.path.dirname(lib),
+          "-lwgaemu", "-lz", "-Wl,-rpath,$ORIGIN"])
+    return CLI_EMU_BIN
 
 
 def build_oracle(force=False):

@@ -342,6 +342,21 @@ int wga_maf_pair_stat(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint6
   return WGA_OK;
 }
 
+int wga_maf_call_runs(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint64_t* d_t_off,
+                      const uint64_t* d_q_off, const uint64_t* d_cols, uint64_t* d_run_cnt,
+                      uint64_t* d_runs, const uint64_t* d_run_off) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (n == 0) return WGA_OK;
+  if (!d_rows || !d_t_off || !d_q_off || !d_cols) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  if (d_runs && !d_run_off) return fail(WGA_E_INVALID_ARG, "d_run_off null", nullptr);
+  WGA_LAUNCH(k_maf_call_runs, (n + 3u) / 4u, WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off,
+             (const u64*)d_q_off, (const u64*)d_cols, (u64*)d_run_cnt, (u64*)d_runs,
+             (const u64*)d_run_off);
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
 int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_target_id,
                           const uint64_t* d_t_start, const uint64_t* d_cov_off,
                           const uint64_t* d_cov_len, int32_t* d_cov) {

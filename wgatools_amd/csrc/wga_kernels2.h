@@ -708,4 +708,57 @@ __global__ __launch_bounds__(256) void k_maf_pair_stat(u32 n, const u8* __restri
   }
 }
 
+/* ============================================================================================ */
+/* K4: MAF call column walk                                                                     */
+/* ============================================================================================ */
+/* Same wave-per-record walk as K3 with the caller's classes (cigar_cat_ext_caller,
+ * cigar.rs:314-328: gap tests first, so '-','-' is its own class W and splits runs).  Besides
+ * its start column every run carries the number of non-gap target / query characters before
+ * it, which is all the host needs for coordinates (caller.rs:399-400,457-458), for REF / ALT
+ * slices (the anchor of an I / D run is the column before it) and for the chunk geometry of
+ * find_safe_chunk_boundary / create_chunk_record (caller.rs:159-265).
+ * Run entry = 3 u64: start_column << 3 | class (0 '=', 1 I, 2 D, 3 X, 4 W), t_before, q_before. */
+__global__ __launch_bounds__(256) void k_maf_call_runs(u32 n, const u8* __restrict__ rows,
+                                                       const u64* t_off, const u64* q_off,
+                                                       const u64* cols, u64* run_cnt, u64* runs,
+                                                       const u64* run_off) {
+  const u32 lane = threadIdx.x & 63u;
+  const u64 i = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const u8* t = rows + t_off[i];
+  const u8* q = rows + q_off[i];
+  const u64 L = cols[i];
+  u64* rout = runs ? runs + 3 * run_off[i] : (u64*)0;
+  u32 carry_cls = 0xFFu;
+  u64 run_base = 0, t_base = 0, q_base = 0;
+  for (u64 c0 = 0; c0 < L; c0 += 64) {
+    const u64 c = c0 + lane;
+    const bool in = c < L;
+    u32 cls = 0xFEu;
+    bool tn = false, qn = false;
+    if (in) {
+      const u8 c1 = t[c], c2 = q[c];
+      tn = c1 != (u8)'-';
+      qn = c2 != (u8)'-';
+      cls = !tn ? (!qn ? 4u : 1u) : (!qn ? 2u : (c1 == c2 ? 0u : 3u));
+    }
+    u32 prev = __shfl_up(cls, 1u);
+    if (lane == 0) prev = carry_cls;
+    const bool start = in && cls != prev;
+    const u64 m = __ballot(start), mt = __ballot(tn), mq = __ballot(qn);
+    const u64 below = (1ull << lane) - 1ull;
+    if (rout && start) {
+      u64* e = rout + 3 * (run_base + (u64)__popcll(m & below));
+      e[0] = (c << 3) | (u64)cls;
+      e[1] = t_base + (u64)__popcll(mt & below);
+      e[2] = q_base + (u64)__popcll(mq & below);
+    }
+    run_base += (u64)__popcll(m);
+    t_base += (u64)__popcll(mt);
+    q_base += (u64)__popcll(mq);
+    carry_cls = __shfl(cls, 63);
+  }
+  if (lane == 0 && run_cnt) run_cnt[i] = run_base;
+}
+
 #endif /* WGA_KERNELS2_H */

@@ -214,6 +214,12 @@ class Engine:
                                                _p(runs), _p(run_off)))
         return counts, run_cnt
 
+    def maf_call_runs(self, n, rows, t_off, q_off, cols, run_cnt=None, runs=None, run_off=None):
+        run_cnt = run_cnt if run_cnt is not None else self.empty(n, np.uint64)
+        self._check(self.lib.wga_maf_call_runs(self.ctx, n, _p(rows), _p(t_off), _p(q_off), _p(cols),
+                                               _p(run_cnt), _p(runs), _p(run_off)))
+        return run_cnt
+
     def pafcov_accumulate(self, batch, target_id, t_start, cov_off, cov_len, cov):
         self._check(self.lib.wga_pafcov_accumulate(self.ctx, C.byref(batch.c), _p(target_id),
                                                    _p(t_start), _p(cov_off), _p(cov_len), _p(cov)))

@@ -14,6 +14,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <regex>
 
 #include "wga_host.hpp"
 
@@ -675,6 +676,304 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
   return 0;
 }
 
+
+/* ---- call (MAF) (caller.rs:42-265, 388-608) ------------------------------------------------------------
+ * GPU: the column walk — runs of equal caller class with non-gap prefix counts (wga_maf_call_runs).
+ * Host: everything that works on runs instead of columns — SV-safe chunk cuts, chunk coordinates,
+ * the after_m event rules, REF/ALT slices and the VCF text (noodles-vcf 0.43 layout, README.md:323-343). */
+struct CallRun {
+  uint64_t start, tb, qb;
+  uint32_t cls; /* 0 '=', 1 I, 2 D, 3 X, 4 W */
+};
+struct CallBlock {
+  const MafRecord* rec;
+  std::vector<CallRun> runs;
+  uint64_t total;
+  uint64_t end(size_t k) const { return k + 1 < runs.size() ? runs[k + 1].start : total; }
+  size_t run_at(uint64_t col) const { /* run containing column col */
+    size_t lo = 0, hi = runs.size();
+    while (hi - lo > 1) {
+      size_t mid = (lo + hi) / 2;
+      if (runs[mid].start <= col)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    return lo;
+  }
+  static bool adv_t(uint32_t c) { return c == 0 || c == 3 || c == 2; }
+  static bool adv_q(uint32_t c) { return c == 0 || c == 3 || c == 1; }
+  uint64_t t_before(uint64_t col) const {
+    if (col >= total) return runs.empty() ? 0 : runs.back().tb + (adv_t(runs.back().cls) ? total - runs.back().start : 0);
+    size_t k = run_at(col);
+    return runs[k].tb + (adv_t(runs[k].cls) ? col - runs[k].start : 0);
+  }
+  uint64_t q_before(uint64_t col) const {
+    if (col >= total) return runs.empty() ? 0 : runs.back().qb + (adv_q(runs.back().cls) ? total - runs.back().start : 0);
+    size_t k = run_at(col);
+    return runs[k].qb + (adv_q(runs[k].cls) ? col - runs[k].start : 0);
+  }
+  /* n characters of the gap-stripped target / query row starting at non-gap index idx */
+  std::string ref_slice(bool is_t, uint64_t idx, uint64_t n) const {
+    const std::string& row = is_t ? rec->t().seq : rec->q().seq;
+    std::string out;
+    size_t lo = 0, hi = runs.size(); /* last run whose prefix count is <= idx: it advances */
+    while (hi - lo > 1) {
+      size_t mid = (lo + hi) / 2;
+      if ((is_t ? runs[mid].tb : runs[mid].qb) <= idx)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    size_t k = lo;
+    while (n && k < runs.size()) {
+      bool adv = is_t ? adv_t(runs[k].cls) : adv_q(runs[k].cls);
+      uint64_t b = is_t ? runs[k].tb : runs[k].qb, len = end(k) - runs[k].start;
+      if (adv && idx < b + len) {
+        uint64_t take = std::min(n, b + len - idx);
+        out.append(row, runs[k].start + (idx - b), take);
+        idx += take;
+        n -= take;
+      }
+      k++;
+    }
+    if (n) fail("panic: VCF REF/ALT slice out of range (caller.rs:500-501,554-555)");
+    return out;
+  }
+};
+
+/* find_safe_chunk_boundary, caller.rs:159-219, on runs: a gap segment = adjacent I/D/W runs */
+uint64_t safe_chunk_end(const CallBlock& b, uint64_t start, uint64_t chunk_size, uint64_t svlen) {
+  const uint64_t proposed = std::min(start + chunk_size, b.total);
+  uint64_t safe_end = proposed;
+  size_t k = b.run_at(start);
+  while (k < b.runs.size() && b.runs[k].start < proposed) {
+    uint32_t c = b.runs[k].cls;
+    if (c == 0 || c == 3) {
+      k++;
+      continue;
+    }
+    size_t j = k;
+    while (j + 1 < b.runs.size() && b.runs[j + 1].cls != 0 && b.runs[j + 1].cls != 3) j++;
+    const uint64_t gs = std::max(b.runs[k].start, start), ge = b.end(j);
+    if (ge < proposed) {
+      if (ge - gs >= svlen) safe_end = ge;
+    } else {
+      if (proposed - gs >= svlen) safe_end = ge < b.total ? ge : proposed;
+    }
+    k = j + 1;
+  }
+  return safe_end;
+}
+
+void vcf_line(std::string& out, const std::string& chro, uint64_t pos, const std::string& ref,
+              const std::string& alt, bool symbolic, const std::string& info, const std::string& sample) {
+  auto bases = [&](const std::string& s) { /* noodles parses bases case-insensitively, prints upper case */
+    for (char c : s) {
+      char u = (c >= 'a' && c <= 'z') ? (char)(c - 32) : c;
+      if (u != 'A' && u != 'C' && u != 'G' && u != 'T' && u != 'N')
+        fail(std::string("invalid reference/alternate base `") + c + "` for a VCF record (noodles-vcf parse error)");
+      out.push_back(u);
+    }
+  };
+  out += chro;
+  out.push_back('\t');
+  append_u64(out, pos);
+  out += "\t.\t";
+  bases(ref);
+  out.push_back('\t');
+  if (symbolic)
+    out += alt;
+  else
+    bases(alt);
+  out += "\t.\t.\t";
+  out += info.empty() ? "." : info;
+  out += "\tGT:QI\t1|1:";
+  out += sample;
+  out.push_back('\n');
+}
+
+/* call_within_var on chunk [cs, ce), caller.rs:388-608 */
+void call_chunk(const CallBlock& b, uint64_t cs, uint64_t ce, bool snp, bool inv, uint64_t svlen, std::string& out) {
+  const MafRecord& r = *b.rec;
+  const uint64_t tb0 = b.t_before(cs), qb0 = b.q_before(cs);
+  const uint64_t t_align = b.t_before(ce) - tb0, q_align = b.q_before(ce) - qb0;
+  /* create_chunk_record (:221-265) + accessors (maf.rs:433-450,464-470) */
+  const uint64_t t_start = r.t().start + tb0, t_end = t_start + t_align;
+  const uint64_t q_sline_start = r.q().start + qb0;
+  const bool neg = r.q().neg;
+  const uint64_t q_start = neg ? r.q().size - q_sline_start - q_align : q_sline_start;
+  const uint64_t q_end = neg ? r.q().size - q_sline_start : q_sline_start + q_align;
+  const std::string &chro = r.t().name, &q_chro = r.q().name;
+  const char suffix = neg ? 'N' : 'P';
+  auto qi = [&](uint64_t a, uint64_t b2, bool three) {
+    std::string s = q_chro + "@";
+    append_u64(s, a);
+    if (!three) {
+      s.push_back('@');
+      append_u64(s, b2);
+    }
+    s.push_back('@');
+    s.push_back(suffix);
+    return s;
+  };
+  if (neg && t_align != 0 && inv) { /* :423-440 */
+    std::string info = "SVTYPE=INV;END=";
+    append_u64(info, t_end);
+    vcf_line(out, chro, t_start + 1, b.ref_slice(true, tb0, 1), "<INV>", true, info, qi(q_start, q_end, false));
+  }
+  const std::string init_info = neg ? "INV_NEST=TRUE;" : "";
+  uint64_t t_off = t_start, q_off = q_start;
+  bool after_m = false;
+  for (size_t k = b.run_at(cs); k < b.runs.size() && b.runs[k].start < ce; k++) {
+    const uint64_t s0 = std::max(b.runs[k].start, cs), e0 = std::min(b.end(k), ce);
+    const uint64_t len = e0 - s0;
+    switch (b.runs[k].cls) {
+      case 0:
+        t_off += len;
+        q_off += len;
+        after_m = true;
+        break;
+      case 4: break;
+      case 1: /* I :464-515 */
+        if (len > svlen) {
+          if (!after_m) {
+            q_off += len;
+            after_m = false;
+            continue;
+          }
+          std::string info = init_info + "SVTYPE=INS;SVLEN=";
+          append_u64(info, len);
+          info += ";END=";
+          append_u64(info, t_off);
+          vcf_line(out, chro, t_off, b.ref_slice(true, tb0 + (t_off - t_start - 1), 1),
+                   b.ref_slice(false, qb0 + (q_off - q_start - 1), len + 1), false, info, qi(q_off, q_off + len, false));
+        }
+        q_off += len;
+        after_m = false;
+        break;
+      case 2: /* D :516-569 */
+        if (len > svlen) {
+          if (!after_m) {
+            t_off += len;
+            after_m = false;
+            continue;
+          }
+          std::string info = init_info + "SVTYPE=DEL;SVLEN=";
+          append_u64(info, len);
+          info += ";END=";
+          append_u64(info, t_off + len);
+          vcf_line(out, chro, t_off, b.ref_slice(true, tb0 + (t_off - t_start - 1), len + 1),
+                   b.ref_slice(false, qb0 + (q_off - q_start - 1), 1), false, info, qi(q_off, q_off, false));
+        }
+        t_off += len;
+        after_m = false;
+        break;
+      case 3: /* X :570-603 */
+        if (snp) {
+          for (uint64_t x = 0; x < len; x++) {
+            vcf_line(out, chro, t_off + 1, b.ref_slice(true, tb0 + (t_off - t_start), 1),
+                     b.ref_slice(false, qb0 + (q_off - q_start), 1), false, "", qi(q_off, 0, true));
+            t_off++;
+            q_off++;
+          }
+        } else {
+          t_off += len;
+          q_off += len;
+        }
+        after_m = true;
+        break;
+    }
+  }
+}
+
+int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, const std::string& sample,
+                 const std::string* query_name, const std::string* query_regex, uint64_t chunk_size, Output& out) {
+  std::string header;
+  std::vector<MafRecord> all = parse_maf(read_all(input), &header);
+  std::string text =
+      "##fileformat=VCFv4.4\n"
+      "##INFO=<ID=SVLEN,Number=A,Type=Integer,Description=\"Length of structural variant\">\n"
+      "##INFO=<ID=SVTYPE,Number=1,Type=String,Description=\"Type of structural variant\">\n"
+      "##INFO=<ID=END,Number=1,Type=Integer,Description=\"End position of the longest variant described in this record\">\n"
+      "##INFO=<ID=INV_NEST,Number=1,Type=String,Description=\"Varations nested within inversion\">\n"
+      "##FORMAT=<ID=QI,Number=1,Type=String,Description=\"Query informations\">\n"
+      "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"
+      "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + sample + "\n";
+  /* record selection (:62-108): single-s-line blocks and blocks without the asked query are skipped */
+  std::vector<MafRecord*> recs;
+  std::regex re;
+  if (!query_name && query_regex) re = std::regex(*query_regex); /* is_match_at(name, 0): unanchored search (maf.rs:267-271) */
+  for (auto& r : all) {
+    if (r.slines.size() == 1) continue;
+    if (query_name) {
+      size_t k = 0;
+      for (; k < r.slines.size(); k++)
+        if (r.slines[k].name == *query_name) break;
+      if (k == r.slines.size()) continue;
+      r.query_idx = k;
+    } else if (query_regex) {
+      size_t k = 0;
+      for (; k < r.slines.size(); k++)
+        if (std::regex_search(r.slines[k].name, re)) break;
+      if (k == r.slines.size()) continue;
+      r.query_idx = k;
+    } else {
+      r.query_idx = 1;
+    }
+    if (r.q().seq.size() < r.t().seq.size())
+      fail("panic: query row shorter than the target row (caller.rs:175 slice out of range)");
+    recs.push_back(&r);
+  }
+  const uint32_t n = (uint32_t)recs.size();
+  if (n) {
+    MafPairs p;
+    for (const MafRecord* r : recs) {
+      p.t_off.push_back(p.rows.size());
+      p.rows += r->t().seq;
+      p.q_off.push_back(p.rows.size());
+      p.rows += r->q().seq;
+      p.cols.push_back(r->t().seq.size()); /* total_size = target row length (:115) */
+    }
+    Dev d;
+    d.init();
+    auto* d_rows = d.upload((const uint8_t*)p.rows.data(), p.rows.size());
+    auto *d_t = d.upload(p.t_off), *d_q = d.upload(p.q_off), *d_c = d.upload(p.cols);
+    auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
+    d.check(wga_maf_call_runs(d.ctx, n, d_rows, d_t, d_q, d_c, d_cnt, nullptr, nullptr));
+    auto* d_roff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+    d.check(wga_exclusive_scan_u64(d.ctx, n, d_cnt, d_roff));
+    std::vector<uint64_t> roff(n + 1);
+    d.download(roff.data(), d_roff, n + 1);
+    auto* d_runs = (uint64_t*)d.alloc((3 * roff[n] + 3) * 8);
+    d.check(wga_maf_call_runs(d.ctx, n, d_rows, d_t, d_q, d_c, d_cnt, d_runs, d_roff));
+    std::vector<uint64_t> runs(3 * roff[n]);
+    if (roff[n]) d.download(runs.data(), d_runs, 3 * roff[n]);
+    if (chunk_size == 0) fail("chunk size must be positive (the reference would never terminate)");
+    for (uint32_t k = 0; k < n; k++) {
+      CallBlock b;
+      b.rec = recs[k];
+      b.total = p.cols[k];
+      for (uint64_t x = roff[k]; x < roff[k + 1]; x++)
+        b.runs.push_back(CallRun{runs[3 * x] >> 3, runs[3 * x + 1], runs[3 * x + 2], (uint32_t)(runs[3 * x] & 7)});
+      uint64_t cs = 0;
+      while (cs < b.total) {
+        uint64_t ce = safe_chunk_end(b, cs, chunk_size, svlen);
+        call_chunk(b, cs, ce, snp, inv, svlen, text);
+        if (ce <= cs) fail("panic: chunk boundary did not advance");
+        cs = ce;
+        if (text.size() > (1u << 24)) {
+          out.write(text);
+          text.clear();
+        }
+      }
+    }
+  }
+  out.write(text);
+  out.close();
+  return 0;
+}
+
 /* ---- command line (cli.rs) -------------------------------------------------------------------------- */
 void log_error(const std::string& msg) {
   struct timespec ts;
@@ -695,7 +994,8 @@ void usage() {
           "  maf2paf | m2p  [MAF] [-q QUERY_NAME]\n"
           "  stat    | st   [FILE] [-f maf|paf] [-e] [-q QUERY_NAME]\n"
           "  pafcov  | pc   [PAF]\n"
-          "  pafpseudo | pp [PAF] -o OUTDIR [-f ALL.fa] [-g TARGET]\n");
+          "  pafpseudo | pp [PAF] -o OUTDIR [-f ALL.fa] [-g TARGET]\n"
+          "  call    | c    [MAF] [-s] [-i] [-l SVLEN] [-n SAMPLE] [--query-name N | --query-regex R] [-c CHUNK]\n");
 }
 
 }  // namespace
@@ -780,9 +1080,12 @@ int main(int argc, char** argv) {
       return 0;
     }
     /* per-subcommand options */
-    std::string input_s, target, query, format = "maf", query_name, fasta;
-    bool has_input = false, each = false, has_qname = false, has_fasta = false;
+    std::string input_s, target, query, format = "maf", query_name, fasta, sample = "sample", query_regex;
+    bool has_input = false, each = false, has_qname = false, has_fasta = false, snp = false, inv = false,
+         has_regex = false;
+    uint64_t svlen = 50, chunk_size = 1000000;
     const bool pseudo = cmd == "pafpseudo" || cmd == "pp";
+    const bool call = cmd == "call" || cmd == "c";
     for (size_t i = 0; i < rest.size(); i++) {
       const std::string& a = rest[i];
       auto val = [&]() -> std::string {
@@ -804,6 +1107,22 @@ int main(int argc, char** argv) {
         format = val();
       else if (a == "-e" || a == "--each")
         each = true;
+      else if (call && (a == "-s" || a == "--snp"))
+        snp = true;
+      else if (call && (a == "-i" || a == "--inv"))
+        inv = true;
+      else if (call && (a == "-l" || a == "--svlen"))
+        svlen = strtoull(val().c_str(), nullptr, 10);
+      else if (call && a.size() > 2 && a.compare(0, 2, "-l") == 0)
+        svlen = strtoull(a.c_str() + 2, nullptr, 10);
+      else if (call && (a == "-n" || a == "--sample"))
+        sample = val();
+      else if (call && (a == "-c" || a == "--chunk-size"))
+        chunk_size = strtoull(val().c_str(), nullptr, 10);
+      else if (call && a == "--query-regex") {
+        query_regex = val();
+        has_regex = true;
+      }
       else if (a[0] != '-' && !has_input) {
         input_s = a;
         has_input = true;
@@ -827,6 +1146,11 @@ int main(int argc, char** argv) {
     if (cmd == "maf2paf" || cmd == "m2p") {
       out.open(outfile, rewrite);
       return cmd_maf2paf(input, qn, out);
+    }
+    if (call) {
+      if (format != "maf") fail("call -f paf is not built into this engine yet (MAF input only)");
+      out.open(outfile, rewrite);
+      return cmd_call_maf(input, snp, inv, svlen, sample, qn, has_regex ? &query_regex : nullptr, chunk_size, out);
     }
     if (pseudo)
       return cmd_pafpseudo(input, outfile, rewrite, has_fasta ? &fasta : nullptr, target.empty() ? nullptr : &target);
