@@ -193,6 +193,20 @@ int wga_maf_call_runs(wga_ctx*, uint32_t n, const uint8_t* d_rows, const uint64_
                       const uint64_t* d_q_off, const uint64_t* d_cols, uint64_t* d_run_cnt,
                       uint64_t* d_runs, const uint64_t* d_run_off);
 
+/* ---- call on PAF: the op walk (replaces the fold of call_within_var_paf, caller.rs:664-819) ---
+ * Walks each record's ops with the running target / query positions and the `after_m` flag of
+ * the reference and lists the ops that raise VCF rows: every X op when `snp` is set (one row per
+ * column, :688-717), and every I / D op that directly follows an M / = / X op and is longer than
+ * `svlen` (:719-813).  The walk of a record stops at its first op outside M = X I D (the
+ * reference's fold keeps the CigarOpInvalid in its accumulator, skips the remaining ops and then
+ * discards the error, :673,815-819).  An I / D whose length was split by the packer (>= 2^28) is
+ * listed when a continuation piece follows; the caller applies the cutoff to the summed length.
+ * Event = 3 u64: op index within the record, target bases before the op, query bases before it
+ * (both relative to the record's start coordinates).  Same two-call protocol as wga_maf_call_runs:
+ * d_ev == NULL -> only d_ev_cnt[n]; then d_ev_off = exclusive scan and the call again. */
+int wga_paf_call_events(wga_ctx*, const wga_cigar_batch*, uint64_t svlen, int snp, uint64_t* d_ev_cnt,
+                        uint64_t* d_ev, const uint64_t* d_ev_off);
+
 /* ---- K5: pafcov (replaces update_cov_vec, cigar.rs:710-741, and the per-thread array merge of
  *      pafcov.rs:29-53) ------------------------------------------------------------------------
  * Record i adds +1 to d_cov[cov_off[target_id[i]] + p] for every base p of its M / = ops that

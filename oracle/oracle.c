@@ -756,6 +756,123 @@ done:
   return rc;
 }
 
+/* call_within_var_paf, caller.rs:610-822.  t_seq / q_seq are what target_seq_with_fa /
+ * query_seq_with_fa (paf.rs:221-237) fetched: [start, end] INCLUSIVE, forward strand, no
+ * reverse complement for '-'.  `cg` includes the "cg:Z:" tag.  Errors raised inside the fold are
+ * kept in its accumulator (which stops the walk) and then discarded (:673, :815-819); slices
+ * out of range panic. */
+int orc_call_within_var_paf(const char* chro, const char* q_chro, const char* cg, size_t cg_n,
+                            const char* t_seq, size_t t_n, const char* q_seq, size_t q_n,
+                            uint64_t t_start, uint64_t t_end, uint64_t q_start, uint64_t q_end,
+                            int strand_neg, int if_snp, uint64_t svlen_cutoff, char** out,
+                            size_t* out_len, orc_err* err) {
+  sbuf sb = {*out, *out_len, *out ? *out_len + 1 : 0};
+  if (!sb.s) sb_push(&sb, "", 0);
+  char suffix = strand_neg ? 'N' : 'P';
+  char info[256], qi[512];
+  int rc = 0;
+  if (strand_neg) { /* :640-658, no -i gate */
+    if (t_n < 1) {
+      rc = ORC_PANIC;
+      goto done;
+    }
+    snprintf(info, sizeof info, "SVTYPE=INV;END=%llu", (unsigned long long)t_end);
+    snprintf(qi, sizeof qi, "GT:QI\t1|1:%s@%llu@%llu@%c", q_chro, (unsigned long long)q_start,
+             (unsigned long long)q_end, suffix);
+    emit_vcf(&sb, chro, t_start + 1, t_seq, 1, "<INV>", 5, 1, info, qi);
+  }
+  const char* p = cg;
+  const char* end = cg + cg_n;
+  rc = strip_tag(&p, end, err); /* :662 */
+  if (rc) goto done;
+  if (p == end) { /* fold_many1 without a single tuple: Many1 error -> errors.rs:92 */
+    rc = ORC_PANIC;
+    goto done;
+  }
+  uint64_t t_pos = t_start, q_pos = q_start;
+  const char* init_info = strand_neg ? "INV_NEST=TRUE;" : "";
+  int after_m = 0;
+  cst_t tok;
+  while (parse_cigar_str_tuple(&p, end, &tok)) {
+    const char* op;
+    size_t op_n;
+    uint64_t len;
+    orc_err e2;
+    if (cst2cu(&tok, &op, &op_n, &len, &e2)) break; /* res = Err: the remaining ops are skipped */
+    char c = op_n == 1 ? op[0] : '?';
+    if (c == 'M' || c == '=') {
+      t_pos += len;
+      q_pos += len;
+      after_m = 1;
+    } else if (c == 'X') {
+      if (if_snp) {
+        for (uint64_t k = 0; k < len; k++) {
+          uint64_t ts = t_pos - t_start, qs = q_pos - q_start;
+          if (ts + 1 > t_n || qs + 1 > q_n) {
+            rc = ORC_PANIC;
+            goto done;
+          }
+          snprintf(qi, sizeof qi, "GT:QI\t1|1:%s@%llu@%c", q_chro, (unsigned long long)q_pos, suffix);
+          emit_vcf(&sb, chro, t_pos + 1, t_seq + ts, 1, q_seq + qs, 1, 0, NULL, qi);
+          t_pos++;
+          q_pos++;
+        }
+      } else {
+        t_pos += len;
+        q_pos += len;
+      }
+      after_m = 1;
+    } else if (c == 'I') {
+      if (len > svlen_cutoff) {
+        if (!after_m) {
+          q_pos += len;
+          after_m = 0;
+          continue;
+        }
+        uint64_t ts = t_pos - t_start - 1, qs = q_pos - q_start - 1;
+        if (ts + 1 > t_n || qs + len + 1 > q_n) {
+          rc = ORC_PANIC;
+          goto done;
+        }
+        snprintf(info, sizeof info, "%sSVTYPE=INS;SVLEN=%llu;END=%llu", init_info,
+                 (unsigned long long)len, (unsigned long long)t_pos);
+        snprintf(qi, sizeof qi, "GT:QI\t1|1:%s@%llu@%llu@%c", q_chro, (unsigned long long)q_pos,
+                 (unsigned long long)(q_pos + len), suffix);
+        emit_vcf(&sb, chro, t_pos, t_seq + ts, 1, q_seq + qs, (size_t)len + 1, 0, info, qi);
+      }
+      q_pos += len;
+      after_m = 0;
+    } else if (c == 'D') {
+      if (len > svlen_cutoff) {
+        if (!after_m) {
+          t_pos += len;
+          after_m = 0;
+          continue;
+        }
+        uint64_t ts = t_pos - t_start - 1, qs = q_pos - q_start - 1;
+        if (ts + len + 1 > t_n || qs + 1 > q_n) {
+          rc = ORC_PANIC;
+          goto done;
+        }
+        snprintf(info, sizeof info, "%sSVTYPE=DEL;SVLEN=%llu;END=%llu", init_info,
+                 (unsigned long long)len, (unsigned long long)(t_pos + len));
+        snprintf(qi, sizeof qi, "GT:QI\t1|1:%s@%llu@%llu@%c", q_chro, (unsigned long long)q_pos,
+                 (unsigned long long)q_pos, suffix);
+        emit_vcf(&sb, chro, t_pos, t_seq + ts, (size_t)len + 1, q_seq + qs, 1, 0, info, qi);
+      }
+      t_pos += len;
+      after_m = 0;
+    } else {
+      break; /* CigarOpInvalid kept in the accumulator, discarded after the fold */
+    }
+  }
+done:
+  if (rc == ORC_PANIC && err) set_err(err, ORC_PANIC, "slice", 5);
+  *out = sb.s;
+  *out_len = sb.n;
+  return rc;
+}
+
 /* per-record chunk loop of call_var_maf, caller.rs:115-149, with create_chunk_record
  * (:221-265: start += non-gap chars of the prefix, align_size = non-gap chars of the chunk) and
  * the strand-aware accessors of maf.rs:433-450,468-470 applied to the chunk record. */

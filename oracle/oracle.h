@@ -95,6 +95,14 @@ int orc_call_var_maf_record(const char* chro, const char* q_chro, const char* t,
                             int strand_neg, int if_snp, int if_inv, uint64_t svlen_cutoff,
                             size_t chunk_size, char** out, size_t* out_len);
 
+/* caller.rs:610-822 call_within_var_paf on one PAF record; t_seq / q_seq as fetched by
+ * paf.rs:221-237 (inclusive end, no reverse complement); appends VCF body lines to *out. */
+int orc_call_within_var_paf(const char* chro, const char* q_chro, const char* cg, size_t cg_n,
+                            const char* t_seq, size_t t_n, const char* q_seq, size_t q_n,
+                            uint64_t t_start, uint64_t t_end, uint64_t q_start, uint64_t q_end,
+                            int strand_neg, int if_snp, uint64_t svlen_cutoff, char** out,
+                            size_t* out_len, orc_err* err);
+
 void orc_free(void* p);
 /* test helper: packed ops -> "cg:Z:..." text; returns length (0 if cap too small) */
 size_t orc_ops_to_text(const uint32_t* ops, size_t n, char* out, size_t cap);

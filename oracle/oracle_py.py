@@ -56,6 +56,8 @@ def lib():
         L.orc_gen_pesudo_maf_by_cigar.argtypes = [C.c_char_p, Z, P, P, C.c_int, P]
         L.orc_call_var_maf_record.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, Z,
                                               U, U, U, U, U, C.c_int, C.c_int, C.c_int, U, Z, P, P]
+        L.orc_call_within_var_paf.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, Z, C.c_char_p, Z,
+                                              C.c_char_p, Z, U, U, U, U, C.c_int, C.c_int, U, P, P, P]
         L.orc_ops_to_text.restype = Z
         L.orc_ops_to_text.argtypes = [P, Z, C.c_char_p, Z]
         L.orc_free.argtypes = [C.c_void_p]
@@ -199,6 +201,27 @@ def call_var_maf_record(chro, q_chro, t_row, q_row, t_start, q_sline_start, q_sl
         lib().orc_free(out)
     if rc:
         raise OracleError(rc, "", "call_within_var panicked")
+    return s
+
+
+def call_within_var_paf(chro, q_chro, cg, t_seq, q_seq, t_start, t_end, q_start, q_end, strand_neg,
+                        if_snp, svlen_cutoff):
+    """caller.rs:610-822 for one PAF record -> VCF body text"""
+    cg = cg.encode() if isinstance(cg, str) else bytes(cg)
+    t_seq, q_seq = bytes(t_seq), bytes(q_seq)
+    out = C.c_void_p()
+    out_len = C.c_size_t(0)
+    err = Err()
+    rc = lib().orc_call_within_var_paf(
+        chro.encode(), q_chro.encode(), cg, C.c_size_t(len(cg)), t_seq, C.c_size_t(len(t_seq)), q_seq,
+        C.c_size_t(len(q_seq)), C.c_uint64(t_start), C.c_uint64(t_end), C.c_uint64(q_start),
+        C.c_uint64(q_end), int(strand_neg), int(if_snp), C.c_uint64(svlen_cutoff), C.byref(out),
+        C.byref(out_len), C.byref(err))
+    s = C.string_at(out, out_len.value).decode() if out.value else ""
+    if out.value:
+        lib().orc_free(out)
+    if rc:
+        _raise(err)
     return s
 
 

@@ -400,3 +400,61 @@ def test_call_query_selection(cli, tmp_path):
     assert out.decode() == _expected_vcf(blocks, "sample", True, False, 0, 1000000)
     rc, out, err = run(cli, "c", str(maf), "-s", "-l0", "--query-name", "absent")
     assert rc == 0 and out.decode() == VCF_HEADER % "sample"
+
+
+# ---- call (PAF) ------------------------------------------------------------------------------------
+def _expected_paf_vcf(b, sample, snp, svlen, cigars=None):
+    body = []
+    tp, qp = b["t_pool"].tobytes(), b["q_pool"].tobytes()
+    for i in range(len(b["strand_neg"])):
+        qs, ql = int(b["q_src_off"][i]), int(b["q_src_len"][i])
+        ts, tl = int(b["t_src_off"][i]), int(b["t_src_len"][i])
+        cg = cigars[i] if cigars and cigars.get(i) else pc.rec_text(b, i)
+        # paf.rs:221-237: [start, end] inclusive, clipped at the contig end, forward strand
+        body.append(orc.call_within_var_paf("tchr", "qchr", cg, tp[ts:ts + tl + 1], qp[qs:qs + ql + 1], ts, ts + tl,
+                                            qs, qs + ql, bool(b["strand_neg"][i]), snp, svlen))
+    return (VCF_HEADER % sample + "".join(body)).encode()
+
+
+@pytest.mark.parametrize("snp,svlen", [(True, 0), (False, 2), (True, 50)])
+def test_call_paf_end_to_end(cli, tmp_path, snp, svlen):
+    b = synth.make_paf_batch(91, 40, 250, 150000)
+    t_fa, q_fa, paf = _write_paf2maf_case(tmp_path, b, np.zeros(40, dtype=int))
+    args = ["call", "-f", "paf", paf, "--target", t_fa, "-q", q_fa, "-l", str(svlen), "-n", "S1"]
+    rc, out, err = run(cli, *(args + (["-s"] if snp else [])))
+    assert rc == 0, err
+    assert out == _expected_paf_vcf(b, "S1", snp, svlen)
+
+
+def test_call_paf_fold_errors_are_discarded(cli, tmp_path):
+    """caller.rs:673,815-819: an invalid op / token ends that record's walk silently; a missing tag
+    and an empty CIGAR still abort, and nothing is written (buffered driver)"""
+    b = synth.make_paf_batch(92, 6, 60, 20000)
+    bad = {1: "cg:Z:30=2X4I7=3N5=1X", 3: "cg:Z:12=3I5=1X4", 4: "cg:Z:9=1XX3="}
+    for i, cg in bad.items():
+        t_fa, q_fa, paf = _write_paf2maf_case(tmp_path, b, np.zeros(6, dtype=int), bad=(i, cg))
+        rc, out, err = run(cli, "c", "-f", "paf", paf, "--target", t_fa, "--query", q_fa, "-s", "-l0")
+        assert rc == 0, err
+        assert out == _expected_paf_vcf(b, "sample", True, 0, cigars={i: cg})
+    t_fa, q_fa, paf = _write_paf2maf_case(tmp_path, b, np.zeros(6, dtype=int), bad=(2, "xx:i:1"))
+    rc, out, err = run(cli, "c", "-f", "paf", paf, "--target", t_fa, "--query", q_fa, "-s", "-l0")
+    assert rc == 1 and out == b"" and err.strip().endswith("ERROR CIGAR start tag not found")
+    rc, out, err = run(cli, "c", "-f", "paf", paf)
+    assert rc == 1 and err.strip().endswith("ERROR target and query are necessary")
+
+
+def test_call_maf_index_contigs(cli, tmp_path):
+    """utils.rs:414-436 + caller.rs:340-357: `<maf>.index` adds natord-sorted ##contig lines of the
+    reference sequences (placement after the FORMAT lines is unpinned)"""
+    import shutil
+    maf = tmp_path / "t.maf"
+    shutil.copy(os.path.join(GOLDEN, "test.maf"), maf)
+    with open(str(maf) + ".index", "w") as f:
+        f.write('{"ref.chr10":{"ivls":[{"start":1,"end":2,"strand":"+","offset":17}],"size":500,"isref":true},'
+                '"query.chr8":{"ivls":[],"size":183119688,"isref":false},'
+                ' "ref.chr8" : {"ivls":[], "size": 182411202, "isref": true}}')
+    rc, out, err = run(cli, "call", str(maf), "-l0")
+    assert rc == 0, err
+    lines = out.decode().splitlines()
+    assert lines[7:10] == ["##contig=<ID=ref.chr8,length=182411202>", "##contig=<ID=ref.chr10,length=500>",
+                           "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsample"]

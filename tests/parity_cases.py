@@ -404,6 +404,55 @@ def check_maf_call_runs(eng, pairs):
 
 
 # ------------------------------------------------------------------------------------------------
+# K7 PAF call op walk
+# ------------------------------------------------------------------------------------------------
+def expected_paf_call_events(ops, svlen, snp):
+    """op-serial restatement of the fold of call_within_var_paf (caller.rs:664-819) over packed ops"""
+    ev, t, q, after_m, k = [], 0, 0, False, 0
+    n = len(ops)
+    while k < n:
+        code, ln = int(ops[k]) & 15, int(ops[k]) >> 4
+        if code in (0, 7):
+            t += ln; q += ln; after_m = True; k += 1
+        elif code == 8:
+            if snp:
+                ev.append((k, t, q))
+            t += ln; q += ln; after_m = True; k += 1
+        elif code in (1, 2):
+            j, tot = k + 1, ln
+            while j < n and (int(ops[j]) & 15) in (9, 10):
+                tot += int(ops[j]) >> 4
+                j += 1
+            if after_m and (ln > svlen or j > k + 1):     # the host applies `tot > svlen` to split ops
+                ev.append((k, t, q))
+            if code == 1:
+                q += tot
+            else:
+                t += tot
+            after_m = False
+            k = j
+        else:
+            break
+    return ev
+
+
+def check_paf_call_events(eng, ops, op_off, svlen, snp):
+    n = len(op_off) - 1
+    batch = eng.make_batch(ops, op_off, np.zeros(n, dtype=np.uint8))
+    cnt = eng.paf_call_events(batch, svlen, snp)
+    off = eng.exclusive_scan_u64(n, cnt)
+    o = off.numpy()
+    ev = eng.empty(3 * int(o[-1]) + 3, np.uint64).fill(0)
+    eng.paf_call_events(batch, svlen, snp, ev_cnt=cnt, ev=ev, ev_off=off)
+    e = ev.numpy()
+    for i in range(n):
+        want = expected_paf_call_events(ops[int(op_off[i]):int(op_off[i + 1])], svlen, snp)
+        got = [tuple(int(x) for x in e[3 * k:3 * k + 3]) for k in range(int(o[i]), int(o[i + 1]))]
+        assert got == want, (i, got[:5], want[:5])
+    return int(o[-1])
+
+
+# ------------------------------------------------------------------------------------------------
 # a second, linear-time expectation for long records (the C oracle's insert_str is quadratic)
 # ------------------------------------------------------------------------------------------------
 def fast_expected_rows(ops, t_seq, q_seq, neg):

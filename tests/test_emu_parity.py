@@ -216,3 +216,21 @@ def test_fast_expected_matches_oracle():
         t = b["t_pool"][int(b["t_src_off"][i]):int(b["t_src_off"][i] + b["t_src_len"][i])].tobytes()
         q = b["q_pool"][int(b["q_src_off"][i]):int(b["q_src_off"][i] + b["q_src_len"][i])].tobytes()
         assert pc.fast_expected_rows(pc.rec_ops(b, i), t, q, b["strand_neg"][i]) == pc.oracle_rows(b, i)
+
+
+def test_paf_call_events(emu):
+    b = synth.make_paf_batch(33, 12, 150, 400000)
+    for svlen, snp in ((0, True), (3, False), (50, True)):
+        assert pc.check_paf_call_events(emu, b["ops"], b["op_off"], svlen, snp) > 0
+    # invalid op mid-record, zero-length ops, lengths split by the packer (head + continuation pieces)
+    L = (1 << 28) - 1
+    mk = lambda *p: [(ln << 4) | c for c, ln in p]
+    recs = [mk((7, 5), (1, 3), (3, 9), (8, 1), (2, 7)),                       # N stops the walk
+            mk((7, 5), (1, L), (9, L), (9, 12), (7, 2), (2, 1), (10, 0), (8, 3)),  # split I, split D of small total
+            mk((1, 9), (7, 1), (2, 9), (1, 9), (0, 0), (1, 9)),                # leading I, I after D, 0M then I
+            mk((8, 2), (2, L), (10, L), (8, 1)),
+            [], mk((11, 4), (7, 3))]
+    ops = np.array([o for r in recs for o in r], dtype=np.uint32)
+    off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+    for svlen, snp in ((0, True), (8, True), (1 << 40, False)):
+        pc.check_paf_call_events(emu, ops, off, svlen, snp)

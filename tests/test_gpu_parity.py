@@ -232,3 +232,21 @@ def test_scan(gpu):
         v = rng.integers(0, 1 << 40, n).astype(np.uint64)
         got = gpu.exclusive_scan_u64(n, gpu.upload(v) if n else None).numpy()
         assert (got == np.concatenate([np.zeros(1, np.uint64), np.cumsum(v, dtype=np.uint64)])).all()
+
+
+def test_paf_call_events(gpu):
+    b = synth.make_paf_batch(33, 300, 3000, 400000)
+    for svlen, snp in ((0, True), (3, False), (50, True)):
+        assert pc.check_paf_call_events(gpu, b["ops"], b["op_off"], svlen, snp) > 0
+    # invalid op mid-record, zero-length ops, lengths split by the packer (head + continuation pieces)
+    L = (1 << 28) - 1
+    mk = lambda *p: [(ln << 4) | c for c, ln in p]
+    recs = [mk((7, 5), (1, 3), (3, 9), (8, 1), (2, 7)),                       # N stops the walk
+            mk((7, 5), (1, L), (9, L), (9, 12), (7, 2), (2, 1), (10, 0), (8, 3)),  # split I, split D of small total
+            mk((1, 9), (7, 1), (2, 9), (1, 9), (0, 0), (1, 9)),                # leading I, I after D, 0M then I
+            mk((8, 2), (2, L), (10, L), (8, 1)),
+            [], mk((11, 4), (7, 3))]
+    ops = np.array([o for r in recs for o in r], dtype=np.uint32)
+    off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+    for svlen, snp in ((0, True), (8, True), (1 << 40, False)):
+        pc.check_paf_call_events(gpu, ops, off, svlen, snp)

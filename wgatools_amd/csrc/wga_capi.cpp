@@ -357,6 +357,20 @@ int wga_maf_call_runs(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint6
   return WGA_OK;
 }
 
+int wga_paf_call_events(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, int snp,
+                        uint64_t* d_ev_cnt, uint64_t* d_ev, const uint64_t* d_ev_off) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if ((rc = check_batch(b))) return rc;
+  if (b->n == 0) return WGA_OK;
+  if (d_ev && !d_ev_off) return fail(WGA_E_INVALID_ARG, "d_ev_off null", nullptr);
+  WGA_LAUNCH(k_paf_call_events, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
+             (const u64*)b->d_op_off, (u64)svlen, (u32)(snp != 0), (u64*)d_ev_cnt, (u64*)d_ev,
+             (const u64*)d_ev_off);
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
 int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_target_id,
                           const uint64_t* d_t_start, const uint64_t* d_cov_off,
                           const uint64_t* d_cov_len, int32_t* d_cov) {

@@ -761,4 +761,74 @@ __global__ __launch_bounds__(256) void k_maf_call_runs(u32 n, const u8* __restri
   if (lane == 0 && run_cnt) run_cnt[i] = run_base;
 }
 
+/* ============================================================================================ */
+/* K7: PAF call op walk                                                                         */
+/* ============================================================================================ */
+/* call_within_var_paf (caller.rs:610-822) walks the op stream with two running positions and an
+ * `after_m` flag and raises events at X ops (when SNPs are asked for) and at I / D ops longer
+ * than the cutoff that directly follow an M / = / X op.  Per record one wave scans the ops 64 at
+ * a time: exclusive u64 prefix sums of the target / query advance, `after_m` from the previous
+ * op's code, compaction of the event ops by ballot.  The walk stops at the first op that is not
+ * M = X I D (the reference's fold keeps its Err and skips the rest, :673,815-819).
+ * A length >= 2^28 is packed as a head op plus continuation pieces (codes 9 / 10): the head is
+ * flagged when `len > svlen` or a continuation follows; the host applies the cutoff to the sum.
+ * Event entry = 3 u64: op index in the record, target advance before it, query advance before it. */
+__device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, u32 lane) {
+#pragma unroll
+  for (u32 d = 1; d < 64; d <<= 1) {
+    const u64 o = __shfl_up(v, d);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_paf_call_events(u32 n, const u32* __restrict__ ops,
+                                                         const u64* __restrict__ op_off, u64 svlen,
+                                                         u32 snp, u64* ev_cnt, u64* ev,
+                                                         const u64* ev_off) {
+  const u32 lane = threadIdx.x & 63u;
+  const u64 i = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
+  const u32* rec = ops + o0;
+  u64* eout = ev ? ev + 3 * ev_off[i] : (u64*)0;
+  u64 t_base = 0, q_base = 0, e_base = 0;
+  u32 carry_code = 0xFu;
+  for (u64 k0 = 0; k0 < nops; k0 += 64) {
+    const u64 k = k0 + lane;
+    const bool in = k < nops;
+    const u32 op = in ? rec[k] : 0xFu;
+    const u32 code = op & 15u;
+    const u64 len = (u64)(op >> 4);
+    const bool mlike = code == WGA_OP_M || code == WGA_OP_EQ, isx = code == WGA_OP_X;
+    const bool isi = code == WGA_OP_I || code == WGA_OP_I_CONT, isd = code == WGA_OP_D || code == WGA_OP_D_CONT;
+    const bool valid = mlike || isx || isi || isd;
+    const u64 bad = __ballot(in && !valid);
+    const u64 live_mask = bad ? ((1ull << (u32)__builtin_ctzll(bad)) - 1ull) : ~0ull;
+    const bool live = in && ((live_mask >> lane) & 1ull);
+    const u64 ta = live && !isi ? len : 0ull, qa = live && !isd ? len : 0ull;
+    const u64 ti = wave_incl_scan_u64(ta, lane), qi = wave_incl_scan_u64(qa, lane);
+    u32 prev = __shfl_up(code, 1u);
+    if (lane == 0) prev = carry_code;
+    const bool after_m = prev == WGA_OP_M || prev == WGA_OP_EQ || prev == WGA_OP_X;
+    const u32 nxt = (k + 1 < nops) ? (rec[k + 1] & 15u) : 0xFu;
+    const bool cont_follows = nxt == WGA_OP_I_CONT || nxt == WGA_OP_D_CONT;
+    const bool head_indel = code == WGA_OP_I || code == WGA_OP_D;
+    const bool is_ev = live && ((isx && snp) || (head_indel && after_m && (len > svlen || cont_follows)));
+    const u64 m = __ballot(is_ev);
+    if (eout && is_ev) {
+      u64* e = eout + 3 * (e_base + (u64)__popcll(m & ((1ull << lane) - 1ull)));
+      e[0] = k;
+      e[1] = t_base + ti - ta;
+      e[2] = q_base + qi - qa;
+    }
+    e_base += (u64)__popcll(m);
+    t_base += __shfl(ti, 63);
+    q_base += __shfl(qi, 63);
+    carry_code = __shfl(code, 63);
+    if (bad) break;
+  }
+  if (lane == 0 && ev_cnt) ev_cnt[i] = e_base;
+}
+
 #endif /* WGA_KERNELS2_H */

@@ -220,6 +220,12 @@ class Engine:
                                                _p(run_cnt), _p(runs), _p(run_off)))
         return run_cnt
 
+    def paf_call_events(self, batch, svlen, snp, ev_cnt=None, ev=None, ev_off=None):
+        ev_cnt = ev_cnt if ev_cnt is not None else self.empty(batch.n, np.uint64)
+        self._check(self.lib.wga_paf_call_events(self.ctx, C.byref(batch.c), int(svlen), int(bool(snp)),
+                                                 _p(ev_cnt), _p(ev), _p(ev_off)))
+        return ev_cnt
+
     def pafcov_accumulate(self, batch, target_id, t_start, cov_off, cov_len, cov):
         self._check(self.lib.wga_pafcov_accumulate(self.ctx, C.byref(batch.c), _p(target_id),
                                                    _p(t_start), _p(cov_off), _p(cov_len), _p(cov)))

@@ -516,6 +516,136 @@ void Faidx::fetch(const std::string& name, uint64_t beg_u, uint64_t end_u, uint6
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* MAF index (JSON) -> reference contigs                                                        */
+/* ------------------------------------------------------------------------------------------ */
+namespace {
+struct Json { /* just enough of a JSON reader for tools/index.rs:78-95 */
+  const std::string& t;
+  size_t p = 0;
+  explicit Json(const std::string& text) : t(text) {}
+  void ws() {
+    while (p < t.size() && (t[p] == ' ' || t[p] == '\n' || t[p] == '\r' || t[p] == '\t')) p++;
+  }
+  [[noreturn]] void bad() { fail("maf index: invalid JSON at byte " + std::to_string(p)); }
+  bool eat(char c) {
+    ws();
+    if (p < t.size() && t[p] == c) {
+      p++;
+      return true;
+    }
+    return false;
+  }
+  void need(char c) {
+    if (!eat(c)) bad();
+  }
+  std::string str() {
+    need('"');
+    std::string o;
+    while (p < t.size() && t[p] != '"') {
+      if (t[p] == '\\') {
+        if (++p >= t.size()) bad();
+        switch (t[p]) {
+          case 'n': o.push_back('\n'); break;
+          case 't': o.push_back('\t'); break;
+          case 'r': o.push_back('\r'); break;
+          case 'b': o.push_back('\b'); break;
+          case 'f': o.push_back('\f'); break;
+          case 'u': { /* \uXXXX -> UTF-8 (BMP only; names are ASCII in practice) */
+            if (p + 4 >= t.size()) bad();
+            unsigned cp = (unsigned)strtoul(t.substr(p + 1, 4).c_str(), nullptr, 16);
+            p += 4;
+            if (cp < 0x80)
+              o.push_back((char)cp);
+            else if (cp < 0x800) {
+              o.push_back((char)(0xC0 | (cp >> 6)));
+              o.push_back((char)(0x80 | (cp & 63)));
+            } else {
+              o.push_back((char)(0xE0 | (cp >> 12)));
+              o.push_back((char)(0x80 | ((cp >> 6) & 63)));
+              o.push_back((char)(0x80 | (cp & 63)));
+            }
+            break;
+          }
+          default: o.push_back(t[p]);
+        }
+        p++;
+      } else {
+        o.push_back(t[p++]);
+      }
+    }
+    if (p >= t.size()) bad();
+    p++;
+    return o;
+  }
+  /* skips any value; numbers / literals are returned as text */
+  std::string skip() {
+    ws();
+    if (p >= t.size()) bad();
+    if (t[p] == '"') return str();
+    if (t[p] == '{') {
+      p++;
+      if (eat('}')) return "";
+      do {
+        str();
+        need(':');
+        skip();
+      } while (eat(','));
+      need('}');
+      return "";
+    }
+    if (t[p] == '[') {
+      p++;
+      if (eat(']')) return "";
+      do skip();
+      while (eat(','));
+      need(']');
+      return "";
+    }
+    size_t s = p;
+    while (p < t.size() && t[p] != ',' && t[p] != '}' && t[p] != ']' && t[p] != ' ' && t[p] != '\n' && t[p] != '\r' &&
+           t[p] != '\t')
+      p++;
+    if (p == s) bad();
+    return t.substr(s, p - s);
+  }
+};
+}  // namespace
+
+std::vector<std::pair<std::string, uint64_t>> maf_index_ref_contigs(const std::string& path) {
+  std::vector<std::pair<std::string, uint64_t>> out;
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return out;
+  fclose(f);
+  std::string text = read_all(&path);
+  Json j(text);
+  j.need('{');
+  if (!j.eat('}')) {
+    do {
+      std::string name = j.str();
+      j.need(':');
+      j.need('{');
+      uint64_t size = 0;
+      bool isref = false;
+      if (!j.eat('}')) {
+        do {
+          std::string key = j.str();
+          j.need(':');
+          std::string v = j.skip();
+          if (key == "size") size = strtoull(v.c_str(), nullptr, 10);
+          if (key == "isref") isref = v == "true";
+        } while (j.eat(','));
+        j.need('}');
+      }
+      if (isref) out.emplace_back(name, size);
+    } while (j.eat(','));
+    j.need('}');
+  }
+  std::stable_sort(out.begin(), out.end(),
+                   [](const auto& a, const auto& b) { return natord_compare(a.first, b.first) < 0; });
+  return out;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* stat (common.rs:116-140, stat.rs)                                                           */
 /* ------------------------------------------------------------------------------------------ */
 RecStat recstat_from(const wga_cigar_counts& c) {

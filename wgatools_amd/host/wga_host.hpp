@@ -84,6 +84,10 @@ struct MafRecord { /* maf.rs:216-220 */
 /* maf.rs:25-36 + 371-421: first line is always the header; a block = maximal run of 's' lines */
 std::vector<MafRecord> parse_maf(const std::string& text, std::string* header);
 
+/* `<maf>.index` (tools/index.rs:78-95, serde_json map name -> {ivls,size,isref}): the (name, size) of
+ * the entries with isref, natord-sorted (caller.rs:340-357).  Missing file -> empty. */
+std::vector<std::pair<std::string, uint64_t>> maf_index_ref_contigs(const std::string& path);
+
 /* ---- FASTA index ------------------------------------------------------------------------------ */
 struct Faidx {
   struct Contig {

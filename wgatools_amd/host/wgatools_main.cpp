@@ -887,23 +887,177 @@ void call_chunk(const CallBlock& b, uint64_t cs, uint64_t ce, bool snp, bool inv
   }
 }
 
-int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, const std::string& sample,
-                 const std::string* query_name, const std::string* query_regex, uint64_t chunk_size, Output& out) {
-  std::string header;
-  std::vector<MafRecord> all = parse_maf(read_all(input), &header);
-  std::string text =
+/* build_header, caller.rs:304-338 as noodles-vcf 0.43 prints it (README.md:323-331) */
+std::string vcf_header(const std::string& sample, const std::vector<std::pair<std::string, uint64_t>>& contigs) {
+  std::string h =
       "##fileformat=VCFv4.4\n"
       "##INFO=<ID=SVLEN,Number=A,Type=Integer,Description=\"Length of structural variant\">\n"
       "##INFO=<ID=SVTYPE,Number=1,Type=String,Description=\"Type of structural variant\">\n"
       "##INFO=<ID=END,Number=1,Type=Integer,Description=\"End position of the longest variant described in this record\">\n"
       "##INFO=<ID=INV_NEST,Number=1,Type=String,Description=\"Varations nested within inversion\">\n"
       "##FORMAT=<ID=QI,Number=1,Type=String,Description=\"Query informations\">\n"
-      "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n"
-      "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + sample + "\n";
+      "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n";
+  for (auto& c : contigs) { /* add_header_contig :340-357; placement after FORMAT is unpinned */
+    h += "##contig=<ID=" + c.first + ",length=";
+    append_u64(h, c.second);
+    h += ">\n";
+  }
+  h += "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + sample + "\n";
+  return h;
+}
+
+/* ---- call (PAF) (caller.rs:268-302, 610-822) -----------------------------------------------------------
+ * GPU: the op walk (wga_paf_call_events).  Host: fetch coordinates, the event -> VCF row text. */
+int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::string& q_fa, bool snp,
+                 uint64_t svlen, const std::string& sample, Output& out) {
+  std::vector<PafRecord> recs = parse_paf(read_all(input));
+  Faidx tf, qf;
+  tf.load(t_fa);
+  qf.load(q_fa);
+  std::string body;
+  Dev d;
+  d.init();
+  const uint64_t kMaxOps = 64ull << 20;
+  size_t i0 = 0;
+  while (i0 < recs.size()) {
+    PackedBatch b;
+    std::vector<uint64_t> t_off, t_len, q_off, q_len;
+    size_t i = i0;
+    for (; i < recs.size(); i++) {
+      const PafRecord& r = recs[i];
+      if (!b.strand.empty() && b.ops.size() > kMaxOps) break;
+      uint64_t to, tl, qo, ql;
+      tf.fetch(r.target_name, r.target_start, r.target_end, &to, &tl); /* paf.rs:221-237: end inclusive */
+      qf.fetch(r.query_name, r.query_start, r.query_end, &qo, &ql);
+      if (r.neg && tl == 0) fail("panic: byte index 1 is out of bounds of the fetched target (caller.rs:642)");
+      int err = 0;
+      std::string cg = paf_cigar_string(r, &err);
+      if (err) fail("CIGAR start tag not found");
+      std::string text = cg.substr(5);
+      if (text.empty()) fail(cigar_error_message(WGA_REC_PANIC, text, 0, 0));
+      /* tokeniser errors end the walk but are discarded (:673,815-819): keep the ops before them */
+      size_t need = text.size() + 1, n = 0, eo = 0, el = 0, base = b.ops.size();
+      int32_t rerr = 0;
+      b.ops.resize(base + need);
+      int rc = wga_cigar_pack(text.data(), text.size(), b.ops.data() + base, need, &n, &rerr, &eo, &el);
+      if (rc == WGA_E_TOO_SMALL) {
+        b.ops.resize(base + n);
+        wga_cigar_pack(text.data(), text.size(), b.ops.data() + base, n, &n, &rerr, &eo, &el);
+      }
+      b.ops.resize(base + n);
+      b.op_off.push_back(b.ops.size());
+      b.strand.push_back(r.neg ? 1 : 0);
+      t_off.push_back(to);
+      t_len.push_back(tl);
+      q_off.push_back(qo);
+      q_len.push_back(ql);
+    }
+    const uint32_t n = (uint32_t)b.strand.size();
+    if (n) {
+      if (b.ops.empty()) b.ops.push_back(0);
+      wga_cigar_batch cb = device_batch(d, b);
+      cb.n_ops = b.op_off.back();
+      auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
+      d.check(wga_paf_call_events(d.ctx, &cb, svlen, snp, d_cnt, nullptr, nullptr));
+      auto* d_eoff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+      d.check(wga_exclusive_scan_u64(d.ctx, n, d_cnt, d_eoff));
+      std::vector<uint64_t> eoff(n + 1);
+      d.download(eoff.data(), d_eoff, n + 1);
+      auto* d_ev = (uint64_t*)d.alloc((3 * eoff[n] + 3) * 8);
+      d.check(wga_paf_call_events(d.ctx, &cb, svlen, snp, d_cnt, d_ev, d_eoff));
+      std::vector<uint64_t> ev(3 * eoff[n]);
+      if (eoff[n]) d.download(ev.data(), d_ev, 3 * eoff[n]);
+      for (uint32_t k = 0; k < n; k++) {
+        const PafRecord& r = recs[i0 + k];
+        const char* ts = tf.pool.data() + t_off[k];
+        const char* qs = qf.pool.data() + q_off[k];
+        const uint64_t tn = t_len[k], qn = q_len[k];
+        const char suffix = r.neg ? 'N' : 'P';
+        auto qi = [&](uint64_t a, uint64_t b2, bool three) {
+          std::string s2 = r.query_name + "@";
+          append_u64(s2, a);
+          if (!three) {
+            s2.push_back('@');
+            append_u64(s2, b2);
+          }
+          s2.push_back('@');
+          s2.push_back(suffix);
+          return s2;
+        };
+        if (r.neg) { /* :640-658 */
+          std::string info = "SVTYPE=INV;END=";
+          append_u64(info, r.target_end);
+          vcf_line(body, r.target_name, r.target_start + 1, std::string(ts, 1), "<INV>", true, info,
+                   qi(r.query_start, r.query_end, false));
+        }
+        const std::string init_info = r.neg ? "INV_NEST=TRUE;" : "";
+        const uint32_t* rops = b.ops.data() + b.op_off[k];
+        const uint64_t nops = b.op_off[k + 1] - b.op_off[k];
+        auto oob = [&]() { fail("panic: VCF REF/ALT slice out of the fetched sequence (caller.rs:695-696,753-754,800-801)"); };
+        for (uint64_t e = eoff[k]; e < eoff[k + 1]; e++) {
+          const uint64_t oi = ev[3 * e], tb = ev[3 * e + 1], qb = ev[3 * e + 2];
+          const uint32_t code = rops[oi] & 15u;
+          uint64_t len = rops[oi] >> 4;
+          for (uint64_t j = oi + 1; j < nops && ((rops[j] & 15u) == WGA_OP_I_CONT || (rops[j] & 15u) == WGA_OP_D_CONT); j++)
+            len += rops[j] >> 4;
+          const uint64_t t_pos = r.target_start + tb, q_pos = r.query_start + qb;
+          if (code == WGA_OP_X) {
+            for (uint64_t x = 0; x < len; x++) {
+              if (tb + x + 1 > tn || qb + x + 1 > qn) oob();
+              vcf_line(body, r.target_name, t_pos + x + 1, std::string(ts + tb + x, 1), std::string(qs + qb + x, 1),
+                       false, "", qi(q_pos + x, 0, true));
+            }
+          } else if (len > svlen) {
+            if (tb == 0 || qb == 0) oob(); /* `t_pos - t_start - 1` wraps */
+            std::string info = init_info;
+            if (code == WGA_OP_I) {
+              if (tb > tn || qb + len > qn) oob();
+              info += "SVTYPE=INS;SVLEN=";
+              append_u64(info, len);
+              info += ";END=";
+              append_u64(info, t_pos);
+              vcf_line(body, r.target_name, t_pos, std::string(ts + tb - 1, 1), std::string(qs + qb - 1, len + 1), false,
+                       info, qi(q_pos, q_pos + len, false));
+            } else {
+              if (tb + len > tn || qb > qn) oob();
+              info += "SVTYPE=DEL;SVLEN=";
+              append_u64(info, len);
+              info += ";END=";
+              append_u64(info, t_pos + len);
+              vcf_line(body, r.target_name, t_pos, std::string(ts + tb - 1, len + 1), std::string(qs + qb - 1, 1), false,
+                       info, qi(q_pos, q_pos, false));
+            }
+          }
+        }
+      }
+      d.release_all();
+    }
+    i0 = i;
+  }
+  /* everything is buffered; the header goes out first, after all records were processed (:294-299) */
+  out.write(vcf_header(sample, {}));
+  out.write(body);
+  out.close();
+  return 0;
+}
+
+int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, const std::string& sample,
+                 const std::string* query_name, const std::string* query_regex, uint64_t chunk_size, Output& out) {
+  std::string header;
+  std::vector<MafRecord> all = parse_maf(read_all(input), &header);
+  /* utils.rs:414-436: `<input>.index` (JSON written by `maf-index`) supplies ##contig lines */
+  std::vector<std::pair<std::string, uint64_t>> contigs;
+  if (input) contigs = maf_index_ref_contigs(*input + ".index");
+  std::string text = vcf_header(sample, contigs);
   /* record selection (:62-108): single-s-line blocks and blocks without the asked query are skipped */
   std::vector<MafRecord*> recs;
   std::regex re;
-  if (!query_name && query_regex) re = std::regex(*query_regex); /* is_match_at(name, 0): unanchored search (maf.rs:267-271) */
+  if (!query_name && query_regex) { /* cli.rs:332-343 anchors the pattern; maf.rs:267-271 searches from 0 */
+    std::string pat = *query_regex;
+    if (pat.empty() || pat.front() != '^') pat.insert(pat.begin(), '^');
+    if (pat.back() != '$') pat.push_back('$');
+    re = std::regex(pat);
+  }
   for (auto& r : all) {
     if (r.slines.size() == 1) continue;
     if (query_name) {
@@ -995,7 +1149,8 @@ void usage() {
           "  stat    | st   [FILE] [-f maf|paf] [-e] [-q QUERY_NAME]\n"
           "  pafcov  | pc   [PAF]\n"
           "  pafpseudo | pp [PAF] -o OUTDIR [-f ALL.fa] [-g TARGET]\n"
-          "  call    | c    [MAF] [-s] [-i] [-l SVLEN] [-n SAMPLE] [--query-name N | --query-regex R] [-c CHUNK]\n");
+          "  call    | c    [MAF] [-s] [-i] [-l SVLEN] [-n SAMPLE] [--query-name N | --query-regex R] [-c CHUNK]\n"
+          "  call    | c    -f paf [PAF] --target T.fa --query Q.fa [-s] [-l SVLEN] [-n SAMPLE]\n");
 }
 
 }  // namespace
@@ -1095,7 +1250,7 @@ int main(int argc, char** argv) {
       bool conv = cmd == "paf2maf" || cmd == "p2m";
       if (a == "-g" || a == "--target")
         target = val();
-      else if ((a == "-q" || a == "--query") && conv)
+      else if ((a == "-q" || a == "--query") && (conv || call))
         query = val();
       else if (a == "-q" || a == "--query-name") {
         query_name = val();
@@ -1148,7 +1303,12 @@ int main(int argc, char** argv) {
       return cmd_maf2paf(input, qn, out);
     }
     if (call) {
-      if (format != "maf") fail("call -f paf is not built into this engine yet (MAF input only)");
+      if (format == "paf") {
+        if (target.empty() || query.empty()) fail("target and query are necessary"); /* main.rs:103-110 */
+        out.open(outfile, rewrite);
+        return cmd_call_paf(input, target, query, snp, svlen, sample, out);
+      }
+      if (format != "maf") fail("format is not supported");
       out.open(outfile, rewrite);
       return cmd_call_maf(input, snp, inv, svlen, sample, qn, has_regex ? &query_regex : nullptr, chunk_size, out);
     }
