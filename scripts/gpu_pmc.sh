@@ -12,16 +12,25 @@ run() { # name counters...
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- $BENCH > $OUT/$name.json 2> $OUT/$name.err
   echo "$name rc=$?"
 }
+PASSES=${2:-"sq1 sq2 fetch write tcc"}
+want() { [[ " $PASSES " == *" $1 "* ]]; }
+run() { # name counters...
+  name=$1; shift
+  want $name || return 0
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- $BENCH > $OUT/$name.json 2> $OUT/$name.err
+  echo "$name rc=$?"
+}
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS
 run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE
 run fetch FETCH_SIZE
 run write WRITE_SIZE
+run sq3 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_LDS
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 cd $R
 python - <<PY
 import csv, glob, collections, os
 out = "$OUT"
-for d in ("sq1","sq2","fetch","write","tcc"):
+for d in ("sq1","sq2","sq3","fetch","write","tcc"):
     for f in glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
         for row in csv.DictReader(open(f)):

@@ -49,6 +49,7 @@ def build_hip(force=False, verbose=False):
         raise RuntimeError("hipcc not found: libwgahip.so cannot be built here")
     objs = []
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall"] + STAGE2
+    flags += os.environ.get("WGA_EXTRA_FLAGS", "").split()  # e.g. -DWGA_PROFILE (ablation knobs)
     for src, xflag in (("wga_capi.cpp", ["-x", "hip"]), ("wga_pack.cpp", [])):
         obj = os.path.join(CSRC, src.replace(".cpp", ".o"))
         out = _run([hipcc] + flags + xflag + ["-c", os.path.join(CSRC, src), "-o", obj])

@@ -470,9 +470,13 @@ struct WinRaw {
 
 __device__ __forceinline__ void win_issue(const RowSrc& src, u64 sbase, int off, int pa, int pb,
                                           WinRaw& r) {
+#ifdef WGA_PROFILE
   if (src.ablate & 2) {
     r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0x41414141u;
-  } else if (src.safe) {
+    return;
+  }
+#endif
+  if (src.safe) {
     /* pointer arithmetic only (no integer round trip): keeps this a global_load, not flat */
     const int sgn = src.rc ? -1 : 0; /* uniform */
     const u8* p = src.win_base + (i64)((off ^ sgn) - sgn);
@@ -617,6 +621,15 @@ __device__ __forceinline__ void emit_walk(u32 o[4], u32 c, u32 c_end, u32 cz, in
   }
 }
 
+/* dwords k, k+1 of a value spread over the lanes of a wave (wave-uniform result) */
+__device__ __forceinline__ u64 wave_get_u64(u32 v, int k) {
+#ifdef WGA_EMU
+  return (u64)__shfl(v, k) | ((u64)__shfl(v, k + 1) << 32);
+#else
+  return (u64)(u32)__builtin_amdgcn_readlane((int)v, k) | ((u64)(u32)__builtin_amdgcn_readlane((int)v, k + 1) << 32);
+#endif
+}
+
 /* tell the compiler a value is wave-uniform so that it lives in SGPRs (scalar loads, no VGPRs) */
 #ifdef WGA_EMU
 #define WGA_UNI32(x) ((u32)(x))
@@ -646,6 +659,58 @@ __device__ __forceinline__ void emit_walk(u32 o[4], u32 c, u32 c_end, u32 cz, in
 #define WGA_TBL_COLS 32768u                       /* widest tile the granule table covers */
 #define WGA_TBL_N (WGA_TBL_COLS >> WGA_TBL_SHIFT) /* 2048 granules (+2 sentinels) */
 #define WGA_QCAP 192u                             /* per-wave queue of complex chunks */
+
+/* Granule table: one 16-bit field per row (target row = low half, query row = high half of a
+ * word; `tsh` selects).  After the exclusive scan entry j holds, for the events of that row,
+ *   bits 0-10  how many start in granules < j (tile-wide entry index of the first one at / after j)
+ *   bit  11    COVER: granule j-1 begins inside a gap that started in an earlier granule
+ *   bit  12    FULL:  ... and that gap runs through the end of granule j-1
+ * (COVER / FULL of granule j are read from entry j+1.)  They come from +1 / -1 marks at the
+ * first covered granule and after the last one; a field's prefix sums are never negative, so the
+ * borrows that packed two's-complement adds take from the neighbouring fields cancel out. */
+#define WGA_TBL_CNT 0x7FFu
+#define WGA_TBL_COVER 0x800u
+#define WGA_TBL_FULL 0x1000u
+__device__ __forceinline__ void tbl_mark_event(u32* tbl, u32 gs, u32 gl, u32 gsh, u32 tsh) {
+  const u32 js1 = (gs >> gsh) + 1u;
+  atomicAdd(&tbl[js1 - 1u], 1u << tsh);
+  const u32 ge = gs + gl;
+  const u32 jc = (ge + (1u << gsh) - 1u) >> gsh, jf = ge >> gsh; /* jf <= jc */
+  if (jc > js1) {
+    const bool any_full = jf > js1;
+    atomicAdd(&tbl[js1], (any_full ? (WGA_TBL_COVER | WGA_TBL_FULL) : WGA_TBL_COVER) << tsh);
+    if (any_full && jf != jc) atomicAdd(&tbl[jf], (0u - WGA_TBL_FULL) << tsh);
+    atomicAdd(&tbl[jc], (0u - ((any_full && jf == jc) ? (WGA_TBL_COVER | WGA_TBL_FULL) : WGA_TBL_COVER)) << tsh);
+  }
+}
+/* exclusive scan of the raw per-granule marks, in place; entries [WGA_TBL_N], [WGA_TBL_N+1] = total */
+__device__ __forceinline__ void tbl_scan(u32* tbl, u32* s_w4) {
+  const u32 tid = threadIdx.x;
+  u32 v[WGA_TBL_N / WGA_BLOCK], sum = 0;
+#pragma unroll
+  for (u32 e = 0; e < WGA_TBL_N / WGA_BLOCK; e++) {
+    v[e] = tbl[tid * (WGA_TBL_N / WGA_BLOCK) + e];
+    sum += v[e];
+  }
+  const u32 lane = tid & 63u, wave = tid >> 6;
+  const u32 inc = wave_incl_scan_u32(sum);
+  __syncthreads();
+  if (lane == 63u) s_w4[wave] = inc;
+  __syncthreads();
+  u32 run = inc - sum, tot = 0;
+#pragma unroll
+  for (u32 w = 0; w < 4; w++) {
+    const u32 x = s_w4[w];
+    run += w < wave ? x : 0u;
+    tot += x;
+  }
+#pragma unroll
+  for (u32 e = 0; e < WGA_TBL_N / WGA_BLOCK; e++) {
+    tbl[tid * (WGA_TBL_N / WGA_BLOCK) + e] = run;
+    run += v[e];
+  }
+  if (tid == WGA_BLOCK - 1) tbl[WGA_TBL_N] = tbl[WGA_TBL_N + 1] = tot;
+}
 
 /* Chunks are the 16-column granules of the tile-relative column space (so the granule table
  * classifies them exactly); their output address is whatever it is — stores are byte-aligned
@@ -683,10 +748,12 @@ __device__ __forceinline__ ChunkGeom chunk_geom(const RowGeom& r, u32 rel) {
   return g;
 }
 __device__ __forceinline__ void chunk_store(const ChunkGeom& g, const u32 o[4], int ablate = 0) {
+#ifdef WGA_PROFILE
   if (ablate & 4) {
     if (o[0] == 0x12345678u && o[1] == 0x9ABCDEF0u && o[3] == 7u) *(u32*)g.p = o[2];
     return;
   }
+#endif
   if (g.a0 == 0u && g.b0 == 16u) {
     u32x4_a1 v = {o[0], o[1], o[2], o[3]};
     *(u32x4_a1*)g.p = v;
@@ -705,96 +772,82 @@ __device__ __forceinline__ void chunk_store(const ChunkGeom& g, const u32 o[4], 
 __device__ __forceinline__ int find_entry(const RowDesc& rd, u32 c) {
   const int ga = rd.ga, gb = rd.gb;
   const u32 j = c >> rd.gsh;
-  int k = (int)((rd.tbl[j] >> rd.tsh) & 0xFFFFu);
-  const int hi = (int)((rd.tbl[j + 1] >> rd.tsh) & 0xFFFFu);
+  int k = (int)((rd.tbl[j] >> rd.tsh) & WGA_TBL_CNT);
+  const int hi = (int)((rd.tbl[j + 1] >> rd.tsh) & WGA_TBL_CNT);
   while (k < hi && rd.G_col[k] <= c) k++;
   k -= 1;
   return k < ga ? ga - 1 : (k >= gb ? gb - 1 : k);
 }
 
-/* A chunk that touches an event boundary: copy0 | gap1 | copy1 (possibly starting inside gap0)
- * with at most two source windows.  Split so that its loads can be in flight together with
- * the fast path's: complex_issue looks the events up and issues the windows, complex_finish
- * assembles and stores; more than two events inside 16 columns continue in emit_walk. */
-struct ComplexState {
-  ChunkGeom g;
-  WinRaw r0, r1;
-  u32 a1, b1, e1, b2, gs1, adj1;
-  int off0, off1, n1;
-  bool in_gap0, need0, need1, hasB;
-};
+/* A chunk that touches an event boundary, straight-line for rows whose windows need no bounds
+ * checks:  [gap0 rest] copy0 | gap1 | copy1  with two source windows, assembled with byte masks
+ * from the low-mask table; a third event inside the 16 columns continues in emit_walk.  Every
+ * lane of a drain runs the same instructions whatever its chunk looks like (pieces may be
+ * empty): the drains mix all shapes, so branches would only add their overhead. */
+__device__ __forceinline__ u32 bfi32(u32 mask, u32 a, u32 b) { return (a & mask) | (b & ~mask); }
 
-__device__ __forceinline__ void complex_issue(ComplexState& st, const ChunkGeom& g, int i,
-                                              const RowDesc& rd, const RowSrc& src) {
+__device__ __forceinline__ void complex_chunk(const ChunkGeom& g, const RowDesc& rd,
+                                              const RowSrc& src, u64* bad_base_pos) {
   const int ga = rd.ga, gb = rd.gb;
   const u32 c = g.c, c_end = g.c_end, cz = g.cz;
-  st.g = g;
-  bool in_gap0 = false;
-  u32 gap0_end = 0, adj0 = rd.gcum_a;
-  if (i >= ga) {
-    const u32 gs0 = rd.G_col[i];
-    const u32 gl0 = rd.G_cum[i + 1] - rd.G_cum[i];
-    if (c - gs0 < gl0) {
-      in_gap0 = true;
-      gap0_end = gs0 + gl0;
-    }
-    adj0 = rd.G_adj[i + 1];
-  }
+  const int i = find_entry(rd, c);
+  const bool has0 = i >= ga;
+  const int ic = has0 ? i : ga; /* always a readable index */
+  const u32 gs0 = rd.G_col[ic], cum0a = rd.G_cum[ic], cum0b = rd.G_cum[ic + 1];
+  const u32 adj0b = rd.G_adj[ic + 1];
+  const u32 gl0 = cum0b - cum0a;
+  const bool in_gap0 = has0 && (c - gs0 < gl0);
+  const u32 adj0 = has0 ? adj0b : rd.gcum_a;
   const int n1 = i + 1;
   const u32 gs1 = n1 < gb ? rd.G_col[n1] : 0xFFFFFFFFu;
-  const int offz = (int)(cz - rd.c_org);
-  u32 gl1 = 0u, adj1 = adj0, gs2 = 0xFFFFFFFFu;
+  const u32 gl1 = rd.G_cum[n1 + 1] - rd.G_cum[n1]; /* two sentinels: readable up to gb + 1 */
+  const u32 adj1 = rd.G_adj[n1 + 1];
+  const u32 gs2 = n1 + 1 < gb ? rd.G_col[n1 + 1] : 0xFFFFFFFFu;
   const bool hasB = gs1 < c_end;
-  if (hasB) {
-    gl1 = rd.G_cum[n1 + 1] - rd.G_cum[n1];
-    adj1 = rd.G_adj[n1 + 1];
-    if (n1 + 1 < gb) gs2 = rd.G_col[n1 + 1];
-  }
-  st.in_gap0 = in_gap0;
-  st.hasB = hasB;
-  st.n1 = n1;
-  st.gs1 = gs1;
-  st.adj1 = adj1;
-  st.a1 = in_gap0 ? (gap0_end < c_end ? gap0_end : c_end) : c; /* copy piece 0 */
-  st.b1 = hasB ? gs1 : c_end;
-  st.e1 = hasB ? (gs1 + gl1 < c_end ? gs1 + gl1 : c_end) : c_end; /* end of gap 1 */
-  st.b2 = gs2 < c_end ? gs2 : c_end;                              /* copy piece 1 */
-  st.need0 = st.b1 > st.a1;
-  st.need1 = hasB && st.b2 > st.e1;
-  st.off0 = offz - (int)(adj0 - rd.gcum_a);
-  st.off1 = offz - (int)(adj1 - rd.gcum_a);
-  if (st.need0) win_issue(src, rd.sbase, st.off0, (int)(st.a1 - cz), (int)(st.b1 - cz), st.r0);
-  if (st.need1) win_issue(src, rd.sbase, st.off1, (int)(st.e1 - cz), (int)(st.b2 - cz), st.r1);
-}
-
-__device__ __forceinline__ void complex_finish(const ComplexState& st, const RowDesc& rd,
-                                               const RowSrc& src, u64* bad_base_pos) {
-  const u32 cz = st.g.cz, c = st.g.c, c_end = st.g.c_end;
-  u32 o[4] = {0u, 0u, 0u, 0u};
-  if (st.in_gap0) merge_dash(o, (int)(c - cz), (int)(st.a1 - cz), rd.lowmask);
-  if (st.need0) {
-    u32 W[4], inv[4];
-    win_finish(src, st.r0, W, inv);
-    if (src.rc)
-      flag_bad_bases(inv, (int)(st.a1 - cz), (int)(st.b1 - cz), (i64)rd.sbase + st.off0, rd.lowmask, bad_base_pos);
-    merge16(o, W, (int)(st.a1 - cz), (int)(st.b1 - cz), rd.lowmask);
-  }
-  if (st.hasB) {
-    merge_dash(o, (int)(st.gs1 - cz), (int)(st.e1 - cz), rd.lowmask);
-    if (st.need1) {
-      u32 W[4], inv[4];
-      win_finish(src, st.r1, W, inv);
-      if (src.rc)
-        flag_bad_bases(inv, (int)(st.e1 - cz), (int)(st.b2 - cz), (i64)rd.sbase + st.off1, rd.lowmask, bad_base_pos);
-      merge16(o, W, (int)(st.e1 - cz), (int)(st.b2 - cz), rd.lowmask);
+  const u32 g0e = gs0 + gl0;
+  const u32 a1 = in_gap0 ? (g0e < c_end ? g0e : c_end) : c;       /* copy piece 0 = [a1, b1) */
+  const u32 b1 = hasB ? gs1 : c_end;
+  const u32 g1e = gs1 + gl1;
+  const u32 e1 = hasB ? (g1e < c_end ? g1e : c_end) : c_end;      /* gap 1 = [b1, e1)        */
+  const u32 b2 = hasB ? (gs2 < c_end ? gs2 : c_end) : c_end;      /* copy piece 1 = [e1, b2) */
+  const int offz = (int)(cz - rd.c_org);
+  const int off0 = offz - (int)(adj0 - rd.gcum_a), off1 = offz - (int)(adj1 - rd.gcum_a);
+  u32 o[4];
+  if (src.safe) {
+    WinRaw r0, r1;
+    r0.v[0] = r0.v[1] = r0.v[2] = r0.v[3] = 0u;
+    r1 = r0;
+    if (b1 > a1) win_issue(src, rd.sbase, off0, 0, 16, r0);
+    if (b2 > e1) win_issue(src, rd.sbase, off1, 0, 16, r1);
+    const u32x4_a16 La1 = rd.lowmask[a1 - cz], Lb1 = rd.lowmask[b1 - cz], Le1 = rd.lowmask[e1 - cz],
+                    Lb2 = rd.lowmask[b2 - cz];
+    u32 W0[4], W1[4], inv0[4], inv1[4];
+    win_finish(src, r0, W0, inv0);
+    win_finish(src, r1, W1, inv1);
+    u32 bad = 0u;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const u32 m0 = Lb1[d] & ~La1[d], m1 = Lb2[d] & ~Le1[d];
+      const u32 md = bfi32(Lb1[d], La1[d], Le1[d]); /* [0, a1) + [b1, e1): bytes below c are never stored */
+      o[d] = bfi32(m0, W0[d], bfi32(m1, W1[d], md & 0x2D2D2D2Du));
+      bad |= (inv0[d] & m0) | (inv1[d] & m1);
     }
-    if (st.b2 < c_end) /* a third event inside 16 columns: rare, generic walk from there */
-      emit_walk(o, st.b2, c_end, cz, st.n1, false, 0u, st.adj1, rd, src, bad_base_pos);
+    if (bad) { /* rare: report the first invalid base (utils.rs:97) */
+      flag_bad_bases(inv0, (int)(a1 - cz), (int)(b1 - cz), (i64)rd.sbase + off0, rd.lowmask, bad_base_pos);
+      flag_bad_bases(inv1, (int)(e1 - cz), (int)(b2 - cz), (i64)rd.sbase + off1, rd.lowmask, bad_base_pos);
+    }
+    if (b2 < c_end) /* a third event inside 16 columns: rare, generic walk from there */
+      emit_walk(o, b2, c_end, cz, n1, false, 0u, adj1, rd, src, bad_base_pos);
+  } else { /* a row at a pool edge: guarded byte loads, generic walk */
+    o[0] = o[1] = o[2] = o[3] = 0u;
+    emit_walk(o, c, c_end, cz, i, in_gap0, g0e, adj0, rd, src, bad_base_pos);
   }
-  chunk_store(st.g, o, src.ablate);
+  chunk_store(g, o, src.ablate);
 }
 
+#ifndef WGA_EMIT_U
 #define WGA_EMIT_U 2 /* chunks in flight per lane */
+#endif
 
 __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& rd,
                                          const RowSrc& src, u32 tid, u32 nthreads,
@@ -802,24 +855,30 @@ __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& 
   if (N == 0) return;
   const u32 lane = tid & 63u;
   const RowGeom rg = row_geom(dst, N, c0);
-  const int ga = rd.ga;
   u32* const queue = rd.queue + (tid >> 6) * WGA_QCAP;
   u32 qn = 0; /* wave-uniform queue length */
   const u32 per_it = nthreads * WGA_EMIT_U;
   const u32 niter = (rg.nchunks + per_it - 1) / per_it;
-  const bool head_full = rg.head == 0u, tail_full = rg.last_b0 == 16u;
+  /* chunks [lo_full, lo_full + n_full) are whole 16-column granules */
+  const u32 lo_full = rg.head == 0u ? 0u : 1u;
+  const u32 n_full = rg.nchunks - lo_full - (rg.last_b0 == 16u ? 0u : 1u); /* may wrap to "none" */
+  const bool any_full = rg.nchunks >= lo_full + (rg.last_b0 == 16u ? 0u : 1u) + 1u;
+  const int koff = (int)(rd.gcum_a - rd.c_org); /* window offset of a chunk = cz + koff - adj */
+#ifdef WGA_PROFILE
   const bool row_fast = src.safe && !(src.ablate & 32);
+#else
+  const bool row_fast = src.safe;
+#endif
+  const bool fast_ok = row_fast && any_full;
 #pragma nounroll
   for (u32 it = 0; it < niter; it++) {
-    /* Fast path: a full 16-column granule that no event touches (or that lies wholly inside
-     * one gap), from a row whose windows need no bounds checks, with only valid bases.  It is
-     * written branch-free — unconditional, index-clamped LDS reads and selects, one predicated
-     * load and one predicated store per chunk — and WGA_EMIT_U chunks per lane go through it
-     * together (all lookups, then all loads, then all stores).  Everything else is deferred to
-     * the queue; complex_issue/finish handle every case. */
+    /* Fast path: a whole granule that no event of this row touches — plain copy — or that lies
+     * inside one gap — dashes — read off the granule table (two words) plus one adjustment.
+     * WGA_EMIT_U chunks per lane go through it together (lookups, then loads, then stores);
+     * everything else is deferred to the queue. */
     u32 rel[WGA_EMIT_U];
     int off0[WGA_EMIT_U];
-    bool act[WGA_EMIT_U], cand[WGA_EMIT_U], wgap[WGA_EMIT_U];
+    bool act[WGA_EMIT_U], cand[WGA_EMIT_U], dash[WGA_EMIT_U];
     WinRaw raw[WGA_EMIT_U];
 #pragma unroll
     for (int u = 0; u < WGA_EMIT_U; u++) {
@@ -828,46 +887,49 @@ __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& 
       const u32 relc = act[u] ? rel[u] : 0u;
       const u32 cz = (rg.j0 + relc) << 4;
       const u32 jg = cz >> rd.gsh;
-      const u32 t0 = (rd.tbl[jg] >> rd.tsh) & 0xFFFFu, t1 = (rd.tbl[jg + 1] >> rd.tsh) & 0xFFFFu;
-      int i = (int)t0 - 1;
-      i = i < ga ? ga - 1 : i;
-      const bool has = i >= ga;
-      const int ic = has ? i : ga; /* always a readable index */
-      const u32 gs0 = rd.G_col[ic], cum0 = rd.G_cum[ic], cum1 = rd.G_cum[ic + 1];
-      const u32 adj1 = rd.G_adj[ic + 1];
-      const u32 gl0 = cum1 - cum0;
-      const u32 c = cz + (relc == 0u ? rg.head : 0u);
-      const bool in_gap0 = has && (c - gs0 < gl0);
-      wgap[u] = in_gap0 && (gs0 + gl0 >= cz + 16u);
-      const u32 adj0 = has ? adj1 : rd.gcum_a;
-      const bool full = (relc != 0u || head_full) && (relc != rg.nchunks - 1u || tail_full);
-      cand[u] = act[u] && full && t0 == t1 && (wgap[u] || !in_gap0) && row_fast;
-      off0[u] = (int)(cz - rd.c_org) - (int)(adj0 - rd.gcum_a);
+      const u32 w0 = rd.tbl[jg] >> rd.tsh, w1 = rd.tbl[jg + 1] >> rd.tsh;
+      const u32 adj = rd.G_adj[w0 & WGA_TBL_CNT];
+      const u32 st = w1 & (WGA_TBL_COVER | WGA_TBL_FULL);
+      dash[u] = st == (WGA_TBL_COVER | WGA_TBL_FULL);
+      cand[u] = fast_ok && (rel[u] - lo_full < n_full) && ((w0 ^ w1) & WGA_TBL_CNT) == 0u && st != WGA_TBL_COVER;
+      off0[u] = (int)cz + koff - (int)adj;
     }
 #pragma unroll
     for (int u = 0; u < WGA_EMIT_U; u++)
-      if (cand[u]) win_issue(src, rd.sbase, off0[u], 0, 16, raw[u]);
+      if (cand[u] && !dash[u]) win_issue(src, rd.sbase, off0[u], 0, 16, raw[u]);
 #pragma unroll
     for (int u = 0; u < WGA_EMIT_U; u++) {
       bool cx = act[u] && !cand[u];
       if (cand[u]) {
-        u32 o[4], inv[4];
-        win_finish(src, raw[u], o, inv);
-        if (wgap[u]) {
-          o[0] = o[1] = o[2] = o[3] = 0x2D2D2D2Du;
-          inv[0] = inv[1] = inv[2] = inv[3] = 0u;
-        }
-        if ((inv[0] | inv[1] | inv[2] | inv[3]) == 0u) {
-          if (!(src.ablate & 4)) {
-            u32x4_a1 v = {o[0], o[1], o[2], o[3]};
-            *(u32x4_a1*)(rg.base + (rel[u] << 4)) = v;
+        u8* const p = rg.base + (rel[u] << 4);
+        if (dash[u]) {
+#ifdef WGA_PROFILE
+          if (!(src.ablate & 4))
+#endif
+          {
+            u32x4_a1 v = {0x2D2D2D2Du, 0x2D2D2D2Du, 0x2D2D2D2Du, 0x2D2D2D2Du};
+            *(u32x4_a1*)p = v;
           }
         } else {
-          cx = true; /* an invalid base: the complex path finds and reports it */
+          u32 o[4], inv[4];
+          win_finish(src, raw[u], o, inv);
+          if ((inv[0] | inv[1] | inv[2] | inv[3]) == 0u) {
+#ifdef WGA_PROFILE
+            if (!(src.ablate & 4))
+#endif
+            {
+              u32x4_a1 v = {o[0], o[1], o[2], o[3]};
+              *(u32x4_a1*)p = v;
+            }
+          } else {
+            cx = true; /* an invalid base: the complex path finds and reports it */
+          }
         }
       }
-      /* compact the complex chunks into the wave queue */
+#ifdef WGA_PROFILE
       if (src.ablate & 16) cx = false;
+#endif
+      /* compact the complex chunks into the wave queue */
       const u64 m = __ballot(cx);
       if (m) {
         if (cx) queue[qn + (u32)__popcll(m & ((1ull << lane) - 1ull))] = rel[u];
@@ -880,12 +942,7 @@ __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& 
     while (qn >= 64u || (last && qn > 0u)) {
       const u32 take = qn < 64u ? qn : 64u;
       qn -= take;
-      if (lane < take) {
-        const ChunkGeom g = chunk_geom(rg, queue[qn + lane]);
-        ComplexState cst;
-        complex_issue(cst, g, find_entry(rd, g.c), rd, src);
-        complex_finish(cst, rd, src, bad_base_pos);
-      }
+      if (lane < take) complex_chunk(chunk_geom(rg, queue[qn + lane]), rd, src, bad_base_pos);
       WGA_WAVE_SYNC(); /* the drained slots are rewritten by the next pushes */
     }
   }
@@ -909,7 +966,8 @@ __device__ __forceinline__ void emit_tail(u8* dst, u64 n, u64 sbase, RowSrc src,
     if (m > (1ull << 30)) m = 1ull << 30;
     RowDesc rd;
     rd.c_org = 0u;
-    rd.G_col = rd.G_cum = rd.G_adj = dummy;
+    rd.G_col = rd.G_cum = dummy;
+    rd.G_adj = zero2; /* the fast path reads G_adj[0] */
     rd.ga = rd.gb = 0;
     rd.gcum_a = 0u;
     rd.sbase = sbase + done;
@@ -1066,8 +1124,19 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
   u32 gsh = a.no_table ? 8u : WGA_TBL_SHIFT;
   while ((tile_cols >> gsh) >= WGA_TBL_N) gsh++;
   const bool use_tbl = fast;
+  /* the first segment's descriptors: their (scalar) loads are issued here so that they land
+   * while phase A runs instead of costing two more serial round trips after it */
+  const u32 r0 = WGA_UNI32((u32)tsum.rec);
+  u32 pre = 0u; /* lane k of every wave holds dword k of {recs[r0] (20), bases[g] (6), op_off[r0..r0+1] (4)}:
+                   one VGPR instead of 30 SGPRs kept alive across phase A */
+  {
+    const u32* p = (const u32*)(a.recs + r0) + lane;
+    if (lane >= 20u) p = (const u32*)(a.bases + g) + (lane - 20u);
+    if (lane >= 26u) p = (const u32*)(a.op_off + r0) + (lane - 26u);
+    if (lane < 30u) pre = *p;
+  }
   if (use_tbl)
-    for (u32 k = tid; k < WGA_TBL_N; k += WGA_BLOCK) s_tbl[k] = 0u;
+    for (u32 k = tid; k < WGA_TBL_N + 2u; k += WGA_BLOCK) s_tbl[k] = 0u;
   if (tid < 2u) s_zero2[tid] = 0u;
 
   /* ---- phase A: 4 consecutive ops per thread, block scan into LDS -------------------------- */
@@ -1109,13 +1178,13 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
       if (cls[e] == CLS_I) {
         s_tg_col[x_cnt & 0xFFFFu] = x_col;
         s_tg_cum[x_cnt & 0xFFFFu] = x_i;
-        if (use_tbl) atomicAdd(&s_tbl[x_col >> gsh], 1u);
+        if (use_tbl) tbl_mark_event(s_tbl, x_col, opw[e] >> 4, gsh, 0u);
         x_i += opw[e] >> 4;
         x_cnt += 1u;
       } else if (cls[e] == CLS_D) {
         s_qg_col[x_cnt >> 16] = x_col;
         s_qg_cum[x_cnt >> 16] = x_d;
-        if (use_tbl) atomicAdd(&s_tbl[x_col >> gsh], 0x10000u);
+        if (use_tbl) tbl_mark_event(s_tbl, x_col, opw[e] >> 4, gsh, 16u);
         x_d += opw[e] >> 4;
         x_cnt += 0x10000u;
       }
@@ -1133,22 +1202,9 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
       s_qg_col[(x_cnt >> 16) + 1u] = x_col;
       s_qg_cum[(x_cnt >> 16) + 1u] = x_d;
     }
-    if (use_tbl) { /* per-granule counts -> exclusive prefix (tile-wide entry index) */
+    if (use_tbl) { /* raw marks -> exclusive prefix */
       __syncthreads();
-      u32 v[WGA_TBL_N / WGA_BLOCK], sum = 0;
-      for (u32 e = 0; e < WGA_TBL_N / WGA_BLOCK; e++) {
-        v[e] = s_tbl[tid * (WGA_TBL_N / WGA_BLOCK) + e];
-        sum += v[e];
-      }
-      const u32 tv[4] = {sum, 0u, 0u, 0u}; /* both 16-bit halves <= 1024 */
-      u32 tx[4], ttot[4];
-      block_excl_scan4_u32(tv, tx, ttot, s_w4);
-      u32 run = tx[0];
-      for (u32 e = 0; e < WGA_TBL_N / WGA_BLOCK; e++) {
-        s_tbl[tid * (WGA_TBL_N / WGA_BLOCK) + e] = run;
-        run += v[e];
-      }
-      if (tid == WGA_BLOCK - 1) s_tbl[WGA_TBL_N] = s_tbl[WGA_TBL_N + 1] = run;
+      tbl_scan(s_tbl, s_w4);
     }
   }
   __syncthreads();
@@ -1156,32 +1212,46 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
   if (a.dbg) stamp[1] = WGA_CLOCK();
   if (a.ablate & 1) return;
   /* ---- phase B: walk the record segments of this tile ------------------------------------- */
-  u32 r = WGA_UNI32((u32)tsum.rec);
+  u32 r = r0;
   u64 cur = tile_start;
+  u64 re = wave_get_u64(pre, 28);
   while (cur < tile_end) {
-    u64 re = a.op_off[r + 1];
     while (re <= cur) {
       r++;
       re = a.op_off[r + 1];
     }
-    const u64 rs = a.op_off[r];
+    const bool is0 = r == r0;
+    const u64 rs = is0 ? wave_get_u64(pre, 26) : a.op_off[r];
     const u64 seg_end = re < tile_end ? re : tile_end;
     const u32 ka = (u32)(cur - tile_start), kb = (u32)(seg_end - tile_start);
 
     /* class sums of this record before the tile (only the tile's first segment can continue a
      * record; k_tile_base worked them out) and the record's geometry (k_rec_desc) */
     u64 b_mx = 0, b_i = 0, b_d = 0;
-    if (rs < tile_start) {
-      const wga_tile_base tbs = a.bases[g];
-      b_mx = tbs.mx;
-      b_i = tbs.i;
-      b_d = tbs.d;
+    if (rs < tile_start) { /* only the tile's first record can continue from earlier tiles */
+      b_mx = wave_get_u64(pre, 20);
+      b_i = wave_get_u64(pre, 22);
+      b_d = wave_get_u64(pre, 24);
     }
     const u64 cb = b_mx + b_i + b_d; /* record-relative column of the segment start */
     const u64 tb = b_mx + b_d;       /* target bases consumed before it              */
     const u64 qb = b_mx + b_i;       /* query bases consumed before it               */
 
-    const wga_rec_desc rdsc = a.recs[r];
+    wga_rec_desc rdsc;
+    if (is0) {
+      rdsc.t_row_off = wave_get_u64(pre, 0);
+      rdsc.q_row_off = wave_get_u64(pre, 2);
+      rdsc.t_src_off = wave_get_u64(pre, 4);
+      rdsc.t_src_len = wave_get_u64(pre, 6);
+      rdsc.q_src_off = wave_get_u64(pre, 8);
+      rdsc.q_src_len = wave_get_u64(pre, 10);
+      rdsc.I_total = wave_get_u64(pre, 12);
+      rdsc.D_total = wave_get_u64(pre, 14);
+      rdsc.L = wave_get_u64(pre, 16);
+      rdsc.neg = wave_get_u64(pre, 18);
+    } else {
+      rdsc = a.recs[r];
+    }
     const u64 I_total = rdsc.I_total, D_total = rdsc.D_total, L = rdsc.L;
     RowSrc ts, qs;
     ts.fa = a.t_fa;
@@ -1307,6 +1377,7 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
     }
     cur = seg_end;
     r++;
+    if (cur < tile_end) re = a.op_off[r + 1];
     stamp[6] += 1;
   }
   if (a.dbg && tid == 0) {

@@ -378,6 +378,7 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
   __shared__ u32 s_tbl[WGA_TBL_N + 2];  /* events that start before each column granule          */
   __shared__ u32 s_zero2[2];
   __shared__ u64 s_w[5];
+  __shared__ u32 s_w4[4];
   __shared__ u64 s_red[4][4];
   __shared__ u32x4_a16 s_lowmask[17];
   __shared__ u32 s_queue[4 * WGA_QCAP];
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
   u32 gsh = WGA_TBL_SHIFT;
   while (((tsum.tot[CLS_MX] + tsum.tot[CLS_D]) >> gsh) >= WGA_TBL_N) gsh++;
   if (fast)
-    for (u32 k = tid; k < WGA_TBL_N; k += WGA_BLOCK) s_tbl[k] = 0u;
+    for (u32 k = tid; k < WGA_TBL_N + 2u; k += WGA_BLOCK) s_tbl[k] = 0u;
   if (tid < 2u) s_zero2[tid] = 0u;
 
   u32 opw[4];
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
         s_g_col[x_cnt] = x_col;
         s_g_cum[x_cnt] = x_d;
         s_g_adj[x_cnt] = x_d - x_is;
-        atomicAdd(&s_tbl[x_col >> gsh], 1u);
+        tbl_mark_event(s_tbl, x_col, cls[e] == CLS_D ? (opw[e] >> 4) : 0u, gsh, 0u);
         if (cls[e] == CLS_D)
           x_d += opw[e] >> 4;
         else
@@ -455,21 +456,8 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
       s_g_cum[x_cnt] = s_g_cum[x_cnt + 1u] = x_d;
       s_g_adj[x_cnt] = s_g_adj[x_cnt + 1u] = x_d - x_is;
     }
-    { /* per-granule counts -> exclusive prefix */
-      __syncthreads();
-      u32 v[WGA_TBL_N / WGA_BLOCK], sum = 0;
-      for (u32 e = 0; e < WGA_TBL_N / WGA_BLOCK; e++) {
-        v[e] = s_tbl[tid * (WGA_TBL_N / WGA_BLOCK) + e];
-        sum += v[e];
-      }
-      u64 tot;
-      u32 run = (u32)block_excl_scan_u64((u64)sum, s_w, &tot);
-      for (u32 e = 0; e < WGA_TBL_N / WGA_BLOCK; e++) {
-        s_tbl[tid * (WGA_TBL_N / WGA_BLOCK) + e] = run;
-        run += v[e];
-      }
-      if (tid == WGA_BLOCK - 1) s_tbl[WGA_TBL_N] = s_tbl[WGA_TBL_N + 1] = run;
-    }
+    __syncthreads(); /* raw marks -> exclusive prefix */
+    tbl_scan(s_tbl, s_w4);
   }
   __syncthreads();
 
