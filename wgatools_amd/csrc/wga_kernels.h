@@ -427,6 +427,52 @@ __device__ __forceinline__ u32 byte_perm(u32 hi, u32 lo, u32 sel) {
 #endif
 }
 
+/* Raw buffer access (128-bit descriptor in SGPRs, 32-bit per-lane byte offset).  An offset at or
+ * beyond `bytes` is out of range: the load returns zeros and the store is dropped — per-lane
+ * predication without exec-mask branches, which keeps the chunk loop one basic block (the
+ * compiler then places its s_waitcnt exactly; with branches around the memory ops it falls back
+ * to vmcnt(0) between them and serialises the loads).  Byte-unaligned offsets are fine. */
+#define WGA_BUF_OOB 0xFFFFFFFFu
+#ifdef WGA_EMU
+struct BufRsrc {
+  u8* base;
+  u32 bytes;
+};
+__device__ __forceinline__ BufRsrc buf_make(const void* base, u32 bytes) {
+  BufRsrc r;
+  r.base = (u8*)base;
+  r.bytes = bytes;
+  return r;
+}
+__device__ __forceinline__ void buf_load16(const BufRsrc& r, u32 off, u32 v[4]) {
+  for (int d = 0; d < 4; d++) {
+    v[d] = 0u;
+    if ((u64)off + 4u * d + 4u <= (u64)r.bytes) memcpy(&v[d], r.base + off + 4 * d, 4);
+  }
+}
+__device__ __forceinline__ void buf_store16(const BufRsrc& r, u32 off, const u32 v[4]) {
+  for (int d = 0; d < 4; d++)
+    if ((u64)off + 4u * d + 4u <= (u64)r.bytes) memcpy(r.base + off + 4 * d, &v[d], 4);
+}
+#else
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+typedef u32 u32x4_v __attribute__((vector_size(16)));
+__device__ __forceinline__ BufRsrc buf_make(const void* base, u32 bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_load16(const BufRsrc& r, u32 off, u32 v[4]) {
+  const u32x4_v x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  v[0] = x[0];
+  v[1] = x[1];
+  v[2] = x[2];
+  v[3] = x[3];
+}
+__device__ __forceinline__ void buf_store16(const BufRsrc& r, u32 off, const u32 v[4]) {
+  const u32x4_v x = {v[0], v[1], v[2], v[3]};
+  __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)off, 0, 0);
+}
+#endif
+
 /* Complement 4 packed bases (utils.rs:86-96) with two 8-entry byte LUTs indexed by the low
  * THREE bits of each base — A=1 C=3 T=4 N=6 G=7 are distinct.  `fold` is the upper-case base a
  * valid byte must equal once its case bit is cleared (0xFF for the unused indices, which no
@@ -870,16 +916,21 @@ __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& 
   const bool row_fast = src.safe;
 #endif
   const bool fast_ok = row_fast && any_full;
+  /* buffers of the fast path: the source windows of this row relative to its first window (for
+   * rc the windows walk down from it: offsets are biased by 2^31), and the row's output granules */
+  const u32 sgn = src.rc ? 0xFFFFFFFFu : 0u, kbias = src.rc ? 0x80000000u : 0u;
+  const BufRsrc lbuf = buf_make(src.rc ? src.win_base - 0x80000000ll : src.win_base, 0xFFFFFFF0u);
+  const BufRsrc sbuf = buf_make(rg.base, rg.nchunks << 4);
 #pragma nounroll
   for (u32 it = 0; it < niter; it++) {
     /* Fast path: a whole granule that no event of this row touches — plain copy — or that lies
      * inside one gap — dashes — read off the granule table (two words) plus one adjustment.
-     * WGA_EMIT_U chunks per lane go through it together (lookups, then loads, then stores);
-     * everything else is deferred to the queue. */
-    u32 rel[WGA_EMIT_U];
-    int off0[WGA_EMIT_U];
+     * WGA_EMIT_U chunks per lane go through it together (lookups, then loads, then stores), all
+     * of it branch-free: lanes without a candidate use an out-of-range buffer offset.
+     * Everything else is deferred to the queue. */
+    u32 rel[WGA_EMIT_U], loff[WGA_EMIT_U];
     bool act[WGA_EMIT_U], cand[WGA_EMIT_U], dash[WGA_EMIT_U];
-    WinRaw raw[WGA_EMIT_U];
+    u32 raw[WGA_EMIT_U][4];
 #pragma unroll
     for (int u = 0; u < WGA_EMIT_U; u++) {
       rel[u] = (it * WGA_EMIT_U + (u32)u) * nthreads + tid;
@@ -892,47 +943,40 @@ __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& 
       const u32 st = w1 & (WGA_TBL_COVER | WGA_TBL_FULL);
       dash[u] = st == (WGA_TBL_COVER | WGA_TBL_FULL);
       cand[u] = fast_ok && (rel[u] - lo_full < n_full) && ((w0 ^ w1) & WGA_TBL_CNT) == 0u && st != WGA_TBL_COVER;
-      off0[u] = (int)cz + koff - (int)adj;
+      const u32 off = cz + (u32)koff - adj; /* slice index of the granule relative to sbase, >= 0 */
+      loff[u] = (cand[u] && !dash[u]) ? ((off ^ sgn) - sgn) + kbias : WGA_BUF_OOB;
     }
 #pragma unroll
-    for (int u = 0; u < WGA_EMIT_U; u++)
-      if (cand[u] && !dash[u]) win_issue(src, rd.sbase, off0[u], 0, 16, raw[u]);
+    for (int u = 0; u < WGA_EMIT_U; u++) buf_load16(lbuf, loff[u], raw[u]);
+    bool cxs[WGA_EMIT_U];
 #pragma unroll
     for (int u = 0; u < WGA_EMIT_U; u++) {
-      bool cx = act[u] && !cand[u];
-      if (cand[u]) {
-        u8* const p = rg.base + (rel[u] << 4);
-        if (dash[u]) {
+      u32 o[4], inv[4];
+      WinRaw wr;
+      wr.v[0] = raw[u][0];
+      wr.v[1] = raw[u][1];
+      wr.v[2] = raw[u][2];
+      wr.v[3] = raw[u][3];
+      win_finish(src, wr, o, inv);
+      const bool bad = ((inv[0] | inv[1] | inv[2] | inv[3]) != 0u) && !dash[u];
+#pragma unroll
+      for (int d = 0; d < 4; d++) o[d] = dash[u] ? 0x2D2D2D2Du : o[d];
+      const bool st_ok = cand[u] && !bad; /* an invalid base: the complex path finds and reports it */
 #ifdef WGA_PROFILE
-          if (!(src.ablate & 4))
+      if (!(src.ablate & 4))
 #endif
-          {
-            u32x4_a1 v = {0x2D2D2D2Du, 0x2D2D2D2Du, 0x2D2D2D2Du, 0x2D2D2D2Du};
-            *(u32x4_a1*)p = v;
-          }
-        } else {
-          u32 o[4], inv[4];
-          win_finish(src, raw[u], o, inv);
-          if ((inv[0] | inv[1] | inv[2] | inv[3]) == 0u) {
+        buf_store16(sbuf, st_ok ? rel[u] << 4 : WGA_BUF_OOB, o);
+      cxs[u] = act[u] && !st_ok;
 #ifdef WGA_PROFILE
-            if (!(src.ablate & 4))
+      if (src.ablate & 16) cxs[u] = false;
 #endif
-            {
-              u32x4_a1 v = {o[0], o[1], o[2], o[3]};
-              *(u32x4_a1*)p = v;
-            }
-          } else {
-            cx = true; /* an invalid base: the complex path finds and reports it */
-          }
-        }
-      }
-#ifdef WGA_PROFILE
-      if (src.ablate & 16) cx = false;
-#endif
-      /* compact the complex chunks into the wave queue */
-      const u64 m = __ballot(cx);
+    }
+    /* compact the complex chunks into the wave queue */
+#pragma unroll
+    for (int u = 0; u < WGA_EMIT_U; u++) {
+      const u64 m = __ballot(cxs[u]);
       if (m) {
-        if (cx) queue[qn + (u32)__popcll(m & ((1ull << lane) - 1ull))] = rel[u];
+        if (cxs[u]) queue[qn + (u32)__popcll(m & ((1ull << lane) - 1ull))] = rel[u];
         qn += (u32)__popcll(m);
       }
     }
