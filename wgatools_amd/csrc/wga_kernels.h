@@ -704,7 +704,10 @@ __device__ __forceinline__ u64 wave_get_u64(u32 v, int k) {
 #define WGA_TBL_SHIFT 4u                          /* granule = 16 columns */
 #define WGA_TBL_COLS 32768u                       /* widest tile the granule table covers */
 #define WGA_TBL_N (WGA_TBL_COLS >> WGA_TBL_SHIFT) /* 2048 granules (+2 sentinels) */
-#define WGA_QCAP 192u                             /* per-wave queue of complex chunks */
+#ifndef WGA_EMIT_U
+#define WGA_EMIT_U 4 /* chunks in flight per lane */
+#endif
+#define WGA_QCAP (64u * (WGA_EMIT_U + 1u)) /* per-wave queue of complex chunks: < 64 left over + one iteration's pushes */
 
 /* Granule table: one 16-bit field per row (target row = low half, query row = high half of a
  * word; `tsh` selects).  After the exclusive scan entry j holds, for the events of that row,
@@ -832,8 +835,19 @@ __device__ __forceinline__ int find_entry(const RowDesc& rd, u32 c) {
  * empty): the drains mix all shapes, so branches would only add their overhead. */
 __device__ __forceinline__ u32 bfi32(u32 mask, u32 a, u32 b) { return (a & mask) | (b & ~mask); }
 
-__device__ __forceinline__ void complex_chunk(const ChunkGeom& g, const RowDesc& rd,
-                                              const RowSrc& src, u64* bad_base_pos) {
+/* the two buffers of a row (see emit_row): source windows, biased so that small negative and
+ * downward (rc) offsets stay positive, and the row's output granules */
+struct RowBufs {
+  BufRsrc lbuf, sbuf;
+  u32 sgn, kbias;
+};
+__device__ __forceinline__ u32 rowbuf_loff(const RowBufs& b, int off) {
+  return (((u32)off ^ b.sgn) - b.sgn) + b.kbias;
+}
+
+__device__ __forceinline__ void complex_chunk(const ChunkGeom& g, u32 rel, const RowDesc& rd,
+                                              const RowSrc& src, const RowBufs& rb,
+                                              u64* bad_base_pos) {
   const int ga = rd.ga, gb = rd.gb;
   const u32 c = g.c, c_end = g.c_end, cz = g.cz;
   const int i = find_entry(rd, c);
@@ -861,10 +875,8 @@ __device__ __forceinline__ void complex_chunk(const ChunkGeom& g, const RowDesc&
   u32 o[4];
   if (src.safe) {
     WinRaw r0, r1;
-    r0.v[0] = r0.v[1] = r0.v[2] = r0.v[3] = 0u;
-    r1 = r0;
-    if (b1 > a1) win_issue(src, rd.sbase, off0, 0, 16, r0);
-    if (b2 > e1) win_issue(src, rd.sbase, off1, 0, 16, r1);
+    buf_load16(rb.lbuf, b1 > a1 ? rowbuf_loff(rb, off0) : WGA_BUF_OOB, r0.v);
+    buf_load16(rb.lbuf, b2 > e1 ? rowbuf_loff(rb, off1) : WGA_BUF_OOB, r1.v);
     const u32x4_a16 La1 = rd.lowmask[a1 - cz], Lb1 = rd.lowmask[b1 - cz], Le1 = rd.lowmask[e1 - cz],
                     Lb2 = rd.lowmask[b2 - cz];
     u32 W0[4], W1[4], inv0[4], inv1[4];
@@ -888,12 +900,13 @@ __device__ __forceinline__ void complex_chunk(const ChunkGeom& g, const RowDesc&
     o[0] = o[1] = o[2] = o[3] = 0u;
     emit_walk(o, c, c_end, cz, i, in_gap0, g0e, adj0, rd, src, bad_base_pos);
   }
-  chunk_store(g, o, src.ablate);
-}
-
-#ifndef WGA_EMIT_U
-#define WGA_EMIT_U 2 /* chunks in flight per lane */
+  const bool whole = g.a0 == 0u && g.b0 == 16u;
+#ifdef WGA_PROFILE
+  if (src.ablate & 4) return;
 #endif
+  buf_store16(rb.sbuf, whole ? rel << 4 : WGA_BUF_OOB, o);
+  if (!whole) chunk_store(g, o, 0); /* a row / tile edge: byte stores */
+}
 
 __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& rd,
                                          const RowSrc& src, u32 tid, u32 nthreads,
@@ -918,9 +931,11 @@ __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& 
   const bool fast_ok = row_fast && any_full;
   /* buffers of the fast path: the source windows of this row relative to its first window (for
    * rc the windows walk down from it: offsets are biased by 2^31), and the row's output granules */
-  const u32 sgn = src.rc ? 0xFFFFFFFFu : 0u, kbias = src.rc ? 0x80000000u : 0u;
-  const BufRsrc lbuf = buf_make(src.rc ? src.win_base - 0x80000000ll : src.win_base, 0xFFFFFFF0u);
-  const BufRsrc sbuf = buf_make(rg.base, rg.nchunks << 4);
+  RowBufs rb;
+  rb.sgn = src.rc ? 0xFFFFFFFFu : 0u;
+  rb.kbias = src.rc ? 0x80000000u : 64u;
+  rb.lbuf = buf_make(src.win_base - (i64)rb.kbias, 0xFFFFFFF0u);
+  rb.sbuf = buf_make(rg.base, rg.nchunks << 4);
 #pragma nounroll
   for (u32 it = 0; it < niter; it++) {
     /* Fast path: a whole granule that no event of this row touches — plain copy — or that lies
@@ -944,10 +959,10 @@ __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& 
       dash[u] = st == (WGA_TBL_COVER | WGA_TBL_FULL);
       cand[u] = fast_ok && (rel[u] - lo_full < n_full) && ((w0 ^ w1) & WGA_TBL_CNT) == 0u && st != WGA_TBL_COVER;
       const u32 off = cz + (u32)koff - adj; /* slice index of the granule relative to sbase, >= 0 */
-      loff[u] = (cand[u] && !dash[u]) ? ((off ^ sgn) - sgn) + kbias : WGA_BUF_OOB;
+      loff[u] = (cand[u] && !dash[u]) ? rowbuf_loff(rb, (int)off) : WGA_BUF_OOB;
     }
 #pragma unroll
-    for (int u = 0; u < WGA_EMIT_U; u++) buf_load16(lbuf, loff[u], raw[u]);
+    for (int u = 0; u < WGA_EMIT_U; u++) buf_load16(rb.lbuf, loff[u], raw[u]);
     bool cxs[WGA_EMIT_U];
 #pragma unroll
     for (int u = 0; u < WGA_EMIT_U; u++) {
@@ -965,7 +980,7 @@ __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& 
 #ifdef WGA_PROFILE
       if (!(src.ablate & 4))
 #endif
-        buf_store16(sbuf, st_ok ? rel[u] << 4 : WGA_BUF_OOB, o);
+        buf_store16(rb.sbuf, st_ok ? rel[u] << 4 : WGA_BUF_OOB, o);
       cxs[u] = act[u] && !st_ok;
 #ifdef WGA_PROFILE
       if (src.ablate & 16) cxs[u] = false;
@@ -986,7 +1001,10 @@ __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& 
     while (qn >= 64u || (last && qn > 0u)) {
       const u32 take = qn < 64u ? qn : 64u;
       qn -= take;
-      if (lane < take) complex_chunk(chunk_geom(rg, queue[qn + lane]), rd, src, bad_base_pos);
+      if (lane < take) {
+        const u32 qrel = queue[qn + lane];
+        complex_chunk(chunk_geom(rg, qrel), qrel, rd, src, rb, bad_base_pos);
+      }
       WGA_WAVE_SYNC(); /* the drained slots are rewritten by the next pushes */
     }
   }
