@@ -276,23 +276,22 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
   /* pre-pass: per-record descriptors and per-tile base sums, in the context's scratch arena */
   void* ws;
   size_t rec_bytes = ((size_t)b->n * sizeof(wga_rec_desc) + 255) & ~(size_t)255;
-  if ((rc = ctx_scratch(c, rec_bytes + (size_t)nt * sizeof(wga_tile_base), &ws))) return rc;
+  if ((rc = ctx_scratch(c, rec_bytes + (size_t)nt * sizeof(wga_tile_desc), &ws))) return rc;
   wga_rec_desc* recs = (wga_rec_desc*)ws;
-  wga_tile_base* bases = (wga_tile_base*)((char*)ws + rec_bytes);
+  wga_tile_desc* tdesc = (wga_tile_desc*)((char*)ws + rec_bytes);
   WGA_LAUNCH(k_rec_desc, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, b->n, d_counts,
              b->d_strand_neg, (const u64*)d_t_src_off, (const u64*)d_t_src_len,
              (const u64*)d_q_src_off, (const u64*)d_q_src_len, (const u64*)d_t_row_off,
              (const u64*)d_q_row_off, recs);
   LAUNCH_CHECK();
   WGA_LAUNCH(k_tile_base, (u32)((nt + 3) / 4), WGA_BLOCK, c->stream, (const u64*)b->d_op_off,
-             (u64)b->n_ops, (const wga_tile_sum*)d_tile_ws, bases);
+             (u64)b->n_ops, (const wga_tile_sum*)d_tile_ws, (const wga_rec_desc*)recs, tdesc);
   LAUNCH_CHECK();
   ExpandArgs a;
   a.ops = b->d_ops;
   a.op_off = (const u64*)b->d_op_off;
   a.n_ops = b->n_ops;
-  a.tiles = (const wga_tile_sum*)d_tile_ws;
-  a.bases = bases;
+  a.tdesc = tdesc;
   a.recs = recs;
   a.t_fa = d_t_fa;
   a.t_fa_bytes = t_fa_bytes;

@@ -122,12 +122,12 @@ __device__ __forceinline__ u32 wave_min_u32(u32 v) {
 /* exclusive scan of four u32 values across a 256-thread block; tot[] = block totals.
  * s_w4: 16 words of LDS. */
 __device__ __forceinline__ void block_excl_scan4_u32(const u32 v[4], u32 ex[4], u32 tot[4],
-                                                     u32* s_w4) {
+                                                     u32* s_w4, bool s_w4_idle = false) {
   const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   u32 inc[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) inc[k] = wave_incl_scan_u32(v[k]);
-  __syncthreads(); /* protect s_w4 reuse */
+  if (!s_w4_idle) __syncthreads(); /* protect s_w4 reuse */
   if (lane == 63u) {
 #pragma unroll
     for (int k = 0; k < 4; k++) s_w4[wave * 4 + k] = inc[k];
@@ -676,6 +676,14 @@ __device__ __forceinline__ u64 wave_get_u64(u32 v, int k) {
 #endif
 }
 
+__device__ __forceinline__ u32 wave_get_u32(u32 v, int k) {
+#ifdef WGA_EMU
+  return __shfl(v, k);
+#else
+  return (u32)__builtin_amdgcn_readlane((int)v, k);
+#endif
+}
+
 /* tell the compiler a value is wave-uniform so that it lives in SGPRs (scalar loads, no VGPRs) */
 #ifdef WGA_EMU
 #define WGA_UNI32(x) ((u32)(x))
@@ -743,8 +751,7 @@ __device__ __forceinline__ void tbl_scan(u32* tbl, u32* s_w4) {
   }
   const u32 lane = tid & 63u, wave = tid >> 6;
   const u32 inc = wave_incl_scan_u32(sum);
-  __syncthreads();
-  if (lane == 63u) s_w4[wave] = inc;
+  if (lane == 63u) s_w4[wave] = inc; /* callers have a barrier between the last use of s_w4 and this */
   __syncthreads();
   u32 run = inc - sum, tot = 0;
 #pragma unroll
@@ -1082,6 +1089,17 @@ struct wga_rec_desc {
 struct wga_tile_base {
   u64 mx, i, d;
 };
+/* Everything the expand kernel needs before it can start on a tile, in one 128-byte record that
+ * every wave fetches with a single 32-lane load at the top of the kernel (no dependent round
+ * trips: tile summary -> record index -> offsets / descriptor).  Dword layout is fixed: the
+ * kernel picks fields out of lanes with v_readlane. */
+struct wga_tile_desc {
+  u64 tile_cols;        /* dwords 0-1   columns of the tile (M = X I D bases)                  */
+  u32 rec, neg;         /* 2, 3         record of the tile's first op; its strand              */
+  u64 b_mx, b_i, b_d;   /* 4-9          class sums of that record before the tile              */
+  u64 rs, re;           /* 10-13        op_off[rec], op_off[rec + 1]                           */
+  u64 t_row_off, q_row_off, t_src_off, t_src_len, q_src_off, q_src_len, I_total, D_total, L; /* 14-31 */
+};
 
 __global__ __launch_bounds__(256) void k_rec_desc(u32 n, const wga_cigar_counts* counts,
                                                   const u8* strand_neg, const u64* t_src_off,
@@ -1109,12 +1127,13 @@ __global__ __launch_bounds__(256) void k_rec_desc(u32 n, const wga_cigar_counts*
  * where the record starts + totals of the tiles in between (summaries are read 64 at a time) */
 __global__ __launch_bounds__(256) void k_tile_base(const u64* op_off, u64 n_ops,
                                                    const wga_tile_sum* tiles,
-                                                   wga_tile_base* bases) {
+                                                   const wga_rec_desc* recs, wga_tile_desc* descs) {
   const u32 lane = threadIdx.x & 63u;
   const u64 g = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
   const u64 tile_start = g * WGA_TILE;
   if (tile_start >= n_ops) return;
-  const u64 rs = op_off[tiles[g].rec];
+  const wga_tile_sum ts = tiles[g];
+  const u64 rs = op_off[ts.rec];
   u64 p_mx = 0, p_i = 0, p_d = 0;
   if (rs < tile_start) {
     const u64 g0 = rs / WGA_TILE;
@@ -1129,11 +1148,26 @@ __global__ __launch_bounds__(256) void k_tile_base(const u64* op_off, u64 n_ops,
   p_i = wave_sum_u64(p_i);
   p_d = wave_sum_u64(p_d);
   if (lane == 0) {
-    wga_tile_base b;
-    b.mx = p_mx;
-    b.i = p_i;
-    b.d = p_d;
-    bases[g] = b;
+    const wga_rec_desc rd = recs[ts.rec];
+    wga_tile_desc d;
+    d.tile_cols = ts.tot[CLS_MX] + ts.tot[CLS_I] + ts.tot[CLS_D];
+    d.rec = (u32)ts.rec;
+    d.neg = (u32)rd.neg;
+    d.b_mx = p_mx;
+    d.b_i = p_i;
+    d.b_d = p_d;
+    d.rs = rs;
+    d.re = op_off[ts.rec + 1];
+    d.t_row_off = rd.t_row_off;
+    d.q_row_off = rd.q_row_off;
+    d.t_src_off = rd.t_src_off;
+    d.t_src_len = rd.t_src_len;
+    d.q_src_off = rd.q_src_off;
+    d.q_src_len = rd.q_src_len;
+    d.I_total = rd.I_total;
+    d.D_total = rd.D_total;
+    d.L = rd.L;
+    descs[g] = d;
   }
 }
 
@@ -1141,8 +1175,7 @@ struct ExpandArgs {
   const u32* ops;
   const u64* op_off;
   u64 n_ops;
-  const wga_tile_sum* tiles;
-  const wga_tile_base* bases;
+  const wga_tile_desc* tdesc;
   const wga_rec_desc* recs;
   const u8* t_fa;
   u64 t_fa_bytes;
@@ -1179,24 +1212,17 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
   u64 stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (a.dbg) stamp[0] = WGA_CLOCK();
 
-  const wga_tile_sum tsum = a.tiles[g];
-  const u64 tile_cols = tsum.tot[CLS_MX] + tsum.tot[CLS_I] + tsum.tot[CLS_D];
+  /* lane k of every wave holds dword k of this tile's wga_tile_desc: one VGPR, no dependent
+   * loads; fields are picked out with v_readlane when they are needed */
+  u32 pre = 0u;
+  if (lane < 32u) pre = ((const u32*)(a.tdesc + g))[lane];
+  const u64 tile_cols = wave_get_u64(pre, 0);
   const bool fast = !a.force_slow && tile_cols <= WGA_FAST_COL_LIMIT;
   /* granule width: 16 columns unless the tile is wider than the table covers */
   u32 gsh = a.no_table ? 8u : WGA_TBL_SHIFT;
   while ((tile_cols >> gsh) >= WGA_TBL_N) gsh++;
   const bool use_tbl = fast;
-  /* the first segment's descriptors: their (scalar) loads are issued here so that they land
-   * while phase A runs instead of costing two more serial round trips after it */
-  const u32 r0 = WGA_UNI32((u32)tsum.rec);
-  u32 pre = 0u; /* lane k of every wave holds dword k of {recs[r0] (20), bases[g] (6), op_off[r0..r0+1] (4)}:
-                   one VGPR instead of 30 SGPRs kept alive across phase A */
-  {
-    const u32* p = (const u32*)(a.recs + r0) + lane;
-    if (lane >= 20u) p = (const u32*)(a.bases + g) + (lane - 20u);
-    if (lane >= 26u) p = (const u32*)(a.op_off + r0) + (lane - 26u);
-    if (lane < 30u) pre = *p;
-  }
+  const u32 r0 = wave_get_u32(pre, 2);
   if (use_tbl)
     for (u32 k = tid; k < WGA_TBL_N + 2u; k += WGA_BLOCK) s_tbl[k] = 0u;
   if (tid < 2u) s_zero2[tid] = 0u;
@@ -1231,7 +1257,7 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
      * below 2^31 on the fast path */
     const u32 sv[4] = {sl, si, sd, cnt};
     u32 sx[4], stot[4];
-    block_excl_scan4_u32(sv, sx, stot, s_w4);
+    block_excl_scan4_u32(sv, sx, stot, s_w4, true);
     u32 x_col = sx[0], x_i = sx[1], x_d = sx[2], x_cnt = sx[3];
     for (int e = 0; e < 4; e++) {
       u32 k = tid * 4u + (u32)e;
@@ -1276,14 +1302,14 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
   /* ---- phase B: walk the record segments of this tile ------------------------------------- */
   u32 r = r0;
   u64 cur = tile_start;
-  u64 re = wave_get_u64(pre, 28);
+  u64 re = wave_get_u64(pre, 12);
   while (cur < tile_end) {
     while (re <= cur) {
       r++;
       re = a.op_off[r + 1];
     }
     const bool is0 = r == r0;
-    const u64 rs = is0 ? wave_get_u64(pre, 26) : a.op_off[r];
+    const u64 rs = is0 ? wave_get_u64(pre, 10) : a.op_off[r];
     const u64 seg_end = re < tile_end ? re : tile_end;
     const u32 ka = (u32)(cur - tile_start), kb = (u32)(seg_end - tile_start);
 
@@ -1291,9 +1317,9 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
      * record; k_tile_base worked them out) and the record's geometry (k_rec_desc) */
     u64 b_mx = 0, b_i = 0, b_d = 0;
     if (rs < tile_start) { /* only the tile's first record can continue from earlier tiles */
-      b_mx = wave_get_u64(pre, 20);
-      b_i = wave_get_u64(pre, 22);
-      b_d = wave_get_u64(pre, 24);
+      b_mx = wave_get_u64(pre, 4);
+      b_i = wave_get_u64(pre, 6);
+      b_d = wave_get_u64(pre, 8);
     }
     const u64 cb = b_mx + b_i + b_d; /* record-relative column of the segment start */
     const u64 tb = b_mx + b_d;       /* target bases consumed before it              */
@@ -1301,16 +1327,16 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
 
     wga_rec_desc rdsc;
     if (is0) {
-      rdsc.t_row_off = wave_get_u64(pre, 0);
-      rdsc.q_row_off = wave_get_u64(pre, 2);
-      rdsc.t_src_off = wave_get_u64(pre, 4);
-      rdsc.t_src_len = wave_get_u64(pre, 6);
-      rdsc.q_src_off = wave_get_u64(pre, 8);
-      rdsc.q_src_len = wave_get_u64(pre, 10);
-      rdsc.I_total = wave_get_u64(pre, 12);
-      rdsc.D_total = wave_get_u64(pre, 14);
-      rdsc.L = wave_get_u64(pre, 16);
-      rdsc.neg = wave_get_u64(pre, 18);
+      rdsc.t_row_off = wave_get_u64(pre, 14);
+      rdsc.q_row_off = wave_get_u64(pre, 16);
+      rdsc.t_src_off = wave_get_u64(pre, 18);
+      rdsc.t_src_len = wave_get_u64(pre, 20);
+      rdsc.q_src_off = wave_get_u64(pre, 22);
+      rdsc.q_src_len = wave_get_u64(pre, 24);
+      rdsc.I_total = wave_get_u64(pre, 26);
+      rdsc.D_total = wave_get_u64(pre, 28);
+      rdsc.L = wave_get_u64(pre, 30);
+      rdsc.neg = (u64)wave_get_u32(pre, 3);
     } else {
       rdsc = a.recs[r];
     }
