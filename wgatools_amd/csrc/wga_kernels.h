@@ -1201,6 +1201,10 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
   __shared__ u32x4_a16 s_lowmask[17];
   __shared__ u32 s_tbl[WGA_TBL_N + 2];   /* entries before each 16-column granule: I | D<<16  */
   __shared__ u32 s_queue[4 * WGA_QCAP];  /* per-wave queues of complex chunks                 */
+#ifdef WGA_LDS_PAD /* occupancy experiments: extra LDS words per block */
+  __shared__ u32 s_pad[WGA_LDS_PAD];
+  if (a.n_ops == 0xFFFFFFFFFFFFFFFFull) ((volatile u32*)s_pad)[threadIdx.x] = 1u;
+#endif
 
   const u32 tid = threadIdx.x;
   const u32 lane = tid & 63u, wave = tid >> 6;
