@@ -60,6 +60,22 @@ def cpu_baseline(tb, budget_s=15.0, max_records=40000):
                       "%.1f s of oracle time on 1 core" % (done, ops_done, t_work)}
 
 
+def pmc_traffic(args, job):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE and
+    WRITE_SIZE are collected in their own rocprofv3 runs — scripts/gpu_pmc.sh — and corrected as
+    MI355X_MICROARCH.md prescribes; they cannot be read live).  Only valid for the workload they
+    were measured on."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None
+    w = t.get("workload", {})
+    if w.get("records") != args.records or w.get("mean_ops") != args.mean_ops or w.get("ops") != job.n_ops:
+        return None
+    return t["hbm_bytes_per_launch"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +137,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # HIP events inside the library bracket the dominant kernel alone (on the launch stream)
+    eng.set_param("expand_timing", 1)
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -145,7 +163,9 @@ def main():
     if rank == 0:
         k_stat = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
         k_layout = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
-        k_expand = sum(e[2].elapsed_time(e[3]) for e in events) / args.steps
+        k_expand_call = sum(e[2].elapsed_time(e[3]) for e in events) / args.steps   # pre-pass + kernel
+        ms_sum, n_timed = eng.expand_timing()
+        k_expand = ms_sum / n_timed if n_timed else k_expand_call
         ab = job.algorithmic_bytes()
         in_bytes = 4 * job.n_ops + int(tb["t_src_len"].sum()) + int(tb["q_src_len"].sum())
         ach = ab["expand"] / (k_expand * 1e-3) / 1e9
@@ -171,10 +191,11 @@ def main():
                 "output_bytes_per_gpu": job.out_bytes, "sharding": "records, no data-path collective",
             },
             "input_GBps": in_bytes * world * args.steps / elapsed / 1e9,
-            "kernel_ms": {"k_cigar_stat": k_stat, "layout_scan": k_layout, "k_paf2maf_expand": k_expand},
+            "kernel_ms": {"k_cigar_stat": k_stat, "layout_scan": k_layout, "k_paf2maf_expand": k_expand,
+                          "expand_prepass (k_rec_desc + k_tile_base)": k_expand_call - k_expand},
             "roofline": {
                 "kernel": "k_paf2maf_expand", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args, job),
                 "algorithmic_bytes_per_launch": ab["expand"],
                 "k_cigar_stat_GBps": ab["stat"] / (k_stat * 1e-3) / 1e9,
             },

@@ -112,6 +112,11 @@ int wga_ctx_reset_stream(wga_ctx*);
 /* Tunables (test knobs): "expand_force_slow" (0/1) forces the u64 op-serial fallback of the
  * expand kernel; "expand_no_table" (0/1) forces its binary-search event lookup. */
 int wga_ctx_set_param(wga_ctx*, const char* name, int64_t value);
+/* Measurement hook: after wga_ctx_set_param(ctx, "expand_timing", 1) every wga_paf2maf_expand
+ * brackets its gap-insertion kernel (without the descriptor pre-pass) with two events on the
+ * launch stream.  Returns the summed kernel time of the launches since the last call (at most the
+ * 64 most recent) and their number; waits for them. */
+int wga_ctx_expand_timing(wga_ctx*, double* ms_sum, uint32_t* launches);
 int wga_sync(wga_ctx*);
 int wga_malloc(wga_ctx*, size_t bytes, void** d_out);
 int wga_free(wga_ctx*, void* d_ptr);

@@ -23,6 +23,11 @@ struct wga_ctx {
   void* expand_dbg = nullptr;
   void* scratch = nullptr;
   size_t scratch_cap = 0;
+  /* optional per-launch timing of the expand kernel proper (events on the launch stream) */
+  static const int kTimingRing = 64;
+  bool timing = false;
+  rt_event_t ev[2 * kTimingRing];
+  uint32_t ev_n = 0;
 };
 
 static thread_local std::string g_last_error;
@@ -109,6 +114,8 @@ int wga_ctx_create(int device, wga_ctx** out) {
 }
 
 void wga_ctx_destroy(wga_ctx* c) {
+  if (c && c->timing)
+    for (int k = 0; k < 2 * wga_ctx::kTimingRing; k++) rt_event_destroy(c->ev[k]);
   if (!c) return;
   (void)rt_set_device(c->device);
   (void)rt_sync(c->stream);
@@ -145,6 +152,18 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
   }
   if (strcmp(name, "expand_no_table") == 0) {
     c->expand_no_table = value != 0;
+    return WGA_OK;
+  }
+  if (strcmp(name, "expand_timing") == 0) {
+    if (value && !c->timing) {
+      int rc = ctx_bind(c);
+      if (rc) return rc;
+      for (int k = 0; k < 2 * wga_ctx::kTimingRing; k++) RT_CHECK(rt_event_create(&c->ev[k]));
+    }
+    if (!value && c->timing)
+      for (int k = 0; k < 2 * wga_ctx::kTimingRing; k++) rt_event_destroy(c->ev[k]);
+    c->timing = value != 0;
+    c->ev_n = 0;
     return WGA_OK;
   }
   return fail(WGA_E_INVALID_ARG, "unknown parameter", name);
@@ -303,8 +322,32 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
   a.no_table = c->expand_no_table;
   a.ablate = c->expand_ablate;
   a.dbg = (u64*)c->expand_dbg;
+  const uint32_t slot = c->ev_n % (uint32_t)wga_ctx::kTimingRing;
+  if (c->timing) RT_CHECK(rt_event_record(c->ev[2 * slot], c->stream));
   WGA_LAUNCH(k_paf2maf_expand, (u32)nt, WGA_BLOCK, c->stream, a);
   LAUNCH_CHECK();
+  if (c->timing) {
+    RT_CHECK(rt_event_record(c->ev[2 * slot + 1], c->stream));
+    c->ev_n++;
+  }
+  return WGA_OK;
+}
+
+int wga_ctx_expand_timing(wga_ctx* c, double* ms_sum, uint32_t* launches) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (!ms_sum || !launches) return fail(WGA_E_INVALID_ARG, "null argument", nullptr);
+  *ms_sum = 0.0;
+  *launches = 0;
+  if (!c->timing) return WGA_OK;
+  const uint32_t n = c->ev_n < (uint32_t)wga_ctx::kTimingRing ? c->ev_n : (uint32_t)wga_ctx::kTimingRing;
+  for (uint32_t k = 0; k < n; k++) {
+    float ms = 0.0f;
+    RT_CHECK(rt_event_elapsed_ms(c->ev[2 * k], c->ev[2 * k + 1], &ms));
+    *ms_sum += (double)ms;
+  }
+  *launches = n;
+  c->ev_n = 0;
   return WGA_OK;
 }
 

@@ -46,6 +46,17 @@ static inline const char* rt_memset(void* d, int v, size_t n, wga_stream_t) {
   return nullptr;
 }
 static inline const char* rt_launch_error() { return nullptr; }
+typedef int rt_event_t;
+static inline const char* rt_event_create(rt_event_t* e) {
+  *e = 0;
+  return nullptr;
+}
+static inline void rt_event_destroy(rt_event_t) {}
+static inline const char* rt_event_record(rt_event_t, wga_stream_t) { return nullptr; }
+static inline const char* rt_event_elapsed_ms(rt_event_t, rt_event_t, float* ms) {
+  *ms = 0.0f;
+  return nullptr;
+}
 #else
 #include <hip/hip_runtime.h>
 typedef hipStream_t wga_stream_t;
@@ -77,6 +88,15 @@ static inline const char* rt_memset(void* d, int v, size_t n, wga_stream_t s) {
   return rt_err(hipMemsetAsync(d, v, n, s));
 }
 static inline const char* rt_launch_error() { return rt_err(hipGetLastError()); }
+typedef hipEvent_t rt_event_t;
+static inline const char* rt_event_create(rt_event_t* e) { return rt_err(hipEventCreate(e)); }
+static inline void rt_event_destroy(rt_event_t e) { (void)hipEventDestroy(e); }
+static inline const char* rt_event_record(rt_event_t e, wga_stream_t s) { return rt_err(hipEventRecord(e, s)); }
+static inline const char* rt_event_elapsed_ms(rt_event_t a, rt_event_t b, float* ms) {
+  hipError_t r = hipEventSynchronize(b);
+  if (r != hipSuccess) return hipGetErrorString(r);
+  return rt_err(hipEventElapsedTime(ms, a, b));
+}
 #endif
 
 #endif

@@ -132,6 +132,12 @@ class Engine:
     def set_param(self, name, value):
         self._check(self.lib.wga_ctx_set_param(self.ctx, name.encode(), int(value)))
 
+    def expand_timing(self):
+        """(summed ms, launches) of the expand kernel proper since the last call ("expand_timing" param)"""
+        ms, n = C.c_double(0.0), C.c_uint32(0)
+        self._check(self.lib.wga_ctx_expand_timing(self.ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     # ---- host packer ------------------------------------------------------------------------
     def pack_cigar(self, text):
         """CIGAR text (after 'cg:Z:') -> (ops u32[], err code, (tok_off, tok_len))."""
