@@ -303,7 +303,7 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
              (const u64*)d_q_src_off, (const u64*)d_q_src_len, (const u64*)d_t_row_off,
              (const u64*)d_q_row_off, recs);
   LAUNCH_CHECK();
-  WGA_LAUNCH(k_tile_base, (u32)((nt + 3) / 4), WGA_BLOCK, c->stream, (const u64*)b->d_op_off,
+  WGA_LAUNCH(k_tile_base, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const u64*)b->d_op_off,
              (u64)b->n_ops, (const wga_tile_sum*)d_tile_ws, (const wga_rec_desc*)recs, tdesc);
   LAUNCH_CHECK();
   ExpandArgs a;

@@ -1123,52 +1123,81 @@ __global__ __launch_bounds__(256) void k_rec_desc(u32 n, const wga_cigar_counts*
   out[r] = d;
 }
 
-/* one wave per tile: class sums of the tile's first record before the tile = tail of the tile
- * where the record starts + totals of the tiles in between (summaries are read 64 at a time) */
+/* One thread per tile: class sums of the tile's first record before the tile = tail of the tile
+ * where the record starts + totals of the tiles in between, plus everything else the expand
+ * kernel wants to know up front (wga_tile_desc).  Walk-backs over more than 64 tiles (records
+ * beyond 64 kop) are summed by the whole wave, one such tile at a time. */
 __global__ __launch_bounds__(256) void k_tile_base(const u64* op_off, u64 n_ops,
                                                    const wga_tile_sum* tiles,
                                                    const wga_rec_desc* recs, wga_tile_desc* descs) {
   const u32 lane = threadIdx.x & 63u;
-  const u64 g = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
   const u64 tile_start = g * WGA_TILE;
-  if (tile_start >= n_ops) return;
-  const wga_tile_sum ts = tiles[g];
-  const u64 rs = op_off[ts.rec];
+  const bool valid = tile_start < n_ops;
+  wga_tile_sum ts;
+  u64 rs = 0, re = 0, g0 = 0;
+  if (valid) {
+    ts = tiles[g];
+    rs = op_off[ts.rec];
+    re = op_off[ts.rec + 1];
+  }
   u64 p_mx = 0, p_i = 0, p_d = 0;
-  if (rs < tile_start) {
-    const u64 g0 = rs / WGA_TILE;
-    for (u64 k = g0 + lane; k < g; k += 64) {
-      const u64* v = (k == g0) ? tiles[k].tail : tiles[k].tot;
-      p_mx += v[CLS_MX];
-      p_i += v[CLS_I];
-      p_d += v[CLS_D];
+  bool far = false;
+  if (valid && rs < tile_start) {
+    g0 = rs / WGA_TILE;
+    if (g - g0 <= 64) {
+      for (u64 k = g0; k < g; k++) {
+        const u64* v = (k == g0) ? tiles[k].tail : tiles[k].tot;
+        p_mx += v[CLS_MX];
+        p_i += v[CLS_I];
+        p_d += v[CLS_D];
+      }
+    } else {
+      far = true;
     }
   }
-  p_mx = wave_sum_u64(p_mx);
-  p_i = wave_sum_u64(p_i);
-  p_d = wave_sum_u64(p_d);
-  if (lane == 0) {
-    const wga_rec_desc rd = recs[ts.rec];
-    wga_tile_desc d;
-    d.tile_cols = ts.tot[CLS_MX] + ts.tot[CLS_I] + ts.tot[CLS_D];
-    d.rec = (u32)ts.rec;
-    d.neg = (u32)rd.neg;
-    d.b_mx = p_mx;
-    d.b_i = p_i;
-    d.b_d = p_d;
-    d.rs = rs;
-    d.re = op_off[ts.rec + 1];
-    d.t_row_off = rd.t_row_off;
-    d.q_row_off = rd.q_row_off;
-    d.t_src_off = rd.t_src_off;
-    d.t_src_len = rd.t_src_len;
-    d.q_src_off = rd.q_src_off;
-    d.q_src_len = rd.q_src_len;
-    d.I_total = rd.I_total;
-    d.D_total = rd.D_total;
-    d.L = rd.L;
-    descs[g] = d;
+  u64 m = __ballot(far);
+  while (m) {
+    const int src = (int)__builtin_ctzll(m);
+    const u64 gg = __shfl(g, src), gg0 = __shfl(g0, src);
+    u64 a_mx = 0, a_i = 0, a_d = 0;
+    for (u64 k = gg0 + lane; k < gg; k += 64) {
+      const u64* v = (k == gg0) ? tiles[k].tail : tiles[k].tot;
+      a_mx += v[CLS_MX];
+      a_i += v[CLS_I];
+      a_d += v[CLS_D];
+    }
+    a_mx = wave_sum_u64(a_mx);
+    a_i = wave_sum_u64(a_i);
+    a_d = wave_sum_u64(a_d);
+    if ((int)lane == src) {
+      p_mx = a_mx;
+      p_i = a_i;
+      p_d = a_d;
+    }
+    m &= m - 1;
   }
+  if (!valid) return;
+  const wga_rec_desc rd = recs[ts.rec];
+  wga_tile_desc d;
+  d.tile_cols = ts.tot[CLS_MX] + ts.tot[CLS_I] + ts.tot[CLS_D];
+  d.rec = (u32)ts.rec;
+  d.neg = (u32)rd.neg;
+  d.b_mx = p_mx;
+  d.b_i = p_i;
+  d.b_d = p_d;
+  d.rs = rs;
+  d.re = re;
+  d.t_row_off = rd.t_row_off;
+  d.q_row_off = rd.q_row_off;
+  d.t_src_off = rd.t_src_off;
+  d.t_src_len = rd.t_src_len;
+  d.q_src_off = rd.q_src_off;
+  d.q_src_len = rd.q_src_len;
+  d.I_total = rd.I_total;
+  d.D_total = rd.D_total;
+  d.L = rd.L;
+  descs[g] = d;
 }
 
 struct ExpandArgs {
