@@ -458,7 +458,13 @@ __device__ __forceinline__ void buf_store16(const BufRsrc& r, u32 off, const u32
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 typedef u32 u32x4_v __attribute__((vector_size(16)));
 __device__ __forceinline__ BufRsrc buf_make(const void* base, u32 bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)bytes, 0x00020000);
+  /* the descriptor must live in SGPRs: values the compiler cannot prove wave-uniform would make it
+   * wrap every access in a readfirstlane "waterfall" loop */
+  const u64 b = (u64)base;
+  const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)b);
+  const u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(b >> 32));
+  const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((u64)hi << 32) | (u64)lo), (short)0, (int)n, 0x00020000);
 }
 __device__ __forceinline__ void buf_load16(const BufRsrc& r, u32 off, u32 v[4]) {
   const u32x4_v x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
@@ -683,6 +689,14 @@ __device__ __forceinline__ u32 wave_get_u32(u32 v, int k) {
   return (u32)__builtin_amdgcn_readlane((int)v, k);
 #endif
 }
+
+/* keep the computation of a value where it is written (the compiler otherwise sinks LDS reads into
+ * exec-masked branches "to save them", which costs more in branch overhead than the reads) */
+#ifdef WGA_EMU
+#define WGA_PIN(x) ((void)0)
+#else
+#define WGA_PIN(x) asm volatile("" : "+v"(x))
+#endif
 
 /* tell the compiler a value is wave-uniform so that it lives in SGPRs (scalar loads, no VGPRs) */
 #ifdef WGA_EMU
@@ -960,13 +974,18 @@ __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& 
       const u32 relc = act[u] ? rel[u] : 0u;
       const u32 cz = (rg.j0 + relc) << 4;
       const u32 jg = cz >> rd.gsh;
-      const u32 w0 = rd.tbl[jg] >> rd.tsh, w1 = rd.tbl[jg + 1] >> rd.tsh;
-      const u32 adj = rd.G_adj[w0 & WGA_TBL_CNT];
+      u32 w0 = rd.tbl[jg] >> rd.tsh, w1 = rd.tbl[jg + 1] >> rd.tsh;
+      WGA_PIN(w0);
+      WGA_PIN(w1);
+      u32 adj = rd.G_adj[w0 & WGA_TBL_CNT];
+      WGA_PIN(adj);
       const u32 st = w1 & (WGA_TBL_COVER | WGA_TBL_FULL);
       dash[u] = st == (WGA_TBL_COVER | WGA_TBL_FULL);
-      cand[u] = fast_ok && (rel[u] - lo_full < n_full) && ((w0 ^ w1) & WGA_TBL_CNT) == 0u && st != WGA_TBL_COVER;
+      /* bitwise, not &&: short-circuit evaluation would come back as exec-mask branches */
+      cand[u] = (bool)((int)fast_ok & (int)(rel[u] - lo_full < n_full) & (int)(((w0 ^ w1) & WGA_TBL_CNT) == 0u) &
+                       (int)(st != WGA_TBL_COVER));
       const u32 off = cz + (u32)koff - adj; /* slice index of the granule relative to sbase, >= 0 */
-      loff[u] = (cand[u] && !dash[u]) ? rowbuf_loff(rb, (int)off) : WGA_BUF_OOB;
+      loff[u] = ((int)cand[u] & (int)!dash[u]) ? rowbuf_loff(rb, (int)off) : WGA_BUF_OOB;
     }
 #pragma unroll
     for (int u = 0; u < WGA_EMIT_U; u++) buf_load16(rb.lbuf, loff[u], raw[u]);
