@@ -212,7 +212,7 @@ def main():
                 gt, gq = job.record_rows(i)
                 assert gt == et and gq == eq, "record %d differs from the oracle" % i
             result["parity_spot_check"] = "%d records bit-identical to oracle rows" % len(step_idx)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only
             result["cpu_baseline"] = cpu_baseline(tb)
         print(json.dumps(result), flush=True)
     if world > 1:
