@@ -929,10 +929,15 @@ __device__ __forceinline__ void complex_chunk(const ChunkGeom& g, u32 rel, const
   if (!whole) chunk_store(g, o, 0); /* a row / tile edge: byte stores */
 }
 
-__device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& rd,
-                                         const RowSrc& src, u32 tid, u32 nthreads,
-                                         u64* bad_base_pos) {
+/* RC = the row is read reverse-complemented: a compile-time copy of src.rc, so that each of the
+ * two instantiations carries only its own window post-processing */
+template <bool RC>
+__device__ __forceinline__ void emit_row_t(u8* dst, u32 N, u32 c0, const RowDesc& rd,
+                                           const RowSrc& src_in, u32 tid, u32 nthreads,
+                                           u64* bad_base_pos) {
   if (N == 0) return;
+  RowSrc src = src_in;
+  src.rc = RC;
   const u32 lane = tid & 63u;
   const RowGeom rg = row_geom(dst, N, c0);
   u32* const queue = rd.queue + (tid >> 6) * WGA_QCAP;
@@ -1034,6 +1039,15 @@ __device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& 
       WGA_WAVE_SYNC(); /* the drained slots are rewritten by the next pushes */
     }
   }
+}
+
+__device__ __forceinline__ void emit_row(u8* dst, u32 N, u32 c0, const RowDesc& rd,
+                                         const RowSrc& src, u32 tid, u32 nthreads,
+                                         u64* bad_base_pos) {
+  if (src.rc)
+    emit_row_t<true>(dst, N, c0, rd, src, tid, nthreads, bad_base_pos);
+  else
+    emit_row_t<false>(dst, N, c0, rd, src, tid, nthreads, bad_base_pos);
 }
 
 /* finish a RowSrc: the wave-uniform 64-bit part of every window address of this row */
