@@ -1275,8 +1275,13 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
   const u64 tile_end = tile_start + WGA_TILE < a.n_ops ? tile_start + WGA_TILE : a.n_ops;
   const u32 nt = (u32)(tile_end - tile_start);
   build_lowmask(s_lowmask);
+#ifdef WGA_PROFILE /* s_memtime stamps per phase (scripts/gpu_stamps.py); 16 SGPRs the product build keeps free */
   u64 stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (a.dbg) stamp[0] = WGA_CLOCK();
+#define WGA_STAMP(code) code
+#else
+#define WGA_STAMP(code)
+#endif
 
   /* lane k of every wave holds dword k of this tile's wga_tile_desc: one VGPR, no dependent
    * loads; fields are picked out with v_readlane when they are needed */
@@ -1363,8 +1368,10 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
   }
   __syncthreads();
 
-  if (a.dbg) stamp[1] = WGA_CLOCK();
+  WGA_STAMP(if (a.dbg) stamp[1] = WGA_CLOCK();)
+#ifdef WGA_PROFILE
   if (a.ablate & 1) return;
+#endif
   /* ---- phase B: walk the record segments of this tile ------------------------------------- */
   u32 r = r0;
   u64 cur = tile_start;
@@ -1391,37 +1398,17 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
     const u64 tb = b_mx + b_d;       /* target bases consumed before it              */
     const u64 qb = b_mx + b_i;       /* query bases consumed before it               */
 
-    wga_rec_desc rdsc;
-    if (is0) {
-      rdsc.t_row_off = wave_get_u64(pre, 14);
-      rdsc.q_row_off = wave_get_u64(pre, 16);
-      rdsc.t_src_off = wave_get_u64(pre, 18);
-      rdsc.t_src_len = wave_get_u64(pre, 20);
-      rdsc.q_src_off = wave_get_u64(pre, 22);
-      rdsc.q_src_len = wave_get_u64(pre, 24);
-      rdsc.I_total = wave_get_u64(pre, 26);
-      rdsc.D_total = wave_get_u64(pre, 28);
-      rdsc.L = wave_get_u64(pre, 30);
-      rdsc.neg = (u64)wave_get_u32(pre, 3);
-    } else {
-      rdsc = a.recs[r];
+    /* The record's geometry stays spread over the lanes of `dsc` (layout of wga_tile_desc lanes
+     * 14..31, strand in lane 3): a field costs one v_readlane where it is used instead of an
+     * SGPR pair held — and spilled — across the whole segment. */
+    u32 dsc = pre;
+    if (!is0) {
+      const u32* rp = (const u32*)(a.recs + r);
+      dsc = 0u;
+      if (lane >= 14u && lane < 32u) dsc = rp[lane - 14u];
+      if (lane == 3u) dsc = rp[18];
     }
-    const u64 I_total = rdsc.I_total, D_total = rdsc.D_total, L = rdsc.L;
-    RowSrc ts, qs;
-    ts.fa = a.t_fa;
-    ts.fa_bytes = a.t_fa_bytes;
-    ts.src_off = rdsc.t_src_off;
-    ts.src_len = rdsc.t_src_len;
-    ts.rc = false;
-    ts.ablate = qs.ablate = a.ablate;
-    qs.fa = a.q_fa;
-    qs.fa_bytes = a.q_fa_bytes;
-    qs.src_off = rdsc.q_src_off;
-    qs.src_len = rdsc.q_src_len;
-    qs.rc = rdsc.neg != 0;
-    const u64 t_row_len = ts.src_len + I_total, q_row_len = qs.src_len + D_total;
-    u8* const t_dst = a.out + rdsc.t_row_off;
-    u8* const q_dst = a.out + rdsc.q_row_off;
+    const u64 t_src_len = wave_get_u64(dsc, 20), q_src_len = wave_get_u64(dsc, 24);
     u64* const bad_base = (u64*)&a.diag[r].bad_base_pos;
     u64* const panic_idx = (u64*)&a.diag[r].panic_op_idx;
 
@@ -1444,16 +1431,16 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
        * (serial rescan by the detecting thread) when that ever happens. */
       bool pan = false;
       for (int i = ia + (int)tid; i < ib; i += (int)WGA_BLOCK)
-        pan |= tb + (u64)(s_tg_col[i] - col_a) - (u64)(s_tg_cum[i] - icum_a) > ts.src_len;
+        pan |= tb + (u64)(s_tg_col[i] - col_a) - (u64)(s_tg_cum[i] - icum_a) > t_src_len;
       for (int i = ja + (int)tid; i < jb; i += (int)WGA_BLOCK)
-        pan |= qb + (u64)(s_qg_col[i] - col_a) - (u64)(s_qg_cum[i] - dcum_a) > qs.src_len;
+        pan |= qb + (u64)(s_qg_col[i] - col_a) - (u64)(s_qg_cum[i] - dcum_a) > q_src_len;
       if (pan) {
         u64 tp = tb, qp = qb;
         for (u64 k = cur; k < seg_end; k++) {
           const u32 op = a.ops[k];
           const u32 c = op_class(op & 15u);
           const u64 len = op >> 4;
-          if ((c == CLS_I && tp > ts.src_len) || (c == CLS_D && qp > qs.src_len)) {
+          if ((c == CLS_I && tp > t_src_len) || (c == CLS_D && qp > q_src_len)) {
             atomicMin(panic_idx, k - rs);
             break;
           }
@@ -1464,6 +1451,21 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
     } else {
       /* u64 fallback for tiles wider than 2^31 columns: ops are walked serially (every thread
        * redundantly), each op's columns are written block-strided, one byte per store */
+      RowSrc ts, qs;
+      ts.fa = a.t_fa;
+      ts.fa_bytes = a.t_fa_bytes;
+      ts.src_off = wave_get_u64(dsc, 18);
+      ts.src_len = t_src_len;
+      ts.rc = false;
+      ts.ablate = qs.ablate = 0;
+      qs.fa = a.q_fa;
+      qs.fa_bytes = a.q_fa_bytes;
+      qs.src_off = wave_get_u64(dsc, 22);
+      qs.src_len = q_src_len;
+      qs.rc = wave_get_u32(dsc, 3) != 0u;
+      const u64 t_row_len = t_src_len + wave_get_u64(dsc, 26), q_row_len = q_src_len + wave_get_u64(dsc, 28);
+      u8* const t_dst = a.out + wave_get_u64(dsc, 14);
+      u8* const q_dst = a.out + wave_get_u64(dsc, 16);
       u64 x = cb, tp = tb, qp = qb;
       for (u64 k = cur; k < seg_end; k++) {
         const u32 op = a.ops[k];
@@ -1487,14 +1489,28 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
      * 0/1 = this segment of the target / query row (rows end where a short slice ends);
      * 2/3 = once the record ends in this tile, what the slices hold beyond the CIGAR. */
     const bool rec_ends = seg_end == re;
-    if (a.dbg && stamp[2] == 0) stamp[2] = WGA_CLOCK();
+    WGA_STAMP(if (a.dbg && stamp[2] == 0) stamp[2] = WGA_CLOCK();)
 #pragma nounroll
     for (int job = 0; job < 4; job++) {
-      if (a.dbg && job == 1 && stamp[3] == 0) stamp[3] = WGA_CLOCK();
-      if (a.dbg && job == 2 && stamp[4] == 0) stamp[4] = WGA_CLOCK();
+      WGA_STAMP(if (a.dbg && job == 1 && stamp[3] == 0) stamp[3] = WGA_CLOCK();)
+      WGA_STAMP(if (a.dbg && job == 2 && stamp[4] == 0) stamp[4] = WGA_CLOCK();)
       const bool is_q = (job & 1) != 0, is_tail = job >= 2;
+#ifdef WGA_PROFILE
       if (a.ablate & 8) continue;
-      const u64 row_len = is_q ? q_row_len : t_row_len;
+#endif
+      /* this row's fields: the query ones sit 2 (offsets, gap totals) or 4 (slice) lanes after
+       * the target ones */
+      const int q2 = is_q ? 2 : 0, q4 = is_q ? 4 : 0;
+      const u64 gap_total = wave_get_u64(dsc, 26 + q2); /* I bases (target row) / D bases (query row) */
+      const u64 L = wave_get_u64(dsc, 30);
+      RowSrc src;
+      src.fa = is_q ? a.q_fa : a.t_fa;
+      src.fa_bytes = is_q ? a.q_fa_bytes : a.t_fa_bytes;
+      src.src_off = wave_get_u64(dsc, 18 + q4);
+      src.src_len = is_q ? q_src_len : t_src_len;
+      src.rc = is_q && wave_get_u32(dsc, 3) != 0u;
+      src.ablate = a.ablate;
+      const u64 row_len = src.src_len + gap_total;
       u64 x0, nbytes;
       if (!is_tail) {
         if (!fast) continue;
@@ -1507,9 +1523,8 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
         nbytes = row_len > L ? row_len - L : 0;
       }
       if (nbytes == 0) continue;
-      RowSrc src = is_q ? qs : ts;
-      u8* const dst = (is_q ? q_dst : t_dst) + x0;
-      const u64 sb0 = is_tail ? L - (is_q ? D_total : I_total) : (is_q ? qb : tb);
+      u8* const dst = a.out + wave_get_u64(dsc, 14 + q2) + x0;
+      const u64 sb0 = is_tail ? L - gap_total : (is_q ? qb : tb);
       for (u64 done = 0; done < nbytes; done += (1ull << 30)) {
         const u64 m = nbytes - done < (1ull << 30) ? nbytes - done : (1ull << 30);
         RowDesc rd;
@@ -1532,12 +1547,14 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
     cur = seg_end;
     r++;
     if (cur < tile_end) re = a.op_off[r + 1];
-    stamp[6] += 1;
+    WGA_STAMP(stamp[6] += 1;)
   }
+#ifdef WGA_PROFILE
   if (a.dbg && tid == 0) {
     stamp[5] = WGA_CLOCK();
     for (int k = 0; k < 8; k++) a.dbg[g * 8 + k] = stamp[k];
   }
+#endif
 }
 
 /* ---- copy n variable-length snippets (MAF line text between the rows) ------------------------ */
