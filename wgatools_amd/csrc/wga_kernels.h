@@ -1334,18 +1334,18 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
       u32 k = tid * 4u + (u32)e;
       s_col[k] = x_col;
       s_ev[k] = x_cnt;
-      if (cls[e] == CLS_I) {
-        s_tg_col[x_cnt & 0xFFFFu] = x_col;
-        s_tg_cum[x_cnt & 0xFFFFu] = x_i;
-        if (use_tbl) tbl_mark_event(s_tbl, x_col, opw[e] >> 4, gsh, 0u);
-        x_i += opw[e] >> 4;
-        x_cnt += 1u;
-      } else if (cls[e] == CLS_D) {
-        s_qg_col[x_cnt >> 16] = x_col;
-        s_qg_cum[x_cnt >> 16] = x_d;
-        if (use_tbl) tbl_mark_event(s_tbl, x_col, opw[e] >> 4, gsh, 16u);
-        x_d += opw[e] >> 4;
-        x_cnt += 0x10000u;
+      const bool isi = cls[e] == CLS_I, isd = cls[e] == CLS_D;
+      if (isi | isd) { /* ONE instance for both kinds of gap op: the body runs once per wave and op slot */
+        const u32 len = opw[e] >> 4;
+        const u32 slot = isi ? (x_cnt & 0xFFFFu) : (x_cnt >> 16);
+        u32* const g_col = isi ? s_tg_col : s_qg_col;
+        u32* const g_cum = isi ? s_tg_cum : s_qg_cum;
+        g_col[slot] = x_col;
+        g_cum[slot] = isi ? x_i : x_d;
+        if (use_tbl) tbl_mark_event(s_tbl, x_col, len, gsh, isi ? 0u : 16u);
+        x_i += isi ? len : 0u;
+        x_d += isi ? 0u : len;
+        x_cnt += isi ? 1u : 0x10000u;
       }
       x_col += l[e];
     }
