@@ -1251,9 +1251,11 @@ struct ExpandArgs {
   u64* dbg;     /* profiling: 8 s_memtime stamps per tile (NULL: off) */
 };
 
-__global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
-  __shared__ u32 s_col[WGA_TILE + 1];    /* tile-relative exclusive column prefix per op      */
-  __shared__ u32 s_ev[WGA_TILE + 1];     /* exclusive (#I-class ops | #D-class ops << 16)     */
+__global__ __launch_bounds__(256, 5) void k_paf2maf_expand(ExpandArgs a) {
+  __shared__ u32 s_bnd[3][2];            /* (column, I | D << 16 gap-op counts) before the op where a record
+                                            ends inside the tile: [0] the first such op (written in phase A),
+                                            [1], [2] later ones (rebuilt on demand)               */
+  __shared__ u32 s_tot[2];               /* ... and at the end of the tile                    */
   __shared__ u32 s_tg_col[WGA_TILE + 2]; /* target-row gaps (I ops): start column             */
   __shared__ u32 s_tg_cum[WGA_TILE + 2]; /*                           gap bases before        */
   __shared__ u32 s_qg_col[WGA_TILE + 2]; /* query-row gaps (D ops)                            */
@@ -1294,6 +1296,9 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
   while ((tile_cols >> gsh) >= WGA_TBL_N) gsh++;
   const bool use_tbl = fast;
   const u32 r0 = wave_get_u32(pre, 2);
+  /* op index (tile-relative) where the tile's first record ends; >= nt if it does not end here */
+  const u64 re0 = wave_get_u64(pre, 12);
+  const u32 kb0 = re0 < tile_end ? (u32)(re0 - tile_start) : 0xFFFFFFFFu;
   if (use_tbl)
     for (u32 k = tid; k < WGA_TBL_N + 2u; k += WGA_BLOCK) s_tbl[k] = 0u;
   if (tid < 2u) s_zero2[tid] = 0u;
@@ -1312,6 +1317,9 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
       for (int e = 0; e < 4; e++) opw[e] = (base + e < nt) ? a.ops[tile_start + base + e] : 0u;
     }
   }
+  /* exclusive (column, gap-op counts) prefix at this thread's first op, kept for record boundaries
+   * beyond the first one (per-op prefix arrays would cost 8 KB of LDS and the fifth block per CU) */
+  u32 my_col = 0, my_cnt = 0;
   if (fast) {
     u32 cls[4];
     u32 l[4], sl = 0, si = 0, sd = 0, cnt = 0;
@@ -1330,10 +1338,13 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
     u32 sx[4], stot[4];
     block_excl_scan4_u32(sv, sx, stot, s_w4, true);
     u32 x_col = sx[0], x_i = sx[1], x_d = sx[2], x_cnt = sx[3];
+    my_col = x_col;
+    my_cnt = x_cnt;
     for (int e = 0; e < 4; e++) {
-      u32 k = tid * 4u + (u32)e;
-      s_col[k] = x_col;
-      s_ev[k] = x_cnt;
+      if (tid * 4u + (u32)e == kb0) { /* the tile's first record ends before this op */
+        s_bnd[0][0] = x_col;
+        s_bnd[0][1] = x_cnt;
+      }
       const bool isi = cls[e] == CLS_I, isd = cls[e] == CLS_D;
       if (isi | isd) { /* ONE instance for both kinds of gap op: the body runs once per wave and op slot */
         const u32 len = opw[e] >> 4;
@@ -1350,8 +1361,8 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
       x_col += l[e];
     }
     if (tid == WGA_BLOCK - 1) { /* sentinels: totals (two, so that index i+1 is always readable) */
-      s_col[WGA_TILE] = x_col;
-      s_ev[WGA_TILE] = x_cnt;
+      s_tot[0] = x_col;
+      s_tot[1] = x_cnt;
       s_tg_col[x_cnt & 0xFFFFu] = x_col;
       s_tg_cum[x_cnt & 0xFFFFu] = x_i;
       s_tg_col[(x_cnt & 0xFFFFu) + 1u] = x_col;
@@ -1376,6 +1387,7 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
   u32 r = r0;
   u64 cur = tile_start;
   u64 re = wave_get_u64(pre, 12);
+  u32 bnd_col = 0u, bnd_ev = 0u, nseg = 0u; /* prefix at the start of the current segment */
   while (cur < tile_end) {
     while (re <= cur) {
       r++;
@@ -1415,9 +1427,35 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
     u32 col_a = 0, seg_cols = 0, icum_a = 0, dcum_a = 0;
     int ia = 0, ib = 0, ja = 0, jb = 0;
     if (fast) {
-      col_a = WGA_UNI32(s_col[ka]);
-      seg_cols = WGA_UNI32(s_col[kb]) - col_a;
-      const u32 eva = WGA_UNI32(s_ev[ka]), evb = WGA_UNI32(s_ev[kb]);
+      u32 col_b, evb;
+      if (kb == nt) {
+        col_b = WGA_UNI32(s_tot[0]);
+        evb = WGA_UNI32(s_tot[1]);
+      } else if (nseg == 0u) { /* written in phase A */
+        col_b = WGA_UNI32(s_bnd[0][0]);
+        evb = WGA_UNI32(s_bnd[0][1]);
+      } else { /* a further record ends inside the tile: the owner of op kb rebuilds its prefix */
+        u32* const slot = s_bnd[1u + (nseg & 1u)];
+        if (tid == (kb >> 2)) {
+          u32 c = my_col, n = my_cnt;
+          for (u32 e = 0; e < (kb & 3u); e++) {
+            const u32 op = a.ops[tile_start + (kb & ~3u) + e];
+            const u32 cl = op_class(op & 15u);
+            c += cl <= CLS_D ? (op >> 4) : 0u;
+            n += cl == CLS_I ? 1u : (cl == CLS_D ? 0x10000u : 0u);
+          }
+          slot[0] = c;
+          slot[1] = n;
+        }
+        __syncthreads(); /* uniform: every thread walks the same segments */
+        col_b = WGA_UNI32(slot[0]);
+        evb = WGA_UNI32(slot[1]);
+      }
+      col_a = bnd_col;
+      seg_cols = col_b - col_a;
+      const u32 eva = bnd_ev;
+      bnd_col = col_b;
+      bnd_ev = evb;
       ia = (int)(eva & 0xFFFFu);
       ib = (int)(evb & 0xFFFFu);
       ja = (int)(eva >> 16);
@@ -1547,6 +1585,7 @@ __global__ __launch_bounds__(256, 4) void k_paf2maf_expand(ExpandArgs a) {
     cur = seg_end;
     r++;
     if (cur < tile_end) re = a.op_off[r + 1];
+    nseg++;
     WGA_STAMP(stamp[6] += 1;)
   }
 #ifdef WGA_PROFILE
