@@ -234,9 +234,16 @@ int wga_cigar_stat(wga_ctx* c, const wga_cigar_batch* b, wga_cigar_counts* d_cou
   RT_CHECK(rt_memset(d_diag, 0xFF, (size_t)b->n * sizeof(wga_rec_diag), c->stream));
   u64 nt = n_tiles(b->n_ops);
   if (nt == 0) return WGA_OK;
+  void* ws;
+  if ((rc = ctx_scratch(c, (size_t)nt * sizeof(wga_tile_rec), &ws))) return rc;
+  wga_tile_rec* tile_rec = (wga_tile_rec*)ws;
+  WGA_LAUNCH(k_tile_rec, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const u64*)b->d_op_off,
+             b->d_strand_neg, b->n, (u64)b->n_ops, tile_rec);
+  LAUNCH_CHECK();
   u32 grid = (u32)((nt + 3) / 4);
   WGA_LAUNCH(k_cigar_stat, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off,
-             b->d_strand_neg, b->n, (u64)b->n_ops, d_counts, d_diag, (wga_tile_sum*)d_tile_ws);
+             b->d_strand_neg, b->n, (u64)b->n_ops, (const wga_tile_rec*)tile_rec, d_counts, d_diag,
+             (wga_tile_sum*)d_tile_ws);
   LAUNCH_CHECK();
   return WGA_OK;
 }

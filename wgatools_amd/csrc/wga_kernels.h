@@ -74,6 +74,25 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
   return v;
 }
 
+/* tell the compiler a value is wave-uniform so that it lives in SGPRs (scalar loads, no VGPRs) */
+#ifdef WGA_EMU
+#define WGA_UNI32(x) ((u32)(x))
+#define WGA_UNI64(x) ((u64)(x))
+#else
+#define WGA_UNI32(x) ((u32)__builtin_amdgcn_readfirstlane((int)(x)))
+#define WGA_UNI64(x)                                                               \
+  (((u64)(u32)__builtin_amdgcn_readfirstlane((int)((u64)(x) >> 32)) << 32) |       \
+   (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(u64)(x)))
+#endif
+
+/* keep the computation of a value where it is written (the compiler otherwise sinks LDS reads into
+ * exec-masked branches "to save them", which costs more in branch overhead than the reads) */
+#ifdef WGA_EMU
+#define WGA_PIN(x) ((void)0)
+#else
+#define WGA_PIN(x) asm volatile("" : "+v"(x))
+#endif
+
 /* Inclusive scan of a u32 over the 64 lanes.  On gfx950 this is six DPP adds (row_shr 1/2/4/8
  * inside each 16-lane row, then row_bcast:15 and row_bcast:31 across rows): no LDS crossbar, no
  * index arithmetic — a __shfl_up formulation costs ~5x the VALU work.  Lanes that a step does
@@ -169,10 +188,40 @@ __device__ __forceinline__ u32 wga_find_rec(const u64* off, u32 n, u64 x) {
 /* ============================================================================================ */
 /* K1: PAF stat walk — parse_paf_to_cigar (cigar.rs:629-707) over packed ops                    */
 /* ============================================================================================ */
+/* record that holds the first op of every tile: one thread per tile, plain binary search.  Done
+ * ahead of the walk kernels so that their waves start with one load instead of a chain of
+ * dependent probes. */
+struct wga_tile_rec {
+  u32 rec, neg; /* the record and its strand */
+  u64 rs, re;   /* op_off[rec], op_off[rec + 1] */
+};
+__global__ __launch_bounds__(256) void k_tile_rec(const u64* __restrict__ op_off,
+                                                  const u8* __restrict__ strand_neg, u32 n, u64 n_ops,
+                                                  wga_tile_rec* __restrict__ tile_rec) {
+  const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
+  const u64 x = g * WGA_TILE;
+  if (x >= n_ops) return;
+  u32 lo = 0, hi = n; /* last r with op_off[r] <= x; op_off[0] == 0, op_off[n] == n_ops > x */
+  while (hi - lo > 1u) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if (op_off[mid] <= x)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  wga_tile_rec t;
+  t.rec = lo;
+  t.neg = strand_neg[lo] != 0 ? 1u : 0u;
+  t.rs = op_off[lo];
+  t.re = op_off[lo + 1];
+  tile_rec[g] = t;
+}
+
 __global__ __launch_bounds__(256) void k_cigar_stat(const u32* __restrict__ ops,
                                                     const u64* __restrict__ op_off,
                                                     const u8* __restrict__ strand_neg, u32 n,
-                                                    u64 n_ops, wga_cigar_counts* counts,
+                                                    u64 n_ops, const wga_tile_rec* __restrict__ tile_rec,
+                                                    wga_cigar_counts* counts,
                                                     wga_rec_diag* diag, wga_tile_sum* tiles) {
   const u32 lane = threadIdx.x & 63u;
   const u32 wave = threadIdx.x >> 6;
@@ -200,56 +249,84 @@ __global__ __launch_bounds__(256) void k_cigar_stat(const u32* __restrict__ ops,
     }
   }
 
-  u32 r = wga_find_rec(op_off, n, tile_start);
+  /* the first segment's record, bounds and strand arrive with the ops (k_tile_rec); later
+   * segments — records that start inside the tile — load theirs */
+  const wga_tile_rec tr = tile_rec[g];
+  u32 r = WGA_UNI32(tr.rec);
   const u32 r_first = r;
   u64 cur = tile_start;
   u64 tot[5] = {0, 0, 0, 0, 0}, tail[5] = {0, 0, 0, 0, 0};
+  u64 re = WGA_UNI64(tr.re);
   while (cur < tile_end) {
-    u64 re = op_off[r + 1];
     while (re <= cur) { /* skip empty records */
       r++;
       re = op_off[r + 1];
     }
-    const u64 rs = op_off[r];
+    const bool first = r == r_first;
+    const u64 rs = first ? WGA_UNI64(tr.rs) : op_off[r];
+    const bool neg = first ? (WGA_UNI32(tr.neg) != 0u) : (strand_neg[r] != 0);
     const u64 seg_end = re < tile_end ? re : tile_end;
     const u32 a = (u32)(cur - tile_start), b = (u32)(seg_end - tile_start);
 
-    /* per-lane partials: 16 ops * (2^28-1) < 2^32, so u32 is exact */
-    u32 s[5] = {0, 0, 0, 0, 0};
-    u32 s_match = 0; /* M,= only (X is the rest of CLS_MX) */
-    u32 ev = 0;      /* ins events | del events << 16 */
+    /* per-lane partials: 16 ops * (2^28-1) < 2^32, so u32 is exact.  Ops outside the segment are
+     * first turned into 0M (neutral), so that ONE short loop serves whole-tile and partial
+     * segments alike; S / other ops and the first bad op are only worked out when a wave vote
+     * says the segment holds any (they end the run with an error anyway). */
+    u32 wm[16];
+    if (a == 0u && b == nt) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) wm[k] = w[k];
+    } else {
+      const u32 span = b - a;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const u32 idx = ((u32)(k >> 2) * 64u + lane) * 4u + (u32)(k & 3);
+        wm[k] = (idx - a < span) ? w[k] : 0u;
+      }
+    }
+    u32 s_mx = 0, s_i = 0, s_d = 0, s_s = 0, s_o = 0;
+    u32 s_x = 0;  /* X only: match = s_mx - s_x */
+    u32 ev = 0;   /* ins events | del events << 16 */
     u32 bad = 0xFFFFFFFFu;
+    u32 rare = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int k = 0; k < 16; k++) {
+      const u32 op = wm[k];
+      const u32 code = op & 15u, len = op >> 4;
+      const u32 cls = op_class(code);
+      s_mx += cls == CLS_MX ? len : 0u;
+      s_i += cls == CLS_I ? len : 0u;
+      s_d += cls == CLS_D ? len : 0u;
+      s_x += code == WGA_OP_X ? len : 0u;
+      ev += code == WGA_OP_I ? 1u : 0u;
+      ev += code == WGA_OP_D ? 0x10000u : 0u;
+      rare |= cls >= CLS_S ? 1u : 0u;
+    }
+    const bool any_rare = __ballot(rare != 0u) != 0ull;
+    if (any_rare) {
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        u32 idx = ((u32)j * 64u + lane) * 4u + (u32)e;
-        u32 op = w[4 * j + e];
-        u32 code = op & 15u, len = op >> 4;
-        bool in = idx >= a && idx < b;
-        u32 cls = op_class(code);
-        u32 l = in ? len : 0u;
-        s[0] += cls == CLS_MX ? l : 0u;
-        s[1] += cls == CLS_I ? l : 0u;
-        s[2] += cls == CLS_D ? l : 0u;
-        s[3] += cls == CLS_S ? l : 0u;
-        s[4] += cls == CLS_O ? l : 0u;
-        s_match += (code == WGA_OP_M || code == WGA_OP_EQ) ? l : 0u;
-        ev += (in && code == WGA_OP_I) ? 1u : 0u;
-        ev += (in && code == WGA_OP_D) ? 0x10000u : 0u;
-        bool isbad = in && (cls == CLS_S || cls == CLS_O);
-        bad = (isbad && idx < bad) ? idx : bad;
+      for (int k = 0; k < 16; k++) {
+        const u32 idx = ((u32)(k >> 2) * 64u + lane) * 4u + (u32)(k & 3);
+        u32 op = wm[k];
+        WGA_PIN(op); /* opaque: no sharing of compare masks with the loop above */
+        const u32 cls = op_class(op & 15u), len = op >> 4;
+        s_s += cls == CLS_S ? len : 0u;
+        s_o += cls == CLS_O ? len : 0u;
+        bad = (cls >= CLS_S && idx < bad) ? idx : bad;
       }
     }
     u64 S[5];
-#pragma unroll
-    for (int c = 0; c < 5; c++) S[c] = wave_sum_u32_wide(s[c]);
-    const u64 Smatch = wave_sum_u32_wide(s_match);
+    S[0] = wave_sum_u32_wide(s_mx);
+    S[1] = wave_sum_u32_wide(s_i);
+    S[2] = wave_sum_u32_wide(s_d);
+    const u64 Sx = wave_sum_u32_wide(s_x);
     const u32 EV = wave_sum_u32(ev);
-    const u32 BAD = wave_min_u32(bad);
+    S[3] = any_rare ? wave_sum_u32_wide(s_s) : 0ull;
+    S[4] = any_rare ? wave_sum_u32_wide(s_o) : 0ull;
+    const u32 BAD = any_rare ? wave_min_u32(bad) : 0xFFFFFFFFu;
+    const u64 Smatch = S[0] - Sx;
 
     if (lane == 0) {
-      const bool neg = strand_neg[r] != 0;
       const bool whole = rs >= tile_start && re <= tile_end;
       const u64 match = Smatch, mism = S[0] - Smatch;
       const u64 iev = EV & 0xFFFFu, dev = EV >> 16;
@@ -286,6 +363,7 @@ __global__ __launch_bounds__(256) void k_cigar_stat(const u32* __restrict__ ops,
     }
     cur = seg_end;
     r++;
+    if (cur < tile_end) re = op_off[r + 1];
   }
   if (tiles && lane == 0) {
     wga_tile_sum ts;
@@ -689,25 +767,6 @@ __device__ __forceinline__ u32 wave_get_u32(u32 v, int k) {
   return (u32)__builtin_amdgcn_readlane((int)v, k);
 #endif
 }
-
-/* keep the computation of a value where it is written (the compiler otherwise sinks LDS reads into
- * exec-masked branches "to save them", which costs more in branch overhead than the reads) */
-#ifdef WGA_EMU
-#define WGA_PIN(x) ((void)0)
-#else
-#define WGA_PIN(x) asm volatile("" : "+v"(x))
-#endif
-
-/* tell the compiler a value is wave-uniform so that it lives in SGPRs (scalar loads, no VGPRs) */
-#ifdef WGA_EMU
-#define WGA_UNI32(x) ((u32)(x))
-#define WGA_UNI64(x) ((u64)(x))
-#else
-#define WGA_UNI32(x) ((u32)__builtin_amdgcn_readfirstlane((int)(x)))
-#define WGA_UNI64(x)                                                               \
-  (((u64)(u32)__builtin_amdgcn_readfirstlane((int)((u64)(x) >> 32)) << 32) |       \
-   (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(u64)(x)))
-#endif
 
 #ifdef WGA_EMU
 #define WGA_CLOCK() 0ull
