@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void k_tile_rec(const u64* __restrict__ op_off
   tile_rec[g] = t;
 }
 
-__global__ __launch_bounds__(256) void k_cigar_stat(const u32* __restrict__ ops,
+__global__ __launch_bounds__(256, 5) void k_cigar_stat(const u32* __restrict__ ops,
                                                     const u64* __restrict__ op_off,
                                                     const u8* __restrict__ strand_neg, u32 n,
                                                     u64 n_ops, const wga_tile_rec* __restrict__ tile_rec,
@@ -269,21 +269,10 @@ __global__ __launch_bounds__(256) void k_cigar_stat(const u32* __restrict__ ops,
     const u32 a = (u32)(cur - tile_start), b = (u32)(seg_end - tile_start);
 
     /* per-lane partials: 16 ops * (2^28-1) < 2^32, so u32 is exact.  Ops outside the segment are
-     * first turned into 0M (neutral), so that ONE short loop serves whole-tile and partial
+     * turned into 0M (neutral) on the fly, so that ONE short loop serves whole-tile and partial
      * segments alike; S / other ops and the first bad op are only worked out when a wave vote
      * says the segment holds any (they end the run with an error anyway). */
-    u32 wm[16];
-    if (a == 0u && b == nt) {
-#pragma unroll
-      for (int k = 0; k < 16; k++) wm[k] = w[k];
-    } else {
-      const u32 span = b - a;
-#pragma unroll
-      for (int k = 0; k < 16; k++) {
-        const u32 idx = ((u32)(k >> 2) * 64u + lane) * 4u + (u32)(k & 3);
-        wm[k] = (idx - a < span) ? w[k] : 0u;
-      }
-    }
+    const u32 span = b - a, lane4 = lane * 4u;
     u32 s_mx = 0, s_i = 0, s_d = 0, s_s = 0, s_o = 0;
     u32 s_x = 0;  /* X only: match = s_mx - s_x */
     u32 ev = 0;   /* ins events | del events << 16 */
@@ -291,7 +280,8 @@ __global__ __launch_bounds__(256) void k_cigar_stat(const u32* __restrict__ ops,
     u32 rare = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      const u32 op = wm[k];
+      const u32 idx = (u32)(k >> 2) * 256u + (u32)(k & 3) + lane4;
+      const u32 op = (idx - a < span) ? w[k] : 0u;
       const u32 code = op & 15u, len = op >> 4;
       const u32 cls = op_class(code);
       s_mx += cls == CLS_MX ? len : 0u;
@@ -306,8 +296,8 @@ __global__ __launch_bounds__(256) void k_cigar_stat(const u32* __restrict__ ops,
     if (any_rare) {
 #pragma unroll
       for (int k = 0; k < 16; k++) {
-        const u32 idx = ((u32)(k >> 2) * 64u + lane) * 4u + (u32)(k & 3);
-        u32 op = wm[k];
+        const u32 idx = (u32)(k >> 2) * 256u + (u32)(k & 3) + lane4;
+        u32 op = (idx - a < span) ? w[k] : 0u;
         WGA_PIN(op); /* opaque: no sharing of compare masks with the loop above */
         const u32 cls = op_class(op & 15u), len = op >> 4;
         s_s += cls == CLS_S ? len : 0u;
