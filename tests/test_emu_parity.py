@@ -195,7 +195,7 @@ def test_maf_pair_stat(emu):
         except Exception:
             pass
     # ... and free-form rows: '-'/'-' columns count as '=', case matters, unequal lengths zip
-    for L in (0, 1, 63, 64, 65, 200, 1000):
+    for L in (0, 1, 15, 16, 17, 63, 64, 65, 200, 1000, 1023, 1024, 1025, 1041, 2100):
         t = pc.rand_seq(rng, L, b"ACGTacgt--N")
         q = pc.rand_seq(rng, L + int(rng.integers(0, 3)), b"ACGTacgt--N")
         pairs.append((t, q))

@@ -215,7 +215,7 @@ def test_maf_pair_stat(gpu):
     for i in range(40):
         pairs.append(pc.oracle_rows(b, i))
         strands.append(int(b["strand_neg"][i]))
-    for L in (0, 1, 63, 64, 65, 200, 1000, 100000):
+    for L in (0, 1, 15, 16, 17, 63, 64, 65, 200, 1000, 1023, 1024, 1025, 1041, 2100, 100000):
         pairs.append((pc.rand_seq(rng, L, b"ACGTacgt--N"), pc.rand_seq(rng, L + int(rng.integers(0, 3)), b"ACGTacgt--N")))
         strands.append(L & 1)
     from helpers import GOLDEN, read_maf_blocks

@@ -611,12 +611,192 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
 }
 
 /* ============================================================================================ */
-/* K3: MAF column-pair walk                                                                     */
+/* K3 / K4: MAF column-pair walks                                                               */
 /* ============================================================================================ */
-/* One wave per record; column c is handled by lane c % 64 so that the run boundary test needs
- * one __shfl_up.  cigar_cat_ext (cigar.rs:298-308): equal bytes -> '=' (also '-','-', and
- * case-sensitive), else target gap -> I, else query gap -> D, else X.  Events are run starts.
- * Run list entry: start_col << 3 | class (0 '=', 1 I, 2 D, 3 X); lengths are differences. */
+/* One wave per record, 16 columns per lane and step (one byte-unaligned 16 B load per row, 1 KiB
+ * per row and wave instruction).  Columns are classified four at a time on packed bytes: a byte
+ * test leaves 0x80 in every byte that satisfies it, classes are small integers kept one per byte,
+ * run starts are the bytes whose class differs from the byte before (the previous lane's last
+ * class comes by DPP / shuffle, the previous step's by a carried value).  Counting is popcount;
+ * only the few run starts are walked bit by bit.
+ *   K3  cigar_cat_ext (cigar.rs:298-308): equal bytes -> '=' (also '-','-'; case-sensitive), else
+ *       target gap -> I, else query gap -> D, else X.  Run entry = start_col << 3 | class
+ *       (0 '=', 1 I, 2 D, 3 X).
+ *   K4  cigar_cat_ext_caller (cigar.rs:314-328): gap tests first, so '-','-' is its own class W
+ *       and splits runs.  Run entry = 3 u64: start_col << 3 | class (0 '=', 1 I, 2 D, 3 X, 4 W),
+ *       non-gap target characters before the run, non-gap query characters before it. */
+__device__ __forceinline__ u32 zero_bytes(u32 x) { /* 0x80 in every byte of x that is 0 (exact) */
+  return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+}
+__device__ __forceinline__ u32 popc32(u32 x) { return (u32)__builtin_popcount(x); }
+
+struct MafWalkOut {
+  u64 ncol[5], nrun[5]; /* columns / runs per class (wave totals, valid in every lane) */
+  u64 runs;             /* runs in all */
+};
+
+template <bool CALLER>
+__device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __restrict__ q, u64 L,
+                                         u64* rout, MafWalkOut& out) {
+  const u32 lane = threadIdx.x & 63u;
+  constexpr int NC = CALLER ? 5 : 4;
+  u32 ncol[NC], nrun[NC];
+  u64 ncol_hi[NC];
+#pragma unroll
+  for (int k = 0; k < NC; k++) ncol[k] = nrun[k] = 0u, ncol_hi[k] = 0ull;
+  u32 carry_cls = 0xFFu; /* class of the column before this step's first one */
+  u64 run_base = 0, t_base = 0, q_base = 0;
+  u32 steps = 0;
+  for (u64 c0 = 0; c0 < L; c0 += 1024) {
+    const u64 c = c0 + (u64)lane * 16u;
+    const u32 nv = c >= L ? 0u : (L - c >= 16u ? 16u : (u32)(L - c)); /* valid columns of this lane */
+    u32 tw[4] = {0u, 0u, 0u, 0u}, qw[4] = {0u, 0u, 0u, 0u};
+    if (nv == 16u) {
+      const u32x4_a1 a = *(const u32x4_a1*)(t + c), b = *(const u32x4_a1*)(q + c);
+#pragma unroll
+      for (int d = 0; d < 4; d++) tw[d] = a[d], qw[d] = b[d];
+    } else if (nv) { /* the record's last, partial piece: never read beyond the row */
+      for (u32 j = 0; j < nv; j++) {
+        tw[j >> 2] |= (u32)t[c + j] << (8u * (j & 3u));
+        qw[j >> 2] |= (u32)q[c + j] << (8u * (j & 3u));
+      }
+    }
+    u32 cls[4], st[4], tn[4], qn[4], vm[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const int lo = 4 * d;
+      vm[d] = nv >= (u32)lo + 4u ? 0x80808080u : (nv > (u32)lo ? (0x80808080u >> (8u * (4u - (nv - (u32)lo)))) : 0u);
+      const u32 eq = zero_bytes(tw[d] ^ qw[d]);
+      const u32 tg = zero_bytes(tw[d] ^ 0x2D2D2D2Du), qg = zero_bytes(qw[d] ^ 0x2D2D2D2Du);
+      u32 cI, cD, cX, cW = 0u;
+      if (CALLER) {
+        cW = tg & qg;
+        cI = tg & ~qg;
+        cD = qg & ~tg;
+        cX = ~(eq | tg | qg) & 0x80808080u;
+      } else {
+        cI = tg & ~eq;
+        cD = qg & ~eq;
+        cX = ~(eq | tg | qg) & 0x80808080u;
+      }
+      cls[d] = (cI >> 7) | (cD >> 6) | ((cX >> 7) * 3u) | (cW >> 5); /* 0..4 in every byte */
+      tn[d] = ~tg & vm[d];
+      qn[d] = ~qg & vm[d];
+      ncol[1] += popc32(cI & vm[d]);
+      ncol[2] += popc32(cD & vm[d]);
+      ncol[3] += popc32(cX & vm[d]);
+      if (CALLER) ncol[4] += popc32(cW & vm[d]);
+    }
+    ncol[0] += nv;
+    /* class of the column before each byte: bytes shifted up by one across the 16-byte vector */
+    const u32 my_last = nv ? ((cls[(nv - 1u) >> 2] >> (8u * ((nv - 1u) & 3u))) & 0xFFu) : 0xFEu;
+    u32 prev_last = __shfl_up(my_last, 1u);
+    if (lane == 0) prev_last = carry_cls;
+    u32 nst = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const u32 below = d == 0 ? prev_last : (cls[d - 1] >> 24);
+      const u32 prev = (cls[d] << 8) | (below & 0xFFu);
+      st[d] = ~zero_bytes(cls[d] ^ prev) & vm[d]; /* 0x80 where a run starts */
+      nst += popc32(st[d]);
+    }
+    /* per-class run starts: a start byte's class */
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const u32 s7 = st[d] >> 7; /* 1 in the low bit of start bytes */
+      const u32 k = cls[d];
+      nrun[1] += popc32(s7 & k & ~(k >> 1) & ~(k >> 2) & 0x01010101u);          /* class 1: 001 */
+      nrun[2] += popc32(s7 & (k >> 1) & ~k & 0x01010101u);                     /* class 2: 010 */
+      nrun[3] += popc32(s7 & (k >> 1) & k & 0x01010101u);                      /* class 3: 011 */
+      if (CALLER) nrun[4] += popc32(s7 & (k >> 2) & 0x01010101u);              /* class 4: 100 */
+    }
+    nrun[0] += nst;
+    /* ordered run list: wave-exclusive offsets of the per-lane start counts */
+    const u32 incl = wave_incl_scan_u32(nst);
+    const u32 tnc = popc32(tn[0]) + popc32(tn[1]) + popc32(tn[2]) + popc32(tn[3]);
+    const u32 qnc = popc32(qn[0]) + popc32(qn[1]) + popc32(qn[2]) + popc32(qn[3]);
+    u32 t_excl = 0, q_excl = 0, t_tot = 0, q_tot = 0;
+    if (CALLER) {
+      const u32 ti = wave_incl_scan_u32(tnc), qi = wave_incl_scan_u32(qnc);
+      t_excl = ti - tnc;
+      q_excl = qi - qnc;
+      t_tot = wave_last_u32(ti);
+      q_tot = wave_last_u32(qi);
+    }
+    if (rout && nst) {
+      u64 slot = run_base + (u64)(incl - nst);
+      u32 tb = 0, qb = 0; /* non-gap bytes of this lane before the dword being walked */
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        u32 m = st[d];
+        while (m) {
+          const u32 bit = (u32)__builtin_ctz(m); /* 7, 15, 23 or 31 */
+          const u32 j = bit >> 3;
+          const u32 k = (cls[d] >> (8u * j)) & 7u;
+          const u64 col = c + 4u * (u32)d + j;
+          if (CALLER) {
+            const u32 bm = (1u << bit) - 1u; /* bytes below j */
+            u64* e = rout + 3 * slot;
+            e[0] = (col << 3) | (u64)k;
+            e[1] = t_base + t_excl + tb + popc32(tn[d] & bm);
+            e[2] = q_base + q_excl + qb + popc32(qn[d] & bm);
+          } else {
+            rout[slot] = (col << 3) | (u64)k;
+          }
+          slot++;
+          m &= m - 1u;
+        }
+        tb += popc32(tn[d]);
+        qb += popc32(qn[d]);
+      }
+    }
+    run_base += (u64)wave_last_u32(incl);
+    t_base += t_tot;
+    q_base += q_tot;
+    /* the last valid column of this step is in the last lane that has any */
+    const u64 has = __ballot(nv != 0u);
+    const int last_lane = 63 - (int)__builtin_clzll(has); /* has != 0 inside the loop */
+    carry_cls = __shfl(my_last, last_lane);
+    if (++steps == 0x00100000u) { /* keep the u32 lane counters from wrapping (16 per step) */
+#pragma unroll
+      for (int k = 0; k < NC; k++) ncol_hi[k] += ncol[k], ncol[k] = 0u;
+      steps = 0;
+    }
+  }
+  /* class 0 columns / runs = all minus the others */
+  u64 C[NC], R[NC];
+  if (L < 65536u) { /* every wave total fits 16 bits: two quantities per scan */
+    const u32 a0 = wave_sum_u32(ncol[0] | (nrun[0] << 16));
+    const u32 a1 = wave_sum_u32(ncol[1] | (ncol[2] << 16));
+    const u32 a2 = wave_sum_u32(nrun[1] | (nrun[2] << 16));
+    const u32 a3 = wave_sum_u32(ncol[3] | (nrun[3] << 16));
+    C[0] = a0 & 0xFFFFu, R[0] = a0 >> 16;
+    C[1] = a1 & 0xFFFFu, C[2] = a1 >> 16;
+    R[1] = a2 & 0xFFFFu, R[2] = a2 >> 16;
+    C[3] = a3 & 0xFFFFu, R[3] = a3 >> 16;
+    if (CALLER) {
+      const u32 a4 = wave_sum_u32(ncol[NC - 1] | (nrun[NC - 1] << 16));
+      C[NC - 1] = a4 & 0xFFFFu, R[NC - 1] = a4 >> 16;
+    }
+  } else {
+    const bool spilled = L >= (u64)0x00100000u * 1024u; /* the lane counters were folded at least once */
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+      C[k] = wave_sum_u32_wide(ncol[k]) + (spilled ? wave_sum_u64(ncol_hi[k]) : 0ull);
+      R[k] = wave_sum_u32_wide(nrun[k]);
+    }
+  }
+  u64 oc = 0, orn = 0;
+#pragma unroll
+  for (int k = 1; k < NC; k++) oc += C[k], orn += R[k];
+  out.ncol[0] = C[0] - oc;
+  out.nrun[0] = R[0] - orn;
+#pragma unroll
+  for (int k = 1; k < NC; k++) out.ncol[k] = C[k], out.nrun[k] = R[k];
+  if (!CALLER) out.ncol[4] = out.nrun[4] = 0;
+  out.runs = run_base;
+}
+
 __global__ __launch_bounds__(256) void k_maf_pair_stat(u32 n, const u8* __restrict__ rows,
                                                        const u64* t_off, const u64* q_off,
                                                        const u64* cols, const u8* strand_neg,
@@ -625,87 +805,27 @@ __global__ __launch_bounds__(256) void k_maf_pair_stat(u32 n, const u8* __restri
   const u32 lane = threadIdx.x & 63u;
   const u64 i = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
-  const u8* t = rows + t_off[i];
-  const u8* q = rows + q_off[i];
-  const u64 L = cols[i];
-  u64* rout = runs ? runs + run_off[i] : (u64*)0;
-  u32 ncol[4] = {0, 0, 0, 0}, nrun[4] = {0, 0, 0, 0}; /* per lane: < 2^32 for L < 2^38 */
-  u64 ncol_hi[4] = {0, 0, 0, 0};
-  u32 carry_cls = 0xFFu; /* class of the column before this iteration's lane 0 */
-  u64 run_base = 0;
-  u32 it_in_acc = 0;
-  for (u64 c0 = 0; c0 < L; c0 += 64) {
-    const u64 c = c0 + lane;
-    const bool in = c < L;
-    u32 cls = 0xFEu;
-    if (in) {
-      u8 c1 = t[c], c2 = q[c];
-      cls = (c1 == c2) ? 0u : (c1 == (u8)'-') ? 1u : (c2 == (u8)'-') ? 2u : 3u;
-    }
-    u32 prev = __shfl_up(cls, 1u);
-    if (lane == 0) prev = carry_cls;
-    const bool start = in && cls != prev;
-    if (in) {
-      ncol[0] += cls == 0u;
-      ncol[1] += cls == 1u;
-      ncol[2] += cls == 2u;
-      ncol[3] += cls == 3u;
-    }
-    if (start) {
-      nrun[0] += cls == 0u;
-      nrun[1] += cls == 1u;
-      nrun[2] += cls == 2u;
-      nrun[3] += cls == 3u;
-    }
-    const u64 m = __ballot(start);
-    if (rout && start) {
-      u64 below = m & ((1ull << lane) - 1ull);
-      rout[run_base + (u64)__popcll(below)] = (c << 3) | (u64)cls;
-    }
-    run_base += (u64)__popcll(m);
-    carry_cls = __shfl(cls, 63);
-    if (++it_in_acc == 0x40000000u) { /* keep the u32 lane counters from wrapping */
-      for (int k = 0; k < 4; k++) {
-        ncol_hi[k] += ncol[k];
-        ncol[k] = 0;
-      }
-      it_in_acc = 0;
-    }
-  }
-  u64 C[4], R[4];
-  for (int k = 0; k < 4; k++) {
-    C[k] = wave_sum_u64(ncol_hi[k] + ncol[k]);
-    R[k] = wave_sum_u64((u64)nrun[k]);
-  }
+  MafWalkOut w;
+  maf_walk<false>(rows + t_off[i], rows + q_off[i], cols[i], runs ? runs + run_off[i] : (u64*)0, w);
   if (lane == 0) {
     const bool neg = strand_neg[i] != 0;
     wga_cigar_counts o;
-    o.match = C[0];
-    o.mismatch = C[3];
-    o.ins_ev = neg ? 0 : R[1];
-    o.ins_bp = neg ? 0 : C[1];
-    o.del_ev = neg ? 0 : R[2];
-    o.del_bp = neg ? 0 : C[2];
-    o.inv_ins_ev = neg ? R[1] : 0;
-    o.inv_ins_bp = neg ? C[1] : 0;
-    o.inv_del_ev = neg ? R[2] : 0;
-    o.inv_del_bp = neg ? C[2] : 0;
+    o.match = w.ncol[0];
+    o.mismatch = w.ncol[3];
+    o.ins_ev = neg ? 0 : w.nrun[1];
+    o.ins_bp = neg ? 0 : w.ncol[1];
+    o.del_ev = neg ? 0 : w.nrun[2];
+    o.del_bp = neg ? 0 : w.ncol[2];
+    o.inv_ins_ev = neg ? w.nrun[1] : 0;
+    o.inv_ins_bp = neg ? w.ncol[1] : 0;
+    o.inv_del_ev = neg ? w.nrun[2] : 0;
+    o.inv_del_bp = neg ? w.ncol[2] : 0;
     o.inv_ev = neg ? 1 : 0;
     counts[i] = o;
-    if (run_cnt) run_cnt[i] = run_base;
+    if (run_cnt) run_cnt[i] = w.runs;
   }
 }
 
-/* ============================================================================================ */
-/* K4: MAF call column walk                                                                     */
-/* ============================================================================================ */
-/* Same wave-per-record walk as K3 with the caller's classes (cigar_cat_ext_caller,
- * cigar.rs:314-328: gap tests first, so '-','-' is its own class W and splits runs).  Besides
- * its start column every run carries the number of non-gap target / query characters before
- * it, which is all the host needs for coordinates (caller.rs:399-400,457-458), for REF / ALT
- * slices (the anchor of an I / D run is the column before it) and for the chunk geometry of
- * find_safe_chunk_boundary / create_chunk_record (caller.rs:159-265).
- * Run entry = 3 u64: start_column << 3 | class (0 '=', 1 I, 2 D, 3 X, 4 W), t_before, q_before. */
 __global__ __launch_bounds__(256) void k_maf_call_runs(u32 n, const u8* __restrict__ rows,
                                                        const u64* t_off, const u64* q_off,
                                                        const u64* cols, u64* run_cnt, u64* runs,
@@ -713,40 +833,9 @@ __global__ __launch_bounds__(256) void k_maf_call_runs(u32 n, const u8* __restri
   const u32 lane = threadIdx.x & 63u;
   const u64 i = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
-  const u8* t = rows + t_off[i];
-  const u8* q = rows + q_off[i];
-  const u64 L = cols[i];
-  u64* rout = runs ? runs + 3 * run_off[i] : (u64*)0;
-  u32 carry_cls = 0xFFu;
-  u64 run_base = 0, t_base = 0, q_base = 0;
-  for (u64 c0 = 0; c0 < L; c0 += 64) {
-    const u64 c = c0 + lane;
-    const bool in = c < L;
-    u32 cls = 0xFEu;
-    bool tn = false, qn = false;
-    if (in) {
-      const u8 c1 = t[c], c2 = q[c];
-      tn = c1 != (u8)'-';
-      qn = c2 != (u8)'-';
-      cls = !tn ? (!qn ? 4u : 1u) : (!qn ? 2u : (c1 == c2 ? 0u : 3u));
-    }
-    u32 prev = __shfl_up(cls, 1u);
-    if (lane == 0) prev = carry_cls;
-    const bool start = in && cls != prev;
-    const u64 m = __ballot(start), mt = __ballot(tn), mq = __ballot(qn);
-    const u64 below = (1ull << lane) - 1ull;
-    if (rout && start) {
-      u64* e = rout + 3 * (run_base + (u64)__popcll(m & below));
-      e[0] = (c << 3) | (u64)cls;
-      e[1] = t_base + (u64)__popcll(mt & below);
-      e[2] = q_base + (u64)__popcll(mq & below);
-    }
-    run_base += (u64)__popcll(m);
-    t_base += (u64)__popcll(mt);
-    q_base += (u64)__popcll(mq);
-    carry_cls = __shfl(cls, 63);
-  }
-  if (lane == 0 && run_cnt) run_cnt[i] = run_base;
+  MafWalkOut w;
+  maf_walk<true>(rows + t_off[i], rows + q_off[i], cols[i], runs ? runs + 3 * run_off[i] : (u64*)0, w);
+  if (lane == 0 && run_cnt) run_cnt[i] = w.runs;
 }
 
 /* ============================================================================================ */
