@@ -134,6 +134,22 @@ int wga_cigar_pack(const char* text, size_t len, uint32_t* ops, size_t cap, size
 /* Upper bound of ops wga_cigar_pack can emit for `len` bytes of text. */
 size_t wga_cigar_pack_bound(const char* text, size_t len);
 
+/* ---- device tokeniser: the same text -> packed ops conversion as wga_cigar_pack, for callers that
+ *      keep the CIGAR text on the device (the host tokeniser is the floor of
+ *      every end-to-end run).  Record i's text (after the tag) is d_text[d_text_off[i] ..
+ *      d_text_off[i+1]).  Two calls: with d_ops == NULL it fills d_op_cnt[n] (ops the record packs
+ *      to, up to its first tokeniser error) and d_err[n]; after an exclusive scan of the counts the
+ *      second call writes the ops at d_ops + d_op_off[i].  Error codes, token offsets and the
+ *      splitting of lengths >= 2^28 are those of wga_cigar_pack. */
+typedef struct {
+  int32_t err;      /* wga_rec_err */
+  uint32_t tok_len; /* offending token inside the record's text: length ... */
+  uint64_t tok_off; /* ... and offset */
+} wga_tok_err;
+int wga_cigar_tokenise(wga_ctx*, uint32_t n, const uint8_t* d_text, const uint64_t* d_text_off,
+                       uint64_t* d_op_cnt, wga_tok_err* d_err, uint32_t* d_ops,
+                       const uint64_t* d_op_off);
+
 /* ---- K1: PAF stat walk (replaces parse_paf_to_cigar, cigar.rs:629-707) ----------------------
  * d_counts[n]; d_diag[n] (bad_op_idx set for ops other than M = X I D).
  * d_tile_ws (optional, may be NULL): wga_tile_ws_bytes(n_ops) bytes, filled with the per-tile

@@ -1,0 +1,59 @@
+"""throughput of the remaining op-stream kernels (K5 pafcov, K6 pafpseudo, K7 PAF call events) on the
+BASELINE configs[1] batch (100 000 records x mean 5 kop)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from wgatools_amd import engine, synth
+
+nrec = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+dev = torch.device("cuda", 0)
+tb = synth.make_paf_batch_torch(0x5747415F + 2, nrec, 5000, 50_000_000, dev)
+eng = engine.Engine(0)
+eng.set_stream(torch.cuda.current_stream().cuda_stream)
+batch = engine.Batch(tb["ops"], tb["op_off"], tb["strand_neg"], tb["n"], tb["n_ops"])
+n, n_ops = tb["n"], tb["n_ops"]
+
+def timed(f, reps=5):
+    f(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): f()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+# ---- K5 pafcov: one 50 Mb target -----------------------------------------------------------------
+tlen = int(tb["t_pool"].numel())
+cov = torch.zeros(tlen + 1, dtype=torch.int32, device=dev)
+target_id = torch.zeros(n, dtype=torch.int32, device=dev)
+cov_off = torch.zeros(1, dtype=torch.int64, device=dev)
+cov_len = torch.full((1,), tlen, dtype=torch.int64, device=dev)
+ms_a = timed(lambda: eng.pafcov_accumulate(batch, target_id, tb["t_src_off"], cov_off, cov_len, cov))
+ms_f = timed(lambda: eng.pafcov_finalize(1, cov_off, cov_len, cov))
+n_meq = int(((tb["ops"] & 15) == 7).sum().item() + ((tb["ops"] & 15) == 0).sum().item())
+print("K5 pafcov accumulate: %.3f ms  %.0f GB/s (4 B/op + 2 x 4 B atomics per M/= op: %.2e such ops)" % (ms_a, (4 * n_ops + 8 * n_meq) / ms_a / 1e6, n_meq))
+print("K5 pafcov finalize  : %.3f ms  %.0f GB/s (8 B per target base, %d bases)" % (ms_f, 8 * tlen / ms_f / 1e6, tlen))
+# ---- K6 pafpseudo -----------------------------------------------------------------------------------
+cs = torch.zeros((n, 5), dtype=torch.int64, device=dev)
+eng.cigar_class_sums(batch, sums=cs)
+seg = (cs[:, 0] + cs[:, 2])
+dst_off = torch.zeros(n, dtype=torch.int64, device=dev)
+dst_off[1:] = torch.cumsum(seg, 0)[:-1]
+total = int(seg.sum().item())
+out = torch.zeros(total + 64, dtype=torch.uint8, device=dev)
+skip = torch.zeros(n, dtype=torch.int64, device=dev)
+for mode in (0, 1):
+    ms = timed(lambda: eng.pafpseudo_fill(batch, mode, tb["q_pool"], int(tb["q_pool"].numel()), tb["q_src_off"], tb["q_src_len"], skip, out, dst_off))
+    rd = 4 * n_ops + (int(tb["q_src_len"].sum().item()) if mode else 0)
+    print("K6 pafpseudo %s : %.3f ms  %.0f GB/s (4 B/op%s + %d B written)" % ("base  " if mode else "symbol", ms, (rd + total) / ms / 1e6, " + query bases" if mode else "", total))
+# ---- K7 PAF call events -----------------------------------------------------------------------------
+for svlen, snp in ((50, 1), (0, 0)):
+    cnt = torch.zeros(n, dtype=torch.int64, device=dev)
+    ms_c = timed(lambda: eng.paf_call_events(batch, svlen, snp, ev_cnt=cnt))
+    off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    eng.exclusive_scan_u64(n, cnt, off)
+    ne = int(off[-1].item())
+    ev = torch.zeros(3 * ne + 3, dtype=torch.int64, device=dev)
+    ms_e = timed(lambda: eng.paf_call_events(batch, svlen, snp, ev_cnt=cnt, ev=ev, ev_off=off))
+    print("K7 call events svlen=%d snp=%d: count %.3f ms %.0f GB/s; fill %.3f ms %.0f GB/s (4 B/op + 24 B x %d events)" % (
+        svlen, snp, ms_c, 4 * n_ops / ms_c / 1e6, ms_e, (4 * n_ops + 24 * ne) / ms_e / 1e6, ne))
+print("records %d ops %.3e" % (n, n_ops))

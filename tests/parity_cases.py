@@ -453,6 +453,46 @@ def check_paf_call_events(eng, ops, op_off, svlen, snp):
 
 
 # ------------------------------------------------------------------------------------------------
+# K8 device tokeniser vs the host packer (which is tested against the oracle's messages)
+# ------------------------------------------------------------------------------------------------
+TOKENISER_EDGE_TEXTS = [
+    b"", b"5", b"M", b"5M", b"10=3I", b"12", b"3M4", b"3MM2I", b"3M2II", b"I", b"4=I3M", b"0M", b"00012=",
+    b"0000000000000000000000000000000000000000000005M2I",       # 40+ leading zeros: beyond the history window
+    b"18446744073709551616M", b"99999999999999999999M3I",         # u64 overflow (20 digits)
+    b"0000000000000000000000012345M",                              # > 19 digits, small value
+    b"268435455M", b"268435456M", b"536870911I4=", b"1073741824D",  # split lengths (2^28 - 1 is the largest op)
+    "3\u00e9".encode(), "3\u00e95M".encode(), b"3\xc3", b"4\xe2\x82\xac2M", b"2M\xff\xfe3I", b"7 M", b"7\tM3I",
+    b"5B3z", b"10=2X" * 100 + b"4", b"10=2X" * 100 + b"MM", b"1=" * 700,  # > 1 KiB: errors in a later chunk
+    b"123456789=" * 120 + b"5I", b"9" * 15 + b"M" + b"1=" * 520,
+]
+
+
+def check_tokeniser(eng, texts):
+    """count pass + scan + fill pass must reproduce wga_cigar_pack for every record"""
+    n = len(texts)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(t) for t in texts], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(texts) + b"0" * 16, dtype=np.uint8)   # a few bytes of slack behind the last text
+    d_text, d_off = eng.upload(blob), eng.upload(offs)
+    cnt, err = eng.cigar_tokenise(n, d_text, d_off)
+    op_off = eng.exclusive_scan_u64(n, cnt)
+    oo = op_off.numpy()
+    ops = eng.empty(int(oo[-1]) + 1, np.uint32).fill(0xEE)
+    eng.cigar_tokenise(n, d_text, d_off, op_cnt=cnt, err=err, ops=ops, op_off=op_off)
+    c, e, o = cnt.numpy(), err.numpy(), ops.numpy()
+    for i, t in enumerate(texts):
+        want_ops, want_err, (eo, el) = eng.pack_cigar(t)
+        assert int(c[i]) == len(want_ops), (i, t[:40], int(c[i]), len(want_ops))
+        got = o[int(oo[i]):int(oo[i + 1])]
+        assert (got == want_ops).all(), (i, t[:40], got[:8], want_ops[:8])
+        assert int(e[i]["err"]) == want_err, (i, t[:40], int(e[i]["err"]), want_err)
+        if want_err not in (0, 6):
+            assert (int(e[i]["tok_off"]), int(e[i]["tok_len"])) == (eo, el), (i, t[:40], e[i], eo, el)
+    assert int(o[int(oo[-1])]) == 0xEEEEEEEE
+
+
+
+# ------------------------------------------------------------------------------------------------
 # a second, linear-time expectation for long records (the C oracle's insert_str is quadratic)
 # ------------------------------------------------------------------------------------------------
 def fast_expected_rows(ops, t_seq, q_seq, neg):

@@ -234,3 +234,10 @@ def test_paf_call_events(emu):
     off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
     for svlen, snp in ((0, True), (8, True), (1 << 40, False)):
         pc.check_paf_call_events(emu, ops, off, svlen, snp)
+
+
+def test_device_tokeniser(emu):
+    pc.check_tokeniser(emu, pc.TOKENISER_EDGE_TEXTS)
+    b = synth.make_paf_batch(41, 10, 300, 300000)
+    texts = [synth.cigar_text(pc.rec_ops(b, i)).encode() for i in range(10)]
+    pc.check_tokeniser(emu, texts + [b"3M", b""] + texts[:3])

@@ -250,3 +250,10 @@ def test_paf_call_events(gpu):
     off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
     for svlen, snp in ((0, True), (8, True), (1 << 40, False)):
         pc.check_paf_call_events(gpu, ops, off, svlen, snp)
+
+
+def test_device_tokeniser(gpu):
+    pc.check_tokeniser(gpu, pc.TOKENISER_EDGE_TEXTS)
+    b = synth.make_paf_batch(41, 400, 3000, 300000)
+    texts = [synth.cigar_text(pc.rec_ops(b, i)).encode() for i in range(400)]
+    pc.check_tokeniser(gpu, texts + [b"3M", b""] + texts[:3])

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "wga_scatter_bytes": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp]),
     "wga_maf_pair_stat": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "wga_maf_call_runs": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]),
+    "wga_cigar_tokenise": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp]),
     "wga_paf_call_events": (C.c_int, [vp, C.POINTER(CigarBatch), C.c_uint64, C.c_int, vp, vp, vp]),
     "wga_pafcov_accumulate": (C.c_int, [vp, C.POINTER(CigarBatch), vp, vp, vp, vp, vp]),
     "wga_pafcov_finalize": (C.c_int, [vp, C.c_uint32, vp, vp, vp]),

@@ -406,6 +406,21 @@ int wga_maf_call_runs(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint6
   return WGA_OK;
 }
 
+int wga_cigar_tokenise(wga_ctx* c, uint32_t n, const uint8_t* d_text, const uint64_t* d_text_off,
+                       uint64_t* d_op_cnt, wga_tok_err* d_err, uint32_t* d_ops,
+                       const uint64_t* d_op_off) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (n == 0) return WGA_OK;
+  if (!d_text || !d_text_off) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  if (d_ops && !d_op_off) return fail(WGA_E_INVALID_ARG, "d_op_off null", nullptr);
+  static_assert(sizeof(wga_tok_err) == sizeof(wga_tok_err_dev), "wga_tok_err layout");
+  WGA_LAUNCH(k_cigar_tokenise, (n + 3u) / 4u, WGA_BLOCK, c->stream, n, d_text, (const u64*)d_text_off,
+             (u64*)d_op_cnt, (wga_tok_err_dev*)d_err, d_ops, (const u64*)d_op_off);
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
 int wga_paf_call_events(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, int snp,
                         uint64_t* d_ev_cnt, uint64_t* d_ev, const uint64_t* d_ev_off) {
   int rc = ctx_bind(c);

@@ -13,6 +13,7 @@ COUNTS_DTYPE = np.dtype([(k, "<u8") for k in (
     "match", "mismatch", "ins_ev", "ins_bp", "del_ev", "del_bp", "inv_ins_ev", "inv_ins_bp",
     "inv_del_ev", "inv_del_bp", "inv_ev")])
 DIAG_DTYPE = np.dtype([("bad_op_idx", "<u8"), ("panic_op_idx", "<u8"), ("bad_base_pos", "<u8")])
+TOK_ERR_DTYPE = np.dtype([("err", np.int32), ("tok_len", np.uint32), ("tok_off", np.uint64)])
 CLASS_SUMS_DTYPE = np.dtype([(k, "<u8") for k in ("mx", "i", "d", "s", "o")])
 NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
 
@@ -225,6 +226,14 @@ class Engine:
         self._check(self.lib.wga_maf_call_runs(self.ctx, n, _p(rows), _p(t_off), _p(q_off), _p(cols),
                                                _p(run_cnt), _p(runs), _p(run_off)))
         return run_cnt
+
+    def cigar_tokenise(self, n, text, text_off, op_cnt=None, err=None, ops=None, op_off=None):
+        """device tokeniser (wga_cigar_tokenise): count pass when ops is None, fill pass otherwise"""
+        op_cnt = op_cnt if op_cnt is not None else self.empty(n, np.uint64)
+        err = err if err is not None else self.empty(n, TOK_ERR_DTYPE)
+        self._check(self.lib.wga_cigar_tokenise(self.ctx, n, _p(text), _p(text_off), _p(op_cnt), _p(err),
+                                                _p(ops), _p(op_off)))
+        return op_cnt, err
 
     def paf_call_events(self, batch, svlen, snp, ev_cnt=None, ev=None, ev_off=None):
         ev_cnt = ev_cnt if ev_cnt is not None else self.empty(batch.n, np.uint64)
