@@ -458,3 +458,25 @@ def test_call_maf_index_contigs(cli, tmp_path):
     lines = out.decode().splitlines()
     assert lines[7:10] == ["##contig=<ID=ref.chr8,length=182411202>", "##contig=<ID=ref.chr10,length=500>",
                            "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsample"]
+
+
+def test_stat_paf_error_order(cli, tmp_path):
+    """buffered driver: the first failing record in input order decides the message, whether it fails
+    in the tokeniser (device) or in the walk (K1); nothing is written"""
+    def paf(cigars):
+        p = tmp_path / "e.paf"
+        with open(p, "w") as f:
+            for k, cg in enumerate(cigars):
+                f.write("q%d\t100\t0\t10\t+\tt\t100\t0\t10\t0\t0\t0\t%s\n" % (k, cg))
+        return str(p)
+    cases = [
+        (["cg:Z:10=", "cg:Z:5=2N3=", "cg:Z:10=", "cg:Z:10=3"], "CIGAR OP `N` invalid"),
+        (["cg:Z:10=", "cg:Z:10=3", "cg:Z:5=2N3="], "CIGAR OP `` invalid"),
+        (["cg:Z:10=", "cg:Z:=", "cg:Z:5=2N3="], "Parse `` Into Integer Error"),
+        (["cg:Z:10=", "cg:Z:3MM", "xx:i:0"], "CIGAR OP `MM` invalid"),
+        (["cg:Z:10=", "xx:i:0", "cg:Z:3MM"], "CIGAR start tag not found"),
+        (["cg:Z:10=", "cg:Z:99999999999999999999M"], "Parse `99999999999999999999` Into Integer Error"),
+    ]
+    for cigars, msg in cases:
+        rc, out, err = run(cli, "stat", "-f", "paf", paf(cigars))
+        assert rc == 1 and out == b"" and err.strip().endswith("ERROR " + msg), (cigars, err)

@@ -256,28 +256,88 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
 }
 
 /* ---- stat (stat.rs) ----------------------------------------------------------------------------- */
+/* CIGAR texts of a run of records -> device batch through the device tokeniser (wga_cigar_tokenise):
+ * the host only finds the tag; digits and op chars are parsed on the GPU.  Returns the reference's
+ * message for the first failing record in input order ("" if none). */
+std::string device_tokenise(Dev& d, const std::vector<PafRecord>& recs, std::vector<std::string>& cigars,
+                            wga_cigar_batch* cb) {
+  const uint32_t n = (uint32_t)recs.size();
+  std::string blob, first_err;
+  std::vector<uint64_t> toff{0};
+  std::vector<uint8_t> strand;
+  uint32_t n_ok = n;
+  for (uint32_t k = 0; k < n; k++) {
+    int err = 0;
+    std::string cg = paf_cigar_string(recs[k], &err);
+    if (err) { /* errors.rs:57: only the records before it can fail earlier */
+      first_err = "CIGAR start tag not found";
+      n_ok = k;
+      break;
+    }
+    cigars.push_back(cg.substr(5));
+    blob += cigars.back();
+    toff.push_back(blob.size());
+    strand.push_back(recs[k].neg ? 1 : 0);
+  }
+  cb->n = n_ok;
+  cb->n_ops = 0;
+  cb->d_ops = nullptr;
+  cb->d_op_off = nullptr;
+  cb->d_strand_neg = nullptr;
+  if (n_ok == 0) return first_err;
+  blob.append(64, '0'); /* slack behind the last text */
+  auto* d_text = d.upload((const uint8_t*)blob.data(), blob.size());
+  auto* d_toff = d.upload(toff);
+  auto* d_cnt = (uint64_t*)d.alloc((size_t)n_ok * 8);
+  auto* d_err = (wga_tok_err*)d.alloc((size_t)n_ok * sizeof(wga_tok_err));
+  d.check(wga_cigar_tokenise(d.ctx, n_ok, d_text, d_toff, d_cnt, d_err, nullptr, nullptr));
+  auto* d_ooff = (uint64_t*)d.alloc(((size_t)n_ok + 1) * 8);
+  d.check(wga_exclusive_scan_u64(d.ctx, n_ok, d_cnt, d_ooff));
+  uint64_t total = 0;
+  d.download(&total, d_ooff + n_ok, 1);
+  auto* d_ops = (uint32_t*)d.alloc((total + 4) * 4);
+  d.check(wga_cigar_tokenise(d.ctx, n_ok, d_text, d_toff, d_cnt, d_err, d_ops, d_ooff));
+  std::vector<wga_tok_err> errs(n_ok);
+  d.download(errs.data(), d_err, n_ok);
+  cb->d_ops = d_ops;
+  cb->d_op_off = d_ooff;
+  cb->d_strand_neg = d.upload(strand);
+  cb->n_ops = total;
+  for (uint32_t k = 0; k < n_ok; k++)
+    if (errs[k].err) { /* the batch is cut before the failing record: earlier ones may still fail in a walk */
+      first_err = cigar_error_message(errs[k].err, cigars[k], (size_t)errs[k].tok_off, errs[k].tok_len);
+      cb->n = k;
+      std::vector<uint64_t> oo(1);
+      d.download(oo.data(), d_ooff + k, 1);
+      cb->n_ops = oo[0];
+      break;
+    }
+  return first_err;
+}
+
 int cmd_stat_paf(const std::string* input, bool each, Output& out) {
   std::vector<PafRecord> recs = parse_paf(read_all(input));
-  PackedBatch b;
-  for (const auto& r : recs) {
-    std::string e = pack_record(r, b);
-    if (!e.empty()) fail(e); /* buffered driver: nothing is written on error */
-  }
-  const uint32_t n = (uint32_t)b.strand.size();
+  const uint32_t n = (uint32_t)recs.size();
   std::vector<wga_cigar_counts> counts(n);
   if (n) {
     Dev d;
     d.init();
-    wga_cigar_batch cb = device_batch(d, b);
-    auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
-    auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
-    d.check(wga_cigar_stat(d.ctx, &cb, d_counts, d_diag, nullptr));
-    std::vector<wga_rec_diag> diag(n);
-    d.download(diag.data(), d_diag, n);
-    d.download(counts.data(), d_counts, n);
-    for (uint32_t k = 0; k < n; k++)
-      if (diag[k].bad_op_idx != WGA_NONE)
-        fail("CIGAR OP `" + cigar_op_token_at(b.cigars[k], diag[k].bad_op_idx) + "` invalid");
+    std::vector<std::string> cigars;
+    wga_cigar_batch cb;
+    const std::string e = device_tokenise(d, recs, cigars, &cb);
+    const uint32_t m = cb.n; /* records before the first tag / tokeniser error */
+    if (m) {
+      auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)m * sizeof(wga_cigar_counts));
+      auto* d_diag = (wga_rec_diag*)d.alloc((size_t)m * sizeof(wga_rec_diag));
+      d.check(wga_cigar_stat(d.ctx, &cb, d_counts, d_diag, nullptr));
+      std::vector<wga_rec_diag> diag(m);
+      d.download(diag.data(), d_diag, m);
+      d.download(counts.data(), d_counts, m);
+      for (uint32_t k = 0; k < m; k++)
+        if (diag[k].bad_op_idx != WGA_NONE)
+          fail("CIGAR OP `" + cigar_op_token_at(cigars[k], diag[k].bad_op_idx) + "` invalid");
+    }
+    if (!e.empty()) fail(e); /* buffered driver: nothing is written on error */
   }
   std::vector<StatInput> in;
   in.reserve(n);
