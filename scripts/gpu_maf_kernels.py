@@ -5,8 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from wgatools_amd import engine
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
+n_all = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
+n = min(n_all, 200_000)           # rows are generated for n blocks and repeated up to n_all
+rep = max(1, n_all // n)
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(7)
 cols = torch.full((n,), L, dtype=torch.int64, device=dev)
@@ -28,7 +30,9 @@ in_gap = (idx - last_start < last_len) & (last_start > 0)
 which = (last_start % 2 == 0)
 t[in_gap & which] = 45
 q[in_gap & ~which] = 45
-rows = torch.cat([t, q]).contiguous()
+rows = torch.cat([t.repeat(rep), q.repeat(rep)]).contiguous()
+n, tot = n * rep, tot * rep
+cols = torch.full((n,), L, dtype=torch.int64, device=dev)
 t_off = (torch.arange(n, device=dev) * L).to(torch.int64)
 q_off = t_off + tot
 strand = (torch.rand(n, device=dev, generator=g) < 0.1).to(torch.uint8)
