@@ -2,11 +2,11 @@
  * wga_kernels.h — hand-written HIP kernels for gfx950 (CDNA4, wave64) of the wgatools CIGAR hot
  * path.  Integer / byte work, HBM-bound: no MFMA anywhere.  Included by wga_capi.cpp.
  *
- * Work decomposition (all kernels): the packed op stream of a whole batch is cut into
+ * Work decomposition (all op-stream kernels): the packed op stream of a whole batch is cut into
  * *globally aligned tiles* of WGA_TILE ops, independent of record boundaries, so the load is
- * balanced whatever the record-length skew (1-op records and 2 Mop records in one launch).  A
- * tile finds the record of its first op with a 64-ary ballot search over op_off, then walks the
- * record segments it intersects.
+ * balanced whatever the record-length skew (1-op records and 2 Mop records in one launch).  Small
+ * pre-pass kernels (k_tile_rec, k_rec_desc, k_tile_base) tell every tile which record its first op
+ * belongs to and where that record stands, so that the walk kernels start with one load.
  *
  *   K1 k_cigar_stat      one wave per tile; 16 B/lane coalesced op loads; per-segment wave
  *                        reduction; writes per-record counts (atomics only for records that span
@@ -14,11 +14,13 @@
  *                        last segment) that lets any later kernel place a tile inside a long
  *                        record by summing summaries instead of rescanning ops.
  *   K2 k_paf2maf_expand  one 256-thread block per tile; block scan of the tile's ops into LDS
- *                        (column prefix + compacted per-row gap lists); then every thread owns
- *                        16-byte aligned output chunks, binary-searches the gap list in LDS and
- *                        assembles the chunk from <=16-byte source windows (funnel-shifted
- *                        dword loads; reverse-complement fused for '-' strand) — coalesced
- *                        16 B/lane stores, no read-modify-write.
+ *                        (compacted per-row gap lists + a per-16-column granule table); every
+ *                        lane then owns 16-column output granules: a table lookup says "plain
+ *                        copy" (one byte-unaligned 16 B window load, reverse-complement fused for
+ *                        '-' strand), "all dashes", or "touches a gap" (queued and assembled from
+ *                        two windows under byte masks).  Raw buffer loads / stores with
+ *                        out-of-range offsets as the lane predicate; no read-modify-write.
+ *   (K3..K8 are in wga_kernels2.h.)
  *
  * The same source also compiles under tests/emu/simt_emu.h (WGA_EMU) for CPU-side logic tests.
  */
