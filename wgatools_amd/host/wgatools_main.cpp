@@ -112,156 +112,11 @@ wga_cigar_batch device_batch(Dev& d, const PackedBatch& b) {
   return cb;
 }
 
-/* ---- paf2maf (converter.rs:176-265) ------------------------------------------------------------- */
-int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::string& q_fa, Output& out) {
-  std::vector<PafRecord> recs = parse_paf(read_all(input));
-  Faidx tf, qf;
-  tf.load(t_fa);
-  qf.load(q_fa);
-  out.write("#maf version=1.6 convert_from=paf t_seq_path=" + t_fa + " q_seq_path=" + q_fa + "\n");
-  Dev d;
-  d.init();
-  uint8_t* d_tpool = d.upload((const uint8_t*)tf.pool.data(), tf.pool.size());
-  uint8_t* d_qpool = d.upload((const uint8_t*)qf.pool.data(), qf.pool.size());
-  const uint64_t kMaxOps = 64ull << 20, kMaxBytes = 6ull << 30;
-  size_t i0 = 0;
-  std::string pending_error;
-  while (i0 < recs.size() && pending_error.empty()) {
-    PackedBatch b;
-    std::vector<uint64_t> t_off, t_len, q_off, q_len;
-    std::vector<uint32_t> pre_t, pre_q, post;
-    std::string blob;
-    std::vector<uint64_t> blob_off{0};
-    uint64_t est = 0;
-    size_t i = i0;
-    for (; i < recs.size(); i++) {
-      const PafRecord& r = recs[i];
-      if (!b.strand.empty() && (b.ops.size() > kMaxOps || est > kMaxBytes)) break;
-      uint64_t to, tl, qo, ql;
-      try { /* fetch order of converter.rs:219-225: target first, then query */
-        tf.fetch(r.target_name, r.target_start, r.target_end - 1, &to, &tl);
-        qf.fetch(r.query_name, r.query_start, r.query_end - 1, &qo, &ql);
-      } catch (Error& e) {
-        pending_error = e.msg;
-        break;
-      }
-      /* reverse_complement runs before the CIGAR is looked at: an invalid base wins — the
-       * kernel reports it; tag / tokeniser errors are known now */
-      std::string perr = pack_record(r, b);
-      if (!perr.empty()) {
-        /* ... unless the query slice holds an invalid base (checked on the host: rare path) */
-        if (r.neg)
-          for (uint64_t k = ql; k-- > 0;) {
-            char c = qf.pool[qo + k];
-            if (!strchr("ACGTNacgtn", c) || c == 0) {
-              perr = std::string("Invalid Base: `") + c + "`";
-              break;
-            }
-          }
-        pending_error = perr;
-        break;
-      }
-      t_off.push_back(to);
-      t_len.push_back(tl);
-      q_off.push_back(qo);
-      q_len.push_back(ql);
-      std::string a = "a score=";
-      append_u64(a, r.mapq);
-      a += "\ns\t" + r.target_name + "\t";
-      append_u64(a, r.target_start);
-      a.push_back('\t');
-      append_u64(a, r.target_end - r.target_start);
-      a += "\t+\t";
-      append_u64(a, r.target_length);
-      a.push_back('\t');
-      std::string q = "\ns\t" + r.query_name + "\t";
-      append_u64(q, r.neg ? r.query_length - r.query_end : r.query_start); /* converter.rs:213-216 */
-      q.push_back('\t');
-      append_u64(q, r.query_end - r.query_start);
-      q += r.neg ? "\t-\t" : "\t+\t";
-      append_u64(q, r.query_length);
-      q.push_back('\t');
-      pre_t.push_back((uint32_t)a.size());
-      pre_q.push_back((uint32_t)q.size());
-      post.push_back(2);
-      blob += a;
-      blob_off.push_back(blob.size());
-      blob += q;
-      blob_off.push_back(blob.size());
-      blob += "\n\n";
-      blob_off.push_back(blob.size());
-      est += tl + ql + (tl + ql) / 4;
-    }
-    const uint32_t n = (uint32_t)b.strand.size();
-    if (n) {
-      wga_cigar_batch cb = device_batch(d, b);
-      auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
-      auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
-      void* d_tiles = d.alloc(wga_tile_ws_bytes(cb.n_ops));
-      d.check(wga_cigar_stat(d.ctx, &cb, d_counts, d_diag, d_tiles));
-      uint64_t *d_to = d.upload(t_off), *d_tl = d.upload(t_len), *d_qo = d.upload(q_off), *d_ql = d.upload(q_len);
-      uint32_t *d_pt = d.upload(pre_t), *d_pq = d.upload(pre_q), *d_po = d.upload(post);
-      auto* d_tro = (uint64_t*)d.alloc((size_t)n * 8);
-      auto* d_qro = (uint64_t*)d.alloc((size_t)n * 8);
-      auto* d_rec = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
-      d.check(wga_paf2maf_layout(d.ctx, n, d_counts, d_tl, d_ql, d_pt, d_pq, d_po, d_tro, d_qro, d_rec));
-      std::vector<uint64_t> rec_off(n + 1), tro(n), qro(n);
-      d.download(rec_off.data(), d_rec, n + 1);
-      d.download(tro.data(), d_tro, n);
-      d.download(qro.data(), d_qro, n);
-      std::vector<wga_cigar_counts> counts(n);
-      d.download(counts.data(), d_counts, n);
-      auto* d_out = (uint8_t*)d.alloc(rec_off[n] + 64);
-      d.check(wga_paf2maf_expand(d.ctx, &cb, d_counts, d_tiles, d_tpool, tf.pool.size(), d_to, d_tl, d_qpool,
-                                 qf.pool.size(), d_qo, d_ql, d_out, d_tro, d_qro, d_diag));
-      /* the MAF line text around the rows: three snippets per record */
-      std::vector<uint64_t> dst(3 * (size_t)n);
-      for (uint32_t k = 0; k < n; k++) {
-        dst[3 * k] = rec_off[k];
-        dst[3 * k + 1] = tro[k] + t_len[k] + counts[k].ins_bp + counts[k].inv_ins_bp;
-        dst[3 * k + 2] = rec_off[k + 1] - 2;
-      }
-      uint8_t* d_blob = d.upload((const uint8_t*)blob.data(), blob.size());
-      uint64_t *d_boff = d.upload(blob_off), *d_dst = d.upload(dst);
-      d.check(wga_scatter_bytes(d.ctx, 3 * n, d_blob, d_boff, d_out, d_dst));
-      std::vector<wga_rec_diag> diag(n);
-      d.download(diag.data(), d_diag, n);
-      uint32_t good = n;
-      for (uint32_t k = 0; k < n; k++) {
-        const wga_rec_diag& g = diag[k];
-        if (g.bad_base_pos == WGA_NONE && g.bad_op_idx == WGA_NONE && g.panic_op_idx == WGA_NONE) continue;
-        good = k;
-        if (g.bad_base_pos != WGA_NONE) { /* utils.rs:97 */
-          char c = qf.pool[q_off[k] + q_len[k] - 1 - g.bad_base_pos];
-          pending_error = std::string("Invalid Base: `") + c + "`";
-        } else if (g.bad_op_idx < g.panic_op_idx) { /* errors.rs:59 */
-          pending_error = "CIGAR OP `" + cigar_op_token_at(b.cigars[k], g.bad_op_idx) + "` invalid";
-        } else {
-          pending_error = "panic: String::insert_str beyond the end of the fetched sequence (cigar.rs:507,513)";
-        }
-        break;
-      }
-      std::string host((size_t)rec_off[good], '\0');
-      if (rec_off[good]) d.download((uint8_t*)host.data(), d_out, rec_off[good]);
-      out.write(host);
-      /* free this batch's buffers (the pools stay) */
-      d.check(wga_sync(d.ctx));
-      while (d.owned.size() > 2) d.release(d.owned.back());
-    }
-    i0 = i;
-  }
-  out.close();
-  if (!pending_error.empty()) fail(pending_error);
-  return 0;
-}
-
-/* ---- stat (stat.rs) ----------------------------------------------------------------------------- */
 /* CIGAR texts of a run of records -> device batch through the device tokeniser (wga_cigar_tokenise):
  * the host only finds the tag; digits and op chars are parsed on the GPU.  Returns the reference's
  * message for the first failing record in input order ("" if none). */
-std::string device_tokenise(Dev& d, const std::vector<PafRecord>& recs, std::vector<std::string>& cigars,
+std::string device_tokenise(Dev& d, const PafRecord* recs, uint32_t n, std::vector<std::string>& cigars,
                             wga_cigar_batch* cb) {
-  const uint32_t n = (uint32_t)recs.size();
   std::string blob, first_err;
   std::vector<uint64_t> toff{0};
   std::vector<uint8_t> strand;
@@ -315,6 +170,167 @@ std::string device_tokenise(Dev& d, const std::vector<PafRecord>& recs, std::vec
   return first_err;
 }
 
+/* ---- paf2maf (converter.rs:176-265) ------------------------------------------------------------- */
+int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::string& q_fa, Output& out) {
+  std::vector<PafRecord> recs = parse_paf(read_all(input));
+  Faidx tf, qf;
+  tf.load(t_fa);
+  qf.load(q_fa);
+  out.write("#maf version=1.6 convert_from=paf t_seq_path=" + t_fa + " q_seq_path=" + q_fa + "\n");
+  Dev d;
+  d.init();
+  uint8_t* d_tpool = d.upload((const uint8_t*)tf.pool.data(), tf.pool.size());
+  uint8_t* d_qpool = d.upload((const uint8_t*)qf.pool.data(), qf.pool.size());
+  const uint64_t kMaxBytes = 6ull << 30;
+  size_t i0 = 0;
+  std::string pending_error;
+  while (i0 < recs.size() && pending_error.empty()) {
+    std::vector<uint64_t> t_off, t_len, q_off, q_len;
+    std::vector<uint32_t> pre_t, pre_q, post;
+    std::string blob;
+    std::vector<uint64_t> blob_off{0};
+    uint64_t est = 0, est_text = 0;
+    const uint64_t kMaxText = 160ull << 20; /* ~64 M ops */
+    size_t i = i0;
+    for (; i < recs.size(); i++) {
+      const PafRecord& r = recs[i];
+      if (i > i0 && (est_text > kMaxText || est > kMaxBytes)) break;
+      uint64_t to, tl, qo, ql;
+      try { /* fetch order of converter.rs:219-225: target first, then query */
+        tf.fetch(r.target_name, r.target_start, r.target_end - 1, &to, &tl);
+        qf.fetch(r.query_name, r.query_start, r.query_end - 1, &qo, &ql);
+      } catch (Error& e) {
+        pending_error = e.msg;
+        break;
+      }
+      for (const auto& tg : r.tags) est_text += tg.size();
+      t_off.push_back(to);
+      t_len.push_back(tl);
+      q_off.push_back(qo);
+      q_len.push_back(ql);
+      std::string a = "a score=";
+      append_u64(a, r.mapq);
+      a += "\ns\t" + r.target_name + "\t";
+      append_u64(a, r.target_start);
+      a.push_back('\t');
+      append_u64(a, r.target_end - r.target_start);
+      a += "\t+\t";
+      append_u64(a, r.target_length);
+      a.push_back('\t');
+      std::string q = "\ns\t" + r.query_name + "\t";
+      append_u64(q, r.neg ? r.query_length - r.query_end : r.query_start); /* converter.rs:213-216 */
+      q.push_back('\t');
+      append_u64(q, r.query_end - r.query_start);
+      q += r.neg ? "\t-\t" : "\t+\t";
+      append_u64(q, r.query_length);
+      q.push_back('\t');
+      pre_t.push_back((uint32_t)a.size());
+      pre_q.push_back((uint32_t)q.size());
+      post.push_back(2);
+      blob += a;
+      blob_off.push_back(blob.size());
+      blob += q;
+      blob_off.push_back(blob.size());
+      blob += "\n\n";
+      blob_off.push_back(blob.size());
+      est += tl + ql + (tl + ql) / 4;
+    }
+    /* the CIGARs of records [i0, i) are tokenised on the device; a tag / tokeniser error cuts the
+     * batch before the failing record (reverse_complement runs before the CIGAR is looked at, so
+     * an invalid base in that record's query slice still wins: checked on the host, rare path) */
+    std::vector<std::string> cigars;
+    wga_cigar_batch cb;
+    cb.n = 0;
+    if (i > i0) {
+      const std::string terr = device_tokenise(d, &recs[i0], (uint32_t)(i - i0), cigars, &cb);
+      if (!terr.empty()) {
+        const size_t k = cb.n;
+        std::string perr = terr;
+        const PafRecord& r = recs[i0 + k];
+        if (r.neg)
+          for (uint64_t x = q_len[k]; x-- > 0;) {
+            char c = qf.pool[q_off[k] + x];
+            if (!strchr("ACGTNacgtn", c) || c == 0) {
+              perr = std::string("Invalid Base: `") + c + "`";
+              break;
+            }
+          }
+        pending_error = perr;
+        i = i0 + k;
+        t_off.resize(k);
+        t_len.resize(k);
+        q_off.resize(k);
+        q_len.resize(k);
+        pre_t.resize(k);
+        pre_q.resize(k);
+        post.resize(k);
+        blob_off.resize(3 * k + 1);
+        blob.resize(blob_off.back());
+      }
+    }
+    const uint32_t n = cb.n;
+    if (n) {
+      auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
+      auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
+      void* d_tiles = d.alloc(wga_tile_ws_bytes(cb.n_ops));
+      d.check(wga_cigar_stat(d.ctx, &cb, d_counts, d_diag, d_tiles));
+      uint64_t *d_to = d.upload(t_off), *d_tl = d.upload(t_len), *d_qo = d.upload(q_off), *d_ql = d.upload(q_len);
+      uint32_t *d_pt = d.upload(pre_t), *d_pq = d.upload(pre_q), *d_po = d.upload(post);
+      auto* d_tro = (uint64_t*)d.alloc((size_t)n * 8);
+      auto* d_qro = (uint64_t*)d.alloc((size_t)n * 8);
+      auto* d_rec = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+      d.check(wga_paf2maf_layout(d.ctx, n, d_counts, d_tl, d_ql, d_pt, d_pq, d_po, d_tro, d_qro, d_rec));
+      std::vector<uint64_t> rec_off(n + 1), tro(n), qro(n);
+      d.download(rec_off.data(), d_rec, n + 1);
+      d.download(tro.data(), d_tro, n);
+      d.download(qro.data(), d_qro, n);
+      std::vector<wga_cigar_counts> counts(n);
+      d.download(counts.data(), d_counts, n);
+      auto* d_out = (uint8_t*)d.alloc(rec_off[n] + 64);
+      d.check(wga_paf2maf_expand(d.ctx, &cb, d_counts, d_tiles, d_tpool, tf.pool.size(), d_to, d_tl, d_qpool,
+                                 qf.pool.size(), d_qo, d_ql, d_out, d_tro, d_qro, d_diag));
+      /* the MAF line text around the rows: three snippets per record */
+      std::vector<uint64_t> dst(3 * (size_t)n);
+      for (uint32_t k = 0; k < n; k++) {
+        dst[3 * k] = rec_off[k];
+        dst[3 * k + 1] = tro[k] + t_len[k] + counts[k].ins_bp + counts[k].inv_ins_bp;
+        dst[3 * k + 2] = rec_off[k + 1] - 2;
+      }
+      uint8_t* d_blob = d.upload((const uint8_t*)blob.data(), blob.size());
+      uint64_t *d_boff = d.upload(blob_off), *d_dst = d.upload(dst);
+      d.check(wga_scatter_bytes(d.ctx, 3 * n, d_blob, d_boff, d_out, d_dst));
+      std::vector<wga_rec_diag> diag(n);
+      d.download(diag.data(), d_diag, n);
+      uint32_t good = n;
+      for (uint32_t k = 0; k < n; k++) {
+        const wga_rec_diag& g = diag[k];
+        if (g.bad_base_pos == WGA_NONE && g.bad_op_idx == WGA_NONE && g.panic_op_idx == WGA_NONE) continue;
+        good = k;
+        if (g.bad_base_pos != WGA_NONE) { /* utils.rs:97 */
+          char c = qf.pool[q_off[k] + q_len[k] - 1 - g.bad_base_pos];
+          pending_error = std::string("Invalid Base: `") + c + "`";
+        } else if (g.bad_op_idx < g.panic_op_idx) { /* errors.rs:59 */
+          pending_error = "CIGAR OP `" + cigar_op_token_at(cigars[k], g.bad_op_idx) + "` invalid";
+        } else {
+          pending_error = "panic: String::insert_str beyond the end of the fetched sequence (cigar.rs:507,513)";
+        }
+        break;
+      }
+      std::string host((size_t)rec_off[good], '\0');
+      if (rec_off[good]) d.download((uint8_t*)host.data(), d_out, rec_off[good]);
+      out.write(host);
+      /* free this batch's buffers (the pools stay) */
+      d.check(wga_sync(d.ctx));
+      while (d.owned.size() > 2) d.release(d.owned.back());
+    }
+    i0 = i;
+  }
+  out.close();
+  if (!pending_error.empty()) fail(pending_error);
+  return 0;
+}
+
+/* ---- stat (stat.rs) ----------------------------------------------------------------------------- */
 int cmd_stat_paf(const std::string* input, bool each, Output& out) {
   std::vector<PafRecord> recs = parse_paf(read_all(input));
   const uint32_t n = (uint32_t)recs.size();
@@ -324,7 +340,7 @@ int cmd_stat_paf(const std::string* input, bool each, Output& out) {
     d.init();
     std::vector<std::string> cigars;
     wga_cigar_batch cb;
-    const std::string e = device_tokenise(d, recs, cigars, &cb);
+    const std::string e = device_tokenise(d, recs.data(), n, cigars, &cb);
     const uint32_t m = cb.n; /* records before the first tag / tokeniser error */
     if (m) {
       auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)m * sizeof(wga_cigar_counts));
