@@ -239,6 +239,14 @@ int wga_pafcov_accumulate(wga_ctx*, const wga_cigar_batch*, const uint32_t* d_ta
 int wga_pafcov_finalize(wga_ctx*, uint32_t n_targets, const uint64_t* d_cov_off,
                         const uint64_t* d_cov_len, int32_t* d_cov);
 
+/* pafcov's text back end (pafcov.rs:56-60): the BED lines
+ * "<name>\t<pos>\t<pos+1>\t<count>\n" for positions p0 .. p0+count-1 of one target, d_cov pointing
+ * at the counter of p0.  Two calls: with d_out == NULL it fills d_line_off[count+1] (exclusive
+ * scan of the line lengths, total bytes in the last entry); the second call writes line k at
+ * d_out + d_line_off[k]. */
+int wga_pafcov_format(wga_ctx*, const uint8_t* d_name, uint32_t name_len, const int32_t* d_cov,
+                      uint64_t p0, uint32_t count, uint64_t* d_line_off, uint8_t* d_out);
+
 /* ---- per-record class sums of a batch: bases in M/=/X, I, D, S and "other" (N H P ...) ops.
  *      pafpseudo's host logic (pseudomaf.rs:147-202) needs M+X+D (target span) and the edited
  *      query length q_len - (I+S) + D before it can place segments.  d_sums: n x 5 u64. ------- */

@@ -57,3 +57,14 @@ for svlen, snp in ((50, 1), (0, 0)):
     print("K7 call events svlen=%d snp=%d: count %.3f ms %.0f GB/s; fill %.3f ms %.0f GB/s (4 B/op + 24 B x %d events)" % (
         svlen, snp, ms_c, 4 * n_ops / ms_c / 1e6, ms_e, (4 * n_ops + 24 * ne) / ms_e / 1e6, ne))
 print("records %d ops %.3e" % (n, n_ops))
+# ---- K9 pafcov BED text ----------------------------------------------------------------------------
+name = torch.tensor(list(b"g01#1#chr1"), dtype=torch.uint8, device=dev)
+cnt9 = 16 << 20
+covv = torch.randint(0, 200, (cnt9,), dtype=torch.int32, device=dev)
+loff = torch.zeros(cnt9 + 1, dtype=torch.int64, device=dev)
+ms_s = timed(lambda: eng.pafcov_format(name, covv, 30_000_000, cnt9, line_off=loff))
+tot9 = int(loff[-1].item())
+txt = torch.zeros(tot9 + 8, dtype=torch.uint8, device=dev)
+ms_w = timed(lambda: eng.pafcov_format(name, covv, 30_000_000, cnt9, line_off=loff, out=txt))
+print("K9 pafcov format: lengths+scan %.3f ms, write %.3f ms for %d lines, %.2f GB of text = %.0f GB/s (text written)" % (
+    ms_s, ms_w, cnt9, tot9 / 1e9, tot9 / ms_w / 1e6))

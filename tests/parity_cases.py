@@ -493,6 +493,28 @@ def check_tokeniser(eng, texts):
 
 
 # ------------------------------------------------------------------------------------------------
+# K9 pafcov BED text
+# ------------------------------------------------------------------------------------------------
+def check_pafcov_format(eng, name, cov, p0):
+    """lines "<name>\\t<pos>\\t<pos+1>\\t<count>\\n" exactly as pafcov.rs:56-60 prints them"""
+    cov = np.asarray(cov, dtype=np.int32)
+    n = len(cov)
+    d_name = eng.upload(np.frombuffer(name or b"\0", dtype=np.uint8)[: max(1, len(name))])
+    d_name.shape = (len(name),)
+    d_cov = eng.upload(cov if n else np.zeros(1, np.int32))
+    off = eng.pafcov_format(d_name, d_cov, p0, n)
+    o = off.numpy()
+    want = b"".join(b"%s\t%d\t%d\t%d\n" % (name, p0 + i, p0 + i + 1, int(np.uint32(cov[i]))) for i in range(n))
+    assert int(o[n]) - int(o[0]) == len(want), (int(o[n]), len(want))
+    out = eng.empty(len(want) + 8, np.uint8).fill(0x23)
+    eng.pafcov_format(d_name, d_cov, p0, n, line_off=off, out=out)
+    got = out.numpy()
+    assert got[: len(want)].tobytes() == want
+    assert (got[len(want):] == 0x23).all()
+
+
+
+# ------------------------------------------------------------------------------------------------
 # a second, linear-time expectation for long records (the C oracle's insert_str is quadratic)
 # ------------------------------------------------------------------------------------------------
 def fast_expected_rows(ops, t_seq, q_seq, neg):

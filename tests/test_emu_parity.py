@@ -241,3 +241,14 @@ def test_device_tokeniser(emu):
     b = synth.make_paf_batch(41, 10, 300, 300000)
     texts = [synth.cigar_text(pc.rec_ops(b, i)).encode() for i in range(10)]
     pc.check_tokeniser(emu, texts + [b"3M", b""] + texts[:3])
+
+
+def test_pafcov_format(emu):
+    rng = np.random.default_rng(3)
+    pc.check_pafcov_format(emu, b"chr1", [0, 1, 9, 10, 99, 100, 2147483647, 12345], 0)
+    pc.check_pafcov_format(emu, b"g01#1#chr1", rng.integers(0, 500, 1300), 95)
+    pc.check_pafcov_format(emu, b"t", rng.integers(0, 3, 40), 999_999_990)
+    pc.check_pafcov_format(emu, b"big", rng.integers(0, 70000, 30), 9_999_999_990)
+    pc.check_pafcov_format(emu, b"huge", [7, 8], 18_446_744_073_709_551_000)
+    pc.check_pafcov_format(emu, b"", [5], 41)
+    pc.check_pafcov_format(emu, b"none", [], 0)

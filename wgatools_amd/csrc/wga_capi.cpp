@@ -421,6 +421,23 @@ int wga_cigar_tokenise(wga_ctx* c, uint32_t n, const uint8_t* d_text, const uint
   return WGA_OK;
 }
 
+int wga_pafcov_format(wga_ctx* c, const uint8_t* d_name, uint32_t name_len, const int32_t* d_cov,
+                      uint64_t p0, uint32_t count, uint64_t* d_line_off, uint8_t* d_out) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (!d_line_off || (count && !d_cov) || (name_len && !d_name)) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  ScanCovLine f;
+  f.cov = (const int*)d_cov;
+  f.p0 = p0;
+  f.name_len = name_len;
+  if (!d_out) return run_scan(c, f, count, (u64*)d_line_off);
+  if (count == 0) return WGA_OK;
+  WGA_LAUNCH(k_pafcov_format, (count + 255u) / 256u, WGA_BLOCK, c->stream, f, count, d_name,
+             (const u64*)d_line_off, d_out);
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
 int wga_paf_call_events(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, int snp,
                         uint64_t* d_ev_cnt, uint64_t* d_ev, const uint64_t* d_ev_off) {
   int rc = ctx_bind(c);

@@ -249,6 +249,13 @@ class Engine:
         self._check(self.lib.wga_pafcov_finalize(self.ctx, n_targets, _p(cov_off), _p(cov_len),
                                                  _p(cov)))
 
+    def pafcov_format(self, name, cov, p0, count, line_off=None, out=None):
+        """BED text of pafcov for positions p0 .. p0+count-1 (cov = device pointer of position p0's counter)"""
+        line_off = line_off if line_off is not None else self.empty(count + 1, np.uint64)
+        self._check(self.lib.wga_pafcov_format(self.ctx, _p(name), int(name.numel() if hasattr(name, 'numel') else name.size), _p(cov), int(p0), int(count),
+                                               _p(line_off), _p(out)))
+        return line_off
+
     def pafpseudo_fill(self, batch, base_mode, q_fa, q_fa_bytes, q_src_off, q_src_len, skip, out,
                        dst_off, diag=None):
         diag = diag if diag is not None else self.empty(batch.n, DIAG_DTYPE)

@@ -523,25 +523,32 @@ int cmd_pafcov(const std::string* input, Output& out) {
     auto *d_off = d.upload(cov_off), *d_len = d.upload(cov_len);
     d.check(wga_pafcov_accumulate(d.ctx, &cb, d.upload(target_id), d.upload(t_start), d_off, d_len, d_cov));
     d.check(wga_pafcov_finalize(d.ctx, nt, d_off, d_len, d_cov));
-    std::vector<int32_t> cov(total);
-    if (total) d.download(cov.data(), d_cov, total);
+    /* the BED text is formatted on the device, a few million positions at a time (pafcov.rs:56-60) */
+    const uint32_t kChunk = 4u << 20;
+    auto* d_loff = (uint64_t*)d.alloc(((size_t)kChunk + 1) * 8);
+    uint8_t* d_txt = nullptr;
+    uint64_t txt_cap = 0;
     std::string text;
     for (uint32_t t = 0; t < nt; t++) {
-      for (uint64_t pos = 0; pos < cov_len[t]; pos++) {
-        text += targets[t];
-        text.push_back('\t');
-        append_u64(text, pos);
-        text.push_back('\t');
-        append_u64(text, pos + 1);
-        text.push_back('\t');
-        append_u64(text, (uint64_t)(uint32_t)cov[cov_off[t] + pos]);
-        text.push_back('\n');
-        if (text.size() > (1u << 24)) {
-          out.write(text);
-          text.clear();
+      auto* d_name = d.upload((const uint8_t*)targets[t].data(), targets[t].size());
+      for (uint64_t pos = 0; pos < cov_len[t]; pos += kChunk) {
+        const uint32_t cnt = (uint32_t)std::min<uint64_t>(kChunk, cov_len[t] - pos);
+        const int32_t* cp = d_cov + cov_off[t] + pos;
+        d.check(wga_pafcov_format(d.ctx, d_name, (uint32_t)targets[t].size(), cp, pos, cnt, d_loff, nullptr));
+        uint64_t bytes = 0;
+        d.download(&bytes, d_loff + cnt, 1);
+        if (bytes > txt_cap) {
+          if (d_txt) d.release(d_txt);
+          txt_cap = bytes + bytes / 4;
+          d_txt = (uint8_t*)d.alloc(txt_cap);
         }
+        d.check(wga_pafcov_format(d.ctx, d_name, (uint32_t)targets[t].size(), cp, pos, cnt, d_loff, d_txt));
+        text.resize(bytes);
+        if (bytes) d.download((uint8_t*)&text[0], d_txt, bytes);
+        out.write(text);
       }
     }
+    text.clear();
     out.write(text);
   }
   out.close();
