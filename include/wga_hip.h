@@ -232,10 +232,13 @@ int wga_paf_call_events(wga_ctx*, const wga_cigar_batch*, uint64_t svlen, int sn
  *      pafcov.rs:29-53) ------------------------------------------------------------------------
  * Record i adds +1 to d_cov[cov_off[target_id[i]] + p] for every base p of its M / = ops that
  * lies below cov_len[target_id[i]].  Implemented as a difference array: accumulate() adds the
- * ±1 marks, finalize() turns marks into counts by an inclusive scan per target. */
+ * ±1 marks, finalize() turns marks into counts by an inclusive scan per target.  `total_cov` =
+ * number of counters in d_cov (max over targets of cov_off + cov_len).  accumulate() may be
+ * called for several batches before finalize(); it waits for its own pre-pass once (it reads a
+ * count back to size a work list). */
 int wga_pafcov_accumulate(wga_ctx*, const wga_cigar_batch*, const uint32_t* d_target_id,
                           const uint64_t* d_t_start, const uint64_t* d_cov_off,
-                          const uint64_t* d_cov_len, int32_t* d_cov);
+                          const uint64_t* d_cov_len, int32_t* d_cov, uint64_t total_cov);
 int wga_pafcov_finalize(wga_ctx*, uint32_t n_targets, const uint64_t* d_cov_off,
                         const uint64_t* d_cov_len, int32_t* d_cov);
 

@@ -27,7 +27,7 @@ cov = torch.zeros(tlen + 1, dtype=torch.int32, device=dev)
 target_id = torch.zeros(n, dtype=torch.int32, device=dev)
 cov_off = torch.zeros(1, dtype=torch.int64, device=dev)
 cov_len = torch.full((1,), tlen, dtype=torch.int64, device=dev)
-ms_a = timed(lambda: eng.pafcov_accumulate(batch, target_id, tb["t_src_off"], cov_off, cov_len, cov))
+ms_a = timed(lambda: eng.pafcov_accumulate(batch, target_id, tb["t_src_off"], cov_off, cov_len, cov, tlen))
 ms_f = timed(lambda: eng.pafcov_finalize(1, cov_off, cov_len, cov))
 n_meq = int(((tb["ops"] & 15) == 7).sum().item() + ((tb["ops"] & 15) == 0).sum().item())
 print("K5 pafcov accumulate: %.3f ms  %.0f GB/s (4 B/op + 2 x 4 B atomics per M/= op: %.2e such ops)" % (ms_a, (4 * n_ops + 8 * n_meq) / ms_a / 1e6, n_meq))

@@ -220,7 +220,7 @@ def text_any(ops_slice):
     return "cg:Z:" + "".join("%d%s" % (w >> 4, chars[w & 15]) for w in ops_slice.tolist())
 
 
-def check_pafcov(eng, b, target_id, t_start, target_len, align=4):
+def check_pafcov(eng, b, target_id, t_start, target_len, align=4, split=False):
     n = len(b["strand_neg"])
     nt = len(target_len)
     cov_off = np.zeros(nt, dtype=np.uint64)
@@ -230,11 +230,14 @@ def check_pafcov(eng, b, target_id, t_start, target_len, align=4):
         cov_off[t] = p
         p += int(target_len[t])
     total = p + 8
-    batch = eng.make_batch(b["ops"], b["op_off"], b["strand_neg"])
     cov = eng.empty(total, np.int32).fill(0)
     d_off, d_len = eng.upload(cov_off), eng.upload(np.asarray(target_len, dtype=np.uint64))
-    eng.pafcov_accumulate(batch, eng.upload(np.asarray(target_id, dtype=np.uint32)),
-                          eng.upload(np.asarray(t_start, dtype=np.uint64)), d_off, d_len, cov)
+    cuts = [0, n // 3, n] if split and n >= 3 else [0, n]      # several accumulate() calls, one finalize()
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        a, z = int(b["op_off"][lo]), int(b["op_off"][hi])
+        batch = eng.make_batch(b["ops"][a:z], b["op_off"][lo:hi + 1] - np.uint64(a), b["strand_neg"][lo:hi])
+        eng.pafcov_accumulate(batch, eng.upload(np.asarray(target_id[lo:hi], dtype=np.uint32)),
+                              eng.upload(np.asarray(t_start[lo:hi], dtype=np.uint64)), d_off, d_len, cov, p)
     eng.pafcov_finalize(nt, d_off, d_len, cov)
     got = cov.numpy()
     exp = [np.zeros(int(l), dtype=np.uint64) for l in target_len]

@@ -141,6 +141,7 @@ def _cov_problem(seed, n, mean, nt):
 def test_pafcov(emu, seed, n, mean, nt, align):
     b, tid, tstart, tlen = _cov_problem(seed, n, mean, nt)
     pc.check_pafcov(emu, b, tid, tstart, tlen, align=align)
+    pc.check_pafcov(emu, b, tid, tstart, tlen, align=align, split=True)
 
 
 def test_pafcov_long_target(emu):

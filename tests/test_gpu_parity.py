@@ -178,6 +178,7 @@ def _cov_problem(seed, n, mean, nt, tmax):
 def test_pafcov(gpu, seed, n, mean, nt, tmax, align):
     b, tid, tstart, tlen = _cov_problem(seed, n, mean, nt, tmax)
     pc.check_pafcov(gpu, b, tid, tstart, tlen, align=align)
+    pc.check_pafcov(gpu, b, tid, tstart, tlen, align=align, split=True)
 
 
 @pytest.mark.parametrize("base", [0, 1])

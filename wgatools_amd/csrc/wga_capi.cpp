@@ -23,6 +23,8 @@ struct wga_ctx {
   void* expand_dbg = nullptr;
   void* scratch = nullptr;
   size_t scratch_cap = 0;
+  void* cov_pieces = nullptr; /* pafcov: (window, piece) list, grow-only */
+  u64 cov_pieces_cap = 0;
   /* optional per-launch timing of the expand kernel proper (events on the launch stream) */
   static const int kTimingRing = 64;
   bool timing = false;
@@ -120,6 +122,7 @@ void wga_ctx_destroy(wga_ctx* c) {
   (void)rt_set_device(c->device);
   (void)rt_sync(c->stream);
   if (c->scratch) (void)rt_free(c->scratch);
+  if (c->cov_pieces) (void)rt_free(c->cov_pieces);
   rt_stream_destroy(c->own_stream);
   delete c;
 }
@@ -454,7 +457,7 @@ int wga_paf_call_events(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, in
 
 int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_target_id,
                           const uint64_t* d_t_start, const uint64_t* d_cov_off,
-                          const uint64_t* d_cov_len, int32_t* d_cov) {
+                          const uint64_t* d_cov_len, int32_t* d_cov, uint64_t total_cov) {
   int rc = ctx_bind(c);
   if (rc) return rc;
   if ((rc = check_batch(b))) return rc;
@@ -463,15 +466,64 @@ int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* 
     return fail(WGA_E_INVALID_ARG, "null array", nullptr);
   u64 nt = n_tiles(b->n_ops);
   void* ws;
-  if ((rc = ctx_scratch(c, (size_t)nt * sizeof(wga_tile_sum), &ws))) return rc;
+  {
+    const u64 nw0 = (total_cov >> WGA_COV_WIN_SHIFT) + 1;
+    const size_t bytes = (size_t)nt * sizeof(wga_tile_sum) + (size_t)nw0 * 4 + 16 + ((size_t)nw0 + 1) * 8 +
+                         ((size_t)(nw0 + 1023) / 1024 + 2) * 8;
+    if ((rc = ctx_scratch(c, bytes, &ws))) return rc;
+  }
   wga_tile_sum* tiles = (wga_tile_sum*)ws;
   u32 grid = (u32)((nt + 3) / 4);
   WGA_LAUNCH(k_class_tiles, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off, b->n,
              (u64)b->n_ops, tiles, (wga_class_sums*)nullptr);
   LAUNCH_CHECK();
-  WGA_LAUNCH(k_pafcov_accumulate, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off,
-             b->n, (u64)b->n_ops, (const wga_tile_sum*)tiles, d_target_id, (const u64*)d_t_start,
-             (const u64*)d_cov_off, (const u64*)d_cov_len, (int*)d_cov);
+  /* pieces per window: count, scan, fill; then one block per window (see wga_kernels2.h K5) */
+  if (total_cov == 0) return WGA_OK;
+  const u64 nw = (total_cov >> WGA_COV_WIN_SHIFT) + 1;
+  if (nw > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "coverage arrays too large for one call", nullptr);
+  u32* win_cnt = (u32*)(tiles + nt);
+  u64* win_off = (u64*)(((uintptr_t)(win_cnt + nw) + 15) & ~(uintptr_t)15);
+  RT_CHECK(rt_memset(win_cnt, 0, (size_t)nw * sizeof(u32), c->stream));
+  WGA_LAUNCH(k_cov_pieces<false>, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off,
+             (u64)b->n_ops, (const wga_tile_sum*)tiles, d_target_id, (const u64*)d_t_start,
+             (const u64*)d_cov_off, (const u64*)d_cov_len, win_cnt, (const u64*)nullptr,
+             (wga_cov_piece*)nullptr);
+  LAUNCH_CHECK();
+  {
+    /* run_scan uses the context scratch itself: give it its own small buffer behind win_off */
+    ScanU32 f;
+    f.in = win_cnt;
+    u32 nb = ((u32)nw + 1023u) / 1024u;
+    u64* partial = win_off + nw + 1;
+    if (nb) {
+      WGA_LAUNCH(k_scan_partials<ScanU32>, nb, WGA_BLOCK, c->stream, f, (u32)nw, partial);
+      LAUNCH_CHECK();
+    }
+    WGA_LAUNCH(k_scan_top, 1, WGA_BLOCK, c->stream, partial, nb, win_off + nw);
+    LAUNCH_CHECK();
+    if (nb) {
+      WGA_LAUNCH(k_scan_final<ScanU32>, nb, WGA_BLOCK, c->stream, f, (u32)nw, (const u64*)partial, win_off);
+      LAUNCH_CHECK();
+    }
+  }
+  u64 n_pieces = 0;
+  RT_CHECK(rt_d2h(&n_pieces, win_off + nw, sizeof(u64), c->stream));
+  if (n_pieces == 0) return WGA_OK;
+  if (c->cov_pieces_cap < n_pieces) {
+    if (c->cov_pieces) RT_CHECK(rt_free(c->cov_pieces));
+    c->cov_pieces = nullptr;
+    c->cov_pieces_cap = 0;
+    RT_CHECK(rt_malloc(&c->cov_pieces, (size_t)(n_pieces + n_pieces / 4) * sizeof(wga_cov_piece)));
+    c->cov_pieces_cap = n_pieces + n_pieces / 4;
+  }
+  RT_CHECK(rt_memset(win_cnt, 0, (size_t)nw * sizeof(u32), c->stream));
+  WGA_LAUNCH(k_cov_pieces<true>, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off,
+             (u64)b->n_ops, (const wga_tile_sum*)tiles, d_target_id, (const u64*)d_t_start,
+             (const u64*)d_cov_off, (const u64*)d_cov_len, win_cnt, (const u64*)win_off,
+             (wga_cov_piece*)c->cov_pieces);
+  LAUNCH_CHECK();
+  WGA_LAUNCH(k_cov_windows, (u32)nw, WGA_BLOCK, c->stream, b->d_ops, (u64)b->n_ops,
+             (const wga_cov_piece*)c->cov_pieces, (const u64*)win_off, (int*)d_cov);
   LAUNCH_CHECK();
   return WGA_OK;
 }

@@ -110,29 +110,35 @@ __global__ __launch_bounds__(256) void k_class_tiles(const u32* __restrict__ ops
 /* ============================================================================================ */
 /* K5: pafcov                                                                                   */
 /* ============================================================================================ */
-/* One wave per tile, 16 *consecutive* ops per lane so that a lane can walk its ops serially
- * after one wave-level exclusive scan of the position advance.  Only M and = are counted; I and
- * S do not move; every other op (D X N H P ...) moves without counting (cigar.rs:720-733).
- * A covered span [pos, pos+len) becomes +1 at pos and -1 at pos+len (both only below the
- * target length): two atomics per M/= op instead of len increments. */
-__global__ __launch_bounds__(256) void k_pafcov_accumulate(
-    const u32* __restrict__ ops, const u64* __restrict__ op_off, u32 n, u64 n_ops,
-    const wga_tile_sum* __restrict__ tiles, const u32* __restrict__ target_id,
-    const u64* __restrict__ t_start, const u64* __restrict__ cov_off,
-    const u64* __restrict__ cov_len, int* cov) {
-  const u32 lane = threadIdx.x & 63u;
-  const u32 wave = threadIdx.x >> 6;
-  const u64 g = (u64)blockIdx.x * 4 + wave;
-  const u64 tile_start = g * WGA_TILE;
-  if (tile_start >= n_ops) return;
-  const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
-  const u32 nt = (u32)(tile_end - tile_start);
-  u32 w[16];
+/* Only M and = are counted; I and S do not move; every other op (D X N H P ...) moves without
+ * counting (cigar.rs:720-733).  A covered span [pos, pos+len) becomes +1 at pos and -1 at pos+len
+ * (both only below the target length): two marks per M/= op instead of len increments.  A wave
+ * takes a tile with 16 *consecutive* ops per lane, so that a lane can walk its ops serially after
+ * one wave-level exclusive scan of the position advance. */
+/* Global atomics run at ~27 G/s on this part whatever their scope or locality
+ * (scripts/micro/atomic_scope.hip), i.e. 19 ms for the 5e8 marks of configs[1].  So the marks are
+ * not sent to memory one by one: the coverage index space is cut into windows of WGA_COV_WIN
+ * counters, every (tile, record segment) piece is listed under the windows it touches
+ * (k_cov_pieces: count, scan, fill), and one block per window replays its pieces with LDS
+ * atomics and adds the window to memory with plain stores — it is the only writer. */
+#define WGA_COV_WIN_SHIFT 13u
+#define WGA_COV_WIN (1u << WGA_COV_WIN_SHIFT)
+
+struct wga_cov_piece {
+  u32 g;       /* tile */
+  u32 ab;      /* first op | end op << 16, tile-relative (<= 1024) */
+  u64 pos0;    /* coverage index (cov_off + target position) of the segment's first op */
+  u64 limit;   /* coverage index one past the target's last counter */
+};
+
+/* 16 consecutive ops per lane of tile g, zero-filled beyond the stream */
+__device__ __forceinline__ void cov_load_ops(const u32* __restrict__ ops, u64 tile_start, u32 nt, u32 lane,
+                                             u32 w[16]) {
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    u32 base = lane * 16u + (u32)j * 4u;
+    const u32 base = lane * 16u + (u32)j * 4u;
     if (base + 3 < nt) {
-      u32x4_a16 v = *(const u32x4_a16*)(ops + tile_start + base);
+      const u32x4_a16 v = *(const u32x4_a16*)(ops + tile_start + base);
       w[4 * j + 0] = v[0];
       w[4 * j + 1] = v[1];
       w[4 * j + 2] = v[2];
@@ -142,6 +148,35 @@ __global__ __launch_bounds__(256) void k_pafcov_accumulate(
       for (int e = 0; e < 4; e++) w[4 * j + e] = (base + e < nt) ? ops[tile_start + base + e] : 0u;
     }
   }
+}
+/* target advance of this lane's ops inside [a, b): everything but I and S moves (cigar.rs:720-733) */
+__device__ __forceinline__ u64 cov_lane_moves(const u32 w[16], u32 lane, u32 a, u32 b) {
+  u64 mv = 0;
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    const u32 idx = lane * 16u + (u32)e;
+    const u32 cls = op_class(w[e] & 15u);
+    const bool moves = cls == CLS_MX || cls == CLS_D || cls == CLS_O;
+    mv += (idx - a < b - a && moves) ? (u64)(w[e] >> 4) : 0ull;
+  }
+  return mv;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_cov_pieces(
+    const u32* __restrict__ ops, const u64* __restrict__ op_off, u64 n_ops,
+    const wga_tile_sum* __restrict__ tiles, const u32* __restrict__ target_id,
+    const u64* __restrict__ t_start, const u64* __restrict__ cov_off,
+    const u64* __restrict__ cov_len, u32* win_cnt, const u64* __restrict__ win_off,
+    wga_cov_piece* pieces) {
+  const u32 lane = threadIdx.x & 63u;
+  const u64 g = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const u64 tile_start = g * WGA_TILE;
+  if (tile_start >= n_ops) return;
+  const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
+  const u32 nt = (u32)(tile_end - tile_start);
+  u32 w[16];
+  cov_load_ops(ops, tile_start, nt, lane, w);
   u32 r = (u32)tiles[g].rec;
   u64 cur = tile_start;
   while (cur < tile_end) {
@@ -153,21 +188,9 @@ __global__ __launch_bounds__(256) void k_pafcov_accumulate(
     const u64 rs = op_off[r];
     const u64 seg_end = re < tile_end ? re : tile_end;
     const u32 a = (u32)(cur - tile_start), b = (u32)(seg_end - tile_start);
-    u64 mv = 0;
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-      u32 idx = lane * 16u + (u32)e;
-      u32 cls = op_class(w[e] & 15u);
-      bool moves = cls == CLS_MX || cls == CLS_D || cls == CLS_O;
-      mv += (idx >= a && idx < b && moves) ? (u64)(w[e] >> 4) : 0ull;
-    }
-    u64 inc = mv;
-    for (u32 d = 1; d < 64; d <<= 1) {
-      u64 t = __shfl_up(inc, d);
-      if (lane >= d) inc += t;
-    }
+    const u64 span = wave_sum_u64(cov_lane_moves(w, lane, a, b));
     u64 base = 0;
-    if (rs < tile_start) { /* wave-uniform */
+    if (rs < tile_start) { /* wave-uniform: target advance of the record before this tile */
       const u64 g0 = rs / WGA_TILE;
       u64 p = 0;
       for (u64 k = g0 + lane; k < g; k += 64) {
@@ -178,28 +201,81 @@ __global__ __launch_bounds__(256) void k_pafcov_accumulate(
     }
     const u32 tg = target_id[r];
     const u64 coff = cov_off[tg], clen = cov_len[tg];
-    u64 pos = t_start[r] + base + (inc - mv);
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-      u32 idx = lane * 16u + (u32)e;
-      if (idx >= a && idx < b) {
-        u32 code = w[e] & 15u;
-        u64 len = w[e] >> 4;
-        u32 cls = op_class(code);
-        if (code == WGA_OP_M || code == WGA_OP_EQ) {
-          if (pos < clen) {
-            atomicAdd(cov + coff + pos, 1);
-            if (pos + len < clen) atomicAdd(cov + coff + pos + len, -1);
-          }
-          pos += len;
-        } else if (cls == CLS_I || cls == CLS_S) {
-        } else {
-          pos += len;
+    const u64 pos = t_start[r] + base;
+    if (pos < clen) { /* marks lie in [pos, min(pos + span, clen - 1)] */
+      const u64 last = pos + span < clen ? pos + span : clen - 1;
+      const u64 wlo = (coff + pos) >> WGA_COV_WIN_SHIFT, whi = (coff + last) >> WGA_COV_WIN_SHIFT;
+      for (u64 wi = wlo + lane; wi <= whi; wi += 64) {
+        const u32 slot = atomicAdd(&win_cnt[wi], 1u);
+        if (FILL) {
+          wga_cov_piece pc;
+          pc.g = (u32)g;
+          pc.ab = a | (b << 16);
+          pc.pos0 = coff + pos;
+          pc.limit = coff + clen;
+          pieces[win_off[wi] + slot] = pc;
         }
       }
     }
     cur = seg_end;
     r++;
+  }
+}
+
+struct ScanU32 {
+  const u32* in;
+  __device__ u64 operator()(u32 i) const { return (u64)in[i]; }
+};
+
+__global__ __launch_bounds__(256) void k_cov_windows(const u32* __restrict__ ops, u64 n_ops,
+                                                     const wga_cov_piece* __restrict__ pieces,
+                                                     const u64* __restrict__ win_off, int* cov) {
+  __shared__ int s_win[WGA_COV_WIN];
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u64 wi = blockIdx.x;
+  const u64 p_lo = win_off[wi], p_hi = win_off[wi + 1];
+  if (p_lo == p_hi) return; /* block-uniform */
+  for (u32 k = tid; k < WGA_COV_WIN; k += WGA_BLOCK) s_win[k] = 0;
+  __syncthreads();
+  const u64 w0 = wi << WGA_COV_WIN_SHIFT;
+  for (u64 p = p_lo + wave; p < p_hi; p += 4) {
+    const wga_cov_piece pc = pieces[p];
+    const u64 tile_start = (u64)pc.g * WGA_TILE;
+    const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
+    const u32 a = pc.ab & 0xFFFFu, b = pc.ab >> 16;
+    u32 w[16];
+    cov_load_ops(ops, tile_start, (u32)(tile_end - tile_start), lane, w);
+    const u64 mv = cov_lane_moves(w, lane, a, b);
+    u64 inc = mv;
+    for (u32 d = 1; d < 64; d <<= 1) {
+      const u64 t = __shfl_up(inc, d);
+      if (lane >= d) inc += t;
+    }
+    u64 pos = pc.pos0 + (inc - mv);
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const u32 idx = lane * 16u + (u32)e;
+      if (idx - a < b - a) {
+        const u32 code = w[e] & 15u;
+        const u64 len = w[e] >> 4;
+        const u32 cls = op_class(code);
+        if (code == WGA_OP_M || code == WGA_OP_EQ) {
+          if (pos < pc.limit) {
+            if (pos - w0 < (u64)WGA_COV_WIN) atomicAdd(&s_win[pos - w0], 1);
+            const u64 pe = pos + len;
+            if (pe < pc.limit && pe - w0 < (u64)WGA_COV_WIN) atomicAdd(&s_win[pe - w0], -1);
+          }
+          pos += len;
+        } else if (cls != CLS_I && cls != CLS_S) {
+          pos += len;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (u32 k = tid; k < WGA_COV_WIN; k += WGA_BLOCK) {
+    const int v = s_win[k];
+    if (v) cov[w0 + k] += v; /* this block is the window's only writer */
   }
 }
 

@@ -241,9 +241,10 @@ class Engine:
                                                  _p(ev_cnt), _p(ev), _p(ev_off)))
         return ev_cnt
 
-    def pafcov_accumulate(self, batch, target_id, t_start, cov_off, cov_len, cov):
+    def pafcov_accumulate(self, batch, target_id, t_start, cov_off, cov_len, cov, total_cov):
         self._check(self.lib.wga_pafcov_accumulate(self.ctx, C.byref(batch.c), _p(target_id),
-                                                   _p(t_start), _p(cov_off), _p(cov_len), _p(cov)))
+                                                   _p(t_start), _p(cov_off), _p(cov_len), _p(cov),
+                                                   int(total_cov)))
 
     def pafcov_finalize(self, n_targets, cov_off, cov_len, cov):
         self._check(self.lib.wga_pafcov_finalize(self.ctx, n_targets, _p(cov_off), _p(cov_len),

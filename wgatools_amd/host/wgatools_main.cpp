@@ -521,7 +521,7 @@ int cmd_pafcov(const std::string* input, Output& out) {
     auto* d_cov = (int32_t*)d.alloc((total + 4) * 4);
     d.check(wga_memset(d.ctx, d_cov, 0, (total + 4) * 4));
     auto *d_off = d.upload(cov_off), *d_len = d.upload(cov_len);
-    d.check(wga_pafcov_accumulate(d.ctx, &cb, d.upload(target_id), d.upload(t_start), d_off, d_len, d_cov));
+    d.check(wga_pafcov_accumulate(d.ctx, &cb, d.upload(target_id), d.upload(t_start), d_off, d_len, d_cov, total));
     d.check(wga_pafcov_finalize(d.ctx, nt, d_off, d_len, d_cov));
     /* the BED text is formatted on the device, a few million positions at a time (pafcov.rs:56-60) */
     const uint32_t kChunk = 4u << 20;
