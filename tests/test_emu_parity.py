@@ -253,3 +253,23 @@ def test_pafcov_format(emu):
     pc.check_pafcov_format(emu, b"huge", [7, 8], 18_446_744_073_709_551_000)
     pc.check_pafcov_format(emu, b"", [5], 41)
     pc.check_pafcov_format(emu, b"none", [], 0)
+
+
+def test_device_tokeniser_random_bytes(emu):
+    """adversarial texts: digits, op letters and stray bytes in any order — the device tokeniser must agree
+    with the host packer on ops, error code and error token for every one of them"""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    alphabet = [bytes([c]) for c in b"0123456789"] * 3 + [bytes([c]) for c in b"MIDNSHP=XB"] * 2 + \
+               [b" ", b"\t", b"\xc3\xa9", b"\xe2\x82\xac", b"\xff", b"0000000000", b"99999999", b"268435455", b"268435456"]
+    texts_st = st.lists(st.lists(st.sampled_from(alphabet), min_size=0, max_size=40).map(b"".join), min_size=1, max_size=12)
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(texts_st)
+    def run(texts):
+        # keep split lengths bounded: a length of 10^17 would pack to 4·10^8 ops (u64 overflows are fine:
+        # they are errors and pack to nothing)
+        import re
+        texts = [t for t in texts if all(int(r) < (1 << 33) or int(r) > 0xFFFFFFFFFFFFFFFF for r in re.findall(rb"[0-9]+", t))]
+        if texts:
+            pc.check_tokeniser(emu, texts)
+    run()
