@@ -947,39 +947,83 @@ __global__ __launch_bounds__(256) void k_paf_call_events(u32 n, const u32* __res
   u64* eout = ev ? ev + 3 * ev_off[i] : (u64*)0;
   u64 t_base = 0, q_base = 0, e_base = 0;
   u32 carry_code = 0xFu;
-  for (u64 k0 = 0; k0 < nops; k0 += 64) {
-    const u64 k = k0 + lane;
-    const bool in = k < nops;
-    const u32 op = in ? rec[k] : 0xFu;
-    const u32 code = op & 15u;
-    const u64 len = (u64)(op >> 4);
-    const bool mlike = code == WGA_OP_M || code == WGA_OP_EQ, isx = code == WGA_OP_X;
-    const bool isi = code == WGA_OP_I || code == WGA_OP_I_CONT, isd = code == WGA_OP_D || code == WGA_OP_D_CONT;
-    const bool valid = mlike || isx || isi || isd;
-    const u64 bad = __ballot(in && !valid);
-    const u64 live_mask = bad ? ((1ull << (u32)__builtin_ctzll(bad)) - 1ull) : ~0ull;
-    const bool live = in && ((live_mask >> lane) & 1ull);
-    const u64 ta = live && !isi ? len : 0ull, qa = live && !isd ? len : 0ull;
-    const u64 ti = wave_incl_scan_u64(ta, lane), qi = wave_incl_scan_u64(qa, lane);
-    u32 prev = __shfl_up(code, 1u);
-    if (lane == 0) prev = carry_code;
-    const bool after_m = prev == WGA_OP_M || prev == WGA_OP_EQ || prev == WGA_OP_X;
-    const u32 nxt = (k + 1 < nops) ? (rec[k + 1] & 15u) : 0xFu;
-    const bool cont_follows = nxt == WGA_OP_I_CONT || nxt == WGA_OP_D_CONT;
-    const bool head_indel = code == WGA_OP_I || code == WGA_OP_D;
-    const bool is_ev = live && ((isx && snp) || (head_indel && after_m && (len > svlen || cont_follows)));
-    const u64 m = __ballot(is_ev);
-    if (eout && is_ev) {
-      u64* e = eout + 3 * (e_base + (u64)__popcll(m & ((1ull << lane) - 1ull)));
-      e[0] = k;
-      e[1] = t_base + ti - ta;
-      e[2] = q_base + qi - qa;
+  /* 4 consecutive ops per lane and step (256 ops per wave step) */
+  for (u64 k0 = 0; k0 < nops; k0 += 256) {
+    const u64 kb = k0 + (u64)lane * 4u;
+    u32 w[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) w[e] = kb + (u64)e < nops ? rec[kb + e] : 0xFu; /* 0xF: no op */
+    u32 code[4], len[4];
+    bool valid[4], isi[4], isd[4];
+    u32 firstbad = 4u; /* first op of this lane outside M = X I D (and inside the record) */
+#pragma unroll
+    for (int e = 3; e >= 0; e--) {
+      code[e] = w[e] & 15u;
+      len[e] = w[e] >> 4;
+      const bool mlike = code[e] == WGA_OP_M || code[e] == WGA_OP_EQ || code[e] == WGA_OP_X;
+      isi[e] = code[e] == WGA_OP_I || code[e] == WGA_OP_I_CONT;
+      isd[e] = code[e] == WGA_OP_D || code[e] == WGA_OP_D_CONT;
+      valid[e] = mlike || isi[e] || isd[e];
+      if (kb + (u64)e < nops && !valid[e]) firstbad = (u32)e;
     }
-    e_base += (u64)__popcll(m);
-    t_base += __shfl(ti, 63);
-    q_base += __shfl(qi, 63);
-    carry_code = __shfl(code, 63);
-    if (bad) break;
+    /* the walk stops at the first bad op of the record: ops at or after it are dead */
+    const u64 badm = __ballot(firstbad < 4u);
+    u32 stop = 0xFFFFFFFFu; /* index inside this step */
+    if (badm) {
+      const int bl = (int)__builtin_ctzll(badm);
+      stop = (u32)bl * 4u + (u32)__shfl((int)firstbad, bl);
+    }
+    u32 ta[4], qa[4], tsum = 0, qsum = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const bool live = (kb + (u64)e < nops) && (lane * 4u + (u32)e < stop);
+      ta[e] = live && !isi[e] ? len[e] : 0u;
+      qa[e] = live && !isd[e] ? len[e] : 0u;
+      tsum += ta[e];
+      qsum += qa[e];
+    }
+    /* lane sums are < 2^30 and their wave prefix < 2^36: scan the two 16-bit halves (DPP) and recombine */
+    const u32 tl = wave_incl_scan_u32(tsum & 0xFFFFu), th = wave_incl_scan_u32(tsum >> 16);
+    const u32 ql = wave_incl_scan_u32(qsum & 0xFFFFu), qh = wave_incl_scan_u32(qsum >> 16);
+    const u64 t_incl = ((u64)th << 16) + (u64)tl, q_incl = ((u64)qh << 16) + (u64)ql;
+    u64 tp = t_base + t_incl - (u64)tsum, qp = q_base + q_incl - (u64)qsum; /* before this lane's first op */
+    u32 prev = (u32)__shfl_up((int)code[3], 1u);
+    if (lane == 0) prev = carry_code;
+    u32 nxt = (u32)__shfl_down((int)code[0], 1u);
+    if (lane == 63u) nxt = k0 + 256u < nops ? (rec[k0 + 256u] & 15u) : 0xFu;
+    bool is_ev[4];
+    u32 nev = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const u32 pc = e == 0 ? prev : code[e - 1];
+      const u32 nc = e == 3 ? nxt : code[e + 1];
+      const bool live = (kb + (u64)e < nops) && (lane * 4u + (u32)e < stop);
+      const bool after_m = pc == WGA_OP_M || pc == WGA_OP_EQ || pc == WGA_OP_X;
+      const bool cont_follows = nc == WGA_OP_I_CONT || nc == WGA_OP_D_CONT;
+      const bool head_indel = code[e] == WGA_OP_I || code[e] == WGA_OP_D;
+      is_ev[e] = live && ((code[e] == WGA_OP_X && snp) || (head_indel && after_m && ((u64)len[e] > svlen || cont_follows)));
+      nev += is_ev[e] ? 1u : 0u;
+    }
+    const u32 einc = wave_incl_scan_u32(nev);
+    if (eout && nev) {
+      u64* e_out = eout + 3 * (e_base + (u64)(einc - nev));
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        if (is_ev[e]) {
+          e_out[0] = kb + (u64)e;
+          e_out[1] = tp;
+          e_out[2] = qp;
+          e_out += 3;
+        }
+        tp += ta[e];
+        qp += qa[e];
+      }
+    }
+    e_base += (u64)wave_last_u32(einc);
+    t_base += ((u64)wave_last_u32(th) << 16) + (u64)wave_last_u32(tl);
+    q_base += ((u64)wave_last_u32(qh) << 16) + (u64)wave_last_u32(ql);
+    carry_code = (u32)__shfl((int)code[3], 63);
+    if (badm) break;
   }
   if (lane == 0 && ev_cnt) ev_cnt[i] = e_base;
 }
