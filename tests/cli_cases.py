@@ -480,3 +480,31 @@ def test_stat_paf_error_order(cli, tmp_path):
     for cigars, msg in cases:
         rc, out, err = run(cli, "stat", "-f", "paf", paf(cigars))
         assert rc == 1 and out == b"" and err.strip().endswith("ERROR " + msg), (cigars, err)
+
+
+# ---- validate ------------------------------------------------------------------
+def test_validate_report_and_fix(cli, tmp_path):
+    """validate.rs:44-141: expected ends from the CIGAR (inv_* slots for strand '-'), report text of
+    Display + writeln (trailing blank line), --fix rows = csv serialisation of the corrected records"""
+    paf = tmp_path / "v.paf"
+    rows = ["q1\t100\t10\t30\t+\tt1\t200\t5\t25\t0\t0\t60\tcg:Z:10=2I8=\tNM:i:2",     # target end should be 23
+            "q2\t100\t0\t20\t-\tt1\t200\t0\t20\t0\t0\t60\tcg:Z:10=3D7=",               # query end should be 17
+            "q3\t50\t0\t12\t+\tt2\t60\t1\t13\t0\t0\t0\tcg:Z:5=1X6=",                    # fine
+            "q4\t50\t3\t9\t+\tt2\t60\t1\t9\t0\t0\t0\tcs:Z::4*ag:2"]                       # cs tag: 4M1X2M -> q 10, t 8
+    paf.write_text("\n".join(rows) + "\n")
+    rc, out, err = run(cli, "validate", str(paf))
+    assert rc == 0, err
+    assert out.decode() == ("Total records: 4\nQuery invalid records: 2\nTarget invalid records: 2\n"
+                            "Query invalid list:\nq2:0-20\nq4:3-9\nTarget invalid list:\nt1:5-25\nt2:1-9\n\n")
+    fixed = tmp_path / "fixed.paf"
+    rc, out2, err = run(cli, "vf", str(paf), "-f", str(fixed), "-o", str(tmp_path / "rep.txt"))
+    assert rc == 0, err
+    assert (tmp_path / "rep.txt").read_bytes() == out
+    want = [rows[0].replace("\t5\t25\t", "\t5\t23\t"), rows[1].replace("\t0\t20\t-", "\t0\t17\t-"), rows[2],
+            rows[3].replace("\t3\t9\t+", "\t3\t10\t+").replace("\t1\t9\t0", "\t1\t8\t0")]
+    assert fixed.read_text() == "\n".join(want) + "\n"
+    rc, out, err = run(cli, "validate", str(paf), "--fix", str(paf))
+    assert rc == 1 and err.strip().endswith("ERROR fixed file should not be the same as output file")
+    paf.write_text(rows[0] + "\n" + "q9\t9\t0\t5\t+\tt\t9\t0\t5\t0\t0\t0\tcg:Z:3=2N\n")
+    rc, out, err = run(cli, "validate", str(paf))
+    assert rc == 1 and out == b"" and "CIGAR OP `N` invalid" in err

@@ -487,6 +487,106 @@ int cmd_maf2paf(const std::string* input, const std::string* query_name, Output&
   return 0;
 }
 
+/* ---- validate (validate.rs:44-141; SURVEY.md 8f rank 3: free once K1 exists) ------------------------------
+ * query_start + M + X + I must be query_end, target_start + M + X + D must be target_end.  Report to the
+ * output, optionally all records with corrected ends to --fix.  Lists are in input order (the reference's
+ * par_bridge order is not deterministic). */
+int cmd_validate(const std::string* input, const std::string* fix, Output& out) {
+  std::vector<PafRecord> recs = parse_paf(read_all(input));
+  const uint32_t n = (uint32_t)recs.size();
+  std::vector<wga_cigar_counts> counts(n);
+  if (n) {
+    Dev d;
+    d.init();
+    std::vector<std::string> cigars;
+    wga_cigar_batch cb;
+    std::string e = device_tokenise(d, recs.data(), n, cigars, &cb);
+    const uint32_t m = cb.n;
+    if (m) {
+      auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)m * sizeof(wga_cigar_counts));
+      auto* d_diag = (wga_rec_diag*)d.alloc((size_t)m * sizeof(wga_rec_diag));
+      d.check(wga_cigar_stat(d.ctx, &cb, d_counts, d_diag, nullptr));
+      std::vector<wga_rec_diag> diag(m);
+      d.download(diag.data(), d_diag, m);
+      d.download(counts.data(), d_counts, m);
+      for (uint32_t k = 0; k < m && e.empty(); k++)
+        if (diag[k].bad_op_idx != WGA_NONE) {
+          e = "CIGAR OP `" + cigar_op_token_at(cigars[k], diag[k].bad_op_idx) + "` invalid";
+          break;
+        }
+    }
+    /* rec.get_stat().unwrap() (:79) */
+    if (!e.empty()) fail("panic: called `Result::unwrap()` on an `Err` value: " + e);
+  }
+  uint64_t q_bad = 0, t_bad = 0;
+  std::string q_list, t_list;
+  for (uint32_t k = 0; k < n; k++) {
+    PafRecord& r = recs[k];
+    const wga_cigar_counts& c = counts[k];
+    const uint64_t mx = c.match + c.mismatch;
+    const uint64_t eq = r.query_start + mx + c.ins_bp + c.inv_ins_bp, et = r.target_start + mx + c.del_bp + c.inv_del_bp;
+    if (eq != r.query_end) {
+      q_bad++;
+      q_list += r.query_name + ":";
+      append_u64(q_list, r.query_start);
+      q_list.push_back('-');
+      append_u64(q_list, r.query_end);
+      q_list.push_back('\n');
+      r.query_end = eq;
+    }
+    if (et != r.target_end) {
+      t_bad++;
+      t_list += r.target_name + ":";
+      append_u64(t_list, r.target_start);
+      t_list.push_back('-');
+      append_u64(t_list, r.target_end);
+      t_list.push_back('\n');
+      r.target_end = et;
+    }
+  }
+  std::string text = "Total records: ";
+  append_u64(text, n);
+  text += "\nQuery invalid records: ";
+  append_u64(text, q_bad);
+  text += "\nTarget invalid records: ";
+  append_u64(text, t_bad);
+  text += "\nQuery invalid list:\n" + q_list + "Target invalid list:\n" + t_list + "\n"; /* writeln!("{}", ..) */
+  out.write(text);
+  if (fix) { /* csv writer: tab, flexible, no header; PafRecord field order (paf.rs:50-65) */
+    std::string rows;
+    for (const PafRecord& r : recs) {
+      append_csv_field(rows, r.query_name, '\t');
+      const uint64_t a[] = {r.query_length, r.query_start, r.query_end};
+      for (uint64_t v : a) {
+        rows.push_back('\t');
+        append_u64(rows, v);
+      }
+      rows += r.neg ? "\t-\t" : "\t+\t";
+      append_csv_field(rows, r.target_name, '\t');
+      const uint64_t b2[] = {r.target_length, r.target_start, r.target_end, r.matches, r.block_length, r.mapq};
+      for (uint64_t v : b2) {
+        rows.push_back('\t');
+        append_u64(rows, v);
+      }
+      for (const std::string& tg : r.tags) {
+        rows.push_back('\t');
+        append_csv_field(rows, tg, '\t');
+      }
+      rows.push_back('\n');
+    }
+    if (*fix == "-") {
+      out.write(rows);
+    } else {
+      Output fo;
+      fo.open(*fix, true);
+      fo.write(rows);
+      fo.close();
+    }
+  }
+  out.close();
+  return 0;
+}
+
 /* ---- pafcov (pafcov.rs:13-83) --------------------------------------------------------------------- */
 int cmd_pafcov(const std::string* input, Output& out) {
   std::vector<PafRecord> recs = parse_paf(read_all(input));
@@ -1232,6 +1332,7 @@ void usage() {
           "  stat    | st   [FILE] [-f maf|paf] [-e] [-q QUERY_NAME]\n"
           "  pafcov  | pc   [PAF]\n"
           "  pafpseudo | pp [PAF] -o OUTDIR [-f ALL.fa] [-g TARGET]\n"
+          "  validate | vf  [PAF] [-f FIXED.paf]\n"
           "  call    | c    [MAF] [-s] [-i] [-l SVLEN] [-n SAMPLE] [--query-name N | --query-regex R] [-c CHUNK]\n"
           "  call    | c    -f paf [PAF] --target T.fa --query Q.fa [-s] [-l SVLEN] [-n SAMPLE]\n");
 }
@@ -1324,6 +1425,9 @@ int main(int argc, char** argv) {
     uint64_t svlen = 50, chunk_size = 1000000;
     const bool pseudo = cmd == "pafpseudo" || cmd == "pp";
     const bool call = cmd == "call" || cmd == "c";
+    const bool validate = cmd == "validate" || cmd == "vf";
+    std::string fix_path;
+    bool has_fix = false;
     for (size_t i = 0; i < rest.size(); i++) {
       const std::string& a = rest[i];
       auto val = [&]() -> std::string {
@@ -1338,6 +1442,9 @@ int main(int argc, char** argv) {
       else if (a == "-q" || a == "--query-name") {
         query_name = val();
         has_qname = true;
+      } else if ((a == "-f" || a == "--fix") && validate) {
+        fix_path = val();
+        has_fix = true;
       } else if ((a == "-f" || a == "--fasta") && pseudo) {
         fasta = val();
         has_fasta = true;
@@ -1380,6 +1487,12 @@ int main(int argc, char** argv) {
       if (format == "paf") return cmd_stat_paf(input, each, out);
       if (format == "maf") return cmd_stat_maf(input, each, qn, out);
       fail("format `" + format + "` is not supported by this engine (maf | paf)");
+    }
+    if (validate) {
+      if (has_fix && fix_path == (has_input ? input_s : std::string("stdin")))
+        fail("fixed file should not be the same as output file"); /* utils.rs:754-758 */
+      out.open(outfile, rewrite);
+      return cmd_validate(input, has_fix ? &fix_path : nullptr, out);
     }
     if (cmd == "maf2paf" || cmd == "m2p") {
       out.open(outfile, rewrite);
