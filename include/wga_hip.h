@@ -228,6 +228,19 @@ int wga_maf_call_runs(wga_ctx*, uint32_t n, const uint8_t* d_rows, const uint64_
 int wga_paf_call_events(wga_ctx*, const wga_cigar_batch*, uint64_t svlen, int snp, uint64_t* d_ev_cnt,
                         uint64_t* d_ev, const uint64_t* d_ev_off);
 
+/* ---- paf2chain: the data lines of parse_cigar_to_chain + cigar_unit_chain
+ *      (cigar.rs:251-295,460-490) and the head / tail indel trim of parse_cigar_to_trim
+ *      (cigar.rs:202-245) that the chain header needs (chain.rs:142-183) ----------------------------
+ * Record i's text is "\n<size>\t<dt>\t<dq>" per block but the last, then "\n<size>"; the caller puts
+ * the header in front and "\n\n" behind (converter.rs:148-173).  Two calls: with d_out == NULL the
+ * kernel fills d_trim[n], d_nbytes[n] (text bytes of record i) and d_diag[n].bad_op_idx (first op
+ * outside M = X I D: CigarOpInvalid); the second call writes record i's text at d_out + d_out_off[i]. */
+typedef struct {
+  uint64_t head_ins, head_del, tail_ins, tail_del;
+} wga_chain_trim_t;
+int wga_cigar_chain(wga_ctx*, const wga_cigar_batch*, wga_chain_trim_t* d_trim, uint64_t* d_nbytes,
+                    wga_rec_diag* d_diag, uint8_t* d_out, const uint64_t* d_out_off);
+
 /* ---- K5: pafcov (replaces update_cov_vec, cigar.rs:710-741, and the per-thread array merge of
  *      pafcov.rs:29-53) ------------------------------------------------------------------------
  * Record i adds +1 to d_cov[cov_off[target_id[i]] + p] for every base p of its M / = ops that

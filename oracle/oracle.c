@@ -873,6 +873,114 @@ done:
   return rc;
 }
 
+/* ---- paf2chain ---------------------------------------------------------
+ * parse_cigar_to_trim, cigar.rs:202-245: I / D bases before the first M-like op; tail = length of
+ * the LAST I / D op behind the last M-like op (assignment, not accumulation). */
+int orc_parse_cigar_to_trim(const char* cg, size_t n, uint64_t out[4], orc_err* err) {
+  uint64_t head_ins = 0, head_del = 0, tail_ins = 0, tail_del = 0;
+  int head_indel = 1;
+  const char* p = cg;
+  const char* end = cg + n;
+  int rc = strip_tag(&p, end, err);
+  if (rc) return rc;
+  if (p == end) {
+    set_err(err, ORC_PANIC, "empty", 5);
+    return ORC_PANIC;
+  }
+  cst_t tok;
+  while (parse_cigar_str_tuple(&p, end, &tok)) {
+    const char* op;
+    size_t op_n;
+    uint64_t len;
+    rc = cst2cu(&tok, &op, &op_n, &len, err);
+    if (rc) return rc;
+    char c = op_n == 1 ? op[0] : '?';
+    if (c == 'M' || c == '=' || c == 'X') {
+      tail_ins = 0;
+      tail_del = 0;
+      head_indel = 0;
+    } else if (c == 'I') {
+      if (head_indel) head_ins += len;
+      tail_ins = len;
+    } else if (c == 'D') {
+      if (head_indel) head_del += len;
+      tail_del = len;
+    } else {
+      set_err(err, ORC_CIGAR_OP_INVALID, op, op_n);
+      return ORC_CIGAR_OP_INVALID;
+    }
+  }
+  out[0] = head_ins;
+  out[1] = head_del;
+  out[2] = tail_ins;
+  out[3] = tail_del;
+  return ORC_OK;
+}
+
+/* one record of converter::paf2chain (converter.rs:148-173): ChainHeader::try_from(&PafRecord)
+ * (chain.rs:142-183, incl. the '-' strand arithmetic that reuses the already updated start), its
+ * Display (:185-203, score 255 prints as "255"), parse_cigar_to_chain + cigar_unit_chain
+ * (cigar.rs:251-295,460-490) and the closing "\n\n".  *out is malloc'd. */
+int orc_paf2chain_record(const char* q_name, uint64_t q_size, uint64_t q_start, uint64_t q_end,
+                         int strand_neg, const char* t_name, uint64_t t_size, uint64_t t_start,
+                         uint64_t t_end, const char* cg, size_t n, uint64_t chain_id, char** out,
+                         size_t* out_len, orc_err* err) {
+  uint64_t tr[4];
+  int rc = orc_parse_cigar_to_trim(cg, n, tr, err);
+  if (rc) return rc;
+  uint64_t qs = q_start, qe = q_end, ts = t_start, te = t_end;
+  if (!strand_neg) {
+    qs += tr[0];
+    ts += tr[1];
+    qe -= tr[2];
+    te -= tr[3];
+  } else {
+    ts += tr[1];
+    te -= tr[3];
+    qs = q_size - (qe - tr[0]);
+    qe = q_size - (qs + tr[2]);
+  }
+  sbuf sb = {NULL, 0, 0};
+  char line[1024];
+  snprintf(line, sizeof line, "chain\t255\t%s\t%llu\t+\t%llu\t%llu\t%s\t%llu\t%c\t%llu\t%llu\t%llu", t_name,
+           (unsigned long long)t_size, (unsigned long long)ts, (unsigned long long)te, q_name,
+           (unsigned long long)q_size, strand_neg ? '-' : '+', (unsigned long long)qs,
+           (unsigned long long)qe, (unsigned long long)chain_id);
+  sb_push(&sb, line, strlen(line));
+  const char* p = cg;
+  const char* end = cg + n;
+  strip_tag(&p, end, err);
+  uint64_t size = 0, qd = 0, td = 0;
+  cst_t tok;
+  while (parse_cigar_str_tuple(&p, end, &tok)) {
+    const char* op;
+    size_t op_n;
+    uint64_t len;
+    if (cst2cu(&tok, &op, &op_n, &len, err)) break; /* cannot happen: the trim pass accepted the text */
+    char c = op[0];
+    if (c == 'M' || c == 'X' || c == '=') {
+      if (size != 0 && td + qd != 0) {
+        snprintf(line, sizeof line, "\n%llu\t%llu\t%llu", (unsigned long long)size,
+                 (unsigned long long)qd, (unsigned long long)td);
+        sb_push(&sb, line, strlen(line));
+        size = 0;
+      }
+      size += len;
+      td = 0;
+      qd = 0;
+    } else if (c == 'I') {
+      td += len;
+    } else {
+      qd += len;
+    }
+  }
+  snprintf(line, sizeof line, "\n%llu\n\n", (unsigned long long)size);
+  sb_push(&sb, line, strlen(line));
+  *out = sb.s;
+  *out_len = sb.n;
+  return ORC_OK;
+}
+
 /* per-record chunk loop of call_var_maf, caller.rs:115-149, with create_chunk_record
  * (:221-265: start += non-gap chars of the prefix, align_size = non-gap chars of the chunk) and
  * the strand-aware accessors of maf.rs:433-450,468-470 applied to the chunk record. */

@@ -103,6 +103,14 @@ int orc_call_within_var_paf(const char* chro, const char* q_chro, const char* cg
                             int strand_neg, int if_snp, uint64_t svlen_cutoff, char** out,
                             size_t* out_len, orc_err* err);
 
+/* cigar.rs:202-245 parse_cigar_to_trim: out = head_ins, head_del, tail_ins, tail_del */
+int orc_parse_cigar_to_trim(const char* cg, size_t n, uint64_t out[4], orc_err* err);
+/* one record of converter.rs:148-173 paf2chain (header + data lines + "\n\n"); *out malloc'd */
+int orc_paf2chain_record(const char* q_name, uint64_t q_size, uint64_t q_start, uint64_t q_end,
+                         int strand_neg, const char* t_name, uint64_t t_size, uint64_t t_start,
+                         uint64_t t_end, const char* cg, size_t n, uint64_t chain_id, char** out,
+                         size_t* out_len, orc_err* err);
+
 void orc_free(void* p);
 /* test helper: packed ops -> "cg:Z:..." text; returns length (0 if cap too small) */
 size_t orc_ops_to_text(const uint32_t* ops, size_t n, char* out, size_t cap);

@@ -58,6 +58,8 @@ def lib():
                                               U, U, U, U, U, C.c_int, C.c_int, C.c_int, U, Z, P, P]
         L.orc_call_within_var_paf.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, Z, C.c_char_p, Z,
                                               C.c_char_p, Z, U, U, U, U, C.c_int, C.c_int, U, P, P, P]
+        L.orc_parse_cigar_to_trim.argtypes = [C.c_char_p, Z, P, P]
+        L.orc_paf2chain_record.argtypes = [C.c_char_p, U, U, U, C.c_int, C.c_char_p, U, U, U, C.c_char_p, Z, U, P, P, P]
         L.orc_ops_to_text.restype = Z
         L.orc_ops_to_text.argtypes = [P, Z, C.c_char_p, Z]
         L.orc_free.argtypes = [C.c_void_p]
@@ -222,6 +224,32 @@ def call_within_var_paf(chro, q_chro, cg, t_seq, q_seq, t_start, t_end, q_start,
         lib().orc_free(out)
     if rc:
         _raise(err)
+    return s
+
+
+def parse_cigar_to_trim(cg):
+    """cigar.rs:202-245 -> (head_ins, head_del, tail_ins, tail_del)"""
+    cg = cg.encode() if isinstance(cg, str) else bytes(cg)
+    out = (C.c_uint64 * 4)()
+    err = Err()
+    if lib().orc_parse_cigar_to_trim(cg, len(cg), out, C.byref(err)):
+        _raise(err)
+    return tuple(int(x) for x in out)
+
+
+def paf2chain_record(q_name, q_size, q_start, q_end, strand_neg, t_name, t_size, t_start, t_end, cg, chain_id):
+    """converter.rs:148-173 for one PAF record -> chain text (header, data lines, blank line)"""
+    cg = cg.encode() if isinstance(cg, str) else bytes(cg)
+    out = C.c_void_p()
+    out_len = C.c_size_t(0)
+    err = Err()
+    rc = lib().orc_paf2chain_record(q_name.encode(), q_size, q_start, q_end, int(strand_neg), t_name.encode(),
+                                    t_size, t_start, t_end, cg, len(cg), chain_id, C.byref(out),
+                                    C.byref(out_len), C.byref(err))
+    if rc:
+        _raise(err)
+    s = C.string_at(out, out_len.value)
+    lib().orc_free(out)
     return s
 
 

@@ -68,3 +68,15 @@ txt = torch.zeros(tot9 + 8, dtype=torch.uint8, device=dev)
 ms_w = timed(lambda: eng.pafcov_format(name, covv, 30_000_000, cnt9, line_off=loff, out=txt))
 print("K9 pafcov format: lengths+scan %.3f ms, write %.3f ms for %d lines, %.2f GB of text = %.0f GB/s (text written)" % (
     ms_s, ms_w, cnt9, tot9 / 1e9, tot9 / ms_w / 1e6))
+# ---- K10 paf2chain data lines ------------------------------------------------------------------------
+trim = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+nb10 = torch.zeros(n, dtype=torch.int64, device=dev)
+dg10 = torch.zeros((n, 3), dtype=torch.int64, device=dev)
+ms_c = timed(lambda: eng.cigar_chain(batch, trim=trim, nbytes=nb10, diag=dg10))
+off10 = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+eng.exclusive_scan_u64(n, nb10, off10)
+tot10 = int(off10[-1].item())
+txt10 = torch.zeros(tot10 + 8, dtype=torch.uint8, device=dev)
+ms_f = timed(lambda: eng.cigar_chain(batch, out=txt10, out_off=off10))
+print("K10 paf2chain: count pass %.3f ms %.0f GB/s (4 B/op); fill pass %.3f ms %.0f GB/s (4 B/op + %.2f GB of text)" % (
+    ms_c, 4 * n_ops / ms_c / 1e6, ms_f, (4 * n_ops + tot10) / ms_f / 1e6, tot10 / 1e9))

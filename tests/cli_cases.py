@@ -508,3 +508,36 @@ def test_validate_report_and_fix(cli, tmp_path):
     paf.write_text(rows[0] + "\n" + "q9\t9\t0\t5\t+\tt\t9\t0\t5\t0\t0\t0\tcg:Z:3=2N\n")
     rc, out, err = run(cli, "validate", str(paf))
     assert rc == 1 and out == b"" and "CIGAR OP `N` invalid" in err
+
+
+# ---- paf2chain ---------------------------------------------------------------------
+def test_paf2chain_end_to_end(cli, tmp_path):
+    """converter.rs:148-173: header (with head / tail indel trim), data lines, blank line per record, chain id =
+    record index; a failing record writes nothing of itself and ends the run (streaming driver)"""
+    b = synth.make_paf_batch(63, 40, 400, 300000)
+    rng = np.random.default_rng(4)
+    n = len(b["strand_neg"])
+    recs, want = [], []
+    for i in range(n):
+        cg = pc.rec_text(b, i)
+        if i % 5 == 0:
+            cg = "cg:Z:3I2D" + cg[5:] + "7D4I"       # head and tail indels
+        qs, qe = int(rng.integers(0, 1000)), 0
+        ts = int(rng.integers(0, 1000))
+        # coordinates need not match the CIGAR for the converter: take generous ends
+        qe, te = qs + 10 ** 7, ts + 10 ** 7
+        neg = bool(b["strand_neg"][i])
+        recs.append("q%d\t%d\t%d\t%d\t%s\tt%d\t%d\t%d\t%d\t0\t0\t60\t%s" % (i % 3, 10 ** 9, qs, qe, "-" if neg else "+", i % 2,
+                                                                  2 * 10 ** 9, ts, te, cg))
+        want.append(orc.paf2chain_record("q%d" % (i % 3), 10 ** 9, qs, qe, neg, "t%d" % (i % 2), 2 * 10 ** 9, ts, te, cg, i))
+    paf = tmp_path / "in.paf"
+    paf.write_text("\n".join(recs) + "\n")
+    rc, out, err = run(cli, "paf2chain", str(paf))
+    assert rc == 0, err
+    assert out == b"".join(want)
+    bad = list(recs)
+    bad[7] = bad[7].rsplit("\t", 1)[0] + "\tcg:Z:10=3N5="
+    paf.write_text("\n".join(bad) + "\n")
+    rc, out, err = run(cli, "p2c", str(paf))
+    assert rc == 1 and err.strip().endswith("ERROR CIGAR OP `N` invalid")
+    assert out == b"".join(want[:7])

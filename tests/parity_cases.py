@@ -518,6 +518,52 @@ def check_pafcov_format(eng, name, cov, p0):
 
 
 # ------------------------------------------------------------------------------------------------
+# K10 paf2chain data lines + header trim
+# ------------------------------------------------------------------------------------------------
+def check_cigar_chain(eng, ops, op_off):
+    """per record: trims = parse_cigar_to_trim, text = the data lines of parse_cigar_to_chain (between the
+    header and the closing blank line of the oracle's record text)"""
+    n = len(op_off) - 1
+    batch = eng.make_batch(ops, op_off, np.zeros(n, dtype=np.uint8))
+    trim, nbytes, diag = eng.cigar_chain(batch)
+    tr, nb, dg = trim.numpy(), nbytes.numpy(), diag.numpy()
+    off = eng.exclusive_scan_u64(n, nbytes)
+    oo = off.numpy()
+    out = eng.empty(int(oo[-1]) + 8, np.uint8).fill(0x23)
+    eng.cigar_chain(batch, out=out, out_off=off)
+    o = out.numpy()
+    def text_merged(sl):   # a head op and its continuation pieces (codes 9 / 10) are ONE op of the text
+        toks = []
+        for w in sl.tolist():
+            c, ln = w & 15, w >> 4
+            if c in (9, 10) and toks:
+                toks[-1][0] += ln
+            else:
+                toks.append([ln, synth.OP_CHARS[c] if c < 9 else "B"])
+        return "".join("%d%s" % (ln, ch) for ln, ch in toks)
+    for i in range(n):
+        cg = "cg:Z:" + text_merged(ops[int(op_off[i]):int(op_off[i + 1])])
+        try:
+            want_tr = orc.parse_cigar_to_trim(cg)
+        except orc.OracleError as e:
+            if e.kind == 2:                      # CigarOpInvalid: first op outside M = X I D
+                assert int(dg[i]["bad_op_idx"]) != NONE, (i, cg[:60])
+                codes = (ops[int(op_off[i]):int(op_off[i + 1])] & 15)
+                firstbad = int(np.flatnonzero(~np.isin(codes, [0, 7, 8, 1, 2, 9, 10]))[0])
+                assert int(dg[i]["bad_op_idx"]) == firstbad
+            continue                             # empty CIGAR: the host refuses it before the kernel
+        assert int(dg[i]["bad_op_idx"]) == NONE, (i, cg[:60])
+        assert tuple(int(tr[i][k]) for k in ("head_ins", "head_del", "tail_ins", "tail_del")) == want_tr, (i, cg[:80], tr[i], want_tr)
+        rec = orc.paf2chain_record("q", 10 ** 12, 0, 10 ** 11, 0, "t", 10 ** 12, 0, 10 ** 11, cg, 0)
+        want = rec[rec.index(b"\n"):-2]
+        got = o[int(oo[i]):int(oo[i + 1])].tobytes()
+        assert int(nb[i]) == len(want), (i, cg[:80], int(nb[i]), len(want))
+        assert got == want, (i, cg[:80], got[:60], want[:60])
+    assert (o[int(oo[-1]):] == 0x23).all()
+
+
+
+# ------------------------------------------------------------------------------------------------
 # a second, linear-time expectation for long records (the C oracle's insert_str is quadratic)
 # ------------------------------------------------------------------------------------------------
 def fast_expected_rows(ops, t_seq, q_seq, neg):

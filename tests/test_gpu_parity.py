@@ -269,3 +269,19 @@ def test_pafcov_format(gpu):
     pc.check_pafcov_format(gpu, b"huge", [7, 8], 18_446_744_073_709_551_000)
     pc.check_pafcov_format(gpu, b"", [5], 41)
     pc.check_pafcov_format(gpu, b"none", [], 0)
+
+
+def test_cigar_chain(gpu):
+    b = synth.make_paf_batch(57, 300, 3000, 400000)
+    pc.check_cigar_chain(gpu, b["ops"], b["op_off"])
+    L = (1 << 28) - 1
+    mk = lambda *p: [(ln << 4) | c for c, ln in p]
+    recs = [mk((1, 2), (2, 3), (7, 5), (1, 2), (7, 3), (8, 1), (2, 4), (1, 2), (2, 1)),     # head + tail indels
+            mk((7, 9)), mk((1, 4)), mk((2, 4), (1, 1)), mk((0, 0), (1, 3), (0, 5)),          # M only, I only, no M, 0M
+            mk((7, 5), (1, 3), (3, 9), (7, 1)), mk((3, 2), (7, 4)),                            # N stops the fold
+            mk((7, 5), (1, L), (9, L), (9, 12), (7, 2), (2, L), (10, 5)),                     # split I / D, split D in the tail
+            mk((7, 3), (1, 1), (2, 2), (1, 3), (8, 1), (2, 2), (2, 3), (7, 7)),               # mixed groups, repeated kinds
+            mk(*([(7, 1), (1, 1)] * 300 + [(7, 2)])), mk(*([(1, 1)] * 260 + [(7, 1)] + [(2, 2)] * 270))]  # > 256 ops
+    ops = np.array([o for r in recs for o in r], dtype=np.uint32)
+    off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+    pc.check_cigar_chain(gpu, ops, off)

@@ -441,6 +441,29 @@ int wga_pafcov_format(wga_ctx* c, const uint8_t* d_name, uint32_t name_len, cons
   return WGA_OK;
 }
 
+int wga_cigar_chain(wga_ctx* c, const wga_cigar_batch* b, wga_chain_trim_t* d_trim, uint64_t* d_nbytes,
+                    wga_rec_diag* d_diag, uint8_t* d_out, const uint64_t* d_out_off) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if ((rc = check_batch(b))) return rc;
+  if (b->n == 0) return WGA_OK;
+  static_assert(sizeof(wga_chain_trim_t) == sizeof(wga_chain_trim), "wga_chain_trim layout");
+  if (!d_out) {
+    if (!d_trim || !d_nbytes || !d_diag) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+    RT_CHECK(rt_memset(d_diag, 0xFF, (size_t)b->n * sizeof(wga_rec_diag), c->stream));
+    WGA_LAUNCH(k_cigar_chain<false>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
+               (const u64*)b->d_op_off, (wga_chain_trim*)d_trim, (u64*)d_nbytes, d_diag, (u8*)nullptr,
+               (const u64*)nullptr);
+  } else {
+    if (!d_out_off) return fail(WGA_E_INVALID_ARG, "d_out_off null", nullptr);
+    WGA_LAUNCH(k_cigar_chain<true>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
+               (const u64*)b->d_op_off, (wga_chain_trim*)nullptr, (u64*)nullptr, (wga_rec_diag*)nullptr,
+               d_out, (const u64*)d_out_off);
+  }
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
 int wga_paf_call_events(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, int snp,
                         uint64_t* d_ev_cnt, uint64_t* d_ev, const uint64_t* d_ev_off) {
   int rc = ctx_bind(c);

@@ -1301,4 +1301,334 @@ __global__ __launch_bounds__(256) void k_pafcov_format(ScanCovLine f, u32 n, con
   *p = (u8)'\n';
 }
 
+/* ============================================================================================ */
+/* K10: paf2chain data lines                                              */
+/* ============================================================================================ */
+/* parse_cigar_to_chain + cigar_unit_chain (cigar.rs:251-295,460-490): runs of M / = / X ops form a
+ * block; when an M-like op follows an indel group and a block is open, the line
+ * "\n<size>\t<D bases of the group>\t<I bases of the group>" goes out; leading indels are dropped,
+ * the last block ends the record as "\n<size>" (trailing indels dropped).  parse_cigar_to_trim
+ * (cigar.rs:202-245) for the chain header: I / D bases before the first M-like op, and the
+ * length of the LAST I / D op behind the last M-like op (assignment, not a sum).
+ * One wave per record, 4 consecutive ops per lane and 256 per step.  With exclusive prefix sums
+ * PM, PD, PI of the M-like / D / I lengths, the line raised at op j is the difference between the
+ * prefix triple at j and the triple at the previous raising op (the first M-like op for the first
+ * line): the triples of a step go through LDS so that every raising op can read its predecessor.
+ * Two passes: text bytes per record, then the text. */
+struct wga_chain_trim {
+  u64 head_ins, head_del, tail_ins, tail_del;
+};
+
+__device__ __forceinline__ int ballot4_first(const bool f[4], u32 lane) { /* smallest lane*4+e with f set, or -1 */
+  int best = -1;
+#pragma unroll
+  for (int e = 3; e >= 0; e--) {
+    const u64 m = __ballot(f[e]);
+    if (m) {
+      const int idx = (int)__builtin_ctzll(m) * 4 + e;
+      best = (best < 0 || idx < best) ? idx : best;
+    }
+  }
+  (void)lane;
+  return best;
+}
+__device__ __forceinline__ int ballot4_last(const bool f[4]) { /* greatest lane*4+e with f set, or -1 */
+  int best = -1;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const u64 m = __ballot(f[e]);
+    if (m) {
+      const int idx = (63 - (int)__builtin_clzll(m)) * 4 + e;
+      best = idx > best ? idx : best;
+    }
+  }
+  return best;
+}
+
+/* the reference's loops verbatim on packed ops (lane 0 only): used for records with zero-length ops,
+ * whose "size != 0" / "diffs != 0" tests (cigar.rs:472) the prefix formulation does not cover */
+__device__ __forceinline__ void chain_serial(const u32* rec, u64 nops, u8* text, wga_chain_trim& tr,
+                                             u64& nbytes, u64& bad_idx) {
+  u64 size = 0, qd = 0, td = 0, off = 0;
+  u64 head_ins = 0, head_del = 0, tail_ins = 0, tail_del = 0;
+  bool head = true;
+  bad_idx = WGA_NONE;
+  for (u64 k = 0; k < nops; k++) {
+    const u32 code = rec[k] & 15u;
+    const u64 len = rec[k] >> 4;
+    if (code == WGA_OP_M || code == WGA_OP_EQ || code == WGA_OP_X) {
+      if (size != 0 && td + qd != 0) {
+        const u32 a = dec_digits(size), b = dec_digits(qd), c = dec_digits(td);
+        if (text) {
+          u8* p = text + off;
+          *p++ = (u8)'\n';
+          dec_write(p, size, a);
+          p += a;
+          *p++ = (u8)'\t';
+          dec_write(p, qd, b);
+          p += b;
+          *p++ = (u8)'\t';
+          dec_write(p, td, c);
+        }
+        off += 3u + a + b + c;
+        size = 0;
+      }
+      size += len;
+      td = qd = 0;
+      tail_ins = tail_del = 0;
+      head = false;
+    } else if (code == WGA_OP_I || code == WGA_OP_I_CONT) {
+      td += len;
+      if (head) head_ins += len;
+      tail_ins = code == WGA_OP_I ? len : tail_ins + len;
+    } else if (code == WGA_OP_D || code == WGA_OP_D_CONT) {
+      qd += len;
+      if (head) head_del += len;
+      tail_del = code == WGA_OP_D ? len : tail_del + len;
+    } else {
+      bad_idx = k;
+      break;
+    }
+  }
+  const u32 dl = dec_digits(size);
+  if (text && bad_idx == WGA_NONE) {
+    u8* p = text + off;
+    *p++ = (u8)'\n';
+    dec_write(p, size, dl);
+  }
+  nbytes = off + 1u + dl;
+  tr.head_ins = head_ins;
+  tr.head_del = head_del;
+  tr.tail_ins = tail_ins;
+  tr.tail_del = tail_del;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_cigar_chain(u32 n, const u32* __restrict__ ops,
+                                                     const u64* __restrict__ op_off,
+                                                     wga_chain_trim* trims, u64* nbytes,
+                                                     wga_rec_diag* diag, u8* out,
+                                                     const u64* out_off) {
+  __shared__ u64 s_ent[4][257][3];
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const u64 i = (u64)blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
+  const u32* rec = ops + o0;
+  u8* const text = FILL ? out + out_off[i] : (u8*)0;
+  u64(*const ent)[3] = s_ent[wave];
+  u64 pm_base = 0, pd_base = 0, pi_base = 0, toff = 0;
+  u64 c_pm = 0, c_pd = 0, c_pi = 0; /* triple of the last raising op (or of the first M-like op) */
+  bool seen_m = false;
+  u64 first_m = 0;                  /* op index of the record's first M-like op */
+  wga_chain_trim tr;
+  tr.head_ins = tr.head_del = tr.tail_ins = tr.tail_del = 0;
+  u32 carry_code = 0xFu;
+  u64 bad_idx = WGA_NONE;
+  i64 last_m = -1, last_i = -1, last_d = -1;
+  u64 last_i_pi = 0, last_d_pd = 0;
+  bool weird = false;
+  for (u64 k0 = 0; k0 < nops; k0 += 256) {
+    const u64 kb = k0 + (u64)lane * 4u;
+    u32 code[4], len[4];
+    bool in[4], mlike[4], isi[4], isd[4], badop[4];
+    bool zero_len = false;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      in[e] = kb + (u64)e < nops;
+      const u32 w = in[e] ? rec[kb + e] : 0xFu;
+      code[e] = w & 15u;
+      len[e] = w >> 4;
+      mlike[e] = code[e] == WGA_OP_M || code[e] == WGA_OP_EQ || code[e] == WGA_OP_X;
+      isi[e] = code[e] == WGA_OP_I || code[e] == WGA_OP_I_CONT;
+      isd[e] = code[e] == WGA_OP_D || code[e] == WGA_OP_D_CONT;
+      badop[e] = in[e] && !(mlike[e] || isi[e] || isd[e]);
+      zero_len |= in[e] && len[e] == 0u;
+    }
+    if (__ballot(zero_len)) { /* wave-uniform: a zero-length op somewhere: the serial walk is exact for those */
+      weird = true;
+      break;
+    }
+    /* the fold stops at the first op outside M = X I D (CigarOpInvalid): ops from there on are dead */
+    const int stop = ballot4_first(badop, lane);
+    bool live[4], lm[4], li[4], ld[4];
+    u32 sm = 0, sd = 0, si = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      live[e] = in[e] && (stop < 0 || (int)(lane * 4u + (u32)e) < stop);
+      lm[e] = live[e] && mlike[e];
+      li[e] = live[e] && isi[e];
+      ld[e] = live[e] && isd[e];
+      sm += lm[e] ? len[e] : 0u;
+      sd += ld[e] ? len[e] : 0u;
+      si += li[e] ? len[e] : 0u;
+    }
+    /* exact wave scans of the lane sums (< 2^30) on 16-bit halves */
+    const u32 ml = wave_incl_scan_u32(sm & 0xFFFFu), mh = wave_incl_scan_u32(sm >> 16);
+    const u32 dl = wave_incl_scan_u32(sd & 0xFFFFu), dh = wave_incl_scan_u32(sd >> 16);
+    const u32 il = wave_incl_scan_u32(si & 0xFFFFu), ih = wave_incl_scan_u32(si >> 16);
+    u64 pm = pm_base + (((u64)mh << 16) + (u64)ml) - (u64)sm; /* prefixes before this lane's first op */
+    u64 pd = pd_base + (((u64)dh << 16) + (u64)dl) - (u64)sd;
+    u64 pi = pi_base + (((u64)ih << 16) + (u64)il) - (u64)si;
+    u64 pme[4], pde[4], pie[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      pme[e] = pm;
+      pde[e] = pd;
+      pie[e] = pi;
+      pm += lm[e] ? len[e] : 0u;
+      pd += ld[e] ? len[e] : 0u;
+      pi += li[e] ? len[e] : 0u;
+    }
+    /* the record's first M-like op: its triple opens the first line, its D / I prefixes are the head trim */
+    if (!seen_m) {
+      const int f = ballot4_first(lm, lane);
+      if (f >= 0) {
+        const int fl = f >> 2, fe = f & 3;
+        const u64 vd = fe == 0 ? pde[0] : fe == 1 ? pde[1] : fe == 2 ? pde[2] : pde[3];
+        const u64 vi = fe == 0 ? pie[0] : fe == 1 ? pie[1] : fe == 2 ? pie[2] : pie[3];
+        c_pm = 0;
+        c_pd = __shfl(vd, fl);
+        c_pi = __shfl(vi, fl);
+        tr.head_del = c_pd;
+        tr.head_ins = c_pi;
+        first_m = k0 + (u64)f;
+        seen_m = true;
+      }
+    }
+    /* raising ops: an M-like op right behind an indel op, with an M-like op somewhere before it */
+    u32 prevc = (u32)__shfl_up((int)code[3], 1u);
+    if (lane == 0) prevc = carry_code;
+    bool em[4];
+    u32 nem = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const u32 pc = e == 0 ? prevc : code[e - 1];
+      const bool prev_indel = pc == WGA_OP_I || pc == WGA_OP_I_CONT || pc == WGA_OP_D || pc == WGA_OP_D_CONT;
+      em[e] = lm[e] && prev_indel && seen_m && (kb + (u64)e > first_m);
+      nem += em[e] ? 1u : 0u;
+    }
+    const u32 einc = wave_incl_scan_u32(nem);
+    const u32 tot_em = wave_last_u32(einc);
+    if (tot_em) { /* wave-uniform */
+      WGA_WAVE_SYNC();
+      if (lane == 0) ent[0][0] = c_pm, ent[0][1] = c_pd, ent[0][2] = c_pi;
+      u32 rank = einc - nem;
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (em[e]) {
+          rank++;
+          ent[rank][0] = pme[e];
+          ent[rank][1] = pde[e];
+          ent[rank][2] = pie[e];
+        }
+      WGA_WAVE_SYNC();
+      /* line lengths, then offsets, then text */
+      u64 vs[4], vq[4], vt[4];
+      u32 ll[4], lsum = 0;
+      rank = einc - nem;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        ll[e] = 0;
+        if (em[e]) {
+          vs[e] = pme[e] - ent[rank][0];
+          vq[e] = pde[e] - ent[rank][1];
+          vt[e] = pie[e] - ent[rank][2];
+          ll[e] = 3u + dec_digits(vs[e]) + dec_digits(vq[e]) + dec_digits(vt[e]);
+          rank++;
+        }
+        lsum += ll[e];
+      }
+      const u32 linc = wave_incl_scan_u32(lsum); /* <= 256 lines x 63 bytes */
+      if (FILL) {
+        u8* p = text + toff + (u64)(linc - lsum);
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (em[e]) {
+            const u32 a = dec_digits(vs[e]), b = dec_digits(vq[e]), c = dec_digits(vt[e]);
+            *p++ = (u8)'\n';
+            dec_write(p, vs[e], a);
+            p += a;
+            *p++ = (u8)'\t';
+            dec_write(p, vq[e], b);
+            p += b;
+            *p++ = (u8)'\t';
+            dec_write(p, vt[e], c);
+            p += c;
+          }
+      }
+      toff += (u64)wave_last_u32(linc);
+      c_pm = ent[tot_em][0];
+      c_pd = ent[tot_em][1];
+      c_pi = ent[tot_em][2];
+    }
+    /* tail trim = length of the last I / D op behind the last M-like op: remember where the last
+     * M-like op and the last I / D *head* ops are, and the I / D prefix in front of those heads
+     * (a length split by the packer is head + continuation pieces) */
+    {
+      bool hi_[4], hd_[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        hi_[e] = live[e] && code[e] == WGA_OP_I;
+        hd_[e] = live[e] && code[e] == WGA_OP_D;
+      }
+      const int xm = ballot4_last(lm), xi = ballot4_last(hi_), xd = ballot4_last(hd_);
+      if (xm >= 0) last_m = (i64)(k0 + (u64)xm);
+      if (xi >= 0) {
+        const int e = xi & 3;
+        const u64 v = e == 0 ? pie[0] : e == 1 ? pie[1] : e == 2 ? pie[2] : pie[3];
+        last_i = (i64)(k0 + (u64)xi);
+        last_i_pi = __shfl(v, xi >> 2);
+      }
+      if (xd >= 0) {
+        const int e = xd & 3;
+        const u64 v = e == 0 ? pde[0] : e == 1 ? pde[1] : e == 2 ? pde[2] : pde[3];
+        last_d = (i64)(k0 + (u64)xd);
+        last_d_pd = __shfl(v, xd >> 2);
+      }
+    }
+    pm_base += ((u64)wave_last_u32(mh) << 16) + (u64)wave_last_u32(ml);
+    pd_base += ((u64)wave_last_u32(dh) << 16) + (u64)wave_last_u32(dl);
+    pi_base += ((u64)wave_last_u32(ih) << 16) + (u64)wave_last_u32(il);
+    carry_code = (u32)__shfl((int)code[3], 63);
+    if (stop >= 0) {
+      bad_idx = k0 + (u64)stop;
+      break;
+    }
+  }
+  if (weird) { /* wave-uniform */
+    if (lane == 0) {
+      u64 nb = 0, bad = WGA_NONE;
+      chain_serial(rec, nops, text, tr, nb, bad);
+      if (!FILL) {
+        nbytes[i] = nb;
+        trims[i] = tr;
+        if (bad != WGA_NONE) diag[i].bad_op_idx = bad;
+      }
+    }
+    return;
+  }
+  if (!seen_m) { /* no M-like op at all: every indel is "head" */
+    tr.head_ins = pi_base;
+    tr.head_del = pd_base;
+  }
+  tr.tail_ins = last_i > last_m ? pi_base - last_i_pi : 0ull;
+  tr.tail_del = last_d > last_m ? pd_base - last_d_pd : 0ull;
+  /* the last block: "\n<size>" (cigar.rs:289-291; 0 when the record has no M-like op) */
+  const u64 last = seen_m ? pm_base - c_pm : 0ull;
+  const u32 dl2 = dec_digits(last);
+  if (lane == 0) {
+    if (FILL && bad_idx == WGA_NONE) {
+      u8* p = text + toff;
+      *p++ = (u8)'\n';
+      dec_write(p, last, dl2);
+    }
+    if (!FILL) {
+      nbytes[i] = toff + 1u + dl2;
+      trims[i] = tr;
+      if (bad_idx != WGA_NONE) diag[i].bad_op_idx = bad_idx;
+    }
+  }
+}
+
 #endif /* WGA_KERNELS2_H */

@@ -13,6 +13,7 @@ COUNTS_DTYPE = np.dtype([(k, "<u8") for k in (
     "match", "mismatch", "ins_ev", "ins_bp", "del_ev", "del_bp", "inv_ins_ev", "inv_ins_bp",
     "inv_del_ev", "inv_del_bp", "inv_ev")])
 DIAG_DTYPE = np.dtype([("bad_op_idx", "<u8"), ("panic_op_idx", "<u8"), ("bad_base_pos", "<u8")])
+CHAIN_TRIM_DTYPE = np.dtype([(k, "<u8") for k in ("head_ins", "head_del", "tail_ins", "tail_del")])
 TOK_ERR_DTYPE = np.dtype([("err", np.int32), ("tok_len", np.uint32), ("tok_off", np.uint64)])
 CLASS_SUMS_DTYPE = np.dtype([(k, "<u8") for k in ("mx", "i", "d", "s", "o")])
 NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -234,6 +235,16 @@ class Engine:
         self._check(self.lib.wga_cigar_tokenise(self.ctx, n, _p(text), _p(text_off), _p(op_cnt), _p(err),
                                                 _p(ops), _p(op_off)))
         return op_cnt, err
+
+    def cigar_chain(self, batch, trim=None, nbytes=None, diag=None, out=None, out_off=None):
+        """paf2chain data lines: count pass when out is None (trim, nbytes, diag), fill pass otherwise"""
+        if out is None:
+            trim = trim if trim is not None else self.empty(batch.n, CHAIN_TRIM_DTYPE)
+            nbytes = nbytes if nbytes is not None else self.empty(batch.n, np.uint64)
+            diag = diag if diag is not None else self.empty(batch.n, DIAG_DTYPE)
+        self._check(self.lib.wga_cigar_chain(self.ctx, C.byref(batch.c), _p(trim), _p(nbytes), _p(diag),
+                                             _p(out), _p(out_off)))
+        return trim, nbytes, diag
 
     def paf_call_events(self, batch, svlen, snp, ev_cnt=None, ev=None, ev_off=None):
         ev_cnt = ev_cnt if ev_cnt is not None else self.empty(batch.n, np.uint64)

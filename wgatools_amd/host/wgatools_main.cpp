@@ -587,6 +587,107 @@ int cmd_validate(const std::string* input, const std::string* fix, Output& out) 
   return 0;
 }
 
+/* ---- paf2chain (converter.rs:148-173) ------------------------------------------------
+ * GPU: tokeniser, data lines and head / tail trims (wga_cigar_chain).  Host: chain headers
+ * (chain.rs:142-203, incl. the '-' strand arithmetic that reuses the updated start) and the layout. */
+int cmd_paf2chain(const std::string* input, Output& out) {
+  std::vector<PafRecord> recs = parse_paf(read_all(input));
+  Dev d;
+  bool dev_ready = false;
+  const uint64_t kMaxText = 160ull << 20;
+  size_t i0 = 0;
+  std::string pending_error;
+  while (i0 < recs.size() && pending_error.empty()) {
+    size_t i = i0;
+    uint64_t est_text = 0;
+    for (; i < recs.size(); i++) {
+      if (i > i0 && est_text > kMaxText) break;
+      for (const auto& tg : recs[i].tags) est_text += tg.size();
+    }
+    if (!dev_ready) {
+      d.init();
+      dev_ready = true;
+    }
+    std::vector<std::string> cigars;
+    wga_cigar_batch cb;
+    pending_error = device_tokenise(d, &recs[i0], (uint32_t)(i - i0), cigars, &cb);
+    uint32_t n = cb.n;
+    if (n) {
+      auto* d_trim = (wga_chain_trim_t*)d.alloc((size_t)n * sizeof(wga_chain_trim_t));
+      auto* d_nb = (uint64_t*)d.alloc((size_t)n * 8);
+      auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
+      d.check(wga_cigar_chain(d.ctx, &cb, d_trim, d_nb, d_diag, nullptr, nullptr));
+      std::vector<wga_chain_trim_t> trim(n);
+      std::vector<uint64_t> nb(n);
+      std::vector<wga_rec_diag> diag(n);
+      d.download(trim.data(), d_trim, n);
+      d.download(nb.data(), d_nb, n);
+      d.download(diag.data(), d_diag, n);
+      for (uint32_t k = 0; k < n; k++)
+        if (diag[k].bad_op_idx != WGA_NONE) { /* parse_cigar_to_trim fails before anything of the record is written */
+          pending_error = "CIGAR OP `" + cigar_op_token_at(cigars[k], diag[k].bad_op_idx) + "` invalid";
+          n = k;
+          break;
+        }
+      if (n) {
+        std::string blob;
+        std::vector<uint64_t> blob_off{0}, dst, data_off(n);
+        uint64_t pos = 0;
+        for (uint32_t k = 0; k < n; k++) {
+          const PafRecord& r = recs[i0 + k];
+          const wga_chain_trim_t& t = trim[k];
+          uint64_t qs = r.query_start, qe = r.query_end, ts = r.target_start + t.head_del, te = r.target_end - t.tail_del;
+          if (!r.neg) {
+            qs += t.head_ins;
+            qe -= t.tail_ins;
+          } else {
+            qs = r.query_length - (qe - t.head_ins);
+            qe = r.query_length - (qs + t.tail_ins);
+          }
+          std::string h = "chain\t255\t" + r.target_name + "\t";
+          append_u64(h, r.target_length);
+          h += "\t+\t";
+          append_u64(h, ts);
+          h.push_back('\t');
+          append_u64(h, te);
+          h += "\t" + r.query_name + "\t";
+          append_u64(h, r.query_length);
+          h += r.neg ? "\t-\t" : "\t+\t";
+          append_u64(h, qs);
+          h.push_back('\t');
+          append_u64(h, qe);
+          h.push_back('\t');
+          append_u64(h, (uint64_t)(i0 + k));
+          dst.push_back(pos);
+          blob += h;
+          blob_off.push_back(blob.size());
+          pos += h.size();
+          data_off[k] = pos;
+          pos += nb[k];
+          dst.push_back(pos);
+          blob += "\n\n";
+          blob_off.push_back(blob.size());
+          pos += 2;
+        }
+        auto* d_out = (uint8_t*)d.alloc(pos + 64);
+        wga_cigar_batch cb2 = cb;
+        cb2.n = n;
+        d.check(wga_cigar_chain(d.ctx, &cb2, nullptr, nullptr, nullptr, d_out, d.upload(data_off)));
+        d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off),
+                                  d_out, d.upload(dst)));
+        std::string host((size_t)pos, '\0');
+        d.download((uint8_t*)&host[0], d_out, pos);
+        out.write(host);
+      }
+    }
+    d.release_all();
+    i0 = i;
+  }
+  out.close();
+  if (!pending_error.empty()) fail(pending_error);
+  return 0;
+}
+
 /* ---- pafcov (pafcov.rs:13-83) --------------------------------------------------------------------- */
 int cmd_pafcov(const std::string* input, Output& out) {
   std::vector<PafRecord> recs = parse_paf(read_all(input));
@@ -1333,6 +1434,7 @@ void usage() {
           "  pafcov  | pc   [PAF]\n"
           "  pafpseudo | pp [PAF] -o OUTDIR [-f ALL.fa] [-g TARGET]\n"
           "  validate | vf  [PAF] [-f FIXED.paf]\n"
+          "  paf2chain | p2c [PAF]\n"
           "  call    | c    [MAF] [-s] [-i] [-l SVLEN] [-n SAMPLE] [--query-name N | --query-regex R] [-c CHUNK]\n"
           "  call    | c    -f paf [PAF] --target T.fa --query Q.fa [-s] [-l SVLEN] [-n SAMPLE]\n");
 }
@@ -1487,6 +1589,10 @@ int main(int argc, char** argv) {
       if (format == "paf") return cmd_stat_paf(input, each, out);
       if (format == "maf") return cmd_stat_maf(input, each, qn, out);
       fail("format `" + format + "` is not supported by this engine (maf | paf)");
+    }
+    if (cmd == "paf2chain" || cmd == "p2c") {
+      out.open(outfile, rewrite);
+      return cmd_paf2chain(input, out);
     }
     if (validate) {
       if (has_fix && fix_path == (has_input ? input_s : std::string("stdin")))
