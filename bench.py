@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--check", type=int, default=8, help="records spot-checked against the oracle")
     ap.add_argument("--param", action="append", default=[], help="engine test knob name=value")
     ap.add_argument("--neg-frac", type=float, default=0.5)
+    ap.add_argument("--m-only", action="store_true", help="variant of configs[1] with = / X merged into M ops")
     args = ap.parse_args()
 
     import torch
@@ -133,7 +134,7 @@ def main():
         eng.set_param(k, int(v))
     seed = 0x5747415F + 2 + rank
     tb = synth.make_paf_batch_torch(seed, args.records, args.mean_ops, args.pool_mb * 1_000_000, dev,
-                                    neg_frac=args.neg_frac)
+                                    neg_frac=args.neg_frac, use_m=args.m_only)
     job = pipeline.Paf2MafStatJob(eng, tb)
     job.bind_stream()
     totals = torch.zeros(11, dtype=torch.int64, device=dev)
