@@ -780,6 +780,9 @@ __device__ __forceinline__ u32 wave_get_u32(u32 v, int k) {
 #ifndef WGA_EMIT_U
 #define WGA_EMIT_U 4 /* chunks in flight per lane */
 #endif
+#ifndef WGA_SOLO_BYTES
+#define WGA_SOLO_BYTES 8192u /* rows up to this many bytes are emitted by a single wave */
+#endif
 #define WGA_QCAP (64u * (WGA_EMIT_U + 1u)) /* per-wave queue of complex chunks: < 64 left over + one iteration's pushes */
 
 /* Granule table: one 16-bit field per row (target row = low half, query row = high half of a
@@ -991,7 +994,7 @@ __device__ __forceinline__ void emit_row_t(u8* dst, u32 N, u32 c0, const RowDesc
   src.rc = RC;
   const u32 lane = tid & 63u;
   const RowGeom rg = row_geom(dst, N, c0);
-  u32* const queue = rd.queue + (tid >> 6) * WGA_QCAP;
+  u32* const queue = rd.queue + (threadIdx.x >> 6) * WGA_QCAP; /* the wave's own, whoever it works with */
   u32 qn = 0; /* wave-uniform queue length */
   const u32 per_it = nthreads * WGA_EMIT_U;
   const u32 niter = (rg.nchunks + per_it - 1) / per_it;
@@ -1439,6 +1442,7 @@ __global__ __launch_bounds__(256, 5) void k_paf2maf_expand(ExpandArgs a) {
   u64 cur = tile_start;
   u64 re = wave_get_u64(pre, 12);
   u32 bnd_col = 0u, bnd_ev = 0u, nseg = 0u; /* prefix at the start of the current segment */
+  u32 njob = 0u;                           /* short-row jobs seen so far (same count in every wave) */
   while (cur < tile_end) {
     while (re <= cur) {
       r++;
@@ -1612,6 +1616,11 @@ __global__ __launch_bounds__(256, 5) void k_paf2maf_expand(ExpandArgs a) {
         nbytes = row_len > L ? row_len - L : 0;
       }
       if (nbytes == 0) continue;
+      /* a short row is taken by ONE wave (round-robin over the tile's row jobs) instead of a quarter
+       * each by all four: one prologue and one queue drain per row instead of four — what short
+       * records (several segments per tile) spend most of their time in */
+      const bool solo = nbytes <= WGA_SOLO_BYTES;
+      if (solo && (njob++ & 3u) != wave) continue;
       u8* const dst = a.out + wave_get_u64(dsc, 14 + q2) + x0;
       const u64 sb0 = is_tail ? L - gap_total : (is_q ? qb : tb);
       for (u64 done = 0; done < nbytes; done += (1ull << 30)) {
@@ -1630,7 +1639,8 @@ __global__ __launch_bounds__(256, 5) void k_paf2maf_expand(ExpandArgs a) {
         rd.gsh = is_tail ? 31u : gsh;
         rd.queue = s_queue;
         rowsrc_prepare(src, rd.sbase);
-        emit_row(dst + done, (u32)m, is_tail ? 0u : col_a + (u32)done, rd, src, tid, WGA_BLOCK, bad_base);
+        emit_row(dst + done, (u32)m, is_tail ? 0u : col_a + (u32)done, rd, src, solo ? lane : tid,
+                 solo ? 64u : WGA_BLOCK, bad_base);
       }
     }
     cur = seg_end;
