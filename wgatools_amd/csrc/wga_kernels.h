@@ -781,7 +781,10 @@ __device__ __forceinline__ u32 wave_get_u32(u32 v, int k) {
 #define WGA_EMIT_U 4 /* chunks in flight per lane */
 #endif
 #ifndef WGA_SOLO_BYTES
-#define WGA_SOLO_BYTES 8192u /* rows up to this many bytes are emitted by a single wave */
+#define WGA_SOLO_BYTES 65536u /* rows up to this many bytes are emitted wave by wave, longer ones by the block */
+#endif
+#ifndef WGA_SPLIT_BYTES
+#define WGA_SPLIT_BYTES 8192u /* ... in two halves beyond this */
 #endif
 #define WGA_QCAP (64u * (WGA_EMIT_U + 1u)) /* per-wave queue of complex chunks: < 64 left over + one iteration's pushes */
 
@@ -1616,31 +1619,42 @@ __global__ __launch_bounds__(256, 5) void k_paf2maf_expand(ExpandArgs a) {
         nbytes = row_len > L ? row_len - L : 0;
       }
       if (nbytes == 0) continue;
-      /* a short row is taken by ONE wave (round-robin over the tile's row jobs) instead of a quarter
-       * each by all four: one prologue and one queue drain per row instead of four — what short
-       * records (several segments per tile) spend most of their time in */
-      const bool solo = nbytes <= WGA_SOLO_BYTES;
-      if (solo && (njob++ & 3u) != wave) continue;
+      /* Rows of ordinary size are not shared out thread by thread: a row (or each half of it, cut
+       * on a granule boundary) is taken by ONE wave, round-robin over the tile's row jobs — one
+       * prologue and one set of queue drains per row instead of four quarter-full ones.  Only
+       * rows beyond WGA_SOLO_BYTES (giant tiles) are emitted by the whole block together. */
+      const bool coop = nbytes > WGA_SOLO_BYTES;
+      const u32 c_row = is_tail ? 0u : col_a; /* column of the row's first byte */
+      u64 cut = nbytes;                        /* first piece = [0, cut), second = [cut, nbytes) */
+      if (!coop && nbytes > WGA_SPLIT_BYTES) {
+        const u32 cc = (c_row + (u32)(nbytes >> 1)) & ~15u;
+        if (cc > c_row && (u64)(cc - c_row) < nbytes) cut = cc - c_row;
+      }
       u8* const dst = a.out + wave_get_u64(dsc, 14 + q2) + x0;
       const u64 sb0 = is_tail ? L - gap_total : (is_q ? qb : tb);
-      for (u64 done = 0; done < nbytes; done += (1ull << 30)) {
-        const u64 m = nbytes - done < (1ull << 30) ? nbytes - done : (1ull << 30);
-        RowDesc rd;
-        rd.c_org = is_tail ? 0u : col_a;
-        rd.G_col = is_q ? s_qg_col : s_tg_col;
-        rd.G_cum = rd.G_adj = is_q ? s_qg_cum : s_tg_cum;
-        rd.ga = is_tail ? 0 : (is_q ? ja : ia);
-        rd.gb = is_tail ? 0 : (is_q ? jb : ib);
-        rd.gcum_a = is_tail ? 0u : (is_q ? dcum_a : icum_a);
-        rd.sbase = is_tail ? sb0 + done : sb0;
-        rd.lowmask = s_lowmask;
-        rd.tbl = is_tail ? s_zero2 : s_tbl;
-        rd.tsh = (is_q && !is_tail) ? 16u : 0u;
-        rd.gsh = is_tail ? 31u : gsh;
-        rd.queue = s_queue;
-        rowsrc_prepare(src, rd.sbase);
-        emit_row(dst + done, (u32)m, is_tail ? 0u : col_a + (u32)done, rd, src, solo ? lane : tid,
-                 solo ? 64u : WGA_BLOCK, bad_base);
+      for (int piece = 0; piece < 2; piece++) {
+        const u64 lo = piece == 0 ? 0 : cut, hi = piece == 0 ? cut : nbytes;
+        if (lo >= hi) continue;
+        if (!coop && (njob++ & 3u) != wave) continue;
+        for (u64 done = lo; done < hi; done += (1ull << 30)) {
+          const u64 m = hi - done < (1ull << 30) ? hi - done : (1ull << 30);
+          RowDesc rd;
+          rd.c_org = is_tail ? 0u : col_a;
+          rd.G_col = is_q ? s_qg_col : s_tg_col;
+          rd.G_cum = rd.G_adj = is_q ? s_qg_cum : s_tg_cum;
+          rd.ga = is_tail ? 0 : (is_q ? ja : ia);
+          rd.gb = is_tail ? 0 : (is_q ? jb : ib);
+          rd.gcum_a = is_tail ? 0u : (is_q ? dcum_a : icum_a);
+          rd.sbase = is_tail ? sb0 + done : sb0;
+          rd.lowmask = s_lowmask;
+          rd.tbl = is_tail ? s_zero2 : s_tbl;
+          rd.tsh = (is_q && !is_tail) ? 16u : 0u;
+          rd.gsh = is_tail ? 31u : gsh;
+          rd.queue = s_queue;
+          rowsrc_prepare(src, rd.sbase);
+          emit_row(dst + done, (u32)m, is_tail ? 0u : col_a + (u32)done, rd, src, coop ? tid : lane,
+                   coop ? WGA_BLOCK : 64u, bad_base);
+        }
       }
     }
     cur = seg_end;
