@@ -783,6 +783,9 @@ __device__ __forceinline__ u32 wave_get_u32(u32 v, int k) {
 #ifndef WGA_SOLO_BYTES
 #define WGA_SOLO_BYTES 65536u /* rows up to this many bytes are emitted wave by wave, longer ones by the block */
 #endif
+#ifndef WGA_DRAIN_MIN
+#define WGA_DRAIN_MIN 64u /* queued complex chunks that trigger a drain before the row ends */
+#endif
 #ifndef WGA_SPLIT_BYTES
 #define WGA_SPLIT_BYTES 8192u /* ... in two halves beyond this */
 #endif
@@ -1086,7 +1089,7 @@ __device__ __forceinline__ void emit_row_t(u8* dst, u32 N, u32 c0, const RowDesc
     WGA_WAVE_SYNC();
     /* drain the queue 64 chunks at a time, and whatever is left when the row ends */
     const bool last = it + 1 >= niter;
-    while (qn >= 64u || (last && qn > 0u)) {
+    while (qn >= WGA_DRAIN_MIN || (last && qn > 0u)) {
       const u32 take = qn < 64u ? qn : 64u;
       qn -= take;
       if (lane < take) {
