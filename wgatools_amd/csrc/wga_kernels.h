@@ -1457,7 +1457,7 @@ __global__ __launch_bounds__(256, 5) void k_paf2maf_expand(ExpandArgs a) {
     const bool is0 = r == r0;
     const u64 rs = is0 ? wave_get_u64(pre, 10) : a.op_off[r];
     const u64 seg_end = re < tile_end ? re : tile_end;
-    const u32 ka = (u32)(cur - tile_start), kb = (u32)(seg_end - tile_start);
+    const u32 kb = (u32)(seg_end - tile_start);
 
     /* class sums of this record before the tile (only the tile's first segment can continue a
      * record; k_tile_base worked them out) and the record's geometry (k_rec_desc) */
