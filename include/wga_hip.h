@@ -241,6 +241,32 @@ typedef struct {
 int wga_cigar_chain(wga_ctx*, const wga_cigar_batch*, wga_chain_trim_t* d_trim, uint64_t* d_nbytes,
                     wga_rec_diag* d_diag, uint8_t* d_out, const uint64_t* d_out_off);
 
+/* ---- K11: bridges between run / data-line lists, packed ops and CIGAR text ----
+ * The remaining chain converters and maf2paf's text all reduce to walks that already exist once
+ * their input is a wga_cigar_batch, and their CIGAR text is pure integer formatting:
+ *   maf2chain  (converter.rs:57-91, parse_maf_seq_to_chain / _trim cigar.rs:155-199,435-457)
+ *              = K3 runs -> wga_maf_runs_ops -> wga_cigar_chain  (cigar_cat merges '=' and X into M:
+ *              cigar_unit_chain adds adjacent M-like ops into one size, cigar.rs:467-476)
+ *   maf2paf    cg:Z: text (maf.rs:484-520, cigar.rs:400-401)          = wga_maf_runs_cigar_text
+ *   chain2maf  (converter.rs:268-358, parse_chain_to_insert :360-388) = wga_chain_lines_ops -> K1 -> K2
+ *   chain2paf  (chain.rs:430-452, parse_chain_to_cigar cigar.rs:554-627)
+ *              = wga_chain_lines_ops -> K1 (matches, block length) + wga_chain_lines_cigar_text
+ * A data line is three u64: size, 2nd text column (D bases), 3rd text column (I bases); a line is
+ * walked as M size, I, D (zero lengths are left out of the ops; the text always has "<size>M").
+ * Runs are K3's (wga_maf_pair_stat).  n_elems = d_*_off[n] = total runs / lines (< 2^32).
+ * Two calls each: d_out == NULL fills d_cnt[n] (ops / bytes of record i); then record i's output is
+ * written at d_out + d_out_off[i] (ops: in elements; text: in bytes). */
+int wga_maf_runs_ops(wga_ctx*, uint32_t n, uint64_t n_elems, const uint64_t* d_runs, const uint64_t* d_run_off,
+                     const uint64_t* d_cols, uint64_t* d_cnt, uint32_t* d_out, const uint64_t* d_out_off);
+int wga_maf_runs_cigar_text(wga_ctx*, uint32_t n, uint64_t n_elems, const uint64_t* d_runs,
+                            const uint64_t* d_run_off, const uint64_t* d_cols, uint64_t* d_cnt, uint8_t* d_out,
+                            const uint64_t* d_out_off);
+int wga_chain_lines_ops(wga_ctx*, uint32_t n, uint64_t n_elems, const uint64_t* d_lines,
+                        const uint64_t* d_line_off, uint64_t* d_cnt, uint32_t* d_out, const uint64_t* d_out_off);
+int wga_chain_lines_cigar_text(wga_ctx*, uint32_t n, uint64_t n_elems, const uint64_t* d_lines,
+                               const uint64_t* d_line_off, uint64_t* d_cnt, uint8_t* d_out,
+                               const uint64_t* d_out_off);
+
 /* ---- K5: pafcov (replaces update_cov_vec, cigar.rs:710-741, and the per-thread array merge of
  *      pafcov.rs:29-53) ------------------------------------------------------------------------
  * Record i adds +1 to d_cov[cov_off[target_id[i]] + p] for every base p of its M / = ops that

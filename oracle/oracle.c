@@ -981,6 +981,178 @@ int orc_paf2chain_record(const char* q_name, uint64_t q_size, uint64_t q_start, 
   return ORC_OK;
 }
 
+/* ---- the other chain converters ------------------------------------------- */
+/* cigar_cat, cigar.rs:331-341: equal or both non-gap -> 'M' */
+static char cigar_cat(char c1, char c2) {
+  if (c1 == c2) return 'M';
+  if (c1 == '-') return 'I';
+  if (c2 == '-') return 'D';
+  return 'M';
+}
+
+/* parse_maf_seq_to_trim, cigar.rs:155-199 (group_by(cigar_cat_ext); zip truncates) */
+void orc_parse_maf_seq_to_trim(const char* t, size_t tn, const char* q, size_t qn, uint64_t out[4]) {
+  uint64_t head_ins = 0, head_del = 0, tail_ins = 0, tail_del = 0;
+  int head_indel = 1;
+  size_t cols = tn < qn ? tn : qn, i = 0;
+  while (i < cols) {
+    char k = cigar_cat_ext(t[i], q[i]);
+    size_t j = i + 1;
+    while (j < cols && cigar_cat_ext(t[j], q[j]) == k) j++;
+    uint64_t count = (uint64_t)(j - i);
+    if (k == 'I') {
+      if (head_indel) head_ins += count;
+      tail_ins = count;
+    } else if (k == 'D') {
+      if (head_indel) head_del += count;
+      tail_del = count;
+    } else { /* 'M' | 'X' | '=' */
+      tail_ins = 0;
+      tail_del = 0;
+      head_indel = 0;
+    }
+    i = j;
+  }
+  out[0] = head_ins;
+  out[1] = head_del;
+  out[2] = tail_ins;
+  out[3] = tail_del;
+}
+
+/* one record of converter::maf2chain (converter.rs:57-91): ChainHeader::try_from(&MAFRecord)
+ * (chain.rs:103-140: target strand always '+', query coordinates through the strand-aware
+ * accessors of maf.rs:433-450, then the same trim arithmetic as for PAF), its Display, the data
+ * lines of parse_maf_seq_to_chain (cigar.rs:435-457: group_by(cigar_cat) through cigar_unit_chain)
+ * and the closing "\n\n".  q_start / q_align are the s-line's own fields.  *out is malloc'd. */
+void orc_maf2chain_record(const char* t_name, uint64_t t_size, uint64_t t_start, uint64_t t_align,
+                          const char* q_name, uint64_t q_size, uint64_t q_sline_start,
+                          uint64_t q_sline_align, int strand_neg, const char* t, size_t tn,
+                          const char* q, size_t qn, uint64_t chain_id, char** out, size_t* out_len) {
+  uint64_t tr[4];
+  orc_parse_maf_seq_to_trim(t, tn, q, qn, tr);
+  uint64_t qs = strand_neg ? q_size - q_sline_start - q_sline_align : q_sline_start;
+  uint64_t qe = strand_neg ? q_size - q_sline_start : q_sline_start + q_sline_align;
+  uint64_t ts = t_start, te = t_start + t_align;
+  if (!strand_neg) {
+    qs += tr[0];
+    ts += tr[1];
+    qe -= tr[2];
+    te -= tr[3];
+  } else {
+    ts += tr[1];
+    te -= tr[3];
+    qs = q_size - (qe - tr[0]);
+    qe = q_size - (qs + tr[2]);
+  }
+  sbuf sb = {NULL, 0, 0};
+  char line[1024];
+  snprintf(line, sizeof line, "chain\t255\t%s\t%llu\t+\t%llu\t%llu\t%s\t%llu\t%c\t%llu\t%llu\t%llu", t_name,
+           (unsigned long long)t_size, (unsigned long long)ts, (unsigned long long)te, q_name,
+           (unsigned long long)q_size, strand_neg ? '-' : '+', (unsigned long long)qs,
+           (unsigned long long)qe, (unsigned long long)chain_id);
+  sb_push(&sb, line, strlen(line));
+  uint64_t size = 0, qd = 0, td = 0;
+  size_t cols = tn < qn ? tn : qn, i = 0;
+  while (i < cols) {
+    char k = cigar_cat(t[i], q[i]);
+    size_t j = i + 1;
+    while (j < cols && cigar_cat(t[j], q[j]) == k) j++;
+    uint64_t len = (uint64_t)(j - i);
+    if (k == 'M') { /* cigar_unit_chain, cigar.rs:467-476 */
+      if (size != 0 && td + qd != 0) {
+        snprintf(line, sizeof line, "\n%llu\t%llu\t%llu", (unsigned long long)size, (unsigned long long)qd,
+                 (unsigned long long)td);
+        sb_push(&sb, line, strlen(line));
+        size = 0;
+      }
+      size += len;
+      td = 0;
+      qd = 0;
+    } else if (k == 'I') {
+      td += len;
+    } else {
+      qd += len;
+    }
+    i = j;
+  }
+  snprintf(line, sizeof line, "\n%llu\n\n", (unsigned long long)size);
+  sb_push(&sb, line, strlen(line));
+  *out = sb.s;
+  *out_len = sb.n;
+}
+
+/* parse_chain_to_cigar, cigar.rs:554-627.  lines = n_lines x (size, query_diff, target_diff) in the
+ * order chain.rs:330-348 reads a data line.  *text = malloc'd NUL-terminated CIGAR (no tag). */
+void orc_parse_chain_to_cigar(const uint64_t* lines, size_t n_lines, int strand_neg, orc_counts* out,
+                              char** text) {
+  memset(out, 0, sizeof(*out));
+  sbuf sb = {0, 0, 0};
+  sb_push(&sb, "", 0);
+  if (strand_neg) out->inv_ev = 1;
+  for (size_t k = 0; k < n_lines; k++) {
+    const uint64_t match_len = lines[3 * k], del_len = lines[3 * k + 1], ins_len = lines[3 * k + 2];
+    sb_printf_u64(&sb, match_len);
+    sb_push(&sb, "M", 1);
+    out->match += match_len;
+    if (ins_len) {
+      sb_printf_u64(&sb, ins_len);
+      sb_push(&sb, "I", 1);
+      if (strand_neg) {
+        out->inv_ins_ev += 1;
+        out->inv_ins_bp += ins_len;
+      } else {
+        out->ins_ev += 1;
+        out->ins_bp += ins_len;
+      }
+    }
+    if (del_len) {
+      sb_printf_u64(&sb, del_len);
+      sb_push(&sb, "D", 1);
+      if (strand_neg) {
+        out->inv_del_ev += 1;
+        out->inv_del_bp += del_len;
+      } else {
+        out->del_ev += 1;
+        out->del_bp += del_len;
+      }
+    }
+  }
+  sb_push(&sb, "\0", 1);
+  *text = sb.s;
+}
+
+/* parse_chain_to_insert, converter.rs:360-388: String::insert_str of '-' runs at the running
+ * column offset; returns ORC_PANIC where insert_str would panic (offset beyond the string).
+ * *t / *q are malloc'd buffers, re-allocated as they grow. */
+static int insert_dashes(char** s, size_t* n, uint64_t at, uint64_t count) {
+  if (at > *n) return -1;
+  char* r = (char*)malloc(*n + (size_t)count + 1);
+  memcpy(r, *s, (size_t)at);
+  memset(r + at, '-', (size_t)count);
+  memcpy(r + at + count, *s + at, *n - (size_t)at);
+  free(*s);
+  *s = r;
+  *n += (size_t)count;
+  return 0;
+}
+int orc_parse_chain_to_insert(const uint64_t* lines, size_t n_lines, char** t, size_t* tn, char** q,
+                              size_t* qn) {
+  uint64_t cur = 0;
+  for (size_t k = 0; k < n_lines; k++) {
+    const uint64_t del_len = lines[3 * k + 1], ins_len = lines[3 * k + 2];
+    cur += lines[3 * k];
+    if (ins_len) {
+      if (insert_dashes(t, tn, cur, ins_len)) return ORC_PANIC;
+      cur += ins_len;
+    }
+    if (del_len) {
+      if (insert_dashes(q, qn, cur, del_len)) return ORC_PANIC;
+      cur += del_len;
+    }
+  }
+  return ORC_OK;
+}
+
 /* per-record chunk loop of call_var_maf, caller.rs:115-149, with create_chunk_record
  * (:221-265: start += non-gap chars of the prefix, align_size = non-gap chars of the chunk) and
  * the strand-aware accessors of maf.rs:433-450,468-470 applied to the chunk record. */

@@ -111,6 +111,20 @@ int orc_paf2chain_record(const char* q_name, uint64_t q_size, uint64_t q_start, 
                          uint64_t t_end, const char* cg, size_t n, uint64_t chain_id, char** out,
                          size_t* out_len, orc_err* err);
 
+/* cigar.rs:155-199 parse_maf_seq_to_trim over the two rows (zip truncates to the shorter) */
+void orc_parse_maf_seq_to_trim(const char* t, size_t tn, const char* q, size_t qn, uint64_t out[4]);
+/* one record of converter.rs:57-91 maf2chain (chain.rs:103-140 header, cigar.rs:435-457 data lines) */
+void orc_maf2chain_record(const char* t_name, uint64_t t_size, uint64_t t_start, uint64_t t_align,
+                          const char* q_name, uint64_t q_size, uint64_t q_sline_start,
+                          uint64_t q_sline_align, int strand_neg, const char* t, size_t tn,
+                          const char* q, size_t qn, uint64_t chain_id, char** out, size_t* out_len);
+/* cigar.rs:554-627 parse_chain_to_cigar; lines = n_lines x (size, query_diff, target_diff) */
+void orc_parse_chain_to_cigar(const uint64_t* lines, size_t n_lines, int strand_neg, orc_counts* out,
+                              char** text);
+/* converter.rs:360-388 parse_chain_to_insert; ORC_PANIC where String::insert_str would panic */
+int orc_parse_chain_to_insert(const uint64_t* lines, size_t n_lines, char** t, size_t* tn, char** q,
+                              size_t* qn);
+
 void orc_free(void* p);
 /* test helper: packed ops -> "cg:Z:..." text; returns length (0 if cap too small) */
 size_t orc_ops_to_text(const uint32_t* ops, size_t n, char* out, size_t cap);

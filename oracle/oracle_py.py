@@ -60,6 +60,14 @@ def lib():
                                               C.c_char_p, Z, U, U, U, U, C.c_int, C.c_int, U, P, P, P]
         L.orc_parse_cigar_to_trim.argtypes = [C.c_char_p, Z, P, P]
         L.orc_paf2chain_record.argtypes = [C.c_char_p, U, U, U, C.c_int, C.c_char_p, U, U, U, C.c_char_p, Z, U, P, P, P]
+        L.orc_parse_maf_seq_to_trim.argtypes = [C.c_char_p, Z, C.c_char_p, Z, P]
+        L.orc_parse_maf_seq_to_trim.restype = None
+        L.orc_maf2chain_record.argtypes = [C.c_char_p, U, U, U, C.c_char_p, U, U, U, C.c_int, C.c_char_p, Z,
+                                           C.c_char_p, Z, U, P, P]
+        L.orc_maf2chain_record.restype = None
+        L.orc_parse_chain_to_cigar.argtypes = [P, Z, C.c_int, P, P]
+        L.orc_parse_chain_to_cigar.restype = None
+        L.orc_parse_chain_to_insert.argtypes = [P, Z, P, P, P, P]
         L.orc_ops_to_text.restype = Z
         L.orc_ops_to_text.argtypes = [P, Z, C.c_char_p, Z]
         L.orc_free.argtypes = [C.c_void_p]
@@ -251,6 +259,61 @@ def paf2chain_record(q_name, q_size, q_start, q_end, strand_neg, t_name, t_size,
     s = C.string_at(out, out_len.value)
     lib().orc_free(out)
     return s
+
+
+def parse_maf_seq_to_trim(t_row, q_row):
+    """cigar.rs:155-199 -> (head_ins, head_del, tail_ins, tail_del)"""
+    t_row, q_row = bytes(t_row), bytes(q_row)
+    out = (C.c_uint64 * 4)()
+    lib().orc_parse_maf_seq_to_trim(t_row, len(t_row), q_row, len(q_row), out)
+    return tuple(int(x) for x in out)
+
+
+def maf2chain_record(t_name, t_size, t_start, t_align, q_name, q_size, q_start, q_align, strand_neg, t_row,
+                     q_row, chain_id):
+    """converter.rs:57-91 for one MAF block -> chain text (header, data lines, blank line)"""
+    t_row, q_row = bytes(t_row), bytes(q_row)
+    out = C.c_void_p()
+    out_len = C.c_size_t(0)
+    lib().orc_maf2chain_record(t_name.encode(), t_size, t_start, t_align, q_name.encode(), q_size, q_start,
+                               q_align, int(strand_neg), t_row, len(t_row), q_row, len(q_row), chain_id,
+                               C.byref(out), C.byref(out_len))
+    s = C.string_at(out, out_len.value)
+    lib().orc_free(out)
+    return s
+
+
+def _lines_array(lines):
+    a = np.ascontiguousarray(np.asarray(lines, dtype=np.uint64).reshape(-1, 3))
+    return a, C.c_void_p(a.ctypes.data)
+
+
+def parse_chain_to_cigar(lines, strand_neg):
+    """cigar.rs:554-627: lines = [(size, query_diff, target_diff)] -> (counts 11-tuple, CIGAR text)"""
+    a, ptr = _lines_array(lines)
+    out = Counts()
+    txt = C.c_void_p()
+    lib().orc_parse_chain_to_cigar(ptr, len(a), int(strand_neg), C.byref(out), C.byref(txt))
+    s = C.string_at(txt).decode()
+    lib().orc_free(txt)
+    return out.as_tuple(), s
+
+
+def parse_chain_to_insert(lines, t_seq, q_seq):
+    """converter.rs:360-388: the two gapped rows (bytes); OracleError where insert_str panics"""
+    a, ptr = _lines_array(lines)
+    t, q = _malloc_copy(bytes(t_seq)), _malloc_copy(bytes(q_seq))
+    tn, qn = C.c_size_t(len(t_seq)), C.c_size_t(len(q_seq))
+    rc = lib().orc_parse_chain_to_insert(ptr, len(a), C.byref(t), C.byref(tn), C.byref(q), C.byref(qn))
+    try:
+        if rc:
+            e = Err()
+            e.kind = rc
+            _raise(e)
+        return C.string_at(t, tn.value), C.string_at(q, qn.value)
+    finally:
+        lib().orc_free(t)
+        lib().orc_free(q)
 
 
 def ops_to_text(ops):

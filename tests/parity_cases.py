@@ -364,6 +364,140 @@ def check_maf_pair(eng, pairs, strands):
                       for k in range(len(mine)))
         assert txt == exp_txt, (i, txt[:80], exp_txt[:80])
         assert int(rc[i]) == len(mine)
+    # K11: the same runs as maf2paf's cg:Z: text, and as packed ops through the chain kernel = maf2chain
+    ne = int(ro[-1])
+    tcnt = eng.maf_runs_cigar_text(n, ne, runs, run_off, d_c)
+    toff = eng.exclusive_scan_u64(n, tcnt)
+    to_ = toff.numpy()
+    text = eng.empty(int(to_[-1]) + 8, np.uint8).fill(0x23)
+    eng.maf_runs_cigar_text(n, ne, runs, run_off, d_c, out=text, out_off=toff)
+    tx = text.numpy()
+    ocnt = eng.maf_runs_ops(n, ne, runs, run_off, d_c)
+    ooff = eng.exclusive_scan_u64(n, ocnt)
+    oo = ooff.numpy()
+    ops = eng.empty(int(oo[-1]) + 4, np.uint32).fill(0)
+    eng.maf_runs_ops(n, ne, runs, run_off, d_c, out=ops, out_off=ooff)
+    assert (oo == ro).all()                       # no run reaches 2^28 columns here
+    batch = eng.make_batch_device(ops, ooff, d_s, n, int(oo[-1]))
+    trim, nbytes, diag = eng.cigar_chain(batch)
+    coff = eng.exclusive_scan_u64(n, nbytes)
+    co = coff.numpy()
+    ctext = eng.empty(int(co[-1]) + 8, np.uint8).fill(0x23)
+    eng.cigar_chain(batch, out=ctext, out_off=coff)
+    ct, tr = ctext.numpy(), trim.numpy()
+    for i, (t, q) in enumerate(pairs):
+        _, exp_txt = orc.parse_maf_seq_to_cigar(t, q, strands[i])
+        assert tx[int(to_[i]):int(to_[i + 1])].tobytes().decode() == exp_txt, i
+        assert tuple(int(tr[i][k]) for k in ("head_ins", "head_del", "tail_ins", "tail_del")) == \
+            orc.parse_maf_seq_to_trim(t, q), i
+        rec = orc.maf2chain_record("t", 10 ** 12, 0, 10 ** 11, "q", 10 ** 12, 0, 10 ** 11, strands[i], t, q, i)
+        assert ct[int(co[i]):int(co[i + 1])].tobytes() == rec[rec.index(b"\n"):-2], (i, rec[:80])
+    assert (tx[int(to_[-1]):] == 0x23).all() and (ct[int(co[-1]):] == 0x23).all()
+
+
+def expected_split(length, code, cont):
+    out, first = [], True
+    while length:
+        piece = min(length, (1 << 28) - 1)
+        out.append((piece << 4) | (code if first else cont))
+        length -= piece
+        first = False
+    return out
+
+
+def check_runs_bridge_synthetic(eng, recs):
+    """recs: per record a list of (length, class) runs, lengths up to and beyond 2^28 (no rows needed:
+    the bridges only read the run list).  Ops = the PAF packer's split rule, text = '<len><op>'."""
+    n = len(recs)
+    runs, run_off, cols = [], [0], []
+    for r in recs:
+        pos = 0
+        for ln, cls in r:
+            runs.append((pos << 3) | cls)
+            pos += ln
+        run_off.append(len(runs))
+        cols.append(pos)
+    ne = len(runs)
+    d_runs = eng.upload(np.array(runs + [0], dtype=np.uint64))
+    d_roff = eng.upload(np.array(run_off, dtype=np.uint64))
+    d_cols = eng.upload(np.array(cols, dtype=np.uint64))
+    ocnt = eng.maf_runs_ops(n, ne, d_runs, d_roff, d_cols)
+    ooff = eng.exclusive_scan_u64(n, ocnt)
+    oo = ooff.numpy()
+    ops = eng.empty(int(oo[-1]) + 4, np.uint32).fill(0xFFFFFFFF)
+    eng.maf_runs_ops(n, ne, d_runs, d_roff, d_cols, out=ops, out_off=ooff)
+    tcnt = eng.maf_runs_cigar_text(n, ne, d_runs, d_roff, d_cols)
+    toff = eng.exclusive_scan_u64(n, tcnt)
+    to_ = toff.numpy()
+    text = eng.empty(int(to_[-1]) + 8, np.uint8).fill(0x23)
+    eng.maf_runs_cigar_text(n, ne, d_runs, d_roff, d_cols, out=text, out_off=toff)
+    o, tx = ops.numpy(), text.numpy()
+    CODE, CONT = (7, 1, 2, 8), (7, 9, 10, 8)
+    for i, r in enumerate(recs):
+        want = [w for ln, cls in r for w in expected_split(ln, CODE[cls], CONT[cls])]
+        assert o[int(oo[i]):int(oo[i + 1])].tolist() == want, i
+        assert tx[int(to_[i]):int(to_[i + 1])].tobytes().decode() == "".join("%d%s" % (ln, "=IDX"[c]) for ln, c in r), i
+    assert (o[int(oo[-1]):] == 0xFFFFFFFF).all() and (tx[int(to_[-1]):] == 0x23).all()
+
+
+def check_chain_lines(eng, recs, strands, seqs=None):
+    """recs: per record a list of (size, query_diff, target_diff) data lines.  ops + K1 == the counts of
+    parse_chain_to_cigar, text == its CIGAR, and (seqs given: per record (t_seq, q_seq)) ops + K2 ==
+    parse_chain_to_insert."""
+    n = len(recs)
+    flat = [v for r in recs for ln in r for v in ln]
+    line_off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+    ne = int(line_off[-1])
+    d_lines = eng.upload(np.array(flat + [0, 0, 0], dtype=np.uint64))
+    d_loff = eng.upload(line_off)
+    ocnt = eng.chain_lines_ops(n, ne, d_lines, d_loff)
+    ooff = eng.exclusive_scan_u64(n, ocnt)
+    oo = ooff.numpy()
+    ops = eng.empty(int(oo[-1]) + 4, np.uint32).fill(0xFFFFFFFF)
+    eng.chain_lines_ops(n, ne, d_lines, d_loff, out=ops, out_off=ooff)
+    tcnt = eng.chain_lines_cigar_text(n, ne, d_lines, d_loff)
+    toff = eng.exclusive_scan_u64(n, tcnt)
+    to_ = toff.numpy()
+    text = eng.empty(int(to_[-1]) + 8, np.uint8).fill(0x23)
+    eng.chain_lines_cigar_text(n, ne, d_lines, d_loff, out=text, out_off=toff)
+    o, tx = ops.numpy(), text.numpy()
+    strand = np.array(strands, dtype=np.uint8)
+    batch = eng.make_batch_device(ops, ooff, eng.upload(strand), n, int(oo[-1]))
+    counts, diag, _ = eng.cigar_stat(batch)
+    c = counts.numpy()
+    for i, r in enumerate(recs):
+        want = [w for (sz, qd, td) in r for w in
+                expected_split(sz, 0, 0) + expected_split(td, 1, 9) + expected_split(qd, 2, 10)]
+        assert o[int(oo[i]):int(oo[i + 1])].tolist() == want, i
+        exp_counts, exp_txt = orc.parse_chain_to_cigar(r, strands[i])
+        assert tx[int(to_[i]):int(to_[i + 1])].tobytes().decode() == exp_txt, (i, exp_txt[:80])
+        assert tuple(int(x) for x in c[i]) == exp_counts, (i, exp_counts, c[i])
+    assert (o[int(oo[-1]):] == 0xFFFFFFFF).all() and (tx[int(to_[-1]):] == 0x23).all()
+    if seqs is None:
+        return
+    def pool(ss):
+        offs, buf = [], bytearray(b"N" * 16)
+        for x in ss:
+            offs.append(len(buf))
+            buf += x
+        buf += b"N" * 16
+        return np.frombuffer(bytes(buf), dtype=np.uint8).copy(), np.array(offs, dtype=np.uint64)
+    tp, to = pool([t for t, _ in seqs])
+    qp, qo = pool([q for _, q in seqs])
+    b = dict(ops=o[:int(oo[-1])].copy(), op_off=oo.copy(), strand_neg=strand, t_pool=tp, q_pool=qp, t_src_off=to,
+             q_src_off=qo, t_src_len=np.array([len(t) for t, _ in seqs], dtype=np.uint64),
+             q_src_len=np.array([len(q) for _, q in seqs], dtype=np.uint64))
+    r = run_paf2maf(eng, b)
+    for i, (t, q) in enumerate(seqs):
+        qq = orc.reverse_complement(q) if strands[i] else q
+        try:
+            et, eq = orc.parse_chain_to_insert(recs[i], t, qq)
+        except orc.OracleError as e:
+            assert e.kind == 6 and int(r["diag"][i]["panic_op_idx"]) != NONE, (i, r["diag"][i])
+            continue
+        assert int(r["diag"][i]["panic_op_idx"]) == NONE, (i, r["diag"][i])
+        a, bq = int(r["t_row_off"][i]), int(r["q_row_off"][i])
+        assert r["out"][a:a + len(et)].tobytes() == et and r["out"][bq:bq + len(eq)].tobytes() == eq, i
 
 
 # ------------------------------------------------------------------------------------------------

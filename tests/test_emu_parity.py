@@ -289,3 +289,35 @@ def test_cigar_chain(emu):
     ops = np.array([o for r in recs for o in r], dtype=np.uint32)
     off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
     pc.check_cigar_chain(emu, ops, off)
+
+
+def test_runs_bridge_synthetic(emu):
+    L = (1 << 28) - 1
+    recs = [[(5, 0), (3, 1), (2, 3), (4, 2)], [], [(L, 0), (L + 1, 1), (2 * L + 7, 2), (1, 3), (3 * L, 3)],
+            [(1, c) for c in (0, 1, 2, 3)] * 200, [(10 ** 9, 2)], [(123456789, 0)]]
+    pc.check_runs_bridge_synthetic(emu, recs)
+
+
+def test_chain_lines(emu):
+    rng = np.random.default_rng(77)
+    L = (1 << 28) - 1
+    recs = [[(10, 2, 0), (5, 0, 3), (7, 1, 1), (4, 0, 0)], [(9, 0, 0)], [],
+            [(0, 0, 4), (3, 0, 0), (0, 2, 0), (6, 0, 0)],              # zero sizes: "0M" in the text, no op
+            [(L + 5, 2 * L + 1, L), (1, 0, 0)],                         # lengths beyond one packed op
+            [(int(rng.integers(1, 50)), int(rng.integers(0, 4)), int(rng.integers(0, 4))) for _ in range(700)] + [(3, 0, 0)]]
+    strands = [0, 1, 0, 1, 0, 1]
+    pc.check_chain_lines(emu, recs, strands)
+    # rows: sequences exactly as long as the lines consume, one too short (insert_str panics), one longer (tail copied)
+    recs2, seqs, strands2 = [], [], []
+    for k in range(9):
+        r = [(int(rng.integers(1, 40)), int(rng.integers(0, 3)) * int(rng.integers(0, 9)),
+              int(rng.integers(0, 3)) * int(rng.integers(0, 9))) for _ in range(int(rng.integers(1, 90)))]
+        r[-1] = (r[-1][0], 0, 0)
+        tn = sum(s + qd for s, qd, td in r)
+        qn = sum(s + td for s, qd, td in r)
+        extra = (0, 0, 5, -3, 0, 2, 0, 0, -200)[k]
+        recs2.append(r)
+        seqs.append((pc.rand_seq(rng, max(tn + extra, 0), b"ACGTN"), pc.rand_seq(rng, max(qn + extra, 0), b"ACGTNacgtn")))
+        strands2.append(k & 1)
+    pc.check_chain_lines(emu, recs2, strands2, seqs=seqs)
+

@@ -72,6 +72,21 @@ static int ctx_scratch(wga_ctx* c, size_t bytes, void** out) {
 
 /* exclusive scan driver shared by wga_exclusive_scan_u64 and the layout */
 template <typename F>
+static int run_scan_ws(wga_ctx* c, F f, u32 n, u64* d_out /* n+1 */, u64* partial /* n/1024 + 2 */) {
+  u32 nb = (n + 1023u) / 1024u;
+  if (nb) {
+    WGA_LAUNCH(k_scan_partials<F>, nb, WGA_BLOCK, c->stream, f, n, partial);
+    LAUNCH_CHECK();
+  }
+  WGA_LAUNCH(k_scan_top, 1, WGA_BLOCK, c->stream, partial, nb, d_out + n);
+  LAUNCH_CHECK();
+  if (nb) {
+    WGA_LAUNCH(k_scan_final<F>, nb, WGA_BLOCK, c->stream, f, n, (const u64*)partial, d_out);
+    LAUNCH_CHECK();
+  }
+  return WGA_OK;
+}
+template <typename F>
 static int run_scan(wga_ctx* c, F f, u32 n, u64* d_out /* n+1 */) {
   u32 nb = (n + 1023u) / 1024u;
   void* ws;
@@ -89,6 +104,46 @@ static int run_scan(wga_ctx* c, F f, u32 n, u64* d_out /* n+1 */) {
     LAUNCH_CHECK();
   }
   return WGA_OK;
+}
+
+/* K11 driver: element sizes -> exclusive scan (context scratch) -> per-record totals or the fill */
+template <typename F>
+static int run_elems(wga_ctx* c, F f, u32 n, uint64_t n_elems, const uint64_t* d_elem_off, uint64_t* d_cnt,
+                     typename F::out_t* d_out, const uint64_t* d_out_off) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (n == 0) return WGA_OK;
+  if (!d_elem_off) return fail(WGA_E_INVALID_ARG, "element offsets null", nullptr);
+  if (n_elems > 0xFFFFFFF0ull) return fail(WGA_E_INVALID_ARG, "too many elements for one call", nullptr);
+  if (!d_out && !d_cnt) return fail(WGA_E_INVALID_ARG, "d_cnt null", nullptr);
+  if (d_out && !d_out_off) return fail(WGA_E_INVALID_ARG, "d_out_off null", nullptr);
+  const u32 ne = (u32)n_elems;
+  void* ws;
+  if ((rc = ctx_scratch(c, ((size_t)ne + 1 + (size_t)ne / 1024 + 4) * sizeof(u64), &ws))) return rc;
+  u64* esc = (u64*)ws;
+  ScanElem<F> sf;
+  sf.f = f;
+  sf.elem_off = (const u64*)d_elem_off;
+  sf.n = n;
+  if ((rc = run_scan_ws(c, sf, ne, esc, esc + ne + 1))) return rc;
+  if (!d_out) {
+    WGA_LAUNCH(k_elem_rec_totals, (n + 255u) / 256u, WGA_BLOCK, c->stream, n, (const u64*)d_elem_off,
+               (const u64*)esc, (u64*)d_cnt);
+    LAUNCH_CHECK();
+  } else if (ne) {
+    WGA_LAUNCH(k_elem_fill<F>, (ne + 255u) / 256u, WGA_BLOCK, c->stream, f, n, ne, (const u64*)d_elem_off,
+               (const u64*)esc, d_out, (const u64*)d_out_off);
+    LAUNCH_CHECK();
+  }
+  return WGA_OK;
+}
+
+static MafRunSrc maf_run_src(const uint64_t* d_runs, const uint64_t* d_run_off, const uint64_t* d_cols) {
+  MafRunSrc s;
+  s.runs = (const u64*)d_runs;
+  s.run_off = (const u64*)d_run_off;
+  s.cols = (const u64*)d_cols;
+  return s;
 }
 
 extern "C" {
@@ -462,6 +517,40 @@ int wga_cigar_chain(wga_ctx* c, const wga_cigar_batch* b, wga_chain_trim_t* d_tr
   }
   LAUNCH_CHECK();
   return WGA_OK;
+}
+
+int wga_maf_runs_ops(wga_ctx* c, uint32_t n, uint64_t n_elems, const uint64_t* d_runs, const uint64_t* d_run_off,
+                     const uint64_t* d_cols, uint64_t* d_cnt, uint32_t* d_out, const uint64_t* d_out_off) {
+  if (n && (!d_cols || (n_elems && !d_runs))) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  MafRunOps f;
+  f.s = maf_run_src(d_runs, d_run_off, d_cols);
+  return run_elems(c, f, n, n_elems, d_run_off, d_cnt, d_out, d_out_off);
+}
+
+int wga_maf_runs_cigar_text(wga_ctx* c, uint32_t n, uint64_t n_elems, const uint64_t* d_runs,
+                            const uint64_t* d_run_off, const uint64_t* d_cols, uint64_t* d_cnt, uint8_t* d_out,
+                            const uint64_t* d_out_off) {
+  if (n && (!d_cols || (n_elems && !d_runs))) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  MafRunText f;
+  f.s = maf_run_src(d_runs, d_run_off, d_cols);
+  return run_elems(c, f, n, n_elems, d_run_off, d_cnt, d_out, d_out_off);
+}
+
+int wga_chain_lines_ops(wga_ctx* c, uint32_t n, uint64_t n_elems, const uint64_t* d_lines,
+                        const uint64_t* d_line_off, uint64_t* d_cnt, uint32_t* d_out, const uint64_t* d_out_off) {
+  if (n && n_elems && !d_lines) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  ChainLineOps f;
+  f.s.lines = (const u64*)d_lines;
+  return run_elems(c, f, n, n_elems, d_line_off, d_cnt, d_out, d_out_off);
+}
+
+int wga_chain_lines_cigar_text(wga_ctx* c, uint32_t n, uint64_t n_elems, const uint64_t* d_lines,
+                               const uint64_t* d_line_off, uint64_t* d_cnt, uint8_t* d_out,
+                               const uint64_t* d_out_off) {
+  if (n && n_elems && !d_lines) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  ChainLineText f;
+  f.s.lines = (const u64*)d_lines;
+  return run_elems(c, f, n, n_elems, d_line_off, d_cnt, d_out, d_out_off);
 }
 
 int wga_paf_call_events(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, int snp,

@@ -169,6 +169,10 @@ class Engine:
         assert len(op_off) == n + 1 and int(op_off[-1]) == len(ops)
         return Batch(self.upload(ops), self.upload(op_off), self.upload(strand_neg), n, len(ops))
 
+    def make_batch_device(self, ops, op_off, strand_neg, n, n_ops):
+        """device arrays (e.g. written by the tokeniser or the K11 bridges) -> Batch"""
+        return Batch(ops, op_off, strand_neg, int(n), int(n_ops))
+
     # ---- kernels ----------------------------------------------------------------------------
     def tile_ws(self, n_ops):
         return self.empty(self.lib.wga_tile_ws_bytes(int(n_ops)), np.uint8)
@@ -245,6 +249,34 @@ class Engine:
         self._check(self.lib.wga_cigar_chain(self.ctx, C.byref(batch.c), _p(trim), _p(nbytes), _p(diag),
                                              _p(out), _p(out_off)))
         return trim, nbytes, diag
+
+    def maf_runs_ops(self, n, n_elems, runs, run_off, cols, cnt=None, out=None, out_off=None):
+        """K3 runs -> packed ops (count pass when out is None)"""
+        cnt = cnt if cnt is not None or out is not None else self.empty(n, np.uint64)
+        self._check(self.lib.wga_maf_runs_ops(self.ctx, n, int(n_elems), _p(runs), _p(run_off), _p(cols),
+                                              _p(cnt), _p(out), _p(out_off)))
+        return cnt
+
+    def maf_runs_cigar_text(self, n, n_elems, runs, run_off, cols, cnt=None, out=None, out_off=None):
+        """K3 runs -> maf2paf's cg:Z: text (count pass when out is None)"""
+        cnt = cnt if cnt is not None or out is not None else self.empty(n, np.uint64)
+        self._check(self.lib.wga_maf_runs_cigar_text(self.ctx, n, int(n_elems), _p(runs), _p(run_off),
+                                                     _p(cols), _p(cnt), _p(out), _p(out_off)))
+        return cnt
+
+    def chain_lines_ops(self, n, n_elems, lines, line_off, cnt=None, out=None, out_off=None):
+        """chain data lines (size, D, I) -> packed ops (count pass when out is None)"""
+        cnt = cnt if cnt is not None or out is not None else self.empty(n, np.uint64)
+        self._check(self.lib.wga_chain_lines_ops(self.ctx, n, int(n_elems), _p(lines), _p(line_off), _p(cnt),
+                                                 _p(out), _p(out_off)))
+        return cnt
+
+    def chain_lines_cigar_text(self, n, n_elems, lines, line_off, cnt=None, out=None, out_off=None):
+        """chain data lines -> chain2paf's CIGAR text (count pass when out is None)"""
+        cnt = cnt if cnt is not None or out is not None else self.empty(n, np.uint64)
+        self._check(self.lib.wga_chain_lines_cigar_text(self.ctx, n, int(n_elems), _p(lines), _p(line_off),
+                                                        _p(cnt), _p(out), _p(out_off)))
+        return cnt
 
     def paf_call_events(self, batch, svlen, snp, ev_cnt=None, ev=None, ev_off=None):
         ev_cnt = ev_cnt if ev_cnt is not None else self.empty(batch.n, np.uint64)
