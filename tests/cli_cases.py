@@ -541,3 +541,159 @@ def test_paf2chain_end_to_end(cli, tmp_path):
     rc, out, err = run(cli, "p2c", str(paf))
     assert rc == 1 and err.strip().endswith("ERROR CIGAR OP `N` invalid")
     assert out == b"".join(want[:7])
+
+
+# ---- the other chain converters --------------------------------------------------------
+def test_maf2chain_end_to_end(cli, tmp_path):
+    """converter.rs:57-91: header from the s-lines (strand-aware query coordinates, trims), data lines over
+    cigar_cat groups, chain id = block index"""
+    blocks = _synth_maf_blocks(91, 14, 900)
+    # blocks that start / end with indels, and one without any aligned column
+    blocks[3]["t"], blocks[3]["q"] = b"--AC" + blocks[3]["t"] + b"GT---", b"TTA-" + blocks[3]["q"] + b"--ACG"
+    blocks[5]["t"], blocks[5]["q"] = b"ACGT----", b"----ACGT"
+    maf = str(tmp_path / "in.maf")
+    _write_maf(maf, blocks)
+    want = b"".join(orc.maf2chain_record(b["t_name"], b["t_size"], b["t_start"], b["t_align"], b["q_name"], b["q_size"],
+                                         b["q_start"], b["q_align"], b["neg"], b["t"], b["q"], k)
+                    for k, b in enumerate(blocks))
+    rc, out, err = run(cli, "maf2chain", maf)
+    assert rc == 0, err
+    assert out == want
+    # -q picks another row of the block; an unknown name fails at the first block
+    _write_maf(maf, blocks, extra_sline=True)
+    rc, out, err = run(cli, "m2c", maf, "-q", blocks[0]["q_name"])
+    first = [k for k, b in enumerate(blocks) if b["q_name"] != blocks[0]["q_name"]][0]
+    assert rc == 1 and ("Query name:%s not found in MAF" % blocks[0]["q_name"]) in err
+    assert out == b"".join(orc.maf2chain_record(b["t_name"], b["t_size"], b["t_start"], b["t_align"], b["q_name"],
+                                                b["q_size"], b["q_start"], b["q_align"], b["neg"], b["t"], b["q"], k)
+                           for k, b in enumerate(blocks[:first]))
+    rc, out, err = run(cli, "m2c", maf, "-q", "other.x")
+    assert rc == 0, err
+    assert out == b"".join(orc.maf2chain_record(b["t_name"], b["t_size"], b["t_start"], b["t_align"], "other.x", 99999,
+                                                5, b["t_align"], False, b["t"], b["t"], k)
+                           for k, b in enumerate(blocks))
+
+
+def _synth_chain(seed, n, max_lines=120):
+    rng = np.random.default_rng(seed)
+    recs = []
+    for k in range(n):
+        nl = int(rng.integers(1, max_lines))
+        lines = [(int(rng.integers(1, 60)), int(rng.integers(0, 3)) * int(rng.integers(0, 12)),
+                  int(rng.integers(0, 3)) * int(rng.integers(0, 12))) for _ in range(nl)]
+        lines[-1] = (lines[-1][0], 0, 0)
+        t_ali = sum(s + dt for s, dt, dq in lines)
+        q_ali = sum(s + dq for s, dt, dq in lines)
+        recs.append(dict(lines=lines, t_ali=t_ali, q_ali=q_ali, neg=bool(rng.integers(0, 2)), id=int(rng.integers(0, 10 ** 6))))
+    return recs
+
+
+def _chain_text(recs, t_name, t_size, q_name, q_size, starts, eol="\n", last_full=False, blank=True):
+    out = []
+    for r, (ts, qs) in zip(recs, starts):
+        out.append("chain %d %s %d + %d %d %s %d %s %d %d %d%s" % (1000 + r["id"], t_name, t_size, ts, ts + r["t_ali"], q_name,
+                                                                  q_size, "-" if r["neg"] else "+", qs, qs + r["q_ali"],
+                                                                  r["id"], eol))
+        for j, (s, dt, dq) in enumerate(r["lines"]):
+            if j == len(r["lines"]) - 1 and not last_full:
+                out.append("%d%s" % (s, eol))
+            else:
+                out.append("%d\t%d\t%d%s" % (s, dt, dq, eol))
+        if blank:
+            out.append(eol)
+    return "".join(out)
+
+
+def _expected_chain2paf(recs, t_name, t_size, q_name, q_size, starts):
+    out = []
+    for r, (ts, qs) in zip(recs, starts):
+        counts, cg = orc.parse_chain_to_cigar(r["lines"], r["neg"])
+        match, mism, del_bp, inv_del_bp = counts[0], counts[1], counts[5], counts[9]
+        out.append("%s\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t255\tcg:Z:%s\n" % (
+            q_name, q_size, qs, qs + r["q_ali"], "-" if r["neg"] else "+", t_name, t_size, ts, ts + r["t_ali"], match,
+            match + mism + del_bp + inv_del_bp, cg))
+    return "".join(out).encode()
+
+
+def test_chain2paf_end_to_end(cli, tmp_path):
+    """converter.rs:391-416 + chain.rs:430-452: CIGAR '<size>M[<dq>I][<dt>D]' per data line, matches = sum of sizes,
+    block length = matches + D bases; the nom reader's corner cases"""
+    recs = _synth_chain(5, 30)
+    starts = [(100 * k, 37 * k) for k in range(len(recs))]
+    ch = tmp_path / "in.chain"
+    ch.write_text(_chain_text(recs, "tchr", 10 ** 8, "qchr", 10 ** 8, starts))
+    want = _expected_chain2paf(recs, "tchr", 10 ** 8, "qchr", 10 ** 8, starts)
+    rc, out, err = run(cli, "chain2paf", str(ch))
+    assert rc == 0, err
+    assert out == want
+    # \r\n line ends, three-column last lines, no blank lines between the records
+    ch.write_text(_chain_text(recs, "tchr", 10 ** 8, "qchr", 10 ** 8, starts, eol="\r\n", last_full=True, blank=False), newline="")
+    rc, out, err = run(cli, "c2p", str(ch))
+    assert rc == 0 and out == want, err
+    # ... with them, the "\r" of a blank "\r\n" line is a data line without fields for is_not("chain\n")
+    ch.write_text(_chain_text(recs, "tchr", 10 ** 8, "qchr", 10 ** 8, starts, eol="\r\n"), newline="")
+    rc, out, err = run(cli, "c2p", str(ch))
+    assert rc == 1 and out == b"" and err.strip().endswith("ERROR Parse Chain Error By: Chain Line Field `size` Missing")
+    # a last data line without newline is not a data line (line_ending fails): dropped when others precede it
+    two = [dict(lines=[(5, 1, 2), (7, 0, 0)], t_ali=13, q_ali=14, neg=False, id=1)]
+    ch.write_text("chain 1 t 100 + 0 13 q 100 + 0 14 1\n5\t1\t2\n7")
+    cut = [dict(two[0], lines=[(5, 1, 2)])]
+    rc, out, err = run(cli, "c2p", str(ch))
+    assert rc == 0 and out == _expected_chain2paf(cut, "t", 100, "q", 100, [(0, 0)]).replace(b"\t0\t6\t", b"\t0\t13\t").replace(b"\t0\t7\t", b"\t0\t14\t"), (out, err)
+    # ... and a record whose only data line lacks it has none: fold_many1 fails
+    ch.write_text("chain 1 t 100 + 0 13 q 100 + 0 14 1\n7 and some more text")
+    rc, out, err = run(cli, "c2p", str(ch))
+    assert rc == 1 and out == b"" and "Format error Many1 at: 7 and some Parse Error by rust::nom, please check" in err
+    # errors: nothing is written (all records are converted before the first is serialised)
+    good = _chain_text(recs[:3], "t", 10 ** 8, "q", 10 ** 8, starts[:3])
+    for bad, msg in (("chain 1 t 100 + 0 13 q 100 + 0 14\n5\n\n", "Parse Chain Error By: Chain Line Field `chain_id` Missing"),
+                     ("chain x t 100 + 0 13 q 100 + 0 14 1\n5\n\n", "Parse `x` Into Float Error"),
+                     ("chain 1e3 t 100 * 0 13 q 100 + 0 14 1\n5\n\n", "Parse Strand `*` Error"),
+                     ("chain 1 t 100 + 0 13 q 100 + 0 14 1\n5\t-1\t0\n5\n\n", "Parse `-1` Into Integer Error"),
+                     ("chain 1 t 100 + 0 13 q 100 + 0 14 1\n \t \n5\n\n", "Parse Chain Error By: Chain Line Field `size` Missing"),
+                     ("chain 1 t 100 + 0 13 q 100 + 0 14 1\n5\n\ncomment line here\n", "Format error Tag at: comment li Parse Error by rust::nom, please check"),
+                     ("track name=x and more\n", "Format error Tag at: track name Parse Error by rust::nom, please check")):
+        ch.write_text(good + bad if not bad.startswith("track") else bad + good)
+        rc, out, err = run(cli, "c2p", str(ch))
+        assert rc == 1 and out == b"" and err.strip().endswith("ERROR " + msg), (bad, err)
+
+
+def test_chain2maf_end_to_end(cli, tmp_path):
+    """converter.rs:268-358: slices fetched on the forward strand, query reverse-complemented for '-', '-' runs
+    inserted per data line (parse_chain_to_insert); score 255; the failing record ends the stream"""
+    rng = np.random.default_rng(8)
+    recs = _synth_chain(6, 25, max_lines=200)
+    T, Q = 400000, 380000
+    t_pool, q_pool = pc.rand_seq(rng, T, b"ACGTacgtN"), pc.rand_seq(rng, Q, b"ACGTacgtN")
+    starts = [(int(rng.integers(0, T - r["t_ali"] - 1)), int(rng.integers(0, Q - r["q_ali"] - 1))) for r in recs]
+    t_fa, q_fa, ch = tmp_path / "t.fa", tmp_path / "q.fa", tmp_path / "in.chain"
+    for path, name, seq in ((t_fa, b"tchr", t_pool), (q_fa, b"qchr", q_pool)):
+        with open(path, "wb") as f:
+            f.write(b">" + name + b"\n")
+            for i in range(0, len(seq), 60):
+                f.write(seq[i:i + 60] + b"\n")
+    def expected(rs, ss):
+        out = ["#maf version=1.6 convert_from=chain t_seq_path=%s q_seq_path=%s\n" % (t_fa, q_fa)]
+        for r, (ts, qs) in zip(rs, ss):
+            t = t_pool[ts:ts + r["t_ali"]]
+            q = q_pool[qs:qs + r["q_ali"]]
+            if r["neg"]:
+                q = orc.reverse_complement(q)
+            et, eq = orc.parse_chain_to_insert(r["lines"], t, q)
+            out.append("a score=255\ns\ttchr\t%d\t%d\t+\t%d\t%s\ns\tqchr\t%d\t%d\t%s\t%d\t%s\n\n" % (
+                ts, r["t_ali"], T, et.decode(), Q - (qs + r["q_ali"]) if r["neg"] else qs, r["q_ali"],
+                "-" if r["neg"] else "+", Q, eq.decode()))
+        return "".join(out).encode()
+    ch.write_text(_chain_text(recs, "tchr", T, "qchr", Q, starts))
+    rc, out, err = run(cli, "chain2maf", str(ch), "--target", str(t_fa), "--query", str(q_fa))
+    assert rc == 0, err
+    assert out == expected(recs, starts)
+    # record 9 claims fewer bases than its lines consume: String::insert_str panics in the reference
+    broken = [dict(r) for r in recs]
+    broken[9]["t_ali"] -= 40
+    broken[9]["q_ali"] -= 40
+    broken[9]["lines"] = broken[9]["lines"][:-1] + [(broken[9]["lines"][-1][0], 3, 0), (1, 0, 0)]
+    ch.write_text(_chain_text(broken, "tchr", T, "qchr", Q, starts))
+    rc, out, err = run(cli, "c2m", str(ch), "-g", str(t_fa), "-q", str(q_fa))
+    assert rc == 1 and "panic" in err
+    assert out == expected(recs[:9], starts[:9])

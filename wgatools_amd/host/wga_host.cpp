@@ -3,6 +3,7 @@
  */
 #include "wga_host.hpp"
 
+#include <ctype.h>
 #include <stdio.h>
 #include <string.h>
 #include <sys/stat.h>
@@ -453,6 +454,142 @@ std::vector<MafRecord> parse_maf(const std::string& text, std::string* header) {
         break; /* the terminating line is consumed and dropped */
     }
     out.push_back(std::move(rec));
+  }
+  return out;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* chain (chain.rs)                                                                            */
+/* ------------------------------------------------------------------------------------------ */
+/* From<nom::Err<Error<&str>>> (errors.rs:88-96): the message quotes the first 10 bytes of the
+ * unparsed input and the slice panics when fewer are left */
+static std::string nom_error(const char* kind, const std::string& text, size_t at) {
+  if (text.size() - at < 10)
+    return "panic: byte index 10 is out of range of the unparsed input (errors.rs:92)";
+  return std::string("Format error ") + kind + " at: " + text.substr(at, 10) + " Parse Error by rust::nom, please check";
+}
+/* f64::from_str accepts: [+-] (inf | infinity | nan | digits[.digits][e[+-]digits] | .digits[e..]) */
+static bool valid_f64(const std::string& s) {
+  size_t i = 0, n = s.size();
+  if (i < n && (s[i] == '+' || s[i] == '-')) i++;
+  std::string rest = s.substr(i);
+  for (auto& c : rest) c = (char)tolower((unsigned char)c);
+  if (rest == "inf" || rest == "infinity" || rest == "nan") return true;
+  size_t d0 = i;
+  while (i < n && isdigit((unsigned char)s[i])) i++;
+  size_t nd = i - d0;
+  if (i < n && s[i] == '.') {
+    i++;
+    size_t f0 = i;
+    while (i < n && isdigit((unsigned char)s[i])) i++;
+    nd += i - f0;
+  }
+  if (nd == 0) return false;
+  if (i < n && (s[i] == 'e' || s[i] == 'E')) {
+    i++;
+    if (i < n && (s[i] == '+' || s[i] == '-')) i++;
+    size_t e0 = i;
+    while (i < n && isdigit((unsigned char)s[i])) i++;
+    if (i == e0) return false;
+  }
+  return i == n;
+}
+
+std::vector<ChainRecord> parse_chain(const std::string& text, std::string* err) {
+  std::vector<ChainRecord> out;
+  err->clear();
+  const size_t n = text.size();
+  size_t p = 0;
+  auto line_ending = [&](size_t at) -> size_t { /* length of "\n" / "\r\n" at `at`, 0 if none */
+    if (at < n && text[at] == '\n') return 1;
+    if (at + 1 < n && text[at] == '\r' && text[at + 1] == '\n') return 2;
+    return 0;
+  };
+  while (p < n) {
+    /* tag("chain") */
+    if (text.compare(p, 5, "chain") != 0) {
+      *err = nom_error("Tag", text, p);
+      return out;
+    }
+    p += 5;
+    /* not_line_ending: up to the first \r or \n; a lone \r is an error */
+    size_t e = p;
+    while (e < n && text[e] != '\n' && text[e] != '\r') e++;
+    if (e < n && text[e] == '\r' && !(e + 1 < n && text[e + 1] == '\n')) {
+      *err = nom_error("Tag", text, p);
+      return out;
+    }
+    /* parse_header (chain.rs:206-322): whitespace-separated, surplus fields ignored */
+    static const char* names[] = {"score", "target_name", "target_size", "target_strand", "target_start", "target_end",
+                                  "query_name", "query_size", "query_strand", "query_start", "query_end", "chain_id"};
+    std::vector<std::string> f = split_ws(text.substr(p, e - p));
+    ChainRecord r;
+    uint64_t* ints[12] = {nullptr, nullptr, &r.target_size, nullptr, &r.target_start, &r.target_end,
+                          nullptr, &r.query_size, nullptr, &r.query_start, &r.query_end, &r.chain_id};
+    for (size_t k = 0; k < 12; k++) {
+      if (k >= f.size()) {
+        *err = std::string("Parse Chain Error By: Chain Line Field `") + names[k] + "` Missing";
+        return out;
+      }
+      if (k == 0) {
+        if (!valid_f64(f[0])) {
+          *err = "Parse `" + f[0] + "` Into Float Error";
+          return out;
+        }
+      } else if (k == 1) {
+        r.target_name = f[1];
+      } else if (k == 6) {
+        r.query_name = f[6];
+      } else if (k == 3 || k == 8) {
+        if (f[k] != "+" && f[k] != "-") {
+          *err = "Parse Strand `" + f[k] + "` Error";
+          return out;
+        }
+        (k == 3 ? r.target_neg : r.query_neg) = f[k] == "-";
+      } else if (!parse_u64(f[k], ints[k])) {
+        *err = "Parse `" + f[k] + "` Into Integer Error";
+        return out;
+      }
+    }
+    /* line_ending */
+    size_t le = line_ending(e);
+    if (!le) {
+      *err = nom_error("CrLf", text, e);
+      return out;
+    }
+    p = e + le;
+    /* fold_many1(terminated(is_not("chain\n"), line_ending)) */
+    size_t n_lines = 0;
+    std::string line_err;
+    for (;;) {
+      size_t q = p;
+      while (q < n && !strchr("chain\n", text[q])) q++; /* (a NUL byte also stops here: not text) */
+      if (q == p) break;
+      size_t l2 = line_ending(q);
+      if (!l2) break;
+      if (line_err.empty()) { /* after an error the fold keeps consuming lines but ignores them */
+        std::vector<std::string> d = split_ws(text.substr(p, q - p));
+        uint64_t v[3] = {0, 0, 0};
+        if (d.empty())
+          line_err = "Parse Chain Error By: Chain Line Field `size` Missing";
+        for (size_t k = 0; k < 3 && k < d.size() && line_err.empty(); k++)
+          if (!parse_u64(d[k], &v[k])) line_err = "Parse `" + d[k] + "` Into Integer Error";
+        if (line_err.empty()) r.lines.insert(r.lines.end(), v, v + 3);
+      }
+      n_lines++;
+      p = q + l2;
+    }
+    if (n_lines == 0) {
+      *err = nom_error("Many1", text, p);
+      return out;
+    }
+    if (!line_err.empty()) {
+      *err = line_err;
+      return out;
+    }
+    /* take_while(|x| x != 'c') */
+    while (p < n && text[p] != 'c') p++;
+    out.push_back(std::move(r));
   }
   return out;
 }

@@ -8,6 +8,7 @@
  *   get_cigar_string / cs_to_cigar parser/paf.rs:122-218
  *   MAFSLine / MAFRecord / reader  parser/maf.rs:65-73,138-211,216-220,371-421,424-478
  *   MAFWriter                      parser/maf.rs:543-582
+ *   ChainRecord / chain_parser     parser/chain.rs:49-91,206-383 (nom 7 combinators)
  *   faidx fetch_seq_string         rust-htslib 0.44.1 faidx (htslib faidx_fetch_seq64)  [unpinned]
  *   RecStat::from                  parser/common.rs:116-140
  *   Statistic / merge / split      tools/stat.rs:27-50,129-223
@@ -87,6 +88,21 @@ std::vector<MafRecord> parse_maf(const std::string& text, std::string* header);
 /* `<maf>.index` (tools/index.rs:78-95, serde_json map name -> {ivls,size,isref}): the (name, size) of
  * the entries with isref, natord-sorted (caller.rs:340-357).  Missing file -> empty. */
 std::vector<std::pair<std::string, uint64_t>> maf_index_ref_contigs(const std::string& path);
+
+/* ---- chain ---------------------------------------------------------------------------------- */
+struct ChainRecord { /* chain.rs:49-55,76-91: header fields + data lines */
+  std::string target_name, query_name;
+  uint64_t target_size = 0, target_start = 0, target_end = 0;
+  uint64_t query_size = 0, query_start = 0, query_end = 0;
+  bool target_neg = false, query_neg = false;
+  uint64_t chain_id = 0;
+  std::vector<uint64_t> lines; /* 3 per data line: size, 2nd column (query_diff), 3rd column (target_diff) */
+};
+/* ChainRecords::next + chain_parser (chain.rs:58-73,206-383) with nom's behaviour: records start at
+ * "chain", a data line is consumed only when it ends in a newline and holds none of the letters of
+ * "chain", everything up to the next 'c' is skipped after the data lines.  Parsing stops at the first
+ * error: *err receives the reference's message and the records before it are returned. */
+std::vector<ChainRecord> parse_chain(const std::string& text, std::string* err);
 
 /* ---- FASTA index ------------------------------------------------------------------------------ */
 struct Faidx {

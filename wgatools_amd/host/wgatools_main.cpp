@@ -170,6 +170,111 @@ std::string device_tokenise(Dev& d, const PafRecord* recs, uint32_t n, std::vect
   return first_err;
 }
 
+/* ---- rows of a batch of records -> MAF text (shared by paf2maf and chain2maf) ------------------------
+ * The host supplies the fetched slices and the line text around the rows (MAFWriter, maf.rs:566-581:
+ * "a score=..", "s\tname\tstart\tsize\tstrand\tsrcsize\t<row>" twice, blank line); K1, the layout scan,
+ * K2 and the snippet scatter run on the device and one copy brings the finished text back. */
+struct ExpandJob {
+  std::vector<uint64_t> t_off, t_len, q_off, q_len;
+  std::vector<uint32_t> pre_t, pre_q, post;
+  std::string blob;
+  std::vector<uint64_t> blob_off{0};
+  void add(uint64_t to, uint64_t tl, uint64_t qo, uint64_t ql, uint64_t score, const std::string& t_name,
+           uint64_t t_start, uint64_t t_ali, bool t_neg, uint64_t t_size, const std::string& q_name, uint64_t q_start,
+           uint64_t q_ali, bool q_neg, uint64_t q_size) {
+    t_off.push_back(to);
+    t_len.push_back(tl);
+    q_off.push_back(qo);
+    q_len.push_back(ql);
+    std::string a = "a score=";
+    append_u64(a, score);
+    a += "\ns\t" + t_name + "\t";
+    append_u64(a, t_start);
+    a.push_back('\t');
+    append_u64(a, t_ali);
+    a += t_neg ? "\t-\t" : "\t+\t";
+    append_u64(a, t_size);
+    a.push_back('\t');
+    std::string q = "\ns\t" + q_name + "\t";
+    append_u64(q, q_start);
+    q.push_back('\t');
+    append_u64(q, q_ali);
+    q += q_neg ? "\t-\t" : "\t+\t";
+    append_u64(q, q_size);
+    q.push_back('\t');
+    pre_t.push_back((uint32_t)a.size());
+    pre_q.push_back((uint32_t)q.size());
+    post.push_back(2);
+    blob += a;
+    blob_off.push_back(blob.size());
+    blob += q;
+    blob_off.push_back(blob.size());
+    blob += "\n\n";
+    blob_off.push_back(blob.size());
+  }
+  void resize(size_t k) {
+    t_off.resize(k);
+    t_len.resize(k);
+    q_off.resize(k);
+    q_len.resize(k);
+    pre_t.resize(k);
+    pre_q.resize(k);
+    post.resize(k);
+    blob_off.resize(3 * k + 1);
+    blob.resize(blob_off.back());
+  }
+};
+
+/* Writes the text of the leading records without a diagnostic; returns their number and, when it is
+ * below cb.n, the diagnostic of the first failing record in *first_bad. */
+uint32_t expand_batch(Dev& d, const wga_cigar_batch& cb, const ExpandJob& j, const uint8_t* d_tpool, uint64_t t_bytes,
+                      const uint8_t* d_qpool, uint64_t q_bytes, Output& out, wga_rec_diag* first_bad) {
+  const uint32_t n = cb.n;
+  auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
+  auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
+  void* d_tiles = d.alloc(wga_tile_ws_bytes(cb.n_ops));
+  d.check(wga_cigar_stat(d.ctx, &cb, d_counts, d_diag, d_tiles));
+  uint64_t *d_to = d.upload(j.t_off), *d_tl = d.upload(j.t_len), *d_qo = d.upload(j.q_off), *d_ql = d.upload(j.q_len);
+  uint32_t *d_pt = d.upload(j.pre_t), *d_pq = d.upload(j.pre_q), *d_po = d.upload(j.post);
+  auto* d_tro = (uint64_t*)d.alloc((size_t)n * 8);
+  auto* d_qro = (uint64_t*)d.alloc((size_t)n * 8);
+  auto* d_rec = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+  d.check(wga_paf2maf_layout(d.ctx, n, d_counts, d_tl, d_ql, d_pt, d_pq, d_po, d_tro, d_qro, d_rec));
+  std::vector<uint64_t> rec_off(n + 1), tro(n), qro(n);
+  d.download(rec_off.data(), d_rec, n + 1);
+  d.download(tro.data(), d_tro, n);
+  d.download(qro.data(), d_qro, n);
+  std::vector<wga_cigar_counts> counts(n);
+  d.download(counts.data(), d_counts, n);
+  auto* d_out = (uint8_t*)d.alloc(rec_off[n] + 64);
+  d.check(wga_paf2maf_expand(d.ctx, &cb, d_counts, d_tiles, d_tpool, t_bytes, d_to, d_tl, d_qpool, q_bytes, d_qo, d_ql,
+                             d_out, d_tro, d_qro, d_diag));
+  /* the MAF line text around the rows: three snippets per record */
+  std::vector<uint64_t> dst(3 * (size_t)n);
+  for (uint32_t k = 0; k < n; k++) {
+    dst[3 * k] = rec_off[k];
+    dst[3 * k + 1] = tro[k] + j.t_len[k] + counts[k].ins_bp + counts[k].inv_ins_bp;
+    dst[3 * k + 2] = rec_off[k + 1] - 2;
+  }
+  uint8_t* d_blob = d.upload((const uint8_t*)j.blob.data(), j.blob.size());
+  uint64_t *d_boff = d.upload(j.blob_off), *d_dst = d.upload(dst);
+  d.check(wga_scatter_bytes(d.ctx, 3 * n, d_blob, d_boff, d_out, d_dst));
+  std::vector<wga_rec_diag> diag(n);
+  d.download(diag.data(), d_diag, n);
+  uint32_t good = n;
+  for (uint32_t k = 0; k < n; k++) {
+    const wga_rec_diag& g = diag[k];
+    if (g.bad_base_pos == WGA_NONE && g.bad_op_idx == WGA_NONE && g.panic_op_idx == WGA_NONE) continue;
+    good = k;
+    *first_bad = g;
+    break;
+  }
+  std::string host((size_t)rec_off[good], '\0');
+  if (rec_off[good]) d.download((uint8_t*)host.data(), d_out, rec_off[good]);
+  out.write(host);
+  return good;
+}
+
 /* ---- paf2maf (converter.rs:176-265) ------------------------------------------------------------- */
 int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::string& q_fa, Output& out) {
   std::vector<PafRecord> recs = parse_paf(read_all(input));
@@ -185,10 +290,7 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
   size_t i0 = 0;
   std::string pending_error;
   while (i0 < recs.size() && pending_error.empty()) {
-    std::vector<uint64_t> t_off, t_len, q_off, q_len;
-    std::vector<uint32_t> pre_t, pre_q, post;
-    std::string blob;
-    std::vector<uint64_t> blob_off{0};
+    ExpandJob job;
     uint64_t est = 0, est_text = 0;
     const uint64_t kMaxText = 160ull << 20; /* ~64 M ops */
     size_t i = i0;
@@ -204,35 +306,9 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
         break;
       }
       for (const auto& tg : r.tags) est_text += tg.size();
-      t_off.push_back(to);
-      t_len.push_back(tl);
-      q_off.push_back(qo);
-      q_len.push_back(ql);
-      std::string a = "a score=";
-      append_u64(a, r.mapq);
-      a += "\ns\t" + r.target_name + "\t";
-      append_u64(a, r.target_start);
-      a.push_back('\t');
-      append_u64(a, r.target_end - r.target_start);
-      a += "\t+\t";
-      append_u64(a, r.target_length);
-      a.push_back('\t');
-      std::string q = "\ns\t" + r.query_name + "\t";
-      append_u64(q, r.neg ? r.query_length - r.query_end : r.query_start); /* converter.rs:213-216 */
-      q.push_back('\t');
-      append_u64(q, r.query_end - r.query_start);
-      q += r.neg ? "\t-\t" : "\t+\t";
-      append_u64(q, r.query_length);
-      q.push_back('\t');
-      pre_t.push_back((uint32_t)a.size());
-      pre_q.push_back((uint32_t)q.size());
-      post.push_back(2);
-      blob += a;
-      blob_off.push_back(blob.size());
-      blob += q;
-      blob_off.push_back(blob.size());
-      blob += "\n\n";
-      blob_off.push_back(blob.size());
+      job.add(to, tl, qo, ql, r.mapq, r.target_name, r.target_start, r.target_end - r.target_start, false,
+              r.target_length, r.query_name, r.neg ? r.query_length - r.query_end : r.query_start, /* converter.rs:213-216 */
+              r.query_end - r.query_start, r.neg, r.query_length);
       est += tl + ql + (tl + ql) / 4;
     }
     /* the CIGARs of records [i0, i) are tokenised on the device; a tag / tokeniser error cuts the
@@ -248,8 +324,8 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
         std::string perr = terr;
         const PafRecord& r = recs[i0 + k];
         if (r.neg)
-          for (uint64_t x = q_len[k]; x-- > 0;) {
-            char c = qf.pool[q_off[k] + x];
+          for (uint64_t x = job.q_len[k]; x-- > 0;) {
+            char c = qf.pool[job.q_off[k] + x];
             if (!strchr("ACGTNacgtn", c) || c == 0) {
               perr = std::string("Invalid Base: `") + c + "`";
               break;
@@ -257,68 +333,24 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
           }
         pending_error = perr;
         i = i0 + k;
-        t_off.resize(k);
-        t_len.resize(k);
-        q_off.resize(k);
-        q_len.resize(k);
-        pre_t.resize(k);
-        pre_q.resize(k);
-        post.resize(k);
-        blob_off.resize(3 * k + 1);
-        blob.resize(blob_off.back());
       }
     }
     const uint32_t n = cb.n;
     if (n) {
-      auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
-      auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
-      void* d_tiles = d.alloc(wga_tile_ws_bytes(cb.n_ops));
-      d.check(wga_cigar_stat(d.ctx, &cb, d_counts, d_diag, d_tiles));
-      uint64_t *d_to = d.upload(t_off), *d_tl = d.upload(t_len), *d_qo = d.upload(q_off), *d_ql = d.upload(q_len);
-      uint32_t *d_pt = d.upload(pre_t), *d_pq = d.upload(pre_q), *d_po = d.upload(post);
-      auto* d_tro = (uint64_t*)d.alloc((size_t)n * 8);
-      auto* d_qro = (uint64_t*)d.alloc((size_t)n * 8);
-      auto* d_rec = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
-      d.check(wga_paf2maf_layout(d.ctx, n, d_counts, d_tl, d_ql, d_pt, d_pq, d_po, d_tro, d_qro, d_rec));
-      std::vector<uint64_t> rec_off(n + 1), tro(n), qro(n);
-      d.download(rec_off.data(), d_rec, n + 1);
-      d.download(tro.data(), d_tro, n);
-      d.download(qro.data(), d_qro, n);
-      std::vector<wga_cigar_counts> counts(n);
-      d.download(counts.data(), d_counts, n);
-      auto* d_out = (uint8_t*)d.alloc(rec_off[n] + 64);
-      d.check(wga_paf2maf_expand(d.ctx, &cb, d_counts, d_tiles, d_tpool, tf.pool.size(), d_to, d_tl, d_qpool,
-                                 qf.pool.size(), d_qo, d_ql, d_out, d_tro, d_qro, d_diag));
-      /* the MAF line text around the rows: three snippets per record */
-      std::vector<uint64_t> dst(3 * (size_t)n);
-      for (uint32_t k = 0; k < n; k++) {
-        dst[3 * k] = rec_off[k];
-        dst[3 * k + 1] = tro[k] + t_len[k] + counts[k].ins_bp + counts[k].inv_ins_bp;
-        dst[3 * k + 2] = rec_off[k + 1] - 2;
-      }
-      uint8_t* d_blob = d.upload((const uint8_t*)blob.data(), blob.size());
-      uint64_t *d_boff = d.upload(blob_off), *d_dst = d.upload(dst);
-      d.check(wga_scatter_bytes(d.ctx, 3 * n, d_blob, d_boff, d_out, d_dst));
-      std::vector<wga_rec_diag> diag(n);
-      d.download(diag.data(), d_diag, n);
-      uint32_t good = n;
-      for (uint32_t k = 0; k < n; k++) {
-        const wga_rec_diag& g = diag[k];
-        if (g.bad_base_pos == WGA_NONE && g.bad_op_idx == WGA_NONE && g.panic_op_idx == WGA_NONE) continue;
-        good = k;
+      job.resize(n);
+      wga_rec_diag g;
+      const uint32_t good = expand_batch(d, cb, job, d_tpool, tf.pool.size(), d_qpool, qf.pool.size(), out, &g);
+      if (good < n) {
+        const uint32_t k = good;
         if (g.bad_base_pos != WGA_NONE) { /* utils.rs:97 */
-          char c = qf.pool[q_off[k] + q_len[k] - 1 - g.bad_base_pos];
+          char c = qf.pool[job.q_off[k] + job.q_len[k] - 1 - g.bad_base_pos];
           pending_error = std::string("Invalid Base: `") + c + "`";
         } else if (g.bad_op_idx < g.panic_op_idx) { /* errors.rs:59 */
           pending_error = "CIGAR OP `" + cigar_op_token_at(cigars[k], g.bad_op_idx) + "` invalid";
         } else {
           pending_error = "panic: String::insert_str beyond the end of the fetched sequence (cigar.rs:507,513)";
         }
-        break;
       }
-      std::string host((size_t)rec_off[good], '\0');
-      if (rec_off[good]) d.download((uint8_t*)host.data(), d_out, rec_off[good]);
-      out.write(host);
       /* free this batch's buffers (the pools stay) */
       d.check(wga_sync(d.ctx));
       while (d.owned.size() > 2) d.release(d.owned.back());
@@ -450,37 +482,54 @@ int cmd_maf2paf(const std::string* input, const std::string* query_name, Output&
     d.download(roff.data(), d_roff, n + 1);
     auto* d_runs = (uint64_t*)d.alloc((roff[n] + 1) * 8);
     d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, d_runs, d_roff));
-    std::vector<uint64_t> runs(roff[n]);
-    if (roff[n]) d.download(runs.data(), d_runs, roff[n]);
+    /* the cg:Z: text is formatted on the device (wga_maf_runs_cigar_text) between the host's fields */
+    auto* d_tb = (uint64_t*)d.alloc((size_t)n * 8);
+    d.check(wga_maf_runs_cigar_text(d.ctx, n, roff[n], d_runs, d_roff, d_c, d_tb, nullptr, nullptr));
+    std::vector<uint64_t> tb(n);
+    d.download(tb.data(), d_tb, n);
     std::vector<wga_cigar_counts> counts(n);
     d.download(counts.data(), d_counts, n);
+    std::string blob;
+    std::vector<uint64_t> blob_off{0}, dst, text_off(n);
+    uint64_t pos = 0;
     for (uint32_t k = 0; k < n; k++) {
       const MafRecord& r = recs[k];
       const wga_cigar_counts& c = counts[k];
       uint64_t block = c.match + c.mismatch + c.ins_bp + c.inv_ins_bp + c.del_bp + c.inv_del_bp;
-      append_csv_field(text, r.q().name, '\t');
+      std::string h;
+      append_csv_field(h, r.q().name, '\t');
       uint64_t a[] = {r.q().size, r.query_start(), r.query_end()};
       for (uint64_t v : a) {
-        text.push_back('\t');
-        append_u64(text, v);
+        h.push_back('\t');
+        append_u64(h, v);
       }
-      text += r.q().neg ? "\t-\t" : "\t+\t";
-      append_csv_field(text, r.t().name, '\t');
+      h += r.q().neg ? "\t-\t" : "\t+\t";
+      append_csv_field(h, r.t().name, '\t');
       uint64_t bb[] = {r.t().size, r.t().start, r.t().start + r.t().align_size, c.match, block, 255};
       for (uint64_t v : bb) {
-        text.push_back('\t');
-        append_u64(text, v);
+        h.push_back('\t');
+        append_u64(h, v);
       }
-      text += "\tNM:i:";
-      append_u64(text, block - c.match);
-      text += "\tcg:Z:";
-      for (uint64_t x = roff[k]; x < roff[k + 1]; x++) {
-        uint64_t start = runs[x] >> 3, end = x + 1 < roff[k + 1] ? runs[x + 1] >> 3 : p.cols[k];
-        append_u64(text, end - start);
-        text.push_back("=IDX"[runs[x] & 7]);
-      }
-      text.push_back('\n');
+      h += "\tNM:i:";
+      append_u64(h, block - c.match);
+      h += "\tcg:Z:";
+      dst.push_back(pos);
+      blob += h;
+      blob_off.push_back(blob.size());
+      pos += h.size();
+      text_off[k] = pos;
+      pos += tb[k];
+      dst.push_back(pos);
+      blob += "\n";
+      blob_off.push_back(blob.size());
+      pos += 1;
     }
+    auto* d_out = (uint8_t*)d.alloc(pos + 64);
+    d.check(wga_maf_runs_cigar_text(d.ctx, n, roff[n], d_runs, d_roff, d_c, nullptr, d_out, d.upload(text_off)));
+    d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off), d_out,
+                              d.upload(dst)));
+    text.resize((size_t)pos);
+    if (pos) d.download((uint8_t*)&text[0], d_out, pos);
   }
   out.write(text);
   out.close();
@@ -682,6 +731,314 @@ int cmd_paf2chain(const std::string* input, Output& out) {
     }
     d.release_all();
     i0 = i;
+  }
+  out.close();
+  if (!pending_error.empty()) fail(pending_error);
+  return 0;
+}
+
+/* ---- the chain readers' device batch: data lines -> packed ops (wga_chain_lines_ops) ----------------- */
+struct ChainBatch {
+  wga_cigar_batch cb;
+  uint64_t* d_lines = nullptr;
+  uint64_t* d_line_off = nullptr;
+  uint64_t n_lines = 0;
+};
+ChainBatch chain_device_batch(Dev& d, const ChainRecord* recs, uint32_t n) {
+  ChainBatch b;
+  std::vector<uint64_t> lines, line_off{0};
+  std::vector<uint8_t> strand;
+  for (uint32_t k = 0; k < n; k++) {
+    lines.insert(lines.end(), recs[k].lines.begin(), recs[k].lines.end());
+    line_off.push_back(lines.size() / 3);
+    strand.push_back(recs[k].query_neg ? 1 : 0);
+  }
+  b.n_lines = lines.size() / 3;
+  lines.resize(lines.size() + 3);
+  b.d_lines = d.upload(lines);
+  b.d_line_off = d.upload(line_off);
+  auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
+  d.check(wga_chain_lines_ops(d.ctx, n, b.n_lines, b.d_lines, b.d_line_off, d_cnt, nullptr, nullptr));
+  auto* d_ooff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+  d.check(wga_exclusive_scan_u64(d.ctx, n, d_cnt, d_ooff));
+  uint64_t total = 0;
+  d.download(&total, d_ooff + n, 1);
+  auto* d_ops = (uint32_t*)d.alloc((total + 4) * 4);
+  d.check(wga_chain_lines_ops(d.ctx, n, b.n_lines, b.d_lines, b.d_line_off, nullptr, d_ops, d_ooff));
+  b.cb.d_ops = d_ops;
+  b.cb.d_op_off = d_ooff;
+  b.cb.d_strand_neg = d.upload(strand);
+  b.cb.n_ops = total;
+  b.cb.n = n;
+  return b;
+}
+
+/* ---- chain2maf (converter.rs:268-358) ------------------------------------------------------------------
+ * A data line (size, dt, dq) is the op group "size M, dq I, dt D" of parse_chain_to_insert (:360-388), so the
+ * rows come from the same kernels as paf2maf.  Records before a failing one are written, like the reference. */
+int cmd_chain2maf(const std::string* input, const std::string& t_fa, const std::string& q_fa, Output& out) {
+  std::string pending_error;
+  std::vector<ChainRecord> recs = parse_chain(read_all(input), &pending_error);
+  Faidx tf, qf;
+  tf.load(t_fa);
+  qf.load(q_fa);
+  out.write("#maf version=1.6 convert_from=chain t_seq_path=" + t_fa + " q_seq_path=" + q_fa + "\n");
+  Dev d;
+  d.init();
+  uint8_t* d_tpool = d.upload((const uint8_t*)tf.pool.data(), tf.pool.size());
+  uint8_t* d_qpool = d.upload((const uint8_t*)qf.pool.data(), qf.pool.size());
+  const uint64_t kMaxBytes = 6ull << 30, kMaxLines = 32ull << 20;
+  size_t i0 = 0;
+  while (i0 < recs.size()) {
+    ExpandJob job;
+    uint64_t est = 0, est_lines = 0;
+    size_t i = i0;
+    std::string fetch_error;
+    for (; i < recs.size(); i++) {
+      const ChainRecord& r = recs[i];
+      if (i > i0 && (est > kMaxBytes || est_lines > kMaxLines)) break;
+      uint64_t to, tl, qo, ql;
+      try { /* :309-316: target first, then query, both on the forward strand */
+        tf.fetch(r.target_name, r.target_start, r.target_end - 1, &to, &tl);
+        qf.fetch(r.query_name, r.query_start, r.query_end - 1, &qo, &ql);
+      } catch (Error& e) {
+        fetch_error = e.msg;
+        break;
+      }
+      job.add(to, tl, qo, ql, 255, r.target_name, r.target_start, r.target_end - r.target_start, r.target_neg,
+              r.target_size, r.query_name, r.query_neg ? r.query_size - r.query_end : r.query_start, /* :299-302 */
+              r.query_end - r.query_start, r.query_neg, r.query_size);
+      est += tl + ql + (tl + ql) / 4;
+      est_lines += r.lines.size() / 3;
+    }
+    const uint32_t n = (uint32_t)(i - i0);
+    if (n) {
+      ChainBatch b = chain_device_batch(d, &recs[i0], n);
+      wga_rec_diag g;
+      const uint32_t good = expand_batch(d, b.cb, job, d_tpool, tf.pool.size(), d_qpool, qf.pool.size(), out, &g);
+      d.check(wga_sync(d.ctx));
+      while (d.owned.size() > 2) d.release(d.owned.back());
+      if (good < n) {
+        if (g.bad_base_pos != WGA_NONE) { /* utils.rs:97, reverse_complement of the query slice (:320-325) */
+          char c = qf.pool[job.q_off[good] + job.q_len[good] - 1 - g.bad_base_pos];
+          pending_error = std::string("Invalid Base: `") + c + "`";
+        } else {
+          pending_error = "panic: String::insert_str beyond the end of the fetched sequence (converter.rs:375,383)";
+        }
+        break;
+      }
+    }
+    if (!fetch_error.empty()) {
+      pending_error = fetch_error;
+      break;
+    }
+    i0 = i;
+  }
+  out.close();
+  if (!pending_error.empty()) fail(pending_error);
+  return 0;
+}
+
+/* ---- chain2paf (converter.rs:391-416, chain.rs:430-452) ------------------------------------------------
+ * GPU: data lines -> ops -> K1 (matches, block length) and the CIGAR text (wga_chain_lines_cigar_text).
+ * All records are converted before the first is written (:402-410): an error leaves the output empty. */
+int cmd_chain2paf(const std::string* input, Output& out) {
+  std::string perr;
+  std::vector<ChainRecord> recs = parse_chain(read_all(input), &perr);
+  if (!perr.empty()) {
+    out.close();
+    fail(perr);
+  }
+  Dev d;
+  bool dev_ready = false;
+  const uint64_t kMaxLines = 32ull << 20;
+  size_t i0 = 0;
+  while (i0 < recs.size()) {
+    size_t i = i0;
+    uint64_t est = 0;
+    for (; i < recs.size(); i++) {
+      if (i > i0 && est > kMaxLines) break;
+      est += recs[i].lines.size() / 3;
+    }
+    if (!dev_ready) {
+      d.init();
+      dev_ready = true;
+    }
+    const uint32_t n = (uint32_t)(i - i0);
+    ChainBatch b = chain_device_batch(d, &recs[i0], n);
+    auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
+    auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
+    d.check(wga_cigar_stat(d.ctx, &b.cb, d_counts, d_diag, nullptr));
+    std::vector<wga_cigar_counts> counts(n);
+    d.download(counts.data(), d_counts, n);
+    auto* d_tb = (uint64_t*)d.alloc((size_t)n * 8);
+    d.check(wga_chain_lines_cigar_text(d.ctx, n, b.n_lines, b.d_lines, b.d_line_off, d_tb, nullptr, nullptr));
+    std::vector<uint64_t> tb(n);
+    d.download(tb.data(), d_tb, n);
+    /* record text = host fields up to "cg:Z:" | device CIGAR | "\n" */
+    std::string blob;
+    std::vector<uint64_t> blob_off{0}, dst, text_off(n);
+    uint64_t pos = 0;
+    for (uint32_t k = 0; k < n; k++) {
+      const ChainRecord& r = recs[i0 + k];
+      const wga_cigar_counts& c = counts[k];
+      std::string h;
+      append_csv_field(h, r.query_name, '\t');
+      const uint64_t a[] = {r.query_size, r.query_start, r.query_end};
+      for (uint64_t v : a) {
+        h.push_back('\t');
+        append_u64(h, v);
+      }
+      h += r.query_neg ? "\t-\t" : "\t+\t";
+      append_csv_field(h, r.target_name, '\t');
+      /* block_length = match + mismatch + del + inv_del (chain.rs:433-435) */
+      const uint64_t b2[] = {r.target_size, r.target_start, r.target_end, c.match,
+                             c.match + c.mismatch + c.del_bp + c.inv_del_bp, 255};
+      for (uint64_t v : b2) {
+        h.push_back('\t');
+        append_u64(h, v);
+      }
+      h += "\tcg:Z:";
+      dst.push_back(pos);
+      blob += h;
+      blob_off.push_back(blob.size());
+      pos += h.size();
+      text_off[k] = pos;
+      pos += tb[k];
+      dst.push_back(pos);
+      blob += "\n";
+      blob_off.push_back(blob.size());
+      pos += 1;
+    }
+    auto* d_out = (uint8_t*)d.alloc(pos + 64);
+    d.check(wga_chain_lines_cigar_text(d.ctx, n, b.n_lines, b.d_lines, b.d_line_off, nullptr, d_out, d.upload(text_off)));
+    d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off), d_out,
+                              d.upload(dst)));
+    std::string host((size_t)pos, '\0');
+    if (pos) d.download((uint8_t*)&host[0], d_out, pos);
+    out.write(host);
+    d.release_all();
+    i0 = i;
+  }
+  out.close();
+  return 0;
+}
+
+/* ---- maf2chain (converter.rs:57-91) ---------------------------------------------------------------------
+ * GPU: K3 column-pair runs -> packed ops (wga_maf_runs_ops) -> data lines and trims (wga_cigar_chain; '=' and X
+ * runs add up into one block like cigar_cat's M).  Host: chain headers (chain.rs:103-140,185-203). */
+int cmd_maf2chain(const std::string* input, const std::string* query_name, Output& out) {
+  std::string header;
+  std::vector<MafRecord> recs = parse_maf(read_all(input), &header);
+  /* set_query_idx_byname fails per record, after the earlier records were written (:66-73) */
+  std::string pending_error;
+  size_t n_ok = recs.size();
+  for (size_t k = 0; k < recs.size() && pending_error.empty(); k++) {
+    MafRecord& r = recs[k];
+    if (query_name) {
+      size_t x = 0;
+      for (; x < r.slines.size(); x++)
+        if (r.slines[x].name == *query_name) break;
+      if (x == r.slines.size()) {
+        pending_error = "Query name:" + *query_name + " not found in MAF";
+        n_ok = k;
+        break;
+      }
+      r.query_idx = x;
+    }
+    if (r.query_idx >= r.slines.size()) {
+      pending_error = "panic: MAF block with a single s-line has no query row (maf.rs:426 index out of bounds)";
+      n_ok = k;
+    }
+  }
+  recs.resize(n_ok);
+  const uint32_t n = (uint32_t)recs.size();
+  if (n) {
+    MafPairs p = gather_pairs(recs);
+    Dev d;
+    d.init();
+    auto* d_rows = d.upload((const uint8_t*)p.rows.data(), p.rows.size());
+    auto *d_t = d.upload(p.t_off), *d_q = d.upload(p.q_off), *d_c = d.upload(p.cols);
+    auto* d_s = d.upload(p.strand);
+    auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
+    auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
+    d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, nullptr, nullptr));
+    auto* d_roff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+    d.check(wga_exclusive_scan_u64(d.ctx, n, d_cnt, d_roff));
+    uint64_t n_runs = 0;
+    d.download(&n_runs, d_roff + n, 1);
+    auto* d_runs = (uint64_t*)d.alloc((n_runs + 1) * 8);
+    d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, d_runs, d_roff));
+    auto* d_ocnt = (uint64_t*)d.alloc((size_t)n * 8);
+    d.check(wga_maf_runs_ops(d.ctx, n, n_runs, d_runs, d_roff, d_c, d_ocnt, nullptr, nullptr));
+    auto* d_ooff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+    d.check(wga_exclusive_scan_u64(d.ctx, n, d_ocnt, d_ooff));
+    uint64_t n_ops = 0;
+    d.download(&n_ops, d_ooff + n, 1);
+    auto* d_ops = (uint32_t*)d.alloc((n_ops + 4) * 4);
+    d.check(wga_maf_runs_ops(d.ctx, n, n_runs, d_runs, d_roff, d_c, nullptr, d_ops, d_ooff));
+    wga_cigar_batch cb;
+    cb.d_ops = d_ops;
+    cb.d_op_off = d_ooff;
+    cb.d_strand_neg = d_s;
+    cb.n_ops = n_ops;
+    cb.n = n;
+    auto* d_trim = (wga_chain_trim_t*)d.alloc((size_t)n * sizeof(wga_chain_trim_t));
+    auto* d_nb = (uint64_t*)d.alloc((size_t)n * 8);
+    auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
+    d.check(wga_cigar_chain(d.ctx, &cb, d_trim, d_nb, d_diag, nullptr, nullptr));
+    std::vector<wga_chain_trim_t> trim(n);
+    std::vector<uint64_t> nb(n);
+    d.download(trim.data(), d_trim, n);
+    d.download(nb.data(), d_nb, n);
+    std::string blob;
+    std::vector<uint64_t> blob_off{0}, dst, data_off(n);
+    uint64_t pos = 0;
+    for (uint32_t k = 0; k < n; k++) {
+      const MafRecord& r = recs[k];
+      const wga_chain_trim_t& t = trim[k];
+      const bool neg = r.q().neg;
+      uint64_t qs = r.query_start(), qe = r.query_end();
+      const uint64_t ts = r.t().start + t.head_del, te = r.t().start + r.t().align_size - t.tail_del;
+      if (!neg) {
+        qs += t.head_ins;
+        qe -= t.tail_ins;
+      } else { /* chain.rs:131-136: the new end is computed from the already updated start */
+        qs = r.q().size - (qe - t.head_ins);
+        qe = r.q().size - (qs + t.tail_ins);
+      }
+      std::string h = "chain\t255\t" + r.t().name + "\t";
+      append_u64(h, r.t().size);
+      h += "\t+\t";
+      append_u64(h, ts);
+      h.push_back('\t');
+      append_u64(h, te);
+      h += "\t" + r.q().name + "\t";
+      append_u64(h, r.q().size);
+      h += neg ? "\t-\t" : "\t+\t";
+      append_u64(h, qs);
+      h.push_back('\t');
+      append_u64(h, qe);
+      h.push_back('\t');
+      append_u64(h, (uint64_t)k);
+      dst.push_back(pos);
+      blob += h;
+      blob_off.push_back(blob.size());
+      pos += h.size();
+      data_off[k] = pos;
+      pos += nb[k];
+      dst.push_back(pos);
+      blob += "\n\n";
+      blob_off.push_back(blob.size());
+      pos += 2;
+    }
+    auto* d_out = (uint8_t*)d.alloc(pos + 64);
+    d.check(wga_cigar_chain(d.ctx, &cb, nullptr, nullptr, nullptr, d_out, d.upload(data_off)));
+    d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off), d_out,
+                              d.upload(dst)));
+    std::string host((size_t)pos, '\0');
+    d.download((uint8_t*)&host[0], d_out, pos);
+    out.write(host);
   }
   out.close();
   if (!pending_error.empty()) fail(pending_error);
@@ -1435,6 +1792,9 @@ void usage() {
           "  pafpseudo | pp [PAF] -o OUTDIR [-f ALL.fa] [-g TARGET]\n"
           "  validate | vf  [PAF] [-f FIXED.paf]\n"
           "  paf2chain | p2c [PAF]\n"
+          "  maf2chain | m2c [MAF] [-q QUERY_NAME]\n"
+          "  chain2paf | c2p [CHAIN]\n"
+          "  chain2maf | c2m [CHAIN] --target TARGET.fa --query QUERY.fa   (-g / -q)\n"
           "  call    | c    [MAF] [-s] [-i] [-l SVLEN] [-n SAMPLE] [--query-name N | --query-regex R] [-c CHUNK]\n"
           "  call    | c    -f paf [PAF] --target T.fa --query Q.fa [-s] [-l SVLEN] [-n SAMPLE]\n");
 }
@@ -1536,7 +1896,7 @@ int main(int argc, char** argv) {
         if (i + 1 >= rest.size()) fail("a value is required for '" + a + "'");
         return rest[++i];
       };
-      bool conv = cmd == "paf2maf" || cmd == "p2m";
+      bool conv = cmd == "paf2maf" || cmd == "p2m" || cmd == "chain2maf" || cmd == "c2m";
       if (a == "-g" || a == "--target")
         target = val();
       else if ((a == "-q" || a == "--query") && (conv || call))
@@ -1593,6 +1953,19 @@ int main(int argc, char** argv) {
     if (cmd == "paf2chain" || cmd == "p2c") {
       out.open(outfile, rewrite);
       return cmd_paf2chain(input, out);
+    }
+    if (cmd == "maf2chain" || cmd == "m2c") {
+      out.open(outfile, rewrite);
+      return cmd_maf2chain(input, qn, out);
+    }
+    if (cmd == "chain2paf" || cmd == "c2p") {
+      out.open(outfile, rewrite);
+      return cmd_chain2paf(input, out);
+    }
+    if (cmd == "chain2maf" || cmd == "c2m") {
+      if (target.empty() || query.empty()) fail("the following required arguments were not provided: --target --query");
+      out.open(outfile, rewrite);
+      return cmd_chain2maf(input, target, query, out);
     }
     if (validate) {
       if (has_fix && fix_path == (has_input ? input_s : std::string("stdin")))
