@@ -267,6 +267,19 @@ int wga_chain_lines_cigar_text(wga_ctx*, uint32_t n, uint64_t n_elems, const uin
                                const uint64_t* d_line_off, uint64_t* d_cnt, uint8_t* d_out,
                                const uint64_t* d_out_off);
 
+/* ---- K12: dotplot base-level segments (replaces the fold over
+ *      emit_baseplotdatas, cigar.rs:815-914, of parse_cigar_to_base_plotdata :917-952 and — on ops
+ *      from wga_maf_runs_ops — parse_maf_to_base_plotdata :955-985) ----------------------------------
+ * Per record the ordered BasePlotdata list (dotplot.rs:181-190) without the two names: 5 u64 per
+ * segment = ref_start, ref_end, query_start, query_end (start / end swapped for '-' records as
+ * reserve_query_start_end does), kind 0 'M' / 1 'I' / 2 'D'.  An I / D longer than `cutoff` is its
+ * own segment; M-like ops and shorter indels merge into M segments; other ops are ignored.
+ * d_t_start / d_q_start = target_start() / query_start() of the records.  Two calls: d_segs == NULL
+ * fills d_seg_cnt[n]; then record i's segments go to d_segs + 5 * d_seg_off[i]. */
+int wga_cigar_dotplot(wga_ctx*, const wga_cigar_batch*, uint64_t cutoff, const uint64_t* d_t_start,
+                      const uint64_t* d_q_start, uint64_t* d_seg_cnt, uint64_t* d_segs,
+                      const uint64_t* d_seg_off);
+
 /* ---- K5: pafcov (replaces update_cov_vec, cigar.rs:710-741, and the per-thread array merge of
  *      pafcov.rs:29-53) ------------------------------------------------------------------------
  * Record i adds +1 to d_cov[cov_off[target_id[i]] + p] for every base p of its M / = ops that

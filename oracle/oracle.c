@@ -1153,6 +1153,113 @@ int orc_parse_chain_to_insert(const uint64_t* lines, size_t n_lines, char** t, s
   return ORC_OK;
 }
 
+/* ---- dotplot base-level segments ----------------------------------------- */
+/* emit_baseplotdatas, cigar.rs:815-914, on a growing array of 5-u64 rows: ref_start, ref_end,
+ * query_start, query_end, kind (0 'M', 1 'I', 2 'D'); reserve_query_start_end (:807-812) swaps the
+ * query pair of a new row for '-' records, later updates go to the swapped field. */
+typedef struct {
+  uint64_t* v;
+  size_t n, cap;
+} segvec;
+static void seg_push(segvec* sv, uint64_t rs, uint64_t re, uint64_t qs, uint64_t qe, uint64_t kind, int neg) {
+  if (sv->n == sv->cap) {
+    sv->cap = sv->cap ? sv->cap * 2 : 16;
+    sv->v = (uint64_t*)realloc(sv->v, sv->cap * 5 * sizeof(uint64_t));
+  }
+  uint64_t* s = sv->v + 5 * sv->n++;
+  s[0] = rs;
+  s[1] = re;
+  s[2] = neg ? qe : qs;
+  s[3] = neg ? qs : qe;
+  s[4] = kind;
+}
+static void emit_baseplotdatas(uint64_t* ref_off, uint64_t* q_off, int neg, char op, uint64_t length,
+                               uint64_t cutoff, segvec* sv, int* last_m) {
+  if (op == 'M' || op == '=' || op == 'X') {
+    uint64_t ref_end = *ref_off + length, q_end = *q_off + length;
+    if (!*last_m) {
+      seg_push(sv, *ref_off, ref_end, *q_off, q_end, 0, neg);
+    } else {
+      uint64_t* m = sv->v + 5 * (sv->n - 1);
+      m[1] = ref_end;
+      if (neg) m[2] = q_end; else m[3] = q_end;
+    }
+    *ref_off += length;
+    *q_off += length;
+    *last_m = 1;
+  } else if (op == 'I') {
+    uint64_t q_end = *q_off + length;
+    if (length > cutoff) {
+      seg_push(sv, *ref_off, *ref_off, *q_off, q_end, 1, neg);
+      *last_m = 0;
+    } else if (*last_m) {
+      uint64_t* m = sv->v + 5 * (sv->n - 1);
+      if (neg) m[2] = q_end; else m[3] = q_end;
+    }
+    *q_off += length;
+  } else if (op == 'D') {
+    uint64_t ref_end = *ref_off + length;
+    if (length > cutoff) {
+      seg_push(sv, *ref_off, ref_end, *q_off, *q_off, 2, neg);
+      *last_m = 0;
+    } else if (*last_m) {
+      sv->v[5 * (sv->n - 1) + 1] = ref_end;
+    }
+    *ref_off += length;
+  }
+}
+
+/* parse_cigar_to_base_plotdata, cigar.rs:917-952; *segs = malloc'd n_segs x 5 u64 */
+int orc_cigar_to_base_plotdata(const char* cg, size_t n, uint64_t t_start, uint64_t q_start, int strand_neg,
+                               uint64_t cutoff, uint64_t** segs, size_t* n_segs, orc_err* err) {
+  const char* p = cg;
+  const char* end = cg + n;
+  *segs = NULL;
+  *n_segs = 0;
+  if (strip_tag(&p, end, err)) return err->kind;
+  segvec sv = {NULL, 0, 0};
+  uint64_t r = t_start, q = q_start;
+  int last_m = 0, any = 0;
+  cst_t tok;
+  while (parse_cigar_str_tuple(&p, end, &tok)) {
+    const char* op;
+    size_t op_n;
+    uint64_t len;
+    any = 1;
+    if (cst2cu(&tok, &op, &op_n, &len, err)) {
+      free(sv.v);
+      return err->kind;
+    }
+    emit_baseplotdatas(&r, &q, strand_neg, op[0], len, cutoff, &sv, &last_m);
+  }
+  if (!any) { /* fold_many1 on an empty CIGAR */
+    free(sv.v);
+    return empty_cigar_panic(err);
+  }
+  *segs = sv.v;
+  *n_segs = sv.n;
+  return ORC_OK;
+}
+
+/* parse_maf_to_base_plotdata, cigar.rs:955-985 (group_by(cigar_cat_ext)) */
+void orc_maf_to_base_plotdata(const char* t, size_t tn, const char* q, size_t qn, uint64_t t_start,
+                              uint64_t q_start, int strand_neg, uint64_t cutoff, uint64_t** segs,
+                              size_t* n_segs) {
+  segvec sv = {NULL, 0, 0};
+  uint64_t r = t_start, qo = q_start;
+  int last_m = 0;
+  size_t cols = tn < qn ? tn : qn, i = 0;
+  while (i < cols) {
+    char k = cigar_cat_ext(t[i], q[i]);
+    size_t j = i + 1;
+    while (j < cols && cigar_cat_ext(t[j], q[j]) == k) j++;
+    emit_baseplotdatas(&r, &qo, strand_neg, k, (uint64_t)(j - i), cutoff, &sv, &last_m);
+    i = j;
+  }
+  *segs = sv.v;
+  *n_segs = sv.n;
+}
+
 /* per-record chunk loop of call_var_maf, caller.rs:115-149, with create_chunk_record
  * (:221-265: start += non-gap chars of the prefix, align_size = non-gap chars of the chunk) and
  * the strand-aware accessors of maf.rs:433-450,468-470 applied to the chunk record. */

@@ -125,6 +125,15 @@ void orc_parse_chain_to_cigar(const uint64_t* lines, size_t n_lines, int strand_
 int orc_parse_chain_to_insert(const uint64_t* lines, size_t n_lines, char** t, size_t* tn, char** q,
                               size_t* qn);
 
+/* cigar.rs:917-952 parse_cigar_to_base_plotdata (+ emit_baseplotdatas :815-914): *segs = malloc'd
+ * n_segs x 5 u64 (ref_start, ref_end, query_start, query_end, kind 0 M / 1 I / 2 D) */
+int orc_cigar_to_base_plotdata(const char* cg, size_t n, uint64_t t_start, uint64_t q_start, int strand_neg,
+                               uint64_t cutoff, uint64_t** segs, size_t* n_segs, orc_err* err);
+/* cigar.rs:955-985 parse_maf_to_base_plotdata */
+void orc_maf_to_base_plotdata(const char* t, size_t tn, const char* q, size_t qn, uint64_t t_start,
+                              uint64_t q_start, int strand_neg, uint64_t cutoff, uint64_t** segs,
+                              size_t* n_segs);
+
 void orc_free(void* p);
 /* test helper: packed ops -> "cg:Z:..." text; returns length (0 if cap too small) */
 size_t orc_ops_to_text(const uint32_t* ops, size_t n, char* out, size_t cap);

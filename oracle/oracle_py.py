@@ -68,6 +68,9 @@ def lib():
         L.orc_parse_chain_to_cigar.argtypes = [P, Z, C.c_int, P, P]
         L.orc_parse_chain_to_cigar.restype = None
         L.orc_parse_chain_to_insert.argtypes = [P, Z, P, P, P, P]
+        L.orc_cigar_to_base_plotdata.argtypes = [C.c_char_p, Z, U, U, C.c_int, U, P, P, P]
+        L.orc_maf_to_base_plotdata.argtypes = [C.c_char_p, Z, C.c_char_p, Z, U, U, C.c_int, U, P, P]
+        L.orc_maf_to_base_plotdata.restype = None
         L.orc_ops_to_text.restype = Z
         L.orc_ops_to_text.argtypes = [P, Z, C.c_char_p, Z]
         L.orc_free.argtypes = [C.c_void_p]
@@ -314,6 +317,33 @@ def parse_chain_to_insert(lines, t_seq, q_seq):
     finally:
         lib().orc_free(t)
         lib().orc_free(q)
+
+
+def _take_segs(ptr, n):
+    if not n:
+        return np.zeros((0, 5), dtype=np.uint64)
+    a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(n * 5,)).copy().reshape(n, 5)
+    lib().orc_free(ptr)
+    return a
+
+
+def cigar_to_base_plotdata(cg, t_start, q_start, strand_neg, cutoff):
+    """cigar.rs:917-952 -> (n, 5) uint64 rows ref_start, ref_end, query_start, query_end, kind"""
+    cg = cg.encode() if isinstance(cg, str) else bytes(cg)
+    segs, n, err = C.c_void_p(), C.c_size_t(0), Err()
+    if lib().orc_cigar_to_base_plotdata(cg, len(cg), t_start, q_start, int(strand_neg), int(cutoff), C.byref(segs),
+                                        C.byref(n), C.byref(err)):
+        _raise(err)
+    return _take_segs(segs, n.value)
+
+
+def maf_to_base_plotdata(t_row, q_row, t_start, q_start, strand_neg, cutoff):
+    """cigar.rs:955-985"""
+    t_row, q_row = bytes(t_row), bytes(q_row)
+    segs, n = C.c_void_p(), C.c_size_t(0)
+    lib().orc_maf_to_base_plotdata(t_row, len(t_row), q_row, len(q_row), t_start, q_start, int(strand_neg),
+                                   int(cutoff), C.byref(segs), C.byref(n))
+    return _take_segs(segs, n.value)
 
 
 def ops_to_text(ops):

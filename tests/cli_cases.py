@@ -697,3 +697,96 @@ def test_chain2maf_end_to_end(cli, tmp_path):
     rc, out, err = run(cli, "c2m", str(ch), "-g", str(t_fa), "-q", str(q_fa))
     assert rc == 1 and "panic" in err
     assert out == expected(recs[:9], starts[:9])
+
+
+# ---- dotplot --out-format csv ----------------------------------------------------------
+def _seg_csv(segs, t_name, q_name):
+    return "".join("%d,%d,%d,%d,%s,%s,%s\n" % (s[0], s[1], s[2], s[3], "MID"[int(s[4])], t_name, q_name) for s in segs)
+
+
+def test_dotplot_base_level_csv(cli, tmp_path):
+    """tools/dotplot.rs base-level mode: one csv row per BasePlotdata (cigar.rs:815-985), default cutoff 50"""
+    b = synth.make_paf_batch(19, 25, 500, 300000)
+    n = len(b["strand_neg"])
+    rng = np.random.default_rng(6)
+    lines, recs = [], []
+    for i in range(n):
+        cg = pc.rec_text(b, i)
+        if i % 4 == 0:
+            cg = "cg:Z:70I3D" + cg[5:] + "120D4I2S"
+        ts, qs = int(rng.integers(0, 10 ** 6)), int(rng.integers(0, 10 ** 6))
+        neg = bool(b["strand_neg"][i])
+        name_t, name_q = ("t,%d" % i if i == 3 else "t%d" % (i % 2)), "q%d" % (i % 3)
+        lines.append("%s\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t0\t0\t60\t%s" % (name_q, 10 ** 9, qs, qs + 5, "-" if neg else "+", name_t,
+                                                                       10 ** 9, ts, ts + 5, cg))
+        recs.append((cg, ts, qs, neg, name_t, name_q))
+    paf = tmp_path / "in.paf"
+    paf.write_text("\n".join(lines) + "\n")
+    for args, cutoff in ((["-l", "0"], 0), ([], 50), (["--length", "7"], 7)):
+        want = "ref_start,ref_end,query_start,query_end,cigar,ref_chro,query_chro\n" + "".join(
+            _seg_csv(orc.cigar_to_base_plotdata(cg, ts, qs, neg, cutoff), '"%s"' % nt if "," in nt else nt, nq)
+            for cg, ts, qs, neg, nt, nq in recs)
+        rc, out, err = run(cli, "dotplot", "-f", "paf", "--out-format", "csv", str(paf), *args)
+        assert rc == 0, err
+        assert out.decode() == want
+    # MAF rows: K3 runs -> ops -> the same walk; strand-aware query start (maf.rs:433-442)
+    blocks = _synth_maf_blocks(33, 10, 1200)
+    maf = str(tmp_path / "in.maf")
+    _write_maf(maf, blocks)
+    want = "ref_start,ref_end,query_start,query_end,cigar,ref_chro,query_chro\n" + "".join(
+        _seg_csv(orc.maf_to_base_plotdata(k["t"], k["q"], k["t_start"], k["q_size"] - k["q_start"] - k["q_align"] if k["neg"]
+                                          else k["q_start"], k["neg"], 5), k["t_name"], k["q_name"]) for k in blocks)
+    rc, out, err = run(cli, "dp", maf, "--out-format", "csv", "-l", "5", "-m", "base-level")
+    assert rc == 0, err
+    assert out.decode() == want
+    # errors leave the output empty; html needs the reference's template
+    paf.write_text("\n".join(lines[:5] + [lines[5].rsplit("\t", 1)[0] + "\tcg:Z:10=3"] + lines[6:]) + "\n")
+    rc, out, err = run(cli, "dotplot", "-f", "paf", "--out-format", "csv", str(paf))
+    assert rc == 1 and out == b"" and "CIGAR OP `` invalid" in err
+    rc, out, err = run(cli, "dotplot", "-f", "paf", str(paf))
+    assert rc == 1 and "not provided by this engine" in err
+
+
+def test_dotplot_overview_csv(cli, tmp_path):
+    """overview mode (dotplot.rs:384-423): record extents, query pair swapped for '-', identity = matched / target span"""
+    blocks = _synth_maf_blocks(34, 8, 700)
+    maf = str(tmp_path / "in.maf")
+    _write_maf(maf, blocks)
+    rows = []
+    for k in blocks:
+        counts, _ = orc.parse_maf_seq_to_cigar(k["t"], k["q"], k["neg"])
+        qs = k["q_size"] - k["q_start"] - k["q_align"] if k["neg"] else k["q_start"]
+        qe = k["q_size"] - k["q_start"] if k["neg"] else k["q_start"] + k["q_align"]
+        if k["neg"]:
+            qs, qe = qe, qs
+        rows.append("%d,%d,%d,%d,%s,%s,%s\n" % (k["t_start"], k["t_start"] + k["t_align"], qs, qe, repr(counts[0] / k["t_align"]),
+                                               k["t_name"], k["q_name"]))
+    head = "ref_start,ref_end,query_start,query_end,identity,ref_chro,query_chro\n"
+    rc, out, err = run(cli, "dotplot", maf, "--out-format", "csv", "-m", "overview")
+    assert rc == 0, err
+    assert out.decode() == head + "".join(rows)
+    rc, out, err = run(cli, "dotplot", maf, "--out-format", "csv", "-m", "overview", "-d")
+    assert rc == 0 and out.decode() == head + "".join(r.rsplit(",", 3)[0] + ",1.0," + ",".join(r.rsplit(",", 2)[1:]) for r in rows), err
+    # PAF: matched counts M and = (cigar.rs:629-707); an op outside M = X I D fails get_stat unless -d
+    paf = tmp_path / "in.paf"
+    paf.write_text("q\t1000\t10\t60\t-\tt\t2000\t100\t150\t0\t0\t60\tcg:Z:20=5X10M3I15=2D\n"
+                   "q\t1000\t0\t8\t+\tt\t2000\t7\t7\t0\t0\t60\tcg:Z:8I\n")
+    rc, out, err = run(cli, "dotplot", "-f", "paf", str(paf), "--out-format", "csv", "-m", "overview")
+    assert rc == 0, err
+    assert out.decode() == head + "100,150,60,10,0.9,t,q\n7,7,0,8,NaN,t,q\n"
+    paf.write_text("q\t1000\t10\t60\t-\tt\t2000\t100\t150\t0\t0\t60\tcg:Z:20=5N\n")
+    rc, out, err = run(cli, "dotplot", "-f", "paf", str(paf), "--out-format", "csv", "-m", "overview")
+    assert rc == 1 and out == b"" and "CIGAR OP `N` invalid" in err
+    rc, out, err = run(cli, "dotplot", "-f", "paf", str(paf), "--out-format", "csv", "-m", "overview", "-d")
+    assert rc == 0 and out.decode() == head + "100,150,60,10,1.0,t,q\n"
+
+
+def test_format_f64_matches_ryu_layout(cli):
+    """ryu pretty::format64: plain decimals for 1e-5 <= |x| < 1e16, exponent form outside [unpinned: ryu 1.0.14]"""
+    import struct
+    cases = [(1.0, "1.0"), (0.1, "0.1"), (1e-5, "0.00001"), (1e-6, "1e-6"), (1.5e-7, "1.5e-7"), (1e16, "1e16"),
+             (1e15, "1000000000000000.0"), (1234567890123456.0, "1234567890123456.0"), (0.3333333333333333, "0.3333333333333333"),
+             (123456.789, "123456.789"), (-2.5, "-2.5"), (float("nan"), "NaN"), (float("inf"), "inf"), (1.2345e22, "1.2345e22")]
+    args = ["%016x" % struct.unpack("<Q", struct.pack("<d", v))[0] for v, _ in cases]
+    rc, out, err = run(cli, "__fmt_f64", *args)
+    assert rc == 0 and out.decode().split() == [w for _, w in cases]

@@ -728,3 +728,80 @@ def fast_expected_rows(ops, t_seq, q_seq, neg):
     t_row = np.where(is_i[op_of_col], ord("-"), t[ti] if len(t) else ord("-")).astype(np.uint8)
     q_row = np.where(is_d[op_of_col], ord("-"), q[qi] if len(q) else ord("-")).astype(np.uint8)
     return t_row.tobytes(), q_row.tobytes()
+
+
+# ------------------------------------------------------------------------------------------------
+# K12 dotplot base-level segments
+# ------------------------------------------------------------------------------------------------
+def check_dotplot(eng, ops, op_off, strands, cutoff, seed=3):
+    """per record: the segment list of parse_cigar_to_base_plotdata (cigar.rs:917-952)"""
+    n = len(op_off) - 1
+    rng = np.random.default_rng(seed)
+    ts = rng.integers(0, 10 ** 9, n).astype(np.uint64)
+    qs = rng.integers(0, 10 ** 9, n).astype(np.uint64)
+    batch = eng.make_batch(ops, op_off, np.asarray(strands, dtype=np.uint8))
+    d_ts, d_qs = eng.upload(ts), eng.upload(qs)
+    cnt = eng.cigar_dotplot(batch, cutoff, d_ts, d_qs)
+    off = eng.exclusive_scan_u64(n, cnt)
+    oo, cc = off.numpy(), cnt.numpy()
+    segs = eng.empty((int(oo[-1]) + 1) * 5, np.uint64).fill(0x2323232323232323)
+    eng.cigar_dotplot(batch, cutoff, d_ts, d_qs, segs=segs, seg_off=off)
+    sg = segs.numpy().reshape(-1, 5)
+    def text_merged(sl):
+        toks = []
+        for w in sl.tolist():
+            c, ln = w & 15, w >> 4
+            if c in (9, 10) and toks:
+                toks[-1][0] += ln
+            else:
+                toks.append([ln, synth.OP_CHARS[c] if c < 9 else "B"])
+        return "".join("%d%s" % (ln, ch) for ln, ch in toks)
+    for i in range(n):
+        sl = ops[int(op_off[i]):int(op_off[i + 1])]
+        if len(sl) == 0:
+            assert int(cc[i]) == 0
+            continue
+        want = orc.cigar_to_base_plotdata("cg:Z:" + text_merged(sl), int(ts[i]), int(qs[i]), strands[i], cutoff)
+        got = sg[int(oo[i]):int(oo[i + 1])]
+        assert int(cc[i]) == len(want), (i, int(cc[i]), len(want))
+        assert (got == want).all(), (i, got[:4], want[:4])
+    assert (sg[int(oo[-1]):] == 0x2323232323232323).all()
+
+
+def check_dotplot_maf(eng, pairs, strands, cutoff):
+    """MAF rows -> K3 runs -> ops (K11) -> segments == parse_maf_to_base_plotdata (cigar.rs:955-985)"""
+    n = len(pairs)
+    buf, t_off, q_off, cols = bytearray(b"@@@"), [], [], []
+    for t, q in pairs:
+        t_off.append(len(buf))
+        buf += t + b"@"
+        q_off.append(len(buf))
+        buf += q + b"@@"
+        cols.append(min(len(t), len(q)))
+    rows = eng.upload(np.frombuffer(bytes(buf), dtype=np.uint8))
+    d_t, d_q = eng.upload(np.array(t_off, dtype=np.uint64)), eng.upload(np.array(q_off, dtype=np.uint64))
+    d_c, d_s = eng.upload(np.array(cols, dtype=np.uint64)), eng.upload(np.array(strands, dtype=np.uint8))
+    counts, run_cnt = eng.maf_pair_stat(n, rows, d_t, d_q, d_c, d_s)
+    run_off = eng.exclusive_scan_u64(n, run_cnt)
+    ne = int(run_off.numpy()[-1])
+    runs = eng.empty(ne + 1, np.uint64).fill(0)
+    eng.maf_pair_stat(n, rows, d_t, d_q, d_c, d_s, counts=counts, run_cnt=run_cnt, runs=runs, run_off=run_off)
+    ocnt = eng.maf_runs_ops(n, ne, runs, run_off, d_c)
+    ooff = eng.exclusive_scan_u64(n, ocnt)
+    nops = int(ooff.numpy()[-1])
+    ops = eng.empty(nops + 4, np.uint32).fill(0)
+    eng.maf_runs_ops(n, ne, runs, run_off, d_c, out=ops, out_off=ooff)
+    batch = eng.make_batch_device(ops, ooff, d_s, n, nops)
+    ts = np.arange(n, dtype=np.uint64) * np.uint64(1000) + np.uint64(7)
+    qs = np.arange(n, dtype=np.uint64) * np.uint64(3000) + np.uint64(11)
+    d_ts, d_qs = eng.upload(ts), eng.upload(qs)
+    cnt = eng.cigar_dotplot(batch, cutoff, d_ts, d_qs)
+    off = eng.exclusive_scan_u64(n, cnt)
+    oo = off.numpy()
+    segs = eng.empty((int(oo[-1]) + 1) * 5, np.uint64).fill(0)
+    eng.cigar_dotplot(batch, cutoff, d_ts, d_qs, segs=segs, seg_off=off)
+    sg = segs.numpy().reshape(-1, 5)
+    for i, (t, q) in enumerate(pairs):
+        want = orc.maf_to_base_plotdata(t, q, int(ts[i]), int(qs[i]), strands[i], cutoff)
+        got = sg[int(oo[i]):int(oo[i + 1])]
+        assert len(got) == len(want) and (got == want).all(), (i, got[:4], want[:4])

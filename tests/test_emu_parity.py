@@ -321,3 +321,31 @@ def test_chain_lines(emu):
         strands2.append(k & 1)
     pc.check_chain_lines(emu, recs2, strands2, seqs=seqs)
 
+
+def test_dotplot_segments(emu):
+    b = synth.make_paf_batch(91, 14, 700, 500000)
+    pc.sprinkle_ops(np.random.default_rng(2), b, frac=0.03)
+    for cutoff in (0, 3, 50, 10 ** 6):
+        pc.check_dotplot(emu, b["ops"], b["op_off"], b["strand_neg"], cutoff)
+    L = (1 << 28) - 1
+    mk = lambda *p: [(ln << 4) | c for c, ln in p]
+    recs = [mk((1, 9), (2, 3), (7, 5), (1, 2), (7, 3), (8, 1), (2, 40), (1, 2), (2, 1)),    # leading indels, small + long
+            mk((7, 9)), mk((1, 40)), mk((2, 4), (1, 1)), mk((0, 0), (1, 30), (0, 0), (2, 0), (7, 5)),   # zero lengths
+            mk((7, 5), (1, 3), (3, 9), (4, 2), (7, 1), (11, 6), (2, 99), (5, 1)),              # ignored ops keep the segment open
+            mk((7, 5), (1, L), (9, L), (9, 12), (7, 2), (2, L), (10, 5), (7, 1)),              # split I / D: serial walk
+            mk(*([(7, 1), (1, 30), (2, 1)] * 300 + [(7, 2)])), mk(*([(1, 1)] * 260 + [(7, 1)] + [(2, 20)] * 270)),  # > 256 ops
+            mk(*([(7, 3), (1, 2)] * 129)), []]
+    ops = np.array([o for r in recs for o in r], dtype=np.uint32)
+    off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+    strands = [k & 1 for k in range(len(recs))]
+    for cutoff in (0, 10, 2 * L):
+        pc.check_dotplot(emu, ops, off, strands, cutoff)
+    rng = np.random.default_rng(12)
+    pairs, st = [], []
+    for L2 in (0, 1, 17, 64, 300, 1025, 2100):
+        pairs.append((pc.rand_seq(rng, L2, b"ACGTacgt--N"), pc.rand_seq(rng, L2 + int(rng.integers(0, 3)), b"ACGTacgt--N")))
+        st.append(L2 & 1)
+    for cutoff in (0, 1, 5):
+        pc.check_dotplot_maf(emu, pairs, st, cutoff)
+
+

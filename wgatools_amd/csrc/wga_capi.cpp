@@ -553,6 +553,29 @@ int wga_chain_lines_cigar_text(wga_ctx* c, uint32_t n, uint64_t n_elems, const u
   return run_elems(c, f, n, n_elems, d_line_off, d_cnt, d_out, d_out_off);
 }
 
+int wga_cigar_dotplot(wga_ctx* c, const wga_cigar_batch* b, uint64_t cutoff, const uint64_t* d_t_start,
+                      const uint64_t* d_q_start, uint64_t* d_seg_cnt, uint64_t* d_segs,
+                      const uint64_t* d_seg_off) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if ((rc = check_batch(b))) return rc;
+  if (b->n == 0) return WGA_OK;
+  if (!d_t_start || !d_q_start) return fail(WGA_E_INVALID_ARG, "start arrays null", nullptr);
+  if (!d_segs) {
+    if (!d_seg_cnt) return fail(WGA_E_INVALID_ARG, "d_seg_cnt null", nullptr);
+    WGA_LAUNCH(k_dotplot_segments<false>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
+               (const u64*)b->d_op_off, b->d_strand_neg, (u64)cutoff, (const u64*)d_t_start,
+               (const u64*)d_q_start, (u64*)d_seg_cnt, (u64*)nullptr, (const u64*)nullptr);
+  } else {
+    if (!d_seg_off) return fail(WGA_E_INVALID_ARG, "d_seg_off null", nullptr);
+    WGA_LAUNCH(k_dotplot_segments<true>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
+               (const u64*)b->d_op_off, b->d_strand_neg, (u64)cutoff, (const u64*)d_t_start,
+               (const u64*)d_q_start, (u64*)nullptr, (u64*)d_segs, (const u64*)d_seg_off);
+  }
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
 int wga_paf_call_events(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, int snp,
                         uint64_t* d_ev_cnt, uint64_t* d_ev, const uint64_t* d_ev_off) {
   int rc = ctx_bind(c);

@@ -1764,4 +1764,177 @@ __global__ __launch_bounds__(256) void k_elem_fill(F f, u32 n, u32 ne, const u64
   f.write((u64)x, r, out + out_off[r] + (esc[x] - esc[elem_off[r]]));
 }
 
+/* ============================================================================================ */
+/* K12: dotplot base-level segments (emit_baseplotdatas, cigar.rs:815-914) */
+/* ============================================================================================ */
+/* The reference folds the ops with a `last_m` flag: an I / D longer than the cutoff is a segment
+ * of its own and closes the open M segment; an M-like op opens an M segment unless one is open;
+ * every other M / small I / small D moves the end of the open segment to the running offsets
+ * (small indels with no open segment only advance the offsets; ops outside M = X I D are
+ * ignored).  Read as intervals between "breaks" (long indels): an interval holds one M segment
+ * iff it has an M-like op; it starts at the offsets of the first such op and ends at the offsets
+ * at the end of the interval.  So the opener writes the start fields and the closer — the next
+ * break, or the end of the record — writes the end fields, and nothing is serial.
+ * One wave per record, 256 ops per step.  Segment = 5 u64: ref_start, ref_end, query_start,
+ * query_end (the two swapped for '-' records, cigar.rs:807-812), kind 0 M / 1 I / 2 D.
+ * A record with a split (>= 2^28) I / D goes through the serial walk: its pieces count as one op. */
+#define WGA_SEG_WORDS 5u
+__device__ __forceinline__ void seg_write(u64* s, u64 rs, u64 re, u64 qs, u64 qe, u64 kind, bool neg) {
+  s[0] = rs;
+  s[1] = re;
+  s[2] = neg ? qe : qs;
+  s[3] = neg ? qs : qe;
+  s[4] = kind;
+}
+__device__ __forceinline__ u64 dotplot_serial(const u32* rec, u64 nops, u64 cutoff, u64 r, u64 q, bool neg,
+                                              u64* segs) {
+  u64 ns = 0;
+  bool last_m = false;
+  for (u64 k = 0; k < nops;) {
+    const u32 code = rec[k] & 15u;
+    u64 len = rec[k] >> 4;
+    u64 k2 = k + 1;
+    if (code == WGA_OP_I || code == WGA_OP_D) /* pieces of one split length */
+      while (k2 < nops && (rec[k2] & 15u) == (code == WGA_OP_I ? (u32)WGA_OP_I_CONT : (u32)WGA_OP_D_CONT)) len += rec[k2++] >> 4;
+    const bool isi = code == WGA_OP_I || code == WGA_OP_I_CONT, isd = code == WGA_OP_D || code == WGA_OP_D_CONT;
+    if (code == WGA_OP_M || code == WGA_OP_EQ || code == WGA_OP_X) {
+      if (!last_m) {
+        if (segs) seg_write(segs + ns * WGA_SEG_WORDS, r, r + len, q, q + len, 0, neg);
+        ns++;
+      } else if (segs) {
+        u64* s = segs + (ns - 1) * WGA_SEG_WORDS;
+        s[1] = r + len;
+        s[neg ? 2 : 3] = q + len;
+      }
+      r += len;
+      q += len;
+      last_m = true;
+    } else if (isi || isd) {
+      const u64 re = isd ? r + len : r, qe = isi ? q + len : q;
+      if (len > cutoff) {
+        if (segs) seg_write(segs + ns * WGA_SEG_WORDS, r, re, q, qe, isi ? 1 : 2, neg);
+        ns++;
+        last_m = false;
+      } else if (last_m && segs) {
+        u64* s = segs + (ns - 1) * WGA_SEG_WORDS;
+        if (isd) s[1] = re; else s[neg ? 2 : 3] = qe;
+      }
+      r = re;
+      q = qe;
+    }
+    k = k2;
+  }
+  return ns;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_dotplot_segments(u32 n, const u32* __restrict__ ops,
+                                                          const u64* __restrict__ op_off,
+                                                          const u8* __restrict__ strand_neg, u64 cutoff,
+                                                          const u64* __restrict__ t_start,
+                                                          const u64* __restrict__ q_start, u64* seg_cnt,
+                                                          u64* segs, const u64* seg_off) {
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const u64 i = (u64)blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
+  const u32* rec = ops + o0;
+  const bool neg = strand_neg[i] != 0;
+  u64* const out = FILL ? segs + seg_off[i] * WGA_SEG_WORDS : (u64*)0;
+  u64 r_base = t_start[i], q_base = q_start[i], nseg = 0;
+  u32 carry_state = 0; /* 0 / 1: no open M segment (start, or a break was the last event), 2: open */
+  bool weird = false;
+  for (u64 k0 = 0; k0 < nops; k0 += 256) {
+    const u64 kb = k0 + (u64)lane * 4u;
+    u32 len[4], radv[4], qadv[4];
+    bool ml[4], brk[4], isi[4];
+    bool cont = false;
+    u32 sr = 0, sq = 0, last_ev = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const bool in = kb + (u64)e < nops;
+      const u32 w = in ? rec[kb + e] : 0xFu;
+      const u32 code = w & 15u;
+      len[e] = w >> 4;
+      ml[e] = code == WGA_OP_M || code == WGA_OP_EQ || code == WGA_OP_X;
+      isi[e] = code == WGA_OP_I;
+      const bool isd = code == WGA_OP_D;
+      cont |= code == WGA_OP_I_CONT || code == WGA_OP_D_CONT;
+      brk[e] = (isi[e] || isd) && (u64)len[e] > cutoff;
+      radv[e] = (ml[e] || isd) ? len[e] : 0u;
+      qadv[e] = (ml[e] || isi[e]) ? len[e] : 0u;
+      sr += radv[e];
+      sq += qadv[e];
+      last_ev = ml[e] ? 2u : brk[e] ? 1u : last_ev;
+    }
+    if (__ballot(cont)) { /* wave-uniform */
+      weird = true;
+      break;
+    }
+    /* offsets in front of this lane's ops: exact wave scans of the lane sums (< 2^30) on 16-bit halves */
+    const u32 rl = wave_incl_scan_u32(sr & 0xFFFFu), rh = wave_incl_scan_u32(sr >> 16);
+    const u32 ql = wave_incl_scan_u32(sq & 0xFFFFu), qh = wave_incl_scan_u32(sq >> 16);
+    u64 r = r_base + (((u64)rh << 16) + (u64)rl) - (u64)sr;
+    u64 q = q_base + (((u64)qh << 16) + (u64)ql) - (u64)sq;
+    /* open / closed in front of this lane = the last event of the nearest earlier lane that has one */
+    const u64 evm = __ballot(last_ev != 0u) & ((1ull << lane) - 1ull);
+    const int src = evm ? 63 - (int)__builtin_clzll(evm) : 0;
+    const u32 got = (u32)__shfl((int)last_ev, src);
+    u32 state = evm ? got : carry_state;
+    /* segments this lane raises, then their ranks */
+    u32 st = state, cnt = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      cnt += (brk[e] || (ml[e] && st != 2u)) ? 1u : 0u;
+      st = ml[e] ? 2u : brk[e] ? 1u : st;
+    }
+    const u32 cinc = wave_incl_scan_u32(cnt);
+    if (FILL) {
+      u64 idx = nseg + (u64)(cinc - cnt);
+      st = state;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        if (brk[e]) {
+          if (st == 2u) { /* closes the open M segment */
+            u64* s = out + (idx - 1) * WGA_SEG_WORDS;
+            s[1] = r;
+            s[neg ? 2 : 3] = q;
+          }
+          seg_write(out + idx * WGA_SEG_WORDS, r, r + radv[e], q, q + qadv[e], isi[e] ? 1 : 2, neg);
+          idx++;
+        } else if (ml[e] && st != 2u) { /* opens one: the end fields come from its closer */
+          u64* s = out + idx * WGA_SEG_WORDS;
+          s[0] = r;
+          s[neg ? 3 : 2] = q;
+          s[4] = 0;
+          idx++;
+        }
+        st = ml[e] ? 2u : brk[e] ? 1u : st;
+        r += radv[e];
+        q += qadv[e];
+      }
+    }
+    nseg += (u64)wave_last_u32(cinc);
+    r_base += ((u64)wave_last_u32(rh) << 16) + (u64)wave_last_u32(rl);
+    q_base += ((u64)wave_last_u32(qh) << 16) + (u64)wave_last_u32(ql);
+    const u64 all_ev = __ballot(last_ev != 0u);
+    if (all_ev) carry_state = (u32)__shfl((int)last_ev, 63 - (int)__builtin_clzll(all_ev));
+  }
+  if (weird) { /* wave-uniform */
+    if (lane == 0) {
+      const u64 ns = dotplot_serial(rec, nops, cutoff, t_start[i], q_start[i], neg, out);
+      if (!FILL) seg_cnt[i] = ns;
+    }
+    return;
+  }
+  if (lane == 0) {
+    if (FILL && carry_state == 2u) { /* the end of the record closes the open M segment */
+      u64* s = out + (nseg - 1) * WGA_SEG_WORDS;
+      s[1] = r_base;
+      s[neg ? 2 : 3] = q_base;
+    }
+    if (!FILL) seg_cnt[i] = nseg;
+  }
+}
+
 #endif /* WGA_KERNELS2_H */

@@ -278,6 +278,13 @@ class Engine:
                                                         _p(cnt), _p(out), _p(out_off)))
         return cnt
 
+    def cigar_dotplot(self, batch, cutoff, t_start, q_start, seg_cnt=None, segs=None, seg_off=None):
+        """dotplot base-level segments (5 u64 each): count pass when segs is None"""
+        seg_cnt = seg_cnt if seg_cnt is not None or segs is not None else self.empty(batch.n, np.uint64)
+        self._check(self.lib.wga_cigar_dotplot(self.ctx, C.byref(batch.c), int(cutoff), _p(t_start), _p(q_start),
+                                               _p(seg_cnt), _p(segs), _p(seg_off)))
+        return seg_cnt
+
     def paf_call_events(self, batch, svlen, snp, ev_cnt=None, ev=None, ev_off=None):
         ev_cnt = ev_cnt if ev_cnt is not None else self.empty(batch.n, np.uint64)
         self._check(self.lib.wga_paf_call_events(self.ctx, C.byref(batch.c), int(svlen), int(bool(snp)),

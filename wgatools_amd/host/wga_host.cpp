@@ -162,6 +162,54 @@ std::string format_f32(float f) {
   return out;
 }
 
+/* ryu::Buffer::format(f64) -> pretty::format64: as format32 with the bounds 16 and -5 */
+std::string format_f64(double f) {
+  if (std::isnan(f)) return "NaN";
+  if (std::isinf(f)) return f < 0 ? "-inf" : "inf";
+  if (f == 0.0) return std::signbit(f) ? "-0.0" : "0.0";
+  char b[64];
+  auto r = std::to_chars(b, b + sizeof b, f, std::chars_format::scientific);
+  std::string sci(b, r.ptr);
+  std::string out;
+  size_t p = 0;
+  if (sci[0] == '-') {
+    out.push_back('-');
+    p = 1;
+  }
+  size_t epos = sci.find('e', p);
+  std::string digits;
+  for (size_t i = p; i < epos; i++)
+    if (sci[i] != '.') digits.push_back(sci[i]);
+  int exp10 = atoi(sci.c_str() + epos + 1);
+  int len = (int)digits.size();
+  int k = exp10 - (len - 1);
+  int kk = len + k;
+  if (0 <= k && kk <= 16) {
+    out += digits;
+    out.append((size_t)k, '0');
+    out += ".0";
+  } else if (0 < kk && kk <= 16) {
+    out.append(digits, 0, (size_t)kk);
+    out.push_back('.');
+    out.append(digits, (size_t)kk, std::string::npos);
+  } else if (-5 < kk && kk <= 0) {
+    out += "0.";
+    out.append((size_t)(-kk), '0');
+    out += digits;
+  } else if (len == 1) {
+    out += digits;
+    out.push_back('e');
+    out += std::to_string(kk - 1);
+  } else {
+    out.push_back(digits[0]);
+    out.push_back('.');
+    out.append(digits, 1, std::string::npos);
+    out.push_back('e');
+    out += std::to_string(kk - 1);
+  }
+  return out;
+}
+
 void append_csv_field(std::string& s, const std::string& f, char delim) {
   bool need = false;
   for (char c : f)

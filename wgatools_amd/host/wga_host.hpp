@@ -120,6 +120,7 @@ struct Faidx {
 void append_u64(std::string& s, uint64_t v);
 /* ryu::Buffer::format(f32) as used by csv's serializer */
 std::string format_f32(float f);
+std::string format_f64(double f);
 /* csv writer, QuoteStyle::Necessary */
 void append_csv_field(std::string& s, const std::string& f, char delim);
 /* natord::compare (natural order, digit runs numeric) */

@@ -1045,6 +1045,170 @@ int cmd_maf2chain(const std::string* input, const std::string* query_name, Outpu
   return 0;
 }
 
+/* ---- dotplot --out-format csv (tools/dotplot.rs) -----------------------------------
+ * base-level: segments from wga_cigar_dotplot (PAF: device tokeniser; MAF: K3 runs -> wga_maf_runs_ops);
+ * overview: one row per record, identity = matched / target_align_size from K1 / K3.  All data is generated
+ * before anything is written (:208-262), so an error leaves the output empty.  The html / json outputs embed
+ * the reference's Vega-Lite document and are not provided. */
+int cmd_dotplot(const std::string* input, const std::string& format, const std::string& out_format,
+                const std::string& mode, bool no_identity, uint64_t cutoff, const std::string* query_name, Output& out) {
+  if (mode != "base-level" && mode != "overview") fail("invalid value '" + mode + "' for '--mode <MODE>'");
+  if (out_format != "csv") {
+    if (out_format == "html" || out_format == "json")
+      fail("out-format `" + out_format + "` embeds the reference's Vega-Lite document and is not provided by this engine (use --out-format csv)");
+    fail("invalid value '" + out_format + "' for '--out-format <OUT_FORMAT>'");
+  }
+  if (format != "maf" && format != "paf") fail("Only support MAF and PAF format");
+  const bool base = mode == "base-level";
+  std::string text;
+  std::vector<std::string> t_names, q_names;
+  std::vector<uint64_t> ts, te, qs, qe;
+  std::vector<uint8_t> negs;
+  Dev d;
+  wga_cigar_batch cb;
+  cb.n = 0;
+  std::vector<wga_cigar_counts> counts;
+  std::vector<uint64_t> ali;
+  if (format == "paf") {
+    std::vector<PafRecord> recs = parse_paf(read_all(input));
+    const uint32_t n = (uint32_t)recs.size();
+    for (const PafRecord& r : recs) {
+      t_names.push_back(r.target_name);
+      q_names.push_back(r.query_name);
+      ts.push_back(r.target_start);
+      te.push_back(r.target_end);
+      qs.push_back(r.query_start);
+      qe.push_back(r.query_end);
+      negs.push_back(r.neg ? 1 : 0);
+      ali.push_back(r.target_end - r.target_start);
+    }
+    if (n && (base || !no_identity)) {
+      d.init();
+      std::vector<std::string> cigars;
+      std::string e = device_tokenise(d, recs.data(), n, cigars, &cb);
+      if (!base && cb.n) { /* get_stat (paf.rs:205-209): ops outside M = X I D are an error */
+        auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)cb.n * sizeof(wga_cigar_counts));
+        auto* d_diag = (wga_rec_diag*)d.alloc((size_t)cb.n * sizeof(wga_rec_diag));
+        d.check(wga_cigar_stat(d.ctx, &cb, d_counts, d_diag, nullptr));
+        counts.resize(cb.n);
+        std::vector<wga_rec_diag> diag(cb.n);
+        d.download(counts.data(), d_counts, cb.n);
+        d.download(diag.data(), d_diag, cb.n);
+        for (uint32_t k = 0; k < cb.n; k++)
+          if (diag[k].bad_op_idx != WGA_NONE) {
+            e = "CIGAR OP `" + cigar_op_token_at(cigars[k], diag[k].bad_op_idx) + "` invalid";
+            break;
+          }
+      }
+      if (!e.empty()) {
+        out.close();
+        fail(e);
+      }
+    }
+  } else {
+    std::string header;
+    std::vector<MafRecord> recs = parse_maf(read_all(input), &header);
+    select_query(recs, query_name);
+    const uint32_t n = (uint32_t)recs.size();
+    for (const MafRecord& r : recs) {
+      t_names.push_back(r.t().name);
+      q_names.push_back(r.q().name);
+      ts.push_back(r.t().start);
+      te.push_back(r.t().start + r.t().align_size);
+      qs.push_back(r.query_start());
+      qe.push_back(r.query_end());
+      negs.push_back(r.q().neg ? 1 : 0);
+      ali.push_back(r.t().align_size);
+    }
+    if (n && (base || !no_identity)) {
+      d.init();
+      MafPairs p = gather_pairs(recs);
+      auto* d_rows = d.upload((const uint8_t*)p.rows.data(), p.rows.size());
+      auto *d_t = d.upload(p.t_off), *d_q = d.upload(p.q_off), *d_c = d.upload(p.cols);
+      auto* d_s = d.upload(p.strand);
+      auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
+      auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
+      d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, nullptr, nullptr));
+      if (!base) {
+        counts.resize(n);
+        d.download(counts.data(), d_counts, n);
+      } else {
+        auto* d_roff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+        d.check(wga_exclusive_scan_u64(d.ctx, n, d_cnt, d_roff));
+        uint64_t n_runs = 0;
+        d.download(&n_runs, d_roff + n, 1);
+        auto* d_runs = (uint64_t*)d.alloc((n_runs + 1) * 8);
+        d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, d_runs, d_roff));
+        auto* d_ocnt = (uint64_t*)d.alloc((size_t)n * 8);
+        d.check(wga_maf_runs_ops(d.ctx, n, n_runs, d_runs, d_roff, d_c, d_ocnt, nullptr, nullptr));
+        auto* d_ooff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+        d.check(wga_exclusive_scan_u64(d.ctx, n, d_ocnt, d_ooff));
+        uint64_t n_ops = 0;
+        d.download(&n_ops, d_ooff + n, 1);
+        auto* d_ops = (uint32_t*)d.alloc((n_ops + 4) * 4);
+        d.check(wga_maf_runs_ops(d.ctx, n, n_runs, d_runs, d_roff, d_c, nullptr, d_ops, d_ooff));
+        cb.d_ops = d_ops;
+        cb.d_op_off = d_ooff;
+        cb.d_strand_neg = d_s;
+        cb.n_ops = n_ops;
+        cb.n = n;
+      }
+    }
+  }
+  const uint32_t n = (uint32_t)t_names.size();
+  if (base) {
+    if (n) {
+      auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
+      auto *d_ts = d.upload(ts), *d_qs = d.upload(qs);
+      d.check(wga_cigar_dotplot(d.ctx, &cb, cutoff, d_ts, d_qs, d_cnt, nullptr, nullptr));
+      auto* d_off = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+      d.check(wga_exclusive_scan_u64(d.ctx, n, d_cnt, d_off));
+      std::vector<uint64_t> off(n + 1);
+      d.download(off.data(), d_off, n + 1);
+      auto* d_segs = (uint64_t*)d.alloc((off[n] + 1) * 5 * 8);
+      d.check(wga_cigar_dotplot(d.ctx, &cb, cutoff, d_ts, d_qs, nullptr, d_segs, d_off));
+      std::vector<uint64_t> segs(off[n] * 5);
+      if (off[n]) d.download(segs.data(), d_segs, off[n] * 5);
+      if (off[n]) text = "ref_start,ref_end,query_start,query_end,cigar,ref_chro,query_chro\n";
+      for (uint32_t k = 0; k < n; k++) {
+        std::string names;
+        names.push_back(',');
+        append_csv_field(names, t_names[k], ',');
+        names.push_back(',');
+        append_csv_field(names, q_names[k], ',');
+        names.push_back('\n');
+        for (uint64_t x = off[k]; x < off[k + 1]; x++) {
+          const uint64_t* sg = &segs[5 * x];
+          for (int f = 0; f < 4; f++) {
+            append_u64(text, sg[f]);
+            text.push_back(',');
+          }
+          text.push_back("MID"[sg[4]]);
+          text += names;
+        }
+      }
+    }
+  } else {
+    if (n) text = "ref_start,ref_end,query_start,query_end,identity,ref_chro,query_chro\n";
+    for (uint32_t k = 0; k < n; k++) {
+      const uint64_t a[] = {ts[k], te[k], negs[k] ? qe[k] : qs[k], negs[k] ? qs[k] : qe[k]}; /* dotplot.rs:400-406 */
+      for (uint64_t v : a) {
+        append_u64(text, v);
+        text.push_back(',');
+      }
+      text += format_f64(no_identity ? 1.0 : (double)counts[k].match / (double)ali[k]);
+      text.push_back(',');
+      append_csv_field(text, t_names[k], ',');
+      text.push_back(',');
+      append_csv_field(text, q_names[k], ',');
+      text.push_back('\n');
+    }
+  }
+  out.write(text);
+  out.close();
+  return 0;
+}
+
 /* ---- pafcov (pafcov.rs:13-83) --------------------------------------------------------------------- */
 int cmd_pafcov(const std::string* input, Output& out) {
   std::vector<PafRecord> recs = parse_paf(read_all(input));
@@ -1794,6 +1958,7 @@ void usage() {
           "  paf2chain | p2c [PAF]\n"
           "  maf2chain | m2c [MAF] [-q QUERY_NAME]\n"
           "  chain2paf | c2p [CHAIN]\n"
+          "  dotplot | dp   [FILE] [-f maf|paf] --out-format csv [-m base-level|overview] [-d] [-l CUTOFF] [-q QUERY_NAME]\n"
           "  chain2maf | c2m [CHAIN] --target TARGET.fa --query QUERY.fa   (-g / -q)\n"
           "  call    | c    [MAF] [-s] [-i] [-l SVLEN] [-n SAMPLE] [--query-name N | --query-regex R] [-c CHUNK]\n"
           "  call    | c    -f paf [PAF] --target T.fa --query Q.fa [-s] [-l SVLEN] [-n SAMPLE]\n");
@@ -1846,6 +2011,15 @@ int main(int argc, char** argv) {
       }
       return 0;
     }
+    if (cmd == "__fmt_f64") {
+      for (const auto& a : rest) {
+        uint64_t bits = strtoull(a.c_str(), nullptr, 16);
+        double f;
+        memcpy(&f, &bits, 8);
+        printf("%s\n", format_f64(f).c_str());
+      }
+      return 0;
+    }
     if (cmd == "__natord") {
       for (size_t i = 0; i + 1 < rest.size(); i += 2) printf("%d\n", natord_compare(rest[i], rest[i + 1]));
       return 0;
@@ -1888,6 +2062,10 @@ int main(int argc, char** argv) {
     const bool pseudo = cmd == "pafpseudo" || cmd == "pp";
     const bool call = cmd == "call" || cmd == "c";
     const bool validate = cmd == "validate" || cmd == "vf";
+    const bool dotp = cmd == "dotplot" || cmd == "dp";
+    std::string out_format = "html", mode = "base-level";
+    bool no_identity = false, has_cutoff = false;
+    uint64_t cutoff = 50; /* utils.rs:709-710 */
     std::string fix_path;
     bool has_fix = false;
     for (size_t i = 0; i < rest.size(); i++) {
@@ -1912,6 +2090,17 @@ int main(int argc, char** argv) {
         has_fasta = true;
       } else if (a == "-f" || a == "--format")
         format = val();
+      else if (dotp && a == "--out-format")
+        out_format = val();
+      else if (dotp && (a == "-m" || a == "--mode"))
+        mode = val();
+      else if (dotp && (a == "-d" || a == "--no-identity"))
+        no_identity = true;
+      else if (dotp && (a == "-l" || a == "--length")) {
+        cutoff = strtoull(val().c_str(), nullptr, 10);
+        has_cutoff = true;
+      } else if (dotp && a == "--color")
+        (void)val(); /* colours only exist in the Vega-Lite outputs */
       else if (a == "-e" || a == "--each")
         each = true;
       else if (call && (a == "-s" || a == "--snp"))
@@ -1953,6 +2142,11 @@ int main(int argc, char** argv) {
     if (cmd == "paf2chain" || cmd == "p2c") {
       out.open(outfile, rewrite);
       return cmd_paf2chain(input, out);
+    }
+    if (dotp) {
+      (void)has_cutoff;
+      out.open(outfile, rewrite);
+      return cmd_dotplot(input, format, out_format, mode, no_identity, cutoff, qn, out);
     }
     if (cmd == "maf2chain" || cmd == "m2c") {
       out.open(outfile, rewrite);
