@@ -80,3 +80,36 @@ txt10 = torch.zeros(tot10 + 8, dtype=torch.uint8, device=dev)
 ms_f = timed(lambda: eng.cigar_chain(batch, out=txt10, out_off=off10))
 print("K10 paf2chain: count pass %.3f ms %.0f GB/s (4 B/op); fill pass %.3f ms %.0f GB/s (4 B/op + %.2f GB of text)" % (
     ms_c, 4 * n_ops / ms_c / 1e6, ms_f, (4 * n_ops + tot10) / ms_f / 1e6, tot10 / 1e9))
+# ---- K12 dotplot segments ----------------------------------------------------------------------------
+for cutoff in (50, 0):
+    cnt12 = torch.zeros(n, dtype=torch.int64, device=dev)
+    ms_c = timed(lambda: eng.cigar_dotplot(batch, cutoff, tb["t_src_off"], tb["q_src_off"], seg_cnt=cnt12))
+    off12 = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    eng.exclusive_scan_u64(n, cnt12, off12)
+    ns = int(off12[-1].item())
+    sg = torch.zeros(5 * ns + 5, dtype=torch.int64, device=dev)
+    ms_f = timed(lambda: eng.cigar_dotplot(batch, cutoff, tb["t_src_off"], tb["q_src_off"], segs=sg, seg_off=off12))
+    print("K12 dotplot cutoff=%d: count %.3f ms %.0f GB/s (4 B/op); fill %.3f ms %.0f GB/s (4 B/op + 40 B x %d segments)" % (
+        cutoff, ms_c, 4 * n_ops / ms_c / 1e6, ms_f, (4 * n_ops + 40 * ns) / ms_f / 1e6, ns))
+# ---- K11 bridges: chain data lines (one line per 3 ops of the batch) -> ops and CIGAR text --------------
+nl = min(n_ops // 3, 150_000_000)
+g = torch.Generator(device=dev); g.manual_seed(5)
+lines = torch.randint(0, 3000, (nl + 1, 3), dtype=torch.int64, device=dev, generator=g)
+loff11 = (torch.arange(n + 1, dtype=torch.int64, device=dev) * (nl // n)).contiguous()
+loff11[-1] = nl
+c11 = torch.zeros(n, dtype=torch.int64, device=dev)
+ms_c = timed(lambda: eng.chain_lines_ops(n, nl, lines, loff11, cnt=c11))
+o11 = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+eng.exclusive_scan_u64(n, c11, o11)
+no = int(o11[-1].item())
+ops11 = torch.zeros(no + 4, dtype=torch.int32, device=dev)
+ms_f = timed(lambda: eng.chain_lines_ops(n, nl, lines, loff11, out=ops11, out_off=o11))
+print("K11 chain lines -> ops : count %.3f ms, fill %.3f ms %.0f GB/s (24 B/line x %d lines + 4 B x %d ops)" % (
+    ms_c, ms_f, (24 * nl + 4 * no) / ms_f / 1e6, nl, no))
+ms_c = timed(lambda: eng.chain_lines_cigar_text(n, nl, lines, loff11, cnt=c11))
+eng.exclusive_scan_u64(n, c11, o11)
+nt = int(o11[-1].item())
+txt11 = torch.zeros(nt + 8, dtype=torch.uint8, device=dev)
+ms_f = timed(lambda: eng.chain_lines_cigar_text(n, nl, lines, loff11, out=txt11, out_off=o11))
+print("K11 chain lines -> text: count %.3f ms, fill %.3f ms %.0f GB/s (24 B/line + %.2f GB of text)" % (
+    ms_c, ms_f, (24 * nl + nt) / ms_f / 1e6, nt / 1e9))
