@@ -280,6 +280,34 @@ int wga_cigar_dotplot(wga_ctx*, const wga_cigar_batch*, uint64_t cutoff, const u
                       const uint64_t* d_q_start, uint64_t* d_seg_cnt, uint64_t* d_segs,
                       const uint64_t* d_seg_off);
 
+/* ---- K13: PAF field splitter (replaces the csv / serde record reader of
+ *      paf.rs:24-30,50-78 and the tag lookup of get_cigar_string :122-141 for plain files) ---------
+ * d_text = the PAF file as read (n_bytes < 4 GiB).  One wga_paf_line per text line, in order:
+ * status WGA_PAF_OK (a record: the 12 fixed fields parsed like u64::from_str / Strand::from_str,
+ * name spans and the span of the cg:Z: text as byte offsets into d_text — cg_beg == WGA_NONE when the
+ * record has no cg:Z: tag), WGA_PAF_SKIP (blank line or '#' comment, which the csv reader drops) or
+ * WGA_PAF_FALLBACK (a '"' or CR on the line, fewer than 12 fields, a field that does not parse, or
+ * a cs:Z: tag standing in for cg:Z:): if any line says FALLBACK the caller must read the file with a
+ * csv-semantics parser, which yields the same records or the reference's error text.
+ * Two calls: d_lines == NULL returns *n_lines (host value; the call synchronises); then
+ * d_lines[cap_lines >= *n_lines] is filled.  The cg spans feed wga_cigar_tokenise_spans, the
+ * tokeniser on texts that are not back to back (record i = d_text[d_beg[i], d_end[i])). */
+#define WGA_PAF_OK 0
+#define WGA_PAF_SKIP 1
+#define WGA_PAF_FALLBACK 2
+typedef struct {
+  uint64_t num[9]; /* query_length, query_start, query_end, target_length, target_start, target_end,
+                      matches, block_length, mapq (paf.rs:50-65) */
+  uint64_t qname_off, tname_off, cg_beg, cg_end;
+  uint32_t qname_len, tname_len, n_fields;
+  uint8_t strand_neg, status, pad[2];
+} wga_paf_line;
+int wga_paf_split(wga_ctx*, const uint8_t* d_text, uint64_t n_bytes, uint64_t* n_lines, wga_paf_line* d_lines,
+                  uint64_t cap_lines);
+int wga_cigar_tokenise_spans(wga_ctx*, uint32_t n, const uint8_t* d_text, const uint64_t* d_beg,
+                             const uint64_t* d_end, uint64_t* d_op_cnt, wga_tok_err* d_err, uint32_t* d_ops,
+                             const uint64_t* d_op_off);
+
 /* ---- K5: pafcov (replaces update_cov_vec, cigar.rs:710-741, and the per-thread array merge of
  *      pafcov.rs:29-53) ------------------------------------------------------------------------
  * Record i adds +1 to d_cov[cov_off[target_id[i]] + p] for every base p of its M / = ops that

@@ -790,3 +790,34 @@ def test_format_f64_matches_ryu_layout(cli):
     args = ["%016x" % struct.unpack("<Q", struct.pack("<d", v))[0] for v, _ in cases]
     rc, out, err = run(cli, "__fmt_f64", *args)
     assert rc == 0 and out.decode().split() == [w for _, w in cases]
+
+
+# ---- PAF input: device splitter for plain files, csv-semantics host reader otherwise ----
+def test_paf_reader_selection(cli, tmp_path):
+    b = synth.make_paf_batch(5, 30, 200, 100000)
+    mapq = np.arange(30)
+    _, _, paf = _write_paf2maf_case(tmp_path, b, mapq)
+    rc, out, err = run(cli, "__paf_reader", paf)
+    assert rc == 0, err
+    lines = out.decode().splitlines()
+    assert lines[0] == "device" and len(lines) == 31
+    text = open(paf).read()
+    # the same file with a quoted name, or CRLF line ends, needs the csv state machine: same records from the host reader
+    for variant in (text.replace("qchr\t", '"qchr"\t', 1), text.replace("\n", "\r\n")):
+        p2 = tmp_path / "v.paf"
+        with open(p2, "w", newline="") as f:
+            f.write(variant)
+        rc, out2, err = run(cli, "__paf_reader", str(p2))
+        assert rc == 0, err
+        l2 = out2.decode().splitlines()
+        assert l2[0] == "host" and l2[1:] == lines[1:]
+    # a malformed line: the host reader reports it the way the csv crate does
+    p3 = tmp_path / "bad.paf"
+    p3.write_text(text + "q\t1\t2\n")
+    rc, out3, err = run(cli, "stat", "-f", "paf", str(p3))
+    assert rc == 1 and "CSV deserialize error" in err and "invalid length 3" in err
+    # cs:Z: in place of cg:Z: is converted by the host reader (paf.rs:159-218)
+    p4 = tmp_path / "cs.paf"
+    p4.write_text("q\t100\t0\t10\t+\tt\t100\t0\t10\t10\t10\t60\tcs:Z::6*ag:3\n")
+    rc, out4, err = run(cli, "__paf_reader", str(p4))
+    assert rc == 0 and out4.decode().splitlines() == ["host", "q|100|0|10|+|t|100|0|10|10|10|60|cg:Z:6M1X3M"], (out4, err)

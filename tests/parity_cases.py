@@ -805,3 +805,95 @@ def check_dotplot_maf(eng, pairs, strands, cutoff):
         want = orc.maf_to_base_plotdata(t, q, int(ts[i]), int(qs[i]), strands[i], cutoff)
         got = sg[int(oo[i]):int(oo[i + 1])]
         assert len(got) == len(want) and (got == want).all(), (i, got[:4], want[:4])
+
+
+# ------------------------------------------------------------------------------------------------
+# K13 PAF field splitter (+ the tokeniser on spans)
+# ------------------------------------------------------------------------------------------------
+def expected_paf_lines(text):
+    """plain-Python restatement of what the csv reader + PafRecord deserialiser (paf.rs:24-30,50-78) do with a
+    line that needs no csv state machine; everything else is FALLBACK"""
+    def u64(b):
+        b2 = b[1:] if b[:1] == b"+" else b
+        if not b2 or not b2.isdigit() or not all(48 <= c <= 57 for c in b2) or int(b2) > 0xFFFFFFFFFFFFFFFF:
+            return None
+        return int(b2)
+    out, pos = [], 0
+    if not text:
+        return out
+    lines = text.split(b"\n")
+    if text.endswith(b"\n"):
+        lines.pop()
+    for ln in lines:
+        start = pos
+        pos += len(ln) + 1
+        if ln == b"" or ln[:1] == b"#":
+            out.append(dict(status=2 if b"\r" in ln else 1))
+            continue
+        if b'"' in ln or b"\r" in ln:
+            out.append(dict(status=2))
+            continue
+        f = ln.split(b"\t")
+        offs = np.cumsum([0] + [len(x) + 1 for x in f])[:-1] + start
+        nums = [u64(f[k]) if k < len(f) else None for k in (1, 2, 3, 6, 7, 8, 9, 10, 11)]
+        if len(f) < 12 or any(v is None for v in nums) or f[4] not in (b"+", b"-"):
+            out.append(dict(status=2))
+            continue
+        cg = next((k for k in range(12, len(f)) if f[k][:5] == b"cg:Z:"), None)
+        cs = any(x[:5] == b"cs:Z:" for x in f[12:])
+        if cg is None and cs:
+            out.append(dict(status=2))
+            continue
+        out.append(dict(status=0, num=nums, neg=f[4] == b"-", qname=(int(offs[0]), len(f[0])), tname=(int(offs[5]), len(f[5])),
+                        cg=None if cg is None else (int(offs[cg]) + 5, int(offs[cg]) + len(f[cg])), n_fields=len(f)))
+    return out
+
+
+def check_paf_split(eng, text):
+    text = bytes(text)
+    d_text = eng.upload(np.frombuffer(text + b"\0" * 16, dtype=np.uint8))
+    n = eng.paf_split(d_text, len(text))
+    want = expected_paf_lines(text)
+    assert n == len(want), (n, len(want))
+    if n == 0:
+        return
+    lines = eng.empty(n + 1, engine.PAF_LINE_DTYPE).fill(0xEE)
+    assert eng.paf_split(d_text, len(text), lines) == n
+    got = lines.numpy()
+    spans = []
+    for j, w in enumerate(want):
+        g = got[j]
+        assert int(g["status"]) == w["status"], (j, int(g["status"]), w)
+        if w["status"]:
+            continue
+        assert [int(x) for x in g["num"]] == w["num"], (j, g["num"], w["num"])
+        assert bool(g["strand_neg"]) == w["neg"] and int(g["n_fields"]) == w["n_fields"], j
+        assert (int(g["qname_off"]), int(g["qname_len"])) == w["qname"], j
+        assert (int(g["tname_off"]), int(g["tname_len"])) == w["tname"], j
+        if w["cg"] is None:
+            assert int(g["cg_beg"]) == NONE, j
+        else:
+            assert (int(g["cg_beg"]), int(g["cg_end"])) == w["cg"], (j, g["cg_beg"], g["cg_end"], w["cg"])
+            spans.append(w["cg"])
+    assert (got[n:n + 1].view(np.uint8) == 0xEE).all()
+    if spans:       # the span tokeniser == the CSR tokeniser on the extracted texts
+        m = len(spans)
+        beg = eng.upload(np.array([a for a, _ in spans], dtype=np.uint64))
+        end = eng.upload(np.array([b for _, b in spans], dtype=np.uint64))
+        cnt, err = eng.cigar_tokenise_spans(m, d_text, beg, end)
+        blob = b"".join(text[a:b] for a, b in spans)
+        toff = np.cumsum([0] + [b - a for a, b in spans]).astype(np.uint64)
+        d_blob = eng.upload(np.frombuffer(blob + b"0" * 64, dtype=np.uint8))
+        cnt2, err2 = eng.cigar_tokenise(m, d_blob, eng.upload(toff))
+        assert (cnt.numpy() == cnt2.numpy()).all() and (err.numpy() == err2.numpy()).all()
+        off = eng.exclusive_scan_u64(m, cnt)
+        tot = int(off.numpy()[-1])
+        o1 = eng.empty(tot + 4, np.uint32).fill(0)
+        o2 = eng.empty(tot + 4, np.uint32).fill(0)
+        eng.cigar_tokenise_spans(m, d_text, beg, end, op_cnt=cnt, err=err, ops=o1, op_off=off)
+        eng.cigar_tokenise(m, d_blob, eng.upload(toff), op_cnt=cnt2, err=err2, ops=o2, op_off=off)
+        ok = np.array([e == 0 for e in err.numpy()["err"]])
+        a1, a2, oo = o1.numpy(), o2.numpy(), off.numpy()
+        for k in range(m):
+            if ok[k]:
+                assert (a1[int(oo[k]):int(oo[k + 1])] == a2[int(oo[k]):int(oo[k + 1])]).all(), k

@@ -349,3 +349,39 @@ def test_dotplot_segments(emu):
         pc.check_dotplot_maf(emu, pairs, st, cutoff)
 
 
+def test_paf_split(emu):
+    rng = np.random.default_rng(3)
+    b = synth.make_paf_batch(23, 40, 600, 200000)
+    rows = []
+    for i in range(40):
+        cg = pc.rec_text(b, i)
+        tags = ["NM:i:%d" % i, "tp:A:P", cg, "zd:i:3"][: 2 + int(rng.integers(0, 3))]
+        if i % 7 == 3:
+            tags = ["cg:Z:5=", cg]                     # the first cg:Z: wins
+        if i % 11 == 5:
+            tags = ["NM:i:0"]                          # no CIGAR tag: not a parse error
+        rows.append("q%d\t%d\t%d\t%d\t%s\tchr%d\t%d\t%d\t%d\t%d\t%d\t%d\t%s" % (
+            i, 10 ** 9 + i, i, i + 5, "-+"[i & 1], i % 3, 18446744073709551615 if i == 2 else 2 * 10 ** 9, 7 * i, 7 * i + 9, i,
+            2 * i, 60, "\t".join(tags)))
+    clean = ("# header comment\n" + "\n".join(rows[:20]) + "\n\n# mid\tcomment \"x\"\n" + "\n".join(rows[20:])).encode()
+    pc.check_paf_split(emu, clean + b"\n")
+    pc.check_paf_split(emu, clean)                       # no newline at the end
+    pc.check_paf_split(emu, b"")
+    pc.check_paf_split(emu, b"\n\n")
+    odd = [b"q\t1\t2\t3\t+\tt\t4\t5\t6\t7\t8",                      # 11 fields
+           b"q\t1\t2\t3\t*\tt\t4\t5\t6\t7\t8\t9\tcg:Z:5=",          # strand
+           b"q\t1\t2x\t3\t+\tt\t4\t5\t6\t7\t8\t9\tcg:Z:5=",         # digit
+           b"q\t\t2\t3\t+\tt\t4\t5\t6\t7\t8\t9\tcg:Z:5=",           # empty integer
+           b"q\t18446744073709551616\t2\t3\t+\tt\t4\t5\t6\t7\t8\t9",    # overflow
+           b"q\t+1\t2\t3\t+\tt\t4\t5\t6\t7\t8\t9\tcs:Z::5",          # '+1' parses; cs instead of cg
+           b"\"q\"\t1\t2\t3\t+\tt\t4\t5\t6\t7\t8\t9\tcg:Z:5=",       # quoted field
+           b"q\t1\t2\t3\t+\tt\t4\t5\t6\t7\t8\t9\tcg:Z:5=\r",         # CRLF
+           b"q\t1\t2\t3\t+\tt\t4\t5\t6\t7\t8\t9\tcs:Z::5\tcg:Z:7=",   # both: cg wins
+           b"#c\rq\t1", b"q\t1\t2\t3\t-\tt\t4\t5\t6\t7\t8\t9"]
+    pc.check_paf_split(emu, b"\n".join(odd) + b"\n" + clean)
+    # delimiters right at the 16-byte / 4096-byte block edges
+    for pad in (4080, 4095, 4096, 4097, 8191):
+        pc.check_paf_split(emu, b"#" + b"x" * (pad - 1) + b"\n" + rows[0].encode() + b"\n" + b"\t" * 40 + b"\n")
+
+
+

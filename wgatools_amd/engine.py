@@ -17,6 +17,10 @@ CHAIN_TRIM_DTYPE = np.dtype([(k, "<u8") for k in ("head_ins", "head_del", "tail_
 TOK_ERR_DTYPE = np.dtype([("err", np.int32), ("tok_len", np.uint32), ("tok_off", np.uint64)])
 CLASS_SUMS_DTYPE = np.dtype([(k, "<u8") for k in ("mx", "i", "d", "s", "o")])
 NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
+PAF_LINE_DTYPE = np.dtype([("num", np.uint64, 9), ("qname_off", np.uint64), ("tname_off", np.uint64),
+                           ("cg_beg", np.uint64), ("cg_end", np.uint64), ("qname_len", np.uint32),
+                           ("tname_len", np.uint32), ("n_fields", np.uint32), ("strand_neg", np.uint8),
+                           ("status", np.uint8), ("pad", np.uint8, 2)])
 
 OP_CODES = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4, "H": 5, "P": 6, "=": 7, "X": 8}
 OP_I_CONT, OP_D_CONT, OP_OTHER = 9, 10, 11
@@ -284,6 +288,21 @@ class Engine:
         self._check(self.lib.wga_cigar_dotplot(self.ctx, C.byref(batch.c), int(cutoff), _p(t_start), _p(q_start),
                                                _p(seg_cnt), _p(segs), _p(seg_off)))
         return seg_cnt
+
+    def paf_split(self, text, n_bytes, lines=None):
+        """K13: number of text lines (lines is None), or the wga_paf_line of every line"""
+        nl = C.c_uint64(0)
+        cap = 0 if lines is None else (lines.numel() if hasattr(lines, "numel") else lines.size)
+        self._check(self.lib.wga_paf_split(self.ctx, _p(text), int(n_bytes), C.byref(nl), _p(lines), int(cap)))
+        return int(nl.value)
+
+    def cigar_tokenise_spans(self, n, text, beg, end, op_cnt=None, err=None, ops=None, op_off=None):
+        """device tokeniser on spans text[beg[i], end[i]) (e.g. the cg:Z: texts inside a PAF file)"""
+        op_cnt = op_cnt if op_cnt is not None else self.empty(n, np.uint64)
+        err = err if err is not None else self.empty(n, TOK_ERR_DTYPE)
+        self._check(self.lib.wga_cigar_tokenise_spans(self.ctx, n, _p(text), _p(beg), _p(end), _p(op_cnt), _p(err),
+                                                      _p(ops), _p(op_off)))
+        return op_cnt, err
 
     def paf_call_events(self, batch, svlen, snp, ev_cnt=None, ev=None, ev_off=None):
         ev_cnt = ev_cnt if ev_cnt is not None else self.empty(batch.n, np.uint64)

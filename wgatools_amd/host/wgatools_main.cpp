@@ -60,6 +60,13 @@ struct Dev {
     for (void* p : owned) wga_free(ctx, p);
     owned.clear();
   }
+  void release_to(size_t keep) { /* frees everything allocated after the first `keep` buffers */
+    check(wga_sync(ctx));
+    while (owned.size() > keep) {
+      wga_free(ctx, owned.back());
+      owned.pop_back();
+    }
+  }
   ~Dev() {
     if (ctx) {
       for (void* p : owned) wga_free(ctx, p);
@@ -112,46 +119,149 @@ wga_cigar_batch device_batch(Dev& d, const PackedBatch& b) {
   return cb;
 }
 
+/* the CIGAR text (after the tag) of record k of a batch, for error messages: owned strings, or spans
+ * of the input file when the records came from the device splitter */
+struct CigarTexts {
+  std::vector<std::string> owned;
+  const std::string* file = nullptr;
+  std::vector<uint64_t> beg, end;
+  void push_back(std::string s) { owned.push_back(std::move(s)); }
+  const std::string& back() const { return owned.back(); }
+  std::string operator[](size_t k) const { return file ? file->substr(beg[k], end[k] - beg[k]) : owned[k]; }
+};
+
+/* A PAF input: the records (paf.rs:50-65) and where their CIGARs are.  Plain files are split on the
+ * device (wga_paf_split: fixed fields, name spans, the cg:Z: span; tags are not materialised) and their
+ * CIGARs are tokenised where they lie in the uploaded text; a file with any line the splitter does not
+ * take (quotes, CR, short or malformed lines, cs:Z: only) goes through the csv-semantics host parser. */
+struct PafInput {
+  std::string text;
+  std::vector<PafRecord> recs;
+  bool on_device = false;
+  uint8_t* d_text = nullptr;
+  std::vector<uint64_t> cg_beg, cg_end; /* on_device: per record, cg_beg == WGA_NONE without a cg:Z: tag */
+  uint64_t cigar_bytes(size_t i) const {
+    if (on_device) return cg_beg[i] == WGA_NONE ? 0 : cg_end[i] - cg_beg[i];
+    uint64_t b = 0;
+    for (const auto& tg : recs[i].tags) b += tg.size();
+    return b;
+  }
+};
+PafInput load_paf(Dev& d, const std::string* input, bool want_tags) {
+  PafInput in;
+  in.text = read_all(input);
+  if (!want_tags && !in.text.empty() && in.text.size() < 0xFFFFFFF0ull) {
+    d.init();
+    in.text.append(16, '\0'); /* slack behind the text for whole-vector loads */
+    in.d_text = d.upload((const uint8_t*)in.text.data(), in.text.size());
+    in.text.resize(in.text.size() - 16);
+    uint64_t n_lines = 0;
+    d.check(wga_paf_split(d.ctx, in.d_text, in.text.size(), &n_lines, nullptr, 0));
+    auto* d_lines = (wga_paf_line*)d.alloc((size_t)(n_lines + 1) * sizeof(wga_paf_line));
+    d.check(wga_paf_split(d.ctx, in.d_text, in.text.size(), &n_lines, d_lines, n_lines));
+    std::vector<wga_paf_line> lines((size_t)n_lines);
+    if (n_lines) d.download(lines.data(), d_lines, (size_t)n_lines);
+    d.release(d_lines);
+    bool plain = true;
+    size_t n_rec = 0;
+    for (const wga_paf_line& L : lines) {
+      if (L.status == WGA_PAF_FALLBACK) plain = false;
+      if (L.status == WGA_PAF_OK) n_rec++;
+    }
+    if (plain) {
+      in.on_device = true;
+      in.recs.reserve(n_rec);
+      in.cg_beg.reserve(n_rec);
+      in.cg_end.reserve(n_rec);
+      for (const wga_paf_line& L : lines) {
+        if (L.status != WGA_PAF_OK) continue;
+        PafRecord r;
+        r.query_name.assign(in.text, (size_t)L.qname_off, L.qname_len);
+        r.target_name.assign(in.text, (size_t)L.tname_off, L.tname_len);
+        r.query_length = L.num[0];
+        r.query_start = L.num[1];
+        r.query_end = L.num[2];
+        r.target_length = L.num[3];
+        r.target_start = L.num[4];
+        r.target_end = L.num[5];
+        r.matches = L.num[6];
+        r.block_length = L.num[7];
+        r.mapq = L.num[8];
+        r.neg = L.strand_neg != 0;
+        in.recs.push_back(std::move(r));
+        in.cg_beg.push_back(L.cg_beg);
+        in.cg_end.push_back(L.cg_end);
+      }
+      return in;
+    }
+    d.release(in.d_text);
+    in.d_text = nullptr;
+  }
+  in.recs = parse_paf(in.text);
+  return in;
+}
+
 /* CIGAR texts of a run of records -> device batch through the device tokeniser (wga_cigar_tokenise):
  * the host only finds the tag; digits and op chars are parsed on the GPU.  Returns the reference's
  * message for the first failing record in input order ("" if none). */
-std::string device_tokenise(Dev& d, const PafRecord* recs, uint32_t n, std::vector<std::string>& cigars,
+std::string device_tokenise(Dev& d, const PafInput& in, size_t first, uint32_t n, CigarTexts& cigars,
                             wga_cigar_batch* cb) {
+  const PafRecord* recs = in.recs.data() + first;
   std::string blob, first_err;
   std::vector<uint64_t> toff{0};
   std::vector<uint8_t> strand;
   uint32_t n_ok = n;
   for (uint32_t k = 0; k < n; k++) {
-    int err = 0;
-    std::string cg = paf_cigar_string(recs[k], &err);
-    if (err) { /* errors.rs:57: only the records before it can fail earlier */
-      first_err = "CIGAR start tag not found";
-      n_ok = k;
-      break;
+    if (in.on_device) {
+      if (in.cg_beg[first + k] == WGA_NONE) { /* errors.rs:57: only the records before it can fail earlier */
+        first_err = "CIGAR start tag not found";
+        n_ok = k;
+        break;
+      }
+      cigars.beg.push_back(in.cg_beg[first + k]);
+      cigars.end.push_back(in.cg_end[first + k]);
+    } else {
+      int err = 0;
+      std::string cg = paf_cigar_string(recs[k], &err);
+      if (err) {
+        first_err = "CIGAR start tag not found";
+        n_ok = k;
+        break;
+      }
+      cigars.push_back(cg.substr(5));
+      blob += cigars.back();
+      toff.push_back(blob.size());
     }
-    cigars.push_back(cg.substr(5));
-    blob += cigars.back();
-    toff.push_back(blob.size());
     strand.push_back(recs[k].neg ? 1 : 0);
   }
+  if (in.on_device) cigars.file = &in.text;
   cb->n = n_ok;
   cb->n_ops = 0;
   cb->d_ops = nullptr;
   cb->d_op_off = nullptr;
   cb->d_strand_neg = nullptr;
   if (n_ok == 0) return first_err;
-  blob.append(64, '0'); /* slack behind the last text */
-  auto* d_text = d.upload((const uint8_t*)blob.data(), blob.size());
-  auto* d_toff = d.upload(toff);
+  const uint8_t* d_text;
+  const uint64_t *d_beg, *d_end;
+  if (in.on_device) {
+    d_text = in.d_text;
+    d_beg = d.upload(cigars.beg);
+    d_end = d.upload(cigars.end);
+  } else {
+    blob.append(64, '0'); /* slack behind the last text */
+    d_text = d.upload((const uint8_t*)blob.data(), blob.size());
+    d_beg = d.upload(toff);
+    d_end = d_beg + 1;
+  }
   auto* d_cnt = (uint64_t*)d.alloc((size_t)n_ok * 8);
   auto* d_err = (wga_tok_err*)d.alloc((size_t)n_ok * sizeof(wga_tok_err));
-  d.check(wga_cigar_tokenise(d.ctx, n_ok, d_text, d_toff, d_cnt, d_err, nullptr, nullptr));
+  d.check(wga_cigar_tokenise_spans(d.ctx, n_ok, d_text, d_beg, d_end, d_cnt, d_err, nullptr, nullptr));
   auto* d_ooff = (uint64_t*)d.alloc(((size_t)n_ok + 1) * 8);
   d.check(wga_exclusive_scan_u64(d.ctx, n_ok, d_cnt, d_ooff));
   uint64_t total = 0;
   d.download(&total, d_ooff + n_ok, 1);
   auto* d_ops = (uint32_t*)d.alloc((total + 4) * 4);
-  d.check(wga_cigar_tokenise(d.ctx, n_ok, d_text, d_toff, d_cnt, d_err, d_ops, d_ooff));
+  d.check(wga_cigar_tokenise_spans(d.ctx, n_ok, d_text, d_beg, d_end, d_cnt, d_err, d_ops, d_ooff));
   std::vector<wga_tok_err> errs(n_ok);
   d.download(errs.data(), d_err, n_ok);
   cb->d_ops = d_ops;
@@ -277,15 +387,17 @@ uint32_t expand_batch(Dev& d, const wga_cigar_batch& cb, const ExpandJob& j, con
 
 /* ---- paf2maf (converter.rs:176-265) ------------------------------------------------------------- */
 int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::string& q_fa, Output& out) {
-  std::vector<PafRecord> recs = parse_paf(read_all(input));
+  Dev d;
+  PafInput in = load_paf(d, input, false);
+  const std::vector<PafRecord>& recs = in.recs;
   Faidx tf, qf;
   tf.load(t_fa);
   qf.load(q_fa);
   out.write("#maf version=1.6 convert_from=paf t_seq_path=" + t_fa + " q_seq_path=" + q_fa + "\n");
-  Dev d;
   d.init();
   uint8_t* d_tpool = d.upload((const uint8_t*)tf.pool.data(), tf.pool.size());
   uint8_t* d_qpool = d.upload((const uint8_t*)qf.pool.data(), qf.pool.size());
+  const size_t keep = d.owned.size(); /* the input text and the pools stay for the whole run */
   const uint64_t kMaxBytes = 6ull << 30;
   size_t i0 = 0;
   std::string pending_error;
@@ -305,7 +417,7 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
         pending_error = e.msg;
         break;
       }
-      for (const auto& tg : r.tags) est_text += tg.size();
+      est_text += in.cigar_bytes(i);
       job.add(to, tl, qo, ql, r.mapq, r.target_name, r.target_start, r.target_end - r.target_start, false,
               r.target_length, r.query_name, r.neg ? r.query_length - r.query_end : r.query_start, /* converter.rs:213-216 */
               r.query_end - r.query_start, r.neg, r.query_length);
@@ -314,11 +426,11 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
     /* the CIGARs of records [i0, i) are tokenised on the device; a tag / tokeniser error cuts the
      * batch before the failing record (reverse_complement runs before the CIGAR is looked at, so
      * an invalid base in that record's query slice still wins: checked on the host, rare path) */
-    std::vector<std::string> cigars;
+    CigarTexts cigars;
     wga_cigar_batch cb;
     cb.n = 0;
     if (i > i0) {
-      const std::string terr = device_tokenise(d, &recs[i0], (uint32_t)(i - i0), cigars, &cb);
+      const std::string terr = device_tokenise(d, in, i0, (uint32_t)(i - i0), cigars, &cb);
       if (!terr.empty()) {
         const size_t k = cb.n;
         std::string perr = terr;
@@ -351,10 +463,8 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
           pending_error = "panic: String::insert_str beyond the end of the fetched sequence (cigar.rs:507,513)";
         }
       }
-      /* free this batch's buffers (the pools stay) */
-      d.check(wga_sync(d.ctx));
-      while (d.owned.size() > 2) d.release(d.owned.back());
     }
+    d.release_to(keep); /* this batch's buffers */
     i0 = i;
   }
   out.close();
@@ -364,15 +474,16 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
 
 /* ---- stat (stat.rs) ----------------------------------------------------------------------------- */
 int cmd_stat_paf(const std::string* input, bool each, Output& out) {
-  std::vector<PafRecord> recs = parse_paf(read_all(input));
+  Dev d;
+  PafInput pin = load_paf(d, input, false);
+  const std::vector<PafRecord>& recs = pin.recs;
   const uint32_t n = (uint32_t)recs.size();
   std::vector<wga_cigar_counts> counts(n);
   if (n) {
-    Dev d;
     d.init();
-    std::vector<std::string> cigars;
+    CigarTexts cigars;
     wga_cigar_batch cb;
-    const std::string e = device_tokenise(d, recs.data(), n, cigars, &cb);
+    const std::string e = device_tokenise(d, pin, 0, n, cigars, &cb);
     const uint32_t m = cb.n; /* records before the first tag / tokeniser error */
     if (m) {
       auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)m * sizeof(wga_cigar_counts));
@@ -541,15 +652,16 @@ int cmd_maf2paf(const std::string* input, const std::string* query_name, Output&
  * output, optionally all records with corrected ends to --fix.  Lists are in input order (the reference's
  * par_bridge order is not deterministic). */
 int cmd_validate(const std::string* input, const std::string* fix, Output& out) {
-  std::vector<PafRecord> recs = parse_paf(read_all(input));
+  Dev d;
+  PafInput pin = load_paf(d, input, fix != nullptr); /* --fix re-serialises every tag: host reader */
+  std::vector<PafRecord>& recs = pin.recs;
   const uint32_t n = (uint32_t)recs.size();
   std::vector<wga_cigar_counts> counts(n);
   if (n) {
-    Dev d;
     d.init();
-    std::vector<std::string> cigars;
+    CigarTexts cigars;
     wga_cigar_batch cb;
-    std::string e = device_tokenise(d, recs.data(), n, cigars, &cb);
+    std::string e = device_tokenise(d, pin, 0, n, cigars, &cb);
     const uint32_t m = cb.n;
     if (m) {
       auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)m * sizeof(wga_cigar_counts));
@@ -640,8 +752,10 @@ int cmd_validate(const std::string* input, const std::string* fix, Output& out) 
  * GPU: tokeniser, data lines and head / tail trims (wga_cigar_chain).  Host: chain headers
  * (chain.rs:142-203, incl. the '-' strand arithmetic that reuses the updated start) and the layout. */
 int cmd_paf2chain(const std::string* input, Output& out) {
-  std::vector<PafRecord> recs = parse_paf(read_all(input));
   Dev d;
+  PafInput pin = load_paf(d, input, false);
+  const std::vector<PafRecord>& recs = pin.recs;
+  const size_t keep = d.owned.size();
   bool dev_ready = false;
   const uint64_t kMaxText = 160ull << 20;
   size_t i0 = 0;
@@ -651,15 +765,15 @@ int cmd_paf2chain(const std::string* input, Output& out) {
     uint64_t est_text = 0;
     for (; i < recs.size(); i++) {
       if (i > i0 && est_text > kMaxText) break;
-      for (const auto& tg : recs[i].tags) est_text += tg.size();
+      est_text += pin.cigar_bytes(i);
     }
     if (!dev_ready) {
       d.init();
       dev_ready = true;
     }
-    std::vector<std::string> cigars;
+    CigarTexts cigars;
     wga_cigar_batch cb;
-    pending_error = device_tokenise(d, &recs[i0], (uint32_t)(i - i0), cigars, &cb);
+    pending_error = device_tokenise(d, pin, i0, (uint32_t)(i - i0), cigars, &cb);
     uint32_t n = cb.n;
     if (n) {
       auto* d_trim = (wga_chain_trim_t*)d.alloc((size_t)n * sizeof(wga_chain_trim_t));
@@ -729,7 +843,7 @@ int cmd_paf2chain(const std::string* input, Output& out) {
         out.write(host);
       }
     }
-    d.release_all();
+    d.release_to(keep);
     i0 = i;
   }
   out.close();
@@ -1070,7 +1184,8 @@ int cmd_dotplot(const std::string* input, const std::string& format, const std::
   std::vector<wga_cigar_counts> counts;
   std::vector<uint64_t> ali;
   if (format == "paf") {
-    std::vector<PafRecord> recs = parse_paf(read_all(input));
+    PafInput pin = load_paf(d, input, false);
+    const std::vector<PafRecord>& recs = pin.recs;
     const uint32_t n = (uint32_t)recs.size();
     for (const PafRecord& r : recs) {
       t_names.push_back(r.target_name);
@@ -1084,8 +1199,8 @@ int cmd_dotplot(const std::string* input, const std::string& format, const std::
     }
     if (n && (base || !no_identity)) {
       d.init();
-      std::vector<std::string> cigars;
-      std::string e = device_tokenise(d, recs.data(), n, cigars, &cb);
+      CigarTexts cigars;
+      std::string e = device_tokenise(d, pin, 0, n, cigars, &cb);
       if (!base && cb.n) { /* get_stat (paf.rs:205-209): ops outside M = X I D are an error */
         auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)cb.n * sizeof(wga_cigar_counts));
         auto* d_diag = (wga_rec_diag*)d.alloc((size_t)cb.n * sizeof(wga_rec_diag));
@@ -2026,6 +2141,29 @@ int main(int argc, char** argv) {
     }
     if (cmd == "__cs2cg") {
       for (const auto& a : rest) printf("%s\n", cs_to_cigar(a).c_str());
+      return 0;
+    }
+    if (cmd == "__paf_reader") { /* which reader takes this file, and the fixed fields it yields */
+      Dev d;
+      PafInput pin = load_paf(d, rest.empty() ? nullptr : &rest[0], false);
+      printf("%s\n", pin.on_device ? "device" : "host");
+      for (size_t k = 0; k < pin.recs.size(); k++) {
+        const PafRecord& r = pin.recs[k];
+        printf("%s|%llu|%llu|%llu|%c|%s|%llu|%llu|%llu|%llu|%llu|%llu", r.query_name.c_str(),
+               (unsigned long long)r.query_length, (unsigned long long)r.query_start,
+               (unsigned long long)r.query_end, r.neg ? '-' : '+', r.target_name.c_str(),
+               (unsigned long long)r.target_length, (unsigned long long)r.target_start,
+               (unsigned long long)r.target_end, (unsigned long long)r.matches,
+               (unsigned long long)r.block_length, (unsigned long long)r.mapq);
+        if (pin.on_device) {
+          if (pin.cg_beg[k] != WGA_NONE) printf("|cg:Z:%s", pin.text.substr(pin.cg_beg[k], pin.cg_end[k] - pin.cg_beg[k]).c_str());
+        } else {
+          int err = 0;
+          std::string cg = paf_cigar_string(r, &err);
+          if (!err) printf("|%s", cg.c_str());
+        }
+        printf("\n");
+      }
       return 0;
     }
     if (cmd == "__parse_paf" || cmd == "__parse_maf") { /* echo the parsed records */
