@@ -29,9 +29,9 @@ with open(paf, "w") as f:
 nops = int(off[-1])
 print("input: %d records, %.3e ops, PAF %.1f MB" % (n, nops, os.path.getsize(paf) / 1e6))
 cli = build.CLI_BIN
-def run(name, args, outp):
+def run(name, args, outp, env=None):
     t0 = time.perf_counter()
-    r = subprocess.run([cli] + args + ["-o", outp, "-r"], stderr=subprocess.PIPE)
+    r = subprocess.run([cli] + args + ["-o", outp, "-r"], stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})))
     dt = time.perf_counter() - t0
     sz = os.path.getsize(outp) if os.path.exists(outp) else 0
     print("%-9s %.2f s wall  rc=%d  output %.1f MB  -> %.2e ops/s end to end" % (name, dt, r.returncode, sz / 1e6, nops / dt))
@@ -39,3 +39,11 @@ def run(name, args, outp):
 run("stat", ["stat", "-f", "paf", paf], os.path.join(tmp, "out.tsv"))
 run("paf2maf", ["paf2maf", paf, "-g", t_fa, "-q", q_fa], os.path.join(tmp, "out.maf"))
 run("pafcov", ["pafcov", paf], os.path.join(tmp, "out.bed"))
+run("paf2chain", ["paf2chain", paf], os.path.join(tmp, "out.chain"))
+run("validate", ["validate", paf], os.path.join(tmp, "out.val"))
+run("dotplot", ["dotplot", "-f", "paf", "--out-format", "csv", paf], os.path.join(tmp, "out.csv"))
+run("chain2paf", ["chain2paf", os.path.join(tmp, "out.chain")], os.path.join(tmp, "out2.paf"))
+# the same with the csv-semantics host reader instead of the device splitter
+run("stat/host", ["stat", "-f", "paf", paf], os.path.join(tmp, "out.tsv"), env={"WGA_PAF_READER": "host"})
+run("p2c/host", ["paf2chain", paf], os.path.join(tmp, "out.chain"), env={"WGA_PAF_READER": "host"})
+run("stat", ["stat", "-f", "paf", paf], os.path.join(tmp, "out.tsv"))

@@ -548,6 +548,8 @@ std::vector<ChainRecord> parse_chain(const std::string& text, std::string* err) 
   err->clear();
   const size_t n = text.size();
   size_t p = 0;
+  bool stop[256] = {false}; /* is_not("chain\n") */
+  for (const char* c = "chain\n"; *c; c++) stop[(unsigned char)*c] = true;
   auto line_ending = [&](size_t at) -> size_t { /* length of "\n" / "\r\n" at `at`, 0 if none */
     if (at < n && text[at] == '\n') return 1;
     if (at + 1 < n && text[at] == '\r' && text[at + 1] == '\n') return 2;
@@ -611,17 +613,33 @@ std::vector<ChainRecord> parse_chain(const std::string& text, std::string* err) 
     std::string line_err;
     for (;;) {
       size_t q = p;
-      while (q < n && !strchr("chain\n", text[q])) q++; /* (a NUL byte also stops here: not text) */
+      while (q < n && !stop[(unsigned char)text[q]]) q++;
       if (q == p) break;
       size_t l2 = line_ending(q);
       if (!l2) break;
       if (line_err.empty()) { /* after an error the fold keeps consuming lines but ignores them */
-        std::vector<std::string> d = split_ws(text.substr(p, q - p));
         uint64_t v[3] = {0, 0, 0};
-        if (d.empty())
-          line_err = "Parse Chain Error By: Chain Line Field `size` Missing";
-        for (size_t k = 0; k < 3 && k < d.size() && line_err.empty(); k++)
-          if (!parse_u64(d[k], &v[k])) line_err = "Parse `" + d[k] + "` Into Integer Error";
+        size_t a = p, nf = 0;
+        for (; nf < 3; nf++) { /* split_whitespace: up to three tokens, the rest is ignored */
+          while (a < q && is_ws((unsigned char)text[a])) a++;
+          if (a >= q) break;
+          size_t b = a;
+          uint64_t x = 0;
+          bool ok = true;
+          size_t dstart = b < q && text[b] == '+' ? b + 1 : b;
+          for (b = dstart; b < q && !is_ws((unsigned char)text[b]); b++) {
+            const unsigned dgt = (unsigned)(text[b] - '0');
+            if (dgt > 9 || x > (UINT64_MAX - dgt) / 10) ok = false;
+            if (ok) x = x * 10 + dgt;
+          }
+          if (!ok || b == dstart) {
+            line_err = "Parse `" + text.substr(a, b - a) + "` Into Integer Error";
+            break;
+          }
+          v[nf] = x;
+          a = b;
+        }
+        if (line_err.empty() && nf == 0) line_err = "Parse Chain Error By: Chain Line Field `size` Missing";
         if (line_err.empty()) r.lines.insert(r.lines.end(), v, v + 3);
       }
       n_lines++;

@@ -150,7 +150,8 @@ struct PafInput {
 PafInput load_paf(Dev& d, const std::string* input, bool want_tags) {
   PafInput in;
   in.text = read_all(input);
-  if (!want_tags && !in.text.empty() && in.text.size() < 0xFFFFFFF0ull) {
+  const char* force = getenv("WGA_PAF_READER"); /* "host": always the csv-semantics reader (measurements) */
+  if (!want_tags && !in.text.empty() && in.text.size() < 0xFFFFFFF0ull && !(force && strcmp(force, "host") == 0)) {
     d.init();
     in.text.append(16, '\0'); /* slack behind the text for whole-vector loads */
     in.d_text = d.upload((const uint8_t*)in.text.data(), in.text.size());
@@ -1326,15 +1327,14 @@ int cmd_dotplot(const std::string* input, const std::string& format, const std::
 
 /* ---- pafcov (pafcov.rs:13-83) --------------------------------------------------------------------- */
 int cmd_pafcov(const std::string* input, Output& out) {
-  std::vector<PafRecord> recs = parse_paf(read_all(input));
-  PackedBatch b;
+  Dev d;
+  PafInput pin = load_paf(d, input, false);
+  const std::vector<PafRecord>& recs = pin.recs;
   std::vector<std::string> targets; /* first-appearance order (the reference: HashMap order) */
   std::unordered_map<std::string, uint32_t> tid;
   std::vector<uint64_t> cov_len, t_start;
   std::vector<uint32_t> target_id;
   for (const auto& r : recs) {
-    std::string e = pack_record(r, b);
-    if (!e.empty()) fail(e);
     auto it = tid.find(r.target_name);
     if (it == tid.end()) { /* array length = target_length of the first record seen */
       it = tid.emplace(r.target_name, (uint32_t)targets.size()).first;
@@ -1344,7 +1344,7 @@ int cmd_pafcov(const std::string* input, Output& out) {
     target_id.push_back(it->second);
     t_start.push_back(r.target_start);
   }
-  const uint32_t n = (uint32_t)b.strand.size(), nt = (uint32_t)targets.size();
+  const uint32_t n = (uint32_t)recs.size(), nt = (uint32_t)targets.size();
   if (n) {
     std::vector<uint64_t> cov_off(nt);
     uint64_t total = 0;
@@ -1352,9 +1352,11 @@ int cmd_pafcov(const std::string* input, Output& out) {
       cov_off[t] = total;
       total += (cov_len[t] + 3) & ~3ull;
     }
-    Dev d;
     d.init();
-    wga_cigar_batch cb = device_batch(d, b);
+    CigarTexts cigars;
+    wga_cigar_batch cb;
+    const std::string terr = device_tokenise(d, pin, 0, n, cigars, &cb); /* update_cov_vec takes every op char */
+    if (!terr.empty()) fail(terr);
     auto* d_cov = (int32_t*)d.alloc((total + 4) * 4);
     d.check(wga_memset(d.ctx, d_cov, 0, (total + 4) * 4));
     auto *d_off = d.upload(cov_off), *d_len = d.upload(cov_len);
@@ -2141,6 +2143,14 @@ int main(int argc, char** argv) {
     }
     if (cmd == "__cs2cg") {
       for (const auto& a : rest) printf("%s\n", cs_to_cigar(a).c_str());
+      return 0;
+    }
+    if (cmd == "__parse_chain") { /* host chain reader only: record and line counts */
+      std::string e;
+      std::vector<ChainRecord> recs = parse_chain(read_all(rest.empty() ? nullptr : &rest[0]), &e);
+      size_t nl = 0;
+      for (const auto& r : recs) nl += r.lines.size() / 3;
+      printf("%zu records %zu lines %s\n", recs.size(), nl, e.c_str());
       return 0;
     }
     if (cmd == "__paf_reader") { /* which reader takes this file, and the fixed fields it yields */
