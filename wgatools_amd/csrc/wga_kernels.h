@@ -789,6 +789,12 @@ __device__ __forceinline__ u32 wave_get_u32(u32 v, int k) {
 #ifndef WGA_SPLIT_BYTES
 #define WGA_SPLIT_BYTES 8192u /* ... in two halves beyond this */
 #endif
+#ifndef WGA_MBCNT
+#define WGA_MBCNT 1
+#endif
+#ifndef WGA_OWNER_SETUP
+#define WGA_OWNER_SETUP 1 /* 1: only the wave that owns a row piece reads the row's source / destination fields */
+#endif
 #define WGA_QCAP (64u * (WGA_EMIT_U + 1u)) /* per-wave queue of complex chunks: < 64 left over + one iteration's pushes */
 
 /* Granule table: one 16-bit field per row (target row = low half, query row = high half of a
@@ -863,6 +869,9 @@ __device__ __forceinline__ RowGeom row_geom(u8* dst, u32 N, u32 c0) {
   r.head = c0 & 15u;
   r.j0 = c0 >> 4;
   r.base = dst - r.head; /* pointer arithmetic: stores stay global_store */
+#if defined(WGA_EXP_ALIGN) && (WGA_EXP_ALIGN & 1) /* timing experiment only (wrong output): 16-byte aligned stores */
+  r.base -= (uintptr_t)r.base & 15u;
+#endif
   r.nchunks = (r.head + N + 15u) >> 4;
   r.last_b0 = ((r.head + N - 1u) & 15u) + 1u;
   return r;
@@ -989,6 +998,16 @@ __device__ __forceinline__ void complex_chunk(const ChunkGeom& g, u32 rel, const
   if (!whole) chunk_store(g, o, 0); /* a row / tile edge: byte stores */
 }
 
+/* set bits of m below this lane's (v_mbcnt_lo / v_mbcnt_hi) */
+__device__ __forceinline__ u32 lane_rank(u64 m, u32 lane) {
+#if defined(WGA_EMU) || !WGA_MBCNT
+  return (u32)__popcll(m & ((1ull << lane) - 1ull));
+#else
+  (void)lane;
+  return (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+#endif
+}
+
 /* RC = the row is read reverse-complemented: a compile-time copy of src.rc, so that each of the
  * two instantiations carries only its own window post-processing */
 template <bool RC>
@@ -1051,6 +1070,9 @@ __device__ __forceinline__ void emit_row_t(u8* dst, u32 N, u32 c0, const RowDesc
                        (int)(st != WGA_TBL_COVER));
       const u32 off = cz + (u32)koff - adj; /* slice index of the granule relative to sbase, >= 0 */
       loff[u] = ((int)cand[u] & (int)!dash[u]) ? rowbuf_loff(rb, (int)off) : WGA_BUF_OOB;
+#if defined(WGA_EXP_ALIGN) && (WGA_EXP_ALIGN & 2) /* timing experiment only: 16-byte aligned window loads */
+      loff[u] &= ~15u;
+#endif
     }
 #pragma unroll
     for (int u = 0; u < WGA_EMIT_U; u++) buf_load16(rb.lbuf, loff[u], raw[u]);
@@ -1082,7 +1104,7 @@ __device__ __forceinline__ void emit_row_t(u8* dst, u32 N, u32 c0, const RowDesc
     for (int u = 0; u < WGA_EMIT_U; u++) {
       const u64 m = __ballot(cxs[u]);
       if (m) {
-        if (cxs[u]) queue[qn + (u32)__popcll(m & ((1ull << lane) - 1ull))] = rel[u];
+        if (cxs[u]) queue[qn + lane_rank(m, lane)] = rel[u];
         qn += (u32)__popcll(m);
       }
     }
@@ -1598,18 +1620,22 @@ __global__ __launch_bounds__(256, 5) void k_paf2maf_expand(ExpandArgs a) {
       if (a.ablate & 8) continue;
 #endif
       /* this row's fields: the query ones sit 2 (offsets, gap totals) or 4 (slice) lanes after
-       * the target ones */
+       * the target ones.  Every wave works out the size of the job (that decides who owns its
+       * pieces); everything else is only read by the owner. */
       const int q2 = is_q ? 2 : 0, q4 = is_q ? 4 : 0;
       const u64 gap_total = wave_get_u64(dsc, 26 + q2); /* I bases (target row) / D bases (query row) */
       const u64 L = wave_get_u64(dsc, 30);
+      const u64 src_len = is_q ? q_src_len : t_src_len;
+      const u64 row_len = src_len + gap_total;
+#if !WGA_OWNER_SETUP
       RowSrc src;
       src.fa = is_q ? a.q_fa : a.t_fa;
       src.fa_bytes = is_q ? a.q_fa_bytes : a.t_fa_bytes;
       src.src_off = wave_get_u64(dsc, 18 + q4);
-      src.src_len = is_q ? q_src_len : t_src_len;
+      src.src_len = src_len;
       src.rc = is_q && wave_get_u32(dsc, 3) != 0u;
       src.ablate = a.ablate;
-      const u64 row_len = src.src_len + gap_total;
+#endif
       u64 x0, nbytes;
       if (!is_tail) {
         if (!fast) continue;
@@ -1633,12 +1659,25 @@ __global__ __launch_bounds__(256, 5) void k_paf2maf_expand(ExpandArgs a) {
         const u32 cc = (c_row + (u32)(nbytes >> 1)) & ~15u;
         if (cc > c_row && (u64)(cc - c_row) < nbytes) cut = cc - c_row;
       }
+#if !WGA_OWNER_SETUP
       u8* const dst = a.out + wave_get_u64(dsc, 14 + q2) + x0;
       const u64 sb0 = is_tail ? L - gap_total : (is_q ? qb : tb);
+#endif
       for (int piece = 0; piece < 2; piece++) {
         const u64 lo = piece == 0 ? 0 : cut, hi = piece == 0 ? cut : nbytes;
         if (lo >= hi) continue;
         if (!coop && (njob++ & 3u) != wave) continue;
+#if WGA_OWNER_SETUP
+        RowSrc src;
+        src.fa = is_q ? a.q_fa : a.t_fa;
+        src.fa_bytes = is_q ? a.q_fa_bytes : a.t_fa_bytes;
+        src.src_off = wave_get_u64(dsc, 18 + q4);
+        src.src_len = src_len;
+        src.rc = is_q && wave_get_u32(dsc, 3) != 0u;
+        src.ablate = a.ablate;
+        u8* const dst = a.out + wave_get_u64(dsc, 14 + q2) + x0;
+        const u64 sb0 = is_tail ? L - gap_total : (is_q ? qb : tb);
+#endif
         for (u64 done = lo; done < hi; done += (1ull << 30)) {
           const u64 m = hi - done < (1ull << 30) ? hi - done : (1ull << 30);
           RowDesc rd;
