@@ -308,6 +308,27 @@ int wga_cigar_tokenise_spans(wga_ctx*, uint32_t n, const uint8_t* d_text, const 
                              const uint64_t* d_end, uint64_t* d_op_cnt, wga_tok_err* d_err, uint32_t* d_ops,
                              const uint64_t* d_op_off);
 
+/* ---- K14: MAF line splitter (replaces MAFReader / parse_sline for plain files, maf.rs:25-36,138-211,
+ *      371-421; with it the K3 / K4 walks read the rows straight out of the uploaded file) -----------
+ * One wga_maf_line per text line: WGA_MAF_SLINE (a line starting with 's' other than the file's first
+ * line, split at white space into mode, name, start, size, strand, srcSize, text: numbers parsed like
+ * u64::from_str / Strand::from_str, name and text as byte spans of d_text), WGA_MAF_OTHER (any other
+ * line: it ends the block in progress) or WGA_MAF_FALLBACK (an s-line without exactly seven tokens,
+ * with a field that does not parse or with a non-ASCII byte): the caller then reads the file with its
+ * host reader, which returns the reference's error.  A block is a maximal run of s-lines.  Same
+ * two-call protocol and size limit as wga_paf_split. */
+#define WGA_MAF_SLINE 0
+#define WGA_MAF_OTHER 1
+#define WGA_MAF_FALLBACK 2
+typedef struct {
+  uint64_t num[3]; /* start, align_size, size (maf.rs:65-73) */
+  uint64_t name_off, seq_off, seq_len;
+  uint32_t name_len;
+  uint8_t strand_neg, status, pad[2];
+} wga_maf_line;
+int wga_maf_split(wga_ctx*, const uint8_t* d_text, uint64_t n_bytes, uint64_t* n_lines, wga_maf_line* d_lines,
+                  uint64_t cap_lines);
+
 /* ---- K5: pafcov (replaces update_cov_vec, cigar.rs:710-741, and the per-thread array merge of
  *      pafcov.rs:29-53) ------------------------------------------------------------------------
  * Record i adds +1 to d_cov[cov_off[target_id[i]] + p] for every base p of its M / = ops that

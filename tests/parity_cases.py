@@ -897,3 +897,71 @@ def check_paf_split(eng, text):
         for k in range(m):
             if ok[k]:
                 assert (a1[int(oo[k]):int(oo[k + 1])] == a2[int(oo[k]):int(oo[k + 1])]).all(), k
+
+
+# ------------------------------------------------------------------------------------------------
+# K14 MAF line splitter
+# ------------------------------------------------------------------------------------------------
+def expected_maf_lines(text):
+    """what MAFReader + parse_sline (maf.rs:25-36,138-211,371-421) make of every line that needs no
+    Unicode-aware splitting; status 0 s-line, 1 other, 2 fallback"""
+    def u64(b):
+        b2 = b[1:] if b[:1] == b"+" else b
+        if not b2 or not all(48 <= c <= 57 for c in b2) or int(b2) > 0xFFFFFFFFFFFFFFFF:
+            return None
+        return int(b2)
+    out, pos = [], 0
+    if not text:
+        return out
+    lines = text.split(b"\n")
+    if text.endswith(b"\n"):
+        lines.pop()
+    for j, ln in enumerate(lines):
+        start = pos
+        pos += len(ln) + 1
+        if j == 0 or ln[:1] != b"s":
+            out.append(dict(status=1))
+            continue
+        toks, k = [], 0          # (offset, bytes) of the white-space separated tokens
+        while k < len(ln):
+            if ln[k] in b" \t\r\x0b\x0c":
+                k += 1
+                continue
+            k2 = k
+            while k2 < len(ln) and ln[k2] not in b" \t\r\x0b\x0c":
+                k2 += 1
+            toks.append((start + k, ln[k:k2]))
+            k = k2
+        if any(c >= 0x80 for c in ln):
+            out.append(dict(status=2))
+            continue
+        nums = [u64(toks[i][1]) if i < len(toks) else None for i in (2, 3, 5)]
+        if len(toks) != 7 or any(v is None for v in nums) or toks[4][1] not in (b"+", b"-"):
+            out.append(dict(status=2))
+            continue
+        out.append(dict(status=0, num=nums, neg=toks[4][1] == b"-", name=(toks[1][0], len(toks[1][1])),
+                        seq=(toks[6][0], len(toks[6][1]))))
+    return out
+
+
+def check_maf_split(eng, text):
+    text = bytes(text)
+    d_text = eng.upload(np.frombuffer(text + b"\0" * 16, dtype=np.uint8))
+    n = eng.maf_split(d_text, len(text))
+    want = expected_maf_lines(text)
+    assert n == len(want), (n, len(want))
+    if n == 0:
+        return
+    lines = eng.empty(n + 1, engine.MAF_LINE_DTYPE).fill(0xEE)
+    assert eng.maf_split(d_text, len(text), lines) == n
+    got = lines.numpy()
+    for j, w in enumerate(want):
+        g = got[j]
+        assert int(g["status"]) == w["status"], (j, int(g["status"]), w)
+        if w["status"]:
+            continue
+        assert [int(x) for x in g["num"]] == w["num"], (j, g["num"], w["num"])
+        assert bool(g["strand_neg"]) == w["neg"], j
+        assert (int(g["name_off"]), int(g["name_len"])) == w["name"], j
+        assert (int(g["seq_off"]), int(g["seq_len"])) == w["seq"], j
+    assert (got[n:n + 1].view(np.uint8) == 0xEE).all()

@@ -384,4 +384,26 @@ def test_paf_split(emu):
         pc.check_paf_split(emu, b"#" + b"x" * (pad - 1) + b"\n" + rows[0].encode() + b"\n" + b"\t" * 40 + b"\n")
 
 
+def test_maf_split(emu):
+    rng = np.random.default_rng(8)
+    def block(k, cols, extra=b""):
+        t = pc.rand_seq(rng, cols, b"ACGTacgt-N")
+        q = pc.rand_seq(rng, cols, b"ACGTacgt-N")
+        return (b"a score=%d\n" % k + b"s ref.chr%d   %d %d + 1000000 " % (k, 7 * k, cols) + t + b"\n" +
+                b"s\tqry.%d\t%d\t%d\t-\t+2000000\t" % (k, 11 * k, cols) + q + extra + b"\n\n")
+    clean = b"##maf version=1 scoring=x\n# a comment\n" + b"".join(block(k, c) for k, c in enumerate((1, 15, 16, 17, 300, 4100, 9000)))
+    pc.check_maf_split(emu, clean)
+    pc.check_maf_split(emu, clean[:-2])                      # no newline at the end
+    pc.check_maf_split(emu, b"")
+    pc.check_maf_split(emu, b"s first line is the header even if it looks like an s-line\ns a 1 2 + 3 ACGT\n")
+    odd = [b"s a 1 2 + 3", b"s a 1 2 + 3 ACGT extra", b"s a x 2 + 3 ACGT", b"s a 1 2 * 3 ACGT", b"s a 1 2 + 18446744073709551616 ACGT",
+           b"sX a 1 2 + 3 ACGT", b" s a 1 2 + 3 ACGT", b"s a 1 2 + 3 ACGT \r", b"s\x0ba\x0c1 2 + 3 ACGT", b"s a\xc2\xa01 2 + 3 ACGT",
+           b"i a N 0 C 0", b"e a 1 2 + 3 I", b"q a 99", b"", b"s", b"s a +1 2 - 3 AC-GT"]
+    pc.check_maf_split(emu, b"##maf\n" + b"\n".join(odd) + b"\n" + clean)
+    pc.check_maf_split(emu, (b"##maf\n" + b"\n".join(odd)).replace(b"\n", b"\r\n"))
+    for pad in (4079, 4095, 4096, 4097):                     # delimiters at the block edges
+        pc.check_maf_split(emu, b"#" + b"x" * (pad - 1) + b"\n" + block(3, 50) + b" " * 40 + b"\n")
+
+
+
 

@@ -146,6 +146,62 @@ static MafRunSrc maf_run_src(const uint64_t* d_runs, const uint64_t* d_run_off, 
   return s;
 }
 
+/* K13 / K14 driver: delimiter lists (count, scan, fill) in the context scratch, then one thread per line.
+ * MODE 0 = PAF (wga_paf_line), 1 = MAF (wga_maf_line). */
+template <int MODE>
+static int split_lines(wga_ctx* c, const uint8_t* d_text, uint64_t n_bytes, uint64_t* n_lines, void* d_lines,
+                       uint64_t cap_lines) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (!n_lines) return fail(WGA_E_INVALID_ARG, "n_lines null", nullptr);
+  *n_lines = 0;
+  if (n_bytes == 0) return WGA_OK;
+  if (!d_text) return fail(WGA_E_INVALID_ARG, "d_text null", nullptr);
+  if (n_bytes >= 0xFFFFFFFFull) return fail(WGA_E_INVALID_ARG, "text of 4 GiB or more: split it at line ends", nullptr);
+  const u32 nb = (u32)((n_bytes + 4095u) / 4096u);
+  const size_t head = ((size_t)nb + 1 + (size_t)nb / 1024 + 4) * sizeof(u64);
+  u64 tot = 0;
+  void* ws = nullptr;
+  if ((rc = ctx_scratch(c, head, &ws))) return rc;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    u64* blk = (u64*)c->scratch;
+    WGA_LAUNCH((k_paf_delims<false, MODE>), nb, WGA_BLOCK, c->stream, d_text, (u64)n_bytes, blk, (const u64*)nullptr,
+               (u64*)nullptr, (u64*)nullptr);
+    LAUNCH_CHECK();
+    /* exclusive scan of the block counts in place (k_scan_final reads its four values, then writes them) */
+    ScanPlain f;
+    f.in = blk;
+    if ((rc = run_scan_ws(c, f, nb, blk, blk + nb + 1))) return rc;
+    RT_CHECK(rt_d2h(&tot, blk + nb, sizeof(u64), c->stream));
+    /* the two lists follow the block offsets; their sizes are only known now: growing the arena
+     * drops its contents, so the count pass is repeated once */
+    const size_t want = head + ((size_t)(tot & 0xFFFFFFFFull) + (size_t)(tot >> 32) + 2) * sizeof(u64);
+    if (c->scratch_cap >= want) break;
+    if ((rc = ctx_scratch(c, want, &ws))) return rc;
+  }
+  const u64 n_delims = tot & 0xFFFFFFFFull, n_newlines = tot >> 32;
+  u8 last = 0;
+  RT_CHECK(rt_d2h(&last, d_text + n_bytes - 1, 1, c->stream));
+  *n_lines = n_newlines + (last != (u8)0x0A ? 1 : 0);
+  if (!d_lines) return WGA_OK;
+  if (cap_lines < *n_lines) return fail(WGA_E_TOO_SMALL, "d_lines too small", nullptr);
+  u64* blk_off = (u64*)c->scratch;
+  u64* delims = (u64*)((char*)c->scratch + head);
+  u64* nl_idx = delims + n_delims + 1;
+  WGA_LAUNCH((k_paf_delims<true, MODE>), nb, WGA_BLOCK, c->stream, d_text, (u64)n_bytes, (u64*)nullptr,
+             (const u64*)blk_off, delims, nl_idx);
+  LAUNCH_CHECK();
+  if (MODE == 0) {
+    WGA_LAUNCH(k_paf_fields, (u32)((*n_lines + 255u) / 256u), WGA_BLOCK, c->stream, d_text, (u64)n_bytes,
+               (u64)*n_lines, n_newlines, n_delims, (const u64*)delims, (const u64*)nl_idx, (wga_paf_line_dev*)d_lines);
+  } else {
+    WGA_LAUNCH(k_maf_lines, (u32)((*n_lines + 255u) / 256u), WGA_BLOCK, c->stream, d_text, (u64)n_bytes,
+               (u64)*n_lines, n_newlines, n_delims, (const u64*)delims, (const u64*)nl_idx, (wga_maf_line_dev*)d_lines);
+  }
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
 extern "C" {
 
 int wga_abi_version(void) { return WGA_ABI_VERSION; }
@@ -495,51 +551,14 @@ int wga_cigar_tokenise_spans(wga_ctx* c, uint32_t n, const uint8_t* d_text, cons
 
 int wga_paf_split(wga_ctx* c, const uint8_t* d_text, uint64_t n_bytes, uint64_t* n_lines, wga_paf_line* d_lines,
                   uint64_t cap_lines) {
-  int rc = ctx_bind(c);
-  if (rc) return rc;
-  if (!n_lines) return fail(WGA_E_INVALID_ARG, "n_lines null", nullptr);
-  *n_lines = 0;
-  if (n_bytes == 0) return WGA_OK;
-  if (!d_text) return fail(WGA_E_INVALID_ARG, "d_text null", nullptr);
-  if (n_bytes >= 0xFFFFFFFFull) return fail(WGA_E_INVALID_ARG, "text of 4 GiB or more: split it at line ends", nullptr);
   static_assert(sizeof(wga_paf_line) == sizeof(wga_paf_line_dev), "wga_paf_line layout");
-  const u32 nb = (u32)((n_bytes + 4095u) / 4096u);
-  const size_t head = ((size_t)nb + 1 + (size_t)nb / 1024 + 4) * sizeof(u64);
-  u64 tot = 0;
-  void* ws = nullptr;
-  if ((rc = ctx_scratch(c, head, &ws))) return rc;
-  for (int attempt = 0; attempt < 2; attempt++) {
-    u64* blk = (u64*)c->scratch;
-    WGA_LAUNCH(k_paf_delims<false>, nb, WGA_BLOCK, c->stream, d_text, (u64)n_bytes, blk, (const u64*)nullptr,
-               (u64*)nullptr, (u64*)nullptr);
-    LAUNCH_CHECK();
-    /* exclusive scan of the block counts in place (k_scan_final reads its four values, then writes them) */
-    ScanPlain f;
-    f.in = blk;
-    if ((rc = run_scan_ws(c, f, nb, blk, blk + nb + 1))) return rc;
-    RT_CHECK(rt_d2h(&tot, blk + nb, sizeof(u64), c->stream));
-    /* the two lists follow the block offsets; their sizes are only known now: growing the arena
-     * drops its contents, so the count pass is repeated once */
-    const size_t want = head + ((size_t)(tot & 0xFFFFFFFFull) + (size_t)(tot >> 32) + 2) * sizeof(u64);
-    if (c->scratch_cap >= want) break;
-    if ((rc = ctx_scratch(c, want, &ws))) return rc;
-  }
-  const u64 n_delims = tot & 0xFFFFFFFFull, n_newlines = tot >> 32;
-  u8 last = 0;
-  RT_CHECK(rt_d2h(&last, d_text + n_bytes - 1, 1, c->stream));
-  *n_lines = n_newlines + (last != (u8)0x0A ? 1 : 0);
-  if (!d_lines) return WGA_OK;
-  if (cap_lines < *n_lines) return fail(WGA_E_TOO_SMALL, "d_lines too small", nullptr);
-  u64* blk_off = (u64*)c->scratch;
-  u64* delims = (u64*)((char*)c->scratch + head);
-  u64* nl_idx = delims + n_delims + 1;
-  WGA_LAUNCH(k_paf_delims<true>, nb, WGA_BLOCK, c->stream, d_text, (u64)n_bytes, (u64*)nullptr,
-             (const u64*)blk_off, delims, nl_idx);
-  LAUNCH_CHECK();
-  WGA_LAUNCH(k_paf_fields, (u32)((*n_lines + 255u) / 256u), WGA_BLOCK, c->stream, d_text, (u64)n_bytes,
-             (u64)*n_lines, n_newlines, n_delims, (const u64*)delims, (const u64*)nl_idx, (wga_paf_line_dev*)d_lines);
-  LAUNCH_CHECK();
-  return WGA_OK;
+  return split_lines<0>(c, d_text, n_bytes, n_lines, (void*)d_lines, cap_lines);
+}
+
+int wga_maf_split(wga_ctx* c, const uint8_t* d_text, uint64_t n_bytes, uint64_t* n_lines, wga_maf_line* d_lines,
+                  uint64_t cap_lines) {
+  static_assert(sizeof(wga_maf_line) == sizeof(wga_maf_line_dev), "wga_maf_line layout");
+  return split_lines<1>(c, d_text, n_bytes, n_lines, (void*)d_lines, cap_lines);
 }
 
 int wga_pafcov_format(wga_ctx* c, const uint8_t* d_name, uint32_t name_len, const int32_t* d_cov,

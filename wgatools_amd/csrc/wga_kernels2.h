@@ -706,6 +706,9 @@ __device__ __forceinline__ u32 zero_bytes(u32 x) { /* 0x80 in every byte of x th
 }
 __device__ __forceinline__ u32 popc32(u32 x) { return (u32)__builtin_popcount(x); }
 
+#ifndef WGA_K3_BLOCKS
+#define WGA_K3_BLOCKS 8 /* blocks per CU the register budget of k_maf_pair_stat is sized for */
+#endif
 struct MafWalkOut {
   u64 ncol[5], nrun[5]; /* columns / runs per class (wave totals, valid in every lane) */
   u64 runs;             /* runs in all */
@@ -873,7 +876,7 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
   out.runs = run_base;
 }
 
-__global__ __launch_bounds__(256) void k_maf_pair_stat(u32 n, const u8* __restrict__ rows,
+__global__ __launch_bounds__(256, WGA_K3_BLOCKS) void k_maf_pair_stat(u32 n, const u8* __restrict__ rows,
                                                        const u64* t_off, const u64* q_off,
                                                        const u64* cols, const u8* strand_neg,
                                                        wga_cigar_counts* counts, u64* run_cnt,
@@ -1960,6 +1963,9 @@ struct wga_paf_line_dev {
   u8 strand_neg, status, pad[2];
 };
 
+/* MODE 0 (PAF): tab, newline, '"', CR.  MODE 1 (MAF): newline, the ASCII white space of
+ * split_whitespace (9-13, 32) and every byte >= 0x80 (Unicode white space: left to the host). */
+template <int MODE>
 __device__ __forceinline__ u32 paf_delim_masks(const u32 w[4], u32* nl_mask) {
   u32 dm = 0, nm = 0;
 #pragma unroll
@@ -1969,14 +1975,17 @@ __device__ __forceinline__ u32 paf_delim_masks(const u32 w[4], u32* nl_mask) {
       const u32 ch = (w[d] >> (8 * b)) & 0xFFu;
       const u32 bit = 1u << (4 * d + b);
       nm |= ch == 0x0Au ? bit : 0u;
-      dm |= (ch == 0x0Au || ch == 0x09u || ch == 0x22u || ch == 0x0Du) ? bit : 0u;
+      if (MODE == 0)
+        dm |= (ch == 0x0Au || ch == 0x09u || ch == 0x22u || ch == 0x0Du) ? bit : 0u;
+      else
+        dm |= (ch - 9u <= 4u || ch == 0x20u || ch >= 0x80u) ? bit : 0u;
     }
   }
   *nl_mask = nm;
   return dm;
 }
 
-template <bool FILL>
+template <bool FILL, int MODE>
 __global__ __launch_bounds__(256) void k_paf_delims(const u8* __restrict__ text, u64 n_bytes, u64* blk,
                                                     const u64* blk_off, u64* delims, u64* nl_idx) {
   __shared__ u64 s_w[5];
@@ -1989,7 +1998,7 @@ __global__ __launch_bounds__(256) void k_paf_delims(const u8* __restrict__ text,
     for (u32 j = 0; j < (u32)(n_bytes - c); j++) w[j >> 2] |= (u32)text[c + j] << (8u * (j & 3u));
   }
   u32 nm;
-  u32 dm = paf_delim_masks(w, &nm);
+  u32 dm = paf_delim_masks<MODE>(w, &nm);
   const u64 cnt = (u64)__builtin_popcount(dm) | ((u64)__builtin_popcount(nm) << 32);
   u64 tot;
   const u64 ex = block_excl_scan_u64(cnt, s_w, &tot);
@@ -2095,6 +2104,74 @@ __global__ __launch_bounds__(256) void k_paf_fields(const u8* __restrict__ text,
     }
     L.n_fields = nf;
     if (status == WGA_PAF_OK && (nf < 12u || (!seen_cg && seen_cs))) status = WGA_PAF_FALLBACK;
+  }
+  L.status = status;
+  lines[j] = L;
+}
+
+/* ============================================================================================ */
+/* K14: MAF line splitter (the reader of maf.rs:25-36,138-211,371-421 for plain files)           */
+/* ============================================================================================ */
+/* Same two lists as K13, with white space as the field delimiter.  One thread per line: a line that
+ * starts with 's' (and is not the file's first line, which is always the header) is an s-line:
+ * seven white-space separated tokens — mode, name, start, size, strand, srcSize, text — of which
+ * the name and the text stay where they are (spans).  The K3 / K4 walks then read the rows straight
+ * out of the uploaded file.  Blocks (maximal runs of s-lines) are put together by the caller. */
+#define WGA_MAF_SLINE 0
+#define WGA_MAF_OTHER 1    /* header, or a line that does not start with 's': ends a block */
+#define WGA_MAF_FALLBACK 2 /* not seven tokens, a bad number or strand, a non-ASCII byte in front of the text */
+struct wga_maf_line_dev {
+  u64 num[3]; /* start, align_size, size (maf.rs:65-73) */
+  u64 name_off, seq_off, seq_len;
+  u32 name_len;
+  u8 strand_neg, status, pad[2];
+};
+
+__global__ __launch_bounds__(256) void k_maf_lines(const u8* __restrict__ text, u64 n_bytes, u64 n_lines,
+                                                   u64 n_newlines, u64 n_delims,
+                                                   const u64* __restrict__ delims,
+                                                   const u64* __restrict__ nl_idx, wga_maf_line_dev* lines) {
+  const u64 j = (u64)blockIdx.x * 256u + threadIdx.x;
+  if (j >= n_lines) return;
+  const u64 d0 = j ? nl_idx[j - 1] + 1 : 0;
+  const u64 s = j ? delims[nl_idx[j - 1]] + 1 : 0;
+  const u64 d1 = j < n_newlines ? nl_idx[j] : n_delims;
+  const u64 e = j < n_newlines ? delims[nl_idx[j]] : n_bytes;
+  wga_maf_line_dev L;
+  L.num[0] = L.num[1] = L.num[2] = 0;
+  L.name_off = L.seq_off = L.seq_len = 0;
+  L.name_len = 0;
+  L.strand_neg = 0;
+  L.pad[0] = L.pad[1] = 0;
+  u8 status = WGA_MAF_OTHER;
+  if (j > 0 && s < e && text[s] == (u8)'s') {
+    status = WGA_MAF_SLINE;
+    u64 prev = s;
+    u32 nt = 0;
+    for (u64 d = d0; d <= d1 && status == WGA_MAF_SLINE; d++) {
+      const u64 p = d < d1 ? delims[d] : e;
+      if (d < d1 && text[p] >= 0x80u) status = WGA_MAF_FALLBACK;
+      if (p > prev) { /* a token */
+        bool ok = true;
+        switch (nt) {
+          case 0: break; /* mode: its first char, not looked at again */
+          case 1: L.name_off = prev; L.name_len = (u32)(p - prev); ok = p - prev < 0xFFFFFFFFull; break;
+          case 2: ok = paf_parse_u64(text, prev, p, &L.num[0]); break;
+          case 3: ok = paf_parse_u64(text, prev, p, &L.num[1]); break;
+          case 4:
+            ok = p - prev == 1u && (text[prev] == (u8)'+' || text[prev] == (u8)'-');
+            L.strand_neg = ok && text[prev] == (u8)'-' ? 1 : 0;
+            break;
+          case 5: ok = paf_parse_u64(text, prev, p, &L.num[2]); break;
+          case 6: L.seq_off = prev; L.seq_len = p - prev; break;
+          default: ok = false; break; /* SurplusField */
+        }
+        if (!ok) status = WGA_MAF_FALLBACK;
+        nt++;
+      }
+      prev = p + 1;
+    }
+    if (status == WGA_MAF_SLINE && nt != 7u) status = WGA_MAF_FALLBACK;
   }
   L.status = status;
   lines[j] = L;

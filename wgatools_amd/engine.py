@@ -17,6 +17,9 @@ CHAIN_TRIM_DTYPE = np.dtype([(k, "<u8") for k in ("head_ins", "head_del", "tail_
 TOK_ERR_DTYPE = np.dtype([("err", np.int32), ("tok_len", np.uint32), ("tok_off", np.uint64)])
 CLASS_SUMS_DTYPE = np.dtype([(k, "<u8") for k in ("mx", "i", "d", "s", "o")])
 NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
+MAF_LINE_DTYPE = np.dtype([("num", np.uint64, 3), ("name_off", np.uint64), ("seq_off", np.uint64),
+                           ("seq_len", np.uint64), ("name_len", np.uint32), ("strand_neg", np.uint8),
+                           ("status", np.uint8), ("pad", np.uint8, 2)])
 PAF_LINE_DTYPE = np.dtype([("num", np.uint64, 9), ("qname_off", np.uint64), ("tname_off", np.uint64),
                            ("cg_beg", np.uint64), ("cg_end", np.uint64), ("qname_len", np.uint32),
                            ("tname_len", np.uint32), ("n_fields", np.uint32), ("strand_neg", np.uint8),
@@ -294,6 +297,13 @@ class Engine:
         nl = C.c_uint64(0)
         cap = 0 if lines is None else (lines.numel() if hasattr(lines, "numel") else lines.size)
         self._check(self.lib.wga_paf_split(self.ctx, _p(text), int(n_bytes), C.byref(nl), _p(lines), int(cap)))
+        return int(nl.value)
+
+    def maf_split(self, text, n_bytes, lines=None):
+        """K14: number of text lines (lines is None), or the wga_maf_line of every line"""
+        nl = C.c_uint64(0)
+        cap = 0 if lines is None else (lines.numel() if hasattr(lines, "numel") else lines.size)
+        self._check(self.lib.wga_maf_split(self.ctx, _p(text), int(n_bytes), C.byref(nl), _p(lines), int(cap)))
         return int(nl.value)
 
     def cigar_tokenise_spans(self, n, text, beg, end, op_cnt=None, err=None, ops=None, op_off=None):
