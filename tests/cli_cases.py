@@ -821,3 +821,46 @@ def test_paf_reader_selection(cli, tmp_path):
     p4.write_text("q\t100\t0\t10\t+\tt\t100\t0\t10\t10\t10\t60\tcs:Z::6*ag:3\n")
     rc, out4, err = run(cli, "__paf_reader", str(p4))
     assert rc == 0 and out4.decode().splitlines() == ["host", "q|100|0|10|+|t|100|0|10|10|10|60|cg:Z:6M1X3M"], (out4, err)
+
+
+def test_maf_reader_selection(cli, tmp_path):
+    """plain MAF files are split on the device (K14) and the rows are read where they were uploaded; the host
+    reader takes over when a line needs it, with the same blocks or the reference's error"""
+    blocks = _synth_maf_blocks(44, 6, 300)
+    maf = str(tmp_path / "in.maf")
+    _write_maf(maf, blocks, extra_sline=True)
+    rc, out, err = run(cli, "__maf_reader", maf)
+    assert rc == 0, err
+    lines = out.decode().splitlines()
+    assert lines[0] == "device" and lines[1] == "##maf version=1" and len(lines) == 2 + len(blocks)
+    assert all(l.startswith("block 3 ") for l in lines[2:])
+    os.environ["WGA_MAF_READER"] = "host"
+    try:
+        rc, out2, err = run(cli, "__maf_reader", maf)
+    finally:
+        del os.environ["WGA_MAF_READER"]
+    assert rc == 0 and out2.decode().splitlines() == ["host"] + lines[1:], err
+    # a non-ASCII byte among the fields: host reader, same blocks (U+00A0 is white space for split_whitespace only
+    # in the reference; here the line simply stays with the host reader)
+    text = open(maf, "rb").read()
+    p2 = str(tmp_path / "v.maf")
+    open(p2, "wb").write(text.replace(b"a score=255\n", b"a score=255 \xc3\xa9\n", 1))
+    rc, out3, err = run(cli, "__maf_reader", p2)
+    assert rc == 0 and out3.decode().splitlines()[0] == "device"          # not on an s-line: no fallback needed
+    open(p2, "wb").write(text.replace(b"\tother.x\t", b"\tother.\xc3\xa9\t", 1))
+    rc, out3, err = run(cli, "__maf_reader", p2)
+    assert rc == 0 and out3.decode().splitlines()[0] == "host"
+    # errors come from the host reader with the reference's text
+    open(p2, "wb").write(text.replace(b"\t+\t99999\t", b"\t+\t", 1))
+    rc, out4, err = run(cli, "stat", p2)
+    assert rc == 1 and "S-line Filed `seq` Missing" in err
+    # every MAF command gives the same bytes through both readers
+    for args in (["stat"], ["maf2paf"], ["maf2chain"], ["call", "-s", "-l", "3"], ["dotplot", "--out-format", "csv", "-l", "2"]):
+        rc, a, err = run(cli, *args, maf)
+        assert rc == 0, (args, err)
+        os.environ["WGA_MAF_READER"] = "host"
+        try:
+            rc, b, err = run(cli, *args, maf)
+        finally:
+            del os.environ["WGA_MAF_READER"]
+        assert rc == 0 and a == b, args

@@ -70,7 +70,11 @@ struct MafSLine { /* maf.rs:65-73 */
   uint64_t start = 0, align_size = 0;
   bool neg = false;
   uint64_t size = 0;
-  std::string seq;
+  std::string seq;              /* the row text (host reader) ... */
+  const char* file = nullptr;   /* ... or a span of the input file, which stays in memory (device splitter) */
+  uint64_t seq_off = 0, seq_len = 0;
+  size_t seq_size() const { return file ? (size_t)seq_len : seq.size(); }
+  const char* seq_data() const { return file ? file + seq_off : seq.data(); }
 };
 struct MafRecord { /* maf.rs:216-220 */
   uint64_t score = 255;

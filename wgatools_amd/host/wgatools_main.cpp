@@ -14,6 +14,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <memory>
 #include <regex>
 
 #include "wga_host.hpp"
@@ -511,12 +512,115 @@ int cmd_stat_paf(const std::string* input, bool each, Output& out) {
   return 0;
 }
 
-/* MAF blocks -> one row buffer + offsets; runs the column-pair kernel */
-struct MafPairs {
-  std::string rows;
-  std::vector<uint64_t> t_off, q_off, cols;
-  std::vector<uint8_t> strand;
+/* A MAF input: blocks with their s-lines.  Plain files are split on the device (wga_maf_split): the rows
+ * are never copied — the K3 / K4 walks read them in the uploaded file, the host keeps spans into its own
+ * copy of the text for the few places that need row characters (VCF REF / ALT).  A file with a line the
+ * splitter does not take goes through the host reader (the reference's errors). */
+struct MafInput {
+  std::shared_ptr<std::string> text = std::make_shared<std::string>();
+  std::string header;
+  std::vector<MafRecord> recs;
+  bool on_device = false;
+  uint8_t* d_text = nullptr;
 };
+MafInput load_maf(Dev& d, const std::string* input) {
+  MafInput in;
+  *in.text = read_all(input);
+  const std::string& text = *in.text;
+  const char* force = getenv("WGA_MAF_READER"); /* "host": always the host reader (measurements) */
+  if (!text.empty() && text.size() < 0xFFFFFFF0ull && !(force && strcmp(force, "host") == 0)) {
+    d.init();
+    in.text->append(16, '\0'); /* slack behind the text for whole-vector loads */
+    in.d_text = d.upload((const uint8_t*)text.data(), text.size());
+    in.text->resize(text.size() - 16);
+    uint64_t n_lines = 0;
+    d.check(wga_maf_split(d.ctx, in.d_text, text.size(), &n_lines, nullptr, 0));
+    auto* d_lines = (wga_maf_line*)d.alloc((size_t)(n_lines + 1) * sizeof(wga_maf_line));
+    d.check(wga_maf_split(d.ctx, in.d_text, text.size(), &n_lines, d_lines, n_lines));
+    std::vector<wga_maf_line> lines((size_t)n_lines);
+    if (n_lines) d.download(lines.data(), d_lines, (size_t)n_lines);
+    d.release(d_lines);
+    bool plain = true;
+    for (const wga_maf_line& L : lines)
+      if (L.status == WGA_MAF_FALLBACK) plain = false;
+    if (plain) {
+      in.on_device = true;
+      size_t he = text.find('\n'); /* the first line is always the header (maf.rs:25-36) */
+      if (he == std::string::npos) he = text.size();
+      if (he > 0 && text[he - 1] == '\r') he--;
+      in.header.assign(text, 0, he);
+      bool open = false;
+      for (const wga_maf_line& L : lines) {
+        if (L.status != WGA_MAF_SLINE) { /* any other line ends the block in progress */
+          open = false;
+          continue;
+        }
+        if (!open) {
+          in.recs.emplace_back();
+          open = true;
+        }
+        MafSLine sl;
+        sl.name.assign(text, (size_t)L.name_off, L.name_len);
+        sl.start = L.num[0];
+        sl.align_size = L.num[1];
+        sl.size = L.num[2];
+        sl.neg = L.strand_neg != 0;
+        sl.file = text.data();
+        sl.seq_off = L.seq_off;
+        sl.seq_len = L.seq_len;
+        in.recs.back().slines.push_back(std::move(sl));
+      }
+      return in;
+    }
+    d.release(in.d_text);
+    in.d_text = nullptr;
+  }
+  in.recs = parse_maf(text, &in.header);
+  return in;
+}
+
+/* the (target row, query row) pairs of a list of blocks on the device: offsets into the uploaded file, or
+ * — host reader — into one buffer the rows are gathered in */
+struct MafRows {
+  const uint8_t* d_rows = nullptr;
+  uint64_t *d_t = nullptr, *d_q = nullptr, *d_c = nullptr;
+  uint8_t* d_s = nullptr;
+  std::vector<uint64_t> cols;
+};
+MafRows device_rows(Dev& d, const MafInput& in, const std::vector<const MafRecord*>& recs, bool cols_target) {
+  MafRows m;
+  std::vector<uint64_t> t_off, q_off;
+  std::vector<uint8_t> strand;
+  std::string blob;
+  for (const MafRecord* r : recs) {
+    const MafSLine &t = r->t(), &q = r->q();
+    if (in.on_device) {
+      t_off.push_back(t.seq_off);
+      q_off.push_back(q.seq_off);
+    } else {
+      t_off.push_back(blob.size());
+      blob.append(t.seq_data(), t.seq_size());
+      q_off.push_back(blob.size());
+      blob.append(q.seq_data(), q.seq_size());
+    }
+    /* zip truncates to the shorter row; `call` walks the target row's length (caller.rs:115) */
+    m.cols.push_back(cols_target ? t.seq_size() : std::min(t.seq_size(), q.seq_size()));
+    strand.push_back(q.neg ? 1 : 0);
+  }
+  d.init();
+  m.d_rows = in.on_device ? in.d_text : d.upload((const uint8_t*)blob.data(), blob.size());
+  m.d_t = d.upload(t_off);
+  m.d_q = d.upload(q_off);
+  m.d_c = d.upload(m.cols);
+  m.d_s = d.upload(strand);
+  return m;
+}
+std::vector<const MafRecord*> all_records(const std::vector<MafRecord>& recs) {
+  std::vector<const MafRecord*> v;
+  v.reserve(recs.size());
+  for (const auto& r : recs) v.push_back(&r);
+  return v;
+}
 void select_query(std::vector<MafRecord>& recs, const std::string* query_name) {
   for (auto& r : recs) {
     if (query_name) { /* maf.rs:277-285 */
@@ -530,34 +634,19 @@ void select_query(std::vector<MafRecord>& recs, const std::string* query_name) {
       fail("panic: MAF block with a single s-line has no query row (maf.rs:426 index out of bounds)");
   }
 }
-MafPairs gather_pairs(const std::vector<MafRecord>& recs) {
-  MafPairs p;
-  for (const auto& r : recs) {
-    p.t_off.push_back(p.rows.size());
-    p.rows += r.t().seq;
-    p.q_off.push_back(p.rows.size());
-    p.rows += r.q().seq;
-    p.cols.push_back(std::min(r.t().seq.size(), r.q().seq.size()));
-    p.strand.push_back(r.q().neg ? 1 : 0);
-  }
-  return p;
-}
 
 int cmd_stat_maf(const std::string* input, bool each, const std::string* query_name, Output& out) {
-  std::string header;
-  std::vector<MafRecord> recs = parse_maf(read_all(input), &header);
+  Dev d;
+  MafInput min = load_maf(d, input);
+  std::vector<MafRecord>& recs = min.recs;
   select_query(recs, query_name);
   const uint32_t n = (uint32_t)recs.size();
   std::vector<wga_cigar_counts> counts(n);
   if (n) {
-    MafPairs p = gather_pairs(recs);
-    Dev d;
-    d.init();
-    auto* d_rows = d.upload((const uint8_t*)p.rows.data(), p.rows.size());
+    MafRows p = device_rows(d, min, all_records(recs), false);
     auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
     auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
-    d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d.upload(p.t_off), d.upload(p.q_off), d.upload(p.cols),
-                              d.upload(p.strand), d_counts, d_cnt, nullptr, nullptr));
+    d.check(wga_maf_pair_stat(d.ctx, n, p.d_rows, p.d_t, p.d_q, p.d_c, p.d_s, d_counts, d_cnt, nullptr, nullptr));
     d.download(counts.data(), d_counts, n);
   }
   std::vector<StatInput> in;
@@ -573,18 +662,17 @@ int cmd_stat_maf(const std::string* input, bool each, const std::string* query_n
 
 /* ---- maf2paf (converter.rs:29-54, maf.rs:484-520) ------------------------------------------------ */
 int cmd_maf2paf(const std::string* input, const std::string* query_name, Output& out) {
-  std::string header;
-  std::vector<MafRecord> recs = parse_maf(read_all(input), &header);
+  Dev d;
+  MafInput min = load_maf(d, input);
+  std::vector<MafRecord>& recs = min.recs;
   select_query(recs, query_name);
   const uint32_t n = (uint32_t)recs.size();
   std::string text;
   if (n) {
-    MafPairs p = gather_pairs(recs);
-    Dev d;
-    d.init();
-    auto* d_rows = d.upload((const uint8_t*)p.rows.data(), p.rows.size());
-    auto *d_t = d.upload(p.t_off), *d_q = d.upload(p.q_off), *d_c = d.upload(p.cols);
-    auto* d_s = d.upload(p.strand);
+    MafRows p = device_rows(d, min, all_records(recs), false);
+    const uint8_t* d_rows = p.d_rows;
+    auto *d_t = p.d_t, *d_q = p.d_q, *d_c = p.d_c;
+    auto* d_s = p.d_s;
     auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
     auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
     d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, nullptr, nullptr));
@@ -1043,8 +1131,9 @@ int cmd_chain2paf(const std::string* input, Output& out) {
  * GPU: K3 column-pair runs -> packed ops (wga_maf_runs_ops) -> data lines and trims (wga_cigar_chain; '=' and X
  * runs add up into one block like cigar_cat's M).  Host: chain headers (chain.rs:103-140,185-203). */
 int cmd_maf2chain(const std::string* input, const std::string* query_name, Output& out) {
-  std::string header;
-  std::vector<MafRecord> recs = parse_maf(read_all(input), &header);
+  Dev d;
+  MafInput min = load_maf(d, input);
+  std::vector<MafRecord>& recs = min.recs;
   /* set_query_idx_byname fails per record, after the earlier records were written (:66-73) */
   std::string pending_error;
   size_t n_ok = recs.size();
@@ -1069,12 +1158,10 @@ int cmd_maf2chain(const std::string* input, const std::string* query_name, Outpu
   recs.resize(n_ok);
   const uint32_t n = (uint32_t)recs.size();
   if (n) {
-    MafPairs p = gather_pairs(recs);
-    Dev d;
-    d.init();
-    auto* d_rows = d.upload((const uint8_t*)p.rows.data(), p.rows.size());
-    auto *d_t = d.upload(p.t_off), *d_q = d.upload(p.q_off), *d_c = d.upload(p.cols);
-    auto* d_s = d.upload(p.strand);
+    MafRows p = device_rows(d, min, all_records(recs), false);
+    const uint8_t* d_rows = p.d_rows;
+    auto *d_t = p.d_t, *d_q = p.d_q, *d_c = p.d_c;
+    auto* d_s = p.d_s;
     auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
     auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
     d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, nullptr, nullptr));
@@ -1222,8 +1309,8 @@ int cmd_dotplot(const std::string* input, const std::string& format, const std::
       }
     }
   } else {
-    std::string header;
-    std::vector<MafRecord> recs = parse_maf(read_all(input), &header);
+    MafInput min = load_maf(d, input);
+    std::vector<MafRecord>& recs = min.recs;
     select_query(recs, query_name);
     const uint32_t n = (uint32_t)recs.size();
     for (const MafRecord& r : recs) {
@@ -1237,11 +1324,10 @@ int cmd_dotplot(const std::string* input, const std::string& format, const std::
       ali.push_back(r.t().align_size);
     }
     if (n && (base || !no_identity)) {
-      d.init();
-      MafPairs p = gather_pairs(recs);
-      auto* d_rows = d.upload((const uint8_t*)p.rows.data(), p.rows.size());
-      auto *d_t = d.upload(p.t_off), *d_q = d.upload(p.q_off), *d_c = d.upload(p.cols);
-      auto* d_s = d.upload(p.strand);
+      MafRows p = device_rows(d, min, all_records(recs), false);
+      const uint8_t* d_rows = p.d_rows;
+      auto *d_t = p.d_t, *d_q = p.d_q, *d_c = p.d_c;
+      auto* d_s = p.d_s;
       auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
       auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
       d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, nullptr, nullptr));
@@ -1637,7 +1723,7 @@ struct CallBlock {
   }
   /* n characters of the gap-stripped target / query row starting at non-gap index idx */
   std::string ref_slice(bool is_t, uint64_t idx, uint64_t n) const {
-    const std::string& row = is_t ? rec->t().seq : rec->q().seq;
+    const char* row = is_t ? rec->t().seq_data() : rec->q().seq_data();
     std::string out;
     size_t lo = 0, hi = runs.size(); /* last run whose prefix count is <= idx: it advances */
     while (hi - lo > 1) {
@@ -1653,7 +1739,7 @@ struct CallBlock {
       uint64_t b = is_t ? runs[k].tb : runs[k].qb, len = end(k) - runs[k].start;
       if (adv && idx < b + len) {
         uint64_t take = std::min(n, b + len - idx);
-        out.append(row, runs[k].start + (idx - b), take);
+        out.append(row + runs[k].start + (idx - b), take);
         idx += take;
         n -= take;
       }
@@ -1965,14 +2051,15 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
 
 int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, const std::string& sample,
                  const std::string* query_name, const std::string* query_regex, uint64_t chunk_size, Output& out) {
-  std::string header;
-  std::vector<MafRecord> all = parse_maf(read_all(input), &header);
+  Dev d;
+  MafInput min = load_maf(d, input);
+  std::vector<MafRecord>& all = min.recs;
   /* utils.rs:414-436: `<input>.index` (JSON written by `maf-index`) supplies ##contig lines */
   std::vector<std::pair<std::string, uint64_t>> contigs;
   if (input) contigs = maf_index_ref_contigs(*input + ".index");
   std::string text = vcf_header(sample, contigs);
   /* record selection (:62-108): single-s-line blocks and blocks without the asked query are skipped */
-  std::vector<MafRecord*> recs;
+  std::vector<const MafRecord*> recs;
   std::regex re;
   if (!query_name && query_regex) { /* cli.rs:332-343 anchors the pattern; maf.rs:267-271 searches from 0 */
     std::string pat = *query_regex;
@@ -1997,24 +2084,15 @@ int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, c
     } else {
       r.query_idx = 1;
     }
-    if (r.q().seq.size() < r.t().seq.size())
+    if (r.q().seq_size() < r.t().seq_size())
       fail("panic: query row shorter than the target row (caller.rs:175 slice out of range)");
     recs.push_back(&r);
   }
   const uint32_t n = (uint32_t)recs.size();
   if (n) {
-    MafPairs p;
-    for (const MafRecord* r : recs) {
-      p.t_off.push_back(p.rows.size());
-      p.rows += r->t().seq;
-      p.q_off.push_back(p.rows.size());
-      p.rows += r->q().seq;
-      p.cols.push_back(r->t().seq.size()); /* total_size = target row length (:115) */
-    }
-    Dev d;
-    d.init();
-    auto* d_rows = d.upload((const uint8_t*)p.rows.data(), p.rows.size());
-    auto *d_t = d.upload(p.t_off), *d_q = d.upload(p.q_off), *d_c = d.upload(p.cols);
+    MafRows p = device_rows(d, min, recs, true); /* total_size = target row length (:115) */
+    const uint8_t* d_rows = p.d_rows;
+    auto *d_t = p.d_t, *d_q = p.d_q, *d_c = p.d_c;
     auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
     d.check(wga_maf_call_runs(d.ctx, n, d_rows, d_t, d_q, d_c, d_cnt, nullptr, nullptr));
     auto* d_roff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
@@ -2145,6 +2223,20 @@ int main(int argc, char** argv) {
       for (const auto& a : rest) printf("%s\n", cs_to_cigar(a).c_str());
       return 0;
     }
+    if (cmd == "__maf_reader") { /* which reader takes this file, and the blocks it yields */
+      Dev d;
+      MafInput min = load_maf(d, rest.empty() ? nullptr : &rest[0]);
+      printf("%s\n%s\n", min.on_device ? "device" : "host", min.header.c_str());
+      for (const auto& r : min.recs) {
+        printf("block %zu", r.slines.size());
+        for (const auto& sl : r.slines)
+          printf(" [%s %llu %llu %c %llu %.*s]", sl.name.c_str(), (unsigned long long)sl.start,
+                 (unsigned long long)sl.align_size, sl.neg ? '-' : '+', (unsigned long long)sl.size,
+                 (int)std::min<size_t>(sl.seq_size(), 40), sl.seq_data());
+        printf("\n");
+      }
+      return 0;
+    }
     if (cmd == "__parse_chain") { /* host chain reader only: record and line counts */
       std::string e;
       std::vector<ChainRecord> recs = parse_chain(read_all(rest.empty() ? nullptr : &rest[0]), &e);
@@ -2196,7 +2288,7 @@ int main(int argc, char** argv) {
           for (const auto& sl : r.slines)
             printf(" [%s %llu %llu %c %llu %zu]", sl.name.c_str(), (unsigned long long)sl.start,
                    (unsigned long long)sl.align_size, sl.neg ? '-' : '+', (unsigned long long)sl.size,
-                   sl.seq.size());
+                   sl.seq_size());
           printf("\n");
         }
       }
