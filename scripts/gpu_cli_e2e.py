@@ -47,3 +47,40 @@ run("chain2paf", ["chain2paf", os.path.join(tmp, "out.chain")], os.path.join(tmp
 run("stat/host", ["stat", "-f", "paf", paf], os.path.join(tmp, "out.tsv"), env={"WGA_PAF_READER": "host"})
 run("p2c/host", ["paf2chain", paf], os.path.join(tmp, "out.chain"), env={"WGA_PAF_READER": "host"})
 run("stat", ["stat", "-f", "paf", paf], os.path.join(tmp, "out.tsv"))
+# ---- MAF commands on a config-3 shaped file: NB blocks x 1500 columns ----------------------------------
+nb = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000
+rng = np.random.default_rng(3)
+cols = 1500
+alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+maf = os.path.join(tmp, "in.maf")
+with open(maf, "wb") as f:
+    f.write(b"##maf version=1\n")
+    CH = 2000
+    for c0 in range(0, nb, CH):
+        m = min(CH, nb - c0)
+        t = alpha[rng.integers(0, 4, (m, cols))]
+        q = t.copy()
+        snp = rng.random((m, cols)) < 0.012
+        q[snp] = alpha[rng.integers(0, 4, int(snp.sum()))]
+        gap = rng.random((m, cols)) < 0.0015
+        q[gap] = 45
+        gap2 = rng.random((m, cols)) < 0.0015
+        t[gap2 & ~gap] = 45
+        for k in range(m):
+            tal = cols - int((t[k] == 45).sum()); qal = cols - int((q[k] == 45).sum())
+            f.write(b"a score=255\ns\tref.chr1\t%d\t%d\t+\t250000000\t" % (1000 * (c0 + k), tal) + t[k].tobytes() +
+                    b"\ns\tqry.chr1\t%d\t%d\t%s\t240000000\t" % (900 * (c0 + k), qal, b"-" if (c0 + k) % 10 == 0 else b"+") + q[k].tobytes() + b"\n\n")
+ncol = nb * cols
+print("MAF input: %d blocks, %.3e columns, %.1f MB" % (nb, ncol, os.path.getsize(maf) / 1e6))
+def runm(name, args, outp, env=None):
+    t0 = time.perf_counter()
+    r = subprocess.run([cli] + args + ["-o", outp, "-r"], stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})))
+    dt = time.perf_counter() - t0
+    sz = os.path.getsize(outp) if os.path.exists(outp) else 0
+    print("%-13s %.2f s wall  rc=%d  output %.1f MB  -> %.2e columns/s end to end" % (name, dt, r.returncode, sz / 1e6, ncol / dt))
+    if r.returncode: print(r.stderr.decode()[-300:])
+for env, tag in (({}, ""), ({"WGA_MAF_READER": "host"}, "/host")):
+    runm("stat maf" + tag, ["stat", maf], os.path.join(tmp, "m.tsv"), env)
+    runm("maf2paf" + tag, ["maf2paf", maf], os.path.join(tmp, "m.paf"), env)
+    runm("call -s" + tag, ["call", "-s", "-l", "50", maf], os.path.join(tmp, "m.vcf"), env)
+    runm("maf2chain" + tag, ["maf2chain", maf], os.path.join(tmp, "m.chain"), env)
