@@ -1,7 +1,8 @@
 /*
  * oracle.c — CPU restatement of wgatools' CIGAR hot path.  TEST INFRASTRUCTURE ONLY
- * (see oracle.h for the usage rule and the parity-pinning statement: README VCF golden pins the
- * `call` walk; stat / paf2maf / maf2paf / pafcov / pafpseudo are "parity unpinned").
+ * (see oracle.h for the usage rule and the parity-pinning statement: the README VCF golden pins the
+ * `call` walk, the data rows of the reference's test/test.html pin the dotplot segment fold; stat /
+ * paf2maf / maf2paf / pafcov / pafpseudo / the chain converters are "parity unpinned").
  *
  * Deliberately naive: it keeps the reference's algorithmic structure — text tokenising per
  * consumer, String::insert_str / drain with tail memmove (quadratic), per-base coverage

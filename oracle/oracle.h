@@ -9,10 +9,12 @@
  *
  * PARITY PINNING.  The reference (Rust) cannot be built or run in this environment and has no
  * unit tests.  Pinned: orc_call_within_var + orc_find_safe_chunk_boundary + orc_cigar_cat_ext_caller
- * reproduce the only golden output in the reference repository (README.md:323-343, VCF of
- * `wgatools call test/test.maf -s -l0`; tests/test_oracle_golden.py).  Everything else —
- * stat, paf2maf, maf2paf, pafcov, pafpseudo — is checked only against expected outputs derived
- * by reading the code: for those paths this oracle is **parity unpinned**.
+ * reproduce the golden VCF of the reference repository (README.md:323-343, `wgatools call
+ * test/test.maf -s -l0`), and orc_cigar_to_base_plotdata reproduces the data rows of its committed
+ * test/test.html (`dotplot` of test/testdotplot.paf, record 1); both in tests/test_oracle_golden.py.
+ * Everything else — stat, paf2maf, maf2paf, pafcov, pafpseudo, the chain converters — is checked
+ * only against expected outputs derived by reading the code: for those
+ * paths this oracle is **parity unpinned**.
  */
 #ifndef WGA_ORACLE_H
 #define WGA_ORACLE_H

@@ -864,3 +864,15 @@ def test_maf_reader_selection(cli, tmp_path):
         finally:
             del os.environ["WGA_MAF_READER"]
         assert rc == 0 and a == b, args
+
+
+def test_dotplot_test_html_golden(cli):
+    """the reference's committed test/test.html rows (tests/golden/test_html_values.json) through the command line"""
+    import json
+    want = json.load(open(os.path.join(GOLDEN, "test_html_values.json")))
+    rc, out, err = run(cli, "dotplot", "-f", "paf", "--out-format", "csv", "-l", "9", os.path.join(GOLDEN, "testdotplot.paf"))
+    assert rc == 0, err
+    rows = out.decode().splitlines()
+    assert rows[0] == "ref_start,ref_end,query_start,query_end,cigar,ref_chro,query_chro"
+    assert rows[1:1 + len(want)] == ["%d,%d,%d,%d,%s,%s,%s" % (w["ref_start"], w["ref_end"], w["query_start"], w["query_end"],
+                                                            w["cigar"], w["ref_chro"], w["query_chro"]) for w in want]

@@ -2,6 +2,8 @@
 
 * The README VCF (reference README.md:323-343) is the only golden *output* in the reference repo:
   it pins the MAF column walk of `call` (caller.rs:388-608) incl. cigar_cat_ext_caller/group_by.
+* test/test.html (a committed `dotplot` output) holds the base-level segments of record 1 of
+  test/testdotplot.paf: it pins the fold over emit_baseplotdatas (cigar.rs:815-952).
 * test/test.maf and test/testdotplot.paf are the reference's demo inputs; their expected stat /
   maf2paf / pafcov results were derived by reading the code — those
   assertions document the semantics but are "parity unpinned".
@@ -158,3 +160,18 @@ def test_cs_to_cigar():
     """paf.rs:154-158 doc example"""
     assert orc.cs_to_cigar(":6-ata:10+gtc:4*at*tg:3") == "6M3D10M3I4M2X3M"
     assert orc.cs_to_cigar(":5=ACGT*ag:2") == "5M1X2M"
+
+
+def test_dotplot_test_html_golden():
+    """the data rows of the reference's committed test/test.html = `dotplot` base-level segments of record 1 of
+    test/testdotplot.paf (the file predates the second record and the cutoff default of 50: any cutoff below the
+    record's shortest indel, 10, reproduces it)"""
+    import json
+    want = json.load(open(os.path.join(GOLDEN, "test_html_values.json")))
+    line = open(os.path.join(GOLDEN, "testdotplot.paf")).read().splitlines()[0].split("\t")
+    cg = [t for t in line[12:] if t.startswith("cg:Z:")][0]
+    for cutoff in (0, 9):
+        segs = orc.cigar_to_base_plotdata(cg, int(line[7]), int(line[2]), line[4] == "-", cutoff)
+        got = [dict(cigar="MID"[int(s[4])], query_chro=line[0], query_end=int(s[3]), query_start=int(s[2]),
+                    ref_chro=line[5], ref_end=int(s[1]), ref_start=int(s[0])) for s in segs]
+        assert got == want

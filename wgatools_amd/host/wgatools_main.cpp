@@ -7,6 +7,7 @@
  *   paf2maf | p2m   converter.rs:176-265      stat | st      tools/stat.rs:61-126
  *   maf2paf | m2p   converter.rs:29-54        pafcov | pc    tools/pafcov.rs:13-83
  */
+#include <errno.h>
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
@@ -1526,8 +1527,13 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
   if (outdir == "-") fail("Stdout not allowed here"); /* errors.rs:37 */
   struct stat st;
   if (stat(outdir.c_str(), &st) != 0) {
-    std::string cmd = "mkdir -p '" + outdir + "'";
-    if (system(cmd.c_str()) != 0) fail("IO error:cannot create directory `" + outdir + "`");
+    /* create_dir_all: every missing component, no shell involved */
+    for (size_t k = 1; k <= outdir.size(); k++)
+      if (k == outdir.size() || outdir[k] == '/') {
+        const std::string part = outdir.substr(0, k);
+        if (mkdir(part.c_str(), 0777) != 0 && errno != EEXIST)
+          fail("IO error:cannot create directory `" + outdir + "`: " + strerror(errno));
+      }
   } else {
     if (!S_ISDIR(st.st_mode)) fail("Path `" + outdir + "` is not a dir");
     if (!rewrite) fail("File `" + outdir + "` already exists, please add `-r` to rewrite it.");
