@@ -413,6 +413,33 @@ def test_paf_split(gpu):
 
 
 
+def test_maf_pair_long_rows_fold_lane_counters(gpu):
+    """rows beyond 4095 steps of 1024 columns: the 16-bit lane counters are folded into the wave totals on the way
+    (the emulator build of the CPU suite folds every 3 steps instead); counts against the oracle"""
+    rng = np.random.default_rng(21)
+    L = 4095 * 1024 * 2 + 1500
+    t = pc.rand_seq(rng, L, b"ACGTacgt--N")
+    q = pc.rand_seq(rng, L, b"ACGTacgt--N")
+    pairs, strands = [(t, q), (t[:70000], q[:70000]), (t[:4095 * 1024], q[:4095 * 1024])], [1, 0, 0]
+    buf, t_off, q_off = bytearray(b"@@@"), [], []
+    for a, b in pairs:
+        t_off.append(len(buf))
+        buf += a + b"@"
+        q_off.append(len(buf))
+        buf += b + b"@@"
+    rows = gpu.upload(np.frombuffer(bytes(buf), dtype=np.uint8))
+    n = len(pairs)
+    counts, run_cnt = gpu.maf_pair_stat(n, rows, gpu.upload(np.array(t_off, dtype=np.uint64)),
+                                        gpu.upload(np.array(q_off, dtype=np.uint64)),
+                                        gpu.upload(np.array([len(a) for a, _ in pairs], dtype=np.uint64)),
+                                        gpu.upload(np.array(strands, dtype=np.uint8)))
+    c, rc = counts.numpy(), run_cnt.numpy()
+    for i, (a, b) in enumerate(pairs):
+        exp_counts, exp_txt = orc.parse_maf_seq_to_cigar(a, b, strands[i])
+        assert tuple(int(x) for x in c[i]) == exp_counts, (i, exp_counts, c[i])
+        assert int(rc[i]) == sum(1 for ch in exp_txt if not ch.isdigit())
+
+
 def test_maf_split(gpu):
     rng = np.random.default_rng(8)
     def block(k, cols, extra=b""):

@@ -65,7 +65,8 @@ def build_emu(force=False):
     srcs = _sources() + [os.path.join(ROOT, "tests", "emu", "simt_emu.h")]
     if not force and not _newer(EMU_LIB, srcs):
         return EMU_LIB
-    _run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DWGA_EMU", "-Wall",
+    # -DWGA_MAF_FOLD_STEPS: fold the MAF walks' 16-bit lane counters every 3 steps, so that small test rows reach that path
+    _run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DWGA_EMU", "-DWGA_MAF_FOLD_STEPS=3u", "-Wall",
           "-Wno-unknown-pragmas", "-I" + os.path.join(ROOT, "tests", "emu")] + STAGE2
          + [os.path.join(CSRC, "wga_capi.cpp"), os.path.join(CSRC, "wga_pack.cpp"), "-o", EMU_LIB])
     return EMU_LIB

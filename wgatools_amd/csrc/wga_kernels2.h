@@ -706,6 +706,9 @@ __device__ __forceinline__ u32 zero_bytes(u32 x) { /* 0x80 in every byte of x th
 }
 __device__ __forceinline__ u32 popc32(u32 x) { return (u32)__builtin_popcount(x); }
 
+#ifndef WGA_MAF_FOLD_STEPS
+#define WGA_MAF_FOLD_STEPS 4095u /* the emulator build of the tests folds every few steps instead */
+#endif
 #ifndef WGA_K3_BLOCKS
 #define WGA_K3_BLOCKS 8 /* blocks per CU the register budget of k_maf_pair_stat is sized for */
 #endif
@@ -719,10 +722,13 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
                                          u64* rout, MafWalkOut& out) {
   const u32 lane = threadIdx.x & 63u;
   constexpr int NC = CALLER ? 5 : 4;
-  u32 ncol[NC], nrun[NC];
-  u64 ncol_hi[NC];
+  /* per-lane counters of classes 1..NC-1, columns in the low and run starts in the high 16 bits (a step adds at
+   * most 16 to either): folded into wave-uniform totals before they can wrap.  Class 0 needs none: its columns
+   * and runs are what is left of L and of the run total. */
+  u32 pk[NC];
+  u64 Ctot[NC], Rtot[NC];
 #pragma unroll
-  for (int k = 0; k < NC; k++) ncol[k] = nrun[k] = 0u, ncol_hi[k] = 0ull;
+  for (int k = 0; k < NC; k++) pk[k] = 0u, Ctot[k] = Rtot[k] = 0ull;
   u32 carry_cls = 0xFFu; /* class of the column before this step's first one */
   u64 run_base = 0, t_base = 0, q_base = 0;
   u32 steps = 0;
@@ -761,12 +767,11 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
       cls[d] = (cI >> 7) | (cD >> 6) | ((cX >> 7) * 3u) | (cW >> 5); /* 0..4 in every byte */
       tn[d] = ~tg & vm[d];
       qn[d] = ~qg & vm[d];
-      ncol[1] += popc32(cI & vm[d]);
-      ncol[2] += popc32(cD & vm[d]);
-      ncol[3] += popc32(cX & vm[d]);
-      if (CALLER) ncol[4] += popc32(cW & vm[d]);
+      pk[1] += popc32(cI & vm[d]);
+      pk[2] += popc32(cD & vm[d]);
+      pk[3] += popc32(cX & vm[d]);
+      if (CALLER) pk[NC - 1] += popc32(cW & vm[d]);
     }
-    ncol[0] += nv;
     /* class of the column before each byte: bytes shifted up by one across the 16-byte vector */
     const u32 my_last = nv ? ((cls[(nv - 1u) >> 2] >> (8u * ((nv - 1u) & 3u))) & 0xFFu) : 0xFEu;
     u32 prev_last = __shfl_up(my_last, 1u);
@@ -780,16 +785,20 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
       nst += popc32(st[d]);
     }
     /* per-class run starts: a start byte's class */
+    u32 rs1 = 0, rs2 = 0, rs3 = 0, rs4 = 0;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
       const u32 s7 = st[d] >> 7; /* 1 in the low bit of start bytes */
       const u32 k = cls[d];
-      nrun[1] += popc32(s7 & k & ~(k >> 1) & ~(k >> 2) & 0x01010101u);          /* class 1: 001 */
-      nrun[2] += popc32(s7 & (k >> 1) & ~k & 0x01010101u);                     /* class 2: 010 */
-      nrun[3] += popc32(s7 & (k >> 1) & k & 0x01010101u);                      /* class 3: 011 */
-      if (CALLER) nrun[4] += popc32(s7 & (k >> 2) & 0x01010101u);              /* class 4: 100 */
+      rs1 += popc32(s7 & k & ~(k >> 1) & ~(k >> 2) & 0x01010101u);          /* class 1: 001 */
+      rs2 += popc32(s7 & (k >> 1) & ~k & 0x01010101u);                     /* class 2: 010 */
+      rs3 += popc32(s7 & (k >> 1) & k & 0x01010101u);                      /* class 3: 011 */
+      if (CALLER) rs4 += popc32(s7 & (k >> 2) & 0x01010101u);              /* class 4: 100 */
     }
-    nrun[0] += nst;
+    pk[1] += rs1 << 16;
+    pk[2] += rs2 << 16;
+    pk[3] += rs3 << 16;
+    if (CALLER) pk[NC - 1] += rs4 << 16;
     /* ordered run list: wave-exclusive offsets of the per-lane start counts */
     const u32 incl = wave_incl_scan_u32(nst);
     const u32 tnc = popc32(tn[0]) + popc32(tn[1]) + popc32(tn[2]) + popc32(tn[3]);
@@ -836,33 +845,31 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
     const u64 has = __ballot(nv != 0u);
     const int last_lane = 63 - (int)__builtin_clzll(has); /* has != 0 inside the loop */
     carry_cls = __shfl(my_last, last_lane);
-    if (++steps == 0x00100000u) { /* keep the u32 lane counters from wrapping (16 per step) */
+    if (++steps == WGA_MAF_FOLD_STEPS) { /* 16 x 4095 < 2^16: fold the lane counters before a half can wrap */
 #pragma unroll
-      for (int k = 0; k < NC; k++) ncol_hi[k] += ncol[k], ncol[k] = 0u;
+      for (int k = 1; k < NC; k++) {
+        Ctot[k] += wave_sum_u32(pk[k] & 0xFFFFu);
+        Rtot[k] += wave_sum_u32(pk[k] >> 16);
+        pk[k] = 0u;
+      }
       steps = 0;
     }
   }
   /* class 0 columns / runs = all minus the others */
   u64 C[NC], R[NC];
-  if (L < 65536u) { /* every wave total fits 16 bits: two quantities per scan */
-    const u32 a0 = wave_sum_u32(ncol[0] | (nrun[0] << 16));
-    const u32 a1 = wave_sum_u32(ncol[1] | (ncol[2] << 16));
-    const u32 a2 = wave_sum_u32(nrun[1] | (nrun[2] << 16));
-    const u32 a3 = wave_sum_u32(ncol[3] | (nrun[3] << 16));
-    C[0] = a0 & 0xFFFFu, R[0] = a0 >> 16;
-    C[1] = a1 & 0xFFFFu, C[2] = a1 >> 16;
-    R[1] = a2 & 0xFFFFu, R[2] = a2 >> 16;
-    C[3] = a3 & 0xFFFFu, R[3] = a3 >> 16;
-    if (CALLER) {
-      const u32 a4 = wave_sum_u32(ncol[NC - 1] | (nrun[NC - 1] << 16));
-      C[NC - 1] = a4 & 0xFFFFu, R[NC - 1] = a4 >> 16;
+  C[0] = L;
+  R[0] = run_base;
+  if (L < 65536u && L <= (u64)(WGA_MAF_FOLD_STEPS - 1u) * 1024u) { /* no fold happened and every wave total fits 16 bits: both halves in one scan */
+#pragma unroll
+    for (int k = 1; k < NC; k++) {
+      const u32 a = wave_sum_u32(pk[k]);
+      C[k] = a & 0xFFFFu, R[k] = a >> 16;
     }
   } else {
-    const bool spilled = L >= (u64)0x00100000u * 1024u; /* the lane counters were folded at least once */
 #pragma unroll
-    for (int k = 0; k < NC; k++) {
-      C[k] = wave_sum_u32_wide(ncol[k]) + (spilled ? wave_sum_u64(ncol_hi[k]) : 0ull);
-      R[k] = wave_sum_u32_wide(nrun[k]);
+    for (int k = 1; k < NC; k++) {
+      C[k] = Ctot[k] + wave_sum_u32(pk[k] & 0xFFFFu);
+      R[k] = Rtot[k] + wave_sum_u32(pk[k] >> 16);
     }
   }
   u64 oc = 0, orn = 0;
