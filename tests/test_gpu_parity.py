@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 
+import oracle_py as orc
 import parity_cases as pc
 from wgatools_amd import engine, synth
 
