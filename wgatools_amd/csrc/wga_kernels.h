@@ -87,6 +87,16 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
    (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(u64)(x)))
 #endif
 
+/* index of the wave inside its block.  threadIdx.x >> 6 is the same in all 64 lanes, but the compiler's
+ * divergence analysis does not know: everything derived from it (tile / record index, offsets loaded with it,
+ * loop bounds) would be treated as per-lane — vector loads, exec-masked loops, VGPR-held "uniform" values.
+ * WGA_WAVE_ID(t) can be switched back to the plain shift with -DWGA_WAVE_ID_PLAIN for A/B measurements. */
+#if defined(WGA_EMU) || defined(WGA_WAVE_ID_PLAIN)
+#define WGA_WAVE_ID(t) ((u32)(t) >> 6)
+#else
+#define WGA_WAVE_ID(t) ((u32)__builtin_amdgcn_readfirstlane((int)((u32)(t) >> 6)))
+#endif
+
 /* keep the computation of a value where it is written (the compiler otherwise sinks LDS reads into
  * exec-masked branches "to save them", which costs more in branch overhead than the reads) */
 #ifdef WGA_EMU
@@ -125,6 +135,20 @@ __device__ __forceinline__ u32 wave_last_u32(u32 incl) {
   return (u32)__builtin_amdgcn_readlane((int)incl, 63);
 #endif
 }
+/* v with lane K's copy replaced by a wave-uniform value (v_writelane_b32 x 2; this clang has no builtin for it) */
+template <u32 K>
+__device__ __forceinline__ u64 lane_put_u64(u64 v, u64 uniform_val, u32 lane) {
+#ifdef WGA_EMU
+  return lane == K ? uniform_val : v;
+#else
+  (void)lane;
+  u32 lo = (u32)v, hi = (u32)(v >> 32);
+  const u32 ulo = WGA_UNI32((u32)uniform_val), uhi = WGA_UNI32((u32)(uniform_val >> 32));
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"(ulo), "n"(K));
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"(uhi), "n"(K));
+  return ((u64)hi << 32) | (u64)lo;
+#endif
+}
 /* exact sum of 64 u32 values (up to 2^38): two 16-bit halves scanned separately */
 __device__ __forceinline__ u64 wave_sum_u32_wide(u32 v) {
   const u32 lo = wave_last_u32(wave_incl_scan_u32(v & 0xFFFFu));
@@ -144,7 +168,7 @@ __device__ __forceinline__ u32 wave_min_u32(u32 v) {
  * s_w4: 16 words of LDS. */
 __device__ __forceinline__ void block_excl_scan4_u32(const u32 v[4], u32 ex[4], u32 tot[4],
                                                      u32* s_w4, bool s_w4_idle = false) {
-  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const u32 lane = threadIdx.x & 63u, wave = WGA_WAVE_ID(threadIdx.x);
   u32 inc[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) inc[k] = wave_incl_scan_u32(v[k]);
@@ -226,7 +250,7 @@ __global__ __launch_bounds__(256, 5) void k_cigar_stat(const u32* __restrict__ o
                                                     wga_cigar_counts* counts,
                                                     wga_rec_diag* diag, wga_tile_sum* tiles) {
   const u32 lane = threadIdx.x & 63u;
-  const u32 wave = threadIdx.x >> 6;
+  const u32 wave = WGA_WAVE_ID(threadIdx.x);
   const u64 g = (u64)blockIdx.x * 4 + wave;
   const u64 tile_start = g * WGA_TILE;
   if (tile_start >= n_ops) return; /* wave-uniform; this kernel has no block barrier */
@@ -318,6 +342,38 @@ __global__ __launch_bounds__(256, 5) void k_cigar_stat(const u32* __restrict__ o
     const u32 BAD = any_rare ? wave_min_u32(bad) : 0xFFFFFFFFu;
     const u64 Smatch = S[0] - Sx;
 
+#if WGA_K1_LANE_STORE
+    {
+      /* the 11 counters go out from lanes 0..10, one field per lane (v_writelane from the wave-uniform sums):
+       * one 88-byte store — or one atomic instruction when the record spans tiles — instead of eleven, and
+       * two registers instead of twenty-two */
+      const bool whole = rs >= tile_start && re <= tile_end;
+      const u64 match = Smatch, mism = S[0] - Smatch;
+      const u64 iev = EV & 0xFFFFu, dev = EV >> 16;
+      const u64 z = 0;
+      u64 v = 0;
+      v = lane_put_u64<0u>(v, match, lane);
+      v = lane_put_u64<1u>(v, mism, lane);
+      v = lane_put_u64<2u>(v, neg ? z : iev, lane);   /* ins_ev.. or inv_ins_ev.. (cigar.rs:667-684) */
+      v = lane_put_u64<3u>(v, neg ? z : S[1], lane);
+      v = lane_put_u64<4u>(v, neg ? z : dev, lane);
+      v = lane_put_u64<5u>(v, neg ? z : S[2], lane);
+      v = lane_put_u64<6u>(v, neg ? iev : z, lane);
+      v = lane_put_u64<7u>(v, neg ? S[1] : z, lane);
+      v = lane_put_u64<8u>(v, neg ? dev : z, lane);
+      v = lane_put_u64<9u>(v, neg ? S[2] : z, lane);
+      /* inv_event = 1 per '-' record: stored with a whole record, added once by the record's first tile */
+      v = lane_put_u64<10u>(v, (neg && (whole || rs >= tile_start)) ? (u64)1 : z, lane);
+      u64* const f = (u64*)(counts + r);
+      if (lane < 11u) {
+        if (whole)
+          f[lane] = v; /* the record lives in this tile only: plain stores */
+        else if (v)
+          atomicAdd(f + lane, v); /* record spans tiles: counts were zeroed by the launcher */
+      }
+      if (lane == 0 && BAD != 0xFFFFFFFFu) atomicMin((u64*)&diag[r].bad_op_idx, tile_start + BAD - rs);
+    }
+#else
     if (lane == 0) {
       const bool whole = rs >= tile_start && re <= tile_end;
       const u64 match = Smatch, mism = S[0] - Smatch;
@@ -348,6 +404,7 @@ __global__ __launch_bounds__(256, 5) void k_cigar_stat(const u32* __restrict__ o
       }
       if (BAD != 0xFFFFFFFFu) atomicMin((u64*)&diag[r].bad_op_idx, tile_start + BAD - rs);
     }
+#endif
 #pragma unroll
     for (int c = 0; c < 5; c++) {
       tot[c] += S[c];
@@ -357,6 +414,23 @@ __global__ __launch_bounds__(256, 5) void k_cigar_stat(const u32* __restrict__ o
     r++;
     if (cur < tile_end) re = op_off[r + 1];
   }
+#if WGA_K1_LANE_STORE
+  if (tiles) { /* wga_tile_sum = tot[5], tail[5], rec: one field per lane */
+    u64 v = 0;
+    v = lane_put_u64<0u>(v, tot[0], lane);
+    v = lane_put_u64<1u>(v, tot[1], lane);
+    v = lane_put_u64<2u>(v, tot[2], lane);
+    v = lane_put_u64<3u>(v, tot[3], lane);
+    v = lane_put_u64<4u>(v, tot[4], lane);
+    v = lane_put_u64<5u>(v, tail[0], lane);
+    v = lane_put_u64<6u>(v, tail[1], lane);
+    v = lane_put_u64<7u>(v, tail[2], lane);
+    v = lane_put_u64<8u>(v, tail[3], lane);
+    v = lane_put_u64<9u>(v, tail[4], lane);
+    v = lane_put_u64<10u>(v, (u64)r_first, lane);
+    if (lane < 11u) ((u64*)(tiles + g))[lane] = v;
+  }
+#else
   if (tiles && lane == 0) {
     wga_tile_sum ts;
 #pragma unroll
@@ -367,13 +441,14 @@ __global__ __launch_bounds__(256, 5) void k_cigar_stat(const u32* __restrict__ o
     ts.rec = r_first;
     tiles[g] = ts;
   }
+#endif
 }
 
 /* ============================================================================================ */
 /* block-level exclusive scan helpers (256 threads)                                             */
 /* ============================================================================================ */
 __device__ __forceinline__ u64 block_excl_scan_u64(u64 v, u64* s_w /*[5]*/, u64* total) {
-  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const u32 lane = threadIdx.x & 63u, wave = WGA_WAVE_ID(threadIdx.x);
   u64 inc = v;
   for (u32 d = 1; d < 64; d <<= 1) {
     u64 t = __shfl_up(inc, d);
@@ -789,6 +864,9 @@ __device__ __forceinline__ u32 wave_get_u32(u32 v, int k) {
 #ifndef WGA_SPLIT_BYTES
 #define WGA_SPLIT_BYTES 8192u /* ... in two halves beyond this */
 #endif
+#ifndef WGA_K1_LANE_STORE
+#define WGA_K1_LANE_STORE 1 /* K1 writes its counters one field per lane (v_writelane) instead of from lane 0 */
+#endif
 #ifndef WGA_MBCNT
 #define WGA_MBCNT 1
 #endif
@@ -829,7 +907,7 @@ __device__ __forceinline__ void tbl_scan(u32* tbl, u32* s_w4) {
     v[e] = tbl[tid * (WGA_TBL_N / WGA_BLOCK) + e];
     sum += v[e];
   }
-  const u32 lane = tid & 63u, wave = tid >> 6;
+  const u32 lane = tid & 63u, wave = WGA_WAVE_ID(tid);
   const u32 inc = wave_incl_scan_u32(sum);
   if (lane == 63u) s_w4[wave] = inc; /* callers have a barrier between the last use of s_w4 and this */
   __syncthreads();
@@ -1019,7 +1097,7 @@ __device__ __forceinline__ void emit_row_t(u8* dst, u32 N, u32 c0, const RowDesc
   src.rc = RC;
   const u32 lane = tid & 63u;
   const RowGeom rg = row_geom(dst, N, c0);
-  u32* const queue = rd.queue + (threadIdx.x >> 6) * WGA_QCAP; /* the wave's own, whoever it works with */
+  u32* const queue = rd.queue + WGA_WAVE_ID(threadIdx.x) * WGA_QCAP; /* the wave's own, whoever it works with */
   u32 qn = 0; /* wave-uniform queue length */
   const u32 per_it = nthreads * WGA_EMIT_U;
   const u32 niter = (rg.nchunks + per_it - 1) / per_it;
@@ -1353,7 +1431,7 @@ __global__ __launch_bounds__(256, 5) void k_paf2maf_expand(ExpandArgs a) {
 #endif
 
   const u32 tid = threadIdx.x;
-  const u32 lane = tid & 63u, wave = tid >> 6;
+  const u32 lane = tid & 63u, wave = WGA_WAVE_ID(tid);
   const u64 g = blockIdx.x;
   const u64 tile_start = g * WGA_TILE;
   const u64 tile_end = tile_start + WGA_TILE < a.n_ops ? tile_start + WGA_TILE : a.n_ops;
@@ -1718,7 +1796,7 @@ __global__ __launch_bounds__(256) void k_scatter_bytes(u32 n, const u8* src, con
                                                        u8* dst, const u64* dst_off) {
   /* one wave per snippet; snippets are tens of bytes */
   const u32 lane = threadIdx.x & 63u;
-  const u64 i = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const u64 i = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
   if (i >= n) return;
   const u64 s0 = src_off[i], s1 = src_off[i + 1], d0 = dst_off[i];
   for (u64 k = s0 + lane; k < s1; k += 64) dst[d0 + (k - s0)] = src[k];

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k_class_tiles(const u32* __restrict__ ops
                                                      u64 n_ops, wga_tile_sum* tiles,
                                                      wga_class_sums* rec_sums) {
   const u32 lane = threadIdx.x & 63u;
-  const u32 wave = threadIdx.x >> 6;
+  const u32 wave = WGA_WAVE_ID(threadIdx.x);
   const u64 g = (u64)blockIdx.x * 4 + wave;
   const u64 tile_start = g * WGA_TILE;
   if (tile_start >= n_ops) return;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_cov_pieces(
     const u64* __restrict__ cov_len, u32* win_cnt, const u64* __restrict__ win_off,
     wga_cov_piece* pieces) {
   const u32 lane = threadIdx.x & 63u;
-  const u64 g = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const u64 g = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
   const u64 tile_start = g * WGA_TILE;
   if (tile_start >= n_ops) return;
   const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_cov_windows(const u32* __restrict__ ops
                                                      const wga_cov_piece* __restrict__ pieces,
                                                      const u64* __restrict__ win_off, int* cov) {
   __shared__ int s_win[WGA_COV_WIN];
-  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = WGA_WAVE_ID(tid);
   const u64 wi = blockIdx.x;
   const u64 p_lo = win_off[wi], p_hi = win_off[wi + 1];
   if (p_lo == p_hi) return; /* block-uniform */
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
 
   const u32 tid = threadIdx.x;
   build_lowmask(s_lowmask);
-  const u32 lane = tid & 63u, wave = tid >> 6;
+  const u32 lane = tid & 63u, wave = WGA_WAVE_ID(tid);
   const u64 g = blockIdx.x;
   const u64 tile_start = g * WGA_TILE;
   const u64 tile_end = tile_start + WGA_TILE < a.n_ops ? tile_start + WGA_TILE : a.n_ops;
@@ -889,7 +889,7 @@ __global__ __launch_bounds__(256, WGA_K3_BLOCKS) void k_maf_pair_stat(u32 n, con
                                                        wga_cigar_counts* counts, u64* run_cnt,
                                                        u64* runs, const u64* run_off) {
   const u32 lane = threadIdx.x & 63u;
-  const u64 i = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const u64 i = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
   if (i >= n) return;
   MafWalkOut w;
   maf_walk<false>(rows + t_off[i], rows + q_off[i], cols[i], runs ? runs + run_off[i] : (u64*)0, w);
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(256) void k_maf_call_runs(u32 n, const u8* __restri
                                                        const u64* cols, u64* run_cnt, u64* runs,
                                                        const u64* run_off) {
   const u32 lane = threadIdx.x & 63u;
-  const u64 i = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const u64 i = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
   if (i >= n) return;
   MafWalkOut w;
   maf_walk<true>(rows + t_off[i], rows + q_off[i], cols[i], runs ? runs + 3 * run_off[i] : (u64*)0, w);
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(256) void k_paf_call_events(u32 n, const u32* __res
                                                          u32 snp, u64* ev_cnt, u64* ev,
                                                          const u64* ev_off) {
   const u32 lane = threadIdx.x & 63u;
-  const u64 i = (u64)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const u64 i = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
   if (i >= n) return;
   const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
   const u32* rec = ops + o0;
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(256) void k_cigar_tokenise(u32 n, const u8* __restr
                                                         u64* op_cnt, wga_tok_err_dev* errs,
                                                         u32* ops, const u64* op_off) {
   __shared__ __attribute__((aligned(16))) u8 s_txt[4][WGA_TOK_HIST + 1024u + 16u];
-  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const u32 lane = threadIdx.x & 63u, wave = WGA_WAVE_ID(threadIdx.x);
   const u64 i = (u64)blockIdx.x * 4 + wave;
   if (i >= n) return;
   const u8* rec = text + text_beg[i]; /* CSR texts: text_end = text_beg + 1; spans of a file: two arrays */
@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__(256) void k_cigar_chain(u32 n, const u32* __restric
                                                      wga_rec_diag* diag, u8* out,
                                                      const u64* out_off) {
   __shared__ u64 s_ent[4][257][3];
-  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const u32 lane = threadIdx.x & 63u, wave = WGA_WAVE_ID(threadIdx.x);
   const u64 i = (u64)blockIdx.x * 4 + wave;
   if (i >= n) return;
   const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
@@ -1845,7 +1845,7 @@ __global__ __launch_bounds__(256) void k_dotplot_segments(u32 n, const u32* __re
                                                           const u64* __restrict__ t_start,
                                                           const u64* __restrict__ q_start, u64* seg_cnt,
                                                           u64* segs, const u64* seg_off) {
-  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const u32 lane = threadIdx.x & 63u, wave = WGA_WAVE_ID(threadIdx.x);
   const u64 i = (u64)blockIdx.x * 4 + wave;
   if (i >= n) return;
   const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
