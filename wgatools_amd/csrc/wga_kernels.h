@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void k_tile_rec(const u64* __restrict__ op_off
   tile_rec[g] = t;
 }
 
-__global__ __launch_bounds__(256, 5) void k_cigar_stat(const u32* __restrict__ ops,
+__global__ __launch_bounds__(256, WGA_K1_BLOCKS) void k_cigar_stat(const u32* __restrict__ ops,
                                                     const u64* __restrict__ op_off,
                                                     const u8* __restrict__ strand_neg, u32 n,
                                                     u64 n_ops, const wga_tile_rec* __restrict__ tile_rec,
@@ -863,6 +863,9 @@ __device__ __forceinline__ u32 wave_get_u32(u32 v, int k) {
 #endif
 #ifndef WGA_SPLIT_BYTES
 #define WGA_SPLIT_BYTES 8192u /* ... in two halves beyond this */
+#endif
+#ifndef WGA_K1_BLOCKS
+#define WGA_K1_BLOCKS 6 /* blocks per CU the register budget of k_cigar_stat is sized for (80 VGPRs + 12 B scratch; 5: 0.573, 6: 0.559, 8: 1.95 ms) */
 #endif
 #ifndef WGA_K1_LANE_STORE
 #define WGA_K1_LANE_STORE 1 /* K1 writes its counters one field per lane (v_writelane) instead of from lane 0 */
