@@ -87,6 +87,13 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
    (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(u64)(x)))
 #endif
 
+#ifndef WGA_K1_BLOCKS
+#define WGA_K1_BLOCKS 6 /* blocks per CU the register budget of k_cigar_stat is sized for (80 VGPRs + 12 B scratch; 5: 0.573, 6: 0.559, 8: 1.95 ms) */
+#endif
+#ifndef WGA_K1_LANE_STORE
+#define WGA_K1_LANE_STORE 1 /* K1 writes its counters one field per lane (v_writelane) instead of from lane 0 */
+#endif
+
 /* index of the wave inside its block.  threadIdx.x >> 6 is the same in all 64 lanes, but the compiler's
  * divergence analysis does not know: everything derived from it (tile / record index, offsets loaded with it,
  * loop bounds) would be treated as per-lane — vector loads, exec-masked loops, VGPR-held "uniform" values.
@@ -863,12 +870,6 @@ __device__ __forceinline__ u32 wave_get_u32(u32 v, int k) {
 #endif
 #ifndef WGA_SPLIT_BYTES
 #define WGA_SPLIT_BYTES 8192u /* ... in two halves beyond this */
-#endif
-#ifndef WGA_K1_BLOCKS
-#define WGA_K1_BLOCKS 6 /* blocks per CU the register budget of k_cigar_stat is sized for (80 VGPRs + 12 B scratch; 5: 0.573, 6: 0.559, 8: 1.95 ms) */
-#endif
-#ifndef WGA_K1_LANE_STORE
-#define WGA_K1_LANE_STORE 1 /* K1 writes its counters one field per lane (v_writelane) instead of from lane 0 */
 #endif
 #ifndef WGA_MBCNT
 #define WGA_MBCNT 1
