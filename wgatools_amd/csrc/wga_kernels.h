@@ -88,7 +88,7 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
 #endif
 
 #ifndef WGA_K1_BLOCKS
-#define WGA_K1_BLOCKS 6 /* blocks per CU the register budget of k_cigar_stat is sized for (80 VGPRs + 12 B scratch; 5: 0.573, 6: 0.559, 8: 1.95 ms) */
+#define WGA_K1_BLOCKS 5 /* blocks per CU the register budget of k_cigar_stat is sized for: 94 VGPRs, no scratch.  6 (80 VGPRs + 12 B of scratch) measured 0.56 ms on one box and 0.70 ms on two others against 0.54-0.57 ms for 5 */
 #endif
 #ifndef WGA_K1_LANE_STORE
 #define WGA_K1_LANE_STORE 1 /* K1 writes its counters one field per lane (v_writelane) instead of from lane 0 */
