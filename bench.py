@@ -151,7 +151,7 @@ def main():
         job.expand()
         if evs:
             evs[3].record()
-        torch.sum(job.counts, dim=0, out=totals)            # global stat totals
+        eng.counts_total(job.n, job.counts, totals)          # global stat totals (88 bytes)
         if world > 1:
             dist.all_reduce(totals)                          # RCCL over xGMI: 88 bytes
 

@@ -329,6 +329,11 @@ typedef struct {
 int wga_maf_split(wga_ctx*, const uint8_t* d_text, uint64_t n_bytes, uint64_t* n_lines, wga_maf_line* d_lines,
                   uint64_t cap_lines);
 
+/* ---- stat totals: d_totals[11] = the column sums of d_counts[n] (wga_cigar_counts order).  What
+ *      Statistic::merge adds up for one (ref, query) pair (stat.rs:181-223); with records sharded over
+ *      GPUs these 88 bytes are the only thing `stat` has to all-reduce.  d_totals is overwritten. */
+int wga_counts_total(wga_ctx*, uint32_t n, const wga_cigar_counts* d_counts, uint64_t* d_totals);
+
 /* ---- K5: pafcov (replaces update_cov_vec, cigar.rs:710-741, and the per-thread array merge of
  *      pafcov.rs:29-53) ------------------------------------------------------------------------
  * Record i adds +1 to d_cov[cov_off[target_id[i]] + p] for every base p of its M / = ops that

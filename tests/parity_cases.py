@@ -27,6 +27,10 @@ def check_stat(eng, b, sample=None):
     batch = eng.make_batch(b["ops"], b["op_off"], b["strand_neg"])
     counts, diag, _ = eng.cigar_stat(batch)
     c, d = counts.numpy(), diag.numpy()
+    # stat totals = column sums of the counters
+    tot = eng.counts_total(batch.n, counts).numpy()
+    cm = c.view(np.uint64).reshape(batch.n, 11) if batch.n else np.zeros((0, 11), dtype=np.uint64)
+    assert (tot == cm.sum(axis=0, dtype=np.uint64)).all(), (tot, cm.sum(axis=0))
     idx = range(batch.n) if sample is None else sample
     for i in idx:
         try:

@@ -658,6 +658,20 @@ int wga_cigar_dotplot(wga_ctx* c, const wga_cigar_batch* b, uint64_t cutoff, con
   return WGA_OK;
 }
 
+int wga_counts_total(wga_ctx* c, uint32_t n, const wga_cigar_counts* d_counts, uint64_t* d_totals) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (!d_totals || (n && !d_counts)) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  static_assert(sizeof(wga_cigar_counts) == 88, "wga_cigar_counts is 11 u64");
+  RT_CHECK(rt_memset(d_totals, 0, 88, c->stream));
+  if (n == 0) return WGA_OK;
+  u32 grid = (u32)(((u64)n * 11ull + 253ull * 8ull - 1ull) / (253ull * 8ull)); /* ~8 values per thread */
+  if (grid > 2048u) grid = 2048u;
+  WGA_LAUNCH(k_counts_total, grid, WGA_BLOCK, c->stream, n, (const u64*)d_counts, (u64*)d_totals);
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
 int wga_paf_call_events(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, int snp,
                         uint64_t* d_ev_cnt, uint64_t* d_ev, const uint64_t* d_ev_off) {
   int rc = ctx_bind(c);

@@ -2184,4 +2184,26 @@ __global__ __launch_bounds__(256) void k_maf_lines(const u8* __restrict__ text, 
   lines[j] = L;
 }
 
+/* ============================================================================================ */
+/* stat totals: the sum of all records' counters (what `stat` aggregates per pair, stat.rs:181-223, */
+/* for one pair; the 88 bytes a multi-GPU run all-reduces)                                         */
+/* ============================================================================================ */
+/* grid-stride over the n x 11 u64 matrix read as a flat array: thread t always meets field t % 11 when the
+ * stride is a multiple of 11; wave sums by shuffles, then one atomic per field and wave */
+__global__ __launch_bounds__(256) void k_counts_total(u32 n, const u64* __restrict__ counts, u64* totals) {
+  const u64 total = (u64)n * 11ull;
+  const u64 stride = (u64)gridDim.x * 253ull; /* 253 = 23 x 11 threads of each block work */
+  u64 acc = 0;
+  if (threadIdx.x < 253u)
+    for (u64 x = (u64)blockIdx.x * 253ull + threadIdx.x; x < total; x += stride) acc += counts[x];
+  __shared__ u64 s_acc[256];
+  s_acc[threadIdx.x] = threadIdx.x < 253u ? acc : 0ull;
+  __syncthreads();
+  if (threadIdx.x < 11u) { /* field f = threadIdx.x: threads f, f + 11, ... */
+    u64 sum = 0;
+    for (u32 k = threadIdx.x; k < 253u; k += 11u) sum += s_acc[k];
+    if (sum) atomicAdd(totals + threadIdx.x, sum);
+  }
+}
+
 #endif /* WGA_KERNELS2_H */

@@ -314,6 +314,12 @@ class Engine:
                                                       _p(ops), _p(op_off)))
         return op_cnt, err
 
+    def counts_total(self, n, counts, totals=None):
+        """column sums of the n x 11 counter matrix (stat totals)"""
+        totals = totals if totals is not None else self.empty(11, np.uint64)
+        self._check(self.lib.wga_counts_total(self.ctx, int(n), _p(counts), _p(totals)))
+        return totals
+
     def paf_call_events(self, batch, svlen, snp, ev_cnt=None, ev=None, ev_off=None):
         ev_cnt = ev_cnt if ev_cnt is not None else self.empty(batch.n, np.uint64)
         self._check(self.lib.wga_paf_call_events(self.ctx, C.byref(batch.c), int(svlen), int(bool(snp)),
