@@ -859,7 +859,10 @@ int wga_pafpseudo_fill(wga_ctx* c, const wga_cigar_batch* b, int base_mode, cons
   a.dst_off = (const u64*)d_dst_off;
   a.diag = d_diag;
   if (nt > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "batch too large for one launch", nullptr);
-  WGA_LAUNCH(k_pafpseudo_fill, (u32)nt, WGA_BLOCK, c->stream, a);
+  if (base_mode)
+    WGA_LAUNCH(k_pafpseudo_fill<true>, (u32)nt, WGA_BLOCK, c->stream, a);
+  else
+    WGA_LAUNCH(k_pafpseudo_fill<false>, (u32)nt, WGA_BLOCK, c->stream, a);
   LAUNCH_CHECK();
   return WGA_OK;
 }

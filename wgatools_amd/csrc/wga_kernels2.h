@@ -397,7 +397,7 @@ __device__ __forceinline__ u32 pseudo_symbol(u32 code) {
 
 /* fill N bytes whose value depends only on the op covering the column (symbol mode) */
 __device__ __forceinline__ void emit_symbols(u8* dst, u32 N, u32 c0, const u32* s_col,
-                                             const u32* s_sym, int ka, int kb,
+                                             const u32* s_sym, int ka, int kb, const u32* optbl, u32 gsh,
                                              const u32x4_a16* lowmask, u32 tid, u32 nthreads) {
   if (N == 0) return;
   const u64 A = (u64)dst, E = A + N;
@@ -409,15 +409,11 @@ __device__ __forceinline__ void emit_symbols(u8* dst, u32 N, u32 c0, const u32* 
     const u32 cz = c0 + (u32)(base_addr - A);
     u32 c = cz + a0;
     const u32 c_end = cz + b0;
-    int lo = ka, hi = kb; /* last op in [ka,kb) whose start column is <= c: it has length > 0 */
-    while (lo < hi) {
-      int mid = (lo + hi) >> 1;
-      if (s_col[mid] <= c)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    int k = lo - 1;
+    /* an op that starts at or before c: the last one that starts before c's granule (optbl = ops that start
+     * before each granule), or the segment's first; ops that end before c are stepped over below */
+    (void)kb;
+    int k = (int)optbl[c >> gsh] - 1; /* c, not cz: cz wraps below zero for a row that starts mid-granule */
+    k = k < ka ? ka : k;
     u32 o[4] = {0u, 0u, 0u, 0u};
     while (c < c_end) {
       u32 oe = s_col[k + 1];
@@ -444,6 +440,9 @@ __device__ __forceinline__ void emit_symbols(u8* dst, u32 N, u32 c0, const u32* 
   }
 }
 
+/* BASE = base mode (query bases; the row emitter of K2) or symbol mode: two kernels, so that the symbol one does
+ * not carry the emitter's registers and LDS */
+template <bool BASE>
 __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
   __shared__ u32 s_col[WGA_TILE + 1];   /* exclusive prefix of target columns (M = X D)          */
   __shared__ u32 s_ev[WGA_TILE + 1];    /* exclusive count of event ops (D, I, S)                */
@@ -511,12 +510,17 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
       e_d[e] = x_d;
       s_col[k] = x_col;
       s_ev[k] = x_cnt;
-      s_sym[k] = pseudo_symbol(opw[e] & 15u);
+      if (!BASE) {
+        s_sym[k] = pseudo_symbol(opw[e] & 15u);
+        if (k < nt) atomicAdd(&s_tbl[x_col >> gsh], 1u); /* symbol mode: the table counts op starts per granule */
+      }
       if (cls[e] == CLS_D || cls[e] == CLS_I || cls[e] == CLS_S) {
-        s_g_col[x_cnt] = x_col;
-        s_g_cum[x_cnt] = x_d;
-        s_g_adj[x_cnt] = x_d - x_is;
-        tbl_mark_event(s_tbl, x_col, cls[e] == CLS_D ? (opw[e] >> 4) : 0u, gsh, 0u);
+        if (BASE) {
+          s_g_col[x_cnt] = x_col;
+          s_g_cum[x_cnt] = x_d;
+          s_g_adj[x_cnt] = x_d - x_is;
+          tbl_mark_event(s_tbl, x_col, cls[e] == CLS_D ? (opw[e] >> 4) : 0u, gsh, 0u);
+        }
         if (cls[e] == CLS_D)
           x_d += opw[e] >> 4;
         else
@@ -528,9 +532,11 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
     if (tid == WGA_BLOCK - 1) {
       s_col[WGA_TILE] = x_col;
       s_ev[WGA_TILE] = x_cnt;
-      s_g_col[x_cnt] = s_g_col[x_cnt + 1u] = x_col;
-      s_g_cum[x_cnt] = s_g_cum[x_cnt + 1u] = x_d;
-      s_g_adj[x_cnt] = s_g_adj[x_cnt + 1u] = x_d - x_is;
+      if (BASE) {
+        s_g_col[x_cnt] = s_g_col[x_cnt + 1u] = x_col;
+        s_g_cum[x_cnt] = s_g_cum[x_cnt + 1u] = x_d;
+        s_g_adj[x_cnt] = s_g_adj[x_cnt + 1u] = x_d - x_is;
+      }
     }
     __syncthreads(); /* raw marks -> exclusive prefix */
     tbl_scan(s_tbl, s_w4);
@@ -589,12 +595,12 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
     RowSrc qs;
     qs.fa = a.q_fa;
     qs.fa_bytes = a.q_fa_bytes;
-    qs.src_off = a.base_mode ? a.q_src_off[r] : 0;
-    qs.src_len = a.base_mode ? a.q_src_len[r] : 0;
+    qs.src_off = BASE ? a.q_src_off[r] : 0;
+    qs.src_len = BASE ? a.q_src_len[r] : 0;
     qs.rc = a.strand_neg[r] != 0;
     qs.ablate = 0;
     /* edited length: String::drain / insert_str semantics (cigar.rs:769-786) */
-    const u64 row_len = a.base_mode ? qs.src_len - (cs.i + cs.s) + cs.d : T_total;
+    const u64 row_len = BASE ? qs.src_len - (cs.i + cs.s) + cs.d : T_total;
     const u64 skip = a.skip[r];
     u8* const dst = a.out + a.dst_off[r];
     u64* const bad_base = (u64*)&a.diag[r].bad_base_pos;
@@ -603,8 +609,8 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
     if (fast) {
       const u32 col_a = s_col[ka], seg_cols = s_col[kb] - col_a;
       const int ea = (int)s_ev[ka], eb = (int)s_ev[kb];
-      const u32 adj_a = s_g_adj[ea];
-      if (a.base_mode) {
+      const u32 adj_a = BASE ? s_g_adj[ea] : 0u;
+      if (BASE) {
         /* drain(offset..offset+len) panics past the end of the string, insert_str(offset)
          * beyond it (cigar.rs:772,779): in slice terms, an I/S op needs q_before + len <= slice
          * length, a D op q_before <= slice length */
@@ -624,7 +630,7 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
       u64 x1 = cb + seg_cols < row_len ? cb + seg_cols : row_len;
       if (x1 > x0) {
         const u32 c_first = col_a + (u32)(x0 - cb);
-        if (a.base_mode) {
+        if (BASE) {
           RowDesc rd;
           rd.c_org = col_a;
           rd.G_col = s_g_col;
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
           rowsrc_prepare(qs, qb);
           emit_row(dst + (x0 - skip), (u32)(x1 - x0), c_first, rd, qs, tid, WGA_BLOCK, bad_base);
         } else
-          emit_symbols(dst + (x0 - skip), (u32)(x1 - x0), c_first, s_col, s_sym, (int)ka, (int)kb,
+          emit_symbols(dst + (x0 - skip), (u32)(x1 - x0), c_first, s_col, s_sym, (int)ka, (int)kb, s_tbl, gsh,
                        s_lowmask, tid, WGA_BLOCK);
       }
     }
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
         const u32 code = op & 15u;
         const u32 c = op_class(code);
         const u64 len = op >> 4;
-        if (a.base_mode && tid == 0) {
+        if (BASE && tid == 0) {
           if ((c == CLS_I || c == CLS_S) && qp + len > qs.src_len) atomicMin(panic_idx, k - rs);
           if (c == CLS_D && qp > qs.src_len) atomicMin(panic_idx, k - rs);
         }
@@ -663,7 +669,7 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
             u64 xx = x + j;
             if (xx >= skip && xx < row_len) {
               u8 v;
-              if (a.base_mode)
+              if (BASE)
                 v = (c == CLS_D) ? (u8)'-' : src_byte(qs, qp + j, bad_base);
               else
                 v = (u8)(pseudo_symbol(code) & 0xFFu);
@@ -676,7 +682,7 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
       }
     }
     /* leftover query bases beyond the CIGAR stay at the end of the edited string */
-    if (seg_end == re && a.base_mode && row_len > T_total) {
+    if (seg_end == re && BASE && row_len > T_total) {
       u64 x0 = T_total > skip ? T_total : skip;
       if (row_len > x0)
         emit_tail(dst + (x0 - skip), row_len - x0, Q_total + (x0 - T_total), qs, s_lowmask, s_queue, s_zero2, s_g_col, tid, WGA_BLOCK, bad_base);
