@@ -487,8 +487,8 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
       for (int e = 0; e < 4; e++) opw[e] = (base + e < nt) ? a.ops[tile_start + base + e] : 0u;
     }
   }
-  u32 e_col[4], e_is[4], e_d[4], cls[4];
   if (fast) {
+    u32 cls[4];
     u32 l[4], sl = 0, sd = 0, sis = 0, cnt = 0;
     for (int e = 0; e < 4; e++) {
       u32 len = opw[e] >> 4;
@@ -505,9 +505,6 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
     u32 x_col = (u32)exA, x_d = (u32)(exA >> 32), x_is = (u32)exB, x_cnt = (u32)(exB >> 32);
     for (int e = 0; e < 4; e++) {
       u32 k = tid * 4u + (u32)e;
-      e_col[e] = x_col;
-      e_is[e] = x_is;
-      e_d[e] = x_d;
       s_col[k] = x_col;
       s_ev[k] = x_cnt;
       if (!BASE) {
@@ -618,11 +615,18 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
         for (int e = 0; e < 4; e++) {
           u32 k = tid * 4u + (u32)e;
           if (k >= ka && k < kb) {
-            u64 q_before = qb + (u64)(e_col[e] - col_a) - (u64)(e_d[e] - d_a) + (u64)(e_is[e] - is_a);
-            u64 len = opw[e] >> 4;
-            if ((cls[e] == CLS_I || cls[e] == CLS_S) && q_before + len > qs.src_len)
-              atomicMin(panic_idx, tile_start + k - rs);
-            if (cls[e] == CLS_D && q_before > qs.src_len) atomicMin(panic_idx, tile_start + k - rs);
+            /* the op is read again (it is not kept in registers across the row emitter), its own prefixes sit in
+             * the event lists at its slot (s_ev = events before op k) */
+            const u32 op = a.ops[tile_start + k];
+            const u32 c = op_class(op & 15u);
+            if (c == CLS_I || c == CLS_S || c == CLS_D) {
+              const u32 ev = s_ev[k];
+              const u32 e_d = s_g_cum[ev], e_is = e_d - s_g_adj[ev];
+              u64 q_before = qb + (u64)(s_col[k] - col_a) - (u64)(e_d - d_a) + (u64)(e_is - is_a);
+              u64 len = op >> 4;
+              if (c != CLS_D && q_before + len > qs.src_len) atomicMin(panic_idx, tile_start + k - rs);
+              if (c == CLS_D && q_before > qs.src_len) atomicMin(panic_idx, tile_start + k - rs);
+            }
           }
         }
       }
