@@ -876,3 +876,42 @@ def test_dotplot_test_html_golden(cli):
     assert rows[0] == "ref_start,ref_end,query_start,query_end,cigar,ref_chro,query_chro"
     assert rows[1:1 + len(want)] == ["%d,%d,%d,%d,%s,%s,%s" % (w["ref_start"], w["ref_end"], w["query_start"], w["query_end"],
                                                             w["cigar"], w["ref_chro"], w["query_chro"]) for w in want]
+
+
+def test_streaming_pieces_give_the_same_bytes(cli, tmp_path):
+    """paf2maf, stat, validate and paf2chain read the PAF in pieces that end at line ends (1 GiB; WGA_CHUNK_BYTES for
+    the test): same output whatever the piece size, chain ids and csv error positions count over the whole input"""
+    b = synth.make_paf_batch(17, 50, 150, 60000)
+    mapq = np.arange(50)
+    t_fa, q_fa, paf = _write_paf2maf_case(tmp_path, b, mapq)
+    def both(*args):
+        res = []
+        for chunk in (None, "1500", "1"):
+            if chunk:
+                os.environ["WGA_CHUNK_BYTES"] = chunk
+            try:
+                res.append(run(cli, *args))
+            finally:
+                os.environ.pop("WGA_CHUNK_BYTES", None)
+        return res
+    for args in (["paf2maf", paf, "-g", t_fa, "-q", q_fa], ["stat", "-f", "paf", paf], ["stat", "-f", "paf", "-e", paf],
+                 ["validate", paf], ["validate", paf, "-f", "-"], ["paf2chain", paf]):
+        r = both(*args)
+        assert r[0][0] == 0, (args, r[0][2])
+        assert r[0][:2] == r[1][:2] == r[2][:2], args
+    # a malformed line near the end: the csv error names the same record, line and byte; paf2maf and paf2chain have
+    # written everything before it
+    text = open(paf).read()
+    bad = str(tmp_path / "bad.paf")
+    lines = text.splitlines(keepends=True)
+    open(bad, "w").write("".join(lines[:40]) + "q\t1\t2\n" + "".join(lines[40:]))
+    msg = lambda err: err.strip().split(" ERROR ", 1)[1]
+    for args in (["stat", "-f", "paf", bad], ["paf2maf", bad, "-g", t_fa, "-q", q_fa], ["paf2chain", bad]):
+        r = both(*args)
+        assert r[0][0] == r[1][0] == r[2][0] == 1, args
+        assert msg(r[0][2]) == msg(r[1][2]) == msg(r[2][2]) and "invalid length 3" in msg(r[0][2]), (args, r[0][2], r[1][2])
+    whole, small, single = both("paf2chain", bad)
+    good = run(cli, "paf2chain", paf)[1]
+    assert whole[1] == b"" and good.startswith(small[1]) and good.startswith(single[1])
+    assert 30 <= small[1].count(b"chain\t") <= 39          # the pieces in front of the one with the bad line
+    assert single[1].count(b"chain\t") == 39                # one line per piece: every record in front of it

@@ -41,6 +41,63 @@ std::string read_all(const std::string* path) {
   return out;
 }
 
+void LineChunkReader::open(const std::string* path) {
+  if (!path) {
+    if (isatty(0)) fail("Empty stdin, please add `-h` for help"); /* errors.rs:23 */
+    is_stdin = true;
+    return;
+  }
+  gz = gzopen(path->c_str(), "rb");
+  if (!gz) fail("File path `" + *path + "` not exist"); /* errors.rs:13 */
+  gzbuffer((gzFile)gz, 1 << 20);
+}
+LineChunkReader::~LineChunkReader() {
+  if (gz) gzclose((gzFile)gz);
+}
+bool LineChunkReader::next(std::string& piece, size_t target) {
+  piece.clear();
+  piece.swap(carry);
+  bytes_before = next_bytes;
+  lines_before = next_lines;
+  if (target == 0) target = 1;
+  std::string buf((size_t)4 << 20, '\0');
+  auto more = [&]() -> bool { /* appends the next read to `piece` */
+    if (eof) return false;
+    size_t n = is_stdin ? fread(&buf[0], 1, buf.size(), stdin)
+                        : (size_t)std::max(0, gzread((gzFile)gz, &buf[0], (unsigned)buf.size()));
+    if (n == 0) {
+      eof = true;
+      return false;
+    }
+    piece.append(buf.data(), n);
+    return true;
+  };
+  size_t scanned = 0; /* bytes of `piece` already searched for a quote */
+  bool whole = false;
+  for (;;) {
+    if (!whole && piece.find('"', scanned) != std::string::npos) whole = true;
+    scanned = piece.size();
+    if (whole) { /* a quoted field may hold line ends: no cut is safe, take the rest of the input */
+      while (more()) {
+      }
+      break;
+    }
+    if (piece.size() >= target) { /* the piece ends behind the first line end at or after `target` bytes */
+      size_t cut = piece.find('\n', target - 1);
+      if (cut != std::string::npos) {
+        carry.assign(piece, cut + 1, std::string::npos);
+        piece.resize(cut + 1);
+        break;
+      }
+    }
+    if (!more()) break;
+  }
+  if (piece.empty()) return false;
+  next_bytes = bytes_before + piece.size();
+  next_lines = lines_before + (uint64_t)std::count(piece.begin(), piece.end(), '\n');
+  return true;
+}
+
 static bool ends_with(const std::string& s, const char* suf) {
   size_t n = strlen(suf);
   return s.size() >= n && memcmp(s.data() + s.size() - n, suf, n) == 0;
@@ -288,10 +345,12 @@ int natord_compare(const std::string& a, const std::string& b) {
 /* ------------------------------------------------------------------------------------------ */
 /* PAF (paf.rs)                                                                                */
 /* ------------------------------------------------------------------------------------------ */
-std::vector<PafRecord> parse_paf(const std::string& text) {
+std::vector<PafRecord> parse_paf(const std::string& text) { return parse_paf(text, 0, 0, 0); }
+
+std::vector<PafRecord> parse_paf(const std::string& text, uint64_t rec0, uint64_t line0, uint64_t byte0) {
   std::vector<PafRecord> out;
   size_t p = 0, n = text.size();
-  uint64_t recno = 0, line = 1;
+  uint64_t recno = rec0, line = line0 + 1;
   std::vector<std::string> fields;
   while (p < n) {
     /* record terminators: \n, \r\n, \r; blank lines are skipped */
@@ -304,7 +363,7 @@ std::vector<PafRecord> parse_paf(const std::string& text) {
       while (p < n && text[p] != '\n' && text[p] != '\r') p++;
       continue;
     }
-    size_t rec_byte = p;
+    uint64_t rec_byte = byte0 + p;
     fields.clear();
     for (;;) {
       std::string f;

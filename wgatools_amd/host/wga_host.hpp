@@ -60,6 +60,23 @@ struct PafRecord { /* paf.rs:50-65 */
 /* csv-crate reading: records end at \n, \r\n or \r; empty lines and lines starting with '#' are
  * skipped; fields split on tabs with '"' quoting. */
 std::vector<PafRecord> parse_paf(const std::string& text);
+/* the same on a piece of a file: rec0 / line0 / byte0 = records, lines and bytes in front of the piece (they only
+ * show in the csv crate's error text) */
+std::vector<PafRecord> parse_paf(const std::string& text, uint64_t rec0, uint64_t line0, uint64_t byte0);
+
+/* Reads a (plain or gzip) file or stdin in pieces that end at a line end: next() returns false at the end of the
+ * input.  A piece holds at least `target` bytes unless the input ends; a piece that contains a '"' takes the rest of
+ * the input with it (a quoted csv field may hold line ends). */
+struct LineChunkReader {
+  void* gz = nullptr; /* gzFile; nullptr = stdin */
+  bool is_stdin = false, eof = false;
+  std::string carry;
+  uint64_t bytes_before = 0, lines_before = 0; /* of the piece next() returned last */
+  uint64_t next_bytes = 0, next_lines = 0;
+  void open(const std::string* path);
+  bool next(std::string& piece, size_t target);
+  ~LineChunkReader();
+};
 /* paf.rs:122-141: the cg:Z: tag, or the cs:Z: tag converted; "" + err=1 when neither exists */
 std::string paf_cigar_string(const PafRecord& r, int* err);
 std::string cs_to_cigar(const std::string& cs);

@@ -149,9 +149,10 @@ struct PafInput {
     return b;
   }
 };
-PafInput load_paf(Dev& d, const std::string* input, bool want_tags) {
+PafInput paf_from_text(Dev& d, std::string&& text, bool want_tags, uint64_t rec0 = 0, uint64_t line0 = 0,
+                       uint64_t byte0 = 0) {
   PafInput in;
-  in.text = read_all(input);
+  in.text = std::move(text);
   const char* force = getenv("WGA_PAF_READER"); /* "host": always the csv-semantics reader (measurements) */
   if (!want_tags && !in.text.empty() && in.text.size() < 0xFFFFFFF0ull && !(force && strcmp(force, "host") == 0)) {
     d.init();
@@ -200,9 +201,37 @@ PafInput load_paf(Dev& d, const std::string* input, bool want_tags) {
     d.release(in.d_text);
     in.d_text = nullptr;
   }
-  in.recs = parse_paf(in.text);
+  in.recs = parse_paf(in.text, rec0, line0, byte0);
   return in;
 }
+PafInput load_paf(Dev& d, const std::string* input, bool want_tags) {
+  return paf_from_text(d, read_all(input), want_tags);
+}
+
+/* A PAF input in pieces of about 1 GiB that end at line ends (WGA_CHUNK_BYTES overrides the size): the streaming
+ * commands hold one piece of the file, and its buffers on the device, at a time. */
+struct PafChunks {
+  LineChunkReader rd;
+  bool want_tags;
+  size_t target = (size_t)1 << 30;
+  uint64_t recs_before = 0;
+  PafChunks(const std::string* input, bool tags) : want_tags(tags) {
+    rd.open(input);
+    if (const char* e = getenv("WGA_CHUNK_BYTES")) target = (size_t)strtoull(e, nullptr, 10);
+    if (target == 0) target = 1;
+  }
+  /* the next piece with at least one record, or false at the end of the input */
+  bool next(Dev& d, PafInput& in) {
+    std::string piece;
+    while (rd.next(piece, target)) {
+      in = paf_from_text(d, std::move(piece), want_tags, recs_before, rd.lines_before, rd.bytes_before);
+      recs_before += in.recs.size();
+      if (!in.recs.empty()) return true;
+      if (in.d_text) d.release(in.d_text);
+    }
+    return false;
+  }
+};
 
 /* CIGAR texts of a run of records -> device batch through the device tokeniser (wga_cigar_tokenise):
  * the host only finds the tag; digits and op chars are parsed on the GPU.  Returns the reference's
@@ -391,8 +420,7 @@ uint32_t expand_batch(Dev& d, const wga_cigar_batch& cb, const ExpandJob& j, con
 /* ---- paf2maf (converter.rs:176-265) ------------------------------------------------------------- */
 int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::string& q_fa, Output& out) {
   Dev d;
-  PafInput in = load_paf(d, input, false);
-  const std::vector<PafRecord>& recs = in.recs;
+  PafChunks chunks(input, false); /* the input is opened first, then the two indexed FASTA files (utils.rs, converter.rs:183-186) */
   Faidx tf, qf;
   tf.load(t_fa);
   qf.load(q_fa);
@@ -400,10 +428,22 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
   d.init();
   uint8_t* d_tpool = d.upload((const uint8_t*)tf.pool.data(), tf.pool.size());
   uint8_t* d_qpool = d.upload((const uint8_t*)qf.pool.data(), qf.pool.size());
-  const size_t keep = d.owned.size(); /* the input text and the pools stay for the whole run */
+  const size_t keep_pools = d.owned.size(); /* the pools stay for the whole run */
   const uint64_t kMaxBytes = 6ull << 30;
-  size_t i0 = 0;
   std::string pending_error;
+  PafInput in;
+  /* the input streams through in pieces (records before a failing one are written, like the reference's reader loop) */
+  for (;;) {
+  bool more = false;
+  try {
+    more = chunks.next(d, in);
+  } catch (Error& e) {
+    pending_error = e.msg;
+  }
+  if (!more) break;
+  const std::vector<PafRecord>& recs = in.recs;
+  const size_t keep = d.owned.size(); /* + this piece's text */
+  size_t i0 = 0;
   while (i0 < recs.size() && pending_error.empty()) {
     ExpandJob job;
     uint64_t est = 0, est_text = 0;
@@ -470,6 +510,9 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
     d.release_to(keep); /* this batch's buffers */
     i0 = i;
   }
+  d.release_to(keep_pools);
+  if (!pending_error.empty()) break;
+  }
   out.close();
   if (!pending_error.empty()) fail(pending_error);
   return 0;
@@ -478,11 +521,13 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
 /* ---- stat (stat.rs) ----------------------------------------------------------------------------- */
 int cmd_stat_paf(const std::string* input, bool each, Output& out) {
   Dev d;
-  PafInput pin = load_paf(d, input, false);
-  const std::vector<PafRecord>& recs = pin.recs;
-  const uint32_t n = (uint32_t)recs.size();
-  std::vector<wga_cigar_counts> counts(n);
-  if (n) {
+  PafChunks chunks(input, false);
+  std::vector<StatInput> in;
+  PafInput pin;
+  while (chunks.next(d, pin)) { /* one piece of the file at a time; only the per-record statistics are kept */
+    const std::vector<PafRecord>& recs = pin.recs;
+    const uint32_t n = (uint32_t)recs.size();
+    std::vector<wga_cigar_counts> counts(n);
     d.init();
     CigarTexts cigars;
     wga_cigar_batch cb;
@@ -500,13 +545,13 @@ int cmd_stat_paf(const std::string* input, bool each, Output& out) {
           fail("CIGAR OP `" + cigar_op_token_at(cigars[k], diag[k].bad_op_idx) + "` invalid");
     }
     if (!e.empty()) fail(e); /* buffered driver: nothing is written on error */
-  }
-  std::vector<StatInput> in;
-  in.reserve(n);
-  for (uint32_t k = 0; k < n; k++) {
-    const PafRecord& r = recs[k];
-    in.push_back(StatInput{r.target_name, r.query_name, r.target_length, r.query_length, r.target_start,
-                           r.query_start, recstat_from(counts[k])});
+    in.reserve(in.size() + n);
+    for (uint32_t k = 0; k < n; k++) {
+      const PafRecord& r = recs[k];
+      in.push_back(StatInput{r.target_name, r.query_name, r.target_length, r.query_length, r.target_start,
+                             r.query_start, recstat_from(counts[k])});
+    }
+    d.release_all();
   }
   out.write(stat_tsv(in, each));
   out.close();
@@ -743,11 +788,14 @@ int cmd_maf2paf(const std::string* input, const std::string* query_name, Output&
  * par_bridge order is not deterministic). */
 int cmd_validate(const std::string* input, const std::string* fix, Output& out) {
   Dev d;
-  PafInput pin = load_paf(d, input, fix != nullptr); /* --fix re-serialises every tag: host reader */
-  std::vector<PafRecord>& recs = pin.recs;
-  const uint32_t n = (uint32_t)recs.size();
-  std::vector<wga_cigar_counts> counts(n);
-  if (n) {
+  PafChunks chunks(input, fix != nullptr); /* --fix re-serialises every tag: host reader */
+  uint64_t n_total = 0, q_bad = 0, t_bad = 0;
+  std::string q_list, t_list, rows;
+  PafInput pin;
+  while (chunks.next(d, pin)) { /* one piece of the file at a time */
+    std::vector<PafRecord>& recs = pin.recs;
+    const uint32_t n = (uint32_t)recs.size();
+    std::vector<wga_cigar_counts> counts(n);
     d.init();
     CigarTexts cigars;
     wga_cigar_batch cb;
@@ -768,63 +816,63 @@ int cmd_validate(const std::string* input, const std::string* fix, Output& out) 
     }
     /* rec.get_stat().unwrap() (:79) */
     if (!e.empty()) fail("panic: called `Result::unwrap()` on an `Err` value: " + e);
-  }
-  uint64_t q_bad = 0, t_bad = 0;
-  std::string q_list, t_list;
-  for (uint32_t k = 0; k < n; k++) {
-    PafRecord& r = recs[k];
-    const wga_cigar_counts& c = counts[k];
-    const uint64_t mx = c.match + c.mismatch;
-    const uint64_t eq = r.query_start + mx + c.ins_bp + c.inv_ins_bp, et = r.target_start + mx + c.del_bp + c.inv_del_bp;
-    if (eq != r.query_end) {
-      q_bad++;
-      q_list += r.query_name + ":";
-      append_u64(q_list, r.query_start);
-      q_list.push_back('-');
-      append_u64(q_list, r.query_end);
-      q_list.push_back('\n');
-      r.query_end = eq;
+    n_total += n;
+    for (uint32_t k = 0; k < n; k++) {
+      PafRecord& r = recs[k];
+      const wga_cigar_counts& c = counts[k];
+      const uint64_t mx = c.match + c.mismatch;
+      const uint64_t eq = r.query_start + mx + c.ins_bp + c.inv_ins_bp, et = r.target_start + mx + c.del_bp + c.inv_del_bp;
+      if (eq != r.query_end) {
+        q_bad++;
+        q_list += r.query_name + ":";
+        append_u64(q_list, r.query_start);
+        q_list.push_back('-');
+        append_u64(q_list, r.query_end);
+        q_list.push_back('\n');
+        r.query_end = eq;
+      }
+      if (et != r.target_end) {
+        t_bad++;
+        t_list += r.target_name + ":";
+        append_u64(t_list, r.target_start);
+        t_list.push_back('-');
+        append_u64(t_list, r.target_end);
+        t_list.push_back('\n');
+        r.target_end = et;
+      }
     }
-    if (et != r.target_end) {
-      t_bad++;
-      t_list += r.target_name + ":";
-      append_u64(t_list, r.target_start);
-      t_list.push_back('-');
-      append_u64(t_list, r.target_end);
-      t_list.push_back('\n');
-      r.target_end = et;
-    }
+    if (fix) /* csv writer: tab, flexible, no header; PafRecord field order (paf.rs:50-65) */
+      for (const PafRecord& r : recs) {
+        append_csv_field(rows, r.query_name, '\t');
+        const uint64_t a[] = {r.query_length, r.query_start, r.query_end};
+        for (uint64_t v : a) {
+          rows.push_back('\t');
+          append_u64(rows, v);
+        }
+        rows += r.neg ? "\t-\t" : "\t+\t";
+        append_csv_field(rows, r.target_name, '\t');
+        const uint64_t b2[] = {r.target_length, r.target_start, r.target_end, r.matches, r.block_length, r.mapq};
+        for (uint64_t v : b2) {
+          rows.push_back('\t');
+          append_u64(rows, v);
+        }
+        for (const std::string& tg : r.tags) {
+          rows.push_back('\t');
+          append_csv_field(rows, tg, '\t');
+        }
+        rows.push_back('\n');
+      }
+    d.release_all();
   }
   std::string text = "Total records: ";
-  append_u64(text, n);
+  append_u64(text, n_total);
   text += "\nQuery invalid records: ";
   append_u64(text, q_bad);
   text += "\nTarget invalid records: ";
   append_u64(text, t_bad);
   text += "\nQuery invalid list:\n" + q_list + "Target invalid list:\n" + t_list + "\n"; /* writeln!("{}", ..) */
   out.write(text);
-  if (fix) { /* csv writer: tab, flexible, no header; PafRecord field order (paf.rs:50-65) */
-    std::string rows;
-    for (const PafRecord& r : recs) {
-      append_csv_field(rows, r.query_name, '\t');
-      const uint64_t a[] = {r.query_length, r.query_start, r.query_end};
-      for (uint64_t v : a) {
-        rows.push_back('\t');
-        append_u64(rows, v);
-      }
-      rows += r.neg ? "\t-\t" : "\t+\t";
-      append_csv_field(rows, r.target_name, '\t');
-      const uint64_t b2[] = {r.target_length, r.target_start, r.target_end, r.matches, r.block_length, r.mapq};
-      for (uint64_t v : b2) {
-        rows.push_back('\t');
-        append_u64(rows, v);
-      }
-      for (const std::string& tg : r.tags) {
-        rows.push_back('\t');
-        append_csv_field(rows, tg, '\t');
-      }
-      rows.push_back('\n');
-    }
+  if (fix) {
     if (*fix == "-") {
       out.write(rows);
     } else {
@@ -843,13 +891,23 @@ int cmd_validate(const std::string* input, const std::string* fix, Output& out) 
  * (chain.rs:142-203, incl. the '-' strand arithmetic that reuses the updated start) and the layout. */
 int cmd_paf2chain(const std::string* input, Output& out) {
   Dev d;
-  PafInput pin = load_paf(d, input, false);
-  const std::vector<PafRecord>& recs = pin.recs;
-  const size_t keep = d.owned.size();
+  PafChunks chunks(input, false);
   bool dev_ready = false;
   const uint64_t kMaxText = 160ull << 20;
-  size_t i0 = 0;
   std::string pending_error;
+  PafInput pin;
+  uint64_t chain_base = 0; /* chain id = index of the record in the whole input */
+  for (;;) {
+  bool more = false;
+  try {
+    more = chunks.next(d, pin);
+  } catch (Error& e) {
+    pending_error = e.msg;
+  }
+  if (!more) break;
+  const std::vector<PafRecord>& recs = pin.recs;
+  const size_t keep = d.owned.size(); /* this piece's text */
+  size_t i0 = 0;
   while (i0 < recs.size() && pending_error.empty()) {
     size_t i = i0;
     uint64_t est_text = 0;
@@ -910,7 +968,7 @@ int cmd_paf2chain(const std::string* input, Output& out) {
           h.push_back('\t');
           append_u64(h, qe);
           h.push_back('\t');
-          append_u64(h, (uint64_t)(i0 + k));
+          append_u64(h, chain_base + (uint64_t)(i0 + k));
           dst.push_back(pos);
           blob += h;
           blob_off.push_back(blob.size());
@@ -935,6 +993,10 @@ int cmd_paf2chain(const std::string* input, Output& out) {
     }
     d.release_to(keep);
     i0 = i;
+  }
+  chain_base += recs.size();
+  d.release_all();
+  if (!pending_error.empty()) break;
   }
   out.close();
   if (!pending_error.empty()) fail(pending_error);
