@@ -577,10 +577,10 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
       }
       __syncthreads();
       for (int w2 = 0; w2 < 4; w2++) {
-        b_mx += s_red[w2][0];
-        b_i += s_red[w2][1];
-        b_d += s_red[w2][2];
-        b_s += s_red[w2][3];
+        b_mx += WGA_UNI64(s_red[w2][0]);
+        b_i += WGA_UNI64(s_red[w2][1]);
+        b_d += WGA_UNI64(s_red[w2][2]);
+        b_s += WGA_UNI64(s_red[w2][3]);
       }
     }
     const u64 cb = b_mx + b_d;       /* target columns of this record before the segment */
@@ -604,14 +604,16 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
     u64* const panic_idx = (u64*)&a.diag[r].panic_op_idx;
 
     if (fast) {
-      const u32 col_a = s_col[ka], seg_cols = s_col[kb] - col_a;
-      const int ea = (int)s_ev[ka], eb = (int)s_ev[kb];
-      const u32 adj_a = BASE ? s_g_adj[ea] : 0u;
+      /* the same in every lane, but read from LDS: told to the compiler, or the whole row emitter below sits in
+       * exec-masked control flow with its loop bounds in VGPRs */
+      const u32 col_a = WGA_UNI32(s_col[ka]), seg_cols = WGA_UNI32(s_col[kb]) - col_a;
+      const int ea = (int)WGA_UNI32(s_ev[ka]), eb = (int)WGA_UNI32(s_ev[kb]);
+      const u32 adj_a = BASE ? WGA_UNI32(s_g_adj[ea]) : 0u;
       if (BASE) {
         /* drain(offset..offset+len) panics past the end of the string, insert_str(offset)
          * beyond it (cigar.rs:772,779): in slice terms, an I/S op needs q_before + len <= slice
          * length, a D op q_before <= slice length */
-        const u32 d_a = s_g_cum[ea], is_a = d_a - adj_a;
+        const u32 d_a = WGA_UNI32(s_g_cum[ea]), is_a = d_a - adj_a;
         for (int e = 0; e < 4; e++) {
           u32 k = tid * 4u + (u32)e;
           if (k >= ka && k < kb) {
