@@ -895,10 +895,13 @@ def test_streaming_pieces_give_the_same_bytes(cli, tmp_path):
                 os.environ.pop("WGA_CHUNK_BYTES", None)
         return res
     for args in (["paf2maf", paf, "-g", t_fa, "-q", q_fa], ["stat", "-f", "paf", paf], ["stat", "-f", "paf", "-e", paf],
-                 ["validate", paf], ["validate", paf, "-f", "-"], ["paf2chain", paf]):
+                 ["validate", paf], ["validate", paf, "-f", "-"], ["paf2chain", paf], ["pafcov", paf]):
         r = both(*args)
         assert r[0][0] == 0, (args, r[0][2])
         assert r[0][:2] == r[1][:2] == r[2][:2], args
+    # pafcov reads a file twice (targets, then coverage) and stdin whole: same bytes
+    r = subprocess.run([cli, "pafcov"], stdin=open(paf, "rb"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and r.stdout == run(cli, "pafcov", paf)[1]
     # a malformed line near the end: the csv error names the same record, line and byte; paf2maf and paf2chain have
     # written everything before it
     text = open(paf).read()

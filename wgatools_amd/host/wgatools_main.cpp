@@ -1477,24 +1477,37 @@ int cmd_dotplot(const std::string* input, const std::string& format, const std::
 /* ---- pafcov (pafcov.rs:13-83) --------------------------------------------------------------------- */
 int cmd_pafcov(const std::string* input, Output& out) {
   Dev d;
-  PafInput pin = load_paf(d, input, false);
-  const std::vector<PafRecord>& recs = pin.recs;
+  /* A file is read twice in line-aligned pieces — first for the targets (names in first-appearance order, array
+   * length = target_length of the first record seen), then to accumulate — so that only one piece of text is held at
+   * a time; stdin cannot be read twice and is taken whole. */
   std::vector<std::string> targets; /* first-appearance order (the reference: HashMap order) */
   std::unordered_map<std::string, uint32_t> tid;
-  std::vector<uint64_t> cov_len, t_start;
-  std::vector<uint32_t> target_id;
-  for (const auto& r : recs) {
-    auto it = tid.find(r.target_name);
-    if (it == tid.end()) { /* array length = target_length of the first record seen */
-      it = tid.emplace(r.target_name, (uint32_t)targets.size()).first;
-      targets.push_back(r.target_name);
-      cov_len.push_back(r.target_length);
+  std::vector<uint64_t> cov_len;
+  uint64_t n_records = 0;
+  auto note_targets = [&](const std::vector<PafRecord>& recs) {
+    for (const auto& r : recs) {
+      if (tid.find(r.target_name) == tid.end()) {
+        tid.emplace(r.target_name, (uint32_t)targets.size());
+        targets.push_back(r.target_name);
+        cov_len.push_back(r.target_length);
+      }
     }
-    target_id.push_back(it->second);
-    t_start.push_back(r.target_start);
+    n_records += recs.size();
+  };
+  PafInput whole;
+  if (!input) {
+    whole = load_paf(d, input, false);
+    note_targets(whole.recs);
+  } else {
+    PafChunks first(input, false);
+    PafInput pin;
+    while (first.next(d, pin)) {
+      note_targets(pin.recs);
+      d.release_all();
+    }
   }
-  const uint32_t n = (uint32_t)recs.size(), nt = (uint32_t)targets.size();
-  if (n) {
+  const uint32_t nt = (uint32_t)targets.size();
+  if (n_records) {
     std::vector<uint64_t> cov_off(nt);
     uint64_t total = 0;
     for (uint32_t t = 0; t < nt; t++) {
@@ -1502,14 +1515,36 @@ int cmd_pafcov(const std::string* input, Output& out) {
       total += (cov_len[t] + 3) & ~3ull;
     }
     d.init();
-    CigarTexts cigars;
-    wga_cigar_batch cb;
-    const std::string terr = device_tokenise(d, pin, 0, n, cigars, &cb); /* update_cov_vec takes every op char */
-    if (!terr.empty()) fail(terr);
     auto* d_cov = (int32_t*)d.alloc((total + 4) * 4);
     d.check(wga_memset(d.ctx, d_cov, 0, (total + 4) * 4));
     auto *d_off = d.upload(cov_off), *d_len = d.upload(cov_len);
-    d.check(wga_pafcov_accumulate(d.ctx, &cb, d.upload(target_id), d.upload(t_start), d_off, d_len, d_cov, total));
+    const size_t keep = d.owned.size();
+    auto accumulate = [&](const PafInput& pin) {
+      const std::vector<PafRecord>& recs = pin.recs;
+      const uint32_t n = (uint32_t)recs.size();
+      std::vector<uint64_t> t_start;
+      std::vector<uint32_t> target_id;
+      for (const auto& r : recs) {
+        target_id.push_back(tid[r.target_name]);
+        t_start.push_back(r.target_start);
+      }
+      CigarTexts cigars;
+      wga_cigar_batch cb;
+      const std::string terr = device_tokenise(d, pin, 0, n, cigars, &cb); /* update_cov_vec takes every op char */
+      if (!terr.empty()) fail(terr);
+      d.check(wga_pafcov_accumulate(d.ctx, &cb, d.upload(target_id), d.upload(t_start), d_off, d_len, d_cov, total));
+    };
+    if (!input) {
+      accumulate(whole);
+    } else {
+      PafChunks second(input, false);
+      PafInput pin;
+      while (second.next(d, pin)) {
+        accumulate(pin);
+        d.check(wga_sync(d.ctx));
+        while (d.owned.size() > keep) d.release(d.owned.back()); /* this piece's text and buffers */
+      }
+    }
     d.check(wga_pafcov_finalize(d.ctx, nt, d_off, d_len, d_cov));
     /* the BED text is formatted on the device, a few million positions at a time (pafcov.rs:56-60) */
     const uint32_t kChunk = 4u << 20;
