@@ -857,8 +857,11 @@ __device__ __forceinline__ u32 wave_get_u32(u32 v, int k) {
 #endif
 
 #define WGA_TBL_SHIFT 4u                          /* granule = 16 columns */
-#define WGA_TBL_COLS 32768u                       /* widest tile the granule table covers */
-#define WGA_TBL_N (WGA_TBL_COLS >> WGA_TBL_SHIFT) /* 2048 granules (+2 sentinels) */
+#ifndef WGA_TBL_COLS
+#define WGA_TBL_COLS 16384u /* widest tile the 16-column granule table covers (wider tiles use 32-, 64-... column granules);
+                               32768 costs 4 KB more LDS and with it the sixth block per CU, and measures no faster */
+#endif
+#define WGA_TBL_N (WGA_TBL_COLS >> WGA_TBL_SHIFT) /* 1024 granules (+2 sentinels) */
 #ifndef WGA_EMIT_U
 #define WGA_EMIT_U 4 /* chunks in flight per lane */
 #endif
@@ -1415,7 +1418,11 @@ struct ExpandArgs {
   u64* dbg;     /* profiling: 8 s_memtime stamps per tile (NULL: off) */
 };
 
-__global__ __launch_bounds__(256, 5) void k_paf2maf_expand(ExpandArgs a) {
+#ifndef WGA_K2_BLOCKS
+#define WGA_K2_BLOCKS 6 /* blocks per CU the register budget of k_paf2maf_expand is sized for: 80 VGPRs, no scratch,
+                           26 KB of LDS.  Five (93 VGPRs, 30 KB with the 32768-column table): 7.24-7.6 ms, six: 6.88 ms */
+#endif
+__global__ __launch_bounds__(256, WGA_K2_BLOCKS) void k_paf2maf_expand(ExpandArgs a) {
   __shared__ u32 s_bnd[3][2];            /* (column, I | D << 16 gap-op counts) before the op where a record
                                             ends inside the tile: [0] the first such op (written in phase A),
                                             [1], [2] later ones (rebuilt on demand)               */
