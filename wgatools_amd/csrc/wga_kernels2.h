@@ -905,22 +905,24 @@ __global__ __launch_bounds__(256, WGA_K3_BLOCKS) void k_maf_pair_stat(u32 n, con
   if (i >= n) return;
   MafWalkOut w;
   maf_walk<false>(rows + t_off[i], rows + q_off[i], cols[i], runs ? runs + run_off[i] : (u64*)0, w);
-  if (lane == 0) {
+  {
+    /* the 11 counters leave from lanes 0..10, one field per lane (as in K1): one 88-byte store per record */
     const bool neg = strand_neg[i] != 0;
-    wga_cigar_counts o;
-    o.match = w.ncol[0];
-    o.mismatch = w.ncol[3];
-    o.ins_ev = neg ? 0 : w.nrun[1];
-    o.ins_bp = neg ? 0 : w.ncol[1];
-    o.del_ev = neg ? 0 : w.nrun[2];
-    o.del_bp = neg ? 0 : w.ncol[2];
-    o.inv_ins_ev = neg ? w.nrun[1] : 0;
-    o.inv_ins_bp = neg ? w.ncol[1] : 0;
-    o.inv_del_ev = neg ? w.nrun[2] : 0;
-    o.inv_del_bp = neg ? w.ncol[2] : 0;
-    o.inv_ev = neg ? 1 : 0;
-    counts[i] = o;
-    if (run_cnt) run_cnt[i] = w.runs;
+    const u64 z = 0;
+    u64 v = 0;
+    v = lane_put_u64<0u>(v, w.ncol[0], lane);
+    v = lane_put_u64<1u>(v, w.ncol[3], lane);
+    v = lane_put_u64<2u>(v, neg ? z : w.nrun[1], lane);
+    v = lane_put_u64<3u>(v, neg ? z : w.ncol[1], lane);
+    v = lane_put_u64<4u>(v, neg ? z : w.nrun[2], lane);
+    v = lane_put_u64<5u>(v, neg ? z : w.ncol[2], lane);
+    v = lane_put_u64<6u>(v, neg ? w.nrun[1] : z, lane);
+    v = lane_put_u64<7u>(v, neg ? w.ncol[1] : z, lane);
+    v = lane_put_u64<8u>(v, neg ? w.nrun[2] : z, lane);
+    v = lane_put_u64<9u>(v, neg ? w.ncol[2] : z, lane);
+    v = lane_put_u64<10u>(v, neg ? (u64)1 : z, lane);
+    if (lane < 11u) ((u64*)(counts + i))[lane] = v;
+    if (lane == 0 && run_cnt) run_cnt[i] = w.runs;
   }
 }
 
