@@ -918,3 +918,23 @@ def test_streaming_pieces_give_the_same_bytes(cli, tmp_path):
     assert whole[1] == b"" and good.startswith(small[1]) and good.startswith(single[1])
     assert 30 <= small[1].count(b"chain\t") <= 39          # the pieces in front of the one with the bad line
     assert single[1].count(b"chain\t") == 39                # one line per piece: every record in front of it
+
+
+def test_maf_streaming_pieces_give_the_same_bytes(cli, tmp_path):
+    """stat, maf2paf, maf2chain and call read a MAF in pieces cut between blocks (in front of a piece's trailing run of
+    s-lines); chain ids count over the whole input; a block longer than a piece is kept together"""
+    blocks = _synth_maf_blocks(52, 12, 700)
+    maf = str(tmp_path / "in.maf")
+    _write_maf(maf, blocks, extra_sline=True)
+    for args in (["stat", maf], ["stat", "-e", maf], ["maf2paf", maf], ["maf2chain", maf], ["call", "-s", "-l", "2", maf],
+                 ["call", "-i", "-c", "300", maf], ["maf2paf", maf, "-q", "other.x"]):
+        res = []
+        for chunk in (None, "5000", "64"):
+            if chunk:
+                os.environ["WGA_CHUNK_BYTES"] = chunk
+            try:
+                res.append(run(cli, *args))
+            finally:
+                os.environ.pop("WGA_CHUNK_BYTES", None)
+        assert res[0][0] == 0, (args, res[0][2])
+        assert res[0][:2] == res[1][:2] == res[2][:2], args

@@ -569,9 +569,9 @@ struct MafInput {
   bool on_device = false;
   uint8_t* d_text = nullptr;
 };
-MafInput load_maf(Dev& d, const std::string* input) {
+MafInput maf_from_text(Dev& d, std::string&& whole_text) {
   MafInput in;
-  *in.text = read_all(input);
+  *in.text = std::move(whole_text);
   const std::string& text = *in.text;
   const char* force = getenv("WGA_MAF_READER"); /* "host": always the host reader (measurements) */
   if (!text.empty() && text.size() < 0xFFFFFFF0ull && !(force && strcmp(force, "host") == 0)) {
@@ -624,6 +624,62 @@ MafInput load_maf(Dev& d, const std::string* input) {
   in.recs = parse_maf(text, &in.header);
   return in;
 }
+MafInput load_maf(Dev& d, const std::string* input) { return maf_from_text(d, read_all(input)); }
+
+/* A MAF input in pieces of about 1 GiB (WGA_CHUNK_BYTES) that end between blocks: a piece is cut in front of its trailing
+ * run of `s` lines, which open the next piece.  The reader's rule that the file's first line is the header is kept for
+ * the later pieces by a dummy first line. */
+struct MafChunks {
+  LineChunkReader rd;
+  size_t target = (size_t)1 << 30;
+  std::string pending; /* trailing s-lines of the previous piece */
+  bool first = true, done = false;
+  std::string header;
+  explicit MafChunks(const std::string* input) {
+    rd.open(input);
+    if (const char* e = getenv("WGA_CHUNK_BYTES")) target = (size_t)strtoull(e, nullptr, 10);
+    if (target == 0) target = 1;
+  }
+  /* the next piece with at least one block, or false at the end of the input */
+  bool next(Dev& d, MafInput& in) {
+    while (!done) {
+      std::string text = first ? std::string() : std::string("#\n");
+      const size_t skip = text.size();
+      text += pending;
+      pending.clear();
+      std::string piece;
+      bool more = rd.next(piece, target);
+      text += piece;
+      if (!more) {
+        done = true;
+      } else { /* cut in front of the trailing run of lines that start with 's' (the header line never counts) */
+        size_t cut = text.size();
+        while (cut > skip) {
+          size_t ls = cut >= 2 ? text.rfind('\n', cut - 2) : std::string::npos; /* start of the last line in [.., cut) */
+          ls = (ls == std::string::npos || ls + 1 < skip) ? skip : ls + 1;
+          const bool is_header = first && ls == 0;
+          if (text[ls] == 's' && !is_header)
+            cut = ls;
+          else
+            break;
+        }
+        if (cut == skip && text.size() > skip) { /* nothing but s-lines so far: one block longer than a piece */
+          pending.assign(text, skip, std::string::npos);
+          continue;
+        }
+        pending.assign(text, cut, std::string::npos);
+        text.resize(cut);
+      }
+      if (text.size() == skip) continue;
+      in = maf_from_text(d, std::move(text));
+      if (first) header = in.header;
+      first = false;
+      if (!in.recs.empty()) return true;
+      if (in.d_text) d.release(in.d_text);
+    }
+    return false;
+  }
+};
 
 /* the (target row, query row) pairs of a list of blocks on the device: offsets into the uploaded file, or
  * — host reader — into one buffer the rows are gathered in */
@@ -683,23 +739,25 @@ void select_query(std::vector<MafRecord>& recs, const std::string* query_name) {
 
 int cmd_stat_maf(const std::string* input, bool each, const std::string* query_name, Output& out) {
   Dev d;
-  MafInput min = load_maf(d, input);
-  std::vector<MafRecord>& recs = min.recs;
-  select_query(recs, query_name);
-  const uint32_t n = (uint32_t)recs.size();
-  std::vector<wga_cigar_counts> counts(n);
-  if (n) {
+  MafChunks chunks(input);
+  std::vector<StatInput> in;
+  MafInput min;
+  while (chunks.next(d, min)) { /* one piece of the file at a time; only the per-block statistics are kept */
+    std::vector<MafRecord>& recs = min.recs;
+    select_query(recs, query_name);
+    const uint32_t n = (uint32_t)recs.size();
+    std::vector<wga_cigar_counts> counts(n);
     MafRows p = device_rows(d, min, all_records(recs), false);
     auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
     auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
     d.check(wga_maf_pair_stat(d.ctx, n, p.d_rows, p.d_t, p.d_q, p.d_c, p.d_s, d_counts, d_cnt, nullptr, nullptr));
     d.download(counts.data(), d_counts, n);
-  }
-  std::vector<StatInput> in;
-  for (uint32_t k = 0; k < n; k++) {
-    const MafRecord& r = recs[k];
-    in.push_back(StatInput{r.t().name, r.q().name, r.t().size, r.q().size, r.t().start, r.query_start(),
-                           recstat_from(counts[k])});
+    for (uint32_t k = 0; k < n; k++) {
+      const MafRecord& r = recs[k];
+      in.push_back(StatInput{r.t().name, r.q().name, r.t().size, r.q().size, r.t().start, r.query_start(),
+                             recstat_from(counts[k])});
+    }
+    d.release_all();
   }
   out.write(stat_tsv(in, each));
   out.close();
@@ -709,7 +767,10 @@ int cmd_stat_maf(const std::string* input, bool each, const std::string* query_n
 /* ---- maf2paf (converter.rs:29-54, maf.rs:484-520) ------------------------------------------------ */
 int cmd_maf2paf(const std::string* input, const std::string* query_name, Output& out) {
   Dev d;
-  MafInput min = load_maf(d, input);
+  MafChunks chunks(input);
+  std::string all_text; /* converter.rs:40-52 collects every record before it writes the first: an error leaves no output */
+  MafInput min;
+  while (chunks.next(d, min)) {
   std::vector<MafRecord>& recs = min.recs;
   select_query(recs, query_name);
   const uint32_t n = (uint32_t)recs.size();
@@ -777,7 +838,10 @@ int cmd_maf2paf(const std::string* input, const std::string* query_name, Output&
     text.resize((size_t)pos);
     if (pos) d.download((uint8_t*)&text[0], d_out, pos);
   }
-  out.write(text);
+  all_text += text;
+  d.release_all();
+  }
+  out.write(all_text);
   out.close();
   return 0;
 }
@@ -1195,10 +1259,14 @@ int cmd_chain2paf(const std::string* input, Output& out) {
  * runs add up into one block like cigar_cat's M).  Host: chain headers (chain.rs:103-140,185-203). */
 int cmd_maf2chain(const std::string* input, const std::string* query_name, Output& out) {
   Dev d;
-  MafInput min = load_maf(d, input);
-  std::vector<MafRecord>& recs = min.recs;
-  /* set_query_idx_byname fails per record, after the earlier records were written (:66-73) */
+  MafChunks chunks(input);
+  MafInput min;
+  uint64_t chain_base = 0; /* chain id = index of the block in the whole input */
   std::string pending_error;
+  while (pending_error.empty() && chunks.next(d, min)) {
+  std::vector<MafRecord>& recs = min.recs;
+  const uint64_t n_in_piece = recs.size();
+  /* set_query_idx_byname fails per record, after the earlier records were written (:66-73) */
   size_t n_ok = recs.size();
   for (size_t k = 0; k < recs.size() && pending_error.empty(); k++) {
     MafRecord& r = recs[k];
@@ -1285,7 +1353,7 @@ int cmd_maf2chain(const std::string* input, const std::string* query_name, Outpu
       h.push_back('\t');
       append_u64(h, qe);
       h.push_back('\t');
-      append_u64(h, (uint64_t)k);
+      append_u64(h, chain_base + (uint64_t)k);
       dst.push_back(pos);
       blob += h;
       blob_off.push_back(blob.size());
@@ -1304,6 +1372,9 @@ int cmd_maf2chain(const std::string* input, const std::string* query_name, Outpu
     std::string host((size_t)pos, '\0');
     d.download((uint8_t*)&host[0], d_out, pos);
     out.write(host);
+  }
+  chain_base += n_in_piece;
+  d.release_all();
   }
   out.close();
   if (!pending_error.empty()) fail(pending_error);
@@ -2155,14 +2226,11 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
 int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, const std::string& sample,
                  const std::string* query_name, const std::string* query_regex, uint64_t chunk_size, Output& out) {
   Dev d;
-  MafInput min = load_maf(d, input);
-  std::vector<MafRecord>& all = min.recs;
+  MafChunks chunks(input);
   /* utils.rs:414-436: `<input>.index` (JSON written by `maf-index`) supplies ##contig lines */
   std::vector<std::pair<std::string, uint64_t>> contigs;
   if (input) contigs = maf_index_ref_contigs(*input + ".index");
   std::string text = vcf_header(sample, contigs);
-  /* record selection (:62-108): single-s-line blocks and blocks without the asked query are skipped */
-  std::vector<const MafRecord*> recs;
   std::regex re;
   if (!query_name && query_regex) { /* cli.rs:332-343 anchors the pattern; maf.rs:267-271 searches from 0 */
     std::string pat = *query_regex;
@@ -2170,6 +2238,12 @@ int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, c
     if (pat.back() != '$') pat.push_back('$');
     re = std::regex(pat);
   }
+  if (chunk_size == 0) fail("chunk size must be positive (the reference would never terminate)");
+  MafInput min;
+  while (chunks.next(d, min)) { /* one piece of the file at a time, rows written as they are called (caller.rs:62-149) */
+  std::vector<MafRecord>& all = min.recs;
+  /* record selection (:62-108): single-s-line blocks and blocks without the asked query are skipped */
+  std::vector<const MafRecord*> recs;
   for (auto& r : all) {
     if (r.slines.size() == 1) continue;
     if (query_name) {
@@ -2206,7 +2280,6 @@ int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, c
     d.check(wga_maf_call_runs(d.ctx, n, d_rows, d_t, d_q, d_c, d_cnt, d_runs, d_roff));
     std::vector<uint64_t> runs(3 * roff[n]);
     if (roff[n]) d.download(runs.data(), d_runs, 3 * roff[n]);
-    if (chunk_size == 0) fail("chunk size must be positive (the reference would never terminate)");
     for (uint32_t k = 0; k < n; k++) {
       CallBlock b;
       b.rec = recs[k];
@@ -2225,6 +2298,8 @@ int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, c
         }
       }
     }
+  }
+  d.release_all();
   }
   out.write(text);
   out.close();
