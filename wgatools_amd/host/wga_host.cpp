@@ -54,25 +54,25 @@ void LineChunkReader::open(const std::string* path) {
 LineChunkReader::~LineChunkReader() {
   if (gz) gzclose((gzFile)gz);
 }
-bool LineChunkReader::next(std::string& piece, size_t target) {
-  piece.clear();
-  piece.swap(carry);
+bool LineChunkReader::next(std::string& piece, size_t target, size_t keep) {
+  /* piece[0, keep) is the caller's own prefix (kept, not counted); the carried-over tail and fresh reads follow */
+  piece.resize(keep);
+  piece += carry;
+  carry.clear();
   bytes_before = next_bytes;
   lines_before = next_lines;
   if (target == 0) target = 1;
-  std::string buf((size_t)4 << 20, '\0');
-  auto more = [&]() -> bool { /* appends the next read to `piece` */
+  const size_t kRead = (size_t)8 << 20;
+  auto more = [&]() -> bool { /* reads straight into the end of `piece` */
     if (eof) return false;
-    size_t n = is_stdin ? fread(&buf[0], 1, buf.size(), stdin)
-                        : (size_t)std::max(0, gzread((gzFile)gz, &buf[0], (unsigned)buf.size()));
-    if (n == 0) {
-      eof = true;
-      return false;
-    }
-    piece.append(buf.data(), n);
-    return true;
+    const size_t at = piece.size();
+    piece.resize(at + kRead);
+    size_t n = is_stdin ? fread(&piece[at], 1, kRead, stdin) : (size_t)std::max(0, gzread((gzFile)gz, &piece[at], (unsigned)kRead));
+    piece.resize(at + n);
+    if (n == 0) eof = true;
+    return n != 0;
   };
-  size_t scanned = 0; /* bytes of `piece` already searched for a quote */
+  size_t scanned = keep; /* bytes of `piece` already searched for a quote */
   bool whole = false;
   for (;;) {
     if (!whole && piece.find('"', scanned) != std::string::npos) whole = true;
@@ -82,8 +82,8 @@ bool LineChunkReader::next(std::string& piece, size_t target) {
       }
       break;
     }
-    if (piece.size() >= target) { /* the piece ends behind the first line end at or after `target` bytes */
-      size_t cut = piece.find('\n', target - 1);
+    if (piece.size() - keep >= target) { /* the piece ends behind the first line end at or after `target` bytes */
+      size_t cut = piece.find('\n', keep + target - 1);
       if (cut != std::string::npos) {
         carry.assign(piece, cut + 1, std::string::npos);
         piece.resize(cut + 1);
@@ -92,9 +92,9 @@ bool LineChunkReader::next(std::string& piece, size_t target) {
     }
     if (!more()) break;
   }
-  if (piece.empty()) return false;
-  next_bytes = bytes_before + piece.size();
-  next_lines = lines_before + (uint64_t)std::count(piece.begin(), piece.end(), '\n');
+  if (piece.size() == keep) return false;
+  next_bytes = bytes_before + (piece.size() - keep);
+  next_lines = lines_before + (uint64_t)std::count(piece.begin() + (long)keep, piece.end(), '\n');
   return true;
 }
 

@@ -74,7 +74,7 @@ struct LineChunkReader {
   uint64_t bytes_before = 0, lines_before = 0; /* of the piece next() returned last */
   uint64_t next_bytes = 0, next_lines = 0;
   void open(const std::string* path);
-  bool next(std::string& piece, size_t target);
+  bool next(std::string& piece, size_t target, size_t keep = 0); /* piece[0, keep) = the caller's prefix, kept */
   ~LineChunkReader();
 };
 /* paf.rs:122-141: the cg:Z: tag, or the cs:Z: tag converted; "" + err=1 when neither exists */

@@ -647,9 +647,7 @@ struct MafChunks {
       const size_t skip = text.size();
       text += pending;
       pending.clear();
-      std::string piece;
-      bool more = rd.next(piece, target);
-      text += piece;
+      const bool more = rd.next(text, target, text.size()); /* reads behind the prefix, no second copy */
       if (!more) {
         done = true;
       } else { /* cut in front of the trailing run of lines that start with 's' (the header line never counts) */
