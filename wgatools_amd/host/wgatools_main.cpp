@@ -1564,15 +1564,26 @@ int cmd_pafcov(const std::string* input, Output& out) {
     n_records += recs.size();
   };
   PafInput whole;
+  bool single = false; /* the input is one piece: kept, not read again */
   if (!input) {
     whole = load_paf(d, input, false);
     note_targets(whole.recs);
+    single = true;
   } else {
     PafChunks first(input, false);
     PafInput pin;
-    while (first.next(d, pin)) {
-      note_targets(pin.recs);
-      d.release_all();
+    if (first.next(d, whole)) {
+      note_targets(whole.recs);
+      if (!first.next(d, pin)) {
+        single = true;
+      } else {
+        if (whole.d_text) d.release(whole.d_text);
+        whole = PafInput();
+        do {
+          note_targets(pin.recs);
+          d.release_all();
+        } while (first.next(d, pin));
+      }
     }
   }
   const uint32_t nt = (uint32_t)targets.size();
@@ -1603,7 +1614,7 @@ int cmd_pafcov(const std::string* input, Output& out) {
       if (!terr.empty()) fail(terr);
       d.check(wga_pafcov_accumulate(d.ctx, &cb, d.upload(target_id), d.upload(t_start), d_off, d_len, d_cov, total));
     };
-    if (!input) {
+    if (single) {
       accumulate(whole);
     } else {
       PafChunks second(input, false);
