@@ -895,7 +895,8 @@ def test_streaming_pieces_give_the_same_bytes(cli, tmp_path):
                 os.environ.pop("WGA_CHUNK_BYTES", None)
         return res
     for args in (["paf2maf", paf, "-g", t_fa, "-q", q_fa], ["stat", "-f", "paf", paf], ["stat", "-f", "paf", "-e", paf],
-                 ["validate", paf], ["validate", paf, "-f", "-"], ["paf2chain", paf], ["pafcov", paf]):
+                 ["validate", paf], ["validate", paf, "-f", "-"], ["paf2chain", paf], ["pafcov", paf],
+                 ["dotplot", "-f", "paf", "--out-format", "csv", "-l", "4", paf]):
         r = both(*args)
         assert r[0][0] == 0, (args, r[0][2])
         assert r[0][:2] == r[1][:2] == r[2][:2], args
@@ -927,7 +928,8 @@ def test_maf_streaming_pieces_give_the_same_bytes(cli, tmp_path):
     maf = str(tmp_path / "in.maf")
     _write_maf(maf, blocks, extra_sline=True)
     for args in (["stat", maf], ["stat", "-e", maf], ["maf2paf", maf], ["maf2chain", maf], ["call", "-s", "-l", "2", maf],
-                 ["call", "-i", "-c", "300", maf], ["maf2paf", maf, "-q", "other.x"]):
+                 ["call", "-i", "-c", "300", maf], ["maf2paf", maf, "-q", "other.x"],
+                 ["dotplot", maf, "--out-format", "csv", "-l", "3"], ["dotplot", maf, "--out-format", "csv", "-m", "overview"]):
         res = []
         for chunk in (None, "5000", "64"):
             if chunk:

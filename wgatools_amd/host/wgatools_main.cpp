@@ -1394,17 +1394,19 @@ int cmd_dotplot(const std::string* input, const std::string& format, const std::
   }
   if (format != "maf" && format != "paf") fail("Only support MAF and PAF format");
   const bool base = mode == "base-level";
-  std::string text;
+  std::string text; /* all data is generated before anything is written (dotplot.rs:208-262) */
+  Dev d;
+  /* one piece of the input (PAF records or MAF blocks) -> csv rows appended to `text` */
+  auto piece = [&](PafInput* ppin, MafInput* pmin) {
   std::vector<std::string> t_names, q_names;
   std::vector<uint64_t> ts, te, qs, qe;
   std::vector<uint8_t> negs;
-  Dev d;
   wga_cigar_batch cb;
   cb.n = 0;
   std::vector<wga_cigar_counts> counts;
   std::vector<uint64_t> ali;
-  if (format == "paf") {
-    PafInput pin = load_paf(d, input, false);
+  if (ppin) {
+    PafInput& pin = *ppin;
     const std::vector<PafRecord>& recs = pin.recs;
     const uint32_t n = (uint32_t)recs.size();
     for (const PafRecord& r : recs) {
@@ -1441,7 +1443,7 @@ int cmd_dotplot(const std::string* input, const std::string& format, const std::
       }
     }
   } else {
-    MafInput min = load_maf(d, input);
+    MafInput& min = *pmin;
     std::vector<MafRecord>& recs = min.recs;
     select_query(recs, query_name);
     const uint32_t n = (uint32_t)recs.size();
@@ -1503,7 +1505,7 @@ int cmd_dotplot(const std::string* input, const std::string& format, const std::
       d.check(wga_cigar_dotplot(d.ctx, &cb, cutoff, d_ts, d_qs, nullptr, d_segs, d_off));
       std::vector<uint64_t> segs(off[n] * 5);
       if (off[n]) d.download(segs.data(), d_segs, off[n] * 5);
-      if (off[n]) text = "ref_start,ref_end,query_start,query_end,cigar,ref_chro,query_chro\n";
+      if (off[n] && text.empty()) text = "ref_start,ref_end,query_start,query_end,cigar,ref_chro,query_chro\n";
       for (uint32_t k = 0; k < n; k++) {
         std::string names;
         names.push_back(',');
@@ -1523,7 +1525,7 @@ int cmd_dotplot(const std::string* input, const std::string& format, const std::
       }
     }
   } else {
-    if (n) text = "ref_start,ref_end,query_start,query_end,identity,ref_chro,query_chro\n";
+    if (n && text.empty()) text = "ref_start,ref_end,query_start,query_end,identity,ref_chro,query_chro\n";
     for (uint32_t k = 0; k < n; k++) {
       const uint64_t a[] = {ts[k], te[k], negs[k] ? qe[k] : qs[k], negs[k] ? qs[k] : qe[k]}; /* dotplot.rs:400-406 */
       for (uint64_t v : a) {
@@ -1537,6 +1539,17 @@ int cmd_dotplot(const std::string* input, const std::string& format, const std::
       append_csv_field(text, q_names[k], ',');
       text.push_back('\n');
     }
+  }
+  d.release_all();
+  }; /* piece */
+  if (format == "paf") {
+    PafChunks chunks(input, false);
+    PafInput pin;
+    while (chunks.next(d, pin)) piece(&pin, nullptr);
+  } else {
+    MafChunks chunks(input);
+    MafInput min;
+    while (chunks.next(d, min)) piece(nullptr, &min);
   }
   out.write(text);
   out.close();
