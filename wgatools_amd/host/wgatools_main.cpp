@@ -77,50 +77,6 @@ struct Dev {
   }
 };
 
-/* a packed batch of PAF CIGARs (host side of wga_cigar_batch) */
-struct PackedBatch {
-  std::vector<uint32_t> ops;
-  std::vector<uint64_t> op_off{0};
-  std::vector<uint8_t> strand;
-  std::vector<std::string> cigars; /* text after the tag, for error messages */
-};
-
-/* Pack record r; returns "" or the reference's error message for this record. */
-std::string pack_record(const PafRecord& r, PackedBatch& b) {
-  int err = 0;
-  std::string cg = paf_cigar_string(r, &err);
-  if (err) return "CIGAR start tag not found"; /* errors.rs:57 */
-  std::string text = cg.substr(5);
-  size_t need = text.size() + 1, n = 0, eo = 0, el = 0;
-  int32_t rerr = 0;
-  size_t base = b.ops.size();
-  b.ops.resize(base + need);
-  int rc = wga_cigar_pack(text.data(), text.size(), b.ops.data() + base, need, &n, &rerr, &eo, &el);
-  if (rc == WGA_E_TOO_SMALL) { /* lengths >= 2^28 were split */
-    b.ops.resize(base + n);
-    rc = wga_cigar_pack(text.data(), text.size(), b.ops.data() + base, n, &n, &rerr, &eo, &el);
-  }
-  b.ops.resize(base + n);
-  if (rerr) {
-    b.ops.resize(base);
-    return cigar_error_message(rerr, text, eo, el);
-  }
-  b.op_off.push_back(b.ops.size());
-  b.strand.push_back(r.neg ? 1 : 0);
-  b.cigars.push_back(std::move(text));
-  return "";
-}
-
-wga_cigar_batch device_batch(Dev& d, const PackedBatch& b) {
-  wga_cigar_batch cb;
-  cb.d_ops = d.upload(b.ops);
-  cb.d_op_off = d.upload(b.op_off);
-  cb.d_strand_neg = d.upload(b.strand);
-  cb.n_ops = b.ops.size();
-  cb.n = (uint32_t)b.strand.size();
-  return cb;
-}
-
 /* the CIGAR text (after the tag) of record k of a batch, for error messages: owned strings, or spans
  * of the input file when the records came from the device splitter */
 struct CigarTexts {
@@ -237,7 +193,7 @@ struct PafChunks {
  * the host only finds the tag; digits and op chars are parsed on the GPU.  Returns the reference's
  * message for the first failing record in input order ("" if none). */
 std::string device_tokenise(Dev& d, const PafInput& in, size_t first, uint32_t n, CigarTexts& cigars,
-                            wga_cigar_batch* cb) {
+                            wga_cigar_batch* cb, std::vector<wga_tok_err>* all_errs = nullptr) {
   const PafRecord* recs = in.recs.data() + first;
   std::string blob, first_err;
   std::vector<uint64_t> toff{0};
@@ -300,6 +256,10 @@ std::string device_tokenise(Dev& d, const PafInput& in, size_t first, uint32_t n
   cb->d_op_off = d_ooff;
   cb->d_strand_neg = d.upload(strand);
   cb->n_ops = total;
+  if (all_errs) { /* the caller keeps the ops in front of a tokeniser error (call on PAF discards such errors) */
+    *all_errs = errs;
+    return first_err;
+  }
   for (uint32_t k = 0; k < n_ok; k++)
     if (errs[k].err) { /* the batch is cut before the failing record: earlier ones may still fail in a walk */
       first_err = cigar_error_message(errs[k].err, cigars[k], (size_t)errs[k].tok_off, errs[k].tok_len);
@@ -1728,10 +1688,41 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
     if (!S_ISDIR(st.st_mode)) fail("Path `" + outdir + "` is not a dir");
     if (!rewrite) fail("File `" + outdir + "` already exists, please add `-r` to rewrite it.");
   }
-  std::vector<PafRecord> recs = parse_paf(read_all(input));
+  Dev d;
+  PafInput pin = load_paf(d, input, false);
+  const std::vector<PafRecord>& recs = pin.recs;
   Faidx fa;
   const bool base = fasta != nullptr;
   if (base) fa.load(*fasta);
+  /* every record's CIGAR is tokenised on the device, in file order; a record's tag / tokeniser error only counts
+   * when the walk below reaches that record (the reference parses a CIGAR when it processes the record) */
+  const uint32_t n_all = (uint32_t)recs.size();
+  CigarTexts cigars;
+  wga_cigar_batch cb;
+  cb.n = 0;
+  std::vector<wga_tok_err> terrs;
+  std::vector<uint8_t> has_tag(n_all, 1);
+  if (n_all) {
+    d.init();
+    /* records without a tag are given an empty span so that the batch keeps file order */
+    if (pin.on_device) {
+      for (uint32_t i = 0; i < n_all; i++)
+        if (pin.cg_beg[i] == WGA_NONE) {
+          has_tag[i] = 0;
+          pin.cg_beg[i] = pin.cg_end[i] = 0;
+        }
+    } else {
+      for (uint32_t i = 0; i < n_all; i++) {
+        int err = 0;
+        (void)paf_cigar_string(recs[i], &err);
+        if (err) {
+          has_tag[i] = 0;
+          pin.recs[i].tags.push_back("cg:Z:"); /* placeholder: tokenises to the empty-CIGAR error, never used */
+        }
+      }
+    }
+    (void)device_tokenise(d, pin, 0, n_all, cigars, &cb, &terrs);
+  }
   /* 1. group by target (:25-42), then by query with sorted insertion (:86-95) */
   std::vector<PseudoTarget> targets;
   std::unordered_map<std::string, size_t> tindex;
@@ -1746,8 +1737,7 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
     }
     targets[it->second].recs.push_back(i);
   }
-  PackedBatch b;
-  std::vector<uint64_t> q_off, q_len, skip;
+  std::vector<uint64_t> q_off(n_all, 0), q_len(n_all, 0), skip(n_all, UINT64_MAX); /* skip = all: a record the walk drops */
   for (auto& t : targets) {
     std::unordered_map<std::string, size_t> qindex;
     for (size_t i : t.recs) {
@@ -1786,11 +1776,11 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
         last_target_end = r.target_end;
         uint64_t qo = 0, ql = 0;
         if (base) fa.fetch(q.name, r.query_start, r.query_end - 1, &qo, &ql); /* :222-225 */
-        std::string e = pack_record(r, b);
-        if (!e.empty()) fail(e);
-        q_off.push_back(qo);
-        q_len.push_back(ql);
-        skip.push_back(overlap);
+        if (!has_tag[i]) fail("CIGAR start tag not found"); /* errors.rs:57 */
+        if (terrs[i].err) fail(cigar_error_message(terrs[i].err, cigars[i], (size_t)terrs[i].tok_off, terrs[i].tok_len));
+        q_off[i] = qo;
+        q_len[i] = ql;
+        skip[i] = overlap;
         q.segs.push_back(PseudoSeg{i, gap, overlap});
         first_query = false;
       }
@@ -1799,25 +1789,26 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
       q.tail = target_size - last_target_end;
     }
   }
-  /* 3. GPU: class sums -> segment lengths -> fill */
-  const uint32_t n = (uint32_t)b.strand.size();
-  std::vector<uint64_t> seg_len(n), dst_off(n + 1, 0);
+  /* 3. GPU: class sums -> segment lengths -> fill; the batch is the whole file in file order, dropped records write nothing */
+  const uint32_t n = n_all;
+  std::vector<uint64_t> seg_len(n, 0), dst_off(n + 1, 0);
   std::string segs;
   if (n) {
-    Dev d;
-    d.init();
-    wga_cigar_batch cb = device_batch(d, b);
     auto* d_sums = (wga_class_sums*)d.alloc((size_t)n * sizeof(wga_class_sums));
     d.check(wga_cigar_class_sums(d.ctx, &cb, d_sums));
     std::vector<wga_class_sums> sums(n);
     d.download(sums.data(), d_sums, n);
-    for (uint32_t k = 0; k < n; k++) {
-      uint64_t len = base ? q_len[k] - (sums[k].i + sums[k].s) + sums[k].d : sums[k].mx + sums[k].d;
-      if (base && q_len[k] < sums[k].i + sums[k].s) len = 0; /* reported as a panic below */
-      if (skip[k] > len) fail("panic: String::drain range out of bounds (pseudomaf.rs:191)");
-      seg_len[k] = len - skip[k];
-      dst_off[k + 1] = dst_off[k] + seg_len[k];
-    }
+    /* in the order the reference processes the records (an error of an earlier one wins) */
+    for (const auto& t : targets)
+      for (const auto& q : t.queries)
+        for (const auto& sg : q.segs) {
+          const size_t k = sg.rec;
+          uint64_t len = base ? q_len[k] - (sums[k].i + sums[k].s) + sums[k].d : sums[k].mx + sums[k].d;
+          if (base && q_len[k] < sums[k].i + sums[k].s) len = 0; /* reported as a panic below */
+          if (skip[k] > len) fail("panic: String::drain range out of bounds (pseudomaf.rs:191)");
+          seg_len[k] = len - skip[k];
+        }
+    for (uint32_t k = 0; k < n; k++) dst_off[k + 1] = dst_off[k] + seg_len[k];
     auto* d_out = (uint8_t*)d.alloc(dst_off[n] + 64);
     auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
     uint8_t* d_pool = base ? d.upload((const uint8_t*)fa.pool.data(), fa.pool.size()) : nullptr;
@@ -1825,17 +1816,19 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
                                base ? d.upload(q_len) : nullptr, d.upload(skip), d_out, d.upload(dst_off), d_diag));
     std::vector<wga_rec_diag> diag(n);
     d.download(diag.data(), d_diag, n);
-    for (uint32_t k = 0; k < n; k++) {
-      if (diag[k].bad_base_pos != WGA_NONE)
-        fail(std::string("Invalid Base: `") + fa.pool[q_off[k] + q_len[k] - 1 - diag[k].bad_base_pos] + "`");
-      if (diag[k].panic_op_idx != WGA_NONE)
-        fail("panic: String::drain / insert_str beyond the end of the query sequence (cigar.rs:772,779)");
-    }
+    for (const auto& t : targets)
+      for (const auto& q : t.queries)
+        for (const auto& sg : q.segs) {
+          const size_t k = sg.rec;
+          if (diag[k].bad_base_pos != WGA_NONE)
+            fail(std::string("Invalid Base: `") + fa.pool[q_off[k] + q_len[k] - 1 - diag[k].bad_base_pos] + "`");
+          if (diag[k].panic_op_idx != WGA_NONE)
+            fail("panic: String::drain / insert_str beyond the end of the query sequence (cigar.rs:772,779)");
+        }
     segs.resize(dst_off[n]);
     if (dst_off[n]) d.download((uint8_t*)segs.data(), d_out, dst_off[n]);
   }
   /* 4. one file per target (:62-72, :98-209) */
-  size_t k = 0;
   for (const auto& t : targets) {
     Output out;
     out.open(outdir + "/" + t.name + ".maf", true);
@@ -1863,8 +1856,7 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
       text.push_back('\t');
       for (const auto& sg : q.segs) {
         text.append(sg.gap, '-');
-        text.append(segs, dst_off[k], seg_len[k]);
-        k++;
+        text.append(segs, dst_off[sg.rec], seg_len[sg.rec]);
       }
       text.append(q.tail, '-');
       text.push_back('\n');
@@ -2114,53 +2106,65 @@ std::string vcf_header(const std::string& sample, const std::vector<std::pair<st
  * GPU: the op walk (wga_paf_call_events).  Host: fetch coordinates, the event -> VCF row text. */
 int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::string& q_fa, bool snp,
                  uint64_t svlen, const std::string& sample, Output& out) {
-  std::vector<PafRecord> recs = parse_paf(read_all(input));
+  Dev d;
+  PafInput pin = load_paf(d, input, false);
+  const std::vector<PafRecord>& recs = pin.recs;
   Faidx tf, qf;
   tf.load(t_fa);
   qf.load(q_fa);
   std::string body;
-  Dev d;
   d.init();
-  const uint64_t kMaxOps = 64ull << 20;
+  const size_t keep = d.owned.size(); /* the input text */
+  const uint64_t kMaxText = 160ull << 20; /* ~64 M ops per batch */
   size_t i0 = 0;
   while (i0 < recs.size()) {
-    PackedBatch b;
     std::vector<uint64_t> t_off, t_len, q_off, q_len;
     size_t i = i0;
+    uint64_t est_text = 0;
     for (; i < recs.size(); i++) {
       const PafRecord& r = recs[i];
-      if (!b.strand.empty() && b.ops.size() > kMaxOps) break;
+      if (i > i0 && est_text > kMaxText) break;
       uint64_t to, tl, qo, ql;
       tf.fetch(r.target_name, r.target_start, r.target_end, &to, &tl); /* paf.rs:221-237: end inclusive */
       qf.fetch(r.query_name, r.query_start, r.query_end, &qo, &ql);
       if (r.neg && tl == 0) fail("panic: byte index 1 is out of bounds of the fetched target (caller.rs:642)");
-      int err = 0;
-      std::string cg = paf_cigar_string(r, &err);
-      if (err) fail("CIGAR start tag not found");
-      std::string text = cg.substr(5);
-      if (text.empty()) fail(cigar_error_message(WGA_REC_PANIC, text, 0, 0));
-      /* tokeniser errors end the walk but are discarded (:673,815-819): keep the ops before them */
-      size_t need = text.size() + 1, n = 0, eo = 0, el = 0, base = b.ops.size();
-      int32_t rerr = 0;
-      b.ops.resize(base + need);
-      int rc = wga_cigar_pack(text.data(), text.size(), b.ops.data() + base, need, &n, &rerr, &eo, &el);
-      if (rc == WGA_E_TOO_SMALL) {
-        b.ops.resize(base + n);
-        wga_cigar_pack(text.data(), text.size(), b.ops.data() + base, n, &n, &rerr, &eo, &el);
+      { /* a missing tag or an empty CIGAR ends the run at this record (checked here to keep the order of the errors) */
+        bool has_tag, empty;
+        if (pin.on_device) {
+          has_tag = pin.cg_beg[i] != WGA_NONE;
+          empty = has_tag && pin.cg_end[i] == pin.cg_beg[i];
+        } else {
+          int err = 0;
+          const std::string cg = paf_cigar_string(r, &err);
+          has_tag = !err;
+          empty = has_tag && cg.size() == 5;
+        }
+        if (!has_tag) fail("CIGAR start tag not found");
+        if (empty) fail(cigar_error_message(WGA_REC_PANIC, std::string(), 0, 0));
       }
-      b.ops.resize(base + n);
-      b.op_off.push_back(b.ops.size());
-      b.strand.push_back(r.neg ? 1 : 0);
+      est_text += pin.cigar_bytes(i);
       t_off.push_back(to);
       t_len.push_back(tl);
       q_off.push_back(qo);
       q_len.push_back(ql);
     }
-    const uint32_t n = (uint32_t)b.strand.size();
+    /* the CIGARs are tokenised on the device; tokeniser errors end a record's walk but are discarded
+     * (:673,815-819): the ops in front of them are kept.  Only a missing tag and an empty CIGAR are fatal. */
+    CigarTexts cigars;
+    wga_cigar_batch cb;
+    std::vector<wga_tok_err> terrs;
+    const uint32_t n_asked = (uint32_t)(i - i0);
+    const std::string tag_err = device_tokenise(d, pin, i0, n_asked, cigars, &cb, &terrs);
+    for (uint32_t k = 0; k < cb.n; k++)
+      if (terrs[k].err == WGA_REC_PANIC) fail(cigar_error_message(WGA_REC_PANIC, std::string(), 0, 0));
+    if (cb.n < n_asked) fail(tag_err); /* records are processed in order: the first failing one ends the run */
+    const uint32_t n = cb.n;
+    std::vector<uint32_t> h_ops;
+    std::vector<uint64_t> h_op_off(n + 1, 0);
     if (n) {
-      if (b.ops.empty()) b.ops.push_back(0);
-      wga_cigar_batch cb = device_batch(d, b);
-      cb.n_ops = b.op_off.back();
+      h_ops.resize(cb.n_ops + 1);
+      if (cb.n_ops) d.download(h_ops.data(), (const uint32_t*)cb.d_ops, cb.n_ops);
+      d.download(h_op_off.data(), (const uint64_t*)cb.d_op_off, n + 1);
       auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
       d.check(wga_paf_call_events(d.ctx, &cb, svlen, snp, d_cnt, nullptr, nullptr));
       auto* d_eoff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
@@ -2195,8 +2199,8 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
                    qi(r.query_start, r.query_end, false));
         }
         const std::string init_info = r.neg ? "INV_NEST=TRUE;" : "";
-        const uint32_t* rops = b.ops.data() + b.op_off[k];
-        const uint64_t nops = b.op_off[k + 1] - b.op_off[k];
+        const uint32_t* rops = h_ops.data() + h_op_off[k];
+        const uint64_t nops = h_op_off[k + 1] - h_op_off[k];
         auto oob = [&]() { fail("panic: VCF REF/ALT slice out of the fetched sequence (caller.rs:695-696,753-754,800-801)"); };
         for (uint64_t e = eoff[k]; e < eoff[k + 1]; e++) {
           const uint64_t oi = ev[3 * e], tb = ev[3 * e + 1], qb = ev[3 * e + 2];
@@ -2234,8 +2238,8 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
           }
         }
       }
-      d.release_all();
     }
+    d.release_to(keep);
     i0 = i;
   }
   /* everything is buffered; the header goes out first, after all records were processed (:294-299) */
