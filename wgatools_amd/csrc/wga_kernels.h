@@ -956,9 +956,6 @@ __device__ __forceinline__ RowGeom row_geom(u8* dst, u32 N, u32 c0) {
   r.head = c0 & 15u;
   r.j0 = c0 >> 4;
   r.base = dst - r.head; /* pointer arithmetic: stores stay global_store */
-#if defined(WGA_EXP_ALIGN) && (WGA_EXP_ALIGN & 1) /* timing experiment only (wrong output): 16-byte aligned stores */
-  r.base -= (uintptr_t)r.base & 15u;
-#endif
   r.nchunks = (r.head + N + 15u) >> 4;
   r.last_b0 = ((r.head + N - 1u) & 15u) + 1u;
   return r;
@@ -1157,9 +1154,6 @@ __device__ __forceinline__ void emit_row_t(u8* dst, u32 N, u32 c0, const RowDesc
                        (int)(st != WGA_TBL_COVER));
       const u32 off = cz + (u32)koff - adj; /* slice index of the granule relative to sbase, >= 0 */
       loff[u] = ((int)cand[u] & (int)!dash[u]) ? rowbuf_loff(rb, (int)off) : WGA_BUF_OOB;
-#if defined(WGA_EXP_ALIGN) && (WGA_EXP_ALIGN & 2) /* timing experiment only: 16-byte aligned window loads */
-      loff[u] &= ~15u;
-#endif
     }
 #pragma unroll
     for (int u = 0; u < WGA_EMIT_U; u++) buf_load16(rb.lbuf, loff[u], raw[u]);
