@@ -294,6 +294,50 @@ def test_pafpseudo_end_to_end(cli, tmp_path, base):
     assert rc == 0, err
 
 
+def _pseudo_line(q, ts, te, cg):
+    return "%s\t1000\t0\t%d\t+\ttA\t500\t%d\t%d\t0\t0\t60\t%s\n" % (q, te - ts, ts, te, cg)
+
+
+@pytest.mark.parametrize("reader", ["device", "host"])
+def test_pafpseudo_errors_follow_the_walk(cli, tmp_path, reader):
+    """pseudomaf.rs:147-202: only records that survive the contained / overlap logic reach
+    gen_pesudo_maf_by_cigar, so a dropped record's missing tag or broken CIGAR is never seen; the first
+    kept record with a problem (targets, then queries, then sorted by target start) ends the run"""
+    env_before = os.environ.get("WGA_PAF_READER")
+    if reader == "host":
+        os.environ["WGA_PAF_READER"] = "host"
+    try:
+        def go(lines, name):
+            paf = tmp_path / (name + ".paf")
+            paf.write_text("".join(lines))
+            return run(cli, "pafpseudo", str(paf), "-o", str(tmp_path / (name + "_out")))
+        ok = _pseudo_line("q1", 10, 110, "cg:Z:100=")
+        # contained in [10,110): dropped before its CIGAR is looked at
+        rc, _, err = go([ok, _pseudo_line("q1", 20, 60, "xx:i:0"), _pseudo_line("q1", 30, 70, "cg:Z:20=5")], "dropped")
+        assert rc == 0, err
+        rows = open(tmp_path / "dropped_out" / "tA.maf", "rb").read().split(b"\n")
+        assert rows[2] == b"s\tq1\t0\t1000\t+\t1000\t" + b"-" * 10 + orc.gen_pesudo_maf_by_cigar("cg:Z:100=", b"", False) + b"-" * 390
+        # kept: without a tag / with a token the tokeniser rejects; an unknown op letter is skipped (`_ => {}`, cigar.rs:796)
+        rc, _, err = go([ok, _pseudo_line("q1", 200, 240, "xx:i:0")], "notag")
+        assert rc == 1 and err.strip().endswith("ERROR CIGAR start tag not found")
+        rc, _, err = go([ok, _pseudo_line("q1", 200, 240, "cg:Z:20=5Q15=")], "unknown")
+        assert rc == 0, err
+        rows = open(tmp_path / "unknown_out" / "tA.maf", "rb").read().split(b"\n")
+        assert rows[2].endswith(b"-" * 90 + orc.gen_pesudo_maf_by_cigar("cg:Z:20=5Q15=", b"", False) + b"-" * 260)
+        rc, _, err = go([ok, _pseudo_line("q1", 200, 240, "cg:Z:20=M")], "nolen")
+        assert rc == 1 and err.strip().endswith("ERROR CIGAR OP `=M` invalid")
+        rc, _, err = go([ok, _pseudo_line("q1", 200, 240, "cg:Z:20=5")], "noop")
+        assert rc == 1 and err.strip().endswith("ERROR CIGAR OP `` invalid")
+        # the sorted walk meets the record at 120 (no tag) before the one at 300 (bad op), whatever the file order
+        rc, _, err = go([ok, _pseudo_line("q1", 300, 340, "cg:Z:20=5"), _pseudo_line("q1", 120, 160, "xx:i:0")], "order")
+        assert rc == 1 and err.strip().endswith("ERROR CIGAR start tag not found")
+    finally:
+        if env_before is None:
+            os.environ.pop("WGA_PAF_READER", None)
+        else:
+            os.environ["WGA_PAF_READER"] = env_before
+
+
 # ---- call (MAF) ------------------------------------------------------------------------------------
 VCF_HEADER = (
     "##fileformat=VCFv4.4\n"
