@@ -56,3 +56,19 @@ def test_host_packer():
     assert Engine.pack_cigar(e, "")[1] == 6              # the reference panics on an empty CIGAR
     assert Engine.pack_cigar(e, "3é")[1] == 0       # one multi-byte char is one (OTHER) op
     assert int(Engine.pack_cigar(e, "3é")[0][0]) & 15 == 11
+
+
+def test_product_does_not_touch_the_oracle():
+    """oracle/ is test infrastructure: nothing in the package imports, links or loads it (build.py only
+    knows how to compile it for the tests), and neither product binary depends on it"""
+    import subprocess
+    pkg = os.path.join(ROOT, "wgatools_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")) or f == "build.py":
+                continue
+            txt = open(os.path.join(dirpath, f), errors="replace").read()
+            assert not re.search(r"oracle_py|liboracle|\borc_", txt), os.path.join(dirpath, f)
+    for binary in (build.build_hip(), build.build_cli()):
+        needed = subprocess.run(["readelf", "-d", binary], stdout=subprocess.PIPE).stdout.decode()
+        assert "oracle" not in needed, binary
