@@ -4,11 +4,13 @@
  * as plain C++ over tests/emu/simt_emu.h (CPU logic tests only).
  */
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
 
 #include "wga_kernels.h"
+#include "wga_kernels_k2s.h"
 #ifdef WGA_STAGE2
 #include "wga_kernels2.h"
 #endif
@@ -20,6 +22,7 @@ struct wga_ctx {
   int expand_force_slow = 0;
   int expand_no_table = 0;
   int expand_ablate = 0;
+  int expand_variant = 0; /* 0: v1, granules stored as produced; 1: the experimental line-complete kernel of wga_kernels_k2s.h (A/B) */
   void* expand_dbg = nullptr;
   void* scratch = nullptr;
   size_t scratch_cap = 0;
@@ -222,6 +225,8 @@ int wga_ctx_create(int device, wga_ctx** out) {
     return fail(WGA_E_HIP, "context creation", e);
   }
   c->stream = c->own_stream;
+  /* A/B switch for measurements: WGA_EXPAND_VARIANT=0 selects v1 of the paf2maf row kernel (wga_ctx_set_param overrides) */
+  if (const char* v = getenv("WGA_EXPAND_VARIANT")) c->expand_variant = atoi(v) != 0;
   *out = c;
   return WGA_OK;
 }
@@ -266,6 +271,10 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
   }
   if (strcmp(name, "expand_no_table") == 0) {
     c->expand_no_table = value != 0;
+    return WGA_OK;
+  }
+  if (strcmp(name, "expand_variant") == 0) {
+    c->expand_variant = value != 0;
     return WGA_OK;
   }
   if (strcmp(name, "expand_timing") == 0) {
@@ -416,9 +425,13 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
   /* pre-pass: per-record descriptors and per-tile base sums, in the context's scratch arena */
   void* ws;
   size_t rec_bytes = ((size_t)b->n * sizeof(wga_rec_desc) + 255) & ~(size_t)255;
-  if ((rc = ctx_scratch(c, rec_bytes + (size_t)nt * sizeof(wga_tile_desc), &ws))) return rc;
+  const size_t desc_bytes = (size_t)nt * sizeof(wga_tile_desc);
+  const size_t list_bytes = 256 + 2 * (size_t)nt * sizeof(u32); /* two counters + the lists of wide / huge tiles */
+  if ((rc = ctx_scratch(c, rec_bytes + desc_bytes + list_bytes, &ws))) return rc;
   wga_rec_desc* recs = (wga_rec_desc*)ws;
   wga_tile_desc* tdesc = (wga_tile_desc*)((char*)ws + rec_bytes);
+  u32* const wide_counts = (u32*)((char*)ws + rec_bytes + desc_bytes);
+  u32* const wide_list = wide_counts + 64;
   WGA_LAUNCH(k_rec_desc, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, b->n, d_counts,
              b->d_strand_neg, (const u64*)d_t_src_off, (const u64*)d_t_src_len,
              (const u64*)d_q_src_off, (const u64*)d_q_src_len, (const u64*)d_t_row_off,
@@ -443,10 +456,48 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
   a.no_table = c->expand_no_table;
   a.ablate = c->expand_ablate;
   a.dbg = (u64*)c->expand_dbg;
+  a.tile_count = nullptr;
+  a.tile_list = nullptr;
+  /* the staged kernel takes every tile below 2^31 columns; test / profiling knobs that address v1 select v1 */
+  const bool staged = c->expand_variant != 0 && !c->expand_force_slow && !c->expand_ablate && !c->expand_dbg;
+  if (staged) {
+    RT_CHECK(rt_memset(wide_counts, 0, 256, c->stream));
+    WGA_LAUNCH(k_list_wide_tiles, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const wga_tile_desc*)tdesc, (u64)nt,
+               wide_counts, wide_list);
+    LAUNCH_CHECK();
+  }
   const uint32_t slot = c->ev_n % (uint32_t)wga_ctx::kTimingRing;
   if (c->timing) RT_CHECK(rt_event_record(c->ev[2 * slot], c->stream));
-  WGA_LAUNCH(k_paf2maf_expand, (u32)nt, WGA_BLOCK, c->stream, a);
-  LAUNCH_CHECK();
+  if (!staged) {
+    WGA_LAUNCH(k_paf2maf_expand, (u32)nt, WGA_BLOCK, c->stream, a);
+    LAUNCH_CHECK();
+  } else {
+    ExpandArgsS s;
+    s.ops = a.ops;
+    s.op_off = a.op_off;
+    s.n_ops = a.n_ops;
+    s.tdesc = tdesc;
+    s.recs = recs;
+    s.t_fa = d_t_fa;
+    s.t_fa_bytes = t_fa_bytes;
+    s.q_fa = d_q_fa;
+    s.q_fa_bytes = q_fa_bytes;
+    s.out = d_out;
+    s.diag = d_diag;
+    s.no_table = c->expand_no_table;
+    s.wide_count = wide_counts;
+    s.wide_list = wide_list;
+    WGA_LAUNCH(k_paf2maf_expand_s, (u32)nt, WGA_BLOCK, c->stream, s);
+    LAUNCH_CHECK();
+    /* normally empty: tiles of 65 536 .. 2^31 columns (u32 gap lists), tiles beyond (v1's op-serial walk) */
+    const u32 side_grid = nt < 1024 ? (u32)nt : 1024u;
+    WGA_LAUNCH(k_paf2maf_expand_s_wide, side_grid, WGA_BLOCK, c->stream, s);
+    LAUNCH_CHECK();
+    a.tile_count = wide_counts + 1;
+    a.tile_list = wide_list + nt;
+    WGA_LAUNCH(k_paf2maf_expand_list, side_grid < 256u ? side_grid : 256u, WGA_BLOCK, c->stream, a);
+    LAUNCH_CHECK();
+  }
   if (c->timing) {
     RT_CHECK(rt_event_record(c->ev[2 * slot + 1], c->stream));
     c->ev_n++;

@@ -1412,13 +1412,15 @@ struct ExpandArgs {
   int no_table; /* test knob: 256-column granules (the coarse-table path of very wide tiles) */
   int ablate;   /* profiling knob: 1 = stop after phase A, 2 = no source loads, 4 = no stores */
   u64* dbg;     /* profiling: 8 s_memtime stamps per tile (NULL: off) */
+  const u32* tile_count; /* k_paf2maf_expand_list: the blocks loop over tile_list[0 .. *tile_count) */
+  const u32* tile_list;
 };
 
 #ifndef WGA_K2_BLOCKS
 #define WGA_K2_BLOCKS 6 /* blocks per CU the register budget of k_paf2maf_expand is sized for: 80 VGPRs, no scratch,
                            26 KB of LDS.  Five (93 VGPRs, 30 KB with the 32768-column table): 7.24-7.6 ms, six: 6.88 ms */
 #endif
-__global__ __launch_bounds__(256, WGA_K2_BLOCKS) void k_paf2maf_expand(ExpandArgs a) {
+__device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g) {
   __shared__ u32 s_bnd[3][2];            /* (column, I | D << 16 gap-op counts) before the op where a record
                                             ends inside the tile: [0] the first such op (written in phase A),
                                             [1], [2] later ones (rebuilt on demand)               */
@@ -1439,7 +1441,6 @@ __global__ __launch_bounds__(256, WGA_K2_BLOCKS) void k_paf2maf_expand(ExpandArg
 
   const u32 tid = threadIdx.x;
   const u32 lane = tid & 63u, wave = WGA_WAVE_ID(tid);
-  const u64 g = blockIdx.x;
   const u64 tile_start = g * WGA_TILE;
   const u64 tile_end = tile_start + WGA_TILE < a.n_ops ? tile_start + WGA_TILE : a.n_ops;
   const u32 nt = (u32)(tile_end - tile_start);
@@ -1768,7 +1769,9 @@ __global__ __launch_bounds__(256, WGA_K2_BLOCKS) void k_paf2maf_expand(ExpandArg
           RowDesc rd;
           rd.c_org = is_tail ? 0u : col_a;
           rd.G_col = is_q ? s_qg_col : s_tg_col;
-          rd.G_cum = rd.G_adj = is_q ? s_qg_cum : s_tg_cum;
+          rd.G_cum = is_q ? s_qg_cum : s_tg_cum;
+          rd.G_adj = is_tail ? s_zero2 : rd.G_cum; /* a tail's fast path reads G_adj[0]: the gap lists are not even
+                                                      initialised when the tile takes the op-serial walk */
           rd.ga = is_tail ? 0 : (is_q ? ja : ia);
           rd.gb = is_tail ? 0 : (is_q ? jb : ib);
           rd.gcum_a = is_tail ? 0u : (is_q ? dcum_a : icum_a);
@@ -1796,6 +1799,19 @@ __global__ __launch_bounds__(256, WGA_K2_BLOCKS) void k_paf2maf_expand(ExpandArg
     for (int k = 0; k < 8; k++) a.dbg[g * 8 + k] = stamp[k];
   }
 #endif
+}
+
+/* v1 of the row kernel (granules stored as they are produced: lines reach the L2 in pieces).  It stays as the A/B
+ * reference (`expand_variant` 0: one block per tile of the batch) and — as k_paf2maf_expand_list — for the tiles the
+ * staged kernel of wga_kernels_k2s.h leaves out: beyond 2^31 columns, the op-serial u64 walk. */
+__global__ __launch_bounds__(256, WGA_K2_BLOCKS) void k_paf2maf_expand(ExpandArgs a) { expand_tile_v1(a, blockIdx.x); }
+
+__global__ __launch_bounds__(256, 4) void k_paf2maf_expand_list(ExpandArgs a) {
+  const u32 n_list = *a.tile_count;
+  for (u32 idx = blockIdx.x; idx < n_list; idx += gridDim.x) {
+    expand_tile_v1(a, a.tile_list[idx]);
+    __syncthreads(); /* the tile's LDS state is dead */
+  }
 }
 
 /* ---- copy n variable-length snippets (MAF line text between the rows) ------------------------ */
