@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counter passes of the paf2maf row kernel, v1 against the staged build given in $1 (WGA_EXTRA_FLAGS)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
-OUT=$R/gpurun_out/${2:-k2s_sq}; mkdir -p $OUT
+OUT=$R/gpurun_out/${2:-k2_sq}; mkdir -p $OUT
 export TMPDIR=/tmp
 WGA_EXTRA_FLAGS="$1" python -c "from wgatools_amd import build; build.build_hip(force=True)" > /dev/null 2>&1
 cd /tmp
@@ -22,7 +22,7 @@ for var in (0, 1):
             agg = collections.defaultdict(lambda: collections.defaultdict(list))
             for row in csv.DictReader(open(f)):
                 k = row["Kernel_Name"].split("(")[0]
-                if k in ("k_paf2maf_expand", "k_paf2maf_expand_s"): agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                if k in ("k_paf2maf_expand", "k_paf2maf_expand_p"): agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
             for k, v in agg.items():
                 for c, x in sorted(v.items()):
                     if sum(x): print("variant %d %-20s %-24s %.4g per launch" % (var, k, c, sum(x) / len(x)))

@@ -3,6 +3,8 @@
    * tests/test_gpu_parity.py — libwgahip.so on a real MI355X (`-m gpu`), through the C-ABI.
 Bit-exact: every comparison is equality of integers / bytes.
 """
+import os
+
 import numpy as np
 
 import oracle_py as orc
@@ -54,12 +56,18 @@ def check_stat(eng, b, sample=None):
 # ------------------------------------------------------------------------------------------------
 # K2
 # ------------------------------------------------------------------------------------------------
-def run_paf2maf(eng, b, pre=None, force_slow=0, fill=0x23, no_table=0):
-    """stat -> layout -> expand; returns host copies"""
+DEFAULT_EXPAND_VARIANT = int(os.environ.get("WGA_EXPAND_VARIANT", "0") != "0")
+
+
+def run_paf2maf(eng, b, pre=None, force_slow=0, fill=0x23, no_table=0, variant=None):
+    """stat -> layout -> expand; returns host copies.  variant: 0 = v1 of the row kernel, 1 = the planned,
+    line-complete one (wga_kernels_k2p.h); None = whatever the context runs by default"""
     n = len(b["strand_neg"])
     batch = eng.make_batch(b["ops"], b["op_off"], b["strand_neg"])
     eng.set_param("expand_force_slow", force_slow)
     eng.set_param("expand_no_table", no_table)
+    if variant is not None:
+        eng.set_param("expand_variant", variant)
     counts, diag, tws = eng.cigar_stat(batch)
     tl, ql = eng.upload(b["t_src_len"]), eng.upload(b["q_src_len"])
     to, qo = eng.upload(b["t_src_off"]), eng.upload(b["q_src_off"])
@@ -75,6 +83,8 @@ def run_paf2maf(eng, b, pre=None, force_slow=0, fill=0x23, no_table=0):
                        ql, out, tro, qro, diag)
     eng.set_param("expand_force_slow", 0)
     eng.set_param("expand_no_table", 0)
+    if variant is not None:
+        eng.set_param("expand_variant", DEFAULT_EXPAND_VARIANT)
     return dict(out=out.numpy(), t_row_off=tro.numpy(), q_row_off=qro.numpy(),
                 rec_off=reco.numpy(), counts=counts.numpy(), diag=diag.numpy(), total=total)
 
@@ -88,8 +98,8 @@ def oracle_rows(b, i):
     return orc.parse_cigar_to_insert(rec_text(b, i), t, q)  # may raise CigarOpInvalid / panic
 
 
-def check_paf2maf(eng, b, pre=None, force_slow=0, sample=None, no_table=0):
-    r = run_paf2maf(eng, b, pre=pre, force_slow=force_slow, no_table=no_table)
+def check_paf2maf(eng, b, pre=None, force_slow=0, sample=None, no_table=0, variant=None):
+    r = run_paf2maf(eng, b, pre=pre, force_slow=force_slow, no_table=no_table, variant=variant)
     out, n = r["out"], len(b["strand_neg"])
     covered = np.zeros(len(out), dtype=bool)
     idx = range(n) if sample is None else sample
@@ -203,6 +213,40 @@ def edge_case_batch(eng, seed=7):
         t_seqs.append(rand_seq(rng, tl))
         q_seqs.append(rand_seq(rng, ql))
     return batch_from_texts(eng, cigars, strands, t_seqs, q_seqs)
+
+
+def wide_tile_batch(eng, seed=3):
+    """records whose tiles hold 65 536 .. 2^31 columns (one long D / I op each, next to ordinary ops): the u32
+    instance of the planned row kernel; the short records around them stay in narrow tiles"""
+    rng = np.random.default_rng(seed)
+    cigars = ["20=", "30=70000D25=3I8=", "9=2X9=", "12=100000I12=", "5=1I5=", "40=66000D3X90000I17="]
+    strands = [0, 1, 1, 0, 0, 1]
+    t_seqs, q_seqs = [], []
+    for c in cigars:
+        t, q = consumption(c)
+        t_seqs.append(rand_seq(rng, t))
+        q_seqs.append(rand_seq(rng, q))
+    return batch_from_texts(eng, cigars, strands, t_seqs, q_seqs)
+
+
+def planned_kernel_cases(eng):
+    """the line-complete row kernel (expand_variant 1) against the oracle: random mixtures, edge cases with odd row
+    alignments, coarse granules, records over many tiles, many records per tile, wide tiles"""
+    from wgatools_amd import synth
+    for seed, n, mean, pool, use_m in [(1, 12, 700, 50000, False), (2, 40, 60, 20000, False), (3, 300, 3, 5000, True),
+                                       (4, 3, 5000, 200000, True)]:
+        b = synth.make_paf_batch(seed, n, mean, pool, use_m=use_m)
+        rng = np.random.default_rng(seed)
+        check_paf2maf(eng, b, variant=1)
+        check_paf2maf(eng, b, pre=(rng.integers(0, 40, n), rng.integers(0, 40, n), rng.integers(0, 5, n)), variant=1)
+    e = edge_case_batch(eng)
+    ne = len(e["strand_neg"])
+    rng = np.random.default_rng(5)
+    check_paf2maf(eng, e, variant=1)
+    check_paf2maf(eng, e, pre=(rng.integers(0, 33, ne), rng.integers(0, 33, ne), rng.integers(0, 3, ne)), variant=1)
+    check_paf2maf(eng, e, no_table=1, variant=1)
+    check_paf2maf(eng, synth.make_paf_batch(8, 30, 500, 60000), no_table=1, variant=1)
+    check_paf2maf(eng, wide_tile_batch(eng), variant=1)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -107,6 +107,32 @@ def test_paf2maf_long_record_many_tiles(emu):
     pc.check_paf2maf(emu, nb)
 
 
+def test_paf2maf_planned_kernel(emu):
+    pc.planned_kernel_cases(emu)
+
+
+def test_paf2maf_planned_kernel_errors_and_long_record(emu):
+    cigars = ["10=", "10=", "6M1I", "3=1D", "4=2N4="]
+    strands = [1, 1, 0, 0, 0]
+    t = [b"ACGTACGTAC", b"ACGTACGTAC", b"ACGT", b"ACGT", b"ACGTACGT"]
+    q = [b"ACGTRCGYAC", b"ACGTACGTAC", b"ACGTACG", b"AC", b"ACGTACGT"]
+    r = pc.check_paf2maf(emu, pc.batch_from_texts(emu, cigars, strands, t, q), variant=1)
+    d = r["diag"]
+    assert int(d["bad_base_pos"][0]) == 2 and int(d["bad_base_pos"][1]) == int(engine.NONE)
+    assert int(d["panic_op_idx"][2]) == 1 and int(d["panic_op_idx"][3]) == 1
+    assert int(d["bad_op_idx"][4]) == 1
+    big = synth.make_paf_batch(12, 1, 40_000, 400_000, sigma=0.01)  # one record over ~40 tiles
+    pc.check_paf2maf(emu, big, variant=1)
+    # an invalid base in the middle of a long '-' strand record (found by a plain granule, not a queued one)
+    bad = synth.make_paf_batch(13, 2, 3000, 100_000)
+    bad["strand_neg"][:] = 1
+    qp = bad["q_pool"].copy()
+    k = int(bad["q_src_off"][1] + bad["q_src_len"][1] // 2)
+    qp[k] = ord("R")
+    bad["q_pool"] = qp
+    pc.check_paf2maf(emu, bad, variant=1)
+
+
 def test_scan_and_scatter(emu):
     rng = np.random.default_rng(3)
     for n in (0, 1, 5, 1024, 1025, 5000, 300000):

@@ -131,9 +131,23 @@ def test_paf2maf_config2_full_size_properties(gpu):
         assert job.record_rows(i) == pc.oracle_rows(r, 0), i
 
 
-def test_paf2maf_wide_tile_auto_slow_path(gpu):
-    """one tile wider than 2^31 columns (9 D ops of 2^28-1) takes the u64 fallback by itself"""
+def test_paf2maf_planned_kernel(gpu):
+    pc.planned_kernel_cases(gpu)
+    pc.check_paf2maf(gpu, synth.make_paf_batch(6, 500, 400, 2_000_000), variant=1)
+    bad = synth.make_paf_batch(13, 2, 3000, 100_000)   # an invalid base found by a plain granule of a '-' strand row
+    bad["strand_neg"][:] = 1
+    qp = bad["q_pool"].copy()
+    qp[int(bad["q_src_off"][1] + bad["q_src_len"][1] // 2)] = ord("R")
+    bad["q_pool"] = qp
+    pc.check_paf2maf(gpu, bad, variant=1)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_paf2maf_wide_tile_auto_slow_path(gpu, variant):
+    """one tile wider than 2^31 columns (9 D ops of 2^28-1) takes the u64 fallback by itself (variant 1: through the
+    list of such tiles that the planned kernel leaves to v1's op-serial walk)"""
     import torch
+    gpu.set_param("expand_variant", variant)
     dev = torch.device("cuda", 0)
     big = (1 << 28) - 1
     ops = np.array([(5 << 4) | 7] + [(big << 4) | 2] * 9 + [(7 << 4) | 7], dtype=np.uint32)
@@ -162,6 +176,7 @@ def test_paf2maf_wide_tile_auto_slow_path(gpu):
     assert bool((qrow[5:-7] == 45).all()) and bool((out[total:] == 0x23).all())
     c = counts.numpy()[0]
     assert int(c["del_bp"]) == 9 * big and int(c["del_ev"]) == 9 and int(c["match"]) == 12
+    gpu.set_param("expand_variant", pc.DEFAULT_EXPAND_VARIANT)
 
 
 # ---- the other consumers ---------------------------------------------------------------------------

@@ -10,7 +10,7 @@
 #include <string>
 
 #include "wga_kernels.h"
-#include "wga_kernels_k2s.h"
+#include "wga_kernels_k2p.h"
 #ifdef WGA_STAGE2
 #include "wga_kernels2.h"
 #endif
@@ -22,7 +22,7 @@ struct wga_ctx {
   int expand_force_slow = 0;
   int expand_no_table = 0;
   int expand_ablate = 0;
-  int expand_variant = 0; /* 0: v1, granules stored as produced; 1: the experimental line-complete kernel of wga_kernels_k2s.h (A/B) */
+  int expand_variant = 0; /* 0: v1 (fastest measured, profiles/r02_k2_experiments.md); 1: the planned, line-complete kernel of wga_kernels_k2p.h */
   void* expand_dbg = nullptr;
   void* scratch = nullptr;
   size_t scratch_cap = 0;
@@ -472,7 +472,7 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
     WGA_LAUNCH(k_paf2maf_expand, (u32)nt, WGA_BLOCK, c->stream, a);
     LAUNCH_CHECK();
   } else {
-    ExpandArgsS s;
+    ExpandArgsP s;
     s.ops = a.ops;
     s.op_off = a.op_off;
     s.n_ops = a.n_ops;
@@ -487,11 +487,11 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
     s.no_table = c->expand_no_table;
     s.wide_count = wide_counts;
     s.wide_list = wide_list;
-    WGA_LAUNCH(k_paf2maf_expand_s, (u32)nt, WGA_BLOCK, c->stream, s);
+    WGA_LAUNCH(k_paf2maf_expand_p, (u32)nt, WGA_BLOCK, c->stream, s);
     LAUNCH_CHECK();
     /* normally empty: tiles of 65 536 .. 2^31 columns (u32 gap lists), tiles beyond (v1's op-serial walk) */
     const u32 side_grid = nt < 1024 ? (u32)nt : 1024u;
-    WGA_LAUNCH(k_paf2maf_expand_s_wide, side_grid, WGA_BLOCK, c->stream, s);
+    WGA_LAUNCH(k_paf2maf_expand_p_wide, side_grid, WGA_BLOCK, c->stream, s);
     LAUNCH_CHECK();
     a.tile_count = wide_counts + 1;
     a.tile_list = wide_list + nt;

@@ -606,6 +606,7 @@ __device__ __forceinline__ void buf_store16(const BufRsrc& r, u32 off, const u32
   for (int d = 0; d < 4; d++)
     if ((u64)off + 4u * d + 4u <= (u64)r.bytes) memcpy(r.base + off + 4 * d, &v[d], 4);
 }
+__device__ __forceinline__ void buf_store16_stream(const BufRsrc& r, u32 off, const u32 v[4]) { buf_store16(r, off, v); }
 #else
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 typedef u32 u32x4_v __attribute__((vector_size(16)));
@@ -625,9 +626,21 @@ __device__ __forceinline__ void buf_load16(const BufRsrc& r, u32 off, u32 v[4]) 
   v[2] = x[2];
   v[3] = x[3];
 }
+#ifndef WGA_STORE_AUX
+#define WGA_STORE_AUX 0 /* cache policy of the row stores: 0 default, 2 nt, 16 sc1 (write-through) */
+#endif
 __device__ __forceinline__ void buf_store16(const BufRsrc& r, u32 off, const u32 v[4]) {
   const u32x4_v x = {v[0], v[1], v[2], v[3]};
-  __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)off, 0, WGA_STORE_AUX);
+}
+/* streaming store (nt): for output that leaves in whole 128-byte lines and is not read again by the kernel.  On lines
+ * that arrive in pieces it is much slower than the default policy (profiles/r02_k2_experiments.md). */
+#ifndef WGA_STREAM_AUX
+#define WGA_STREAM_AUX 2
+#endif
+__device__ __forceinline__ void buf_store16_stream(const BufRsrc& r, u32 off, const u32 v[4]) {
+  const u32x4_v x = {v[0], v[1], v[2], v[3]};
+  __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)off, 0, WGA_STREAM_AUX);
 }
 #endif
 
@@ -1476,7 +1489,11 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
   {
     u32 base = tid * 4u;
     if (base + 3 < nt) {
+#if defined(WGA_OPS_NT) && !defined(WGA_EMU)
+      u32x4_a16 v = __builtin_nontemporal_load((const u32x4_a16*)(a.ops + tile_start + base));
+#else
       u32x4_a16 v = *(const u32x4_a16*)(a.ops + tile_start + base);
+#endif
       opw[0] = v[0];
       opw[1] = v[1];
       opw[2] = v[2];
