@@ -103,6 +103,11 @@ typedef struct wga_ctx wga_ctx;
 int wga_abi_version(void);
 const char* wga_last_error(void);
 int wga_device_count(void);
+/* THREADING / STREAM CONTRACT.  A context belongs to ONE host thread at a time and orders all its work on ONE
+ * stream: its scratch arenas (scan partials, descriptors, coverage piece lists) are shared by every entry point and
+ * reused from call to call, which is only safe because calls are stream-ordered.  Use one context per host thread /
+ * per device; wga_ctx_set_stream / wga_ctx_reset_stream drain the stream they leave before switching.
+ * wga_ctx_destroy waits for the context's stream. */
 int wga_ctx_create(int device, wga_ctx** out);
 void wga_ctx_destroy(wga_ctx*);
 /* Launch on an external stream (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream;
@@ -110,7 +115,9 @@ void wga_ctx_destroy(wga_ctx*);
 int wga_ctx_set_stream(wga_ctx*, void* hip_stream);
 int wga_ctx_reset_stream(wga_ctx*);
 /* Tunables (test knobs): "expand_force_slow" (0/1) forces the u64 op-serial fallback of the
- * expand kernel; "expand_no_table" (0/1) forces its binary-search event lookup. */
+ * expand kernel; "expand_no_table" (0/1) forces its binary-search event lookup; "expand_variant" picks the row
+ * kernel (0: v1, the default and the fastest measured; 1: the planned, line-complete kernel — same bytes;
+ * environment: WGA_EXPAND_VARIANT). */
 int wga_ctx_set_param(wga_ctx*, const char* name, int64_t value);
 /* Measurement hook: after wga_ctx_set_param(ctx, "expand_timing", 1) every wga_paf2maf_expand
  * brackets its gap-insertion kernel (without the descriptor pre-pass) with two events on the

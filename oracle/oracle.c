@@ -131,6 +131,51 @@ static int cst2cu(const cst_t* t, const char** op, size_t* op_n, uint64_t* len, 
   return ORC_OK;
 }
 
+/* The token stream every reference consumer folds over (fold_many1(parse_cigar_str_tuple) + cst2cu, cigar.rs:43-75):
+ * the (length, op char) pairs up to the first error, the error that ends the fold, and the byte span of the token it
+ * quotes.  `text` is the CIGAR behind the "cg:Z:" tag.  op_first[] gets the first byte of each op char. */
+int orc_tokenise(const char* text, size_t n, uint64_t* lens, unsigned char* op_first, size_t cap, size_t* n_tok,
+                 orc_err* err, size_t* err_off, size_t* err_len) {
+  const char* p = text;
+  const char* end = text + n;
+  size_t k = 0;
+  int rc = ORC_OK;
+  if (err) err->kind = ORC_OK;
+  if (err_off) *err_off = 0;
+  if (err_len) *err_len = 0;
+  if (n == 0) { /* fold_many1 on no input: Many1 error -> errors.rs:92 slices input[..10] of an empty string: panic */
+    if (err) set_err(err, ORC_PANIC, "", 0);
+    if (n_tok) *n_tok = 0;
+    return ORC_PANIC;
+  }
+  cst_t t;
+  while (parse_cigar_str_tuple(&p, end, &t)) {
+    const char* op;
+    size_t op_n;
+    uint64_t len;
+    orc_err e;
+    rc = cst2cu(&t, &op, &op_n, &len, &e);
+    if (rc) {
+      if (err) *err = e;
+      if (rc == ORC_CIGAR_OP_INVALID) {
+        if (err_off) *err_off = (size_t)(t.op - text);
+        if (err_len) *err_len = t.op_n;
+      } else { /* ParseIntError quotes the length token (empty, or the overflowing digits) */
+        if (err_off) *err_off = (size_t)(t.len - text);
+        if (err_len) *err_len = t.len_n;
+      }
+      break;
+    }
+    if (k < cap) {
+      lens[k] = len;
+      op_first[k] = (unsigned char)op[0];
+    }
+    k++;
+  }
+  if (n_tok) *n_tok = k;
+  return rc;
+}
+
 /* tag("cg:Z:") + the From<nom::Err> conversion of errors.rs:88-96 (slices input[..10]). */
 static int strip_tag(const char** p, const char* end, orc_err* err) {
   size_t n = (size_t)(end - *p);

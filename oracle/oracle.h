@@ -136,6 +136,11 @@ void orc_maf_to_base_plotdata(const char* t, size_t tn, const char* q, size_t qn
                               uint64_t q_start, int strand_neg, uint64_t cutoff, uint64_t** segs,
                               size_t* n_segs);
 
+/* cigar.rs:43-75: the (length, op) tokens every consumer folds over, up to the first error; the error and the byte
+ * span [*err_off, +*err_len) of the token its message quotes.  `text` = the CIGAR behind "cg:Z:".  Returns the kind. */
+int orc_tokenise(const char* text, size_t n, uint64_t* lens, unsigned char* op_first, size_t cap, size_t* n_tok,
+                 orc_err* err, size_t* err_off, size_t* err_len);
+
 void orc_free(void* p);
 /* test helper: packed ops -> "cg:Z:..." text; returns length (0 if cap too small) */
 size_t orc_ops_to_text(const uint32_t* ops, size_t n, char* out, size_t cap);

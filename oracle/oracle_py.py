@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
+LIB_PATH = os.environ.get("WGA_ORACLE_LIB") or os.path.join(ROOT, "oracle", "liboracle.so")  # the env override: sanitizer builds
 
 COUNT_FIELDS = ("match", "mismatch", "ins_ev", "ins_bp", "del_ev", "del_bp", "inv_ins_ev",
                 "inv_ins_bp", "inv_del_ev", "inv_del_bp", "inv_ev")
@@ -40,7 +40,7 @@ def lib():
     global _lib
     if _lib is None:
         src = [os.path.join(ROOT, "oracle", f) for f in ("oracle.c", "oracle.h")]
-        if (not os.path.exists(LIB_PATH)
+        if not os.environ.get("WGA_ORACLE_LIB") and (not os.path.exists(LIB_PATH)
                 or any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH)
                        for s in src)):
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
@@ -71,6 +71,7 @@ def lib():
         L.orc_cigar_to_base_plotdata.argtypes = [C.c_char_p, Z, U, U, C.c_int, U, P, P, P]
         L.orc_maf_to_base_plotdata.argtypes = [C.c_char_p, Z, C.c_char_p, Z, U, U, C.c_int, U, P, P]
         L.orc_maf_to_base_plotdata.restype = None
+        L.orc_tokenise.argtypes = [C.c_char_p, Z, P, P, Z, P, P, P, P]
         L.orc_ops_to_text.restype = Z
         L.orc_ops_to_text.argtypes = [P, Z, C.c_char_p, Z]
         L.orc_free.argtypes = [C.c_void_p]
@@ -217,6 +218,27 @@ def call_var_maf_record(chro, q_chro, t_row, q_row, t_start, q_sline_start, q_sl
     return s
 
 
+def call_within_var(chro, q_chro, t_row, q_row, t_start, t_end, q_start, q_end, strand_neg, if_snp, svlen_cutoff,
+                    if_inv):
+    """caller.rs:388-608 on ONE chunk (no chunking, coordinates as given) -> VCF body text"""
+    t_row, q_row = bytes(t_row), bytes(q_row)
+    cols = min(len(t_row), len(q_row))
+    out = C.c_void_p()
+    out_len = C.c_size_t(0)
+    L = lib()
+    L.orc_call_within_var.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_uint64,
+                                      C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_int,
+                                      C.c_void_p, C.c_void_p]
+    rc = L.orc_call_within_var(chro.encode(), q_chro.encode(), t_row, q_row, cols, t_start, t_end, q_start, q_end,
+                               int(strand_neg), int(if_snp), svlen_cutoff, int(if_inv), C.byref(out), C.byref(out_len))
+    s = C.string_at(out, out_len.value).decode() if out.value else ""
+    if out.value:
+        L.orc_free(out)
+    if rc:
+        raise OracleError(rc, "", "call_within_var panicked")
+    return s
+
+
 def call_within_var_paf(chro, q_chro, cg, t_seq, q_seq, t_start, t_end, q_start, q_end, strand_neg,
                         if_snp, svlen_cutoff):
     """caller.rs:610-822 for one PAF record -> VCF body text"""
@@ -353,3 +375,16 @@ def ops_to_text(ops):
     buf = C.create_string_buffer(cap)
     k = lib().orc_ops_to_text(C.c_void_p(ops.ctypes.data), len(ops), buf, cap)
     return buf.raw[:k]
+
+
+def tokenise(text):
+    """cigar.rs:43-75 over the CIGAR behind "cg:Z:": ([(length, first byte of the op char)], error kind,
+    (offset, length) of the token the error message quotes)"""
+    text = text.encode() if isinstance(text, str) else bytes(text)
+    cap = len(text) + 1
+    lens = (C.c_uint64 * cap)()
+    opc = (C.c_ubyte * cap)()
+    n, eo, el = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    err = Err()
+    kind = lib().orc_tokenise(text, len(text), lens, opc, cap, C.byref(n), C.byref(err), C.byref(eo), C.byref(el))
+    return [(int(lens[i]), int(opc[i])) for i in range(n.value)], int(kind), (eo.value, el.value)

@@ -897,7 +897,18 @@ def test_maf_reader_selection(cli, tmp_path):
     # errors come from the host reader with the reference's text
     open(p2, "wb").write(text.replace(b"\t+\t99999\t", b"\t+\t", 1))
     rc, out4, err = run(cli, "stat", p2)
-    assert rc == 1 and "S-line Filed `seq` Missing" in err
+    # six tokens: the row text stands where the size is read, and fails to parse before `seq` is found missing
+    assert rc == 1 and "Into Integer Error" in err and "Parse `" in err, err
+    # maf.rs:138-211 reads the tokens left to right: a short line with a bad number reports the number
+    open(p2, "wb").write(b"##maf version=1\na score=1\ns ref abc\ns q 0 1 + 10 A\n\n")
+    rc, out4, err = run(cli, "stat", p2)
+    assert rc == 1 and "Parse `abc` Into Integer Error" in err, err
+    open(p2, "wb").write(b"##maf version=1\na score=1\ns ref 3 4 x\ns q 0 1 + 10 A\n\n")
+    rc, out4, err = run(cli, "stat", p2)
+    assert rc == 1 and "Parse Strand `x` Error" in err, err
+    open(p2, "wb").write(b"##maf version=1\na score=1\ns ref 3\ns q 0 1 + 10 A\n\n")
+    rc, out4, err = run(cli, "stat", p2)
+    assert rc == 1 and "S-line Filed `align_size` Missing" in err, err
     # every MAF command gives the same bytes through both readers
     for args in (["stat"], ["maf2paf"], ["maf2chain"], ["call", "-s", "-l", "3"], ["dotplot", "--out-format", "csv", "-l", "2"]):
         rc, a, err = run(cli, *args, maf)

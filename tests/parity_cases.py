@@ -215,6 +215,83 @@ def edge_case_batch(eng, seed=7):
     return batch_from_texts(eng, cigars, strands, t_seqs, q_seqs)
 
 
+def consistent_batch(seed, n, mean_ops):
+    """records whose sequences AGREE with their CIGAR (= columns equal, X columns differ, upper-case ACGT), ops drawn
+    as  = run, edit, = run, edit ... with no two neighbouring ops of one kind: the MAF rows paf2maf writes for them
+    read back (parse_maf_seq_to_cigar, cigar.rs:344-432) as exactly the CIGAR they came from"""
+    rng = np.random.default_rng(seed)
+    nops = np.maximum(1, rng.poisson(mean_ops, n)) | 1            # odd: starts and ends with an = run
+    tot = int(nops.sum())
+    op_off = np.zeros(n + 1, dtype=np.uint64)
+    op_off[1:] = np.cumsum(nops)
+    pos = np.arange(tot) - np.repeat(op_off[:-1].astype(np.int64), nops)
+    is_eq = (pos & 1) == 0
+    kind = rng.choice(np.array([8, 1, 2], dtype=np.uint32), tot, p=[0.6, 0.2, 0.2])
+    code = np.where(is_eq, np.uint32(7), kind).astype(np.uint32)
+    ln = np.where(is_eq, rng.geometric(1 / 24.0, tot), np.where(code == 8, rng.integers(1, 3, tot), rng.geometric(1 / 3.0, tot)))
+    ln = np.where((code != 8) & ~is_eq & (rng.random(tot) < 0.01), rng.integers(50, 2000, tot), ln).astype(np.uint32)
+    ops = (ln << np.uint32(4)) | code
+    # per-column classes of the whole batch
+    ccls = np.repeat(code, ln)
+    ncol = len(ccls)
+    tb = rng.integers(0, 4, ncol).astype(np.uint8)
+    qb = np.where(ccls == 7, tb, np.where(ccls == 8, (tb + rng.integers(1, 4, ncol)) & 3, rng.integers(0, 4, ncol))).astype(np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    has_t, has_q = ccls != 1, ccls != 2
+    col_rec = np.repeat(np.arange(n), np.add.reduceat(ln.astype(np.int64), op_off[:-1].astype(np.int64)))
+    strand = rng.integers(0, 2, n).astype(np.uint8)
+    t_len = np.bincount(col_rec[has_t], minlength=n).astype(np.uint64)
+    q_len = np.bincount(col_rec[has_q], minlength=n).astype(np.uint64)
+    t_flat, q_flat = lut[tb[has_t]], lut[qb[has_q]]
+    pad = np.frombuffer(b"N" * 32, dtype=np.uint8)
+    t_off = np.zeros(n, dtype=np.uint64)
+    t_off[1:] = np.cumsum(t_len)[:-1]
+    q_off = np.zeros(n, dtype=np.uint64)
+    q_off[1:] = np.cumsum(q_len)[:-1]
+    # '-' strand: the pool holds the reverse complement of what the row shows
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    q_pool_core = q_flat.copy()
+    for i in np.flatnonzero(strand):
+        a, z = int(q_off[i]), int(q_off[i] + q_len[i])
+        q_pool_core[a:z] = comp[q_flat[a:z]][::-1]
+    return dict(ops=ops, op_off=op_off, strand_neg=strand, t_pool=np.concatenate([pad, t_flat, pad]),
+                q_pool=np.concatenate([pad, q_pool_core, pad]), t_src_off=t_off + np.uint64(32), t_src_len=t_len,
+                q_src_off=q_off + np.uint64(32), q_src_len=q_len)
+
+
+def check_paf2maf_maf2paf_roundtrip(eng, seed, n, mean_ops):
+    """paf2maf (K1 + layout + K2) then maf2paf's walk (K3 runs -> K11 packed ops) over the rows it wrote gives back
+    the op stream and the counters it started from: two kernels that share no code agree"""
+    b = consistent_batch(seed, n, mean_ops)
+    r = run_paf2maf(eng, b)
+    assert (r["diag"]["bad_op_idx"] == NONE).all() and (r["diag"]["panic_op_idx"] == NONE).all()
+    c = r["counts"]
+    cols = (c["match"] + c["mismatch"] + c["ins_bp"] + c["inv_ins_bp"] + c["del_bp"] + c["inv_del_bp"]).astype(np.uint64)
+    rows = eng.upload(r["out"])
+    d_t, d_q, d_c = eng.upload(r["t_row_off"]), eng.upload(r["q_row_off"]), eng.upload(cols)
+    d_s = eng.upload(b["strand_neg"])
+    counts2, run_cnt = eng.maf_pair_stat(n, rows, d_t, d_q, d_c, d_s)
+    run_off = eng.exclusive_scan_u64(n, run_cnt)
+    ne = int(run_off.numpy()[-1])
+    runs = eng.empty(ne + 1, np.uint64).fill(0)
+    counts2, _ = eng.maf_pair_stat(n, rows, d_t, d_q, d_c, d_s, counts=counts2, run_cnt=run_cnt, runs=runs, run_off=run_off)
+    ocnt = eng.maf_runs_ops(n, ne, runs, run_off, d_c)
+    ooff = eng.exclusive_scan_u64(n, ocnt)
+    oo = ooff.numpy()
+    ops2 = eng.empty(int(oo[-1]) + 4, np.uint32).fill(0)
+    eng.maf_runs_ops(n, ne, runs, run_off, d_c, out=ops2, out_off=ooff)
+    assert (oo == b["op_off"]).all(), "op counts per record differ"
+    got = ops2.numpy()[: int(oo[-1])]
+    if not (got == b["ops"]).all():
+        k = int(np.flatnonzero(got != b["ops"])[0])
+        raise AssertionError("op %d differs: %#x vs %#x" % (k, int(got[k]), int(b["ops"][k])))
+    c2 = counts2.numpy()
+    for f in c.dtype.names:
+        assert (c2[f] == c[f]).all(), f
+    return int(oo[-1])
+
+
 def wide_tile_batch(eng, seed=3):
     """records whose tiles hold 65 536 .. 2^31 columns (one long D / I op each, next to ordinary ops): the u32
     instance of the planned row kernel; the short records around them stay in narrow tiles"""
@@ -586,6 +663,29 @@ def check_maf_call_runs(eng, pairs):
         assert ((mine[:, 0] & np.uint64(7)).astype(np.int64) == cls[starts]).all(), i
         assert (mine[:, 1].astype(np.int64) == tb).all(), i
         assert (mine[:, 2].astype(np.int64) == qb).all(), i
+        # ... and against the ORACLE: the variants call_within_var (caller.rs:388-608, orc_call_within_var) reports for
+        # this pair as one chunk with -s -l0 are exactly what the run list implies — a SNP per column of an X run, an
+        # INS / DEL per target- / query-gap run that follows an = or X run (both-gap runs in between do not count),
+        # anchored at the target base before it
+        if L and not (tg & qg).all():
+            t_start = 1000 + 7 * i
+            vcf = orc.call_within_var("chrT", "qry", t, q, t_start, t_start + int((~tg).sum()), 50, 50 + int((~qg).sum()),
+                                      False, True, 0, False)
+            want = [(int(f[1]), "INS" if "SVTYPE=INS" in f[7] else "DEL" if "SVTYPE=DEL" in f[7] else "SNP",
+                     int(f[7].split("SVLEN=")[1].split(";")[0]) if "SVLEN=" in f[7] else 1)
+                    for f in (ln.split("\t") for ln in vcf.splitlines())]
+            got, after_m = [], False   # after_m (caller.rs:453): set by = / X groups, cleared by I / D, kept by W
+            ends = list(mine[1:, 0] >> np.uint64(3)) + [L]
+            for k in range(len(mine)):
+                s0, c = int(mine[k, 0] >> np.uint64(3)), int(mine[k, 0] & np.uint64(7))
+                ln, tbk = int(ends[k]) - s0, int(mine[k, 1])
+                if c == 3:
+                    got += [(t_start + tbk + j + 1, "SNP", 1) for j in range(ln)]
+                elif c in (1, 2) and after_m:
+                    got.append((t_start + tbk, "INS" if c == 1 else "DEL", ln))
+                after_m = True if c in (0, 3) else False if c in (1, 2) else after_m
+            d = next((k for k in range(min(len(got), len(want))) if got[k] != want[k]), min(len(got), len(want)))
+            assert got == want, (i, d, got[max(0, d - 2):d + 3], want[max(0, d - 2):d + 3], t[:60], q[:60])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -630,15 +730,37 @@ def check_paf_call_events(eng, ops, op_off, svlen, snp):
     ev = eng.empty(3 * int(o[-1]) + 3, np.uint64).fill(0)
     eng.paf_call_events(batch, svlen, snp, ev_cnt=cnt, ev=ev, ev_off=off)
     e = ev.numpy()
+    rng = np.random.default_rng(17)
     for i in range(n):
-        want = expected_paf_call_events(ops[int(op_off[i]):int(op_off[i + 1])], svlen, snp)
+        rops = ops[int(op_off[i]):int(op_off[i + 1])]
+        want = expected_paf_call_events(rops, svlen, snp)
         got = [tuple(int(x) for x in e[3 * k:3 * k + 3]) for k in range(int(o[i]), int(o[i + 1]))]
         assert got == want, (i, got[:5], want[:5])
+        # ... and against the ORACLE (orc_call_within_var_paf, caller.rs:610-822): the event list implies exactly the
+        # VCF rows it writes for the record — one SNP per base of an X op, one INS / DEL per event op, anchored at the
+        # target base before it.  Records with split (>= 2^28) indels are left to the python restatement above.
+        if len(rops) and not ((rops & 15) >= 9).any() and len(rops) < 4000:
+            t_cons = int(sum(int(w) >> 4 for w in rops if (int(w) & 15) in (0, 2, 7, 8)))
+            q_cons = int(sum(int(w) >> 4 for w in rops if (int(w) & 15) in (0, 1, 7, 8)))
+            t_seq, q_seq = rand_seq(rng, t_cons + 1, b"ACGT"), rand_seq(rng, q_cons + 1, b"ACGT")
+            t_start = 500 + 3 * i
+            vcf = orc.call_within_var_paf("tchr", "qchr", text_any(rops), t_seq, q_seq, t_start, t_start + t_cons, 70,
+                                          70 + q_cons, False, snp, svlen)
+            want_rows = [(int(f[1]), "INS" if "SVTYPE=INS" in f[7] else "DEL" if "SVTYPE=DEL" in f[7] else "SNP")
+                         for f in (ln.split("\t") for ln in vcf.splitlines())]
+            got_rows = []
+            for k, t, q in got:
+                code, ln = int(rops[k]) & 15, int(rops[k]) >> 4
+                if code == 8:
+                    got_rows += [(t_start + t + j + 1, "SNP") for j in range(ln)]
+                else:
+                    got_rows.append((t_start + t, "INS" if code == 1 else "DEL"))
+            assert got_rows == want_rows, (i, got_rows[:6], want_rows[:6])
     return int(o[-1])
 
 
 # ------------------------------------------------------------------------------------------------
-# K8 device tokeniser vs the host packer (which is tested against the oracle's messages)
+# K8 device tokeniser (and the host packer) vs the oracle's token stream
 # ------------------------------------------------------------------------------------------------
 TOKENISER_EDGE_TEXTS = [
     b"", b"5", b"M", b"5M", b"10=3I", b"12", b"3M4", b"3MM2I", b"3M2II", b"I", b"4=I3M", b"0M", b"00012=",
@@ -652,8 +774,33 @@ TOKENISER_EDGE_TEXTS = [
 ]
 
 
+PACK_CODES = {ord(c): k for k, c in enumerate("MIDNSHP=X")}
+OP_MAX_LEN = (1 << 28) - 1
+
+
+def oracle_packed(text):
+    """the packed u32 stream the boundary defines (include/wga_hip.h: len << 4 | code, lengths beyond 2^28 - 1 split,
+    later pieces of an I / D marked as continuations) for the tokens the ORACLE yields (orc_tokenise, cigar.rs:43-75),
+    its error kind as a wga_rec_err and the quoted token span"""
+    toks, kind, span = orc.tokenise(text)
+    ops = []
+    for ln, ch in toks:
+        code = PACK_CODES.get(ch, 11)
+        cont = 9 if code == 1 else 10 if code == 2 else code
+        first = True
+        while True:
+            piece = min(ln, OP_MAX_LEN)
+            ops.append((piece << 4) | (code if first else cont))
+            ln -= piece
+            first = False
+            if ln == 0:
+                break
+    return np.array(ops, dtype=np.uint32), kind, span
+
+
 def check_tokeniser(eng, texts):
-    """count pass + scan + fill pass must reproduce wga_cigar_pack for every record"""
+    """count pass + scan + fill pass must reproduce the oracle's token stream (packed as the boundary defines) for
+    every record, its error kind and the token the message quotes — and so must the host packer"""
     n = len(texts)
     offs = np.zeros(n + 1, dtype=np.uint64)
     offs[1:] = np.cumsum([len(t) for t in texts], dtype=np.uint64)
@@ -666,7 +813,11 @@ def check_tokeniser(eng, texts):
     eng.cigar_tokenise(n, d_text, d_off, op_cnt=cnt, err=err, ops=ops, op_off=op_off)
     c, e, o = cnt.numpy(), err.numpy(), ops.numpy()
     for i, t in enumerate(texts):
-        want_ops, want_err, (eo, el) = eng.pack_cigar(t)
+        want_ops, want_err, (eo, el) = oracle_packed(t)
+        h_ops, h_err, h_span = eng.pack_cigar(t)       # the host packer of the same library
+        assert (h_ops == want_ops).all() and h_err == want_err, (i, t[:40], h_err, want_err)
+        if want_err not in (0, 6):
+            assert tuple(h_span) == (eo, el), (i, t[:40], h_span, eo, el)
         assert int(c[i]) == len(want_ops), (i, t[:40], int(c[i]), len(want_ops))
         got = o[int(oo[i]):int(oo[i + 1])]
         assert (got == want_ops).all(), (i, t[:40], got[:8], want_ops[:8])

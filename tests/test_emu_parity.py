@@ -133,6 +133,10 @@ def test_paf2maf_planned_kernel_errors_and_long_record(emu):
     pc.check_paf2maf(emu, bad, variant=1)
 
 
+def test_paf2maf_maf2paf_roundtrip(emu):
+    assert pc.check_paf2maf_maf2paf_roundtrip(emu, 5, 24, 180) > 3000
+
+
 def test_scan_and_scatter(emu):
     rng = np.random.default_rng(3)
     for n in (0, 1, 5, 1024, 1025, 5000, 300000):

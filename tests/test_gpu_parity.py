@@ -131,6 +131,11 @@ def test_paf2maf_config2_full_size_properties(gpu):
         assert job.record_rows(i) == pc.oracle_rows(r, 0), i
 
 
+def test_paf2maf_maf2paf_roundtrip(gpu):
+    """5e6 ops / 7e7 columns: K1 + K2 and K3 + K11 agree on every op and counter"""
+    assert pc.check_paf2maf_maf2paf_roundtrip(gpu, 9, 1200, 4000) > 4_500_000
+
+
 def test_paf2maf_planned_kernel(gpu):
     pc.planned_kernel_cases(gpu)
     pc.check_paf2maf(gpu, synth.make_paf_batch(6, 500, 400, 2_000_000), variant=1)

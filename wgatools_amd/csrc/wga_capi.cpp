@@ -232,25 +232,31 @@ int wga_ctx_create(int device, wga_ctx** out) {
 }
 
 void wga_ctx_destroy(wga_ctx* c) {
-  if (c && c->timing)
-    for (int k = 0; k < 2 * wga_ctx::kTimingRing; k++) rt_event_destroy(c->ev[k]);
   if (!c) return;
   (void)rt_set_device(c->device);
   (void)rt_sync(c->stream);
+  if (c->timing)
+    for (int k = 0; k < 2 * wga_ctx::kTimingRing; k++) rt_event_destroy(c->ev[k]);
   if (c->scratch) (void)rt_free(c->scratch);
   if (c->cov_pieces) (void)rt_free(c->cov_pieces);
   rt_stream_destroy(c->own_stream);
   delete c;
 }
 
+/* The context's scratch arenas are ordered on ONE stream: work still in flight on the stream that is being left must
+ * not see them reused or regrown by calls on the new one, so a switch drains the old stream first. */
 int wga_ctx_set_stream(wga_ctx* c, void* hip_stream) {
-  if (!c) return fail(WGA_E_INVALID_ARG, "null context", nullptr);
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (c->stream != (wga_stream_t)hip_stream) RT_CHECK(rt_sync(c->stream));
   c->stream = (wga_stream_t)hip_stream;
   return WGA_OK;
 }
 
 int wga_ctx_reset_stream(wga_ctx* c) {
-  if (!c) return fail(WGA_E_INVALID_ARG, "null context", nullptr);
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (c->stream != c->own_stream) RT_CHECK(rt_sync(c->stream));
   c->stream = c->own_stream;
   return WGA_OK;
 }
@@ -281,7 +287,13 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
     if (value && !c->timing) {
       int rc = ctx_bind(c);
       if (rc) return rc;
-      for (int k = 0; k < 2 * wga_ctx::kTimingRing; k++) RT_CHECK(rt_event_create(&c->ev[k]));
+      for (int k = 0; k < 2 * wga_ctx::kTimingRing; k++) {
+        const char* e = rt_event_create(&c->ev[k]);
+        if (e) { /* give back what was created: `timing` stays off, nobody else would destroy them */
+          for (int j = 0; j < k; j++) rt_event_destroy(c->ev[j]);
+          return fail(WGA_E_HIP, "rt_event_create", e);
+        }
+      }
     }
     if (!value && c->timing)
       for (int k = 0; k < 2 * wga_ctx::kTimingRing; k++) rt_event_destroy(c->ev[k]);

@@ -37,6 +37,12 @@ std::string read_all(const std::string* path) {
   char buf[1 << 16];
   int n;
   while ((n = gzread(f, buf, sizeof buf)) > 0) out.append(buf, (size_t)n);
+  if (n < 0) { /* a damaged / truncated gzip member: the reference's decoder raises an io::Error (errors.rs:10) */
+    int ec = 0;
+    const std::string why = gzerror(f, &ec);
+    gzclose(f);
+    fail("IO error:" + why);
+  }
   gzclose(f);
   return out;
 }
@@ -67,7 +73,17 @@ bool LineChunkReader::next(std::string& piece, size_t target, size_t keep) {
     if (eof) return false;
     const size_t at = piece.size();
     piece.resize(at + kRead);
-    size_t n = is_stdin ? fread(&piece[at], 1, kRead, stdin) : (size_t)std::max(0, gzread((gzFile)gz, &piece[at], (unsigned)kRead));
+    size_t n;
+    if (is_stdin) {
+      n = fread(&piece[at], 1, kRead, stdin);
+    } else {
+      const int got = gzread((gzFile)gz, &piece[at], (unsigned)kRead);
+      if (got < 0) { /* a damaged / truncated gzip member is an error, not the end of the input (errors.rs:10) */
+        int ec = 0;
+        fail(std::string("IO error:") + gzerror((gzFile)gz, &ec));
+      }
+      n = (size_t)got;
+    }
     piece.resize(at + n);
     if (n == 0) eof = true;
     return n != 0;
@@ -516,21 +532,28 @@ static std::vector<std::string> split_ws(const std::string& line) {
 }
 
 static MafSLine parse_sline(const std::string& line) { /* maf.rs:138-211 */
+  /* the reference takes the tokens left to right and fails at the FIRST one that is absent or malformed: a short
+   * line with a bad number reports the number, not the missing field behind it */
   static const char* names[] = {"mode", "name", "start", "align_size", "strand", "size", "seq"};
   std::vector<std::string> f = split_ws(line);
-  if (f.size() < 7) fail(std::string("Parse MAF error by: S-line Filed `") + names[f.size()] + "` Missing");
+  auto need = [&](size_t k) -> const std::string& {
+    if (k >= f.size()) fail(std::string("Parse MAF error by: S-line Filed `") + names[k] + "` Missing");
+    return f[k];
+  };
   MafSLine s;
-  s.name = f[1];
-  if (!parse_u64(f[2], &s.start)) fail("Parse `" + f[2] + "` Into Integer Error");
-  if (!parse_u64(f[3], &s.align_size)) fail("Parse `" + f[3] + "` Into Integer Error");
-  if (f[4] == "+")
+  (void)need(0);
+  s.name = need(1);
+  if (!parse_u64(need(2), &s.start)) fail("Parse `" + f[2] + "` Into Integer Error");
+  if (!parse_u64(need(3), &s.align_size)) fail("Parse `" + f[3] + "` Into Integer Error");
+  const std::string& st = need(4);
+  if (st == "+")
     s.neg = false;
-  else if (f[4] == "-")
+  else if (st == "-")
     s.neg = true;
   else
-    fail("Parse Strand `" + f[4] + "` Error");
-  if (!parse_u64(f[5], &s.size)) fail("Parse `" + f[5] + "` Into Integer Error");
-  s.seq = f[6];
+    fail("Parse Strand `" + st + "` Error");
+  if (!parse_u64(need(5), &s.size)) fail("Parse `" + f[5] + "` Into Integer Error");
+  s.seq = need(6);
   if (f.size() > 7) fail("Parse MAF error by: Surplus Filed > 7");
   return s;
 }
@@ -731,8 +754,8 @@ void Faidx::load(const std::string& path) {
   std::string cur;
   uint64_t cur_off = 0;
   bool have = false;
-  auto close = [&]() {
-    if (have) contigs[cur] = Contig{(uint64_t)pool.size() - cur_off, cur_off};
+  auto close = [&]() { /* a repeated name keeps its FIRST sequence, as htslib's fai_build does */
+    if (have) contigs.emplace(cur, Contig{(uint64_t)pool.size() - cur_off, cur_off});
   };
   while (p < n) {
     size_t e = text.find('\n', p);
