@@ -24,79 +24,136 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy rate
 
 
-def cpu_baseline(tb, budget_s=12.0, max_records=40000):
-    """The oracle (oracle/oracle.c: reference-faithful port, text tokenising + String::insert_str
-    tail memmoves) timed on the host over a bounded sample of the same batch.  `value` is ONE core —
-    the reference's paf2maf is a serial loop (converter.rs:196) — and `all_cores` shows the same
-    per-record work spread over every host core (what a rayon-parallel paf2maf would get; the
-    reference only parallelises stat)."""
+def host_info():
+    """CPU model / sockets / cores / threads / NUMA nodes of the box the baseline runs on, and how the port was built"""
+    info = {}
+    try:
+        import subprocess
+        for line in subprocess.run(["lscpu"], stdout=subprocess.PIPE, text=True).stdout.splitlines():
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k in ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core", "NUMA node(s)", "CPU(s)"):
+                info[k] = v
+    except Exception:
+        pass
+    info["usable_threads"] = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    info["numa_policy"] = "none (threads float; first-touch)"
+    info["build"] = "gcc -O2 -std=gnu11, pthreads (oracle/Makefile)"
+    return info
+
+
+def cpu_baseline(tb, budget_s=8.0, max_records=40000):
+    """oracle/cpu_bench.c on the host cores over a bounded sample (the first records) of the same batch, BASELINE.md
+    section 3's three forms:
+      ref_faithful_1    stat + paf2maf exactly as the reference structures them (text tokenised per consumer,
+                        String::insert_str tail memmoves), one thread — the reference's default -t 1
+      ref_faithful_all  the same with -t <all cores>: stat spreads over the cores (rayon par_bridge, stat.rs:67-81),
+                        paf2maf stays the serial loop it is in the reference (converter.rs:196)
+      optimised_all     one pass over packed ops, linear-time rows, every core on both tools
+    `value` = ref_faithful_1 (cores 1).  Baselines, not targets: the GPU / CPU ratio says nothing about kernel quality."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle_py as orc
-    from concurrent.futures import ThreadPoolExecutor
-    n = min(tb["n"], max_records)
-    op_off = tb["op_off"][: n + 1].cpu().numpy()
-    ops = tb["ops"][: int(op_off[n])].cpu().numpy().view(np.uint32)
-    t_pool, q_pool = tb["t_pool"].cpu().numpy(), tb["q_pool"].cpu().numpy()
-    to, tl = tb["t_src_off"][:n].cpu().numpy(), tb["t_src_len"][:n].cpu().numpy()
-    qo, ql = tb["q_src_off"][:n].cpu().numpy(), tb["q_src_len"][:n].cpu().numpy()
-    strand = tb["strand_neg"][:n].cpu().numpy()
     orc.lib()
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_all = min(tb["n"], max_records)
+    op_off = tb["op_off"][: n_all + 1].cpu().numpy().astype(np.uint64)
+    ops = tb["ops"][: int(op_off[n_all])].cpu().numpy().view(np.uint32)
+    t_pool, q_pool = tb["t_pool"].cpu().numpy(), tb["q_pool"].cpu().numpy()
 
-    def prep(i):                                    # input preparation: never timed
-        a, b = int(op_off[i]), int(op_off[i + 1])
-        return (orc.ops_to_text(ops[a:b]), t_pool[int(to[i]):int(to[i] + tl[i])].tobytes(),
-                q_pool[int(qo[i]):int(qo[i] + ql[i])].tobytes(), int(strand[i]), b - a)
+    def arrays(n, with_text=True):
+        blob = cg_off = None
+        if with_text:   # input preparation: never timed
+            texts = [orc.ops_to_text(ops[int(op_off[i]):int(op_off[i + 1])]) for i in range(n)]
+            texts = [t if isinstance(t, bytes) else t.encode() for t in texts]
+            cg_off = np.zeros(n + 1, dtype=np.uint64)
+            cg_off[1:] = np.cumsum([len(t) for t in texts])
+            blob = np.frombuffer(b"".join(texts), dtype=np.uint8).copy()
+        f = lambda k: np.ascontiguousarray(tb[k][:n].cpu().numpy().astype(np.uint64))
+        return (blob, cg_off, ops, np.ascontiguousarray(op_off[: n + 1]), np.ascontiguousarray(tb["strand_neg"][:n].cpu().numpy()),
+                t_pool, f("t_src_off"), f("t_src_len"), q_pool, f("q_src_off"), f("q_src_len"))
 
-    def work(x):
-        cg, t, q, neg, nops = x
-        t0 = time.perf_counter()
-        orc.parse_paf_to_cigar(cg, neg)                       # stat
-        if neg:
-            q = orc.reverse_complement(q)                     # paf2maf
-        orc.parse_cigar_to_insert(cg, t, q)
-        return nops, time.perf_counter() - t0
+    # pilot: how many records fit the budget of the slowest leg (serial quadratic paf2maf)
+    pilot = min(n_all, 200)
+    r = orc.bench_run(1, 1, *arrays(pilot))
+    per_rec = max(r.seconds / pilot, 1e-6)
+    n = int(max(pilot, min(n_all, budget_s / per_rec)))
+    a = arrays(n)
+    stat1 = orc.bench_run(0, 1, *a)
+    p2m1 = orc.bench_run(1, 1, *a)
+    stat_all = orc.bench_run(0, threads, *a)
+    p2m_all = orc.bench_run(1, threads, *a)
+    big = arrays(n_all, with_text=False)   # the packed-op port is fast: it gets the larger sample
+    opt1 = orc.bench_run(2, 1, *big)
+    opt_all = orc.bench_run(2, threads, *big)
+    nops = int(stat1.ops)
+    rate = lambda secs: nops / secs
+    sample = "first %d records (%d ops) of the same batch" % (n, nops)
+    return {
+        "value": rate(stat1.seconds + p2m1.seconds), "unit": "ops/s", "cores": 1, "kind": "port",
+        "sample": sample + ": stat %.2f s + paf2maf %.2f s on one core" % (stat1.seconds, p2m1.seconds),
+        "ref_faithful_1": {"value": rate(stat1.seconds + p2m1.seconds), "unit": "ops/s", "cores": 1,
+                           "stat_ops_per_s": rate(stat1.seconds), "paf2maf_ops_per_s": rate(p2m1.seconds)},
+        "ref_faithful_all": {"value": rate(stat_all.seconds + p2m1.seconds), "unit": "ops/s", "cores": threads,
+                             "stat_ops_per_s": rate(stat_all.seconds), "paf2maf_ops_per_s": rate(p2m1.seconds),
+                             "note": "stat over %d threads (par_bridge); paf2maf is a serial loop in the reference "
+                                     "(converter.rs:196) and stays on one core" % threads,
+                             "paf2maf_if_it_were_parallel_ops_per_s": rate(p2m_all.seconds)},
+        "optimised_all": {"value": opt_all.ops / opt_all.seconds, "unit": "ops/s", "cores": threads,
+                          "one_core_ops_per_s": opt1.ops / opt1.seconds,
+                          "sample": "first %d records (%d ops)" % (n_all, int(opt1.ops)),
+                          "note": "single pass over packed ops, linear-time rows, stat + paf2maf fused"},
+        "host": host_info(),
+    }
 
-    ops_done, done, t_work = 0, 0, 0.0
-    t_start = time.perf_counter()
-    for i in range(n):
-        o, dt = work(prep(i))
-        ops_done += o
-        t_work += dt
-        done += 1
-        if t_work > budget_s or time.perf_counter() - t_start > 4 * budget_s:
-            break
-    res = {"value": ops_done / t_work, "unit": "ops/s", "cores": 1, "kind": "port",
-           "sample": "first %d records (%d ops) of the same batch, stat + paf2maf per record, "
-                     "%.1f s of oracle time on 1 core" % (done, ops_done, t_work)}
-    # the same per-record work over all cores (ctypes drops the GIL inside the oracle calls)
-    cores = os.cpu_count() or 1
-    if cores > 1:
-        m = min(n, 8000)
-        items = [prep(i) for i in range(m)]
-        t1 = time.perf_counter()
-        with ThreadPoolExecutor(max_workers=cores) as ex:
-            tot = sum(o for o, _ in ex.map(work, items, chunksize=4))
-        wall = time.perf_counter() - t1
-        res["all_cores"] = {"value": tot / wall, "unit": "ops/s", "cores": cores,
-                            "sample": "%d records (%d ops) in %.2f s wall over %d threads" % (m, tot, wall, cores)}
-    return res
+
+def kernel_source_sha():
+    """the row kernel's source: roofline.traffic is only valid for the kernel it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("wga_kernels.h", "wga_kernels_k2p.h"):
+        h.update(open(os.path.join(ROOT, "wgatools_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(args, job):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE and
-    WRITE_SIZE are collected in their own rocprofv3 runs — scripts/gpu_pmc.sh — and corrected as
-    MI355X_MICROARCH.md prescribes; they cannot be read live).  Only valid for the workload they
-    were measured on."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        t = json.load(open(path))
-    except Exception:
-        return None
-    w = t.get("workload", {})
-    if w.get("records") != args.records or w.get("mean_ops") != args.mean_ops or w.get("ops") != job.n_ops:
-        return None
-    return t["hbm_bytes_per_launch"]
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE and WRITE_SIZE are
+    collected in their own rocprofv3 runs — scripts/gpu_pmc.sh — and corrected as MI355X_MICROARCH.md prescribes; they
+    cannot be read live).  Only valid for the workload AND the kernel source they were measured on: anything else -> null."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        w = t.get("workload", {})
+        if w.get("records") != args.records or w.get("mean_ops") != args.mean_ops or w.get("ops") != job.n_ops:
+            continue
+        if t.get("kernel_source_sha") != kernel_source_sha():
+            continue
+        return t["hbm_bytes_per_launch"]
+    return None
+
+
+def extra_shape(eng, synth, pipeline, torch, dev, seed, records, mean_ops, pool_mb, steps=3):
+    """K2 alone on another shape of the workload (the pool size and the record length move the fraction: the default
+    50 Mb pools sit in the 256 MB Infinity Cache) -> (kernel ms, fraction of the HBM peak)"""
+    tb = synth.make_paf_batch_torch(seed, records, mean_ops, pool_mb * 1_000_000, dev)
+    job = pipeline.Paf2MafStatJob(eng, tb)
+    job.bind_stream()
+    job.step()
+    torch.cuda.synchronize()
+    eng.expand_timing()   # drop what the warm-up recorded
+    for _ in range(steps):
+        job.step()
+    torch.cuda.synchronize()
+    ms_sum, n_timed = eng.expand_timing()
+    ms = ms_sum / max(1, n_timed)
+    ok = bool((job.diag == -1).all())
+    frac = job.algorithmic_bytes()["expand"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    del job, tb
+    torch.cuda.empty_cache()
+    assert ok, "kernel reported per-record errors on clean synthetic input"
+    return ms, frac
 
 
 def main():
@@ -112,6 +169,7 @@ def main():
     ap.add_argument("--param", action="append", default=[], help="engine test knob name=value")
     ap.add_argument("--neg-frac", type=float, default=0.5)
     ap.add_argument("--m-only", action="store_true", help="variant of configs[1] with = / X merged into M ops")
+    ap.add_argument("--no-extras", action="store_true", help="skip the genome-sized-pool and 50-kop-record K2 measurements")
     args = ap.parse_args()
 
     import torch
@@ -224,6 +282,9 @@ def main():
                 "k_cigar_stat_GBps": ab["stat"] / (k_stat * 1e-3) / 1e9,
             },
         }
+        result["metric_scope"] = ("kernel-only: K1 + layout + K2 (+ totals) on packed ops and sequence pools resident in HBM; no "
+                                  "CIGAR tokenising, PAF / FASTA parsing, PCIe or file I/O — file-to-file command-line timings "
+                                  "are in profiles/ (r02_cli_e2e.txt) and DESIGN.md section 6")
         if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only
             result["cpu_baseline"] = cpu_baseline(tb)
             # part of the same leg (the only place bench.py touches oracle/): a few of the rows the timed steps
@@ -238,6 +299,18 @@ def main():
                     gt, gq = job.record_rows(i)
                     assert gt == et and gq == eq, "record %d differs from the oracle" % i
                 result["cpu_baseline"]["parity_spot_check"] = "%d records bit-identical to oracle rows" % len(step_idx)
+        if world == 1 and not args.no_extras and not args.param and args.records == 100_000 and args.mean_ops == 5000:
+            # the same kernel where the default shape flatters it: pools beyond the Infinity Cache, and the
+            # north-star record length
+            del job
+            torch.cuda.empty_cache()
+            ms_g, frac_g = extra_shape(eng, synth, pipeline, torch, dev, seed, args.records, args.mean_ops, 1000)
+            ms_l, frac_l = extra_shape(eng, synth, pipeline, torch, dev, seed + 100, 10_000, 50_000, args.pool_mb)
+            ms_lg, frac_lg = extra_shape(eng, synth, pipeline, torch, dev, seed + 100, 10_000, 50_000, 1000)
+            result["roofline"]["frac_genome_pools"] = frac_g
+            result["roofline"]["frac_50kop_records"] = frac_l
+            result["roofline"]["frac_50kop_records_genome_pools"] = frac_lg
+            result["roofline"]["extra_shapes_ms"] = {"2x1GB_pools": ms_g, "10000x50kop": ms_l, "10000x50kop_2x1GB_pools": ms_lg}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

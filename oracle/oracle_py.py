@@ -39,7 +39,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        src = [os.path.join(ROOT, "oracle", f) for f in ("oracle.c", "oracle.h")]
+        src = [os.path.join(ROOT, "oracle", f) for f in ("oracle.c", "cpu_bench.c", "oracle.h")]
         if not os.environ.get("WGA_ORACLE_LIB") and (not os.path.exists(LIB_PATH)
                 or any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH)
                        for s in src)):
@@ -388,3 +388,22 @@ def tokenise(text):
     err = Err()
     kind = lib().orc_tokenise(text, len(text), lens, opc, cap, C.byref(n), C.byref(err), C.byref(eo), C.byref(el))
     return [(int(lens[i]), int(opc[i])) for i in range(n.value)], int(kind), (eo.value, el.value)
+
+
+class BenchResult(C.Structure):
+    _fields_ = [("seconds", C.c_double), ("ops", C.c_uint64), ("out_bytes", C.c_uint64), ("checksum", C.c_uint64)]
+
+
+def bench_run(mode, threads, cg_blob, cg_off, ops, op_off, strand, t_pool, t_off, t_len, q_pool, q_off, q_len):
+    """oracle/cpu_bench.c: mode 0 ref-faithful stat, 1 ref-faithful paf2maf, 2 optimised stat + paf2maf; numpy arrays in"""
+    L = lib()
+    P = C.c_void_p
+    L.orc_bench_run.argtypes = [C.c_int, C.c_int, C.c_uint32] + [P] * 11 + [P]
+    n = len(strand)
+    res = BenchResult()
+    ptr = lambda a: a.ctypes.data_as(P) if a is not None else None
+    rc = L.orc_bench_run(mode, threads, n, ptr(cg_blob), ptr(cg_off), ptr(ops), ptr(op_off), ptr(strand), ptr(t_pool),
+                         ptr(t_off), ptr(t_len), ptr(q_pool), ptr(q_off), ptr(q_len), C.byref(res))
+    if rc:
+        raise RuntimeError("cpu_bench: a record failed (rc %d)" % rc)
+    return res

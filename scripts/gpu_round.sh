@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call: parity tests, smoke, bench, rocprofv3 kernel stats.  Everything lands in
 # gpurun_out/ (merged back by gpurun).  Usage: gpurun -- 'bash scripts/gpu_round.sh [tag]'
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT

@@ -32,8 +32,10 @@ k = "k_paf2maf_expand"
 fetch_kb, write_kb = agg_all[(k, "FETCH_SIZE")], agg_all[(k, "WRITE_SIZE")]
 rd = 2.0 * fetch_kb * 1024 / launches   # gfx950: FETCH_SIZE = TCC_EA0_RDREQ x 64 B tallies 128-B requests at 64 B
 wr = write_kb * 1024 / launches
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (kernel_source_sha: the traffic figure is only valid for the kernel source it was measured on)
 json.dump({
-    "kernel": k, "launches": launches,
+    "kernel": k, "launches": launches, "kernel_source_sha": bench.kernel_source_sha(),
     "workload": {"records": records, "mean_ops": mean_ops, "ops": ops},
     "FETCH_SIZE_KB_sum": fetch_kb, "WRITE_SIZE_KB_sum": write_kb,
     "TCC_EA0_RDREQ_sum": agg_all.get((k, "TCC_EA0_RDREQ_sum")), "TCC_EA0_WRREQ_sum": agg_all.get((k, "TCC_EA0_WRREQ_sum")),

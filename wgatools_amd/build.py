@@ -104,7 +104,7 @@ def build_cli_emu(force=False):
 
 
 def build_oracle(force=False):
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle.c", "oracle.h")]
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle.c", "cpu_bench.c", "oracle.h")]
     if not force and not _newer(ORACLE_LIB, srcs):
         return ORACLE_LIB
     _run(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
