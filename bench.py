@@ -170,6 +170,11 @@ def main():
     ap.add_argument("--neg-frac", type=float, default=0.5)
     ap.add_argument("--m-only", action="store_true", help="variant of configs[1] with = / X merged into M ops")
     ap.add_argument("--no-extras", action="store_true", help="skip the genome-sized-pool and 50-kop-record K2 measurements")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): --records per GPU; strong: --records in all, sharded by hash(target_name) %% N")
+    ap.add_argument("--targets", type=int, default=64, help="strong scaling: number of target names")
+    ap.add_argument("--zipf", type=float, default=1.2, help="strong scaling: skew of the records over the targets "
+                                                            "(P(target k) ~ 1 / (k + 1)^zipf; 0 = uniform)")
     args = ap.parse_args()
 
     import torch
@@ -185,14 +190,32 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from wgatools_amd import engine, pipeline, synth
+    from wgatools_amd import engine, multigpu, pipeline, synth
     eng = engine.Engine(local_rank)
     for kv in args.param:
         k, v = kv.split("=")
         eng.set_param(k, int(v))
     seed = 0x5747415F + 2 + rank
-    tb = synth.make_paf_batch_torch(seed, args.records, args.mean_ops, args.pool_mb * 1_000_000, dev,
-                                    neg_frac=args.neg_frac, use_m=args.m_only)
+    strong = args.scaling == "strong"
+    if strong:
+        # ONE global batch whatever N: record lengths and target names from the global seed; a rank generates the records
+        # fnv1a64(target_name) % N gives it (the product's sharding rule), so the skew over targets becomes load imbalance
+        import numpy as np
+        gseed = 0x5747415F + 2
+        n_ops_all = synth.record_lengths(gseed, args.records, args.mean_ops)
+        rng = np.random.default_rng(gseed + 1)
+        p = 1.0 / np.arange(1, args.targets + 1) ** args.zipf
+        tid = rng.choice(args.targets, size=args.records, p=p / p.sum())
+        names = ["g%02d#1#chr1" % k for k in range(args.targets)]
+        owner = multigpu.owners([names[k] for k in tid], world)
+        mine = multigpu.my_records(owner, rank)
+        tb = synth.make_paf_batch_torch(seed, len(mine), args.mean_ops, args.pool_mb * 1_000_000, dev,
+                                        neg_frac=args.neg_frac, use_m=args.m_only, n_ops=n_ops_all[mine])
+        mine_idx = torch.as_tensor(mine, dtype=torch.int64, device=dev)
+        sizes_global = torch.zeros(args.records, dtype=torch.int64, device=dev)
+    else:
+        tb = synth.make_paf_batch_torch(seed, args.records, args.mean_ops, args.pool_mb * 1_000_000, dev,
+                                        neg_frac=args.neg_frac, use_m=args.m_only)
     job = pipeline.Paf2MafStatJob(eng, tb)
     job.bind_stream()
     totals = torch.zeros(11, dtype=torch.int64, device=dev)
@@ -204,6 +227,14 @@ def main():
         if evs:
             evs[1].record()
         job.layout()
+        if strong:
+            # ordered output without a gather: every record's byte count is known now, before a row byte exists; one
+            # all-reduce of the global size vector gives each rank the final (input-order) offsets of its records
+            sizes_global.zero_()
+            sizes_global[mine_idx] = job.rec_off[1:] - job.rec_off[:-1]
+            if world > 1:
+                dist.all_reduce(sizes_global)
+            global_off = torch.cumsum(sizes_global, 0) - sizes_global   # noqa: F841  (what the writer would use)
         if evs:
             evs[2].record()
         job.expand()
@@ -242,6 +273,7 @@ def main():
     if not args.param:
         assert bool((job.diag == -1).all()), "kernel reported per-record errors on clean synthetic input"
 
+    per_rank_ops, imb = multigpu.imbalance(job.n_ops, dist if world > 1 else None, dev)
     if rank == 0:
         k_stat = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
         k_layout = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
@@ -260,17 +292,22 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: paf2maf+stat, %d records/GPU x mean %d ops "
+                "workload": "BASELINE configs[1]: paf2maf+stat, %d records%s x mean %d ops "
                             "(lognormal s=0.5; =/X/I/D mix), 2 x %d Mb pools, strand 50/50, "
-                            "HBM-resident" % (args.records, args.mean_ops, args.pool_mb),
+                            "HBM-resident" % (args.records, "" if strong else "/GPU", args.mean_ops, args.pool_mb),
                 "records_per_gpu": args.records, "ops_per_gpu": job.n_ops,
                 "columns_per_gpu": int((tb["mx"] + tb["i"] + tb["d"]).sum()),
-                "output_bytes_per_gpu": job.out_bytes, "sharding": "records, no data-path collective",
+                "output_bytes_per_gpu": job.out_bytes,
+                "sharding": ("one global batch of %d records over %d target names (zipf %.2f), rank = fnv1a64(target_name) %% N; "
+                             "per step one all-reduce of the per-record output sizes (ordered output) and one of the stat "
+                             "totals; row bytes never cross GPUs" % (args.records, args.targets, args.zipf)) if strong
+                            else "records, no data-path collective",
+                "ops_per_rank": per_rank_ops, "imbalance_max_over_mean": imb,
             },
             "input_GBps": in_bytes * world * args.steps / elapsed / 1e9,
             "kernel_ms": {"k_cigar_stat": k_stat, "layout_scan": k_layout, "k_paf2maf_expand": k_expand,

@@ -106,16 +106,27 @@ def cigar_text(ops_slice):
 # ------------------------------------------------------------------------------------------------
 # device-side generator (torch is plumbing: it only fills HBM with synthetic input)
 # ------------------------------------------------------------------------------------------------
+def record_lengths(seed, n_rec, mean_ops, sigma=0.5):
+    """ops per record of the synthetic mixture (lognormal, at least 1): drawn apart so that a global batch can be cut
+    into shards whose records keep their lengths whatever the number of ranks"""
+    rng = np.random.default_rng(seed)
+    mu = np.log(mean_ops) - 0.5 * sigma * sigma
+    return np.maximum(1, rng.lognormal(mu, sigma, size=n_rec).astype(np.int64))
+
+
 def make_paf_batch_torch(seed, n_rec, mean_ops, pool_bytes, device, use_m=False, sigma=0.5,
-                         neg_frac=0.5):
+                         neg_frac=0.5, n_ops=None):
     """Same mixture as make_paf_batch, generated in HBM.  Returns a dict of torch tensors
-    (ops int32 view of the packed u32 ops, op_off/src offsets int64) plus host n_ops."""
+    (ops int32 view of the packed u32 ops, op_off/src offsets int64) plus host n_ops.
+    n_ops: the records' op counts (default: record_lengths(seed, ...))."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(int(seed))
-    rng = np.random.default_rng(seed)
-    mu = np.log(mean_ops) - 0.5 * sigma * sigma
-    n_ops = np.maximum(1, rng.lognormal(mu, sigma, size=n_rec).astype(np.int64))
+    if n_ops is None:
+        n_ops = record_lengths(seed, n_rec, mean_ops, sigma)
+    else:
+        n_ops = np.asarray(n_ops, dtype=np.int64)
+        n_rec = len(n_ops)
     op_off_h = np.zeros(n_rec + 1, dtype=np.int64)
     np.cumsum(n_ops, out=op_off_h[1:])
     total = int(op_off_h[-1])
