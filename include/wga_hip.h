@@ -341,6 +341,24 @@ int wga_maf_split(wga_ctx*, const uint8_t* d_text, uint64_t n_bytes, uint64_t* n
  *      GPUs these 88 bytes are the only thing `stat` has to all-reduce.  d_totals is overwritten. */
 int wga_counts_total(wga_ctx*, uint32_t n, const wga_cigar_counts* d_counts, uint64_t* d_totals);
 
+/* ---- FASTA text in HBM -> sequence pool (replaces the htslib faidx fetches of converter.rs:183-184,219-225,
+ *      paf.rs:221-237, pseudomaf.rs:214-237: the drivers hand (contig, start, length) as an offset into the pool) ----
+ * d_text = the FASTA file as read (decompressed if it was bgzf / gzip).  A header line starts with '>' at a line start;
+ * the pool holds every byte of the sequence lines behind the first header, minus '\n' and a '\r' in front of one, case
+ * preserved, contigs back to back in file order.  Two calls:
+ *   d_pool == NULL: counts -> *n_contigs, *pool_bytes (host values; synchronises).
+ *   otherwise     : fills d_pool[pool_bytes] and d_contigs[n_contigs]; a contig's name is the text behind '>' at
+ *                   hdr_start up to the first white space (the host reads it from its own copy of the text).
+ * Lookups keep htslib's semantics on the host side: first of duplicate names, end inclusive, clipped to the contig. */
+typedef struct {
+  uint64_t hdr_start; /* offset of the '>'                                          */
+  uint64_t hdr_end;   /* offset of the header line's '\n' (n_bytes if the file ends) */
+  uint64_t pool_off;  /* first base of the contig in the pool                        */
+  uint64_t len;       /* bases                                                       */
+} wga_fa_contig;
+int wga_fasta_pool(wga_ctx*, const uint8_t* d_text, uint64_t n_bytes, uint64_t* n_contigs, uint64_t* pool_bytes,
+                   uint8_t* d_pool, wga_fa_contig* d_contigs);
+
 /* ---- K5: pafcov (replaces update_cov_vec, cigar.rs:710-741, and the per-thread array merge of
  *      pafcov.rs:29-53) ------------------------------------------------------------------------
  * Record i adds +1 to d_cov[cov_off[target_id[i]] + p] for every base p of its M / = ops that

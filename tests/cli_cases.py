@@ -114,6 +114,74 @@ def test_paf2maf_end_to_end(cli, tmp_path):
     assert rc == 0 and gzip.open(gz, "rb").read() == _expected_maf(b, mapq, t_fa, q_fa, 60)
 
 
+def _bgzf_write(path, data, block=0xFF00):
+    """BGZF (SAM spec 4.1): gzip members of <= 64 KB with the block size in a BC extra field, then the EOF marker"""
+    import struct
+    import zlib
+    with open(path, "wb") as f:
+        for a in list(range(0, len(data), block)) + [None]:
+            chunk = b"" if a is None else data[a:a + block]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            cdata = co.compress(chunk) + co.flush()
+            bsize = 18 + len(cdata) + 8
+            f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize - 1) + cdata +
+                    struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+
+def test_paf2maf_fasta_readers(cli, tmp_path):
+    """the sequence pools are built on the device from the uploaded FASTA text — several contigs,
+    ragged line lengths, blank lines, CRLF, duplicate names (the first wins), plain / gzip / BGZF files — and every
+    variant gives the bytes of the host faidx reader (WGA_FASTA_READER=host) and of the oracle"""
+    import gzip
+    b = synth.make_paf_batch(79, 40, 200, 120000)
+    mapq = np.arange(40) % 61
+    t_fa, q_fa, paf = _write_paf2maf_case(tmp_path, b, mapq)
+    want = _expected_maf(b, mapq, t_fa, q_fa, 40)
+    rng = np.random.default_rng(2)
+
+    def messy(path, name, seq, crlf):
+        eol = b"\r\n" if crlf else b"\n"
+        out = bytearray(b"; a comment line in front of the first header" + eol)
+        out += b">decoy1 first" + eol + b"ACGTNNNN" + eol + eol
+        out += b">" + name + b" the real one" + eol
+        p = 0
+        while p < len(seq):
+            w = int(rng.integers(1, 200))
+            out += seq[p:p + w] + eol
+            p += w
+            if rng.random() < 0.05:
+                out += eol
+        out += b">" + name + b" a duplicate: ignored" + eol + b"TTTTTTTT" + eol + b">decoy2" + eol + b"GG"
+        open(path, "wb").write(bytes(out))
+        return bytes(out)
+
+    t2, q2 = str(tmp_path / "t2.fa"), str(tmp_path / "q2.fa")
+    t_txt = messy(t2, b"tchr", b["t_pool"].tobytes(), False)
+    q_txt = messy(q2, b"qchr", b["q_pool"].tobytes(), True)
+    tgz, qbgz = str(tmp_path / "t2.fa.gz"), str(tmp_path / "q2.bgz.fa.gz")
+    with gzip.open(tgz, "wb") as f:
+        f.write(t_txt)
+    _bgzf_write(qbgz, q_txt, block=3000)          # ~80 blocks: the threaded inflate path
+    for tf_, qf_ in ((t_fa, q_fa), (t2, q2), (tgz, qbgz)):
+        outs = []
+        for reader in ("device", "host"):
+            os.environ["WGA_FASTA_READER"] = reader
+            try:
+                rc, out, err = run(cli, "paf2maf", paf, "-g", tf_, "-q", qf_)
+            finally:
+                del os.environ["WGA_FASTA_READER"]
+            assert rc == 0, err
+            outs.append(out.split(b"\n", 1)[1])    # the header line names the FASTA paths
+        assert outs[0] == outs[1] == want.split(b"\n", 1)[1], (tf_, qf_)
+    # a damaged BGZF block is an IO error, not silently truncated input
+    raw = bytearray(open(qbgz, "rb").read())
+    raw[len(raw) // 2] ^= 0x5A
+    bad = str(tmp_path / "bad.fa.gz")
+    open(bad, "wb").write(bytes(raw))
+    rc, out, err = run(cli, "paf2maf", paf, "-g", t_fa, "-q", bad)
+    assert rc == 1 and "ERROR" in err, err
+
+
 def test_paf2maf_error_is_streamed(cli, tmp_path):
     """streaming driver: records before the failing one are written, then `ERROR <msg>`, exit 1"""
     b = synth.make_paf_batch(78, 12, 80, 30000)

@@ -1164,3 +1164,68 @@ def check_maf_split(eng, text):
         assert (int(g["name_off"]), int(g["name_len"])) == w["name"], j
         assert (int(g["seq_off"]), int(g["seq_len"])) == w["seq"], j
     assert (got[n:n + 1].view(np.uint8) == 0xEE).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# K15 FASTA text -> sequence pool (against the host faidx reader's semantics, restated here)
+# ------------------------------------------------------------------------------------------------
+def host_fasta_pool(text):
+    """what the host reader builds (wga_host.cpp Faidx::load, htslib faidx semantics for well-formed files): the bytes
+    of the lines behind the first header minus line ends (one '\\r' in front of a '\\n' / at the end of the file goes
+    too), contigs in file order; name = up to the first white space"""
+    pool, contigs, cur = bytearray(), [], None
+    for line in text.split(b"\n"):
+        if line.endswith(b"\r"):
+            line = line[:-1]
+        if line.startswith(b">"):
+            if cur is not None:
+                contigs.append((cur[0], cur[1], len(pool) - cur[1]))
+            nm = line[1:].split(None, 1)[0] if line[1:].split(None, 1) else b""
+            if line[1:2].isspace():
+                nm = b""
+            cur = (nm, len(pool))
+        elif cur is not None:
+            pool += line
+    if cur is not None:
+        contigs.append((cur[0], cur[1], len(pool) - cur[1]))
+    return bytes(pool), contigs
+
+
+FASTA_CASES = [
+    b"", b"ACGT\n", b">a\n", b">a", b">a\nACGT", b">a\nACGT\n", b"junk before\nmore\n>c1 desc here\nACGT\nAC\n>c2\n\nGG\n",
+    b">x\r\nAC\r\nGT\r\n>y\r\nTT\r", b">e1\n>e2\n>e3\nA\n>e4\n", b">t\tname\nNNNNacgtRYKM\n\n\nAC\n",
+    b">s\nAC>GT\n>\nTT\n> spaced\nGG\n", b">dup\nAAAA\n>dup\nCCCC\n",
+]
+
+
+def check_fasta_pool(eng, text):
+    blob = np.frombuffer(text + b"\0", dtype=np.uint8)
+    d_text = eng.upload(blob)
+    pool, contigs = eng.fasta_pool(d_text, len(text))
+    want_pool, want = host_fasta_pool(text)
+    got_pool = pool.numpy().tobytes()[: len(want_pool)] if len(want_pool) else b""
+    assert pool.shape[0] == len(want_pool), (pool.shape, len(want_pool), text[:60])
+    assert got_pool == want_pool, text[:60]
+    assert len(contigs) == len(want), (len(contigs), len(want), text[:60])
+    for c, (nm, off, ln) in zip(contigs, want):
+        hs = int(c["hdr_start"])
+        assert text[hs:hs + 1] == b">"
+        line = text[hs + 1:int(c["hdr_end"])]
+        got_nm = b"" if (not line or line[:1].isspace()) else line.split(None, 1)[0]
+        assert got_nm == nm and int(c["pool_off"]) == off and int(c["len"]) == ln, (c, nm, off, ln, text[:60])
+
+
+def random_fasta(rng, n_contigs, max_len, width=None, crlf=False):
+    eol = b"\r\n" if crlf else b"\n"
+    out = bytearray()
+    for k in range(n_contigs):
+        out += b">ctg%d some description" % k + eol
+        seq = rand_seq(rng, int(rng.integers(0, max_len)), b"ACGTacgtNn")
+        w = width or int(rng.integers(1, 120))
+        for a in range(0, len(seq), w):
+            out += seq[a:a + w] + eol
+        if rng.random() < 0.2:
+            out += eol                       # a blank line
+    if out and rng.random() < 0.5:
+        out = out[:-len(eol)]                # no line end at the end of the file
+    return bytes(out)

@@ -437,3 +437,12 @@ def test_maf_split(emu):
 
 
 
+
+
+def test_fasta_pool(emu):
+    for t in pc.FASTA_CASES:
+        pc.check_fasta_pool(emu, t)
+    rng = np.random.default_rng(3)
+    for k in range(6):
+        pc.check_fasta_pool(emu, pc.random_fasta(rng, int(rng.integers(1, 9)), 9000, crlf=bool(k & 1)))
+    pc.check_fasta_pool(emu, pc.random_fasta(rng, 3, 30000, width=60))      # the usual 60-column layout, several blocks

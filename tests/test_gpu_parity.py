@@ -584,3 +584,13 @@ def test_pafpseudo_config5_long_cigar_cross_check(gpu):
         want = qrow[trow != 45]
         got = out[int(dst_off[i]):int(dst_off[i]) + int(seg[i])]
         assert want.numel() == got.numel() and bool((want == got).all()), i
+
+
+def test_fasta_pool(gpu):
+    """device-built sequence pools == the host faidx reader's, on multi-contig, ragged-line, CRLF and odd inputs"""
+    for t in pc.FASTA_CASES:
+        pc.check_fasta_pool(gpu, t)
+    rng = np.random.default_rng(3)
+    for k in range(8):
+        pc.check_fasta_pool(gpu, pc.random_fasta(rng, int(rng.integers(1, 40)), 200_000, crlf=bool(k & 1)))
+    pc.check_fasta_pool(gpu, pc.random_fasta(rng, 5, 20_000_000, width=60))

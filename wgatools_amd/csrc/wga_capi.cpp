@@ -624,6 +624,79 @@ int wga_maf_split(wga_ctx* c, const uint8_t* d_text, uint64_t n_bytes, uint64_t*
   return split_lines<1>(c, d_text, n_bytes, n_lines, (void*)d_lines, cap_lines);
 }
 
+int wga_fasta_pool(wga_ctx* c, const uint8_t* d_text, uint64_t n_bytes, uint64_t* n_contigs, uint64_t* pool_bytes,
+                   uint8_t* d_pool, wga_fa_contig* d_contigs) {
+  static_assert(sizeof(wga_fa_contig) == sizeof(wga_fa_contig_dev), "wga_fa_contig layout");
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (!n_contigs || !pool_bytes) return fail(WGA_E_INVALID_ARG, "null count", nullptr);
+  if (n_bytes && !d_text) return fail(WGA_E_INVALID_ARG, "d_text null", nullptr);
+  if (n_bytes == 0) {
+    *n_contigs = *pool_bytes = 0;
+    return WGA_OK;
+  }
+  const u64 nb64 = (n_bytes + 4095u) / 4096u;
+  if (nb64 > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "text too large for one call", nullptr);
+  const u32 nb = (u32)nb64;
+  /* scratch: block counts | their exclusive scan (+ total) | scan partials | (count call only) the contig table */
+  void* ws;
+  const size_t head = ((size_t)nb * 2 + 2 + (size_t)nb / 1024 + 4) * sizeof(u64);
+  if ((rc = ctx_scratch(c, head, &ws))) return rc;
+  u64* blk = (u64*)ws;
+  u64* blk_off = blk + nb;
+  u64* partial = blk_off + nb + 1;
+  ScanPlain sp;
+  sp.in = blk;
+  WGA_LAUNCH(k_fa_headers<false>, nb, WGA_BLOCK, c->stream, d_text, (u64)n_bytes, blk, (const u64*)nullptr,
+             (wga_fa_contig_dev*)nullptr);
+  LAUNCH_CHECK();
+  if ((rc = run_scan_ws(c, sp, nb, blk_off, partial))) return rc;
+  u64 nh = 0;
+  RT_CHECK(rt_d2h(&nh, blk_off + nb, sizeof nh, c->stream));
+  wga_fa_contig_dev* contigs = (wga_fa_contig_dev*)d_contigs;
+  if (!d_pool) { /* the count call keeps its own contig table in the scratch arena */
+    const size_t need = head + 64 + (size_t)nh * sizeof(wga_fa_contig_dev);
+    if (c->scratch_cap < need) { /* regrowing frees the arena: start again with room for the table */
+      if ((rc = ctx_scratch(c, need, &ws))) return rc;
+      blk = (u64*)ws;
+      blk_off = blk + nb;
+      partial = blk_off + nb + 1;
+      sp.in = blk;
+      WGA_LAUNCH(k_fa_headers<false>, nb, WGA_BLOCK, c->stream, d_text, (u64)n_bytes, blk, (const u64*)nullptr,
+                 (wga_fa_contig_dev*)nullptr);
+      LAUNCH_CHECK();
+      if ((rc = run_scan_ws(c, sp, nb, blk_off, partial))) return rc;
+    }
+    contigs = (wga_fa_contig_dev*)((char*)ws + ((head + 63) & ~(size_t)63));
+  } else if (nh && !d_contigs) {
+    return fail(WGA_E_INVALID_ARG, "d_contigs null", nullptr);
+  }
+  if (nh) {
+    WGA_LAUNCH(k_fa_headers<true>, nb, WGA_BLOCK, c->stream, d_text, (u64)n_bytes, blk, (const u64*)blk_off, contigs);
+    LAUNCH_CHECK();
+    WGA_LAUNCH(k_fa_header_ends, (u32)((nh + 255) / 256), WGA_BLOCK, c->stream, d_text, (u64)n_bytes, nh, contigs);
+    LAUNCH_CHECK();
+  }
+  WGA_LAUNCH(k_fa_bases<false>, nb, WGA_BLOCK, c->stream, d_text, (u64)n_bytes, nh, contigs, blk, (const u64*)nullptr,
+             (u8*)nullptr);
+  LAUNCH_CHECK();
+  if ((rc = run_scan_ws(c, sp, nb, blk_off, partial))) return rc;
+  u64 total = 0;
+  RT_CHECK(rt_d2h(&total, blk_off + nb, sizeof total, c->stream));
+  *n_contigs = nh;
+  *pool_bytes = total;
+  if (!d_pool) return WGA_OK;
+  WGA_LAUNCH(k_fa_bases<true>, nb, WGA_BLOCK, c->stream, d_text, (u64)n_bytes, nh, contigs, blk, (const u64*)blk_off, d_pool);
+  LAUNCH_CHECK();
+  if (nh) {
+    WGA_LAUNCH(k_fa_finish, (u32)((nh + 255) / 256), WGA_BLOCK, c->stream, (u64)n_bytes, nh, total, contigs);
+    LAUNCH_CHECK();
+    WGA_LAUNCH(k_fa_lengths, (u32)((nh + 255) / 256), WGA_BLOCK, c->stream, nh, total, contigs);
+    LAUNCH_CHECK();
+  }
+  return WGA_OK;
+}
+
 int wga_pafcov_format(wga_ctx* c, const uint8_t* d_name, uint32_t name_len, const int32_t* d_cov,
                       uint64_t p0, uint32_t count, uint64_t* d_line_off, uint8_t* d_out) {
   int rc = ctx_bind(c);

@@ -16,6 +16,7 @@ DIAG_DTYPE = np.dtype([("bad_op_idx", "<u8"), ("panic_op_idx", "<u8"), ("bad_bas
 CHAIN_TRIM_DTYPE = np.dtype([(k, "<u8") for k in ("head_ins", "head_del", "tail_ins", "tail_del")])
 TOK_ERR_DTYPE = np.dtype([("err", np.int32), ("tok_len", np.uint32), ("tok_off", np.uint64)])
 CLASS_SUMS_DTYPE = np.dtype([(k, "<u8") for k in ("mx", "i", "d", "s", "o")])
+FA_CONTIG_DTYPE = np.dtype([(k, "<u8") for k in ("hdr_start", "hdr_end", "pool_off", "len")])
 NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
 MAF_LINE_DTYPE = np.dtype([("num", np.uint64, 3), ("name_off", np.uint64), ("seq_off", np.uint64),
                            ("seq_len", np.uint64), ("name_len", np.uint32), ("strand_neg", np.uint8),
@@ -319,6 +320,16 @@ class Engine:
         totals = totals if totals is not None else self.empty(11, np.uint64)
         self._check(self.lib.wga_counts_total(self.ctx, int(n), _p(counts), _p(totals)))
         return totals
+
+    def fasta_pool(self, text, n_bytes):
+        """FASTA text in HBM -> (pool DeviceArray, contig table as numpy FA_CONTIG_DTYPE); two calls of wga_fasta_pool"""
+        nc, nb = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.wga_fasta_pool(self.ctx, _p(text), int(n_bytes), C.byref(nc), C.byref(nb), None, None))
+        pool = self.empty(max(1, nb.value), np.uint8)
+        contigs = self.empty(max(1, nc.value), FA_CONTIG_DTYPE)
+        self._check(self.lib.wga_fasta_pool(self.ctx, _p(text), int(n_bytes), C.byref(nc), C.byref(nb), _p(pool), _p(contigs)))
+        pool.shape = (nb.value,)
+        return pool, contigs.numpy()[: nc.value]
 
     def paf_call_events(self, batch, svlen, snp, ev_cnt=None, ev=None, ev_off=None):
         ev_cnt = ev_cnt if ev_cnt is not None else self.empty(batch.n, np.uint64)

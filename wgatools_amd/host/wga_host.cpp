@@ -11,7 +11,9 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <charconv>
+#include <thread>
 #include <cmath>
 
 namespace wga {
@@ -44,6 +46,105 @@ std::string read_all(const std::string* path) {
     fail("IO error:" + why);
   }
   gzclose(f);
+  return out;
+}
+
+/* ---- BGZF: gzip members of <= 64 KB whose extra field carries the block size ("BC", SAM spec 4.1) ---------------- */
+namespace {
+struct BgzfBlock {
+  size_t cdata, clen; /* the raw deflate stream inside the file image */
+  size_t out, isize;
+};
+inline uint32_t le16(const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+inline uint32_t le32(const unsigned char* p) { return le16(p) | (le16(p + 2) << 16); }
+/* walks the members; false if the file is not BGZF from end to end */
+bool bgzf_blocks(const std::string& img, std::vector<BgzfBlock>& blocks, size_t* total) {
+  const unsigned char* b = (const unsigned char*)img.data();
+  size_t p = 0, n = img.size(), out = 0;
+  while (p < n) {
+    if (n - p < 18 || b[p] != 31 || b[p + 1] != 139 || b[p + 2] != 8 || !(b[p + 3] & 4)) return false;
+    const size_t xlen = le16(b + p + 10);
+    if (n - p < 12 + xlen) return false;
+    size_t bsize = 0;
+    for (size_t x = p + 12; x + 4 <= p + 12 + xlen;) {
+      const size_t slen = le16(b + x + 2);
+      if (b[x] == 'B' && b[x + 1] == 'C' && slen == 2 && x + 6 <= p + 12 + xlen) bsize = le16(b + x + 4) + 1u;
+      x += 4 + slen;
+    }
+    if (bsize < 12 + xlen + 8 || bsize > n - p) return false;
+    BgzfBlock k;
+    k.cdata = p + 12 + xlen;
+    k.clen = bsize - (12 + xlen) - 8;
+    k.isize = le32(b + p + bsize - 4);
+    k.out = out;
+    out += k.isize;
+    blocks.push_back(k);
+    p += bsize;
+  }
+  *total = out;
+  return !blocks.empty();
+}
+}  // namespace
+
+std::string read_all_parallel(const std::string& path) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) fail("File path `" + path + "` not exist"); /* errors.rs:13 */
+  unsigned char magic[4] = {0, 0, 0, 0};
+  const size_t got = fread(magic, 1, 4, f);
+  const bool maybe_bgzf = got == 4 && magic[0] == 31 && magic[1] == 139 && magic[2] == 8 && (magic[3] & 4);
+  if (!maybe_bgzf) {
+    fclose(f);
+    return read_all(&path); /* plain text or ordinary gzip */
+  }
+  std::string img;
+  {
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    img.resize(sz > 0 ? (size_t)sz : 0);
+    if (!img.empty() && fread(&img[0], 1, img.size(), f) != img.size()) {
+      fclose(f);
+      fail("IO error:short read of `" + path + "`");
+    }
+    fclose(f);
+  }
+  std::vector<BgzfBlock> blocks;
+  size_t total = 0;
+  if (!bgzf_blocks(img, blocks, &total)) return read_all(&path);
+  std::string out(total, '\0');
+  std::atomic<size_t> next{0};
+  std::atomic<int> bad{0};
+  auto work = [&]() {
+    z_stream zs;
+    for (;;) {
+      const size_t a = next.fetch_add(16);
+      if (a >= blocks.size()) break;
+      for (size_t i = a; i < std::min(blocks.size(), a + 16); i++) {
+        const BgzfBlock& k = blocks[i];
+        if (k.isize == 0) continue; /* the EOF marker block */
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) {
+          bad = 1;
+          continue;
+        }
+        zs.next_in = (Bytef*)(img.data() + k.cdata);
+        zs.avail_in = (uInt)k.clen;
+        zs.next_out = (Bytef*)&out[k.out];
+        zs.avail_out = (uInt)k.isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        if (rc != Z_STREAM_END || zs.avail_out != 0) bad = 1;
+        inflateEnd(&zs);
+      }
+    }
+  };
+  unsigned nthr = std::thread::hardware_concurrency();
+  nthr = nthr < 1 ? 1 : (nthr > 32 ? 32 : nthr);
+  if (blocks.size() < 64) nthr = 1;
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nthr; t++) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
+  if (bad) fail("IO error:corrupt BGZF block in `" + path + "`");
   return out;
 }
 
@@ -746,7 +847,7 @@ std::vector<ChainRecord> parse_chain(const std::string& text, std::string* err) 
 /* FASTA                                                                                       */
 /* ------------------------------------------------------------------------------------------ */
 void Faidx::load(const std::string& path) {
-  std::string text = read_all(&path);
+  std::string text = read_all_parallel(path);
   pool.clear();
   pool.reserve(text.size());
   contigs.clear();
@@ -775,6 +876,19 @@ void Faidx::load(const std::string& path) {
     p = e == std::string::npos ? n : e + 1;
   }
   close();
+}
+
+void Faidx::set_table(const std::string& text, const uint64_t* tab, size_t n) {
+  contigs.clear();
+  for (size_t k = 0; k < n; k++) {
+    const uint64_t hs = tab[4 * k], he = tab[4 * k + 1];
+    size_t s = (size_t)hs + 1, q = s;
+    size_t le = (size_t)he;
+    if (le > s && text[le - 1] == '\r') le--;
+    while (q < le && !is_ws((unsigned char)text[q])) q++;
+    /* a repeated name keeps its FIRST sequence, as htslib's fai_build does */
+    contigs.emplace(std::string(text, s, q - s), Contig{tab[4 * k + 3], tab[4 * k + 2]});
+  }
 }
 
 void Faidx::fetch(const std::string& name, uint64_t beg_u, uint64_t end_u, uint64_t* off,

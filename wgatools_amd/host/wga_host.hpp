@@ -37,6 +37,9 @@ struct Error {
 
 /* ---- input / output (utils.rs:135-246: plain or gzip; "-" = stdin/stdout; -r to overwrite) --- */
 std::string read_all(const std::string* path); /* nullptr = stdin */
+/* the same bytes for a file; a BGZF file (`all.fa.gz` next to its .gzi / .fai, pseudomaf.rs:222) is inflated block by
+ * block on all host cores — its blocks are independent gzip members */
+std::string read_all_parallel(const std::string& path);
 struct Output {
   std::string path;
   void* gz = nullptr;
@@ -131,8 +134,11 @@ struct Faidx {
     uint64_t len, pool_off;
   };
   std::unordered_map<std::string, Contig> contigs;
-  std::string pool; /* all contigs, newlines stripped, case preserved */
+  std::string pool; /* all contigs, newlines stripped, case preserved (host reader only) */
   void load(const std::string& path);
+  /* device reader: the pool is built in HBM by wga_fasta_pool from the uploaded text; the table comes back as
+   * (header start, header end, pool offset, length) per contig and only the names are read on the host */
+  void set_table(const std::string& text, const uint64_t* tab /* n x 4 */, size_t n);
   /* faidx_fetch_seq64(name, beg, end inclusive) clipping: returns (pool offset, length) */
   void fetch(const std::string& name, uint64_t beg, uint64_t end_incl, uint64_t* off, uint64_t* len) const;
 };

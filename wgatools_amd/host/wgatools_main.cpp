@@ -77,6 +77,66 @@ struct Dev {
   }
 };
 
+/* An indexed FASTA whose sequence pool lives in HBM.  The file — plain, gzip or BGZF (inflated on
+ * all host cores) — is uploaded as text, wga_fasta_pool strips the line ends on the device and returns the contig table;
+ * the drivers then address (contig, start, length) as pool offsets with htslib's clipping (Faidx::fetch) and never copy
+ * a slice.  Commands that need bases on the host (VCF REF / ALT text, a target row of pafpseudo, the offending base of
+ * an error message) read them back from the device.  WGA_FASTA_READER=host keeps the host line stripper (A/B, tests). */
+struct DevFasta {
+  Faidx idx;
+  uint8_t* d_pool = nullptr;
+  uint64_t bytes = 0;
+  bool have_host = false;
+  void load(Dev& d, const std::string& path) {
+    const char* mode = getenv("WGA_FASTA_READER");
+    if (mode && strcmp(mode, "host") == 0) {
+      idx.load(path);
+      bytes = idx.pool.size();
+      d_pool = d.upload((const uint8_t*)idx.pool.data(), idx.pool.size());
+      have_host = true;
+      return;
+    }
+    std::string text = read_all_parallel(path);
+    uint8_t* d_text = d.upload((const uint8_t*)text.data(), text.size());
+    uint64_t nc = 0, nb = 0;
+    d.check(wga_fasta_pool(d.ctx, d_text, text.size(), &nc, &nb, nullptr, nullptr));
+    d_pool = (uint8_t*)d.alloc(nb + 64);
+    auto* d_tab = (wga_fa_contig*)d.alloc((nc + 1) * sizeof(wga_fa_contig));
+    d.check(wga_fasta_pool(d.ctx, d_text, text.size(), &nc, &nb, d_pool, d_tab));
+    std::vector<wga_fa_contig> tab(nc);
+    if (nc) d.download(tab.data(), (const wga_fa_contig*)d_tab, nc);
+    static_assert(sizeof(wga_fa_contig) == 4 * sizeof(uint64_t), "wga_fa_contig layout");
+    idx.set_table(text, (const uint64_t*)tab.data(), nc);
+    bytes = nb;
+    d.release(d_tab);
+    d.release(d_text);
+  }
+  void fetch(const std::string& name, uint64_t beg, uint64_t end_incl, uint64_t* off, uint64_t* len) const {
+    idx.fetch(name, beg, end_incl, off, len);
+  }
+  /* the whole pool on the host (downloaded once) */
+  const std::string& host_pool(Dev& d) {
+    if (!have_host) {
+      idx.pool.resize(bytes);
+      if (bytes) d.download((uint8_t*)&idx.pool[0], (const uint8_t*)d_pool, bytes);
+      have_host = true;
+    }
+    return idx.pool;
+  }
+  char at(Dev& d, uint64_t off) {
+    if (have_host) return idx.pool[off];
+    uint8_t c = 0;
+    d.download(&c, (const uint8_t*)d_pool + off, 1);
+    return (char)c;
+  }
+  std::string slice(Dev& d, uint64_t off, uint64_t len) {
+    if (have_host) return idx.pool.substr(off, len);
+    std::string s2(len, '\0');
+    if (len) d.download((uint8_t*)&s2[0], (const uint8_t*)d_pool + off, len);
+    return s2;
+  }
+};
+
 /* the CIGAR text (after the tag) of record k of a batch, for error messages: owned strings, or spans
  * of the input file when the records came from the device splitter */
 struct CigarTexts {
@@ -381,13 +441,13 @@ uint32_t expand_batch(Dev& d, const wga_cigar_batch& cb, const ExpandJob& j, con
 int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::string& q_fa, Output& out) {
   Dev d;
   PafChunks chunks(input, false); /* the input is opened first, then the two indexed FASTA files (utils.rs, converter.rs:183-186) */
-  Faidx tf, qf;
-  tf.load(t_fa);
-  qf.load(q_fa);
-  out.write("#maf version=1.6 convert_from=paf t_seq_path=" + t_fa + " q_seq_path=" + q_fa + "\n");
+  DevFasta tf, qf;
   d.init();
-  uint8_t* d_tpool = d.upload((const uint8_t*)tf.pool.data(), tf.pool.size());
-  uint8_t* d_qpool = d.upload((const uint8_t*)qf.pool.data(), qf.pool.size());
+  tf.load(d, t_fa);
+  qf.load(d, q_fa);
+  out.write("#maf version=1.6 convert_from=paf t_seq_path=" + t_fa + " q_seq_path=" + q_fa + "\n");
+  uint8_t* d_tpool = tf.d_pool;
+  uint8_t* d_qpool = qf.d_pool;
   const size_t keep_pools = d.owned.size(); /* the pools stay for the whole run */
   const uint64_t kMaxBytes = 6ull << 30;
   std::string pending_error;
@@ -438,14 +498,16 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
         const size_t k = cb.n;
         std::string perr = terr;
         const PafRecord& r = recs[i0 + k];
-        if (r.neg)
+        if (r.neg) {
+          const std::string qs = qf.slice(d, job.q_off[k], job.q_len[k]);
           for (uint64_t x = job.q_len[k]; x-- > 0;) {
-            char c = qf.pool[job.q_off[k] + x];
+            char c = qs[x];
             if (!strchr("ACGTNacgtn", c) || c == 0) {
               perr = std::string("Invalid Base: `") + c + "`";
               break;
             }
           }
+        }
         pending_error = perr;
         i = i0 + k;
       }
@@ -454,11 +516,11 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
     if (n) {
       job.resize(n);
       wga_rec_diag g;
-      const uint32_t good = expand_batch(d, cb, job, d_tpool, tf.pool.size(), d_qpool, qf.pool.size(), out, &g);
+      const uint32_t good = expand_batch(d, cb, job, d_tpool, tf.bytes, d_qpool, qf.bytes, out, &g);
       if (good < n) {
         const uint32_t k = good;
         if (g.bad_base_pos != WGA_NONE) { /* utils.rs:97 */
-          char c = qf.pool[job.q_off[k] + job.q_len[k] - 1 - g.bad_base_pos];
+          char c = qf.at(d, job.q_off[k] + job.q_len[k] - 1 - g.bad_base_pos);
           pending_error = std::string("Invalid Base: `") + c + "`";
         } else if (g.bad_op_idx < g.panic_op_idx) { /* errors.rs:59 */
           pending_error = "CIGAR OP `" + cigar_op_token_at(cigars[k], g.bad_op_idx) + "` invalid";
@@ -1067,14 +1129,14 @@ ChainBatch chain_device_batch(Dev& d, const ChainRecord* recs, uint32_t n) {
 int cmd_chain2maf(const std::string* input, const std::string& t_fa, const std::string& q_fa, Output& out) {
   std::string pending_error;
   std::vector<ChainRecord> recs = parse_chain(read_all(input), &pending_error);
-  Faidx tf, qf;
-  tf.load(t_fa);
-  qf.load(q_fa);
-  out.write("#maf version=1.6 convert_from=chain t_seq_path=" + t_fa + " q_seq_path=" + q_fa + "\n");
+  DevFasta tf, qf;
   Dev d;
   d.init();
-  uint8_t* d_tpool = d.upload((const uint8_t*)tf.pool.data(), tf.pool.size());
-  uint8_t* d_qpool = d.upload((const uint8_t*)qf.pool.data(), qf.pool.size());
+  tf.load(d, t_fa);
+  qf.load(d, q_fa);
+  out.write("#maf version=1.6 convert_from=chain t_seq_path=" + t_fa + " q_seq_path=" + q_fa + "\n");
+  uint8_t* d_tpool = tf.d_pool;
+  uint8_t* d_qpool = qf.d_pool;
   const uint64_t kMaxBytes = 6ull << 30, kMaxLines = 32ull << 20;
   size_t i0 = 0;
   while (i0 < recs.size()) {
@@ -1103,12 +1165,12 @@ int cmd_chain2maf(const std::string* input, const std::string& t_fa, const std::
     if (n) {
       ChainBatch b = chain_device_batch(d, &recs[i0], n);
       wga_rec_diag g;
-      const uint32_t good = expand_batch(d, b.cb, job, d_tpool, tf.pool.size(), d_qpool, qf.pool.size(), out, &g);
+      const uint32_t good = expand_batch(d, b.cb, job, d_tpool, tf.bytes, d_qpool, qf.bytes, out, &g);
       d.check(wga_sync(d.ctx));
       while (d.owned.size() > 2) d.release(d.owned.back());
       if (good < n) {
         if (g.bad_base_pos != WGA_NONE) { /* utils.rs:97, reverse_complement of the query slice (:320-325) */
-          char c = qf.pool[job.q_off[good] + job.q_len[good] - 1 - g.bad_base_pos];
+          char c = qf.at(d, job.q_off[good] + job.q_len[good] - 1 - g.bad_base_pos);
           pending_error = std::string("Invalid Base: `") + c + "`";
         } else {
           pending_error = "panic: String::insert_str beyond the end of the fetched sequence (converter.rs:375,383)";
@@ -1691,9 +1753,12 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
   Dev d;
   PafInput pin = load_paf(d, input, false);
   const std::vector<PafRecord>& recs = pin.recs;
-  Faidx fa;
+  DevFasta fa;
   const bool base = fasta != nullptr;
-  if (base) fa.load(*fasta);
+  if (base) {
+    d.init();
+    fa.load(d, *fasta);
+  }
   /* every record's CIGAR is tokenised on the device, in file order; a record's tag / tokeniser error only counts
    * when the walk below reaches that record (the reference parses a CIGAR when it processes the record) */
   const uint32_t n_all = (uint32_t)recs.size();
@@ -1811,8 +1876,8 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
     for (uint32_t k = 0; k < n; k++) dst_off[k + 1] = dst_off[k] + seg_len[k];
     auto* d_out = (uint8_t*)d.alloc(dst_off[n] + 64);
     auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
-    uint8_t* d_pool = base ? d.upload((const uint8_t*)fa.pool.data(), fa.pool.size()) : nullptr;
-    d.check(wga_pafpseudo_fill(d.ctx, &cb, base ? 1 : 0, d_pool, fa.pool.size(), base ? d.upload(q_off) : nullptr,
+    uint8_t* d_pool = base ? fa.d_pool : nullptr;
+    d.check(wga_pafpseudo_fill(d.ctx, &cb, base ? 1 : 0, d_pool, fa.bytes, base ? d.upload(q_off) : nullptr,
                                base ? d.upload(q_len) : nullptr, d.upload(skip), d_out, d.upload(dst_off), d_diag));
     std::vector<wga_rec_diag> diag(n);
     d.download(diag.data(), d_diag, n);
@@ -1821,7 +1886,7 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
         for (const auto& sg : q.segs) {
           const size_t k = sg.rec;
           if (diag[k].bad_base_pos != WGA_NONE)
-            fail(std::string("Invalid Base: `") + fa.pool[q_off[k] + q_len[k] - 1 - diag[k].bad_base_pos] + "`");
+            fail(std::string("Invalid Base: `") + fa.at(d, q_off[k] + q_len[k] - 1 - diag[k].bad_base_pos) + "`");
           if (diag[k].panic_op_idx != WGA_NONE)
             fail("panic: String::drain / insert_str beyond the end of the query sequence (cigar.rs:772,779)");
         }
@@ -1842,7 +1907,7 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
       if (base) {
         uint64_t o, l;
         fa.fetch(t.name, 0, t.target_size_first - 1, &o, &l);
-        text.append(fa.pool, o, l);
+        text += fa.slice(d, o, l);
       } else {
         text.append(t.target_size_first, 'N');
       }
@@ -2109,11 +2174,13 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
   Dev d;
   PafInput pin = load_paf(d, input, false);
   const std::vector<PafRecord>& recs = pin.recs;
-  Faidx tf, qf;
-  tf.load(t_fa);
-  qf.load(q_fa);
-  std::string body;
+  DevFasta tf, qf;
   d.init();
+  tf.load(d, t_fa);
+  qf.load(d, q_fa);
+  const std::string& t_host = tf.host_pool(d); /* REF / ALT text is cut from the bases on the host */
+  const std::string& q_host = qf.host_pool(d);
+  std::string body;
   const size_t keep = d.owned.size(); /* the input text */
   const uint64_t kMaxText = 160ull << 20; /* ~64 M ops per batch */
   size_t i0 = 0;
@@ -2177,8 +2244,8 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
       if (eoff[n]) d.download(ev.data(), d_ev, 3 * eoff[n]);
       for (uint32_t k = 0; k < n; k++) {
         const PafRecord& r = recs[i0 + k];
-        const char* ts = tf.pool.data() + t_off[k];
-        const char* qs = qf.pool.data() + q_off[k];
+        const char* ts = t_host.data() + t_off[k];
+        const char* qs = q_host.data() + q_off[k];
         const uint64_t tn = t_len[k], qn = q_len[k];
         const char suffix = r.neg ? 'N' : 'P';
         auto qi = [&](uint64_t a, uint64_t b2, bool three) {
