@@ -498,6 +498,25 @@ def test_call_synthetic_blocks(cli, tmp_path, snp, inv, svlen, chunk):
     assert out.decode() == _expected_vcf(blocks, "smp", snp, inv, svlen, chunk)
 
 
+def test_call_and_maf2paf_on_a_long_block(cli, tmp_path):
+    """a block far beyond 32 768 columns is walked piece by piece on the device (k_maf_piece_walk): `call` with its
+    SV-safe chunk cuts (caller.rs:119-265) and `maf2paf`'s cg:Z: text come out as the oracle's"""
+    blocks = _synth_maf_blocks(23, 1, 90000) + _synth_maf_blocks(24, 2, 700)
+    maf = tmp_path / "long.maf"
+    _write_maf(maf, blocks)
+    for svlen, chunk in ((3, 20000), (0, 1000000), (8, 33333)):
+        rc, out, err = run(cli, "call", str(maf), "-s", "-i", "-l", str(svlen), "-c", str(chunk), "-n", "smp")
+        assert rc == 0, err
+        assert out.decode() == _expected_vcf(blocks, "smp", True, True, svlen, chunk), (svlen, chunk)
+    rc, out, err = run(cli, "maf2paf", str(maf))
+    assert rc == 0, err
+    lines = out.decode().splitlines()
+    assert len(lines) == 3
+    for b, ln in zip(blocks, lines):
+        _, txt = orc.parse_maf_seq_to_cigar(b["t"], b["q"], b["neg"])
+        assert ln.split("\t")[-1] == "cg:Z:" + txt
+
+
 def test_call_query_selection(cli, tmp_path):
     """caller.rs:62-108: --query-name / --query-regex pick the query s-line; blocks without it are skipped"""
     blocks = _synth_maf_blocks(5, 4, 400)

@@ -446,3 +446,26 @@ def test_fasta_pool(emu):
     for k in range(6):
         pc.check_fasta_pool(emu, pc.random_fasta(rng, int(rng.integers(1, 9)), 9000, crlf=bool(k & 1)))
     pc.check_fasta_pool(emu, pc.random_fasta(rng, 3, 30000, width=60))      # the usual 60-column layout, several blocks
+
+
+def test_maf_long_blocks_piecewise(emu):
+    """blocks beyond `maf_long_cols` are walked in pieces of `maf_piece_cols` (one wave each, class of the column in front
+    carried in, run slots and non-gap prefixes from a scan over the pieces): same counters and run lists, against the oracle"""
+    rng = np.random.default_rng(77)
+    pairs, strands = [], []
+    for L in (5, 63, 64, 65, 130, 999, 1024, 2100, 5000):
+        t = pc.rand_seq(rng, L, b"ACGTacgt--N")
+        q = pc.rand_seq(rng, L + int(rng.integers(0, 3)), b"ACGTacgt--N")
+        pairs.append((t, q))
+        strands.append(L & 1)
+    pairs.append((b"-" * 700 + b"ACGT" * 100, b"-" * 650 + b"A" * 50 + b"ACGA" * 100))   # long runs across piece borders
+    strands.append(1)
+    try:
+        for long_cols, piece_cols in ((100, 64), (1, 1000), (500, 17), (64, 1024)):
+            emu.set_param("maf_long_cols", long_cols)
+            emu.set_param("maf_piece_cols", piece_cols)
+            pc.check_maf_pair(emu, pairs, strands)
+            pc.check_maf_call_runs(emu, pairs)
+    finally:
+        emu.set_param("maf_long_cols", 32768)
+        emu.set_param("maf_piece_cols", 16384)

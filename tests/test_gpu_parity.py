@@ -450,15 +450,107 @@ def test_maf_pair_long_rows_fold_lane_counters(gpu):
         buf += b + b"@@"
     rows = gpu.upload(np.frombuffer(bytes(buf), dtype=np.uint8))
     n = len(pairs)
-    counts, run_cnt = gpu.maf_pair_stat(n, rows, gpu.upload(np.array(t_off, dtype=np.uint64)),
-                                        gpu.upload(np.array(q_off, dtype=np.uint64)),
-                                        gpu.upload(np.array([len(a) for a, _ in pairs], dtype=np.uint64)),
-                                        gpu.upload(np.array(strands, dtype=np.uint8)))
-    c, rc = counts.numpy(), run_cnt.numpy()
-    for i, (a, b) in enumerate(pairs):
-        exp_counts, exp_txt = orc.parse_maf_seq_to_cigar(a, b, strands[i])
-        assert tuple(int(x) for x in c[i]) == exp_counts, (i, exp_counts, c[i])
-        assert int(rc[i]) == sum(1 for ch in exp_txt if not ch.isdigit())
+    exp = [orc.parse_maf_seq_to_cigar(a, b, strands[i]) for i, (a, b) in enumerate(pairs)]
+    # once as ONE wave per row (the fold of the lane counters), once piece by piece (the default beyond 32 768 columns)
+    for long_cols in (1 << 62, 32768):
+        gpu.set_param("maf_long_cols", long_cols)
+        try:
+            counts, run_cnt = gpu.maf_pair_stat(n, rows, gpu.upload(np.array(t_off, dtype=np.uint64)),
+                                                gpu.upload(np.array(q_off, dtype=np.uint64)),
+                                                gpu.upload(np.array([len(a) for a, _ in pairs], dtype=np.uint64)),
+                                                gpu.upload(np.array(strands, dtype=np.uint8)))
+        finally:
+            gpu.set_param("maf_long_cols", 32768)
+        c, rc = counts.numpy(), run_cnt.numpy()
+        for i in range(n):
+            exp_counts, exp_txt = exp[i]
+            assert tuple(int(x) for x in c[i]) == exp_counts, (long_cols, i, exp_counts, c[i])
+            assert int(rc[i]) == sum(1 for ch in exp_txt if not ch.isdigit())
+
+
+def test_maf_long_blocks_piecewise(gpu):
+    rng = np.random.default_rng(77)
+    pairs, strands = [], []
+    for L in (5, 63, 64, 65, 130, 999, 1024, 2100, 5000, 70000):
+        t = pc.rand_seq(rng, L, b"ACGTacgt--N")
+        q = pc.rand_seq(rng, L + int(rng.integers(0, 3)), b"ACGTacgt--N")
+        pairs.append((t, q))
+        strands.append(L & 1)
+    pairs.append((b"-" * 700 + b"ACGT" * 100, b"-" * 650 + b"A" * 50 + b"ACGA" * 100))
+    strands.append(1)
+    try:
+        for long_cols, piece_cols in ((100, 64), (1, 1000), (500, 17), (64, 1024), (32768, 16384)):
+            gpu.set_param("maf_long_cols", long_cols)
+            gpu.set_param("maf_piece_cols", piece_cols)
+            pc.check_maf_pair(gpu, pairs, strands)
+            pc.check_maf_call_runs(gpu, pairs)
+    finally:
+        gpu.set_param("maf_long_cols", 32768)
+        gpu.set_param("maf_piece_cols", 16384)
+
+
+def test_maf_block_of_1e8_columns(gpu):
+    """ONE two-row block of 10^8 columns tiles across the chip (6 104 pieces): counters and
+    run count against the oracle, the full run lists of both walks against an independent computation on the device,
+    and the rate of the two count passes (printed; profiles/r02_other_kernels.txt)"""
+    import torch
+    dev = torch.device("cuda", 0)
+    L = 100_000_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    alpha = torch.tensor(list(b"ACGTACGTACGTACGTACGTACGTACGTACG-"), dtype=torch.uint8, device=dev)   # 1/32 gaps
+    t = alpha[torch.randint(0, 32, (L,), device=dev, generator=g)]
+    q = torch.where(torch.rand(L, device=dev, generator=g) < 0.9, t, alpha[torch.randint(0, 32, (L,), device=dev, generator=g)])
+    rows = torch.cat([t, torch.full((64,), 64, dtype=torch.uint8, device=dev), q, torch.full((64,), 64, dtype=torch.uint8, device=dev)])
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_t, d_q = gpu.upload(np.array([0], dtype=np.uint64)), gpu.upload(np.array([L + 64], dtype=np.uint64))
+    d_c, d_s = gpu.upload(np.array([L], dtype=np.uint64)), gpu.upload(np.array([0], dtype=np.uint8))
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    counts, run_cnt = gpu.maf_pair_stat(1, rows, d_t, d_q, d_c, d_s)              # warm-up
+    ev[0].record()
+    counts, run_cnt = gpu.maf_pair_stat(1, rows, d_t, d_q, d_c, d_s)
+    ev[1].record()
+    crun_cnt = gpu.maf_call_runs(1, rows, d_t, d_q, d_c)
+    ev[2].record()
+    torch.cuda.synchronize()
+    ms3, ms4 = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    print("\n1e8-column block: K3 count pass %.3f ms = %.0f GB/s, K4 count pass %.3f ms = %.0f GB/s" % (
+        ms3, 2 * L / ms3 / 1e6, ms4, 2 * L / ms4 / 1e6))
+    # independent expectation on the device
+    tg, qg = t == 45, q == 45
+    cls3 = torch.where(t == q, 0, torch.where(tg, 1, torch.where(qg, 2, 3))).to(torch.uint8)
+    cls4 = torch.where(tg & qg, 4, torch.where(tg, 1, torch.where(qg, 2, torch.where(t == q, 0, 3)))).to(torch.uint8)
+    for cls, caller in ((cls3, False), (cls4, True)):
+        start = torch.ones(L, dtype=torch.bool, device=dev)
+        start[1:] = cls[1:] != cls[:-1]
+        idx = torch.nonzero(start).flatten()
+        nrun = int(idx.numel())
+        if not caller:
+            assert int(run_cnt.numpy()[0]) == nrun
+            run_off = gpu.exclusive_scan_u64(1, run_cnt)
+            runs = torch.zeros(nrun + 1, dtype=torch.int64, device=dev)
+            gpu.maf_pair_stat(1, rows, d_t, d_q, d_c, d_s, counts=counts, run_cnt=run_cnt, runs=runs, run_off=run_off)
+            gpu.sync()
+            want = (idx << 3) | cls[idx].to(torch.int64)
+            assert bool((runs[:nrun] == want).all())
+        else:
+            assert int(crun_cnt.numpy()[0]) == nrun
+            run_off = gpu.exclusive_scan_u64(1, crun_cnt)
+            runs = torch.zeros(3 * nrun + 3, dtype=torch.int64, device=dev)
+            gpu.maf_call_runs(1, rows, d_t, d_q, d_c, run_cnt=crun_cnt, runs=runs, run_off=run_off)
+            gpu.sync()
+            r3 = runs[:3 * nrun].view(nrun, 3)
+            tb = torch.cumsum((~tg).to(torch.int64), 0) - (~tg).to(torch.int64)
+            qb = torch.cumsum((~qg).to(torch.int64), 0) - (~qg).to(torch.int64)
+            assert bool((r3[:, 0] == ((idx << 3) | cls[idx].to(torch.int64))).all())
+            assert bool((r3[:, 1] == tb[idx]).all()) and bool((r3[:, 2] == qb[idx]).all())
+        del start, idx, runs
+    # the oracle on the whole block: counters and run count
+    exp_counts, exp_txt = orc.parse_maf_seq_to_cigar(t.cpu().numpy().tobytes(), q.cpu().numpy().tobytes(), 0)
+    assert tuple(int(x) for x in counts.numpy()[0]) == exp_counts
+    assert int(run_cnt.numpy()[0]) == sum(1 for ch in exp_txt if not ch.isdigit())
+    gpu.reset_stream()
 
 
 def test_maf_split(gpu):

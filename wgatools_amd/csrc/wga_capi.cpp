@@ -22,6 +22,8 @@ struct wga_ctx {
   int expand_force_slow = 0;
   int expand_no_table = 0;
   int expand_ablate = 0;
+  uint64_t maf_long_cols = 32768;  /* MAF blocks beyond this many columns are walked piece by piece ... */
+  uint64_t maf_piece_cols = 16384; /* ... of this many columns, one wave each (test knobs: "maf_long_cols", "maf_piece_cols") */
   int expand_variant = 0; /* 0: v1 (fastest measured, profiles/r02_k2_experiments.md); 1: the planned, line-complete kernel of wga_kernels_k2p.h */
   void* expand_dbg = nullptr;
   void* scratch = nullptr;
@@ -205,6 +207,75 @@ static int split_lines(wga_ctx* c, const uint8_t* d_text, uint64_t n_bytes, uint
   return WGA_OK;
 }
 
+/* the long blocks of a MAF walk call, piece by piece (see k_maf_piece_walk); returns at once when there are none */
+template <bool CALLER>
+static int maf_long_blocks(wga_ctx* c, u32 n, const u8* d_rows, const u64* d_t_off, const u64* d_q_off, const u64* d_cols,
+                           const u8* d_strand_neg, wga_cigar_counts* d_counts, u64* d_run_cnt, u64* d_runs,
+                           const u64* d_run_off) {
+  int rc;
+  void* ws;
+  const size_t head = ((size_t)n * 2 + 2 + (size_t)n / 1024 + 4) * sizeof(u64);
+  if ((rc = ctx_scratch(c, head, &ws))) return rc;
+  u64* npieces = (u64*)ws;
+  u64* piece_off = npieces + n;
+  u64* partial = piece_off + n + 1;
+  /* the fill call must not clear what the count call left in the caller's arrays */
+  WGA_LAUNCH(k_maf_piece_counts, (n + 255u) / 256u, WGA_BLOCK, c->stream, n, d_cols, (u64)c->maf_long_cols,
+             (u64)c->maf_piece_cols, npieces, d_runs ? (wga_cigar_counts*)nullptr : d_counts,
+             d_runs ? (u64*)nullptr : d_run_cnt);
+  LAUNCH_CHECK();
+  ScanPlain sp;
+  sp.in = npieces;
+  if ((rc = run_scan_ws(c, sp, n, piece_off, partial))) return rc;
+  u64 total = 0;
+  RT_CHECK(rt_d2h(&total, piece_off + n, sizeof total, c->stream));
+  if (total == 0) return WGA_OK;
+  if (total > 0xFFFFFFF0ull) return fail(WGA_E_INVALID_ARG, "too many pieces for one call", nullptr);
+  const u32 np = (u32)total;
+  /* the piece arrays go behind the record arrays; regrowing the arena frees it, so the head is rebuilt */
+  const size_t piece_bytes = (size_t)np * sizeof(wga_maf_piece_tot) + 3 * ((size_t)np + 1) * sizeof(u64) +
+                             ((size_t)np / 1024 + 4) * sizeof(u64) + 256;
+  if (c->scratch_cap < head + piece_bytes) {
+    if ((rc = ctx_scratch(c, head + piece_bytes, &ws))) return rc;
+    npieces = (u64*)ws;
+    piece_off = npieces + n;
+    partial = piece_off + n + 1;
+    WGA_LAUNCH(k_maf_piece_counts, (n + 255u) / 256u, WGA_BLOCK, c->stream, n, d_cols, (u64)c->maf_long_cols,
+               (u64)c->maf_piece_cols, npieces, (wga_cigar_counts*)nullptr, (u64*)nullptr);
+    LAUNCH_CHECK();
+    sp.in = npieces;
+    if ((rc = run_scan_ws(c, sp, n, piece_off, partial))) return rc;
+  }
+  char* base = (char*)ws + ((head + 63) & ~(size_t)63);
+  wga_maf_piece_tot* ptot = (wga_maf_piece_tot*)base;
+  u64* ex_runs = (u64*)(ptot + np);
+  u64* ex_t = ex_runs + np + 1;
+  u64* ex_q = ex_t + np + 1;
+  u64* ppartial = ex_q + np + 1;
+  const u32 grid = np < 4u * 2048u ? (np + 3u) / 4u : 2048u;
+  WGA_LAUNCH((k_maf_piece_walk<CALLER, 0>), grid, WGA_BLOCK, c->stream, n, d_rows, d_t_off, d_q_off, d_cols, d_strand_neg,
+             (const u64*)piece_off, (u64)c->maf_piece_cols, ptot, (const u64*)nullptr, (const u64*)nullptr,
+             (const u64*)nullptr, d_runs ? (wga_cigar_counts*)nullptr : d_counts, d_runs ? (u64*)nullptr : d_run_cnt,
+             (u64*)nullptr, (const u64*)nullptr);
+  LAUNCH_CHECK();
+  if (!d_runs) return WGA_OK;
+  ScanPieceTot st;
+  st.in = ptot;
+  st.field = 0;
+  if ((rc = run_scan_ws(c, st, np, ex_runs, ppartial))) return rc;
+  if (CALLER) {
+    st.field = 1;
+    if ((rc = run_scan_ws(c, st, np, ex_t, ppartial))) return rc;
+    st.field = 2;
+    if ((rc = run_scan_ws(c, st, np, ex_q, ppartial))) return rc;
+  }
+  WGA_LAUNCH((k_maf_piece_walk<CALLER, 1>), grid, WGA_BLOCK, c->stream, n, d_rows, d_t_off, d_q_off, d_cols, d_strand_neg,
+             (const u64*)piece_off, (u64)c->maf_piece_cols, ptot, (const u64*)ex_runs, (const u64*)ex_t, (const u64*)ex_q,
+             (wga_cigar_counts*)nullptr, (u64*)nullptr, d_runs, d_run_off);
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
 extern "C" {
 
 int wga_abi_version(void) { return WGA_ABI_VERSION; }
@@ -277,6 +348,11 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
   }
   if (strcmp(name, "expand_no_table") == 0) {
     c->expand_no_table = value != 0;
+    return WGA_OK;
+  }
+  if (strcmp(name, "maf_long_cols") == 0 || strcmp(name, "maf_piece_cols") == 0) {
+    if (value < 1) return fail(WGA_E_INVALID_ARG, "must be positive", name);
+    (name[4] == 'l' ? c->maf_long_cols : c->maf_piece_cols) = (uint64_t)value;
     return WGA_OK;
   }
   if (strcmp(name, "expand_variant") == 0) {
@@ -563,9 +639,10 @@ int wga_maf_pair_stat(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint6
   if (d_runs && !d_run_off) return fail(WGA_E_INVALID_ARG, "d_run_off null", nullptr);
   WGA_LAUNCH(k_maf_pair_stat, (n + 3u) / 4u, WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off,
              (const u64*)d_q_off, (const u64*)d_cols, d_strand_neg, d_counts, (u64*)d_run_cnt,
-             (u64*)d_runs, (const u64*)d_run_off);
+             (u64*)d_runs, (const u64*)d_run_off, (u64)c->maf_long_cols);
   LAUNCH_CHECK();
-  return WGA_OK;
+  return maf_long_blocks<false>(c, n, d_rows, (const u64*)d_t_off, (const u64*)d_q_off, (const u64*)d_cols, d_strand_neg,
+                                d_counts, (u64*)d_run_cnt, (u64*)d_runs, (const u64*)d_run_off);
 }
 
 int wga_maf_call_runs(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint64_t* d_t_off,
@@ -578,9 +655,11 @@ int wga_maf_call_runs(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint6
   if (d_runs && !d_run_off) return fail(WGA_E_INVALID_ARG, "d_run_off null", nullptr);
   WGA_LAUNCH(k_maf_call_runs, (n + 3u) / 4u, WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off,
              (const u64*)d_q_off, (const u64*)d_cols, (u64*)d_run_cnt, (u64*)d_runs,
-             (const u64*)d_run_off);
+             (const u64*)d_run_off, (u64)c->maf_long_cols);
   LAUNCH_CHECK();
-  return WGA_OK;
+  return maf_long_blocks<true>(c, n, d_rows, (const u64*)d_t_off, (const u64*)d_q_off, (const u64*)d_cols,
+                               (const u8*)nullptr, (wga_cigar_counts*)nullptr, (u64*)d_run_cnt, (u64*)d_runs,
+                               (const u64*)d_run_off);
 }
 
 int wga_cigar_tokenise(wga_ctx* c, uint32_t n, const uint8_t* d_text, const uint64_t* d_text_off,

@@ -727,11 +727,21 @@ __device__ __forceinline__ u32 popc32(u32 x) { return (u32)__builtin_popcount(x)
 struct MafWalkOut {
   u64 ncol[5], nrun[5]; /* columns / runs per class (wave totals, valid in every lane) */
   u64 runs;             /* runs in all */
+  u64 t_nongap, q_nongap; /* caller walk: non-gap characters of the two rows (including the start values) */
+};
+
+/* The walk of columns [0, L) of the rows t, q.  For a PIECE of a longer row pair the caller passes the rows advanced
+ * to the piece's first column, that column's index as col_bias (reported run starts are row-relative), the class of
+ * the column in front of it (carry0; 0xFF at a row start) and the non-gap characters / runs of the row in front of
+ * the piece (t_base0, q_base0 for the caller walk; rout already points at the piece's first run slot). */
+struct MafWalkStart {
+  u64 col_bias, t_base, q_base;
+  u32 carry;
 };
 
 template <bool CALLER>
 __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __restrict__ q, u64 L,
-                                         u64* rout, MafWalkOut& out) {
+                                         u64* rout, MafWalkOut& out, const MafWalkStart st0 = MafWalkStart{0, 0, 0, 0xFFu}) {
   const u32 lane = threadIdx.x & 63u;
   constexpr int NC = CALLER ? 5 : 4;
   /* per-lane counters of classes 1..NC-1, columns in the low and run starts in the high 16 bits (a step adds at
@@ -741,8 +751,8 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
   u64 Ctot[NC], Rtot[NC];
 #pragma unroll
   for (int k = 0; k < NC; k++) pk[k] = 0u, Ctot[k] = Rtot[k] = 0ull;
-  u32 carry_cls = 0xFFu; /* class of the column before this step's first one */
-  u64 run_base = 0, t_base = 0, q_base = 0;
+  u32 carry_cls = st0.carry; /* class of the column before this step's first one */
+  u64 run_base = 0, t_base = st0.t_base, q_base = st0.q_base;
   u32 steps = 0;
   for (u64 c0 = 0; c0 < L; c0 += 1024) {
     const u64 c = c0 + (u64)lane * 16u;
@@ -833,7 +843,7 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
           const u32 bit = (u32)__builtin_ctz(m); /* 7, 15, 23 or 31 */
           const u32 j = bit >> 3;
           const u32 k = (cls[d] >> (8u * j)) & 7u;
-          const u64 col = c + 4u * (u32)d + j;
+          const u64 col = st0.col_bias + c + 4u * (u32)d + j;
           if (CALLER) {
             const u32 bm = (1u << bit) - 1u; /* bytes below j */
             u64* e = rout + 3 * slot;
@@ -893,16 +903,19 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
   for (int k = 1; k < NC; k++) out.ncol[k] = C[k], out.nrun[k] = R[k];
   if (!CALLER) out.ncol[4] = out.nrun[4] = 0;
   out.runs = run_base;
+  out.t_nongap = t_base;
+  out.q_nongap = q_base;
 }
 
 __global__ __launch_bounds__(256, WGA_K3_BLOCKS) void k_maf_pair_stat(u32 n, const u8* __restrict__ rows,
                                                        const u64* t_off, const u64* q_off,
                                                        const u64* cols, const u8* strand_neg,
                                                        wga_cigar_counts* counts, u64* run_cnt,
-                                                       u64* runs, const u64* run_off) {
+                                                       u64* runs, const u64* run_off, u64 long_cols) {
   const u32 lane = threadIdx.x & 63u;
   const u64 i = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
   if (i >= n) return;
+  if (cols[i] > long_cols) return; /* a long block: walked piece by piece (k_maf_piece_walk) */
   MafWalkOut w;
   maf_walk<false>(rows + t_off[i], rows + q_off[i], cols[i], runs ? runs + run_off[i] : (u64*)0, w);
   {
@@ -929,13 +942,129 @@ __global__ __launch_bounds__(256, WGA_K3_BLOCKS) void k_maf_pair_stat(u32 n, con
 __global__ __launch_bounds__(256) void k_maf_call_runs(u32 n, const u8* __restrict__ rows,
                                                        const u64* t_off, const u64* q_off,
                                                        const u64* cols, u64* run_cnt, u64* runs,
-                                                       const u64* run_off) {
+                                                       const u64* run_off, u64 long_cols) {
   const u32 lane = threadIdx.x & 63u;
   const u64 i = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
   if (i >= n) return;
+  if (cols[i] > long_cols) return; /* a long block: walked piece by piece (k_maf_piece_walk) */
   MafWalkOut w;
   maf_walk<true>(rows + t_off[i], rows + q_off[i], cols[i], runs ? runs + 3 * run_off[i] : (u64*)0, w);
   if (lane == 0 && run_cnt) run_cnt[i] = w.runs;
+}
+
+/* ---- long blocks: the same walks, piece by piece ---------------------------------------------------------------
+ * A block of 10^8 columns (`call --chunk-size` exists because such blocks do) is no work for
+ * one wave.  Nothing in the walk is sequential: the class of a column is a function of that column, a run starts
+ * where the class differs from the column before, the counters are sums and the caller walk's "non-gap characters
+ * before the run" are prefix sums.  A block beyond `long_cols` columns is cut into pieces of `piece_cols`; every
+ * piece is one wave's walk (k_maf_piece_walk, a persistent grid over the piece list), started with the class of the
+ * column in front of it; a first pass leaves every piece's run and non-gap totals, an exclusive scan turns them into
+ * the piece's first run slot and start values, and the fill pass writes the runs in order.  The counters of a long
+ * block are added up with one atomic per field and piece. */
+struct wga_maf_piece_tot {
+  u64 runs, t_nongap, q_nongap;
+};
+/* pieces per record (0 for the records the one-wave kernels keep); long records get their counters zeroed */
+__global__ __launch_bounds__(256) void k_maf_piece_counts(u32 n, const u64* cols, u64 long_cols, u64 piece_cols,
+                                                          u64* npieces, wga_cigar_counts* counts, u64* run_cnt) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const u64 c = cols[i];
+  const bool lng = c > long_cols;
+  npieces[i] = lng ? (c + piece_cols - 1) / piece_cols : 0;
+  if (lng) {
+    if (counts) {
+      u64* f = (u64*)(counts + i);
+      for (int k = 0; k < 11; k++) f[k] = 0;
+    }
+    if (run_cnt) run_cnt[i] = 0;
+  }
+}
+
+__device__ __forceinline__ u32 maf_col_class(u8 tc, u8 qc, bool caller) {
+  const bool tg = tc == (u8)'-', qg = qc == (u8)'-';
+  if (caller) return (tg && qg) ? 4u : tg ? 1u : qg ? 2u : (tc == qc ? 0u : 3u);
+  return tc == qc ? 0u : tg ? 1u : qg ? 2u : 3u;
+}
+
+struct ScanPieceTot { /* three exclusive scans in one pass over the piece totals */
+  const wga_maf_piece_tot* in;
+  int field;
+  __device__ u64 operator()(u32 p) const { return field == 0 ? in[p].runs : field == 1 ? in[p].t_nongap : in[p].q_nongap; }
+};
+
+/* MODE 0: count (piece totals; K3 also adds the piece's counters to its record; run_cnt[i] += runs).
+ * MODE 1: fill (runs written at the piece's slot).  piece_off = exclusive scan of npieces (n + 1 entries);
+ * ex_runs / ex_t / ex_q = exclusive scans of the piece totals (fill only). */
+template <bool CALLER, int MODE>
+__global__ __launch_bounds__(256) void k_maf_piece_walk(u32 n, const u8* __restrict__ rows, const u64* t_off,
+                                                        const u64* q_off, const u64* cols, const u8* strand_neg,
+                                                        const u64* piece_off, u64 piece_cols,
+                                                        wga_maf_piece_tot* ptot, const u64* ex_runs, const u64* ex_t,
+                                                        const u64* ex_q, wga_cigar_counts* counts, u64* run_cnt,
+                                                        u64* runs, const u64* run_off) {
+  const u32 lane = threadIdx.x & 63u;
+  const u64 n_pieces = piece_off[n];
+  const u64 n_waves = (u64)gridDim.x * 4u;
+  for (u64 p = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x); p < n_pieces; p += n_waves) {
+    /* record of piece p: last i with piece_off[i] <= p (wave-uniform bisection) */
+    u32 lo = 0, hi = n;
+    while (hi - lo > 1u) {
+      const u32 mid = lo + ((hi - lo) >> 1);
+      if (piece_off[mid] <= p)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    const u32 i = lo;
+    const u64 p0 = piece_off[i];
+    const u64 c0 = (p - p0) * piece_cols;
+    const u64 L = cols[i] - c0 < piece_cols ? cols[i] - c0 : piece_cols;
+    const u8* t = rows + t_off[i];
+    const u8* q = rows + q_off[i];
+    MafWalkStart st;
+    st.col_bias = c0;
+    st.carry = c0 ? maf_col_class(t[c0 - 1], q[c0 - 1], CALLER) : 0xFFu;
+    st.t_base = st.q_base = 0;
+    u64* rout = (u64*)0;
+    if (MODE == 1) {
+      const u64 first = ex_runs[p] - ex_runs[p0]; /* runs of this record in front of the piece */
+      rout = runs + (CALLER ? 3u : 1u) * (run_off[i] + first);
+      if (CALLER) {
+        st.t_base = ex_t[p] - ex_t[p0];
+        st.q_base = ex_q[p] - ex_q[p0];
+      }
+    }
+    MafWalkOut w;
+    maf_walk<CALLER>(t + c0, q + c0, L, rout, w, st);
+    if (MODE == 0) {
+      if (lane == 0) {
+        wga_maf_piece_tot pt;
+        pt.runs = w.runs;
+        pt.t_nongap = w.t_nongap;
+        pt.q_nongap = w.q_nongap;
+        ptot[p] = pt;
+        if (run_cnt) atomicAdd(run_cnt + i, w.runs);
+      }
+      if (!CALLER && counts) {
+        const bool neg = strand_neg[i] != 0;
+        const u64 z = 0;
+        u64 v = 0;
+        v = lane_put_u64<0u>(v, w.ncol[0], lane);
+        v = lane_put_u64<1u>(v, w.ncol[3], lane);
+        v = lane_put_u64<2u>(v, neg ? z : w.nrun[1], lane);
+        v = lane_put_u64<3u>(v, neg ? z : w.ncol[1], lane);
+        v = lane_put_u64<4u>(v, neg ? z : w.nrun[2], lane);
+        v = lane_put_u64<5u>(v, neg ? z : w.ncol[2], lane);
+        v = lane_put_u64<6u>(v, neg ? w.nrun[1] : z, lane);
+        v = lane_put_u64<7u>(v, neg ? w.ncol[1] : z, lane);
+        v = lane_put_u64<8u>(v, neg ? w.nrun[2] : z, lane);
+        v = lane_put_u64<9u>(v, neg ? w.ncol[2] : z, lane);
+        v = lane_put_u64<10u>(v, (neg && p == p0) ? (u64)1 : z, lane); /* inv_event = 1 per '-' record: its first piece */
+        if (lane < 11u && v) atomicAdd((u64*)(counts + i) + lane, v);
+      }
+    }
+  }
 }
 
 /* ============================================================================================ */
