@@ -130,6 +130,12 @@ int wga_free(wga_ctx*, void* d_ptr);
 int wga_memcpy_h2d(wga_ctx*, void* d_dst, const void* h_src, size_t bytes);
 int wga_memcpy_d2h(wga_ctx*, void* h_dst, const void* d_src, size_t bytes); /* synchronises */
 int wga_memset(wga_ctx*, void* d_dst, int byte, size_t bytes);
+/* Pinned host memory and an asynchronous device-to-host copy on the context's stream: what a writer needs to stream
+ * a result (the MAF text of converter.rs:237-262, the BED lines of pafcov.rs:56-60) out of HBM in pieces while the
+ * next piece is copied — wga_sync (or a later synchronising call) before the host reads h_dst. */
+int wga_host_alloc(wga_ctx*, size_t bytes, void** h_out);
+int wga_host_free(wga_ctx*, void* h_ptr);
+int wga_memcpy_d2h_async(wga_ctx*, void* h_dst, const void* d_src, size_t bytes);
 
 /* ---- host: CIGAR text -> packed ops (replaces the nom tokeniser, cigar.rs:43-75,
  *      utils.rs:69-74; driven per record by every consumer, e.g. cigar.rs:529-549) ------------

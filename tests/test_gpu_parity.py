@@ -678,6 +678,127 @@ def test_pafpseudo_config5_long_cigar_cross_check(gpu):
         assert want.numel() == got.numel() and bool((want == got).all()), i
 
 
+FULL = os.environ.get("WGA_FULL_CONFIGS", "0") != "0"
+
+
+@pytest.mark.skipif(not FULL, reason="BASELINE configs[3] at its stated size (64 x 100 Mb, 20 M records: ~2 min on one "
+                                     "GPU): WGA_FULL_CONFIGS=1; the log of the last run is profiles/r02_full_configs.txt")
+def test_pafcov_config4_at_stated_size(gpu):
+    """64 targets x 100 Mb = 6.4e9 int32 counters (25.6 GB), 20 M records of ~1300 ops generated on the device in ten
+    chunks and accumulated into ONE resident coverage array; per target the summed coverage equals the M / = bases K1
+    counts for the records that hit it, coverage is never negative"""
+    import torch
+    dev = torch.device("cuda", 0)
+    nt, tlen, chunks, per = 64, 100_000_000, 10, 2_000_000
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    cov_len = torch.full((nt,), tlen, dtype=torch.int64, device=dev)
+    cov_off = torch.arange(nt, device=dev, dtype=torch.int64) * (tlen + 4)
+    total = int(nt * (tlen + 4))
+    cov = torch.zeros(total + 8, dtype=torch.int32, device=dev)
+    want = torch.zeros(nt, dtype=torch.int64, device=dev)
+    ms_acc, n_ops = 0.0, 0
+    for k in range(chunks):
+        tb = synth.make_paf_batch_torch(400 + k, per, 1300, tlen, dev)
+        n = tb["n"]
+        batch = engine.Batch(tb["ops"], tb["op_off"], tb["strand_neg"], n, tb["n_ops"])
+        g = torch.Generator(device=dev)
+        g.manual_seed(900 + k)
+        target_id = torch.randint(0, nt, (n,), device=dev, generator=g, dtype=torch.int32)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        gpu.pafcov_accumulate(batch, target_id, tb["t_src_off"], cov_off, cov_len, cov, total)
+        e1.record()
+        counts = torch.zeros((n, 11), dtype=torch.int64, device=dev)
+        diag = torch.zeros((n, 3), dtype=torch.int64, device=dev)
+        gpu.cigar_stat(batch, counts, diag, None)
+        torch.cuda.synchronize()
+        ms_acc += e0.elapsed_time(e1)
+        n_ops += tb["n_ops"]
+        want.index_add_(0, target_id.long(), counts[:, 0])
+        del tb, batch, counts, diag, target_id
+        torch.cuda.empty_cache()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    gpu.pafcov_finalize(nt, cov_off, cov_len, cov)
+    e1.record()
+    torch.cuda.synchronize()
+    ms_fin = e0.elapsed_time(e1)
+    print("\nconfig 4 at size: %d records, %.3g ops, %d x %d counters: accumulate %.1f ms in all (%.0f GB/s of op stream), "
+          "finalize %.1f ms (%.0f GB/s over 8 B per counter)" % (chunks * per, n_ops, nt, tlen, ms_acc, 4 * n_ops / ms_acc / 1e6,
+                                                                ms_fin, 8.0 * nt * tlen / ms_fin / 1e6))
+    for t in range(nt):
+        c = cov[int(cov_off[t]):int(cov_off[t]) + tlen]
+        assert int(c.sum(dtype=torch.int64)) == int(want[t]), t
+        assert int(c.min()) >= 0
+    gpu.reset_stream()
+
+
+@pytest.mark.skipif(not FULL, reason="BASELINE configs[4] stress at its stated size (10 000 records >= 200 kop): WGA_FULL_CONFIGS=1")
+def test_pafpseudo_config5_at_stated_size(gpu):
+    """10 000 records of >= 200 kop (2.5e9 ops, 3.7e10 columns) in chunks of 400: the base-mode pseudo-MAF row equals
+    paf2maf's query row minus the columns where its target row is gapped (K6 against K2), the symbol-mode row equals
+    the op symbols expanded on the device with torch"""
+    import torch
+    from wgatools_amd import pipeline
+    dev = torch.device("cuda", 0)
+    per, chunks = 400, 25
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    sym = torch.zeros(16, dtype=torch.uint8, device=dev)
+    sym[0] = sym[7] = ord("1")
+    sym[8] = ord("0")
+    sym[2] = ord("-")
+    ms = {0: 0.0, 1: 0.0}
+    out_bytes, n_ops = 0, 0
+    for k in range(chunks):
+        tb = synth.make_paf_batch_torch(700 + k, per, 250_000, 60_000_000, dev, sigma=0.05)
+        n = tb["n"]
+        assert int(torch.diff(tb["op_off"]).min()) >= 200_000
+        job = pipeline.Paf2MafStatJob(gpu, tb)
+        job.bind_stream()
+        job.step()
+        batch = engine.Batch(tb["ops"], tb["op_off"], tb["strand_neg"], n, tb["n_ops"])
+        seg = tb["mx"] + tb["d"]
+        dst_off = torch.zeros(n, dtype=torch.int64, device=dev)
+        dst_off[1:] = torch.cumsum(seg, 0)[:-1]
+        total = int(seg.sum())
+        skip = torch.zeros(n, dtype=torch.int64, device=dev)
+        outs = {}
+        for mode in (1, 0):
+            out = torch.zeros(total + 64, dtype=torch.uint8, device=dev)
+            gpu.pafpseudo_fill(batch, mode, tb["q_pool"], int(tb["q_pool"].numel()), tb["q_src_off"], tb["q_src_len"], skip, out, dst_off)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            gpu.pafpseudo_fill(batch, mode, tb["q_pool"], int(tb["q_pool"].numel()), tb["q_src_off"], tb["q_src_len"], skip, out, dst_off)
+            e1.record()
+            torch.cuda.synchronize()
+            ms[mode] += e0.elapsed_time(e1)
+            outs[mode] = out
+        out_bytes += total
+        n_ops += tb["n_ops"]
+        # base mode against K2: rows are laid out t row, q row per record; concatenated over the chunk
+        L = tb["mx"] + tb["i"] + tb["d"]
+        rec = torch.repeat_interleave(torch.arange(n, device=dev), L)
+        col = torch.arange(int(L.sum()), device=dev) - torch.repeat_interleave(torch.cumsum(L, 0) - L, L)
+        trow = job.out[job.t_row_off[rec] + col]
+        qrow = job.out[job.q_row_off[rec] + col]
+        want = qrow[trow != 45]
+        assert want.numel() == total and bool((want == outs[1][:total]).all()), k
+        del rec, col, trow, qrow, want
+        # symbol mode against the ops expanded with torch
+        code = (tb["ops"] & 15).long()
+        ln = (tb["ops"] >> 4).long()
+        keep = (code == 0) | (code == 7) | (code == 8) | (code == 2)
+        want_sym = torch.repeat_interleave(sym[code[keep]], ln[keep])
+        assert want_sym.numel() == total and bool((want_sym == outs[0][:total]).all()), k
+        del tb, job, batch, outs, code, ln, keep, want_sym
+        torch.cuda.empty_cache()
+    print("\nconfig 5 stress at size: %d records, %.3g ops, %.3g row bytes per mode: base mode %.1f ms in all (%.0f GB/s of "
+          "4n + 2 x row bytes), symbol mode %.1f ms (%.0f GB/s of 4n + row bytes)" % (
+              per * chunks, n_ops, out_bytes, ms[1], (4 * n_ops + 2 * out_bytes) / ms[1] / 1e6, ms[0],
+              (4 * n_ops + out_bytes) / ms[0] / 1e6))
+    gpu.reset_stream()
+
+
 def test_fasta_pool(gpu):
     """device-built sequence pools == the host faidx reader's, on multi-contig, ragged-line, CRLF and odd inputs"""
     for t in pc.FASTA_CASES:

@@ -69,6 +69,9 @@ PROTOTYPES = {
     "wga_maf_split": (C.c_int, [vp, vp, C.c_uint64, C.POINTER(C.c_uint64), vp, C.c_uint64]),
     "wga_cigar_tokenise_spans": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]),
     "wga_counts_total": (C.c_int, [vp, C.c_uint32, vp, vp]),
+    "wga_host_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "wga_host_free": (C.c_int, [vp, vp]),
+    "wga_memcpy_d2h_async": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "wga_fasta_pool": (C.c_int, [vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp, vp]),
     "wga_paf_call_events": (C.c_int, [vp, C.POINTER(CigarBatch), C.c_uint64, C.c_int, vp, vp, vp]),
     "wga_pafcov_accumulate": (C.c_int, [vp, C.POINTER(CigarBatch), vp, vp, vp, vp, vp, C.c_uint64]),

@@ -84,7 +84,7 @@ def build_cli(force=False):
         return CLI_BIN
     os.makedirs(os.path.dirname(CLI_BIN), exist_ok=True)
     _run(["g++", "-O2", "-g", "-std=c++17", "-Wall", srcs[0], srcs[1], "-o", CLI_BIN,
-          "-L" + os.path.dirname(lib), "-lwgahip", "-lz", "-Wl,-rpath,$ORIGIN/..",
+          "-L" + os.path.dirname(lib), "-lwgahip", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN/..",
           "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
     return CLI_BIN
 
@@ -99,7 +99,7 @@ def build_cli_emu(force=False):
         return CLI_EMU_BIN
     _run(["g++", "-O1", "-g", "-std=c++17", "-Wall", os.path.join(ROOT, "wgatools_amd", "host", "wgatools_main.cpp"),
           os.path.join(ROOT, "wgatools_amd", "host", "wga_host.cpp"), "-o", CLI_EMU_BIN, "-L" + os.path.dirname(lib),
-          "-lwgaemu", "-lz", "-Wl,-rpath,$ORIGIN"])
+          "-lwgaemu", "-lz", "-lpthread", "-Wl,-rpath,$ORIGIN"])
     return CLI_EMU_BIN
 
 

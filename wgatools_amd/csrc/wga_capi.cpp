@@ -415,6 +415,26 @@ int wga_memcpy_d2h(wga_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
     RT_CHECK(rt_sync(c->stream));
   return WGA_OK;
 }
+int wga_host_alloc(wga_ctx* c, size_t bytes, void** h_out) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (!h_out) return fail(WGA_E_INVALID_ARG, "h_out is null", nullptr);
+  const char* e = rt_host_alloc(h_out, bytes);
+  if (e) return fail(WGA_E_OOM, "pinned host allocation", e);
+  return WGA_OK;
+}
+int wga_host_free(wga_ctx* c, void* h_ptr) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (h_ptr) RT_CHECK(rt_host_free(h_ptr));
+  return WGA_OK;
+}
+int wga_memcpy_d2h_async(wga_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (bytes) RT_CHECK(rt_d2h_async(h_dst, d_src, bytes, c->stream));
+  return WGA_OK;
+}
 int wga_memset(wga_ctx* c, void* d_dst, int byte, size_t bytes) {
   int rc = ctx_bind(c);
   if (rc) return rc;

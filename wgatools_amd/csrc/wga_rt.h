@@ -45,6 +45,18 @@ static inline const char* rt_memset(void* d, int v, size_t n, wga_stream_t) {
   memset(d, v, n);
   return nullptr;
 }
+static inline const char* rt_host_alloc(void** p, size_t n) {
+  *p = malloc(n ? n : 1);
+  return *p ? nullptr : "malloc failed";
+}
+static inline const char* rt_host_free(void* p) {
+  free(p);
+  return nullptr;
+}
+static inline const char* rt_d2h_async(void* h, const void* d, size_t n, wga_stream_t) {
+  memcpy(h, d, n);
+  return nullptr;
+}
 static inline const char* rt_launch_error() { return nullptr; }
 typedef int rt_event_t;
 static inline const char* rt_event_create(rt_event_t* e) {
@@ -86,6 +98,11 @@ static inline const char* rt_d2h(void* h, const void* d, size_t n, wga_stream_t 
 }
 static inline const char* rt_memset(void* d, int v, size_t n, wga_stream_t s) {
   return rt_err(hipMemsetAsync(d, v, n, s));
+}
+static inline const char* rt_host_alloc(void** p, size_t n) { return rt_err(hipHostMalloc(p, n ? n : 1, hipHostMallocDefault)); }
+static inline const char* rt_host_free(void* p) { return rt_err(hipHostFree(p)); }
+static inline const char* rt_d2h_async(void* h, const void* d, size_t n, wga_stream_t s) {
+  return rt_err(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s));
 }
 static inline const char* rt_launch_error() { return rt_err(hipGetLastError()); }
 typedef hipEvent_t rt_event_t;

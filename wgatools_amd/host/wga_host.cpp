@@ -252,6 +252,17 @@ void Output::write(const char* p, size_t n) {
     fail("IO error:write failed");
   }
 }
+int Output::plain_fd(uint64_t* pos) {
+  if (gz || !fp || fp == stdout) return -1;
+  fflush(fp);
+  const long at = ftell(fp);
+  if (at < 0) return -1;
+  *pos = (uint64_t)at;
+  return fileno(fp);
+}
+void Output::advance(uint64_t n) {
+  if (fp && fp != stdout && fseek(fp, (long)n, SEEK_CUR) != 0) fail("IO error:seek failed");
+}
 void Output::close() {
   if (gz) gzclose((gzFile)gz);
   if (fp && fp != stdout) fclose(fp);

@@ -48,6 +48,10 @@ struct Output {
   void write(const char* p, size_t n);
   void write(const std::string& s) { write(s.data(), s.size()); }
   void close();
+  /* a plain file (not stdout, not .gz): positional writes from several threads are possible.  Returns the file
+   * descriptor after flushing what stdio holds and the offset where the next byte belongs, or -1. */
+  int plain_fd(uint64_t* pos);
+  void advance(uint64_t n); /* the caller wrote n bytes at the position plain_fd reported */
 };
 
 /* ---- PAF ------------------------------------------------------------------------------------ */

@@ -13,10 +13,14 @@
 #include <stdlib.h>
 #include <sys/stat.h>
 #include <time.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <regex>
+#include <thread>
 
 #include "wga_host.hpp"
 
@@ -74,6 +78,126 @@ struct Dev {
       for (void* p : owned) wga_free(ctx, p);
       wga_ctx_destroy(ctx);
     }
+  }
+};
+
+/* Streams n bytes of a device buffer into the output: pinned staging buffers, the copy of piece k + 1 runs while
+ * piece k is written; into a plain file the pieces are written with pwrite by a few threads (one write() stream into
+ * the page cache moves 2-4 GB/s, the copy engine > 40 GB/s), anything else (stdout, .gz) keeps the one ordered
+ * writer.  Replaces "download everything into one std::string, then fwrite" (r01: paf2maf 1.8 s for 3 GB of MAF). */
+struct DevStreamer {
+  static const size_t kPiece = (size_t)32 << 20;
+  static const int kBufs = 6;
+  Dev& d;
+  void* buf[kBufs];
+  DevStreamer(Dev& dev) : d(dev) {
+    for (int k = 0; k < kBufs; k++) buf[k] = nullptr;
+  }
+  ~DevStreamer() {
+    for (int k = 0; k < kBufs; k++)
+      if (buf[k]) wga_host_free(d.ctx, buf[k]);
+  }
+  void run(Output& out, const uint8_t* d_src, size_t n) {
+    if (n == 0) return;
+    for (int k = 0; k < kBufs; k++)
+      if (!buf[k]) d.check(wga_host_alloc(d.ctx, kPiece, &buf[k]));
+    uint64_t pos0 = 0;
+    const int fd = out.plain_fd(&pos0);
+    const size_t np = (n + kPiece - 1) / kPiece;
+    std::vector<std::thread> writers;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int> state(kBufs, 0); /* 0 free, 1 filled (piece index in `which`) */
+    std::vector<size_t> which(kBufs, 0);
+    size_t next_write = 0; /* ordered writer: next piece to go out */
+    bool failed = false, done_filling = false;
+    auto writer = [&]() {
+      for (;;) {
+        int b = -1;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] {
+            if (failed) return true;
+            for (int k = 0; k < kBufs; k++)
+              if (state[k] == 1 && (fd >= 0 || which[k] == next_write)) return true;
+            return done_filling;
+          });
+          if (failed) return;
+          for (int k = 0; k < kBufs; k++)
+            if (state[k] == 1 && (fd >= 0 || which[k] == next_write)) {
+              b = k;
+              state[k] = 2;
+              break;
+            }
+          if (b < 0) return; /* done_filling and nothing left for this thread */
+        }
+        const size_t p = which[b], off = p * kPiece, len = std::min(kPiece, n - off);
+        bool ok = true;
+        if (fd >= 0) {
+          size_t w = 0;
+          while (w < len) {
+            const ssize_t r = pwrite(fd, (const char*)buf[b] + w, len - w, (off_t)(pos0 + off + w));
+            if (r <= 0) {
+              ok = false;
+              break;
+            }
+            w += (size_t)r;
+          }
+        } else {
+          try {
+            out.write((const char*)buf[b], len);
+          } catch (...) {
+            ok = false;
+          }
+        }
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          state[b] = 0;
+          if (fd < 0) next_write++;
+          if (!ok) failed = true;
+        }
+        cv.notify_all();
+      }
+    };
+    const int nthreads = fd >= 0 ? 4 : 1;
+    for (int t = 0; t < nthreads; t++) writers.emplace_back(writer);
+    /* the filler: issue the copy of a piece into a free buffer, wait for it, hand it over */
+    for (size_t p = 0; p < np && !failed; p++) {
+      int b = -1;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] {
+          if (failed) return true;
+          for (int k = 0; k < kBufs; k++)
+            if (state[k] == 0) return true;
+          return false;
+        });
+        if (failed) break;
+        for (int k = 0; k < kBufs; k++)
+          if (state[k] == 0) {
+            b = k;
+            state[k] = 3; /* being filled */
+            break;
+          }
+      }
+      const size_t off = p * kPiece, len = std::min(kPiece, n - off);
+      d.check(wga_memcpy_d2h_async(d.ctx, buf[b], d_src + off, len));
+      d.check(wga_sync(d.ctx));
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        which[b] = p;
+        state[b] = 1;
+      }
+      cv.notify_all();
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      done_filling = true;
+    }
+    cv.notify_all();
+    for (auto& t : writers) t.join();
+    if (failed) fail("IO error:write failed");
+    if (fd >= 0) out.advance(n);
   }
 };
 
@@ -431,9 +555,7 @@ uint32_t expand_batch(Dev& d, const wga_cigar_batch& cb, const ExpandJob& j, con
     *first_bad = g;
     break;
   }
-  std::string host((size_t)rec_off[good], '\0');
-  if (rec_off[good]) d.download((uint8_t*)host.data(), d_out, rec_off[good]);
-  out.write(host);
+  DevStreamer(d).run(out, d_out, (size_t)rec_off[good]);
   return good;
 }
 
@@ -1070,9 +1192,7 @@ int cmd_paf2chain(const std::string* input, Output& out) {
         d.check(wga_cigar_chain(d.ctx, &cb2, nullptr, nullptr, nullptr, d_out, d.upload(data_off)));
         d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off),
                                   d_out, d.upload(dst)));
-        std::string host((size_t)pos, '\0');
-        d.download((uint8_t*)&host[0], d_out, pos);
-        out.write(host);
+        DevStreamer(d).run(out, d_out, (size_t)pos);
       }
     }
     d.release_to(keep);
@@ -1264,9 +1384,7 @@ int cmd_chain2paf(const std::string* input, Output& out) {
     d.check(wga_chain_lines_cigar_text(d.ctx, n, b.n_lines, b.d_lines, b.d_line_off, nullptr, d_out, d.upload(text_off)));
     d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off), d_out,
                               d.upload(dst)));
-    std::string host((size_t)pos, '\0');
-    if (pos) d.download((uint8_t*)&host[0], d_out, pos);
-    out.write(host);
+    DevStreamer(d).run(out, d_out, (size_t)pos);
     d.release_all();
     i0 = i;
   }
@@ -1389,9 +1507,7 @@ int cmd_maf2chain(const std::string* input, const std::string* query_name, Outpu
     d.check(wga_cigar_chain(d.ctx, &cb, nullptr, nullptr, nullptr, d_out, d.upload(data_off)));
     d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off), d_out,
                               d.upload(dst)));
-    std::string host((size_t)pos, '\0');
-    d.download((uint8_t*)&host[0], d_out, pos);
-    out.write(host);
+    DevStreamer(d).run(out, d_out, (size_t)pos);
   }
   chain_base += n_in_piece;
   d.release_all();
@@ -1667,6 +1783,7 @@ int cmd_pafcov(const std::string* input, Output& out) {
     uint8_t* d_txt = nullptr;
     uint64_t txt_cap = 0;
     std::string text;
+    DevStreamer streamer(d);
     for (uint32_t t = 0; t < nt; t++) {
       auto* d_name = d.upload((const uint8_t*)targets[t].data(), targets[t].size());
       for (uint64_t pos = 0; pos < cov_len[t]; pos += kChunk) {
@@ -1681,9 +1798,7 @@ int cmd_pafcov(const std::string* input, Output& out) {
           d_txt = (uint8_t*)d.alloc(txt_cap);
         }
         d.check(wga_pafcov_format(d.ctx, d_name, (uint32_t)targets[t].size(), cp, pos, cnt, d_loff, d_txt));
-        text.resize(bytes);
-        if (bytes) d.download((uint8_t*)&text[0], d_txt, bytes);
-        out.write(text);
+        streamer.run(out, d_txt, (size_t)bytes); /* 4 M positions of BED text per piece, copied and written in overlap */
       }
     }
     text.clear();
