@@ -517,6 +517,21 @@ def test_call_and_maf2paf_on_a_long_block(cli, tmp_path):
         assert ln.split("\t")[-1] == "cg:Z:" + txt
 
 
+def test_call_blocks_over_host_threads(cli, tmp_path):
+    """the event rules / VCF text of the blocks are worked out by several host threads: same bytes, block order kept"""
+    blocks = _synth_maf_blocks(31, 23, 900)
+    maf = tmp_path / "in.maf"
+    _write_maf(maf, blocks)
+    want = _expected_vcf(blocks, "smp", True, True, 2, 500)
+    for thr in ("1", "3", "8", "64"):
+        os.environ["WGA_HOST_THREADS"] = thr
+        try:
+            rc, out, err = run(cli, "call", str(maf), "-s", "-i", "-l", "2", "-c", "500", "-n", "smp")
+        finally:
+            del os.environ["WGA_HOST_THREADS"]
+        assert rc == 0 and out.decode() == want, (thr, err)
+
+
 def test_call_query_selection(cli, tmp_path):
     """caller.rs:62-108: --query-name / --query-regex pick the query s-line; blocks without it are skipped"""
     blocks = _synth_maf_blocks(5, 4, 400)

@@ -29,13 +29,50 @@ using namespace wga;
 namespace {
 
 /* ---- device helper ---------------------------------------------------------------------------- */
+/* WGA_TIMING=1: wall time per phase of a command on stderr when it ends (profiles/r02_cli_e2e.txt) */
+struct PhaseTimer {
+  bool on = getenv("WGA_TIMING") != nullptr;
+  std::vector<std::pair<std::string, double>> acc;
+  double last = now();
+  static double now() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+  }
+  void mark(const char* name) { /* the time since the previous mark belongs to `name` */
+    if (!on) return;
+    const double t = now();
+    for (auto& a : acc)
+      if (a.first == name) {
+        a.second += t - last;
+        last = t;
+        return;
+      }
+    acc.emplace_back(name, t - last);
+    last = t;
+  }
+  ~PhaseTimer() {
+    if (!on) return;
+    double tot = 0;
+    for (auto& a : acc) tot += a.second;
+    fprintf(stderr, "[timing]");
+    for (auto& a : acc) fprintf(stderr, " %s %.3f s |", a.first.c_str(), a.second);
+    fprintf(stderr, " marked total %.3f s\n", tot);
+  }
+};
+static PhaseTimer g_timer;
+
 struct Dev {
   wga_ctx* ctx = nullptr;
   std::vector<void*> owned;
   void init() {
     if (ctx) return;
+    g_timer.mark("host");
     int rc = wga_ctx_create(0, &ctx);
     if (rc) fail(std::string("GPU engine: ") + wga_last_error());
+    void* warm = nullptr; /* the first allocation pays for the runtime's lazy initialisation */
+    if (wga_malloc(ctx, 256, &warm) == 0) wga_free(ctx, warm);
+    g_timer.mark("hip init");
   }
   void check(int rc) {
     if (rc) fail(std::string("GPU engine: ") + wga_last_error());
@@ -2448,7 +2485,9 @@ int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, c
   }
   if (chunk_size == 0) fail("chunk size must be positive (the reference would never terminate)");
   MafInput min;
+  g_timer.mark("host");
   while (chunks.next(d, min)) { /* one piece of the file at a time, rows written as they are called (caller.rs:62-149) */
+  g_timer.mark("read + upload + split");
   std::vector<MafRecord>& all = min.recs;
   /* record selection (:62-108): single-s-line blocks and blocks without the asked query are skipped */
   std::vector<const MafRecord*> recs;
@@ -2488,24 +2527,56 @@ int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, c
     d.check(wga_maf_call_runs(d.ctx, n, d_rows, d_t, d_q, d_c, d_cnt, d_runs, d_roff));
     std::vector<uint64_t> runs(3 * roff[n]);
     if (roff[n]) d.download(runs.data(), d_runs, 3 * roff[n]);
-    for (uint32_t k = 0; k < n; k++) {
-      CallBlock b;
-      b.rec = recs[k];
-      b.total = p.cols[k];
-      for (uint64_t x = roff[k]; x < roff[k + 1]; x++)
-        b.runs.push_back(CallRun{runs[3 * x] >> 3, runs[3 * x + 1], runs[3 * x + 2], (uint32_t)(runs[3 * x] & 7)});
-      uint64_t cs = 0;
-      while (cs < b.total) {
-        uint64_t ce = safe_chunk_end(b, cs, chunk_size, svlen);
-        call_chunk(b, cs, ce, snp, inv, svlen, text);
-        if (ce <= cs) fail("panic: chunk boundary did not advance");
-        cs = ce;
-        if (text.size() > (1u << 24)) {
-          out.write(text);
-          text.clear();
+    g_timer.mark("kernels + run list download");
+    /* the event rules and the VCF text of a block depend on that block alone: contiguous ranges of blocks go to host
+     * threads, their text is written in block order (rows in front of a failing block are written, then the error) */
+    unsigned nthr = std::thread::hardware_concurrency();
+    nthr = std::max(1u, std::min({nthr, 32u, n / 256u + 1u}));
+    if (const char* e = getenv("WGA_HOST_THREADS")) nthr = std::max(1u, std::min((unsigned)atoi(e), n)); /* tests */
+    std::vector<std::string> parts(nthr), errs(nthr);
+    auto work = [&](unsigned t) {
+      const uint32_t lo = (uint32_t)((uint64_t)n * t / nthr), hi = (uint32_t)((uint64_t)n * (t + 1) / nthr);
+      std::string& txt = parts[t];
+      try {
+        CallBlock b;
+        for (uint32_t k = lo; k < hi; k++) {
+          b.rec = recs[k];
+          b.total = p.cols[k];
+          b.runs.clear();
+          b.runs.reserve(roff[k + 1] - roff[k]);
+          for (uint64_t x = roff[k]; x < roff[k + 1]; x++)
+            b.runs.push_back(CallRun{runs[3 * x] >> 3, runs[3 * x + 1], runs[3 * x + 2], (uint32_t)(runs[3 * x] & 7)});
+          uint64_t cs = 0;
+          while (cs < b.total) {
+            uint64_t ce = safe_chunk_end(b, cs, chunk_size, svlen);
+            call_chunk(b, cs, ce, snp, inv, svlen, txt);
+            if (ce <= cs) fail("panic: chunk boundary did not advance");
+            cs = ce;
+          }
         }
+      } catch (Error& e) {
+        errs[t] = e.msg.empty() ? std::string("error") : e.msg;
+      }
+    };
+    {
+      std::vector<std::thread> th;
+      for (unsigned t = 1; t < nthr; t++) th.emplace_back(work, t);
+      work(0);
+      for (auto& x : th) x.join();
+    }
+    g_timer.mark("host event rules + VCF text");
+    for (unsigned t = 0; t < nthr; t++) {
+      text += parts[t];
+      if (!errs[t].empty()) {
+        out.write(text);
+        fail(errs[t]);
+      }
+      if (text.size() > (1u << 24)) {
+        out.write(text);
+        text.clear();
       }
     }
+    g_timer.mark("write");
   }
   d.release_all();
   }
