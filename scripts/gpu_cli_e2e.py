@@ -45,7 +45,10 @@ run("dotplot", ["dotplot", "-f", "paf", "--out-format", "csv", paf], os.path.joi
 run("chain2paf", ["chain2paf", os.path.join(tmp, "out.chain")], os.path.join(tmp, "out2.paf"))
 run("call paf", ["call", "-f", "paf", paf, "--target", t_fa, "--query", q_fa, "-s", "-l", "50"], os.path.join(tmp, "out.vcf"))
 run("pafpseudo", ["pafpseudo", paf], os.path.join(tmp, "pseudo_sym"))
-run("pafpseudo-f", ["pafpseudo", paf, "-f", q_fa], os.path.join(tmp, "pseudo_base"))
+all_fa = os.path.join(tmp, "all.fa")      # pafpseudo -f wants every genome in one FASTA (pseudomaf.rs:214-237)
+with open(all_fa, "wb") as f:
+    f.write(open(t_fa, "rb").read() + open(q_fa, "rb").read())
+run("pafpseudo-f", ["pafpseudo", paf, "-f", all_fa], os.path.join(tmp, "pseudo_base"))
 # the same with the csv-semantics host reader instead of the device splitter
 run("stat/host", ["stat", "-f", "paf", paf], os.path.join(tmp, "out.tsv"), env={"WGA_PAF_READER": "host"})
 run("p2c/host", ["paf2chain", paf], os.path.join(tmp, "out.chain"), env={"WGA_PAF_READER": "host"})

@@ -75,7 +75,8 @@ std::vector<PafRecord> parse_paf(const std::string& text, uint64_t rec0, uint64_
  * input.  A piece holds at least `target` bytes unless the input ends; a piece that contains a '"' takes the rest of
  * the input with it (a quoted csv field may hold line ends). */
 struct LineChunkReader {
-  void* gz = nullptr; /* gzFile; nullptr = stdin */
+  void* gz = nullptr; /* gzFile of a gzip input */
+  int fd = -1;        /* a plain file is read with read(2): zlib's transparent mode copies at ~1.2 GB/s */
   bool is_stdin = false, eof = false;
   std::string carry;
   uint64_t bytes_before = 0, lines_before = 0; /* of the piece next() returned last */
