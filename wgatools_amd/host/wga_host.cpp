@@ -182,6 +182,8 @@ void LineChunkReader::open(const std::string* path) {
     if (!(got == 2 && m[0] == 31 && m[1] == 139)) {
       fd = ::open(path->c_str(), O_RDONLY);
       if (fd < 0) fail("File path `" + *path + "` not exist");
+      struct stat st;
+      if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) file_left = (uint64_t)st.st_size;
       return;
     }
   }
@@ -202,17 +204,51 @@ bool LineChunkReader::next(std::string& piece, size_t target, size_t keep) {
   lines_before = next_lines;
   if (target == 0) target = 1;
   const size_t kRead = (size_t)8 << 20;
+  if (fd >= 0 && file_left) /* one allocation for the piece: what is left of the file, or the target plus a long line */
+    piece.reserve(piece.size() + (size_t)std::min<uint64_t>(file_left, (uint64_t)target + 2 * kRead) + kRead + 64);
   auto more = [&]() -> bool { /* reads straight into the end of `piece` */
     if (eof) return false;
     const size_t at = piece.size();
     piece.resize(at + kRead);
-    size_t n;
+    size_t n, kept_size = 0;
     if (is_stdin) {
       n = fread(&piece[at], 1, kRead, stdin);
+    } else if (fd >= 0 && file_left > 4 * kRead && target > 4 * kRead) {
+      /* a large regular file: what this piece still needs is read by a few threads at once (pread into disjoint
+       * ranges of the buffer): one reader moves ~1.8 GB/s out of the page cache */
+      const size_t have = at - keep;
+      const size_t want = (size_t)std::min<uint64_t>(file_left, (uint64_t)(have < target ? target - have : 0) + kRead);
+      piece.resize(at + want);
+      const off_t pos = lseek(fd, 0, SEEK_CUR);
+      const unsigned T = 6;
+      std::vector<size_t> got(T, 0);
+      std::vector<std::thread> th;
+      auto rd = [&](unsigned t) {
+        const size_t a = want * t / T, z = want * (t + 1) / T;
+        size_t done = a;
+        while (done < z) {
+          const ssize_t r = pread(fd, &piece[at + done], z - done, pos + (off_t)done);
+          if (r <= 0) break;
+          done += (size_t)r;
+        }
+        got[t] = done - a;
+      };
+      for (unsigned t = 1; t < T; t++) th.emplace_back(rd, t);
+      rd(0);
+      for (auto& x : th) x.join();
+      n = 0;
+      for (unsigned t = 0; t < T; t++) {
+        if (got[t] != want * (t + 1) / T - want * t / T) fail("IO error:short read");
+        n += got[t];
+      }
+      lseek(fd, pos + (off_t)n, SEEK_SET);
+      file_left -= (uint64_t)n;
+      kept_size = at + n;
     } else if (fd >= 0) {
       const ssize_t got = ::read(fd, &piece[at], kRead);
       if (got < 0) fail("IO error:read failed");
       n = (size_t)got;
+      file_left -= std::min<uint64_t>(file_left, (uint64_t)n);
     } else {
       const int got = gzread((gzFile)gz, &piece[at], (unsigned)kRead);
       if (got < 0) { /* a damaged / truncated gzip member is an error, not the end of the input (errors.rs:10) */
@@ -221,7 +257,7 @@ bool LineChunkReader::next(std::string& piece, size_t target, size_t keep) {
       }
       n = (size_t)got;
     }
-    piece.resize(at + n);
+    piece.resize(kept_size ? kept_size : at + n);
     if (n == 0) eof = true;
     return n != 0;
   };

@@ -77,6 +77,7 @@ std::vector<PafRecord> parse_paf(const std::string& text, uint64_t rec0, uint64_
 struct LineChunkReader {
   void* gz = nullptr; /* gzFile of a gzip input */
   int fd = -1;        /* a plain file is read with read(2): zlib's transparent mode copies at ~1.2 GB/s */
+  uint64_t file_left = 0; /* ... and its size is known: a piece's buffer is reserved once instead of grown by doubling */
   bool is_stdin = false, eof = false;
   std::string carry;
   uint64_t bytes_before = 0, lines_before = 0; /* of the piece next() returned last */

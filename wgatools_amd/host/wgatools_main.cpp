@@ -797,10 +797,12 @@ MafInput maf_from_text(Dev& d, std::string&& whole_text) {
   const std::string& text = *in.text;
   const char* force = getenv("WGA_MAF_READER"); /* "host": always the host reader (measurements) */
   if (!text.empty() && text.size() < 0xFFFFFFF0ull && !(force && strcmp(force, "host") == 0)) {
+    g_timer.mark("file read");
     d.init();
     in.text->append(16, '\0'); /* slack behind the text for whole-vector loads */
     in.d_text = d.upload((const uint8_t*)text.data(), text.size());
     in.text->resize(text.size() - 16);
+    g_timer.mark("upload");
     uint64_t n_lines = 0;
     d.check(wga_maf_split(d.ctx, in.d_text, text.size(), &n_lines, nullptr, 0));
     auto* d_lines = (wga_maf_line*)d.alloc((size_t)(n_lines + 1) * sizeof(wga_maf_line));
@@ -808,6 +810,7 @@ MafInput maf_from_text(Dev& d, std::string&& whole_text) {
     std::vector<wga_maf_line> lines((size_t)n_lines);
     if (n_lines) d.download(lines.data(), d_lines, (size_t)n_lines);
     d.release(d_lines);
+    g_timer.mark("device split + line table");
     bool plain = true;
     for (const wga_maf_line& L : lines)
       if (L.status == WGA_MAF_FALLBACK) plain = false;
@@ -838,6 +841,7 @@ MafInput maf_from_text(Dev& d, std::string&& whole_text) {
         sl.seq_len = L.seq_len;
         in.recs.back().slines.push_back(std::move(sl));
       }
+      g_timer.mark("host records");
       return in;
     }
     d.release(in.d_text);
