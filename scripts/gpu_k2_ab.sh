@@ -8,6 +8,6 @@ for A in "$@"; do
   V=${A%%|*}; F=${A#*|}
   WGA_EXTRA_FLAGS="$F" python -c "from wgatools_amd import build; build.build_hip(force=True)" > /dev/null 2>&1 || { echo "[$A] build failed"; continue; }
   for cfg in "${CF[@]}"; do for rep in $(seq $REPS); do
-    WGA_EXPAND_VARIANT=$V python bench.py --no-cpu-baseline --check 0 --steps 8 $cfg 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[v$V $F] [$cfg] K2 %.3f ms frac %.3f  step %.3f ms' % (d['kernel_ms']['k_paf2maf_expand'], d['roofline']['frac'], d['ms_per_step']))"
+    WGA_EXPAND_VARIANT=$V python bench.py --no-cpu-baseline --no-extras --check 0 --steps 8 $cfg 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('[v$V $F] [$cfg] K2 %.3f ms frac %.3f  step %.3f ms' % (d['kernel_ms']['k_paf2maf_expand'], d['roofline']['frac'], d['ms_per_step']))"
   done; done
 done

@@ -7,7 +7,7 @@ WGA_EXTRA_FLAGS="$1" python -c "from wgatools_amd import build; build.build_hip(
 cd /tmp
 run() { # var name counters...
   var=$1; name=$2; shift; shift
-  WGA_EXPAND_VARIANT=$var timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/v${var}_$name -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --check 0 ${BENCH_ARGS} > /dev/null 2> $OUT/v${var}_$name.err; echo "v$var $name rc=$?"
+  WGA_EXPAND_VARIANT=$var timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/v${var}_$name -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --check 0 ${BENCH_ARGS} > /dev/null 2> $OUT/v${var}_$name.err; echo "v$var $name rc=$?"
 }
 for var in 0 1; do
   run $var sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS

@@ -7,8 +7,8 @@ export TMPDIR=/tmp
 for abl in 1 2 3 0; do
   F="${BASEFLAGS:--DWGA_K2P_BLOCKS=5}"; [ $abl != 0 ] && F="$F -DWGA_P_ABLATE=$abl"
   WGA_EXTRA_FLAGS="$F" python -c "from wgatools_amd import build; build.build_hip(force=True)" > /dev/null 2>&1
-  (cd /tmp; WGA_EXPAND_VARIANT=1 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/a$abl -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --check 0 > /dev/null 2> $OUT/a$abl.err)
-  WGA_EXPAND_VARIANT=1 python bench.py --no-cpu-baseline --check 0 --steps 8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ablate $abl: K2 %.3f ms' % d['kernel_ms']['k_paf2maf_expand'])"
+  (cd /tmp; WGA_EXPAND_VARIANT=1 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/a$abl -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --check 0 > /dev/null 2> $OUT/a$abl.err)
+  WGA_EXPAND_VARIANT=1 python bench.py --no-cpu-baseline --no-extras --check 0 --steps 8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ablate $abl: K2 %.3f ms' % d['kernel_ms']['k_paf2maf_expand'])"
   python - <<PY
 import csv, glob, os, collections
 for f in glob.glob(os.path.join("$OUT", "a$abl", "**", "*counter_collection.csv"), recursive=True):

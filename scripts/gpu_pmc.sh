@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --check 0"
+BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --check 0"
 run() { # name counters...
   name=$1; shift
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- $BENCH > $OUT/$name.json 2> $OUT/$name.err

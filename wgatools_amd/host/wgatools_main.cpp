@@ -89,70 +89,6 @@ struct GpuWarm {
 };
 static GpuWarm g_warm;
 
-struct Dev {
-  wga_ctx* ctx = nullptr;
-  std::vector<void*> owned;
-  void init() {
-    if (ctx) return;
-    g_timer.mark("host");
-    if (g_warm.started && !g_warm.taken) {
-      if (g_warm.th.joinable()) g_warm.th.join();
-      g_warm.taken = true;
-      if (g_warm.rc) fail("GPU engine: " + g_warm.err);
-      ctx = g_warm.ctx;
-      g_timer.mark("hip init (what was left of it)");
-      return;
-    }
-    int rc = wga_ctx_create(0, &ctx);
-    if (rc) fail(std::string("GPU engine: ") + wga_last_error());
-    void* warm = nullptr;
-    if (wga_malloc(ctx, 256, &warm) == 0) wga_free(ctx, warm);
-    g_timer.mark("hip init");
-  }
-  void check(int rc) {
-    if (rc) fail(std::string("GPU engine: ") + wga_last_error());
-  }
-  void* alloc(size_t bytes) {
-    void* p = nullptr;
-    check(wga_malloc(ctx, bytes ? bytes : 16, &p));
-    owned.push_back(p);
-    return p;
-  }
-  template <typename T>
-  T* upload(const T* h, size_t n) {
-    T* d = (T*)alloc(n * sizeof(T));
-    if (n) check(wga_memcpy_h2d(ctx, d, h, n * sizeof(T)));
-    return d;
-  }
-  template <typename T>
-  T* upload(const std::vector<T>& v) { return upload(v.data(), v.size()); }
-  template <typename T>
-  void download(T* h, const T* d, size_t n) { check(wga_memcpy_d2h(ctx, h, d, n * sizeof(T))); }
-  void release(void* p) {
-    auto it = std::find(owned.begin(), owned.end(), p);
-    if (it != owned.end()) owned.erase(it);
-    wga_free(ctx, p);
-  }
-  void release_all() {
-    check(wga_sync(ctx));
-    for (void* p : owned) wga_free(ctx, p);
-    owned.clear();
-  }
-  void release_to(size_t keep) { /* frees everything allocated after the first `keep` buffers */
-    check(wga_sync(ctx));
-    while (owned.size() > keep) {
-      wga_free(ctx, owned.back());
-      owned.pop_back();
-    }
-  }
-  ~Dev() {
-    if (ctx) {
-      for (void* p : owned) wga_free(ctx, p);
-      wga_ctx_destroy(ctx);
-    }
-  }
-};
-
 /* Streams n bytes of a device buffer into the output: pinned staging buffers, the copy of piece k + 1 runs while
  * piece k is written; into a plain file the pieces are written with pwrite by a few threads (one write() stream into
  * the page cache moves 2-4 GB/s, the copy engine > 40 GB/s), anything else (stdout, .gz) keeps the one ordered
@@ -160,26 +96,28 @@ struct Dev {
 struct DevStreamer {
   static const size_t kPiece = (size_t)16 << 20;
   static const int kBufs = 12;
-  Dev& d;
+  wga_ctx* ctx;
   void* buf[kBufs];
-  DevStreamer(Dev& dev) : d(dev) {
+  explicit DevStreamer(wga_ctx* c) : ctx(c) {
     for (int k = 0; k < kBufs; k++) buf[k] = nullptr;
   }
   ~DevStreamer() {
     for (int k = 0; k < kBufs; k++)
-      if (buf[k]) wga_host_free(d.ctx, buf[k]);
+      if (buf[k]) wga_host_free(ctx, buf[k]);
   }
   void run(Output& out, const uint8_t* d_src, size_t n) {
     if (n == 0) return;
-    for (int k = 0; k < kBufs; k++)
-      if (!buf[k]) d.check(wga_host_alloc(d.ctx, kPiece, &buf[k]));
+    const size_t np = (n + kPiece - 1) / kPiece;
+    const int nbuf = (int)std::min<size_t>((size_t)kBufs, np + 1); /* pinned memory is slow to get: only what this run uses */
+    for (int k = 0; k < nbuf; k++)
+      if (!buf[k] && wga_host_alloc(ctx, kPiece, &buf[k])) fail(std::string("GPU engine: ") + wga_last_error());
     uint64_t pos0 = 0;
     const int fd = out.plain_fd(&pos0);
-    const size_t np = (n + kPiece - 1) / kPiece;
     std::vector<std::thread> writers;
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<int> state(kBufs, 0); /* 0 free, 1 filled (piece index in `which`) */
+    std::vector<int> state(kBufs, 4); /* 0 free, 1 filled (piece index in `which`), 2 being written, 3 being filled, 4 not allocated */
+    for (int k = 0; k < nbuf; k++) state[k] = 0;
     std::vector<size_t> which(kBufs, 0);
     size_t next_write = 0; /* ordered writer: next piece to go out */
     bool failed = false, done_filling = false;
@@ -253,8 +191,7 @@ struct DevStreamer {
           }
       }
       const size_t off = p * kPiece, len = std::min(kPiece, n - off);
-      d.check(wga_memcpy_d2h_async(d.ctx, buf[b], d_src + off, len));
-      d.check(wga_sync(d.ctx));
+      if (wga_memcpy_d2h_async(ctx, buf[b], d_src + off, len) || wga_sync(ctx)) fail(std::string("GPU engine: ") + wga_last_error());
       {
         std::lock_guard<std::mutex> lk(mu);
         which[b] = p;
@@ -272,6 +209,76 @@ struct DevStreamer {
     if (fd >= 0) out.advance(n);
   }
 };
+
+struct Dev {
+  wga_ctx* ctx = nullptr;
+  std::vector<void*> owned;
+  std::unique_ptr<DevStreamer> streamer; /* pinned buffers, allocated once per process */
+  void init() {
+    if (ctx) return;
+    g_timer.mark("host");
+    if (g_warm.started && !g_warm.taken) {
+      if (g_warm.th.joinable()) g_warm.th.join();
+      g_warm.taken = true;
+      if (g_warm.rc) fail("GPU engine: " + g_warm.err);
+      ctx = g_warm.ctx;
+      g_timer.mark("hip init (what was left of it)");
+      return;
+    }
+    int rc = wga_ctx_create(0, &ctx);
+    if (rc) fail(std::string("GPU engine: ") + wga_last_error());
+    void* warm = nullptr;
+    if (wga_malloc(ctx, 256, &warm) == 0) wga_free(ctx, warm);
+    g_timer.mark("hip init");
+  }
+  void check(int rc) {
+    if (rc) fail(std::string("GPU engine: ") + wga_last_error());
+  }
+  void* alloc(size_t bytes) {
+    void* p = nullptr;
+    check(wga_malloc(ctx, bytes ? bytes : 16, &p));
+    owned.push_back(p);
+    return p;
+  }
+  template <typename T>
+  T* upload(const T* h, size_t n) {
+    T* d = (T*)alloc(n * sizeof(T));
+    if (n) check(wga_memcpy_h2d(ctx, d, h, n * sizeof(T)));
+    return d;
+  }
+  template <typename T>
+  T* upload(const std::vector<T>& v) { return upload(v.data(), v.size()); }
+  template <typename T>
+  void download(T* h, const T* d, size_t n) { check(wga_memcpy_d2h(ctx, h, d, n * sizeof(T))); }
+  void release(void* p) {
+    auto it = std::find(owned.begin(), owned.end(), p);
+    if (it != owned.end()) owned.erase(it);
+    wga_free(ctx, p);
+  }
+  void release_all() {
+    check(wga_sync(ctx));
+    for (void* p : owned) wga_free(ctx, p);
+    owned.clear();
+  }
+  void release_to(size_t keep) { /* frees everything allocated after the first `keep` buffers */
+    check(wga_sync(ctx));
+    while (owned.size() > keep) {
+      wga_free(ctx, owned.back());
+      owned.pop_back();
+    }
+  }
+  ~Dev() {
+    if (ctx) {
+      streamer.reset();
+      for (void* p : owned) wga_free(ctx, p);
+      wga_ctx_destroy(ctx);
+    }
+  }
+};
+static void stream_out(Dev& d, Output& out, const uint8_t* d_src, size_t n) {
+  if (!d.streamer) d.streamer.reset(new DevStreamer(d.ctx));
+  d.streamer->run(out, d_src, n);
+}
 
 /* An indexed FASTA whose sequence pool lives in HBM.  The file — plain, gzip or BGZF (inflated on
  * all host cores) — is uploaded as text, wga_fasta_pool strips the line ends on the device and returns the contig table;
@@ -629,7 +636,7 @@ uint32_t expand_batch(Dev& d, const wga_cigar_batch& cb, const ExpandJob& j, con
   }
   d.check(wga_sync(d.ctx));
   g_timer.mark("kernels + row tables");
-  DevStreamer(d).run(out, d_out, (size_t)rec_off[good]);
+  stream_out(d, out, d_out, (size_t)rec_off[good]);
   g_timer.mark("copy out + write");
   return good;
 }
@@ -1274,7 +1281,7 @@ int cmd_paf2chain(const std::string* input, Output& out) {
         d.check(wga_cigar_chain(d.ctx, &cb2, nullptr, nullptr, nullptr, d_out, d.upload(data_off)));
         d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off),
                                   d_out, d.upload(dst)));
-        DevStreamer(d).run(out, d_out, (size_t)pos);
+        stream_out(d, out, d_out, (size_t)pos);
       }
     }
     d.release_to(keep);
@@ -1466,7 +1473,7 @@ int cmd_chain2paf(const std::string* input, Output& out) {
     d.check(wga_chain_lines_cigar_text(d.ctx, n, b.n_lines, b.d_lines, b.d_line_off, nullptr, d_out, d.upload(text_off)));
     d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off), d_out,
                               d.upload(dst)));
-    DevStreamer(d).run(out, d_out, (size_t)pos);
+    stream_out(d, out, d_out, (size_t)pos);
     d.release_all();
     i0 = i;
   }
@@ -1589,7 +1596,7 @@ int cmd_maf2chain(const std::string* input, const std::string* query_name, Outpu
     d.check(wga_cigar_chain(d.ctx, &cb, nullptr, nullptr, nullptr, d_out, d.upload(data_off)));
     d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off), d_out,
                               d.upload(dst)));
-    DevStreamer(d).run(out, d_out, (size_t)pos);
+    stream_out(d, out, d_out, (size_t)pos);
   }
   chain_base += n_in_piece;
   d.release_all();
@@ -1865,7 +1872,6 @@ int cmd_pafcov(const std::string* input, Output& out) {
     uint8_t* d_txt = nullptr;
     uint64_t txt_cap = 0;
     std::string text;
-    DevStreamer streamer(d);
     for (uint32_t t = 0; t < nt; t++) {
       auto* d_name = d.upload((const uint8_t*)targets[t].data(), targets[t].size());
       for (uint64_t pos = 0; pos < cov_len[t]; pos += kChunk) {
@@ -1880,7 +1886,7 @@ int cmd_pafcov(const std::string* input, Output& out) {
           d_txt = (uint8_t*)d.alloc(txt_cap);
         }
         d.check(wga_pafcov_format(d.ctx, d_name, (uint32_t)targets[t].size(), cp, pos, cnt, d_loff, d_txt));
-        streamer.run(out, d_txt, (size_t)bytes); /* 4 M positions of BED text per piece, copied and written in overlap */
+        stream_out(d, out, d_txt, (size_t)bytes); /* 4 M positions of BED text per piece, copied and written in overlap */
       }
     }
     text.clear();
