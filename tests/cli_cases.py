@@ -572,6 +572,19 @@ def test_call_paf_end_to_end(cli, tmp_path, snp, svlen):
     assert out == _expected_paf_vcf(b, "S1", snp, svlen)
 
 
+def test_call_paf_over_host_threads(cli, tmp_path):
+    b = synth.make_paf_batch(93, 30, 200, 100000)
+    t_fa, q_fa, paf = _write_paf2maf_case(tmp_path, b, np.zeros(30, dtype=int))
+    want = _expected_paf_vcf(b, "S1", True, 2)
+    for thr in ("1", "4", "30"):
+        os.environ["WGA_HOST_THREADS"] = thr
+        try:
+            rc, out, err = run(cli, "call", "-f", "paf", paf, "--target", t_fa, "-q", q_fa, "-l", "2", "-n", "S1", "-s")
+        finally:
+            del os.environ["WGA_HOST_THREADS"]
+        assert rc == 0 and out == want, (thr, err)
+
+
 def test_call_paf_fold_errors_are_discarded(cli, tmp_path):
     """caller.rs:673,815-819: an invalid op / token ends that record's walk silently; a missing tag
     and an empty CIGAR still abort, and nothing is written (buffered driver)"""

@@ -2445,7 +2445,13 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
       d.check(wga_paf_call_events(d.ctx, &cb, svlen, snp, d_cnt, d_ev, d_eoff));
       std::vector<uint64_t> ev(3 * eoff[n]);
       if (eoff[n]) d.download(ev.data(), d_ev, 3 * eoff[n]);
-      for (uint32_t k = 0; k < n; k++) {
+      /* the VCF text of a record depends on that record alone: ranges of records go to host threads, their text is
+       * appended in record order; the driver is buffered, so an error in any record leaves nothing written (:294-299) */
+      unsigned nthr = std::thread::hardware_concurrency();
+      nthr = std::max(1u, std::min({nthr, 32u, n / 64u + 1u}));
+      if (const char* e = getenv("WGA_HOST_THREADS")) nthr = std::max(1u, std::min((unsigned)atoi(e), n)); /* tests */
+      std::vector<std::string> parts(nthr), errs(nthr);
+      auto one_record = [&](uint32_t k, std::string& body) {
         const PafRecord& r = recs[i0 + k];
         const char* ts = t_host.data() + t_off[k];
         const char* qs = q_host.data() + q_off[k];
@@ -2507,7 +2513,24 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
             }
           }
         }
+      };
+      auto work = [&](unsigned t) {
+        const uint32_t lo = (uint32_t)((uint64_t)n * t / nthr), hi = (uint32_t)((uint64_t)n * (t + 1) / nthr);
+        try {
+          for (uint32_t k = lo; k < hi; k++) one_record(k, parts[t]);
+        } catch (Error& e) {
+          errs[t] = e.msg.empty() ? std::string("error") : e.msg;
+        }
+      };
+      {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nthr; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
       }
+      for (unsigned t = 0; t < nthr; t++)
+        if (!errs[t].empty()) fail(errs[t]); /* the first failing record in input order */
+      for (unsigned t = 0; t < nthr; t++) body += parts[t];
     }
     d.release_to(keep);
     i0 = i;
