@@ -1328,7 +1328,9 @@ __global__ __launch_bounds__(256) void k_rec_desc(u32 n, const wga_cigar_counts*
   d.I_total = cn.ins_bp + cn.inv_ins_bp;
   d.D_total = cn.del_bp + cn.inv_del_bp;
   d.L = cn.match + cn.mismatch + d.I_total + d.D_total;
-  d.neg = strand_neg[r] != 0 ? 1 : 0;
+  /* bit 0 strand; bits 1 / 2: the target / query slice is longer than the CIGAR consumes (a tail to append) — lets the
+   * row kernels skip the two tail jobs of a record, which are empty in any consistent PAF, without reading a field */
+  d.neg = (strand_neg[r] != 0 ? 1u : 0u) | (d.t_src_len + d.I_total > d.L ? 2u : 0u) | (d.q_src_len + d.D_total > d.L ? 4u : 0u);
   out[r] = d;
 }
 
@@ -1686,7 +1688,7 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
       qs.fa_bytes = a.q_fa_bytes;
       qs.src_off = wave_get_u64(dsc, 22);
       qs.src_len = q_src_len;
-      qs.rc = wave_get_u32(dsc, 3) != 0u;
+      qs.rc = (wave_get_u32(dsc, 3) & 1u) != 0u;
       const u64 t_row_len = t_src_len + wave_get_u64(dsc, 26), q_row_len = q_src_len + wave_get_u64(dsc, 28);
       u8* const t_dst = a.out + wave_get_u64(dsc, 14);
       u8* const q_dst = a.out + wave_get_u64(dsc, 16);
@@ -1713,6 +1715,7 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
      * 0/1 = this segment of the target / query row (rows end where a short slice ends);
      * 2/3 = once the record ends in this tile, what the slices hold beyond the CIGAR. */
     const bool rec_ends = seg_end == re;
+    const u32 rec_flags = wave_get_u32(dsc, 3);
     WGA_STAMP(if (a.dbg && stamp[2] == 0) stamp[2] = WGA_CLOCK();)
 #pragma nounroll
     for (int job = 0; job < 4; job++) {
@@ -1722,6 +1725,7 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
 #ifdef WGA_PROFILE
       if (a.ablate & 8) continue;
 #endif
+      if (is_tail && (!rec_ends || !(rec_flags & (is_q ? 4u : 2u)))) continue; /* no tail: nothing read, nothing computed */
       /* this row's fields: the query ones sit 2 (offsets, gap totals) or 4 (slice) lanes after
        * the target ones.  Every wave works out the size of the job (that decides who owns its
        * pieces); everything else is only read by the owner. */
@@ -1736,7 +1740,7 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
       src.fa_bytes = is_q ? a.q_fa_bytes : a.t_fa_bytes;
       src.src_off = wave_get_u64(dsc, 18 + q4);
       src.src_len = src_len;
-      src.rc = is_q && wave_get_u32(dsc, 3) != 0u;
+      src.rc = is_q && (wave_get_u32(dsc, 3) & 1u) != 0u;
       src.ablate = a.ablate;
 #endif
       u64 x0, nbytes;
@@ -1776,7 +1780,7 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
         src.fa_bytes = is_q ? a.q_fa_bytes : a.t_fa_bytes;
         src.src_off = wave_get_u64(dsc, 18 + q4);
         src.src_len = src_len;
-        src.rc = is_q && wave_get_u32(dsc, 3) != 0u;
+        src.rc = is_q && (wave_get_u32(dsc, 3) & 1u) != 0u;
         src.ablate = a.ablate;
         u8* const dst = a.out + wave_get_u64(dsc, 14 + q2) + x0;
         const u64 sb0 = is_tail ? L - gap_total : (is_q ? qb : tb);

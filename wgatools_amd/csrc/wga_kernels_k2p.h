@@ -600,6 +600,7 @@ __device__ __forceinline__ void expand_tile_p(const ExpandArgsP& a, const u64 g,
         for (int job = 0; job < 4; job++) {
           const bool is_q = (job & 1) != 0, is_tail = job >= 2;
           if (is_tail && !rec_ends) break;
+          if (is_tail && !(neg & (is_q ? 4u : 2u))) continue; /* wga_rec_desc::neg bits 1 / 2: no tail */
           const int q2 = is_q ? 2 : 0, q4 = is_q ? 4 : 0;
           const u64 gap_total = wave_get_u64(dsc, 26 + q2); /* I bases (target row) / D bases (query row) */
           const u64 src_len = is_q ? q_src_len : t_src_len;
@@ -617,7 +618,7 @@ __device__ __forceinline__ void expand_tile_p(const ExpandArgsP& a, const u64 g,
           const u64 src_off = wave_get_u64(dsc, 18 + q4);
           const u64 fa_bytes = is_q ? a.q_fa_bytes : a.t_fa_bytes;
           const u8* const fa = is_q ? a.q_fa : a.t_fa;
-          const bool rc = is_q && neg != 0u;
+          const bool rc = is_q && (neg & 1u) != 0u;
           const bool safe = src_off >= 16 && src_off + src_len + 16 <= fa_bytes; /* rowsrc_prepare */
           const u64 dst0 = (u64)(a.out) + wave_get_u64(dsc, 14 + q2) + x0;      /* address of the job's first byte */
           const u32 flags = (is_q ? 1u : 0u) | (rc ? 2u : 0u) | (safe ? 4u : 0u) | (is_tail ? 8u : 0u);
