@@ -1575,7 +1575,6 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
   u64 cur = tile_start;
   u64 re = wave_get_u64(pre, 12);
   u32 bnd_col = 0u, bnd_ev = 0u, nseg = 0u; /* prefix at the start of the current segment */
-  u32 njob = 0u;                           /* short-row jobs seen so far (same count in every wave) */
   while (cur < tile_end) {
     while (re <= cur) {
       r++;
@@ -1726,9 +1725,17 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
       if (a.ablate & 8) continue;
 #endif
       if (is_tail && (!rec_ends || !(rec_flags & (is_q ? 4u : 2u)))) continue; /* no tail: nothing read, nothing computed */
+      /* Ownership is static: piece p of this job goes to wave (job + 2 p + segment index) mod 4 — the two halves of
+       * the two rows of a segment land on four different waves, and the rotation with the segment spreads the
+       * single-piece rows of short records.  A wave that owns neither piece reads nothing of the job (rows beyond
+       * WGA_SOLO_BYTES are the whole block's: only possible when the segment is that wide). */
+#ifndef WGA_OWN_STRIDE
+#define WGA_OWN_STRIDE 2u /* piece 1 of a job goes to the wave this many behind piece 0's */
+#endif
+      const u32 own0 = ((u32)job * (WGA_OWN_STRIDE == 2u ? 1u : 2u) + nseg) & 3u, own1 = (own0 + WGA_OWN_STRIDE) & 3u;
+      if (!is_tail && seg_cols <= WGA_SOLO_BYTES && own0 != wave && own1 != wave) continue;
       /* this row's fields: the query ones sit 2 (offsets, gap totals) or 4 (slice) lanes after
-       * the target ones.  Every wave works out the size of the job (that decides who owns its
-       * pieces); everything else is only read by the owner. */
+       * the target ones. */
       const int q2 = is_q ? 2 : 0, q4 = is_q ? 4 : 0;
       const u64 gap_total = wave_get_u64(dsc, 26 + q2); /* I bases (target row) / D bases (query row) */
       const u64 L = wave_get_u64(dsc, 30);
@@ -1773,7 +1780,7 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
       for (int piece = 0; piece < 2; piece++) {
         const u64 lo = piece == 0 ? 0 : cut, hi = piece == 0 ? cut : nbytes;
         if (lo >= hi) continue;
-        if (!coop && (njob++ & 3u) != wave) continue;
+        if (!coop && (piece == 0 ? own0 : own1) != wave) continue;
 #if WGA_OWNER_SETUP
         RowSrc src;
         src.fa = is_q ? a.q_fa : a.t_fa;
