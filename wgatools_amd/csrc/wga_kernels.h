@@ -1570,6 +1570,9 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
 #ifdef WGA_PROFILE
   if (a.ablate & 1) return;
 #endif
+#if defined(WGA_V1_ABLATE) && WGA_V1_ABLATE == 1 /* counts of phase A in an otherwise unchanged product build */
+  return;
+#endif
   /* ---- phase B: walk the record segments of this tile ------------------------------------- */
   u32 r = r0;
   u64 cur = tile_start;
