@@ -9,3 +9,6 @@ for rep in 1 2; do
   echo "call -s:";  time WGA_TIMING=1 wgatools_amd/bin/wgatools call -s -l 50 /tmp/wga_e2e/in.maf -o /tmp/wga_e2e/o.vcf -r
   echo "stat maf:"; time WGA_TIMING=1 wgatools_amd/bin/wgatools stat /tmp/wga_e2e/in.maf -o /tmp/wga_e2e/o.tsv -r
 done
+echo "paf2chain:"; time WGA_TIMING=1 wgatools_amd/bin/wgatools paf2chain /tmp/wga_e2e/in.paf -o /tmp/wga_e2e/o.chain -r
+echo "pafcov:"; time WGA_TIMING=1 wgatools_amd/bin/wgatools pafcov /tmp/wga_e2e/in.paf -o /tmp/wga_e2e/o.bed -r
+echo "stat paf:"; time WGA_TIMING=1 wgatools_amd/bin/wgatools stat -f paf /tmp/wga_e2e/in.paf -o /tmp/wga_e2e/o.tsv -r

@@ -277,7 +277,10 @@ struct Dev {
 };
 static void stream_out(Dev& d, Output& out, const uint8_t* d_src, size_t n) {
   if (!d.streamer) d.streamer.reset(new DevStreamer(d.ctx));
+  d.check(wga_sync(d.ctx));
+  g_timer.mark("kernels + host tables");
   d.streamer->run(out, d_src, n);
+  g_timer.mark("copy out + write");
 }
 
 /* An indexed FASTA whose sequence pool lives in HBM.  The file — plain, gzip or BGZF (inflated on
@@ -374,10 +377,12 @@ PafInput paf_from_text(Dev& d, std::string&& text, bool want_tags, uint64_t rec0
   in.text = std::move(text);
   const char* force = getenv("WGA_PAF_READER"); /* "host": always the csv-semantics reader (measurements) */
   if (!want_tags && !in.text.empty() && in.text.size() < 0xFFFFFFF0ull && !(force && strcmp(force, "host") == 0)) {
+    g_timer.mark("file read");
     d.init();
     in.text.append(16, '\0'); /* slack behind the text for whole-vector loads */
     in.d_text = d.upload((const uint8_t*)in.text.data(), in.text.size());
     in.text.resize(in.text.size() - 16);
+    g_timer.mark("upload");
     uint64_t n_lines = 0;
     d.check(wga_paf_split(d.ctx, in.d_text, in.text.size(), &n_lines, nullptr, 0));
     auto* d_lines = (wga_paf_line*)d.alloc((size_t)(n_lines + 1) * sizeof(wga_paf_line));
@@ -415,6 +420,7 @@ PafInput paf_from_text(Dev& d, std::string&& text, bool want_tags, uint64_t rec0
         in.cg_beg.push_back(L.cg_beg);
         in.cg_end.push_back(L.cg_end);
       }
+      g_timer.mark("device split + host records");
       return in;
     }
     d.release(in.d_text);
@@ -634,10 +640,7 @@ uint32_t expand_batch(Dev& d, const wga_cigar_batch& cb, const ExpandJob& j, con
     *first_bad = g;
     break;
   }
-  d.check(wga_sync(d.ctx));
-  g_timer.mark("kernels + row tables");
   stream_out(d, out, d_out, (size_t)rec_off[good]);
-  g_timer.mark("copy out + write");
   return good;
 }
 
