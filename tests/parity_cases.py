@@ -896,6 +896,60 @@ def check_cigar_chain(eng, ops, op_off):
 
 
 
+def chain_stress_records(seed, n=40, max_ops=2600):
+    """records that exercise the step structure of K10 (512-op steps, 8 ops per lane, 64 lines per round): several
+    steps, steps without a raise, a raise on every other op, leading / trailing indel runs longer than a step, ten-digit
+    values, open sums that pass 2^32 (the serial path), continuation pieces"""
+    rng = np.random.default_rng(seed)
+    L = (1 << 28) - 1
+    mk = lambda p: [(int(ln) << 4) | int(c) for c, ln in p]
+    recs = []
+    recs.append(mk([(7, 1), (1, 1)] * 1300 + [(7, 3)]))                       # a raise on every other op, 6 steps
+    recs.append(mk([(7, 2), (8, 1)] * 700 + [(1, 5), (7, 9)]))                # three steps without a raise, then one
+    recs.append(mk([(1, 3)] * 600 + [(2, 1)] * 30 + [(7, 4), (2, 2), (7, 1)]))  # the first M-like op in step 2
+    recs.append(mk([(7, 5)] + [(2, 7)] * 1100))                               # a tail longer than two steps
+    recs.append(mk([(7, 5)] + [(1, 2), (9, 3)] * 40 + [(2, 9)] * 70))         # tail I behind 64+ D ops
+    recs.append(mk([(7, L), (8, L)] * 5 + [(1, L), (7, 1)]))                  # ten digits
+    recs.append(mk([(7, L)] * 20 + [(1, 1), (7, L)]))                         # 2^32 passed inside one block: serial
+    recs.append(mk([(7, 4)] * 511 + [(1, 1)] + [(7, 2)] * 3))                 # the raise is op 0 of a step
+    recs.append(mk([(7, 4)] * 510 + [(1, 1), (2, 1), (7, 2), (1, 1)]))        # group across the step's end, I at the end
+    recs.append(mk([(2, 1)] * 512 + [(7, 1)]))                                # dropped line is the 2nd step's first
+    recs.append(mk([(7, 1), (2, 1)] * 256))                                   # exactly one step, ends in D
+    recs.append(mk([(7, 1), (2, 1)] * 256 + [(7, 1)]))
+    # zero-length ops and ops outside M = X I D inside later steps: those steps run the reference's loop as it stands
+    recs.append(mk([(7, 3), (1, 2)] * 400 + [(7, 0), (2, 3), (7, 4), (1, 0), (7, 2), (2, 0), (1, 1), (7, 0), (7, 5)] + [(7, 1), (2, 2)] * 300))
+    recs.append(mk([(1, 0)] * 3 + [(7, 0), (2, 2), (7, 3)] + [(8, 1), (1, 1)] * 600))          # 0I 0= lead the record
+    recs.append(mk([(2, 4)] * 520 + [(7, 0), (1, 2), (7, 3), (2, 1), (7, 1)]))                  # the first M-like op is 0=
+    recs.append(mk([(7, 2), (1, 1)] * 700 + [(3, 5)] + [(7, 2), (1, 1)] * 100))                 # N in the third step
+    recs.append(mk([(7, 2), (1, 1)] * 300 + [(2, 0), (4, 1), (7, 1)]))                          # S behind a 0D, last step
+    recs.append(mk([(7, 2), (2, 0)] * 600 + [(1, 3)]))                                          # every indel is empty
+    for _ in range(n):
+        k = int(rng.integers(1, max_ops))
+        style = int(rng.integers(0, 4))
+        if style == 0:      # mostly M-like, few indels
+            codes = rng.choice([7, 8, 0, 1, 2], size=k, p=[0.55, 0.3, 0.05, 0.05, 0.05])
+        elif style == 1:    # indel heavy
+            codes = rng.choice([7, 8, 1, 2, 9, 10], size=k, p=[0.3, 0.1, 0.25, 0.25, 0.05, 0.05])
+        elif style == 2:    # long runs of one kind
+            codes = np.repeat(rng.choice([7, 1, 2, 8], size=k // 50 + 1), 50)[:k]
+        else:
+            codes = rng.choice([7, 1, 2], size=k)
+        lens = rng.integers(1, 5000, size=k)
+        big = rng.random(k) < 0.01
+        lens = np.where(big, rng.integers(1, L, size=k), lens)
+        pairs = []
+        for c, ln in zip(codes.tolist(), lens.tolist()):
+            if c in (9, 10):            # a continuation piece follows an op of its own kind (the packer's invariant)
+                c -= 8
+                pairs.append((c, ln))
+                c += 8
+            pairs.append((c, ln))
+        recs.append(mk(pairs))
+    ops = np.array([o for r in recs for o in r], dtype=np.uint32)
+    off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+    return ops, off
+
+
 # ------------------------------------------------------------------------------------------------
 # a second, linear-time expectation for long records (the C oracle's insert_str is quadratic)
 # ------------------------------------------------------------------------------------------------

@@ -321,6 +321,12 @@ def test_cigar_chain(emu):
     pc.check_cigar_chain(emu, ops, off)
 
 
+def test_cigar_chain_steps(emu):
+    for seed in (1, 2):
+        ops, off = pc.chain_stress_records(seed)
+        pc.check_cigar_chain(emu, ops, off)
+
+
 def test_runs_bridge_synthetic(emu):
     L = (1 << 28) - 1
     recs = [[(5, 0), (3, 1), (2, 3), (4, 2)], [], [(L, 0), (L + 1, 1), (2 * L + 7, 2), (1, 3), (3 * L, 3)],

@@ -308,6 +308,13 @@ def test_cigar_chain(gpu):
     pc.check_cigar_chain(gpu, ops, off)
 
 
+@pytest.mark.gpu
+def test_cigar_chain_steps(gpu):
+    for seed in (1, 2):
+        ops, off = pc.chain_stress_records(seed)
+        pc.check_cigar_chain(gpu, ops, off)
+
+
 # ---- the other BASELINE configs at (or near) their stated sizes: properties checked on the device ------------
 def _synthetic_maf_rows(dev, n, L, seed):
     """config 3 shaped rows: n blocks x L columns, 1.2 % SNP, 0.15 % indel-open with geometric lengths; the rows of
