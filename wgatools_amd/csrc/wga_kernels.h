@@ -1834,8 +1834,25 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
 
 /* v1 of the row kernel (granules stored as they are produced: lines reach the L2 in pieces).  It stays as the A/B
  * reference (`expand_variant` 0: one block per tile of the batch) and — as k_paf2maf_expand_list — for the tiles the
- * staged kernel of wga_kernels_k2s.h leaves out: beyond 2^31 columns, the op-serial u64 walk. */
-__global__ __launch_bounds__(256, WGA_K2_BLOCKS) void k_paf2maf_expand(ExpandArgs a) { expand_tile_v1(a, blockIdx.x); }
+ * planned kernel of wga_kernels_k2p.h leaves out: beyond 2^31 columns, the op-serial u64 walk. */
+/* Blocks go to the 8 XCDs round robin (block b runs on XCD b % 8), each with its own L2.  Every XCD gets one contiguous
+ * eighth of the tiles, in order: the ~190 tiles an XCD has in flight are then neighbours — the output lines two tiles
+ * share and the source windows of one record's tiles meet in one L2.  Measured (profiles/r02_k2_experiments.md):
+ * 6.75 -> 6.65 ms with 2 x 50 Mb pools, 7.69 -> 6.9-7.3 ms with 2 x 1 Gb pools.  -DWGA_K2_XCD=0: tile = block. */
+#ifndef WGA_K2_XCD
+#define WGA_K2_XCD 1
+#endif
+__device__ __forceinline__ u64 xcd_tile_of_block() {
+#if WGA_K2_XCD
+  const u32 nt = gridDim.x, b = blockIdx.x, x = b & 7u, q = nt >> 3, r = nt & 7u;
+  return (u64)(x * q + (x < r ? x : r) + (b >> 3));
+#else
+  return blockIdx.x;
+#endif
+}
+__global__ __launch_bounds__(256, WGA_K2_BLOCKS) void k_paf2maf_expand(ExpandArgs a) {
+  expand_tile_v1(a, xcd_tile_of_block());
+}
 
 __global__ __launch_bounds__(256, 4) void k_paf2maf_expand_list(ExpandArgs a) {
   const u32 n_list = *a.tile_count;

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
   const u32 tid = threadIdx.x;
   build_lowmask(s_lowmask);
   const u32 lane = tid & 63u, wave = WGA_WAVE_ID(tid);
-  const u64 g = blockIdx.x;
+  const u64 g = xcd_tile_of_block();
   const u64 tile_start = g * WGA_TILE;
   const u64 tile_end = tile_start + WGA_TILE < a.n_ops ? tile_start + WGA_TILE : a.n_ops;
   const u32 nt = (u32)(tile_end - tile_start);

@@ -762,7 +762,7 @@ __device__ __forceinline__ void expand_tile_p(const ExpandArgsP& a, const u64 g,
 __global__ __launch_bounds__(256, WGA_K2P_BLOCKS) void k_paf2maf_expand_p(ExpandArgsP a) {
   WGA_K2P_SHARED(u16)
   const u32 lane = threadIdx.x & 63u;
-  const u64 g = blockIdx.x;
+  const u64 g = xcd_tile_of_block();
   u32 pre = 0u;
   if (lane < 32u) pre = ((const u32*)(a.tdesc + g))[lane];
   const u64 tile_cols = wave_get_u64(pre, 0);
