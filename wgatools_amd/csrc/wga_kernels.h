@@ -549,8 +549,13 @@ __global__ __launch_bounds__(256) void k_layout_rows(ScanLayout f, u32 n, const 
   u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   u64 t = rec_off[i] + (f.pre_t ? f.pre_t[i] : 0u);
+  u64 q = t + f.t_row(i) + (f.pre_q ? f.pre_q[i] : 0u);
+#ifdef WGA_HACK_ALIGN /* measurements only (wrong output): what would rows that start on a 16 / 128-byte boundary buy? */
+  t &= ~(u64)(WGA_HACK_ALIGN - 1);
+  q &= ~(u64)(WGA_HACK_ALIGN - 1);
+#endif
   t_row_off[i] = t;
-  q_row_off[i] = t + f.t_row(i) + (f.pre_q ? f.pre_q[i] : 0u);
+  q_row_off[i] = q;
 }
 
 /* ============================================================================================ */
