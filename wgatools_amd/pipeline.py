@@ -12,7 +12,8 @@ from . import engine
 class Paf2MafStatJob:
     """stat (K1) -> row layout (scan) -> gap insertion (K2) over one resident batch."""
 
-    def __init__(self, eng, tb, with_text=False):
+    def __init__(self, eng, tb, with_text=False, out=None):
+        """out: a caller-owned output buffer (uint8, at least the rows' bytes + 64), e.g. one reserved at process start"""
         import torch
         self.torch = torch
         self.eng = eng
@@ -35,7 +36,9 @@ class Paf2MafStatJob:
             self.pre = tuple(torch.full((n,), v, dtype=torch.int32, device=dev) for v in (48, 40, 2))
             rows += n * 90
         self.out_bytes = rows
-        self.out = torch.empty(rows + 64, dtype=torch.uint8, device=dev)
+        if out is not None and out.numel() < rows + 64:
+            raise ValueError("output buffer too small: %d < %d" % (out.numel(), rows + 64))
+        self.out = out[: rows + 64] if out is not None else torch.empty(rows + 64, dtype=torch.uint8, device=dev)
 
     def bind_stream(self):
         self.eng.set_stream(self.torch.cuda.current_stream().cuda_stream)
