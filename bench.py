@@ -370,6 +370,10 @@ def main():
             "input_GBps": in_bytes * world * args.steps / elapsed / 1e9,
             "kernel_ms": {"k_cigar_stat": k_stat, "layout_scan": k_layout, "k_paf2maf_expand": k_expand,
                           "expand_prepass (k_rec_desc + k_tile_base)": k_expand_call - k_expand},
+            "expand_drain_min": {"used": eng.get_param("expand_drain_min"),
+                                 "autotune_settled": eng.get_param("expand_autotune_settled"),
+                                 "note": "when a wave emits its queued gap-touching chunks; tried 64 / 32 / 16 on the warm-up "
+                                         "launches, same bytes (include/wga_hip.h, wga_ctx_set_param)"},
             "roofline": {
                 "kernel": "k_paf2maf_expand", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args, job),

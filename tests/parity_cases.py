@@ -89,6 +89,31 @@ def run_paf2maf(eng, b, pre=None, force_slow=0, fill=0x23, no_table=0, variant=N
                 rec_off=reco.numpy(), counts=counts.numpy(), diag=diag.numpy(), total=total)
 
 
+def check_drain_min_settings(eng, b):
+    """RowSrc::drain_min only decides WHEN a wave emits its queued gap-touching chunks: every setting, and the
+    library's own choice, must give the bytes the oracle gives"""
+    ref = None
+    for dm in (0, 1, 16, 32, 64):
+        eng.set_param("expand_drain_min", dm)
+        try:
+            check_paf2maf(eng, b)
+            r = run_paf2maf(eng, b)
+        finally:
+            eng.set_param("expand_drain_min", 0)
+        assert eng.get_param("expand_drain_min") == (dm if dm else eng.get_param("expand_drain_min"))
+        if ref is None:
+            ref = r["out"].copy()
+        assert (r["out"] == ref).all(), dm
+    for bad in (-1, 65):
+        try:
+            eng.set_param("expand_drain_min", bad)
+        except Exception:
+            pass
+        else:
+            raise AssertionError("expand_drain_min %d accepted" % bad)
+    assert eng.get_param("expand_variant") == DEFAULT_EXPAND_VARIANT
+
+
 def oracle_rows(b, i):
     """what converter.rs:219-235 does for one record, through the oracle"""
     t = b["t_pool"][int(b["t_src_off"][i]):int(b["t_src_off"][i] + b["t_src_len"][i])].tobytes()

@@ -305,6 +305,10 @@ def test_device_tokeniser_random_bytes(emu):
     run()
 
 
+def test_paf2maf_drain_min_settings(emu):
+    pc.check_drain_min_settings(emu, synth.make_paf_batch(21, 6, 900, 200_000))
+
+
 def test_cigar_chain(emu):
     b = synth.make_paf_batch(57, 12, 300, 400000)
     pc.check_cigar_chain(emu, b["ops"], b["op_off"])

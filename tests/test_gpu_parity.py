@@ -136,6 +136,40 @@ def test_paf2maf_maf2paf_roundtrip(gpu):
     assert pc.check_paf2maf_maf2paf_roundtrip(gpu, 9, 1200, 4000) > 4_500_000
 
 
+def test_paf2maf_drain_min_settings(gpu):
+    pc.check_drain_min_settings(gpu, synth.make_paf_batch(21, 200, 900, 2_000_000))
+
+
+def test_paf2maf_drain_autotune_same_bytes(gpu):
+    """launches of >= 8192 tiles on one output buffer: a warming launch, three trials (drain_min 64 / 32 / 16 on live
+    work), then the fastest stays; the rows are the same bytes in every launch"""
+    import torch
+    dev = torch.device("cuda", 0)
+    tb = synth.make_paf_batch_torch(77, 3000, 4000, 20_000_000, dev)
+    assert tb["n_ops"] >= 8192 * 1024
+    from wgatools_amd import pipeline
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    gpu.set_param("expand_autotune", 1)
+    job = pipeline.Paf2MafStatJob(gpu, tb)
+    job.stat(); job.layout()
+    sums, used = [], []
+    for k in range(7):
+        job.out.fill_(0x23)
+        job.expand()
+        torch.cuda.synchronize()
+        used.append(gpu.get_param("expand_drain_min"))
+        sums.append((int(job.out[:job.out_bytes].to(torch.int64).sum()), int((job.out[:job.out_bytes:4097].to(torch.int64) * 31).sum())))
+    assert used[1:4] == [64, 32, 16] and used[4] in (64, 32, 16) and used[5] == used[4] == used[6], used
+    assert gpu.get_param("expand_autotune_settled") == 1
+    assert len(set(sums)) == 1, sums
+    assert bool((job.diag == -1).all())
+    gpu.set_param("expand_autotune", 0)
+    job.expand(); torch.cuda.synchronize()
+    assert gpu.get_param("expand_drain_min") == 32          # 2 x 20 MB pools, no trials
+    gpu.set_param("expand_autotune", 1)
+    gpu.reset_stream()
+
+
 def test_paf2maf_planned_kernel(gpu):
     pc.planned_kernel_cases(gpu)
     pc.check_paf2maf(gpu, synth.make_paf_batch(6, 500, 400, 2_000_000), variant=1)

@@ -38,6 +38,7 @@ PROTOTYPES = {
     "wga_ctx_set_stream": (C.c_int, [vp, vp]),
     "wga_ctx_reset_stream": (C.c_int, [vp]),
     "wga_ctx_set_param": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+    "wga_ctx_get_param": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "wga_ctx_expand_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "wga_sync": (C.c_int, [vp]),
     "wga_malloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),

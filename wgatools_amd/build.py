@@ -61,6 +61,25 @@ def build_hip(force=False, verbose=False):
     return HIP_LIB
 
 
+def build_hip_variant(name, extra_flags):
+    """build_variants/libwgahip_<name>.so: the library with extra compiler flags, next to the product build (A/B
+    measurements in ONE process on the same buffers: scripts/gpu_k2_same_buffers.py).  Never loaded by the product."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    vdir = os.path.join(ROOT, "build_variants")
+    os.makedirs(vdir, exist_ok=True)
+    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall"] + STAGE2 + list(extra_flags)
+    objs = []
+    for src, xflag in (("wga_capi.cpp", ["-x", "hip"]), ("wga_pack.cpp", [])):
+        obj = os.path.join(vdir, "%s_%s" % (name, src.replace(".cpp", ".o")))
+        _run([hipcc] + flags + xflag + ["-c", os.path.join(CSRC, src), "-o", obj])
+        objs.append(obj)
+    lib = os.path.join(vdir, "libwgahip_%s.so" % name)
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-o", lib] + objs + ["-Wl,-rpath,/opt/rocm/lib"])
+    for o in objs:
+        os.remove(o)
+    return lib
+
+
 def build_emu(force=False):
     srcs = _sources() + [os.path.join(ROOT, "tests", "emu", "simt_emu.h")]
     if not force and not _newer(EMU_LIB, srcs):

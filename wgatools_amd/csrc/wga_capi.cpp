@@ -22,6 +22,21 @@ struct wga_ctx {
   int expand_force_slow = 0;
   int expand_no_table = 0;
   int expand_ablate = 0;
+  unsigned expand_drain_min = 0; /* 0 = by the size of the pools, refined by trial (below) */
+  bool expand_autotune = true;
+  /* The cost of emitting gap-touching chunks late (lines wait half written in the L2) depends on where the output buffer
+   * lies in HBM: on one and the same buffer drain_min 64 / 32 / 16 measure 6.46 / 6.67 / 6.92 ms, on the next one 7.19 /
+   * 6.87 / 6.92 (profiles/r02_k2_experiments.md, section 8).  The bytes written do not depend on it, so the first
+   * launches on an output buffer try the candidates on live work and the fastest per tile stays. */
+  struct DrainTune {
+    const void* out = nullptr;
+    int phase = 0; /* 0: the next launch warms the buffer; 1..3: trials; 4: read the last trial; 5: settled */
+    bool pending = false, have_ev = false;
+    unsigned cur = 0, best = 0, last = 0;
+    double best_ms = 0.0;
+    uint64_t tiles = 0;
+    rt_event_t ev[2];
+  } tune;
   uint64_t maf_long_cols = 32768;  /* MAF blocks beyond this many columns are walked piece by piece ... */
   uint64_t maf_piece_cols = 16384; /* ... of this many columns, one wave each (test knobs: "maf_long_cols", "maf_piece_cols") */
   int expand_variant = 0; /* 0: v1 (fastest measured, profiles/r02_k2_experiments.md); 1: the planned, line-complete kernel of wga_kernels_k2p.h */
@@ -298,6 +313,11 @@ int wga_ctx_create(int device, wga_ctx** out) {
   c->stream = c->own_stream;
   /* A/B switch for measurements: WGA_EXPAND_VARIANT=0 selects v1 of the paf2maf row kernel (wga_ctx_set_param overrides) */
   if (const char* v = getenv("WGA_EXPAND_VARIANT")) c->expand_variant = atoi(v) != 0;
+  if (const char* v = getenv("WGA_EXPAND_AUTOTUNE")) c->expand_autotune = atoi(v) != 0;
+  if (const char* v = getenv("WGA_EXPAND_DRAIN_MIN")) {
+    const int d = atoi(v);
+    if (d >= 0 && d <= 64) c->expand_drain_min = (unsigned)d;
+  }
   *out = c;
   return WGA_OK;
 }
@@ -308,6 +328,7 @@ void wga_ctx_destroy(wga_ctx* c) {
   (void)rt_sync(c->stream);
   if (c->timing)
     for (int k = 0; k < 2 * wga_ctx::kTimingRing; k++) rt_event_destroy(c->ev[k]);
+  if (c->tune.have_ev) rt_event_destroy(c->tune.ev[0]), rt_event_destroy(c->tune.ev[1]);
   if (c->scratch) (void)rt_free(c->scratch);
   if (c->cov_pieces) (void)rt_free(c->cov_pieces);
   rt_stream_destroy(c->own_stream);
@@ -340,6 +361,16 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
   }
   if (strcmp(name, "expand_dbg_ptr") == 0) {
     c->expand_dbg = (void*)(uintptr_t)value;
+    return WGA_OK;
+  }
+  if (strcmp(name, "expand_drain_min") == 0) { /* 0 = chosen by the size of the sequence pools (WGA_DRAIN_POOL_BYTES) */
+    if (value < 0 || value > 64) return fail(WGA_E_INVALID_ARG, "expand_drain_min: 0 .. 64", nullptr);
+    c->expand_drain_min = (unsigned)value;
+    return WGA_OK;
+  }
+  if (strcmp(name, "expand_autotune") == 0) {
+    c->expand_autotune = value != 0;
+    c->tune.out = nullptr;
     return WGA_OK;
   }
   if (strcmp(name, "expand_ablate") == 0) {
@@ -563,6 +594,7 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
   a.force_slow = c->expand_force_slow;
   a.no_table = c->expand_no_table;
   a.ablate = c->expand_ablate;
+  a.drain_min = 0; /* below */
   a.dbg = (u64*)c->expand_dbg;
   a.tile_count = nullptr;
   a.tile_list = nullptr;
@@ -574,11 +606,60 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
                wide_counts, wide_list);
     LAUNCH_CHECK();
   }
+  /* when the gap-touching chunks are emitted (RowSrc::drain_min) */
+  bool tune_timed = false;
+  {
+    const unsigned dflt = (u64)t_fa_bytes + (u64)q_fa_bytes > WGA_DRAIN_POOL_BYTES ? 16u : 32u;
+    unsigned dm = dflt;
+    wga_ctx::DrainTune& T = c->tune;
+    if (c->expand_drain_min) {
+      dm = c->expand_drain_min;
+    } else if (c->expand_autotune && !staged && !c->expand_dbg && (u64)nt >= WGA_TUNE_MIN_TILES) {
+      if (!T.have_ev) {
+        const char* e = rt_event_create(&T.ev[0]);
+        if (!e && (e = rt_event_create(&T.ev[1]))) rt_event_destroy(T.ev[0]);
+        if (e) return fail(WGA_E_HIP, "rt_event_create", e);
+        T.have_ev = true;
+      }
+      if (T.out != (const void*)d_out) {
+        T.out = (const void*)d_out;
+        T.phase = 0;
+        T.pending = false;
+      }
+      if (T.pending) { /* the trial launched by the previous call */
+        float ms = 0.0f;
+        RT_CHECK(rt_event_elapsed_ms(T.ev[0], T.ev[1], &ms));
+        const double per_tile = (double)ms / (double)T.tiles;
+        if (T.best == 0u || per_tile < T.best_ms) T.best_ms = per_tile, T.best = T.cur;
+        T.pending = false;
+      }
+      static const unsigned cand[3] = {64u, 32u, 16u};
+      if (T.phase == 0) { /* first touch of the buffer: not timed */
+        T.best = 0u;
+        T.phase = 1;
+      } else if (T.phase <= 3) {
+        dm = T.cur = cand[T.phase - 1];
+        T.tiles = (uint64_t)nt;
+        T.phase++;
+        tune_timed = true;
+      } else {
+        dm = T.best ? T.best : dflt;
+        T.phase = 5;
+      }
+    }
+    T.last = dm;
+    a.drain_min = dm;
+  }
   const uint32_t slot = c->ev_n % (uint32_t)wga_ctx::kTimingRing;
   if (c->timing) RT_CHECK(rt_event_record(c->ev[2 * slot], c->stream));
   if (!staged) {
+    if (tune_timed) RT_CHECK(rt_event_record(c->tune.ev[0], c->stream));
     WGA_LAUNCH(k_paf2maf_expand, (u32)nt, WGA_BLOCK, c->stream, a);
     LAUNCH_CHECK();
+    if (tune_timed) {
+      RT_CHECK(rt_event_record(c->tune.ev[1], c->stream));
+      c->tune.pending = true;
+    }
   } else {
     ExpandArgsP s;
     s.ops = a.ops;
@@ -611,6 +692,23 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
     c->ev_n++;
   }
   return WGA_OK;
+}
+
+int wga_ctx_get_param(wga_ctx* c, const char* name, int64_t* value) {
+  if (!c || !name || !value) return fail(WGA_E_INVALID_ARG, "null argument", nullptr);
+  if (strcmp(name, "expand_drain_min") == 0) { /* what the last wga_paf2maf_expand used */
+    *value = (int64_t)c->tune.last;
+    return WGA_OK;
+  }
+  if (strcmp(name, "expand_autotune_settled") == 0) {
+    *value = c->tune.phase == 5 ? 1 : 0;
+    return WGA_OK;
+  }
+  if (strcmp(name, "expand_variant") == 0) {
+    *value = (int64_t)c->expand_variant;
+    return WGA_OK;
+  }
+  return fail(WGA_E_INVALID_ARG, "unknown parameter", name);
 }
 
 int wga_ctx_expand_timing(wga_ctx* c, double* ms_sum, uint32_t* launches) {

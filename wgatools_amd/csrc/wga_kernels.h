@@ -561,6 +561,19 @@ __global__ __launch_bounds__(256) void k_layout_rows(ScanLayout f, u32 n, const 
 /* ============================================================================================ */
 /* K2: paf2maf gap insertion                                                                    */
 /* ============================================================================================ */
+#ifndef WGA_DRAIN_MIN
+#define WGA_DRAIN_MIN 32u /* queued complex chunks that trigger a drain before the row ends: the rows of K2 take the value from
+                             the host (ExpandArgs::drain_min), everything else this one.  64 fills the drain's lanes (fewest
+                             instructions) but lets the lines its chunks belong to wait half written in the L2; 16 completes them
+                             at once.  Same buffers, one process (scripts/gpu_k2_same_buffers.py): with 2 x 50 MB pools 64 / 32 /
+                             16 = 6.19 / 6.44 / 6.66 ms, with 2 x 1 GB pools (the L2 churns with source lines) 8.65 / 8.07 / 7.85 */
+#endif
+#ifndef WGA_TUNE_MIN_TILES
+#define WGA_TUNE_MIN_TILES 8192ull /* launches below this (8 M ops) are too short to compare drain_min settings on */
+#endif
+#ifndef WGA_DRAIN_POOL_BYTES
+#define WGA_DRAIN_POOL_BYTES (192ull << 20) /* sequence pools beyond this (together) do not stay in the 256 MB Infinity Cache */
+#endif
 struct RowSrc {
   const u8* fa;  /* sequence pool */
   u64 fa_bytes;  /* pool size (window loads are bounds-checked against it) */
@@ -569,6 +582,7 @@ struct RowSrc {
   bool rc;       /* read reversed + complemented (utils.rs:83-101) */
   bool safe;     /* every 20-byte window of this row lies inside the pool (rowsrc_prepare) */
   int ablate;    /* profiling knob (see ExpandArgs) */
+  u32 drain_min = WGA_DRAIN_MIN; /* queued complex chunks that trigger a drain before the row ends (see WGA_DRAIN_MIN) */
   const u8* win_base; /* address of slice index sbase (rc: of the mirrored window start) */
 };
 
@@ -885,11 +899,6 @@ __device__ __forceinline__ u32 wave_get_u32(u32 v, int k) {
 #endif
 #ifndef WGA_SOLO_BYTES
 #define WGA_SOLO_BYTES 65536u /* rows up to this many bytes are emitted wave by wave, longer ones by the block */
-#endif
-#ifndef WGA_DRAIN_MIN
-#define WGA_DRAIN_MIN 32u /* queued complex chunks that trigger a drain before the row ends.  64 fills the drain's lanes but lets
-                             the lines its chunks belong to leave the L2 half written: with pools beyond the Infinity Cache 32 is
-                             6-8 % faster (8.1 -> 7.6 ms), with configs[1]'s 50 MB pools the same; 16 / 8 / 1 lose on the latter */
 #endif
 #ifndef WGA_SPLIT_BYTES
 #define WGA_SPLIT_BYTES 8192u /* ... in two halves beyond this */
@@ -1210,7 +1219,7 @@ __device__ __forceinline__ void emit_row_t(u8* dst, u32 N, u32 c0, const RowDesc
     WGA_WAVE_SYNC();
     /* drain the queue 64 chunks at a time, and whatever is left when the row ends */
     const bool last = it + 1 >= niter;
-    while (qn >= WGA_DRAIN_MIN || (last && qn > 0u)) {
+    while (qn >= src.drain_min || (last && qn > 0u)) {
       const u32 take = qn < 64u ? qn : 64u;
       qn -= take;
       if (lane < take) {
@@ -1431,6 +1440,7 @@ struct ExpandArgs {
   int force_slow;
   int no_table; /* test knob: 256-column granules (the coarse-table path of very wide tiles) */
   int ablate;   /* profiling knob: 1 = stop after phase A, 2 = no source loads, 4 = no stores */
+  u32 drain_min; /* RowSrc::drain_min of the rows */
   u64* dbg;     /* profiling: 8 s_memtime stamps per tile (NULL: off) */
   const u32* tile_count; /* k_paf2maf_expand_list: the blocks loop over tile_list[0 .. *tile_count) */
   const u32* tile_list;
@@ -1757,6 +1767,7 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
       src.src_len = src_len;
       src.rc = is_q && (wave_get_u32(dsc, 3) & 1u) != 0u;
       src.ablate = a.ablate;
+      src.drain_min = a.drain_min;
 #endif
       u64 x0, nbytes;
       if (!is_tail) {
@@ -1797,6 +1808,7 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
         src.src_len = src_len;
         src.rc = is_q && (wave_get_u32(dsc, 3) & 1u) != 0u;
         src.ablate = a.ablate;
+        src.drain_min = a.drain_min;
         u8* const dst = a.out + wave_get_u64(dsc, 14 + q2) + x0;
         const u64 sb0 = is_tail ? L - gap_total : (is_q ? qb : tb);
 #endif

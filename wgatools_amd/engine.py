@@ -142,6 +142,11 @@ class Engine:
     def set_param(self, name, value):
         self._check(self.lib.wga_ctx_set_param(self.ctx, name.encode(), int(value)))
 
+    def get_param(self, name):
+        v = C.c_int64(0)
+        self._check(self.lib.wga_ctx_get_param(self.ctx, name.encode(), C.byref(v)))
+        return v.value
+
     def expand_timing(self):
         """(summed ms, launches) of the expand kernel proper since the last call ("expand_timing" param)"""
         ms, n = C.c_double(0.0), C.c_uint32(0)
