@@ -6,6 +6,8 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
+# the library would spend these three launches on its drain_min trials (64 / 32 / 16): fix the value it settles on for this shape
+export WGA_EXPAND_DRAIN_MIN=${WGA_EXPAND_DRAIN_MIN:-64}
 BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --check 0"
 run() { # name counters...
   name=$1; shift
