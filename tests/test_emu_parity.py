@@ -309,6 +309,39 @@ def test_paf2maf_drain_min_settings(emu):
     pc.check_drain_min_settings(emu, synth.make_paf_batch(21, 6, 900, 200_000))
 
 
+def test_paf2maf_drain_trials_state_machine(emu):
+    """the emulator build starts the trials at 2 tiles: on one output buffer the launches use the default, then 64 / 32 / 16,
+    then the winner (the emulator's events read 0 ms, so the first candidate stays); a new buffer starts over; every
+    launch writes the same bytes"""
+    b = synth.make_paf_batch(33, 5, 1500, 300_000)
+    n = len(b["strand_neg"])
+    batch = emu.make_batch(b["ops"], b["op_off"], b["strand_neg"])
+    counts, diag, tws = emu.cigar_stat(batch)
+    tl, ql = emu.upload(b["t_src_len"]), emu.upload(b["q_src_len"])
+    to, qo = emu.upload(b["t_src_off"]), emu.upload(b["q_src_off"])
+    tro, qro, reco = emu.paf2maf_layout(n, counts, tl, ql)
+    total = int(reco.numpy()[-1])
+    tp, qp = emu.upload(b["t_pool"]), emu.upload(b["q_pool"])
+    assert emu.get_param("expand_variant") == pc.DEFAULT_EXPAND_VARIANT
+    ref = None
+    for buf in range(2):
+        out = emu.empty(total + 64, np.uint8)
+        used = []
+        for k in range(6):
+            out.fill(0x23)
+            emu.paf2maf_expand(batch, counts, tws, tp, len(b["t_pool"]), to, tl, qp, len(b["q_pool"]), qo, ql, out, tro, qro, diag)
+            used.append(emu.get_param("expand_drain_min"))
+            got = out.numpy().copy()
+            ref = got if ref is None else ref
+            assert (got == ref).all(), (buf, k)
+        assert used == [32, 64, 32, 16, 64, 64], used
+        assert emu.get_param("expand_autotune_settled") == 1
+    emu.set_param("expand_autotune", 0)
+    emu.paf2maf_expand(batch, counts, tws, tp, len(b["t_pool"]), to, tl, qp, len(b["q_pool"]), qo, ql, out, tro, qro, diag)
+    assert emu.get_param("expand_drain_min") == 32 and emu.get_param("expand_autotune_settled") == 0
+    emu.set_param("expand_autotune", 1)
+
+
 def test_cigar_chain(emu):
     b = synth.make_paf_batch(57, 12, 300, 400000)
     pc.check_cigar_chain(emu, b["ops"], b["op_off"])

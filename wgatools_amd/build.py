@@ -85,7 +85,8 @@ def build_emu(force=False):
     if not force and not _newer(EMU_LIB, srcs):
         return EMU_LIB
     # -DWGA_MAF_FOLD_STEPS: fold the MAF walks' 16-bit lane counters every 3 steps, so that small test rows reach that path
-    _run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DWGA_EMU", "-DWGA_MAF_FOLD_STEPS=3u", "-Wall",
+    # -DWGA_TUNE_MIN_TILES: the drain_min trials of wga_paf2maf_expand start at 2 tiles, so that test batches run them
+    _run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DWGA_EMU", "-DWGA_MAF_FOLD_STEPS=3u", "-DWGA_TUNE_MIN_TILES=2ull", "-Wall",
           "-Wno-unknown-pragmas", "-I" + os.path.join(ROOT, "tests", "emu")] + STAGE2
          + [os.path.join(CSRC, "wga_capi.cpp"), os.path.join(CSRC, "wga_pack.cpp"), "-o", EMU_LIB])
     return EMU_LIB

@@ -370,7 +370,9 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
   }
   if (strcmp(name, "expand_autotune") == 0) {
     c->expand_autotune = value != 0;
-    c->tune.out = nullptr;
+    c->tune.out = nullptr; /* what was learnt is forgotten */
+    c->tune.phase = 0;
+    c->tune.pending = false;
     return WGA_OK;
   }
   if (strcmp(name, "expand_ablate") == 0) {
