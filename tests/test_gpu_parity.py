@@ -257,6 +257,17 @@ def test_pafpseudo(gpu, base, seed, n, mean):
     pc.check_pafpseudo(gpu, b, base, skip=skip)
 
 
+def test_pafpseudo_symbol_runs(gpu):
+    """symbol mode, per-granule walk over the ops that cover it: long X / D runs, rows that start inside a granule, dense
+    single-column ops, one op of 1.2 M columns, trimmed heads up to 8191 columns"""
+    cigars = ["100=50X9000D3=1X40D8000=33X7=", "5=1200000D5=", "1=1X" * 600 + "4=", "70D", "70X", "3=2I4=1X5=",
+              "20=" + "35X2=" * 300, "9000=1D9000=1X100="]
+    strands = [0, 1, 0, 0, 1, 0, 0, 1]
+    b = pc.batch_from_texts(gpu, cigars, strands, [b"A"] * 8, [b"A"] * 8)
+    pc.check_pafpseudo(gpu, b, 0)
+    pc.check_pafpseudo(gpu, b, 0, skip=[0, 3, 17, 0, 5, 2, 33, 8191])
+
+
 def test_pafpseudo_length_mismatch(gpu):
     cigars = ["5=2I3=", "5=2I3=", "4=3D4=", "10=", "8=2I", "8=1D", "3=2S1="]
     strands = [0, 1, 1, 0, 0, 1, 0]
