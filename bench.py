@@ -240,6 +240,9 @@ def main():
     ap.add_argument("--targets", type=int, default=64, help="strong scaling: number of target names")
     ap.add_argument("--zipf", type=float, default=1.2, help="strong scaling: skew of the records over the targets "
                                                             "(P(target k) ~ 1 / (k + 1)^zipf; 0 = uniform)")
+    ap.add_argument("--no-placement-probe", action="store_true", help="take the first output buffer the allocator returns instead "
+                    "of the fastest of --placement-candidates (see pipeline.pick_output_buffer)")
+    ap.add_argument("--placement-candidates", type=int, default=8)
     ap.add_argument("--north-star", action="store_true", help="the 10 M x 50 kop headline shape as a stream of resident batches (N = 1)")
     ap.add_argument("--ns-records", type=int, default=400_000)
     ap.add_argument("--ns-batch-records", type=int, default=40_000)
@@ -286,7 +289,16 @@ def main():
     else:
         tb = synth.make_paf_batch_torch(seed, args.records, args.mean_ops, args.pool_mb * 1_000_000, dev,
                                         neg_frac=args.neg_frac, use_m=args.m_only)
-    job = pipeline.Paf2MafStatJob(eng, tb)
+    placement = None
+    out_buf = None
+    if not args.no_placement_probe:
+        # where the output arena lies in HBM sets the row kernel's level: try several buffers, keep the
+        # fastest, as a long-lived caller would do once per process; every candidate's time goes into the line
+        out_buf, cand_ms = pipeline.pick_output_buffer(eng, tb, candidates=args.placement_candidates)
+        placement = {"policy": "fastest of %d candidate output buffers, each timed on 3 untimed launches of the real step before "
+                               "the warm-up (pipeline.pick_output_buffer); --no-placement-probe takes the first allocation" % len(cand_ms),
+                     "k2_ms_by_candidate": [round(x, 3) for x in cand_ms]}
+    job = pipeline.Paf2MafStatJob(eng, tb, out=out_buf)
     job.bind_stream()
     totals = torch.zeros(11, dtype=torch.int64, device=dev)
 
@@ -382,6 +394,7 @@ def main():
             "input_GBps": in_bytes * world * args.steps / elapsed / 1e9,
             "kernel_ms": {"k_cigar_stat": k_stat, "layout_scan": k_layout, "k_paf2maf_expand": k_expand,
                           "expand_prepass (k_rec_desc + k_tile_base)": k_expand_call - k_expand},
+            "output_placement": placement,
             "expand_drain_min": {"used": eng.get_param("expand_drain_min"),
                                  "autotune_settled": eng.get_param("expand_autotune_settled"),
                                  "note": "when a wave emits its queued gap-touching chunks; tried 64 / 32 / 16 on the warm-up "

@@ -81,3 +81,41 @@ class Paf2MafStatJob:
         to, qo = int(self.t_row_off[i]), int(self.q_row_off[i])
         return (self.out[to:to + tl].cpu().numpy().tobytes(),
                 self.out[qo:qo + ql].cpu().numpy().tobytes())
+
+
+def pick_output_buffer(eng, tb, candidates=8, launches=3):
+    """Placement policy for the hot output arena (profiles/r02_k2_experiments.md, sections 7 and 10): the row kernel's time is
+    a function of the REGION of HBM its output buffer lies in (6.65 / 6.8 / 7.2 ms on the same batch, reproducibly), and
+    nothing in the allocation API says which region a buffer got.  So a long-lived caller tries several: `candidates` buffers
+    of the needed size are allocated, each gets one warming launch and `launches` measured ones of the real step on the real
+    batch (library HIP events), the fastest is kept and the others are returned to the allocator.  Returns
+    (buffer, [K2 ms per candidate]).  The bytes written do not depend on the choice."""
+    import torch
+    need = int((tb["t_src_len"] + tb["i"]).sum() + (tb["q_src_len"] + tb["d"]).sum()) + 64
+    bufs = []
+    for _ in range(candidates):
+        try:
+            bufs.append(torch.empty(need, dtype=torch.uint8, device=tb["ops"].device))
+        except RuntimeError:            # out of memory: fewer candidates
+            break
+    if not bufs:
+        raise RuntimeError("no memory for the output buffer (%d bytes)" % need)
+    eng.set_param("expand_timing", 1)
+    ms = []
+    for b in bufs:
+        job = Paf2MafStatJob(eng, tb, out=b)
+        job.bind_stream()
+        job.step()
+        torch.cuda.synchronize()
+        eng.expand_timing()
+        for _ in range(launches):
+            job.expand()
+        torch.cuda.synchronize()
+        t, n = eng.expand_timing()
+        ms.append(t / max(1, n))
+        del job
+    best = min(range(len(bufs)), key=lambda k: ms[k])
+    out = bufs[best]
+    del bufs, b
+    torch.cuda.empty_cache()
+    return out, ms
