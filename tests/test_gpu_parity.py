@@ -170,6 +170,30 @@ def test_paf2maf_drain_autotune_same_bytes(gpu):
     gpu.reset_stream()
 
 
+def test_output_buffer_placement_probe(gpu):
+    """pipeline.pick_output_buffer: every candidate is timed on the real step, one comes back, and the rows written into it
+    are the rows of any other buffer"""
+    import torch
+    from wgatools_amd import pipeline
+    dev = torch.device("cuda", 0)
+    tb = synth.make_paf_batch_torch(78, 600, 3000, 5_000_000, dev)
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    buf, ms = pipeline.pick_output_buffer(gpu, tb, candidates=3, launches=2)
+    assert len(ms) == 3 and all(m > 0 for m in ms)
+    a = pipeline.Paf2MafStatJob(gpu, tb, out=buf)
+    b = pipeline.Paf2MafStatJob(gpu, tb)
+    for j in (a, b):
+        j.out.fill_(0x23)
+        j.step()
+    torch.cuda.synchronize()
+    assert a.out.data_ptr() == buf.data_ptr() and a.out_bytes == b.out_bytes
+    assert bool((a.out[:a.out_bytes] == b.out[:b.out_bytes]).all()) and bool((a.diag == -1).all())
+    small = torch.empty(16, dtype=torch.uint8, device=dev)
+    with pytest.raises(ValueError):
+        pipeline.Paf2MafStatJob(gpu, tb, out=small)
+    gpu.reset_stream()
+
+
 def test_paf2maf_planned_kernel(gpu):
     pc.planned_kernel_cases(gpu)
     pc.check_paf2maf(gpu, synth.make_paf_batch(6, 500, 400, 2_000_000), variant=1)
