@@ -250,6 +250,23 @@ struct Dev {
   T* upload(const std::vector<T>& v) { return upload(v.data(), v.size()); }
   template <typename T>
   void download(T* h, const T* d, size_t n) { check(wga_memcpy_d2h(ctx, h, d, n * sizeof(T))); }
+  /* The rows of paf2maf go into ONE device buffer for the whole run (it grows when a piece needs more): the row kernel's
+   * time depends on where its output lies in HBM and the library learns on the first launches that write to a buffer when
+   * to emit its queued chunks (include/wga_hip.h, "expand_drain_min") — a buffer per piece would start over every time. */
+  void* out_arena = nullptr;
+  size_t out_arena_cap = 0;
+  void* out_buffer(size_t bytes) {
+    if (bytes > out_arena_cap) {
+      if (out_arena) {
+        check(wga_sync(ctx));
+        wga_free(ctx, out_arena);
+        out_arena = nullptr;
+      }
+      out_arena_cap = bytes + bytes / 4;
+      check(wga_malloc(ctx, out_arena_cap, &out_arena));
+    }
+    return out_arena;
+  }
   void release(void* p) {
     auto it = std::find(owned.begin(), owned.end(), p);
     if (it != owned.end()) owned.erase(it);
@@ -270,6 +287,7 @@ struct Dev {
   ~Dev() {
     if (ctx) {
       streamer.reset();
+      if (out_arena) wga_free(ctx, out_arena);
       for (void* p : owned) wga_free(ctx, p);
       wga_ctx_destroy(ctx);
     }
@@ -617,7 +635,7 @@ uint32_t expand_batch(Dev& d, const wga_cigar_batch& cb, const ExpandJob& j, con
   d.download(qro.data(), d_qro, n);
   std::vector<wga_cigar_counts> counts(n);
   d.download(counts.data(), d_counts, n);
-  auto* d_out = (uint8_t*)d.alloc(rec_off[n] + 64);
+  auto* d_out = (uint8_t*)d.out_buffer(rec_off[n] + 64);
   d.check(wga_paf2maf_expand(d.ctx, &cb, d_counts, d_tiles, d_tpool, t_bytes, d_to, d_tl, d_qpool, q_bytes, d_qo, d_ql,
                              d_out, d_tro, d_qro, d_diag));
   /* the MAF line text around the rows: three snippets per record */
