@@ -92,7 +92,7 @@ def check_paf2maf(tmp_path, lib, cli, worlds, port):
     assert r.returncode == 0 and open(ref, "rb").read() == want, r.stderr[-500:]
     for w in worlds:
         outp = str(tmp_path / ("out%d.maf" % w))
-        launch(w, lib, port + w, "paf2maf", paf, "-g", t_fa, "-q", q_fa, "-o", outp)
+        launch(w, lib, port + w, "paf2maf", paf, "-g", t_fa, "-q", q_fa, "-o", outp, "--chunk-bytes", "20000")   # several resident batches per rank
         assert open(outp, "rb").read() == want, w
 
 
@@ -109,7 +109,7 @@ def check_paf2maf_error(tmp_path, lib, worlds, port):
     want = expected_maf(b, mapq, t_fa, q_fa, first)
     for w in worlds:
         outp = str(tmp_path / ("err%d.maf" % w))
-        r = launch(w, lib, port + w, "paf2maf", paf, "-g", t_fa, "-q", q_fa, "-o", outp, expect_rc=1)
+        r = launch(w, lib, port + w, "paf2maf", paf, "-g", t_fa, "-q", q_fa, "-o", outp, "--chunk-bytes", "9000", expect_rc=1)
         assert "Invalid Base: `R`" in r.stderr, r.stderr[-1500:]
         got = open(outp, "rb").read()
         assert got[:len(want)] == want and not got[len(want):].strip(b"\x00"), (w, first, len(got), len(want))
@@ -124,7 +124,7 @@ def check_pafcov(tmp_path, lib, cli, worlds, port):
     for w in worlds:
         for spread in (False, True):
             outp = str(tmp_path / ("cov%d%d.bed" % (w, spread)))
-            launch(w, lib, port + 10 + 2 * w + spread, "pafcov", paf, "-o", outp, *(["--spread"] if spread else []))
+            launch(w, lib, port + 10 + 2 * w + spread, "pafcov", paf, "-o", outp, "--chunk-bytes", "15000", *(["--spread"] if spread else []))
             assert open(outp, "rb").read() == want, (w, spread)
 
 
@@ -135,7 +135,7 @@ def check_totals(tmp_path, lib, worlds, port):
     for i in range(29):
         exp += np.array(orc.parse_paf_to_cigar(pc.rec_text(b, i), b["strand_neg"][i]), dtype=np.int64)
     for w in worlds:
-        r = launch(w, lib, port + 20 + w, "totals", paf)
+        r = launch(w, lib, port + 20 + w, "totals", paf, "--chunk-bytes", "12000")
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
         assert [d[k] for k in engine.COUNTS_DTYPE.names] == exp.tolist() and d["records"] == 29 and d["ranks"] == w, d

@@ -22,7 +22,8 @@ are those of `wgatools paf2maf` / `wgatools pafcov` on one GPU:
   * totals   — all-reduce of the 11 counters (88 bytes).
 
 Scope: a reference driver over the C-ABI, not a second command line — clean `cg:Z:` PAF (no csv quoting, no `cs` tags),
-plain or gzip FASTA read by every rank, one resident batch per rank and pass.  Errors of the hot path (invalid op, invalid
+plain or gzip FASTA read by every rank; a rank works through its records in resident batches of `--chunk-bytes` of CIGAR text
+(paf2maf: sizes first, rows second).  Errors of the hot path (invalid op, invalid
 base, the insert_str panic) end the run on every rank with the reference's message for the first failing record in input
 order; the output keeps the records in front of it, as the reference's reader loop does.
 `--lib PATH` binds another build of the library (the CPU tests pass the SIMT-emulator build and run over gloo); without it
@@ -171,6 +172,12 @@ class Ranks:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
         return int(t.item())
 
+    def all_sum(self, value):
+        t = self.torch.tensor([int(value)], dtype=self.torch.int64, device=self.dev)
+        if self.dist is not None:
+            self.dist.all_reduce(t)
+        return int(t.item())
+
     def close(self):
         self.eng.close()
         if self.dist is not None:
@@ -193,109 +200,142 @@ def pack_records(eng, recs, idx):
     return eng.make_batch(ops, np.array(off, dtype=np.uint64), strand)
 
 
+class RecordError(HotPathError):
+    def __init__(self, index, msg):
+        HotPathError.__init__(self, msg)
+        self.index = int(index)
+
+
+def chunks_of(recs, idx, max_text):
+    """idx cut into runs whose CIGAR text stays below max_text bytes (one resident batch each)"""
+    out, cur, size = [], [], 0
+    for i in idx:
+        ln = len(recs[int(i)]["cigar"])
+        if cur and size + ln > max_text:
+            out.append(cur)
+            cur, size = [], 0
+        cur.append(int(i))
+        size += ln
+    if cur:
+        out.append(cur)
+    return out
+
+
+def maf_piece(eng, recs, idx, tf, qf, d_tp, d_qp, want_rows):
+    """One resident batch of paf2maf: the records idx (input order).  Returns (sizes, rec_off, rows or None, err) where
+    err = None or RecordError of the first failing record of the piece — the arrays then cover the records in front of it
+    (converter.rs:209-235: slices are fetched, then the query is reverse-complemented, then the CIGAR is walked)."""
+    err = None
+    t_off, t_len, q_off, q_len, pre_t, pre_q, blob, blob_off, kept, packed = [], [], [], [], [], [], [], [0], [], []
+    for i in idx:
+        r = recs[i]
+        try:
+            to, tl = tf.fetch(r["tname"], r["tstart"], r["tend"] - 1)
+            qo, ql = qf.fetch(r["qname"], r["qstart"], r["qend"] - 1)
+            o, e, (eo, el) = eng.pack_cigar(r["cigar"])
+            if e:
+                tok = r["cigar"][eo:eo + el].decode("latin-1")
+                raise HotPathError(("Parse `%s` Into Integer Error" % tok) if e == 3 else ("CIGAR OP `%s` invalid" % tok))
+        except HotPathError as ex:
+            err = RecordError(i, str(ex))
+            break
+        kept.append(i)
+        packed.append(o)
+        t_off.append(to); t_len.append(tl); q_off.append(qo); q_len.append(ql)
+        a = "a score=%d\ns\t%s\t%d\t%d\t+\t%d\t" % (r["mapq"], r["tname"], r["tstart"], r["tend"] - r["tstart"], r["tlen"])
+        q = "\ns\t%s\t%d\t%d\t%s\t%d\t" % (r["qname"], r["qlen"] - r["qend"] if r["neg"] else r["qstart"],
+                                            r["qend"] - r["qstart"], "-" if r["neg"] else "+", r["qlen"])
+        for t in (a.encode(), q.encode(), b"\n\n"):
+            blob.append(t)
+            blob_off.append(blob_off[-1] + len(t))
+        pre_t.append(len(a)); pre_q.append(len(q))
+    m = len(kept)
+    if m == 0:
+        return np.zeros(0, np.int64), np.zeros(1, np.uint64), None, err
+    op_off = np.zeros(m + 1, dtype=np.uint64)
+    np.cumsum([len(o) for o in packed], out=op_off[1:])
+    batch = eng.make_batch(np.concatenate(packed), op_off, np.array([1 if recs[i]["neg"] else 0 for i in kept], dtype=np.uint8))
+    up = lambda v, dt: eng.upload(np.asarray(v, dtype=dt))
+    counts, diag, tws = eng.cigar_stat(batch, want_tiles=want_rows)
+    d_tl, d_ql = up(t_len, np.uint64), up(q_len, np.uint64)
+    tro, qro, reco = eng.paf2maf_layout(m, counts, d_tl, d_ql, up(pre_t, np.uint32), up(pre_q, np.uint32), up([2] * m, np.uint32))
+    rec_off = reco.numpy()
+    sizes = (rec_off[1:] - rec_off[:-1]).astype(np.int64)
+    if not want_rows:
+        return sizes, rec_off, None, err
+    out = eng.empty(int(rec_off[-1]) + 64, np.uint8)
+    eng.paf2maf_expand(batch, counts, tws, d_tp, len(tf.pool), up(t_off, np.uint64), d_tl, d_qp, len(qf.pool),
+                       up(q_off, np.uint64), d_ql, out, tro, qro, diag)
+    c, tr = counts.numpy(), tro.numpy()
+    dst = np.empty(3 * m, dtype=np.uint64)
+    dst[0::3] = rec_off[:-1]
+    dst[1::3] = tr + np.asarray(t_len, dtype=np.uint64) + c["ins_bp"] + c["inv_ins_bp"]
+    dst[2::3] = rec_off[1:] - 2
+    eng.scatter_bytes(3 * m, eng.upload(np.frombuffer(b"".join(blob), dtype=np.uint8)), up(blob_off, np.uint64), out, up(dst, np.uint64))
+    dg = diag.numpy()
+    for k in range(m):
+        g = dg[k]
+        if int(g["bad_base_pos"]) == NONE and int(g["bad_op_idx"]) == NONE and int(g["panic_op_idx"]) == NONE:
+            continue
+        if int(g["bad_base_pos"]) != NONE:          # utils.rs:97: reverse_complement runs before the CIGAR is walked
+            msg = "Invalid Base: `%s`" % chr(int(qf.pool[q_off[k] + q_len[k] - 1 - int(g["bad_base_pos"])]))
+        elif int(g["bad_op_idx"]) < int(g["panic_op_idx"]):
+            msg = "CIGAR OP `%s` invalid" % cigar_op_token_at(recs[kept[k]]["cigar"], int(g["bad_op_idx"]))
+        else:
+            msg = "panic: String::insert_str beyond the end of the fetched sequence (cigar.rs:507,513)"
+        return sizes[:k], rec_off[:k + 1], out.numpy(), RecordError(kept[k], msg)
+    return sizes, rec_off, out.numpy(), err
+
+
 def run_paf2maf(R, args):
     eng = R.eng
     recs = parse_paf(read_text(args.input))
     tf, qf = Fasta(args.target), Fasta(args.query)
     n = len(recs)
     owner = multigpu.owners([r["tname"] for r in recs], R.world)
-    mine = multigpu.my_records(owner, R.rank)
+    mine = [int(i) for i in multigpu.my_records(owner, R.rank)]
     header = ("#maf version=1.6 convert_from=paf t_seq_path=%s q_seq_path=%s\n" % (args.target, args.query)).encode()
-    # slices and line text of my records (converter.rs:209-225, maf.rs:566-581)
-    t_off, t_len, q_off, q_len, pre_t, pre_q, blob, blob_off = [], [], [], [], [], [], [], [0]
-    first_err = (n, None)                              # (global record index, message): fetch errors come first
-    kept = []
-    for i in mine:
-        r = recs[i]
-        try:
-            to, tl = tf.fetch(r["tname"], r["tstart"], r["tend"] - 1)
-            qo, ql = qf.fetch(r["qname"], r["qstart"], r["qend"] - 1)
-        except HotPathError as e:
-            first_err = (int(i), str(e))
+    d_tp, d_qp = eng.upload(tf.pool), eng.upload(qf.pool)
+    first_err = None
+    # pass 1: the size of every record's text (K1 + the layout scan; no row byte yet), one resident batch at a time
+    sizes = {}
+    for piece in chunks_of(recs, mine, args.chunk_bytes):
+        sz, _, _, err = maf_piece(eng, recs, piece, tf, qf, d_tp, d_qp, want_rows=False)
+        for i, v in zip(piece, sz):
+            sizes[i] = int(v)
+        if err is not None:
+            first_err = err
             break
-        kept.append(int(i))
-        t_off.append(to); t_len.append(tl); q_off.append(qo); q_len.append(ql)
-        a = "a score=%d\ns\t%s\t%d\t%d\t+\t%d\t" % (r["mapq"], r["tname"], r["tstart"], r["tend"] - r["tstart"], r["tlen"])
-        q = "\ns\t%s\t%d\t%d\t%s\t%d\t" % (r["qname"], r["qlen"] - r["qend"] if r["neg"] else r["qstart"],
-                                            r["qend"] - r["qstart"], "-" if r["neg"] else "+", r["qlen"])
-        for s in (a.encode(), q.encode(), b"\n\n"):
-            blob.append(s)
-            blob_off.append(blob_off[-1] + len(s))
-        pre_t.append(len(a)); pre_q.append(len(q))
-    mine = np.array(kept, dtype=np.int64)
-    m = len(mine)
-    sizes = np.zeros(m, dtype=np.int64)
-    out_host = np.zeros(0, dtype=np.uint8)
-    rec_off = np.zeros(m + 1, dtype=np.uint64)
-    if m:
-        try:
-            batch = pack_records(eng, recs, mine)
-        except HotPathError as e:                      # cannot say which record without packing one by one: do that
-            for k, i in enumerate(mine):
-                try:
-                    pack_records(eng, recs, [i])
-                except HotPathError as e1:
-                    first_err = min(first_err, (int(i), str(e1)))
-                    mine, m = mine[:k], k
-                    break
-            for lst in (t_off, t_len, q_off, q_len, pre_t, pre_q):
-                del lst[m:]
-            del blob[3 * m:], blob_off[3 * m + 1:]
-            batch = pack_records(eng, recs, mine) if m else None
-            sizes = np.zeros(m, dtype=np.int64)
-            rec_off = np.zeros(m + 1, dtype=np.uint64)
-    if m:
-        up = lambda v, dt: eng.upload(np.asarray(v, dtype=dt))
-        counts, diag, tws = eng.cigar_stat(batch)
-        d_tl, d_ql = up(t_len, np.uint64), up(q_len, np.uint64)
-        tro, qro, reco = eng.paf2maf_layout(m, counts, d_tl, d_ql, up(pre_t, np.uint32), up(pre_q, np.uint32),
-                                            up([2] * m, np.uint32))
-        rec_off = reco.numpy()
-        sizes = (rec_off[1:] - rec_off[:-1]).astype(np.int64)
-        out = eng.empty(int(rec_off[-1]) + 64, np.uint8)
-        d_tp, d_qp = eng.upload(tf.pool), eng.upload(qf.pool)
-        eng.paf2maf_expand(batch, counts, tws, d_tp, len(tf.pool), up(t_off, np.uint64), d_tl, d_qp, len(qf.pool),
-                           up(q_off, np.uint64), d_ql, out, tro, qro, diag)
-        c, tr = counts.numpy(), tro.numpy()
-        dst = np.empty(3 * m, dtype=np.uint64)
-        dst[0::3] = rec_off[:-1]
-        dst[1::3] = tr + np.asarray(t_len, dtype=np.uint64) + c["ins_bp"] + c["inv_ins_bp"]
-        dst[2::3] = rec_off[1:] - 2
-        eng.scatter_bytes(3 * m, eng.upload(np.frombuffer(b"".join(blob), dtype=np.uint8)), up(blob_off, np.uint64), out, up(dst, np.uint64))
-        dg = diag.numpy()
-        for k in range(m):
-            g = dg[k]
-            if int(g["bad_base_pos"]) == NONE and int(g["bad_op_idx"]) == NONE and int(g["panic_op_idx"]) == NONE:
-                continue
-            if int(g["bad_base_pos"]) != NONE:          # utils.rs:97: reverse_complement runs before the CIGAR is walked
-                c0 = qf.pool[q_off[k] + q_len[k] - 1 - int(g["bad_base_pos"])]
-                msg = "Invalid Base: `%s`" % chr(int(c0))
-            elif int(g["bad_op_idx"]) < int(g["panic_op_idx"]):
-                msg = "CIGAR OP `%s` invalid" % cigar_op_token_at(recs[int(mine[k])]["cigar"], int(g["bad_op_idx"]))
-            else:
-                msg = "panic: String::insert_str beyond the end of the fetched sequence (cigar.rs:507,513)"
-            first_err = min(first_err, (int(mine[k]), msg))
-            break
-        out_host = out.numpy()
-    # every rank learns the first failing record (input order); records at or behind it are not written
-    bad_at = R.all_min(first_err[0])
-    keep = mine < bad_at
-    sizes_w = np.where(keep, sizes, 0)
-    glob, total = multigpu.ordered_offsets(n, mine, sizes_w, R.dist, R.dev)
-    glob = glob + len(header)
+    if first_err is not None:
+        mine = [i for i in mine if i < first_err.index]
+    my_sizes = np.array([sizes[i] for i in mine], dtype=np.int64)
+    glob, total = multigpu.ordered_offsets(n, np.array(mine, dtype=np.int64), my_sizes, R.dist, R.dev)
+    glob = dict(zip(mine, (glob + len(header)).tolist()))
     total += len(header)
     if R.rank == 0:
         multigpu.write_ordered(args.output, np.frombuffer(header, dtype=np.uint8), [0], [len(header)], [0], total=total, create=True)
     R.barrier()
-    k_keep = int(keep.sum())
-    if k_keep:
-        multigpu.write_ordered(args.output, out_host, rec_off[:-1][:k_keep], sizes[:k_keep], glob[:k_keep])
-    R.barrier()
+    # pass 2: the rows, written where they belong
+    for piece in chunks_of(recs, mine, args.chunk_bytes):
+        sz, rec_off, rows, err = maf_piece(eng, recs, piece, tf, qf, d_tp, d_qp, want_rows=True)
+        k = len(sz)
+        if k:
+            multigpu.write_ordered(args.output, rows, rec_off[:-1][:k], sz, [glob[i] for i in piece[:k]])
+        if err is not None:
+            first_err = err if first_err is None or err.index < first_err.index else first_err
+            break
+    # every rank learns the first failing record (input order): the file ends in front of it
+    bad_at = R.all_min(first_err.index if first_err is not None else n)
     if bad_at < n:
-        msg = first_err[1] if first_err[0] == bad_at else None
-        if msg is not None:
-            sys.stderr.write("ERROR %s\n" % msg)
+        keep_bytes = R.all_sum(sum(sizes[i] for i in mine if i < bad_at)) + len(header)
+        R.barrier()
+        if R.rank == 0:
+            os.truncate(args.output, keep_bytes)
+        R.barrier()
+        if first_err is not None and first_err.index == bad_at:
+            sys.stderr.write("ERROR %s\n" % first_err)
         return 1
+    R.barrier()
     return 0
 
 
@@ -332,15 +372,15 @@ def run_pafcov(R, args):
     cov = torch.zeros(total + 4, dtype=torch.int32, device=R.dev)
     R.torch_done()
     if len(mine) and len(my_targets):
-        batch = pack_records(eng, recs, mine)
-        target_id = np.array([local_id[tid[recs[i]["tname"]]] for i in mine], dtype=np.uint32)
-        t_start = np.array([recs[i]["tstart"] for i in mine], dtype=np.uint64)
         d_off, d_len = eng.upload(cov_off), eng.upload(cov_len)
-        eng.pafcov_accumulate(batch, eng.upload(target_id), eng.upload(t_start), d_off, d_len, cov, total)
+        for piece in chunks_of(recs, mine, args.chunk_bytes):      # one resident batch at a time into the same arrays
+            batch = pack_records(eng, recs, piece)
+            target_id = np.array([local_id[tid[recs[i]["tname"]]] for i in piece], dtype=np.uint32)
+            t_start = np.array([recs[i]["tstart"] for i in piece], dtype=np.uint64)
+            eng.pafcov_accumulate(batch, eng.upload(target_id), eng.upload(t_start), d_off, d_len, cov, total)
+            eng.sync()
         eng.pafcov_finalize(len(my_targets), d_off, d_len, cov)
         eng.sync()
-    elif len(my_targets):
-        pass                                                        # no record of mine: zeros are the coverage
     # pieces of BED text: (target, first position, int32 coverage tensor of the positions)
     pieces = []
     for t in range(nt):
@@ -385,11 +425,14 @@ def run_totals(R, args):
     mine = multigpu.my_records(owner, R.rank)
     tot = torch.zeros(11, dtype=torch.int64, device=R.dev)
     R.torch_done()
-    if len(mine):
-        batch = pack_records(eng, recs, mine)
+    part = torch.zeros(11, dtype=torch.int64, device=R.dev)
+    R.torch_done()
+    for piece in chunks_of(recs, [int(i) for i in mine], args.chunk_bytes):
+        batch = pack_records(eng, recs, piece)
         counts, diag, _ = eng.cigar_stat(batch, want_tiles=False)
-        eng.counts_total(len(mine), counts, tot)
+        eng.counts_total(len(piece), counts, part)
         eng.sync()
+        tot += part
     multigpu.allreduce_totals(tot, R.dist)
     if R.rank == 0:
         print(json.dumps(dict(zip(engine.COUNTS_DTYPE.names, [int(x) for x in tot.cpu().tolist()]), records=len(recs), ranks=R.world)))
@@ -405,12 +448,15 @@ def main(argv=None):
     p.add_argument("-g", "--target", required=True)
     p.add_argument("-q", "--query", required=True)
     p.add_argument("-o", "--output", required=True)
+    p.add_argument("--chunk-bytes", type=int, default=64 << 20, help="CIGAR text per resident batch of a rank (default 64 MiB)")
     p = sub.add_parser("pafcov")
     p.add_argument("input")
     p.add_argument("-o", "--output", required=True)
     p.add_argument("--spread", action="store_true", help="deal the records out round robin and sum the partial coverages with a reduce-scatter per target")
+    p.add_argument("--chunk-bytes", type=int, default=64 << 20)
     p = sub.add_parser("totals")
     p.add_argument("input")
+    p.add_argument("--chunk-bytes", type=int, default=64 << 20)
     args = ap.parse_args(argv)
     R = Ranks(args.lib)
     try:
