@@ -224,8 +224,8 @@ def north_star(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5, help="untimed steps; the library's drain_min trials take the first five launches on a new output buffer")
     ap.add_argument("--records", type=int, default=100_000)
     ap.add_argument("--mean-ops", type=int, default=5000)
     ap.add_argument("--pool-mb", type=int, default=50)
