@@ -392,6 +392,7 @@ def run_pafcov(R, args):
         elif t_owner[t] == R.rank:
             k = local_id[t]
             pieces.append((t, 0, 0, cov[int(cov_off[k]): int(cov_off[k]) + int(cov_len[k])]))
+    R.torch_done()            # the collectives ran on torch's stream; K9 below runs on the library's
     # format my pieces on the device (K9), learn everybody's text sizes, write in (target, slice) order
     texts, sizes = [], np.zeros(nt * R.world, dtype=np.int64)
     for t, slot, p0, part in pieces:
