@@ -334,9 +334,11 @@ def test_paf2maf_drain_trials_state_machine(emu):
     total = int(reco.numpy()[-1])
     tp, qp = emu.upload(b["t_pool"]), emu.upload(b["q_pool"])
     assert emu.get_param("expand_variant") == pc.DEFAULT_EXPAND_VARIANT
-    ref = None
+    emu.set_param("expand_autotune", 1)          # forget what earlier tests' buffers (maybe at this address) taught
+    ref, alive = None, []
     for buf in range(2):
         out = emu.empty(total + 64, np.uint8)
+        alive.append(out)                          # two buffers, two addresses
         used = []
         for k in range(6):
             out.fill(0x23)
