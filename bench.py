@@ -241,7 +241,7 @@ def main():
     ap.add_argument("--zipf", type=float, default=1.2, help="strong scaling: skew of the records over the targets "
                                                             "(P(target k) ~ 1 / (k + 1)^zipf; 0 = uniform)")
     ap.add_argument("--no-placement-probe", action="store_true", help="take the first output buffer the allocator returns instead "
-                    "of the fastest of --placement-candidates (see pipeline.pick_output_buffer)")
+                    "of the arena the library places (wga_arena_alloc, --placement-candidates)")
     ap.add_argument("--placement-candidates", type=int, default=8)
     ap.add_argument("--north-star", action="store_true", help="the 10 M x 50 kop headline shape as a stream of resident batches (N = 1)")
     ap.add_argument("--ns-records", type=int, default=400_000)
@@ -290,20 +290,44 @@ def main():
         tb = synth.make_paf_batch_torch(seed, args.records, args.mean_ops, args.pool_mb * 1_000_000, dev,
                                         neg_frac=args.neg_frac, use_m=args.m_only)
     placement = None
-    out_buf = None
-    if not args.no_placement_probe:
-        # where the output arena lies in HBM sets the row kernel's level: try several buffers, keep the
-        # fastest, as a long-lived caller would do once per process; every candidate's time goes into the line
+    out_buf = arena = None
+    first_alloc_ms = None
+    if world == 1 and not args.param:
+        # what the FIRST buffer the allocator returns gives (no placement policy): five warming steps (first touch + the
+        # library's drain_min trials), then three timed launches of the row kernel; reported next to the arena's number
         try:
-            out_buf, cand_ms = pipeline.pick_output_buffer(eng, tb, candidates=args.placement_candidates)
-            placement = {"policy": "fastest of %d candidate output buffers, each timed on 3 untimed launches of the real step "
-                                   "before the warm-up (pipeline.pick_output_buffer); --no-placement-probe takes the first "
-                                   "allocation" % len(cand_ms),
-                         "k2_ms_by_candidate": [round(x, 3) for x in cand_ms]}
-        except Exception as e:  # noqa: BLE001  (the probe is a policy, not a requirement: fall back to the first allocation)
-            out_buf = None
+            eng.set_param("expand_alias", 1)       # these launches go under the kernel's second name (rocprofv3 --stats keeps
+            job0 = pipeline.Paf2MafStatJob(eng, tb)  # the timed steps' kernel apart from every other shape / buffer)
+            job0.bind_stream()
+            for _ in range(5):
+                job0.step()
+            torch.cuda.synchronize()
+            eng.set_param("expand_timing", 1)
+            eng.expand_timing()
+            for _ in range(3):
+                job0.expand()
+            torch.cuda.synchronize()
+            t_ms, t_n = eng.expand_timing()
+            first_alloc_ms = t_ms / max(1, t_n)
+            del job0
+        except Exception as e:  # noqa: BLE001
+            first_alloc_ms = None
+            placement = {"first_allocation_error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            eng.set_param("expand_alias", 0)
             torch.cuda.empty_cache()
-            placement = {"policy": "first allocation (the probe failed: %s: %s)" % (type(e).__name__, e)}
+    if not args.no_placement_probe:
+        # where the output arena lies in HBM sets the row kernel's level: the library places it
+        # (wga_arena_alloc, the same call the `wgatools` command line makes for its row buffer)
+        try:
+            out_buf, arena, probe = pipeline.arena_output(eng, tb, candidates=args.placement_candidates)
+            placement = dict(placement or {}, policy="wga_arena_alloc: fastest of %d candidate buffers for a plain streaming copy "
+                             "(library policy, also used by the wgatools CLI); --no-placement-probe takes the first "
+                             "allocation" % args.placement_candidates, **probe)
+        except Exception as e:  # noqa: BLE001  (the probe is a policy, not a requirement: fall back to the first allocation)
+            out_buf = arena = None
+            torch.cuda.empty_cache()
+            placement = dict(placement or {}, policy="first allocation (the arena call failed: %s: %s)" % (type(e).__name__, e))
     job = pipeline.Paf2MafStatJob(eng, tb, out=out_buf)
     job.bind_stream()
     totals = torch.zeros(11, dtype=torch.int64, device=dev)
@@ -409,7 +433,20 @@ def main():
                 "kernel": "k_paf2maf_expand", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args, job),
                 "algorithmic_bytes_per_launch": ab["expand"],
+                # the same kernel on the first buffer the allocator returns (no placement policy at all)
+                "frac_first_allocation": (ab["expand"] / (first_alloc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if first_alloc_ms else None,
+                "kernel_ms_first_allocation": first_alloc_ms,
                 "k_cigar_stat_GBps": ab["stat"] / (k_stat * 1e-3) / 1e9,
+                # paf2maf+stat priced both ways.  The step runs K1 and K2 as two kernels, so the packed ops
+                # are read twice (unfused); a fused walk would read them once.
+                "paf2maf_plus_stat": {
+                    "fused": False,
+                    "bytes_unfused": ab["stat"] + ab["expand"], "bytes_fused_minimum": ab["expand"] + 88 * job.n,
+                    "achieved_GBps_unfused_bytes": (ab["stat"] + ab["expand"]) / ((k_stat + k_expand) * 1e-3) / 1e9,
+                    "frac_unfused_bytes": (ab["stat"] + ab["expand"]) / ((k_stat + k_expand) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "frac_fused_minimum_bytes": (ab["expand"] + 88 * job.n) / ((k_stat + k_expand) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "note": "K1 + K2 kernel time; ops (4 B each) read by both kernels",
+                },
             },
         }
         result["metric_scope"] = ("kernel-only: K1 + layout + K2 (+ totals) on packed ops and sequence pools resident in HBM; no "
@@ -435,6 +472,7 @@ def main():
             try:   # additional information: never at the price of the headline line
                 del job
                 torch.cuda.empty_cache()
+                eng.set_param("expand_alias", 1)   # other shapes run under the kernel's second name (rocprofv3 --stats)
                 ms_g, frac_g = extra_shape(eng, synth, pipeline, torch, dev, seed, args.records, args.mean_ops, 1000)
                 ms_l, frac_l = extra_shape(eng, synth, pipeline, torch, dev, seed + 100, 10_000, 50_000, args.pool_mb)
                 ms_lg, frac_lg = extra_shape(eng, synth, pipeline, torch, dev, seed + 100, 10_000, 50_000, 1000)

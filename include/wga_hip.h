@@ -111,7 +111,9 @@ int wga_device_count(void);
 int wga_ctx_create(int device, wga_ctx** out);
 void wga_ctx_destroy(wga_ctx*);
 /* Launch on an external stream (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream;
- * NULL is HIP's default stream).  wga_ctx_reset_stream goes back to the context's own stream. */
+ * NULL is HIP's default stream).  wga_ctx_reset_stream goes back to the context's own stream.  Both
+ * synchronise the stream that is being left: an external stream must stay alive until the next
+ * wga_ctx_set_stream / wga_ctx_reset_stream / wga_ctx_destroy on the context. */
 int wga_ctx_set_stream(wga_ctx*, void* hip_stream);
 int wga_ctx_reset_stream(wga_ctx*);
 /* Tunables (test knobs): "expand_force_slow" (0/1) forces the u64 op-serial fallback of the
@@ -124,7 +126,8 @@ int wga_ctx_reset_stream(wga_ctx*);
  * 16 on the first launches of >= 8192 tiles that write to a given output buffer and keeps the fastest per tile (what
  * late emission costs depends on where the output buffer lies in HBM; the bytes written do not depend on it).  A caller
  * that keeps its output arena pays three slightly slower launches once.  Environment: WGA_EXPAND_DRAIN_MIN,
- * WGA_EXPAND_AUTOTUNE. */
+ * WGA_EXPAND_AUTOTUNE.  "expand_alias" (0/1): launch the row kernel under its second name (k_paf2maf_expand_alias) —
+ * a harness that runs several shapes in one process keeps its per-kernel profiler statistics apart that way. */
 int wga_ctx_set_param(wga_ctx*, const char* name, int64_t value);
 /* Read back: "expand_drain_min" = what the last wga_paf2maf_expand used, "expand_autotune_settled" (0/1),
  * "expand_variant". */
@@ -137,6 +140,15 @@ int wga_ctx_expand_timing(wga_ctx*, double* ms_sum, uint32_t* launches);
 int wga_sync(wga_ctx*);
 int wga_malloc(wga_ctx*, size_t bytes, void** d_out);
 int wga_free(wga_ctx*, void* d_ptr);
+/* Placement policy for a large, long-lived output arena (the MAF rows of converter.rs:237-262, which the reference
+ * keeps in two `String`s per record).  The rate a write-heavy kernel reaches depends on the REGION of HBM its output lies
+ * in (profiles/r02_k2_experiments.md sections 7, 10: the same row kernel at 6.65 / 6.81 / 7.21 ms by region, and a plain
+ * copy moves with it), and nothing in the allocation API says which region a buffer got.  wga_arena_alloc allocates up to
+ * `candidates` buffers of `bytes`, times a plain streaming copy inside each (one warming pass = first touch, two timed
+ * ones; HIP events on the context's stream), keeps the fastest and frees the others.  `gbps_by_candidate` (optional,
+ * `candidates` entries; 0 for candidates that were not allocated) receives the probe's copy rate per candidate, `chosen`
+ * (optional) the index kept.  candidates <= 1 is wga_malloc.  Free the arena with wga_free.  Synchronises. */
+int wga_arena_alloc(wga_ctx*, size_t bytes, int candidates, void** d_out, double* gbps_by_candidate, int* chosen);
 int wga_memcpy_h2d(wga_ctx*, void* d_dst, const void* h_src, size_t bytes);
 int wga_memcpy_d2h(wga_ctx*, void* h_dst, const void* d_src, size_t bytes); /* synchronises */
 int wga_memset(wga_ctx*, void* d_dst, int byte, size_t bytes);

@@ -139,3 +139,30 @@ def check_totals(tmp_path, lib, worlds, port):
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
         assert [d[k] for k in engine.COUNTS_DTYPE.names] == exp.tolist() and d["records"] == 29 and d["ranks"] == w, d
+
+
+def check_bad_cigar_ends_every_rank(tmp_path, lib, worlds, port):
+    """a CIGAR the tokeniser rejects (a length beyond u64) in one record: only the rank that owns the record sees it, yet
+    `pafcov` (sharded and spread) and `totals` end with status 1 on every rank — no collective is left waiting — and the
+    owner prints the reference's message; an op `stat` rejects ends `totals` the same way"""
+    b = synth.make_paf_batch(95, 23, 120, 30_000)
+    t_fa, q_fa, paf = write_case(tmp_path, b, np.zeros(23, dtype=int))
+    lines = open(paf).read().split("\n")
+    def with_cigar(k, text):
+        out = list(lines)
+        f = out[1 + k].split("\t")
+        f[-1] = "cg:Z:" + text
+        out[1 + k] = "\t".join(f)
+        path = str(tmp_path / ("bad_%d_%d.paf" % (k, len(text))))
+        open(path, "w").write("\n".join(out))
+        return path
+    bad_len = with_cigar(11, "5=99999999999999999999999M3=")
+    bad_op = with_cigar(7, "5=3N2=")
+    for w in worlds:
+        for k, extra in enumerate(([], ["--spread"])):
+            r = launch(w, lib, port + 4 * w + k, "pafcov", bad_len, "-o", str(tmp_path / ("bad%d%d.bed" % (w, k))), *extra, expect_rc=1)
+            assert "Parse `99999999999999999999999` Into Integer Error" in r.stderr, r.stderr[-1500:]
+        r = launch(w, lib, port + 4 * w + 2, "totals", bad_len, expect_rc=1)
+        assert "Parse `99999999999999999999999` Into Integer Error" in r.stderr, r.stderr[-1500:]
+        r = launch(w, lib, port + 4 * w + 3, "totals", bad_op, expect_rc=1)
+        assert "CIGAR OP `N` invalid" in r.stderr, r.stderr[-1500:]

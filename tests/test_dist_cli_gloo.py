@@ -25,3 +25,7 @@ def test_pafcov_sharded_and_spread(libs, tmp_path):
 
 def test_totals_allreduce(libs, tmp_path):
     dc.check_totals(tmp_path, libs[0], (1, 2), 29650)
+
+
+def test_bad_cigar_ends_every_rank(libs, tmp_path):
+    dc.check_bad_cigar_ends_every_rank(tmp_path, libs[0], (1, 2), 29660)

@@ -525,3 +525,16 @@ def test_maf_long_blocks_piecewise(emu):
     finally:
         emu.set_param("maf_long_cols", 32768)
         emu.set_param("maf_piece_cols", 16384)
+
+
+def test_arena_alloc(emu):
+    """wga_arena_alloc on the emulator: the probe's copies run (events read 0 ms: the first candidate stays), the arena
+    is a plain allocation of the asked size, candidates <= 1 is wga_malloc"""
+    a, rates, chosen = emu.arena_alloc(10000, 3)
+    assert a.ptr and len(rates) == 3 and chosen == 0 and a.nbytes == 10000
+    a.fill(0x41)
+    assert bytes(a.numpy()[:4]) == b"AAAA" and a.numpy()[-1] == 0x41
+    a.free()
+    b, rates, chosen = emu.arena_alloc(64, 1)
+    assert b.ptr and chosen == 0
+    b.free()

@@ -171,15 +171,21 @@ def test_paf2maf_drain_autotune_same_bytes(gpu):
 
 
 def test_output_buffer_placement_probe(gpu):
-    """pipeline.pick_output_buffer: every candidate is timed on the real step, one comes back, and the rows written into it
-    are the rows of any other buffer"""
+    """wga_arena_alloc (the library's placement policy): every candidate is timed with a plain copy, one comes back, and the
+    rows written into it are the rows of any other buffer"""
     import torch
     from wgatools_amd import pipeline
     dev = torch.device("cuda", 0)
     tb = synth.make_paf_batch_torch(78, 600, 3000, 5_000_000, dev)
     gpu.set_stream(torch.cuda.current_stream().cuda_stream)
-    buf, ms = pipeline.pick_output_buffer(gpu, tb, candidates=3, launches=2)
-    assert len(ms) == 3 and all(m > 0 for m in ms)
+    buf, arena, probe = pipeline.arena_output(gpu, tb, candidates=3)
+    rates = probe["probe_copy_GBps_by_candidate"]
+    assert len(rates) == 3 and all(r > 0 for r in rates) and 0 <= probe["chosen"] < 3
+    assert rates[probe["chosen"]] == max(rates)
+    assert buf.data_ptr() == arena.ptr and buf.numel() == pipeline.output_bytes(tb)
+    one, r1, c1 = gpu.arena_alloc(4096, 1)     # candidates <= 1 is a plain allocation
+    assert one.ptr and c1 == 0
+    one.free()
     a = pipeline.Paf2MafStatJob(gpu, tb, out=buf)
     b = pipeline.Paf2MafStatJob(gpu, tb)
     for j in (a, b):
@@ -754,15 +760,12 @@ def test_pafpseudo_config5_long_cigar_cross_check(gpu):
         assert want.numel() == got.numel() and bool((want == got).all()), i
 
 
-FULL = os.environ.get("WGA_FULL_CONFIGS", "0") != "0"
-
-
-@pytest.mark.skipif(not FULL, reason="BASELINE configs[3] at its stated size (64 x 100 Mb, 20 M records: ~2 min on one "
-                                     "GPU): WGA_FULL_CONFIGS=1; the log of the last run is profiles/r02_full_configs.txt")
 def test_pafcov_config4_at_stated_size(gpu):
-    """64 targets x 100 Mb = 6.4e9 int32 counters (25.6 GB), 20 M records of ~1300 ops generated on the device in ten
-    chunks and accumulated into ONE resident coverage array; per target the summed coverage equals the M / = bases K1
-    counts for the records that hit it, coverage is never negative"""
+    """BASELINE configs[3] at its stated size: 64 targets x 100 Mb = 6.4e9 int32 counters (25.6 GB), 20 M records of ~1300
+    ops generated on the device in ten chunks and gathered into ONE resident batch (2.6e10 ops, 104 GB), accumulated into
+    the resident coverage array with ONE wga_pafcov_accumulate call — the array is read and written once, not once per
+    chunk (288 GB of HBM hold all of it).  Per target the summed coverage equals the M / = bases K1 counts for the
+    records that hit it, coverage is never negative."""
     import torch
     dev = torch.device("cuda", 0)
     nt, tlen, chunks, per = 64, 100_000_000, 10, 2_000_000
@@ -772,35 +775,47 @@ def test_pafcov_config4_at_stated_size(gpu):
     total = int(nt * (tlen + 4))
     cov = torch.zeros(total + 8, dtype=torch.int32, device=dev)
     want = torch.zeros(nt, dtype=torch.int64, device=dev)
-    ms_acc, n_ops = 0.0, 0
+    n_all = chunks * per
+    cap = int(n_all * 1300 * 1.06)
+    ops = torch.empty(cap, dtype=torch.int32, device=dev)
+    op_off = torch.zeros(n_all + 1, dtype=torch.int64, device=dev)
+    strand = torch.zeros(n_all, dtype=torch.uint8, device=dev)
+    t_start = torch.zeros(n_all, dtype=torch.int64, device=dev)
+    target_id = torch.zeros(n_all, dtype=torch.int32, device=dev)
+    n_ops = 0
     for k in range(chunks):
         tb = synth.make_paf_batch_torch(400 + k, per, 1300, tlen, dev)
         n = tb["n"]
+        assert n == per and n_ops + tb["n_ops"] <= cap
         batch = engine.Batch(tb["ops"], tb["op_off"], tb["strand_neg"], n, tb["n_ops"])
         g = torch.Generator(device=dev)
         g.manual_seed(900 + k)
-        target_id = torch.randint(0, nt, (n,), device=dev, generator=g, dtype=torch.int32)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        gpu.pafcov_accumulate(batch, target_id, tb["t_src_off"], cov_off, cov_len, cov, total)
-        e1.record()
+        tid = torch.randint(0, nt, (n,), device=dev, generator=g, dtype=torch.int32)
         counts = torch.zeros((n, 11), dtype=torch.int64, device=dev)
         diag = torch.zeros((n, 3), dtype=torch.int64, device=dev)
         gpu.cigar_stat(batch, counts, diag, None)
         torch.cuda.synchronize()
-        ms_acc += e0.elapsed_time(e1)
+        want.index_add_(0, tid.long(), counts[:, 0])
+        ops[n_ops:n_ops + tb["n_ops"]] = tb["ops"]
+        op_off[k * per + 1:(k + 1) * per + 1] = tb["op_off"][1:] + n_ops
+        strand[k * per:(k + 1) * per] = tb["strand_neg"]
+        t_start[k * per:(k + 1) * per] = tb["t_src_off"]
+        target_id[k * per:(k + 1) * per] = tid
         n_ops += tb["n_ops"]
-        want.index_add_(0, target_id.long(), counts[:, 0])
-        del tb, batch, counts, diag, target_id
+        del tb, batch, counts, diag, tid
         torch.cuda.empty_cache()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    gpu.pafcov_finalize(nt, cov_off, cov_len, cov)
-    e1.record()
+    batch = engine.Batch(ops, op_off, strand, n_all, n_ops)
     torch.cuda.synchronize()
-    ms_fin = e0.elapsed_time(e1)
-    print("\nconfig 4 at size: %d records, %.3g ops, %d x %d counters: accumulate %.1f ms in all (%.0f GB/s of op stream), "
-          "finalize %.1f ms (%.0f GB/s over 8 B per counter)" % (chunks * per, n_ops, nt, tlen, ms_acc, 4 * n_ops / ms_acc / 1e6,
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record()
+    gpu.pafcov_accumulate(batch, target_id, t_start, cov_off, cov_len, cov, total)
+    e1.record()
+    gpu.pafcov_finalize(nt, cov_off, cov_len, cov)
+    e2.record()
+    torch.cuda.synchronize()
+    ms_acc, ms_fin = e0.elapsed_time(e1), e1.elapsed_time(e2)
+    print("\nconfig 4 at size: %d records, %.3g ops, %d x %d counters: ONE accumulate call %.1f ms (%.0f GB/s of op stream), "
+          "finalize %.1f ms (%.0f GB/s over 8 B per counter)" % (n_all, n_ops, nt, tlen, ms_acc, 4 * n_ops / ms_acc / 1e6,
                                                                 ms_fin, 8.0 * nt * tlen / ms_fin / 1e6))
     for t in range(nt):
         c = cov[int(cov_off[t]):int(cov_off[t]) + tlen]
@@ -809,7 +824,6 @@ def test_pafcov_config4_at_stated_size(gpu):
     gpu.reset_stream()
 
 
-@pytest.mark.skipif(not FULL, reason="BASELINE configs[4] stress at its stated size (10 000 records >= 200 kop): WGA_FULL_CONFIGS=1")
 def test_pafpseudo_config5_at_stated_size(gpu):
     """10 000 records of >= 200 kop (2.5e9 ops, 3.7e10 columns) in chunks of 400: the base-mode pseudo-MAF row equals
     paf2maf's query row minus the columns where its target row is gapped (K6 against K2), the symbol-mode row equals

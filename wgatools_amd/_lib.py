@@ -42,6 +42,7 @@ PROTOTYPES = {
     "wga_ctx_expand_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "wga_sync": (C.c_int, [vp]),
     "wga_malloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "wga_arena_alloc": (C.c_int, [vp, C.c_size_t, C.c_int, C.POINTER(vp), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "wga_free": (C.c_int, [vp, vp]),
     "wga_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "wga_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),

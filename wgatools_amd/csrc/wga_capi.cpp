@@ -39,6 +39,7 @@ struct wga_ctx {
   } tune;
   uint64_t maf_long_cols = 32768;  /* MAF blocks beyond this many columns are walked piece by piece ... */
   uint64_t maf_piece_cols = 16384; /* ... of this many columns, one wave each (test knobs: "maf_long_cols", "maf_piece_cols") */
+  int expand_alias = 0;   /* 1: launch the row kernel under its second name (k_paf2maf_expand_alias) */
   int expand_variant = 0; /* 0: v1 (fastest measured, profiles/r02_k2_experiments.md); 1: the planned, line-complete kernel of wga_kernels_k2p.h */
   void* expand_dbg = nullptr;
   void* scratch = nullptr;
@@ -392,6 +393,10 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
     c->expand_variant = value != 0;
     return WGA_OK;
   }
+  if (strcmp(name, "expand_alias") == 0) {
+    c->expand_alias = value != 0;
+    return WGA_OK;
+  }
   if (strcmp(name, "expand_timing") == 0) {
     if (value && !c->timing) {
       int rc = ctx_bind(c);
@@ -425,6 +430,50 @@ int wga_malloc(wga_ctx* c, size_t bytes, void** d_out) {
   if (!d_out) return fail(WGA_E_INVALID_ARG, "d_out is null", nullptr);
   const char* e = rt_malloc(d_out, bytes);
   if (e) return fail(WGA_E_OOM, "device allocation", e);
+  return WGA_OK;
+}
+int wga_arena_alloc(wga_ctx* c, size_t bytes, int candidates, void** d_out, double* gbps_by_candidate, int* chosen) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (!d_out) return fail(WGA_E_INVALID_ARG, "d_out is null", nullptr);
+  if (candidates > 64) candidates = 64;
+  if (gbps_by_candidate)
+    for (int k = 0; k < candidates; k++) gbps_by_candidate[k] = 0.0;
+  if (chosen) *chosen = 0;
+  const u64 half = (u64)bytes / 32u; /* granules per half */
+  if (candidates <= 1 || half == 0) return wga_malloc(c, bytes, d_out);
+  void* cand[64];
+  int n = 0;
+  for (; n < candidates; n++) {
+    if (rt_malloc(&cand[n], bytes)) break; /* out of memory: fewer candidates */
+  }
+  if (n == 0) return fail(WGA_E_OOM, "device allocation", "no memory for one candidate");
+  rt_event_t ev[2];
+  const char* e = rt_event_create(&ev[0]);
+  if (!e && (e = rt_event_create(&ev[1]))) rt_event_destroy(ev[0]);
+  int best = 0;
+  double best_ms = 0.0;
+  const u32 grid = (u32)(half / 256u < 65536u ? (half + 255u) / 256u : 65536u);
+  for (int k = 0; k < n && !e; k++) {
+    WGA_LAUNCH(k_arena_probe, grid, WGA_BLOCK, c->stream, (u32x4_a16*)cand[k], half, 0); /* first touch */
+    if ((e = rt_event_record(ev[0], c->stream))) break;
+    WGA_LAUNCH(k_arena_probe, grid, WGA_BLOCK, c->stream, (u32x4_a16*)cand[k], half, 1);
+    WGA_LAUNCH(k_arena_probe, grid, WGA_BLOCK, c->stream, (u32x4_a16*)cand[k], half, 0);
+    if ((e = rt_event_record(ev[1], c->stream))) break;
+    float ms = 0.0f;
+    if ((e = rt_event_elapsed_ms(ev[0], ev[1], &ms))) break;
+    if ((e = rt_launch_error())) break;
+    if (gbps_by_candidate) gbps_by_candidate[k] = ms > 0.0f ? 4.0 * 16.0 * (double)half / ((double)ms * 1e6) : 0.0;
+    if (k == 0 || (double)ms < best_ms) best = k, best_ms = (double)ms;
+  }
+  if (!e) e = rt_sync(c->stream);
+  rt_event_destroy(ev[0]);
+  rt_event_destroy(ev[1]);
+  for (int k = 0; k < n; k++)
+    if (e || k != best) (void)rt_free(cand[k]);
+  if (e) return fail(WGA_E_HIP, "arena probe", e);
+  *d_out = cand[best];
+  if (chosen) *chosen = best;
   return WGA_OK;
 }
 int wga_free(wga_ctx* c, void* d_ptr) {
@@ -656,7 +705,10 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
   if (c->timing) RT_CHECK(rt_event_record(c->ev[2 * slot], c->stream));
   if (!staged) {
     if (tune_timed) RT_CHECK(rt_event_record(c->tune.ev[0], c->stream));
-    WGA_LAUNCH(k_paf2maf_expand, (u32)nt, WGA_BLOCK, c->stream, a);
+    if (c->expand_alias)
+      WGA_LAUNCH(k_paf2maf_expand_alias, (u32)nt, WGA_BLOCK, c->stream, a);
+    else
+      WGA_LAUNCH(k_paf2maf_expand, (u32)nt, WGA_BLOCK, c->stream, a);
     LAUNCH_CHECK();
     if (tune_timed) {
       RT_CHECK(rt_event_record(c->tune.ev[1], c->stream));

@@ -46,6 +46,14 @@ class HotPathError(Exception):
     pass
 
 
+class RecordError(HotPathError):
+    """a hot-path error of one record (input index): the ranks end the run together on the smallest index"""
+
+    def __init__(self, index, msg):
+        HotPathError.__init__(self, msg)
+        self.index = int(index)
+
+
 # ---- host side: the same text rules as wga_host.cpp ---------------------------------------------------------------
 def read_text(path):
     with open(path, "rb") as f:
@@ -186,24 +194,20 @@ class Ranks:
 
 
 def pack_records(eng, recs, idx):
-    """packed CSR batch of the records idx (host packer of the C-ABI); a tokeniser error ends the run"""
+    """packed CSR batch of the records idx (host packer of the C-ABI); a tokeniser error raises RecordError with the
+    record's input index: only the rank that owns the record sees it, so the callers agree on the first failing index
+    (Ranks.all_min) before any other collective"""
     ops, off = [], [0]
     for i in idx:
         o, err, (eo, el) = eng.pack_cigar(recs[i]["cigar"])
         if err:
             tok = recs[i]["cigar"][eo:eo + el].decode("latin-1")
-            raise HotPathError(("Parse `%s` Into Integer Error" % tok) if err == 3 else ("CIGAR OP `%s` invalid" % tok))
+            raise RecordError(i, ("Parse `%s` Into Integer Error" % tok) if err == 3 else ("CIGAR OP `%s` invalid" % tok))
         ops.append(o)
         off.append(off[-1] + len(o))
     ops = np.concatenate(ops) if ops else np.zeros(0, np.uint32)
     strand = np.array([1 if recs[i]["neg"] else 0 for i in idx], dtype=np.uint8)
     return eng.make_batch(ops, np.array(off, dtype=np.uint64), strand)
-
-
-class RecordError(HotPathError):
-    def __init__(self, index, msg):
-        HotPathError.__init__(self, msg)
-        self.index = int(index)
 
 
 def chunks_of(recs, idx, max_text):
@@ -339,6 +343,17 @@ def run_paf2maf(R, args):
     return 0
 
 
+def end_together(R, first_err, n):
+    """every rank learns the smallest failing record index (one MIN all-reduce, the FIRST collective after the per-rank
+    work); the owner of that record prints the reference's message; True = the run ends with status 1 on every rank"""
+    bad_at = R.all_min(first_err.index if first_err is not None else n)
+    if bad_at >= n:
+        return False
+    if first_err is not None and first_err.index == bad_at:
+        sys.stderr.write("ERROR %s\n" % first_err)
+    return True
+
+
 def paf_targets(recs):
     """names in first-appearance order, array length = target_length of the first record seen (cmd_pafcov)"""
     names, tid, length = [], {}, []
@@ -371,16 +386,24 @@ def run_pafcov(R, args):
         total += (int(cov_len[k]) + 3) & ~3
     cov = torch.zeros(total + 4, dtype=torch.int32, device=R.dev)
     R.torch_done()
+    first_err = None
     if len(mine) and len(my_targets):
         d_off, d_len = eng.upload(cov_off), eng.upload(cov_len)
-        for piece in chunks_of(recs, mine, args.chunk_bytes):      # one resident batch at a time into the same arrays
-            batch = pack_records(eng, recs, piece)
-            target_id = np.array([local_id[tid[recs[i]["tname"]]] for i in piece], dtype=np.uint32)
-            t_start = np.array([recs[i]["tstart"] for i in piece], dtype=np.uint64)
-            eng.pafcov_accumulate(batch, eng.upload(target_id), eng.upload(t_start), d_off, d_len, cov, total)
+        try:
+            for piece in chunks_of(recs, mine, args.chunk_bytes):      # one resident batch at a time into the same arrays
+                batch = pack_records(eng, recs, piece)
+                target_id = np.array([local_id[tid[recs[i]["tname"]]] for i in piece], dtype=np.uint32)
+                t_start = np.array([recs[i]["tstart"] for i in piece], dtype=np.uint64)
+                eng.pafcov_accumulate(batch, eng.upload(target_id), eng.upload(t_start), d_off, d_len, cov, total)
+                eng.sync()
+            eng.pafcov_finalize(len(my_targets), d_off, d_len, cov)
             eng.sync()
-        eng.pafcov_finalize(len(my_targets), d_off, d_len, cov)
-        eng.sync()
+        except RecordError as ex:    # only this rank knows: carry on to the agreement below, with nothing to write
+            first_err = ex
+    # the first failing record in input order ends the run on EVERY rank, before any other collective (pafcov is a
+    # buffered driver: nothing is written, pafcov.rs:29-53)
+    if end_together(R, first_err, len(recs)):
+        return 1
     # pieces of BED text: (target, first position, int32 coverage tensor of the positions)
     pieces = []
     for t in range(nt):
@@ -428,12 +451,23 @@ def run_totals(R, args):
     R.torch_done()
     part = torch.zeros(11, dtype=torch.int64, device=R.dev)
     R.torch_done()
-    for piece in chunks_of(recs, [int(i) for i in mine], args.chunk_bytes):
-        batch = pack_records(eng, recs, piece)
-        counts, diag, _ = eng.cigar_stat(batch, want_tiles=False)
-        eng.counts_total(len(piece), counts, part)
-        eng.sync()
-        tot += part
+    first_err = None
+    try:
+        for piece in chunks_of(recs, [int(i) for i in mine], args.chunk_bytes):
+            batch = pack_records(eng, recs, piece)
+            counts, diag, _ = eng.cigar_stat(batch, want_tiles=False)
+            bad = diag.numpy()["bad_op_idx"]
+            if (bad != np.uint64(NONE)).any():     # parse_paf_to_cigar rejects ops outside M = X I D (cigar.rs:629-707)
+                k = int(np.flatnonzero(bad != np.uint64(NONE))[0])
+                raise RecordError(piece[k], "CIGAR OP `%s` invalid" % cigar_op_token_at(recs[piece[k]]["cigar"], int(bad[k])))
+            eng.counts_total(len(piece), counts, part)
+            eng.sync()
+            tot += part
+            R.torch_done()      # the add runs on torch's stream: it must have read `part` before the next piece overwrites it
+    except RecordError as ex:
+        first_err = ex
+    if end_together(R, first_err, len(recs)):
+        return 1
     multigpu.allreduce_totals(tot, R.dist)
     if R.rank == 0:
         print(json.dumps(dict(zip(engine.COUNTS_DTYPE.names, [int(x) for x in tot.cpu().tolist()]), records=len(recs), ranks=R.world)))

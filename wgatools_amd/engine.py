@@ -62,6 +62,20 @@ class DeviceArray:
         self.eng._check(self.eng.lib.wga_memset(self.eng.ctx, self.ptr, byte, self.nbytes))
         return self
 
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (int(self.ptr), False), "version": 2,
+                "strides": None}
+
+    def torch(self, device):
+        """zero-copy torch view of this allocation (plumbing for the harness: torch only sees the bytes); the
+        DeviceArray must outlive the tensor"""
+        import torch
+        t = torch.as_tensor(self, device=device)
+        if t.data_ptr() != int(self.ptr):
+            raise RuntimeError("torch copied the buffer instead of viewing it")
+        return t
+
     def free(self):
         if self.owner and self.ptr:
             self.eng.lib.wga_free(self.eng.ctx, self.ptr)
@@ -121,6 +135,15 @@ class Engine:
         ptr = C.c_void_p()
         self._check(self.lib.wga_malloc(self.ctx, max(n * dt.itemsize, 16), C.byref(ptr)))
         return DeviceArray(self, ptr.value, shape, dt)
+
+    def arena_alloc(self, nbytes, candidates=8):
+        """a large output arena placed by the library's probe (wga_arena_alloc: the fastest of `candidates` buffers for
+        a plain streaming copy) -> (DeviceArray u8, [probe GB/s per candidate], index kept)"""
+        ptr = C.c_void_p()
+        rates = (C.c_double * max(1, candidates))()
+        chosen = C.c_int(0)
+        self._check(self.lib.wga_arena_alloc(self.ctx, int(nbytes), int(candidates), C.byref(ptr), rates, C.byref(chosen)))
+        return DeviceArray(self, ptr.value, (int(nbytes),), np.uint8), [float(x) for x in rates][:max(1, candidates)], chosen.value
 
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)

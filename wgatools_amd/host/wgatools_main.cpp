@@ -121,6 +121,7 @@ struct DevStreamer {
     std::vector<size_t> which(kBufs, 0);
     size_t next_write = 0; /* ordered writer: next piece to go out */
     bool failed = false, done_filling = false;
+    std::string copy_err;
     auto writer = [&]() {
       for (;;) {
         int b = -1;
@@ -191,7 +192,14 @@ struct DevStreamer {
           }
       }
       const size_t off = p * kPiece, len = std::min(kPiece, n - off);
-      if (wga_memcpy_d2h_async(ctx, buf[b], d_src + off, len) || wga_sync(ctx)) fail(std::string("GPU engine: ") + wga_last_error());
+      if (wga_memcpy_d2h_async(ctx, buf[b], d_src + off, len) || wga_sync(ctx)) {
+        /* the writers are joinable threads: stop and join them before the error leaves this frame (unwinding past a
+         * joinable std::thread is std::terminate, and the message would never be printed) */
+        copy_err = std::string("GPU engine: ") + wga_last_error();
+        std::lock_guard<std::mutex> lk(mu);
+        failed = true;
+        break;
+      }
       {
         std::lock_guard<std::mutex> lk(mu);
         which[b] = p;
@@ -205,6 +213,7 @@ struct DevStreamer {
     }
     cv.notify_all();
     for (auto& t : writers) t.join();
+    if (!copy_err.empty()) fail(copy_err);
     if (failed) fail("IO error:write failed");
     if (fd >= 0) out.advance(n);
   }
@@ -263,7 +272,12 @@ struct Dev {
         out_arena = nullptr;
       }
       out_arena_cap = bytes + bytes / 4;
-      check(wga_malloc(ctx, out_arena_cap, &out_arena));
+      /* a large row buffer is placed by the library's policy (wga_arena_alloc: the fastest of a few candidate buffers
+       * for a plain streaming copy — the row kernel's level depends on the region of HBM its output lies in);
+       * WGA_ARENA_CANDIDATES=1 takes the first allocation */
+      int cand = out_arena_cap >= ((size_t)256 << 20) ? 4 : 1;
+      if (const char* v = getenv("WGA_ARENA_CANDIDATES")) cand = atoi(v);
+      check(wga_arena_alloc(ctx, out_arena_cap, cand, &out_arena, nullptr, nullptr));
     }
     return out_arena;
   }
@@ -2541,6 +2555,8 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
           for (uint32_t k = lo; k < hi; k++) one_record(k, parts[t]);
         } catch (Error& e) {
           errs[t] = e.msg.empty() ? std::string("error") : e.msg;
+        } catch (std::exception& e) { /* bad_alloc and friends: an exception leaving a thread is std::terminate */
+          errs[t] = std::string("internal error: ") + e.what();
         }
       };
       {
@@ -2651,6 +2667,8 @@ int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, c
         }
       } catch (Error& e) {
         errs[t] = e.msg.empty() ? std::string("error") : e.msg;
+      } catch (std::exception& e) {
+        errs[t] = std::string("internal error: ") + e.what();
       }
     };
     {

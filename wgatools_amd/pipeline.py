@@ -83,39 +83,17 @@ class Paf2MafStatJob:
                 self.out[qo:qo + ql].cpu().numpy().tobytes())
 
 
-def pick_output_buffer(eng, tb, candidates=8, launches=3):
-    """Placement policy for the hot output arena (profiles/r02_k2_experiments.md, sections 7 and 10): the row kernel's time is
-    a function of the REGION of HBM its output buffer lies in (6.65 / 6.8 / 7.2 ms on the same batch, reproducibly), and
-    nothing in the allocation API says which region a buffer got.  So a long-lived caller tries several: `candidates` buffers
-    of the needed size are allocated, each gets one warming launch and `launches` measured ones of the real step on the real
-    batch (library HIP events), the fastest is kept and the others are returned to the allocator.  Returns
-    (buffer, [K2 ms per candidate]).  The bytes written do not depend on the choice."""
-    import torch
-    need = int((tb["t_src_len"] + tb["i"]).sum() + (tb["q_src_len"] + tb["d"]).sum()) + 64
-    bufs = []
-    for _ in range(candidates):
-        try:
-            bufs.append(torch.empty(need, dtype=torch.uint8, device=tb["ops"].device))
-        except RuntimeError:            # out of memory: fewer candidates
-            break
-    if not bufs:
-        raise RuntimeError("no memory for the output buffer (%d bytes)" % need)
-    eng.set_param("expand_timing", 1)
-    ms = []
-    for b in bufs:
-        job = Paf2MafStatJob(eng, tb, out=b)
-        job.bind_stream()
-        job.step()
-        torch.cuda.synchronize()
-        eng.expand_timing()
-        for _ in range(launches):
-            job.expand()
-        torch.cuda.synchronize()
-        t, n = eng.expand_timing()
-        ms.append(t / max(1, n))
-        del job
-    best = min(range(len(bufs)), key=lambda k: ms[k])
-    out = bufs[best]
-    del bufs, b
-    torch.cuda.empty_cache()
-    return out, ms
+def output_bytes(tb):
+    """bytes of the two gapped rows of every record of a generated batch (+ slack), known from the generator's class sums"""
+    return int((tb["t_src_len"] + tb["i"]).sum() + (tb["q_src_len"] + tb["d"]).sum()) + 64
+
+
+def arena_output(eng, tb, candidates=8):
+    """The output arena of a long-lived caller, placed by the LIBRARY's policy (wga_arena_alloc, include/wga_hip.h: the
+    row kernel's level is a function of the region of HBM its output lies in — profiles/r02_k2_experiments.md sections
+    7 and 10 — so the library times a plain streaming copy inside `candidates` buffers and keeps the fastest; the
+    `wgatools` command line places its row buffer the same way).  Returns (torch view, DeviceArray that owns the memory,
+    {probe GB/s per candidate, index kept})."""
+    arena, rates, chosen = eng.arena_alloc(output_bytes(tb), candidates)
+    view = arena.torch(tb["ops"].device)
+    return view, arena, {"probe_copy_GBps_by_candidate": [round(r, 1) for r in rates], "chosen": chosen}
