@@ -356,9 +356,11 @@ def main():
         if world > 1:
             dist.all_reduce(totals)                          # RCCL over xGMI: 88 bytes
 
-    for _ in range(args.warmup):
+    eng.set_param("expand_alias", 1)   # warm-up launches (first touch, the library's trials) under the kernel's second name:
+    for _ in range(args.warmup):       # rocprofv3 --stats of this command then holds exactly the timed launches under the first
         step()
     torch.cuda.synchronize()
+    eng.set_param("expand_alias", 0)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

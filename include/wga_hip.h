@@ -118,8 +118,9 @@ int wga_ctx_set_stream(wga_ctx*, void* hip_stream);
 int wga_ctx_reset_stream(wga_ctx*);
 /* Tunables (test knobs): "expand_force_slow" (0/1) forces the u64 op-serial fallback of the
  * expand kernel; "expand_no_table" (0/1) forces its binary-search event lookup; "expand_variant" picks the row
- * kernel (0: v1, the default and the fastest measured; 1: the planned, line-complete kernel — same bytes;
- * environment: WGA_EXPAND_VARIANT); "expand_drain_min" (0 .. 64) = how many gap-touching 16-column chunks a wave
+ * kernel — same bytes either way: -1 (default) by the batch (the window kernel, which assembles 4 KB output windows in
+ * LDS and stores whole lines, for batches below 1500 ops per record, where it is 12-19 % faster; v1 for longer records,
+ * where v1 is 7 % faster), 0: v1, 2: the window kernel; environment: WGA_EXPAND_VARIANT; "expand_drain_min" (0 .. 64) = how many gap-touching 16-column chunks a wave
  * queues before it emits them: 0 (default) lets the library choose by the size of the two sequence pools — 64 when
  * they stay in the 256 MB Infinity Cache, 16 when they do not (the L2 then churns with source lines and half-written
  * output lines should complete at once) as the starting point — and, unless "expand_autotune" is set to 0, tries 64 / 32 /
@@ -130,7 +131,7 @@ int wga_ctx_reset_stream(wga_ctx*);
  * a harness that runs several shapes in one process keeps its per-kernel profiler statistics apart that way. */
 int wga_ctx_set_param(wga_ctx*, const char* name, int64_t value);
 /* Read back: "expand_drain_min" = what the last wga_paf2maf_expand used, "expand_autotune_settled" (0/1),
- * "expand_variant". */
+ * "expand_variant" (the setting), "expand_variant_used" (what the last wga_paf2maf_expand ran). */
 int wga_ctx_get_param(wga_ctx*, const char* name, int64_t* value);
 /* Measurement hook: after wga_ctx_set_param(ctx, "expand_timing", 1) every wga_paf2maf_expand
  * brackets its gap-insertion kernel (without the descriptor pre-pass) with two events on the

@@ -1,0 +1,52 @@
+"""K5 (pafcov accumulate) against the size of ONE resident batch: does the time per op stay flat when the op stream grows
+from 10 GB to 100 GB?  (round 3: one call over 104 GB of ops measured 4.8 s, ten calls over 10 GB each 0.37 s.)
+usage: python scripts/gpu_k5_scaling.py [chunks ...]   (2 M records of ~1300 ops per chunk)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from wgatools_amd import build, engine, _lib, synth
+
+dev = torch.device("cuda", 0)
+eng = engine.Engine(0, _lib.load(build.HIP_LIB))
+eng.set_stream(torch.cuda.current_stream().cuda_stream)
+nt, tlen, per = 64, 100_000_000, 2_000_000
+cov_len = torch.full((nt,), tlen, dtype=torch.int64, device=dev)
+cov_off = torch.arange(nt, device=dev, dtype=torch.int64) * (tlen + 4)
+total = int(nt * (tlen + 4))
+cov = torch.zeros(total + 8, dtype=torch.int32, device=dev)
+for chunks in [int(x) for x in (sys.argv[1:] or ["1", "2", "4", "8"])]:
+    n_all = chunks * per
+    cap = int(n_all * 1300 * 1.06)
+    ops = torch.empty(cap, dtype=torch.int32, device=dev)
+    op_off = torch.zeros(n_all + 1, dtype=torch.int64, device=dev)
+    strand = torch.zeros(n_all, dtype=torch.uint8, device=dev)
+    t_start = torch.zeros(n_all, dtype=torch.int64, device=dev)
+    target_id = torch.zeros(n_all, dtype=torch.int32, device=dev)
+    n_ops = 0
+    for k in range(chunks):
+        tb = synth.make_paf_batch_torch(400 + k, per, 1300, tlen, dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed(900 + k)
+        ops[n_ops:n_ops + tb["n_ops"]] = tb["ops"]
+        op_off[k * per + 1:(k + 1) * per + 1] = tb["op_off"][1:] + n_ops
+        strand[k * per:(k + 1) * per] = tb["strand_neg"]
+        t_start[k * per:(k + 1) * per] = tb["t_src_off"]
+        target_id[k * per:(k + 1) * per] = torch.randint(0, nt, (per,), device=dev, generator=g, dtype=torch.int32)
+        n_ops += tb["n_ops"]
+        del tb
+        torch.cuda.empty_cache()
+    batch = engine.Batch(ops, op_off, strand, n_all, n_ops)
+    for rep in range(2):
+        cov.zero_()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        eng.pafcov_accumulate(batch, target_id, t_start, cov_off, cov_len, cov, total)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        print("chunks %d (%.1f GB of ops, %d records) rep %d: accumulate %.1f ms = %.0f GB/s of op stream" % (
+            chunks, 4 * n_ops / 1e9, n_all, rep, ms, 4 * n_ops / ms / 1e6), flush=True)
+    del ops, op_off, strand, t_start, target_id, batch
+    torch.cuda.empty_cache()

@@ -56,12 +56,12 @@ def check_stat(eng, b, sample=None):
 # ------------------------------------------------------------------------------------------------
 # K2
 # ------------------------------------------------------------------------------------------------
-DEFAULT_EXPAND_VARIANT = int(os.environ.get("WGA_EXPAND_VARIANT", "0") != "0")
+DEFAULT_EXPAND_VARIANT = {"0": 0, "2": 2}.get(os.environ.get("WGA_EXPAND_VARIANT", ""), -1)   # -1: the library picks by the batch
 
 
 def run_paf2maf(eng, b, pre=None, force_slow=0, fill=0x23, no_table=0, variant=None):
-    """stat -> layout -> expand; returns host copies.  variant: 0 = v1 of the row kernel, 1 = the planned,
-    line-complete one (wga_kernels_k2p.h); None = whatever the context runs by default"""
+    """stat -> layout -> expand; returns host copies.  variant: 0 = v1 of the row kernel, 2 = the window kernel
+    (wga_kernels_k2w.h); None = whatever the context runs by default (it picks by the batch)"""
     n = len(b["strand_neg"])
     batch = eng.make_batch(b["ops"], b["op_off"], b["strand_neg"])
     eng.set_param("expand_force_slow", force_slow)
@@ -96,8 +96,8 @@ def check_drain_min_settings(eng, b):
     for dm in (0, 1, 16, 32, 64):
         eng.set_param("expand_drain_min", dm)
         try:
-            check_paf2maf(eng, b)
-            r = run_paf2maf(eng, b)
+            check_paf2maf(eng, b, variant=0)
+            r = run_paf2maf(eng, b, variant=0)
         finally:
             eng.set_param("expand_drain_min", 0)
         assert eng.get_param("expand_drain_min") == (dm if dm else eng.get_param("expand_drain_min"))
@@ -331,24 +331,52 @@ def wide_tile_batch(eng, seed=3):
     return batch_from_texts(eng, cigars, strands, t_seqs, q_seqs)
 
 
-def planned_kernel_cases(eng):
-    """the line-complete row kernel (expand_variant 1) against the oracle: random mixtures, edge cases with odd row
-    alignments, coarse granules, records over many tiles, many records per tile, wide tiles"""
+def window_kernel_cases(eng, variant=2):
+    """the window row kernel (expand_variant 2) against the oracle: random mixtures, edge cases with odd row alignments,
+    records over many tiles, many records per tile (more than 16 and more than 64 record segments in a tile), wide tiles,
+    the op-serial walk behind it"""
     from wgatools_amd import synth
     for seed, n, mean, pool, use_m in [(1, 12, 700, 50000, False), (2, 40, 60, 20000, False), (3, 300, 3, 5000, True),
                                        (4, 3, 5000, 200000, True)]:
         b = synth.make_paf_batch(seed, n, mean, pool, use_m=use_m)
         rng = np.random.default_rng(seed)
-        check_paf2maf(eng, b, variant=1)
-        check_paf2maf(eng, b, pre=(rng.integers(0, 40, n), rng.integers(0, 40, n), rng.integers(0, 5, n)), variant=1)
+        check_paf2maf(eng, b, variant=variant)
+        check_paf2maf(eng, b, pre=(rng.integers(0, 40, n), rng.integers(0, 40, n), rng.integers(0, 5, n)), variant=variant)
     e = edge_case_batch(eng)
     ne = len(e["strand_neg"])
     rng = np.random.default_rng(5)
-    check_paf2maf(eng, e, variant=1)
-    check_paf2maf(eng, e, pre=(rng.integers(0, 33, ne), rng.integers(0, 33, ne), rng.integers(0, 3, ne)), variant=1)
-    check_paf2maf(eng, e, no_table=1, variant=1)
-    check_paf2maf(eng, synth.make_paf_batch(8, 30, 500, 60000), no_table=1, variant=1)
-    check_paf2maf(eng, wide_tile_batch(eng), variant=1)
+    check_paf2maf(eng, e, variant=variant)
+    check_paf2maf(eng, e, pre=(rng.integers(0, 33, ne), rng.integers(0, 33, ne), rng.integers(0, 3, ne)), variant=variant)
+    check_paf2maf(eng, e, force_slow=1, variant=variant)
+    check_paf2maf(eng, wide_tile_batch(eng), variant=variant)
+    for seed in (20, 21):
+        check_paf2maf(eng, synth.make_paf_batch(seed, 700, 2, 8000), variant=variant)      # hundreds of records per tile
+    for seed in (30, 31, 32, 33):
+        n = int(np.random.default_rng(seed).integers(1, 50))
+        mean = int(np.random.default_rng(seed + 1).integers(1, 2000))
+        b = synth.make_paf_batch(seed, n, mean, 100000, use_m=bool(seed & 1))
+        rng = np.random.default_rng(seed)
+        check_paf2maf(eng, b, pre=(rng.integers(0, 130, n), rng.integers(0, 130, n), rng.integers(0, 5, n)), variant=variant)
+
+
+def dense_indel_batch(eng, seed=9):
+    """stretches with an indel every few columns: more than 63 gap ops inside one 4 KB output window, three and more gap ops
+    inside sixteen columns, zero-length gap ops, gaps of thousands of columns (whole-dash windows)"""
+    rng = np.random.default_rng(seed)
+    def dense(n):
+        out = []
+        for _ in range(n):
+            out.append("%d=" % rng.integers(1, 4))
+            out.append("%d%s" % (rng.integers(0, 3), "ID"[int(rng.integers(0, 2))]))
+        return "".join(out) + "7="
+    cigars = [dense(900), "5=" + dense(300) + "9000D3=" + dense(100) + "12000I4=", dense(2500), "3=1I1D1I1D2=0I0D5=" * 40 + "1="]
+    strands = [0, 1, 1, 0]
+    t_seqs, q_seqs = [], []
+    for c in cigars:
+        t, q = consumption(c)
+        t_seqs.append(rand_seq(rng, t))
+        q_seqs.append(rand_seq(rng, q))
+    return batch_from_texts(eng, cigars, strands, t_seqs, q_seqs, pad=40)
 
 
 # ------------------------------------------------------------------------------------------------

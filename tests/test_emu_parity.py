@@ -107,30 +107,46 @@ def test_paf2maf_long_record_many_tiles(emu):
     pc.check_paf2maf(emu, nb)
 
 
-def test_paf2maf_planned_kernel(emu):
-    pc.planned_kernel_cases(emu)
+def test_paf2maf_window_kernel(emu):
+    pc.window_kernel_cases(emu)
 
 
-def test_paf2maf_planned_kernel_errors_and_long_record(emu):
+def test_paf2maf_window_kernel_dense_indels(emu):
+    b = pc.dense_indel_batch(emu)
+    pc.check_paf2maf(emu, b, variant=2)
+    pc.check_paf2maf(emu, b, variant=0)
+
+
+def test_paf2maf_window_kernel_errors_and_long_record(emu):
     cigars = ["10=", "10=", "6M1I", "3=1D", "4=2N4="]
     strands = [1, 1, 0, 0, 0]
     t = [b"ACGTACGTAC", b"ACGTACGTAC", b"ACGT", b"ACGT", b"ACGTACGT"]
     q = [b"ACGTRCGYAC", b"ACGTACGTAC", b"ACGTACG", b"AC", b"ACGTACGT"]
-    r = pc.check_paf2maf(emu, pc.batch_from_texts(emu, cigars, strands, t, q), variant=1)
+    r = pc.check_paf2maf(emu, pc.batch_from_texts(emu, cigars, strands, t, q), variant=2)
     d = r["diag"]
     assert int(d["bad_base_pos"][0]) == 2 and int(d["bad_base_pos"][1]) == int(engine.NONE)
     assert int(d["panic_op_idx"][2]) == 1 and int(d["panic_op_idx"][3]) == 1
     assert int(d["bad_op_idx"][4]) == 1
     big = synth.make_paf_batch(12, 1, 40_000, 400_000, sigma=0.01)  # one record over ~40 tiles
-    pc.check_paf2maf(emu, big, variant=1)
-    # an invalid base in the middle of a long '-' strand record (found by a plain granule, not a queued one)
+    pc.check_paf2maf(emu, big, variant=2)
+    # an invalid base in the middle of a long '-' strand record whose slice overlaps another record's
     bad = synth.make_paf_batch(13, 2, 3000, 100_000)
     bad["strand_neg"][:] = 1
     qp = bad["q_pool"].copy()
     k = int(bad["q_src_off"][1] + bad["q_src_len"][1] // 2)
     qp[k] = ord("R")
     bad["q_pool"] = qp
-    pc.check_paf2maf(emu, bad, variant=1)
+    pc.check_paf2maf(emu, bad, variant=2)
+
+
+def test_expand_variant_by_the_batch(emu):
+    """expand_variant -1 (the default): short records take the window kernel, long ones v1; the bytes are the oracle's"""
+    emu.set_param("expand_variant", -1)
+    pc.check_paf2maf(emu, synth.make_paf_batch(41, 30, 200, 30000))
+    assert emu.get_param("expand_variant_used") == 2
+    pc.check_paf2maf(emu, synth.make_paf_batch(42, 3, 3000, 90000))
+    assert emu.get_param("expand_variant_used") == 0
+    emu.set_param("expand_variant", pc.DEFAULT_EXPAND_VARIANT)
 
 
 def test_paf2maf_maf2paf_roundtrip(emu):
@@ -334,6 +350,7 @@ def test_paf2maf_drain_trials_state_machine(emu):
     total = int(reco.numpy()[-1])
     tp, qp = emu.upload(b["t_pool"]), emu.upload(b["q_pool"])
     assert emu.get_param("expand_variant") == pc.DEFAULT_EXPAND_VARIANT
+    emu.set_param("expand_variant", 0)           # the trials belong to v1 (the window kernel has no queue to drain)
     emu.set_param("expand_autotune", 1)          # forget what earlier tests' buffers (maybe at this address) taught
     ref, alive = None, []
     for buf in range(2):
@@ -353,6 +370,7 @@ def test_paf2maf_drain_trials_state_machine(emu):
     emu.paf2maf_expand(batch, counts, tws, tp, len(b["t_pool"]), to, tl, qp, len(b["q_pool"]), qo, ql, out, tro, qro, diag)
     assert emu.get_param("expand_drain_min") == 32 and emu.get_param("expand_autotune_settled") == 0
     emu.set_param("expand_autotune", 1)
+    emu.set_param("expand_variant", pc.DEFAULT_EXPAND_VARIANT)
 
 
 def test_cigar_chain(emu):

@@ -200,21 +200,52 @@ def test_output_buffer_placement_probe(gpu):
     gpu.reset_stream()
 
 
-def test_paf2maf_planned_kernel(gpu):
-    pc.planned_kernel_cases(gpu)
-    pc.check_paf2maf(gpu, synth.make_paf_batch(6, 500, 400, 2_000_000), variant=1)
-    bad = synth.make_paf_batch(13, 2, 3000, 100_000)   # an invalid base found by a plain granule of a '-' strand row
+def test_paf2maf_window_kernel(gpu):
+    pc.window_kernel_cases(gpu)
+    pc.check_paf2maf(gpu, synth.make_paf_batch(6, 500, 400, 2_000_000), variant=2)
+    b = pc.dense_indel_batch(gpu)
+    pc.check_paf2maf(gpu, b, variant=2)
+    pc.check_paf2maf(gpu, b, variant=0)
+    bad = synth.make_paf_batch(13, 2, 3000, 100_000)   # an invalid base in a '-' strand row whose slice overlaps another record's
     bad["strand_neg"][:] = 1
     qp = bad["q_pool"].copy()
     qp[int(bad["q_src_off"][1] + bad["q_src_len"][1] // 2)] = ord("R")
     bad["q_pool"] = qp
-    pc.check_paf2maf(gpu, bad, variant=1)
+    pc.check_paf2maf(gpu, bad, variant=2)
+    pc.check_paf2maf(gpu, synth.make_paf_batch(12, 1, 300_000, 1_500_000, sigma=0.01), variant=2)   # one record over ~300 tiles
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+def test_paf2maf_kernels_agree_at_size(gpu):
+    """the two row kernels over whole BASELINE-sized batches (configs[1], 500-op records, 30-op records): every byte of the
+    output text identical, on the device"""
+    import torch
+    from wgatools_amd import pipeline
+    dev = torch.device("cuda", 0)
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    for rec, mean, pool in [(100_000, 5000, 50), (1_000_000, 500, 50), (3_000_000, 30, 20)]:
+        tb = synth.make_paf_batch_torch(0x5747415F + 2, rec, mean, pool * 1_000_000, dev)
+        outs = []
+        for v in (0, 2):
+            gpu.set_param("expand_variant", v)
+            job = pipeline.Paf2MafStatJob(gpu, tb, with_text=True)
+            job.out.fill_(0x23)
+            job.bind_stream()
+            job.step()
+            torch.cuda.synchronize()
+            assert bool((job.diag == -1).all()) and gpu.get_param("expand_variant_used") == v
+            outs.append(job.out)
+            del job
+        assert bool(torch.equal(outs[0], outs[1])), (rec, mean)
+        del outs, tb
+        torch.cuda.empty_cache()
+    gpu.set_param("expand_variant", pc.DEFAULT_EXPAND_VARIANT)
+    gpu.reset_stream()
+
+
+@pytest.mark.parametrize("variant", [0, 2])
 def test_paf2maf_wide_tile_auto_slow_path(gpu, variant):
-    """one tile wider than 2^31 columns (9 D ops of 2^28-1) takes the u64 fallback by itself (variant 1: through the
-    list of such tiles that the planned kernel leaves to v1's op-serial walk)"""
+    """one tile wider than 2^31 columns (9 D ops of 2^28-1) takes the u64 fallback by itself (variant 2: through the
+    list of such tiles that the window kernel leaves to v1's op-serial walk)"""
     import torch
     gpu.set_param("expand_variant", variant)
     dev = torch.device("cuda", 0)

@@ -10,7 +10,7 @@
 #include <string>
 
 #include "wga_kernels.h"
-#include "wga_kernels_k2p.h"
+#include "wga_kernels_k2w.h"
 #ifdef WGA_STAGE2
 #include "wga_kernels2.h"
 #endif
@@ -40,7 +40,9 @@ struct wga_ctx {
   uint64_t maf_long_cols = 32768;  /* MAF blocks beyond this many columns are walked piece by piece ... */
   uint64_t maf_piece_cols = 16384; /* ... of this many columns, one wave each (test knobs: "maf_long_cols", "maf_piece_cols") */
   int expand_alias = 0;   /* 1: launch the row kernel under its second name (k_paf2maf_expand_alias) */
-  int expand_variant = 0; /* 0: v1 (fastest measured, profiles/r02_k2_experiments.md); 1: the planned, line-complete kernel of wga_kernels_k2p.h */
+  int expand_variant = -1; /* the row kernel: -1 by the batch (records below WGA_AUTO_SHORT_OPS ops on average take the window
+                              kernel of wga_kernels_k2w.h, longer ones v1), 0 v1 (wga_kernels.h), 2 the window kernel */
+  int expand_variant_used = 0;
   void* expand_dbg = nullptr;
   void* scratch = nullptr;
   size_t scratch_cap = 0;
@@ -313,7 +315,7 @@ int wga_ctx_create(int device, wga_ctx** out) {
   }
   c->stream = c->own_stream;
   /* A/B switch for measurements: WGA_EXPAND_VARIANT=0 selects v1 of the paf2maf row kernel (wga_ctx_set_param overrides) */
-  if (const char* v = getenv("WGA_EXPAND_VARIANT")) c->expand_variant = atoi(v) != 0;
+  if (const char* v = getenv("WGA_EXPAND_VARIANT")) c->expand_variant = (atoi(v) == 0 || atoi(v) == 2) ? atoi(v) : -1;
   if (const char* v = getenv("WGA_EXPAND_AUTOTUNE")) c->expand_autotune = atoi(v) != 0;
   if (const char* v = getenv("WGA_EXPAND_DRAIN_MIN")) {
     const int d = atoi(v);
@@ -390,7 +392,8 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
     return WGA_OK;
   }
   if (strcmp(name, "expand_variant") == 0) {
-    c->expand_variant = value != 0;
+    if (value != -1 && value != 0 && value != 2) return fail(WGA_E_INVALID_ARG, "expand_variant: -1 (by the batch), 0, 2", nullptr);
+    c->expand_variant = (int)value;
     return WGA_OK;
   }
   if (strcmp(name, "expand_alias") == 0) {
@@ -617,7 +620,12 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
   size_t rec_bytes = ((size_t)b->n * sizeof(wga_rec_desc) + 255) & ~(size_t)255;
   const size_t desc_bytes = (size_t)nt * sizeof(wga_tile_desc);
   const size_t list_bytes = 256 + 2 * (size_t)nt * sizeof(u32); /* two counters + the lists of wide / huge tiles */
-  if ((rc = ctx_scratch(c, rec_bytes + desc_bytes + list_bytes, &ws))) return rc;
+  /* which row kernel: the window kernel wins on short records (many row pieces per tile: -12 .. -19 % at 500 ops per record),
+   * v1 on long ones (+7 % at 5 kop, profiles/r03_k2w_experiments.md) */
+  const int variant = c->expand_variant >= 0 ? c->expand_variant : (b->n_ops / (u64)b->n < WGA_AUTO_SHORT_OPS ? 2 : 0);
+  c->expand_variant_used = variant;
+  const size_t plan_bytes = variant == 2 ? (size_t)nt * WGA_W_PLAN_WORDS * sizeof(u32) : 0;
+  if ((rc = ctx_scratch(c, rec_bytes + desc_bytes + list_bytes + plan_bytes, &ws))) return rc;
   wga_rec_desc* recs = (wga_rec_desc*)ws;
   wga_tile_desc* tdesc = (wga_tile_desc*)((char*)ws + rec_bytes);
   u32* const wide_counts = (u32*)((char*)ws + rec_bytes + desc_bytes);
@@ -649,14 +657,9 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
   a.dbg = (u64*)c->expand_dbg;
   a.tile_count = nullptr;
   a.tile_list = nullptr;
-  /* the staged kernel takes every tile below 2^31 columns; test / profiling knobs that address v1 select v1 */
-  const bool staged = c->expand_variant != 0 && !c->expand_force_slow && !c->expand_ablate && !c->expand_dbg;
-  if (staged) {
-    RT_CHECK(rt_memset(wide_counts, 0, 256, c->stream));
-    WGA_LAUNCH(k_list_wide_tiles, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const wga_tile_desc*)tdesc, (u64)nt,
-               wide_counts, wide_list);
-    LAUNCH_CHECK();
-  }
+  a.n_rec = b->n;
+  a.plan = (const u32*)((char*)ws + rec_bytes + desc_bytes + list_bytes);
+  const bool windows = variant == 2 && !c->expand_ablate; /* the profiling knobs address v1 */
   /* when the gap-touching chunks are emitted (RowSrc::drain_min) */
   bool tune_timed = false;
   {
@@ -665,7 +668,7 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
     wga_ctx::DrainTune& T = c->tune;
     if (c->expand_drain_min) {
       dm = c->expand_drain_min;
-    } else if (c->expand_autotune && !staged && !c->expand_dbg && (u64)nt >= WGA_TUNE_MIN_TILES) {
+    } else if (c->expand_autotune && !windows && !c->expand_dbg && (u64)nt >= WGA_TUNE_MIN_TILES) {
       if (!T.have_ev) {
         const char* e = rt_event_create(&T.ev[0]);
         if (!e && (e = rt_event_create(&T.ev[1]))) rt_event_destroy(T.ev[0]);
@@ -701,9 +704,31 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
     T.last = dm;
     a.drain_min = dm;
   }
+  if (windows) { /* part of the pre-pass: the tiles for the op-serial walk, the prepared pieces of one-segment tiles */
+    RT_CHECK(rt_memset(wide_counts, 0, 256, c->stream));
+    WGA_LAUNCH(k_list_slow_tiles, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const wga_tile_desc*)tdesc, (u64)nt,
+               c->expand_force_slow, wide_counts, wide_list);
+    LAUNCH_CHECK();
+    WGA_LAUNCH(k_tile_plan, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const wga_tile_desc*)tdesc, (u64)b->n_ops, d_out, d_t_fa,
+               (u64)t_fa_bytes, d_q_fa, (u64)q_fa_bytes, (u32*)a.plan);
+    LAUNCH_CHECK();
+  }
   const uint32_t slot = c->ev_n % (uint32_t)wga_ctx::kTimingRing;
   if (c->timing) RT_CHECK(rt_event_record(c->ev[2 * slot], c->stream));
-  if (!staged) {
+  if (windows) {
+    /* the window kernel; tiles beyond 2^31 columns (and every tile under "expand_force_slow") are listed for v1's op-serial walk */
+    if (c->expand_alias)
+      WGA_LAUNCH(k_paf2maf_expand_w_alias, (u32)nt, WGA_BLOCK, c->stream, a);
+    else
+      WGA_LAUNCH(k_paf2maf_expand_w, (u32)nt, WGA_BLOCK, c->stream, a);
+    LAUNCH_CHECK();
+    a.force_slow = 1;
+    a.tile_count = wide_counts;
+    a.tile_list = wide_list;
+    const u32 side_grid = nt < 256 ? (u32)nt : 256u;
+    WGA_LAUNCH(k_paf2maf_expand_list, side_grid, WGA_BLOCK, c->stream, a);
+    LAUNCH_CHECK();
+  } else {
     if (tune_timed) RT_CHECK(rt_event_record(c->tune.ev[0], c->stream));
     if (c->expand_alias)
       WGA_LAUNCH(k_paf2maf_expand_alias, (u32)nt, WGA_BLOCK, c->stream, a);
@@ -714,32 +739,6 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
       RT_CHECK(rt_event_record(c->tune.ev[1], c->stream));
       c->tune.pending = true;
     }
-  } else {
-    ExpandArgsP s;
-    s.ops = a.ops;
-    s.op_off = a.op_off;
-    s.n_ops = a.n_ops;
-    s.tdesc = tdesc;
-    s.recs = recs;
-    s.t_fa = d_t_fa;
-    s.t_fa_bytes = t_fa_bytes;
-    s.q_fa = d_q_fa;
-    s.q_fa_bytes = q_fa_bytes;
-    s.out = d_out;
-    s.diag = d_diag;
-    s.no_table = c->expand_no_table;
-    s.wide_count = wide_counts;
-    s.wide_list = wide_list;
-    WGA_LAUNCH(k_paf2maf_expand_p, (u32)nt, WGA_BLOCK, c->stream, s);
-    LAUNCH_CHECK();
-    /* normally empty: tiles of 65 536 .. 2^31 columns (u32 gap lists), tiles beyond (v1's op-serial walk) */
-    const u32 side_grid = nt < 1024 ? (u32)nt : 1024u;
-    WGA_LAUNCH(k_paf2maf_expand_p_wide, side_grid, WGA_BLOCK, c->stream, s);
-    LAUNCH_CHECK();
-    a.tile_count = wide_counts + 1;
-    a.tile_list = wide_list + nt;
-    WGA_LAUNCH(k_paf2maf_expand_list, side_grid < 256u ? side_grid : 256u, WGA_BLOCK, c->stream, a);
-    LAUNCH_CHECK();
   }
   if (c->timing) {
     RT_CHECK(rt_event_record(c->ev[2 * slot + 1], c->stream));
@@ -760,6 +759,10 @@ int wga_ctx_get_param(wga_ctx* c, const char* name, int64_t* value) {
   }
   if (strcmp(name, "expand_variant") == 0) {
     *value = (int64_t)c->expand_variant;
+    return WGA_OK;
+  }
+  if (strcmp(name, "expand_variant_used") == 0) { /* what the last wga_paf2maf_expand ran */
+    *value = (int64_t)c->expand_variant_used;
     return WGA_OK;
   }
   return fail(WGA_E_INVALID_ARG, "unknown parameter", name);

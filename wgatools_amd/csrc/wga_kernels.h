@@ -1344,7 +1344,10 @@ __global__ __launch_bounds__(256) void k_rec_desc(u32 n, const wga_cigar_counts*
   d.L = cn.match + cn.mismatch + d.I_total + d.D_total;
   /* bit 0 strand; bits 1 / 2: the target / query slice is longer than the CIGAR consumes (a tail to append) — lets the
    * row kernels skip the two tail jobs of a record, which are empty in any consistent PAF, without reading a field */
-  d.neg = (strand_neg[r] != 0 ? 1u : 0u) | (d.t_src_len + d.I_total > d.L ? 2u : 0u) | (d.q_src_len + d.D_total > d.L ? 4u : 0u);
+  /* bit 3: a slice is shorter than its CIGAR consumes — the only case in which String::insert_str can be asked to insert beyond
+   * the end (cigar.rs:507,513); the window kernel checks the gap lists of such records only */
+  d.neg = (strand_neg[r] != 0 ? 1u : 0u) | (d.t_src_len + d.I_total > d.L ? 2u : 0u) | (d.q_src_len + d.D_total > d.L ? 4u : 0u) |
+          ((d.t_src_len + d.I_total < d.L || d.q_src_len + d.D_total < d.L) ? 8u : 0u);
   out[r] = d;
 }
 
@@ -1444,6 +1447,8 @@ struct ExpandArgs {
   u64* dbg;     /* profiling: 8 s_memtime stamps per tile (NULL: off) */
   const u32* tile_count; /* k_paf2maf_expand_list: the blocks loop over tile_list[0 .. *tile_count) */
   const u32* tile_list;
+  u32 n_rec;    /* records of the batch (op_off has n_rec + 1 entries) */
+  const u32* plan; /* window kernel: the prepared pieces of one-segment tiles (k_tile_plan) */
 };
 
 #ifndef WGA_K2_BLOCKS
