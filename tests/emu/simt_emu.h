@@ -22,6 +22,7 @@
 #include <ucontext.h>
 
 #include <functional>
+#include <mutex>
 #include <vector>
 
 struct dim3 {
@@ -103,7 +104,15 @@ inline void trampoline() {
 
 static const size_t kStack = 256 * 1024;
 
+/* one kernel at a time: the emulator has ONE set of fibers and `__shared__` is function-static storage, while the host
+ * layer may drive several contexts ("devices", WGA_EMU_DEVICES) from several threads */
+inline std::mutex& launch_mutex() {
+  static std::mutex m;
+  return m;
+}
+
 inline void launch(dim3 grid, dim3 block, std::function<void()> body) {
+  std::lock_guard<std::mutex> lock(launch_mutex());
   State& s = S();
   unsigned nt = block.x * block.y * block.z;
   if (nt > 1024 || nt % 64 != 0) {

@@ -1,0 +1,35 @@
+"""`wgatools --gpus N` on CPU: the host layer linked against the emulator build, which reports WGA_EMU_DEVICES devices
+(independent contexts; kernels run one at a time).  Files byte for byte against `--gpus 1` and the oracle."""
+import os
+
+import pytest
+
+import multi_gpu_cli_cases as mc
+from wgatools_amd import build
+
+ENV = dict(os.environ, WGA_EMU_DEVICES="3")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    return build.build_cli_emu()
+
+
+def test_paf2maf_ordered_output(cli, tmp_path):
+    mc.check_paf2maf(cli, tmp_path, (2, 3), ENV)
+
+
+def test_paf2maf_first_error_in_input_order(cli, tmp_path):
+    mc.check_paf2maf_errors(cli, tmp_path, (2, 3), ENV)
+
+
+def test_stat_counts_meet_on_the_host(cli, tmp_path):
+    mc.check_stat(cli, tmp_path, (2, 3), ENV)
+
+
+def test_pafcov_targets_per_device(cli, tmp_path):
+    mc.check_pafcov(cli, tmp_path, (2, 3), ENV)
+
+
+def test_more_devices_than_visible(cli):
+    mc.check_too_many(cli, ENV, 3)

@@ -24,3 +24,21 @@ def test_dist_cli_one_rank_writes_the_command_lines_bytes(cli, tmp_path):
     dc.check_paf2maf_error(tmp_path, None, (1,), 29710)
     dc.check_pafcov(tmp_path, None, cli, (1,), 29720)
     dc.check_totals(tmp_path, None, (1,), 29740)
+
+
+def test_gpus_flag_with_the_devices_of_this_box(cli, tmp_path):
+    """`wgatools --gpus N` (C++ worker threads, one context per device) with every device this box has — one on the
+    driver's boxes, where the sharded path then runs with a single worker: the same bytes as the plain command line and
+    the oracle; one device more than visible is refused.  2 and 3 devices run on the emulator build
+    (test_emu_cli_multi.py)."""
+    import ctypes
+    import multi_gpu_cli_cases as mc
+    have = ctypes.CDLL(build.HIP_LIB).wga_device_count()
+    assert have >= 1
+    env = dict(os.environ)
+    gpus = tuple(sorted({1, have, min(have, 2)}))
+    mc.check_paf2maf(cli, tmp_path, gpus, env)
+    mc.check_paf2maf_errors(cli, tmp_path, gpus, env)
+    mc.check_stat(cli, tmp_path, gpus, env)
+    mc.check_pafcov(cli, tmp_path, gpus, env)
+    mc.check_too_many(cli, env, have)

@@ -17,7 +17,13 @@
 typedef void* wga_stream_t;
 #define WGA_LAUNCH(kernel, grid, block, stream, ...) \
   emu::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
-static inline int rt_device_count() { return 1; }
+/* WGA_EMU_DEVICES=N: the emulator reports N devices (contexts are independent host-memory arenas), so that the CPU
+ * test-suite can drive the host layer's multi-device paths (`wgatools --gpus N`) */
+static inline int rt_device_count() {
+  const char* e = getenv("WGA_EMU_DEVICES");
+  const int n = e ? atoi(e) : 1;
+  return n >= 1 && n <= 64 ? n : 1;
+}
 static inline const char* rt_set_device(int) { return nullptr; }
 static inline const char* rt_stream_create(wga_stream_t* s) {
   *s = nullptr;

@@ -16,7 +16,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <array>
 #include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <regex>
@@ -39,8 +41,9 @@ struct PhaseTimer {
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
   }
-  void mark(const char* name) { /* the time since the previous mark belongs to `name` */
-    if (!on) return;
+  std::thread::id owner = std::this_thread::get_id();
+  void mark(const char* name) { /* the time since the previous mark belongs to `name` (main thread only: device workers do not mark) */
+    if (!on || std::this_thread::get_id() != owner) return;
     const double t = now();
     for (auto& a : acc)
       if (a.first == name) {
@@ -219,13 +222,26 @@ struct DevStreamer {
   }
 };
 
+/* `wgatools --gpus N` (ours, outside the reference's flag namespace: SURVEY.md section 5): the PAF commands paf2maf, stat and
+ * pafcov shard their records over N devices by fnv1a64(target_name) % N — one worker thread and one context per device */
+static int g_gpus = 1;
+
 struct Dev {
   wga_ctx* ctx = nullptr;
+  bool own_ctx = true; /* false: the context is another Dev's (the reader's, lent to device 0's worker) */
+  int device = 0;
   std::vector<void*> owned;
   std::unique_ptr<DevStreamer> streamer; /* pinned buffers, allocated once per process */
+  Dev() {}
+  explicit Dev(int dev) : device(dev) {}
   void init() {
     if (ctx) return;
     g_timer.mark("host");
+    if (device != 0) { /* the workers' devices: a context each */
+      int rc = wga_ctx_create(device, &ctx);
+      if (rc) fail(std::string("GPU engine: ") + wga_last_error());
+      return;
+    }
     if (g_warm.started && !g_warm.taken) {
       if (g_warm.th.joinable()) g_warm.th.join();
       g_warm.taken = true;
@@ -303,7 +319,7 @@ struct Dev {
       streamer.reset();
       if (out_arena) wga_free(ctx, out_arena);
       for (void* p : owned) wga_free(ctx, p);
-      wga_ctx_destroy(ctx);
+      if (own_ctx) wga_ctx_destroy(ctx);
     }
   }
 };
@@ -494,24 +510,27 @@ struct PafChunks {
  * the host only finds the tag; digits and op chars are parsed on the GPU.  Returns the reference's
  * message for the first failing record in input order ("" if none). */
 std::string device_tokenise(Dev& d, const PafInput& in, size_t first, uint32_t n, CigarTexts& cigars,
-                            wga_cigar_batch* cb, std::vector<wga_tok_err>* all_errs = nullptr) {
-  const PafRecord* recs = in.recs.data() + first;
+                            wga_cigar_batch* cb, std::vector<wga_tok_err>* all_errs = nullptr,
+                            const size_t* which = nullptr, const uint8_t* d_text_here = nullptr) {
+  /* which: the records are in.recs[which[first + k]] (a device worker's share of the piece) instead of in.recs[first + k];
+   * d_text_here: the piece's text on THIS device (the splitter ran on device 0) */
+  auto rec_at = [&](uint32_t k) -> size_t { return which ? which[first + k] : first + k; };
   std::string blob, first_err;
   std::vector<uint64_t> toff{0};
   std::vector<uint8_t> strand;
   uint32_t n_ok = n;
   for (uint32_t k = 0; k < n; k++) {
     if (in.on_device) {
-      if (in.cg_beg[first + k] == WGA_NONE) { /* errors.rs:57: only the records before it can fail earlier */
+      if (in.cg_beg[rec_at(k)] == WGA_NONE) { /* errors.rs:57: only the records before it can fail earlier */
         first_err = "CIGAR start tag not found";
         n_ok = k;
         break;
       }
-      cigars.beg.push_back(in.cg_beg[first + k]);
-      cigars.end.push_back(in.cg_end[first + k]);
+      cigars.beg.push_back(in.cg_beg[rec_at(k)]);
+      cigars.end.push_back(in.cg_end[rec_at(k)]);
     } else {
       int err = 0;
-      std::string cg = paf_cigar_string(recs[k], &err);
+      std::string cg = paf_cigar_string(in.recs[rec_at(k)], &err);
       if (err) {
         first_err = "CIGAR start tag not found";
         n_ok = k;
@@ -521,7 +540,7 @@ std::string device_tokenise(Dev& d, const PafInput& in, size_t first, uint32_t n
       blob += cigars.back();
       toff.push_back(blob.size());
     }
-    strand.push_back(recs[k].neg ? 1 : 0);
+    strand.push_back(in.recs[rec_at(k)].neg ? 1 : 0);
   }
   if (in.on_device) cigars.file = &in.text;
   cb->n = n_ok;
@@ -533,7 +552,7 @@ std::string device_tokenise(Dev& d, const PafInput& in, size_t first, uint32_t n
   const uint8_t* d_text;
   const uint64_t *d_beg, *d_end;
   if (in.on_device) {
-    d_text = in.d_text;
+    d_text = d_text_here ? d_text_here : in.d_text;
     d_beg = d.upload(cigars.beg);
     d_end = d.upload(cigars.end);
   } else {
@@ -628,10 +647,53 @@ struct ExpandJob {
   }
 };
 
-/* Writes the text of the leading records without a diagnostic; returns their number and, when it is
+/* Where the text of a finished batch goes.  STREAM: into the command's output, in order (one device).  The other two serve
+ * `--gpus N`, where a device holds every N-th target's records and the file is still written in input order: SIZES stops
+ * after the layout scan and records every record's byte count (a record's size is known before a row byte exists), ROWS
+ * writes each record with pwrite at the offset the sizes of all devices' records gave it. */
+struct BatchSink {
+  enum Mode { STREAM, SIZES, ROWS } mode = STREAM;
+  Output* out = nullptr;
+  std::vector<uint64_t>* sizes = nullptr;         /* SIZES: by record index of the piece */
+  const std::vector<uint64_t>* offsets = nullptr; /* ROWS: file offset of every record of the piece */
+  int fd = -1;
+  const size_t* which = nullptr; /* record k of the batch is record which[first + k] of the piece */
+  size_t first = 0;
+};
+
+/* n bytes of a device buffer to a file in runs: (offset in the buffer, length, file offset), through one pinned buffer */
+void write_runs(Dev& d, int fd, const uint8_t* d_src, const std::vector<std::array<uint64_t, 3>>& runs) {
+  static const size_t kPiece = (size_t)16 << 20;
+  void* h = nullptr;
+  d.check(wga_host_alloc(d.ctx, kPiece, &h));
+  std::string err;
+  for (const auto& r : runs) {
+    for (uint64_t done = 0; done < r[1] && err.empty(); done += kPiece) {
+      const size_t len = (size_t)std::min<uint64_t>(kPiece, r[1] - done);
+      if (wga_memcpy_d2h_async(d.ctx, h, d_src + r[0] + done, len) || wga_sync(d.ctx)) {
+        err = std::string("GPU engine: ") + wga_last_error();
+        break;
+      }
+      size_t w = 0;
+      while (w < len) {
+        const ssize_t k = pwrite(fd, (const char*)h + w, len - w, (off_t)(r[2] + done + w));
+        if (k <= 0) {
+          err = "IO error:write failed";
+          break;
+        }
+        w += (size_t)k;
+      }
+    }
+    if (!err.empty()) break;
+  }
+  wga_host_free(d.ctx, h);
+  if (!err.empty()) fail(err);
+}
+
+/* Writes (or sizes) the text of the leading records without a diagnostic; returns their number and, when it is
  * below cb.n, the diagnostic of the first failing record in *first_bad. */
 uint32_t expand_batch(Dev& d, const wga_cigar_batch& cb, const ExpandJob& j, const uint8_t* d_tpool, uint64_t t_bytes,
-                      const uint8_t* d_qpool, uint64_t q_bytes, Output& out, wga_rec_diag* first_bad) {
+                      const uint8_t* d_qpool, uint64_t q_bytes, BatchSink& sink, wga_rec_diag* first_bad) {
   const uint32_t n = cb.n;
   auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
   auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
@@ -645,6 +707,10 @@ uint32_t expand_batch(Dev& d, const wga_cigar_batch& cb, const ExpandJob& j, con
   d.check(wga_paf2maf_layout(d.ctx, n, d_counts, d_tl, d_ql, d_pt, d_pq, d_po, d_tro, d_qro, d_rec));
   std::vector<uint64_t> rec_off(n + 1), tro(n), qro(n);
   d.download(rec_off.data(), d_rec, n + 1);
+  if (sink.mode == BatchSink::SIZES) { /* a record's byte count is known here, before a row byte exists */
+    for (uint32_t k = 0; k < n; k++) (*sink.sizes)[sink.which ? sink.which[sink.first + k] : sink.first + k] = rec_off[k + 1] - rec_off[k];
+    return n;
+  }
   d.download(tro.data(), d_tro, n);
   d.download(qro.data(), d_qro, n);
   std::vector<wga_cigar_counts> counts(n);
@@ -672,62 +738,84 @@ uint32_t expand_batch(Dev& d, const wga_cigar_batch& cb, const ExpandJob& j, con
     *first_bad = g;
     break;
   }
-  stream_out(d, out, d_out, (size_t)rec_off[good]);
+  if (sink.mode == BatchSink::STREAM) {
+    stream_out(d, *sink.out, d_out, (size_t)rec_off[good]);
+  } else { /* ROWS: every record where the input order puts it; neighbours in the input leave in one run */
+    std::vector<std::array<uint64_t, 3>> runs;
+    for (uint32_t k = 0; k < good; k++) {
+      const uint64_t off = (*sink.offsets)[sink.which ? sink.which[sink.first + k] : sink.first + k], len = rec_off[k + 1] - rec_off[k];
+      if (!runs.empty() && runs.back()[0] + runs.back()[1] == rec_off[k] && runs.back()[2] + runs.back()[1] == off)
+        runs.back()[1] += len;
+      else
+        runs.push_back({rec_off[k], len, off});
+    }
+    d.check(wga_sync(d.ctx));
+    write_runs(d, sink.fd, d_out, runs);
+  }
   return good;
 }
 
 /* ---- paf2maf (converter.rs:176-265) ------------------------------------------------------------- */
-int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::string& q_fa, Output& out) {
-  Dev d;
-  PafChunks chunks(input, false); /* the input is opened first, then the two indexed FASTA files (utils.rs, converter.rs:183-186) */
-  DevFasta tf, qf;
-  d.init();
-  tf.load(d, t_fa);
-  qf.load(d, q_fa);
-  g_timer.mark("fasta read + device pools");
-  out.write("#maf version=1.6 convert_from=paf t_seq_path=" + t_fa + " q_seq_path=" + q_fa + "\n");
-  uint8_t* d_tpool = tf.d_pool;
-  uint8_t* d_qpool = qf.d_pool;
-  const size_t keep_pools = d.owned.size(); /* the pools stay for the whole run */
-  const uint64_t kMaxBytes = 6ull << 30;
-  std::string pending_error;
-  PafInput in;
-  /* the input streams through in pieces (records before a failing one are written, like the reference's reader loop) */
-  for (;;) {
-  bool more = false;
-  g_timer.mark("host");
-  try {
-    more = chunks.next(d, in);
-  } catch (Error& e) {
-    pending_error = e.msg;
-  }
-  g_timer.mark("paf read + upload + split");
-  if (!more) break;
+/* one thread per device over fn(g); the first worker error (by device number) is rethrown on the caller's thread */
+static void on_devices(int ngpu, const std::function<void(int)>& fn) {
+  std::vector<std::string> werr(ngpu);
+  std::vector<std::thread> th;
+  for (int g = 0; g < ngpu; g++)
+    th.emplace_back([&, g] {
+      try {
+        fn(g);
+      } catch (Error& e) {
+        werr[g] = e.msg.empty() ? std::string("error") : e.msg;
+      } catch (std::exception& e) {
+        werr[g] = std::string("internal error: ") + e.what();
+      }
+    });
+  for (auto& t : th) t.join();
+  for (int g = 0; g < ngpu; g++)
+    if (!werr[g].empty()) fail(werr[g]);
+}
+
+/* fnv1a64(name): the sharding rule of the multi-device paths (the same hash as wgatools_amd/shard.py) */
+static uint64_t fnv1a64(const std::string& s) {
+  uint64_t h = 0xCBF29CE484222325ull;
+  for (unsigned char c : s) h = (h ^ c) * 0x100000001B3ull;
+  return h;
+}
+
+/* The body of the converter's record loop over records which[0 .. n_which) of a piece (which == nullptr: all of them), in
+ * resident batches: slices fetched (target first, then query: converter.rs:219-225), CIGARs tokenised on the device, rows
+ * expanded, text handed to the sink.  Returns the position (in `which` order) of the first failing record, or n_which;
+ * `err` = the reference's message for it. */
+size_t p2m_run(Dev& d, DevFasta& tf, DevFasta& qf, const PafInput& in, const size_t* which, size_t n_which,
+               const uint8_t* d_text_here, BatchSink sink, std::string& err) {
   const std::vector<PafRecord>& recs = in.recs;
-  const size_t keep = d.owned.size(); /* + this piece's text */
+  auto rec_of = [&](size_t k) -> const PafRecord& { return recs[which ? which[k] : k]; };
+  const uint64_t kMaxBytes = 6ull << 30;
+  const size_t keep = d.owned.size();
   size_t i0 = 0;
-  while (i0 < recs.size() && pending_error.empty()) {
+  while (i0 < n_which && err.empty()) {
     ExpandJob job;
     uint64_t est = 0, est_text = 0;
     const uint64_t kMaxText = 160ull << 20; /* ~64 M ops */
     size_t i = i0;
-    for (; i < recs.size(); i++) {
-      const PafRecord& r = recs[i];
+    for (; i < n_which; i++) {
+      const PafRecord& r = rec_of(i);
       if (i > i0 && (est_text > kMaxText || est > kMaxBytes)) break;
       uint64_t to, tl, qo, ql;
       try { /* fetch order of converter.rs:219-225: target first, then query */
         tf.fetch(r.target_name, r.target_start, r.target_end - 1, &to, &tl);
         qf.fetch(r.query_name, r.query_start, r.query_end - 1, &qo, &ql);
       } catch (Error& e) {
-        pending_error = e.msg;
+        err = e.msg;
         break;
       }
-      est_text += in.cigar_bytes(i);
+      est_text += in.cigar_bytes(which ? which[i] : i);
       job.add(to, tl, qo, ql, r.mapq, r.target_name, r.target_start, r.target_end - r.target_start, false,
               r.target_length, r.query_name, r.neg ? r.query_length - r.query_end : r.query_start, /* converter.rs:213-216 */
               r.query_end - r.query_start, r.neg, r.query_length);
       est += tl + ql + (tl + ql) / 4;
     }
+    size_t bad_at = err.empty() ? n_which : i; /* a fetch error belongs to record i */
     /* the CIGARs of records [i0, i) are tokenised on the device; a tag / tokeniser error cuts the
      * batch before the failing record (reverse_complement runs before the CIGAR is looked at, so
      * an invalid base in that record's query slice still wins: checked on the host, rare path) */
@@ -735,11 +823,11 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
     wga_cigar_batch cb;
     cb.n = 0;
     if (i > i0) {
-      const std::string terr = device_tokenise(d, in, i0, (uint32_t)(i - i0), cigars, &cb);
+      const std::string terr = device_tokenise(d, in, i0, (uint32_t)(i - i0), cigars, &cb, nullptr, which, d_text_here);
       if (!terr.empty()) {
         const size_t k = cb.n;
         std::string perr = terr;
-        const PafRecord& r = recs[i0 + k];
+        const PafRecord& r = rec_of(i0 + k);
         if (r.neg) {
           const std::string qs = qf.slice(d, job.q_off[k], job.q_len[k]);
           for (uint64_t x = job.q_len[k]; x-- > 0;) {
@@ -750,32 +838,161 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
             }
           }
         }
-        pending_error = perr;
+        err = perr;
         i = i0 + k;
+        bad_at = i;
       }
     }
     const uint32_t n = cb.n;
     if (n) {
       job.resize(n);
       wga_rec_diag g;
-      const uint32_t good = expand_batch(d, cb, job, d_tpool, tf.bytes, d_qpool, qf.bytes, out, &g);
+      sink.which = which;
+      sink.first = i0;
+      const uint32_t good = expand_batch(d, cb, job, tf.d_pool, tf.bytes, qf.d_pool, qf.bytes, sink, &g);
       if (good < n) {
         const uint32_t k = good;
         if (g.bad_base_pos != WGA_NONE) { /* utils.rs:97 */
           char c = qf.at(d, job.q_off[k] + job.q_len[k] - 1 - g.bad_base_pos);
-          pending_error = std::string("Invalid Base: `") + c + "`";
+          err = std::string("Invalid Base: `") + c + "`";
         } else if (g.bad_op_idx < g.panic_op_idx) { /* errors.rs:59 */
-          pending_error = "CIGAR OP `" + cigar_op_token_at(cigars[k], g.bad_op_idx) + "` invalid";
+          err = "CIGAR OP `" + cigar_op_token_at(cigars[k], g.bad_op_idx) + "` invalid";
         } else {
-          pending_error = "panic: String::insert_str beyond the end of the fetched sequence (cigar.rs:507,513)";
+          err = "panic: String::insert_str beyond the end of the fetched sequence (cigar.rs:507,513)";
         }
+        bad_at = i0 + k;
       }
     }
     d.release_to(keep); /* this batch's buffers */
+    if (!err.empty()) return bad_at;
     i0 = i;
   }
-  d.release_to(keep_pools);
-  if (!pending_error.empty()) break;
+  return n_which;
+}
+
+/* `wgatools --gpus N paf2maf`: a piece of the PAF is framed once (device 0 splits it), every record belongs to device
+ * fnv1a64(target_name) % N, and N worker threads — one context, one pair of sequence pools each — run the same record loop
+ * over their share: a first pass for the byte count of every record (K1 + the layout scan; no row byte yet), then, with the
+ * file offsets those sizes give in INPUT order, a second pass that expands the rows and pwrite()s every record where it
+ * belongs.  No row byte crosses devices; the first failing record in input order ends the run and the file ends in front
+ * of it, as the reference's serial loop leaves it (converter.rs:196-263). */
+int cmd_paf2maf_multi(const std::string* input, const std::string& t_fa, const std::string& q_fa, Output& out, int ngpu) {
+  std::vector<std::unique_ptr<Dev>> devs;
+  for (int g = 0; g < ngpu; g++) devs.emplace_back(new Dev(g));
+  PafChunks chunks(input, false);
+  std::vector<DevFasta> tf(ngpu), qf(ngpu);
+  auto on_all = [&](const std::function<void(int)>& fn) { on_devices(ngpu, fn); };
+  on_all([&](int g) {
+    devs[g]->init();
+    tf[g].load(*devs[g], t_fa);
+    qf[g].load(*devs[g], q_fa);
+  });
+  g_timer.mark("fasta read + device pools");
+  std::vector<size_t> keep_pools(ngpu);
+  for (int g = 0; g < ngpu; g++) keep_pools[g] = devs[g]->owned.size(); /* the pools stay for the whole run */
+  out.write("#maf version=1.6 convert_from=paf t_seq_path=" + t_fa + " q_seq_path=" + q_fa + "\n");
+  uint64_t pos0 = 0;
+  const int fd = out.plain_fd(&pos0);
+  if (fd < 0) fail("internal error: --gpus needs a plain output file");
+  uint64_t file_pos = pos0;
+  std::string pending_error;
+  PafInput in;
+  for (;;) {
+    bool more = false;
+    try {
+      more = chunks.next(*devs[0], in);
+    } catch (Error& e) {
+      pending_error = e.msg;
+    }
+    g_timer.mark("paf read + upload + split");
+    if (!more) break;
+    const size_t n = in.recs.size();
+    std::vector<std::vector<size_t>> mine(ngpu);
+    for (size_t i = 0; i < n; i++) mine[fnv1a64(in.recs[i].target_name) % (uint64_t)ngpu].push_back(i);
+    std::vector<const uint8_t*> d_text(ngpu, nullptr);
+    std::vector<uint64_t> sizes(n, 0), offsets(n + 1, 0);
+    std::vector<size_t> bad_at(ngpu, n); /* input index of a worker's first failing record */
+    std::vector<std::string> bad_msg(ngpu);
+    std::string text16;
+    if (in.on_device && ngpu > 1) text16 = in.text + std::string(16, '\0');
+    auto pass = [&](BatchSink::Mode mode, size_t upto) {
+      on_all([&](int g) {
+        Dev& d = *devs[g];
+        if (in.on_device && !d_text[g])
+          d_text[g] = g == 0 ? in.d_text : d.upload((const uint8_t*)text16.data(), text16.size());
+        std::vector<size_t>& w = mine[g];
+        size_t cnt = std::lower_bound(w.begin(), w.end(), upto) - w.begin(); /* records in front of the first known error */
+        BatchSink sink;
+        sink.mode = mode;
+        sink.sizes = &sizes;
+        sink.offsets = &offsets;
+        sink.fd = fd;
+        std::string err;
+        const size_t k = p2m_run(d, tf[g], qf[g], in, w.data(), cnt, d_text[g], sink, err);
+        if (k < cnt && w[k] < bad_at[g]) {
+          bad_at[g] = w[k];
+          bad_msg[g] = err;
+        }
+      });
+    };
+    pass(BatchSink::SIZES, n);
+    size_t first_bad = n;
+    for (int g = 0; g < ngpu; g++) first_bad = std::min(first_bad, bad_at[g]);
+    offsets[0] = file_pos;
+    for (size_t i = 0; i < n; i++) offsets[i + 1] = offsets[i] + (i < first_bad ? sizes[i] : 0);
+    g_timer.mark("sizes (K1 + layout on every device)");
+    pass(BatchSink::ROWS, first_bad);
+    for (int g = 0; g < ngpu; g++) first_bad = std::min(first_bad, bad_at[g]);
+    g_timer.mark("rows + copy out + write");
+    file_pos = offsets[first_bad];
+    for (int g = 0; g < ngpu; g++) devs[g]->release_to(keep_pools[g]); /* the piece's text on every device */
+    if (first_bad < n) {
+      for (int g = 0; g < ngpu; g++)
+        if (bad_at[g] == first_bad) pending_error = bad_msg[g];
+      break;
+    }
+  }
+  /* the file ends behind the last record in front of the first failing one (later records of other devices may have
+   * been written beyond it) */
+  if (ftruncate(fd, (off_t)file_pos) != 0) fail("IO error:truncate failed");
+  out.advance(file_pos - pos0);
+  out.close();
+  if (!pending_error.empty()) fail(pending_error);
+  return 0;
+}
+
+int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::string& q_fa, Output& out) {
+  {
+    uint64_t pos = 0;
+    if (g_gpus > 1 && out.plain_fd(&pos) >= 0) return cmd_paf2maf_multi(input, t_fa, q_fa, out, g_gpus);
+  }
+  Dev d;
+  PafChunks chunks(input, false); /* the input is opened first, then the two indexed FASTA files (utils.rs, converter.rs:183-186) */
+  DevFasta tf, qf;
+  d.init();
+  tf.load(d, t_fa);
+  qf.load(d, q_fa);
+  g_timer.mark("fasta read + device pools");
+  out.write("#maf version=1.6 convert_from=paf t_seq_path=" + t_fa + " q_seq_path=" + q_fa + "\n");
+  const size_t keep_pools = d.owned.size(); /* the pools stay for the whole run */
+  std::string pending_error;
+  PafInput in;
+  /* the input streams through in pieces (records before a failing one are written, like the reference's reader loop) */
+  for (;;) {
+    bool more = false;
+    g_timer.mark("host");
+    try {
+      more = chunks.next(d, in);
+    } catch (Error& e) {
+      pending_error = e.msg;
+    }
+    g_timer.mark("paf read + upload + split");
+    if (!more) break;
+    BatchSink sink;
+    sink.out = &out;
+    p2m_run(d, tf, qf, in, nullptr, in.recs.size(), nullptr, sink, pending_error);
+    d.release_to(keep_pools);
+    if (!pending_error.empty()) break;
   }
   out.close();
   if (!pending_error.empty()) fail(pending_error);
@@ -783,16 +1000,88 @@ int cmd_paf2maf(const std::string* input, const std::string& t_fa, const std::st
 }
 
 /* ---- stat (stat.rs) ----------------------------------------------------------------------------- */
+/* `wgatools --gpus N stat -f paf`: the records of a piece are counted on device fnv1a64(target_name) % N; the per-record
+ * counters meet on the host, where the Pair group-by runs as on one device (stat.rs:167-223).  No collective: what a
+ * reduction over devices would sum — the grand totals — is the last line of the host's merge. */
+static void stat_piece_multi(std::vector<std::unique_ptr<Dev>>& devs, const PafInput& pin, std::vector<wga_cigar_counts>& counts) {
+  const int ngpu = (int)devs.size();
+  const size_t n = pin.recs.size();
+  std::vector<std::vector<size_t>> mine(ngpu);
+  for (size_t i = 0; i < n; i++) mine[fnv1a64(pin.recs[i].target_name) % (uint64_t)ngpu].push_back(i);
+  std::vector<size_t> bad_at(ngpu, n);
+  std::vector<std::string> bad_msg(ngpu);
+  std::string text16;
+  if (pin.on_device && ngpu > 1) text16 = pin.text + std::string(16, '\0');
+  on_devices(ngpu, [&](int g) {
+    Dev& d = *devs[g];
+    d.init();
+    const std::vector<size_t>& w = mine[g];
+    if (w.empty()) return;
+    const size_t keep = d.owned.size();
+    const uint8_t* d_text = nullptr;
+    if (pin.on_device) d_text = g == 0 ? pin.d_text : d.upload((const uint8_t*)text16.data(), text16.size());
+    CigarTexts cigars;
+    wga_cigar_batch cb;
+    const std::string e = device_tokenise(d, pin, 0, (uint32_t)w.size(), cigars, &cb, nullptr, w.data(), d_text);
+    const uint32_t m = cb.n; /* records before this device's first tag / tokeniser error */
+    if (m) {
+      auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)m * sizeof(wga_cigar_counts));
+      auto* d_diag = (wga_rec_diag*)d.alloc((size_t)m * sizeof(wga_rec_diag));
+      d.check(wga_cigar_stat(d.ctx, &cb, d_counts, d_diag, nullptr));
+      std::vector<wga_rec_diag> diag(m);
+      std::vector<wga_cigar_counts> c(m);
+      d.download(diag.data(), d_diag, m);
+      d.download(c.data(), d_counts, m);
+      for (uint32_t k = 0; k < m; k++) {
+        if (diag[k].bad_op_idx != WGA_NONE) {
+          bad_at[g] = w[k];
+          bad_msg[g] = "CIGAR OP `" + cigar_op_token_at(cigars[k], diag[k].bad_op_idx) + "` invalid";
+          break;
+        }
+        counts[w[k]] = c[k];
+      }
+    }
+    if (!e.empty() && w[m] < bad_at[g]) {
+      bad_at[g] = w[m];
+      bad_msg[g] = e;
+    }
+    d.release_to(keep); /* this piece's buffers (the reader's own copy of the text on device 0 is its to release) */
+  });
+  size_t first_bad = n;
+  for (int g = 0; g < ngpu; g++) first_bad = std::min(first_bad, bad_at[g]);
+  if (first_bad < n) /* buffered driver: nothing is written on error; the first failing record in input order speaks */
+    for (int g = 0; g < ngpu; g++)
+      if (bad_at[g] == first_bad) fail(bad_msg[g]);
+}
+
 int cmd_stat_paf(const std::string* input, bool each, Output& out) {
   Dev d;
   PafChunks chunks(input, false);
   std::vector<StatInput> in;
   PafInput pin;
+  std::vector<std::unique_ptr<Dev>> devs; /* --gpus N: devices 1 .. N - 1 next to `d` */
   while (chunks.next(d, pin)) { /* one piece of the file at a time; only the per-record statistics are kept */
     const std::vector<PafRecord>& recs = pin.recs;
     const uint32_t n = (uint32_t)recs.size();
     std::vector<wga_cigar_counts> counts(n);
     d.init();
+    if (g_gpus > 1) {
+      if (devs.empty()) {
+        devs.emplace_back(new Dev(0));
+        devs[0]->ctx = d.ctx; /* device 0's context is the reader's */
+        devs[0]->own_ctx = false;
+        for (int g = 1; g < g_gpus; g++) devs.emplace_back(new Dev(g));
+      }
+      stat_piece_multi(devs, pin, counts);
+      in.reserve(in.size() + n);
+      for (uint32_t k = 0; k < n; k++) {
+        const PafRecord& r = recs[k];
+        in.push_back(StatInput{r.target_name, r.query_name, r.target_length, r.query_length, r.target_start,
+                               r.query_start, recstat_from(counts[k])});
+      }
+      d.release_all();
+      continue;
+    }
     CigarTexts cigars;
     wga_cigar_batch cb;
     const std::string e = device_tokenise(d, pin, 0, n, cigars, &cb);
@@ -1409,7 +1698,9 @@ int cmd_chain2maf(const std::string* input, const std::string& t_fa, const std::
     if (n) {
       ChainBatch b = chain_device_batch(d, &recs[i0], n);
       wga_rec_diag g;
-      const uint32_t good = expand_batch(d, b.cb, job, d_tpool, tf.bytes, d_qpool, qf.bytes, out, &g);
+      BatchSink sink;
+      sink.out = &out;
+      const uint32_t good = expand_batch(d, b.cb, job, d_tpool, tf.bytes, d_qpool, qf.bytes, sink, &g);
       d.check(wga_sync(d.ctx));
       while (d.owned.size() > 2) d.release(d.owned.back());
       if (good < n) {
@@ -1819,7 +2110,198 @@ int cmd_dotplot(const std::string* input, const std::string& format, const std::
 }
 
 /* ---- pafcov (pafcov.rs:13-83) --------------------------------------------------------------------- */
+/* `wgatools --gpus N pafcov`: a target's coverage array lives on device fnv1a64(target_name) % N, which accumulates the
+ * records of its targets, turns the marks into counts and formats its targets' BED text (pafcov.rs:18-64).  The text is
+ * written in the reference's target order: a first pass asks every device for the byte count of each of its 4 M-position
+ * chunks, the prefix over (target, chunk) gives every chunk its file offset, the second pass formats and pwrite()s.  No
+ * collective: the element-wise merge of the reference's per-thread arrays (pafcov.rs:29-53) has nothing left to merge. */
+int cmd_pafcov_multi(const std::string* input, Output& out, int ngpu) {
+  std::vector<std::unique_ptr<Dev>> devs;
+  for (int g = 0; g < ngpu; g++) devs.emplace_back(new Dev(g));
+  Dev& d0 = *devs[0];
+  std::vector<std::string> targets;
+  std::unordered_map<std::string, uint32_t> tid;
+  std::vector<uint64_t> cov_len;
+  uint64_t n_records = 0;
+  auto note_targets = [&](const std::vector<PafRecord>& recs) {
+    for (const auto& r : recs) {
+      if (tid.find(r.target_name) == tid.end()) {
+        tid.emplace(r.target_name, (uint32_t)targets.size());
+        targets.push_back(r.target_name);
+        cov_len.push_back(r.target_length);
+      }
+    }
+    n_records += recs.size();
+  };
+  PafInput whole;
+  bool single = false;
+  if (!input) {
+    whole = load_paf(d0, input, false);
+    note_targets(whole.recs);
+    single = true;
+  } else {
+    PafChunks first(input, false);
+    PafInput pin;
+    if (first.next(d0, whole)) {
+      note_targets(whole.recs);
+      if (!first.next(d0, pin)) {
+        single = true;
+      } else {
+        if (whole.d_text) d0.release(whole.d_text);
+        whole = PafInput();
+        do {
+          note_targets(pin.recs);
+          d0.release_all();
+        } while (first.next(d0, pin));
+      }
+    }
+  }
+  const uint32_t nt = (uint32_t)targets.size();
+  uint64_t pos0 = 0;
+  const int fd = out.plain_fd(&pos0);
+  if (fd < 0) fail("internal error: --gpus needs a plain output file");
+  uint64_t file_end = pos0;
+  if (n_records) {
+    /* the targets of every device, in the reference's order, and its coverage arrays */
+    std::vector<int> owner(nt);
+    std::vector<uint32_t> local(nt);
+    std::vector<std::vector<uint64_t>> off_g(ngpu), len_g(ngpu);
+    std::vector<uint64_t> total_g(ngpu, 0);
+    for (uint32_t t = 0; t < nt; t++) {
+      const int g = (int)(fnv1a64(targets[t]) % (uint64_t)ngpu);
+      owner[t] = g;
+      local[t] = (uint32_t)off_g[g].size();
+      off_g[g].push_back(total_g[g]);
+      len_g[g].push_back(cov_len[t]);
+      total_g[g] += (cov_len[t] + 3) & ~3ull;
+    }
+    std::vector<int32_t*> d_cov(ngpu, nullptr);
+    std::vector<uint64_t*> d_off(ngpu, nullptr), d_len(ngpu, nullptr);
+    std::vector<size_t> keep(ngpu, 0);
+    on_devices(ngpu, [&](int g) {
+      Dev& d = *devs[g];
+      d.init();
+      if (off_g[g].empty()) return;
+      d_cov[g] = (int32_t*)d.alloc((total_g[g] + 4) * 4);
+      d.check(wga_memset(d.ctx, d_cov[g], 0, (total_g[g] + 4) * 4));
+      d_off[g] = d.upload(off_g[g]);
+      d_len[g] = d.upload(len_g[g]);
+    });
+    for (int g = 0; g < ngpu; g++) keep[g] = devs[g]->owned.size();
+    auto accumulate = [&](const PafInput& pin) {
+      const size_t n = pin.recs.size();
+      std::vector<std::vector<size_t>> mine(ngpu);
+      for (size_t i = 0; i < n; i++) mine[owner[tid[pin.recs[i].target_name]]].push_back(i);
+      std::vector<size_t> bad_at(ngpu, n);
+      std::vector<std::string> bad_msg(ngpu);
+      std::string text16;
+      if (pin.on_device && ngpu > 1) text16 = pin.text + std::string(16, '\0');
+      on_devices(ngpu, [&](int g) {
+        Dev& d = *devs[g];
+        const std::vector<size_t>& w = mine[g];
+        if (w.empty()) return;
+        const size_t mark = d.owned.size();
+        const uint8_t* d_text = nullptr;
+        if (pin.on_device) d_text = g == 0 ? pin.d_text : d.upload((const uint8_t*)text16.data(), text16.size());
+        std::vector<uint64_t> t_start;
+        std::vector<uint32_t> target_id;
+        for (size_t i : w) {
+          target_id.push_back(local[tid[pin.recs[i].target_name]]);
+          t_start.push_back(pin.recs[i].target_start);
+        }
+        CigarTexts cigars;
+        wga_cigar_batch cb;
+        const std::string terr = device_tokenise(d, pin, 0, (uint32_t)w.size(), cigars, &cb, nullptr, w.data(), d_text);
+        if (!terr.empty()) { /* update_cov_vec takes every op char: only the tokeniser can fail */
+          bad_at[g] = w[cb.n];
+          bad_msg[g] = terr;
+          return;
+        }
+        d.check(wga_pafcov_accumulate(d.ctx, &cb, d.upload(target_id), d.upload(t_start), d_off[g], d_len[g], d_cov[g], total_g[g]));
+        d.check(wga_sync(d.ctx));
+        if (g != 0) d.release_to(mark); /* device 0: the reader releases its piece */
+      });
+      size_t first_bad = n;
+      for (int g = 0; g < ngpu; g++) first_bad = std::min(first_bad, bad_at[g]);
+      if (first_bad < n)
+        for (int g = 0; g < ngpu; g++)
+          if (bad_at[g] == first_bad) fail(bad_msg[g]); /* buffered driver: nothing is written */
+    };
+    if (single) {
+      accumulate(whole);
+    } else {
+      PafChunks second(input, false);
+      PafInput pin;
+      while (second.next(d0, pin)) {
+        accumulate(pin);
+        d0.check(wga_sync(d0.ctx));
+        d0.release_to(keep[0]);
+      }
+    }
+    on_devices(ngpu, [&](int g) {
+      Dev& d = *devs[g];
+      if (off_g[g].empty()) return;
+      d.check(wga_pafcov_finalize(d.ctx, (uint32_t)off_g[g].size(), d_off[g], d_len[g], d_cov[g]));
+    });
+    /* BED text, a few million positions at a time (pafcov.rs:56-60): sizes, offsets, then text at its place */
+    const uint32_t kChunk = 4u << 20;
+    std::vector<std::vector<uint64_t>> chunk_bytes(nt), chunk_off(nt);
+    for (uint32_t t = 0; t < nt; t++) chunk_bytes[t].assign((size_t)((cov_len[t] + kChunk - 1) / kChunk), 0);
+    auto format_pass = [&](bool fill) {
+      on_devices(ngpu, [&](int g) {
+        Dev& d = *devs[g];
+        if (off_g[g].empty()) return;
+        const size_t mark = d.owned.size();
+        auto* d_loff = (uint64_t*)d.alloc(((size_t)kChunk + 1) * 8);
+        uint8_t* d_txt = nullptr;
+        uint64_t txt_cap = 0;
+        for (uint32_t t = 0; t < nt; t++) {
+          if (owner[t] != g) continue;
+          auto* d_name = d.upload((const uint8_t*)targets[t].data(), targets[t].size());
+          size_t c = 0;
+          for (uint64_t pos = 0; pos < cov_len[t]; pos += kChunk, c++) {
+            const uint32_t cnt = (uint32_t)std::min<uint64_t>(kChunk, cov_len[t] - pos);
+            const int32_t* cp = d_cov[g] + off_g[g][local[t]] + pos;
+            d.check(wga_pafcov_format(d.ctx, d_name, (uint32_t)targets[t].size(), cp, pos, cnt, d_loff, nullptr));
+            uint64_t bytes = 0;
+            d.download(&bytes, d_loff + cnt, 1);
+            if (!fill) {
+              chunk_bytes[t][c] = bytes;
+              continue;
+            }
+            if (bytes > txt_cap) {
+              if (d_txt) d.release(d_txt);
+              txt_cap = bytes + bytes / 4;
+              d_txt = (uint8_t*)d.alloc(txt_cap);
+            }
+            d.check(wga_pafcov_format(d.ctx, d_name, (uint32_t)targets[t].size(), cp, pos, cnt, d_loff, d_txt));
+            d.check(wga_sync(d.ctx));
+            write_runs(d, fd, d_txt, {{0, bytes, chunk_off[t][c]}});
+          }
+        }
+        d.release_to(mark);
+      });
+    };
+    format_pass(false);
+    for (uint32_t t = 0; t < nt; t++) {
+      chunk_off[t].resize(chunk_bytes[t].size());
+      for (size_t c = 0; c < chunk_bytes[t].size(); c++) {
+        chunk_off[t][c] = file_end;
+        file_end += chunk_bytes[t][c];
+      }
+    }
+    format_pass(true);
+  }
+  out.advance(file_end - pos0);
+  out.close();
+  return 0;
+}
+
 int cmd_pafcov(const std::string* input, Output& out) {
+  {
+    uint64_t pos = 0;
+    if (g_gpus > 1 && out.plain_fd(&pos) >= 0) return cmd_pafcov_multi(input, out, g_gpus);
+  }
   Dev d;
   /* A file is read twice in line-aligned pieces — first for the targets (names in first-appearance order, array
    * length = target_length of the first record seen), then to accumulate — so that only one piece of text is held at
@@ -2750,6 +3232,13 @@ int main(int argc, char** argv) {
         rewrite = true;
       else if (a == "-t" || a == "--threads")
         (void)val("--threads");
+      else if (a == "--gpus") { /* ours: shard the PAF commands' records over N devices (paf2maf, stat -f paf, pafcov) */
+        const std::string v = val("--gpus");
+        char* end = nullptr;
+        const long n = strtol(v.c_str(), &end, 10);
+        if (!end || *end || n < 1 || n > 64) fail("invalid value '" + v + "' for '--gpus <N>'");
+        g_gpus = (int)n;
+      }
       else if (a.size() >= 2 && a[0] == '-' && a.find_first_not_of('v', 1) == std::string::npos)
         ; /* -v, -vv, ... logging level */
       else if (a == "--verbose")
@@ -2766,6 +3255,8 @@ int main(int argc, char** argv) {
       usage();
       return 2;
     }
+    if (g_gpus > 1 && g_gpus > wga_device_count())
+      fail("--gpus " + std::to_string(g_gpus) + ": only " + std::to_string(wga_device_count()) + " device(s) visible");
     if (cmd.compare(0, 5, "__fmt") != 0) g_warm.start(); /* the HIP runtime comes up while the input is opened and read */
     /* hidden hooks for the CPU unit tests of the host formatters (no GPU involved) */
     if (cmd == "__fmt_f32") {
