@@ -428,6 +428,15 @@ int wga_pafpseudo_fill(wga_ctx*, const wga_cigar_batch*, int base_mode, const ui
                        const uint64_t* d_q_src_len, const uint64_t* d_skip, uint8_t* d_out,
                        const uint64_t* d_dst_off, wga_rec_diag* d_diag);
 
+/* ---- several devices in one process: the coverage reduce of a target whose records are spread over the devices
+ *      (the element-wise merge of the reference's per-thread arrays, pafcov.rs:29-53, moved onto xGMI) ---------------------
+ * ctxs[g] = a context on device g (ngpu distinct devices), d_bufs[g] = `count` int32 counters on that device.  After the
+ * call, slice g of the index space — [count * g / ngpu, count * (g + 1) / ngpu) — of d_bufs[g] holds the element-wise sum
+ * over all devices (a reduce-scatter); the rest of every buffer is unchanged.  Every device pulls its slice from every
+ * other device (hipMemcpyPeer: all links busy at once, no ring) and adds it; the call synchronises all the contexts
+ * before and after.  One host thread drives it (the contexts' owner threads must be idle). */
+int wga_reduce_scatter_i32(wga_ctx** ctxs, int ngpu, int32_t** d_bufs, uint64_t count);
+
 /* ---- utility: exclusive scan of n u64 values on device (d_out[n+1], d_out[n] = total) ------- */
 int wga_exclusive_scan_u64(wga_ctx*, uint32_t n, const uint64_t* d_in, uint64_t* d_out);
 

@@ -121,6 +121,17 @@ def check_pafcov(cli, tmp_path, gpus, env):
         rc, _, err = run(cli, "--gpus", str(g), "pafcov", paf, "-o", outp, env=e)
         assert rc == 0, (g, chunk, err)
         assert open(outp, "rb").read() == want, (g, chunk)
+    # --spread: records dealt out round robin, every device holds partial counts of every target, one reduce-scatter over
+    # the devices (wga_reduce_scatter_i32), every device formats the slice of the counter space it ends up with
+    for g in gpus:
+        for chunk in (None, "2000"):
+            e = dict(env)
+            if chunk:
+                e["WGA_CHUNK_BYTES"] = chunk
+            outp = str(tmp_path / ("cs%d%s.bed" % (g, chunk)))
+            rc, _, err = run(cli, "--gpus", str(g), "--spread", "pafcov", paf, "-o", outp, env=e)
+            assert rc == 0, (g, chunk, err)
+            assert open(outp, "rb").read() == want, (g, chunk, "spread")
     # stdin: the input is taken whole
     outp = str(tmp_path / "cs.bed")
     r = subprocess.run([cli, "--gpus", str(gpus[-1]), "pafcov", "-o", outp], stdin=open(paf, "rb"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)

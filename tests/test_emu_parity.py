@@ -556,3 +556,36 @@ def test_arena_alloc(emu):
     b, rates, chosen = emu.arena_alloc(64, 1)
     assert b.ptr and chosen == 0
     b.free()
+
+
+def test_reduce_scatter_i32(monkeypatch):
+    """wga_reduce_scatter_i32 over three emulated devices: slice g of buffer g = the sum over the devices, the rest of every
+    buffer is untouched; one context is a no-op; two contexts on one device are refused"""
+    import ctypes as C
+    from wgatools_amd import build, _lib
+    monkeypatch.setenv("WGA_EMU_DEVICES", "3")
+    lib = _lib.load(build.build_emu())
+    engs = [engine.Engine(g, lib) for g in range(3)]
+    rng = np.random.default_rng(4)
+    for count in (0, 1, 7, 1000, 70001):
+        host = [rng.integers(-1000, 1000, max(count, 1), dtype=np.int32) for _ in range(3)]
+        bufs = [e.upload(h) for e, h in zip(engs, host)]
+        cx = (C.c_void_p * 3)(*[e.ctx for e in engs])
+        bp = (C.c_void_p * 3)(*[b.ptr for b in bufs])
+        assert lib.wga_reduce_scatter_i32(cx, 3, bp, count) == 0
+        total = host[0][:count].astype(np.int64) + host[1][:count] + host[2][:count]
+        for g in range(3):
+            lo, hi = count * g // 3, count * (g + 1) // 3
+            got = bufs[g].numpy()[:count]
+            assert (got[lo:hi] == total[lo:hi]).all(), (count, g)
+            mask = np.ones(count, dtype=bool)
+            mask[lo:hi] = False
+            assert (got[mask] == host[g][:count][mask]).all(), (count, g)
+    one = (C.c_void_p * 1)(engs[0].ctx)
+    b1 = (C.c_void_p * 1)(bufs[0].ptr)
+    assert lib.wga_reduce_scatter_i32(one, 1, b1, 5) == 0
+    dup = (C.c_void_p * 2)(engs[0].ctx, engs[0].ctx)
+    b2 = (C.c_void_p * 2)(bufs[0].ptr, bufs[1].ptr)
+    assert lib.wga_reduce_scatter_i32(dup, 2, b2, 5) == -1
+    for e in engs:
+        e.close()

@@ -81,6 +81,7 @@ PROTOTYPES = {
     "wga_pafcov_finalize": (C.c_int, [vp, C.c_uint32, vp, vp, vp]),
     "wga_pafpseudo_fill": (C.c_int, [vp, C.POINTER(CigarBatch), C.c_int, vp, C.c_uint64, vp, vp,
                                      vp, vp, vp, vp]),
+    "wga_reduce_scatter_i32": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(vp), C.c_uint64]),
     "wga_exclusive_scan_u64": (C.c_int, [vp, C.c_uint32, vp, vp]),
 }
 

@@ -564,6 +564,46 @@ int wga_cigar_stat(wga_ctx* c, const wga_cigar_batch* b, wga_cigar_counts* d_cou
   return WGA_OK;
 }
 
+int wga_reduce_scatter_i32(wga_ctx** ctxs, int ngpu, int32_t** d_bufs, uint64_t count) {
+  if (!ctxs || !d_bufs || ngpu < 1) return fail(WGA_E_INVALID_ARG, "null argument", nullptr);
+  for (int g = 0; g < ngpu; g++) {
+    if (!ctxs[g] || (count && !d_bufs[g])) return fail(WGA_E_INVALID_ARG, "null context / buffer", nullptr);
+    for (int h = 0; h < g; h++)
+      if (ctxs[h]->device == ctxs[g]->device) return fail(WGA_E_INVALID_ARG, "two contexts on one device", nullptr);
+  }
+  if (ngpu == 1 || count == 0) return WGA_OK;
+  int rc;
+  for (int g = 0; g < ngpu; g++) { /* what the owners enqueued has happened */
+    if ((rc = ctx_bind(ctxs[g]))) return rc;
+    RT_CHECK(rt_sync(ctxs[g]->stream));
+  }
+  /* every device pulls its slice from every other one into its scratch arena, then adds: the pulls of all devices are in
+   * flight together (point-to-point xGMI: every link carries one slice) */
+  for (int g = 0; g < ngpu; g++) {
+    wga_ctx* c = ctxs[g];
+    const u64 lo = count * (u64)g / (u64)ngpu, hi = count * (u64)(g + 1) / (u64)ngpu, n = hi - lo;
+    if (n == 0) continue;
+    if ((rc = ctx_bind(c))) return rc;
+    void* ws;
+    if ((rc = ctx_scratch(c, (size_t)n * 4 * (size_t)(ngpu - 1), &ws))) return rc;
+    int k = 0;
+    for (int h = 0; h < ngpu; h++) {
+      if (h == g) continue;
+      int* tmp = (int*)ws + (size_t)k * n;
+      RT_CHECK(rt_peer_copy(tmp, c->device, d_bufs[h] + lo, ctxs[h]->device, (size_t)n * 4, c->stream));
+      const u32 grid = (u32)(n / 256u < 65536u ? (n + 255u) / 256u : 65536u);
+      WGA_LAUNCH(k_add_i32, grid, WGA_BLOCK, c->stream, (int*)d_bufs[g] + lo, (const int*)tmp, (u64)n);
+      LAUNCH_CHECK();
+      k++;
+    }
+  }
+  for (int g = 0; g < ngpu; g++) {
+    if ((rc = ctx_bind(ctxs[g]))) return rc;
+    RT_CHECK(rt_sync(ctxs[g]->stream));
+  }
+  return WGA_OK;
+}
+
 int wga_exclusive_scan_u64(wga_ctx* c, uint32_t n, const uint64_t* d_in, uint64_t* d_out) {
   int rc = ctx_bind(c);
   if (rc) return rc;

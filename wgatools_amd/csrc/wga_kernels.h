@@ -1909,4 +1909,10 @@ __global__ __launch_bounds__(256) void k_arena_probe(u32x4_a16* buf, u64 half /*
   for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < half; i += stride) dst[i] = src[i];
 }
 
+/* ---- wga_reduce_scatter_i32: a += b over n counters (16 B per thread where the pointers allow it) ------------------------ */
+__global__ __launch_bounds__(256) void k_add_i32(int* __restrict__ a, const int* __restrict__ b, u64 n) {
+  const u64 stride = (u64)gridDim.x * 256u;
+  for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) a[i] += b[i];
+}
+
 #endif /* WGA_KERNELS_H */

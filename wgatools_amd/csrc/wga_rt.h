@@ -63,6 +63,10 @@ static inline const char* rt_d2h_async(void* h, const void* d, size_t n, wga_str
   memcpy(h, d, n);
   return nullptr;
 }
+static inline const char* rt_peer_copy(void* dst, int, const void* src, int, size_t n, wga_stream_t) {
+  memcpy(dst, src, n);
+  return nullptr;
+}
 static inline const char* rt_launch_error() { return nullptr; }
 typedef int rt_event_t;
 static inline const char* rt_event_create(rt_event_t* e) {
@@ -109,6 +113,9 @@ static inline const char* rt_host_alloc(void** p, size_t n) { return rt_err(hipH
 static inline const char* rt_host_free(void* p) { return rt_err(hipHostFree(p)); }
 static inline const char* rt_d2h_async(void* h, const void* d, size_t n, wga_stream_t s) {
   return rt_err(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s));
+}
+static inline const char* rt_peer_copy(void* dst, int dst_dev, const void* src, int src_dev, size_t n, wga_stream_t s) {
+  return rt_err(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, n, s));
 }
 static inline const char* rt_launch_error() { return rt_err(hipGetLastError()); }
 typedef hipEvent_t rt_event_t;

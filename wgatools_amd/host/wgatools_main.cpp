@@ -225,6 +225,7 @@ struct DevStreamer {
 /* `wgatools --gpus N` (ours, outside the reference's flag namespace: SURVEY.md section 5): the PAF commands paf2maf, stat and
  * pafcov shard their records over N devices by fnv1a64(target_name) % N — one worker thread and one context per device */
 static int g_gpus = 1;
+static bool g_spread = false; /* `--spread` (with --gpus N, pafcov): deal the records out round robin and sum the coverage over the devices */
 
 struct Dev {
   wga_ctx* ctx = nullptr;
@@ -2115,7 +2116,7 @@ int cmd_dotplot(const std::string* input, const std::string& format, const std::
  * written in the reference's target order: a first pass asks every device for the byte count of each of its 4 M-position
  * chunks, the prefix over (target, chunk) gives every chunk its file offset, the second pass formats and pwrite()s.  No
  * collective: the element-wise merge of the reference's per-thread arrays (pafcov.rs:29-53) has nothing left to merge. */
-int cmd_pafcov_multi(const std::string* input, Output& out, int ngpu) {
+int cmd_pafcov_multi(const std::string* input, Output& out, int ngpu, bool spread) {
   std::vector<std::unique_ptr<Dev>> devs;
   for (int g = 0; g < ngpu; g++) devs.emplace_back(new Dev(g));
   Dev& d0 = *devs[0];
@@ -2170,10 +2171,13 @@ int cmd_pafcov_multi(const std::string* input, Output& out, int ngpu) {
     for (uint32_t t = 0; t < nt; t++) {
       const int g = (int)(fnv1a64(targets[t]) % (uint64_t)ngpu);
       owner[t] = g;
-      local[t] = (uint32_t)off_g[g].size();
-      off_g[g].push_back(total_g[g]);
-      len_g[g].push_back(cov_len[t]);
-      total_g[g] += (cov_len[t] + 3) & ~3ull;
+      for (int h = 0; h < ngpu; h++) {
+        if (!spread && h != g) continue; /* --spread: every device holds (its share of) every target */
+        if (h == g || spread) local[t] = (uint32_t)off_g[h].size();
+        off_g[h].push_back(total_g[h]);
+        len_g[h].push_back(cov_len[t]);
+        total_g[h] += (cov_len[t] + 3) & ~3ull;
+      }
     }
     std::vector<int32_t*> d_cov(ngpu, nullptr);
     std::vector<uint64_t*> d_off(ngpu, nullptr), d_len(ngpu, nullptr);
@@ -2188,10 +2192,13 @@ int cmd_pafcov_multi(const std::string* input, Output& out, int ngpu) {
       d_len[g] = d.upload(len_g[g]);
     });
     for (int g = 0; g < ngpu; g++) keep[g] = devs[g]->owned.size();
+    uint64_t recs_seen = 0;
     auto accumulate = [&](const PafInput& pin) {
       const size_t n = pin.recs.size();
       std::vector<std::vector<size_t>> mine(ngpu);
-      for (size_t i = 0; i < n; i++) mine[owner[tid[pin.recs[i].target_name]]].push_back(i);
+      for (size_t i = 0; i < n; i++) /* --spread deals the records out round robin (one hot target: hash sharding would not spread it) */
+        mine[spread ? (int)((recs_seen + i) % (uint64_t)ngpu) : owner[tid[pin.recs[i].target_name]]].push_back(i);
+      recs_seen += n;
       std::vector<size_t> bad_at(ngpu, n);
       std::vector<std::string> bad_msg(ngpu);
       std::string text16;
@@ -2243,10 +2250,44 @@ int cmd_pafcov_multi(const std::string* input, Output& out, int ngpu) {
       if (off_g[g].empty()) return;
       d.check(wga_pafcov_finalize(d.ctx, (uint32_t)off_g[g].size(), d_off[g], d_len[g], d_cov[g]));
     });
-    /* BED text, a few million positions at a time (pafcov.rs:56-60): sizes, offsets, then text at its place */
+    /* --spread: every device holds partial counts of every target (the scan is linear: partial marks -> partial counts);
+     * one reduce-scatter over the whole counter space leaves device g with the summed slice g (wga_reduce_scatter_i32) */
+    std::vector<uint64_t> slice_lo(ngpu + 1, 0);
+    if (spread) {
+      std::vector<wga_ctx*> cx(ngpu);
+      std::vector<int32_t*> bufs(ngpu);
+      for (int g = 0; g < ngpu; g++) {
+        cx[g] = devs[g]->ctx;
+        bufs[g] = d_cov[g];
+        slice_lo[g] = total_g[0] * (uint64_t)g / (uint64_t)ngpu;
+      }
+      slice_lo[ngpu] = total_g[0];
+      if (wga_reduce_scatter_i32(cx.data(), ngpu, bufs.data(), total_g[0])) fail(std::string("GPU engine: ") + wga_last_error());
+    }
+    /* BED text, a few million positions at a time (pafcov.rs:56-60): sizes, offsets, then text at its place.  A chunk =
+     * positions [pos, pos + cnt) of target t on the device that holds their counts. */
     const uint32_t kChunk = 4u << 20;
-    std::vector<std::vector<uint64_t>> chunk_bytes(nt), chunk_off(nt);
-    for (uint32_t t = 0; t < nt; t++) chunk_bytes[t].assign((size_t)((cov_len[t] + kChunk - 1) / kChunk), 0);
+    struct Chunk {
+      uint32_t t, cnt;
+      uint64_t pos, bytes, off;
+      int g;
+    };
+    std::vector<Chunk> chunks_all;
+    for (uint32_t t = 0; t < nt; t++) {
+      uint64_t pos = 0;
+      while (pos < cov_len[t]) {
+        uint64_t cnt = std::min<uint64_t>(kChunk, cov_len[t] - pos);
+        int g = owner[t];
+        if (spread) { /* cut at the slice boundary of the counter space */
+          const uint64_t x = off_g[0][t] + pos;
+          g = 0;
+          while (g + 1 < ngpu && slice_lo[g + 1] <= x) g++;
+          cnt = std::min<uint64_t>(cnt, slice_lo[g + 1] - x);
+        }
+        chunks_all.push_back(Chunk{t, (uint32_t)cnt, pos, 0, 0, g});
+        pos += cnt;
+      }
+    }
     auto format_pass = [&](bool fill) {
       on_devices(ngpu, [&](int g) {
         Dev& d = *devs[g];
@@ -2255,40 +2296,38 @@ int cmd_pafcov_multi(const std::string* input, Output& out, int ngpu) {
         auto* d_loff = (uint64_t*)d.alloc(((size_t)kChunk + 1) * 8);
         uint8_t* d_txt = nullptr;
         uint64_t txt_cap = 0;
-        for (uint32_t t = 0; t < nt; t++) {
-          if (owner[t] != g) continue;
-          auto* d_name = d.upload((const uint8_t*)targets[t].data(), targets[t].size());
-          size_t c = 0;
-          for (uint64_t pos = 0; pos < cov_len[t]; pos += kChunk, c++) {
-            const uint32_t cnt = (uint32_t)std::min<uint64_t>(kChunk, cov_len[t] - pos);
-            const int32_t* cp = d_cov[g] + off_g[g][local[t]] + pos;
-            d.check(wga_pafcov_format(d.ctx, d_name, (uint32_t)targets[t].size(), cp, pos, cnt, d_loff, nullptr));
-            uint64_t bytes = 0;
-            d.download(&bytes, d_loff + cnt, 1);
-            if (!fill) {
-              chunk_bytes[t][c] = bytes;
-              continue;
-            }
-            if (bytes > txt_cap) {
-              if (d_txt) d.release(d_txt);
-              txt_cap = bytes + bytes / 4;
-              d_txt = (uint8_t*)d.alloc(txt_cap);
-            }
-            d.check(wga_pafcov_format(d.ctx, d_name, (uint32_t)targets[t].size(), cp, pos, cnt, d_loff, d_txt));
-            d.check(wga_sync(d.ctx));
-            write_runs(d, fd, d_txt, {{0, bytes, chunk_off[t][c]}});
+        uint32_t name_of = 0xFFFFFFFFu;
+        uint8_t* d_name = nullptr;
+        for (Chunk& c : chunks_all) {
+          if (c.g != g) continue;
+          if (name_of != c.t) {
+            d_name = d.upload((const uint8_t*)targets[c.t].data(), targets[c.t].size());
+            name_of = c.t;
           }
+          const int32_t* cp = d_cov[g] + off_g[g][local[c.t]] + c.pos;
+          d.check(wga_pafcov_format(d.ctx, d_name, (uint32_t)targets[c.t].size(), cp, c.pos, c.cnt, d_loff, nullptr));
+          uint64_t bytes = 0;
+          d.download(&bytes, d_loff + c.cnt, 1);
+          if (!fill) {
+            c.bytes = bytes;
+            continue;
+          }
+          if (bytes > txt_cap) {
+            if (d_txt) d.release(d_txt);
+            txt_cap = bytes + bytes / 4;
+            d_txt = (uint8_t*)d.alloc(txt_cap);
+          }
+          d.check(wga_pafcov_format(d.ctx, d_name, (uint32_t)targets[c.t].size(), cp, c.pos, c.cnt, d_loff, d_txt));
+          d.check(wga_sync(d.ctx));
+          write_runs(d, fd, d_txt, {{0, bytes, c.off}});
         }
         d.release_to(mark);
       });
     };
     format_pass(false);
-    for (uint32_t t = 0; t < nt; t++) {
-      chunk_off[t].resize(chunk_bytes[t].size());
-      for (size_t c = 0; c < chunk_bytes[t].size(); c++) {
-        chunk_off[t][c] = file_end;
-        file_end += chunk_bytes[t][c];
-      }
+    for (Chunk& c : chunks_all) {
+      c.off = file_end;
+      file_end += c.bytes;
     }
     format_pass(true);
   }
@@ -2297,10 +2336,10 @@ int cmd_pafcov_multi(const std::string* input, Output& out, int ngpu) {
   return 0;
 }
 
-int cmd_pafcov(const std::string* input, Output& out) {
+int cmd_pafcov(const std::string* input, Output& out, bool spread) {
   {
     uint64_t pos = 0;
-    if (g_gpus > 1 && out.plain_fd(&pos) >= 0) return cmd_pafcov_multi(input, out, g_gpus);
+    if (g_gpus > 1 && out.plain_fd(&pos) >= 0) return cmd_pafcov_multi(input, out, g_gpus, spread);
   }
   Dev d;
   /* A file is read twice in line-aligned pieces — first for the targets (names in first-appearance order, array
@@ -3232,6 +3271,8 @@ int main(int argc, char** argv) {
         rewrite = true;
       else if (a == "-t" || a == "--threads")
         (void)val("--threads");
+      else if (a == "--spread")
+        g_spread = true;
       else if (a == "--gpus") { /* ours: shard the PAF commands' records over N devices (paf2maf, stat -f paf, pafcov) */
         const std::string v = val("--gpus");
         char* end = nullptr;
@@ -3487,7 +3528,7 @@ int main(int argc, char** argv) {
       return cmd_pafpseudo(input, outfile, rewrite, has_fasta ? &fasta : nullptr, target.empty() ? nullptr : &target);
     if (cmd == "pafcov" || cmd == "pc") {
       out.open(outfile, rewrite);
-      return cmd_pafcov(input, out);
+      return cmd_pafcov(input, out, g_spread);
     }
     fail("subcommand `" + cmd + "` is not on the CIGAR hot path and is not provided by this engine");
   } catch (Error& e) {
