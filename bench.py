@@ -7,8 +7,9 @@ One "step" = one pass of the hot path over one HBM-resident batch of synthetic P
   K2 wga_paf2maf_expand (parse_cigar_to_insert + reverse_complement, cigar.rs:492-551)
   + a reduction of the stat totals (RCCL all-reduce over xGMI when N > 1)
 Workload at N=1 = BASELINE.json configs[1]: 100 000 records, mean CIGAR 5 kop, 2 x 50 Mb
-sequence pools.  N > 1: weak scaling — every rank owns its own shard of records (records are
-independent; real runs shard by hash(target_name)), no data-path collective.
+sequence pools.  N > 1: the SAME global batch (strong scaling: total work fixed), every rank takes the records
+fnv1a64(target_name) % N gives it, one all-reduce of the per-record output sizes per step (ordered output) and one of the
+stat totals; row bytes never cross GPUs.  `--scaling weak` gives every rank its own shard of --records instead.
 
 Prints ONE JSON line on rank 0.  `python bench.py` defaults to N=1, 5 steps, 2 warm-up steps.
 """
@@ -235,11 +236,14 @@ def main():
     ap.add_argument("--neg-frac", type=float, default=0.5)
     ap.add_argument("--m-only", action="store_true", help="variant of configs[1] with = / X merged into M ops")
     ap.add_argument("--no-extras", action="store_true", help="skip the genome-sized-pool and 50-kop-record K2 measurements")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak (default): --records per GPU; strong: --records in all, sharded by hash(target_name) %% N")
-    ap.add_argument("--targets", type=int, default=64, help="strong scaling: number of target names")
-    ap.add_argument("--zipf", type=float, default=1.2, help="strong scaling: skew of the records over the targets "
-                                                            "(P(target k) ~ 1 / (k + 1)^zipf; 0 = uniform)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong (default): ONE global batch of --records whatever N — the file-shaped job: every rank takes the "
+                         "records fnv1a64(target_name) %% N gives it, ordered output through one all-reduce of the record sizes; "
+                         "weak: --records per GPU, independently generated shards")
+    ap.add_argument("--targets", type=int, default=1600, help="strong scaling: number of target names (default: the contigs of a "
+                                                              "64-genome all-to-all, 64 x 25)")
+    ap.add_argument("--zipf", type=float, default=0.0, help="strong scaling: skew of the records over the targets "
+                                                            "(P(target k) ~ 1 / (k + 1)^zipf; 0 = uniform, the default)")
     ap.add_argument("--no-placement-probe", action="store_true", help="take the first output buffer the allocator returns instead "
                     "of the arena the library places (wga_arena_alloc, --placement-candidates)")
     ap.add_argument("--placement-candidates", type=int, default=8)
@@ -269,7 +273,7 @@ def main():
         k, v = kv.split("=")
         eng.set_param(k, int(v))
     seed = 0x5747415F + 2 + rank
-    strong = args.scaling == "strong"
+    strong = args.scaling == "strong" and world > 1   # at N = 1 the global batch IS the rank's batch: nothing to shard or order
     if strong:
         # ONE global batch whatever N: record lengths and target names from the global seed; a rank generates the records
         # fnv1a64(target_name) % N gives it (the product's sharding rule), so the skew over targets becomes load imbalance
@@ -388,6 +392,24 @@ def main():
         assert bool((job.diag == -1).all()), "kernel reported per-record errors on clean synthetic input"
 
     per_rank_ops, imb = multigpu.imbalance(job.n_ops, dist if world > 1 else None, dev)
+    # N > 1: every rank checks a few of the rows ITS timed steps wrote against the oracle (the checker leg of the line: the only
+    # use bench.py makes of oracle/ besides the N = 1 cpu baseline), and the ranks agree on the verdict — an N-GPU line is
+    # a real partition AND byte-verified
+    ranks_checked = None
+    if world > 1 and args.check and not args.param:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import parity_cases as pc
+        ok = 1
+        for i in torch.linspace(0, tb["n"] - 1, min(args.check, tb["n"])).long().tolist():
+            r = synth.torch_batch_record_to_numpy(tb, i)
+            et, eq = pc.oracle_rows(r, 0)
+            gt, gq = job.record_rows(i)
+            ok &= int(gt == et and gq == eq)
+        okt = torch.tensor([ok], dtype=torch.int64, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        assert int(okt.item()) == 1, "a rank's rows differ from the oracle"
+        ranks_checked = "%d records on each of %d ranks bit-identical to oracle rows" % (min(args.check, tb["n"]), world)
     if rank == 0:
         k_stat = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
         k_layout = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
@@ -413,7 +435,7 @@ def main():
             "config": {
                 "workload": "BASELINE configs[1]: paf2maf+stat, %d records%s x mean %d ops "
                             "(lognormal s=0.5; =/X/I/D mix), 2 x %d Mb pools, strand 50/50, "
-                            "HBM-resident" % (args.records, "" if strong else "/GPU", args.mean_ops, args.pool_mb),
+                            "HBM-resident" % (args.records, "" if args.scaling == "strong" else "/GPU", args.mean_ops, args.pool_mb),
                 "records_per_gpu": args.records, "ops_per_gpu": job.n_ops,
                 "columns_per_gpu": int((tb["mx"] + tb["i"] + tb["d"]).sum()),
                 "output_bytes_per_gpu": job.out_bytes,
@@ -451,6 +473,8 @@ def main():
                 },
             },
         }
+        if ranks_checked:
+            result["parity_spot_check"] = ranks_checked
         result["metric_scope"] = ("kernel-only: K1 + layout + K2 (+ totals) on packed ops and sequence pools resident in HBM; no "
                                   "CIGAR tokenising, PAF / FASTA parsing, PCIe or file I/O — file-to-file command-line timings "
                                   "are in profiles/ (r02_cli_e2e.txt) and DESIGN.md section 6")

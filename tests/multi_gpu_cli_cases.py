@@ -64,7 +64,7 @@ def check_paf2maf_errors(cli, tmp_path, gpus, env):
         cases.append((with_cigar(2, "5=99999999999999999999999M", "len"), 2, "Parse `99999999999999999999999` Into Integer Error"))
     for n, (path, upto, text) in enumerate(cases):
         want_n = dc.expected_maf(b, mapq, t_fa, q_fa, upto)
-        for g in [1] + list(gpus):
+        for g in sorted(set([1] + list(gpus))):
             for chunk in (None, "4000"):
                 e = dict(env)
                 if chunk:
