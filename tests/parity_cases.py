@@ -812,6 +812,58 @@ def check_paf_call_events(eng, ops, op_off, svlen, snp):
     return int(o[-1])
 
 
+def long_record_ops(seed, n_long, long_ops, bad_in=None):
+    """records mixed short / long: every `long` one holds `long_ops` ops; bad_in = (record, op index) gets an op the walks
+    stop at.  Piece boundaries (multiples of 256) are made nasty: an indel right behind a boundary, a continuation piece
+    of a split indel starting a piece, X ops at the cut."""
+    from wgatools_amd import synth
+    rng = np.random.default_rng(seed)
+    L = (1 << 28) - 1
+    recs = []
+    for k in range(n_long):
+        ops, _, _, _ = synth.make_ops(rng, 1, long_ops, sigma=0.01, min_ops=long_ops, max_ops=long_ops)
+        ops = ops.copy()
+        for cut in range(256, len(ops) - 2, 256):
+            kind = (cut // 256 + k) % 4
+            if kind == 0:
+                ops[cut - 1] = (7 << 4) | 7          # '=' then an indel that opens the piece
+                ops[cut] = (60 << 4) | (1 + (cut // 256) % 2)
+            elif kind == 1:
+                ops[cut - 1] = (L << 4) | 1          # a split I whose continuation starts the piece
+                ops[cut] = (5 << 4) | 9
+                ops[cut - 2] = (3 << 4) | 7
+            elif kind == 2:
+                ops[cut - 1] = (2 << 4) | 8          # X | X across the cut
+                ops[cut] = (1 << 4) | 8
+        recs.append(ops)
+        short, _, _, _ = synth.make_ops(rng, 3, 40)
+        recs.append(short)
+    if bad_in is not None:
+        recs[bad_in[0]][bad_in[1]] = (4 << 4) | 3     # N
+    ops = np.concatenate(recs).astype(np.uint32)
+    off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+    return ops, off
+
+
+def check_paf_call_long_records(eng, mops=2):
+    """K7 with records cut into pieces: small knobs (pieces of 256 ops) on nasty cuts and a stop inside a middle piece,
+    then one record of `mops` million ops with the product's piece size"""
+    eng.set_param("op_long_ops", 600)
+    eng.set_param("op_piece_ops", 256)
+    try:
+        ops, off = long_record_ops(5, 3, 2300)
+        for svlen, snp in ((0, True), (8, False), (50, True)):
+            check_paf_call_events(eng, ops, off, svlen, snp)
+        ops, off = long_record_ops(6, 3, 1500, bad_in=(2, 700))
+        check_paf_call_events(eng, ops, off, 3, True)
+    finally:
+        eng.set_param("op_long_ops", 16384)
+        eng.set_param("op_piece_ops", 8192)
+    if mops:
+        ops, off = long_record_ops(7, 1, mops * 1_000_000)
+        check_paf_call_events(eng, ops, off, 20, True)
+
+
 # ------------------------------------------------------------------------------------------------
 # K8 device tokeniser (and the host packer) vs the oracle's token stream
 # ------------------------------------------------------------------------------------------------
@@ -1072,6 +1124,39 @@ def check_dotplot(eng, ops, op_off, strands, cutoff, seed=3):
         assert int(cc[i]) == len(want), (i, int(cc[i]), len(want))
         assert (got == want).all(), (i, got[:4], want[:4])
     assert (sg[int(oo[-1]):] == 0x2323232323232323).all()
+
+
+def check_dotplot_long_records(eng, mops=2):
+    """K12 with records cut into pieces: small knobs on nasty cuts (an M segment open across many pieces, breaks right at a
+    cut, pieces without any event), a split indel in a long record (the serial walk), then one record of `mops` million ops"""
+    eng.set_param("op_long_ops", 600)
+    eng.set_param("op_piece_ops", 256)
+    try:
+        for seed, cutoff in ((5, 0), (5, 50), (6, 5)):
+            ops, off = long_record_ops(seed, 3, 2300)
+            ops = ops.copy()
+            ops[(ops & 15) == 9] = (7 << 4) | 7          # no continuation pieces here: the piece walk itself
+            ops[(ops >> 4) == (1 << 28) - 1] = (9 << 4) | 1
+            n = len(off) - 1
+            check_dotplot(eng, ops, off, [k & 1 for k in range(n)], cutoff)
+        # a long record of small indels only behind its first op: one M segment over every piece; pieces of I ops only
+        mk = lambda *p: [(ln << 4) | c for c, ln in p]
+        rec = mk((7, 9)) + mk((1, 2), (2, 1)) * 700 + mk((7, 4)) + mk((1, 1)) * 600 + mk((2, 80), (7, 3))
+        ops = np.array(rec, dtype=np.uint32)
+        off = np.array([0, len(rec)], dtype=np.uint64)
+        for cutoff in (0, 5, 100):
+            check_dotplot(eng, ops, off, [1], cutoff)
+        ops, off = long_record_ops(8, 2, 1500)           # split indels: continuation pieces -> serial walk
+        check_dotplot(eng, ops, off, [0] * (len(off) - 1), 10)
+    finally:
+        eng.set_param("op_long_ops", 16384)
+        eng.set_param("op_piece_ops", 8192)
+    if mops:
+        ops, off = long_record_ops(7, 1, mops * 1_000_000)
+        ops = ops.copy()
+        ops[(ops & 15) == 9] = (7 << 4) | 7
+        ops[(ops >> 4) == (1 << 28) - 1] = (9 << 4) | 1
+        check_dotplot(eng, ops, off, [1] * (len(off) - 1), 30)
 
 
 def check_dotplot_maf(eng, pairs, strands, cutoff):

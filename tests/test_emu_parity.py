@@ -294,6 +294,16 @@ def test_paf_call_events(emu):
         pc.check_paf_call_events(emu, ops, off, svlen, snp)
 
 
+def test_paf_call_long_records_in_pieces(emu):
+    pc.check_paf_call_long_records(emu, mops=0)
+    ops, off = pc.long_record_ops(7, 1, 40_000)     # the product's piece size: 5 pieces (2 Mop records run on the GPU)
+    pc.check_paf_call_events(emu, ops, off, 20, True)
+
+
+def test_dotplot_long_records_in_pieces(emu):
+    pc.check_dotplot_long_records(emu, mops=0)
+
+
 def test_device_tokeniser(emu):
     pc.check_tokeniser(emu, pc.TOKENISER_EDGE_TEXTS)
     b = synth.make_paf_batch(41, 10, 300, 300000)

@@ -37,6 +37,8 @@ struct wga_ctx {
     uint64_t tiles = 0;
     rt_event_t ev[2];
   } tune;
+  uint64_t op_long_ops = 16384;  /* op walks with one wave per record (K7 call events, K12 dotplot segments): records beyond this many ops ... */
+  uint64_t op_piece_ops = 8192;  /* ... are walked in pieces of this many (a multiple of 256), one wave each (test knobs: "op_long_ops", "op_piece_ops") */
   uint64_t maf_long_cols = 32768;  /* MAF blocks beyond this many columns are walked piece by piece ... */
   uint64_t maf_piece_cols = 16384; /* ... of this many columns, one wave each (test knobs: "maf_long_cols", "maf_piece_cols") */
   int expand_alias = 0;   /* 1: launch the row kernel under its second name (k_paf2maf_expand_alias) */
@@ -294,6 +296,41 @@ static int maf_long_blocks(wga_ctx* c, u32 n, const u8* d_rows, const u64* d_t_o
   return WGA_OK;
 }
 
+/* the piece table of the op walks whose records can be long (K7, K12): per record the number of pieces (0: the one-wave
+ * kernel keeps it), their exclusive scan and the total, in the context's scratch arena, followed by `per_piece` bytes per
+ * piece.  *np = pieces, *piece_off (n + 1 entries), *pieces = the per-piece area. */
+static int op_piece_table(wga_ctx* c, const wga_cigar_batch* b, size_t per_piece, u32* np, u64** piece_off, void** pieces) {
+  const u32 n = b->n;
+  int rc;
+  void* ws;
+  const size_t head = ((size_t)n * 2 + 2 + (size_t)n / 1024 + 4) * sizeof(u64);
+  *np = 0;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    const size_t want = head + 64 + (size_t)*np * per_piece;
+    if ((rc = ctx_scratch(c, want, &ws))) return rc;
+    u64* npieces = (u64*)ws;
+    u64* off = npieces + n;
+    u64* partial = off + n + 1;
+    WGA_LAUNCH(k_op_piece_counts, (n + 255u) / 256u, WGA_BLOCK, c->stream, n, (const u64*)b->d_op_off, (u64)c->op_long_ops,
+               (u64)c->op_piece_ops, npieces);
+    LAUNCH_CHECK();
+    ScanPlain sp;
+    sp.in = npieces;
+    if ((rc = run_scan_ws(c, sp, n, off, partial))) return rc;
+    u64 total = 0;
+    RT_CHECK(rt_d2h(&total, off + n, sizeof total, c->stream));
+    if (total > 0xFFFFFFF0ull) return fail(WGA_E_INVALID_ARG, "too many pieces for one call", nullptr);
+    *piece_off = off;
+    *pieces = (char*)ws + ((head + 63) & ~(size_t)63);
+    if ((u32)total == *np || c->scratch_cap >= head + 64 + (size_t)total * per_piece) {
+      *np = (u32)total;
+      return WGA_OK;
+    }
+    *np = (u32)total; /* the arena must grow: regrowing frees it, so the head is rebuilt */
+  }
+  return WGA_OK;
+}
+
 extern "C" {
 
 int wga_abi_version(void) { return WGA_ABI_VERSION; }
@@ -384,6 +421,16 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
   }
   if (strcmp(name, "expand_no_table") == 0) {
     c->expand_no_table = value != 0;
+    return WGA_OK;
+  }
+  if (strcmp(name, "op_long_ops") == 0) {
+    if (value < 1) return fail(WGA_E_INVALID_ARG, "must be positive", name);
+    c->op_long_ops = (uint64_t)value;
+    return WGA_OK;
+  }
+  if (strcmp(name, "op_piece_ops") == 0) {
+    if (value < 256 || (value & 255)) return fail(WGA_E_INVALID_ARG, "a positive multiple of 256", name);
+    c->op_piece_ops = (uint64_t)value;
     return WGA_OK;
   }
   if (strcmp(name, "maf_long_cols") == 0 || strcmp(name, "maf_piece_cols") == 0) {
@@ -1077,14 +1124,36 @@ int wga_cigar_dotplot(wga_ctx* c, const wga_cigar_batch* b, uint64_t cutoff, con
     if (!d_seg_cnt) return fail(WGA_E_INVALID_ARG, "d_seg_cnt null", nullptr);
     WGA_LAUNCH(k_dotplot_segments<false>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
                (const u64*)b->d_op_off, b->d_strand_neg, (u64)cutoff, (const u64*)d_t_start,
-               (const u64*)d_q_start, (u64*)d_seg_cnt, (u64*)nullptr, (const u64*)nullptr);
+               (const u64*)d_q_start, (u64*)d_seg_cnt, (u64*)nullptr, (const u64*)nullptr, (u64)c->op_long_ops);
   } else {
     if (!d_seg_off) return fail(WGA_E_INVALID_ARG, "d_seg_off null", nullptr);
     WGA_LAUNCH(k_dotplot_segments<true>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
                (const u64*)b->d_op_off, b->d_strand_neg, (u64)cutoff, (const u64*)d_t_start,
-               (const u64*)d_q_start, (u64*)nullptr, (u64*)d_segs, (const u64*)d_seg_off);
+               (const u64*)d_q_start, (u64*)nullptr, (u64*)d_segs, (const u64*)d_seg_off, (u64)c->op_long_ops);
   }
   LAUNCH_CHECK();
+  /* records beyond op_long_ops: pieces over the whole chip (as in wga_paf_call_events) */
+  u32 np = 0;
+  u64* piece_off = nullptr;
+  void* pieces = nullptr;
+  if ((rc = op_piece_table(c, b, sizeof(wga_dot_piece), &np, &piece_off, &pieces))) return rc;
+  if (np == 0) return WGA_OK;
+  wga_dot_piece* pc = (wga_dot_piece*)pieces;
+  const u32 grid = np < 4u * 2048u ? (np + 3u) / 4u : 2048u;
+  WGA_LAUNCH((k_dotplot_pieces<0>), grid, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off, b->d_strand_neg,
+             (u64)cutoff, (const u64*)d_t_start, (const u64*)d_q_start, (const u64*)piece_off, (u64)c->op_piece_ops, pc,
+             (u64*)nullptr, (const u64*)nullptr);
+  LAUNCH_CHECK();
+  WGA_LAUNCH(k_dotplot_piece_scan, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off,
+             b->d_strand_neg, (u64)cutoff, (const u64*)d_t_start, (const u64*)d_q_start, (const u64*)piece_off, pc,
+             d_segs ? (u64*)nullptr : (u64*)d_seg_cnt);
+  LAUNCH_CHECK();
+  if (d_segs) {
+    WGA_LAUNCH((k_dotplot_pieces<1>), grid, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off, b->d_strand_neg,
+               (u64)cutoff, (const u64*)d_t_start, (const u64*)d_q_start, (const u64*)piece_off, (u64)c->op_piece_ops, pc,
+               (u64*)d_segs, (const u64*)d_seg_off);
+    LAUNCH_CHECK();
+  }
   return WGA_OK;
 }
 
@@ -1111,8 +1180,28 @@ int wga_paf_call_events(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, in
   if (d_ev && !d_ev_off) return fail(WGA_E_INVALID_ARG, "d_ev_off null", nullptr);
   WGA_LAUNCH(k_paf_call_events, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
              (const u64*)b->d_op_off, (u64)svlen, (u32)(snp != 0), (u64*)d_ev_cnt, (u64*)d_ev,
-             (const u64*)d_ev_off);
+             (const u64*)d_ev_off, (u64)c->op_long_ops);
   LAUNCH_CHECK();
+  /* records beyond op_long_ops: pieces over the whole chip (both calls of the protocol walk the pieces for their sums; the
+   * fill call then walks them again with their start states) */
+  u32 np = 0;
+  u64* piece_off = nullptr;
+  void* pieces = nullptr;
+  if ((rc = op_piece_table(c, b, sizeof(wga_call_piece), &np, &piece_off, &pieces))) return rc;
+  if (np == 0) return WGA_OK;
+  wga_call_piece* pc = (wga_call_piece*)pieces;
+  const u32 grid = np < 4u * 2048u ? (np + 3u) / 4u : 2048u;
+  WGA_LAUNCH((k_paf_call_pieces<0>), grid, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off, (u64)svlen,
+             (u32)(snp != 0), (const u64*)piece_off, (u64)c->op_piece_ops, pc, (u64*)nullptr, (const u64*)nullptr);
+  LAUNCH_CHECK();
+  WGA_LAUNCH(k_paf_call_piece_scan, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, b->n, (const u64*)piece_off, pc,
+             d_ev ? (u64*)nullptr : (u64*)d_ev_cnt);
+  LAUNCH_CHECK();
+  if (d_ev) {
+    WGA_LAUNCH((k_paf_call_pieces<1>), grid, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off, (u64)svlen,
+               (u32)(snp != 0), (const u64*)piece_off, (u64)c->op_piece_ops, pc, (u64*)d_ev, (const u64*)d_ev_off);
+    LAUNCH_CHECK();
+  }
   return WGA_OK;
 }
 

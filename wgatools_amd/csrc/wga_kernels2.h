@@ -1088,27 +1088,28 @@ __device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, u32 lane) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void k_paf_call_events(u32 n, const u32* __restrict__ ops,
-                                                         const u64* __restrict__ op_off, u64 svlen,
-                                                         u32 snp, u64* ev_cnt, u64* ev,
-                                                         const u64* ev_off) {
-  const u32 lane = threadIdx.x & 63u;
-  const u64 i = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
-  if (i >= n) return;
-  const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
-  const u32* rec = ops + o0;
-  u64* eout = ev ? ev + 3 * ev_off[i] : (u64*)0;
-  u64 t_base = 0, q_base = 0, e_base = 0;
-  u32 carry_code = 0xFu;
-  /* 4 consecutive ops per lane and step (256 ops per wave step) */
-  for (u64 k0 = 0; k0 < nops; k0 += 256) {
+/* The walk of ops [a, b) of one record by one wave, 4 consecutive ops per lane and 256 per step (a is a multiple of 256): running
+ * target / query positions and event count start from `st`, the op in front of a gives `after_m`, the op behind a step
+ * tells whether an indel goes on in a continuation piece.  Events go to eout + 3 * (running count) when eout is given.
+ * Returns the sums over the walked ops in *tot (events counted up to the walk's stop) and the record-relative index of
+ * the first op outside M = X I D in *bad_at (WGA_NONE: none) — the walk stops there, as the reference's fold does before
+ * it discards the error (caller.rs:673,815-819). */
+struct PafCallState {
+  u64 t, q, e;
+};
+__device__ __forceinline__ void paf_call_walk(const u32* __restrict__ rec, u64 nops, u64 a, u64 b, u64 svlen, u32 snp,
+                                              PafCallState st, u64* eout, u32 lane, PafCallState* tot, u64* bad_at) {
+  u64 t_base = st.t, q_base = st.q, e_base = st.e;
+  u32 carry_code = a ? (rec[a - 1] & 15u) : 0xFu;
+  *bad_at = WGA_NONE;
+  for (u64 k0 = a; k0 < b; k0 += 256) {
     const u64 kb = k0 + (u64)lane * 4u;
     u32 w[4];
 #pragma unroll
-    for (int e = 0; e < 4; e++) w[e] = kb + (u64)e < nops ? rec[kb + e] : 0xFu; /* 0xF: no op */
+    for (int e = 0; e < 4; e++) w[e] = kb + (u64)e < b ? rec[kb + e] : 0xFu; /* 0xF: no op */
     u32 code[4], len[4];
     bool valid[4], isi[4], isd[4];
-    u32 firstbad = 4u; /* first op of this lane outside M = X I D (and inside the record) */
+    u32 firstbad = 4u; /* first op of this lane outside M = X I D (and inside the range) */
 #pragma unroll
     for (int e = 3; e >= 0; e--) {
       code[e] = w[e] & 15u;
@@ -1117,7 +1118,7 @@ __global__ __launch_bounds__(256) void k_paf_call_events(u32 n, const u32* __res
       isi[e] = code[e] == WGA_OP_I || code[e] == WGA_OP_I_CONT;
       isd[e] = code[e] == WGA_OP_D || code[e] == WGA_OP_D_CONT;
       valid[e] = mlike || isi[e] || isd[e];
-      if (kb + (u64)e < nops && !valid[e]) firstbad = (u32)e;
+      if (kb + (u64)e < b && !valid[e]) firstbad = (u32)e;
     }
     /* the walk stops at the first bad op of the record: ops at or after it are dead */
     const u64 badm = __ballot(firstbad < 4u);
@@ -1129,7 +1130,7 @@ __global__ __launch_bounds__(256) void k_paf_call_events(u32 n, const u32* __res
     u32 ta[4], qa[4], tsum = 0, qsum = 0;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      const bool live = (kb + (u64)e < nops) && (lane * 4u + (u32)e < stop);
+      const bool live = (kb + (u64)e < b) && (lane * 4u + (u32)e < stop);
       ta[e] = live && !isi[e] ? len[e] : 0u;
       qa[e] = live && !isd[e] ? len[e] : 0u;
       tsum += ta[e];
@@ -1143,14 +1144,14 @@ __global__ __launch_bounds__(256) void k_paf_call_events(u32 n, const u32* __res
     u32 prev = (u32)__shfl_up((int)code[3], 1u);
     if (lane == 0) prev = carry_code;
     u32 nxt = (u32)__shfl_down((int)code[0], 1u);
-    if (lane == 63u) nxt = k0 + 256u < nops ? (rec[k0 + 256u] & 15u) : 0xFu;
+    if (lane == 63u) nxt = k0 + 256u < nops ? (rec[k0 + 256u] & 15u) : 0xFu; /* the record's next op, whoever walks it */
     bool is_ev[4];
     u32 nev = 0;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const u32 pc = e == 0 ? prev : code[e - 1];
       const u32 nc = e == 3 ? nxt : code[e + 1];
-      const bool live = (kb + (u64)e < nops) && (lane * 4u + (u32)e < stop);
+      const bool live = (kb + (u64)e < b) && (lane * 4u + (u32)e < stop);
       const bool after_m = pc == WGA_OP_M || pc == WGA_OP_EQ || pc == WGA_OP_X;
       const bool cont_follows = nc == WGA_OP_I_CONT || nc == WGA_OP_D_CONT;
       const bool head_indel = code[e] == WGA_OP_I || code[e] == WGA_OP_D;
@@ -1176,9 +1177,109 @@ __global__ __launch_bounds__(256) void k_paf_call_events(u32 n, const u32* __res
     t_base += ((u64)wave_last_u32(th) << 16) + (u64)wave_last_u32(tl);
     q_base += ((u64)wave_last_u32(qh) << 16) + (u64)wave_last_u32(ql);
     carry_code = (u32)__shfl((int)code[3], 63);
-    if (badm) break;
+    if (badm) {
+      *bad_at = k0 + (u64)stop;
+      break;
+    }
   }
-  if (lane == 0 && ev_cnt) ev_cnt[i] = e_base;
+  tot->t = t_base - st.t;
+  tot->q = q_base - st.q;
+  tot->e = e_base - st.e;
+}
+
+/* one wave per record; records beyond `long_ops` ops are left to the piece kernels below (long_ops = 0: none are) */
+__global__ __launch_bounds__(256) void k_paf_call_events(u32 n, const u32* __restrict__ ops,
+                                                         const u64* __restrict__ op_off, u64 svlen,
+                                                         u32 snp, u64* ev_cnt, u64* ev,
+                                                         const u64* ev_off, u64 long_ops) {
+  const u32 lane = threadIdx.x & 63u;
+  const u64 i = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
+  if (i >= n) return;
+  const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
+  if (long_ops && nops > long_ops) return;
+  PafCallState z, tot;
+  z.t = z.q = z.e = 0;
+  u64 bad;
+  paf_call_walk(ops + o0, nops, 0, nops, svlen, snp, z, ev ? ev + 3 * ev_off[i] : (u64*)0, lane, &tot, &bad);
+  if (lane == 0 && ev_cnt) ev_cnt[i] = tot.e;
+}
+
+/* ---- long records in pieces (the scheme of the MAF walks): a record beyond `long_ops` ops is cut into pieces of `piece_ops`
+ *      (a multiple of 256), every piece is one wave's walk in a persistent grid over the piece list; a first walk leaves each
+ *      piece's sums, one thread per record turns them into each piece's start state (running positions, events so far, "the
+ *      walk has stopped": a piece behind the record's first bad op is dead), the second walk writes the events. ------------- */
+__global__ __launch_bounds__(256) void k_op_piece_counts(u32 n, const u64* __restrict__ op_off, u64 long_ops, u64 piece_ops,
+                                                         u64* npieces) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const u64 nops = op_off[i + 1] - op_off[i];
+  npieces[i] = nops > long_ops ? (nops + piece_ops - 1) / piece_ops : 0;
+}
+struct wga_call_piece {
+  u64 t, q, e;  /* MODE 0: the piece's sums; after the record scan: its start state */
+  u64 bad;      /* MODE 0: record-relative first bad op or WGA_NONE; after the scan: 1 = dead, 0 = walk it */
+};
+/* record of piece p: last i with piece_off[i] <= p (wave-uniform bisection) */
+__device__ __forceinline__ u32 piece_record(const u64* __restrict__ piece_off, u32 n, u64 p) {
+  u32 lo = 0, hi = n;
+  while (hi - lo > 1u) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if (piece_off[mid] <= p)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_paf_call_pieces(u32 n, const u32* __restrict__ ops, const u64* __restrict__ op_off,
+                                                         u64 svlen, u32 snp, const u64* __restrict__ piece_off, u64 piece_ops,
+                                                         wga_call_piece* pc, u64* ev, const u64* ev_off) {
+  const u32 lane = threadIdx.x & 63u;
+  const u64 n_pieces = piece_off[n];
+  const u64 n_waves = (u64)gridDim.x * 4u;
+  for (u64 p = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x); p < n_pieces; p += n_waves) {
+    const u32 i = piece_record(piece_off, n, p);
+    const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
+    const u64 a = (p - piece_off[i]) * piece_ops, b = a + piece_ops < nops ? a + piece_ops : nops;
+    PafCallState st, tot;
+    st.t = st.q = st.e = 0;
+    u64 bad;
+    if (MODE == 0) {
+      paf_call_walk(ops + o0, nops, a, b, svlen, snp, st, (u64*)0, lane, &tot, &bad);
+      if (lane == 0) {
+        wga_call_piece r;
+        r.t = tot.t, r.q = tot.q, r.e = tot.e, r.bad = bad;
+        pc[p] = r;
+      }
+    } else {
+      const wga_call_piece r = pc[p];
+      if (r.bad) continue; /* behind the record's first bad op: the reference's fold skips these ops */
+      st.t = r.t, st.q = r.q, st.e = r.e;
+      paf_call_walk(ops + o0, nops, a, b, svlen, snp, st, ev + 3 * ev_off[i], lane, &tot, &bad);
+    }
+  }
+}
+/* one thread per long record: its pieces' sums -> start states; the record's event count */
+__global__ __launch_bounds__(256) void k_paf_call_piece_scan(u32 n, const u64* __restrict__ piece_off, wga_call_piece* pc,
+                                                             u64* ev_cnt) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const u64 p0 = piece_off[i], p1 = piece_off[i + 1];
+  if (p0 == p1) return;
+  u64 t = 0, q = 0, e = 0;
+  bool dead = false;
+  for (u64 p = p0; p < p1; p++) {
+    const wga_call_piece r = pc[p];
+    wga_call_piece s;
+    s.t = t, s.q = q, s.e = e, s.bad = dead ? 1u : 0u;
+    pc[p] = s;
+    if (!dead) {
+      t += r.t, q += r.q, e += r.e;
+      dead = r.bad != WGA_NONE;
+    }
+  }
+  if (ev_cnt) ev_cnt[i] = e;
 }
 
 /* ============================================================================================ */
@@ -2106,32 +2207,28 @@ __device__ __forceinline__ u64 dotplot_serial(const u32* rec, u64 nops, u64 cuto
   return ns;
 }
 
+/* The walk of ops [a, b) of one record by one wave (a a multiple of 256): offsets r / q, the number of segments so far and the
+ * open / closed state in front of the range come in through `st` and leave through it; `first_ev` = the first event of the
+ * range (0 none, 1 a break, 2 an M-like op) tells the caller whether a range that follows an open M segment starts a new
+ * one.  Returns false when the range holds a continuation piece of a split indel (the record then takes the serial walk). */
+struct DotState {
+  u64 r, q, nseg;
+  u32 state; /* 0 / 1: no open M segment (start, or a break was the last event), 2: open */
+};
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_dotplot_segments(u32 n, const u32* __restrict__ ops,
-                                                          const u64* __restrict__ op_off,
-                                                          const u8* __restrict__ strand_neg, u64 cutoff,
-                                                          const u64* __restrict__ t_start,
-                                                          const u64* __restrict__ q_start, u64* seg_cnt,
-                                                          u64* segs, const u64* seg_off) {
-  const u32 lane = threadIdx.x & 63u, wave = WGA_WAVE_ID(threadIdx.x);
-  const u64 i = (u64)blockIdx.x * 4 + wave;
-  if (i >= n) return;
-  const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
-  const u32* rec = ops + o0;
-  const bool neg = strand_neg[i] != 0;
-  u64* const out = FILL ? segs + seg_off[i] * WGA_SEG_WORDS : (u64*)0;
-  u64 r_base = t_start[i], q_base = q_start[i], nseg = 0;
-  u32 carry_state = 0; /* 0 / 1: no open M segment (start, or a break was the last event), 2: open */
-  bool weird = false;
-  for (u64 k0 = 0; k0 < nops; k0 += 256) {
+__device__ __forceinline__ bool dotplot_walk(const u32* __restrict__ rec, u64 a, u64 b, u64 cutoff, bool neg, DotState& ds,
+                                             u64* out, u32 lane, u32* first_ev) {
+  u64 r_base = ds.r, q_base = ds.q, nseg = ds.nseg;
+  u32 carry_state = ds.state, first_seen = 0u;
+  for (u64 k0 = a; k0 < b; k0 += 256) {
     const u64 kb = k0 + (u64)lane * 4u;
     u32 len[4], radv[4], qadv[4];
     bool ml[4], brk[4], isi[4];
     bool cont = false;
-    u32 sr = 0, sq = 0, last_ev = 0;
+    u32 sr = 0, sq = 0, last_ev = 0, lane_first = 0;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      const bool in = kb + (u64)e < nops;
+      const bool in = kb + (u64)e < b;
       const u32 w = in ? rec[kb + e] : 0xFu;
       const u32 code = w & 15u;
       len[e] = w >> 4;
@@ -2144,22 +2241,23 @@ __global__ __launch_bounds__(256) void k_dotplot_segments(u32 n, const u32* __re
       qadv[e] = (ml[e] || isi[e]) ? len[e] : 0u;
       sr += radv[e];
       sq += qadv[e];
-      last_ev = ml[e] ? 2u : brk[e] ? 1u : last_ev;
+      const u32 ev = ml[e] ? 2u : brk[e] ? 1u : 0u;
+      last_ev = ev ? ev : last_ev;
+      lane_first = lane_first ? lane_first : ev;
     }
-    if (__ballot(cont)) { /* wave-uniform */
-      weird = true;
-      break;
-    }
+    if (__ballot(cont)) return false; /* wave-uniform */
     /* offsets in front of this lane's ops: exact wave scans of the lane sums (< 2^30) on 16-bit halves */
     const u32 rl = wave_incl_scan_u32(sr & 0xFFFFu), rh = wave_incl_scan_u32(sr >> 16);
     const u32 ql = wave_incl_scan_u32(sq & 0xFFFFu), qh = wave_incl_scan_u32(sq >> 16);
     u64 r = r_base + (((u64)rh << 16) + (u64)rl) - (u64)sr;
     u64 q = q_base + (((u64)qh << 16) + (u64)ql) - (u64)sq;
     /* open / closed in front of this lane = the last event of the nearest earlier lane that has one */
-    const u64 evm = __ballot(last_ev != 0u) & ((1ull << lane) - 1ull);
+    const u64 all_ev = __ballot(last_ev != 0u);
+    const u64 evm = all_ev & ((1ull << lane) - 1ull);
     const int src = evm ? 63 - (int)__builtin_clzll(evm) : 0;
     const u32 got = (u32)__shfl((int)last_ev, src);
     u32 state = evm ? got : carry_state;
+    if (!first_seen && all_ev) first_seen = (u32)__shfl((int)lane_first, (int)__builtin_ctzll(all_ev));
     /* segments this lane raises, then their ranks */
     u32 st = state, cnt = 0;
 #pragma unroll
@@ -2196,10 +2294,36 @@ __global__ __launch_bounds__(256) void k_dotplot_segments(u32 n, const u32* __re
     nseg += (u64)wave_last_u32(cinc);
     r_base += ((u64)wave_last_u32(rh) << 16) + (u64)wave_last_u32(rl);
     q_base += ((u64)wave_last_u32(qh) << 16) + (u64)wave_last_u32(ql);
-    const u64 all_ev = __ballot(last_ev != 0u);
     if (all_ev) carry_state = (u32)__shfl((int)last_ev, 63 - (int)__builtin_clzll(all_ev));
   }
-  if (weird) { /* wave-uniform */
+  ds.r = r_base;
+  ds.q = q_base;
+  ds.nseg = nseg;
+  ds.state = carry_state;
+  *first_ev = first_seen;
+  return true;
+}
+
+/* one wave per record; records beyond `long_ops` ops are left to the piece kernels below (long_ops = 0: none are) */
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_dotplot_segments(u32 n, const u32* __restrict__ ops,
+                                                          const u64* __restrict__ op_off,
+                                                          const u8* __restrict__ strand_neg, u64 cutoff,
+                                                          const u64* __restrict__ t_start,
+                                                          const u64* __restrict__ q_start, u64* seg_cnt,
+                                                          u64* segs, const u64* seg_off, u64 long_ops) {
+  const u32 lane = threadIdx.x & 63u, wave = WGA_WAVE_ID(threadIdx.x);
+  const u64 i = (u64)blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
+  if (long_ops && nops > long_ops) return;
+  const u32* rec = ops + o0;
+  const bool neg = strand_neg[i] != 0;
+  u64* const out = FILL ? segs + seg_off[i] * WGA_SEG_WORDS : (u64*)0;
+  DotState ds;
+  ds.r = t_start[i], ds.q = q_start[i], ds.nseg = 0, ds.state = 0u;
+  u32 first_ev;
+  if (!dotplot_walk<FILL>(rec, 0, nops, cutoff, neg, ds, out, lane, &first_ev)) { /* wave-uniform */
     if (lane == 0) {
       const u64 ns = dotplot_serial(rec, nops, cutoff, t_start[i], q_start[i], neg, out);
       if (!FILL) seg_cnt[i] = ns;
@@ -2207,13 +2331,100 @@ __global__ __launch_bounds__(256) void k_dotplot_segments(u32 n, const u32* __re
     return;
   }
   if (lane == 0) {
-    if (FILL && carry_state == 2u) { /* the end of the record closes the open M segment */
-      u64* s = out + (nseg - 1) * WGA_SEG_WORDS;
-      s[1] = r_base;
-      s[neg ? 2 : 3] = q_base;
+    if (FILL && ds.state == 2u) { /* the end of the record closes the open M segment */
+      u64* s = out + (ds.nseg - 1) * WGA_SEG_WORDS;
+      s[1] = ds.r;
+      s[neg ? 2 : 3] = ds.q;
     }
-    if (!FILL) seg_cnt[i] = nseg;
+    if (!FILL) seg_cnt[i] = ds.nseg;
   }
+}
+
+/* ---- long records in pieces (see the piece kernels of K7): a first walk leaves each piece's offset sums, its segment count
+ *      as if nothing were open in front of it, its first event and the state behind it; one thread per record turns that into
+ *      each piece's start (offsets, segments so far, open / closed); the second walk writes the segments and the record's
+ *      last piece closes the segment that is still open. ----------------------------------------------------------------- */
+struct wga_dot_piece {
+  u64 r, q, nseg; /* MODE 0: sums / count (start closed); after the record scan: the piece's start */
+  u32 state;      /* MODE 0: state behind the piece, 0 when it has no event; after the scan: state in front of it */
+  u32 first_ev;   /* MODE 0: 0 none, 1 break, 2 M-like, 3: a continuation piece of a split indel (serial walk); after the
+                     scan: 3 = the record takes the serial walk */
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void k_dotplot_pieces(u32 n, const u32* __restrict__ ops, const u64* __restrict__ op_off,
+                                                        const u8* __restrict__ strand_neg, u64 cutoff,
+                                                        const u64* __restrict__ t_start, const u64* __restrict__ q_start,
+                                                        const u64* __restrict__ piece_off, u64 piece_ops, wga_dot_piece* pc,
+                                                        u64* segs, const u64* seg_off) {
+  const u32 lane = threadIdx.x & 63u;
+  const u64 n_pieces = piece_off[n];
+  const u64 n_waves = (u64)gridDim.x * 4u;
+  for (u64 p = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x); p < n_pieces; p += n_waves) {
+    const u32 i = piece_record(piece_off, n, p);
+    const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
+    const u64 a = (p - piece_off[i]) * piece_ops, b = a + piece_ops < nops ? a + piece_ops : nops;
+    const bool neg = strand_neg[i] != 0;
+    DotState ds;
+    u32 first_ev = 0u;
+    if (MODE == 0) {
+      ds.r = ds.q = ds.nseg = 0;
+      ds.state = 0u;
+      const bool ok = dotplot_walk<false>(ops + o0, a, b, cutoff, neg, ds, (u64*)0, lane, &first_ev);
+      if (lane == 0) {
+        wga_dot_piece r;
+        r.r = ds.r, r.q = ds.q, r.nseg = ds.nseg;
+        r.state = first_ev ? ds.state : 0u;
+        r.first_ev = ok ? first_ev : 3u;
+        pc[p] = r;
+      }
+    } else {
+      const wga_dot_piece r = pc[p];
+      u64* const out = segs + seg_off[i] * WGA_SEG_WORDS;
+      if (r.first_ev == 3u) { /* a split indel somewhere in the record: the serial walk, by the first piece's first lane */
+        if (a == 0 && lane == 0) dotplot_serial(ops + o0, nops, cutoff, t_start[i], q_start[i], neg, out);
+        continue;
+      }
+      ds.r = r.r, ds.q = r.q, ds.nseg = r.nseg, ds.state = r.state;
+      dotplot_walk<true>(ops + o0, a, b, cutoff, neg, ds, out, lane, &first_ev);
+      if (b == nops && lane == 0 && ds.state == 2u) { /* the end of the record closes the open M segment */
+        u64* s = out + (ds.nseg - 1) * WGA_SEG_WORDS;
+        s[1] = ds.r;
+        s[neg ? 2 : 3] = ds.q;
+      }
+    }
+  }
+}
+/* one thread per long record: piece sums -> piece starts; the record's segment count */
+__global__ __launch_bounds__(256) void k_dotplot_piece_scan(u32 n, const u32* __restrict__ ops, const u64* __restrict__ op_off,
+                                                            const u8* __restrict__ strand_neg, u64 cutoff,
+                                                            const u64* __restrict__ t_start, const u64* __restrict__ q_start,
+                                                            const u64* __restrict__ piece_off, wga_dot_piece* pc, u64* seg_cnt) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const u64 p0 = piece_off[i], p1 = piece_off[i + 1];
+  if (p0 == p1) return;
+  bool weird = false;
+  for (u64 p = p0; p < p1; p++) weird |= pc[p].first_ev == 3u;
+  if (weird) {
+    for (u64 p = p0; p < p1; p++) pc[p].first_ev = 3u;
+    if (seg_cnt)
+      seg_cnt[i] = dotplot_serial(ops + op_off[i], op_off[i + 1] - op_off[i], cutoff, t_start[i], q_start[i], strand_neg[i] != 0, (u64*)0);
+    return;
+  }
+  u64 r = t_start[i], q = q_start[i], ns = 0;
+  u32 state = 0u;
+  for (u64 p = p0; p < p1; p++) {
+    const wga_dot_piece x = pc[p];
+    wga_dot_piece s;
+    s.r = r, s.q = q, s.nseg = ns, s.state = state, s.first_ev = x.first_ev;
+    pc[p] = s;
+    r += x.r;
+    q += x.q;
+    /* counted as if nothing were open: an M-like first event continues the segment that is */
+    ns += x.nseg - ((state == 2u && x.first_ev == 2u) ? 1u : 0u);
+    state = x.first_ev ? x.state : state;
+  }
+  if (seg_cnt) seg_cnt[i] = ns;
 }
 
 /* ============================================================================================ */
