@@ -1001,6 +1001,42 @@ def check_cigar_chain(eng, ops, op_off):
 
 
 
+def check_cigar_chain_long_records(eng, mops=2):
+    """K10 with records cut into pieces where a line is certain: small knobs (pieces of 256 ops) on nasty cuts, records
+    without any cut (their pieces are empty), zero-length ops where a cut would be, a stop inside a middle piece, sums past
+    2^32 inside one piece (the record goes through the serial walk), then one record of `mops` million ops with the
+    product's piece size"""
+    L = (1 << 28) - 1
+    mk = lambda p: np.array([(int(ln) << 4) | int(c) for c, ln in p], dtype=np.uint32)
+    eng.set_param("op_long_ops", 600)
+    eng.set_param("op_piece_ops", 256)
+    try:
+        for seed in (5, 8):
+            ops, off = long_record_ops(seed, 3, 2300)
+            check_cigar_chain(eng, ops, off)
+        ops, off = long_record_ops(6, 3, 1500, bad_in=(2, 700))
+        check_cigar_chain(eng, ops, off)
+        recs = [
+            mk([(7, 2), (8, 1)] * 900),                                           # no indel: one piece, the others empty
+            mk([(7, 2), (1, 0), (7, 1)] * 500),                                   # zero-length indels: never a cut
+            mk([(7, 0), (1, 2), (7, 1)] * 500),                                   # zero-length blocks in front of the indel
+            mk([(1, 3)] * 700 + [(7, 4), (2, 2), (7, 1)] * 300),                  # the head trim is longer than two pieces
+            mk([(7, 5), (2, 1)] * 400 + [(1, 2)] * 700),                          # a tail longer than two pieces
+            mk([(7, 3), (1, 1)] * 200 + [(7, L)] * 20 + [(1, 1), (7, 3)] * 200),  # 2^32 inside a middle piece
+            mk([(7, 1), (1, 1), (2, 1)] * 400 + [(7, 9)]),                        # I D groups: no M indel M pattern at all
+            mk([(7, 1), (1, 1), (2, 1)] * 300 + [(7, 2), (2, 5), (7, 9)] + [(8, 1)] * 400),  # one cut, late
+        ]
+        ops = np.concatenate(recs)
+        off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+        check_cigar_chain(eng, ops, off)
+    finally:
+        eng.set_param("op_long_ops", 16384)
+        eng.set_param("op_piece_ops", 8192)
+    if mops:
+        ops, off = long_record_ops(7, 1, mops * 1_000_000)
+        check_cigar_chain(eng, ops, off)
+
+
 def chain_stress_records(seed, n=40, max_ops=2600):
     """records that exercise the step structure of K10 (512-op steps, 8 ops per lane, 64 lines per round): several
     steps, steps without a raise, a raise on every other op, leading / trailing indel runs longer than a step, ten-digit

@@ -304,6 +304,12 @@ def test_dotplot_long_records_in_pieces(emu):
     pc.check_dotplot_long_records(emu, mops=0)
 
 
+def test_cigar_chain_long_records_in_pieces(emu):
+    pc.check_cigar_chain_long_records(emu, mops=0)
+    ops, off = pc.long_record_ops(7, 1, 40_000)     # the product's piece size
+    pc.check_cigar_chain(emu, ops, off)
+
+
 def test_device_tokeniser(emu):
     pc.check_tokeniser(emu, pc.TOKENISER_EDGE_TEXTS)
     b = synth.make_paf_batch(41, 10, 300, 300000)

@@ -388,6 +388,10 @@ def test_dotplot_long_records_in_pieces(gpu):
     pc.check_dotplot_long_records(gpu, mops=2)
 
 
+def test_cigar_chain_long_records_in_pieces(gpu):
+    pc.check_cigar_chain_long_records(gpu, mops=2)
+
+
 def test_device_tokeniser(gpu):
     pc.check_tokeniser(gpu, pc.TOKENISER_EDGE_TEXTS)
     b = synth.make_paf_batch(41, 400, 3000, 300000)

@@ -1067,14 +1067,37 @@ int wga_cigar_chain(wga_ctx* c, const wga_cigar_batch* b, wga_chain_trim_t* d_tr
     RT_CHECK(rt_memset(d_diag, 0xFF, (size_t)b->n * sizeof(wga_rec_diag), c->stream));
     WGA_LAUNCH(k_cigar_chain<false>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
                (const u64*)b->d_op_off, (wga_chain_trim*)d_trim, (u64*)d_nbytes, d_diag, (u8*)nullptr,
-               (const u64*)nullptr);
+               (const u64*)nullptr, (u64)c->op_long_ops);
   } else {
     if (!d_out_off) return fail(WGA_E_INVALID_ARG, "d_out_off null", nullptr);
     WGA_LAUNCH(k_cigar_chain<true>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
                (const u64*)b->d_op_off, (wga_chain_trim*)nullptr, (u64*)nullptr, (wga_rec_diag*)nullptr,
-               d_out, (const u64*)d_out_off);
+               d_out, (const u64*)d_out_off, (u64)c->op_long_ops);
   }
   LAUNCH_CHECK();
+  /* records beyond op_long_ops: pieces over the whole chip, cut where a line is certain (both calls of the protocol walk the
+   * pieces for their bytes: the scratch arena is not kept between calls) */
+  u32 np = 0;
+  u64* piece_off = nullptr;
+  void* pieces = nullptr;
+  if ((rc = op_piece_table(c, b, sizeof(wga_chain_piece), &np, &piece_off, &pieces))) return rc;
+  if (np == 0) return WGA_OK;
+  wga_chain_piece* pc = (wga_chain_piece*)pieces;
+  const u32 grid = np < 4u * 2048u ? (np + 3u) / 4u : 2048u;
+  WGA_LAUNCH((k_cigar_chain_pieces<0>), grid, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off,
+             (const u64*)piece_off, (u64)c->op_piece_ops, pc, d_out ? (wga_chain_trim*)nullptr : (wga_chain_trim*)d_trim,
+             d_out ? (wga_rec_diag*)nullptr : d_diag, (u8*)nullptr, (const u64*)nullptr);
+  LAUNCH_CHECK();
+  WGA_LAUNCH(k_cigar_chain_piece_scan, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off,
+             (const u64*)piece_off, pc, d_out ? (wga_chain_trim*)nullptr : (wga_chain_trim*)d_trim,
+             d_out ? (u64*)nullptr : (u64*)d_nbytes, d_out ? (wga_rec_diag*)nullptr : d_diag);
+  LAUNCH_CHECK();
+  if (d_out) {
+    WGA_LAUNCH((k_cigar_chain_pieces<1>), grid, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off,
+               (const u64*)piece_off, (u64)c->op_piece_ops, pc, (wga_chain_trim*)nullptr, (wga_rec_diag*)nullptr, d_out,
+               (const u64*)d_out_off);
+    LAUNCH_CHECK();
+  }
   return WGA_OK;
 }
 

@@ -1916,12 +1916,77 @@ __device__ __forceinline__ void chain_tail_trim(const u32* rec, u64 nops, u32 la
   }
 }
 
+/* One wave walks `nops` ops from `rec` as a record of its own: `first` — the head trim is open (the record starts here);
+ * `last` — the walk ends the record ("\n<size>", trailing indels dropped), otherwise an M-like op follows an open block
+ * and an open indel group (a cut of chain_find_cut) and what is open goes out as a line.  Count pass: returns the text bytes;
+ * fill pass: writes them at `text`.  *weird: sums past 2^32 (nothing usable was produced); *bad_idx: first op outside
+ * M = X I D, relative to rec. */
+template <bool FILL>
+__device__ __forceinline__ u64 chain_walk(const u32* rec, u64 nops, u8* text, bool first, bool last, u32 lane,
+                                          u32x4_a16* slot, const u32* p10, u8* tbuf, ChainWalk& st, bool* weird,
+                                          u64* bad_idx) {
+  st.c_size = st.c_qd = st.c_td = 0u;
+  st.seen_m = first ? 0u : 1u;
+  st.head_ins = st.head_del = 0u;
+  st.nbytes = 0;
+  st.fill = st.head_skip = FILL ? (u32)((uintptr_t)text & 127u) : 0u;
+  st.gpos = FILL ? text - st.fill : (u8*)0;
+  *weird = false;
+  *bad_idx = WGA_NONE;
+  u32 w[WGA_CHAIN_OPL];
+  if (nops) chain_load(rec, nops, 0, lane, w);
+  for (u64 k0 = 0; k0 < nops; k0 += WGA_CHAIN_STEP) {
+    u32 nw[WGA_CHAIN_OPL];
+    const bool more = k0 + WGA_CHAIN_STEP < nops;
+    if (more) chain_load(rec, nops, k0 + WGA_CHAIN_STEP, lane, nw);
+    u32 stop;
+    const int rc = more || k0 + WGA_CHAIN_STEP == nops
+                       ? chain_step<FILL, false>(w, WGA_CHAIN_STEP, lane, slot, p10, tbuf, st, &stop)
+                       : chain_step<FILL, true>(w, (u32)(nops - k0), lane, slot, p10, tbuf, st, &stop);
+    if (rc == 2) { /* wave-uniform */
+      *weird = true;
+      return 0;
+    }
+    if (rc == 1) {
+      *bad_idx = k0 + (u64)stop;
+      break;
+    }
+    if (more) {
+#pragma unroll
+      for (int e = 0; e < (int)WGA_CHAIN_OPL; e++) w[e] = nw[e];
+    }
+  }
+  /* the last block: "\n<size>" (cigar.rs:289-291; 0 when the record has no M-like op); at a cut: the line the next op raises */
+  const u32 d0 = dec_digits_u32(st.c_size, p10);
+  const u32 el = last ? 1u + d0 : 3u + d0 + dec_digits_u32(st.c_qd, p10) + dec_digits_u32(st.c_td, p10);
+  if (FILL) {
+    if (lane == 0) {
+      u32 p = st.fill + el;
+      if (!last) {
+        p = chain_put_dec(tbuf, p, st.c_td);
+        tbuf[--p] = (u8)'\t';
+        p = chain_put_dec(tbuf, p, st.c_qd);
+        tbuf[--p] = (u8)'\t';
+      }
+      p = chain_put_dec(tbuf, p, st.c_size);
+      tbuf[p - 1u] = (u8)'\n';
+    }
+    st.fill += el;
+    chain_flush_lines(st, tbuf, lane);
+    WGA_WAVE_SYNC();
+    for (u32 k = st.head_skip + lane; k < st.fill; k += 64u) st.gpos[k] = tbuf[k];
+    return 0;
+  }
+  return wave_sum_u64(st.nbytes) + el;
+}
+
+/* one wave per record; records beyond `long_ops` ops are left to the piece kernels below (long_ops = 0: none are) */
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_cigar_chain(u32 n, const u32* __restrict__ ops,
                                                      const u64* __restrict__ op_off,
                                                      wga_chain_trim* trims, u64* nbytes,
                                                      wga_rec_diag* diag, u8* out,
-                                                     const u64* out_off) {
+                                                     const u64* out_off, u64 long_ops) {
   __shared__ u32x4_a16 s_slot[4][WGA_CHAIN_NL];
   __shared__ u32 s_p10[4][16];
   __shared__ u32x4_a16 s_text[4][FILL ? WGA_CHAIN_TB / 16u : 1u];
@@ -1929,6 +1994,7 @@ __global__ __launch_bounds__(256) void k_cigar_chain(u32 n, const u32* __restric
   const u64 i = (u64)blockIdx.x * 4 + wave;
   if (i >= n) return;
   const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
+  if (long_ops && nops > long_ops) return;
   const u32* rec = ops + o0;
   u8* const text = FILL ? out + out_off[i] : (u8*)0;
   u32x4_a16* const slot = s_slot[wave];
@@ -1941,74 +2007,158 @@ __global__ __launch_bounds__(256) void k_cigar_chain(u32 n, const u32* __restric
   }
   WGA_WAVE_SYNC();
   ChainWalk st;
-  st.c_size = st.c_qd = st.c_td = 0u;
-  st.seen_m = 0u;
-  st.head_ins = st.head_del = 0u;
-  st.nbytes = 0;
-  st.fill = st.head_skip = FILL ? (u32)((uintptr_t)text & 127u) : 0u;
-  st.gpos = FILL ? text - st.fill : (u8*)0;
-  bool weird = false;
-  u64 bad_idx = WGA_NONE;
-  u32 w[WGA_CHAIN_OPL];
-  if (nops) chain_load(rec, nops, 0, lane, w);
-  for (u64 k0 = 0; k0 < nops; k0 += WGA_CHAIN_STEP) {
-    u32 nw[WGA_CHAIN_OPL];
-    const bool more = k0 + WGA_CHAIN_STEP < nops;
-    if (more) chain_load(rec, nops, k0 + WGA_CHAIN_STEP, lane, nw);
-    u32 stop;
-    const int rc = more || k0 + WGA_CHAIN_STEP == nops
-                       ? chain_step<FILL, false>(w, WGA_CHAIN_STEP, lane, slot, p10, tbuf, st, &stop)
-                       : chain_step<FILL, true>(w, (u32)(nops - k0), lane, slot, p10, tbuf, st, &stop);
-    if (rc == 2) { /* wave-uniform */
-      weird = true;
-      break;
-    }
-    if (rc == 1) {
-      bad_idx = k0 + (u64)stop;
-      break;
-    }
-    if (more) {
-#pragma unroll
-      for (int e = 0; e < (int)WGA_CHAIN_OPL; e++) w[e] = nw[e];
-    }
-  }
+  bool weird;
+  u64 bad_idx;
+  const u64 nb = chain_walk<FILL>(rec, nops, text, true, true, lane, slot, p10, tbuf, st, &weird, &bad_idx);
   if (weird) { /* a block, or an indel group, of 2^32 bases or more: the reference's loop as it stands, in u64 */
     if (lane == 0) {
       wga_chain_trim tr;
-      u64 nb = 0, bad = WGA_NONE;
-      chain_serial(rec, nops, text, tr, nb, bad);
+      u64 nbs = 0, bad = WGA_NONE;
+      chain_serial(rec, nops, text, tr, nbs, bad);
       if (!FILL) {
-        nbytes[i] = nb;
+        nbytes[i] = nbs;
         trims[i] = tr;
         if (bad != WGA_NONE) diag[i].bad_op_idx = bad;
       }
     }
     return;
   }
-  /* the last block: "\n<size>" (cigar.rs:289-291; 0 when the record has no M-like op) */
-  const u32 dl = dec_digits_u32(st.c_size, p10);
-  if (FILL) {
-    if (lane == 0) {
-      const u32 p = chain_put_dec(tbuf, st.fill + 1u + dl, st.c_size);
-      tbuf[p - 1u] = (u8)'\n';
-    }
-    st.fill += 1u + dl;
-    chain_flush_lines(st, tbuf, lane);
-    WGA_WAVE_SYNC();
-    for (u32 k = st.head_skip + lane; k < st.fill; k += 64u) st.gpos[k] = tbuf[k];
-  } else {
+  if (!FILL) {
     wga_chain_trim tr;
     /* indels in front of the first M-like op; everything when no M-like op exists */
     tr.head_ins = st.seen_m ? (u64)st.head_ins : (u64)st.c_td;
     tr.head_del = st.seen_m ? (u64)st.head_del : (u64)st.c_qd;
     chain_tail_trim(rec, nops, lane, tr.tail_ins, tr.tail_del);
-    const u64 nb = wave_sum_u64(st.nbytes) + 1u + dl;
     if (lane == 0) {
       nbytes[i] = nb;
       trims[i] = tr;
       if (bad_idx != WGA_NONE) diag[i].bad_op_idx = bad_idx;
     }
   }
+}
+
+/* ---- long records in pieces: the fold's state is (size, D bases, I bases) and it starts again at every line, so a record
+ *      can be cut where a line is certain: op k is M-like, op k-1 an indel op of length >= 1, op k-2 an M-like op of length
+ *      >= 1 ("size != 0 && diffs != 0" holds at k whatever came before, cigar.rs:472).  Piece j of a record beyond
+ *      `long_ops` ops starts at the first such k at or behind j * piece_ops (none inside its piece_ops ops: the piece is
+ *      empty and its ops stay with the piece in front) and ends where the next non-empty piece starts; it is walked as a
+ *      record of its own (chain_walk) whose last line is the one op k raises.  Count walk: bytes per piece; one thread per
+ *      record: the record's bytes and every piece's place in its text; fill walk: the text.  A piece whose sums pass 2^32
+ *      sends its record through chain_serial (by the scan thread, then by piece 0's lane 0). ------------------------------ */
+struct wga_chain_piece {
+  u64 a, b;   /* ops [a, b) of the record; a = WGA_NONE: empty */
+  u64 nb;     /* count walk: text bytes (WGA_NONE: sums past 2^32) */
+  u64 off;    /* record scan: the piece's text starts here inside the record's (WGA_NONE: the record is chain_serial's) */
+};
+__device__ __forceinline__ u64 chain_find_cut(const u32* rec, u64 lo, u64 hi, u32 lane) {
+  for (u64 base = lo < 2u ? 2u : lo; base < hi; base += 64u) {
+    const u64 k = base + lane;
+    bool ok = false;
+    if (k < hi) {
+      const u32 w0 = rec[k], w1 = rec[k - 1], w2 = rec[k - 2];
+      ok = ((WGA_CHAIN_MM >> (w0 & 15u)) & 1u) && (((WGA_CHAIN_IM | WGA_CHAIN_DM) >> (w1 & 15u)) & 1u) && (w1 >> 4) != 0u &&
+           ((WGA_CHAIN_MM >> (w2 & 15u)) & 1u) && (w2 >> 4) != 0u;
+    }
+    const u64 m = __ballot(ok);
+    if (m) return base + (u64)(__ffsll((unsigned long long)m) - 1);
+  }
+  return WGA_NONE;
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_cigar_chain_pieces(u32 n, const u32* __restrict__ ops, const u64* __restrict__ op_off,
+                                                            const u64* __restrict__ piece_off, u64 piece_ops,
+                                                            wga_chain_piece* pc, wga_chain_trim* trims, wga_rec_diag* diag,
+                                                            u8* out, const u64* out_off) {
+  __shared__ u32x4_a16 s_slot[4][WGA_CHAIN_NL];
+  __shared__ u32 s_p10[4][16];
+  __shared__ u32x4_a16 s_text[4][MODE ? WGA_CHAIN_TB / 16u : 1u];
+  const u32 lane = threadIdx.x & 63u, wave = WGA_WAVE_ID(threadIdx.x);
+  u32x4_a16* const slot = s_slot[wave];
+  u32* const p10 = s_p10[wave];
+  u8* const tbuf = (u8*)s_text[wave];
+  if (lane < 10u) {
+    u32 v = 1u;
+    for (u32 k = 0; k < lane; k++) v *= 10u;
+    p10[lane] = v;
+  }
+  WGA_WAVE_SYNC();
+  const u64 n_pieces = piece_off[n];
+  const u64 n_waves = (u64)gridDim.x * 4u;
+  for (u64 p = (u64)blockIdx.x * 4 + wave; p < n_pieces; p += n_waves) {
+    const u32 i = piece_record(piece_off, n, p);
+    const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
+    const u32* rec = ops + o0;
+    const u64 j = p - piece_off[i], np = piece_off[i + 1] - piece_off[i];
+    ChainWalk st;
+    bool weird;
+    u64 bad;
+    if (MODE == 0) {
+      wga_chain_piece r;
+      r.nb = 0, r.off = 0;
+      const u64 lo = j * piece_ops;
+      r.a = j == 0 ? 0 : chain_find_cut(rec, lo, lo + piece_ops < nops ? lo + piece_ops : nops, lane);
+      r.b = WGA_NONE;
+      if (r.a != WGA_NONE) {
+        for (u64 jj = j + 1; jj < np && r.b == WGA_NONE; jj++) {
+          const u64 l2 = jj * piece_ops;
+          r.b = chain_find_cut(rec, l2, l2 + piece_ops < nops ? l2 + piece_ops : nops, lane);
+        }
+        if (r.b == WGA_NONE) r.b = nops;
+        const u64 nb = chain_walk<false>(rec + r.a, r.b - r.a, (u8*)0, j == 0, r.b == nops, lane, slot, p10, tbuf, st, &weird,
+                                         &bad);
+        r.nb = weird ? WGA_NONE : nb;
+        if (bad != WGA_NONE && lane == 0 && diag) atomicMin((u64*)&diag[i].bad_op_idx, r.a + bad);
+        if (j == 0 && !weird && trims) { /* wave-uniform */
+          wga_chain_trim tr;
+          tr.head_ins = st.seen_m ? (u64)st.head_ins : (u64)st.c_td;
+          tr.head_del = st.seen_m ? (u64)st.head_del : (u64)st.c_qd;
+          chain_tail_trim(rec, nops, lane, tr.tail_ins, tr.tail_del);
+          if (lane == 0) trims[i] = tr;
+        }
+      }
+      if (lane == 0) pc[p] = r;
+    } else {
+      const wga_chain_piece r = pc[p];
+      u8* const text = out + out_off[i];
+      if (r.off == WGA_NONE) {
+        if (j == 0 && lane == 0) {
+          wga_chain_trim tr;
+          u64 nbs = 0, bd = WGA_NONE;
+          chain_serial(rec, nops, text, tr, nbs, bd);
+        }
+      } else if (r.a != WGA_NONE) {
+        chain_walk<true>(rec + r.a, r.b - r.a, text + r.off, j == 0, r.b == nops, lane, slot, p10, tbuf, st, &weird, &bad);
+      }
+    }
+    WGA_WAVE_SYNC(); /* the next piece reuses the wave's slots and text buffer */
+  }
+}
+/* one thread per long record: the record's bytes, every piece's place in the text */
+__global__ __launch_bounds__(256) void k_cigar_chain_piece_scan(u32 n, const u32* __restrict__ ops,
+                                                                const u64* __restrict__ op_off,
+                                                                const u64* __restrict__ piece_off, wga_chain_piece* pc,
+                                                                wga_chain_trim* trims, u64* nbytes, wga_rec_diag* diag) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const u64 p0 = piece_off[i], p1 = piece_off[i + 1];
+  if (p0 == p1) return;
+  u64 sum = 0;
+  bool weird = false;
+  for (u64 p = p0; p < p1; p++) {
+    const u64 nb = pc[p].nb;
+    weird = weird || nb == WGA_NONE;
+    pc[p].off = sum;
+    sum += nb;
+  }
+  if (weird) {
+    const u64 o0 = op_off[i];
+    wga_chain_trim tr;
+    u64 bad = WGA_NONE;
+    chain_serial(ops + o0, op_off[i + 1] - o0, (u8*)0, tr, sum, bad);
+    if (nbytes) trims[i] = tr, diag[i].bad_op_idx = bad;
+    for (u64 p = p0; p < p1; p++) pc[p].off = WGA_NONE;
+  }
+  if (nbytes) nbytes[i] = sum;
 }
 
 /* ============================================================================================ */
