@@ -112,7 +112,7 @@ def kernel_source_sha():
     """the row kernel's source: roofline.traffic is only valid for the kernel it was measured on"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("wga_kernels.h", "wga_kernels_k2p.h"):
+    for f in ("wga_kernels.h", "wga_kernels_k2w.h"):
         h.update(open(os.path.join(ROOT, "wgatools_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -121,7 +121,7 @@ def pmc_traffic(args, job):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE and WRITE_SIZE are
     collected in their own rocprofv3 runs — scripts/gpu_pmc.sh — and corrected as MI355X_MICROARCH.md prescribes; they
     cannot be read live).  Only valid for the workload AND the kernel source they were measured on: anything else -> null."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:

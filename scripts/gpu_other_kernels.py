@@ -1,13 +1,14 @@
-"""throughput of the remaining op-stream kernels (K5 pafcov, K6 pafpseudo, K7 PAF call events) on the
-BASELINE configs[1] batch (100 000 records x mean 5 kop)"""
+"""throughput of the remaining op-stream kernels (K5 pafcov, K6 pafpseudo, K7 PAF call events, K9 - K12) on the
+BASELINE configs[1] batch (100 000 records x mean 5 kop), or on `nrec` records of `mean_ops` ops"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from wgatools_amd import engine, synth
 
 nrec = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+mean_ops = int(sys.argv[2]) if len(sys.argv) > 2 else 5000     # e.g. 10000 50000: the records go through the piece kernels
 dev = torch.device("cuda", 0)
-tb = synth.make_paf_batch_torch(0x5747415F + 2, nrec, 5000, 50_000_000, dev)
+tb = synth.make_paf_batch_torch(0x5747415F + 2, nrec, mean_ops, 50_000_000, dev)
 eng = engine.Engine(0)
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 batch = engine.Batch(tb["ops"], tb["op_off"], tb["strand_neg"], tb["n"], tb["n_ops"])

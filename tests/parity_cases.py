@@ -1037,6 +1037,48 @@ def check_cigar_chain_long_records(eng, mops=2):
         check_cigar_chain(eng, ops, off)
 
 
+def check_piece_table_rebuild(eng):
+    """the count call of K7 / K10 / K12 leaves its piece table for the fill call; a fill call that does not find it (another
+    walk ran in between) builds it again: both ways give the same output"""
+    eng.set_param("op_long_ops", 600)
+    eng.set_param("op_piece_ops", 256)
+    try:
+        ops, off = long_record_ops(11, 3, 2300)
+        n = len(off) - 1
+        batch = eng.make_batch(ops, off, np.zeros(n, dtype=np.uint8))
+        zeros = eng.upload(np.zeros(n, dtype=np.uint64))
+        def k7(between):
+            cnt = eng.paf_call_events(batch, 5, True)
+            between()
+            eo = eng.exclusive_scan_u64(n, cnt)
+            ev = eng.empty(3 * int(eo.numpy()[-1]) + 3, np.uint64).fill(0)
+            eng.paf_call_events(batch, 5, True, ev_cnt=cnt, ev=ev, ev_off=eo)
+            return ev.numpy().copy()
+        def k10(between):
+            _, nb, _ = eng.cigar_chain(batch)
+            between()
+            oo = eng.exclusive_scan_u64(n, nb)
+            out = eng.empty(int(oo.numpy()[-1]) + 8, np.uint8).fill(0)
+            eng.cigar_chain(batch, out=out, out_off=oo)
+            return out.numpy().copy()
+        def k12(between):
+            cnt = eng.cigar_dotplot(batch, 0, zeros, zeros)
+            between()
+            so = eng.exclusive_scan_u64(n, cnt)
+            sg = eng.empty(5 * int(so.numpy()[-1]) + 5, np.uint64).fill(0)
+            eng.cigar_dotplot(batch, 0, zeros, zeros, segs=sg, seg_off=so)
+            return sg.numpy().copy()
+        walks = (k7, k10, k12)
+        for x, w in enumerate(walks):
+            kept = w(lambda: None)
+            other = walks[(x + 1) % 3]
+            rebuilt = w(lambda: other(lambda: None))
+            assert kept.size > 100 and (kept == rebuilt).all(), x
+    finally:
+        eng.set_param("op_long_ops", 16384)
+        eng.set_param("op_piece_ops", 8192)
+
+
 def chain_stress_records(seed, n=40, max_ops=2600):
     """records that exercise the step structure of K10 (512-op steps, 8 ops per lane, 64 lines per round): several
     steps, steps without a raise, a raise on every other op, leading / trailing indel runs longer than a step, ten-digit

@@ -304,6 +304,10 @@ def test_dotplot_long_records_in_pieces(emu):
     pc.check_dotplot_long_records(emu, mops=0)
 
 
+def test_piece_table_kept_or_rebuilt(emu):
+    pc.check_piece_table_rebuild(emu)
+
+
 def test_cigar_chain_long_records_in_pieces(emu):
     pc.check_cigar_chain_long_records(emu, mops=0)
     ops, off = pc.long_record_ops(7, 1, 40_000)     # the product's piece size

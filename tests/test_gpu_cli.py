@@ -32,6 +32,7 @@ def test_gpus_flag_with_the_devices_of_this_box(cli, tmp_path):
     the oracle; one device more than visible is refused.  2 and 3 devices run on the emulator build
     (test_emu_cli_multi.py)."""
     import ctypes
+    import torch  # noqa: F401  first, as in conftest._gpu_engine(): libwgahip.so then shares torch's HIP runtime in this process
     import multi_gpu_cli_cases as mc
     have = ctypes.CDLL(build.HIP_LIB).wga_device_count()
     assert have >= 1

@@ -388,6 +388,10 @@ def test_dotplot_long_records_in_pieces(gpu):
     pc.check_dotplot_long_records(gpu, mops=2)
 
 
+def test_piece_table_kept_or_rebuilt(gpu):
+    pc.check_piece_table_rebuild(gpu)
+
+
 def test_cigar_chain_long_records_in_pieces(gpu):
     pc.check_cigar_chain_long_records(gpu, mops=2)
 

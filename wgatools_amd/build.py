@@ -27,7 +27,45 @@ def _newer(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+def _locked(fn):
+    """one build at a time across processes (pytest-xdist workers would otherwise link the same output at once, and run a
+    binary while another worker rewrites it)"""
+    import fcntl
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*a, **kw):
+        if _lock_depth[0]:     # a build that builds what it links against
+            return fn(*a, **kw)
+        with open(os.path.join(ROOT, ".build.lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            _lock_depth[0] += 1
+            try:
+                return fn(*a, **kw)
+            finally:
+                _lock_depth[0] -= 1
+                fcntl.flock(lk, fcntl.LOCK_UN)
+    return wrapper
+
+
+_lock_depth = [0]
+
+
 def _run(cmd, cwd=None):
+    """runs a compiler; an `-o <target>` is produced next to the target and renamed over it (never a half-written file)"""
+    cmd = list(cmd)
+    final = None
+    if "-o" in cmd:
+        k = cmd.index("-o") + 1
+        final = cmd[k]
+        cmd[k] = final + ".tmp%d" % os.getpid()
+    r = _run_raw(cmd, cwd)
+    if final:
+        os.replace(cmd[cmd.index("-o") + 1], final)
+    return r
+
+
+def _run_raw(cmd, cwd=None):
     r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout)
@@ -41,6 +79,7 @@ def _sources():
     ]
 
 
+@_locked
 def build_hip(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not force and not _newer(HIP_LIB, _sources()):
@@ -61,6 +100,7 @@ def build_hip(force=False, verbose=False):
     return HIP_LIB
 
 
+@_locked
 def build_hip_variant(name, extra_flags):
     """build_variants/libwgahip_<name>.so: the library with extra compiler flags, next to the product build (A/B
     measurements in ONE process on the same buffers: scripts/gpu_k2_same_buffers.py).  Never loaded by the product."""
@@ -80,6 +120,7 @@ def build_hip_variant(name, extra_flags):
     return lib
 
 
+@_locked
 def build_emu(force=False):
     srcs = _sources() + [os.path.join(ROOT, "tests", "emu", "simt_emu.h")]
     if not force and not _newer(EMU_LIB, srcs):
@@ -95,6 +136,7 @@ def build_emu(force=False):
 CLI_BIN = os.path.join(ROOT, "wgatools_amd", "bin", "wgatools")
 
 
+@_locked
 def build_cli(force=False):
     """the `wgatools` drop-in command line (C++ host layer over the C-ABI)"""
     hdir = os.path.join(ROOT, "wgatools_amd", "host")
@@ -109,6 +151,7 @@ def build_cli(force=False):
     return CLI_BIN
 
 
+@_locked
 def build_cli_emu(force=False):
     """tests/emu/wgatools_emu — the CLI host code linked against the emulator build of the kernels.
     Test infrastructure: lets the CPU suite exercise the host logic end to end without a GPU."""
@@ -123,6 +166,7 @@ def build_cli_emu(force=False):
     return CLI_EMU_BIN
 
 
+@_locked
 def build_oracle(force=False):
     srcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle.c", "cpu_bench.c", "oracle.h")]
     if not force and not _newer(ORACLE_LIB, srcs):

@@ -48,6 +48,28 @@ struct wga_ctx {
   void* expand_dbg = nullptr;
   void* scratch = nullptr;
   size_t scratch_cap = 0;
+  /* the piece table of the op walks over long records (K7, K10, K12): built by the count call of the two-call protocol and
+   * kept for the fill call on the same batch with the same parameters (the key), in a buffer of its own (grow-only) */
+  struct OpTabKey {
+    int kernel = 0;
+    const void *ops = nullptr, *op_off = nullptr, *x0 = nullptr, *x1 = nullptr, *x2 = nullptr;
+    uint32_t n = 0;
+    uint64_t n_ops = 0, p0 = 0, p1 = 0, long_ops = 0, piece_ops = 0;
+    bool operator==(const OpTabKey& o) const {
+      return kernel == o.kernel && ops == o.ops && op_off == o.op_off && x0 == o.x0 && x1 == o.x1 && x2 == o.x2 && n == o.n &&
+             n_ops == o.n_ops && p0 == o.p0 && p1 == o.p1 && long_ops == o.long_ops && piece_ops == o.piece_ops;
+    }
+  };
+  struct OpTab {
+    void* mem = nullptr;
+    size_t cap = 0;
+    OpTabKey key;
+    bool valid = false;
+    uint32_t np = 0;
+    u64* piece_off = nullptr; /* n + 1 */
+    u32* piece_rec = nullptr; /* np: the record of every piece */
+    void* pieces = nullptr;   /* np x per_piece bytes */
+  } op_tab;
   void* cov_pieces = nullptr; /* pafcov: (window, piece) list, grow-only */
   u64 cov_pieces_cap = 0;
   /* optional per-launch timing of the expand kernel proper (events on the launch stream) */
@@ -296,39 +318,57 @@ static int maf_long_blocks(wga_ctx* c, u32 n, const u8* d_rows, const u64* d_t_o
   return WGA_OK;
 }
 
-/* the piece table of the op walks whose records can be long (K7, K12): per record the number of pieces (0: the one-wave
- * kernel keeps it), their exclusive scan and the total, in the context's scratch arena, followed by `per_piece` bytes per
- * piece.  *np = pieces, *piece_off (n + 1 entries), *pieces = the per-piece area. */
-static int op_piece_table(wga_ctx* c, const wga_cigar_batch* b, size_t per_piece, u32* np, u64** piece_off, void** pieces) {
+/* the piece table of the op walks whose records can be long (K7, K10, K12): per record the number of pieces (0: the one-wave
+ * kernel keeps it), their exclusive scan, every piece's record and `per_piece` bytes per piece, in c->op_tab.  Nothing comes
+ * back to the host: the table is sized by a bound (a record of nops > long_ops ops has at most nops / piece_ops + 1 pieces,
+ * and at most n_ops / long_ops records are long), t.np is that bound (0 when no record can be long) and the walks read the
+ * number of pieces from piece_off[n].  With `reuse` and a table built under the same key nothing is launched (the fill
+ * call of the protocol); otherwise the table is rebuilt and left invalid — the caller validates it (op_tab_keep) once its
+ * count walk and record scan are queued. */
+static int op_piece_table(wga_ctx* c, const wga_cigar_batch* b, size_t per_piece, const wga_ctx::OpTabKey& key, bool reuse,
+                          bool* hit) {
+  wga_ctx::OpTab& t = c->op_tab;
+  *hit = reuse && t.valid && t.key == key;
+  if (*hit) return WGA_OK;
+  t.valid = false;
+  t.np = 0;
+  if (b->n_ops <= c->op_long_ops) return WGA_OK;
   const u32 n = b->n;
   int rc;
-  void* ws;
-  const size_t head = ((size_t)n * 2 + 2 + (size_t)n / 1024 + 4) * sizeof(u64);
-  *np = 0;
-  for (int attempt = 0; attempt < 2; attempt++) {
-    const size_t want = head + 64 + (size_t)*np * per_piece;
-    if ((rc = ctx_scratch(c, want, &ws))) return rc;
-    u64* npieces = (u64*)ws;
-    u64* off = npieces + n;
-    u64* partial = off + n + 1;
-    WGA_LAUNCH(k_op_piece_counts, (n + 255u) / 256u, WGA_BLOCK, c->stream, n, (const u64*)b->d_op_off, (u64)c->op_long_ops,
-               (u64)c->op_piece_ops, npieces);
-    LAUNCH_CHECK();
-    ScanPlain sp;
-    sp.in = npieces;
-    if ((rc = run_scan_ws(c, sp, n, off, partial))) return rc;
-    u64 total = 0;
-    RT_CHECK(rt_d2h(&total, off + n, sizeof total, c->stream));
-    if (total > 0xFFFFFFF0ull) return fail(WGA_E_INVALID_ARG, "too many pieces for one call", nullptr);
-    *piece_off = off;
-    *pieces = (char*)ws + ((head + 63) & ~(size_t)63);
-    if ((u32)total == *np || c->scratch_cap >= head + 64 + (size_t)total * per_piece) {
-      *np = (u32)total;
-      return WGA_OK;
-    }
-    *np = (u32)total; /* the arena must grow: regrowing frees it, so the head is rebuilt */
+  const u64 n_long = b->n_ops / c->op_long_ops < (u64)n ? b->n_ops / c->op_long_ops : (u64)n;
+  const u64 bound = b->n_ops / c->op_piece_ops + n_long + 1;
+  if (bound > 0xFFFFFFF0ull) return fail(WGA_E_INVALID_ARG, "too many pieces for one call", nullptr);
+  const u32 np = (u32)bound;
+  const size_t head = (((size_t)n * 2 + 2 + (size_t)n / 1024 + 4) * sizeof(u64) + 63) & ~(size_t)63;
+  const size_t want = head + (((size_t)np * per_piece + 63) & ~(size_t)63) + (size_t)np * sizeof(u32) + 64;
+  if (t.cap < want) {
+    RT_CHECK(rt_sync(c->stream));
+    if (t.mem) RT_CHECK(rt_free(t.mem));
+    t.mem = nullptr, t.cap = 0;
+    const size_t cap = want < (1u << 20) ? (1u << 20) : want + want / 2;
+    RT_CHECK(rt_malloc(&t.mem, cap));
+    t.cap = cap;
   }
+  u64* npieces = (u64*)t.mem;
+  u64* off = npieces + n;
+  u64* partial = off + n + 1;
+  WGA_LAUNCH(k_op_piece_counts, (n + 255u) / 256u, WGA_BLOCK, c->stream, n, (const u64*)b->d_op_off, (u64)c->op_long_ops,
+             (u64)c->op_piece_ops, npieces);
+  LAUNCH_CHECK();
+  ScanPlain sp;
+  sp.in = npieces;
+  if ((rc = run_scan_ws(c, sp, n, off, partial))) return rc;
+  t.np = np;
+  t.piece_off = off;
+  t.pieces = (char*)t.mem + head;
+  t.piece_rec = (u32*)((char*)t.pieces + (((size_t)np * per_piece + 63) & ~(size_t)63));
+  WGA_LAUNCH(k_op_piece_records, (n + 255u) / 256u, WGA_BLOCK, c->stream, n, (const u64*)t.piece_off, t.piece_rec);
+  LAUNCH_CHECK();
   return WGA_OK;
+}
+static void op_tab_keep(wga_ctx* c, const wga_ctx::OpTabKey& key) {
+  c->op_tab.key = key;
+  c->op_tab.valid = true;
 }
 
 extern "C" {
@@ -371,6 +411,7 @@ void wga_ctx_destroy(wga_ctx* c) {
   if (c->tune.have_ev) rt_event_destroy(c->tune.ev[0]), rt_event_destroy(c->tune.ev[1]);
   if (c->scratch) (void)rt_free(c->scratch);
   if (c->cov_pieces) (void)rt_free(c->cov_pieces);
+  if (c->op_tab.mem) (void)rt_free(c->op_tab.mem);
   rt_stream_destroy(c->own_stream);
   delete c;
 }
@@ -1075,27 +1116,33 @@ int wga_cigar_chain(wga_ctx* c, const wga_cigar_batch* b, wga_chain_trim_t* d_tr
                d_out, (const u64*)d_out_off, (u64)c->op_long_ops);
   }
   LAUNCH_CHECK();
-  /* records beyond op_long_ops: pieces over the whole chip, cut where a line is certain (both calls of the protocol walk the
-   * pieces for their bytes: the scratch arena is not kept between calls) */
-  u32 np = 0;
-  u64* piece_off = nullptr;
-  void* pieces = nullptr;
-  if ((rc = op_piece_table(c, b, sizeof(wga_chain_piece), &np, &piece_off, &pieces))) return rc;
-  if (np == 0) return WGA_OK;
-  wga_chain_piece* pc = (wga_chain_piece*)pieces;
-  const u32 grid = np < 4u * 2048u ? (np + 3u) / 4u : 2048u;
-  WGA_LAUNCH((k_cigar_chain_pieces<0>), grid, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off,
-             (const u64*)piece_off, (u64)c->op_piece_ops, pc, d_out ? (wga_chain_trim*)nullptr : (wga_chain_trim*)d_trim,
-             d_out ? (wga_rec_diag*)nullptr : d_diag, (u8*)nullptr, (const u64*)nullptr);
-  LAUNCH_CHECK();
-  WGA_LAUNCH(k_cigar_chain_piece_scan, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off,
-             (const u64*)piece_off, pc, d_out ? (wga_chain_trim*)nullptr : (wga_chain_trim*)d_trim,
-             d_out ? (u64*)nullptr : (u64*)d_nbytes, d_out ? (wga_rec_diag*)nullptr : d_diag);
-  LAUNCH_CHECK();
+  /* records beyond op_long_ops: pieces over the whole chip, cut where a line is certain; the count call leaves the pieces'
+   * places for the fill call (op_piece_table) */
+  wga_ctx::OpTabKey key;
+  key.kernel = 10, key.ops = b->d_ops, key.op_off = b->d_op_off, key.n = b->n, key.n_ops = b->n_ops;
+  key.long_ops = c->op_long_ops, key.piece_ops = c->op_piece_ops;
+  bool hit = false;
+  if ((rc = op_piece_table(c, b, sizeof(wga_chain_piece), key, d_out != nullptr, &hit))) return rc;
+  const wga_ctx::OpTab& t = c->op_tab;
+  if (t.np == 0) return WGA_OK;
+  wga_chain_piece* pc = (wga_chain_piece*)t.pieces;
+  const u32 grid = t.np < 4u * 2048u ? (t.np + 3u) / 4u : 2048u;
+  if (!hit) {
+    WGA_LAUNCH((k_cigar_chain_pieces<0>), grid, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off,
+               (const u64*)t.piece_off, (const u32*)t.piece_rec, pc,
+               d_out ? (wga_chain_trim*)nullptr : (wga_chain_trim*)d_trim, d_out ? (wga_rec_diag*)nullptr : d_diag,
+               (u8*)nullptr, (const u64*)nullptr);
+    LAUNCH_CHECK();
+    WGA_LAUNCH(k_cigar_chain_piece_scan, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off,
+               (const u64*)t.piece_off, pc, d_out ? (wga_chain_trim*)nullptr : (wga_chain_trim*)d_trim,
+               d_out ? (u64*)nullptr : (u64*)d_nbytes, d_out ? (wga_rec_diag*)nullptr : d_diag);
+    LAUNCH_CHECK();
+    op_tab_keep(c, key);
+  }
   if (d_out) {
     WGA_LAUNCH((k_cigar_chain_pieces<1>), grid, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off,
-               (const u64*)piece_off, (u64)c->op_piece_ops, pc, (wga_chain_trim*)nullptr, (wga_rec_diag*)nullptr, d_out,
-               (const u64*)d_out_off);
+               (const u64*)t.piece_off, (const u32*)t.piece_rec, pc, (wga_chain_trim*)nullptr,
+               (wga_rec_diag*)nullptr, d_out, (const u64*)d_out_off);
     LAUNCH_CHECK();
   }
   return WGA_OK;
@@ -1156,25 +1203,29 @@ int wga_cigar_dotplot(wga_ctx* c, const wga_cigar_batch* b, uint64_t cutoff, con
   }
   LAUNCH_CHECK();
   /* records beyond op_long_ops: pieces over the whole chip (as in wga_paf_call_events) */
-  u32 np = 0;
-  u64* piece_off = nullptr;
-  void* pieces = nullptr;
-  if ((rc = op_piece_table(c, b, sizeof(wga_dot_piece), &np, &piece_off, &pieces))) return rc;
-  if (np == 0) return WGA_OK;
-  wga_dot_piece* pc = (wga_dot_piece*)pieces;
-  const u32 grid = np < 4u * 2048u ? (np + 3u) / 4u : 2048u;
-  WGA_LAUNCH((k_dotplot_pieces<0>), grid, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off, b->d_strand_neg,
-             (u64)cutoff, (const u64*)d_t_start, (const u64*)d_q_start, (const u64*)piece_off, (u64)c->op_piece_ops, pc,
-             (u64*)nullptr, (const u64*)nullptr);
-  LAUNCH_CHECK();
-  WGA_LAUNCH(k_dotplot_piece_scan, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off,
-             b->d_strand_neg, (u64)cutoff, (const u64*)d_t_start, (const u64*)d_q_start, (const u64*)piece_off, pc,
-             d_segs ? (u64*)nullptr : (u64*)d_seg_cnt);
-  LAUNCH_CHECK();
+  wga_ctx::OpTabKey key;
+  key.kernel = 12, key.ops = b->d_ops, key.op_off = b->d_op_off, key.n = b->n, key.n_ops = b->n_ops;
+  key.x0 = b->d_strand_neg, key.x1 = d_t_start, key.x2 = d_q_start, key.p0 = cutoff;
+  key.long_ops = c->op_long_ops, key.piece_ops = c->op_piece_ops;
+  bool hit = false;
+  if ((rc = op_piece_table(c, b, sizeof(wga_dot_piece), key, d_segs != nullptr, &hit))) return rc;
+  const wga_ctx::OpTab& t = c->op_tab;
+  if (t.np == 0) return WGA_OK;
+  wga_dot_piece* pc = (wga_dot_piece*)t.pieces;
+  const u32 grid = t.np < 4u * 2048u ? (t.np + 3u) / 4u : 2048u;
+  if (!hit) {
+    WGA_LAUNCH((k_dotplot_pieces<0>), grid, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off, b->d_strand_neg,
+               (u64)cutoff, (const u64*)d_t_start, (const u64*)d_q_start, (const u64*)t.piece_off, (const u32*)t.piece_rec, pc, (u64*)nullptr, (const u64*)nullptr);
+    LAUNCH_CHECK();
+    WGA_LAUNCH(k_dotplot_piece_scan, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off,
+               b->d_strand_neg, (u64)cutoff, (const u64*)d_t_start, (const u64*)d_q_start, (const u64*)t.piece_off, pc,
+               d_segs ? (u64*)nullptr : (u64*)d_seg_cnt);
+    LAUNCH_CHECK();
+    op_tab_keep(c, key);
+  }
   if (d_segs) {
     WGA_LAUNCH((k_dotplot_pieces<1>), grid, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off, b->d_strand_neg,
-               (u64)cutoff, (const u64*)d_t_start, (const u64*)d_q_start, (const u64*)piece_off, (u64)c->op_piece_ops, pc,
-               (u64*)d_segs, (const u64*)d_seg_off);
+               (u64)cutoff, (const u64*)d_t_start, (const u64*)d_q_start, (const u64*)t.piece_off, (const u32*)t.piece_rec, pc, (u64*)d_segs, (const u64*)d_seg_off);
     LAUNCH_CHECK();
   }
   return WGA_OK;
@@ -1205,24 +1256,31 @@ int wga_paf_call_events(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, in
              (const u64*)b->d_op_off, (u64)svlen, (u32)(snp != 0), (u64*)d_ev_cnt, (u64*)d_ev,
              (const u64*)d_ev_off, (u64)c->op_long_ops);
   LAUNCH_CHECK();
-  /* records beyond op_long_ops: pieces over the whole chip (both calls of the protocol walk the pieces for their sums; the
-   * fill call then walks them again with their start states) */
-  u32 np = 0;
-  u64* piece_off = nullptr;
-  void* pieces = nullptr;
-  if ((rc = op_piece_table(c, b, sizeof(wga_call_piece), &np, &piece_off, &pieces))) return rc;
-  if (np == 0) return WGA_OK;
-  wga_call_piece* pc = (wga_call_piece*)pieces;
-  const u32 grid = np < 4u * 2048u ? (np + 3u) / 4u : 2048u;
-  WGA_LAUNCH((k_paf_call_pieces<0>), grid, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off, (u64)svlen,
-             (u32)(snp != 0), (const u64*)piece_off, (u64)c->op_piece_ops, pc, (u64*)nullptr, (const u64*)nullptr);
-  LAUNCH_CHECK();
-  WGA_LAUNCH(k_paf_call_piece_scan, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, b->n, (const u64*)piece_off, pc,
-             d_ev ? (u64*)nullptr : (u64*)d_ev_cnt);
-  LAUNCH_CHECK();
+  /* records beyond op_long_ops: pieces over the whole chip; the count call walks the pieces for their sums and leaves their
+   * start states for the fill call (op_piece_table), which walks them again and writes */
+  wga_ctx::OpTabKey key;
+  key.kernel = 7, key.ops = b->d_ops, key.op_off = b->d_op_off, key.n = b->n, key.n_ops = b->n_ops;
+  key.p0 = svlen, key.p1 = snp != 0, key.long_ops = c->op_long_ops, key.piece_ops = c->op_piece_ops;
+  bool hit = false;
+  if ((rc = op_piece_table(c, b, sizeof(wga_call_piece), key, d_ev != nullptr, &hit))) return rc;
+  const wga_ctx::OpTab& t = c->op_tab;
+  if (t.np == 0) return WGA_OK;
+  wga_call_piece* pc = (wga_call_piece*)t.pieces;
+  const u32 grid = t.np < 4u * 2048u ? (t.np + 3u) / 4u : 2048u;
+  if (!hit) {
+    WGA_LAUNCH((k_paf_call_pieces<0>), grid, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off, (u64)svlen,
+               (u32)(snp != 0), (const u64*)t.piece_off, (const u32*)t.piece_rec, pc, (u64*)nullptr,
+               (const u64*)nullptr);
+    LAUNCH_CHECK();
+    WGA_LAUNCH(k_paf_call_piece_scan, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, b->n, (const u64*)t.piece_off, pc,
+               d_ev ? (u64*)nullptr : (u64*)d_ev_cnt);
+    LAUNCH_CHECK();
+    op_tab_keep(c, key);
+  }
   if (d_ev) {
     WGA_LAUNCH((k_paf_call_pieces<1>), grid, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off, (u64)svlen,
-               (u32)(snp != 0), (const u64*)piece_off, (u64)c->op_piece_ops, pc, (u64*)d_ev, (const u64*)d_ev_off);
+               (u32)(snp != 0), (const u64*)t.piece_off, (const u32*)t.piece_rec, pc, (u64*)d_ev,
+               (const u64*)d_ev_off);
     LAUNCH_CHECK();
   }
   return WGA_OK;

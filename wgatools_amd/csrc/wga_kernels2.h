@@ -1219,29 +1219,26 @@ struct wga_call_piece {
   u64 t, q, e;  /* MODE 0: the piece's sums; after the record scan: its start state */
   u64 bad;      /* MODE 0: record-relative first bad op or WGA_NONE; after the scan: 1 = dead, 0 = walk it */
 };
-/* record of piece p: last i with piece_off[i] <= p (wave-uniform bisection) */
-__device__ __forceinline__ u32 piece_record(const u64* __restrict__ piece_off, u32 n, u64 p) {
-  u32 lo = 0, hi = n;
-  while (hi - lo > 1u) {
-    const u32 mid = lo + ((hi - lo) >> 1);
-    if (piece_off[mid] <= p)
-      lo = mid;
-    else
-      hi = mid;
-  }
-  return lo;
+/* a record's pieces are equal: its ops over its number of pieces, rounded up to whole 256-op steps (<= piece_ops) */
+__device__ __forceinline__ u64 piece_span(u64 nops, u64 np) { return ((nops + np - 1) / np + 255u) & ~(u64)255u; }
+/* the record of every piece (one thread per record): the walks read it instead of bisecting piece_off per piece */
+__global__ __launch_bounds__(256) void k_op_piece_records(u32 n, const u64* __restrict__ piece_off, u32* piece_rec) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  for (u64 p = piece_off[i]; p < piece_off[i + 1]; p++) piece_rec[p] = i;
 }
 template <int MODE>
 __global__ __launch_bounds__(256) void k_paf_call_pieces(u32 n, const u32* __restrict__ ops, const u64* __restrict__ op_off,
-                                                         u64 svlen, u32 snp, const u64* __restrict__ piece_off, u64 piece_ops,
+                                                         u64 svlen, u32 snp, const u64* __restrict__ piece_off, const u32* __restrict__ piece_rec,
                                                          wga_call_piece* pc, u64* ev, const u64* ev_off) {
   const u32 lane = threadIdx.x & 63u;
   const u64 n_pieces = piece_off[n];
   const u64 n_waves = (u64)gridDim.x * 4u;
   for (u64 p = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x); p < n_pieces; p += n_waves) {
-    const u32 i = piece_record(piece_off, n, p);
+    const u32 i = WGA_UNI32(piece_rec[p]);
     const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
-    const u64 a = (p - piece_off[i]) * piece_ops, b = a + piece_ops < nops ? a + piece_ops : nops;
+    const u64 psz = piece_span(nops, piece_off[i + 1] - piece_off[i]);
+    const u64 a0 = (p - piece_off[i]) * psz, a = a0 < nops ? a0 : nops, b = a + psz < nops ? a + psz : nops;
     PafCallState st, tot;
     st.t = st.q = st.e = 0;
     u64 bad;
@@ -2040,7 +2037,7 @@ __global__ __launch_bounds__(256) void k_cigar_chain(u32 n, const u32* __restric
 /* ---- long records in pieces: the fold's state is (size, D bases, I bases) and it starts again at every line, so a record
  *      can be cut where a line is certain: op k is M-like, op k-1 an indel op of length >= 1, op k-2 an M-like op of length
  *      >= 1 ("size != 0 && diffs != 0" holds at k whatever came before, cigar.rs:472).  Piece j of a record beyond
- *      `long_ops` ops starts at the first such k at or behind j * piece_ops (none inside its piece_ops ops: the piece is
+ *      `long_ops` ops starts at the first such k at or behind j * piece_span (none inside its span: the piece is
  *      empty and its ops stay with the piece in front) and ends where the next non-empty piece starts; it is walked as a
  *      record of its own (chain_walk) whose last line is the one op k raises.  Count walk: bytes per piece; one thread per
  *      record: the record's bytes and every piece's place in its text; fill walk: the text.  A piece whose sums pass 2^32
@@ -2066,7 +2063,7 @@ __device__ __forceinline__ u64 chain_find_cut(const u32* rec, u64 lo, u64 hi, u3
 }
 template <int MODE>
 __global__ __launch_bounds__(256) void k_cigar_chain_pieces(u32 n, const u32* __restrict__ ops, const u64* __restrict__ op_off,
-                                                            const u64* __restrict__ piece_off, u64 piece_ops,
+                                                            const u64* __restrict__ piece_off, const u32* __restrict__ piece_rec,
                                                             wga_chain_piece* pc, wga_chain_trim* trims, wga_rec_diag* diag,
                                                             u8* out, const u64* out_off) {
   __shared__ u32x4_a16 s_slot[4][WGA_CHAIN_NL];
@@ -2085,7 +2082,7 @@ __global__ __launch_bounds__(256) void k_cigar_chain_pieces(u32 n, const u32* __
   const u64 n_pieces = piece_off[n];
   const u64 n_waves = (u64)gridDim.x * 4u;
   for (u64 p = (u64)blockIdx.x * 4 + wave; p < n_pieces; p += n_waves) {
-    const u32 i = piece_record(piece_off, n, p);
+    const u32 i = WGA_UNI32(piece_rec[p]);
     const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
     const u32* rec = ops + o0;
     const u64 j = p - piece_off[i], np = piece_off[i + 1] - piece_off[i];
@@ -2095,13 +2092,14 @@ __global__ __launch_bounds__(256) void k_cigar_chain_pieces(u32 n, const u32* __
     if (MODE == 0) {
       wga_chain_piece r;
       r.nb = 0, r.off = 0;
-      const u64 lo = j * piece_ops;
-      r.a = j == 0 ? 0 : chain_find_cut(rec, lo, lo + piece_ops < nops ? lo + piece_ops : nops, lane);
+      const u64 psz = piece_span(nops, np);
+      const u64 lo = j * psz;
+      r.a = j == 0 ? 0 : chain_find_cut(rec, lo, lo + psz < nops ? lo + psz : nops, lane);
       r.b = WGA_NONE;
       if (r.a != WGA_NONE) {
         for (u64 jj = j + 1; jj < np && r.b == WGA_NONE; jj++) {
-          const u64 l2 = jj * piece_ops;
-          r.b = chain_find_cut(rec, l2, l2 + piece_ops < nops ? l2 + piece_ops : nops, lane);
+          const u64 l2 = jj * psz;
+          r.b = chain_find_cut(rec, l2, l2 + psz < nops ? l2 + psz : nops, lane);
         }
         if (r.b == WGA_NONE) r.b = nops;
         const u64 nb = chain_walk<false>(rec + r.a, r.b - r.a, (u8*)0, j == 0, r.b == nops, lane, slot, p10, tbuf, st, &weird,
@@ -2504,15 +2502,16 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_dotplot_pieces(u32 n, const u32* __restrict__ ops, const u64* __restrict__ op_off,
                                                         const u8* __restrict__ strand_neg, u64 cutoff,
                                                         const u64* __restrict__ t_start, const u64* __restrict__ q_start,
-                                                        const u64* __restrict__ piece_off, u64 piece_ops, wga_dot_piece* pc,
+                                                        const u64* __restrict__ piece_off, const u32* __restrict__ piece_rec, wga_dot_piece* pc,
                                                         u64* segs, const u64* seg_off) {
   const u32 lane = threadIdx.x & 63u;
   const u64 n_pieces = piece_off[n];
   const u64 n_waves = (u64)gridDim.x * 4u;
   for (u64 p = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x); p < n_pieces; p += n_waves) {
-    const u32 i = piece_record(piece_off, n, p);
+    const u32 i = WGA_UNI32(piece_rec[p]);
     const u64 o0 = op_off[i], nops = op_off[i + 1] - o0;
-    const u64 a = (p - piece_off[i]) * piece_ops, b = a + piece_ops < nops ? a + piece_ops : nops;
+    const u64 psz = piece_span(nops, piece_off[i + 1] - piece_off[i]);
+    const u64 a0 = (p - piece_off[i]) * psz, a = a0 < nops ? a0 : nops, b = a + psz < nops ? a + psz : nops;
     const bool neg = strand_neg[i] != 0;
     DotState ds;
     u32 first_ev = 0u;
