@@ -264,6 +264,33 @@ int wga_maf_call_runs(wga_ctx*, uint32_t n, const uint8_t* d_rows, const uint64_
 int wga_paf_call_events(wga_ctx*, const wga_cigar_batch*, uint64_t svlen, int snp, uint64_t* d_ev_cnt,
                         uint64_t* d_ev, const uint64_t* d_ev_off);
 
+/* ---- call on PAF: the VCF rows of the events (replaces the record building and printing of call_within_var_paf,
+ *      caller.rs:640-658 the <INV> row of a '-' record, :688-717 one row per column of an X op, :719-813 the INS / DEL
+ *      rows of indels longer than `svlen`; text layout of noodles-vcf 0.43, README.md:323-343) ---------------------
+ * Record i's text is its rows in the reference's order:
+ *   <target>\t<pos>\t.\t<REF>\t<ALT>\t.\t.\t<INFO or .>\tGT:QI\t1|1:<query>@<a>[@<b>]@<P|N>\n
+ * d_ev / d_ev_off: the events of wga_paf_call_events on the same batch (with the same svlen).  d_recs: per record its
+ * names (offsets into d_names), PAF coordinates and the place of its fetched target / query sequence inside the pools
+ * (paf.rs:221-237: [start, end] inclusive, clipped at the contig end).  Two calls: d_out == NULL -> d_nbytes[n] and
+ * d_err[n]; then d_out_off = exclusive scan of d_nbytes and the call again with d_out.  d_err[i].item == ~0: clean;
+ * otherwise the record's first failing item (0 = the <INV> row, 1 + e = event e) with kind 1 = a REF / ALT slice outside
+ * the fetched sequence (the reference's slice panic, caller.rs:695-696,753-754,800-801) or kind 2 = a base outside
+ * ACGTN in any case (noodles-vcf's parse error; ch = the byte); the record's text ends in front of that item. */
+typedef struct {
+  uint64_t t_name_off, q_name_off;
+  uint32_t t_name_len, q_name_len;
+  uint64_t t_start, t_end, q_start, q_end;
+  uint64_t t_off, t_len, q_off, q_len;
+} wga_vcf_rec;
+typedef struct {
+  uint64_t item;
+  uint32_t kind, ch;
+} wga_vcf_err;
+int wga_paf_call_vcf(wga_ctx*, const wga_cigar_batch*, uint64_t svlen, const uint64_t* d_ev, const uint64_t* d_ev_off,
+                     const wga_vcf_rec* d_recs, const uint8_t* d_names, const uint8_t* d_t_pool,
+                     const uint8_t* d_q_pool, uint64_t* d_nbytes, wga_vcf_err* d_err, uint8_t* d_out,
+                     const uint64_t* d_out_off);
+
 /* ---- paf2chain: the data lines of parse_cigar_to_chain + cigar_unit_chain
  *      (cigar.rs:251-295,460-490) and the head / tail indel trim of parse_cigar_to_trim
  *      (cigar.rs:202-245) that the chain header needs (chain.rs:142-183) ----------------------------

@@ -602,6 +602,48 @@ def test_call_paf_fold_errors_are_discarded(cli, tmp_path):
     assert rc == 1 and err.strip().endswith("ERROR target and query are necessary")
 
 
+def test_call_paf_rows_from_the_device(cli, tmp_path):
+    """the VCF rows are formatted on the device (wga_paf_call_vcf): lower-case bases come out upper-case (noodles-vcf),
+    several records and names, rows longer than the kernel's staging buffer (a 9 kb deletion); a base outside ACGTN and a
+    REF / ALT slice beyond the fetched sequence end the run with nothing written"""
+    rng = np.random.default_rng(12)
+    tseq = bytes(rng.choice(list(b"acgtACGTn"), 12000).astype(np.uint8))
+    qseq = bytes(rng.choice(list(b"ACGTacgt"), 3000).astype(np.uint8))
+    def write(recs, tseq=tseq, qseq=qseq):
+        t_fa, q_fa, paf = tmp_path / "t.fa", tmp_path / "q.fa", tmp_path / "in.paf"
+        for path, name, seq in ((t_fa, b"tg#1#chr1", tseq), (q_fa, b"qry", qseq)):
+            with open(path, "wb") as f:
+                f.write(b">" + name + b"\n")
+                for i in range(0, len(seq), 60):
+                    f.write(seq[i:i + 60] + b"\n")
+        with open(paf, "w") as f:
+            for (q0, q1, neg, t0, t1, cg) in recs:
+                f.write("qry\t%d\t%d\t%d\t%s\ttg#1#chr1\t%d\t%d\t%d\t0\t0\t60\t%s\n" % (
+                    len(qseq), q0, q1, "-" if neg else "+", len(tseq), t0, t1, cg))
+        return str(t_fa), str(q_fa), str(paf)
+    recs = [(0, 30, False, 0, 9030, "cg:Z:5=1X4=9000D3=3X2=4I8="),
+            (100, 1100, True, 9500, 10480, "cg:Z:" + "7=1X2=2I3=1D" * 60 + "40="),
+            (5, 25, False, 11000, 11020, "cg:Z:20="),
+            (2000, 2100, True, 200, 320, "cg:Z:50=20D10=1X39=")]
+    t_fa, q_fa, paf = write(recs)
+    for svlen, snp in ((0, True), (3, False), (10000, True)):
+        rc, out, err = run(cli, *(["call", "-f", "paf", paf, "--target", t_fa, "-q", q_fa, "-l", str(svlen), "-n", "S1"]
+                                  + (["-s"] if snp else [])))
+        assert rc == 0, err
+        want = VCF_HEADER % "S1" + "".join(
+            orc.call_within_var_paf("tg#1#chr1", "qry", cg, tseq[t0:t1 + 1], qseq[q0:q1 + 1], t0, t1, q0, q1, neg, snp, svlen)
+            for (q0, q1, neg, t0, t1, cg) in recs)
+        assert out.decode() == want, (svlen, snp)
+    bad_t = bytearray(tseq)
+    bad_t[9507] = ord("R")                                   # REF of the second record's first X column
+    t_fa, q_fa, paf = write(recs, tseq=bytes(bad_t))
+    rc, out, err = run(cli, "call", "-f", "paf", paf, "--target", t_fa, "-q", q_fa, "-l", "0", "-s")
+    assert rc == 1 and out == b"" and "invalid reference/alternate base `R`" in err, err
+    t_fa, q_fa, paf = write([(0, 30, False, 11990, 12030, "cg:Z:12=1X17=")])   # the contig ends at 12 000
+    rc, out, err = run(cli, "call", "-f", "paf", paf, "--target", t_fa, "-q", q_fa, "-l", "0", "-s")
+    assert rc == 1 and out == b"" and "panic: VCF REF/ALT slice out of the fetched sequence" in err
+
+
 def test_call_maf_index_contigs(cli, tmp_path):
     """utils.rs:414-436 + caller.rs:340-357: `<maf>.index` adds natord-sorted ##contig lines of the
     reference sequences (placement after the FORMAT lines is unpinned)"""

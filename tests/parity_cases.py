@@ -812,9 +812,10 @@ def check_paf_call_events(eng, ops, op_off, svlen, snp):
     return int(o[-1])
 
 
-def long_record_ops(seed, n_long, long_ops, bad_in=None):
-    """records mixed short / long: every `long` one holds `long_ops` ops; bad_in = (record, op index) gets an op the walks
-    stop at.  Piece boundaries (multiples of 256) are made nasty: an indel right behind a boundary, a continuation piece
+def long_record_ops(seed, n_long, long_ops, bad_in=None, shorts=1):
+    """records mixed short / long: every `long` one holds `long_ops` ops and is followed by `shorts` batches of 3 short
+    ones (few of them: every record goes through the piece kernels; many: the short ones stay with the one-wave kernel);
+    bad_in = (record, op index) gets an op the walks stop at.  Piece boundaries (multiples of 256) are made nasty: an indel right behind a boundary, a continuation piece
     of a split indel starting a piece, X ops at the cut."""
     from wgatools_amd import synth
     rng = np.random.default_rng(seed)
@@ -836,8 +837,9 @@ def long_record_ops(seed, n_long, long_ops, bad_in=None):
                 ops[cut - 1] = (2 << 4) | 8          # X | X across the cut
                 ops[cut] = (1 << 4) | 8
         recs.append(ops)
-        short, _, _, _ = synth.make_ops(rng, 3, 40)
-        recs.append(short)
+        for _ in range(shorts):
+            short, _, _, _ = synth.make_ops(rng, 3, 40)
+            recs.append(short)
     if bad_in is not None:
         recs[bad_in[0]][bad_in[1]] = (4 << 4) | 3     # N
     ops = np.concatenate(recs).astype(np.uint32)
@@ -856,6 +858,8 @@ def check_paf_call_long_records(eng, mops=2):
             check_paf_call_events(eng, ops, off, svlen, snp)
         ops, off = long_record_ops(6, 3, 1500, bad_in=(2, 700))
         check_paf_call_events(eng, ops, off, 3, True)
+        ops, off = long_record_ops(9, 2, 2300, shorts=12)      # mostly short records: two kernels share the batch
+        check_paf_call_events(eng, ops, off, 4, True)
     finally:
         eng.set_param("op_long_ops", 16384)
         eng.set_param("op_piece_ops", 8192)
@@ -1015,6 +1019,8 @@ def check_cigar_chain_long_records(eng, mops=2):
             ops, off = long_record_ops(seed, 3, 2300)
             check_cigar_chain(eng, ops, off)
         ops, off = long_record_ops(6, 3, 1500, bad_in=(2, 700))
+        check_cigar_chain(eng, ops, off)
+        ops, off = long_record_ops(9, 2, 2300, shorts=12)      # mostly short records: two kernels share the batch
         check_cigar_chain(eng, ops, off)
         recs = [
             mk([(7, 2), (8, 1)] * 900),                                           # no indel: one piece, the others empty
@@ -1226,6 +1232,8 @@ def check_dotplot_long_records(eng, mops=2):
             check_dotplot(eng, ops, off, [1], cutoff)
         ops, off = long_record_ops(8, 2, 1500)           # split indels: continuation pieces -> serial walk
         check_dotplot(eng, ops, off, [0] * (len(off) - 1), 10)
+        ops, off = long_record_ops(9, 2, 2300, shorts=12)  # mostly short records: two kernels share the batch
+        check_dotplot(eng, ops, off, [k & 1 for k in range(len(off) - 1)], 3)
     finally:
         eng.set_param("op_long_ops", 16384)
         eng.set_param("op_piece_ops", 8192)

@@ -13,6 +13,7 @@
 #include "wga_kernels_k2w.h"
 #ifdef WGA_STAGE2
 #include "wga_kernels2.h"
+#include "wga_kernels3.h"
 #endif
 
 struct wga_ctx {
@@ -66,6 +67,7 @@ struct wga_ctx {
     OpTabKey key;
     bool valid = false;
     uint32_t np = 0;
+    bool all = false;         /* every record is in the table (the one-wave kernel is not launched) */
     u64* piece_off = nullptr; /* n + 1 */
     u32* piece_rec = nullptr; /* np: the record of every piece */
     void* pieces = nullptr;   /* np x per_piece bytes */
@@ -318,6 +320,9 @@ static int maf_long_blocks(wga_ctx* c, u32 n, const u8* d_rows, const u64* d_t_o
   return WGA_OK;
 }
 
+static bool op_all_pieces(const wga_ctx* c, const wga_cigar_batch* b) {
+  return b->n && b->n_ops > c->op_long_ops && b->n_ops / b->n > c->op_long_ops / 2;
+}
 /* the piece table of the op walks whose records can be long (K7, K10, K12): per record the number of pieces (0: the one-wave
  * kernel keeps it), their exclusive scan, every piece's record and `per_piece` bytes per piece, in c->op_tab.  Nothing comes
  * back to the host: the table is sized by a bound (a record of nops > long_ops ops has at most nops / piece_ops + 1 pieces,
@@ -332,10 +337,14 @@ static int op_piece_table(wga_ctx* c, const wga_cigar_batch* b, size_t per_piece
   if (*hit) return WGA_OK;
   t.valid = false;
   t.np = 0;
+  t.all = false;
   if (b->n_ops <= c->op_long_ops) return WGA_OK;
   const u32 n = b->n;
   int rc;
-  const u64 n_long = b->n_ops / c->op_long_ops < (u64)n ? b->n_ops / c->op_long_ops : (u64)n;
+  /* a batch of mostly long records: the few short ones are one piece each, so that one grid walks everything (the one-wave
+   * kernel would run for the length of its longest record with the chip nearly empty) */
+  t.all = op_all_pieces(c, b);
+  const u64 n_long = t.all ? (u64)n : (b->n_ops / c->op_long_ops < (u64)n ? b->n_ops / c->op_long_ops : (u64)n);
   const u64 bound = b->n_ops / c->op_piece_ops + n_long + 1;
   if (bound > 0xFFFFFFF0ull) return fail(WGA_E_INVALID_ARG, "too many pieces for one call", nullptr);
   const u32 np = (u32)bound;
@@ -353,7 +362,7 @@ static int op_piece_table(wga_ctx* c, const wga_cigar_batch* b, size_t per_piece
   u64* off = npieces + n;
   u64* partial = off + n + 1;
   WGA_LAUNCH(k_op_piece_counts, (n + 255u) / 256u, WGA_BLOCK, c->stream, n, (const u64*)b->d_op_off, (u64)c->op_long_ops,
-             (u64)c->op_piece_ops, npieces);
+             (u64)c->op_piece_ops, (u32)t.all, npieces);
   LAUNCH_CHECK();
   ScanPlain sp;
   sp.in = npieces;
@@ -1106,12 +1115,14 @@ int wga_cigar_chain(wga_ctx* c, const wga_cigar_batch* b, wga_chain_trim_t* d_tr
   if (!d_out) {
     if (!d_trim || !d_nbytes || !d_diag) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
     RT_CHECK(rt_memset(d_diag, 0xFF, (size_t)b->n * sizeof(wga_rec_diag), c->stream));
-    WGA_LAUNCH(k_cigar_chain<false>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
+    if (!op_all_pieces(c, b))
+      WGA_LAUNCH(k_cigar_chain<false>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
                (const u64*)b->d_op_off, (wga_chain_trim*)d_trim, (u64*)d_nbytes, d_diag, (u8*)nullptr,
                (const u64*)nullptr, (u64)c->op_long_ops);
   } else {
     if (!d_out_off) return fail(WGA_E_INVALID_ARG, "d_out_off null", nullptr);
-    WGA_LAUNCH(k_cigar_chain<true>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
+    if (!op_all_pieces(c, b))
+      WGA_LAUNCH(k_cigar_chain<true>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
                (const u64*)b->d_op_off, (wga_chain_trim*)nullptr, (u64*)nullptr, (wga_rec_diag*)nullptr,
                d_out, (const u64*)d_out_off, (u64)c->op_long_ops);
   }
@@ -1192,12 +1203,14 @@ int wga_cigar_dotplot(wga_ctx* c, const wga_cigar_batch* b, uint64_t cutoff, con
   if (!d_t_start || !d_q_start) return fail(WGA_E_INVALID_ARG, "start arrays null", nullptr);
   if (!d_segs) {
     if (!d_seg_cnt) return fail(WGA_E_INVALID_ARG, "d_seg_cnt null", nullptr);
-    WGA_LAUNCH(k_dotplot_segments<false>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
+    if (!op_all_pieces(c, b))
+      WGA_LAUNCH(k_dotplot_segments<false>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
                (const u64*)b->d_op_off, b->d_strand_neg, (u64)cutoff, (const u64*)d_t_start,
                (const u64*)d_q_start, (u64*)d_seg_cnt, (u64*)nullptr, (const u64*)nullptr, (u64)c->op_long_ops);
   } else {
     if (!d_seg_off) return fail(WGA_E_INVALID_ARG, "d_seg_off null", nullptr);
-    WGA_LAUNCH(k_dotplot_segments<true>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
+    if (!op_all_pieces(c, b))
+      WGA_LAUNCH(k_dotplot_segments<true>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
                (const u64*)b->d_op_off, b->d_strand_neg, (u64)cutoff, (const u64*)d_t_start,
                (const u64*)d_q_start, (u64*)nullptr, (u64*)d_segs, (const u64*)d_seg_off, (u64)c->op_long_ops);
   }
@@ -1252,7 +1265,8 @@ int wga_paf_call_events(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, in
   if ((rc = check_batch(b))) return rc;
   if (b->n == 0) return WGA_OK;
   if (d_ev && !d_ev_off) return fail(WGA_E_INVALID_ARG, "d_ev_off null", nullptr);
-  WGA_LAUNCH(k_paf_call_events, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
+  if (!op_all_pieces(c, b))
+    WGA_LAUNCH(k_paf_call_events, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops,
              (const u64*)b->d_op_off, (u64)svlen, (u32)(snp != 0), (u64*)d_ev_cnt, (u64*)d_ev,
              (const u64*)d_ev_off, (u64)c->op_long_ops);
   LAUNCH_CHECK();
@@ -1283,6 +1297,32 @@ int wga_paf_call_events(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, in
                (const u64*)d_ev_off);
     LAUNCH_CHECK();
   }
+  return WGA_OK;
+}
+
+int wga_paf_call_vcf(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, const uint64_t* d_ev, const uint64_t* d_ev_off,
+                     const wga_vcf_rec* d_recs, const uint8_t* d_names, const uint8_t* d_t_pool, const uint8_t* d_q_pool,
+                     uint64_t* d_nbytes, wga_vcf_err* d_err, uint8_t* d_out, const uint64_t* d_out_off) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if ((rc = check_batch(b))) return rc;
+  if (b->n == 0) return WGA_OK;
+  static_assert(sizeof(wga_vcf_rec) == sizeof(wga_vcf_rec_dev) && sizeof(wga_vcf_rec) == 88, "wga_vcf_rec layout");
+  static_assert(sizeof(wga_vcf_err) == sizeof(wga_vcf_err_dev) && sizeof(wga_vcf_err) == 16, "wga_vcf_err layout");
+  if (!d_ev_off || !d_recs || !d_names || !d_t_pool || !d_q_pool) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  if (!d_out) {
+    if (!d_nbytes || !d_err) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+    RT_CHECK(rt_memset(d_err, 0xFF, (size_t)b->n * sizeof(wga_vcf_err), c->stream));
+    WGA_LAUNCH(k_paf_call_vcf<false>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off,
+               b->d_strand_neg, (u64)svlen, (const u64*)d_ev, (const u64*)d_ev_off, (const wga_vcf_rec_dev*)d_recs, d_names,
+               d_t_pool, d_q_pool, (u64*)d_nbytes, (wga_vcf_err_dev*)d_err, (u8*)nullptr, (const u64*)nullptr);
+  } else {
+    if (!d_out_off) return fail(WGA_E_INVALID_ARG, "d_out_off null", nullptr);
+    WGA_LAUNCH(k_paf_call_vcf<true>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off,
+               b->d_strand_neg, (u64)svlen, (const u64*)d_ev, (const u64*)d_ev_off, (const wga_vcf_rec_dev*)d_recs, d_names,
+               d_t_pool, d_q_pool, (u64*)nullptr, (wga_vcf_err_dev*)nullptr, d_out, (const u64*)d_out_off);
+  }
+  LAUNCH_CHECK();
   return WGA_OK;
 }
 

@@ -1209,11 +1209,11 @@ __global__ __launch_bounds__(256) void k_paf_call_events(u32 n, const u32* __res
  *      piece's sums, one thread per record turns them into each piece's start state (running positions, events so far, "the
  *      walk has stopped": a piece behind the record's first bad op is dead), the second walk writes the events. ------------- */
 __global__ __launch_bounds__(256) void k_op_piece_counts(u32 n, const u64* __restrict__ op_off, u64 long_ops, u64 piece_ops,
-                                                         u64* npieces) {
+                                                         u32 all, u64* npieces) {
   const u32 i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   const u64 nops = op_off[i + 1] - op_off[i];
-  npieces[i] = nops > long_ops ? (nops + piece_ops - 1) / piece_ops : 0;
+  npieces[i] = nops > long_ops ? (nops + piece_ops - 1) / piece_ops : (u64)all; /* all: the other records are one piece each */
 }
 struct wga_call_piece {
   u64 t, q, e;  /* MODE 0: the piece's sums; after the record scan: its start state */

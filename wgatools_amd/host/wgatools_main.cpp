@@ -2927,7 +2927,7 @@ std::string vcf_header(const std::string& sample, const std::vector<std::pair<st
 }
 
 /* ---- call (PAF) (caller.rs:268-302, 610-822) -----------------------------------------------------------
- * GPU: the op walk (wga_paf_call_events).  Host: fetch coordinates, the event -> VCF row text. */
+ * GPU: the op walk (wga_paf_call_events) and the event -> VCF row text (wga_paf_call_vcf).  Host: fetch coordinates. */
 int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::string& q_fa, bool snp,
                  uint64_t svlen, const std::string& sample, Output& out) {
   Dev d;
@@ -2937,8 +2937,6 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
   d.init();
   tf.load(d, t_fa);
   qf.load(d, q_fa);
-  const std::string& t_host = tf.host_pool(d); /* REF / ALT text is cut from the bases on the host */
-  const std::string& q_host = qf.host_pool(d);
   std::string body;
   const size_t keep = d.owned.size(); /* the input text */
   const uint64_t kMaxText = 160ull << 20; /* ~64 M ops per batch */
@@ -2985,110 +2983,65 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
       if (terrs[k].err == WGA_REC_PANIC) fail(cigar_error_message(WGA_REC_PANIC, std::string(), 0, 0));
     if (cb.n < n_asked) fail(tag_err); /* records are processed in order: the first failing one ends the run */
     const uint32_t n = cb.n;
-    std::vector<uint32_t> h_ops;
-    std::vector<uint64_t> h_op_off(n + 1, 0);
     if (n) {
-      h_ops.resize(cb.n_ops + 1);
-      if (cb.n_ops) d.download(h_ops.data(), (const uint32_t*)cb.d_ops, cb.n_ops);
-      d.download(h_op_off.data(), (const uint64_t*)cb.d_op_off, n + 1);
       auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
       d.check(wga_paf_call_events(d.ctx, &cb, svlen, snp, d_cnt, nullptr, nullptr));
       auto* d_eoff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
       d.check(wga_exclusive_scan_u64(d.ctx, n, d_cnt, d_eoff));
-      std::vector<uint64_t> eoff(n + 1);
-      d.download(eoff.data(), d_eoff, n + 1);
-      auto* d_ev = (uint64_t*)d.alloc((3 * eoff[n] + 3) * 8);
+      uint64_t n_ev = 0;
+      d.download(&n_ev, (const uint64_t*)d_eoff + n, 1);
+      auto* d_ev = (uint64_t*)d.alloc((3 * n_ev + 3) * 8);
       d.check(wga_paf_call_events(d.ctx, &cb, svlen, snp, d_cnt, d_ev, d_eoff));
-      std::vector<uint64_t> ev(3 * eoff[n]);
-      if (eoff[n]) d.download(ev.data(), d_ev, 3 * eoff[n]);
-      /* the VCF text of a record depends on that record alone: ranges of records go to host threads, their text is
-       * appended in record order; the driver is buffered, so an error in any record leaves nothing written (:294-299) */
-      unsigned nthr = std::thread::hardware_concurrency();
-      nthr = std::max(1u, std::min({nthr, 32u, n / 64u + 1u}));
-      if (const char* e = getenv("WGA_HOST_THREADS")) nthr = std::max(1u, std::min((unsigned)atoi(e), n)); /* tests */
-      std::vector<std::string> parts(nthr), errs(nthr);
-      auto one_record = [&](uint32_t k, std::string& body) {
+      /* the rows are formatted where the events lie (wga_paf_call_vcf): names, coordinates and the places of the fetched
+       * sequences go up, the text comes back; the driver is buffered, so an error in any record leaves nothing written
+       * (:294-299) */
+      std::string names;
+      std::unordered_map<std::string, uint64_t> name_at;
+      auto name_off = [&](const std::string& nm) {
+        auto it = name_at.find(nm);
+        if (it != name_at.end()) return it->second;
+        const uint64_t at = names.size();
+        names += nm;
+        name_at.emplace(nm, at);
+        return at;
+      };
+      std::vector<wga_vcf_rec> vr(n);
+      for (uint32_t k = 0; k < n; k++) {
         const PafRecord& r = recs[i0 + k];
-        const char* ts = t_host.data() + t_off[k];
-        const char* qs = q_host.data() + q_off[k];
-        const uint64_t tn = t_len[k], qn = q_len[k];
-        const char suffix = r.neg ? 'N' : 'P';
-        auto qi = [&](uint64_t a, uint64_t b2, bool three) {
-          std::string s2 = r.query_name + "@";
-          append_u64(s2, a);
-          if (!three) {
-            s2.push_back('@');
-            append_u64(s2, b2);
-          }
-          s2.push_back('@');
-          s2.push_back(suffix);
-          return s2;
-        };
-        if (r.neg) { /* :640-658 */
-          std::string info = "SVTYPE=INV;END=";
-          append_u64(info, r.target_end);
-          vcf_line(body, r.target_name, r.target_start + 1, std::string(ts, 1), "<INV>", true, info,
-                   qi(r.query_start, r.query_end, false));
-        }
-        const std::string init_info = r.neg ? "INV_NEST=TRUE;" : "";
-        const uint32_t* rops = h_ops.data() + h_op_off[k];
-        const uint64_t nops = h_op_off[k + 1] - h_op_off[k];
-        auto oob = [&]() { fail("panic: VCF REF/ALT slice out of the fetched sequence (caller.rs:695-696,753-754,800-801)"); };
-        for (uint64_t e = eoff[k]; e < eoff[k + 1]; e++) {
-          const uint64_t oi = ev[3 * e], tb = ev[3 * e + 1], qb = ev[3 * e + 2];
-          const uint32_t code = rops[oi] & 15u;
-          uint64_t len = rops[oi] >> 4;
-          for (uint64_t j = oi + 1; j < nops && ((rops[j] & 15u) == WGA_OP_I_CONT || (rops[j] & 15u) == WGA_OP_D_CONT); j++)
-            len += rops[j] >> 4;
-          const uint64_t t_pos = r.target_start + tb, q_pos = r.query_start + qb;
-          if (code == WGA_OP_X) {
-            for (uint64_t x = 0; x < len; x++) {
-              if (tb + x + 1 > tn || qb + x + 1 > qn) oob();
-              vcf_line(body, r.target_name, t_pos + x + 1, std::string(ts + tb + x, 1), std::string(qs + qb + x, 1),
-                       false, "", qi(q_pos + x, 0, true));
-            }
-          } else if (len > svlen) {
-            if (tb == 0 || qb == 0) oob(); /* `t_pos - t_start - 1` wraps */
-            std::string info = init_info;
-            if (code == WGA_OP_I) {
-              if (tb > tn || qb + len > qn) oob();
-              info += "SVTYPE=INS;SVLEN=";
-              append_u64(info, len);
-              info += ";END=";
-              append_u64(info, t_pos);
-              vcf_line(body, r.target_name, t_pos, std::string(ts + tb - 1, 1), std::string(qs + qb - 1, len + 1), false,
-                       info, qi(q_pos, q_pos + len, false));
-            } else {
-              if (tb + len > tn || qb > qn) oob();
-              info += "SVTYPE=DEL;SVLEN=";
-              append_u64(info, len);
-              info += ";END=";
-              append_u64(info, t_pos + len);
-              vcf_line(body, r.target_name, t_pos, std::string(ts + tb - 1, len + 1), std::string(qs + qb - 1, 1), false,
-                       info, qi(q_pos, q_pos, false));
-            }
-          }
-        }
-      };
-      auto work = [&](unsigned t) {
-        const uint32_t lo = (uint32_t)((uint64_t)n * t / nthr), hi = (uint32_t)((uint64_t)n * (t + 1) / nthr);
-        try {
-          for (uint32_t k = lo; k < hi; k++) one_record(k, parts[t]);
-        } catch (Error& e) {
-          errs[t] = e.msg.empty() ? std::string("error") : e.msg;
-        } catch (std::exception& e) { /* bad_alloc and friends: an exception leaving a thread is std::terminate */
-          errs[t] = std::string("internal error: ") + e.what();
-        }
-      };
-      {
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nthr; t++) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
+        wga_vcf_rec& v = vr[k];
+        v.t_name_off = name_off(r.target_name), v.t_name_len = (uint32_t)r.target_name.size();
+        v.q_name_off = name_off(r.query_name), v.q_name_len = (uint32_t)r.query_name.size();
+        v.t_start = r.target_start, v.t_end = r.target_end, v.q_start = r.query_start, v.q_end = r.query_end;
+        v.t_off = t_off[k], v.t_len = t_len[k], v.q_off = q_off[k], v.q_len = q_len[k];
       }
-      for (unsigned t = 0; t < nthr; t++)
-        if (!errs[t].empty()) fail(errs[t]); /* the first failing record in input order */
-      for (unsigned t = 0; t < nthr; t++) body += parts[t];
+      names.push_back('\0'); /* never empty */
+      const uint8_t* d_names = d.upload((const uint8_t*)names.data(), names.size());
+      const wga_vcf_rec* d_vr = d.upload(vr.data(), vr.size());
+      auto* d_nb = (uint64_t*)d.alloc((size_t)n * 8);
+      auto* d_err = (wga_vcf_err*)d.alloc((size_t)n * sizeof(wga_vcf_err));
+      d.check(wga_paf_call_vcf(d.ctx, &cb, svlen, d_ev, d_eoff, d_vr, d_names, tf.d_pool, qf.d_pool, d_nb, d_err, nullptr,
+                               nullptr));
+      auto* d_toff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+      d.check(wga_exclusive_scan_u64(d.ctx, n, d_nb, d_toff));
+      std::vector<wga_vcf_err> errs(n);
+      d.download(errs.data(), (const wga_vcf_err*)d_err, n);
+      for (uint32_t k = 0; k < n; k++) { /* the first failing record in input order */
+        if (errs[k].item == WGA_NONE) continue;
+        if (errs[k].kind == 1)
+          fail("panic: VCF REF/ALT slice out of the fetched sequence (caller.rs:695-696,753-754,800-801)");
+        fail(std::string("invalid reference/alternate base `") + (char)errs[k].ch +
+             "` for a VCF record (noodles-vcf parse error)");
+      }
+      uint64_t n_text = 0;
+      d.download(&n_text, (const uint64_t*)d_toff + n, 1);
+      if (n_text) {
+        auto* d_text = (uint8_t*)d.alloc(n_text + 64);
+        d.check(wga_paf_call_vcf(d.ctx, &cb, svlen, d_ev, d_eoff, d_vr, d_names, tf.d_pool, qf.d_pool, nullptr, nullptr,
+                                 d_text, d_toff));
+        const size_t at = body.size();
+        body.resize(at + n_text);
+        d.download((uint8_t*)&body[at], (const uint8_t*)d_text, n_text);
+      }
     }
     d.release_to(keep);
     i0 = i;
