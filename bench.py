@@ -158,6 +158,66 @@ def extra_shape(eng, synth, pipeline, torch, dev, seed, records, mean_ops, pool_
     return ms, frac
 
 
+def e2e_leg(tb, synth, torch, check=2):
+    """file to file on the same batch ("input GB/s is reported on the text size as well"): the records as a PAF
+    file and the pools as two FASTA files under /tmp, then the `wgatools` command line (the C++ host layer over the C-ABI)
+    runs `stat` and `paf2maf` on them — text parsing, PCIe both ways, kernels and the MAF written out — under its phase
+    timer (WGA_TIMING=1).  Wall time of the whole process, HIP start-up included.  The first blocks of the MAF are compared
+    with the oracle's rows."""
+    import shutil, subprocess, tempfile
+    from wgatools_amd import build
+    cli = build.build_cli()
+    rows_bytes = 2 * int((tb["mx"] + tb["i"] + tb["d"]).sum().item())
+    tmp = tempfile.mkdtemp(prefix="wga_e2e_", dir="/tmp")
+    try:
+        free = shutil.disk_usage(tmp).free
+        if free < rows_bytes * 1.2 + 4e9:
+            return {"skipped": "%.0f GB free under /tmp, the MAF alone is %.0f GB" % (free / 1e9, rows_bytes / 1e9)}
+        t_fa, q_fa, paf = (os.path.join(tmp, f) for f in ("t.fa", "q.fa", "in.paf"))
+        for path, name, pool in ((t_fa, b"tchr", tb["t_pool"]), (q_fa, b"qchr", tb["q_pool"])):
+            seq = pool.cpu().numpy().tobytes()
+            with open(path, "wb") as f:
+                f.write(b">" + name + b"\n")
+                for i in range(0, len(seq), 1 << 20):
+                    f.write(seq[i:i + (1 << 20)] + b"\n")
+        text = synth.paf_text_torch(tb).cpu().numpy()
+        text.tofile(paf)
+        paf_bytes = int(text.size)
+        del text
+        out = {"records": tb["n"], "ops": tb["n_ops"], "paf_text_bytes": paf_bytes,
+               "fasta_bytes": int(tb["t_pool"].numel() + tb["q_pool"].numel()),
+               "note": "wall time of the wgatools process, file to file under /tmp (page cache), HIP start-up included"}
+        env = dict(os.environ, WGA_TIMING="1")
+        for name, argv, outp in (("stat", ["stat", "-f", "paf", paf], os.path.join(tmp, "out.tsv")),
+                                 ("paf2maf", ["paf2maf", paf, "-g", t_fa, "-q", q_fa], os.path.join(tmp, "out.maf"))):
+            t0 = time.perf_counter()
+            r = subprocess.run([cli] + argv + ["-o", outp, "-r"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env,
+                               timeout=900)
+            dt = time.perf_counter() - t0
+            if r.returncode:
+                out[name] = {"error": r.stderr.decode()[-300:]}
+                continue
+            ob = os.path.getsize(outp)
+            phases = [ln for ln in r.stderr.decode().splitlines() if ln.startswith("[timing]")]
+            out[name] = {"wall_s": dt, "ops_per_s": tb["n_ops"] / dt, "input_text_GBps": paf_bytes / dt / 1e9,
+                         "output_bytes": ob, "output_GBps": ob / dt / 1e9, "phases": phases[-1] if phases else None}
+        if check and "wall_s" in out.get("paf2maf", {}):
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import parity_cases as pc
+            with open(os.path.join(tmp, "out.maf"), "rb") as f:
+                head = f.read(64 << 20)
+            blocks = head.split(b"\n\n")
+            for i in range(check):
+                lines = blocks[i].split(b"\n")
+                srows = [ln for ln in lines if ln.startswith(b"s\t")]
+                et, eq = pc.oracle_rows(synth.torch_batch_record_to_numpy(tb, i), 0)
+                assert srows[0].split(b"\t")[-1] == et and srows[1].split(b"\t")[-1] == eq, "MAF block %d differs from the oracle" % i
+            out["paf2maf"]["parity_spot_check"] = "first %d MAF blocks bit-identical to oracle rows" % check
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def north_star(args):
     """The headline shape of BASELINE.json (`10 M records x mean 50 kop`; 2 TB of packed ops cannot be one resident batch):
     a stream of on-device-generated resident batches (`--ns-batch-records` x mean 50 kop each, <= 64 GB with its rows), every
@@ -235,6 +295,7 @@ def main():
     ap.add_argument("--param", action="append", default=[], help="engine test knob name=value")
     ap.add_argument("--neg-frac", type=float, default=0.5)
     ap.add_argument("--m-only", action="store_true", help="variant of configs[1] with = / X merged into M ops")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file leg (the wgatools command line on the same batch)")
     ap.add_argument("--no-extras", action="store_true", help="skip the genome-sized-pool and 50-kop-record K2 measurements")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
                     help="strong (default): ONE global batch of --records whatever N — the file-shaped job: every rank takes the "
@@ -476,8 +537,8 @@ def main():
         if ranks_checked:
             result["parity_spot_check"] = ranks_checked
         result["metric_scope"] = ("kernel-only: K1 + layout + K2 (+ totals) on packed ops and sequence pools resident in HBM; no "
-                                  "CIGAR tokenising, PAF / FASTA parsing, PCIe or file I/O — file-to-file command-line timings "
-                                  "are in profiles/ (r02_cli_e2e.txt) and DESIGN.md section 6")
+                                  "CIGAR tokenising, PAF / FASTA parsing, PCIe or file I/O — the file-to-file command line on the same "
+                                  "batch is the `e2e` object of this line")
         if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only
             result["cpu_baseline"] = cpu_baseline(tb)
             # part of the same leg (the only place bench.py touches oracle/): a few of the rows the timed steps
@@ -511,6 +572,16 @@ def main():
                                                          "1000000x500op": ms_s}
             except Exception as e:  # noqa: BLE001
                 result["roofline"]["extra_shapes_error"] = "%s: %s" % (type(e).__name__, e)
+        if world == 1 and not args.no_e2e and not args.param:
+            try:   # additional information: never at the price of the headline line
+                try:
+                    del job
+                except NameError:
+                    pass
+                torch.cuda.empty_cache()
+                result["e2e"] = e2e_leg(tb, synth, torch, check=2 if args.check and not args.no_cpu_baseline else 0)
+            except Exception as e:  # noqa: BLE001
+                result["e2e"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

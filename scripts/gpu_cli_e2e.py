@@ -8,34 +8,33 @@ from wgatools_amd import build, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 tmp = sys.argv[2] if len(sys.argv) > 2 else "/tmp/wga_e2e"
 os.makedirs(tmp, exist_ok=True)
-b = synth.make_paf_batch(9, n, 5000, 50_000_000)
+import torch
+dev = torch.device("cuda", 0)
+tb = synth.make_paf_batch_torch(9, n, 5000, 50_000_000, dev)     # records, pools and the PAF text are made in HBM
 def fasta(path, name, seq):
     with open(path, "wb") as f:
         f.write(b">" + name + b"\n")
         for i in range(0, len(seq), 1 << 20):       # 1 MiB lines
             f.write(seq[i:i + (1 << 20)] + b"\n")
 t_fa, q_fa, paf = os.path.join(tmp, "t.fa"), os.path.join(tmp, "q.fa"), os.path.join(tmp, "in.paf")
-fasta(t_fa, b"tchr", b["t_pool"].tobytes())
-fasta(q_fa, b"qchr", b["q_pool"].tobytes())
-lens = (b["ops"] >> 4).astype(np.int64); codes = (b["ops"] & 15).astype(np.int64)
-toks = np.char.add(lens.astype(str), np.array(list("MIDNSHP=XIDB"))[codes])
-off = b["op_off"].astype(np.int64)
-with open(paf, "w") as f:
-    for i in range(n):
-        qs, ql = int(b["q_src_off"][i]), int(b["q_src_len"][i]); ts, tl = int(b["t_src_off"][i]), int(b["t_src_len"][i])
-        f.write("qchr\t%d\t%d\t%d\t%s\ttchr\t%d\t%d\t%d\t0\t0\t60\tcg:Z:%s\n" % (
-            len(b["q_pool"]), qs, qs + ql, "-" if b["strand_neg"][i] else "+", len(b["t_pool"]), ts, ts + tl,
-            "".join(toks[off[i]:off[i + 1]])))
-nops = int(off[-1])
+fasta(t_fa, b"tchr", tb["t_pool"].cpu().numpy().tobytes())
+fasta(q_fa, b"qchr", tb["q_pool"].cpu().numpy().tobytes())
+synth.paf_text_torch(tb).cpu().numpy().tofile(paf)
+nops = tb["n_ops"]
+del tb
+torch.cuda.empty_cache()
 print("input: %d records, %.3e ops, PAF %.1f MB" % (n, nops, os.path.getsize(paf) / 1e6))
 cli = build.CLI_BIN
 def run(name, args, outp, env=None):
     t0 = time.perf_counter()
-    r = subprocess.run([cli] + args + ["-o", outp, "-r"], stderr=subprocess.PIPE, env=dict(os.environ, **(env or {})))
+    r = subprocess.run([cli] + args + ["-o", outp, "-r"], stderr=subprocess.PIPE, env=dict(os.environ, WGA_TIMING="1", **(env or {})))
     dt = time.perf_counter() - t0
     sz = os.path.getsize(outp) if os.path.exists(outp) else 0
     print("%-9s %.2f s wall  rc=%d  output %.1f MB  -> %.2e ops/s end to end" % (name, dt, r.returncode, sz / 1e6, nops / dt))
     if r.returncode: print(r.stderr.decode()[-300:])
+    for ln in r.stderr.decode().splitlines():
+        if ln.startswith("[timing]"): print("          " + ln)
+    if os.path.isfile(outp) and not outp.endswith(".chain"): os.remove(outp)       # 15 GB of MAF, 9 GB of VCF at 100 000 records
 run("stat", ["stat", "-f", "paf", paf], os.path.join(tmp, "out.tsv"))
 run("paf2maf", ["paf2maf", paf, "-g", t_fa, "-q", q_fa], os.path.join(tmp, "out.maf"))
 run("pafcov", ["pafcov", paf], os.path.join(tmp, "out.bed"))

@@ -196,3 +196,65 @@ def torch_batch_record_to_numpy(tb, i):
                 t_pool=tb["t_pool"][to:to + tl].cpu().numpy(), q_pool=tb["q_pool"][qo:qo + ql].cpu().numpy(),
                 t_src_off=np.zeros(1, np.uint64), t_src_len=np.array([tl], dtype=np.uint64),
                 q_src_off=np.zeros(1, np.uint64), q_src_len=np.array([ql], dtype=np.uint64))
+
+
+def paf_text_torch(tb, t_name=b"tchr", q_name=b"qchr", mapq=60):
+    """the PAF file of a torch batch (make_paf_batch_torch), built in HBM: one line per record,
+    `<q>\\t<qlen>\\t<qs>\\t<qe>\\t<strand>\\t<t>\\t<tlen>\\t<ts>\\t<te>\\t0\\t0\\t<mapq>\\tcg:Z:<cigar>\\n` -> uint8 tensor.
+    The 12 columns in front of the CIGAR are formatted on the host (one short string per record), the CIGAR text —
+    all of the bytes — on the device: digits per op, an exclusive scan, one scatter per digit position."""
+    import torch
+    dev = tb["ops"].device
+    n, n_ops = tb["n"], tb["n_ops"]
+    ops = tb["ops"].view(torch.int32)
+    ln = (ops >> 4).to(torch.int64) & 0x0FFFFFFF
+    code = (ops & 15).to(torch.int64)
+    nd = torch.ones(n_ops, dtype=torch.int64, device=dev)
+    p = 10
+    for _ in range(9):
+        nd += (ln >= p).to(torch.int64)
+        p *= 10
+    tlen = nd + 1                                          # digits + the op letter
+    cig_end = torch.cumsum(tlen, 0)                        # inclusive: end of every op's text inside the CIGAR stream
+    op_off = tb["op_off"]
+    rec_cig = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rec_cig[1:] = cig_end[op_off[1:] - 1]                  # every record has >= 1 op
+    # host: the columns in front of the CIGAR
+    qs, ql = tb["q_src_off"].cpu().numpy(), tb["q_src_len"].cpu().numpy()
+    ts, tl = tb["t_src_off"].cpu().numpy(), tb["t_src_len"].cpu().numpy()
+    neg = tb["strand_neg"].cpu().numpy()
+    qn, tn = int(tb["q_pool"].numel()), int(tb["t_pool"].numel())
+    heads = [b"%s\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t0\t0\t%d\tcg:Z:" % (
+        q_name, qn, qs[i], qs[i] + ql[i], b"-" if neg[i] else b"+", t_name, tn, ts[i], ts[i] + tl[i], mapq)
+        for i in range(n)]
+    hl = np.fromiter((len(h) for h in heads), dtype=np.int64, count=n)
+    head_all = torch.from_numpy(np.frombuffer(b"".join(heads), dtype=np.uint8).copy()).to(dev)
+    hl_d = torch.from_numpy(hl).to(dev)
+    # line i = head i + cigar i + '\n'
+    line_len = hl_d + (rec_cig[1:] - rec_cig[:-1]) + 1
+    line_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(line_len, 0, out=line_off[1:])
+    total = int(line_off[-1])
+    out = torch.empty(total, dtype=torch.uint8, device=dev)
+    # heads
+    hoff = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(hl_d, 0, out=hoff[1:])
+    hrec = torch.repeat_interleave(torch.arange(n, device=dev), hl_d)
+    hpos = line_off[hrec] + (torch.arange(int(hoff[-1]), device=dev) - hoff[hrec])
+    out[hpos] = head_all
+    out[line_off[1:] - 1] = ord("\n")
+    del hrec, hpos
+    # cigar text: op k's text ends at  line_off[r] + hl[r] + (cig_end[k] - rec_cig[r])
+    rec = torch.repeat_interleave(torch.arange(n, device=dev), op_off[1:] - op_off[:-1])
+    end = cig_end + (line_off[:-1] + hl_d - rec_cig[:-1])[rec]
+    del rec, cig_end
+    letters = torch.tensor(list(OP_CHARS.encode() if isinstance(OP_CHARS, str) else OP_CHARS), dtype=torch.uint8, device=dev)
+    out[end - 1] = letters[code.clamp(max=len(letters) - 1)]
+    v = ln.clone()
+    for d in range(10):
+        m = nd > d
+        if not bool(m.any()):
+            break
+        out[(end - 2 - d)[m]] = (v[m] % 10 + 48).to(torch.uint8)
+        v //= 10
+    return out
