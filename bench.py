@@ -306,7 +306,7 @@ def main():
     ap.add_argument("--zipf", type=float, default=0.0, help="strong scaling: skew of the records over the targets "
                                                             "(P(target k) ~ 1 / (k + 1)^zipf; 0 = uniform, the default)")
     ap.add_argument("--no-placement-probe", action="store_true", help="take the first output buffer the allocator returns instead "
-                    "of the arena the library places (wga_arena_alloc, --placement-candidates)")
+                    "of the arena the library places for the job (wga_paf2maf_expand_place, --placement-candidates)")
     ap.add_argument("--placement-candidates", type=int, default=8)
     ap.add_argument("--north-star", action="store_true", help="the 10 M x 50 kop headline shape as a stream of resident batches (N = 1)")
     ap.add_argument("--ns-records", type=int, default=400_000)
@@ -355,7 +355,6 @@ def main():
         tb = synth.make_paf_batch_torch(seed, args.records, args.mean_ops, args.pool_mb * 1_000_000, dev,
                                         neg_frac=args.neg_frac, use_m=args.m_only)
     placement = None
-    out_buf = arena = None
     first_alloc_ms = None
     if world == 1 and not args.param:
         # what the FIRST buffer the allocator returns gives (no placement policy): five warming steps (first touch + the
@@ -381,19 +380,24 @@ def main():
         finally:
             eng.set_param("expand_alias", 0)
             torch.cuda.empty_cache()
+    job = None
     if not args.no_placement_probe:
-        # where the output arena lies in HBM sets the row kernel's level: the library places it
-        # (wga_arena_alloc, the same call the `wgatools` command line makes for its row buffer)
+        # where the output arena lies in HBM sets the row kernel's level: the library places it for the
+        # job (wga_paf2maf_expand_place, the same call the `wgatools` command line makes for its row buffer) — the launches
+        # of the placement run under the kernel's second name, so that rocprofv3 --stats holds the timed steps only
         try:
-            out_buf, arena, probe = pipeline.arena_output(eng, tb, candidates=args.placement_candidates)
-            placement = dict(placement or {}, policy="wga_arena_alloc: fastest of %d candidate buffers for a plain streaming copy "
-                             "(library policy, also used by the wgatools CLI); --no-placement-probe takes the first "
-                             "allocation" % args.placement_candidates, **probe)
-        except Exception as e:  # noqa: BLE001  (the probe is a policy, not a requirement: fall back to the first allocation)
-            out_buf = arena = None
+            eng.set_param("expand_alias", 1)
+            job = pipeline.Paf2MafStatJob(eng, tb, place=args.placement_candidates)
+            job.bind_stream()
+            placement = dict(placement or {}, **job.place_output())
+        except Exception as e:  # noqa: BLE001  (the placement is a policy, not a requirement: fall back to the first allocation)
+            job = None
             torch.cuda.empty_cache()
-            placement = dict(placement or {}, policy="first allocation (the arena call failed: %s: %s)" % (type(e).__name__, e))
-    job = pipeline.Paf2MafStatJob(eng, tb, out=out_buf)
+            placement = dict(placement or {}, policy="first allocation (the placement call failed: %s: %s)" % (type(e).__name__, e))
+        finally:
+            eng.set_param("expand_alias", 0)
+    if job is None:
+        job = pipeline.Paf2MafStatJob(eng, tb)
     job.bind_stream()
     totals = torch.zeros(11, dtype=torch.int64, device=dev)
 

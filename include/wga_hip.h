@@ -150,6 +150,12 @@ int wga_free(wga_ctx*, void* d_ptr);
  * `candidates` entries; 0 for candidates that were not allocated) receives the probe's copy rate per candidate, `chosen`
  * (optional) the index kept.  candidates <= 1 is wga_malloc.  Free the arena with wga_free.  Synchronises. */
 int wga_arena_alloc(wga_ctx*, size_t bytes, int candidates, void** d_out, double* gbps_by_candidate, int* chosen);
+/* The probe by itself on a caller's buffer (>= 4 KiB, 16-byte aligned; its contents are overwritten): GB/s of pattern
+ * `kind` — 0 the streaming copy wga_arena_alloc ranks its candidates by, 1 a streaming fill, 2 / 3 the fill with every
+ * 128-byte line written in eight pieces that arrive 1 MiB / 64 KiB of other writes apart, 4 / 5 whole 4 KiB / 64 KiB
+ * chunks written at scattered places.  For measurements of a
+ * placement (profiles/), not needed by a caller of wga_arena_alloc. */
+int wga_arena_probe(wga_ctx*, void* d_buf, size_t bytes, int kind, double* gbps);
 int wga_memcpy_h2d(wga_ctx*, void* d_dst, const void* h_src, size_t bytes);
 int wga_memcpy_d2h(wga_ctx*, void* h_dst, const void* d_src, size_t bytes); /* synchronises */
 int wga_memset(wga_ctx*, void* d_dst, int byte, size_t bytes);
@@ -219,6 +225,24 @@ int wga_paf2maf_expand(wga_ctx*, const wga_cigar_batch*, const wga_cigar_counts*
                        const uint8_t* d_q_fa, uint64_t q_fa_bytes, const uint64_t* d_q_src_off,
                        const uint64_t* d_q_src_len, uint8_t* d_out, const uint64_t* d_t_row_off,
                        const uint64_t* d_q_row_off, wga_rec_diag* d_diag);
+
+/* The same call with the output arena placed BY THE JOB: the level the row kernel runs at depends on the physical region of
+ * HBM its output lies in (regions differ by 20 % in what they give a streaming write and the kernel runs at that rate;
+ * plain probe patterns rank the regions only partly as the kernel does: profiles/r03_arena_probe_kinds.txt).  `candidates`
+ * buffers of `arena_bytes` (>= the rows of this batch; a caller that keeps the arena for later batches asks for more) are
+ * allocated, the rows of THIS batch are written into each — one launch that touches the buffer, two timed — and the
+ * buffer the kernel was fastest on comes back in *d_out, holding the batch's rows; the others are freed (free *d_out with
+ * wga_free).  Fewer candidates are tried when memory runs out; candidates <= 1 is wga_malloc + wga_paf2maf_expand.
+ * ms_by_candidate (optional, `candidates` entries): the timed launches' mean per candidate, 0 where none ran.
+ * The per-buffer trials of "expand_drain_min" start with the first later launch on the chosen buffer.
+ * A long-lived caller does this once for its first batch and keeps the arena (the `wgatools` command line does). */
+int wga_paf2maf_expand_place(wga_ctx*, const wga_cigar_batch*, const wga_cigar_counts* d_counts,
+                             const void* d_tile_ws, const uint8_t* d_t_fa, uint64_t t_fa_bytes,
+                             const uint64_t* d_t_src_off, const uint64_t* d_t_src_len,
+                             const uint8_t* d_q_fa, uint64_t q_fa_bytes, const uint64_t* d_q_src_off,
+                             const uint64_t* d_q_src_len, const uint64_t* d_t_row_off,
+                             const uint64_t* d_q_row_off, wga_rec_diag* d_diag, size_t arena_bytes, int candidates,
+                             void** d_out, double* ms_by_candidate, int* chosen);
 
 /* Copy n variable-length byte snippets: d_dst[d_dst_off[i] ..) = d_src[d_src_off[i] .. d_src_off[i+1])
  * (used to drop the "a score=…" / "s\tname\t…" line text between the rows, maf.rs:566-581). */

@@ -36,7 +36,7 @@ libs = {}
 for _, name, _p in cands:
     if name not in libs:
         path = build.HIP_LIB if name == "tree" else os.path.join(build.ROOT, "build_variants", "libwgahip_%s.so" % name)
-        libs[name] = _lib.load(path)
+        libs[name] = _lib.load(path, require_all=(name == "tree"))   # builds of older commits lack the newer entry points
 for rec, mean, pool in shapes:
     tb = synth.make_paf_batch_torch(0x5747415F + 2, rec, mean, pool * 1_000_000, dev)
     jobs = []

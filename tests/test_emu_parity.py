@@ -576,6 +576,34 @@ def test_arena_alloc(emu):
     b, rates, chosen = emu.arena_alloc(64, 1)
     assert b.ptr and chosen == 0
     b.free()
+    c = emu.empty(1 << 16, np.uint8)
+    for kind in range(14):                     # the measurement patterns write inside the buffer, all of it
+        c.fill(0)
+        emu.arena_probe(c, (1 << 16) - 48, kind)
+        h = c.numpy()
+        assert (h[(1 << 16) - 48:] == 0).all(), kind
+    c.free()
+
+
+def test_expand_place(emu):
+    """wga_paf2maf_expand_place on the emulator (events read 0 ms: the first candidate stays): the arena comes back holding
+    the batch's rows — the bytes the plain call writes"""
+    b = synth.make_paf_batch(21, 30, 200, 50000)
+    n = len(b["strand_neg"])
+    batch = emu.make_batch(b["ops"], b["op_off"], b["strand_neg"])
+    counts, diag, tile_ws = emu.cigar_stat(batch)
+    up = lambda k: emu.upload(np.ascontiguousarray(b[k]))
+    tp, qp = up("t_pool"), up("q_pool")
+    to, tl, qo, ql = up("t_src_off"), up("t_src_len"), up("q_src_off"), up("q_src_len")
+    tro, qro, rec = emu.paf2maf_layout(n, counts, tl, ql)
+    total = int(rec.numpy()[-1])
+    plain = emu.empty(total + 64, np.uint8).fill(0x23)
+    emu.paf2maf_expand(batch, counts, tile_ws, tp, b["t_pool"].size, to, tl, qp, b["q_pool"].size, qo, ql, plain, tro, qro, diag)
+    arena, ms, chosen = emu.paf2maf_expand_place(batch, counts, tile_ws, tp, b["t_pool"].size, to, tl, qp, b["q_pool"].size, qo,
+                                                 ql, tro, qro, diag, total + 64, 3)
+    assert len(ms) == 3 and chosen == 0 and arena.nbytes == total + 64
+    assert (arena.numpy()[:total] == plain.numpy()[:total]).all()
+    arena.free()
 
 
 def test_reduce_scatter_i32(monkeypatch):

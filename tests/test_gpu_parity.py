@@ -170,30 +170,39 @@ def test_paf2maf_drain_autotune_same_bytes(gpu):
     gpu.reset_stream()
 
 
-def test_output_buffer_placement_probe(gpu):
-    """wga_arena_alloc (the library's placement policy): every candidate is timed with a plain copy, one comes back, and the
-    rows written into it are the rows of any other buffer"""
+def test_output_arena_placed_by_the_job(gpu):
+    """wga_paf2maf_expand_place (the library's placement policy for a long-lived caller's output arena): the batch's rows are
+    written into every candidate, the one the row kernel was fastest on comes back holding them — the rows of any other
+    buffer; wga_arena_alloc / wga_arena_probe (plain patterns, measurements) answer too"""
     import torch
     from wgatools_amd import pipeline
     dev = torch.device("cuda", 0)
     tb = synth.make_paf_batch_torch(78, 600, 3000, 5_000_000, dev)
     gpu.set_stream(torch.cuda.current_stream().cuda_stream)
-    buf, arena, probe = pipeline.arena_output(gpu, tb, candidates=3)
-    rates = probe["probe_copy_GBps_by_candidate"]
-    assert len(rates) == 3 and all(r > 0 for r in rates) and 0 <= probe["chosen"] < 3
-    assert rates[probe["chosen"]] == max(rates)
-    assert buf.data_ptr() == arena.ptr and buf.numel() == pipeline.output_bytes(tb)
-    one, r1, c1 = gpu.arena_alloc(4096, 1)     # candidates <= 1 is a plain allocation
-    assert one.ptr and c1 == 0
-    one.free()
-    a = pipeline.Paf2MafStatJob(gpu, tb, out=buf)
+    a = pipeline.Paf2MafStatJob(gpu, tb, place=3)
+    assert a.out is None
+    info = a.place_output()
+    ms = info["k2_ms_by_candidate"]
+    assert len(ms) == 3 and all(m > 0 for m in ms) and 0 <= info["chosen"] < 3 and ms[info["chosen"]] == min(ms)
+    assert a.out.data_ptr() == a.arena.ptr and a.out.numel() == a.out_bytes + 64
     b = pipeline.Paf2MafStatJob(gpu, tb)
-    for j in (a, b):
-        j.out.fill_(0x23)
-        j.step()
+    b.out.fill_(0x23)
+    b.step()
     torch.cuda.synchronize()
-    assert a.out.data_ptr() == buf.data_ptr() and a.out_bytes == b.out_bytes
     assert bool((a.out[:a.out_bytes] == b.out[:b.out_bytes]).all()) and bool((a.diag == -1).all())
+    a.out.fill_(0x23)          # a later batch into the kept arena: the plain call
+    a.step()
+    torch.cuda.synchronize()
+    assert bool((a.out[:a.out_bytes] == b.out[:b.out_bytes]).all())
+    one = pipeline.Paf2MafStatJob(gpu, tb, place=1)     # candidates <= 1: an allocation and the plain call
+    assert one.place_output()["chosen"] == 0
+    torch.cuda.synchronize()
+    assert bool((one.out[:one.out_bytes] == b.out[:b.out_bytes]).all())
+    arena, rates, chosen = gpu.arena_alloc(1 << 24, 3)
+    assert len(rates) == 3 and all(r > 0 for r in rates) and rates[chosen] == max(rates)
+    for kind in (0, 1, 3, 5, 6):
+        assert gpu.arena_probe(arena, 1 << 24, kind) > 0
+    arena.free()
     small = torch.empty(16, dtype=torch.uint8, device=dev)
     with pytest.raises(ValueError):
         pipeline.Paf2MafStatJob(gpu, tb, out=small)

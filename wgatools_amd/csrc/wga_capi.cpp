@@ -576,6 +576,43 @@ int wga_arena_alloc(wga_ctx* c, size_t bytes, int candidates, void** d_out, doub
   if (chosen) *chosen = best;
   return WGA_OK;
 }
+int wga_arena_probe(wga_ctx* c, void* d_buf, size_t bytes, int kind, double* gbps) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (!d_buf || !gbps || kind < 0 || kind > 13 || bytes < 4096 || ((uintptr_t)d_buf & 15u))
+    return fail(WGA_E_INVALID_ARG, "buffer, rate or kind", nullptr);
+  *gbps = 0.0;
+  rt_event_t ev[2];
+  const char* e = rt_event_create(&ev[0]);
+  if (!e && (e = rt_event_create(&ev[1]))) rt_event_destroy(ev[0]);
+  if (e) return fail(WGA_E_HIP, "arena probe", e);
+  const u64 n = (u64)bytes / 16u, half = n / 2u;
+  const u64 per_xcd = ((n >> 3) + 255u) / 256u; /* kinds >= 6: blocks per XCD, a multiple of 8 in all */
+  const u32 grid = kind >= 6 ? 8u * (u32)(per_xcd < 8192u ? (per_xcd ? per_xcd : 1u) : 8192u)
+                             : (u32)(half / 256u < 65536u ? (half + 255u) / 256u : 65536u);
+  double moved = 0.0;
+  for (int pass = 0; pass < 3 && !e; pass++) { /* pass 0: first touch */
+    if (pass == 1) e = rt_event_record(ev[0], c->stream);
+    if (e) break;
+    if (kind == 0) {
+      WGA_LAUNCH(k_arena_probe, grid, WGA_BLOCK, c->stream, (u32x4_a16*)d_buf, half, pass & 1);
+      if (pass) moved += 32.0 * (double)half;
+    } else {
+      WGA_LAUNCH(k_arena_probe_fill, grid, WGA_BLOCK, c->stream, (u32x4_a16*)d_buf, n,
+                 kind == 1 ? 0u : kind == 2 ? 16u : kind == 3 ? 12u : kind == 4 ? 40u : kind == 5 ? 44u : 64u + (u32)(kind - 6), (u32)pass);
+      if (pass) moved += 16.0 * (double)n;
+    }
+    e = rt_launch_error();
+  }
+  if (!e) e = rt_event_record(ev[1], c->stream);
+  float ms = 0.0f;
+  if (!e) e = rt_event_elapsed_ms(ev[0], ev[1], &ms);
+  rt_event_destroy(ev[0]);
+  rt_event_destroy(ev[1]);
+  if (e) return fail(WGA_E_HIP, "arena probe", e);
+  *gbps = ms > 0.0f ? moved / ((double)ms * 1e6) : 0.0;
+  return WGA_OK;
+}
 int wga_free(wga_ctx* c, void* d_ptr) {
   int rc = ctx_bind(c);
   if (rc) return rc;
@@ -920,6 +957,63 @@ int wga_ctx_expand_timing(wga_ctx* c, double* ms_sum, uint32_t* launches) {
   }
   *launches = n;
   c->ev_n = 0;
+  return WGA_OK;
+}
+
+int wga_paf2maf_expand_place(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_counts* d_counts, const void* d_tile_ws,
+                             const uint8_t* d_t_fa, uint64_t t_fa_bytes, const uint64_t* d_t_src_off,
+                             const uint64_t* d_t_src_len, const uint8_t* d_q_fa, uint64_t q_fa_bytes,
+                             const uint64_t* d_q_src_off, const uint64_t* d_q_src_len, const uint64_t* d_t_row_off,
+                             const uint64_t* d_q_row_off, wga_rec_diag* d_diag, size_t arena_bytes, int candidates,
+                             void** d_out, double* ms_by_candidate, int* chosen) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (!d_out || arena_bytes == 0) return fail(WGA_E_INVALID_ARG, "d_out is null or the arena is empty", nullptr);
+  if (candidates < 1) candidates = 1;
+  if (candidates > 64) candidates = 64;
+  if (ms_by_candidate)
+    for (int k = 0; k < candidates; k++) ms_by_candidate[k] = 0.0;
+  if (chosen) *chosen = 0;
+  void* cand[64];
+  int n = 0;
+  for (; n < candidates; n++)
+    if (rt_malloc(&cand[n], arena_bytes)) break; /* out of memory: fewer candidates */
+  if (n == 0) return fail(WGA_E_OOM, "device allocation", "no memory for one candidate");
+  rt_event_t ev[2];
+  const char* e = rt_event_create(&ev[0]);
+  if (!e && (e = rt_event_create(&ev[1]))) rt_event_destroy(ev[0]);
+  /* the trials of drain_min (per output buffer) wait until the buffer is chosen; the timing ring is the caller's */
+  const bool autotune = c->expand_autotune, timing = c->timing;
+  c->expand_autotune = false;
+  c->timing = false;
+  int best = 0;
+  double best_ms = 0.0;
+  for (int k = 0; k < n && !e && !rc; k++) {
+    const int launches = n > 1 ? 3 : 1; /* the first one touches the buffer */
+    for (int l = 0; l < launches && !rc && !e; l++) {
+      if (l == 1) e = rt_event_record(ev[0], c->stream);
+      if (!e)
+        rc = wga_paf2maf_expand(c, b, d_counts, d_tile_ws, d_t_fa, t_fa_bytes, d_t_src_off, d_t_src_len, d_q_fa, q_fa_bytes,
+                                d_q_src_off, d_q_src_len, (uint8_t*)cand[k], d_t_row_off, d_q_row_off, d_diag);
+    }
+    if (rc || e || n == 1) break;
+    if ((e = rt_event_record(ev[1], c->stream))) break;
+    float ms = 0.0f;
+    if ((e = rt_event_elapsed_ms(ev[0], ev[1], &ms))) break;
+    if (ms_by_candidate) ms_by_candidate[k] = (double)ms / 2.0;
+    if (k == 0 || (double)ms < best_ms) best = k, best_ms = (double)ms;
+  }
+  c->expand_autotune = autotune;
+  c->timing = timing;
+  if (!e && !rc) e = rt_sync(c->stream);
+  rt_event_destroy(ev[0]);
+  rt_event_destroy(ev[1]);
+  for (int k = 0; k < n; k++)
+    if (e || rc || k != best) (void)rt_free(cand[k]);
+  if (rc) return rc;
+  if (e) return fail(WGA_E_HIP, "output placement", e);
+  *d_out = cand[best];
+  if (chosen) *chosen = best;
   return WGA_OK;
 }
 

@@ -1908,6 +1908,42 @@ __global__ __launch_bounds__(256) void k_arena_probe(u32x4_a16* buf, u64 half /*
   const u64 stride = (u64)gridDim.x * 256u;
   for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < half; i += stride) dst[i] = src[i];
 }
+/* ---- wga_arena_probe, kinds 1 .. 3: write-only patterns (measurements: which plain pattern ranks buffers as the row kernel
+ *      does).  1: a streaming fill.  2 / 3: the fill with every 128-byte line written in eight 16-byte pieces that arrive
+ *      `lines` x 16 bytes of other writes apart (lines = 65536 / 4096): lines wait partly written, as the rows' lines do
+ *      when a gap-touching chunk is emitted late.  4 / 5: whole 4 KiB / 64 KiB chunks at scattered places (many pages in flight). */
+__global__ __launch_bounds__(256) void k_arena_probe_fill(u32x4_a16* buf, u64 n /* granules */, u32 lines_log2, u32 seed) {
+  const u64 stride = (u64)gridDim.x * 256u;
+  u32x4_a16 v;
+  v[0] = v[1] = v[2] = v[3] = seed;
+  if (lines_log2 == 0u) {
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) buf[i] = v;
+    return;
+  }
+  if (lines_log2 >= 64u) { /* every XCD (block b runs on XCD b % 8) streams through one eighth of the buffer, as the row kernel's
+                              tiles do; eighth = (XCD + rot) % 8 */
+    const u32 rot = lines_log2 - 64u, x = ((blockIdx.x & 7u) + rot) & 7u;
+    const u64 region = n >> 3, per = (u64)(gridDim.x >> 3) * 256u;
+    u32x4_a16* const dst = buf + (u64)x * region;
+    for (u64 i = (u64)(blockIdx.x >> 3) * 256u + threadIdx.x; i < region; i += per) dst[i] = v;
+    return;
+  }
+  if (lines_log2 >= 32u) { /* whole chunks of 2^(lines_log2 - 32) granules, scattered over the buffer (a prime stride) */
+    const u32 cl = lines_log2 - 32u;
+    const u64 nch = n >> cl;
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < (nch << cl); i += stride) {
+      const u64 c = i >> cl;
+      buf[(((c * 2654435761ull) % nch) << cl) | (i & ((1ull << cl) - 1u))] = v;
+    }
+    return;
+  }
+  const u64 L = 1ull << lines_log2, W = 8ull * L; /* granules per window */
+  for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) {
+    const u64 w = i / W, r = i - w * W;
+    const u64 g = w * W + (r & (L - 1u)) * 8u + (r >> lines_log2); /* piece r / L of line r % L */
+    if (g < n) buf[g] = v;
+  }
+}
 
 /* ---- wga_reduce_scatter_i32: a += b over n counters (16 B per thread where the pointers allow it) ------------------------ */
 __global__ __launch_bounds__(256) void k_add_i32(int* __restrict__ a, const int* __restrict__ b, u64 n) {

@@ -281,23 +281,25 @@ struct Dev {
    * to emit its queued chunks (include/wga_hip.h, "expand_drain_min") — a buffer per piece would start over every time. */
   void* out_arena = nullptr;
   size_t out_arena_cap = 0;
-  void* out_buffer(size_t bytes) {
-    if (bytes > out_arena_cap) {
-      if (out_arena) {
-        check(wga_sync(ctx));
-        wga_free(ctx, out_arena);
-        out_arena = nullptr;
-      }
-      out_arena_cap = bytes + bytes / 4;
-      /* a large row buffer is placed by the library's policy (wga_arena_alloc: the fastest of a few candidate buffers
-       * for a plain streaming copy — the row kernel's level depends on the region of HBM its output lies in);
-       * WGA_ARENA_CANDIDATES=1 takes the first allocation */
-      int cand = out_arena_cap >= ((size_t)256 << 20) ? 4 : 1;
-      if (const char* v = getenv("WGA_ARENA_CANDIDATES")) cand = atoi(v);
-      check(wga_arena_alloc(ctx, out_arena_cap, cand, &out_arena, nullptr, nullptr));
+  /* true when the arena must be (re)allocated for `bytes`: the caller then lets the library place it for its job
+   * (wga_paf2maf_expand_place: the batch's rows are written into a few candidate arenas and the one the row kernel is
+   * fastest on stays); WGA_ARENA_CANDIDATES=1 takes the first allocation */
+  bool out_arena_needs(size_t bytes, size_t* cap, int* cand) {
+    if (bytes <= out_arena_cap) return false;
+    if (out_arena) {
+      check(wga_sync(ctx));
+      wga_free(ctx, out_arena);
+      out_arena = nullptr;
+      out_arena_cap = 0;
     }
-    return out_arena;
+    *cap = bytes + bytes / 4;
+    /* four candidates cost about a dozen launches of the row kernel and save a few per cent of every later one: worth it
+     * from some hundred batches on (a file-to-file run is bound by its I/O long before) */
+    *cand = out_batches_ahead >= 128 ? 4 : 1;
+    if (const char* v = getenv("WGA_ARENA_CANDIDATES")) *cand = atoi(v);
+    return true;
   }
+  uint64_t out_batches_ahead = 0; /* set by the caller that knows how much work follows */
   void release(void* p) {
     auto it = std::find(owned.begin(), owned.end(), p);
     if (it != owned.end()) owned.erase(it);
@@ -716,9 +718,17 @@ uint32_t expand_batch(Dev& d, const wga_cigar_batch& cb, const ExpandJob& j, con
   d.download(qro.data(), d_qro, n);
   std::vector<wga_cigar_counts> counts(n);
   d.download(counts.data(), d_counts, n);
-  auto* d_out = (uint8_t*)d.out_buffer(rec_off[n] + 64);
-  d.check(wga_paf2maf_expand(d.ctx, &cb, d_counts, d_tiles, d_tpool, t_bytes, d_to, d_tl, d_qpool, q_bytes, d_qo, d_ql,
-                             d_out, d_tro, d_qro, d_diag));
+  size_t arena_cap = 0;
+  int arena_cand = 1;
+  if (d.out_arena_needs(rec_off[n] + 64, &arena_cap, &arena_cand)) {
+    d.check(wga_paf2maf_expand_place(d.ctx, &cb, d_counts, d_tiles, d_tpool, t_bytes, d_to, d_tl, d_qpool, q_bytes, d_qo, d_ql,
+                                     d_tro, d_qro, d_diag, arena_cap, arena_cand, &d.out_arena, nullptr, nullptr));
+    d.out_arena_cap = arena_cap;
+  } else {
+    d.check(wga_paf2maf_expand(d.ctx, &cb, d_counts, d_tiles, d_tpool, t_bytes, d_to, d_tl, d_qpool, q_bytes, d_qo, d_ql,
+                               (uint8_t*)d.out_arena, d_tro, d_qro, d_diag));
+  }
+  auto* d_out = (uint8_t*)d.out_arena;
   /* the MAF line text around the rows: three snippets per record */
   std::vector<uint64_t> dst(3 * (size_t)n);
   for (uint32_t k = 0; k < n; k++) {
@@ -792,12 +802,17 @@ size_t p2m_run(Dev& d, DevFasta& tf, DevFasta& qf, const PafInput& in, const siz
   const std::vector<PafRecord>& recs = in.recs;
   auto rec_of = [&](size_t k) -> const PafRecord& { return recs[which ? which[k] : k]; };
   const uint64_t kMaxBytes = 6ull << 30;
+  const uint64_t kMaxText = 160ull << 20; /* ~64 M ops */
   const size_t keep = d.owned.size();
+  {
+    uint64_t text_ahead = 0;
+    for (size_t k = 0; k < n_which; k++) text_ahead += in.cigar_bytes(which ? which[k] : k);
+    d.out_batches_ahead = std::max(d.out_batches_ahead, text_ahead / kMaxText);
+  }
   size_t i0 = 0;
   while (i0 < n_which && err.empty()) {
     ExpandJob job;
     uint64_t est = 0, est_text = 0;
-    const uint64_t kMaxText = 160ull << 20; /* ~64 M ops */
     size_t i = i0;
     for (; i < n_which; i++) {
       const PafRecord& r = rec_of(i);

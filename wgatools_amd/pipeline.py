@@ -12,8 +12,10 @@ from . import engine
 class Paf2MafStatJob:
     """stat (K1) -> row layout (scan) -> gap insertion (K2) over one resident batch."""
 
-    def __init__(self, eng, tb, with_text=False, out=None):
-        """out: a caller-owned output buffer (uint8, at least the rows' bytes + 64), e.g. one reserved at process start"""
+    def __init__(self, eng, tb, with_text=False, out=None, place=0):
+        """out: a caller-owned output buffer (uint8, at least the rows' bytes + 64), e.g. one reserved at process start.
+        place = N > 0: no buffer yet — place_output() lets the library put the arena where this job's row kernel is
+        fastest among N candidates (wga_paf2maf_expand_place)."""
         import torch
         self.torch = torch
         self.eng = eng
@@ -38,7 +40,27 @@ class Paf2MafStatJob:
         self.out_bytes = rows
         if out is not None and out.numel() < rows + 64:
             raise ValueError("output buffer too small: %d < %d" % (out.numel(), rows + 64))
-        self.out = out[: rows + 64] if out is not None else torch.empty(rows + 64, dtype=torch.uint8, device=dev)
+        self.place = int(place)
+        self.arena = None
+        if self.place > 0:
+            self.out = None
+        else:
+            self.out = out[: rows + 64] if out is not None else torch.empty(rows + 64, dtype=torch.uint8, device=dev)
+
+    def place_output(self):
+        """stat + layout, then the rows of this batch into the fastest of `place` candidate arenas (the library's policy for
+        a long-lived caller's output arena, also used by the `wgatools` command line) -> {K2 ms per candidate, index kept}"""
+        tb = self.tb
+        self.stat()
+        self.layout()
+        self.arena, ms, chosen = self.eng.paf2maf_expand_place(
+            self.batch, self.counts, self.tile_ws, tb["t_pool"], tb["t_pool"].numel(), tb["t_src_off"], tb["t_src_len"],
+            tb["q_pool"], tb["q_pool"].numel(), tb["q_src_off"], tb["q_src_len"], self.t_row_off, self.q_row_off, self.diag,
+            self.out_bytes + 64, self.place)
+        self.out = self.arena.torch(tb["ops"].device)[: self.out_bytes + 64]
+        return {"policy": "wga_paf2maf_expand_place: the batch's rows written into each of %d candidate arenas, the one the "
+                          "row kernel was fastest on kept" % self.place,
+                "k2_ms_by_candidate": [round(x, 3) for x in ms], "chosen": chosen}
 
     def bind_stream(self):
         self.eng.set_stream(self.torch.cuda.current_stream().cuda_stream)
@@ -86,14 +108,3 @@ class Paf2MafStatJob:
 def output_bytes(tb):
     """bytes of the two gapped rows of every record of a generated batch (+ slack), known from the generator's class sums"""
     return int((tb["t_src_len"] + tb["i"]).sum() + (tb["q_src_len"] + tb["d"]).sum()) + 64
-
-
-def arena_output(eng, tb, candidates=8):
-    """The output arena of a long-lived caller, placed by the LIBRARY's policy (wga_arena_alloc, include/wga_hip.h: the
-    row kernel's level is a function of the region of HBM its output lies in — profiles/r02_k2_experiments.md sections
-    7 and 10 — so the library times a plain streaming copy inside `candidates` buffers and keeps the fastest; the
-    `wgatools` command line places its row buffer the same way).  Returns (torch view, DeviceArray that owns the memory,
-    {probe GB/s per candidate, index kept})."""
-    arena, rates, chosen = eng.arena_alloc(output_bytes(tb), candidates)
-    view = arena.torch(tb["ops"].device)
-    return view, arena, {"probe_copy_GBps_by_candidate": [round(r, 1) for r in rates], "chosen": chosen}
