@@ -7,6 +7,7 @@ import subprocess
 import numpy as np
 
 import dist_cli_cases as dc
+from parity_cases import rec_text as pc_rec_text
 from wgatools_amd import synth
 
 
@@ -149,6 +150,57 @@ def check_pafcov(cli, tmp_path, gpus, env):
         rc, _, err = run(cli, "--gpus", str(g), "pafcov", badp, "-o", outp, env=env)
         assert rc == 1 and msg(err) == msg(ref[2]), (g, err, ref[2])
         assert os.path.getsize(outp) == 0
+
+
+def check_call_paf(cli, tmp_path, gpus, env):
+    """`call -f paf`: every device walks and formats its records (target name hash), the rows meet in input order; a base
+    outside ACGTN under a VCF row ends the run at the first such record in input order, nothing written"""
+    import cli_cases as cc
+    import oracle_py as orc
+    b = synth.make_paf_batch(95, 31, 220, 50_000)
+    t_fa, q_fa, paf = dc.write_case(tmp_path, b, np.zeros(31, dtype=int))
+    tp, qp = b["t_pool"].tobytes(), b["q_pool"].tobytes()
+    body = []
+    for i in range(31):
+        qs, ql = int(b["q_src_off"][i]), int(b["q_src_len"][i])
+        ts, tl = int(b["t_src_off"][i]), int(b["t_src_len"][i])
+        body.append(orc.call_within_var_paf("t%d" % (i % dc.N_T), "q%d" % (i % dc.N_Q), pc_rec_text(b, i), tp[ts:ts + tl + 1],
+                                            qp[qs:qs + ql + 1], ts, ts + tl, qs, qs + ql, bool(b["strand_neg"][i]), True, 2))
+    want = (cc.VCF_HEADER % "S1" + "".join(body)).encode()
+    for g in (1,) + tuple(gpus):
+        outp = str(tmp_path / ("c%d.vcf" % g))
+        rc, _, err = run(cli, "--gpus", str(g), "call", "-f", "paf", paf, "--target", t_fa, "-q", q_fa, "-l", "2", "-s", "-n", "S1",
+                         "-o", outp, "-r", env=env)
+        assert rc == 0, (g, err)
+        assert open(outp, "rb").read() == want, g
+    # two records with a bad REF base: the earlier one in input order decides, whichever device owns it
+    lines = open(paf).read().split("\n")
+    xs = {}
+    for i in (9, 20):
+        ops = b["ops"][int(b["op_off"][i]):int(b["op_off"][i + 1])]
+        k = int(np.flatnonzero((ops & 15) == 8)[0])                  # first X op: REF = the target base under it
+        tb = int(sum(int(w >> 4) for w in ops[:k] if (w & 15) in (0, 7, 8, 2)))
+        xs[i] = int(b["t_src_off"][i]) + tb
+    tbad = bytearray(b["t_pool"].tobytes())
+    tbad[xs[9]] = ord("R")
+    tbad[xs[20]] = ord("Y")
+    hit = sorted(i for i in range(31) for x, c in ((xs[9], "R"), (xs[20], "Y"))
+                 if int(b["t_src_off"][i]) <= x <= int(b["t_src_off"][i]) + int(b["t_src_len"][i]))
+    with open(t_fa, "wb") as f:
+        for k in range(dc.N_T):
+            f.write(b">t%d description\n" % k)
+            for i in range(0, len(tbad), 60):
+                f.write(bytes(tbad[i:i + 60]) + b"\n")
+    os.remove(t_fa + ".fai") if os.path.exists(t_fa + ".fai") else None
+    msgs = set()
+    for g in (1,) + tuple(gpus):
+        outp = str(tmp_path / ("e%d.vcf" % g))
+        rc, _, err = run(cli, "--gpus", str(g), "call", "-f", "paf", paf, "--target", t_fa, "-q", q_fa, "-l", "2", "-s", "-o", outp,
+                         "-r", env=env)
+        assert rc == 1 and "invalid reference/alternate base" in err, (g, err)
+        assert not os.path.exists(outp) or os.path.getsize(outp) == 0
+        msgs.add(msg(err))
+    assert len(msgs) == 1, msgs          # the same record's message with every device count
 
 
 def check_too_many(cli, env, have):

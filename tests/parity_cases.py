@@ -618,6 +618,51 @@ def check_runs_bridge_synthetic(eng, recs):
     assert (o[int(oo[-1]):] == 0xFFFFFFFF).all() and (tx[int(to_[-1]):] == 0x23).all()
 
 
+def check_bridge_blocks(eng, seed=3, n=24):
+    """K11's fill: blocks of 256 elements inside one record go through an LDS buffer and out in 16-byte stores, blocks across
+    a record border write directly.  Records of 150 - 900 data lines, the records' outputs placed with gaps of 0 - 37 units
+    between them (every alignment of a stretch inside its 16-byte group): ops and text as expected, not a byte outside."""
+    rng = np.random.default_rng(seed)
+    L = (1 << 28) - 1
+    recs = []
+    for k in range(n):
+        m = int(rng.integers(150, 900)) if k != 5 else 0
+        r = [(int(rng.integers(0, 3000)), int(rng.integers(0, 3)) * int(rng.integers(0, 500)),
+              int(rng.integers(0, 3)) * int(rng.integers(0, 70))) for _ in range(m)]
+        if k == 7:
+            r[100] = (3 * L + 2, 2 * L, L + 1)              # split lengths: more units than lines
+        recs.append(r)
+    flat = [v for r in recs for ln in r for v in ln]
+    line_off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+    ne = int(line_off[-1])
+    d_lines = eng.upload(np.array(flat + [0, 0, 0], dtype=np.uint64))
+    d_loff = eng.upload(line_off)
+    for kind in ("ops", "text"):
+        call = eng.chain_lines_ops if kind == "ops" else eng.chain_lines_cigar_text
+        cnt = call(n, ne, d_lines, d_loff).numpy().astype(np.int64)
+        gaps = rng.integers(0, 38, n)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(cnt + gaps)
+        off[:-1] += gaps.astype(np.uint64)                   # record i starts behind its gap
+        total = int(off[-1]) + 40
+        out = eng.empty(total, np.uint32 if kind == "ops" else np.uint8).fill(0xFF if kind == "ops" else 0x23)
+        call(n, ne, d_lines, d_loff, out=out, out_off=eng.upload(off))
+        h = out.numpy()
+        guard = 0xFFFFFFFF if kind == "ops" else 0x23
+        seen = np.zeros(total, dtype=bool)
+        for i, r in enumerate(recs):
+            a = int(off[i])
+            if kind == "ops":
+                want = [w for (sz, qd, td) in r for w in
+                        expected_split(sz, 0, 0) + expected_split(td, 1, 9) + expected_split(qd, 2, 10)]
+                assert len(want) == cnt[i] and h[a:a + len(want)].tolist() == want, (kind, i)
+            else:
+                want = "".join("%dM" % sz + ("%dI" % td if td else "") + ("%dD" % qd if qd else "") for sz, qd, td in r).encode()
+                assert len(want) == cnt[i] and h[a:a + len(want)].tobytes() == want, (kind, i)
+            seen[a:a + int(cnt[i])] = True
+        assert (h[~seen] == guard).all(), kind
+
+
 def check_chain_lines(eng, recs, strands, seqs=None):
     """recs: per record a list of (size, query_diff, target_diff) data lines.  ops + K1 == the counts of
     parse_chain_to_cigar, text == its CIGAR, and (seqs given: per record (t_seq, q_seq)) ops + K2 ==

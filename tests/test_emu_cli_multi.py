@@ -31,5 +31,9 @@ def test_pafcov_targets_per_device(cli, tmp_path):
     mc.check_pafcov(cli, tmp_path, (2, 3), ENV)
 
 
+def test_call_paf_rows_meet_in_input_order(cli, tmp_path):
+    mc.check_call_paf(cli, tmp_path, (2, 3), ENV)
+
+
 def test_more_devices_than_visible(cli):
     mc.check_too_many(cli, ENV, 3)

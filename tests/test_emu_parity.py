@@ -422,6 +422,10 @@ def test_runs_bridge_synthetic(emu):
     pc.check_runs_bridge_synthetic(emu, recs)
 
 
+def test_bridge_blocks(emu):
+    pc.check_bridge_blocks(emu)
+
+
 def test_chain_lines(emu):
     rng = np.random.default_rng(77)
     L = (1 << 28) - 1

@@ -42,4 +42,5 @@ def test_gpus_flag_with_the_devices_of_this_box(cli, tmp_path):
     mc.check_paf2maf_errors(cli, tmp_path, gpus, env)
     mc.check_stat(cli, tmp_path, gpus, env)
     mc.check_pafcov(cli, tmp_path, gpus, env)
+    mc.check_call_paf(cli, tmp_path, gpus, env)
     mc.check_too_many(cli, env, have)

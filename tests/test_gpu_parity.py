@@ -483,6 +483,10 @@ def test_runs_bridge_synthetic(gpu):
     pc.check_runs_bridge_synthetic(gpu, recs)
 
 
+def test_bridge_blocks(gpu):
+    pc.check_bridge_blocks(gpu)
+
+
 def test_chain_lines(gpu):
     rng = np.random.default_rng(77)
     L = (1 << 28) - 1

@@ -442,21 +442,28 @@ __device__ __forceinline__ void emit_symbols(u8* dst, u32 N, u32 c0, const u32* 
 
 /* BASE = base mode (query bases; the row emitter of K2) or symbol mode: two kernels, so that the symbol one does
  * not carry the emitter's registers and LDS */
+#ifndef WGA_K6_BLOCKS_BASE
+#define WGA_K6_BLOCKS_BASE 4
+#endif
+#ifndef WGA_K6_BLOCKS_SYM
+#define WGA_K6_BLOCKS_SYM 6
+#endif
 template <bool BASE>
-__global__ __launch_bounds__(256) void k_pafpseudo_fill(PseudoArgs a) {
-  __shared__ u32 s_col[WGA_TILE + 1];   /* exclusive prefix of target columns (M = X D)          */
-  __shared__ u32 s_ev[WGA_TILE + 1];    /* exclusive count of event ops (D, I, S)                */
-  __shared__ u32 s_sym[WGA_TILE + 1];   /* symbol-mode byte of the op                            */
-  __shared__ u32 s_g_col[WGA_TILE + 2]; /* events: column                                        */
-  __shared__ u32 s_g_cum[WGA_TILE + 2]; /*         '-' bases before (D)                          */
-  __shared__ u32 s_g_adj[WGA_TILE + 2]; /*         D bases - (I+S) bases before (wrapping)       */
-  __shared__ u32 s_tbl[WGA_TBL_N + 2];  /* events that start before each column granule          */
+__global__ __launch_bounds__(256, BASE ? WGA_K6_BLOCKS_BASE : WGA_K6_BLOCKS_SYM) void k_pafpseudo_fill(PseudoArgs a) {
+  /* the event lists and the chunk queue belong to the row emitter (base mode); symbol mode keeps 13 KB of LDS */
+  __shared__ u32 s_col[WGA_TILE + 1];                  /* exclusive prefix of target columns (M = X D)          */
+  __shared__ u32 s_ev[WGA_TILE + 1];                   /* exclusive count of event ops (D, I, S)                */
+  __shared__ u32 s_sym[BASE ? 1 : WGA_TILE + 1];       /* symbol-mode byte of the op                            */
+  __shared__ u32 s_g_col[BASE ? WGA_TILE + 2 : 2];     /* events: column                                        */
+  __shared__ u32 s_g_cum[BASE ? WGA_TILE + 2 : 2];     /*         '-' bases before (D)                          */
+  __shared__ u32 s_g_adj[BASE ? WGA_TILE + 2 : 2];     /*         D bases - (I+S) bases before (wrapping)       */
+  __shared__ u32 s_tbl[WGA_TBL_N + 2];                 /* events that start before each column granule          */
   __shared__ u32 s_zero2[2];
   __shared__ u64 s_w[5];
   __shared__ u32 s_w4[4];
   __shared__ u64 s_red[4][4];
   __shared__ u32x4_a16 s_lowmask[17];
-  __shared__ u32 s_queue[4 * WGA_QCAP];
+  __shared__ u32 s_queue[BASE ? 4 * WGA_QCAP : 4];
 
   const u32 tid = threadIdx.x;
   build_lowmask(s_lowmask);
@@ -2282,14 +2289,62 @@ __global__ __launch_bounds__(256) void k_elem_rec_totals(u32 n, const u64* __res
   const u32 r = blockIdx.x * 256u + threadIdx.x;
   if (r < n) cnt[r] = esc[elem_off[r + 1]] - esc[elem_off[r]];
 }
+/* bytes [a, a + total) of an LDS text buffer go to gb + a (gb 16-byte aligned: the buffer mirrors the output's position
+ * inside its 16-byte group): whole groups with 16-byte stores, the ragged head and tail (< 16 bytes each) by bytes.
+ * `nthr` threads share the work (a wave or a block; the caller synchronises around the call). */
+__device__ __forceinline__ void lds_text_flush(const u8* tbuf, u32 a, u32 total, u8* gb, u32 tid, u32 nthr) {
+  const u32 end = a + total;
+  const u32 g_lo = (a + 15u) >> 4, g_hi = end >> 4; /* whole 16-byte groups [g_lo, g_hi) */
+  for (u32 g = g_lo + tid; g < g_hi; g += nthr) *(u32x4_a16*)(gb + 16u * g) = *(const u32x4_a16*)(tbuf + 16u * g);
+  const u32 head_end = 16u * g_lo < end ? 16u * g_lo : end;           /* [a, head_end) */
+  const u32 tail_beg = 16u * g_hi > head_end ? 16u * g_hi : head_end; /* [tail_beg, end) */
+  if (tid < 16u) {
+    const u32 x = a + tid;
+    if (x < head_end) gb[x] = tbuf[x];
+  } else if (tid < 32u) {
+    const u32 x = tail_beg + (tid - 16u);
+    if (x < end) gb[x] = tbuf[x];
+  }
+}
+
+/* One thread per element, 256 consecutive elements per block.  The records of the block's first and last element are
+ * found once (two bisections per block); every thread then looks inside that window — one record in nearly every block.
+ * A block whose elements belong to ONE record writes one contiguous stretch of that record's output: its threads put
+ * their units into an LDS buffer that mirrors the stretch's position inside its 16-byte group, and the stretch goes out
+ * in 16-byte stores.  Blocks across a record border, or with more output than the buffer holds, write directly. */
+#define WGA_ELEM_STAGE 16384u
 template <typename F>
 __global__ __launch_bounds__(256) void k_elem_fill(F f, u32 n, u32 ne, const u64* __restrict__ elem_off,
                                                    const u64* __restrict__ esc, typename F::out_t* out,
                                                    const u64* __restrict__ out_off) {
-  const u32 x = blockIdx.x * 256u + threadIdx.x;
-  if (x >= ne) return;
-  const u32 r = csr_find_rec(elem_off, n, (u64)x);
-  f.write((u64)x, r, out + out_off[r] + (esc[x] - esc[elem_off[r]]));
+  typedef typename F::out_t out_t;
+  __shared__ u32x4_a16 s_buf[(WGA_ELEM_STAGE + 32u) / 16u];
+  __shared__ u32 s_r[2];
+  const u32 tid = threadIdx.x;
+  const u32 x0 = blockIdx.x * 256u, x1 = x0 + 256u < ne ? x0 + 256u : ne;
+  if (tid == 0u) s_r[0] = csr_find_rec(elem_off, n, (u64)x0);
+  if (tid == 64u) s_r[1] = csr_find_rec(elem_off, n, (u64)(x1 - 1u));
+  __syncthreads();
+  const u32 r_lo = WGA_UNI32(s_r[0]), r_hi = WGA_UNI32(s_r[1]);
+  const u32 x = x0 + tid;
+  const u64 e0 = esc[x0], e1 = esc[x1]; /* units in front of the block, and behind it */
+  const bool staged = r_lo == r_hi && (e1 - e0) * sizeof(out_t) <= (u64)WGA_ELEM_STAGE;
+  if (staged) { /* block-uniform */
+    out_t* const g0 = out + out_off[r_lo] + (e0 - esc[elem_off[r_lo]]);
+    const u32 a = (u32)((uintptr_t)g0 & 15u);
+    u8* const tbuf = (u8*)s_buf;
+    if (x < x1) f.write((u64)x, r_lo, (out_t*)(tbuf + a) + (esc[x] - e0));
+    __syncthreads();
+    lds_text_flush(tbuf, a, (u32)((e1 - e0) * sizeof(out_t)), (u8*)g0 - a, tid, 256u);
+    return;
+  }
+  if (x >= x1) return;
+  u32 lo = r_lo, hi = r_hi + 1u; /* largest r in [r_lo, r_hi] with elem_off[r] <= x */
+  while (hi - lo > 1u) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if (elem_off[mid] <= (u64)x) lo = mid; else hi = mid;
+  }
+  f.write((u64)x, lo, out + out_off[lo] + (esc[x] - esc[elem_off[lo]]));
 }
 
 /* ============================================================================================ */

@@ -215,19 +215,7 @@ __global__ __launch_bounds__(256) void k_paf_call_vcf(u32 n, const u32* __restri
       }
       if (staged) {
         WGA_WAVE_SYNC();
-        const u32 end = a + (u32)total;
-        const u32 g_lo = (a + 15u) >> 4, g_hi = end >> 4; /* whole 16-byte groups [g_lo, g_hi) */
-        u8* const gb = g0 - a;
-        for (u32 g = g_lo + lane; g < g_hi; g += 64u) *(u32x4_a16*)(gb + 16u * g) = *(const u32x4_a16*)(tbuf + 16u * g);
-        const u32 head_end = 16u * g_lo < end ? 16u * g_lo : end;             /* [a, head_end): < 16 bytes */
-        const u32 tail_beg = 16u * g_hi > head_end ? 16u * g_hi : head_end;   /* [tail_beg, end): < 16 bytes */
-        if (lane < 16u) {
-          const u32 x = a + lane;
-          if (x < head_end) gb[x] = tbuf[x];
-        } else if (lane < 32u) {
-          const u32 x = tail_beg + (lane - 16u);
-          if (x < end) gb[x] = tbuf[x];
-        }
+        lds_text_flush(tbuf, a, (u32)total, g0 - a, lane, 64u);
         WGA_WAVE_SYNC();
       }
     }

@@ -2943,25 +2943,24 @@ std::string vcf_header(const std::string& sample, const std::vector<std::pair<st
 
 /* ---- call (PAF) (caller.rs:268-302, 610-822) -----------------------------------------------------------
  * GPU: the op walk (wga_paf_call_events) and the event -> VCF row text (wga_paf_call_vcf).  Host: fetch coordinates. */
-int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::string& q_fa, bool snp,
-                 uint64_t svlen, const std::string& sample, Output& out) {
-  Dev d;
-  PafInput pin = load_paf(d, input, false);
+/* the records which[0 .. n_which) of a piece (which == nullptr: all of them) in resident batches; their VCF rows are
+ * appended to `body` in that order (`sizes`, when given, gets every record's byte count).  Errors are thrown; *bad_at is then
+ * the position (in `which` order) of the record they belong to. */
+void call_paf_run(Dev& d, DevFasta& tf, DevFasta& qf, const PafInput& pin, const size_t* which, size_t n_which,
+                  const uint8_t* d_text_here, bool snp, uint64_t svlen, std::string& body, std::vector<uint64_t>* sizes,
+                  size_t* bad_at) {
   const std::vector<PafRecord>& recs = pin.recs;
-  DevFasta tf, qf;
-  d.init();
-  tf.load(d, t_fa);
-  qf.load(d, q_fa);
-  std::string body;
-  const size_t keep = d.owned.size(); /* the input text */
+  const size_t keep = d.owned.size(); /* the input text, the pools */
   const uint64_t kMaxText = 160ull << 20; /* ~64 M ops per batch */
   size_t i0 = 0;
-  while (i0 < recs.size()) {
+  while (i0 < n_which) {
     std::vector<uint64_t> t_off, t_len, q_off, q_len;
     size_t i = i0;
     uint64_t est_text = 0;
-    for (; i < recs.size(); i++) {
-      const PafRecord& r = recs[i];
+    for (; i < n_which; i++) {
+      const size_t ri = which ? which[i] : i;
+      const PafRecord& r = recs[ri];
+      *bad_at = i; /* an error raised from here on belongs to this record */
       if (i > i0 && est_text > kMaxText) break;
       uint64_t to, tl, qo, ql;
       tf.fetch(r.target_name, r.target_start, r.target_end, &to, &tl); /* paf.rs:221-237: end inclusive */
@@ -2970,8 +2969,8 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
       { /* a missing tag or an empty CIGAR ends the run at this record (checked here to keep the order of the errors) */
         bool has_tag, empty;
         if (pin.on_device) {
-          has_tag = pin.cg_beg[i] != WGA_NONE;
-          empty = has_tag && pin.cg_end[i] == pin.cg_beg[i];
+          has_tag = pin.cg_beg[ri] != WGA_NONE;
+          empty = has_tag && pin.cg_end[ri] == pin.cg_beg[ri];
         } else {
           int err = 0;
           const std::string cg = paf_cigar_string(r, &err);
@@ -2981,7 +2980,7 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
         if (!has_tag) fail("CIGAR start tag not found");
         if (empty) fail(cigar_error_message(WGA_REC_PANIC, std::string(), 0, 0));
       }
-      est_text += pin.cigar_bytes(i);
+      est_text += pin.cigar_bytes(ri);
       t_off.push_back(to);
       t_len.push_back(tl);
       q_off.push_back(qo);
@@ -2993,9 +2992,13 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
     wga_cigar_batch cb;
     std::vector<wga_tok_err> terrs;
     const uint32_t n_asked = (uint32_t)(i - i0);
-    const std::string tag_err = device_tokenise(d, pin, i0, n_asked, cigars, &cb, &terrs);
+    const std::string tag_err = device_tokenise(d, pin, i0, n_asked, cigars, &cb, &terrs, which, d_text_here);
     for (uint32_t k = 0; k < cb.n; k++)
-      if (terrs[k].err == WGA_REC_PANIC) fail(cigar_error_message(WGA_REC_PANIC, std::string(), 0, 0));
+      if (terrs[k].err == WGA_REC_PANIC) {
+        *bad_at = i0 + k;
+        fail(cigar_error_message(WGA_REC_PANIC, std::string(), 0, 0));
+      }
+    *bad_at = i0 + cb.n;
     if (cb.n < n_asked) fail(tag_err); /* records are processed in order: the first failing one ends the run */
     const uint32_t n = cb.n;
     if (n) {
@@ -3022,7 +3025,7 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
       };
       std::vector<wga_vcf_rec> vr(n);
       for (uint32_t k = 0; k < n; k++) {
-        const PafRecord& r = recs[i0 + k];
+        const PafRecord& r = recs[which ? which[i0 + k] : i0 + k];
         wga_vcf_rec& v = vr[k];
         v.t_name_off = name_off(r.target_name), v.t_name_len = (uint32_t)r.target_name.size();
         v.q_name_off = name_off(r.query_name), v.q_name_len = (uint32_t)r.query_name.size();
@@ -3042,6 +3045,7 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
       d.download(errs.data(), (const wga_vcf_err*)d_err, n);
       for (uint32_t k = 0; k < n; k++) { /* the first failing record in input order */
         if (errs[k].item == WGA_NONE) continue;
+        *bad_at = i0 + k;
         if (errs[k].kind == 1)
           fail("panic: VCF REF/ALT slice out of the fetched sequence (caller.rs:695-696,753-754,800-801)");
         fail(std::string("invalid reference/alternate base `") + (char)errs[k].ch +
@@ -3049,6 +3053,11 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
       }
       uint64_t n_text = 0;
       d.download(&n_text, (const uint64_t*)d_toff + n, 1);
+      if (sizes) {
+        std::vector<uint64_t> nb(n);
+        d.download(nb.data(), (const uint64_t*)d_nb, n);
+        sizes->insert(sizes->end(), nb.begin(), nb.end());
+      }
       if (n_text) {
         auto* d_text = (uint8_t*)d.alloc(n_text + 64);
         d.check(wga_paf_call_vcf(d.ctx, &cb, svlen, d_ev, d_eoff, d_vr, d_names, tf.d_pool, qf.d_pool, nullptr, nullptr,
@@ -3061,6 +3070,79 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
     d.release_to(keep);
     i0 = i;
   }
+  *bad_at = n_which;
+}
+
+int cmd_call_paf_multi(const std::string* input, const std::string& t_fa, const std::string& q_fa, bool snp, uint64_t svlen,
+                       const std::string& sample, Output& out, int ngpu) {
+  /* --gpus N: the records go to the devices by fnv1a64(target_name) % N; every device walks and formats its share, the rows
+   * meet on the host in input order (the driver is buffered: caller.rs:294-299); the first failing record in input order
+   * decides the message */
+  std::vector<std::unique_ptr<Dev>> devs;
+  for (int g = 0; g < ngpu; g++) devs.emplace_back(new Dev(g));
+  PafInput pin = load_paf(*devs[0], input, false);
+  const size_t n = pin.recs.size();
+  std::vector<DevFasta> tf(ngpu), qf(ngpu);
+  std::vector<std::vector<size_t>> mine(ngpu);
+  for (size_t i = 0; i < n; i++) mine[fnv1a64(pin.recs[i].target_name) % (uint64_t)ngpu].push_back(i);
+  std::string text16;
+  if (pin.on_device && ngpu > 1) text16 = pin.text + std::string(16, '\0');
+  std::vector<std::string> bodies(ngpu), msgs(ngpu);
+  std::vector<std::vector<uint64_t>> sizes(ngpu);
+  std::vector<size_t> bad(ngpu, n); /* input index of a worker's failing record */
+  on_devices(ngpu, [&](int g) {
+    Dev& d = *devs[g];
+    size_t at = 0;
+    try {
+      d.init();
+      tf[g].load(d, t_fa);
+      qf[g].load(d, q_fa);
+      const uint8_t* d_text = nullptr;
+      if (pin.on_device) d_text = g == 0 ? pin.d_text : d.upload((const uint8_t*)text16.data(), text16.size());
+      call_paf_run(d, tf[g], qf[g], pin, mine[g].data(), mine[g].size(), d_text, snp, svlen, bodies[g], &sizes[g], &at);
+    } catch (Error& e) {
+      bad[g] = at < mine[g].size() ? mine[g][at] : (mine[g].empty() ? 0 : mine[g].back());
+      msgs[g] = e.msg.empty() ? std::string("error") : e.msg;
+    } catch (std::exception& e) { /* bad_alloc and friends: an exception leaving a thread is std::terminate */
+      bad[g] = at < mine[g].size() ? mine[g][at] : 0;
+      msgs[g] = std::string("internal error: ") + e.what();
+    }
+  });
+  int first = -1;
+  for (int g = 0; g < ngpu; g++)
+    if (!msgs[g].empty() && (first < 0 || bad[g] < bad[first])) first = g;
+  if (first >= 0) fail(msgs[first]);
+  std::string body;
+  {
+    size_t total = 0;
+    for (int g = 0; g < ngpu; g++) total += bodies[g].size();
+    body.reserve(total);
+    std::vector<size_t> next(ngpu, 0), pos(ngpu, 0);
+    for (size_t i = 0; i < n; i++) {
+      const int g = (int)(fnv1a64(pin.recs[i].target_name) % (uint64_t)ngpu);
+      const uint64_t sz = sizes[g][next[g]++];
+      body.append(bodies[g], pos[g], sz);
+      pos[g] += sz;
+    }
+  }
+  out.write(vcf_header(sample, {}));
+  out.write(body);
+  out.close();
+  return 0;
+}
+
+int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::string& q_fa, bool snp,
+                 uint64_t svlen, const std::string& sample, Output& out) {
+  if (g_gpus > 1) return cmd_call_paf_multi(input, t_fa, q_fa, snp, svlen, sample, out, g_gpus);
+  Dev d;
+  PafInput pin = load_paf(d, input, false);
+  DevFasta tf, qf;
+  d.init();
+  tf.load(d, t_fa);
+  qf.load(d, q_fa);
+  std::string body;
+  size_t bad_at = 0;
+  call_paf_run(d, tf, qf, pin, nullptr, pin.recs.size(), nullptr, snp, svlen, body, nullptr, &bad_at);
   /* everything is buffered; the header goes out first, after all records were processed (:294-299) */
   out.write(vcf_header(sample, {}));
   out.write(body);
