@@ -122,7 +122,7 @@ def build_hip_variant(name, extra_flags):
 
 @_locked
 def build_emu(force=False):
-    srcs = _sources() + [os.path.join(ROOT, "tests", "emu", "simt_emu.h")]
+    srcs = _sources() + [os.path.join(ROOT, "tests", "emu", f) for f in ("simt_emu.h", "wga_intrin_emu.h")]
     if not force and not _newer(EMU_LIB, srcs):
         return EMU_LIB
     # -DWGA_MAF_FOLD_STEPS: fold the MAF walks' 16-bit lane counters every 3 steps, so that small test rows reach that path

@@ -616,6 +616,12 @@ int wga_arena_probe(wga_ctx* c, void* d_buf, size_t bytes, int kind, double* gbp
 int wga_free(wga_ctx* c, void* d_ptr) {
   int rc = ctx_bind(c);
   if (rc) return rc;
+  if (d_ptr && d_ptr == c->tune.out) { /* a later buffer at the same address learns for itself */
+    if (c->tune.pending) (void)rt_sync(c->stream);
+    c->tune.out = nullptr;
+    c->tune.phase = 0;
+    c->tune.pending = false;
+  }
   if (d_ptr) RT_CHECK(rt_free(d_ptr));
   return WGA_OK;
 }
@@ -849,7 +855,10 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
         if (e) return fail(WGA_E_HIP, "rt_event_create", e);
         T.have_ev = true;
       }
-      if (T.out != (const void*)d_out) {
+      /* what was learnt belongs to one buffer and one size of work: another pointer, or a launch of less than half / more
+       * than twice the tiles the trials ran on, starts over (a buffer freed through wga_free is forgotten there) */
+      const bool resized = T.phase > 1 && T.tiles && ((uint64_t)nt > 2 * T.tiles || 2 * (uint64_t)nt < T.tiles);
+      if (T.out != (const void*)d_out || resized) {
         T.out = (const void*)d_out;
         T.phase = 0;
         T.pending = false;

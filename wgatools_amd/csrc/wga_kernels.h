@@ -22,7 +22,8 @@
  *                        out-of-range offsets as the lane predicate; no read-modify-write.
  *   (K3..K8 are in wga_kernels2.h.)
  *
- * The same source also compiles under tests/emu/simt_emu.h (WGA_EMU) for CPU-side logic tests.
+ * The same source also compiles under tests/emu/simt_emu.h for CPU-side logic tests: wga_intrin.h is the one place that
+ * knows (it hands its names over to tests/emu/wga_intrin_emu.h there).
  */
 #ifndef WGA_KERNELS_H
 #define WGA_KERNELS_H
@@ -71,21 +72,13 @@ typedef u32 u32x4_a16 __attribute__((vector_size(16), aligned(16)));
  * the same as aligned ones, unaligned stores ~10 % slower: scripts/micro/unaligned_copy.hip) */
 typedef u32 u32x4_a1 __attribute__((vector_size(16), aligned(1)));
 
+#include "wga_intrin.h" /* the gfx950 instructions the kernels are written with (cross-lane, buffer, uniformity) */
+
 __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
   return v;
 }
 
-/* tell the compiler a value is wave-uniform so that it lives in SGPRs (scalar loads, no VGPRs) */
-#ifdef WGA_EMU
-#define WGA_UNI32(x) ((u32)(x))
-#define WGA_UNI64(x) ((u64)(x))
-#else
-#define WGA_UNI32(x) ((u32)__builtin_amdgcn_readfirstlane((int)(x)))
-#define WGA_UNI64(x)                                                               \
-  (((u64)(u32)__builtin_amdgcn_readfirstlane((int)((u64)(x) >> 32)) << 32) |       \
-   (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(u64)(x)))
-#endif
 
 #ifndef WGA_K1_BLOCKS
 #define WGA_K1_BLOCKS 5 /* blocks per CU the register budget of k_cigar_stat is sized for: 94 VGPRs, no scratch.  6 (80 VGPRs + 12 B of scratch) measured 0.56 ms on one box and 0.70 ms on two others against 0.54-0.57 ms for 5 */
@@ -94,68 +87,8 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
 #define WGA_K1_LANE_STORE 1 /* K1 writes its counters one field per lane (v_writelane) instead of from lane 0 */
 #endif
 
-/* index of the wave inside its block.  threadIdx.x >> 6 is the same in all 64 lanes, but the compiler's
- * divergence analysis does not know: everything derived from it (tile / record index, offsets loaded with it,
- * loop bounds) would be treated as per-lane — vector loads, exec-masked loops, VGPR-held "uniform" values.
- * WGA_WAVE_ID(t) can be switched back to the plain shift with -DWGA_WAVE_ID_PLAIN for A/B measurements. */
-#if defined(WGA_EMU) || defined(WGA_WAVE_ID_PLAIN)
-#define WGA_WAVE_ID(t) ((u32)(t) >> 6)
-#else
-#define WGA_WAVE_ID(t) ((u32)__builtin_amdgcn_readfirstlane((int)((u32)(t) >> 6)))
-#endif
 
-/* keep the computation of a value where it is written (the compiler otherwise sinks LDS reads into
- * exec-masked branches "to save them", which costs more in branch overhead than the reads) */
-#ifdef WGA_EMU
-#define WGA_PIN(x) ((void)0)
-#else
-#define WGA_PIN(x) asm volatile("" : "+v"(x))
-#endif
 
-/* Inclusive scan of a u32 over the 64 lanes.  On gfx950 this is six DPP adds (row_shr 1/2/4/8
- * inside each 16-lane row, then row_bcast:15 and row_bcast:31 across rows): no LDS crossbar, no
- * index arithmetic — a __shfl_up formulation costs ~5x the VALU work.  Lanes that a step does
- * not reach add the `old` operand, 0. */
-__device__ __forceinline__ u32 wave_incl_scan_u32(u32 v) {
-#ifdef WGA_EMU
-  const u32 lane = threadIdx.x & 63u;
-  for (u32 d = 1; d < 64; d <<= 1) {
-    u32 t = __shfl_up(v, d);
-    if (lane >= d) v += t;
-  }
-  return v;
-#else
-  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); /* row_shr:1 */
-  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false); /* row_shr:2 */
-  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false); /* row_shr:4 */
-  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); /* row_shr:8 */
-  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); /* row_bcast:15 */
-  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); /* row_bcast:31 */
-  return v;
-#endif
-}
-/* value of lane 63 of an inclusive scan = the wave total (uniform) */
-__device__ __forceinline__ u32 wave_last_u32(u32 incl) {
-#ifdef WGA_EMU
-  return __shfl(incl, 63);
-#else
-  return (u32)__builtin_amdgcn_readlane((int)incl, 63);
-#endif
-}
-/* v with lane K's copy replaced by a wave-uniform value (v_writelane_b32 x 2; this clang has no builtin for it) */
-template <u32 K>
-__device__ __forceinline__ u64 lane_put_u64(u64 v, u64 uniform_val, u32 lane) {
-#ifdef WGA_EMU
-  return lane == K ? uniform_val : v;
-#else
-  (void)lane;
-  u32 lo = (u32)v, hi = (u32)(v >> 32);
-  const u32 ulo = WGA_UNI32((u32)uniform_val), uhi = WGA_UNI32((u32)(uniform_val >> 32));
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"(ulo), "n"(K));
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"(uhi), "n"(K));
-  return ((u64)hi << 32) | (u64)lo;
-#endif
-}
 /* exact sum of 64 u32 values (up to 2^38): two 16-bit halves scanned separately */
 __device__ __forceinline__ u64 wave_sum_u32_wide(u32 v) {
   const u32 lo = wave_last_u32(wave_incl_scan_u32(v & 0xFFFFu));
@@ -586,82 +519,7 @@ struct RowSrc {
   const u8* win_base; /* address of slice index sbase (rc: of the mirrored window start) */
 };
 
-/* v_perm_b32: result byte k = byte sel[k] (0..7) of the 8-byte pool {hi:7..4, lo:3..0} */
-__device__ __forceinline__ u32 byte_perm(u32 hi, u32 lo, u32 sel) {
-#ifdef WGA_EMU
-  u64 pool = ((u64)hi << 32) | (u64)lo;
-  u32 r = 0;
-  for (int k = 0; k < 4; k++) r |= (u32)((pool >> (8 * ((sel >> (8 * k)) & 7u))) & 0xFFu) << (8 * k);
-  return r;
-#else
-  return __builtin_amdgcn_perm(hi, lo, sel);
-#endif
-}
 
-/* Raw buffer access (128-bit descriptor in SGPRs, 32-bit per-lane byte offset).  An offset at or
- * beyond `bytes` is out of range: the load returns zeros and the store is dropped — per-lane
- * predication without exec-mask branches, which keeps the chunk loop one basic block (the
- * compiler then places its s_waitcnt exactly; with branches around the memory ops it falls back
- * to vmcnt(0) between them and serialises the loads).  Byte-unaligned offsets are fine. */
-#define WGA_BUF_OOB 0xFFFFFFFFu
-#ifdef WGA_EMU
-struct BufRsrc {
-  u8* base;
-  u32 bytes;
-};
-__device__ __forceinline__ BufRsrc buf_make(const void* base, u32 bytes) {
-  BufRsrc r;
-  r.base = (u8*)base;
-  r.bytes = bytes;
-  return r;
-}
-__device__ __forceinline__ void buf_load16(const BufRsrc& r, u32 off, u32 v[4]) {
-  for (int d = 0; d < 4; d++) {
-    v[d] = 0u;
-    if ((u64)off + 4u * d + 4u <= (u64)r.bytes) memcpy(&v[d], r.base + off + 4 * d, 4);
-  }
-}
-__device__ __forceinline__ void buf_store16(const BufRsrc& r, u32 off, const u32 v[4]) {
-  for (int d = 0; d < 4; d++)
-    if ((u64)off + 4u * d + 4u <= (u64)r.bytes) memcpy(r.base + off + 4 * d, &v[d], 4);
-}
-__device__ __forceinline__ void buf_store16_stream(const BufRsrc& r, u32 off, const u32 v[4]) { buf_store16(r, off, v); }
-#else
-typedef __amdgpu_buffer_rsrc_t BufRsrc;
-typedef u32 u32x4_v __attribute__((vector_size(16)));
-__device__ __forceinline__ BufRsrc buf_make(const void* base, u32 bytes) {
-  /* the descriptor must live in SGPRs: values the compiler cannot prove wave-uniform would make it
-   * wrap every access in a readfirstlane "waterfall" loop */
-  const u64 b = (u64)base;
-  const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)b);
-  const u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(b >> 32));
-  const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)bytes);
-  return __builtin_amdgcn_make_buffer_rsrc((void*)(((u64)hi << 32) | (u64)lo), (short)0, (int)n, 0x00020000);
-}
-__device__ __forceinline__ void buf_load16(const BufRsrc& r, u32 off, u32 v[4]) {
-  const u32x4_v x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
-  v[0] = x[0];
-  v[1] = x[1];
-  v[2] = x[2];
-  v[3] = x[3];
-}
-#ifndef WGA_STORE_AUX
-#define WGA_STORE_AUX 0 /* cache policy of the row stores: 0 default, 2 nt, 16 sc1 (write-through) */
-#endif
-__device__ __forceinline__ void buf_store16(const BufRsrc& r, u32 off, const u32 v[4]) {
-  const u32x4_v x = {v[0], v[1], v[2], v[3]};
-  __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)off, 0, WGA_STORE_AUX);
-}
-/* streaming store (nt): for output that leaves in whole 128-byte lines and is not read again by the kernel.  On lines
- * that arrive in pieces it is much slower than the default policy (profiles/r02_k2_experiments.md). */
-#ifndef WGA_STREAM_AUX
-#define WGA_STREAM_AUX 2
-#endif
-__device__ __forceinline__ void buf_store16_stream(const BufRsrc& r, u32 off, const u32 v[4]) {
-  const u32x4_v x = {v[0], v[1], v[2], v[3]};
-  __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)off, 0, WGA_STREAM_AUX);
-}
-#endif
 
 /* Complement 4 packed bases (utils.rs:86-96) with two 8-entry byte LUTs indexed by the low
  * THREE bits of each base — A=1 C=3 T=4 N=6 G=7 are distinct.  `fold` is the upper-case base a
@@ -857,36 +715,6 @@ __device__ __forceinline__ void emit_walk(u32 o[4], u32 c, u32 c_end, u32 cz, in
   }
 }
 
-/* dwords k, k+1 of a value spread over the lanes of a wave (wave-uniform result) */
-__device__ __forceinline__ u64 wave_get_u64(u32 v, int k) {
-#ifdef WGA_EMU
-  return (u64)__shfl(v, k) | ((u64)__shfl(v, k + 1) << 32);
-#else
-  return (u64)(u32)__builtin_amdgcn_readlane((int)v, k) | ((u64)(u32)__builtin_amdgcn_readlane((int)v, k + 1) << 32);
-#endif
-}
-
-__device__ __forceinline__ u32 wave_get_u32(u32 v, int k) {
-#ifdef WGA_EMU
-  return __shfl(v, k);
-#else
-  return (u32)__builtin_amdgcn_readlane((int)v, k);
-#endif
-}
-
-#ifdef WGA_EMU
-#define WGA_CLOCK() 0ull
-#else
-#define WGA_CLOCK() ((u64)__builtin_amdgcn_s_memtime())
-#endif
-
-/* lanes of a wave exchange data through LDS: hardware runs them in lockstep (only the compiler
- * must not reorder), the emulator needs a real wave barrier */
-#ifdef WGA_EMU
-#define WGA_WAVE_SYNC() emu::barrier_wait(emu::S().wave_bar[emu::flat_tid() >> 6])
-#else
-#define WGA_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
-#endif
 
 #define WGA_TBL_SHIFT 4u                          /* granule = 16 columns */
 #ifndef WGA_TBL_COLS
@@ -902,9 +730,6 @@ __device__ __forceinline__ u32 wave_get_u32(u32 v, int k) {
 #endif
 #ifndef WGA_SPLIT_BYTES
 #define WGA_SPLIT_BYTES 8192u /* ... in two halves beyond this */
-#endif
-#ifndef WGA_MBCNT
-#define WGA_MBCNT 1
 #endif
 #ifndef WGA_OWNER_SETUP
 #define WGA_OWNER_SETUP 1 /* 1: only the wave that owns a row piece reads the row's source / destination fields */
@@ -1109,15 +934,6 @@ __device__ __forceinline__ void complex_chunk(const ChunkGeom& g, u32 rel, const
   if (!whole) chunk_store(g, o, 0); /* a row / tile edge: byte stores */
 }
 
-/* set bits of m below this lane's (v_mbcnt_lo / v_mbcnt_hi) */
-__device__ __forceinline__ u32 lane_rank(u64 m, u32 lane) {
-#if defined(WGA_EMU) || !WGA_MBCNT
-  return (u32)__popcll(m & ((1ull << lane) - 1ull));
-#else
-  (void)lane;
-  return (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-#endif
-}
 
 /* RC = the row is read reverse-complemented: a compile-time copy of src.rc, so that each of the
  * two instantiations carries only its own window post-processing */
@@ -1511,11 +1327,7 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
   {
     u32 base = tid * 4u;
     if (base + 3 < nt) {
-#if defined(WGA_OPS_NT) && !defined(WGA_EMU)
-      u32x4_a16 v = __builtin_nontemporal_load((const u32x4_a16*)(a.ops + tile_start + base));
-#else
-      u32x4_a16 v = *(const u32x4_a16*)(a.ops + tile_start + base);
-#endif
+      u32x4_a16 v = ops_load16(a.ops + tile_start + base);
       opw[0] = v[0];
       opw[1] = v[1];
       opw[2] = v[2];

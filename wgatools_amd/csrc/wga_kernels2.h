@@ -1667,14 +1667,6 @@ __device__ __forceinline__ void chain_serial(const u32* rec, u64 nops, u8* text,
 #define WGA_CHAIN_DM ((1u << WGA_OP_D) | (1u << WGA_OP_D_CONT))
 #define WGA_CHAIN_PAD 0xFu /* behind the record's end: no length, no class */
 
-/* all ones when bit idx of bits is set (v_bfe_i32) */
-__device__ __forceinline__ u32 bit_mask(u32 bits, u32 idx) {
-#ifdef WGA_EMU
-  return 0u - ((bits >> (idx & 31u)) & 1u);
-#else
-  return (u32)__builtin_amdgcn_sbfe((int)bits, idx, 1u);
-#endif
-}
 /* decimal digits of a u32; p10[t] = 10^t, t < 10 */
 __device__ __forceinline__ u32 dec_digits_u32(u32 v, const u32* p10) {
   const u32 x = v | 1u;

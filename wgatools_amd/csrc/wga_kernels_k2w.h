@@ -47,31 +47,13 @@
 #ifndef WGA_AUTO_SHORT_OPS
 #define WGA_AUTO_SHORT_OPS 1500ull /* batches below this many ops per record take the window kernel when "expand_variant" is -1 */
 #endif
-#ifndef WGA_W_STORE_AUX
-#define WGA_W_STORE_AUX 2 /* cache policy of the row stores: 0 default, 2 nt (streaming: whole lines that are not read again) */
-#endif
 
 /* The kernel's arguments for the code behind phase A: only the planner and the rare paths read them, so they are
  * fetched from the kernarg segment where they are used (scalar loads) instead of occupying ~40 SGPRs for the whole
  * kernel — the window loop would spill its own scalars to make room for them. */
-#ifdef WGA_EMU
-typedef const ExpandArgs* KArgP;
-#define WGA_KARG_PTR(a) (&(a))
-#define WGA_KARG_FRESH(p) ((void)0)
-#else
-typedef const __attribute__((address_space(4))) ExpandArgs* KArgP;
-#define WGA_KARG_PTR(a) ((KArgP)__builtin_amdgcn_kernarg_segment_ptr())
-#define WGA_KARG_FRESH(p) asm volatile("" : "+s"(p)) /* loads through p stay behind this point */
-#endif
+typedef const WGA_KARG_SPACE ExpandArgs* KArgP;
+#define WGA_KARG_PTR(a) WGA_KARG_SEGMENT(KArgP, a)
 
-/* v_readlane with a wave-uniform lane index */
-__device__ __forceinline__ u32 wave_get_u32_dyn(u32 v, u32 k) {
-#ifdef WGA_EMU
-  return __shfl(v, (int)k);
-#else
-  return (u32)__builtin_amdgcn_readlane((int)v, (int)k);
-#endif
-}
 
 /* one row's gap events of the tile, in column order: col[e] = start column (tile relative), cum[e] = gap bases of the
  * entries before e; two sentinel entries behind the last one (column = the tile's width) */
@@ -119,14 +101,6 @@ struct SpanW {
   u64* bad_base_pos;
 };
 
-#ifdef WGA_EMU
-__device__ __forceinline__ void buf_store16_w(const BufRsrc& r, u32 off, const u32 v[4]) { buf_store16(r, off, v); }
-#else
-__device__ __forceinline__ void buf_store16_w(const BufRsrc& r, u32 off, const u32 v[4]) {
-  const u32x4_v x = {v[0], v[1], v[2], v[3]};
-  __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)off, 0, WGA_W_STORE_AUX);
-}
-#endif
 
 /* sixteen bytes: `a` where the mask is set, `b` elsewhere */
 __device__ __forceinline__ void sel16(u32 o[4], const u32x4_a16& m, const u32 a[4], const u32 b[4]) {
@@ -250,9 +224,7 @@ __device__ __forceinline__ void ev_view(EvView& v, const EvList& L, int e) {
   v.m0 = L.m(e);
   v.m1 = L.m(e + 1);
   v.m2 = L.m(e + 2);
-#ifndef WGA_EMU
-  asm volatile("" : "+v"(v.cprev), "+v"(v.gs), "+v"(v.gsB), "+v"(v.gsC), "+v"(v.m0), "+v"(v.m1), "+v"(v.m2)); /* seven loads, one wait */
-#endif
+  WGA_PIN7(v.cprev, v.gs, v.gsB, v.gsC, v.m0, v.m1, v.m2); /* seven loads, one wait */
 }
 template <bool RC>
 __device__ __forceinline__ void fix1_issue(Fix1& f, const SpanW& sp, const EvView& v, int cw0, int e_lo, int e, bool act) {
@@ -511,8 +483,8 @@ __device__ __forceinline__ void emit_window(KArgP a, const u32* rec, u32 w, cons
     WGA_WAVE_SYNC();
 #pragma unroll
     for (u32 u = 0; u < WGA_W_U; u++) adj[u] = wt[u * 64u + lane];
-#if !defined(WGA_EMU) && WGA_W_U == 4
-    asm volatile("" : "+v"(adj[0]), "+v"(adj[1]), "+v"(adj[2]), "+v"(adj[3])); /* four loads, one wait, before the stage is written */
+#if WGA_W_U == 4
+    WGA_PIN4(adj[0], adj[1], adj[2], adj[3]); /* four loads, one wait, before the stage is written */
 #endif
   }
   WGA_WAVE_SYNC(); /* the table is dead: the stage may be written */
