@@ -112,7 +112,7 @@ def kernel_source_sha():
     """the row kernel's source: roofline.traffic is only valid for the kernel it was measured on"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("wga_kernels.h", "wga_kernels_k2w.h"):
+    for f in ("wga_kernels.h", "wga_kernels_k2w.h", "wga_intrin.h"):
         h.update(open(os.path.join(ROOT, "wgatools_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -187,7 +187,11 @@ def e2e_leg(tb, synth, torch, check=2):
         out = {"records": tb["n"], "ops": tb["n_ops"], "paf_text_bytes": paf_bytes,
                "fasta_bytes": int(tb["t_pool"].numel() + tb["q_pool"].numel()),
                "note": "wall time of the wgatools process, file to file under /tmp (page cache), HIP start-up included"}
-        env = dict(os.environ, WGA_TIMING="1")
+        # a profiler wrapped around bench.py (rocprofv3 --kernel-trace --stats -- python bench.py ...) stays with this process:
+        # the command line's launches of the same kernels would otherwise be counted into the timed steps' statistics
+        env = {k: v for k, v in os.environ.items()
+               if not (k.startswith("ROCPROF") or k.startswith("ROCP_") or k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE"))}
+        env["WGA_TIMING"] = "1"
         for name, argv, outp in (("stat", ["stat", "-f", "paf", paf], os.path.join(tmp, "out.tsv")),
                                  ("paf2maf", ["paf2maf", paf, "-g", t_fa, "-q", q_fa], os.path.join(tmp, "out.maf"))):
             t0 = time.perf_counter()
@@ -295,6 +299,8 @@ def main():
     ap.add_argument("--param", action="append", default=[], help="engine test knob name=value")
     ap.add_argument("--neg-frac", type=float, default=0.5)
     ap.add_argument("--m-only", action="store_true", help="variant of configs[1] with = / X merged into M ops")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group (RCCL) and run the collectives of the N > 1 "
+                    "path at world size 1 too")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file leg (the wgatools command line on the same batch)")
     ap.add_argument("--no-extras", action="store_true", help="skip the genome-sized-pool and 50-kop-record K2 measurements")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
@@ -324,8 +330,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # --force-dist: the process group and every collective of the N > 1 path also at world size 1 (so that the RCCL branches
+    # have run on a one-GPU box; the driver's N > 1 runs take them anyway)
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from wgatools_amd import engine, multigpu, pipeline, synth
@@ -334,7 +344,7 @@ def main():
         k, v = kv.split("=")
         eng.set_param(k, int(v))
     seed = 0x5747415F + 2 + rank
-    strong = args.scaling == "strong" and world > 1   # at N = 1 the global batch IS the rank's batch: nothing to shard or order
+    strong = args.scaling == "strong" and dist_on   # at N = 1 the global batch IS the rank's batch: nothing to shard or order
     if strong:
         # ONE global batch whatever N: record lengths and target names from the global seed; a rank generates the records
         # fnv1a64(target_name) % N gives it (the product's sharding rule), so the skew over targets becomes load imbalance
@@ -413,7 +423,7 @@ def main():
             # all-reduce of the global size vector gives each rank the final (input-order) offsets of its records
             sizes_global.zero_()
             sizes_global[mine_idx] = job.rec_off[1:] - job.rec_off[:-1]
-            if world > 1:
+            if dist_on:
                 dist.all_reduce(sizes_global)
             global_off = torch.cumsum(sizes_global, 0) - sizes_global   # noqa: F841  (what the writer would use)
         if evs:
@@ -422,7 +432,7 @@ def main():
         if evs:
             evs[3].record()
         eng.counts_total(job.n, job.counts, totals)          # global stat totals (88 bytes)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(totals)                          # RCCL over xGMI: 88 bytes
 
     eng.set_param("expand_alias", 1)   # warm-up launches (first touch, the library's trials) under the kernel's second name:
@@ -430,7 +440,7 @@ def main():
         step()
     torch.cuda.synchronize()
     eng.set_param("expand_alias", 0)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     # HIP events inside the library bracket the dominant kernel alone (on the launch stream)
@@ -440,13 +450,13 @@ def main():
     for k in range(args.steps):
         step(events[k])
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     nops = torch.tensor([float(job.n_ops)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(nops)
     elapsed = float(el.item())
@@ -456,12 +466,12 @@ def main():
     if not args.param:
         assert bool((job.diag == -1).all()), "kernel reported per-record errors on clean synthetic input"
 
-    per_rank_ops, imb = multigpu.imbalance(job.n_ops, dist if world > 1 else None, dev)
+    per_rank_ops, imb = multigpu.imbalance(job.n_ops, dist if dist_on else None, dev)
     # N > 1: every rank checks a few of the rows ITS timed steps wrote against the oracle (the checker leg of the line: the only
     # use bench.py makes of oracle/ besides the N = 1 cpu baseline), and the ranks agree on the verdict — an N-GPU line is
     # a real partition AND byte-verified
     ranks_checked = None
-    if world > 1 and args.check and not args.param:
+    if dist_on and args.check and not args.param:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import parity_cases as pc
@@ -587,7 +597,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 result["e2e"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 cd /tmp
 # the library would spend these three launches on its drain_min trials (64 / 32 / 16): fix the value it settles on for this shape
 export WGA_EXPAND_DRAIN_MIN=${WGA_EXPAND_DRAIN_MIN:-64}
-BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-placement-probe --check 0"
+BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-e2e --no-placement-probe --check 0"
 run() { # name counters...
   name=$1; shift
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- $BENCH > $OUT/$name.json 2> $OUT/$name.err

@@ -26,7 +26,8 @@ def check_paf2maf(cli, tmp_path, gpus, env):
     mapq = np.random.default_rng(2).integers(0, 61, 37)
     t_fa, q_fa, paf = dc.write_case(tmp_path, b, mapq)
     want = dc.expected_maf(b, mapq, t_fa, q_fa, 37)
-    for k, (g, chunk) in enumerate([(1, None)] + [(g, c) for g in gpus for c in (None, "3000", "1")]):
+    runs = [(1, None)] + [(gpus[0], c) for c in (None, "3000", "1")] + [(g, "3000") for g in gpus[1:]]
+    for k, (g, chunk) in enumerate(runs):
         e = dict(env)
         if chunk:
             e["WGA_CHUNK_BYTES"] = chunk
@@ -157,7 +158,7 @@ def check_call_paf(cli, tmp_path, gpus, env):
     outside ACGTN under a VCF row ends the run at the first such record in input order, nothing written"""
     import cli_cases as cc
     import oracle_py as orc
-    b = synth.make_paf_batch(95, 31, 220, 50_000)
+    b = synth.make_paf_batch(95, 31, 120, 30_000)
     t_fa, q_fa, paf = dc.write_case(tmp_path, b, np.zeros(31, dtype=int))
     tp, qp = b["t_pool"].tobytes(), b["q_pool"].tobytes()
     body = []

@@ -154,8 +154,12 @@ class Ranks:
         local = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = None
         on_gpu = lib_path is None
-        if self.world > 1:
+        if self.world > 1 or os.environ.get("WGA_DIST_FORCE"):   # WGA_DIST_FORCE=1: the collectives at world size 1 too
             import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29534")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
             dist.init_process_group("nccl" if on_gpu else "gloo")
             self.dist = dist
         if on_gpu:
