@@ -1,5 +1,5 @@
 /*
- * wga_kernels3.h — K15: the VCF rows of `call -f paf` (the caller behind the hot path).
+ * wga_kernels3.h — K16: the VCF rows of `call -f paf` (the caller behind the hot path).
  *
  * The reference turns every event of call_within_var_paf into one noodles-vcf record and prints it
  * (caller.rs:640-658 the <INV> row of a '-' record, :688-717 one row per column of an X op, :719-813 the
