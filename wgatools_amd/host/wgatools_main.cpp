@@ -98,7 +98,7 @@ static GpuWarm g_warm;
  * writer.  Replaces "download everything into one std::string, then fwrite" (r01: paf2maf 1.8 s for 3 GB of MAF). */
 struct DevStreamer {
   static const size_t kPiece = (size_t)16 << 20;
-  static const int kBufs = 12;
+  static const int kBufs = 40; /* at most; a run takes what its writers need (below) */
   wga_ctx* ctx;
   void* buf[kBufs];
   explicit DevStreamer(wga_ctx* c) : ctx(c) {
@@ -111,7 +111,17 @@ struct DevStreamer {
   void run(Output& out, const uint8_t* d_src, size_t n) {
     if (n == 0) return;
     const size_t np = (n + kPiece - 1) / kPiece;
-    const int nbuf = (int)std::min<size_t>((size_t)kBufs, np + 1); /* pinned memory is slow to get: only what this run uses */
+    /* writers: memcpy into the page cache is what bounds a large output (one thread moves 2-3 GB/s), the copy engine delivers
+     * far more; WGA_WRITE_THREADS overrides */
+    int nthreads = 1;
+    {
+      uint64_t pos_probe = 0;
+      if (out.plain_fd(&pos_probe) >= 0) {
+        nthreads = n >= ((size_t)1 << 30) ? 16 : 8;
+        if (const char* e = getenv("WGA_WRITE_THREADS")) nthreads = std::max(1, std::min(32, atoi(e)));
+      }
+    }
+    const int nbuf = (int)std::min<size_t>((size_t)std::min(kBufs, nthreads + 4), np + 1); /* pinned memory is slow to get: only what this run uses */
     for (int k = 0; k < nbuf; k++)
       if (!buf[k] && wga_host_alloc(ctx, kPiece, &buf[k])) fail(std::string("GPU engine: ") + wga_last_error());
     uint64_t pos0 = 0;
@@ -173,7 +183,6 @@ struct DevStreamer {
         cv.notify_all();
       }
     };
-    const int nthreads = fd >= 0 ? 8 : 1;
     for (int t = 0; t < nthreads; t++) writers.emplace_back(writer);
     /* the filler: issue the copy of a piece into a free buffer, wait for it, hand it over */
     for (size_t p = 0; p < np && !failed; p++) {
