@@ -117,7 +117,7 @@ struct DevStreamer {
     {
       uint64_t pos_probe = 0;
       if (out.plain_fd(&pos_probe) >= 0) {
-        nthreads = n >= ((size_t)1 << 30) ? 16 : 8;
+        nthreads = 8; /* 16 / 24 / 32 measured slower at 15 GB (scripts/gpu_write_threads.py: 2.6 / 2.9 / 3.0 s against 2.5) */
         if (const char* e = getenv("WGA_WRITE_THREADS")) nthreads = std::max(1, std::min(32, atoi(e)));
       }
     }
