@@ -1,5 +1,5 @@
 #!/bin/bash
-# same box: builds of the paf2maf row kernel.  Each argument is "<variant>|<WGA_EXTRA_FLAGS>" (variant 0 = v1, 1 = planned)
+# same box: builds of the paf2maf row kernel.  Each argument is "<variant>|<WGA_EXTRA_FLAGS>" (variant 0 = v1, 2 = the window kernel)
 # env: CFGS (bench configurations, ';'-separated), REPS
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 IFS=';' read -ra CF <<< "${CFGS:-;--records 10000 --mean-ops 50000;--records 1000000 --mean-ops 500;--pool-mb 1000}"

@@ -4,7 +4,7 @@ placement of its output buffer (profiles/r02_k2_experiments.md, section 7), so b
   locally:  python scripts/gpu_k2_same_buffers.py build NAME=FLAGS ...     (build_variants/libwgahip_NAME.so; "base=" = no flags)
   GPU box:  python scripts/gpu_k2_same_buffers.py run NAME[:param=val,...] ...  [--shape records,mean_ops,pool_mb]...
 
-Each candidate = a library build plus context parameters (e.g. expand_variant=1).  Every round times every candidate
+Each candidate = a library build plus context parameters (e.g. expand_variant=2).  Every round times every candidate
 (6 launches each, library HIP events), rounds alternate the order; the table gives mean / min per candidate."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
