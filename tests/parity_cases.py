@@ -398,6 +398,25 @@ def text_any(ops_slice):
     return "cg:Z:" + "".join("%d%s" % (w >> 4, chars[w & 15]) for w in ops_slice.tolist())
 
 
+def check_pafcov_long_ops(eng):
+    """K5: a window (8 192 counters) replays only the lanes of a record segment whose ops can mark inside it.  Ops far longer
+    than a window (a segment across 60+ windows, windows without any mark inside), ops ending exactly on window borders,
+    zero-length ops, a record that runs past its target's end, two targets back to back in the coverage array"""
+    W = 8192
+    mk = lambda p: [(int(ln) << 4) | int(c) for c, ln in p]
+    recs = [mk([(7, 300000), (2, 5), (0, 200001), (8, 1), (1, 7), (7, 9)]),
+            mk([(7, W), (7, W), (2, W), (7, 1), (8, W - 1), (7, 0), (0, 3 * W)]),
+            mk([(7, 3), (1, 2)] * 700 + [(7, 100000)] + [(8, 1), (7, 2)] * 300),
+            mk([(7, 5000), (3, 40000), (7, 5000), (2, 70000), (7, 20000)]),      # N and D move without counting
+            mk([(7, 60000)] * 3)]                                                   # runs past the end of its target
+    ops = np.array([o for r in recs for o in r], dtype=np.uint32)
+    off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+    n = len(recs)
+    b = dict(ops=ops, op_off=off, strand_neg=np.zeros(n, dtype=np.uint8))
+    check_pafcov(eng, b, [0, 0, 1, 1, 1], [100, 8192 * 3 - 1, 0, 50000, 150000], [600000, 250000])
+    check_pafcov(eng, b, [0, 0, 1, 1, 1], [100, 8192 * 3 - 1, 0, 50000, 150000], [600000, 250000], split=True)
+
+
 def check_pafcov(eng, b, target_id, t_start, target_len, align=4, split=False):
     n = len(b["strand_neg"])
     nt = len(target_len)

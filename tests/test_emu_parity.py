@@ -196,6 +196,10 @@ def test_pafcov_long_target(emu):
     pc.check_pafcov(emu, b, [0, 0, 1], [10, 5000, 0], [40000, 9000])
 
 
+def test_pafcov_ops_across_many_windows(emu):
+    pc.check_pafcov_long_ops(emu)
+
+
 @pytest.mark.parametrize("base", [0, 1])
 @pytest.mark.parametrize("seed,n,mean", [(1, 20, 60), (2, 150, 4), (3, 3, 2600)])
 def test_pafpseudo(emu, base, seed, n, mean):

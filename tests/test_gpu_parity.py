@@ -412,6 +412,10 @@ def test_device_tokeniser(gpu):
     pc.check_tokeniser(gpu, texts + [b"3M", b""] + texts[:3])
 
 
+def test_pafcov_ops_across_many_windows(gpu):
+    pc.check_pafcov_long_ops(gpu)
+
+
 def test_pafcov_format(gpu):
     rng = np.random.default_rng(3)
     pc.check_pafcov_format(gpu, b"chr1", [0, 1, 9, 10, 99, 100, 2147483647, 12345], 0)

@@ -126,10 +126,18 @@ __global__ __launch_bounds__(256) void k_class_tiles(const u32* __restrict__ ops
 
 struct wga_cov_piece {
   u32 g;       /* tile */
-  u32 ab;      /* first op | end op << 16, tile-relative (<= 1024) */
-  u64 pos0;    /* coverage index (cov_off + target position) of the segment's first op */
+  u32 ab;      /* first op | end op << 16, tile-relative (<= 1024): the ops of the record segment whose marks can lie in the
+                  window the piece is listed under (whole lanes of 16 ops) */
+  u64 pos0;    /* coverage index (cov_off + target position) in front of op `first` */
   u64 limit;   /* coverage index one past the target's last counter */
 };
+__device__ __forceinline__ u64 cov_incl_scan_u64(u64 v, u32 lane) {
+  for (u32 d = 1; d < 64; d <<= 1) {
+    const u64 t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
 
 /* 16 consecutive ops per lane of tile g, zero-filled beyond the stream */
 __device__ __forceinline__ void cov_load_ops(const u32* __restrict__ ops, u64 tile_start, u32 nt, u32 lane,
@@ -188,7 +196,10 @@ __global__ __launch_bounds__(256) void k_cov_pieces(
     const u64 rs = op_off[r];
     const u64 seg_end = re < tile_end ? re : tile_end;
     const u32 a = (u32)(cur - tile_start), b = (u32)(seg_end - tile_start);
-    const u64 span = wave_sum_u64(cov_lane_moves(w, lane, a, b));
+    /* where every lane's 16 ops start and end on the target (monotone over the lanes; lanes outside [a, b) are empty) */
+    const u64 mv = cov_lane_moves(w, lane, a, b);
+    const u64 inc = cov_incl_scan_u64(mv, lane);
+    const u64 span = WGA_UNI64(__shfl(inc, 63));
     u64 base = 0;
     if (rs < tile_start) { /* wave-uniform: target advance of the record before this tile */
       const u64 g0 = rs / WGA_TILE;
@@ -205,15 +216,24 @@ __global__ __launch_bounds__(256) void k_cov_pieces(
     if (pos < clen) { /* marks lie in [pos, min(pos + span, clen - 1)] */
       const u64 last = pos + span < clen ? pos + span : clen - 1;
       const u64 wlo = (coff + pos) >> WGA_COV_WIN_SHIFT, whi = (coff + last) >> WGA_COV_WIN_SHIFT;
-      for (u64 wi = wlo + lane; wi <= whi; wi += 64) {
-        const u32 slot = atomicAdd(&win_cnt[wi], 1u);
-        if (FILL) {
-          wga_cov_piece pc;
-          pc.g = (u32)g;
-          pc.ab = a | (b << 16);
-          pc.pos0 = coff + pos;
-          pc.limit = coff + clen;
-          pieces[win_off[wi] + slot] = pc;
+      const u64 l_end = coff + pos + inc, l_start = l_end - mv; /* this lane's ops mark inside [l_start, l_end] */
+      for (u64 wi = wlo; wi <= whi; wi++) { /* wave-uniform: a window replays only the lanes that can mark inside it */
+        const u64 lo = wi << WGA_COV_WIN_SHIFT, hi = lo + (u64)(WGA_COV_WIN - 1u);
+        const u64 m_ge = __ballot(l_end >= lo), m_le = __ballot(l_start <= hi);
+        const u32 l1 = m_ge ? (u32)__ffsll((unsigned long long)m_ge) - 1u : 63u;
+        const u32 l2 = m_le ? 63u - (u32)__builtin_clzll(m_le) : 0u;
+        const u32 a2 = a > 16u * l1 ? a : 16u * l1, b2 = b < 16u * (l2 + 1u) ? b : 16u * (l2 + 1u);
+        const u64 pos_a2 = WGA_UNI64(__shfl(l_start, (int)l1));
+        if (lane == 0) {
+          const u32 slot = atomicAdd(&win_cnt[wi], 1u);
+          if (FILL) {
+            wga_cov_piece pc;
+            pc.g = (u32)g;
+            pc.ab = a2 | (b2 << 16);
+            pc.pos0 = pos_a2;
+            pc.limit = coff + clen;
+            pieces[win_off[wi] + slot] = pc;
+          }
         }
       }
     }
@@ -242,34 +262,50 @@ __global__ __launch_bounds__(256) void k_cov_windows(const u32* __restrict__ ops
     const wga_cov_piece pc = pieces[p];
     const u64 tile_start = (u64)pc.g * WGA_TILE;
     const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
+    const u32 nt = (u32)(tile_end - tile_start);
     const u32 a = pc.ab & 0xFFFFu, b = pc.ab >> 16;
-    u32 w[16];
-    cov_load_ops(ops, tile_start, (u32)(tile_end - tile_start), lane, w);
-    const u64 mv = cov_lane_moves(w, lane, a, b);
-    u64 inc = mv;
-    for (u32 d = 1; d < 64; d <<= 1) {
-      const u64 t = __shfl_up(inc, d);
-      if (lane >= d) inc += t;
-    }
-    u64 pos = pc.pos0 + (inc - mv);
+    u64 pos_base = pc.pos0;
+    /* the piece's ops, 4 consecutive ones per lane and 256 per step (a is a multiple of 16 or the segment's first op) */
+    for (u32 s0 = a & ~3u; s0 < b; s0 += 256u) {
+      const u32 i0 = s0 + lane * 4u;
+      u32 w[4] = {0u, 0u, 0u, 0u};
+      if (i0 + 3u < nt) {
+        const u32x4_a16 v = *(const u32x4_a16*)(ops + tile_start + i0);
+        w[0] = v[0], w[1] = v[1], w[2] = v[2], w[3] = v[3];
+      } else {
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-      const u32 idx = lane * 16u + (u32)e;
-      if (idx - a < b - a) {
-        const u32 code = w[e] & 15u;
-        const u64 len = w[e] >> 4;
-        const u32 cls = op_class(code);
-        if (code == WGA_OP_M || code == WGA_OP_EQ) {
-          if (pos < pc.limit) {
-            if (pos - w0 < (u64)WGA_COV_WIN) atomicAdd(&s_win[pos - w0], 1);
-            const u64 pe = pos + len;
-            if (pe < pc.limit && pe - w0 < (u64)WGA_COV_WIN) atomicAdd(&s_win[pe - w0], -1);
+        for (int e = 0; e < 4; e++) w[e] = i0 + (u32)e < nt ? ops[tile_start + i0 + e] : 0u;
+      }
+      u64 mv = 0;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const u32 idx = i0 + (u32)e;
+        const u32 cls = op_class(w[e] & 15u);
+        const bool moves = cls == CLS_MX || cls == CLS_D || cls == CLS_O;
+        mv += (idx - a < b - a && moves) ? (u64)(w[e] >> 4) : 0ull;
+      }
+      const u64 inc = cov_incl_scan_u64(mv, lane);
+      u64 pos = pos_base + (inc - mv);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const u32 idx = i0 + (u32)e;
+        if (idx - a < b - a) {
+          const u32 code = w[e] & 15u;
+          const u64 len = w[e] >> 4;
+          const u32 cls = op_class(code);
+          if (code == WGA_OP_M || code == WGA_OP_EQ) {
+            if (pos < pc.limit) {
+              if (pos - w0 < (u64)WGA_COV_WIN) atomicAdd(&s_win[pos - w0], 1);
+              const u64 pe = pos + len;
+              if (pe < pc.limit && pe - w0 < (u64)WGA_COV_WIN) atomicAdd(&s_win[pe - w0], -1);
+            }
+            pos += len;
+          } else if (cls != CLS_I && cls != CLS_S) {
+            pos += len;
           }
-          pos += len;
-        } else if (cls != CLS_I && cls != CLS_S) {
-          pos += len;
         }
       }
+      pos_base += WGA_UNI64(__shfl(inc, 63));
     }
   }
   __syncthreads();
