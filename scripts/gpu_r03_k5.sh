@@ -1,0 +1,11 @@
+#!/bin/bash
+# K5 after the sub-range replay: parity, configs[1] batch rate, scaling of one call, configs[3] at its stated size
+TAG=${1:-r03n}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "cov" -s > $OUT/pytest_cov.log 2>&1; echo "pytest rc=$?"; grep -E "config|passed|failed" $OUT/pytest_cov.log | tail -6
+timeout 600 python scripts/gpu_other_kernels.py 100000 5000 2>&1 | grep "^K5" | tee $OUT/k5_5k.log
+timeout 600 python scripts/gpu_k5_scaling.py 1 2 4 2>&1 | grep -v amdgpu | tee $OUT/k5_scaling.log

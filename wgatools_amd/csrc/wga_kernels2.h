@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_class_tiles(const u32* __restrict__ ops
     }
     u64 S[5];
 #pragma unroll
-    for (int c = 0; c < 5; c++) S[c] = wave_sum_u64((u64)s[c]);
+    for (int c = 0; c < 5; c++) S[c] = wave_sum_u32_wide(s[c]); /* DPP scans on 16-bit halves: exact (a lane's sum < 2^32) */
     if (rec_sums && lane == 0) {
       u64* f = (u64*)(rec_sums + r);
       if (rs >= tile_start && re <= tile_end) {
@@ -247,6 +247,22 @@ struct ScanU32 {
   __device__ u64 operator()(u32 i) const { return (u64)in[i]; }
 };
 
+/* the four ops of this lane in the first 256-op step of a piece */
+__device__ __forceinline__ void cov_step_ops(const u32* __restrict__ ops, u64 n_ops, const wga_cov_piece& pc, u32 lane,
+                                             u32 (&w)[4]) {
+  const u64 tile_start = (u64)pc.g * WGA_TILE;
+  const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
+  const u32 nt = (u32)(tile_end - tile_start);
+  const u32 i0 = ((pc.ab & 0xFFFFu) & ~3u) + lane * 4u;
+  if (i0 + 3u < nt) {
+    const u32x4_a16 v = *(const u32x4_a16*)(ops + tile_start + i0);
+    w[0] = v[0], w[1] = v[1], w[2] = v[2], w[3] = v[3];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; e++) w[e] = i0 + (u32)e < nt ? ops[tile_start + i0 + e] : 0u;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_cov_windows(const u32* __restrict__ ops, u64 n_ops,
                                                      const wga_cov_piece* __restrict__ pieces,
                                                      const u64* __restrict__ win_off, int* cov) {
@@ -258,8 +274,18 @@ __global__ __launch_bounds__(256) void k_cov_windows(const u32* __restrict__ ops
   for (u32 k = tid; k < WGA_COV_WIN; k += WGA_BLOCK) s_win[k] = 0;
   __syncthreads();
   const u64 w0 = wi << WGA_COV_WIN_SHIFT;
-  for (u64 p = p_lo + wave; p < p_hi; p += 4) {
-    const wga_cov_piece pc = pieces[p];
+  /* A wave's pieces one after the other; two dependent loads stand in front of every piece (its descriptor, then its ops), so
+   * the descriptor is fetched two pieces ahead and the first step's ops one piece ahead, behind the work on the current one. */
+  const u64 p0 = p_lo + wave;
+  wga_cov_piece pc, pc1, pc2;
+  pc = pc1 = pc2 = pieces[p0 < p_hi ? p0 : p_lo];
+  if (p0 + 4 < p_hi) pc1 = pieces[p0 + 4];
+  u32 wn[4];
+  cov_step_ops(ops, n_ops, pc, lane, wn);
+  for (u64 p = p0; p < p_hi; p += 4) {
+    if (p + 8 < p_hi) pc2 = pieces[p + 8];
+    u32 w[4] = {wn[0], wn[1], wn[2], wn[3]};
+    if (p + 4 < p_hi) cov_step_ops(ops, n_ops, pc1, lane, wn);
     const u64 tile_start = (u64)pc.g * WGA_TILE;
     const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
     const u32 nt = (u32)(tile_end - tile_start);
@@ -268,13 +294,14 @@ __global__ __launch_bounds__(256) void k_cov_windows(const u32* __restrict__ ops
     /* the piece's ops, 4 consecutive ones per lane and 256 per step (a is a multiple of 16 or the segment's first op) */
     for (u32 s0 = a & ~3u; s0 < b; s0 += 256u) {
       const u32 i0 = s0 + lane * 4u;
-      u32 w[4] = {0u, 0u, 0u, 0u};
-      if (i0 + 3u < nt) {
-        const u32x4_a16 v = *(const u32x4_a16*)(ops + tile_start + i0);
-        w[0] = v[0], w[1] = v[1], w[2] = v[2], w[3] = v[3];
-      } else {
+      if (s0 != (a & ~3u)) { /* wave-uniform: the first step's ops came with the piece */
+        if (i0 + 3u < nt) {
+          const u32x4_a16 v = *(const u32x4_a16*)(ops + tile_start + i0);
+          w[0] = v[0], w[1] = v[1], w[2] = v[2], w[3] = v[3];
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; e++) w[e] = i0 + (u32)e < nt ? ops[tile_start + i0 + e] : 0u;
+          for (int e = 0; e < 4; e++) w[e] = i0 + (u32)e < nt ? ops[tile_start + i0 + e] : 0u;
+        }
       }
       u64 mv = 0;
 #pragma unroll
@@ -307,11 +334,21 @@ __global__ __launch_bounds__(256) void k_cov_windows(const u32* __restrict__ ops
       }
       pos_base += WGA_UNI64(__shfl(inc, 63));
     }
+    pc = pc1;
+    pc1 = pc2;
   }
   __syncthreads();
-  for (u32 k = tid; k < WGA_COV_WIN; k += WGA_BLOCK) {
-    const int v = s_win[k];
-    if (v) cov[w0 + k] += v; /* this block is the window's only writer */
+  /* the window goes to memory: this block is its only writer.  Eight counters per thread and round, their loads in flight
+   * together (one round trip per round instead of one per counter); counters without a mark are not touched. */
+  for (u32 k0 = tid; k0 < WGA_COV_WIN; k0 += 8u * WGA_BLOCK) {
+    int v[8], x[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = s_win[k0 + (u32)j * WGA_BLOCK];
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = v[j] ? cov[w0 + k0 + (u32)j * WGA_BLOCK] : 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (v[j]) cov[w0 + k0 + (u32)j * WGA_BLOCK] = x[j] + v[j];
   }
 }
 
