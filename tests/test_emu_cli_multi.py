@@ -35,5 +35,17 @@ def test_call_paf_rows_meet_in_input_order(cli, tmp_path):
     mc.check_call_paf(cli, tmp_path, (2, 3), ENV)
 
 
+@pytest.mark.parametrize("gpus", ["2", "3"])
+def test_pafpseudo_targets_per_device(cli, tmp_path, monkeypatch, gpus):
+    """pafpseudo under WGA_GPUS (= --gpus): the single-device cases as they stand — rows against the oracle in both modes,
+    and the first error in the reference's processing order whichever device owns the record"""
+    import cli_cases as cc
+    monkeypatch.setenv("WGA_EMU_DEVICES", "3")
+    monkeypatch.setenv("WGA_GPUS", gpus)
+    for base in (False, True):
+        cc.test_pafpseudo_end_to_end(cli, tmp_path, base)
+    cc.test_pafpseudo_errors_follow_the_walk(cli, tmp_path, "device")
+
+
 def test_more_devices_than_visible(cli):
     mc.check_too_many(cli, ENV, 3)

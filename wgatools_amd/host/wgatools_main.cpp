@@ -2533,44 +2533,66 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
     if (!S_ISDIR(st.st_mode)) fail("Path `" + outdir + "` is not a dir");
     if (!rewrite) fail("File `" + outdir + "` already exists, please add `-r` to rewrite it.");
   }
-  Dev d;
+  /* --gpus N: a target's records live on device fnv1a64(target_name) % N (the reference already works target by target,
+   * pseudomaf.rs:62-72); every device tokenises, sums and fills its records, the walk and every check run on the host in the
+   * reference's processing order, so the first error is the same whatever N is */
+  const int ngpu = g_gpus > 1 ? g_gpus : 1;
+  std::vector<std::unique_ptr<Dev>> devs;
+  for (int g = 0; g < ngpu; g++) devs.emplace_back(new Dev(g));
+  Dev& d = *devs[0];
   PafInput pin = load_paf(d, input, false);
   const std::vector<PafRecord>& recs = pin.recs;
-  DevFasta fa;
   const bool base = fasta != nullptr;
-  if (base) {
-    d.init();
-    fa.load(d, *fasta);
-  }
-  /* every record's CIGAR is tokenised on the device, in file order; a record's tag / tokeniser error only counts
-   * when the walk below reaches that record (the reference parses a CIGAR when it processes the record) */
+  std::vector<DevFasta> fas(ngpu);
+  DevFasta& fa = fas[0]; /* the index (names -> pool offsets) is the same on every device */
   const uint32_t n_all = (uint32_t)recs.size();
-  CigarTexts cigars;
-  wga_cigar_batch cb;
-  cb.n = 0;
-  std::vector<wga_tok_err> terrs;
   std::vector<uint8_t> has_tag(n_all, 1);
-  if (n_all) {
-    d.init();
-    /* records without a tag are given an empty span so that the batch keeps file order */
-    if (pin.on_device) {
-      for (uint32_t i = 0; i < n_all; i++)
-        if (pin.cg_beg[i] == WGA_NONE) {
-          has_tag[i] = 0;
-          pin.cg_beg[i] = pin.cg_end[i] = 0;
-        }
-    } else {
-      for (uint32_t i = 0; i < n_all; i++) {
-        int err = 0;
-        (void)paf_cigar_string(recs[i], &err);
-        if (err) {
-          has_tag[i] = 0;
-          pin.recs[i].tags.push_back("cg:Z:"); /* placeholder: tokenises to the empty-CIGAR error, never used */
-        }
+  /* records without a tag are given an empty span so that a device's batch keeps file order */
+  if (pin.on_device) {
+    for (uint32_t i = 0; i < n_all; i++)
+      if (pin.cg_beg[i] == WGA_NONE) {
+        has_tag[i] = 0;
+        pin.cg_beg[i] = pin.cg_end[i] = 0;
+      }
+  } else {
+    for (uint32_t i = 0; i < n_all; i++) {
+      int err = 0;
+      (void)paf_cigar_string(recs[i], &err);
+      if (err) {
+        has_tag[i] = 0;
+        pin.recs[i].tags.push_back("cg:Z:"); /* placeholder: tokenises to the empty-CIGAR error, never used */
       }
     }
-    (void)device_tokenise(d, pin, 0, n_all, cigars, &cb, &terrs);
   }
+  std::vector<std::vector<size_t>> mine(ngpu);
+  std::vector<uint32_t> owner(n_all, 0), at(n_all, 0); /* record i = record at[i] of device owner[i] */
+  for (uint32_t i = 0; i < n_all; i++) {
+    const int g = ngpu > 1 ? (int)(fnv1a64(recs[i].target_name) % (uint64_t)ngpu) : 0;
+    owner[i] = (uint32_t)g;
+    at[i] = (uint32_t)mine[g].size();
+    mine[g].push_back(i);
+  }
+  /* every device: pools, its records' CIGARs tokenised in file order; a record's tag / tokeniser error only counts when
+   * the walk below reaches that record (the reference parses a CIGAR when it processes the record) */
+  std::vector<CigarTexts> cigars(ngpu);
+  std::vector<wga_cigar_batch> cbs(ngpu);
+  std::vector<std::vector<wga_tok_err>> terrs(ngpu);
+  std::string text16;
+  if (pin.on_device && ngpu > 1) text16 = pin.text + std::string(16, '\0');
+  on_devices(ngpu, [&](int g) {
+    Dev& dg = *devs[g];
+    cbs[g].n = 0;
+    if (base) {
+      dg.init();
+      fas[g].load(dg, *fasta);
+    }
+    if (mine[g].empty()) return;
+    dg.init();
+    const uint8_t* d_text = nullptr;
+    if (pin.on_device) d_text = g == 0 ? pin.d_text : dg.upload((const uint8_t*)text16.data(), text16.size());
+    (void)device_tokenise(dg, pin, 0, (uint32_t)mine[g].size(), cigars[g], &cbs[g], &terrs[g], ngpu > 1 ? mine[g].data() : nullptr,
+                          d_text);
+  });
   /* 1. group by target (:25-42), then by query with sorted insertion (:86-95) */
   std::vector<PseudoTarget> targets;
   std::unordered_map<std::string, size_t> tindex;
@@ -2625,7 +2647,8 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
         uint64_t qo = 0, ql = 0;
         if (base) fa.fetch(q.name, r.query_start, r.query_end - 1, &qo, &ql); /* :222-225 */
         if (!has_tag[i]) fail("CIGAR start tag not found"); /* errors.rs:57 */
-        if (terrs[i].err) fail(cigar_error_message(terrs[i].err, cigars[i], (size_t)terrs[i].tok_off, terrs[i].tok_len));
+        const wga_tok_err& te = terrs[owner[i]][at[i]];
+        if (te.err) fail(cigar_error_message(te.err, cigars[owner[i]][at[i]], (size_t)te.tok_off, te.tok_len));
         q_off[i] = qo;
         q_len[i] = ql;
         skip[i] = overlap;
@@ -2637,15 +2660,22 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
       q.tail = target_size - last_target_end;
     }
   }
-  /* 3. GPU: class sums -> segment lengths -> fill; the batch is the whole file in file order, dropped records write nothing */
-  const uint32_t n = n_all;
-  std::vector<uint64_t> seg_len(n, 0), dst_off(n + 1, 0);
-  std::string segs;
-  if (n) {
-    auto* d_sums = (wga_class_sums*)d.alloc((size_t)n * sizeof(wga_class_sums));
-    d.check(wga_cigar_class_sums(d.ctx, &cb, d_sums));
-    std::vector<wga_class_sums> sums(n);
-    d.download(sums.data(), d_sums, n);
+  /* 3. GPU: class sums -> segment lengths -> fill; a device's batch is its records in file order, dropped records write nothing */
+  std::vector<uint64_t> seg_len(n_all, 0), dst_off(n_all, 0); /* dst_off: inside the owner's segment text */
+  std::vector<std::string> segs(ngpu);
+  if (n_all) {
+    std::vector<wga_class_sums> sums(n_all);
+    std::vector<wga_class_sums*> d_sums(ngpu, nullptr);
+    on_devices(ngpu, [&](int g) {
+      const uint32_t n = cbs[g].n;
+      if (!n) return;
+      Dev& dg = *devs[g];
+      d_sums[g] = (wga_class_sums*)dg.alloc((size_t)n * sizeof(wga_class_sums));
+      dg.check(wga_cigar_class_sums(dg.ctx, &cbs[g], d_sums[g]));
+      std::vector<wga_class_sums> part(n);
+      dg.download(part.data(), d_sums[g], n);
+      for (uint32_t k = 0; k < n; k++) sums[mine[g][k]] = part[k];
+    });
     /* in the order the reference processes the records (an error of an earlier one wins) */
     for (const auto& t : targets)
       for (const auto& q : t.queries)
@@ -2656,25 +2686,38 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
           if (skip[k] > len) fail("panic: String::drain range out of bounds (pseudomaf.rs:191)");
           seg_len[k] = len - skip[k];
         }
-    for (uint32_t k = 0; k < n; k++) dst_off[k + 1] = dst_off[k] + seg_len[k];
-    auto* d_out = (uint8_t*)d.alloc(dst_off[n] + 64);
-    auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
-    uint8_t* d_pool = base ? fa.d_pool : nullptr;
-    d.check(wga_pafpseudo_fill(d.ctx, &cb, base ? 1 : 0, d_pool, fa.bytes, base ? d.upload(q_off) : nullptr,
-                               base ? d.upload(q_len) : nullptr, d.upload(skip), d_out, d.upload(dst_off), d_diag));
-    std::vector<wga_rec_diag> diag(n);
-    d.download(diag.data(), d_diag, n);
+    std::vector<std::vector<wga_rec_diag>> diag(ngpu);
+    on_devices(ngpu, [&](int g) {
+      const uint32_t n = cbs[g].n;
+      if (!n) return;
+      Dev& dg = *devs[g];
+      std::vector<uint64_t> qo(n), ql(n), sk(n), doff(n + 1, 0);
+      for (uint32_t k = 0; k < n; k++) {
+        const size_t i = mine[g][k];
+        qo[k] = q_off[i], ql[k] = q_len[i], sk[k] = skip[i];
+        dst_off[i] = doff[k];
+        doff[k + 1] = doff[k] + seg_len[i];
+      }
+      auto* d_out = (uint8_t*)dg.alloc(doff[n] + 64);
+      auto* d_diag = (wga_rec_diag*)dg.alloc((size_t)n * sizeof(wga_rec_diag));
+      uint8_t* d_pool = base ? fas[g].d_pool : nullptr;
+      dg.check(wga_pafpseudo_fill(dg.ctx, &cbs[g], base ? 1 : 0, d_pool, fas[g].bytes, base ? dg.upload(qo) : nullptr,
+                                  base ? dg.upload(ql) : nullptr, dg.upload(sk), d_out, dg.upload(doff), d_diag));
+      diag[g].resize(n);
+      dg.download(diag[g].data(), d_diag, n);
+      segs[g].resize(doff[n]);
+      if (doff[n]) dg.download((uint8_t*)segs[g].data(), d_out, doff[n]);
+    });
     for (const auto& t : targets)
       for (const auto& q : t.queries)
         for (const auto& sg : q.segs) {
           const size_t k = sg.rec;
-          if (diag[k].bad_base_pos != WGA_NONE)
-            fail(std::string("Invalid Base: `") + fa.at(d, q_off[k] + q_len[k] - 1 - diag[k].bad_base_pos) + "`");
-          if (diag[k].panic_op_idx != WGA_NONE)
+          const wga_rec_diag& dk = diag[owner[k]][at[k]];
+          if (dk.bad_base_pos != WGA_NONE)
+            fail(std::string("Invalid Base: `") + fas[owner[k]].at(*devs[owner[k]], q_off[k] + q_len[k] - 1 - dk.bad_base_pos) + "`");
+          if (dk.panic_op_idx != WGA_NONE)
             fail("panic: String::drain / insert_str beyond the end of the query sequence (cigar.rs:772,779)");
         }
-    segs.resize(dst_off[n]);
-    if (dst_off[n]) d.download((uint8_t*)segs.data(), d_out, dst_off[n]);
   }
   /* 4. one file per target (:62-72, :98-209) */
   for (const auto& t : targets) {
@@ -2704,7 +2747,7 @@ int cmd_pafpseudo(const std::string* input, const std::string& outdir, bool rewr
       text.push_back('\t');
       for (const auto& sg : q.segs) {
         text.append(sg.gap, '-');
-        text.append(segs, dst_off[sg.rec], seg_len[sg.rec]);
+        text.append(segs[owner[sg.rec]], dst_off[sg.rec], seg_len[sg.rec]);
       }
       text.append(q.tail, '-');
       text.push_back('\n');
@@ -3332,7 +3375,7 @@ int main(int argc, char** argv) {
         (void)val("--threads");
       else if (a == "--spread")
         g_spread = true;
-      else if (a == "--gpus") { /* ours: shard the PAF commands' records over N devices (paf2maf, stat -f paf, pafcov) */
+      else if (a == "--gpus") { /* ours: shard the PAF commands' records over N devices (paf2maf, stat -f paf, pafcov, pafpseudo, call -f paf) */
         const std::string v = val("--gpus");
         char* end = nullptr;
         const long n = strtol(v.c_str(), &end, 10);
@@ -3355,6 +3398,11 @@ int main(int argc, char** argv) {
       usage();
       return 2;
     }
+    if (g_gpus == 1) /* WGA_GPUS=N: the default of --gpus (a site-wide setting; the tests run whole suites under it) */
+      if (const char* e = getenv("WGA_GPUS")) {
+        const int n = atoi(e);
+        if (n >= 1 && n <= 64) g_gpus = n;
+      }
     if (g_gpus > 1 && g_gpus > wga_device_count())
       fail("--gpus " + std::to_string(g_gpus) + ": only " + std::to_string(wga_device_count()) + " device(s) visible");
     if (cmd.compare(0, 5, "__fmt") != 0) g_warm.start(); /* the HIP runtime comes up while the input is opened and read */
