@@ -47,5 +47,22 @@ def test_pafpseudo_targets_per_device(cli, tmp_path, monkeypatch, gpus):
     cc.test_pafpseudo_errors_follow_the_walk(cli, tmp_path, "device")
 
 
+@pytest.mark.parametrize("gpus", ["2", "3"])
+def test_maf_commands_blocks_per_device(cli, tmp_path, monkeypatch, gpus):
+    """`stat` and `call` on MAF under WGA_GPUS: a piece's blocks are dealt out in contiguous ranges, device 0 reads the rows
+    in place, the others a gathered copy; the single-device cases as they stand (fixture TSV, README golden VCF, synthetic
+    blocks against the oracle, a 90 000-column block in pieces, streaming pieces)"""
+    import cli_cases as cc
+    monkeypatch.setenv("WGA_EMU_DEVICES", "3")
+    monkeypatch.setenv("WGA_GPUS", gpus)
+    cc.test_stat_maf_fixture(cli)
+    cc.test_call_readme_golden(cli)
+    cc.test_call_synthetic_blocks(cli, tmp_path, True, False, 3, 64)
+    cc.test_call_query_selection(cli, tmp_path)
+    if gpus == "2":
+        cc.test_call_and_maf2paf_on_a_long_block(cli, tmp_path)
+        cc.test_maf_streaming_pieces_give_the_same_bytes(cli, tmp_path)
+
+
 def test_more_devices_than_visible(cli):
     mc.check_too_many(cli, ENV, 3)

@@ -1303,6 +1303,42 @@ std::vector<const MafRecord*> all_records(const std::vector<MafRecord>& recs) {
   for (const auto& r : recs) v.push_back(&r);
   return v;
 }
+/* --gpus N for the MAF commands: blocks are independent, so the selected blocks of a piece are dealt out in N contiguous
+ * ranges; device 0 reads the rows where the piece was uploaded, the others get a gathered copy of their range's rows.
+ * fn(g, dev, rows, lo, count) runs on one thread per device; results are merged by the caller in block order. */
+struct MafDevices {
+  Dev& d0;
+  std::vector<std::unique_ptr<Dev>> extra;
+  explicit MafDevices(Dev& first) : d0(first) {
+    for (int g = 1; g < g_gpus; g++) extra.emplace_back(new Dev(g));
+  }
+  int count() const { return 1 + (int)extra.size(); }
+  Dev& dev(int g) { return g == 0 ? d0 : *extra[g - 1]; }
+  void release_all() {
+    if (d0.ctx) d0.release_all();
+    for (auto& e : extra)
+      if (e->ctx) e->release_all(); /* a device that got no block of this piece was never started */
+  }
+  void run(const MafInput& in, const std::vector<const MafRecord*>& recs, bool cols_target,
+           const std::function<void(int, Dev&, const MafRows&, uint32_t, uint32_t)>& fn) {
+    const uint32_t n = (uint32_t)recs.size();
+    const int ng = count();
+    if (ng == 1) {
+      MafRows p = device_rows(d0, in, recs, cols_target);
+      fn(0, d0, p, 0, n);
+      return;
+    }
+    on_devices(ng, [&](int g) {
+      const uint32_t lo = (uint32_t)((uint64_t)n * g / ng), hi = (uint32_t)((uint64_t)n * (g + 1) / ng);
+      if (lo == hi) return;
+      std::vector<const MafRecord*> part(recs.begin() + lo, recs.begin() + hi);
+      MafInput host_view; /* rows gathered from the host copy of the text */
+      MafRows p = device_rows(dev(g), g == 0 ? in : host_view, part, cols_target);
+      fn(g, dev(g), p, lo, hi - lo);
+    });
+  }
+};
+
 void select_query(std::vector<MafRecord>& recs, const std::string* query_name) {
   for (auto& r : recs) {
     if (query_name) { /* maf.rs:277-285 */
@@ -1319,6 +1355,7 @@ void select_query(std::vector<MafRecord>& recs, const std::string* query_name) {
 
 int cmd_stat_maf(const std::string* input, bool each, const std::string* query_name, Output& out) {
   Dev d;
+  MafDevices md(d);
   MafChunks chunks(input);
   std::vector<StatInput> in;
   MafInput min;
@@ -1327,17 +1364,18 @@ int cmd_stat_maf(const std::string* input, bool each, const std::string* query_n
     select_query(recs, query_name);
     const uint32_t n = (uint32_t)recs.size();
     std::vector<wga_cigar_counts> counts(n);
-    MafRows p = device_rows(d, min, all_records(recs), false);
-    auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
-    auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
-    d.check(wga_maf_pair_stat(d.ctx, n, p.d_rows, p.d_t, p.d_q, p.d_c, p.d_s, d_counts, d_cnt, nullptr, nullptr));
-    d.download(counts.data(), d_counts, n);
+    md.run(min, all_records(recs), false, [&](int, Dev& dg, const MafRows& p, uint32_t lo, uint32_t cnt) {
+      auto* d_counts = (wga_cigar_counts*)dg.alloc((size_t)cnt * sizeof(wga_cigar_counts));
+      auto* d_cnt = (uint64_t*)dg.alloc((size_t)cnt * 8);
+      dg.check(wga_maf_pair_stat(dg.ctx, cnt, p.d_rows, p.d_t, p.d_q, p.d_c, p.d_s, d_counts, d_cnt, nullptr, nullptr));
+      dg.download(counts.data() + lo, d_counts, cnt);
+    });
     for (uint32_t k = 0; k < n; k++) {
       const MafRecord& r = recs[k];
       in.push_back(StatInput{r.t().name, r.q().name, r.t().size, r.q().size, r.t().start, r.query_start(),
                              recstat_from(counts[k])});
     }
-    d.release_all();
+    md.release_all();
   }
   out.write(stat_tsv(in, each));
   out.close();
@@ -3205,6 +3243,7 @@ int cmd_call_paf(const std::string* input, const std::string& t_fa, const std::s
 int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, const std::string& sample,
                  const std::string* query_name, const std::string* query_regex, uint64_t chunk_size, Output& out) {
   Dev d;
+  MafDevices md(d);
   MafChunks chunks(input);
   /* utils.rs:414-436: `<input>.index` (JSON written by `maf-index`) supplies ##contig lines */
   std::vector<std::pair<std::string, uint64_t>> contigs;
@@ -3248,19 +3287,29 @@ int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, c
   }
   const uint32_t n = (uint32_t)recs.size();
   if (n) {
-    MafRows p = device_rows(d, min, recs, true); /* total_size = target row length (:115) */
-    const uint8_t* d_rows = p.d_rows;
-    auto *d_t = p.d_t, *d_q = p.d_q, *d_c = p.d_c;
-    auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
-    d.check(wga_maf_call_runs(d.ctx, n, d_rows, d_t, d_q, d_c, d_cnt, nullptr, nullptr));
-    auto* d_roff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
-    d.check(wga_exclusive_scan_u64(d.ctx, n, d_cnt, d_roff));
-    std::vector<uint64_t> roff(n + 1);
-    d.download(roff.data(), d_roff, n + 1);
-    auto* d_runs = (uint64_t*)d.alloc((3 * roff[n] + 3) * 8);
-    d.check(wga_maf_call_runs(d.ctx, n, d_rows, d_t, d_q, d_c, d_cnt, d_runs, d_roff));
+    /* every device walks its range of the blocks (K4: count, scan, fill); the run lists meet here in block order */
+    std::vector<uint64_t> roff(n + 1, 0), cols(n), cnt_all(n);
+    std::vector<std::vector<uint64_t>> runs_of(md.count());
+    std::vector<uint32_t> lo_of(md.count(), 0), n_of(md.count(), 0);
+    md.run(min, recs, true /* total_size = target row length (:115) */, [&](int g, Dev& dg, const MafRows& p, uint32_t lo, uint32_t cnt) {
+      auto* d_cnt = (uint64_t*)dg.alloc((size_t)cnt * 8);
+      dg.check(wga_maf_call_runs(dg.ctx, cnt, p.d_rows, p.d_t, p.d_q, p.d_c, d_cnt, nullptr, nullptr));
+      auto* d_roff = (uint64_t*)dg.alloc(((size_t)cnt + 1) * 8);
+      dg.check(wga_exclusive_scan_u64(dg.ctx, cnt, d_cnt, d_roff));
+      std::vector<uint64_t> ro(cnt + 1);
+      dg.download(ro.data(), d_roff, cnt + 1);
+      auto* d_runs = (uint64_t*)dg.alloc((3 * ro[cnt] + 3) * 8);
+      dg.check(wga_maf_call_runs(dg.ctx, cnt, p.d_rows, p.d_t, p.d_q, p.d_c, d_cnt, d_runs, d_roff));
+      runs_of[g].resize(3 * ro[cnt]);
+      if (ro[cnt]) dg.download(runs_of[g].data(), d_runs, 3 * ro[cnt]);
+      for (uint32_t k = 0; k < cnt; k++) cnt_all[lo + k] = ro[k + 1] - ro[k], cols[lo + k] = p.cols[k];
+      lo_of[g] = lo, n_of[g] = cnt;
+    });
+    for (uint32_t k = 0; k < n; k++) roff[k + 1] = roff[k] + cnt_all[k];
     std::vector<uint64_t> runs(3 * roff[n]);
-    if (roff[n]) d.download(runs.data(), d_runs, 3 * roff[n]);
+    for (int g = 0; g < md.count(); g++)
+      if (n_of[g]) std::copy(runs_of[g].begin(), runs_of[g].end(), runs.begin() + 3 * roff[lo_of[g]]);
+    runs_of.clear();
     g_timer.mark("kernels + run list download");
     /* the event rules and the VCF text of a block depend on that block alone: contiguous ranges of blocks go to host
      * threads, their text is written in block order (rows in front of a failing block are written, then the error) */
@@ -3275,7 +3324,7 @@ int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, c
         CallBlock b;
         for (uint32_t k = lo; k < hi; k++) {
           b.rec = recs[k];
-          b.total = p.cols[k];
+          b.total = cols[k];
           b.runs.clear();
           b.runs.reserve(roff[k + 1] - roff[k]);
           for (uint64_t x = roff[k]; x < roff[k + 1]; x++)
@@ -3314,7 +3363,7 @@ int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, c
     }
     g_timer.mark("write");
   }
-  d.release_all();
+  md.release_all();
   }
   out.write(text);
   out.close();
