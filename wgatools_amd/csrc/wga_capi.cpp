@@ -1052,7 +1052,7 @@ int wga_maf_pair_stat(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint6
   if (!d_rows || !d_t_off || !d_q_off || !d_cols || !d_strand_neg || !d_counts)
     return fail(WGA_E_INVALID_ARG, "null array", nullptr);
   if (d_runs && !d_run_off) return fail(WGA_E_INVALID_ARG, "d_run_off null", nullptr);
-  WGA_LAUNCH(k_maf_pair_stat, (n + 3u) / 4u, WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off,
+  WGA_LAUNCH(k_maf_pair_stat, (n + 7u) / 8u, WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off,
              (const u64*)d_q_off, (const u64*)d_cols, d_strand_neg, d_counts, (u64*)d_run_cnt,
              (u64*)d_runs, (const u64*)d_run_off, (u64)c->maf_long_cols);
   LAUNCH_CHECK();
@@ -1068,7 +1068,7 @@ int wga_maf_call_runs(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint6
   if (n == 0) return WGA_OK;
   if (!d_rows || !d_t_off || !d_q_off || !d_cols) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
   if (d_runs && !d_run_off) return fail(WGA_E_INVALID_ARG, "d_run_off null", nullptr);
-  WGA_LAUNCH(k_maf_call_runs, (n + 3u) / 4u, WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off,
+  WGA_LAUNCH(k_maf_call_runs, (n + 7u) / 8u, WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off,
              (const u64*)d_q_off, (const u64*)d_cols, (u64*)d_run_cnt, (u64*)d_runs,
              (const u64*)d_run_off, (u64)c->maf_long_cols);
   LAUNCH_CHECK();

@@ -802,7 +802,7 @@ __device__ __forceinline__ u32 popc32(u32 x) { return (u32)__builtin_popcount(x)
 #define WGA_MAF_FOLD_STEPS 4095u /* the emulator build of the tests folds every few steps instead */
 #endif
 #ifndef WGA_K3_BLOCKS
-#define WGA_K3_BLOCKS 8 /* blocks per CU the register budget of k_maf_pair_stat is sized for */
+#define WGA_K3_BLOCKS 7 /* blocks per CU the register budget of k_maf_pair_stat is sized for (two records per wave with prefetched rows: 8 spills six registers) */
 #endif
 struct MafWalkOut {
   u64 ncol[5], nrun[5]; /* columns / runs per class (wave totals, valid in every lane) */
@@ -819,9 +819,42 @@ struct MafWalkStart {
   u32 carry;
 };
 
+/* this lane's 16 columns of the step that starts at column c0: two byte-unaligned 16-byte loads, or byte loads in the rows'
+ * last, partial vector (never beyond the rows); zeros behind the rows' end */
+struct MafStepRows {
+  u32 t[4], q[4];
+};
+__device__ __forceinline__ void maf_load_step(const u8* __restrict__ t, const u8* __restrict__ q, u64 L, u64 c0, u32 lane,
+                                              MafStepRows& r) {
+  const u64 c = c0 + (u64)lane * 16u;
+  const u32 nv = c >= L ? 0u : (L - c >= 16u ? 16u : (u32)(L - c));
+#pragma unroll
+  for (int d = 0; d < 4; d++) r.t[d] = r.q[d] = 0u;
+  if (nv == 16u) {
+    const u32x4_a1 a = *(const u32x4_a1*)(t + c), b = *(const u32x4_a1*)(q + c);
+#pragma unroll
+    for (int d = 0; d < 4; d++) r.t[d] = a[d], r.q[d] = b[d];
+  } else if (nv) {
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const u32 j = 4u * (u32)d + (u32)e;
+        if (j < nv) {
+          r.t[d] |= (u32)t[c + j] << (8u * (u32)e);
+          r.q[d] |= (u32)q[c + j] << (8u * (u32)e);
+        }
+      }
+    }
+  }
+}
+
+/* `first`: the rows of the first step, already loaded by the caller (the kernels fetch the next record's behind the work on the
+ * current one); every further step's rows are fetched one step ahead. */
 template <bool CALLER>
 __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __restrict__ q, u64 L,
-                                         u64* rout, MafWalkOut& out, const MafWalkStart st0 = MafWalkStart{0, 0, 0, 0xFFu}) {
+                                         u64* rout, MafWalkOut& out, const MafWalkStart st0, const bool have_first,
+                                         const MafStepRows& first) {
   const u32 lane = threadIdx.x & 63u;
   constexpr int NC = CALLER ? 5 : 4;
   /* per-lane counters of classes 1..NC-1, columns in the low and run starts in the high 16 bits (a step adds at
@@ -834,20 +867,15 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
   u32 carry_cls = st0.carry; /* class of the column before this step's first one */
   u64 run_base = 0, t_base = st0.t_base, q_base = st0.q_base;
   u32 steps = 0;
+  MafStepRows nx = first;
+  if (!have_first) maf_load_step(t, q, L, 0, lane, nx);
   for (u64 c0 = 0; c0 < L; c0 += 1024) {
     const u64 c = c0 + (u64)lane * 16u;
     const u32 nv = c >= L ? 0u : (L - c >= 16u ? 16u : (u32)(L - c)); /* valid columns of this lane */
-    u32 tw[4] = {0u, 0u, 0u, 0u}, qw[4] = {0u, 0u, 0u, 0u};
-    if (nv == 16u) {
-      const u32x4_a1 a = *(const u32x4_a1*)(t + c), b = *(const u32x4_a1*)(q + c);
+    u32 tw[4], qw[4];
 #pragma unroll
-      for (int d = 0; d < 4; d++) tw[d] = a[d], qw[d] = b[d];
-    } else if (nv) { /* the record's last, partial piece: never read beyond the row */
-      for (u32 j = 0; j < nv; j++) {
-        tw[j >> 2] |= (u32)t[c + j] << (8u * (j & 3u));
-        qw[j >> 2] |= (u32)q[c + j] << (8u * (j & 3u));
-      }
-    }
+    for (int d = 0; d < 4; d++) tw[d] = nx.t[d], qw[d] = nx.q[d];
+    if (c0 + 1024 < L) maf_load_step(t, q, L, c0 + 1024, lane, nx); /* wave-uniform: the next step's rows, behind this step's work */
     u32 cls[4], st[4], tn[4], qn[4], vm[4];
 #pragma unroll
     for (int d = 0; d < 4; d++) {
@@ -987,36 +1015,52 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
   out.q_nongap = q_base;
 }
 
+__device__ __forceinline__ void maf_pair_one(const u8* __restrict__ t, const u8* __restrict__ q, u64 L, u64* rout, bool neg,
+                                             const MafStepRows& first, wga_cigar_counts* cnt, u64* run_cnt, u32 lane) {
+  MafWalkOut w;
+  maf_walk<false>(t, q, L, rout, w, MafWalkStart{0, 0, 0, 0xFFu}, true, first);
+  /* the 11 counters leave from lanes 0..10, one field per lane (as in K1): one 88-byte store per record */
+  const u64 z = 0;
+  u64 v = 0;
+  v = lane_put_u64<0u>(v, w.ncol[0], lane);
+  v = lane_put_u64<1u>(v, w.ncol[3], lane);
+  v = lane_put_u64<2u>(v, neg ? z : w.nrun[1], lane);
+  v = lane_put_u64<3u>(v, neg ? z : w.ncol[1], lane);
+  v = lane_put_u64<4u>(v, neg ? z : w.nrun[2], lane);
+  v = lane_put_u64<5u>(v, neg ? z : w.ncol[2], lane);
+  v = lane_put_u64<6u>(v, neg ? w.nrun[1] : z, lane);
+  v = lane_put_u64<7u>(v, neg ? w.ncol[1] : z, lane);
+  v = lane_put_u64<8u>(v, neg ? w.nrun[2] : z, lane);
+  v = lane_put_u64<9u>(v, neg ? w.ncol[2] : z, lane);
+  v = lane_put_u64<10u>(v, neg ? (u64)1 : z, lane);
+  if (lane < 11u) ((u64*)cnt)[lane] = v;
+  if (lane == 0 && run_cnt) *run_cnt = w.runs;
+}
+
+/* Two consecutive records per wave: the offsets of both are fetched together and the second record's first rows travel while
+ * the first record is walked — three dependent round trips (offsets, rows, every further step) stood in front of the work
+ * of a 1 500-column block, the step loop above and this pairing leave one. */
 __global__ __launch_bounds__(256, WGA_K3_BLOCKS) void k_maf_pair_stat(u32 n, const u8* __restrict__ rows,
                                                        const u64* t_off, const u64* q_off,
                                                        const u64* cols, const u8* strand_neg,
                                                        wga_cigar_counts* counts, u64* run_cnt,
                                                        u64* runs, const u64* run_off, u64 long_cols) {
   const u32 lane = threadIdx.x & 63u;
-  const u64 i = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
-  if (i >= n) return;
-  if (cols[i] > long_cols) return; /* a long block: walked piece by piece (k_maf_piece_walk) */
-  MafWalkOut w;
-  maf_walk<false>(rows + t_off[i], rows + q_off[i], cols[i], runs ? runs + run_off[i] : (u64*)0, w);
-  {
-    /* the 11 counters leave from lanes 0..10, one field per lane (as in K1): one 88-byte store per record */
-    const bool neg = strand_neg[i] != 0;
-    const u64 z = 0;
-    u64 v = 0;
-    v = lane_put_u64<0u>(v, w.ncol[0], lane);
-    v = lane_put_u64<1u>(v, w.ncol[3], lane);
-    v = lane_put_u64<2u>(v, neg ? z : w.nrun[1], lane);
-    v = lane_put_u64<3u>(v, neg ? z : w.ncol[1], lane);
-    v = lane_put_u64<4u>(v, neg ? z : w.nrun[2], lane);
-    v = lane_put_u64<5u>(v, neg ? z : w.ncol[2], lane);
-    v = lane_put_u64<6u>(v, neg ? w.nrun[1] : z, lane);
-    v = lane_put_u64<7u>(v, neg ? w.ncol[1] : z, lane);
-    v = lane_put_u64<8u>(v, neg ? w.nrun[2] : z, lane);
-    v = lane_put_u64<9u>(v, neg ? w.ncol[2] : z, lane);
-    v = lane_put_u64<10u>(v, neg ? (u64)1 : z, lane);
-    if (lane < 11u) ((u64*)(counts + i))[lane] = v;
-    if (lane == 0 && run_cnt) run_cnt[i] = w.runs;
-  }
+  const u64 i0 = ((u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x)) * 2u;
+  if (i0 >= n) return;
+  const bool two = i0 + 1u < n;
+  const u64 i1 = two ? i0 + 1u : i0;
+  const u64 L0 = cols[i0], L1 = cols[i1];
+  const u8 *t0 = rows + t_off[i0], *q0 = rows + q_off[i0], *t1 = rows + t_off[i1], *q1 = rows + q_off[i1];
+  const bool neg0 = strand_neg[i0] != 0, neg1 = strand_neg[i1] != 0;
+  u64 *r0 = (u64*)0, *r1 = (u64*)0;
+  if (runs) r0 = runs + run_off[i0], r1 = runs + run_off[i1];
+  const bool do0 = L0 <= long_cols, do1 = two && L1 <= long_cols; /* a long block: walked piece by piece (k_maf_piece_walk) */
+  MafStepRows f0, f1;
+  maf_load_step(t0, q0, do0 ? L0 : 0, 0, lane, f0);
+  maf_load_step(t1, q1, do1 ? L1 : 0, 0, lane, f1);
+  if (do0) maf_pair_one(t0, q0, L0, r0, neg0, f0, counts + i0, run_cnt ? run_cnt + i0 : (u64*)0, lane); /* wave-uniform */
+  if (do1) maf_pair_one(t1, q1, L1, r1, neg1, f1, counts + i1, run_cnt ? run_cnt + i1 : (u64*)0, lane);
 }
 
 __global__ __launch_bounds__(256) void k_maf_call_runs(u32 n, const u8* __restrict__ rows,
@@ -1024,12 +1068,37 @@ __global__ __launch_bounds__(256) void k_maf_call_runs(u32 n, const u8* __restri
                                                        const u64* cols, u64* run_cnt, u64* runs,
                                                        const u64* run_off, u64 long_cols) {
   const u32 lane = threadIdx.x & 63u;
-  const u64 i = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
-  if (i >= n) return;
-  if (cols[i] > long_cols) return; /* a long block: walked piece by piece (k_maf_piece_walk) */
-  MafWalkOut w;
-  maf_walk<true>(rows + t_off[i], rows + q_off[i], cols[i], runs ? runs + 3 * run_off[i] : (u64*)0, w);
-  if (lane == 0 && run_cnt) run_cnt[i] = w.runs;
+  const u64 i0 = ((u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x)) * 2u;
+  if (i0 >= n) return;
+  const bool two = i0 + 1u < n;
+  const u64 i1 = two ? i0 + 1u : i0;
+  const u64 L0 = cols[i0], L1 = cols[i1];
+  const u8 *t0 = rows + t_off[i0], *q0 = rows + q_off[i0], *t1 = rows + t_off[i1], *q1 = rows + q_off[i1];
+  u64 *r0 = (u64*)0, *r1 = (u64*)0;
+  if (runs) r0 = runs + 3 * run_off[i0], r1 = runs + 3 * run_off[i1];
+  const bool do0 = L0 <= long_cols, do1 = two && L1 <= long_cols;
+  MafStepRows f0, f1;
+  maf_load_step(t0, q0, do0 ? L0 : 0, 0, lane, f0);
+  maf_load_step(t1, q1, do1 ? L1 : 0, 0, lane, f1);
+  if (do0) { /* wave-uniform */
+    MafWalkOut w;
+    maf_walk<true>(t0, q0, L0, r0, w, MafWalkStart{0, 0, 0, 0xFFu}, true, f0);
+    if (lane == 0 && run_cnt) run_cnt[i0] = w.runs;
+  }
+  if (do1) {
+    MafWalkOut w;
+    maf_walk<true>(t1, q1, L1, r1, w, MafWalkStart{0, 0, 0, 0xFFu}, true, f1);
+    if (lane == 0 && run_cnt) run_cnt[i1] = w.runs;
+  }
+}
+
+template <bool CALLER>
+__device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __restrict__ q, u64 L, u64* rout, MafWalkOut& out,
+                                         const MafWalkStart st0 = MafWalkStart{0, 0, 0, 0xFFu}) {
+  MafStepRows none;
+#pragma unroll
+  for (int d = 0; d < 4; d++) none.t[d] = none.q[d] = 0u;
+  maf_walk<CALLER>(t, q, L, rout, out, st0, false, none);
 }
 
 /* ---- long blocks: the same walks, piece by piece ---------------------------------------------------------------
