@@ -12,6 +12,7 @@
 #define WGA_KERNELS2_H
 
 #include "wga_kernels.h"
+#include <type_traits>
 
 #define WGA_COV_CHUNK 4096u
 
@@ -802,7 +803,7 @@ __device__ __forceinline__ u32 popc32(u32 x) { return (u32)__builtin_popcount(x)
 #define WGA_MAF_FOLD_STEPS 4095u /* the emulator build of the tests folds every few steps instead */
 #endif
 #ifndef WGA_K3_BLOCKS
-#define WGA_K3_BLOCKS 7 /* blocks per CU the register budget of k_maf_pair_stat is sized for (two records per wave with prefetched rows: 8 spills six registers) */
+#define WGA_K3_BLOCKS 6 /* blocks per CU the register budget of k_maf_pair_stat is sized for (two records per wave with prefetched rows: 8 spills six registers) */
 #endif
 struct MafWalkOut {
   u64 ncol[5], nrun[5]; /* columns / runs per class (wave totals, valid in every lane) */
@@ -869,9 +870,13 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
   u32 steps = 0;
   MafStepRows nx = first;
   if (!have_first) maf_load_step(t, q, L, 0, lane, nx);
-  for (u64 c0 = 0; c0 < L; c0 += 1024) {
+  u64 c0 = 0;
+  /* one step; FULL: every lane holds 16 valid columns (all steps of a row pair but the last): the validity masks and the
+   * search for the last valid column fold away */
+  auto step = [&](auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
     const u64 c = c0 + (u64)lane * 16u;
-    const u32 nv = c >= L ? 0u : (L - c >= 16u ? 16u : (u32)(L - c)); /* valid columns of this lane */
+    const u32 nv = FULL ? 16u : (c >= L ? 0u : (L - c >= 16u ? 16u : (u32)(L - c))); /* valid columns of this lane */
     u32 tw[4], qw[4];
 #pragma unroll
     for (int d = 0; d < 4; d++) tw[d] = nx.t[d], qw[d] = nx.q[d];
@@ -880,7 +885,8 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
 #pragma unroll
     for (int d = 0; d < 4; d++) {
       const int lo = 4 * d;
-      vm[d] = nv >= (u32)lo + 4u ? 0x80808080u : (nv > (u32)lo ? (0x80808080u >> (8u * (4u - (nv - (u32)lo)))) : 0u);
+      vm[d] = FULL ? 0x80808080u
+                   : (nv >= (u32)lo + 4u ? 0x80808080u : (nv > (u32)lo ? (0x80808080u >> (8u * (4u - (nv - (u32)lo)))) : 0u));
       const u32 eq = zero_bytes(tw[d] ^ qw[d]);
       const u32 tg = zero_bytes(tw[d] ^ 0x2D2D2D2Du), qg = zero_bytes(qw[d] ^ 0x2D2D2D2Du);
       u32 cI, cD, cX, cW = 0u;
@@ -903,7 +909,13 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
       if (CALLER) pk[NC - 1] += popc32(cW & vm[d]);
     }
     /* class of the column before each byte: bytes shifted up by one across the 16-byte vector */
-    const u32 my_last = nv ? ((cls[(nv - 1u) >> 2] >> (8u * ((nv - 1u) & 3u))) & 0xFFu) : 0xFEu;
+    u32 my_last;
+    if (FULL) {
+      my_last = cls[3] >> 24;
+    } else { /* no indexing of the register array by a run-time value */
+      const u32 last_dw = nv > 12u ? cls[3] : nv > 8u ? cls[2] : nv > 4u ? cls[1] : cls[0];
+      my_last = nv ? ((last_dw >> (8u * ((nv - 1u) & 3u))) & 0xFFu) : 0xFEu;
+    }
     u32 prev_last = __shfl_up(my_last, 1u);
     if (lane == 0) prev_last = carry_cls;
     u32 nst = 0;
@@ -915,16 +927,19 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
       nst += popc32(st[d]);
     }
     /* per-class run starts: a start byte's class */
-    u32 rs1 = 0, rs2 = 0, rs3 = 0, rs4 = 0;
+    u32 rs1 = 0, rs2 = 0, rs3 = 0, rs4 = 0; /* rs1, rs2: starts whose class has bit 0 / bit 1 set (class 3 has both) */
 #pragma unroll
     for (int d = 0; d < 4; d++) {
       const u32 s7 = st[d] >> 7; /* 1 in the low bit of start bytes */
       const u32 k = cls[d];
-      rs1 += popc32(s7 & k & ~(k >> 1) & ~(k >> 2) & 0x01010101u);          /* class 1: 001 */
-      rs2 += popc32(s7 & (k >> 1) & ~k & 0x01010101u);                     /* class 2: 010 */
-      rs3 += popc32(s7 & (k >> 1) & k & 0x01010101u);                      /* class 3: 011 */
-      if (CALLER) rs4 += popc32(s7 & (k >> 2) & 0x01010101u);              /* class 4: 100 */
+      const u32 b0 = s7 & k, b1 = s7 & (k >> 1);
+      rs1 += popc32(b0);
+      rs2 += popc32(b1);
+      rs3 += popc32(b0 & b1);                                              /* class 3: 011 */
+      if (CALLER) rs4 += popc32(s7 & (k >> 2));                            /* class 4: 100 */
     }
+    rs1 -= rs3; /* class 1: 001 */
+    rs2 -= rs3; /* class 2: 010 */
     pk[1] += rs1 << 16;
     pk[2] += rs2 << 16;
     pk[3] += rs3 << 16;
@@ -972,9 +987,13 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
     t_base += t_tot;
     q_base += q_tot;
     /* the last valid column of this step is in the last lane that has any */
-    const u64 has = __ballot(nv != 0u);
-    const int last_lane = 63 - (int)__builtin_clzll(has); /* has != 0 inside the loop */
-    carry_cls = __shfl(my_last, last_lane);
+    if (FULL) {
+      carry_cls = wave_last_u32(my_last);
+    } else {
+      const u64 has = __ballot(nv != 0u);
+      const int last_lane = 63 - (int)__builtin_clzll(has); /* has != 0 inside the loop */
+      carry_cls = __shfl(my_last, last_lane);
+    }
     if (++steps == WGA_MAF_FOLD_STEPS) { /* 16 x 4095 < 2^16: fold the lane counters before a half can wrap */
 #pragma unroll
       for (int k = 1; k < NC; k++) {
@@ -984,6 +1003,12 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
       }
       steps = 0;
     }
+  };
+  for (; c0 < L; c0 += 1024) {
+    if (c0 + 1024 <= L) /* wave-uniform */
+      step(std::true_type{});
+    else
+      step(std::false_type{});
   }
   /* class 0 columns / runs = all minus the others */
   u64 C[NC], R[NC];
