@@ -238,23 +238,24 @@ def north_star(args):
     nb = (args.ns_records + per - 1) // per
     tot_ops = tot_cols = tot_bytes = 0
     ms_step = ms_k2 = 0.0
-    arena, fresh_arena = None, False
+    arena = keep = placement = None
     for b in range(nb):
         tb = synth.make_paf_batch_torch(0x5747415F + 1000 + b, per, 50_000, args.pool_mb * 1_000_000, dev)
         need = int((tb["t_src_len"] + tb["i"]).sum() + (tb["q_src_len"] + tb["d"]).sum()) + 64
-        if arena is None or arena.numel() < need:   # one output arena for the whole stream, as a long-lived caller keeps
-            arena = None
+        if arena is None or arena.numel() < need:   # one output arena for the whole stream, as a long-lived caller keeps:
+            arena = keep = None                      # placed by the library for the first batch that needs it
             torch.cuda.empty_cache()
-            arena = torch.empty(int(need * 1.08), dtype=torch.uint8, device=dev)
-            fresh_arena = True
-        job = pipeline.Paf2MafStatJob(eng, tb, out=arena)
-        job.bind_stream()
-        if fresh_arena:
-            for _ in range(5):              # warm-up: first touch of the arena + the library's drain_min trials
+            job = pipeline.Paf2MafStatJob(eng, tb, place=args.ns_candidates)
+            job.bind_stream()
+            placement = job.place_output(arena_bytes=int(need * 1.08))
+            arena, keep = job.arena_view, job.arena
+            for _ in range(4):              # warm-up: the library's drain_min trials on the kept arena
                 job.step()
             torch.cuda.synchronize()
             eng.expand_timing()
-            fresh_arena = False
+        else:
+            job = pipeline.Paf2MafStatJob(eng, tb, out=arena)
+            job.bind_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         job.step()
@@ -280,8 +281,9 @@ def north_star(args):
         "roofline": {"kernel": "k_paf2maf_expand", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": tot_bytes},
         "expand_drain_min": {"used": eng.get_param("expand_drain_min"), "autotune_settled": eng.get_param("expand_autotune_settled")},
-        "metric_scope": "kernel-only, summed over the batches, rows written into one output arena; generation between batches "
-                        "is not timed",
+        "output_placement": placement,
+        "metric_scope": "kernel-only, summed over the batches, rows written into one output arena (placed for the first batch by "
+                        "wga_paf2maf_expand_place); generation between batches is not timed",
     }), flush=True)
     eng.close()
 
@@ -317,6 +319,7 @@ def main():
     ap.add_argument("--north-star", action="store_true", help="the 10 M x 50 kop headline shape as a stream of resident batches (N = 1)")
     ap.add_argument("--ns-records", type=int, default=400_000)
     ap.add_argument("--ns-batch-records", type=int, default=40_000)
+    ap.add_argument("--ns-candidates", type=int, default=3, help="candidate arenas of the north-star stream (64 GB each)")
     args = ap.parse_args()
     if args.north_star:
         return north_star(args)

@@ -47,17 +47,19 @@ class Paf2MafStatJob:
         else:
             self.out = out[: rows + 64] if out is not None else torch.empty(rows + 64, dtype=torch.uint8, device=dev)
 
-    def place_output(self):
+    def place_output(self, arena_bytes=None):
         """stat + layout, then the rows of this batch into the fastest of `place` candidate arenas (the library's policy for
-        a long-lived caller's output arena, also used by the `wgatools` command line) -> {K2 ms per candidate, index kept}"""
+        a long-lived caller's output arena, also used by the `wgatools` command line) -> {K2 ms per candidate, index kept}.
+        arena_bytes: size of the arena when it is to serve later, larger batches as well (default: this batch's rows)."""
         tb = self.tb
         self.stat()
         self.layout()
         self.arena, ms, chosen = self.eng.paf2maf_expand_place(
             self.batch, self.counts, self.tile_ws, tb["t_pool"], tb["t_pool"].numel(), tb["t_src_off"], tb["t_src_len"],
             tb["q_pool"], tb["q_pool"].numel(), tb["q_src_off"], tb["q_src_len"], self.t_row_off, self.q_row_off, self.diag,
-            self.out_bytes + 64, self.place)
-        self.out = self.arena.torch(tb["ops"].device)[: self.out_bytes + 64]
+            max(self.out_bytes + 64, int(arena_bytes or 0)), self.place)
+        self.arena_view = self.arena.torch(tb["ops"].device)
+        self.out = self.arena_view[: self.out_bytes + 64]
         return {"policy": "wga_paf2maf_expand_place: the batch's rows written into each of %d candidate arenas, the one the "
                           "row kernel was fastest on kept" % self.place,
                 "k2_ms_by_candidate": [round(x, 3) for x in ms], "chosen": chosen}
