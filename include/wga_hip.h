@@ -120,7 +120,7 @@ int wga_ctx_reset_stream(wga_ctx*);
  * expand kernel; "expand_no_table" (0/1) forces its binary-search event lookup; "expand_variant" picks the row
  * kernel — same bytes either way: -1 (default) by the batch (the window kernel, which assembles 4 KB output windows in
  * LDS and stores whole lines, for batches below 1500 ops per record, where it is 12-19 % faster; v1 for longer records,
- * where v1 is 7 % faster), 0: v1, 2: the window kernel; environment: WGA_EXPAND_VARIANT; "expand_drain_min" (0 .. 64) = how many gap-touching 16-column chunks a wave
+ * where v1 is 9-18 % faster: profiles/r03_k2w_experiments.md), 0: v1, 2: the window kernel; environment: WGA_EXPAND_VARIANT; "expand_drain_min" (0 .. 64) = how many gap-touching 16-column chunks a wave
  * queues before it emits them: 0 (default) lets the library choose by the size of the two sequence pools — 64 when
  * they stay in the 256 MB Infinity Cache, 16 when they do not (the L2 then churns with source lines and half-written
  * output lines should complete at once) as the starting point — and, unless "expand_autotune" is set to 0, tries 64 / 32 /
@@ -128,7 +128,11 @@ int wga_ctx_reset_stream(wga_ctx*);
  * late emission costs depends on where the output buffer lies in HBM; the bytes written do not depend on it).  A caller
  * that keeps its output arena pays three slightly slower launches once.  Environment: WGA_EXPAND_DRAIN_MIN,
  * WGA_EXPAND_AUTOTUNE.  "expand_alias" (0/1): launch the row kernel under its second name (k_paf2maf_expand_alias) —
- * a harness that runs several shapes in one process keeps its per-kernel profiler statistics apart that way. */
+ * a harness that runs several shapes in one process keeps its per-kernel profiler statistics apart that way.
+ * "op_long_ops" (default 16384) / "op_piece_ops" (8192, a multiple of 256): the op walks with one wave per record (call
+ * events, chain lines, dotplot segments) cut records beyond the first into pieces of at most the second and walk the pieces
+ * over the whole chip; "maf_long_cols" (32768) / "maf_piece_cols" (16384): the same for the MAF column walks.  The tests set
+ * small values to reach those paths with small inputs. */
 int wga_ctx_set_param(wga_ctx*, const char* name, int64_t value);
 /* Read back: "expand_drain_min" = what the last wga_paf2maf_expand used, "expand_autotune_settled" (0/1),
  * "expand_variant" (the setting), "expand_variant_used" (what the last wga_paf2maf_expand ran). */

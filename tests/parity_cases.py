@@ -319,7 +319,7 @@ def check_paf2maf_maf2paf_roundtrip(eng, seed, n, mean_ops):
 
 def wide_tile_batch(eng, seed=3):
     """records whose tiles hold 65 536 .. 2^31 columns (one long D / I op each, next to ordinary ops): the u32
-    instance of the planned row kernel; the short records around them stay in narrow tiles"""
+    instance of the row kernels; the short records around them stay in narrow tiles"""
     rng = np.random.default_rng(seed)
     cigars = ["20=", "30=70000D25=3I8=", "9=2X9=", "12=100000I12=", "5=1I5=", "40=66000D3X90000I17="]
     strands = [0, 1, 1, 0, 0, 1]

@@ -1666,9 +1666,9 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
 #endif
 }
 
-/* v1 of the row kernel (granules stored as they are produced: lines reach the L2 in pieces).  It stays as the A/B
- * reference (`expand_variant` 0: one block per tile of the batch) and — as k_paf2maf_expand_list — for the tiles the
- * planned kernel of wga_kernels_k2p.h leaves out: beyond 2^31 columns, the op-serial u64 walk. */
+/* v1 of the row kernel (granules stored as they are produced: lines reach the L2 in pieces): `expand_variant` 0, one block
+ * per tile of the batch; the default for batches of long records (the window kernel of wga_kernels_k2w.h takes the short
+ * ones) and — as k_paf2maf_expand_list — the op-serial u64 walk of the tiles beyond 2^31 columns under either kernel. */
 /* Blocks go to the 8 XCDs round robin (block b runs on XCD b % 8), each with its own L2.  Every XCD gets one contiguous
  * eighth of the tiles, in order: the ~190 tiles an XCD has in flight are then neighbours — the output lines two tiles
  * share and the source windows of one record's tiles meet in one L2.  Measured (profiles/r02_k2_experiments.md):
