@@ -493,28 +493,64 @@ PafInput load_paf(Dev& d, const std::string* input, bool want_tags) {
   return paf_from_text(d, read_all(input), want_tags);
 }
 
-/* A PAF input in pieces of about 1 GiB that end at line ends (WGA_CHUNK_BYTES overrides the size): the streaming
+/* A PAF input in pieces of about 256 MiB that end at line ends (WGA_CHUNK_BYTES overrides the size), the next piece read
+ * ahead while the current one is worked on: the streaming
  * commands hold one piece of the file, and its buffers on the device, at a time. */
 struct PafChunks {
   LineChunkReader rd;
   bool want_tags;
-  size_t target = (size_t)1 << 30;
+  size_t target = (size_t)256 << 20;
   uint64_t recs_before = 0;
+  /* the next piece is read by a helper thread while the caller works on the current one (reading 1 GB takes as long as
+   * every kernel of the run together): `ahead` holds it with the reader's counters for that piece */
+  struct Ahead {
+    bool ok = false;
+    std::string piece, err;
+    uint64_t lines_before = 0, bytes_before = 0;
+  } ahead;
+  std::thread reader;
+  bool started = false;
   PafChunks(const std::string* input, bool tags) : want_tags(tags) {
     rd.open(input);
     if (const char* e = getenv("WGA_CHUNK_BYTES")) target = (size_t)strtoull(e, nullptr, 10);
     if (target == 0) target = 1;
   }
+  ~PafChunks() {
+    if (reader.joinable()) reader.join();
+  }
+  void read_ahead() {
+    reader = std::thread([this] {
+      Ahead a;
+      try {
+        a.ok = rd.next(a.piece, target);
+        a.lines_before = rd.lines_before;
+        a.bytes_before = rd.bytes_before;
+      } catch (Error& e) {
+        a.err = e.msg.empty() ? std::string("error") : e.msg;
+      } catch (std::exception& e) {
+        a.err = std::string("internal error: ") + e.what();
+      }
+      ahead = std::move(a);
+    });
+  }
   /* the next piece with at least one record, or false at the end of the input */
   bool next(Dev& d, PafInput& in) {
-    std::string piece;
-    while (rd.next(piece, target)) {
-      in = paf_from_text(d, std::move(piece), want_tags, recs_before, rd.lines_before, rd.bytes_before);
+    for (;;) {
+      if (!started) {
+        started = true;
+        read_ahead();
+      }
+      if (!reader.joinable()) return false; /* the end was seen */
+      reader.join();
+      Ahead a = std::move(ahead);
+      if (!a.err.empty()) fail(a.err);
+      if (!a.ok) return false;
+      read_ahead();
+      in = paf_from_text(d, std::move(a.piece), want_tags, recs_before, a.lines_before, a.bytes_before);
       recs_before += in.recs.size();
       if (!in.recs.empty()) return true;
       if (in.d_text) d.release(in.d_text);
     }
-    return false;
   }
 };
 
