@@ -315,7 +315,9 @@ def main():
                                                             "(P(target k) ~ 1 / (k + 1)^zipf; 0 = uniform, the default)")
     ap.add_argument("--no-placement-probe", action="store_true", help="take the first output buffer the allocator returns instead "
                     "of the arena the library places for the job (wga_paf2maf_expand_place, --placement-candidates)")
-    ap.add_argument("--placement-candidates", type=int, default=8)
+    ap.add_argument("--placement-candidates", type=int, default=12,
+                    help="candidate output arenas the library places the job among (12 x 15 GB on configs[1]: the regions of HBM that are fast "
+                         "for the row kernel are about a third of them; fewer are tried when memory runs out)")
     ap.add_argument("--north-star", action="store_true", help="the 10 M x 50 kop headline shape as a stream of resident batches (N = 1)")
     ap.add_argument("--ns-records", type=int, default=400_000)
     ap.add_argument("--ns-batch-records", type=int, default=40_000)
