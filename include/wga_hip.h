@@ -319,6 +319,23 @@ int wga_paf_call_vcf(wga_ctx*, const wga_cigar_batch*, uint64_t svlen, const uin
                      const uint8_t* d_q_pool, uint64_t* d_nbytes, wga_vcf_err* d_err, uint8_t* d_out,
                      const uint64_t* d_out_off);
 
+/* ---- BGZF inflate on the device (the reference opens bgzipped FASTA through htslib's faidx,
+ *      converter.rs:183-184, paf.rs:221-237, pseudomaf.rs:214-237) -------------------------------------------------
+ * d_in: the compressed file as it is; d_blocks[n]: per BGZF member the place of its raw DEFLATE stream (behind the gzip
+ * header with the BC field, in front of the CRC32 / ISIZE trailer), ISIZE and the place of its bytes in the output — the
+ * host walks the member headers, nothing else.  Every block is inflated by one wave (RFC 1951: stored, fixed and dynamic
+ * blocks) into d_out + out_off.  d_status[n]: 0, or the reason a stream is corrupt (WGA_INF_* in the kernel source: the
+ * input ends inside a symbol, a bad block type / stored length, bad code lengths, an unused bit pattern, a distance in front
+ * of the block, a size other than ISIZE); a corrupt block never writes outside its own out_len bytes.  The CRC32 of a
+ * member is not checked (neither does the host reader this replaces). */
+typedef struct {
+  uint64_t in_off;
+  uint32_t in_len, out_len;
+  uint64_t out_off;
+} wga_bgzf_block;
+int wga_bgzf_inflate(wga_ctx*, const uint8_t* d_in, uint64_t in_bytes, uint32_t n_blocks, const wga_bgzf_block* d_blocks,
+                     uint8_t* d_out, uint32_t* d_status);
+
 /* ---- paf2chain: the data lines of parse_cigar_to_chain + cigar_unit_chain
  *      (cigar.rs:251-295,460-490) and the head / tail indel trim of parse_cigar_to_trim
  *      (cigar.rs:202-245) that the chain header needs (chain.rs:142-183) ----------------------------

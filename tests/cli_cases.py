@@ -173,6 +173,13 @@ def test_paf2maf_fasta_readers(cli, tmp_path):
             assert rc == 0, err
             outs.append(out.split(b"\n", 1)[1])    # the header line names the FASTA paths
         assert outs[0] == outs[1] == want.split(b"\n", 1)[1], (tf_, qf_)
+    # the BGZF file is inflated on the device by default (wga_bgzf_inflate); WGA_BGZF_DEVICE=0: by host threads — same bytes
+    os.environ["WGA_BGZF_DEVICE"] = "0"
+    try:
+        rc, out, err = run(cli, "paf2maf", paf, "-g", tgz, "-q", qbgz)
+    finally:
+        del os.environ["WGA_BGZF_DEVICE"]
+    assert rc == 0 and out.split(b"\n", 1)[1] == want.split(b"\n", 1)[1], err
     # a damaged BGZF block is an IO error, not silently truncated input
     raw = bytearray(open(qbgz, "rb").read())
     raw[len(raw) // 2] ^= 0x5A

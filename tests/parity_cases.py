@@ -1571,3 +1571,81 @@ def random_fasta(rng, n_contigs, max_len, width=None, crlf=False):
     if out and rng.random() < 0.5:
         out = out[:-len(eol)]                # no line end at the end of the file
     return bytes(out)
+
+
+# ------------------------------------------------------------------------------------------------
+# K17 BGZF inflate (RFC 1951 on the device) against zlib
+# ------------------------------------------------------------------------------------------------
+def bgzf_member(data, level=6, strategy=0):
+    """one BGZF member (RFC 1952 header with the BC extra field, raw DEFLATE, CRC32, ISIZE) of at most 64 KiB of data"""
+    import struct, zlib
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    payload = co.compress(data) + co.flush()
+    bsize = 12 + 6 + len(payload) + 8
+    assert bsize <= 65536
+    return (b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1) + payload
+            + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+
+def bgzf_table(img):
+    """the member table of a BGZF image: (in_off, in_len, out_len, out_off) per member"""
+    import struct
+    rows, p, out = [], 0, 0
+    while p < len(img):
+        xlen = struct.unpack_from("<H", img, p + 10)[0]
+        bsize = struct.unpack_from("<H", img, p + 16)[0] + 1
+        isize = struct.unpack_from("<I", img, p + bsize - 4)[0]
+        rows.append((p + 12 + xlen, bsize - 12 - xlen - 8, isize, out))
+        out += isize
+        p += bsize
+    return np.array(rows, dtype=[("in_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"), ("out_off", "<u8")]), out
+
+
+def check_bgzf_inflate(eng):
+    """every kind of DEFLATE block through wga_bgzf_inflate: stored (level 0), fixed codes (Z_FIXED), dynamic codes at several
+    levels; literals only, long matches at distance 1 (run-length) and near 32 KiB, 258-byte matches, an empty member (the EOF
+    marker), members of one byte and of 65 280 bytes; damaged streams are reported and write nothing outside their range"""
+    import zlib
+    rng = np.random.default_rng(17)
+    dna = bytes(rng.choice(list(b"ACGTacgtN\n"), 60000, p=[.22, .22, .22, .22, .02, .02, .02, .02, .02, .02]).astype(np.uint8))
+    rep = (b"ACGTTGCA" * 4000)[:30000] + dna[:2000] + b"A" * 20000 + dna[:2000]
+    far = dna[:200] + bytes(rng.integers(0, 256, 32500, dtype=np.uint8)) + dna[:200] * 3
+    datas = [(dna, 6, 0), (dna, 1, 0), (dna, 9, 0), (dna[:65280 - 9000], 0, 0), (rep, 6, 0), (rep, 6, zlib.Z_FIXED), (far, 9, 0),
+             (b"", 6, 0), (b"x", 6, 0), (b"ab" * 129 + b"c", 6, zlib.Z_FIXED), (bytes(rng.integers(0, 256, 50000, dtype=np.uint8)), 6, 0),
+             (b"N" * 65280, 6, 0), (dna[:777], 6, zlib.Z_HUFFMAN_ONLY), (rep[:40000], 6, zlib.Z_RLE)]
+    img = b"".join(bgzf_member(d, lv, st) for d, lv, st in datas)
+    want = b"".join(d for d, _, _ in datas)
+    tab, total = bgzf_table(img)
+    assert total == len(want)
+    d_in = eng.upload(np.frombuffer(img + b"\0" * 16, dtype=np.uint8))
+    d_tab = eng.upload(tab.view(np.uint8))
+    out = eng.empty(total + 64, np.uint8).fill(0x23)
+    status = eng.empty(len(tab), np.uint32).fill(0xFF)
+    eng.bgzf_inflate(d_in, len(img), len(tab), d_tab, out, status)
+    st = status.numpy()
+    assert (st == 0).all(), st
+    got = out.numpy()
+    assert got[:total].tobytes() == want and (got[total:] == 0x23).all()
+    # damaged streams: a flipped bit in the middle of every non-trivial member, a truncated payload, a wrong ISIZE
+    bad = bytearray(img)
+    for k in (0, 4, 6):
+        at = int(tab["in_off"][k]) + int(tab["in_len"][k]) // 2
+        bad[at] ^= 0x10
+    tab2 = tab.copy()
+    tab2["in_len"][1] = tab2["in_len"][1] // 2          # the input ends inside the stream
+    tab2["out_len"][2] = tab2["out_len"][2] - 5          # fewer bytes than the stream holds
+    out.fill(0x23)
+    status.fill(0xFF)
+    eng.bgzf_inflate(eng.upload(np.frombuffer(bytes(bad) + b"\0" * 16, dtype=np.uint8)), len(img), len(tab), eng.upload(tab2.view(np.uint8)),
+                     out, status)
+    st = status.numpy()
+    assert st[1] != 0 and st[2] != 0, st
+    for k in (0, 4, 6):                                   # a flipped bit: an error, or (rarely) other bytes of the same length
+        a, n = int(tab["out_off"][k]), int(tab["out_len"][k])
+        assert st[k] != 0 or out.numpy()[a:a + n].tobytes() != want[a:a + n], k
+    got = out.numpy()
+    assert (got[total:] == 0x23).all()
+    for k in range(len(tab)):                             # untouched members are still right
+        if k not in (0, 1, 2, 4, 6):
+            a, n = int(tab["out_off"][k]), int(tab["out_len"][k])
+            assert st[k] == 0 and got[a:a + n].tobytes() == want[a:a + n], k

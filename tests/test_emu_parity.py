@@ -645,3 +645,7 @@ def test_reduce_scatter_i32(monkeypatch):
     assert lib.wga_reduce_scatter_i32(dup, 2, b2, 5) == -1
     for e in engs:
         e.close()
+
+
+def test_bgzf_inflate(emu):
+    pc.check_bgzf_inflate(emu)

@@ -965,3 +965,7 @@ def test_fasta_pool(gpu):
     for k in range(8):
         pc.check_fasta_pool(gpu, pc.random_fasta(rng, int(rng.integers(1, 40)), 200_000, crlf=bool(k & 1)))
     pc.check_fasta_pool(gpu, pc.random_fasta(rng, 5, 20_000_000, width=60))
+
+
+def test_bgzf_inflate(gpu):
+    pc.check_bgzf_inflate(gpu)

@@ -1403,6 +1403,19 @@ int wga_paf_call_events(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, in
   return WGA_OK;
 }
 
+int wga_bgzf_inflate(wga_ctx* c, const uint8_t* d_in, uint64_t in_bytes, uint32_t n_blocks, const wga_bgzf_block* d_blocks,
+                     uint8_t* d_out, uint32_t* d_status) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (n_blocks == 0) return WGA_OK;
+  static_assert(sizeof(wga_bgzf_block) == sizeof(wga_bgzf_block_dev) && sizeof(wga_bgzf_block) == 24, "wga_bgzf_block layout");
+  if (!d_in || !d_blocks || !d_out || !d_status) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  WGA_LAUNCH(k_bgzf_inflate, (n_blocks + 3u) / 4u, WGA_BLOCK, c->stream, d_in, (u64)in_bytes, n_blocks,
+             (const wga_bgzf_block_dev*)d_blocks, d_out, (u32*)d_status);
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
 int wga_paf_call_vcf(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, const uint64_t* d_ev, const uint64_t* d_ev_off,
                      const wga_vcf_rec* d_recs, const uint8_t* d_names, const uint8_t* d_t_pool, const uint8_t* d_q_pool,
                      uint64_t* d_nbytes, wga_vcf_err* d_err, uint8_t* d_out, const uint64_t* d_out_off) {

@@ -232,4 +232,265 @@ __global__ __launch_bounds__(256) void k_paf_call_vcf(u32 n, const u32* __restri
   if (!FILL && lane == 0) nbytes[k] = run;
 }
 
+/* ============================================================================================ */
+/* K17: BGZF blocks inflated where the text will be read ("bgzf reader on the  */
+/*      GPU-direct path"; the reference reaches bgzf through htslib, converter.rs:183-184)        */
+/* ============================================================================================ */
+/* A BGZF file is a series of gzip members of at most 64 KiB, each an independent raw DEFLATE stream (RFC 1951) whose
+ * uncompressed size stands in its trailer: the host walks the member headers (a hop per block), the compressed file goes
+ * to the device as it is, and every block is inflated by one wave straight to its place in the text.  The decoder is
+ * RFC 1951's own description — stored, fixed and dynamic blocks; canonical Huffman codes decoded bit by bit against the
+ * per-length counts (3.2.2), length / distance symbols with their extra bits (3.2.5), the code-length alphabet (3.2.7) —
+ * run by the wave's first lane with its tables in LDS; the parallelism is the tens of thousands of blocks of a genome.
+ * Status per block: 0, or what was wrong (a corrupt stream never writes outside its block's output range). */
+typedef uint16_t u16;
+struct wga_bgzf_block_dev { /* = wga_bgzf_block */
+  u64 in_off;  /* the raw DEFLATE stream inside the file image */
+  u32 in_len;
+  u32 out_len; /* ISIZE */
+  u64 out_off;
+};
+#define WGA_INF_OK 0u
+#define WGA_INF_INPUT 1u   /* the stream ends inside a symbol */
+#define WGA_INF_TYPE 2u    /* block type 3, or a stored block whose length check fails */
+#define WGA_INF_CODES 3u   /* over-subscribed / missing code lengths, a repeat without a previous length */
+#define WGA_INF_SYMBOL 4u  /* a bit pattern no code has, length / distance symbol out of range */
+#define WGA_INF_DIST 5u    /* a distance beyond the start of the block's output */
+#define WGA_INF_SIZE 6u    /* more or fewer bytes than ISIZE */
+
+static __device__ const u16 k_inf_lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+static __device__ const u8 k_inf_lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+static __device__ const u16 k_inf_dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+static __device__ const u8 k_inf_dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+static __device__ const u8 k_inf_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct InfBits {
+  const u8* in;
+  u32 pos, end;
+  u64 buf;
+  u32 cnt, err;
+};
+__device__ __forceinline__ u32 inf_bits(InfBits& b, u32 n) { /* n <= 16 bits, least significant first (3.1.1) */
+  while (b.cnt < n) {
+    if (b.pos >= b.end) {
+      b.err = b.err ? b.err : WGA_INF_INPUT;
+      return 0u;
+    }
+    b.buf |= (u64)b.in[b.pos++] << b.cnt;
+    b.cnt += 8u;
+  }
+  const u32 v = (u32)b.buf & ((1u << n) - 1u);
+  b.buf >>= n;
+  b.cnt -= n;
+  return v;
+}
+/* a canonical code: count[len] codes of every length, the symbols in code order */
+struct InfCode {
+  u16* count;  /* [16] */
+  u16* symbol; /* [n]  */
+};
+/* lengths -> the code; returns < 0 for an over-subscribed set, > 0 for an incomplete one, 0 for a complete one */
+__device__ __forceinline__ int inf_construct(InfCode h, const u16* length, u32 n) {
+  u16 offs[16];
+  for (u32 l = 0; l < 16u; l++) h.count[l] = 0;
+  for (u32 k = 0; k < n; k++) h.count[length[k]]++;
+  if (h.count[0] == n) return 0; /* no codes: complete, and never decoded */
+  int left = 1;
+  for (u32 l = 1; l < 16u; l++) {
+    left <<= 1;
+    left -= (int)h.count[l];
+    if (left < 0) return left;
+  }
+  offs[1] = 0;
+  for (u32 l = 1; l < 15u; l++) offs[l + 1] = (u16)(offs[l] + h.count[l]);
+  for (u32 k = 0; k < n; k++)
+    if (length[k]) h.symbol[offs[length[k]]++] = (u16)k;
+  return left;
+}
+__device__ __forceinline__ int inf_decode(InfBits& b, InfCode h) { /* one symbol, or -1 */
+  int code = 0, first = 0, index = 0;
+  for (u32 l = 1; l < 16u; l++) {
+    code |= (int)inf_bits(b, 1u);
+    if (b.err) return -1;
+    const int cnt = (int)h.count[l];
+    if (code - cnt < first) return (int)h.symbol[index + (code - first)];
+    index += cnt;
+    first += cnt;
+    first <<= 1;
+    code <<= 1;
+  }
+  return -1;
+}
+
+__global__ __launch_bounds__(256) void k_bgzf_inflate(const u8* __restrict__ in, u64 in_bytes, u32 n_blocks,
+                                                      const wga_bgzf_block_dev* __restrict__ blocks, u8* out, u32* status) {
+  __shared__ u16 s_lencnt[4][16], s_lensym[4][288], s_distcnt[4][16], s_distsym[4][32], s_len[4][320];
+  const u32 lane = threadIdx.x & 63u, wave = WGA_WAVE_ID(threadIdx.x);
+  const u64 k = (u64)blockIdx.x * 4 + wave;
+  if (k >= n_blocks || lane != 0u) return; /* one lane decodes; the wave's other lanes have nothing to do */
+  const wga_bgzf_block_dev blk = blocks[k];
+  InfBits b;
+  b.in = in + blk.in_off;
+  b.pos = 0, b.end = blk.in_off + blk.in_len <= in_bytes ? blk.in_len : 0u;
+  b.buf = 0, b.cnt = 0, b.err = 0;
+  u8* const o = out + blk.out_off;
+  const u32 cap = blk.out_len;
+  u32 n_out = 0, err = 0;
+  InfCode lencode, distcode;
+  lencode.count = s_lencnt[wave], lencode.symbol = s_lensym[wave];
+  distcode.count = s_distcnt[wave], distcode.symbol = s_distsym[wave];
+  u16* const length = s_len[wave];
+  u32 last = 0;
+  while (!last && !err && !b.err) {
+    last = inf_bits(b, 1u);
+    const u32 type = inf_bits(b, 2u);
+    if (b.err) break;
+    if (type == 0u) { /* stored (3.2.4): to the next byte boundary, LEN, NLEN, the bytes */
+      b.pos -= b.cnt >> 3; /* whole bytes that were fetched ahead go back */
+      b.buf = 0, b.cnt = 0;
+      if (b.pos + 4u > b.end) {
+        err = WGA_INF_INPUT;
+        break;
+      }
+      const u32 len = (u32)b.in[b.pos] | ((u32)b.in[b.pos + 1] << 8), nlen = (u32)b.in[b.pos + 2] | ((u32)b.in[b.pos + 3] << 8);
+      b.pos += 4u;
+      if (len != (~nlen & 0xFFFFu)) {
+        err = WGA_INF_TYPE;
+        break;
+      }
+      if (b.pos + len > b.end) {
+        err = WGA_INF_INPUT;
+        break;
+      }
+      if (n_out + len > cap) {
+        err = WGA_INF_SIZE;
+        break;
+      }
+      for (u32 j = 0; j < len; j++) o[n_out + j] = b.in[b.pos + j];
+      n_out += len;
+      b.pos += len;
+      continue;
+    }
+    if (type == 3u) {
+      err = WGA_INF_TYPE;
+      break;
+    }
+    if (type == 1u) { /* fixed codes (3.2.6) */
+      u32 sym = 0;
+      for (; sym < 144u; sym++) length[sym] = 8;
+      for (; sym < 256u; sym++) length[sym] = 9;
+      for (; sym < 280u; sym++) length[sym] = 7;
+      for (; sym < 288u; sym++) length[sym] = 8;
+      (void)inf_construct(lencode, length, 288u);
+      for (sym = 0; sym < 30u; sym++) length[sym] = 5;
+      (void)inf_construct(distcode, length, 30u);
+    } else { /* dynamic codes (3.2.7) */
+      const u32 nlen = inf_bits(b, 5u) + 257u, ndist = inf_bits(b, 5u) + 1u, ncode = inf_bits(b, 4u) + 4u;
+      if (b.err) break;
+      if (nlen > 286u || ndist > 30u) {
+        err = WGA_INF_CODES;
+        break;
+      }
+      u32 idx = 0;
+      for (; idx < ncode; idx++) length[k_inf_clorder[idx]] = (u16)inf_bits(b, 3u);
+      for (; idx < 19u; idx++) length[k_inf_clorder[idx]] = 0;
+      if (b.err) break;
+      if (inf_construct(lencode, length, 19u) != 0) { /* the code-length code must be complete */
+        err = WGA_INF_CODES;
+        break;
+      }
+      idx = 0;
+      while (idx < nlen + ndist && !err) {
+        const int sym = inf_decode(b, lencode);
+        if (sym < 0) {
+          err = b.err ? b.err : WGA_INF_SYMBOL;
+          break;
+        }
+        if (sym < 16) {
+          length[idx++] = (u16)sym;
+        } else {
+          u32 prev = 0, rep;
+          if (sym == 16) {
+            if (idx == 0u) {
+              err = WGA_INF_CODES;
+              break;
+            }
+            prev = length[idx - 1u];
+            rep = 3u + inf_bits(b, 2u);
+          } else if (sym == 17) {
+            rep = 3u + inf_bits(b, 3u);
+          } else {
+            rep = 11u + inf_bits(b, 7u);
+          }
+          if (b.err) break;
+          if (idx + rep > nlen + ndist) {
+            err = WGA_INF_CODES;
+            break;
+          }
+          while (rep--) length[idx++] = (u16)prev;
+        }
+      }
+      if (err || b.err) break;
+      if (length[256] == 0u) { /* no end-of-block code */
+        err = WGA_INF_CODES;
+        break;
+      }
+      /* an incomplete set is only allowed when it holds a single code (zlib's rule) */
+      int left = inf_construct(lencode, length, nlen);
+      if (left < 0 || (left > 0 && nlen - lencode.count[0] != 1u)) {
+        err = WGA_INF_CODES;
+        break;
+      }
+      left = inf_construct(distcode, length + nlen, ndist);
+      if (left < 0 || (left > 0 && ndist - distcode.count[0] != 1u)) {
+        err = WGA_INF_CODES;
+        break;
+      }
+    }
+    /* the block's symbols (3.2.3, 3.2.5) */
+    for (;;) {
+      int sym = inf_decode(b, lencode);
+      if (sym < 0) {
+        err = b.err ? b.err : WGA_INF_SYMBOL;
+        break;
+      }
+      if (sym < 256) {
+        if (n_out >= cap) {
+          err = WGA_INF_SIZE;
+          break;
+        }
+        o[n_out++] = (u8)sym;
+        continue;
+      }
+      if (sym == 256) break;
+      sym -= 257;
+      if (sym >= 29) {
+        err = WGA_INF_SYMBOL;
+        break;
+      }
+      const u32 len = (u32)k_inf_lbase[sym] + inf_bits(b, (u32)k_inf_lext[sym]);
+      const int ds = inf_decode(b, distcode);
+      if (ds < 0 || ds >= 30) {
+        err = b.err ? b.err : WGA_INF_SYMBOL;
+        break;
+      }
+      const u32 dist = (u32)k_inf_dbase[ds] + inf_bits(b, (u32)k_inf_dext[ds]);
+      if (b.err) break;
+      if (dist > n_out) {
+        err = WGA_INF_DIST;
+        break;
+      }
+      if (n_out + len > cap) {
+        err = WGA_INF_SIZE;
+        break;
+      }
+      for (u32 j = 0; j < len; j++) o[n_out + j] = o[n_out + j - dist]; /* byte by byte: the ranges may overlap */
+      n_out += len;
+    }
+  }
+  if (!err) err = b.err;
+  if (!err && n_out != cap) err = WGA_INF_SIZE;
+  status[k] = err;
+}
+
 #endif /* WGA_KERNELS3_H */

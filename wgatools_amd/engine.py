@@ -264,6 +264,10 @@ class Engine:
         return (DeviceArray(self, ptr.value, (int(arena_bytes),), np.uint8), [float(x) for x in ms][:max(1, candidates)],
                 chosen.value)
 
+    def bgzf_inflate(self, d_in, in_bytes, n_blocks, blocks, out, status):
+        """BGZF members inflated on the device (wga_bgzf_inflate); blocks: n x (in_off u64, in_len u32, out_len u32, out_off u64)"""
+        self._check(self.lib.wga_bgzf_inflate(self.ctx, _p(d_in), int(in_bytes), int(n_blocks), _p(blocks), _p(out), _p(status)))
+
     def scatter_bytes(self, n, src, src_off, dst, dst_off):
         self._check(self.lib.wga_scatter_bytes(self.ctx, n, _p(src), _p(src_off), _p(dst),
                                                _p(dst_off)))

@@ -105,6 +105,38 @@ bool bgzf_blocks(const std::string& img, std::vector<BgzfBlock>& blocks, size_t*
 }
 }  // namespace
 
+bool read_bgzf_image(const std::string& path, std::string& img, std::vector<BgzfMember>& members, uint64_t* total) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) fail("File path `" + path + "` not exist"); /* errors.rs:13 */
+  unsigned char magic[4] = {0, 0, 0, 0};
+  const size_t got = fread(magic, 1, 4, f);
+  if (!(got == 4 && magic[0] == 31 && magic[1] == 139 && magic[2] == 8 && (magic[3] & 4))) {
+    fclose(f);
+    return false;
+  }
+  fseek(f, 0, SEEK_END);
+  const long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  img.resize(sz > 0 ? (size_t)sz : 0);
+  const bool ok = img.empty() || fread(&img[0], 1, img.size(), f) == img.size();
+  fclose(f);
+  if (!ok) fail("IO error:short read of `" + path + "`");
+  std::vector<BgzfBlock> blocks;
+  size_t out = 0;
+  if (!bgzf_blocks(img, blocks, &out)) {
+    img.clear();
+    return false;
+  }
+  members.clear();
+  for (const BgzfBlock& k : blocks) {
+    if (k.isize == 0) continue; /* the EOF marker */
+    if (k.clen > 0xFFFFFFFFull || k.isize > 0xFFFFFFFFull) return false;
+    members.push_back(BgzfMember{(uint64_t)k.cdata, (uint32_t)k.clen, (uint32_t)k.isize, (uint64_t)k.out});
+  }
+  *total = (uint64_t)out;
+  return true;
+}
+
 std::string read_all_parallel(const std::string& path) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) fail("File path `" + path + "` not exist"); /* errors.rs:13 */

@@ -40,6 +40,14 @@ std::string read_all(const std::string* path); /* nullptr = stdin */
 /* the same bytes for a file; a BGZF file (`all.fa.gz` next to its .gzi / .fai, pseudomaf.rs:222) is inflated block by
  * block on all host cores — its blocks are independent gzip members */
 std::string read_all_parallel(const std::string& path);
+/* a BGZF file as it is, with its members' table (deflate stream offset / length, ISIZE, output offset per member) for the
+ * device inflater (wga_bgzf_inflate): false when the file is not BGZF from end to end (then nothing is returned) */
+struct BgzfMember {
+  uint64_t in_off;
+  uint32_t in_len, out_len;
+  uint64_t out_off;
+};
+bool read_bgzf_image(const std::string& path, std::string& img, std::vector<BgzfMember>& members, uint64_t* total);
 struct Output {
   std::string path;
   void* gz = nullptr;

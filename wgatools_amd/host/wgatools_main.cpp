@@ -362,17 +362,63 @@ struct DevFasta {
       have_host = true;
       return;
     }
-    std::string text = read_all_parallel(path);
-    uint8_t* d_text = d.upload((const uint8_t*)text.data(), text.size());
+    /* a bgzipped FASTA goes to the device compressed and is inflated there, block by block (wga_bgzf_inflate): the text never
+     * exists on the host; WGA_BGZF_DEVICE=0 keeps the host threads' inflate */
+    std::string text;
+    uint8_t* d_text = nullptr;
+    uint64_t n_text = 0;
+    bool on_device_text = false;
+    {
+      const char* e = getenv("WGA_BGZF_DEVICE");
+      std::string img;
+      std::vector<BgzfMember> members;
+      if (!(e && atoi(e) == 0) && read_bgzf_image(path, img, members, &n_text) && n_text < 0xFFFFFFF0ull) {
+        static_assert(sizeof(BgzfMember) == sizeof(wga_bgzf_block), "wga_bgzf_block layout");
+        img.append(16, '\0');
+        const uint8_t* d_img = d.upload((const uint8_t*)img.data(), img.size());
+        const wga_bgzf_block* d_mem = (const wga_bgzf_block*)d.upload(members.data(), members.size());
+        d_text = (uint8_t*)d.alloc(n_text + 64);
+        auto* d_st = (uint32_t*)d.alloc(members.size() * 4 + 4);
+        d.check(wga_bgzf_inflate(d.ctx, d_img, img.size() - 16, (uint32_t)members.size(), d_mem, d_text, d_st));
+        std::vector<uint32_t> st(members.size());
+        if (!st.empty()) d.download(st.data(), (const uint32_t*)d_st, st.size());
+        for (uint32_t v : st)
+          if (v) fail("IO error:corrupt BGZF block in `" + path + "`");
+        d.release(d_st);
+        d.release((void*)d_mem);
+        d.release((void*)d_img);
+        on_device_text = true;
+      }
+    }
+    if (!on_device_text) {
+      text = read_all_parallel(path);
+      n_text = text.size();
+      d_text = d.upload((const uint8_t*)text.data(), text.size());
+    }
     uint64_t nc = 0, nb = 0;
-    d.check(wga_fasta_pool(d.ctx, d_text, text.size(), &nc, &nb, nullptr, nullptr));
+    d.check(wga_fasta_pool(d.ctx, d_text, n_text, &nc, &nb, nullptr, nullptr));
     d_pool = (uint8_t*)d.alloc(nb + 64);
     auto* d_tab = (wga_fa_contig*)d.alloc((nc + 1) * sizeof(wga_fa_contig));
-    d.check(wga_fasta_pool(d.ctx, d_text, text.size(), &nc, &nb, d_pool, d_tab));
+    d.check(wga_fasta_pool(d.ctx, d_text, n_text, &nc, &nb, d_pool, d_tab));
     std::vector<wga_fa_contig> tab(nc);
     if (nc) d.download(tab.data(), (const wga_fa_contig*)d_tab, nc);
     static_assert(sizeof(wga_fa_contig) == 4 * sizeof(uint64_t), "wga_fa_contig layout");
-    idx.set_table(text, (const uint64_t*)tab.data(), nc);
+    if (on_device_text) { /* the names: only the header lines come back, one behind the other */
+      std::string hdrs;
+      std::vector<wga_fa_contig> t2(tab);
+      for (size_t k = 0; k < nc; k++) {
+        const uint64_t hs = tab[k].hdr_start, he = tab[k].hdr_end;
+        const size_t at = hdrs.size();
+        hdrs.resize(at + (size_t)(he - hs) + 1);
+        if (he > hs) d.download((uint8_t*)&hdrs[at], (const uint8_t*)d_text + hs, (size_t)(he - hs));
+        hdrs[at + (size_t)(he - hs)] = '\n';
+        t2[k].hdr_start = at;
+        t2[k].hdr_end = at + (he - hs);
+      }
+      idx.set_table(hdrs, (const uint64_t*)t2.data(), nc);
+    } else {
+      idx.set_table(text, (const uint64_t*)tab.data(), nc);
+    }
     bytes = nb;
     d.release(d_tab);
     d.release(d_text);
