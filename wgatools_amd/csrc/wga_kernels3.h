@@ -264,15 +264,38 @@ static __device__ const u16 k_inf_dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 
 static __device__ const u8 k_inf_dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 static __device__ const u8 k_inf_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
+/* The bit stream: `buf` holds the next cnt bits; the four bytes behind them were loaded when the four before were taken
+ * (`ahead`), so that the load's latency passes under the decoding of the bits already there; pos = the next byte to load. */
+typedef u32 u32_a1 __attribute__((aligned(1)));
 struct InfBits {
   const u8* in;
   u32 pos, end;
   u64 buf;
   u32 cnt, err;
+  u32 ahead, have_ahead;
 };
+__device__ __forceinline__ void inf_prime(InfBits& b) { /* start (or restart) the look-ahead at pos */
+  b.have_ahead = 0u;
+  if (b.pos + 4u <= b.end) {
+    b.ahead = *(const u32_a1*)(b.in + b.pos);
+    b.pos += 4u;
+    b.have_ahead = 1u;
+  }
+}
+__device__ __forceinline__ void inf_refill(InfBits& b) {
+  if (b.cnt <= 32u && b.have_ahead) {
+    b.buf |= (u64)b.ahead << b.cnt;
+    b.cnt += 32u;
+    inf_prime(b);
+  }
+}
 __device__ __forceinline__ u32 inf_bits(InfBits& b, u32 n) { /* n <= 16 bits, least significant first (3.1.1) */
   while (b.cnt < n) {
-    if (b.pos >= b.end) {
+    if (b.have_ahead) {
+      inf_refill(b);
+      continue;
+    }
+    if (b.pos >= b.end) { /* the last one to three bytes come one by one */
       b.err = b.err ? b.err : WGA_INF_INPUT;
       return 0u;
     }
@@ -307,6 +330,39 @@ __device__ __forceinline__ int inf_construct(InfCode h, const u16* length, u32 n
     if (length[k]) h.symbol[offs[length[k]]++] = (u16)k;
   return left;
 }
+/* first-level table of a code: the WGA_INF_FAST bits in front of the stream, as they lie there (a code's bits arrive most
+ * significant first, 3.1.1: the index is the code reversed, and every pattern behind it), -> symbol << 4 | length; 0 for
+ * patterns whose code is longer (decoded bit by bit) or that no code has */
+#define WGA_INF_FAST 9u
+__device__ __forceinline__ void inf_fast_table(InfCode h, u16* fast) {
+  for (u32 k = 0; k < (1u << WGA_INF_FAST); k++) fast[k] = 0;
+  u32 code = 0, index = 0;
+  for (u32 l = 1; l <= WGA_INF_FAST; l++) {
+    code <<= 1;
+    const u32 cnt = h.count[l];
+    for (u32 j = 0; j < cnt; j++, code++, index++) {
+      u32 rev = 0;
+      for (u32 t = 0; t < l; t++) rev |= ((code >> t) & 1u) << (l - 1u - t);
+      const u16 e = (u16)((u32)h.symbol[index] << 4 | l);
+      for (u32 x = rev; x < (1u << WGA_INF_FAST); x += 1u << l) fast[x] = e;
+    }
+  }
+}
+__device__ __forceinline__ int inf_decode(InfBits& b, InfCode h);
+/* one symbol through the first-level table when the stream holds enough bits for it, else bit by bit */
+__device__ __forceinline__ int inf_decode_fast(InfBits& b, InfCode h, const u16* fast) {
+  inf_refill(b);
+  if (b.cnt >= WGA_INF_FAST) {
+    const u32 e = fast[(u32)b.buf & ((1u << WGA_INF_FAST) - 1u)];
+    if (e) {
+      const u32 l = e & 15u;
+      b.buf >>= l;
+      b.cnt -= l;
+      return (int)(e >> 4);
+    }
+  }
+  return inf_decode(b, h);
+}
 __device__ __forceinline__ int inf_decode(InfBits& b, InfCode h) { /* one symbol, or -1 */
   int code = 0, first = 0, index = 0;
   for (u32 l = 1; l < 16u; l++) {
@@ -324,7 +380,7 @@ __device__ __forceinline__ int inf_decode(InfBits& b, InfCode h) { /* one symbol
 
 __global__ __launch_bounds__(256) void k_bgzf_inflate(const u8* __restrict__ in, u64 in_bytes, u32 n_blocks,
                                                       const wga_bgzf_block_dev* __restrict__ blocks, u8* out, u32* status) {
-  __shared__ u16 s_lencnt[4][16], s_lensym[4][288], s_distcnt[4][16], s_distsym[4][32], s_len[4][320];
+  __shared__ u16 s_lencnt[4][16], s_lensym[4][288], s_distcnt[4][16], s_distsym[4][32], s_len[4][320], s_fast[4][1u << WGA_INF_FAST];
   const u32 lane = threadIdx.x & 63u, wave = WGA_WAVE_ID(threadIdx.x);
   const u64 k = (u64)blockIdx.x * 4 + wave;
   if (k >= n_blocks || lane != 0u) return; /* one lane decodes; the wave's other lanes have nothing to do */
@@ -333,6 +389,7 @@ __global__ __launch_bounds__(256) void k_bgzf_inflate(const u8* __restrict__ in,
   b.in = in + blk.in_off;
   b.pos = 0, b.end = blk.in_off + blk.in_len <= in_bytes ? blk.in_len : 0u;
   b.buf = 0, b.cnt = 0, b.err = 0;
+  inf_prime(b);
   u8* const o = out + blk.out_off;
   const u32 cap = blk.out_len;
   u32 n_out = 0, err = 0;
@@ -340,14 +397,15 @@ __global__ __launch_bounds__(256) void k_bgzf_inflate(const u8* __restrict__ in,
   lencode.count = s_lencnt[wave], lencode.symbol = s_lensym[wave];
   distcode.count = s_distcnt[wave], distcode.symbol = s_distsym[wave];
   u16* const length = s_len[wave];
+  u16* const fast = s_fast[wave];
   u32 last = 0;
   while (!last && !err && !b.err) {
     last = inf_bits(b, 1u);
     const u32 type = inf_bits(b, 2u);
     if (b.err) break;
     if (type == 0u) { /* stored (3.2.4): to the next byte boundary, LEN, NLEN, the bytes */
-      b.pos -= b.cnt >> 3; /* whole bytes that were fetched ahead go back */
-      b.buf = 0, b.cnt = 0;
+      b.pos -= (b.cnt >> 3) + (b.have_ahead ? 4u : 0u); /* whole bytes that were fetched ahead go back */
+      b.buf = 0, b.cnt = 0, b.have_ahead = 0u;
       if (b.pos + 4u > b.end) {
         err = WGA_INF_INPUT;
         break;
@@ -369,6 +427,7 @@ __global__ __launch_bounds__(256) void k_bgzf_inflate(const u8* __restrict__ in,
       for (u32 j = 0; j < len; j++) o[n_out + j] = b.in[b.pos + j];
       n_out += len;
       b.pos += len;
+      inf_prime(b);
       continue;
     }
     if (type == 3u) {
@@ -448,8 +507,9 @@ __global__ __launch_bounds__(256) void k_bgzf_inflate(const u8* __restrict__ in,
       }
     }
     /* the block's symbols (3.2.3, 3.2.5) */
+    inf_fast_table(lencode, fast);
     for (;;) {
-      int sym = inf_decode(b, lencode);
+      int sym = inf_decode_fast(b, lencode, fast);
       if (sym < 0) {
         err = b.err ? b.err : WGA_INF_SYMBOL;
         break;
