@@ -417,6 +417,23 @@ def check_pafcov_long_ops(eng):
     check_pafcov(eng, b, [0, 0, 1, 1, 1], [100, 8192 * 3 - 1, 0, 50000, 150000], [600000, 250000], split=True)
 
 
+def check_pafcov_look_back(eng):
+    rng = np.random.default_rng(77)
+    lens = [1024, 1, 2048 + 5, 70 * 1024 + 17, 3, 1019, 1024 * 3, 2, 5000, 1024 - 5]     # ops per record
+    recs = []
+    for n_ops in lens:
+        code = rng.choice(np.array([7, 7, 7, 8, 1, 2, 0, 3, 4], dtype=np.uint32), n_ops)
+        ln = rng.integers(0, 9, n_ops).astype(np.uint32)
+        recs.append((ln << 4) | code)
+    ops = np.concatenate(recs)
+    off = np.cumsum([0] + lens).astype(np.uint64)
+    n = len(lens)
+    b = dict(ops=ops, op_off=off, strand_neg=np.zeros(n, dtype=np.uint8))
+    tid = [0, 1, 0, 1, 0, 0, 1, 1, 0, 1]
+    check_pafcov(eng, b, tid, [0, 5, 100, 40, 9000, 20000, 250000, 7, 30000, 100], [60000, 300000])
+    check_pafcov(eng, b, tid, [0, 5, 100, 40, 9000, 20000, 250000, 7, 30000, 100], [60000, 300000], split=True)
+
+
 def check_pafcov(eng, b, target_id, t_start, target_len, align=4, split=False):
     n = len(b["strand_neg"])
     nt = len(target_len)

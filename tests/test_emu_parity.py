@@ -200,6 +200,20 @@ def test_pafcov_ops_across_many_windows(emu):
     pc.check_pafcov_long_ops(emu)
 
 
+def test_pafcov_look_back(emu, monkeypatch):
+    """K5's list pass: a tile's first segment takes its record's position from the sums the tiles in front of it published —
+    records across 2 .. 70 tiles (more than one round of 64 lanes), tiles that end exactly with a record, and the same with the
+    look-back told to add up the ops itself (what it does when a tile in front has not published in time)"""
+    pc.check_pafcov_look_back(emu)
+    monkeypatch.setenv("WGA_COV_SPIN_LIMIT", "0")
+    from conftest import _emu_engine
+    eng = _emu_engine()
+    try:
+        pc.check_pafcov_look_back(eng)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("base", [0, 1])
 @pytest.mark.parametrize("seed,n,mean", [(1, 20, 60), (2, 150, 4), (3, 3, 2600)])
 def test_pafpseudo(emu, base, seed, n, mean):

@@ -416,6 +416,11 @@ def test_pafcov_ops_across_many_windows(gpu):
     pc.check_pafcov_long_ops(gpu)
 
 
+def test_pafcov_look_back(gpu):
+    """K5's list pass: tile sums by look-back over records of 2 .. 70 tiles (tests/parity_cases.py)"""
+    pc.check_pafcov_look_back(gpu)
+
+
 def test_pafcov_format(gpu):
     rng = np.random.default_rng(3)
     pc.check_pafcov_format(gpu, b"chr1", [0, 1, 9, 10, 99, 100, 2147483647, 12345], 0)

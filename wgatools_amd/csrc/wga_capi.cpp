@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <string>
+#include <vector>
 
 #include "wga_kernels.h"
 #include "wga_kernels_k2w.h"
@@ -74,6 +75,9 @@ struct wga_ctx {
   } op_tab;
   void* cov_pieces = nullptr; /* pafcov: (window, piece) list, grow-only */
   u64 cov_pieces_cap = 0;
+  void* cov_list = nullptr;   /* pafcov: the pieces as the list pass writes them (WGA_COV_LISTS regions of cov_list_rcap) */
+  u64 cov_list_rcap = 0;
+  u32 cov_spin_limit = 1u << 16; /* polls of a tile sum before the look-back adds up the ops itself (WGA_COV_SPIN_LIMIT) */
   /* optional per-launch timing of the expand kernel proper (events on the launch stream) */
   static const int kTimingRing = 64;
   bool timing = false;
@@ -402,6 +406,7 @@ int wga_ctx_create(int device, wga_ctx** out) {
   c->stream = c->own_stream;
   /* A/B switch for measurements: WGA_EXPAND_VARIANT=0 selects v1 of the paf2maf row kernel (wga_ctx_set_param overrides) */
   if (const char* v = getenv("WGA_EXPAND_VARIANT")) c->expand_variant = (atoi(v) == 0 || atoi(v) == 2) ? atoi(v) : -1;
+  if (const char* v = getenv("WGA_COV_SPIN_LIMIT")) c->cov_spin_limit = (u32)strtoul(v, nullptr, 10);
   if (const char* v = getenv("WGA_EXPAND_AUTOTUNE")) c->expand_autotune = atoi(v) != 0;
   if (const char* v = getenv("WGA_EXPAND_DRAIN_MIN")) {
     const int d = atoi(v);
@@ -420,6 +425,7 @@ void wga_ctx_destroy(wga_ctx* c) {
   if (c->tune.have_ev) rt_event_destroy(c->tune.ev[0]), rt_event_destroy(c->tune.ev[1]);
   if (c->scratch) (void)rt_free(c->scratch);
   if (c->cov_pieces) (void)rt_free(c->cov_pieces);
+  if (c->cov_list) (void)rt_free(c->cov_list);
   if (c->op_tab.mem) (void)rt_free(c->op_tab.mem);
   rt_stream_destroy(c->own_stream);
   delete c;
@@ -1451,31 +1457,60 @@ int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* 
   if (b->n == 0 || b->n_ops == 0) return WGA_OK;
   if (!d_target_id || !d_t_start || !d_cov_off || !d_cov_len || !d_cov)
     return fail(WGA_E_INVALID_ARG, "null array", nullptr);
-  u64 nt = n_tiles(b->n_ops);
-  void* ws;
-  {
-    const u64 nw0 = (total_cov >> WGA_COV_WIN_SHIFT) + 1;
-    const size_t bytes = (size_t)nt * sizeof(wga_tile_sum) + (size_t)nw0 * 4 + 16 + ((size_t)nw0 + 1) * 8 +
-                         ((size_t)(nw0 + 1023) / 1024 + 2) * 8;
-    if ((rc = ctx_scratch(c, bytes, &ws))) return rc;
-  }
-  wga_tile_sum* tiles = (wga_tile_sum*)ws;
-  u32 grid = (u32)((nt + 3) / 4);
-  WGA_LAUNCH(k_class_tiles, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off, b->n,
-             (u64)b->n_ops, tiles, (wga_class_sums*)nullptr);
-  LAUNCH_CHECK();
-  /* pieces per window: count, scan, fill; then one block per window (see wga_kernels2.h K5) */
   if (total_cov == 0) return WGA_OK;
+  const u64 nt = n_tiles(b->n_ops);
   const u64 nw = (total_cov >> WGA_COV_WIN_SHIFT) + 1;
   if (nw > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "coverage arrays too large for one call", nullptr);
-  u32* win_cnt = (u32*)(tiles + nt);
-  u64* win_off = (u64*)(((uintptr_t)(win_cnt + nw) + 15) & ~(uintptr_t)15);
-  RT_CHECK(rt_memset(win_cnt, 0, (size_t)nw * sizeof(u32), c->stream));
-  WGA_LAUNCH(k_cov_pieces<false>, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off,
-             (u64)b->n_ops, (const wga_tile_sum*)tiles, d_target_id, (const u64*)d_t_start,
-             (const u64*)d_cov_off, (const u64*)d_cov_len, win_cnt, (const u64*)nullptr,
-             (wga_cov_piece*)nullptr);
+  /* One pass lists every (tile, record segment, window) piece (see wga_kernels2.h K5): tile sums by look-back, a place in the
+   * window from win_cnt, the piece itself into one of WGA_COV_LISTS list regions.  The regions are as large as the last call
+   * needed them (+ 25 %): a first call, or a batch that overflows one, only counts and is run again. */
+  void* ws;
+  const size_t b_tail = (size_t)nt * 8, b_lcnt = (size_t)WGA_COV_LISTS * 8, b_wcnt = (((size_t)nw * 4) + 15) & ~(size_t)15;
+  const size_t b_woff = (((size_t)nw + 1) * 8 + ((size_t)(nw + 1023) / 1024 + 2) * 8 + 15) & ~(size_t)15;
+  {
+    const size_t bytes = b_tail + b_lcnt + b_wcnt + b_woff + (size_t)nt * sizeof(wga_tile_rec) + (size_t)b->n * sizeof(wga_cov_rec);
+    if ((rc = ctx_scratch(c, bytes, &ws))) return rc;
+  }
+  u64* tile_tail = (u64*)ws;
+  u64* list_cnt = tile_tail + nt;
+  u32* win_cnt = (u32*)(list_cnt + WGA_COV_LISTS);
+  u64* win_off = (u64*)((char*)win_cnt + b_wcnt);
+  wga_tile_rec* tile_rec = (wga_tile_rec*)((char*)win_off + b_woff);
+  wga_cov_rec* rec_pos = (wga_cov_rec*)(tile_rec + nt);
+  const u32 grid = (u32)((nt + 3) / 4);
+  /* what a segment needs of its record, one load away: the record of every tile's first op, every record's place in the
+   * coverage index space */
+  WGA_LAUNCH(k_tile_rec, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const u64*)b->d_op_off, b->d_strand_neg, b->n,
+             (u64)b->n_ops, tile_rec);
   LAUNCH_CHECK();
+  WGA_LAUNCH(k_cov_rec_pos, (b->n + WGA_BLOCK - 1) / WGA_BLOCK, WGA_BLOCK, c->stream, b->n, d_target_id, (const u64*)d_t_start,
+             (const u64*)d_cov_off, (const u64*)d_cov_len, rec_pos);
+  LAUNCH_CHECK();
+  std::vector<u64> h_cnt(WGA_COV_LISTS);
+  u64 n_pieces = 0;
+  for (int attempt = 0;; attempt++) {
+    RT_CHECK(rt_memset(ws, 0, b_tail + b_lcnt + b_wcnt, c->stream));
+    WGA_LAUNCH(k_cov_list_pieces, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off, (u64)b->n_ops,
+               (const wga_tile_rec*)tile_rec, (const wga_cov_rec*)rec_pos, tile_tail, win_cnt, list_cnt,
+               (wga_cov_piece*)c->cov_list, (u64)c->cov_list_rcap, (u32)c->cov_spin_limit);
+    LAUNCH_CHECK();
+    RT_CHECK(rt_d2h(h_cnt.data(), list_cnt, b_lcnt, c->stream));
+    u64 most = 0;
+    n_pieces = 0;
+    for (u64 v : h_cnt) {
+      n_pieces += v;
+      if (v > most) most = v;
+    }
+    if (most <= c->cov_list_rcap) break;
+    if (attempt) return fail(WGA_E_HIP, "pafcov: the list regions overflow a second time", nullptr);
+    if (c->cov_list) RT_CHECK(rt_free(c->cov_list));
+    c->cov_list = nullptr;
+    c->cov_list_rcap = 0;
+    const u64 rcap = most + most / 4 + 16;
+    RT_CHECK(rt_malloc(&c->cov_list, (size_t)rcap * WGA_COV_LISTS * sizeof(wga_cov_piece)));
+    c->cov_list_rcap = rcap;
+  }
+  if (n_pieces == 0) return WGA_OK;
   {
     /* run_scan uses the context scratch itself: give it its own small buffer behind win_off */
     ScanU32 f;
@@ -1493,9 +1528,6 @@ int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* 
       LAUNCH_CHECK();
     }
   }
-  u64 n_pieces = 0;
-  RT_CHECK(rt_d2h(&n_pieces, win_off + nw, sizeof(u64), c->stream));
-  if (n_pieces == 0) return WGA_OK;
   if (c->cov_pieces_cap < n_pieces) {
     if (c->cov_pieces) RT_CHECK(rt_free(c->cov_pieces));
     c->cov_pieces = nullptr;
@@ -1503,12 +1535,12 @@ int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* 
     RT_CHECK(rt_malloc(&c->cov_pieces, (size_t)(n_pieces + n_pieces / 4) * sizeof(wga_cov_piece)));
     c->cov_pieces_cap = n_pieces + n_pieces / 4;
   }
-  RT_CHECK(rt_memset(win_cnt, 0, (size_t)nw * sizeof(u32), c->stream));
-  WGA_LAUNCH(k_cov_pieces<true>, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off,
-             (u64)b->n_ops, (const wga_tile_sum*)tiles, d_target_id, (const u64*)d_t_start,
-             (const u64*)d_cov_off, (const u64*)d_cov_len, win_cnt, (const u64*)win_off,
-             (wga_cov_piece*)c->cov_pieces);
-  LAUNCH_CHECK();
+  {
+    dim3 pgrid((u32)((c->cov_list_rcap + WGA_BLOCK - 1) / WGA_BLOCK), WGA_COV_LISTS, 1);
+    WGA_LAUNCH(k_cov_place_pieces, pgrid, WGA_BLOCK, c->stream, (const u64*)list_cnt, (const wga_cov_piece*)c->cov_list,
+               (u64)c->cov_list_rcap, (const u64*)win_off, (wga_cov_piece*)c->cov_pieces);
+    LAUNCH_CHECK();
+  }
   WGA_LAUNCH(k_cov_windows, (u32)nw, WGA_BLOCK, c->stream, b->d_ops, (u64)b->n_ops,
              (const wga_cov_piece*)c->cov_pieces, (const u64*)win_off, (int*)d_cov);
   LAUNCH_CHECK();

@@ -120,24 +120,31 @@ __global__ __launch_bounds__(256) void k_class_tiles(const u32* __restrict__ ops
  * (scripts/micro/atomic_scope.hip), i.e. 19 ms for the 5e8 marks of configs[1].  So the marks are
  * not sent to memory one by one: the coverage index space is cut into windows of WGA_COV_WIN
  * counters, every (tile, record segment) piece is listed under the windows it touches
- * (k_cov_pieces: count, scan, fill), and one block per window replays its pieces with LDS
+ * (k_cov_list_pieces in ONE pass over the ops: tile sums by look-back, places from counters; then a scan of the window counts and
+ * k_cov_place_pieces), and one block per window replays its pieces with LDS
  * atomics and adds the window to memory with plain stores — it is the only writer. */
 #define WGA_COV_WIN_SHIFT 13u
 #define WGA_COV_WIN (1u << WGA_COV_WIN_SHIFT)
 
-struct wga_cov_piece {
+struct __attribute__((aligned(16))) wga_cov_piece {
   u32 g;       /* tile */
   u32 ab;      /* first op | end op << 16, tile-relative (<= 1024): the ops of the record segment whose marks can lie in the
                   window the piece is listed under (whole lanes of 16 ops) */
   u64 pos0;    /* coverage index (cov_off + target position) in front of op `first` */
   u64 limit;   /* coverage index one past the target's last counter */
+  u32 wi;      /* window the piece is listed under */
+  u32 slot;    /* its place among that window's pieces */
 };
-__device__ __forceinline__ u64 cov_incl_scan_u64(u64 v, u32 lane) {
-  for (u32 d = 1; d < 64; d <<= 1) {
-    const u64 t = __shfl_up(v, d);
-    if (lane >= d) v += t;
-  }
-  return v;
+/* The list pass writes its pieces where WGA_COV_LISTS counters hand out places (tile g uses counter g mod WGA_COV_LISTS: one
+ * counter for all tiles would take every segment of the batch through one address), each over a region of `rcap` pieces. */
+#define WGA_COV_LISTS 4096u
+#define WGA_COV_READY (1ull << 63)
+/* inclusive scan over the lanes of a value below 2^40 (a lane's 16 ops advance less than 16 x 2^28), and the wave's total: two
+ * 32-bit DPP scans, on the low 24 bits and on the rest */
+__device__ __forceinline__ u64 cov_incl_scan_u64(u64 v, u64& total) {
+  const u32 lo = wave_incl_scan_u32((u32)v & 0xFFFFFFu), hi = wave_incl_scan_u32((u32)(v >> 24));
+  total = (u64)wave_last_u32(lo) + ((u64)wave_last_u32(hi) << 24);
+  return (u64)lo + ((u64)hi << 24);
 }
 
 /* 16 consecutive ops per lane of tile g, zero-filled beyond the stream */
@@ -171,76 +178,188 @@ __device__ __forceinline__ u64 cov_lane_moves(const u32 w[16], u32 lane, u32 a, 
   return mv;
 }
 
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_cov_pieces(
-    const u32* __restrict__ ops, const u64* __restrict__ op_off, u64 n_ops,
-    const wga_tile_sum* __restrict__ tiles, const u32* __restrict__ target_id,
-    const u64* __restrict__ t_start, const u64* __restrict__ cov_off,
-    const u64* __restrict__ cov_len, u32* win_cnt, const u64* __restrict__ win_off,
-    wga_cov_piece* pieces) {
+/* Target advance of record r's ops in front of tile g (the record starts at op rs, in tile g0 = rs / WGA_TILE): the tail sums the
+ * tiles g0 .. g-1 published (every one of them ends inside the record, so its last segment is the record's part of it).  Those tiles
+ * belong to blocks of the same launch with lower indices, which were dispatched before this one; should one of them not have
+ * published after `spin_limit` polls (or with a limit of 0: at once), the ops themselves are added up — the pass ends whatever
+ * the dispatch order is. */
+__device__ __forceinline__ u64 cov_look_back(u64* tile_tail, const u32* __restrict__ ops, u64 rs, u64 g, u32 lane,
+                                             u32 spin_limit) {
+  const u64 g0 = rs / WGA_TILE;
+  u64 p = 0;
+  bool gave_up = spin_limit == 0; /* wave-uniform */
+  for (u64 k0 = g0; k0 < g && !gave_up; k0 += 64) {
+    const u64 k = k0 + lane;
+    const bool mine = k < g;
+    u64 v = 0;
+    u32 polls = 0;
+    for (;;) {
+      if (mine && !(v & WGA_COV_READY)) v = atomicAdd((unsigned long long*)&tile_tail[k], 0ull);
+      if (!__ballot(mine && !(v & WGA_COV_READY))) break;
+      if (++polls > spin_limit) {
+        gave_up = true;
+        break;
+      }
+    }
+    p += mine ? (v & ~WGA_COV_READY) : 0ull;
+  }
+  if (!gave_up) return wave_sum_u64(p);
+  u64 q = 0;
+  for (u64 i = rs + lane; i < g * WGA_TILE; i += 64) {
+    const u32 op = ops[i];
+    const u32 cls = op_class(op & 15u);
+    q += (cls == CLS_MX || cls == CLS_D || cls == CLS_O) ? (u64)(op >> 4) : 0ull;
+  }
+  return wave_sum_u64(q);
+}
+
+/* where a record stands in the coverage index space: its first base, and one past its target's last counter */
+struct wga_cov_rec {
+  u64 pos0, limit;
+};
+__global__ __launch_bounds__(256) void k_cov_rec_pos(u32 n, const u32* __restrict__ target_id, const u64* __restrict__ t_start,
+                                                     const u64* __restrict__ cov_off, const u64* __restrict__ cov_len,
+                                                     wga_cov_rec* __restrict__ rec_pos) {
+  const u32 r = blockIdx.x * WGA_BLOCK + threadIdx.x;
+  if (r >= n) return;
+  const u32 tg = target_id[r];
+  const u64 coff = cov_off[tg];
+  wga_cov_rec rp;
+  rp.pos0 = coff + t_start[r];
+  rp.limit = coff + cov_len[tg];
+  rec_pos[r] = rp;
+}
+
+/* The list pass: one wave per tile of 1024 ops.  Every record segment of the tile is measured (target advance per lane, scanned),
+ * the tile's last segment is published for the tiles behind it, the first segment looks back for where its record stands, and
+ * every (segment, window) piece takes a place in its window (win_cnt) and is written to the tile's list region.  Segments other
+ * than the first start with their record, so only the first one waits — and it is handled last.  What a segment needs of its
+ * record (k_tile_rec for the tile's first one, op_off and k_cov_rec_pos's pair for the others) is one load away and fetched a
+ * segment ahead: the pass is bound by its chains of dependent loads, not by the 4 bytes per op.  `rcap` = 0 only counts. */
+__global__ __launch_bounds__(256) void k_cov_list_pieces(
+    const u32* __restrict__ ops, const u64* __restrict__ op_off, u64 n_ops, const wga_tile_rec* __restrict__ tile_rec,
+    const wga_cov_rec* __restrict__ rec_pos, u64* tile_tail, u32* win_cnt, u64* list_cnt, wga_cov_piece* list, u64 rcap,
+    u32 spin_limit) {
   const u32 lane = threadIdx.x & 63u;
   const u64 g = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
   const u64 tile_start = g * WGA_TILE;
   if (tile_start >= n_ops) return;
   const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
   const u32 nt = (u32)(tile_end - tile_start);
+  const wga_tile_rec tr = tile_rec[g];
   u32 w[16];
   cov_load_ops(ops, tile_start, nt, lane, w);
-  u32 r = (u32)tiles[g].rec;
-  u64 cur = tile_start;
-  while (cur < tile_end) {
-    u64 re = op_off[r + 1];
-    while (re <= cur) {
-      r++;
-      re = op_off[r + 1];
-    }
-    const u64 rs = op_off[r];
-    const u64 seg_end = re < tile_end ? re : tile_end;
-    const u32 a = (u32)(cur - tile_start), b = (u32)(seg_end - tile_start);
-    /* where every lane's 16 ops start and end on the target (monotone over the lanes; lanes outside [a, b) are empty) */
-    const u64 mv = cov_lane_moves(w, lane, a, b);
-    const u64 inc = cov_incl_scan_u64(mv, lane);
-    const u64 span = WGA_UNI64(__shfl(inc, 63));
-    u64 base = 0;
-    if (rs < tile_start) { /* wave-uniform: target advance of the record before this tile */
-      const u64 g0 = rs / WGA_TILE;
-      u64 p = 0;
-      for (u64 k = g0 + lane; k < g; k += 64) {
-        const u64* v = (k == g0) ? tiles[k].tail : tiles[k].tot;
-        p += v[CLS_MX] + v[CLS_D] + v[CLS_O];
+  const u32 region = (u32)(g % WGA_COV_LISTS);
+  u64* const my_cnt = list_cnt + region;
+  wga_cov_piece* const my_list = list + (u64)region * rcap;
+
+  /* where every lane's 16 ops start and end on the target (monotone over the lanes; lanes outside [a, b) are empty) */
+  auto measure = [&](u32 a, u32 b, u64& mv, u64& inc, u64& span) {
+    mv = cov_lane_moves(w, lane, a, b);
+    inc = cov_incl_scan_u64(mv, span);
+  };
+  auto publish = [&](u64 span) {
+    if (lane == 0) atomicAdd((unsigned long long*)&tile_tail[g], (unsigned long long)(span | WGA_COV_READY));
+  };
+  auto emit = [&](const wga_cov_rec& rp, u32 a, u32 b, u64 mv, u64 inc, u64 span, u64 base) {
+    const u64 pos = rp.pos0 + base; /* coverage index in front of the segment */
+    if (pos >= rp.limit) return;    /* wave-uniform */
+    /* marks lie in [pos, min(pos + span, limit - 1)] */
+    const u64 last = pos + span < rp.limit ? pos + span : rp.limit - 1;
+    const u64 wlo = pos >> WGA_COV_WIN_SHIFT, whi = last >> WGA_COV_WIN_SHIFT;
+    const u64 l_end = pos + inc, l_start = l_end - mv; /* this lane's ops mark inside [l_start, l_end] */
+    const u64 np = whi - wlo + 1;
+    u64 place0 = 0;
+    if (lane == 0) place0 = atomicAdd((unsigned long long*)my_cnt, (unsigned long long)np);
+    place0 = WGA_UNI64(__shfl(place0, 0));
+    for (u64 j0 = 0; j0 < np; j0 += 64) { /* a lane per window: a window replays only the lanes that can mark inside it */
+      const u64 wi = wlo + j0 + lane;
+      const bool on = wi <= whi;
+      const u64 lo = wi << WGA_COV_WIN_SHIFT, hi = lo + (u64)(WGA_COV_WIN - 1u);
+      u32 c1 = 0; /* lanes that end in front of the window (63 when all do) */
+#pragma unroll
+      for (u32 st = 32; st; st >>= 1) {
+        const u64 v = __shfl(l_end, (int)(c1 + st - 1u));
+        c1 += v < lo ? st : 0u;
       }
-      base = wave_sum_u64(p);
-    }
-    const u32 tg = target_id[r];
-    const u64 coff = cov_off[tg], clen = cov_len[tg];
-    const u64 pos = t_start[r] + base;
-    if (pos < clen) { /* marks lie in [pos, min(pos + span, clen - 1)] */
-      const u64 last = pos + span < clen ? pos + span : clen - 1;
-      const u64 wlo = (coff + pos) >> WGA_COV_WIN_SHIFT, whi = (coff + last) >> WGA_COV_WIN_SHIFT;
-      const u64 l_end = coff + pos + inc, l_start = l_end - mv; /* this lane's ops mark inside [l_start, l_end] */
-      for (u64 wi = wlo; wi <= whi; wi++) { /* wave-uniform: a window replays only the lanes that can mark inside it */
-        const u64 lo = wi << WGA_COV_WIN_SHIFT, hi = lo + (u64)(WGA_COV_WIN - 1u);
-        const u64 m_ge = __ballot(l_end >= lo), m_le = __ballot(l_start <= hi);
-        const u32 l1 = m_ge ? (u32)__ffsll((unsigned long long)m_ge) - 1u : 63u;
-        const u32 l2 = m_le ? 63u - (u32)__builtin_clzll(m_le) : 0u;
-        const u32 a2 = a > 16u * l1 ? a : 16u * l1, b2 = b < 16u * (l2 + 1u) ? b : 16u * (l2 + 1u);
-        const u64 pos_a2 = WGA_UNI64(__shfl(l_start, (int)l1));
-        if (lane == 0) {
-          const u32 slot = atomicAdd(&win_cnt[wi], 1u);
-          if (FILL) {
-            wga_cov_piece pc;
-            pc.g = (u32)g;
-            pc.ab = a2 | (b2 << 16);
-            pc.pos0 = pos_a2;
-            pc.limit = coff + clen;
-            pieces[win_off[wi] + slot] = pc;
-          }
+      u32 c2 = 0; /* lanes that start inside or in front of the window */
+#pragma unroll
+      for (u32 st = 32; st; st >>= 1) {
+        const u64 v = __shfl(l_start, (int)(c2 + st - 1u));
+        c2 += v <= hi ? st : 0u;
+      }
+      c2 += __shfl(l_start, (int)c2) <= hi ? 1u : 0u;
+      const u32 l1 = c1, l2 = c2 ? c2 - 1u : 0u;
+      const u32 a2 = a > 16u * l1 ? a : 16u * l1, b2 = b < 16u * (l2 + 1u) ? b : 16u * (l2 + 1u);
+      const u64 pos_a2 = __shfl(l_start, (int)l1);
+      if (on) {
+        const u32 slot = atomicAdd(&win_cnt[wi], 1u);
+        const u64 place = place0 + j0 + lane;
+        if (place < rcap) {
+          wga_cov_piece pc;
+          pc.g = (u32)g;
+          pc.ab = a2 | (b2 << 16);
+          pc.pos0 = pos_a2;
+          pc.limit = rp.limit;
+          pc.wi = (u32)wi;
+          pc.slot = slot;
+          my_list[place] = pc;
         }
       }
     }
+  };
+
+  const u32 r0 = tr.rec;
+  const u64 rs0 = tr.rs, end0 = tr.re < tile_end ? tr.re : tile_end;
+  const u32 b0 = (u32)(end0 - tile_start);
+  const wga_cov_rec rp0 = rec_pos[r0];
+  u64 cur = end0;
+  u32 r = r0 + 1;
+  u64 re_next = 0;
+  wga_cov_rec rp_next = rp0;
+  if (end0 < tile_end) { /* another record follows in this tile */
+    re_next = op_off[r + 1];
+    rp_next = rec_pos[r];
+  }
+  for (;;) { /* the segments behind the first one start with their records; the first one comes last */
+    const bool first = cur >= tile_end;
+    u32 a = 0, b = b0;
+    u64 seg_end = end0;
+    wga_cov_rec rp = rp0;
+    if (!first) {
+      u64 re = re_next;
+      rp = rp_next;
+      while (re <= cur) { /* records without ops */
+        r++;
+        re = op_off[r + 1];
+        rp = rec_pos[r];
+      }
+      seg_end = re < tile_end ? re : tile_end;
+      a = (u32)(cur - tile_start), b = (u32)(seg_end - tile_start);
+      if (seg_end < tile_end) { /* the next record's end and place travel behind this segment's work */
+        re_next = op_off[r + 2];
+        rp_next = rec_pos[r + 1];
+      }
+    }
+    u64 mv, inc, span;
+    measure(a, b, mv, inc, span);
+    if (seg_end == tile_end) publish(span);
+    const u64 base = (first && rs0 < tile_start) ? cov_look_back(tile_tail, ops, rs0, g, lane, spin_limit) : 0ull;
+    emit(rp, a, b, mv, inc, span, base);
+    if (first) break;
     cur = seg_end;
     r++;
   }
+}
+
+/* the listed pieces go to their windows */
+__global__ __launch_bounds__(256) void k_cov_place_pieces(const u64* __restrict__ list_cnt, const wga_cov_piece* __restrict__ list,
+                                                          u64 rcap, const u64* __restrict__ win_off, wga_cov_piece* pieces) {
+  const u32 region = blockIdx.y;
+  const u64 i = (u64)blockIdx.x * WGA_BLOCK + threadIdx.x;
+  if (i >= list_cnt[region]) return;
+  const wga_cov_piece pc = list[(u64)region * rcap + i];
+  pieces[win_off[pc.wi] + pc.slot] = pc;
 }
 
 struct ScanU32 {
@@ -312,28 +431,25 @@ __global__ __launch_bounds__(256) void k_cov_windows(const u32* __restrict__ ops
         const bool moves = cls == CLS_MX || cls == CLS_D || cls == CLS_O;
         mv += (idx - a < b - a && moves) ? (u64)(w[e] >> 4) : 0ull;
       }
-      const u64 inc = cov_incl_scan_u64(mv, lane);
+      u64 step_moves;
+      const u64 inc = cov_incl_scan_u64(mv, step_moves);
       u64 pos = pos_base + (inc - mv);
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
+      for (int e = 0; e < 4; e++) { /* the conditions first, then one branch per mark */
         const u32 idx = i0 + (u32)e;
-        if (idx - a < b - a) {
-          const u32 code = w[e] & 15u;
-          const u64 len = w[e] >> 4;
-          const u32 cls = op_class(code);
-          if (code == WGA_OP_M || code == WGA_OP_EQ) {
-            if (pos < pc.limit) {
-              if (pos - w0 < (u64)WGA_COV_WIN) atomicAdd(&s_win[pos - w0], 1);
-              const u64 pe = pos + len;
-              if (pe < pc.limit && pe - w0 < (u64)WGA_COV_WIN) atomicAdd(&s_win[pe - w0], -1);
-            }
-            pos += len;
-          } else if (cls != CLS_I && cls != CLS_S) {
-            pos += len;
-          }
-        }
+        const u32 code = w[e] & 15u;
+        const u64 len = w[e] >> 4;
+        const u32 cls = op_class(code);
+        const bool in = idx - a < b - a;
+        const bool counts = in && (code == WGA_OP_M || code == WGA_OP_EQ) && pos < pc.limit;
+        const u64 pe = pos + len;
+        const bool up = counts && pos - w0 < (u64)WGA_COV_WIN;
+        const bool down = counts && pe < pc.limit && pe - w0 < (u64)WGA_COV_WIN;
+        if (up) atomicAdd(&s_win[(u32)(pos - w0)], 1);
+        if (down) atomicAdd(&s_win[(u32)(pe - w0)], -1);
+        pos += (in && cls != CLS_I && cls != CLS_S) ? len : 0ull;
       }
-      pos_base += WGA_UNI64(__shfl(inc, 63));
+      pos_base += step_moves;
     }
     pc = pc1;
     pc1 = pc2;
