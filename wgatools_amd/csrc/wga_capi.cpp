@@ -1541,8 +1541,8 @@ int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* 
                (u64)c->cov_list_rcap, (const u64*)win_off, (wga_cov_piece*)c->cov_pieces);
     LAUNCH_CHECK();
   }
-  WGA_LAUNCH(k_cov_windows, (u32)nw, WGA_BLOCK, c->stream, b->d_ops, (u64)b->n_ops,
-             (const wga_cov_piece*)c->cov_pieces, (const u64*)win_off, (int*)d_cov);
+  WGA_LAUNCH(k_cov_windows, (u32)nw, WGA_COV_BLOCK, c->stream, b->d_ops, (u64)b->n_ops,
+             (const wga_cov_piece*)c->cov_pieces, (const u64*)win_off, (int*)d_cov, (u64)total_cov);
   LAUNCH_CHECK();
   return WGA_OK;
 }

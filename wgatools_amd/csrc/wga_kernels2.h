@@ -367,13 +367,8 @@ struct ScanU32 {
   __device__ u64 operator()(u32 i) const { return (u64)in[i]; }
 };
 
-/* the four ops of this lane in the first 256-op step of a piece */
-__device__ __forceinline__ void cov_step_ops(const u32* __restrict__ ops, u64 n_ops, const wga_cov_piece& pc, u32 lane,
-                                             u32 (&w)[4]) {
-  const u64 tile_start = (u64)pc.g * WGA_TILE;
-  const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
-  const u32 nt = (u32)(tile_end - tile_start);
-  const u32 i0 = ((pc.ab & 0xFFFFu) & ~3u) + lane * 4u;
+/* ops [i0, i0 + 4) of a tile of nt ops for this lane (zero beyond the tile) */
+__device__ __forceinline__ void cov_load4(const u32* __restrict__ ops, u64 tile_start, u32 nt, u32 i0, u32 (&w)[4]) {
   if (i0 + 3u < nt) {
     const u32x4_a16 v = *(const u32x4_a16*)(ops + tile_start + i0);
     w[0] = v[0], w[1] = v[1], w[2] = v[2], w[3] = v[3];
@@ -382,30 +377,67 @@ __device__ __forceinline__ void cov_step_ops(const u32* __restrict__ ops, u64 n_
     for (int e = 0; e < 4; e++) w[e] = i0 + (u32)e < nt ? ops[tile_start + i0 + e] : 0u;
   }
 }
+/* the four ops of this lane in the first 256-op step of a piece */
+__device__ __forceinline__ void cov_step_ops(const u32* __restrict__ ops, u64 n_ops, const wga_cov_piece& pc, u32 lane,
+                                             u32 (&w)[4]) {
+  const u64 tile_start = (u64)pc.g * WGA_TILE;
+  const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
+  cov_load4(ops, tile_start, (u32)(tile_end - tile_start), ((pc.ab & 0xFFFFu) & ~3u) + lane * 4u, w);
+}
 
-__global__ __launch_bounds__(256) void k_cov_windows(const u32* __restrict__ ops, u64 n_ops,
-                                                     const wga_cov_piece* __restrict__ pieces,
-                                                     const u64* __restrict__ win_off, int* cov) {
+/* One block per window.  What bounds the replay is the number of bytes it has in flight: a piece is 1 KB of ops at a random
+ * place of the op stream, behind a descriptor — two dependent loads of ≈ 2 us each under load.  So a wave keeps the first ops of
+ * WGA_COV_AHEAD pieces in flight behind the one it works on and their descriptors as far again ahead of those, a block has
+ * WGA_COV_WAVES waves, and the window's counters themselves are read before the replay starts instead of after it. */
+#define WGA_COV_WAVES 8u
+#define WGA_COV_BLOCK (64u * WGA_COV_WAVES)
+#define WGA_COV_AHEAD 2
+__global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __restrict__ ops, u64 n_ops,
+                                                               const wga_cov_piece* __restrict__ pieces,
+                                                               const u64* __restrict__ win_off, int* cov, u64 n_cov) {
   __shared__ int s_win[WGA_COV_WIN];
+  constexpr int D = WGA_COV_AHEAD;
+  constexpr u32 PER = WGA_COV_WIN / WGA_COV_BLOCK;
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = WGA_WAVE_ID(tid);
   const u64 wi = blockIdx.x;
   const u64 p_lo = win_off[wi], p_hi = win_off[wi + 1];
   if (p_lo == p_hi) return; /* block-uniform */
-  for (u32 k = tid; k < WGA_COV_WIN; k += WGA_BLOCK) s_win[k] = 0;
-  __syncthreads();
   const u64 w0 = wi << WGA_COV_WIN_SHIFT;
-  /* A wave's pieces one after the other; two dependent loads stand in front of every piece (its descriptor, then its ops), so
-   * the descriptor is fetched two pieces ahead and the first step's ops one piece ahead, behind the work on the current one. */
+  int old[PER]; /* this block is the window's only writer */
+#pragma unroll
+  for (u32 j = 0; j < PER; j++) {
+    const u64 k = w0 + tid + j * WGA_COV_BLOCK;
+    old[j] = k < n_cov ? cov[k] : 0;
+  }
+#pragma unroll
+  for (u32 j = 0; j < PER; j++) s_win[tid + j * WGA_COV_BLOCK] = 0;
+  __syncthreads();
+  /* a wave's pieces one after the other: dq[k] / wq[k] = descriptor / first ops of the piece k rounds behind the current one */
   const u64 p0 = p_lo + wave;
-  wga_cov_piece pc, pc1, pc2;
-  pc = pc1 = pc2 = pieces[p0 < p_hi ? p0 : p_lo];
-  if (p0 + 4 < p_hi) pc1 = pieces[p0 + 4];
-  u32 wn[4];
-  cov_step_ops(ops, n_ops, pc, lane, wn);
-  for (u64 p = p0; p < p_hi; p += 4) {
-    if (p + 8 < p_hi) pc2 = pieces[p + 8];
-    u32 w[4] = {wn[0], wn[1], wn[2], wn[3]};
-    if (p + 4 < p_hi) cov_step_ops(ops, n_ops, pc1, lane, wn);
+  wga_cov_piece dq[2 * D + 1];
+  u32 wq[D + 1][4];
+#pragma unroll
+  for (int k = 0; k <= 2 * D; k++) {
+    const u64 q = p0 + (u64)k * WGA_COV_WAVES;
+    dq[k] = pieces[q < p_hi ? q : p_lo];
+  }
+#pragma unroll
+  for (int k = 0; k <= D; k++) {
+    wq[k][0] = wq[k][1] = wq[k][2] = wq[k][3] = 0u;
+    if (p0 + (u64)k * WGA_COV_WAVES < p_hi) cov_step_ops(ops, n_ops, dq[k], lane, wq[k]);
+  }
+  for (u64 p = p0; p < p_hi; p += WGA_COV_WAVES) {
+    const wga_cov_piece pc = dq[0];
+    u32 w[4] = {wq[0][0], wq[0][1], wq[0][2], wq[0][3]};
+#pragma unroll
+    for (int k = 0; k < 2 * D; k++) dq[k] = dq[k + 1];
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) wq[k][e] = wq[k + 1][e];
+    }
+    if (p + (u64)(2 * D + 1) * WGA_COV_WAVES < p_hi) dq[2 * D] = pieces[p + (u64)(2 * D + 1) * WGA_COV_WAVES];
+    if (p + (u64)(D + 1) * WGA_COV_WAVES < p_hi) cov_step_ops(ops, n_ops, dq[D], lane, wq[D]);
     const u64 tile_start = (u64)pc.g * WGA_TILE;
     const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
     const u32 nt = (u32)(tile_end - tile_start);
@@ -414,15 +446,9 @@ __global__ __launch_bounds__(256) void k_cov_windows(const u32* __restrict__ ops
     /* the piece's ops, 4 consecutive ones per lane and 256 per step (a is a multiple of 16 or the segment's first op) */
     for (u32 s0 = a & ~3u; s0 < b; s0 += 256u) {
       const u32 i0 = s0 + lane * 4u;
-      if (s0 != (a & ~3u)) { /* wave-uniform: the first step's ops came with the piece */
-        if (i0 + 3u < nt) {
-          const u32x4_a16 v = *(const u32x4_a16*)(ops + tile_start + i0);
-          w[0] = v[0], w[1] = v[1], w[2] = v[2], w[3] = v[3];
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; e++) w[e] = i0 + (u32)e < nt ? ops[tile_start + i0 + e] : 0u;
-        }
-      }
+      const bool more = s0 + 256u < b; /* wave-uniform: a further step's ops travel behind this one's work */
+      u32 wn[4] = {0u, 0u, 0u, 0u};
+      if (more) cov_load4(ops, tile_start, nt, i0 + 256u, wn);
       u64 mv = 0;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
@@ -450,22 +476,16 @@ __global__ __launch_bounds__(256) void k_cov_windows(const u32* __restrict__ ops
         pos += (in && cls != CLS_I && cls != CLS_S) ? len : 0ull;
       }
       pos_base += step_moves;
+#pragma unroll
+      for (int e = 0; e < 4; e++) w[e] = wn[e];
     }
-    pc = pc1;
-    pc1 = pc2;
   }
   __syncthreads();
-  /* the window goes to memory: this block is its only writer.  Eight counters per thread and round, their loads in flight
-   * together (one round trip per round instead of one per counter); counters without a mark are not touched. */
-  for (u32 k0 = tid; k0 < WGA_COV_WIN; k0 += 8u * WGA_BLOCK) {
-    int v[8], x[8];
+  /* the window goes to memory; counters without a mark are not touched */
 #pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = s_win[k0 + (u32)j * WGA_BLOCK];
-#pragma unroll
-    for (int j = 0; j < 8; j++) x[j] = v[j] ? cov[w0 + k0 + (u32)j * WGA_BLOCK] : 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-      if (v[j]) cov[w0 + k0 + (u32)j * WGA_BLOCK] = x[j] + v[j];
+  for (u32 j = 0; j < PER; j++) {
+    const int v = s_win[tid + j * WGA_COV_BLOCK];
+    if (v) cov[w0 + tid + j * WGA_COV_BLOCK] = old[j] + v;
   }
 }
 
