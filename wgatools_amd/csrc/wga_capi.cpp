@@ -1468,30 +1468,30 @@ int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* 
   const size_t b_tail = (size_t)nt * 8, b_lcnt = (size_t)WGA_COV_LISTS * 8, b_wcnt = (((size_t)nw * 4) + 15) & ~(size_t)15;
   const size_t b_woff = (((size_t)nw + 1) * 8 + ((size_t)(nw + 1023) / 1024 + 2) * 8 + 15) & ~(size_t)15;
   {
-    const size_t bytes = b_tail + b_lcnt + b_wcnt + b_woff + (size_t)nt * sizeof(wga_tile_rec) + (size_t)b->n * sizeof(wga_cov_rec);
+    const size_t bytes = b_tail + b_lcnt + b_wcnt + b_woff + (size_t)nt * sizeof(wga_cov_tile) + (size_t)b->n * sizeof(wga_cov_rec);
     if ((rc = ctx_scratch(c, bytes, &ws))) return rc;
   }
   u64* tile_tail = (u64*)ws;
   u64* list_cnt = tile_tail + nt;
   u32* win_cnt = (u32*)(list_cnt + WGA_COV_LISTS);
   u64* win_off = (u64*)((char*)win_cnt + b_wcnt);
-  wga_tile_rec* tile_rec = (wga_tile_rec*)((char*)win_off + b_woff);
-  wga_cov_rec* rec_pos = (wga_cov_rec*)(tile_rec + nt);
+  wga_cov_tile* tile_info = (wga_cov_tile*)((char*)win_off + b_woff);
+  wga_cov_rec* rec_pos = (wga_cov_rec*)(tile_info + nt);
   const u32 grid = (u32)((nt + 3) / 4);
-  /* what a segment needs of its record, one load away: the record of every tile's first op, every record's place in the
-   * coverage index space */
-  WGA_LAUNCH(k_tile_rec, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const u64*)b->d_op_off, b->d_strand_neg, b->n,
-             (u64)b->n_ops, tile_rec);
-  LAUNCH_CHECK();
+  /* what a tile's wave needs of its first two records, in one load: every record's place in the coverage index space, then the
+   * record of every tile's first op with its own and its successor's data */
   WGA_LAUNCH(k_cov_rec_pos, (b->n + WGA_BLOCK - 1) / WGA_BLOCK, WGA_BLOCK, c->stream, b->n, d_target_id, (const u64*)d_t_start,
              (const u64*)d_cov_off, (const u64*)d_cov_len, rec_pos);
+  LAUNCH_CHECK();
+  WGA_LAUNCH(k_cov_tile_info, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const u64*)b->d_op_off, b->n, (u64)b->n_ops,
+             (const wga_cov_rec*)rec_pos, tile_info);
   LAUNCH_CHECK();
   std::vector<u64> h_cnt(WGA_COV_LISTS);
   u64 n_pieces = 0;
   for (int attempt = 0;; attempt++) {
     RT_CHECK(rt_memset(ws, 0, b_tail + b_lcnt + b_wcnt, c->stream));
     WGA_LAUNCH(k_cov_list_pieces, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off, (u64)b->n_ops,
-               (const wga_tile_rec*)tile_rec, (const wga_cov_rec*)rec_pos, tile_tail, win_cnt, list_cnt,
+               (const wga_cov_tile*)tile_info, (const wga_cov_rec*)rec_pos, tile_tail, win_cnt, list_cnt,
                (wga_cov_piece*)c->cov_list, (u64)c->cov_list_rcap, (u32)c->cov_spin_limit);
     LAUNCH_CHECK();
     RT_CHECK(rt_d2h(h_cnt.data(), list_cnt, b_lcnt, c->stream));

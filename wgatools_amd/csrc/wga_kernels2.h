@@ -179,27 +179,32 @@ __device__ __forceinline__ u64 cov_lane_moves(const u32 w[16], u32 lane, u32 a, 
 }
 
 /* Target advance of record r's ops in front of tile g (the record starts at op rs, in tile g0 = rs / WGA_TILE): the tail sums the
- * tiles g0 .. g-1 published (every one of them ends inside the record, so its last segment is the record's part of it).  Those tiles
- * belong to blocks of the same launch with lower indices, which were dispatched before this one; should one of them not have
- * published after `spin_limit` polls (or with a limit of 0: at once), the ops themselves are added up — the pass ends whatever
- * the dispatch order is. */
+ * tiles g0 .. g-1 published (every one of them ends inside the record, so its last segment is the record's part of it).  Lane L
+ * takes tile g-1-L (and 64 further back per round); `early` is what a first poll of round 0 — sent before the tile's other
+ * segments were worked on — brought back (cov_poll_early).  Those tiles belong to blocks of the same launch with lower
+ * indices, which were dispatched before this one; should one of them not have published after `spin_limit` polls (or with a
+ * limit of 0: at once), the ops themselves are added up — the pass ends whatever the dispatch order is. */
+__device__ __forceinline__ u64 cov_poll_early(u64* tile_tail, u64 rs, u64 g, u32 lane) {
+  const u64 g0 = rs / WGA_TILE;
+  return (g - g0 > (u64)lane) ? (u64)atomicAdd((unsigned long long*)&tile_tail[g - 1 - lane], 0ull) : 0ull;
+}
 __device__ __forceinline__ u64 cov_look_back(u64* tile_tail, const u32* __restrict__ ops, u64 rs, u64 g, u32 lane,
-                                             u32 spin_limit) {
+                                             u32 spin_limit, u64 early) {
   const u64 g0 = rs / WGA_TILE;
   u64 p = 0;
   bool gave_up = spin_limit == 0; /* wave-uniform */
-  for (u64 k0 = g0; k0 < g && !gave_up; k0 += 64) {
-    const u64 k = k0 + lane;
-    const bool mine = k < g;
-    u64 v = 0;
+  for (u64 back = 0; back < g - g0 && !gave_up; back += 64) {
+    const bool mine = g - g0 > back + lane;
+    const u64 k = g - 1 - back - lane;
+    u64 v = back == 0 ? early : 0ull;
     u32 polls = 0;
     for (;;) {
-      if (mine && !(v & WGA_COV_READY)) v = atomicAdd((unsigned long long*)&tile_tail[k], 0ull);
       if (!__ballot(mine && !(v & WGA_COV_READY))) break;
       if (++polls > spin_limit) {
         gave_up = true;
         break;
       }
+      if (mine && !(v & WGA_COV_READY)) v = atomicAdd((unsigned long long*)&tile_tail[k], 0ull);
     }
     p += mine ? (v & ~WGA_COV_READY) : 0ull;
   }
@@ -230,14 +235,48 @@ __global__ __launch_bounds__(256) void k_cov_rec_pos(u32 n, const u32* __restric
   rec_pos[r] = rp;
 }
 
+/* what a tile's wave needs before it can start, in one load: the record of its first op and the one behind it */
+struct __attribute__((aligned(16))) wga_cov_tile {
+  u64 rs, re;      /* op_off[rec], op_off[rec + 1] of the record that holds the tile's first op */
+  wga_cov_rec rp0; /* that record's place */
+  u64 re1;         /* op_off[rec + 2] (0 without a further record) */
+  wga_cov_rec rp1; /* the place of record rec + 1 */
+  u32 rec, pad;
+};
+__global__ __launch_bounds__(256) void k_cov_tile_info(const u64* __restrict__ op_off, u32 n, u64 n_ops,
+                                                       const wga_cov_rec* __restrict__ rec_pos, wga_cov_tile* __restrict__ info) {
+  const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
+  const u64 x = g * WGA_TILE;
+  if (x >= n_ops) return;
+  u32 lo = 0, hi = n; /* last r with op_off[r] <= x; op_off[0] == 0, op_off[n] == n_ops > x */
+  while (hi - lo > 1u) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if (op_off[mid] <= x)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  wga_cov_tile t;
+  t.rec = lo;
+  t.pad = 0;
+  t.rs = op_off[lo];
+  t.re = op_off[lo + 1];
+  t.rp0 = rec_pos[lo];
+  const bool more = lo + 1u < n;
+  t.re1 = more ? op_off[lo + 2] : 0ull;
+  t.rp1 = rec_pos[more ? lo + 1u : lo];
+  info[g] = t;
+}
+
 /* The list pass: one wave per tile of 1024 ops.  Every record segment of the tile is measured (target advance per lane, scanned),
  * the tile's last segment is published for the tiles behind it, the first segment looks back for where its record stands, and
  * every (segment, window) piece takes a place in its window (win_cnt) and is written to the tile's list region.  Segments other
- * than the first start with their record, so only the first one waits — and it is handled last.  What a segment needs of its
- * record (k_tile_rec for the tile's first one, op_off and k_cov_rec_pos's pair for the others) is one load away and fetched a
- * segment ahead: the pass is bound by its chains of dependent loads, not by the 4 bytes per op.  `rcap` = 0 only counts. */
+ * than the first start with their record, so only the first one waits — and it is handled last, its first poll sent before the
+ * others are worked on.  The pass is bound by its chain of dependent round trips, not by the 4 bytes per op: what the first two
+ * segments need of their records comes with the tile's ops in one load (k_cov_tile_info), a further segment's record data
+ * (op_off, k_cov_rec_pos's pair) is fetched a segment ahead.  `rcap` = 0 only counts. */
 __global__ __launch_bounds__(256) void k_cov_list_pieces(
-    const u32* __restrict__ ops, const u64* __restrict__ op_off, u64 n_ops, const wga_tile_rec* __restrict__ tile_rec,
+    const u32* __restrict__ ops, const u64* __restrict__ op_off, u64 n_ops, const wga_cov_tile* __restrict__ tile_info,
     const wga_cov_rec* __restrict__ rec_pos, u64* tile_tail, u32* win_cnt, u64* list_cnt, wga_cov_piece* list, u64 rcap,
     u32 spin_limit) {
   const u32 lane = threadIdx.x & 63u;
@@ -246,7 +285,7 @@ __global__ __launch_bounds__(256) void k_cov_list_pieces(
   if (tile_start >= n_ops) return;
   const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
   const u32 nt = (u32)(tile_end - tile_start);
-  const wga_tile_rec tr = tile_rec[g];
+  const wga_cov_tile tr = tile_info[g];
   u32 w[16];
   cov_load_ops(ops, tile_start, nt, lane, w);
   const u32 region = (u32)(g % WGA_COV_LISTS);
@@ -312,15 +351,13 @@ __global__ __launch_bounds__(256) void k_cov_list_pieces(
   const u32 r0 = tr.rec;
   const u64 rs0 = tr.rs, end0 = tr.re < tile_end ? tr.re : tile_end;
   const u32 b0 = (u32)(end0 - tile_start);
-  const wga_cov_rec rp0 = rec_pos[r0];
+  const wga_cov_rec rp0 = tr.rp0;
   u64 cur = end0;
   u32 r = r0 + 1;
-  u64 re_next = 0;
-  wga_cov_rec rp_next = rp0;
-  if (end0 < tile_end) { /* another record follows in this tile */
-    re_next = op_off[r + 1];
-    rp_next = rec_pos[r];
-  }
+  u64 re_next = tr.re1; /* another record follows in this tile when end0 < tile_end */
+  wga_cov_rec rp_next = tr.rp1;
+  const bool waits = rs0 < tile_start; /* the first segment's record began in a tile in front */
+  const u64 early = waits ? cov_poll_early(tile_tail, rs0, g, lane) : 0ull;
   for (;;) { /* the segments behind the first one start with their records; the first one comes last */
     const bool first = cur >= tile_end;
     u32 a = 0, b = b0;
@@ -344,7 +381,7 @@ __global__ __launch_bounds__(256) void k_cov_list_pieces(
     u64 mv, inc, span;
     measure(a, b, mv, inc, span);
     if (seg_end == tile_end) publish(span);
-    const u64 base = (first && rs0 < tile_start) ? cov_look_back(tile_tail, ops, rs0, g, lane, spin_limit) : 0ull;
+    const u64 base = (first && waits) ? cov_look_back(tile_tail, ops, rs0, g, lane, spin_limit, early) : 0ull;
     emit(rp, a, b, mv, inc, span, base);
     if (first) break;
     cur = seg_end;
