@@ -8,7 +8,7 @@ import torch
 from wgatools_amd import build, engine, _lib, synth
 
 dev = torch.device("cuda", 0)
-eng = engine.Engine(0, _lib.load(build.HIP_LIB))
+eng = engine.Engine(0, _lib.load(os.environ.get("WGA_LIB") or build.HIP_LIB))     # WGA_LIB: a build_variants library
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 nt, tlen, per = 64, 100_000_000, 2_000_000
 cov_len = torch.full((nt,), tlen, dtype=torch.int64, device=dev)

@@ -165,17 +165,16 @@ __device__ __forceinline__ void cov_load_ops(const u32* __restrict__ ops, u64 ti
     }
   }
 }
-/* target advance of this lane's ops inside [a, b): everything but I and S moves (cigar.rs:720-733) */
-__device__ __forceinline__ u64 cov_lane_moves(const u32 w[16], u32 lane, u32 a, u32 b) {
-  u64 mv = 0;
+/* an op's advance on the target: everything but I and S moves (cigar.rs:720-733) — codes 1, 4 and 9 (I, S, the rest of a split I)
+ * do not */
+__device__ __forceinline__ bool cov_op_moves(u32 code) { return ((0x212u >> code) & 1u) == 0u; }
+/* target advance of this lane's ops inside [a, b); mvl[e] = the advance of op e (16 lengths below 2^28: the sum fits 32 bits) */
+__device__ __forceinline__ u64 cov_lane_moves(const u32 mvl[16], u32 lane, u32 a, u32 b) {
+  u32 mv = 0;
+  const u32 t = lane * 16u - a, n = b - a;
 #pragma unroll
-  for (int e = 0; e < 16; e++) {
-    const u32 idx = lane * 16u + (u32)e;
-    const u32 cls = op_class(w[e] & 15u);
-    const bool moves = cls == CLS_MX || cls == CLS_D || cls == CLS_O;
-    mv += (idx - a < b - a && moves) ? (u64)(w[e] >> 4) : 0ull;
-  }
-  return mv;
+  for (int e = 0; e < 16; e++) mv += (t + (u32)e < n) ? mvl[e] : 0u;
+  return (u64)mv;
 }
 
 /* Target advance of record r's ops in front of tile g (the record starts at op rs, in tile g0 = rs / WGA_TILE): the tail sums the
@@ -212,8 +211,7 @@ __device__ __forceinline__ u64 cov_look_back(u64* tile_tail, const u32* __restri
   u64 q = 0;
   for (u64 i = rs + lane; i < g * WGA_TILE; i += 64) {
     const u32 op = ops[i];
-    const u32 cls = op_class(op & 15u);
-    q += (cls == CLS_MX || cls == CLS_D || cls == CLS_O) ? (u64)(op >> 4) : 0ull;
+    q += cov_op_moves(op & 15u) ? (u64)(op >> 4) : 0ull;
   }
   return wave_sum_u64(q);
 }
@@ -275,7 +273,10 @@ __global__ __launch_bounds__(256) void k_cov_tile_info(const u64* __restrict__ o
  * others are worked on.  The pass is bound by its chain of dependent round trips, not by the 4 bytes per op: what the first two
  * segments need of their records comes with the tile's ops in one load (k_cov_tile_info), a further segment's record data
  * (op_off, k_cov_rec_pos's pair) is fetched a segment ahead.  `rcap` = 0 only counts. */
-__global__ __launch_bounds__(256) void k_cov_list_pieces(
+#ifndef WGA_K5_LIST_WAVES
+#define WGA_K5_LIST_WAVES 1 /* waves per SIMD the register allocation aims at (8: 62 VGPRs and 12 bytes of scratch) */
+#endif
+__global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
     const u32* __restrict__ ops, const u64* __restrict__ op_off, u64 n_ops, const wga_cov_tile* __restrict__ tile_info,
     const wga_cov_rec* __restrict__ rec_pos, u64* tile_tail, u32* win_cnt, u64* list_cnt, wga_cov_piece* list, u64 rcap,
     u32 spin_limit) {
@@ -288,6 +289,8 @@ __global__ __launch_bounds__(256) void k_cov_list_pieces(
   const wga_cov_tile tr = tile_info[g];
   u32 w[16];
   cov_load_ops(ops, tile_start, nt, lane, w);
+#pragma unroll
+  for (int e = 0; e < 16; e++) w[e] = cov_op_moves(w[e] & 15u) ? w[e] >> 4 : 0u; /* the pass needs the ops' advance only */
   const u32 region = (u32)(g % WGA_COV_LISTS);
   u64* const my_cnt = list_cnt + region;
   wga_cov_piece* const my_list = list + (u64)region * rcap;
@@ -486,14 +489,13 @@ __global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __r
       const bool more = s0 + 256u < b; /* wave-uniform: a further step's ops travel behind this one's work */
       u32 wn[4] = {0u, 0u, 0u, 0u};
       if (more) cov_load4(ops, tile_start, nt, i0 + 256u, wn);
-      u64 mv = 0;
+      u32 mv32 = 0; /* four lengths below 2^28 */
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         const u32 idx = i0 + (u32)e;
-        const u32 cls = op_class(w[e] & 15u);
-        const bool moves = cls == CLS_MX || cls == CLS_D || cls == CLS_O;
-        mv += (idx - a < b - a && moves) ? (u64)(w[e] >> 4) : 0ull;
+        mv32 += (idx - a < b - a && cov_op_moves(w[e] & 15u)) ? w[e] >> 4 : 0u;
       }
+      const u64 mv = mv32;
       u64 step_moves;
       const u64 inc = cov_incl_scan_u64(mv, step_moves);
       u64 pos = pos_base + (inc - mv);
@@ -502,7 +504,6 @@ __global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __r
         const u32 idx = i0 + (u32)e;
         const u32 code = w[e] & 15u;
         const u64 len = w[e] >> 4;
-        const u32 cls = op_class(code);
         const bool in = idx - a < b - a;
         const bool counts = in && (code == WGA_OP_M || code == WGA_OP_EQ) && pos < pc.limit;
         const u64 pe = pos + len;
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __r
         const bool down = counts && pe < pc.limit && pe - w0 < (u64)WGA_COV_WIN;
         if (up) atomicAdd(&s_win[(u32)(pos - w0)], 1);
         if (down) atomicAdd(&s_win[(u32)(pe - w0)], -1);
-        pos += (in && cls != CLS_I && cls != CLS_S) ? len : 0ull;
+        pos += (in && cov_op_moves(code)) ? len : 0ull;
       }
       pos_base += step_moves;
 #pragma unroll
