@@ -75,7 +75,9 @@ struct wga_ctx {
   } op_tab;
   void* cov_pieces = nullptr; /* pafcov: (window, piece) list, grow-only */
   u64 cov_pieces_cap = 0;
-  void* cov_list = nullptr;   /* pafcov: the pieces as the list pass writes them (WGA_COV_LISTS regions of cov_list_rcap) */
+  void* cov_tile_list = nullptr; /* pafcov: WGA_COV_TILE_CAP piece slots per tile of ops, grow-only */
+  u64 cov_tile_list_cap = 0;     /* in tiles */
+  void* cov_list = nullptr;   /* pafcov: the pieces beyond a tile's slots (WGA_COV_LISTS regions of cov_list_rcap) */
   u64 cov_list_rcap = 0;
   u32 cov_spin_limit = 1u << 16; /* polls of a tile sum before the look-back adds up the ops itself (WGA_COV_SPIN_LIMIT) */
   /* optional per-launch timing of the expand kernel proper (events on the launch stream) */
@@ -426,6 +428,7 @@ void wga_ctx_destroy(wga_ctx* c) {
   if (c->scratch) (void)rt_free(c->scratch);
   if (c->cov_pieces) (void)rt_free(c->cov_pieces);
   if (c->cov_list) (void)rt_free(c->cov_list);
+  if (c->cov_tile_list) (void)rt_free(c->cov_tile_list);
   if (c->op_tab.mem) (void)rt_free(c->op_tab.mem);
   rt_stream_destroy(c->own_stream);
   delete c;
@@ -1461,23 +1464,34 @@ int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* 
   const u64 nt = n_tiles(b->n_ops);
   const u64 nw = (total_cov >> WGA_COV_WIN_SHIFT) + 1;
   if (nw > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "coverage arrays too large for one call", nullptr);
-  /* One pass lists every (tile, record segment, window) piece (see wga_kernels2.h K5): tile sums by look-back, a place in the
-   * window from win_cnt, the piece itself into one of WGA_COV_LISTS list regions.  The regions are as large as the last call
-   * needed them (+ 25 %): a first call, or a batch that overflows one, only counts and is run again. */
+  /* One pass lists every (tile, record segment, window) piece (see wga_kernels2.h K5): tile sums by look-back, the pieces into the
+   * tile's own slots and counted under their windows; a scan of the window counts, and the pieces are taken to their windows.
+   * Pieces beyond a tile's slots go to one of WGA_COV_LISTS list regions, as large as the last call needed them (+ 25 %): a call
+   * that overflows one is run again. */
   void* ws;
   const size_t b_tail = (size_t)nt * 8, b_lcnt = (size_t)WGA_COV_LISTS * 8, b_wcnt = (((size_t)nw * 4) + 15) & ~(size_t)15;
   const size_t b_woff = (((size_t)nw + 1) * 8 + ((size_t)(nw + 1023) / 1024 + 2) * 8 + 15) & ~(size_t)15;
+  const size_t b_tcnt = ((size_t)nt * 4 + 15) & ~(size_t)15;
   {
-    const size_t bytes = b_tail + b_lcnt + b_wcnt + b_woff + (size_t)nt * sizeof(wga_cov_tile) + (size_t)b->n * sizeof(wga_cov_rec);
+    const size_t bytes = b_tail + b_lcnt + b_wcnt + b_woff + b_tcnt + (size_t)nt * sizeof(wga_cov_tile) +
+                         (size_t)b->n * sizeof(wga_cov_rec);
     if ((rc = ctx_scratch(c, bytes, &ws))) return rc;
   }
   u64* tile_tail = (u64*)ws;
   u64* list_cnt = tile_tail + nt;
   u32* win_cnt = (u32*)(list_cnt + WGA_COV_LISTS);
   u64* win_off = (u64*)((char*)win_cnt + b_wcnt);
-  wga_cov_tile* tile_info = (wga_cov_tile*)((char*)win_off + b_woff);
+  u32* tile_cnt = (u32*)((char*)win_off + b_woff);
+  wga_cov_tile* tile_info = (wga_cov_tile*)((char*)tile_cnt + b_tcnt);
   wga_cov_rec* rec_pos = (wga_cov_rec*)(tile_info + nt);
   const u32 grid = (u32)((nt + 3) / 4);
+  if (c->cov_tile_list_cap < nt) {
+    if (c->cov_tile_list) RT_CHECK(rt_free(c->cov_tile_list));
+    c->cov_tile_list = nullptr;
+    c->cov_tile_list_cap = 0;
+    RT_CHECK(rt_malloc(&c->cov_tile_list, (size_t)nt * WGA_COV_TILE_CAP * sizeof(wga_cov_piece)));
+    c->cov_tile_list_cap = nt;
+  }
   /* what a tile's wave needs of its first two records, in one load: every record's place in the coverage index space, then the
    * record of every tile's first op with its own and its successor's data */
   WGA_LAUNCH(k_cov_rec_pos, (b->n + WGA_BLOCK - 1) / WGA_BLOCK, WGA_BLOCK, c->stream, b->n, d_target_id, (const u64*)d_t_start,
@@ -1487,18 +1501,19 @@ int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* 
              (const wga_cov_rec*)rec_pos, tile_info);
   LAUNCH_CHECK();
   std::vector<u64> h_cnt(WGA_COV_LISTS);
-  u64 n_pieces = 0;
+  u64 n_over = 0;
   for (int attempt = 0;; attempt++) {
     RT_CHECK(rt_memset(ws, 0, b_tail + b_lcnt + b_wcnt, c->stream));
     WGA_LAUNCH(k_cov_list_pieces, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off, (u64)b->n_ops,
-               (const wga_cov_tile*)tile_info, (const wga_cov_rec*)rec_pos, tile_tail, win_cnt, list_cnt,
-               (wga_cov_piece*)c->cov_list, (u64)c->cov_list_rcap, (u32)c->cov_spin_limit);
+               (const wga_cov_tile*)tile_info, (const wga_cov_rec*)rec_pos, tile_tail, win_cnt,
+               (wga_cov_piece*)c->cov_tile_list, tile_cnt, list_cnt, (wga_cov_piece*)c->cov_list, (u64)c->cov_list_rcap,
+               (u32)c->cov_spin_limit);
     LAUNCH_CHECK();
     RT_CHECK(rt_d2h(h_cnt.data(), list_cnt, b_lcnt, c->stream));
     u64 most = 0;
-    n_pieces = 0;
+    n_over = 0;
     for (u64 v : h_cnt) {
-      n_pieces += v;
+      n_over += v;
       if (v > most) most = v;
     }
     if (most <= c->cov_list_rcap) break;
@@ -1510,7 +1525,6 @@ int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* 
     RT_CHECK(rt_malloc(&c->cov_list, (size_t)rcap * WGA_COV_LISTS * sizeof(wga_cov_piece)));
     c->cov_list_rcap = rcap;
   }
-  if (n_pieces == 0) return WGA_OK;
   {
     /* run_scan uses the context scratch itself: give it its own small buffer behind win_off */
     ScanU32 f;
@@ -1528,6 +1542,9 @@ int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* 
       LAUNCH_CHECK();
     }
   }
+  u64 n_pieces = 0;
+  RT_CHECK(rt_d2h(&n_pieces, win_off + nw, sizeof(u64), c->stream));
+  if (n_pieces == 0) return WGA_OK;
   if (c->cov_pieces_cap < n_pieces) {
     if (c->cov_pieces) RT_CHECK(rt_free(c->cov_pieces));
     c->cov_pieces = nullptr;
@@ -1535,10 +1552,15 @@ int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* 
     RT_CHECK(rt_malloc(&c->cov_pieces, (size_t)(n_pieces + n_pieces / 4) * sizeof(wga_cov_piece)));
     c->cov_pieces_cap = n_pieces + n_pieces / 4;
   }
-  {
+  RT_CHECK(rt_memset(win_cnt, 0, (size_t)nw * 4, c->stream)); /* now the windows' fill counters */
+  WGA_LAUNCH(k_cov_place_tiles, (u32)((nt * WGA_COV_TILE_CAP + WGA_BLOCK - 1) / WGA_BLOCK), WGA_BLOCK, c->stream, (u64)nt,
+             (const u32*)tile_cnt, (const wga_cov_piece*)c->cov_tile_list, win_cnt, (const u64*)win_off,
+             (wga_cov_piece*)c->cov_pieces);
+  LAUNCH_CHECK();
+  if (n_over) {
     dim3 pgrid((u32)((c->cov_list_rcap + WGA_BLOCK - 1) / WGA_BLOCK), WGA_COV_LISTS, 1);
     WGA_LAUNCH(k_cov_place_pieces, pgrid, WGA_BLOCK, c->stream, (const u64*)list_cnt, (const wga_cov_piece*)c->cov_list,
-               (u64)c->cov_list_rcap, (const u64*)win_off, (wga_cov_piece*)c->cov_pieces);
+               (u64)c->cov_list_rcap, win_cnt, (const u64*)win_off, (wga_cov_piece*)c->cov_pieces);
     LAUNCH_CHECK();
   }
   WGA_LAUNCH(k_cov_windows, (u32)nw, WGA_COV_BLOCK, c->stream, b->d_ops, (u64)b->n_ops,

@@ -120,8 +120,8 @@ __global__ __launch_bounds__(256) void k_class_tiles(const u32* __restrict__ ops
  * (scripts/micro/atomic_scope.hip), i.e. 19 ms for the 5e8 marks of configs[1].  So the marks are
  * not sent to memory one by one: the coverage index space is cut into windows of WGA_COV_WIN
  * counters, every (tile, record segment) piece is listed under the windows it touches
- * (k_cov_list_pieces in ONE pass over the ops: tile sums by look-back, places from counters; then a scan of the window counts and
- * k_cov_place_pieces), and one block per window replays its pieces with LDS
+ * (k_cov_list_pieces in ONE pass over the ops: tile sums by look-back, the pieces into the tile's own slots; then a scan of the
+ * window counts and k_cov_place_*), and one block per window replays its pieces with LDS
  * atomics and adds the window to memory with plain stores — it is the only writer. */
 #define WGA_COV_WIN_SHIFT 13u
 #define WGA_COV_WIN (1u << WGA_COV_WIN_SHIFT)
@@ -133,10 +133,12 @@ struct __attribute__((aligned(16))) wga_cov_piece {
   u64 pos0;    /* coverage index (cov_off + target position) in front of op `first` */
   u64 limit;   /* coverage index one past the target's last counter */
   u32 wi;      /* window the piece is listed under */
-  u32 slot;    /* its place among that window's pieces */
+  u32 pad;
 };
-/* The list pass writes its pieces where WGA_COV_LISTS counters hand out places (tile g uses counter g mod WGA_COV_LISTS: one
- * counter for all tiles would take every segment of the batch through one address), each over a region of `rcap` pieces. */
+/* The list pass writes a tile's first WGA_COV_TILE_CAP pieces into the tile's own slots — no atomic with an answer to wait for —
+ * and further ones where WGA_COV_LISTS counters hand out places (tile g uses counter g mod WGA_COV_LISTS: one counter for all
+ * tiles would take every such segment of the batch through one address), each over a region of `rcap` pieces. */
+#define WGA_COV_TILE_CAP 8u
 #define WGA_COV_LISTS 4096u
 #define WGA_COV_READY (1ull << 63)
 /* inclusive scan over the lanes of a value below 2^40 (a lane's 16 ops advance less than 16 x 2^28), and the wave's total: two
@@ -268,7 +270,8 @@ __global__ __launch_bounds__(256) void k_cov_tile_info(const u64* __restrict__ o
 
 /* The list pass: one wave per tile of 1024 ops.  Every record segment of the tile is measured (target advance per lane, scanned),
  * the tile's last segment is published for the tiles behind it, the first segment looks back for where its record stands, and
- * every (segment, window) piece takes a place in its window (win_cnt) and is written to the tile's list region.  Segments other
+ * every (segment, window) piece is counted under its window (win_cnt) and written to the tile's slots (beyond WGA_COV_TILE_CAP
+ * pieces: to the tile's list region) — k_cov_place_* take them to their windows.  Segments other
  * than the first start with their record, so only the first one waits — and it is handled last, its first poll sent before the
  * others are worked on.  The pass is bound by its chain of dependent round trips, not by the 4 bytes per op: what the first two
  * segments need of their records comes with the tile's ops in one load (k_cov_tile_info), a further segment's record data
@@ -278,8 +281,8 @@ __global__ __launch_bounds__(256) void k_cov_tile_info(const u64* __restrict__ o
 #endif
 __global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
     const u32* __restrict__ ops, const u64* __restrict__ op_off, u64 n_ops, const wga_cov_tile* __restrict__ tile_info,
-    const wga_cov_rec* __restrict__ rec_pos, u64* tile_tail, u32* win_cnt, u64* list_cnt, wga_cov_piece* list, u64 rcap,
-    u32 spin_limit) {
+    const wga_cov_rec* __restrict__ rec_pos, u64* tile_tail, u32* win_cnt, wga_cov_piece* tile_list, u32* tile_cnt, u64* list_cnt,
+    wga_cov_piece* list, u64 rcap, u32 spin_limit) {
   const u32 lane = threadIdx.x & 63u;
   const u64 g = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
   const u64 tile_start = g * WGA_TILE;
@@ -294,6 +297,8 @@ __global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
   const u32 region = (u32)(g % WGA_COV_LISTS);
   u64* const my_cnt = list_cnt + region;
   wga_cov_piece* const my_list = list + (u64)region * rcap;
+  wga_cov_piece* const my_slots = tile_list + g * WGA_COV_TILE_CAP;
+  u64 n_mine = 0; /* pieces of this tile so far (wave-uniform) */
 
   /* where every lane's 16 ops start and end on the target (monotone over the lanes; lanes outside [a, b) are empty) */
   auto measure = [&](u32 a, u32 b, u64& mv, u64& inc, u64& span) {
@@ -311,9 +316,14 @@ __global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
     const u64 wlo = pos >> WGA_COV_WIN_SHIFT, whi = last >> WGA_COV_WIN_SHIFT;
     const u64 l_end = pos + inc, l_start = l_end - mv; /* this lane's ops mark inside [l_start, l_end] */
     const u64 np = whi - wlo + 1;
+    /* the pieces beyond the tile's own slots (rare: a tile of many short records, a segment across many windows) take places
+     * in the tile's list region — the only atomic of the pass whose answer is waited for */
+    const u64 over0 = n_mine > (u64)WGA_COV_TILE_CAP ? n_mine : (u64)WGA_COV_TILE_CAP;
     u64 place0 = 0;
-    if (lane == 0) place0 = atomicAdd((unsigned long long*)my_cnt, (unsigned long long)np);
-    place0 = WGA_UNI64(__shfl(place0, 0));
+    if (n_mine + np > over0) { /* wave-uniform */
+      if (lane == 0) place0 = atomicAdd((unsigned long long*)my_cnt, (unsigned long long)(n_mine + np - over0));
+      place0 = WGA_UNI64(__shfl(place0, 0));
+    }
     for (u64 j0 = 0; j0 < np; j0 += 64) { /* a lane per window: a window replays only the lanes that can mark inside it */
       const u64 wi = wlo + j0 + lane;
       const bool on = wi <= whi;
@@ -335,20 +345,22 @@ __global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
       const u32 a2 = a > 16u * l1 ? a : 16u * l1, b2 = b < 16u * (l2 + 1u) ? b : 16u * (l2 + 1u);
       const u64 pos_a2 = __shfl(l_start, (int)l1);
       if (on) {
-        const u32 slot = atomicAdd(&win_cnt[wi], 1u);
-        const u64 place = place0 + j0 + lane;
-        if (place < rcap) {
-          wga_cov_piece pc;
-          pc.g = (u32)g;
-          pc.ab = a2 | (b2 << 16);
-          pc.pos0 = pos_a2;
-          pc.limit = rp.limit;
-          pc.wi = (u32)wi;
-          pc.slot = slot;
-          my_list[place] = pc;
-        }
+        atomicAdd(&win_cnt[wi], 1u);
+        wga_cov_piece pc;
+        pc.g = (u32)g;
+        pc.ab = a2 | (b2 << 16);
+        pc.pos0 = pos_a2;
+        pc.limit = rp.limit;
+        pc.wi = (u32)wi;
+        pc.pad = 0u;
+        const u64 idx = n_mine + j0 + lane;
+        if (idx < (u64)WGA_COV_TILE_CAP)
+          my_slots[idx] = pc;
+        else if (place0 + (idx - over0) < rcap)
+          my_list[place0 + (idx - over0)] = pc;
       }
     }
+    n_mine += np;
   };
 
   const u32 r0 = tr.rec;
@@ -390,16 +402,28 @@ __global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
     cur = seg_end;
     r++;
   }
+  if (lane == 0) tile_cnt[g] = n_mine < (u64)WGA_COV_TILE_CAP ? (u32)n_mine : WGA_COV_TILE_CAP;
 }
 
-/* the listed pieces go to their windows */
+/* the listed pieces go to their windows: a piece takes the next place of its window (win_fill, zero before) — an atomic with an
+ * answer per piece, but of threads that have nothing else to wait for */
+__global__ __launch_bounds__(256) void k_cov_place_tiles(u64 n_tiles, const u32* __restrict__ tile_cnt,
+                                                         const wga_cov_piece* __restrict__ tile_list, u32* win_fill,
+                                                         const u64* __restrict__ win_off, wga_cov_piece* pieces) {
+  const u64 t = (u64)blockIdx.x * WGA_BLOCK + threadIdx.x;
+  const u64 g = t / WGA_COV_TILE_CAP;
+  if (g >= n_tiles || (u32)(t % WGA_COV_TILE_CAP) >= tile_cnt[g]) return;
+  const wga_cov_piece pc = tile_list[t];
+  pieces[win_off[pc.wi] + atomicAdd(&win_fill[pc.wi], 1u)] = pc;
+}
 __global__ __launch_bounds__(256) void k_cov_place_pieces(const u64* __restrict__ list_cnt, const wga_cov_piece* __restrict__ list,
-                                                          u64 rcap, const u64* __restrict__ win_off, wga_cov_piece* pieces) {
+                                                          u64 rcap, u32* win_fill, const u64* __restrict__ win_off,
+                                                          wga_cov_piece* pieces) {
   const u32 region = blockIdx.y;
   const u64 i = (u64)blockIdx.x * WGA_BLOCK + threadIdx.x;
   if (i >= list_cnt[region]) return;
   const wga_cov_piece pc = list[(u64)region * rcap + i];
-  pieces[win_off[pc.wi] + pc.slot] = pc;
+  pieces[win_off[pc.wi] + atomicAdd(&win_fill[pc.wi], 1u)] = pc;
 }
 
 struct ScanU32 {
