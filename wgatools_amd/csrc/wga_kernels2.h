@@ -272,10 +272,9 @@ __global__ __launch_bounds__(256) void k_cov_tile_info(const u64* __restrict__ o
  * the tile's last segment is published for the tiles behind it, the first segment looks back for where its record stands, and
  * every (segment, window) piece is counted under its window (win_cnt) and written to the tile's slots (beyond WGA_COV_TILE_CAP
  * pieces: to the tile's list region) — k_cov_place_* take them to their windows.  Segments other
- * than the first start with their record, so only the first one waits — and it is handled last, its first poll sent before the
- * others are worked on.  The pass is bound by its chain of dependent round trips, not by the 4 bytes per op: what the first two
+ * than the first start with their record, so only the first one waits.  The order is: publish, look back, write.  What the first two
  * segments need of their records comes with the tile's ops in one load (k_cov_tile_info), a further segment's record data
- * (op_off, k_cov_rec_pos's pair) is fetched a segment ahead.  `rcap` = 0 only counts. */
+ * (op_off, k_cov_rec_pos's pair) is fetched a segment ahead.  With `rcap` = 0 the pieces beyond the slots are only counted. */
 #ifndef WGA_K5_LIST_WAVES
 #define WGA_K5_LIST_WAVES 1 /* waves per SIMD the register allocation aims at (8: 62 VGPRs and 12 bytes of scratch) */
 #endif
@@ -290,6 +289,7 @@ __global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
   const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
   const u32 nt = (u32)(tile_end - tile_start);
   const wga_cov_tile tr = tile_info[g];
+  const u64 rs_next = tile_end < n_ops ? tile_info[g + 1].rs : ~0ull; /* where the record of the next tile's first op starts */
   u32 w[16];
   cov_load_ops(ops, tile_start, nt, lane, w);
 #pragma unroll
@@ -367,38 +367,48 @@ __global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
   const u64 rs0 = tr.rs, end0 = tr.re < tile_end ? tr.re : tile_end;
   const u32 b0 = (u32)(end0 - tile_start);
   const wga_cov_rec rp0 = tr.rp0;
+  const bool waits = rs0 < tile_start; /* the first segment's record began in a tile in front */
+  const u64 early = waits ? cov_poll_early(tile_tail, rs0, g, lane) : 0ull;
+  /* Publish first, then look back, then write: the wait for the look-back's answer stands in front of the tile's first store
+   * (a wait behind stores is a wait for their acknowledgements as well — a third of the pass when it was there).  The tile's
+   * last segment starts where the record of the next tile's first op starts; when that record starts with the next tile, no
+   * tile behind will ask for this one's sum. */
+  {
+    u64 span_last = 0;
+    if (rs_next < tile_end) { /* wave-uniform */
+      const u32 a_last = rs_next > tile_start ? (u32)(rs_next - tile_start) : 0u;
+      u64 mv, inc;
+      measure(a_last, nt, mv, inc, span_last);
+    }
+    publish(span_last);
+  }
+  const u64 base0 = waits ? cov_look_back(tile_tail, ops, rs0, g, lane, spin_limit, early) : 0ull;
+  {
+    u64 mv, inc, span;
+    measure(0u, b0, mv, inc, span);
+    emit(rp0, 0u, b0, mv, inc, span, base0);
+  }
   u64 cur = end0;
   u32 r = r0 + 1;
   u64 re_next = tr.re1; /* another record follows in this tile when end0 < tile_end */
   wga_cov_rec rp_next = tr.rp1;
-  const bool waits = rs0 < tile_start; /* the first segment's record began in a tile in front */
-  const u64 early = waits ? cov_poll_early(tile_tail, rs0, g, lane) : 0ull;
-  for (;;) { /* the segments behind the first one start with their records; the first one comes last */
-    const bool first = cur >= tile_end;
-    u32 a = 0, b = b0;
-    u64 seg_end = end0;
-    wga_cov_rec rp = rp0;
-    if (!first) {
-      u64 re = re_next;
-      rp = rp_next;
-      while (re <= cur) { /* records without ops */
-        r++;
-        re = op_off[r + 1];
-        rp = rec_pos[r];
-      }
-      seg_end = re < tile_end ? re : tile_end;
-      a = (u32)(cur - tile_start), b = (u32)(seg_end - tile_start);
-      if (seg_end < tile_end) { /* the next record's end and place travel behind this segment's work */
-        re_next = op_off[r + 2];
-        rp_next = rec_pos[r + 1];
-      }
+  while (cur < tile_end) { /* the segments behind the first one start with their records */
+    u64 re = re_next;
+    wga_cov_rec rp = rp_next;
+    while (re <= cur) { /* records without ops */
+      r++;
+      re = op_off[r + 1];
+      rp = rec_pos[r];
+    }
+    const u64 seg_end = re < tile_end ? re : tile_end;
+    const u32 a = (u32)(cur - tile_start), b = (u32)(seg_end - tile_start);
+    if (seg_end < tile_end) { /* the next record's end and place travel behind this segment's work */
+      re_next = op_off[r + 2];
+      rp_next = rec_pos[r + 1];
     }
     u64 mv, inc, span;
     measure(a, b, mv, inc, span);
-    if (seg_end == tile_end) publish(span);
-    const u64 base = (first && waits) ? cov_look_back(tile_tail, ops, rs0, g, lane, spin_limit, early) : 0ull;
-    emit(rp, a, b, mv, inc, span, base);
-    if (first) break;
+    emit(rp, a, b, mv, inc, span, 0ull);
     cur = seg_end;
     r++;
   }
