@@ -419,7 +419,7 @@ def check_pafcov_long_ops(eng):
 
 def check_pafcov_look_back(eng):
     rng = np.random.default_rng(77)
-    lens = [1024, 1, 2048 + 5, 70 * 1024 + 17, 3, 1019, 1024 * 3, 2, 5000, 1024 - 5]     # ops per record
+    lens = [2048, 1, 4096 + 5, 70 * 2048 + 17, 3, 2043, 2048 * 3, 2, 5000, 2048 - 5, 1024, 1024]     # ops per record (K5's tile: 2048)
     recs = []
     for n_ops in lens:
         code = rng.choice(np.array([7, 7, 7, 8, 1, 2, 0, 3, 4], dtype=np.uint32), n_ops)
@@ -429,9 +429,10 @@ def check_pafcov_look_back(eng):
     off = np.cumsum([0] + lens).astype(np.uint64)
     n = len(lens)
     b = dict(ops=ops, op_off=off, strand_neg=np.zeros(n, dtype=np.uint8))
-    tid = [0, 1, 0, 1, 0, 0, 1, 1, 0, 1]
-    check_pafcov(eng, b, tid, [0, 5, 100, 40, 9000, 20000, 250000, 7, 30000, 100], [60000, 300000])
-    check_pafcov(eng, b, tid, [0, 5, 100, 40, 9000, 20000, 250000, 7, 30000, 100], [60000, 300000], split=True)
+    tid = [0, 1, 0, 1, 0, 0, 1, 1, 0, 1, 0, 1]
+    starts = [0, 5, 100, 40, 9000, 20000, 250000, 7, 30000, 100, 41000, 290000]
+    check_pafcov(eng, b, tid, starts, [60000, 600000])
+    check_pafcov(eng, b, tid, starts, [60000, 600000], split=True)
 
 
 def check_pafcov(eng, b, target_id, t_start, target_len, align=4, split=False):
