@@ -49,19 +49,44 @@ def test_pafpseudo_targets_per_device(cli, tmp_path, monkeypatch, gpus):
 
 @pytest.mark.parametrize("gpus", ["2"])
 def test_maf_commands_blocks_per_device(cli, tmp_path, monkeypatch, gpus):
-    """`stat` and `call` on MAF under WGA_GPUS: a piece's blocks are dealt out in contiguous ranges, device 0 reads the rows
-    in place, the others a gathered copy; the single-device cases as they stand (fixture TSV, README golden VCF, synthetic
-    blocks against the oracle, a 90 000-column block in pieces, streaming pieces)"""
+    """`stat`, `call`, `maf2paf` and `maf2chain` on MAF under WGA_GPUS: a piece's blocks are dealt out in contiguous ranges,
+    device 0 reads the rows in place, the others a gathered copy; the single-device cases as they stand (fixture TSV and PAF,
+    README golden VCF, synthetic blocks against the oracle, a 90 000-column block in pieces, streaming pieces, chains with
+    their ids in input order)"""
     import cli_cases as cc
     monkeypatch.setenv("WGA_EMU_DEVICES", "3")
     monkeypatch.setenv("WGA_GPUS", gpus)
     cc.test_stat_maf_fixture(cli)
+    cc.test_maf2paf_fixture(cli)
+    cc.test_maf2chain_end_to_end(cli, tmp_path)
     cc.test_call_readme_golden(cli)
     cc.test_call_synthetic_blocks(cli, tmp_path, True, False, 3, 64)
     cc.test_call_query_selection(cli, tmp_path)
     if gpus == "2":
         cc.test_call_and_maf2paf_on_a_long_block(cli, tmp_path)
         cc.test_maf_streaming_pieces_give_the_same_bytes(cli, tmp_path)
+
+
+@pytest.mark.parametrize("gpus,chunk", [("3", None), ("2", "2000")])
+def test_paf2chain_ranges_per_device(cli, tmp_path, monkeypatch, gpus, chunk):
+    """`paf2chain` under WGA_GPUS: a piece's records in contiguous ranges over the devices, chain ids and bytes as on one device,
+    a failing record ends the output in front of itself whichever device owns it (one piece, and pieces of 2 000 bytes)"""
+    import cli_cases as cc
+    monkeypatch.setenv("WGA_EMU_DEVICES", "3")
+    monkeypatch.setenv("WGA_GPUS", gpus)
+    if chunk:
+        monkeypatch.setenv("WGA_CHUNK_BYTES", chunk)
+    cc.test_paf2chain_end_to_end(cli, tmp_path)
+    if not chunk:
+        cc.test_chain2paf_end_to_end(cli, tmp_path)      # the chains in contiguous ranges, rows in input order
+
+
+def test_validate_counts_meet_on_the_host(cli, tmp_path, monkeypatch):
+    """`validate` under WGA_GPUS: the records by target hash as `stat`, report and --fix rows as on one device"""
+    import cli_cases as cc
+    monkeypatch.setenv("WGA_EMU_DEVICES", "3")
+    monkeypatch.setenv("WGA_GPUS", "3")
+    cc.test_validate_report_and_fix(cli, tmp_path)
 
 
 def test_more_devices_than_visible(cli):

@@ -1465,18 +1465,9 @@ int cmd_stat_maf(const std::string* input, bool each, const std::string* query_n
 }
 
 /* ---- maf2paf (converter.rs:29-54, maf.rs:484-520) ------------------------------------------------ */
-int cmd_maf2paf(const std::string* input, const std::string* query_name, Output& out) {
-  Dev d;
-  MafChunks chunks(input);
-  std::string all_text; /* converter.rs:40-52 collects every record before it writes the first: an error leaves no output */
-  MafInput min;
-  while (chunks.next(d, min)) {
-  std::vector<MafRecord>& recs = min.recs;
-  select_query(recs, query_name);
-  const uint32_t n = (uint32_t)recs.size();
+/* the PAF rows of blocks recs[0 .. n), whose rows stand on device d (p) */
+static std::string maf2paf_rows(Dev& d, const MafRows& p, const MafRecord* const* recs, uint32_t n) {
   std::string text;
-  if (n) {
-    MafRows p = device_rows(d, min, all_records(recs), false);
     const uint8_t* d_rows = p.d_rows;
     auto *d_t = p.d_t, *d_q = p.d_q, *d_c = p.d_c;
     auto* d_s = p.d_s;
@@ -1500,7 +1491,7 @@ int cmd_maf2paf(const std::string* input, const std::string* query_name, Output&
     std::vector<uint64_t> blob_off{0}, dst, text_off(n);
     uint64_t pos = 0;
     for (uint32_t k = 0; k < n; k++) {
-      const MafRecord& r = recs[k];
+      const MafRecord& r = *recs[k];
       const wga_cigar_counts& c = counts[k];
       uint64_t block = c.match + c.mismatch + c.ins_bp + c.inv_ins_bp + c.del_bp + c.inv_del_bp;
       std::string h;
@@ -1537,9 +1528,27 @@ int cmd_maf2paf(const std::string* input, const std::string* query_name, Output&
                               d.upload(dst)));
     text.resize((size_t)pos);
     if (pos) d.download((uint8_t*)&text[0], d_out, pos);
-  }
-  all_text += text;
-  d.release_all();
+  return text;
+}
+
+int cmd_maf2paf(const std::string* input, const std::string* query_name, Output& out) {
+  Dev d;
+  MafDevices md(d); /* --gpus N: a piece's blocks in contiguous ranges over the devices, the rows meet in block order */
+  MafChunks chunks(input);
+  std::string all_text; /* converter.rs:40-52 collects every record before it writes the first: an error leaves no output */
+  MafInput min;
+  while (chunks.next(d, min)) {
+    std::vector<MafRecord>& recs = min.recs;
+    select_query(recs, query_name);
+    if (!recs.empty()) {
+      const std::vector<const MafRecord*> all = all_records(recs);
+      std::vector<std::string> part(md.count());
+      md.run(min, all, false, [&](int g, Dev& dg, const MafRows& p, uint32_t lo, uint32_t cnt) {
+        part[g] = maf2paf_rows(dg, p, all.data() + lo, cnt);
+      });
+      for (const std::string& t : part) all_text += t;
+    }
+    md.release_all();
   }
   out.write(all_text);
   out.close();
@@ -1556,27 +1565,43 @@ int cmd_validate(const std::string* input, const std::string* fix, Output& out) 
   uint64_t n_total = 0, q_bad = 0, t_bad = 0;
   std::string q_list, t_list, rows;
   PafInput pin;
+  std::vector<std::unique_ptr<Dev>> devs; /* --gpus N: devices 1 .. N - 1 next to `d` */
   while (chunks.next(d, pin)) { /* one piece of the file at a time */
     std::vector<PafRecord>& recs = pin.recs;
     const uint32_t n = (uint32_t)recs.size();
     std::vector<wga_cigar_counts> counts(n);
     d.init();
-    CigarTexts cigars;
-    wga_cigar_batch cb;
-    std::string e = device_tokenise(d, pin, 0, n, cigars, &cb);
-    const uint32_t m = cb.n;
-    if (m) {
-      auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)m * sizeof(wga_cigar_counts));
-      auto* d_diag = (wga_rec_diag*)d.alloc((size_t)m * sizeof(wga_rec_diag));
-      d.check(wga_cigar_stat(d.ctx, &cb, d_counts, d_diag, nullptr));
-      std::vector<wga_rec_diag> diag(m);
-      d.download(diag.data(), d_diag, m);
-      d.download(counts.data(), d_counts, m);
-      for (uint32_t k = 0; k < m && e.empty(); k++)
-        if (diag[k].bad_op_idx != WGA_NONE) {
-          e = "CIGAR OP `" + cigar_op_token_at(cigars[k], diag[k].bad_op_idx) + "` invalid";
-          break;
-        }
+    std::string e;
+    if (g_gpus > 1) { /* --gpus N: the records by target hash, as `stat` (the counts meet on the host) */
+      if (devs.empty()) {
+        devs.emplace_back(new Dev(0));
+        devs[0]->ctx = d.ctx; /* device 0's context is the reader's */
+        devs[0]->own_ctx = false;
+        for (int g = 1; g < g_gpus; g++) devs.emplace_back(new Dev(g));
+      }
+      try {
+        stat_piece_multi(devs, pin, counts);
+      } catch (Error& er) {
+        e = er.msg;
+      }
+    } else {
+      CigarTexts cigars;
+      wga_cigar_batch cb;
+      e = device_tokenise(d, pin, 0, n, cigars, &cb);
+      const uint32_t m = cb.n;
+      if (m) {
+        auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)m * sizeof(wga_cigar_counts));
+        auto* d_diag = (wga_rec_diag*)d.alloc((size_t)m * sizeof(wga_rec_diag));
+        d.check(wga_cigar_stat(d.ctx, &cb, d_counts, d_diag, nullptr));
+        std::vector<wga_rec_diag> diag(m);
+        d.download(diag.data(), d_diag, m);
+        d.download(counts.data(), d_counts, m);
+        for (uint32_t k = 0; k < m && e.empty(); k++)
+          if (diag[k].bad_op_idx != WGA_NONE) {
+            e = "CIGAR OP `" + cigar_op_token_at(cigars[k], diag[k].bad_op_idx) + "` invalid";
+            break;
+          }
+      }
     }
     /* rec.get_stat().unwrap() (:79) */
     if (!e.empty()) fail("panic: called `Result::unwrap()` on an `Err` value: " + e);
@@ -1653,39 +1678,27 @@ int cmd_validate(const std::string* input, const std::string* fix, Output& out) 
 /* ---- paf2chain (converter.rs:148-173) ------------------------------------------------
  * GPU: tokeniser, data lines and head / tail trims (wga_cigar_chain).  Host: chain headers
  * (chain.rs:142-203, incl. the '-' strand arithmetic that reuses the updated start) and the layout. */
-int cmd_paf2chain(const std::string* input, Output& out) {
-  Dev d;
-  PafChunks chunks(input, false);
-  bool dev_ready = false;
+/* the chains of records [lo, hi) of a piece on device d, in resident batches; a batch's text goes to `sink` while it is still on
+ * the device.  Returns the reference's message for the first failing record ("" if none): the records in front of it are written. */
+static std::string paf2chain_range(Dev& d, const PafInput& pin, size_t lo, size_t hi, uint64_t chain_base,
+                                   const uint8_t* d_text_here,
+                                   const std::function<void(Dev&, const uint8_t*, size_t)>& sink) {
+  const std::vector<PafRecord>& recs = pin.recs;
   const uint64_t kMaxText = 160ull << 20;
   std::string pending_error;
-  PafInput pin;
-  uint64_t chain_base = 0; /* chain id = index of the record in the whole input */
-  for (;;) {
-  bool more = false;
-  try {
-    more = chunks.next(d, pin);
-  } catch (Error& e) {
-    pending_error = e.msg;
-  }
-  if (!more) break;
-  const std::vector<PafRecord>& recs = pin.recs;
   const size_t keep = d.owned.size(); /* this piece's text */
-  size_t i0 = 0;
-  while (i0 < recs.size() && pending_error.empty()) {
+  size_t i0 = lo;
+  while (i0 < hi && pending_error.empty()) {
     size_t i = i0;
     uint64_t est_text = 0;
-    for (; i < recs.size(); i++) {
+    for (; i < hi; i++) {
       if (i > i0 && est_text > kMaxText) break;
       est_text += pin.cigar_bytes(i);
     }
-    if (!dev_ready) {
-      d.init();
-      dev_ready = true;
-    }
+    d.init();
     CigarTexts cigars;
     wga_cigar_batch cb;
-    pending_error = device_tokenise(d, pin, i0, (uint32_t)(i - i0), cigars, &cb);
+    pending_error = device_tokenise(d, pin, i0, (uint32_t)(i - i0), cigars, &cb, nullptr, nullptr, d_text_here);
     uint32_t n = cb.n;
     if (n) {
       auto* d_trim = (wga_chain_trim_t*)d.alloc((size_t)n * sizeof(wga_chain_trim_t));
@@ -1750,15 +1763,69 @@ int cmd_paf2chain(const std::string* input, Output& out) {
         d.check(wga_cigar_chain(d.ctx, &cb2, nullptr, nullptr, nullptr, d_out, d.upload(data_off)));
         d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off),
                                   d_out, d.upload(dst)));
-        stream_out(d, out, d_out, (size_t)pos);
+        sink(d, d_out, (size_t)pos);
       }
     }
     d.release_to(keep);
     i0 = i;
   }
-  chain_base += recs.size();
-  d.release_all();
-  if (!pending_error.empty()) break;
+  return pending_error;
+}
+
+int cmd_paf2chain(const std::string* input, Output& out) {
+  Dev d;
+  PafChunks chunks(input, false);
+  std::string pending_error;
+  PafInput pin;
+  uint64_t chain_base = 0; /* chain id = index of the record in the whole input */
+  std::vector<std::unique_ptr<Dev>> devs; /* --gpus N: devices 1 .. N - 1 next to `d` */
+  for (;;) {
+    bool more = false;
+    try {
+      more = chunks.next(d, pin);
+    } catch (Error& e) {
+      pending_error = e.msg;
+    }
+    if (!more) break;
+    const size_t n = pin.recs.size();
+    if (g_gpus == 1) {
+      pending_error = paf2chain_range(d, pin, 0, n, chain_base, nullptr,
+                                      [&](Dev& dg, const uint8_t* d_out, size_t bytes) { stream_out(dg, out, d_out, bytes); });
+    } else { /* a piece's records in contiguous ranges over the devices; the chains meet in input order, up to the first error */
+      d.init();
+      if (devs.empty()) {
+        devs.emplace_back(new Dev(0));
+        devs[0]->ctx = d.ctx; /* device 0's context is the reader's */
+        devs[0]->own_ctx = false;
+        for (int g = 1; g < g_gpus; g++) devs.emplace_back(new Dev(g));
+      }
+      const int ng = g_gpus;
+      std::vector<std::string> part(ng), err(ng);
+      std::string text16;
+      if (pin.on_device) text16 = pin.text + std::string(16, '\0');
+      on_devices(ng, [&](int g) {
+        const size_t lo = n * (size_t)g / ng, hi = n * (size_t)(g + 1) / ng;
+        if (lo == hi) return;
+        Dev& dg = *devs[g];
+        dg.init();
+        const size_t keep = dg.owned.size();
+        const uint8_t* d_text = nullptr;
+        if (pin.on_device) d_text = g == 0 ? pin.d_text : dg.upload((const uint8_t*)text16.data(), text16.size());
+        err[g] = paf2chain_range(dg, pin, lo, hi, chain_base, d_text, [&](Dev& dd, const uint8_t* d_out, size_t bytes) {
+          const size_t at = part[g].size();
+          part[g].resize(at + bytes);
+          if (bytes) dd.download((uint8_t*)&part[g][at], d_out, bytes);
+        });
+        dg.release_to(keep);
+      });
+      for (int g = 0; g < ng && pending_error.empty(); g++) {
+        out.write(part[g]);
+        pending_error = err[g];
+      }
+    }
+    chain_base += n;
+    d.release_all();
+    if (!pending_error.empty()) break;
   }
   out.close();
   if (!pending_error.empty()) fail(pending_error);
@@ -1872,28 +1939,21 @@ int cmd_chain2maf(const std::string* input, const std::string& t_fa, const std::
 /* ---- chain2paf (converter.rs:391-416, chain.rs:430-452) ------------------------------------------------
  * GPU: data lines -> ops -> K1 (matches, block length) and the CIGAR text (wga_chain_lines_cigar_text).
  * All records are converted before the first is written (:402-410): an error leaves the output empty. */
-int cmd_chain2paf(const std::string* input, Output& out) {
-  std::string perr;
-  std::vector<ChainRecord> recs = parse_chain(read_all(input), &perr);
-  if (!perr.empty()) {
-    out.close();
-    fail(perr);
-  }
-  Dev d;
-  bool dev_ready = false;
+/* the PAF rows of chains recs[0 .. n_recs) on device d, in resident batches; a batch's text goes to `sink` while it is on the device */
+static void chain2paf_range(Dev& d, const ChainRecord* recs, size_t n_recs,
+                            const std::function<void(Dev&, const uint8_t*, size_t)>& sink) {
+  d.init();
+  const size_t keep = d.owned.size();
   const uint64_t kMaxLines = 32ull << 20;
   size_t i0 = 0;
-  while (i0 < recs.size()) {
+  while (i0 < n_recs) {
     size_t i = i0;
     uint64_t est = 0;
-    for (; i < recs.size(); i++) {
+    for (; i < n_recs; i++) {
       if (i > i0 && est > kMaxLines) break;
       est += recs[i].lines.size() / 3;
     }
-    if (!dev_ready) {
-      d.init();
-      dev_ready = true;
-    }
+    d.init();
     const uint32_t n = (uint32_t)(i - i0);
     ChainBatch b = chain_device_batch(d, &recs[i0], n);
     auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
@@ -1944,9 +2004,40 @@ int cmd_chain2paf(const std::string* input, Output& out) {
     d.check(wga_chain_lines_cigar_text(d.ctx, n, b.n_lines, b.d_lines, b.d_line_off, nullptr, d_out, d.upload(text_off)));
     d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off), d_out,
                               d.upload(dst)));
-    stream_out(d, out, d_out, (size_t)pos);
-    d.release_all();
+    sink(d, d_out, (size_t)pos);
+    d.release_to(keep);
     i0 = i;
+  }
+}
+
+int cmd_chain2paf(const std::string* input, Output& out) {
+  std::string perr;
+  std::vector<ChainRecord> recs = parse_chain(read_all(input), &perr);
+  if (!perr.empty()) {
+    out.close();
+    fail(perr);
+  }
+  Dev d;
+  if (g_gpus == 1 || recs.size() < 2) {
+    if (!recs.empty())
+      chain2paf_range(d, recs.data(), recs.size(),
+                      [&](Dev& dg, const uint8_t* d_out, size_t bytes) { stream_out(dg, out, d_out, bytes); });
+  } else { /* --gpus N: the chains in contiguous ranges over the devices, the rows meet in input order */
+    const int ng = g_gpus;
+    const size_t n = recs.size();
+    std::vector<std::unique_ptr<Dev>> devs;
+    for (int g = 0; g < ng; g++) devs.emplace_back(new Dev(g));
+    std::vector<std::string> part(ng);
+    on_devices(ng, [&](int g) {
+      const size_t lo = n * (size_t)g / ng, hi = n * (size_t)(g + 1) / ng;
+      if (lo == hi) return;
+      chain2paf_range(*devs[g], recs.data() + lo, hi - lo, [&](Dev& dd, const uint8_t* d_out, size_t bytes) {
+        const size_t at = part[g].size();
+        part[g].resize(at + bytes);
+        if (bytes) dd.download((uint8_t*)&part[g][at], d_out, bytes);
+      });
+    });
+    for (const std::string& t : part) out.write(t);
   }
   out.close();
   return 0;
@@ -1955,39 +2046,10 @@ int cmd_chain2paf(const std::string* input, Output& out) {
 /* ---- maf2chain (converter.rs:57-91) ---------------------------------------------------------------------
  * GPU: K3 column-pair runs -> packed ops (wga_maf_runs_ops) -> data lines and trims (wga_cigar_chain; '=' and X
  * runs add up into one block like cigar_cat's M).  Host: chain headers (chain.rs:103-140,185-203). */
-int cmd_maf2chain(const std::string* input, const std::string* query_name, Output& out) {
-  Dev d;
-  MafChunks chunks(input);
-  MafInput min;
-  uint64_t chain_base = 0; /* chain id = index of the block in the whole input */
-  std::string pending_error;
-  while (pending_error.empty() && chunks.next(d, min)) {
-  std::vector<MafRecord>& recs = min.recs;
-  const uint64_t n_in_piece = recs.size();
-  /* set_query_idx_byname fails per record, after the earlier records were written (:66-73) */
-  size_t n_ok = recs.size();
-  for (size_t k = 0; k < recs.size() && pending_error.empty(); k++) {
-    MafRecord& r = recs[k];
-    if (query_name) {
-      size_t x = 0;
-      for (; x < r.slines.size(); x++)
-        if (r.slines[x].name == *query_name) break;
-      if (x == r.slines.size()) {
-        pending_error = "Query name:" + *query_name + " not found in MAF";
-        n_ok = k;
-        break;
-      }
-      r.query_idx = x;
-    }
-    if (r.query_idx >= r.slines.size()) {
-      pending_error = "panic: MAF block with a single s-line has no query row (maf.rs:426 index out of bounds)";
-      n_ok = k;
-    }
-  }
-  recs.resize(n_ok);
-  const uint32_t n = (uint32_t)recs.size();
-  if (n) {
-    MafRows p = device_rows(d, min, all_records(recs), false);
+/* the chains of blocks recs[0 .. n), whose rows stand on device d (p); chain ids from chain_id0.  The text stays on the device:
+ * *d_text, *bytes. */
+static void maf2chain_text(Dev& d, const MafRows& p, const MafRecord* const* recs, uint32_t n, uint64_t chain_id0,
+                           const uint8_t** d_text, uint64_t* bytes) {
     const uint8_t* d_rows = p.d_rows;
     auto *d_t = p.d_t, *d_q = p.d_q, *d_c = p.d_c;
     auto* d_s = p.d_s;
@@ -2026,7 +2088,7 @@ int cmd_maf2chain(const std::string* input, const std::string* query_name, Outpu
     std::vector<uint64_t> blob_off{0}, dst, data_off(n);
     uint64_t pos = 0;
     for (uint32_t k = 0; k < n; k++) {
-      const MafRecord& r = recs[k];
+      const MafRecord& r = *recs[k];
       const wga_chain_trim_t& t = trim[k];
       const bool neg = r.q().neg;
       uint64_t qs = r.query_start(), qe = r.query_end();
@@ -2051,7 +2113,7 @@ int cmd_maf2chain(const std::string* input, const std::string* query_name, Outpu
       h.push_back('\t');
       append_u64(h, qe);
       h.push_back('\t');
-      append_u64(h, chain_base + (uint64_t)k);
+      append_u64(h, chain_id0 + (uint64_t)k);
       dst.push_back(pos);
       blob += h;
       blob_off.push_back(blob.size());
@@ -2067,10 +2129,64 @@ int cmd_maf2chain(const std::string* input, const std::string* query_name, Outpu
     d.check(wga_cigar_chain(d.ctx, &cb, nullptr, nullptr, nullptr, d_out, d.upload(data_off)));
     d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off), d_out,
                               d.upload(dst)));
-    stream_out(d, out, d_out, (size_t)pos);
+    *d_text = d_out;
+    *bytes = pos;
+}
+
+int cmd_maf2chain(const std::string* input, const std::string* query_name, Output& out) {
+  Dev d;
+  MafDevices md(d);
+  MafChunks chunks(input);
+  MafInput min;
+  uint64_t chain_base = 0; /* chain id = index of the block in the whole input */
+  std::string pending_error;
+  while (pending_error.empty() && chunks.next(d, min)) {
+  std::vector<MafRecord>& recs = min.recs;
+  const uint64_t n_in_piece = recs.size();
+  /* set_query_idx_byname fails per record, after the earlier records were written (:66-73) */
+  size_t n_ok = recs.size();
+  for (size_t k = 0; k < recs.size() && pending_error.empty(); k++) {
+    MafRecord& r = recs[k];
+    if (query_name) {
+      size_t x = 0;
+      for (; x < r.slines.size(); x++)
+        if (r.slines[x].name == *query_name) break;
+      if (x == r.slines.size()) {
+        pending_error = "Query name:" + *query_name + " not found in MAF";
+        n_ok = k;
+        break;
+      }
+      r.query_idx = x;
+    }
+    if (r.query_idx >= r.slines.size()) {
+      pending_error = "panic: MAF block with a single s-line has no query row (maf.rs:426 index out of bounds)";
+      n_ok = k;
+    }
+  }
+  recs.resize(n_ok);
+  if (!recs.empty()) {
+    const std::vector<const MafRecord*> all = all_records(recs);
+    if (md.count() == 1) {
+      md.run(min, all, false, [&](int, Dev& dg, const MafRows& p, uint32_t lo, uint32_t cnt) {
+        const uint8_t* d_text = nullptr;
+        uint64_t bytes = 0;
+        maf2chain_text(dg, p, all.data() + lo, cnt, chain_base + lo, &d_text, &bytes);
+        stream_out(dg, out, d_text, (size_t)bytes);
+      });
+    } else { /* --gpus N: a piece's blocks in contiguous ranges over the devices, the chains meet in block order */
+      std::vector<std::string> part(md.count());
+      md.run(min, all, false, [&](int g, Dev& dg, const MafRows& p, uint32_t lo, uint32_t cnt) {
+        const uint8_t* d_text = nullptr;
+        uint64_t bytes = 0;
+        maf2chain_text(dg, p, all.data() + lo, cnt, chain_base + lo, &d_text, &bytes);
+        part[g].resize((size_t)bytes);
+        if (bytes) dg.download((uint8_t*)&part[g][0], d_text, bytes);
+      });
+      for (const std::string& t : part) out.write(t);
+    }
   }
   chain_base += n_in_piece;
-  d.release_all();
+  md.release_all();
   }
   out.close();
   if (!pending_error.empty()) fail(pending_error);
