@@ -1484,11 +1484,17 @@ __device__ __forceinline__ void paf_call_walk(const u32* __restrict__ rec, u64 n
   u64 t_base = st.t, q_base = st.q, e_base = st.e;
   u32 carry_code = a ? (rec[a - 1] & 15u) : 0xFu;
   *bad_at = WGA_NONE;
+  u32 wnext[4]; /* the next step's ops travel behind the work on this step's */
+#pragma unroll
+  for (int e = 0; e < 4; e++) wnext[e] = a + (u64)lane * 4u + (u64)e < b ? rec[a + (u64)lane * 4u + e] : 0xFu; /* 0xF: no op */
   for (u64 k0 = a; k0 < b; k0 += 256) {
     const u64 kb = k0 + (u64)lane * 4u;
     u32 w[4];
 #pragma unroll
-    for (int e = 0; e < 4; e++) w[e] = kb + (u64)e < b ? rec[kb + e] : 0xFu; /* 0xF: no op */
+    for (int e = 0; e < 4; e++) {
+      w[e] = wnext[e];
+      wnext[e] = kb + 256u + (u64)e < b ? rec[kb + 256u + e] : 0xFu;
+    }
     u32 code[4], len[4];
     bool valid[4], isi[4], isd[4];
     u32 firstbad = 4u; /* first op of this lane outside M = X I D (and inside the range) */
@@ -2790,6 +2796,9 @@ __device__ __forceinline__ bool dotplot_walk(const u32* __restrict__ rec, u64 a,
                                              u64* out, u32 lane, u32* first_ev) {
   u64 r_base = ds.r, q_base = ds.q, nseg = ds.nseg;
   u32 carry_state = ds.state, first_seen = 0u;
+  u32 wnext[4]; /* the next step's ops travel behind the work on this step's */
+#pragma unroll
+  for (int e = 0; e < 4; e++) wnext[e] = a + (u64)lane * 4u + (u64)e < b ? rec[a + (u64)lane * 4u + e] : 0xFu;
   for (u64 k0 = a; k0 < b; k0 += 256) {
     const u64 kb = k0 + (u64)lane * 4u;
     u32 len[4], radv[4], qadv[4];
@@ -2798,8 +2807,8 @@ __device__ __forceinline__ bool dotplot_walk(const u32* __restrict__ rec, u64 a,
     u32 sr = 0, sq = 0, last_ev = 0, lane_first = 0;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-      const bool in = kb + (u64)e < b;
-      const u32 w = in ? rec[kb + e] : 0xFu;
+      const u32 w = wnext[e];
+      wnext[e] = kb + 256u + (u64)e < b ? rec[kb + 256u + e] : 0xFu;
       const u32 code = w & 15u;
       len[e] = w >> 4;
       ml[e] = code == WGA_OP_M || code == WGA_OP_EQ || code == WGA_OP_X;
