@@ -2681,7 +2681,7 @@ __device__ __forceinline__ void lds_text_flush(const u8* tbuf, u32 a, u32 total,
 }
 
 /* One thread per element, 256 consecutive elements per block.  The records of the block's first and last element are
- * found once (two bisections per block); every thread then looks inside that window — one record in nearly every block.
+ * found once (two wave-wide searches per block); every thread then looks inside that window — one record in nearly every block.
  * A block whose elements belong to ONE record writes one contiguous stretch of that record's output: its threads put
  * their units into an LDS buffer that mirrors the stretch's position inside its 16-byte group, and the stretch goes out
  * in 16-byte stores.  Blocks across a record border, or with more output than the buffer holds, write directly. */
@@ -2695,8 +2695,11 @@ __global__ __launch_bounds__(256) void k_elem_fill(F f, u32 n, u32 ne, const u64
   __shared__ u32 s_r[2];
   const u32 tid = threadIdx.x;
   const u32 x0 = blockIdx.x * 256u, x1 = x0 + 256u < ne ? x0 + 256u : ne;
-  if (tid == 0u) s_r[0] = csr_find_rec(elem_off, n, (u64)x0);
-  if (tid == 64u) s_r[1] = csr_find_rec(elem_off, n, (u64)(x1 - 1u));
+  /* two waves search, 64 probes a step (three steps for 10^5 records where one thread's bisection takes seventeen) */
+  if (tid < 128u) { /* wave-uniform */
+    const u32 r = wga_find_rec(elem_off, n, tid < 64u ? (u64)x0 : (u64)(x1 - 1u));
+    if ((tid & 63u) == 0u) s_r[tid >> 6] = r;
+  }
   __syncthreads();
   const u32 r_lo = WGA_UNI32(s_r[0]), r_hi = WGA_UNI32(s_r[1]);
   const u32 x = x0 + tid;
