@@ -866,9 +866,16 @@ def test_chain2paf_end_to_end(cli, tmp_path):
         assert rc == 1 and out == b"" and err.strip().endswith("ERROR " + msg), (bad, err)
 
 
-def test_chain2maf_end_to_end(cli, tmp_path):
+def test_chain2maf_end_to_end(cli, tmp_path, to_file=False):
     """converter.rs:268-358: slices fetched on the forward strand, query reverse-complemented for '-', '-' runs
-    inserted per data line (parse_chain_to_insert); score 255; the failing record ends the stream"""
+    inserted per data line (parse_chain_to_insert); score 255; the failing record ends the stream
+    (to_file: through -o, the path `--gpus N` shards)"""
+    def run_out(*args):
+        if not to_file:
+            return run(cli, *args)
+        path = str(tmp_path / "out.maf")
+        rc, _, err = run(cli, *args, "-o", path, "-r")
+        return rc, open(path, "rb").read(), err
     rng = np.random.default_rng(8)
     recs = _synth_chain(6, 25, max_lines=200)
     T, Q = 400000, 380000
@@ -893,7 +900,7 @@ def test_chain2maf_end_to_end(cli, tmp_path):
                 "-" if r["neg"] else "+", Q, eq.decode()))
         return "".join(out).encode()
     ch.write_text(_chain_text(recs, "tchr", T, "qchr", Q, starts))
-    rc, out, err = run(cli, "chain2maf", str(ch), "--target", str(t_fa), "--query", str(q_fa))
+    rc, out, err = run_out("chain2maf", str(ch), "--target", str(t_fa), "--query", str(q_fa))
     assert rc == 0, err
     assert out == expected(recs, starts)
     # record 9 claims fewer bases than its lines consume: String::insert_str panics in the reference
@@ -902,7 +909,7 @@ def test_chain2maf_end_to_end(cli, tmp_path):
     broken[9]["q_ali"] -= 40
     broken[9]["lines"] = broken[9]["lines"][:-1] + [(broken[9]["lines"][-1][0], 3, 0), (1, 0, 0)]
     ch.write_text(_chain_text(broken, "tchr", T, "qchr", Q, starts))
-    rc, out, err = run(cli, "c2m", str(ch), "-g", str(t_fa), "-q", str(q_fa))
+    rc, out, err = run_out("c2m", str(ch), "-g", str(t_fa), "-q", str(q_fa))
     assert rc == 1 and "panic" in err
     assert out == expected(recs[:9], starts[:9])
 

@@ -79,6 +79,8 @@ def test_paf2chain_ranges_per_device(cli, tmp_path, monkeypatch, gpus, chunk):
     cc.test_paf2chain_end_to_end(cli, tmp_path)
     if not chunk:
         cc.test_chain2paf_end_to_end(cli, tmp_path)      # the chains in contiguous ranges, rows in input order
+        # chain2maf: sizes, offsets, rows pwritten by every device; the file ends in front of the failing record
+        cc.test_chain2maf_end_to_end(cli, tmp_path, to_file=True)
 
 
 def test_validate_counts_meet_on_the_host(cli, tmp_path, monkeypatch):

@@ -1871,29 +1871,24 @@ ChainBatch chain_device_batch(Dev& d, const ChainRecord* recs, uint32_t n) {
 /* ---- chain2maf (converter.rs:268-358) ------------------------------------------------------------------
  * A data line (size, dt, dq) is the op group "size M, dq I, dt D" of parse_chain_to_insert (:360-388), so the
  * rows come from the same kernels as paf2maf.  Records before a failing one are written, like the reference. */
-int cmd_chain2maf(const std::string* input, const std::string& t_fa, const std::string& q_fa, Output& out) {
-  std::string pending_error;
-  std::vector<ChainRecord> recs = parse_chain(read_all(input), &pending_error);
-  DevFasta tf, qf;
-  Dev d;
-  d.init();
-  tf.load(d, t_fa);
-  qf.load(d, q_fa);
-  out.write("#maf version=1.6 convert_from=chain t_seq_path=" + t_fa + " q_seq_path=" + q_fa + "\n");
-  uint8_t* d_tpool = tf.d_pool;
-  uint8_t* d_qpool = qf.d_pool;
+/* the converter's record loop over chains [lo, hi), in resident batches: slices fetched (:309-316: target first, then query, both on
+ * the forward strand), data lines -> ops, rows expanded, text handed to the sink (record k of the run is record k of the file).
+ * Returns the index of the first failing record, or hi; `err` = the reference's message for it. */
+static size_t c2m_run(Dev& d, DevFasta& tf, DevFasta& qf, const std::vector<ChainRecord>& recs, size_t lo, size_t hi, BatchSink sink,
+                      std::string& err) {
   const uint64_t kMaxBytes = 6ull << 30, kMaxLines = 32ull << 20;
-  size_t i0 = 0;
-  while (i0 < recs.size()) {
+  const size_t keep = d.owned.size(); /* the pools stay */
+  size_t i0 = lo;
+  while (i0 < hi) {
     ExpandJob job;
     uint64_t est = 0, est_lines = 0;
     size_t i = i0;
     std::string fetch_error;
-    for (; i < recs.size(); i++) {
+    for (; i < hi; i++) {
       const ChainRecord& r = recs[i];
       if (i > i0 && (est > kMaxBytes || est_lines > kMaxLines)) break;
       uint64_t to, tl, qo, ql;
-      try { /* :309-316: target first, then query, both on the forward strand */
+      try {
         tf.fetch(r.target_name, r.target_start, r.target_end - 1, &to, &tl);
         qf.fetch(r.query_name, r.query_start, r.query_end - 1, &qo, &ql);
       } catch (Error& e) {
@@ -1910,27 +1905,104 @@ int cmd_chain2maf(const std::string* input, const std::string& t_fa, const std::
     if (n) {
       ChainBatch b = chain_device_batch(d, &recs[i0], n);
       wga_rec_diag g;
-      BatchSink sink;
-      sink.out = &out;
-      const uint32_t good = expand_batch(d, b.cb, job, d_tpool, tf.bytes, d_qpool, qf.bytes, sink, &g);
+      sink.which = nullptr;
+      sink.first = i0;
+      const uint32_t good = expand_batch(d, b.cb, job, tf.d_pool, tf.bytes, qf.d_pool, qf.bytes, sink, &g);
       d.check(wga_sync(d.ctx));
-      while (d.owned.size() > 2) d.release(d.owned.back());
       if (good < n) {
         if (g.bad_base_pos != WGA_NONE) { /* utils.rs:97, reverse_complement of the query slice (:320-325) */
           char c = qf.at(d, job.q_off[good] + job.q_len[good] - 1 - g.bad_base_pos);
-          pending_error = std::string("Invalid Base: `") + c + "`";
+          err = std::string("Invalid Base: `") + c + "`";
         } else {
-          pending_error = "panic: String::insert_str beyond the end of the fetched sequence (converter.rs:375,383)";
+          err = "panic: String::insert_str beyond the end of the fetched sequence (converter.rs:375,383)";
         }
-        break;
+        d.release_to(keep);
+        return i0 + good;
       }
+      d.release_to(keep);
     }
     if (!fetch_error.empty()) {
-      pending_error = fetch_error;
-      break;
+      err = fetch_error;
+      return i;
     }
     i0 = i;
   }
+  return hi;
+}
+
+/* `wgatools --gpus N chain2maf`: the chains in N contiguous ranges, both pools on every device; sizes first (K1 + layout), a
+ * prefix gives every record its file offset, rows second, every device pwrite()s its records; the file ends in front of the
+ * first failing record. */
+static int cmd_chain2maf_multi(std::vector<ChainRecord>& recs, std::string pending_error, const std::string& t_fa,
+                               const std::string& q_fa, Output& out, int ngpu) {
+  std::vector<std::unique_ptr<Dev>> devs;
+  for (int g = 0; g < ngpu; g++) devs.emplace_back(new Dev(g));
+  std::vector<DevFasta> tf(ngpu), qf(ngpu);
+  on_devices(ngpu, [&](int g) {
+    devs[g]->init();
+    tf[g].load(*devs[g], t_fa);
+    qf[g].load(*devs[g], q_fa);
+  });
+  out.write("#maf version=1.6 convert_from=chain t_seq_path=" + t_fa + " q_seq_path=" + q_fa + "\n");
+  uint64_t pos0 = 0;
+  const int fd = out.plain_fd(&pos0);
+  if (fd < 0) fail("internal error: --gpus needs a plain output file");
+  const size_t n = recs.size();
+  std::vector<uint64_t> sizes(n, 0), offsets(n + 1, 0);
+  std::vector<size_t> bad_at(ngpu, n);
+  std::vector<std::string> bad_msg(ngpu);
+  auto pass = [&](BatchSink::Mode mode, size_t upto) {
+    on_devices(ngpu, [&](int g) {
+      const size_t lo = n * (size_t)g / ngpu, hi = std::min(upto, n * (size_t)(g + 1) / ngpu);
+      if (lo >= hi) return;
+      BatchSink sink;
+      sink.mode = mode;
+      sink.sizes = &sizes;
+      sink.offsets = &offsets;
+      sink.fd = fd;
+      std::string err;
+      const size_t k = c2m_run(*devs[g], tf[g], qf[g], recs, lo, hi, sink, err);
+      if (k < hi && k < bad_at[g]) {
+        bad_at[g] = k;
+        bad_msg[g] = err;
+      }
+    });
+  };
+  pass(BatchSink::SIZES, n);
+  size_t first_bad = n;
+  for (int g = 0; g < ngpu; g++) first_bad = std::min(first_bad, bad_at[g]);
+  offsets[0] = pos0;
+  for (size_t i = 0; i < n; i++) offsets[i + 1] = offsets[i] + (i < first_bad ? sizes[i] : 0);
+  pass(BatchSink::ROWS, first_bad);
+  for (int g = 0; g < ngpu; g++) first_bad = std::min(first_bad, bad_at[g]);
+  if (first_bad < n)
+    for (int g = 0; g < ngpu; g++)
+      if (bad_at[g] == first_bad) pending_error = bad_msg[g];
+  if (ftruncate(fd, (off_t)offsets[first_bad]) != 0) fail("IO error:truncate failed");
+  out.advance(offsets[first_bad] - pos0);
+  out.close();
+  if (!pending_error.empty()) fail(pending_error);
+  return 0;
+}
+
+int cmd_chain2maf(const std::string* input, const std::string& t_fa, const std::string& q_fa, Output& out) {
+  std::string pending_error;
+  std::vector<ChainRecord> recs = parse_chain(read_all(input), &pending_error);
+  {
+    uint64_t pos = 0;
+    if (g_gpus > 1 && recs.size() > 1 && out.plain_fd(&pos) >= 0)
+      return cmd_chain2maf_multi(recs, pending_error, t_fa, q_fa, out, g_gpus);
+  }
+  DevFasta tf, qf;
+  Dev d;
+  d.init();
+  tf.load(d, t_fa);
+  qf.load(d, q_fa);
+  out.write("#maf version=1.6 convert_from=chain t_seq_path=" + t_fa + " q_seq_path=" + q_fa + "\n");
+  BatchSink sink;
+  sink.out = &out;
+  std::string err;
+  if (c2m_run(d, tf, qf, recs, 0, recs.size(), sink, err) < recs.size()) pending_error = err;
   out.close();
   if (!pending_error.empty()) fail(pending_error);
   return 0;
