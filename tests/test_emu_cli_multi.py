@@ -83,6 +83,17 @@ def test_paf2chain_ranges_per_device(cli, tmp_path, monkeypatch, gpus, chunk):
         cc.test_chain2maf_end_to_end(cli, tmp_path, to_file=True)
 
 
+def test_dotplot_ranges_per_device(cli, tmp_path, monkeypatch):
+    """`dotplot --out-format csv` under WGA_GPUS: a piece's PAF records / MAF blocks in contiguous ranges over the devices,
+    segment rows and overview rows in input order (the single-device cases as they stand, incl. the reference's test.html rows)"""
+    import cli_cases as cc
+    monkeypatch.setenv("WGA_EMU_DEVICES", "3")
+    monkeypatch.setenv("WGA_GPUS", "3")
+    cc.test_dotplot_base_level_csv(cli, tmp_path)
+    cc.test_dotplot_overview_csv(cli, tmp_path)
+    cc.test_dotplot_test_html_golden(cli)
+
+
 def test_validate_counts_meet_on_the_host(cli, tmp_path, monkeypatch):
     """`validate` under WGA_GPUS: the records by target hash as `stat`, report and --fix rows as on one device"""
     import cli_cases as cc

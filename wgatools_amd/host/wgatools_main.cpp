@@ -2270,118 +2270,32 @@ int cmd_maf2chain(const std::string* input, const std::string* query_name, Outpu
  * overview: one row per record, identity = matched / target_align_size from K1 / K3.  All data is generated
  * before anything is written (:208-262), so an error leaves the output empty.  The html / json outputs embed
  * the reference's Vega-Lite document and are not provided. */
-int cmd_dotplot(const std::string* input, const std::string& format, const std::string& out_format,
-                const std::string& mode, bool no_identity, uint64_t cutoff, const std::string* query_name, Output& out) {
-  if (mode != "base-level" && mode != "overview") fail("invalid value '" + mode + "' for '--mode <MODE>'");
-  if (out_format != "csv") {
-    if (out_format == "html" || out_format == "json")
-      fail("out-format `" + out_format + "` embeds the reference's Vega-Lite document and is not provided by this engine (use --out-format csv)");
-    fail("invalid value '" + out_format + "' for '--out-format <OUT_FORMAT>'");
-  }
-  if (format != "maf" && format != "paf") fail("Only support MAF and PAF format");
-  const bool base = mode == "base-level";
-  std::string text; /* all data is generated before anything is written (dotplot.rs:208-262) */
-  Dev d;
-  /* one piece of the input (PAF records or MAF blocks) -> csv rows appended to `text` */
-  auto piece = [&](PafInput* ppin, MafInput* pmin) {
+/* the records of one device's share of a piece, as the csv rows need them */
+struct DotRecs {
   std::vector<std::string> t_names, q_names;
-  std::vector<uint64_t> ts, te, qs, qe;
+  std::vector<uint64_t> ts, te, qs, qe, ali;
   std::vector<uint8_t> negs;
-  wga_cigar_batch cb;
-  cb.n = 0;
-  std::vector<wga_cigar_counts> counts;
-  std::vector<uint64_t> ali;
-  if (ppin) {
-    PafInput& pin = *ppin;
-    const std::vector<PafRecord>& recs = pin.recs;
-    const uint32_t n = (uint32_t)recs.size();
-    for (const PafRecord& r : recs) {
-      t_names.push_back(r.target_name);
-      q_names.push_back(r.query_name);
-      ts.push_back(r.target_start);
-      te.push_back(r.target_end);
-      qs.push_back(r.query_start);
-      qe.push_back(r.query_end);
-      negs.push_back(r.neg ? 1 : 0);
-      ali.push_back(r.target_end - r.target_start);
-    }
-    if (n && (base || !no_identity)) {
-      d.init();
-      CigarTexts cigars;
-      std::string e = device_tokenise(d, pin, 0, n, cigars, &cb);
-      if (!base && cb.n) { /* get_stat (paf.rs:205-209): ops outside M = X I D are an error */
-        auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)cb.n * sizeof(wga_cigar_counts));
-        auto* d_diag = (wga_rec_diag*)d.alloc((size_t)cb.n * sizeof(wga_rec_diag));
-        d.check(wga_cigar_stat(d.ctx, &cb, d_counts, d_diag, nullptr));
-        counts.resize(cb.n);
-        std::vector<wga_rec_diag> diag(cb.n);
-        d.download(counts.data(), d_counts, cb.n);
-        d.download(diag.data(), d_diag, cb.n);
-        for (uint32_t k = 0; k < cb.n; k++)
-          if (diag[k].bad_op_idx != WGA_NONE) {
-            e = "CIGAR OP `" + cigar_op_token_at(cigars[k], diag[k].bad_op_idx) + "` invalid";
-            break;
-          }
-      }
-      if (!e.empty()) {
-        out.close();
-        fail(e);
-      }
-    }
-  } else {
-    MafInput& min = *pmin;
-    std::vector<MafRecord>& recs = min.recs;
-    select_query(recs, query_name);
-    const uint32_t n = (uint32_t)recs.size();
-    for (const MafRecord& r : recs) {
-      t_names.push_back(r.t().name);
-      q_names.push_back(r.q().name);
-      ts.push_back(r.t().start);
-      te.push_back(r.t().start + r.t().align_size);
-      qs.push_back(r.query_start());
-      qe.push_back(r.query_end());
-      negs.push_back(r.q().neg ? 1 : 0);
-      ali.push_back(r.t().align_size);
-    }
-    if (n && (base || !no_identity)) {
-      MafRows p = device_rows(d, min, all_records(recs), false);
-      const uint8_t* d_rows = p.d_rows;
-      auto *d_t = p.d_t, *d_q = p.d_q, *d_c = p.d_c;
-      auto* d_s = p.d_s;
-      auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
-      auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
-      d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, nullptr, nullptr));
-      if (!base) {
-        counts.resize(n);
-        d.download(counts.data(), d_counts, n);
-      } else {
-        auto* d_roff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
-        d.check(wga_exclusive_scan_u64(d.ctx, n, d_cnt, d_roff));
-        uint64_t n_runs = 0;
-        d.download(&n_runs, d_roff + n, 1);
-        auto* d_runs = (uint64_t*)d.alloc((n_runs + 1) * 8);
-        d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, d_runs, d_roff));
-        auto* d_ocnt = (uint64_t*)d.alloc((size_t)n * 8);
-        d.check(wga_maf_runs_ops(d.ctx, n, n_runs, d_runs, d_roff, d_c, d_ocnt, nullptr, nullptr));
-        auto* d_ooff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
-        d.check(wga_exclusive_scan_u64(d.ctx, n, d_ocnt, d_ooff));
-        uint64_t n_ops = 0;
-        d.download(&n_ops, d_ooff + n, 1);
-        auto* d_ops = (uint32_t*)d.alloc((n_ops + 4) * 4);
-        d.check(wga_maf_runs_ops(d.ctx, n, n_runs, d_runs, d_roff, d_c, nullptr, d_ops, d_ooff));
-        cb.d_ops = d_ops;
-        cb.d_op_off = d_ooff;
-        cb.d_strand_neg = d_s;
-        cb.n_ops = n_ops;
-        cb.n = n;
-      }
-    }
+  void add(const std::string& t, const std::string& q, uint64_t ts_, uint64_t te_, uint64_t qs_, uint64_t qe_, bool neg, uint64_t a) {
+    t_names.push_back(t);
+    q_names.push_back(q);
+    ts.push_back(ts_);
+    te.push_back(te_);
+    qs.push_back(qs_);
+    qe.push_back(qe_);
+    negs.push_back(neg ? 1 : 0);
+    ali.push_back(a);
   }
-  const uint32_t n = (uint32_t)t_names.size();
+};
+/* csv rows (no header line) of the records R: base-level segments from wga_cigar_dotplot over the device batch cb, or one
+ * overview row per record from the counts */
+static std::string dotplot_rows(Dev& d, bool base, bool no_identity, uint64_t cutoff, const DotRecs& R, const wga_cigar_batch& cb,
+                                const std::vector<wga_cigar_counts>& counts) {
+  std::string text;
+  const uint32_t n = (uint32_t)R.t_names.size();
   if (base) {
     if (n) {
       auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
-      auto *d_ts = d.upload(ts), *d_qs = d.upload(qs);
+      auto *d_ts = d.upload(R.ts), *d_qs = d.upload(R.qs);
       d.check(wga_cigar_dotplot(d.ctx, &cb, cutoff, d_ts, d_qs, d_cnt, nullptr, nullptr));
       auto* d_off = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
       d.check(wga_exclusive_scan_u64(d.ctx, n, d_cnt, d_off));
@@ -2391,13 +2305,12 @@ int cmd_dotplot(const std::string* input, const std::string& format, const std::
       d.check(wga_cigar_dotplot(d.ctx, &cb, cutoff, d_ts, d_qs, nullptr, d_segs, d_off));
       std::vector<uint64_t> segs(off[n] * 5);
       if (off[n]) d.download(segs.data(), d_segs, off[n] * 5);
-      if (off[n] && text.empty()) text = "ref_start,ref_end,query_start,query_end,cigar,ref_chro,query_chro\n";
       for (uint32_t k = 0; k < n; k++) {
         std::string names;
         names.push_back(',');
-        append_csv_field(names, t_names[k], ',');
+        append_csv_field(names, R.t_names[k], ',');
         names.push_back(',');
-        append_csv_field(names, q_names[k], ',');
+        append_csv_field(names, R.q_names[k], ',');
         names.push_back('\n');
         for (uint64_t x = off[k]; x < off[k + 1]; x++) {
           const uint64_t* sg = &segs[5 * x];
@@ -2411,32 +2324,186 @@ int cmd_dotplot(const std::string* input, const std::string& format, const std::
       }
     }
   } else {
-    if (n && text.empty()) text = "ref_start,ref_end,query_start,query_end,identity,ref_chro,query_chro\n";
     for (uint32_t k = 0; k < n; k++) {
-      const uint64_t a[] = {ts[k], te[k], negs[k] ? qe[k] : qs[k], negs[k] ? qs[k] : qe[k]}; /* dotplot.rs:400-406 */
+      const uint64_t a[] = {R.ts[k], R.te[k], R.negs[k] ? R.qe[k] : R.qs[k], R.negs[k] ? R.qs[k] : R.qe[k]}; /* dotplot.rs:400-406 */
       for (uint64_t v : a) {
         append_u64(text, v);
         text.push_back(',');
       }
-      text += format_f64(no_identity ? 1.0 : (double)counts[k].match / (double)ali[k]);
+      text += format_f64(no_identity ? 1.0 : (double)counts[k].match / (double)R.ali[k]);
       text.push_back(',');
-      append_csv_field(text, t_names[k], ',');
+      append_csv_field(text, R.t_names[k], ',');
       text.push_back(',');
-      append_csv_field(text, q_names[k], ',');
+      append_csv_field(text, R.q_names[k], ',');
       text.push_back('\n');
     }
   }
-  d.release_all();
-  }; /* piece */
+  return text;
+}
+/* records [lo, hi) of a PAF piece on device d; `err` = the reference's message for the first failing record of the range */
+static std::string dotplot_paf_part(Dev& d, const PafInput& pin, size_t lo, size_t hi, const uint8_t* d_text_here, bool base,
+                                    bool no_identity, uint64_t cutoff, std::string& err) {
+  DotRecs R;
+  for (size_t k = lo; k < hi; k++) {
+    const PafRecord& r = pin.recs[k];
+    R.add(r.target_name, r.query_name, r.target_start, r.target_end, r.query_start, r.query_end, r.neg, r.target_end - r.target_start);
+  }
+  wga_cigar_batch cb;
+  cb.n = 0;
+  std::vector<wga_cigar_counts> counts;
+  const uint32_t n = (uint32_t)(hi - lo);
+  if (n && (base || !no_identity)) {
+    d.init();
+    CigarTexts cigars;
+    err = device_tokenise(d, pin, lo, n, cigars, &cb, nullptr, nullptr, d_text_here);
+    if (!base && cb.n) { /* get_stat (paf.rs:205-209): ops outside M = X I D are an error */
+      auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)cb.n * sizeof(wga_cigar_counts));
+      auto* d_diag = (wga_rec_diag*)d.alloc((size_t)cb.n * sizeof(wga_rec_diag));
+      d.check(wga_cigar_stat(d.ctx, &cb, d_counts, d_diag, nullptr));
+      counts.resize(cb.n);
+      std::vector<wga_rec_diag> diag(cb.n);
+      d.download(counts.data(), d_counts, cb.n);
+      d.download(diag.data(), d_diag, cb.n);
+      for (uint32_t k = 0; k < cb.n; k++)
+        if (diag[k].bad_op_idx != WGA_NONE) {
+          err = "CIGAR OP `" + cigar_op_token_at(cigars[k], diag[k].bad_op_idx) + "` invalid";
+          break;
+        }
+    }
+    if (!err.empty()) return std::string();
+  }
+  return dotplot_rows(d, base, no_identity, cutoff, R, cb, counts);
+}
+/* blocks recs[0 .. n) of a MAF piece, whose rows stand on device d (p) */
+static std::string dotplot_maf_part(Dev& d, const MafRows& p, const MafRecord* const* recs, uint32_t n, bool base, bool no_identity,
+                                    uint64_t cutoff) {
+  DotRecs R;
+  for (uint32_t k = 0; k < n; k++) {
+    const MafRecord& r = *recs[k];
+    R.add(r.t().name, r.q().name, r.t().start, r.t().start + r.t().align_size, r.query_start(), r.query_end(), r.q().neg,
+          r.t().align_size);
+  }
+  wga_cigar_batch cb;
+  cb.n = 0;
+  std::vector<wga_cigar_counts> counts;
+  if (n && (base || !no_identity)) {
+    const uint8_t* d_rows = p.d_rows;
+    auto *d_t = p.d_t, *d_q = p.d_q, *d_c = p.d_c;
+    auto* d_s = p.d_s;
+    auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
+    auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
+    d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, nullptr, nullptr));
+    if (!base) {
+      counts.resize(n);
+      d.download(counts.data(), d_counts, n);
+    } else {
+      auto* d_roff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+      d.check(wga_exclusive_scan_u64(d.ctx, n, d_cnt, d_roff));
+      uint64_t n_runs = 0;
+      d.download(&n_runs, d_roff + n, 1);
+      auto* d_runs = (uint64_t*)d.alloc((n_runs + 1) * 8);
+      d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, d_runs, d_roff));
+      auto* d_ocnt = (uint64_t*)d.alloc((size_t)n * 8);
+      d.check(wga_maf_runs_ops(d.ctx, n, n_runs, d_runs, d_roff, d_c, d_ocnt, nullptr, nullptr));
+      auto* d_ooff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+      d.check(wga_exclusive_scan_u64(d.ctx, n, d_ocnt, d_ooff));
+      uint64_t n_ops = 0;
+      d.download(&n_ops, d_ooff + n, 1);
+      auto* d_ops = (uint32_t*)d.alloc((n_ops + 4) * 4);
+      d.check(wga_maf_runs_ops(d.ctx, n, n_runs, d_runs, d_roff, d_c, nullptr, d_ops, d_ooff));
+      cb.d_ops = d_ops;
+      cb.d_op_off = d_ooff;
+      cb.d_strand_neg = d_s;
+      cb.n_ops = n_ops;
+      cb.n = n;
+    }
+  }
+  return dotplot_rows(d, base, no_identity, cutoff, R, cb, counts);
+}
+
+int cmd_dotplot(const std::string* input, const std::string& format, const std::string& out_format,
+                const std::string& mode, bool no_identity, uint64_t cutoff, const std::string* query_name, Output& out) {
+  if (mode != "base-level" && mode != "overview") fail("invalid value '" + mode + "' for '--mode <MODE>'");
+  if (out_format != "csv") {
+    if (out_format == "html" || out_format == "json")
+      fail("out-format `" + out_format + "` embeds the reference's Vega-Lite document and is not provided by this engine (use --out-format csv)");
+    fail("invalid value '" + out_format + "' for '--out-format <OUT_FORMAT>'");
+  }
+  if (format != "maf" && format != "paf") fail("Only support MAF and PAF format");
+  const bool base = mode == "base-level";
+  std::string text; /* all data is generated before anything is written (dotplot.rs:208-262) */
+  uint64_t n_records = 0;
+  Dev d;
+  /* --gpus N: a piece's records / blocks in contiguous ranges over the devices; the rows meet in input order */
   if (format == "paf") {
     PafChunks chunks(input, false);
     PafInput pin;
-    while (chunks.next(d, pin)) piece(&pin, nullptr);
+    std::vector<std::unique_ptr<Dev>> devs;
+    while (chunks.next(d, pin)) {
+      const size_t n = pin.recs.size();
+      n_records += n;
+      const int ng = g_gpus;
+      std::vector<std::string> part(ng), err(ng);
+      if (ng == 1) {
+        part[0] = dotplot_paf_part(d, pin, 0, n, nullptr, base, no_identity, cutoff, err[0]);
+      } else {
+        d.init();
+        if (devs.empty()) {
+          devs.emplace_back(new Dev(0));
+          devs[0]->ctx = d.ctx; /* device 0's context is the reader's */
+          devs[0]->own_ctx = false;
+          for (int g = 1; g < ng; g++) devs.emplace_back(new Dev(g));
+        }
+        std::string text16;
+        if (pin.on_device) text16 = pin.text + std::string(16, '\0');
+        on_devices(ng, [&](int g) {
+          const size_t lo = n * (size_t)g / ng, hi = n * (size_t)(g + 1) / ng;
+          if (lo == hi) return;
+          Dev& dg = *devs[g];
+          dg.init();
+          const size_t keep = dg.owned.size();
+          const uint8_t* d_text = nullptr;
+          if (pin.on_device) d_text = g == 0 ? pin.d_text : dg.upload((const uint8_t*)text16.data(), text16.size());
+          part[g] = dotplot_paf_part(dg, pin, lo, hi, d_text, base, no_identity, cutoff, err[g]);
+          dg.release_to(keep);
+        });
+      }
+      for (int g = 0; g < ng; g++) {
+        if (!err[g].empty()) {
+          out.close();
+          fail(err[g]);
+        }
+        text += part[g];
+      }
+      d.release_all();
+    }
   } else {
+    MafDevices md(d);
     MafChunks chunks(input);
     MafInput min;
-    while (chunks.next(d, min)) piece(nullptr, &min);
+    while (chunks.next(d, min)) {
+      std::vector<MafRecord>& recs = min.recs;
+      select_query(recs, query_name);
+      n_records += recs.size();
+      if (!recs.empty()) {
+        const std::vector<const MafRecord*> all = all_records(recs);
+        std::vector<std::string> part(md.count());
+        if (base || !no_identity) {
+          md.run(min, all, false, [&](int g, Dev& dg, const MafRows& p, uint32_t lo, uint32_t cnt) {
+            part[g] = dotplot_maf_part(dg, p, all.data() + lo, cnt, base, no_identity, cutoff);
+          });
+        } else {
+          part[0] = dotplot_maf_part(d, MafRows(), all.data(), (uint32_t)all.size(), base, no_identity, cutoff);
+        }
+        for (const std::string& t : part) text += t;
+      }
+      md.release_all();
+    }
   }
+  /* the header line: base-level once a segment exists, overview once a record does */
+  if (base ? !text.empty() : n_records != 0)
+    text = std::string(base ? "ref_start,ref_end,query_start,query_end,cigar,ref_chro,query_chro\n"
+                            : "ref_start,ref_end,query_start,query_end,identity,ref_chro,query_chro\n") + text;
   out.write(text);
   out.close();
   return 0;
