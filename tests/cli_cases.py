@@ -1147,6 +1147,49 @@ def test_streaming_pieces_give_the_same_bytes(cli, tmp_path):
     assert single[1].count(b"chain\t") == 39                # one line per piece: every record in front of it
 
 
+def test_bgzipped_paf_and_maf_inputs(cli, tmp_path):
+    """a bgzipped PAF / MAF is inflated on the device (K17 behind the line reader: a run of members at a time), a plain gzip
+    stream and WGA_BGZF_DEVICE=0 by zlib: the same bytes as from the plain file, whatever the piece size; a damaged member
+    is an IO error"""
+    import gzip
+    b = synth.make_paf_batch(23, 30, 200, 50000)
+    mapq = np.arange(30)
+    t_fa, q_fa, paf = _write_paf2maf_case(tmp_path, b, mapq)
+    text = open(paf, "rb").read()
+    bgz, gz = str(tmp_path / "in.paf.bgz"), str(tmp_path / "in.paf.gz")
+    _bgzf_write(bgz, text, block=700)            # ~40 members, lines across member borders
+    gzip.open(gz, "wb").write(text)
+    def runs(*args, **kw):
+        return run(cli, *args, **kw)[:2]
+    for cmd in (lambda f: ["paf2maf", f, "-g", t_fa, "-q", q_fa], lambda f: ["stat", "-f", "paf", f], lambda f: ["pafcov", f],
+                lambda f: ["paf2chain", f]):
+        want = runs(*cmd(paf))
+        assert want[0] == 0
+        assert runs(*cmd(bgz)) == want and runs(*cmd(gz)) == want, cmd("x")[0]
+        for env in ({"WGA_BGZF_DEVICE": "0"}, {"WGA_CHUNK_BYTES": "900"}):
+            e = dict(os.environ)
+            e.update(env)
+            r = subprocess.run([cli] + cmd(bgz), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+            assert (r.returncode, r.stdout) == want, (cmd("x")[0], env)
+    # MAF: the paf2maf output, bgzipped
+    maf_text = run(cli, "paf2maf", paf, "-g", t_fa, "-q", q_fa)[1]
+    maf, mbgz = str(tmp_path / "in.maf"), str(tmp_path / "in.maf.bgz")
+    open(maf, "wb").write(maf_text)
+    _bgzf_write(mbgz, maf_text, block=5000)
+    for cmd in (lambda f: ["stat", f], lambda f: ["maf2paf", f], lambda f: ["call", f, "-s", "-l", "3"]):
+        want = runs(*cmd(maf))
+        assert want[0] == 0 and runs(*cmd(mbgz)) == want, cmd("x")[0]
+    # a member whose deflate data is damaged
+    raw = bytearray(open(bgz, "rb").read())
+    raw[18 + 5] ^= 0xFF
+    bad = str(tmp_path / "bad.paf.bgz")
+    open(bad, "wb").write(bytes(raw))
+    for env in ({}, {"WGA_BGZF_DEVICE": "0"}):       # the member's CRC-32 is checked on either path (gzread's message)
+        r = subprocess.run([cli, "stat", "-f", "paf", bad], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 1 and r.stdout == b"" and b"IO error:" in r.stderr, r.stderr
+
+
 def test_maf_streaming_pieces_give_the_same_bytes(cli, tmp_path):
     """stat, maf2paf, maf2chain and call read a MAF in pieces cut between blocks (in front of a piece's trailing run of
     s-lines); chain ids count over the whole input; a block longer than a piece is kept together"""

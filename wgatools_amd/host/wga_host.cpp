@@ -105,6 +105,8 @@ bool bgzf_blocks(const std::string& img, std::vector<BgzfBlock>& blocks, size_t*
 }
 }  // namespace
 
+uint32_t gzip_crc32(const void* p, size_t n) { return (uint32_t)crc32(0L, (const Bytef*)p, (uInt)n); }
+
 bool read_bgzf_image(const std::string& path, std::string& img, std::vector<BgzfMember>& members, uint64_t* total) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) fail("File path `" + path + "` not exist"); /* errors.rs:13 */
@@ -200,6 +202,7 @@ std::string read_all_parallel(const std::string& path) {
 }
 
 void LineChunkReader::open(const std::string* path) {
+  if (source) return; /* the caller's producer stands for the file */
   if (!path) {
     if (isatty(0)) fail("Empty stdin, please add `-h` for help"); /* errors.rs:23 */
     is_stdin = true;
@@ -243,7 +246,9 @@ bool LineChunkReader::next(std::string& piece, size_t target, size_t keep) {
     const size_t at = piece.size();
     piece.resize(at + kRead);
     size_t n, kept_size = 0;
-    if (is_stdin) {
+    if (source) {
+      n = source(&piece[at], kRead);
+    } else if (is_stdin) {
       n = fread(&piece[at], 1, kRead, stdin);
     } else if (fd >= 0 && file_left > 4 * kRead && target > 4 * kRead) {
       /* a large regular file: what this piece still needs is read by a few threads at once (pread into disjoint

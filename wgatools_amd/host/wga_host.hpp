@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include <map>
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -48,6 +49,7 @@ struct BgzfMember {
   uint64_t out_off;
 };
 bool read_bgzf_image(const std::string& path, std::string& img, std::vector<BgzfMember>& members, uint64_t* total);
+uint32_t gzip_crc32(const void* p, size_t n); /* the CRC-32 of a gzip member's trailer (zlib's) */
 struct Output {
   std::string path;
   void* gz = nullptr;
@@ -90,6 +92,9 @@ struct LineChunkReader {
   std::string carry;
   uint64_t bytes_before = 0, lines_before = 0; /* of the piece next() returned last */
   uint64_t next_bytes = 0, next_lines = 0;
+  /* a producer of the input's bytes in the place of the file (a bgzipped input inflated on the device): returns the number
+   * of bytes written to dst (at most want), 0 at the end */
+  std::function<size_t(char* dst, size_t want)> source;
   void open(const std::string* path);
   bool next(std::string& piece, size_t target, size_t keep = 0); /* piece[0, keep) = the caller's prefix, kept */
   ~LineChunkReader();

@@ -343,6 +343,83 @@ static void stream_out(Dev& d, Output& out, const uint8_t* d_src, size_t n) {
   g_timer.mark("copy out + write");
 }
 
+/* A bgzipped PAF / MAF through the device inflate (K17, wga_bgzf_inflate): the compressed file stays on the host, a run of
+ * members at a time (64 MiB of text) is uploaded, inflated one wave per member and read back; LineChunkReader takes the bytes
+ * where gzread would have produced them.  The producer has a context of its own on device 0 (it runs on the reader's helper
+ * thread).  WGA_BGZF_DEVICE=0, a plain gzip stream or stdin keep zlib. */
+struct BgzfDeviceSource {
+  std::string img, path;
+  std::vector<BgzfMember> members;
+  uint64_t total = 0;
+  size_t next_member = 0;
+  std::string buf;
+  size_t buf_at = 0;
+  Dev d;
+  bool open(const std::string* p) {
+    const char* e = getenv("WGA_BGZF_DEVICE");
+    if (!p || (e && atoi(e) == 0)) return false;
+    if (!read_bgzf_image(*p, img, members, &total)) return false;
+    path = *p;
+    img.append(16, '\0');
+    return true;
+  }
+  bool refill() {
+    if (next_member == members.size()) return false;
+    const uint64_t kBatch = 64ull << 20;
+    const size_t m0 = next_member;
+    size_t m1 = m0;
+    uint64_t out_bytes = 0;
+    while (m1 < members.size() && (m1 == m0 || out_bytes + members[m1].out_len <= kBatch)) out_bytes += members[m1++].out_len;
+    const uint64_t c0 = members[m0].in_off, c1 = members[m1 - 1].in_off + members[m1 - 1].in_len, o0 = members[m0].out_off;
+    std::vector<BgzfMember> part(members.begin() + m0, members.begin() + m1);
+    for (BgzfMember& k : part) {
+      k.in_off -= c0;
+      k.out_off -= o0;
+    }
+    static_assert(sizeof(BgzfMember) == sizeof(wga_bgzf_block), "wga_bgzf_block layout");
+    d.init();
+    const uint8_t* d_img = d.upload((const uint8_t*)img.data() + c0, (size_t)(c1 - c0) + 16);
+    const wga_bgzf_block* d_mem = (const wga_bgzf_block*)d.upload(part.data(), part.size());
+    uint8_t* d_text = (uint8_t*)d.alloc(out_bytes + 64);
+    auto* d_st = (uint32_t*)d.alloc(part.size() * 4 + 4);
+    d.check(wga_bgzf_inflate(d.ctx, d_img, (uint64_t)(c1 - c0), (uint32_t)part.size(), d_mem, d_text, d_st));
+    std::vector<uint32_t> st(part.size());
+    d.download(st.data(), (const uint32_t*)d_st, st.size());
+    for (uint32_t v : st)
+      if (v) fail("IO error:corrupt BGZF block in `" + path + "`");
+    buf.resize((size_t)out_bytes);
+    if (out_bytes) d.download((uint8_t*)&buf[0], d_text, out_bytes);
+    d.release_all();
+    { /* the members' CRC-32 (the trailer behind the deflate data) as gzread checks it: host threads over the members */
+      const unsigned T = 8;
+      std::vector<std::thread> th;
+      std::vector<int> bad(T, 0);
+      for (unsigned t = 0; t < T; t++)
+        th.emplace_back([&, t] {
+          for (size_t k = t; k < part.size(); k += T) {
+            const unsigned char* tr = (const unsigned char*)img.data() + c0 + part[k].in_off + part[k].in_len;
+            const uint32_t want = (uint32_t)tr[0] | (uint32_t)tr[1] << 8 | (uint32_t)tr[2] << 16 | (uint32_t)tr[3] << 24;
+            if (gzip_crc32(buf.data() + part[k].out_off, part[k].out_len) != want) bad[t] = 1;
+          }
+        });
+      for (auto& x : th) x.join();
+      for (int v : bad)
+        if (v) fail("IO error:" + path + ": incorrect data check");
+    }
+    buf_at = 0;
+    next_member = m1;
+    return true;
+  }
+  size_t read(char* dst, size_t want) {
+    while (buf_at == buf.size())
+      if (!refill()) return 0;
+    const size_t n = std::min(want, buf.size() - buf_at);
+    memcpy(dst, buf.data() + buf_at, n);
+    buf_at += n;
+    return n;
+  }
+};
+
 /* An indexed FASTA whose sequence pool lives in HBM.  The file — plain, gzip or BGZF (inflated on
  * all host cores) — is uploaded as text, wga_fasta_pool strips the line ends on the device and returns the contig table;
  * the drivers then address (contig, start, length) as pool offsets with htslib's clipping (Faidx::fetch) and never copy
@@ -556,7 +633,13 @@ struct PafChunks {
   } ahead;
   std::thread reader;
   bool started = false;
+  std::unique_ptr<BgzfDeviceSource> bgzf; /* a bgzipped input: inflated on the device */
   PafChunks(const std::string* input, bool tags) : want_tags(tags) {
+    bgzf.reset(new BgzfDeviceSource());
+    if (bgzf->open(input))
+      rd.source = [this](char* dst, size_t want) { return bgzf->read(dst, want); };
+    else
+      bgzf.reset();
     rd.open(input);
     if (const char* e = getenv("WGA_CHUNK_BYTES")) target = (size_t)strtoull(e, nullptr, 10);
     if (target == 0) target = 1;
@@ -1299,7 +1382,13 @@ struct MafChunks {
   std::string pending; /* trailing s-lines of the previous piece */
   bool first = true, done = false;
   std::string header;
+  std::unique_ptr<BgzfDeviceSource> bgzf; /* a bgzipped input: inflated on the device */
   explicit MafChunks(const std::string* input) {
+    bgzf.reset(new BgzfDeviceSource());
+    if (bgzf->open(input))
+      rd.source = [this](char* dst, size_t want) { return bgzf->read(dst, want); };
+    else
+      bgzf.reset();
     rd.open(input);
     if (const char* e = getenv("WGA_CHUNK_BYTES")) target = (size_t)strtoull(e, nullptr, 10);
     if (target == 0) target = 1;
