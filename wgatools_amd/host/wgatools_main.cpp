@@ -1557,66 +1557,66 @@ int cmd_stat_maf(const std::string* input, bool each, const std::string* query_n
 /* the PAF rows of blocks recs[0 .. n), whose rows stand on device d (p) */
 static std::string maf2paf_rows(Dev& d, const MafRows& p, const MafRecord* const* recs, uint32_t n) {
   std::string text;
-    const uint8_t* d_rows = p.d_rows;
-    auto *d_t = p.d_t, *d_q = p.d_q, *d_c = p.d_c;
-    auto* d_s = p.d_s;
-    auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
-    auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
-    d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, nullptr, nullptr));
-    auto* d_roff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
-    d.check(wga_exclusive_scan_u64(d.ctx, n, d_cnt, d_roff));
-    std::vector<uint64_t> roff(n + 1);
-    d.download(roff.data(), d_roff, n + 1);
-    auto* d_runs = (uint64_t*)d.alloc((roff[n] + 1) * 8);
-    d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, d_runs, d_roff));
-    /* the cg:Z: text is formatted on the device (wga_maf_runs_cigar_text) between the host's fields */
-    auto* d_tb = (uint64_t*)d.alloc((size_t)n * 8);
-    d.check(wga_maf_runs_cigar_text(d.ctx, n, roff[n], d_runs, d_roff, d_c, d_tb, nullptr, nullptr));
-    std::vector<uint64_t> tb(n);
-    d.download(tb.data(), d_tb, n);
-    std::vector<wga_cigar_counts> counts(n);
-    d.download(counts.data(), d_counts, n);
-    std::string blob;
-    std::vector<uint64_t> blob_off{0}, dst, text_off(n);
-    uint64_t pos = 0;
-    for (uint32_t k = 0; k < n; k++) {
-      const MafRecord& r = *recs[k];
-      const wga_cigar_counts& c = counts[k];
-      uint64_t block = c.match + c.mismatch + c.ins_bp + c.inv_ins_bp + c.del_bp + c.inv_del_bp;
-      std::string h;
-      append_csv_field(h, r.q().name, '\t');
-      uint64_t a[] = {r.q().size, r.query_start(), r.query_end()};
-      for (uint64_t v : a) {
-        h.push_back('\t');
-        append_u64(h, v);
-      }
-      h += r.q().neg ? "\t-\t" : "\t+\t";
-      append_csv_field(h, r.t().name, '\t');
-      uint64_t bb[] = {r.t().size, r.t().start, r.t().start + r.t().align_size, c.match, block, 255};
-      for (uint64_t v : bb) {
-        h.push_back('\t');
-        append_u64(h, v);
-      }
-      h += "\tNM:i:";
-      append_u64(h, block - c.match);
-      h += "\tcg:Z:";
-      dst.push_back(pos);
-      blob += h;
-      blob_off.push_back(blob.size());
-      pos += h.size();
-      text_off[k] = pos;
-      pos += tb[k];
-      dst.push_back(pos);
-      blob += "\n";
-      blob_off.push_back(blob.size());
-      pos += 1;
+  const uint8_t* d_rows = p.d_rows;
+  auto *d_t = p.d_t, *d_q = p.d_q, *d_c = p.d_c;
+  auto* d_s = p.d_s;
+  auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
+  auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
+  d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, nullptr, nullptr));
+  auto* d_roff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+  d.check(wga_exclusive_scan_u64(d.ctx, n, d_cnt, d_roff));
+  std::vector<uint64_t> roff(n + 1);
+  d.download(roff.data(), d_roff, n + 1);
+  auto* d_runs = (uint64_t*)d.alloc((roff[n] + 1) * 8);
+  d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, d_runs, d_roff));
+  /* the cg:Z: text is formatted on the device (wga_maf_runs_cigar_text) between the host's fields */
+  auto* d_tb = (uint64_t*)d.alloc((size_t)n * 8);
+  d.check(wga_maf_runs_cigar_text(d.ctx, n, roff[n], d_runs, d_roff, d_c, d_tb, nullptr, nullptr));
+  std::vector<uint64_t> tb(n);
+  d.download(tb.data(), d_tb, n);
+  std::vector<wga_cigar_counts> counts(n);
+  d.download(counts.data(), d_counts, n);
+  std::string blob;
+  std::vector<uint64_t> blob_off{0}, dst, text_off(n);
+  uint64_t pos = 0;
+  for (uint32_t k = 0; k < n; k++) {
+    const MafRecord& r = *recs[k];
+    const wga_cigar_counts& c = counts[k];
+    uint64_t block = c.match + c.mismatch + c.ins_bp + c.inv_ins_bp + c.del_bp + c.inv_del_bp;
+    std::string h;
+    append_csv_field(h, r.q().name, '\t');
+    uint64_t a[] = {r.q().size, r.query_start(), r.query_end()};
+    for (uint64_t v : a) {
+      h.push_back('\t');
+      append_u64(h, v);
     }
-    auto* d_out = (uint8_t*)d.alloc(pos + 64);
-    d.check(wga_maf_runs_cigar_text(d.ctx, n, roff[n], d_runs, d_roff, d_c, nullptr, d_out, d.upload(text_off)));
-    d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off), d_out,
-                              d.upload(dst)));
-    text.resize((size_t)pos);
-    if (pos) d.download((uint8_t*)&text[0], d_out, pos);
+    h += r.q().neg ? "\t-\t" : "\t+\t";
+    append_csv_field(h, r.t().name, '\t');
+    uint64_t bb[] = {r.t().size, r.t().start, r.t().start + r.t().align_size, c.match, block, 255};
+    for (uint64_t v : bb) {
+      h.push_back('\t');
+      append_u64(h, v);
+    }
+    h += "\tNM:i:";
+    append_u64(h, block - c.match);
+    h += "\tcg:Z:";
+    dst.push_back(pos);
+    blob += h;
+    blob_off.push_back(blob.size());
+    pos += h.size();
+    text_off[k] = pos;
+    pos += tb[k];
+    dst.push_back(pos);
+    blob += "\n";
+    blob_off.push_back(blob.size());
+    pos += 1;
+  }
+  auto* d_out = (uint8_t*)d.alloc(pos + 64);
+  d.check(wga_maf_runs_cigar_text(d.ctx, n, roff[n], d_runs, d_roff, d_c, nullptr, d_out, d.upload(text_off)));
+  d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off), d_out,
+                            d.upload(dst)));
+  text.resize((size_t)pos);
+  if (pos) d.download((uint8_t*)&text[0], d_out, pos);
   return text;
 }
 
@@ -2211,87 +2211,87 @@ int cmd_chain2paf(const std::string* input, Output& out) {
  * *d_text, *bytes. */
 static void maf2chain_text(Dev& d, const MafRows& p, const MafRecord* const* recs, uint32_t n, uint64_t chain_id0,
                            const uint8_t** d_text, uint64_t* bytes) {
-    const uint8_t* d_rows = p.d_rows;
-    auto *d_t = p.d_t, *d_q = p.d_q, *d_c = p.d_c;
-    auto* d_s = p.d_s;
-    auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
-    auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
-    d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, nullptr, nullptr));
-    auto* d_roff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
-    d.check(wga_exclusive_scan_u64(d.ctx, n, d_cnt, d_roff));
-    uint64_t n_runs = 0;
-    d.download(&n_runs, d_roff + n, 1);
-    auto* d_runs = (uint64_t*)d.alloc((n_runs + 1) * 8);
-    d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, d_runs, d_roff));
-    auto* d_ocnt = (uint64_t*)d.alloc((size_t)n * 8);
-    d.check(wga_maf_runs_ops(d.ctx, n, n_runs, d_runs, d_roff, d_c, d_ocnt, nullptr, nullptr));
-    auto* d_ooff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
-    d.check(wga_exclusive_scan_u64(d.ctx, n, d_ocnt, d_ooff));
-    uint64_t n_ops = 0;
-    d.download(&n_ops, d_ooff + n, 1);
-    auto* d_ops = (uint32_t*)d.alloc((n_ops + 4) * 4);
-    d.check(wga_maf_runs_ops(d.ctx, n, n_runs, d_runs, d_roff, d_c, nullptr, d_ops, d_ooff));
-    wga_cigar_batch cb;
-    cb.d_ops = d_ops;
-    cb.d_op_off = d_ooff;
-    cb.d_strand_neg = d_s;
-    cb.n_ops = n_ops;
-    cb.n = n;
-    auto* d_trim = (wga_chain_trim_t*)d.alloc((size_t)n * sizeof(wga_chain_trim_t));
-    auto* d_nb = (uint64_t*)d.alloc((size_t)n * 8);
-    auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
-    d.check(wga_cigar_chain(d.ctx, &cb, d_trim, d_nb, d_diag, nullptr, nullptr));
-    std::vector<wga_chain_trim_t> trim(n);
-    std::vector<uint64_t> nb(n);
-    d.download(trim.data(), d_trim, n);
-    d.download(nb.data(), d_nb, n);
-    std::string blob;
-    std::vector<uint64_t> blob_off{0}, dst, data_off(n);
-    uint64_t pos = 0;
-    for (uint32_t k = 0; k < n; k++) {
-      const MafRecord& r = *recs[k];
-      const wga_chain_trim_t& t = trim[k];
-      const bool neg = r.q().neg;
-      uint64_t qs = r.query_start(), qe = r.query_end();
-      const uint64_t ts = r.t().start + t.head_del, te = r.t().start + r.t().align_size - t.tail_del;
-      if (!neg) {
-        qs += t.head_ins;
-        qe -= t.tail_ins;
-      } else { /* chain.rs:131-136: the new end is computed from the already updated start */
-        qs = r.q().size - (qe - t.head_ins);
-        qe = r.q().size - (qs + t.tail_ins);
-      }
-      std::string h = "chain\t255\t" + r.t().name + "\t";
-      append_u64(h, r.t().size);
-      h += "\t+\t";
-      append_u64(h, ts);
-      h.push_back('\t');
-      append_u64(h, te);
-      h += "\t" + r.q().name + "\t";
-      append_u64(h, r.q().size);
-      h += neg ? "\t-\t" : "\t+\t";
-      append_u64(h, qs);
-      h.push_back('\t');
-      append_u64(h, qe);
-      h.push_back('\t');
-      append_u64(h, chain_id0 + (uint64_t)k);
-      dst.push_back(pos);
-      blob += h;
-      blob_off.push_back(blob.size());
-      pos += h.size();
-      data_off[k] = pos;
-      pos += nb[k];
-      dst.push_back(pos);
-      blob += "\n\n";
-      blob_off.push_back(blob.size());
-      pos += 2;
+  const uint8_t* d_rows = p.d_rows;
+  auto *d_t = p.d_t, *d_q = p.d_q, *d_c = p.d_c;
+  auto* d_s = p.d_s;
+  auto* d_counts = (wga_cigar_counts*)d.alloc((size_t)n * sizeof(wga_cigar_counts));
+  auto* d_cnt = (uint64_t*)d.alloc((size_t)n * 8);
+  d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, nullptr, nullptr));
+  auto* d_roff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+  d.check(wga_exclusive_scan_u64(d.ctx, n, d_cnt, d_roff));
+  uint64_t n_runs = 0;
+  d.download(&n_runs, d_roff + n, 1);
+  auto* d_runs = (uint64_t*)d.alloc((n_runs + 1) * 8);
+  d.check(wga_maf_pair_stat(d.ctx, n, d_rows, d_t, d_q, d_c, d_s, d_counts, d_cnt, d_runs, d_roff));
+  auto* d_ocnt = (uint64_t*)d.alloc((size_t)n * 8);
+  d.check(wga_maf_runs_ops(d.ctx, n, n_runs, d_runs, d_roff, d_c, d_ocnt, nullptr, nullptr));
+  auto* d_ooff = (uint64_t*)d.alloc(((size_t)n + 1) * 8);
+  d.check(wga_exclusive_scan_u64(d.ctx, n, d_ocnt, d_ooff));
+  uint64_t n_ops = 0;
+  d.download(&n_ops, d_ooff + n, 1);
+  auto* d_ops = (uint32_t*)d.alloc((n_ops + 4) * 4);
+  d.check(wga_maf_runs_ops(d.ctx, n, n_runs, d_runs, d_roff, d_c, nullptr, d_ops, d_ooff));
+  wga_cigar_batch cb;
+  cb.d_ops = d_ops;
+  cb.d_op_off = d_ooff;
+  cb.d_strand_neg = d_s;
+  cb.n_ops = n_ops;
+  cb.n = n;
+  auto* d_trim = (wga_chain_trim_t*)d.alloc((size_t)n * sizeof(wga_chain_trim_t));
+  auto* d_nb = (uint64_t*)d.alloc((size_t)n * 8);
+  auto* d_diag = (wga_rec_diag*)d.alloc((size_t)n * sizeof(wga_rec_diag));
+  d.check(wga_cigar_chain(d.ctx, &cb, d_trim, d_nb, d_diag, nullptr, nullptr));
+  std::vector<wga_chain_trim_t> trim(n);
+  std::vector<uint64_t> nb(n);
+  d.download(trim.data(), d_trim, n);
+  d.download(nb.data(), d_nb, n);
+  std::string blob;
+  std::vector<uint64_t> blob_off{0}, dst, data_off(n);
+  uint64_t pos = 0;
+  for (uint32_t k = 0; k < n; k++) {
+    const MafRecord& r = *recs[k];
+    const wga_chain_trim_t& t = trim[k];
+    const bool neg = r.q().neg;
+    uint64_t qs = r.query_start(), qe = r.query_end();
+    const uint64_t ts = r.t().start + t.head_del, te = r.t().start + r.t().align_size - t.tail_del;
+    if (!neg) {
+      qs += t.head_ins;
+      qe -= t.tail_ins;
+    } else { /* chain.rs:131-136: the new end is computed from the already updated start */
+      qs = r.q().size - (qe - t.head_ins);
+      qe = r.q().size - (qs + t.tail_ins);
     }
-    auto* d_out = (uint8_t*)d.alloc(pos + 64);
-    d.check(wga_cigar_chain(d.ctx, &cb, nullptr, nullptr, nullptr, d_out, d.upload(data_off)));
-    d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off), d_out,
-                              d.upload(dst)));
-    *d_text = d_out;
-    *bytes = pos;
+    std::string h = "chain\t255\t" + r.t().name + "\t";
+    append_u64(h, r.t().size);
+    h += "\t+\t";
+    append_u64(h, ts);
+    h.push_back('\t');
+    append_u64(h, te);
+    h += "\t" + r.q().name + "\t";
+    append_u64(h, r.q().size);
+    h += neg ? "\t-\t" : "\t+\t";
+    append_u64(h, qs);
+    h.push_back('\t');
+    append_u64(h, qe);
+    h.push_back('\t');
+    append_u64(h, chain_id0 + (uint64_t)k);
+    dst.push_back(pos);
+    blob += h;
+    blob_off.push_back(blob.size());
+    pos += h.size();
+    data_off[k] = pos;
+    pos += nb[k];
+    dst.push_back(pos);
+    blob += "\n\n";
+    blob_off.push_back(blob.size());
+    pos += 2;
+  }
+  auto* d_out = (uint8_t*)d.alloc(pos + 64);
+  d.check(wga_cigar_chain(d.ctx, &cb, nullptr, nullptr, nullptr, d_out, d.upload(data_off)));
+  d.check(wga_scatter_bytes(d.ctx, 2 * n, d.upload((const uint8_t*)blob.data(), blob.size()), d.upload(blob_off), d_out,
+                            d.upload(dst)));
+  *d_text = d_out;
+  *bytes = pos;
 }
 
 int cmd_maf2chain(const std::string* input, const std::string* query_name, Output& out) {
