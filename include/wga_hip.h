@@ -471,7 +471,7 @@ int wga_fasta_pool(wga_ctx*, const uint8_t* d_text, uint64_t n_bytes, uint64_t* 
  * 256 bytes per 1024 ops of the largest batch (the pieces as the list pass writes them) and 40 bytes
  * per piece (a record segment of a tile of ops under a window of 8192 counters; 3.5 per 1024 ops on
  * configs[3]'s records).  WGA_COV_SPIN_LIMIT (environment, read by wga_ctx_create): polls of a
- * neighbouring tile's sum before a wave of the list pass adds up the ops itself (default 65536). */
+ * neighbouring tile's sum before a wave of the list pass adds up the ops itself (default 4096). */
 int wga_pafcov_accumulate(wga_ctx*, const wga_cigar_batch*, const uint32_t* d_target_id,
                           const uint64_t* d_t_start, const uint64_t* d_cov_off,
                           const uint64_t* d_cov_len, int32_t* d_cov, uint64_t total_cov);

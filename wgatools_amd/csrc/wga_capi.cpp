@@ -79,7 +79,8 @@ struct wga_ctx {
   u64 cov_tile_list_cap = 0;     /* in tiles */
   void* cov_list = nullptr;   /* pafcov: the pieces beyond a tile's slots (WGA_COV_LISTS regions of cov_list_rcap) */
   u64 cov_list_rcap = 0;
-  u32 cov_spin_limit = 1u << 16; /* polls of a tile sum before the look-back adds up the ops itself (WGA_COV_SPIN_LIMIT) */
+  u32 cov_spin_limit = 1u << 12; /* polls of a tile sum (milliseconds of waiting where ten microseconds are the rule) before the
+                                    look-back adds up the ops itself (WGA_COV_SPIN_LIMIT) */
   /* optional per-launch timing of the expand kernel proper (events on the launch stream) */
   static const int kTimingRing = 64;
   bool timing = false;
