@@ -435,6 +435,30 @@ def check_pafcov_look_back(eng):
     check_pafcov(eng, b, tid, starts, [60000, 600000], split=True)
 
 
+def check_pafcov_random(eng, seed, cases):
+    """K5 on random shapes: records of 1 .. 5 000 ops with the sizes around the tile (1 024 ops), lane (16) and step (256)
+    borders, ops of every class, a few of them far longer than a window, 1 .. 4 targets short enough to clip records,
+    records that start beyond their target, one call or two"""
+    rng = np.random.default_rng(seed)
+    sizes = [1, 1, 1, 2, 3, 15, 16, 17, 255, 256, 257, 1023, 1024, 1025, 2047, 2048, 2049, 3000, 5000]
+    codes = np.array([7, 7, 7, 0, 8, 1, 2, 3, 4, 5, 6, 11], dtype=np.uint32)
+    for _ in range(cases):
+        n = int(rng.integers(1, 40))
+        lens = [int(rng.choice(sizes)) for _ in range(n)]
+        recs = []
+        for m in lens:
+            c = rng.choice(codes, m)
+            ln = np.where(rng.random(m) < 0.02, rng.integers(0, 120000, m), rng.integers(0, 40, m)).astype(np.uint32)
+            recs.append((ln << 4) | c)
+        b = dict(ops=np.concatenate(recs).astype(np.uint32), op_off=np.cumsum([0] + lens).astype(np.uint64),
+                 strand_neg=np.zeros(n, dtype=np.uint8))
+        nt = int(rng.integers(1, 5))
+        tlen = [int(rng.integers(1, 400000)) for _ in range(nt)]
+        tid = rng.integers(0, nt, n)
+        ts = [int(rng.integers(0, int(tlen[t] * 1.1) + 1)) for t in tid]
+        check_pafcov(eng, b, list(tid), ts, tlen, align=int(rng.choice([1, 4])), split=bool(rng.integers(0, 2)))
+
+
 def check_pafcov(eng, b, target_id, t_start, target_len, align=4, split=False):
     n = len(b["strand_neg"])
     nt = len(target_len)

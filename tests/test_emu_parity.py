@@ -200,6 +200,10 @@ def test_pafcov_ops_across_many_windows(emu):
     pc.check_pafcov_long_ops(emu)
 
 
+def test_pafcov_random_shapes(emu):
+    pc.check_pafcov_random(emu, 11, 12)
+
+
 def test_pafcov_look_back(emu, monkeypatch):
     """K5's list pass: a tile's first segment takes its record's position from the sums the tiles in front of it published —
     records across 2 .. 70 tiles (more than one round of 64 lanes), tiles that end exactly with a record, and the same with the

@@ -416,6 +416,11 @@ def test_pafcov_ops_across_many_windows(gpu):
     pc.check_pafcov_long_ops(gpu)
 
 
+def test_pafcov_random_shapes(gpu):
+    pc.check_pafcov_random(gpu, 11, 12)
+    pc.check_pafcov_random(gpu, 12, 60)
+
+
 def test_pafcov_look_back(gpu):
     """K5's list pass: tile sums by look-back over records of 2 .. 70 tiles (tests/parity_cases.py)"""
     pc.check_pafcov_look_back(gpu)
