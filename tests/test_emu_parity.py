@@ -201,7 +201,7 @@ def test_pafcov_ops_across_many_windows(emu):
 
 
 def test_pafcov_random_shapes(emu):
-    pc.check_pafcov_random(emu, 11, 12)
+    pc.check_pafcov_random(emu, 11, 8)
 
 
 def test_pafcov_look_back(emu, monkeypatch):
