@@ -9,11 +9,8 @@ cd /tmp
 # the library would spend these three launches on its drain_min trials (64 / 32 / 16): fix the value it settles on for this shape
 export WGA_EXPAND_DRAIN_MIN=${WGA_EXPAND_DRAIN_MIN:-64}
 BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-e2e --no-placement-probe --check 0"
-run() { # name counters...
-  name=$1; shift
-  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- $BENCH > $OUT/$name.json 2> $OUT/$name.err
-  echo "$name rc=$?"
-}
+# another command's kernels (e.g. K5: WGA_PMC_CMD="python $R/scripts/gpu_k5_scaling.py 1" bash scripts/gpu_pmc.sh k5pmc "sq1 sq2 sq3 tcc")
+BENCH=${WGA_PMC_CMD:-$BENCH}
 PASSES=${2:-"sq1 sq2 fetch write tcc"}
 want() { [[ " $PASSES " == *" $1 "* ]]; }
 run() { # name counters...
