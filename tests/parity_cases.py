@@ -724,6 +724,42 @@ def check_bridge_blocks(eng, seed=3, n=24):
         assert (h[~seen] == guard).all(), kind
 
 
+def check_elem_scan_reuse(eng):
+    """K11: the count call's scan of the element sizes stays for the fill call.  A fill call without a count call in front
+    computes its own; a second batch in the SAME device arrays (same pointers, same counts of records and lines, other
+    lengths — other sizes per line) is counted anew and filled from the new scan"""
+    def lines_of(seed):
+        rng = np.random.default_rng(seed)
+        recs = [[(int(rng.integers(0, 10 ** int(rng.integers(1, 9)))), int(rng.integers(0, 2)) * int(rng.integers(0, 5000)),
+                  int(rng.integers(0, 2)) * int(rng.integers(0, 300))) for _ in range(m)] for m in (300, 1, 700, 256, 43)]
+        return recs
+    def text_of(r):
+        return "".join("%dM" % sz + ("%dI" % td if td else "") + ("%dD" % qd if qd else "") for sz, qd, td in r).encode()
+    n = 5
+    a, b = lines_of(1), lines_of(2)
+    line_off = np.cumsum([0] + [len(r) for r in a]).astype(np.uint64)
+    ne = int(line_off[-1])
+    flat = lambda recs: np.array([v for r in recs for ln in r for v in ln] + [0, 0, 0], dtype=np.uint64)
+    d_lines, d_loff = eng.upload(flat(a)), eng.upload(line_off)
+    def fill_and_check(recs, count_first):
+        want = [text_of(r) for r in recs]
+        off = np.zeros(n + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(w) for w in want])
+        if count_first:
+            cnt = eng.chain_lines_cigar_text(n, ne, d_lines, d_loff).numpy().astype(np.int64)
+            assert cnt.tolist() == [len(w) for w in want]
+        out = eng.empty(int(off[-1]) + 16, np.uint8).fill(0x23)
+        eng.chain_lines_cigar_text(n, ne, d_lines, d_loff, out=out, out_off=eng.upload(off))
+        assert out.numpy()[:int(off[-1])].tobytes() == b"".join(want)
+    fill_and_check(a, False)            # no count call in front
+    fill_and_check(a, True)
+    fill_and_check(a, False)            # the scan of the count call is still the right one
+    eng.copy_into(d_lines, flat(b))     # the same arrays, another batch
+    fill_and_check(b, True)
+    eng.chain_lines_ops(n, ne, d_lines, d_loff)      # another entry point counts over the same arrays ...
+    fill_and_check(b, False)                          # ... and the text fill does not take its scan
+
+
 def check_chain_lines(eng, recs, strands, seqs=None):
     """recs: per record a list of (size, query_diff, target_diff) data lines.  ops + K1 == the counts of
     parse_chain_to_cigar, text == its CIGAR, and (seqs given: per record (t_seq, q_seq)) ops + K2 ==

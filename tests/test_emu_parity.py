@@ -444,6 +444,10 @@ def test_runs_bridge_synthetic(emu):
     pc.check_runs_bridge_synthetic(emu, recs)
 
 
+def test_elem_scan_reuse(emu):
+    pc.check_elem_scan_reuse(emu)
+
+
 def test_bridge_blocks(emu):
     pc.check_bridge_blocks(emu)
 

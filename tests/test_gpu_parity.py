@@ -497,6 +497,10 @@ def test_runs_bridge_synthetic(gpu):
     pc.check_runs_bridge_synthetic(gpu, recs)
 
 
+def test_elem_scan_reuse(gpu):
+    pc.check_elem_scan_reuse(gpu)
+
+
 def test_bridge_blocks(gpu):
     pc.check_bridge_blocks(gpu)
 

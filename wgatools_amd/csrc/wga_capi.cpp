@@ -73,6 +73,15 @@ struct wga_ctx {
     u32* piece_rec = nullptr; /* np: the record of every piece */
     void* pieces = nullptr;   /* np x per_piece bytes */
   } op_tab;
+  struct ElemScan { /* K11: the count call's scan of the element sizes, kept for the fill call (grow-only buffer) */
+    void* mem = nullptr;
+    size_t cap = 0;
+    bool valid = false;
+    int kind = 0;
+    const void* elem_off = nullptr;
+    uint32_t n = 0, ne = 0;
+    unsigned char src[32] = {0}; /* the entry point's source arrays (its functor) */
+  } elem_scan;
   void* cov_pieces = nullptr; /* pafcov: (window, piece) list, grow-only */
   u64 cov_pieces_cap = 0;
   void* cov_tile_list = nullptr; /* pafcov: WGA_COV_TILE_CAP piece slots per tile of ops, grow-only */
@@ -162,9 +171,11 @@ static int run_scan(wga_ctx* c, F f, u32 n, u64* d_out /* n+1 */) {
   return WGA_OK;
 }
 
-/* K11 driver: element sizes -> exclusive scan (context scratch) -> per-record totals or the fill */
+/* K11 driver: element sizes -> exclusive scan -> per-record totals (the count call) or the fill.  The count call's scan stays for
+ * the fill call of the same protocol (keyed by the entry point, its arrays and the counts, like the piece tables of K7 / K10 /
+ * K12): the fill call then is the fill kernel alone — the scan it used to repeat was more than half of it. */
 template <typename F>
-static int run_elems(wga_ctx* c, F f, u32 n, uint64_t n_elems, const uint64_t* d_elem_off, uint64_t* d_cnt,
+static int run_elems(wga_ctx* c, int kind, F f, u32 n, uint64_t n_elems, const uint64_t* d_elem_off, uint64_t* d_cnt,
                      typename F::out_t* d_out, const uint64_t* d_out_off) {
   int rc = ctx_bind(c);
   if (rc) return rc;
@@ -174,14 +185,39 @@ static int run_elems(wga_ctx* c, F f, u32 n, uint64_t n_elems, const uint64_t* d
   if (!d_out && !d_cnt) return fail(WGA_E_INVALID_ARG, "d_cnt null", nullptr);
   if (d_out && !d_out_off) return fail(WGA_E_INVALID_ARG, "d_out_off null", nullptr);
   const u32 ne = (u32)n_elems;
-  void* ws;
-  if ((rc = ctx_scratch(c, ((size_t)ne + 1 + (size_t)ne / 1024 + 4) * sizeof(u64), &ws))) return rc;
-  u64* esc = (u64*)ws;
-  ScanElem<F> sf;
-  sf.f = f;
-  sf.elem_off = (const u64*)d_elem_off;
-  sf.n = n;
-  if ((rc = run_scan_ws(c, sf, ne, esc, esc + ne + 1))) return rc;
+  static_assert(sizeof(F) <= sizeof(((wga_ctx::ElemScan*)nullptr)->src), "functor larger than the key");
+  wga_ctx::ElemScan& es = c->elem_scan;
+  unsigned char src[sizeof(es.src)];
+  memset(src, 0, sizeof(src));
+  memcpy(src, &f, sizeof(F));
+  const bool hit = d_out && es.valid && es.kind == kind && es.elem_off == (const void*)d_elem_off && es.n == n && es.ne == ne &&
+                   memcmp(es.src, src, sizeof(src)) == 0;
+  if (!hit) {
+    es.valid = false;
+    const size_t need = ((size_t)ne + 1 + (size_t)ne / 1024 + 4) * sizeof(u64);
+    if (es.cap < need) {
+      if (es.mem) RT_CHECK(rt_free(es.mem));
+      es.mem = nullptr;
+      es.cap = 0;
+      RT_CHECK(rt_malloc(&es.mem, need + need / 4));
+      es.cap = need + need / 4;
+    }
+    ScanElem<F> sf;
+    sf.f = f;
+    sf.elem_off = (const u64*)d_elem_off;
+    sf.n = n;
+    u64* const esc0 = (u64*)es.mem;
+    if ((rc = run_scan_ws(c, sf, ne, esc0, esc0 + ne + 1))) return rc;
+    if (!d_out) { /* the count call of the protocol: its scan stays */
+      es.kind = kind;
+      es.elem_off = (const void*)d_elem_off;
+      es.n = n;
+      es.ne = ne;
+      memcpy(es.src, src, sizeof(src));
+      es.valid = true;
+    }
+  }
+  u64* const esc = (u64*)es.mem;
   if (!d_out) {
     WGA_LAUNCH(k_elem_rec_totals, (n + 255u) / 256u, WGA_BLOCK, c->stream, n, (const u64*)d_elem_off,
                (const u64*)esc, (u64*)d_cnt);
@@ -427,6 +463,7 @@ void wga_ctx_destroy(wga_ctx* c) {
     for (int k = 0; k < 2 * wga_ctx::kTimingRing; k++) rt_event_destroy(c->ev[k]);
   if (c->tune.have_ev) rt_event_destroy(c->tune.ev[0]), rt_event_destroy(c->tune.ev[1]);
   if (c->scratch) (void)rt_free(c->scratch);
+  if (c->elem_scan.mem) (void)rt_free(c->elem_scan.mem);
   if (c->cov_pieces) (void)rt_free(c->cov_pieces);
   if (c->cov_list) (void)rt_free(c->cov_list);
   if (c->cov_tile_list) (void)rt_free(c->cov_tile_list);
@@ -631,6 +668,16 @@ int wga_free(wga_ctx* c, void* d_ptr) {
     c->tune.out = nullptr;
     c->tune.phase = 0;
     c->tune.pending = false;
+  }
+  if (d_ptr) { /* what a count call left for its fill call does not outlive the arrays it was made from */
+    const wga_ctx::OpTabKey& k = c->op_tab.key;
+    if (d_ptr == k.ops || d_ptr == k.op_off || d_ptr == k.x0 || d_ptr == k.x1 || d_ptr == k.x2) c->op_tab.valid = false;
+    wga_ctx::ElemScan& es = c->elem_scan;
+    const void* src[sizeof(es.src) / sizeof(void*)];
+    memcpy(src, es.src, sizeof(es.src));
+    for (const void* q : src)
+      if (q == d_ptr) es.valid = false;
+    if (d_ptr == es.elem_off) es.valid = false;
   }
   if (d_ptr) RT_CHECK(rt_free(d_ptr));
   return WGA_OK;
@@ -1277,7 +1324,7 @@ int wga_maf_runs_ops(wga_ctx* c, uint32_t n, uint64_t n_elems, const uint64_t* d
   if (n && (!d_cols || (n_elems && !d_runs))) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
   MafRunOps f;
   f.s = maf_run_src(d_runs, d_run_off, d_cols);
-  return run_elems(c, f, n, n_elems, d_run_off, d_cnt, d_out, d_out_off);
+  return run_elems(c, 1, f, n, n_elems, d_run_off, d_cnt, d_out, d_out_off);
 }
 
 int wga_maf_runs_cigar_text(wga_ctx* c, uint32_t n, uint64_t n_elems, const uint64_t* d_runs,
@@ -1286,7 +1333,7 @@ int wga_maf_runs_cigar_text(wga_ctx* c, uint32_t n, uint64_t n_elems, const uint
   if (n && (!d_cols || (n_elems && !d_runs))) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
   MafRunText f;
   f.s = maf_run_src(d_runs, d_run_off, d_cols);
-  return run_elems(c, f, n, n_elems, d_run_off, d_cnt, d_out, d_out_off);
+  return run_elems(c, 2, f, n, n_elems, d_run_off, d_cnt, d_out, d_out_off);
 }
 
 int wga_chain_lines_ops(wga_ctx* c, uint32_t n, uint64_t n_elems, const uint64_t* d_lines,
@@ -1294,7 +1341,7 @@ int wga_chain_lines_ops(wga_ctx* c, uint32_t n, uint64_t n_elems, const uint64_t
   if (n && n_elems && !d_lines) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
   ChainLineOps f;
   f.s.lines = (const u64*)d_lines;
-  return run_elems(c, f, n, n_elems, d_line_off, d_cnt, d_out, d_out_off);
+  return run_elems(c, 3, f, n, n_elems, d_line_off, d_cnt, d_out, d_out_off);
 }
 
 int wga_chain_lines_cigar_text(wga_ctx* c, uint32_t n, uint64_t n_elems, const uint64_t* d_lines,
@@ -1303,7 +1350,7 @@ int wga_chain_lines_cigar_text(wga_ctx* c, uint32_t n, uint64_t n_elems, const u
   if (n && n_elems && !d_lines) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
   ChainLineText f;
   f.s.lines = (const u64*)d_lines;
-  return run_elems(c, f, n, n_elems, d_line_off, d_cnt, d_out, d_out_off);
+  return run_elems(c, 4, f, n, n_elems, d_line_off, d_cnt, d_out, d_out_off);
 }
 
 int wga_cigar_dotplot(wga_ctx* c, const wga_cigar_batch* b, uint64_t cutoff, const uint64_t* d_t_start,

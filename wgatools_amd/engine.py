@@ -158,6 +158,12 @@ class Engine:
         self.sync()  # the host array may be a temporary
         return d
 
+    def copy_into(self, dst, arr):
+        """host array -> an existing device array (the same pointer keeps its address)"""
+        arr = np.ascontiguousarray(arr)
+        self._check(self.lib.wga_memcpy_h2d(self.ctx, dst.ptr, arr.ctypes.data, arr.nbytes))
+        self.sync()
+
     def sync(self):
         self._check(self.lib.wga_sync(self.ctx))
 
