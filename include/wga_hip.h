@@ -363,7 +363,10 @@ int wga_cigar_chain(wga_ctx*, const wga_cigar_batch*, wga_chain_trim_t* d_trim, 
  * walked as M size, I, D (zero lengths are left out of the ops; the text always has "<size>M").
  * Runs are K3's (wga_maf_pair_stat).  n_elems = d_*_off[n] = total runs / lines (< 2^32).
  * Two calls each: d_out == NULL fills d_cnt[n] (ops / bytes of record i); then record i's output is
- * written at d_out + d_out_off[i] (ops: in elements; text: in bytes). */
+ * written at d_out + d_out_off[i] (ops: in elements; text: in bytes).  The count call's scan of the
+ * element sizes stays in the context for the fill call with the same arrays and counts (8 bytes per
+ * element, grow-only; dropped when wga_free takes one of the arrays): between the two calls the arrays'
+ * contents must not change — a new batch in the same arrays starts with its own count call. */
 int wga_maf_runs_ops(wga_ctx*, uint32_t n, uint64_t n_elems, const uint64_t* d_runs, const uint64_t* d_run_off,
                      const uint64_t* d_cols, uint64_t* d_cnt, uint32_t* d_out, const uint64_t* d_out_off);
 int wga_maf_runs_cigar_text(wga_ctx*, uint32_t n, uint64_t n_elems, const uint64_t* d_runs,
