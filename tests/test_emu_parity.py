@@ -444,6 +444,21 @@ def test_runs_bridge_synthetic(emu):
     pc.check_runs_bridge_synthetic(emu, recs)
 
 
+def test_pafpseudo_fill_without_the_class_sums_call(emu):
+    """wga_pafpseudo_fill takes the sums wga_cigar_class_sums left for the same batch — or computes them when no such call
+    stands in front (other arrays, or none at all)"""
+    b = synth.make_paf_batch(7, 40, 300, 60000)
+    code, length = b["ops"] & 15, (b["ops"] >> 4).astype(np.uint64)
+    v = np.where((code == 0) | (code == 7) | (code == 8) | (code == 1) | (code == 4), length, 0).astype(np.uint64)
+    c = np.concatenate([np.zeros(1, np.uint64), np.cumsum(v, dtype=np.uint64)])
+    b["q_src_len"] = c[b["op_off"][1:].astype(np.int64)] - c[b["op_off"][:-1].astype(np.int64)]
+    b["q_src_off"] = np.zeros(40, dtype=np.uint64)
+    for base in (0, 1):
+        pc.check_pafpseudo(emu, b, base, sums_call=False)
+        pc.check_pafpseudo(emu, b, base)
+        pc.check_pafpseudo(emu, b, base, sums_call=False)
+
+
 def test_elem_scan_reuse(emu):
     pc.check_elem_scan_reuse(emu)
 

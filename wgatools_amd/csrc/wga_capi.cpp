@@ -73,6 +73,16 @@ struct wga_ctx {
     u32* piece_rec = nullptr; /* np: the record of every piece */
     void* pieces = nullptr;   /* np x per_piece bytes */
   } op_tab;
+  struct ClassTab { /* pafpseudo: the tile and record class sums of wga_cigar_class_sums, kept for wga_pafpseudo_fill */
+    void* mem = nullptr;
+    size_t cap = 0;
+    bool valid = false;
+    const void *ops = nullptr, *op_off = nullptr;
+    uint32_t n = 0;
+    uint64_t n_ops = 0;
+    wga_tile_sum* tiles = nullptr;
+    wga_class_sums* rec_sums = nullptr;
+  } class_tab;
   struct ElemScan { /* K11: the count call's scan of the element sizes, kept for the fill call (grow-only buffer) */
     void* mem = nullptr;
     size_t cap = 0;
@@ -464,6 +474,7 @@ void wga_ctx_destroy(wga_ctx* c) {
   if (c->tune.have_ev) rt_event_destroy(c->tune.ev[0]), rt_event_destroy(c->tune.ev[1]);
   if (c->scratch) (void)rt_free(c->scratch);
   if (c->elem_scan.mem) (void)rt_free(c->elem_scan.mem);
+  if (c->class_tab.mem) (void)rt_free(c->class_tab.mem);
   if (c->cov_pieces) (void)rt_free(c->cov_pieces);
   if (c->cov_list) (void)rt_free(c->cov_list);
   if (c->cov_tile_list) (void)rt_free(c->cov_tile_list);
@@ -678,6 +689,7 @@ int wga_free(wga_ctx* c, void* d_ptr) {
     for (const void* q : src)
       if (q == d_ptr) es.valid = false;
     if (d_ptr == es.elem_off) es.valid = false;
+    if (d_ptr == c->class_tab.ops || d_ptr == c->class_tab.op_off) c->class_tab.valid = false;
   }
   if (d_ptr) RT_CHECK(rt_free(d_ptr));
   return WGA_OK;
@@ -1661,18 +1673,47 @@ int wga_pafcov_finalize(wga_ctx* c, uint32_t n_targets, const uint64_t* d_cov_of
   return WGA_OK;
 }
 
+/* The class sums are the count call of pafpseudo's protocol (the host sizes the row segments from them): the tile sums and the
+ * record sums stay in the context for wga_pafpseudo_fill on the same batch (keyed by its arrays and counts, dropped when one of
+ * them is freed), which then is the fill kernel alone. */
 int wga_cigar_class_sums(wga_ctx* c, const wga_cigar_batch* b, wga_class_sums* d_sums) {
   int rc = ctx_bind(c);
   if (rc) return rc;
   if ((rc = check_batch(b))) return rc;
   if (b->n == 0) return WGA_OK;
   if (!d_sums) return fail(WGA_E_INVALID_ARG, "d_sums null", nullptr);
-  RT_CHECK(rt_memset(d_sums, 0, (size_t)b->n * sizeof(wga_class_sums), c->stream));
+  wga_ctx::ClassTab& t = c->class_tab;
+  t.valid = false;
   u64 nt = n_tiles(b->n_ops);
-  if (nt == 0) return WGA_OK;
+  if (nt == 0) {
+    RT_CHECK(rt_memset(d_sums, 0, (size_t)b->n * sizeof(wga_class_sums), c->stream));
+    return WGA_OK;
+  }
+  const size_t tile_bytes = ((size_t)nt * sizeof(wga_tile_sum) + 63) & ~(size_t)63;
+  const size_t need = tile_bytes + (size_t)b->n * sizeof(wga_class_sums);
+  if (t.cap < need) {
+    if (t.mem) RT_CHECK(rt_free(t.mem));
+    t.mem = nullptr;
+    t.cap = 0;
+    RT_CHECK(rt_malloc(&t.mem, need + need / 4));
+    t.cap = need + need / 4;
+  }
+  t.tiles = (wga_tile_sum*)t.mem;
+  t.rec_sums = (wga_class_sums*)((char*)t.mem + tile_bytes);
+  RT_CHECK(rt_memset(t.rec_sums, 0, (size_t)b->n * sizeof(wga_class_sums), c->stream));
   WGA_LAUNCH(k_class_tiles, (u32)((nt + 3) / 4), WGA_BLOCK, c->stream, b->d_ops,
-             (const u64*)b->d_op_off, b->n, (u64)b->n_ops, (wga_tile_sum*)nullptr, d_sums);
+             (const u64*)b->d_op_off, b->n, (u64)b->n_ops, t.tiles, t.rec_sums);
   LAUNCH_CHECK();
+  static_assert(sizeof(wga_class_sums) % 8 == 0, "wga_class_sums in 64-bit words");
+  const u64 words = (u64)b->n * (sizeof(wga_class_sums) / 8);
+  WGA_LAUNCH(k_copy_u64, (u32)((words + WGA_BLOCK - 1) / WGA_BLOCK), WGA_BLOCK, c->stream, words, (const u64*)t.rec_sums,
+             (u64*)d_sums);
+  LAUNCH_CHECK();
+  t.ops = b->d_ops;
+  t.op_off = b->d_op_off;
+  t.n = b->n;
+  t.n_ops = b->n_ops;
+  t.valid = true;
   return WGA_OK;
 }
 
@@ -1690,15 +1731,23 @@ int wga_pafpseudo_fill(wga_ctx* c, const wga_cigar_batch* b, int base_mode, cons
   RT_CHECK(rt_memset(d_diag, 0xFF, (size_t)b->n * sizeof(wga_rec_diag), c->stream));
   u64 nt = n_tiles(b->n_ops);
   if (nt == 0) return WGA_OK;
-  void* ws;
-  size_t tile_bytes = ((size_t)nt * sizeof(wga_tile_sum) + 63) & ~(size_t)63;
-  if ((rc = ctx_scratch(c, tile_bytes + (size_t)b->n * sizeof(wga_class_sums), &ws))) return rc;
-  wga_tile_sum* tiles = (wga_tile_sum*)ws;
-  wga_class_sums* rec_sums = (wga_class_sums*)((char*)ws + tile_bytes);
-  RT_CHECK(rt_memset(rec_sums, 0, (size_t)b->n * sizeof(wga_class_sums), c->stream));
-  WGA_LAUNCH(k_class_tiles, (u32)((nt + 3) / 4), WGA_BLOCK, c->stream, b->d_ops,
-             (const u64*)b->d_op_off, b->n, (u64)b->n_ops, tiles, rec_sums);
-  LAUNCH_CHECK();
+  wga_tile_sum* tiles;
+  wga_class_sums* rec_sums;
+  const wga_ctx::ClassTab& t = c->class_tab;
+  if (t.valid && t.ops == (const void*)b->d_ops && t.op_off == (const void*)b->d_op_off && t.n == b->n && t.n_ops == b->n_ops) {
+    tiles = t.tiles; /* what wga_cigar_class_sums left for this batch */
+    rec_sums = t.rec_sums;
+  } else {
+    void* ws;
+    size_t tile_bytes = ((size_t)nt * sizeof(wga_tile_sum) + 63) & ~(size_t)63;
+    if ((rc = ctx_scratch(c, tile_bytes + (size_t)b->n * sizeof(wga_class_sums), &ws))) return rc;
+    tiles = (wga_tile_sum*)ws;
+    rec_sums = (wga_class_sums*)((char*)ws + tile_bytes);
+    RT_CHECK(rt_memset(rec_sums, 0, (size_t)b->n * sizeof(wga_class_sums), c->stream));
+    WGA_LAUNCH(k_class_tiles, (u32)((nt + 3) / 4), WGA_BLOCK, c->stream, b->d_ops,
+               (const u64*)b->d_op_off, b->n, (u64)b->n_ops, tiles, rec_sums);
+    LAUNCH_CHECK();
+  }
   PseudoArgs a;
   a.ops = b->d_ops;
   a.op_off = (const u64*)b->d_op_off;

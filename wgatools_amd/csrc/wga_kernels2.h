@@ -108,6 +108,12 @@ __global__ __launch_bounds__(256) void k_class_tiles(const u32* __restrict__ ops
   }
 }
 
+/* n 64-bit words from src to dst (a context-owned result handed to the caller's array) */
+__global__ __launch_bounds__(256) void k_copy_u64(u64 n, const u64* __restrict__ src, u64* __restrict__ dst) {
+  const u64 i = (u64)blockIdx.x * WGA_BLOCK + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
 /* ============================================================================================ */
 /* K5: pafcov                                                                                   */
 /* ============================================================================================ */
