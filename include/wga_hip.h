@@ -491,7 +491,11 @@ int wga_pafcov_format(wga_ctx*, const uint8_t* d_name, uint32_t name_len, const 
 
 /* ---- per-record class sums of a batch: bases in M/=/X, I, D, S and "other" (N H P ...) ops.
  *      pafpseudo's host logic (pseudomaf.rs:147-202) needs M+X+D (target span) and the edited
- *      query length q_len - (I+S) + D before it can place segments.  d_sums: n x 5 u64. ------- */
+ *      query length q_len - (I+S) + D before it can place segments.  d_sums: n x 5 u64.
+ *      The call is the count call of pafpseudo's protocol: its tile and record sums stay in the
+ *      context (88 bytes per 1024 ops + 40 per record, grow-only) for wga_pafpseudo_fill on the
+ *      same batch arrays, which then does not compute them again; between the two calls the ops
+ *      must not change (a new batch in the same arrays starts with its own class-sums call). --- */
 typedef struct {
   uint64_t mx, i, d, s, o;
 } wga_class_sums;
