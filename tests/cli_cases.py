@@ -1179,6 +1179,16 @@ def test_bgzipped_paf_and_maf_inputs(cli, tmp_path):
     for cmd in (lambda f: ["stat", f], lambda f: ["maf2paf", f], lambda f: ["call", f, "-s", "-l", "3"]):
         want = runs(*cmd(maf))
         assert want[0] == 0 and runs(*cmd(mbgz)) == want, cmd("x")[0]
+    # two BGZF files one behind the other (an EOF marker in the middle), and a file of the EOF marker alone
+    half = len(text) // 2
+    cut = text.rfind(b"\n", 0, half) + 1
+    pa, pb, pab, pe = (str(tmp_path / x) for x in ("a.bgz", "b.bgz", "ab.paf.bgz", "empty.paf.bgz"))
+    _bgzf_write(pa, text[:cut - 7], block=300)       # the files are cut inside a line
+    _bgzf_write(pb, text[cut - 7:], block=64)
+    open(pab, "wb").write(open(pa, "rb").read() + open(pb, "rb").read())
+    _bgzf_write(pe, b"")
+    assert runs("stat", "-f", "paf", pab) == runs("stat", "-f", "paf", paf)
+    assert runs("stat", "-f", "paf", pe) == (0, b"")
     # a member whose deflate data is damaged
     raw = bytearray(open(bgz, "rb").read())
     raw[18 + 5] ^= 0xFF
