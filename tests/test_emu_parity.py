@@ -202,8 +202,7 @@ def test_pafcov_ops_across_many_windows(emu):
 
 def test_pafcov_segments_across_hundreds_of_windows(emu):
     """K5's list pass takes a lane per window, 64 windows a round: ops of 2 000 000 / 1 500 000 / 900 000 bases (segments across
-    244 / 183 / 110 windows: several rounds, the pieces beyond the tile's own slots in the list regions, which grow), one call
-    and two"""
+    244 / 183 / 110 windows: several rounds, the pieces beyond the tile's own slots in the list regions, which grow)"""
     mk = lambda p: [(int(ln) << 4) | int(c) for c, ln in p]
     recs = [mk([(7, 5), (7, 2_000_000), (2, 3), (0, 1_500_000), (8, 1), (7, 700_000)]),
             mk([(7, 3), (1, 2)] * 300 + [(7, 900_000)] + [(8, 1), (7, 2)] * 200),
@@ -211,8 +210,7 @@ def test_pafcov_segments_across_hundreds_of_windows(emu):
     ops = np.array([o for r in recs for o in r], dtype=np.uint32)
     off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
     b = dict(ops=ops, op_off=off, strand_neg=np.zeros(3, dtype=np.uint8))
-    for split in (False, True):
-        pc.check_pafcov(emu, b, [0, 1, 0], [100, 8191, 4_300_000], [4_400_000, 1_000_000], split=split)
+    pc.check_pafcov(emu, b, [0, 1, 0], [100, 8191, 4_300_000], [4_400_000, 1_000_000])
 
 
 def test_pafcov_random_shapes(emu):
