@@ -28,7 +28,11 @@
 extern "C" {
 #endif
 
-#define WGA_ABI_VERSION 1
+/* 2: what a count call leaves in the context for its fill call (wga_maf_runs_* / wga_chain_lines_*, the op walks
+ *    wga_paf_call_events / wga_cigar_chain / wga_cigar_dotplot over long records, wga_cigar_class_sums -> wga_pafpseudo_fill)
+ *    is ONE-SHOT — the first fill call that takes it consumes it — and is dropped when one of the arrays it was made from is
+ *    written through wga_memcpy_h2d / wga_memset or freed; "expand_variant" takes -1, 0, 2, 3. */
+#define WGA_ABI_VERSION 2
 
 /* ---- status codes (call level) ------------------------------------------------------------ */
 enum wga_status {
@@ -365,8 +369,9 @@ int wga_cigar_chain(wga_ctx*, const wga_cigar_batch*, wga_chain_trim_t* d_trim, 
  * Two calls each: d_out == NULL fills d_cnt[n] (ops / bytes of record i); then record i's output is
  * written at d_out + d_out_off[i] (ops: in elements; text: in bytes).  The count call's scan of the
  * element sizes stays in the context for the fill call with the same arrays and counts (8 bytes per
- * element, grow-only; dropped when wga_free takes one of the arrays): between the two calls the arrays'
- * contents must not change — a new batch in the same arrays starts with its own count call. */
+ * element, grow-only).  It is one-shot (the fill call that takes it consumes it; a second fill call computes its own) and
+ * is dropped when wga_free, wga_memcpy_h2d or wga_memset touches one of the arrays.  Contents changed behind the library's
+ * back (another stream, another library) between the two calls are the caller's to fence with a new count call. */
 int wga_maf_runs_ops(wga_ctx*, uint32_t n, uint64_t n_elems, const uint64_t* d_runs, const uint64_t* d_run_off,
                      const uint64_t* d_cols, uint64_t* d_cnt, uint32_t* d_out, const uint64_t* d_out_off);
 int wga_maf_runs_cigar_text(wga_ctx*, uint32_t n, uint64_t n_elems, const uint64_t* d_runs,
@@ -494,8 +499,8 @@ int wga_pafcov_format(wga_ctx*, const uint8_t* d_name, uint32_t name_len, const 
  *      query length q_len - (I+S) + D before it can place segments.  d_sums: n x 5 u64.
  *      The call is the count call of pafpseudo's protocol: its tile and record sums stay in the
  *      context (88 bytes per 1024 ops + 40 per record, grow-only) for wga_pafpseudo_fill on the
- *      same batch arrays, which then does not compute them again; between the two calls the ops
- *      must not change (a new batch in the same arrays starts with its own class-sums call). --- */
+ *      same batch arrays, which then does not compute them again (one-shot: that fill call consumes
+ *      them; dropped when the op arrays are written through wga_memcpy_h2d / wga_memset or freed). --- */
 typedef struct {
   uint64_t mx, i, d, s, o;
 } wga_class_sums;

@@ -763,6 +763,16 @@ def check_elem_scan_reuse(eng):
     fill_and_check(b, True)
     eng.chain_lines_ops(n, ne, d_lines, d_loff)      # another entry point counts over the same arrays ...
     fill_and_check(b, False)                          # ... and the text fill does not take its scan
+    # a count call, then the arrays' contents replaced through the library, then a fill call WITHOUT a count call: the
+    # scan of the first batch must not be taken (it was, silently)
+    cnt = eng.chain_lines_cigar_text(n, ne, d_lines, d_loff).numpy().astype(np.int64)
+    assert cnt.tolist() == [len(text_of(r)) for r in b]
+    eng.copy_into(d_lines, flat(a))
+    fill_and_check(a, False)
+    # ... and a count-to-fill scan is one-shot: the second fill call after one count call computes its own
+    fill_and_check(a, True)
+    eng.copy_into(d_lines, flat(b))
+    fill_and_check(b, False)
 
 
 def check_chain_lines(eng, recs, strands, seqs=None):

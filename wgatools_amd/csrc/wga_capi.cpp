@@ -202,8 +202,8 @@ static int run_elems(wga_ctx* c, int kind, F f, u32 n, uint64_t n_elems, const u
   memcpy(src, &f, sizeof(F));
   const bool hit = d_out && es.valid && es.kind == kind && es.elem_off == (const void*)d_elem_off && es.n == n && es.ne == ne &&
                    memcmp(es.src, src, sizeof(src)) == 0;
+  es.valid = false; /* one shot: a hit is the fill call of the protocol and consumes what the count call left */
   if (!hit) {
-    es.valid = false;
     const size_t need = ((size_t)ne + 1 + (size_t)ne / 1024 + 4) * sizeof(u64);
     if (es.cap < need) {
       if (es.mem) RT_CHECK(rt_free(es.mem));
@@ -387,8 +387,8 @@ static int op_piece_table(wga_ctx* c, const wga_cigar_batch* b, size_t per_piece
                           bool* hit) {
   wga_ctx::OpTab& t = c->op_tab;
   *hit = reuse && t.valid && t.key == key;
+  t.valid = false; /* one shot: the fill call that takes the table consumes it (its arrays stay where they are for this call) */
   if (*hit) return WGA_OK;
-  t.valid = false;
   t.np = 0;
   t.all = false;
   if (b->n_ops <= c->op_long_ops) return WGA_OK;
@@ -671,6 +671,23 @@ int wga_arena_probe(wga_ctx* c, void* d_buf, size_t bytes, int kind, double* gbp
   *gbps = ms > 0.0f ? moved / ((double)ms * 1e6) : 0.0;
   return WGA_OK;
 }
+/* What a count call left for its fill call (the K11 scan, the piece table of K7 / K10 / K12, pafpseudo's class sums) is keyed
+ * by the arrays it was made from.  Writing into one of those arrays through the library, or freeing it, drops it: a fill call
+ * then computes its own.  [lo, lo + bytes) is the range written (bytes == 0: the allocation that starts at lo). */
+static void ctx_arrays_written(wga_ctx* c, const void* lo, size_t bytes) {
+  const uintptr_t a = (uintptr_t)lo, z = a + (bytes ? bytes : 1);
+  auto in = [&](const void* q) { return q && (uintptr_t)q >= a && (uintptr_t)q < z; };
+  const wga_ctx::OpTabKey& k = c->op_tab.key;
+  if (in(k.ops) || in(k.op_off) || in(k.x0) || in(k.x1) || in(k.x2)) c->op_tab.valid = false;
+  wga_ctx::ElemScan& es = c->elem_scan;
+  const void* src[sizeof(es.src) / sizeof(void*)];
+  memcpy(src, es.src, sizeof(es.src));
+  for (const void* q : src)
+    if (in(q)) es.valid = false;
+  if (in(es.elem_off)) es.valid = false;
+  if (in(c->class_tab.ops) || in(c->class_tab.op_off)) c->class_tab.valid = false;
+}
+
 int wga_free(wga_ctx* c, void* d_ptr) {
   int rc = ctx_bind(c);
   if (rc) return rc;
@@ -680,24 +697,17 @@ int wga_free(wga_ctx* c, void* d_ptr) {
     c->tune.phase = 0;
     c->tune.pending = false;
   }
-  if (d_ptr) { /* what a count call left for its fill call does not outlive the arrays it was made from */
-    const wga_ctx::OpTabKey& k = c->op_tab.key;
-    if (d_ptr == k.ops || d_ptr == k.op_off || d_ptr == k.x0 || d_ptr == k.x1 || d_ptr == k.x2) c->op_tab.valid = false;
-    wga_ctx::ElemScan& es = c->elem_scan;
-    const void* src[sizeof(es.src) / sizeof(void*)];
-    memcpy(src, es.src, sizeof(es.src));
-    for (const void* q : src)
-      if (q == d_ptr) es.valid = false;
-    if (d_ptr == es.elem_off) es.valid = false;
-    if (d_ptr == c->class_tab.ops || d_ptr == c->class_tab.op_off) c->class_tab.valid = false;
-  }
+  if (d_ptr) ctx_arrays_written(c, d_ptr, 0); /* what a count call left for its fill call does not outlive the arrays it was made from */
   if (d_ptr) RT_CHECK(rt_free(d_ptr));
   return WGA_OK;
 }
 int wga_memcpy_h2d(wga_ctx* c, void* d_dst, const void* h_src, size_t bytes) {
   int rc = ctx_bind(c);
   if (rc) return rc;
-  if (bytes) RT_CHECK(rt_h2d(d_dst, h_src, bytes, c->stream));
+  if (bytes) {
+    ctx_arrays_written(c, d_dst, bytes);
+    RT_CHECK(rt_h2d(d_dst, h_src, bytes, c->stream));
+  }
   return WGA_OK;
 }
 int wga_memcpy_d2h(wga_ctx* c, void* h_dst, const void* d_src, size_t bytes) {
@@ -732,7 +742,10 @@ int wga_memcpy_d2h_async(wga_ctx* c, void* h_dst, const void* d_src, size_t byte
 int wga_memset(wga_ctx* c, void* d_dst, int byte, size_t bytes) {
   int rc = ctx_bind(c);
   if (rc) return rc;
-  if (bytes) RT_CHECK(rt_memset(d_dst, byte, bytes, c->stream));
+  if (bytes) {
+    ctx_arrays_written(c, d_dst, bytes);
+    RT_CHECK(rt_memset(d_dst, byte, bytes, c->stream));
+  }
   return WGA_OK;
 }
 
@@ -1733,8 +1746,10 @@ int wga_pafpseudo_fill(wga_ctx* c, const wga_cigar_batch* b, int base_mode, cons
   if (nt == 0) return WGA_OK;
   wga_tile_sum* tiles;
   wga_class_sums* rec_sums;
-  const wga_ctx::ClassTab& t = c->class_tab;
-  if (t.valid && t.ops == (const void*)b->d_ops && t.op_off == (const void*)b->d_op_off && t.n == b->n && t.n_ops == b->n_ops) {
+  wga_ctx::ClassTab& t = c->class_tab;
+  const bool kept = t.valid && t.ops == (const void*)b->d_ops && t.op_off == (const void*)b->d_op_off && t.n == b->n && t.n_ops == b->n_ops;
+  t.valid = false; /* one shot: this fill call consumes what the class-sums call left (the sums stay where they are for this call) */
+  if (kept) {
     tiles = t.tiles; /* what wga_cigar_class_sums left for this batch */
     rec_sums = t.rec_sums;
   } else {
