@@ -1,5 +1,6 @@
-"""The window row kernel (expand_variant 2) on the GPU: the oracle battery of the planned kernel, and the whole output of
-BASELINE configs[1] / 50-kop / 500-op batches byte for byte against v1 (expand_variant 0) on the device."""
+"""A row kernel (expand_variant 2 = the window kernel, 3 = the streaming kernel; argv[1], default 2) on the GPU: the oracle
+battery, and the whole output of BASELINE configs[1] / 50-kop / 500-op batches byte for byte against v1 (expand_variant 0)
+on the device.  Further arguments: context parameters name=value (e.g. expand_job_tiles=8)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -9,7 +10,9 @@ import parity_cases as pc
 from wgatools_amd import build, engine, _lib, synth, pipeline
 
 eng = engine.Engine(0, _lib.load(build.HIP_LIB))
-V = 2
+V = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+for kv in sys.argv[2:]:
+    eng.set_param(kv.split("=")[0], int(kv.split("=")[1]))
 t0 = time.time()
 for seed, n, mean, pool, use_m in [(1, 12, 700, 50000, False), (2, 40, 60, 20000, False), (3, 300, 3, 5000, True), (4, 3, 5000, 200000, True)]:
     b = synth.make_paf_batch(seed, n, mean, pool, use_m=use_m)
@@ -40,7 +43,7 @@ eng.set_stream(torch.cuda.current_stream().cuda_stream)
 for rec, mean, pool in [(100_000, 5000, 50), (10_000, 50_000, 50), (1_000_000, 500, 50), (3_000_000, 30, 20)]:
     tb = synth.make_paf_batch_torch(0x5747415F + 2, rec, mean, pool * 1_000_000, dev)
     outs = []
-    for v in (0, 2):
+    for v in (0, V):
         eng.set_param("expand_variant", v)
         job = pipeline.Paf2MafStatJob(eng, tb, with_text=True)
         job.out.fill_(0x23)
@@ -51,7 +54,7 @@ for rec, mean, pool in [(100_000, 5000, 50), (10_000, 50_000, 50), (1_000_000, 5
         outs.append(job.out)
         del job
     same = bool(torch.equal(outs[0], outs[1]))
-    print("shape %d x %d, 2 x %d MB: variant 2 == variant 0 over %d bytes: %s" % (rec, mean, pool, outs[0].numel(), same), flush=True)
+    print("shape %d x %d, 2 x %d MB: variant %d == variant 0 over %d bytes: %s" % (rec, mean, pool, V, outs[0].numel(), same), flush=True)
     if not same:
         d = (outs[0] != outs[1]).nonzero()[:10].flatten().tolist()
         print("  first differences at", d)
@@ -59,4 +62,4 @@ for rec, mean, pool in [(100_000, 5000, 50), (10_000, 50_000, 50), (1_000_000, 5
     del outs, tb
     torch.cuda.empty_cache()
 eng.set_param("expand_variant", 0)
-print("K2w check ok")
+print("row kernel %d check ok" % V)

@@ -78,4 +78,14 @@ __device__ __forceinline__ u32 bit_mask(u32 bits, u32 idx) { return 0u - ((bits 
 
 __device__ __forceinline__ void buf_store16_w(const BufRsrc& r, u32 off, const u32 v[4]) { buf_store16(r, off, v); }
 
+/* LDS-DMA of the streaming row kernel: the copy happens at once (the emulator cannot show a read that comes too early —
+ * the `-m gpu` parity tests do), the waits are empty */
+__device__ __forceinline__ void lds_dma16(const void* gbase, u32 voff, void* lds_dst) {
+  memcpy((u8*)lds_dst + 16u * (threadIdx.x & 63u), (const u8*)gbase + voff, 16);
+}
+__device__ __forceinline__ void lds_dma16_after_reads(const void* gbase, u32 voff, void* lds_dst) { lds_dma16(gbase, voff, lds_dst); }
+__device__ __forceinline__ void gstore16_nt(void* base, u32 voff, const u32 v[4]) { memcpy((u8*)base + voff, v, 16); }
+__device__ __forceinline__ void vm_wait(u32) {}
+__device__ __forceinline__ u32 bfi_b32(u32 mask, u32 a, u32 b) { return (a & mask) | (b & ~mask); }
+
 #endif /* WGA_INTRIN_EMU_H */

@@ -56,7 +56,7 @@ def check_stat(eng, b, sample=None):
 # ------------------------------------------------------------------------------------------------
 # K2
 # ------------------------------------------------------------------------------------------------
-DEFAULT_EXPAND_VARIANT = {"0": 0, "2": 2}.get(os.environ.get("WGA_EXPAND_VARIANT", ""), -1)   # -1: the library picks by the batch
+DEFAULT_EXPAND_VARIANT = {"0": 0, "2": 2, "3": 3}.get(os.environ.get("WGA_EXPAND_VARIANT", ""), -1)   # -1: the library picks by the batch
 
 
 def run_paf2maf(eng, b, pre=None, force_slow=0, fill=0x23, no_table=0, variant=None):
@@ -357,6 +357,50 @@ def window_kernel_cases(eng, variant=2):
         b = synth.make_paf_batch(seed, n, mean, 100000, use_m=bool(seed & 1))
         rng = np.random.default_rng(seed)
         check_paf2maf(eng, b, pre=(rng.integers(0, 130, n), rng.integers(0, 130, n), rng.integers(0, 5, n)), variant=variant)
+
+
+def stream_kernel_cases(eng):
+    """the streaming row kernel (expand_variant 3) beyond window_kernel_cases: every job length, records that are not clean
+    (left to v1) between clean ones inside one job, long records over many jobs, dense gap events (FIFO pressure, many
+    events per granule), invalid bases on '-' strand rows, slices at both pool edges"""
+    from wgatools_amd import synth
+    try:
+        for jt in (1, 2, 4, 32):
+            eng.set_param("expand_job_tiles", jt)
+            b = synth.make_paf_batch(40 + jt, 9, 3000, 300_000)
+            rng = np.random.default_rng(jt)
+            check_paf2maf(eng, b, pre=(rng.integers(0, 130, 9), rng.integers(0, 130, 9), rng.integers(0, 5, 9)), variant=3)
+            assert eng.get_param("expand_variant_used") == 3 and eng.get_param("expand_stream_left_to_v1") == 0
+            # records 2 and 5 get a tail (slice longer than the CIGAR consumes), record 6 a short slice: their tiles are v1's
+            u = dict(b)
+            tl, ql = b["t_src_len"].copy(), b["q_src_len"].copy()
+            tl[2] += 7
+            ql[5] += 3
+            tl[6] -= min(5, int(tl[6]))
+            u["t_src_len"], u["q_src_len"] = tl, ql
+            check_paf2maf(eng, u, variant=3)
+            assert eng.get_param("expand_stream_left_to_v1") > 0
+            check_paf2maf(eng, dense_indel_batch(eng), variant=3)
+        eng.set_param("expand_job_tiles", 4)
+        big = synth.make_paf_batch(12, 1, 40_000, 400_000, sigma=0.01)  # one record over ~40 tiles = 10 jobs
+        check_paf2maf(eng, big, variant=3)
+        bad = synth.make_paf_batch(13, 3, 3000, 100_000)                # invalid bases on '-' strand rows
+        bad["strand_neg"][:] = 1
+        qp = bad["q_pool"].copy()
+        for r_, f in ((0, 3), (1, 2), (1, 5)):
+            qp[int(bad["q_src_off"][r_] + bad["q_src_len"][r_] * f // 7)] = ord("R-x"[f % 3])
+        bad["q_pool"] = qp
+        r = check_paf2maf(eng, bad, variant=3)
+        assert int(r["diag"]["bad_base_pos"][0]) != int(r["diag"]["bad_base_pos"][2])
+        # slices that begin at byte 0 and end at the last byte of their pools (no padding around them)
+        cig = ["700=3I900=2D650=", "1500=1X200=4D300="]
+        tq = [consumption(c) for c in cig]
+        rs = np.random.default_rng(3)
+        for strands in ([0, 0], [1, 1]):
+            check_paf2maf(eng, batch_from_texts(eng, cig, strands, [rand_seq(rs, t) for t, _ in tq], [rand_seq(rs, q) for _, q in tq], pad=0),
+                          variant=3)
+    finally:
+        eng.set_param("expand_job_tiles", 4)
 
 
 def dense_indel_batch(eng, seed=9):

@@ -139,6 +139,14 @@ def test_paf2maf_window_kernel_errors_and_long_record(emu):
     pc.check_paf2maf(emu, bad, variant=2)
 
 
+def test_paf2maf_stream_kernel(emu):
+    pc.window_kernel_cases(emu, variant=3)
+
+
+def test_paf2maf_stream_kernel_jobs_and_skips(emu):
+    pc.stream_kernel_cases(emu)
+
+
 def test_expand_variant_by_the_batch(emu):
     """expand_variant -1 (the default): short records take the window kernel, long ones v1; the bytes are the oracle's"""
     emu.set_param("expand_variant", -1)

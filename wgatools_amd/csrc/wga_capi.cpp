@@ -12,6 +12,7 @@
 
 #include "wga_kernels.h"
 #include "wga_kernels_k2w.h"
+#include "wga_kernels_k2s.h"
 #ifdef WGA_STAGE2
 #include "wga_kernels2.h"
 #include "wga_kernels3.h"
@@ -47,6 +48,8 @@ struct wga_ctx {
   int expand_variant = -1; /* the row kernel: -1 by the batch (records below WGA_AUTO_SHORT_OPS ops on average take the window
                               kernel of wga_kernels_k2w.h, longer ones v1), 0 v1 (wga_kernels.h), 2 the window kernel */
   int expand_variant_used = 0;
+  int expand_job_tiles = 4; /* streaming kernel: tiles per wave ("expand_job_tiles") */
+  const u32* stream_counts = nullptr; /* streaming kernel: the two counters of the tiles its last launch left to v1 (in the scratch arena) */
   void* expand_dbg = nullptr;
   void* scratch = nullptr;
   size_t scratch_cap = 0;
@@ -136,6 +139,7 @@ static int ctx_scratch(wga_ctx* c, size_t bytes, void** out) {
     RT_CHECK(rt_sync(c->stream));
     if (c->scratch) RT_CHECK(rt_free(c->scratch));
     c->scratch = nullptr;
+    c->stream_counts = nullptr;
     c->scratch_cap = 0;
     size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 2;
     RT_CHECK(rt_malloc(&c->scratch, cap));
@@ -454,7 +458,7 @@ int wga_ctx_create(int device, wga_ctx** out) {
   }
   c->stream = c->own_stream;
   /* A/B switch for measurements: WGA_EXPAND_VARIANT=0 selects v1 of the paf2maf row kernel (wga_ctx_set_param overrides) */
-  if (const char* v = getenv("WGA_EXPAND_VARIANT")) c->expand_variant = (atoi(v) == 0 || atoi(v) == 2) ? atoi(v) : -1;
+  if (const char* v = getenv("WGA_EXPAND_VARIANT")) c->expand_variant = (atoi(v) == 0 || atoi(v) == 2 || atoi(v) == 3) ? atoi(v) : -1;
   if (const char* v = getenv("WGA_COV_SPIN_LIMIT")) c->cov_spin_limit = (u32)strtoul(v, nullptr, 10);
   if (const char* v = getenv("WGA_EXPAND_AUTOTUNE")) c->expand_autotune = atoi(v) != 0;
   if (const char* v = getenv("WGA_EXPAND_DRAIN_MIN")) {
@@ -547,12 +551,17 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
     return WGA_OK;
   }
   if (strcmp(name, "expand_variant") == 0) {
-    if (value != -1 && value != 0 && value != 2) return fail(WGA_E_INVALID_ARG, "expand_variant: -1 (by the batch), 0, 2", nullptr);
+    if (value != -1 && value != 0 && value != 2 && value != 3) return fail(WGA_E_INVALID_ARG, "expand_variant: -1 (by the batch), 0, 2, 3", nullptr);
     c->expand_variant = (int)value;
     return WGA_OK;
   }
   if (strcmp(name, "expand_alias") == 0) {
     c->expand_alias = value != 0;
+    return WGA_OK;
+  }
+  if (strcmp(name, "expand_job_tiles") == 0) { /* streaming row kernel: consecutive tiles per wave */
+    if (value < 1 || value > (int64_t)WGA_S_MAX_JOB_TILES) return fail(WGA_E_INVALID_ARG, "expand_job_tiles: 1 .. 32", nullptr);
+    c->expand_job_tiles = (int)value;
     return WGA_OK;
   }
   if (strcmp(name, "expand_timing") == 0) {
@@ -884,10 +893,11 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
   const size_t list_bytes = 256 + 2 * (size_t)nt * sizeof(u32); /* two counters + the lists of wide / huge tiles */
   /* which row kernel: the window kernel wins on short records (many row pieces per tile: -12 .. -19 % at 500 ops per record),
    * v1 on long ones (+7 % at 5 kop, profiles/r03_k2w_experiments.md) */
-  const int variant = c->expand_variant >= 0 ? c->expand_variant : (b->n_ops / (u64)b->n < WGA_AUTO_SHORT_OPS ? 2 : 0);
+  const int variant = c->expand_variant >= 0 ? c->expand_variant : (b->n_ops / (u64)b->n < WGA_AUTO_SHORT_OPS ? 2 : WGA_AUTO_LONG_VARIANT);
   c->expand_variant_used = variant;
   const size_t plan_bytes = variant == 2 ? (size_t)nt * WGA_W_PLAN_WORDS * sizeof(u32) : 0;
-  if ((rc = ctx_scratch(c, rec_bytes + desc_bytes + list_bytes + plan_bytes, &ws))) return rc;
+  const size_t flag_bytes = variant == 3 ? (((size_t)nt + 255) & ~(size_t)255) : 0; /* streaming kernel: one byte per tile */
+  if ((rc = ctx_scratch(c, rec_bytes + desc_bytes + list_bytes + plan_bytes + flag_bytes, &ws))) return rc;
   wga_rec_desc* recs = (wga_rec_desc*)ws;
   wga_tile_desc* tdesc = (wga_tile_desc*)((char*)ws + rec_bytes);
   u32* const wide_counts = (u32*)((char*)ws + rec_bytes + desc_bytes);
@@ -921,7 +931,9 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
   a.tile_list = nullptr;
   a.n_rec = b->n;
   a.plan = (const u32*)((char*)ws + rec_bytes + desc_bytes + list_bytes);
+  a.job_tiles = c->expand_job_tiles < 1 ? 1u : (c->expand_job_tiles > (int)WGA_S_MAX_JOB_TILES ? WGA_S_MAX_JOB_TILES : (u32)c->expand_job_tiles);
   const bool windows = variant == 2 && !c->expand_ablate; /* the profiling knobs address v1 */
+  const bool stream = variant == 3 && !c->expand_ablate;
   /* when the gap-touching chunks are emitted (RowSrc::drain_min) */
   bool tune_timed = false;
   {
@@ -930,7 +942,7 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
     wga_ctx::DrainTune& T = c->tune;
     if (c->expand_drain_min) {
       dm = c->expand_drain_min;
-    } else if (c->expand_autotune && !windows && !c->expand_dbg && (u64)nt >= WGA_TUNE_MIN_TILES) {
+    } else if (c->expand_autotune && !windows && !stream && !c->expand_dbg && (u64)nt >= WGA_TUNE_MIN_TILES) {
       if (!T.have_ev) {
         const char* e = rt_event_create(&T.ev[0]);
         if (!e && (e = rt_event_create(&T.ev[1]))) rt_event_destroy(T.ev[0]);
@@ -978,9 +990,39 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
                (u64)t_fa_bytes, d_q_fa, (u64)q_fa_bytes, (u32*)a.plan);
     LAUNCH_CHECK();
   }
+  u32* const fast_list = wide_list + nt; /* the second half of the list area: tiles for v1's row emitters */
+  if (stream) { /* part of the pre-pass: the tiles the streaming kernel leaves to v1 (records that are not clean, giant tiles) */
+    u8* const tile_flag = (u8*)ws + rec_bytes + desc_bytes + list_bytes + plan_bytes;
+    RT_CHECK(rt_memset(wide_counts, 0, 256, c->stream));
+    RT_CHECK(rt_memset(tile_flag, 0, flag_bytes, c->stream));
+    WGA_LAUNCH(k_stream_mark_rec, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, b->n, (const wga_rec_desc*)recs,
+               (const u64*)b->d_op_off, tile_flag);
+    LAUNCH_CHECK();
+    WGA_LAUNCH(k_stream_mark_tile, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, tdesc, (u64)nt, (const u8*)tile_flag,
+               c->expand_force_slow, wide_counts, fast_list, wide_list);
+    LAUNCH_CHECK();
+    c->stream_counts = wide_counts;
+  }
   const uint32_t slot = c->ev_n % (uint32_t)wga_ctx::kTimingRing;
   if (c->timing) RT_CHECK(rt_event_record(c->ev[2 * slot], c->stream));
-  if (windows) {
+  if (stream) {
+    const u64 jobs = (nt + a.job_tiles - 1) / a.job_tiles;
+    if (c->expand_alias)
+      WGA_LAUNCH(k_paf2maf_expand_s_alias, (u32)jobs, 128u, c->stream, a);
+    else
+      WGA_LAUNCH(k_paf2maf_expand_s, (u32)jobs, 128u, c->stream, a);
+    LAUNCH_CHECK();
+    const u32 side_grid = nt < 256 ? (u32)nt : 256u;
+    a.tile_count = wide_counts; /* tiles of records that are not clean, tiles beyond 2^24 columns: v1's row emitters */
+    a.tile_list = fast_list;
+    WGA_LAUNCH(k_paf2maf_expand_list, side_grid, WGA_BLOCK, c->stream, a);
+    LAUNCH_CHECK();
+    a.force_slow = 1; /* beyond 2^31 columns (and everything under "expand_force_slow"): the op-serial walk */
+    a.tile_count = wide_counts + 1;
+    a.tile_list = wide_list;
+    WGA_LAUNCH(k_paf2maf_expand_list, side_grid, WGA_BLOCK, c->stream, a);
+    LAUNCH_CHECK();
+  } else if (windows) {
     /* the window kernel; tiles beyond 2^31 columns (and every tile under "expand_force_slow") are listed for v1's op-serial walk */
     if (c->expand_alias)
       WGA_LAUNCH(k_paf2maf_expand_w_alias, (u32)nt, WGA_BLOCK, c->stream, a);
@@ -1024,6 +1066,17 @@ int wga_ctx_get_param(wga_ctx* c, const char* name, int64_t* value) {
   }
   if (strcmp(name, "expand_variant") == 0) {
     *value = (int64_t)c->expand_variant;
+    return WGA_OK;
+  }
+  if (strcmp(name, "expand_stream_left_to_v1") == 0) { /* tiles the streaming kernel's last launch left to v1 (a device read: diagnostics) */
+    *value = 0;
+    if (c->expand_variant_used == 3 && c->stream_counts) {
+      u32 h[2] = {0, 0};
+      int rc = ctx_bind(c);
+      if (rc) return rc;
+      RT_CHECK(rt_d2h(h, c->stream_counts, sizeof(h), c->stream));
+      *value = (int64_t)h[0] + (int64_t)h[1];
+    }
     return WGA_OK;
   }
   if (strcmp(name, "expand_variant_used") == 0) { /* what the last wga_paf2maf_expand ran */

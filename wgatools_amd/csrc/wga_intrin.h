@@ -159,6 +159,59 @@ __device__ __forceinline__ void buf_store16_w(const BufRsrc& r, u32 off, const u
   __builtin_amdgcn_raw_buffer_store_b128(x, r, (int)off, 0, WGA_W_STORE_AUX);
 }
 
+/* ---- LDS-DMA streaming (the streaming row kernel, wga_kernels_k2s.h) ------------------------------------------------
+ * lds_dma16: every active lane copies 16 bytes from gbase + voff (gbase wave-uniform, 16-byte aligned addresses) to the LDS
+ * address lds_dst + 16 * lane (global_load_lds_dwordx4; the destination base travels in M0, saved and restored around the
+ * instruction).  The data lands later — nothing orders an LDS read behind it but this wave's own s_waitcnt vmcnt — and the
+ * instruction is INVISIBLE to the compiler's wait bookkeeping: the kernel counts its vector memory operations itself
+ * (DMAs and the gstore16_nt row stores, one instruction each, in issue order: on gfx9 loads and stores retire in order on
+ * one counter) and waits with vm_wait(k) = "at most k of the operations issued so far are still outstanding".  Operations
+ * the compiler issues on its own (byte stores of partial granules, atomics) are not counted, which only makes a wait
+ * longer than needed, never shorter. */
+__device__ __forceinline__ void lds_dma16(const void* gbase, u32 voff, void* lds_dst) {
+  const u64 gb = WGA_UNI64((u64)gbase);
+  const u32 ld = WGA_UNI32((u32)(u64)lds_dst); /* low half of a generic LDS pointer = the LDS byte address */
+  u32 keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(gb), "s"(ld)
+               : "memory");
+}
+/* the same behind this wave's own LDS reads of the destination (a slot that is refilled right after it was read) */
+__device__ __forceinline__ void lds_dma16_after_reads(const void* gbase, u32 voff, void* lds_dst) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  lds_dma16(gbase, voff, lds_dst);
+}
+/* 16 bytes per lane to base + voff (base wave-uniform), streaming policy, one instruction the kernel counts */
+__device__ __forceinline__ void gstore16_nt(void* base, u32 voff, const u32 v[4]) {
+  const u64 b = WGA_UNI64((u64)base);
+  const u32x4_v x = {v[0], v[1], v[2], v[3]};
+  asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(voff), "v"(x), "s"(b) : "memory");
+}
+__device__ __forceinline__ void vm_wait(u32 k) { /* k wave-uniform */
+  switch (k) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    default: asm volatile("" ::: "memory"); break; /* 16 or more may stay outstanding: nothing to wait for */
+  }
+}
+/* v_bfi_b32: bits of a where mask is set, of b elsewhere */
+__device__ __forceinline__ u32 bfi_b32(u32 mask, u32 a, u32 b) { return (a & mask) | (b & ~mask); }
+
 #endif /* !WGA_EMU */
 
 #endif /* WGA_INTRIN_H */

@@ -1265,6 +1265,7 @@ struct ExpandArgs {
   const u32* tile_list;
   u32 n_rec;    /* records of the batch (op_off has n_rec + 1 entries) */
   const u32* plan; /* window kernel: the prepared pieces of one-segment tiles (k_tile_plan) */
+  u32 job_tiles;   /* streaming kernel: consecutive tiles one wave walks as one stream */
 };
 
 #ifndef WGA_K2_BLOCKS

@@ -1,0 +1,508 @@
+/*
+ * wga_kernels_k2s.h — K2s, the STREAMING row kernel of paf2maf (`expand_variant` 3): the same bytes as v1 (wga_kernels.h)
+ * and the window kernel (wga_kernels_k2w.h), i.e. parse_cigar_to_insert / cigar_unit_insert_seq (cigar.rs:492-551) with
+ * reverse_complement (utils.rs:83-101) fused, written as a stream per wave instead of a block per tile.
+ *
+ * Why another one.  v1 stores granules as they are produced (60 % of the 128-byte lines reach the L2 in two pieces:
+ * 1.4 x the rows written) and the window kernel, which stores whole lines, pays for it with a chain of dependent global
+ * loads per 4 KB window at the occupancy its 128 VGPRs allow (profiles/r03_k2w_experiments.md).  What bounds both is the
+ * latency chain of a tile, not bytes.  Here nothing on a wave's critical path waits for HBM:
+ *   * a wave owns ONE row kind (target or query) of a run of consecutive tiles (a "job") and walks it as a stream;
+ *   * the row's source bytes are brought in by LDS-DMA (global_load_lds_dwordx4) into a per-wave ring of 1 KB chunks,
+ *     several chunks ahead of the columns being written — chunk addresses depend on nothing but how far the stream is,
+ *     so they are issued before the ops that will consume them are even looked at; the ops themselves arrive the same way;
+ *   * output leaves in STEPS: the 64 lanes of the wave write the 64 granules of one 1 KB-aligned kilobyte of the row with
+ *     one streaming store — whole 128-byte lines, once.  A lane assembles its granule in registers from two byte-unaligned
+ *     16-byte LDS reads of the ring ("the source behind the gap that ended before me" | "behind the gap that starts in
+ *     me") under byte masks; which gaps those are comes from a per-step 64-entry histogram of the step's gap events and a
+ *     wave scan.  Granules with more events take a short per-event loop.
+ * Registers: the data path needs ~20; everything that is wave-uniform (positions, ring and record bookkeeping) is scalar.
+ * profiles/r04_micro_stream_dma_copy.txt: the bare mechanism (ring + unaligned reads + aligned stores) runs at the rate of a
+ * plain copy of the same bytes.
+ *
+ * Coordinates.  Within a stream, C counts columns (M = X I D bases) and `cum` the row's gap bases (I for the target row, D
+ * for the query row) over ALL ops since the stream started, across records (u32: a job's tiles hold < 2^24 columns each).
+ * A record segment maps them affinely: column C is byte dst_seg + C of the output; a non-gap column reads the source byte
+ * at pool offset SF + (C - cum)  (forward)  or  SR - (C - cum)  (reverse complement).
+ * The gap events of the row wait in a linear FIFO in LDS (start column, gap bases in front), three sentinels behind.
+ *
+ * What it does NOT do: tiles whose records are not "clean" (a slice longer or shorter than the CIGAR consumes: tails to
+ * append, rows that stop early, String::insert_str panics) and tiles wider than 2^24 columns are marked by a pre-pass
+ * (k_stream_mark_*) and left to v1 (k_paf2maf_expand_list), as the window kernel leaves its giant tiles there.
+ */
+#ifndef WGA_KERNELS_K2S_H
+#define WGA_KERNELS_K2S_H
+
+#include "wga_kernels.h"
+
+#ifndef WGA_S_RING_LOG2
+#define WGA_S_RING_LOG2 13u /* the source ring of a wave: 8 chunks of 1 KB */
+#endif
+#define WGA_S_RING (1u << WGA_S_RING_LOG2)
+#define WGA_S_CHUNKS (WGA_S_RING >> 10)
+#ifndef WGA_S_DEPTH
+#define WGA_S_DEPTH (WGA_S_CHUNKS - 3u) /* chunks on their way behind the one a step needs (a step touches at most 3 chunks; at most 6: the counters of 8 chunks are kept) */
+#endif
+#define WGA_S_FIFO 320u                 /* gap events waiting for their columns to be written (256 of one intake + what is left) */
+#define WGA_S_MAX_TILE_COLS (1ull << 24) /* wider tiles are left to v1 */
+#define WGA_S_MAX_JOB_TILES 32u          /* 32 x 2^24 columns stay below 2^31 */
+#define WGA_S_SKIP 0x100u                /* wga_tile_desc::neg: the streaming kernel leaves this tile to v1 */
+#define WGA_S_WAVE_BYTES (WGA_S_RING + 16u + 1024u + (WGA_S_FIFO + 4u) * 8u + 272u + 16u)
+#ifndef WGA_AUTO_LONG_VARIANT
+#define WGA_AUTO_LONG_VARIANT 0 /* the row kernel of batches of long records when "expand_variant" is -1: 0 = v1, 3 = this one */
+#endif
+
+/* ---- pre-pass: which tiles the streaming kernel leaves to v1 ------------------------------------------------------- */
+/* one thread per record: a record that is not clean (k_rec_desc flags 2 / 4 / 8) marks every tile it has ops in */
+__global__ __launch_bounds__(256) void k_stream_mark_rec(u32 n, const wga_rec_desc* recs, const u64* op_off, u8* tile_flag) {
+  const u32 r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= n) return;
+  if ((recs[r].neg & 0xEull) == 0ull) return;
+  const u64 a = op_off[r], b = op_off[r + 1];
+  if (b <= a) return;
+  for (u64 t = a / WGA_TILE; t <= (b - 1) / WGA_TILE; t++) tile_flag[t] = 1;
+}
+/* one thread per tile: the flag goes into the tile's descriptor; flagged tiles are listed for v1's row emitters, tiles beyond
+ * 2^31 columns for its op-serial walk.  counts[0] / list_fast: v1 fast path, counts[1] / list_slow: op-serial. */
+__global__ __launch_bounds__(256) void k_stream_mark_tile(wga_tile_desc* descs, u64 nt, const u8* tile_flag, int all_slow,
+                                                          u32* counts, u32* list_fast, u32* list_slow) {
+  const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (g >= nt) return;
+  const u64 cols = descs[g].tile_cols;
+  const bool slow = all_slow || cols > WGA_FAST_COL_LIMIT;
+  if (slow || tile_flag[g] || cols > WGA_S_MAX_TILE_COLS) {
+    descs[g].neg |= WGA_S_SKIP;
+    if (slow)
+      list_slow[atomicAdd(&counts[1], 1u)] = (u32)g;
+    else
+      list_fast[atomicAdd(&counts[0], 1u)] = (u32)g;
+  }
+}
+
+/* ---- the stream of one wave ----------------------------------------------------------------------------------------- */
+template <bool QROW>
+__device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, const u32 lane, const u64 t0, const u64 t1) {
+  u8* const ring = lds;                                          /* WGA_S_RING + 16 (the first 16 bytes again) */
+  u32* const s_ops = (u32*)(lds + WGA_S_RING + 16u);             /* 256 ops                                   */
+  u32* const s_fifo = s_ops + 256;                               /* (WGA_S_FIFO + 4) x (start column, cum)    */
+  u32x4_a16* const s_lm = (u32x4_a16*)(s_fifo + 2u * (WGA_S_FIFO + 4u)); /* bytes [0, n) of a granule, n = 0 .. 16 */
+  u64* const s_k = (u64*)(s_lm + 17);                            /* rarely used wave-uniform state: [0] Kseg  */
+  if (lane < 17u) {
+    u32x4_a16 m;
+    for (int d = 0; d < 4; d++) m[d] = bytemask(0, (int)lane - 4 * d);
+    s_lm[lane] = m;
+  }
+  const u8* const fa = QROW ? a.q_fa : a.t_fa;
+  const u64 fa_bytes = QROW ? a.q_fa_bytes : a.t_fa_bytes;
+  const u64 fa_mis = WGA_UNI64((u64)fa & 1023ull);
+  const u8* const P0 = fa - fa_mis;                              /* 1 KB-aligned: chunk j = [P0 + 1024 j, + 1024) */
+  const u64 job_lo = t0 * WGA_TILE;
+  const u32 q_end = WGA_UNI32((u32)((t1 * WGA_TILE < a.n_ops ? t1 * WGA_TILE : a.n_ops) - job_lo)); /* ops of the job */
+
+  /* ---- wave-uniform state (32-bit wherever the job's size allows) ---- */
+  u32 vm = 0;          /* counted vector memory operations issued so far (DMAs, step stores)      */
+  u32 vm_ops_at = 0;   /* vm right behind the DMA of the op chunk that is in s_ops                */
+  u64 vm_at = 0;       /* byte (seq & 7): vm right behind the DMA(s) of source chunk number seq   */
+  u32 C_known = 0, cum_known = 0; /* columns / gap bases of the ops taken in                      */
+  u32 nf = 1;          /* FIFO entries [0, nf), sentinels at nf .. nf + 2; entry 0 lies in front  */
+  u32 e0 = 1;          /* first FIFO entry whose gap starts at or behind pos                      */
+  u32 pos = 0;         /* next column to write                                                    */
+  u32 q = 0;           /* next op to take in (relative to the job's first op; a multiple of 256)  */
+  u32 q_lo = 0, q_hi = 0; /* the ops taken in last                                                */
+  u32 rec = 0, re = 0; /* the record, its last op + 1 (relative to the job, saturated)            */
+  u8* dst_seg = nullptr;     /* byte of column 0 (stream coordinates) of the segment's row       */
+  const u8* src0 = nullptr;  /* source chunk 0 of the segment's stream                            */
+  int S_rel = 0;       /* a non-gap column C reads source byte S_rel +/- (C - cum), relative to src0 */
+  u32 S_ring = 0;      /* ring position of src0's first byte                                      */
+  int hull_a = 0, hull_b = 0; /* the pool's 16-byte hull relative to src0                         */
+  u32 seq_next = 0, seq_last = 0, seq_done = 0; /* source chunks: next to issue, last of the slice, landed */
+  bool rc = false, has_src = false;
+  bool live = false;   /* a stream is under way                                                   */
+  bool bnd = false;    /* a record ends at column C_b (gap bases cum_b in front) of the ops taken in */
+  bool fin = false;    /* write everything known, even a step that does not fill its kilobyte     */
+  u32 C_b = 0, cum_b = 0;
+  u64 t = t0;          /* tile of op q                                                            */
+  u32 l[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0}, xl0 = 0, xg0 = 0; /* the ops taken in last: lengths, gap lengths, prefixes */
+
+  for (;;) {
+    /* ================= write columns: ONE site for the step ================= */
+    {
+      const u32 lim = bnd ? C_b : C_known;
+      const bool all = bnd || fin;
+      while ((int)(lim - pos) > 0) {
+        u8* const A = dst_seg + pos;
+        const u32 mis = (u32)(u64)A & 1023u;
+        u8* const B = A - mis;
+        const u32 room = 1024u - mis;
+        const bool fills = (lim - pos) >= room;
+        if (!all && !fills) break;
+        const u32 Cs = pos, Ce = fills ? pos + room : lim;
+        /* ---- the step: columns [Cs, Ce), all inside the kilobyte of output that starts at B ---- */
+        const u32 Cl0 = Cs - mis; /* column of lane 0's granule (wraps below zero at a stream's start) */
+        const u32 Cl = Cl0 + 16u * lane;
+        int lo = (int)(Cs - Cl), hi = (int)(Ce - Cl);
+        lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
+        hi = hi > 16 ? 16 : (hi < 0 ? 0 : hi);
+        const bool active = hi > lo;
+        /* the step's events: entry e0 + lane; k = the first event that starts in this lane's granule or behind it */
+        u32 k = e0, nE = 0, cumE0 = 0;
+        {
+          u32 base = e0, c;
+          do {
+            const u32 idx = base + lane < nf ? base + lane : nf;
+            const u64 pr = *(const u64*)(s_fifo + 2u * idx);
+            const u32 gsr = (u32)pr - Cl0; /* relative to the step's first granule */
+            if (base == e0) cumE0 = wave_get_u32((u32)(pr >> 32), 0);
+            c = (u32)__popcll(__ballot(gsr < Ce - Cl0));
+            for (u32 e = 0; e < c; e++) k += wave_get_u32_dyn(gsr, e) < 16u * lane ? 1u : 0u;
+            base += c;
+            nE += c;
+          } while (c == 64u);
+        }
+        /* the source this step can touch: make sure it has landed, keep WGA_S_DEPTH chunks behind it on their way */
+        if (has_src) {
+          const int span = (int)(Ce - cumE0);
+          int need = rc ? -((S_rel - span - 16) >> 10) : (S_rel + span + 15) >> 10;
+          need = need < 0 ? 0 : (need > (int)seq_last ? (int)seq_last : need);
+          u32 lim_seq = (u32)need + WGA_S_DEPTH;
+          lim_seq = lim_seq > seq_last ? seq_last : lim_seq;
+          while (seq_next <= lim_seq) {
+            const int rel = rc ? -(int)(seq_next << 10) : (int)(seq_next << 10);
+            const u32 slot = ((S_ring >> 10) + (rc ? 0u - seq_next : seq_next)) & (WGA_S_CHUNKS - 1u);
+            const int lrel = rel + (int)(lane * 16u);
+            if (lrel >= hull_a && lrel < hull_b) lds_dma16(src0 + rel, lane * 16u, ring + slot * 1024u);
+            vm++;
+            if (slot == 0u) { /* windows that start in the last slot read across the end of the ring */
+              if (lane == 0u && rel >= hull_a && rel < hull_b) lds_dma16(src0 + rel, 0u, ring + WGA_S_RING);
+              vm++;
+            }
+            const u32 sh = 8u * (seq_next & 7u);
+            vm_at = (vm_at & ~(0xFFull << sh)) | ((u64)(vm & 0xFFu) << sh);
+            seq_next++;
+          }
+          if ((u32)need >= seq_done) {
+            vm_wait((vm - (u32)(vm_at >> (8u * ((u32)need & 7u)))) & 0xFFu);
+            seq_done = (u32)need + 1u;
+          }
+        }
+        WGA_WAVE_SYNC();
+        const u32x4_a1 ea = *(const u32x4_a1*)(s_fifo + 2u * (k - 1u)); /* events k - 1, k */
+        const u32x4_a1 eb = *(const u32x4_a1*)(s_fifo + 2u * (k + 1u)); /* events k + 1, k + 2 */
+        const u32 gs0 = ea[0], cu0 = ea[1], gs1 = ea[2], cu1 = ea[3], gs2 = eb[0], cu2 = eb[1];
+        /* [lo, a1) the rest of the gap in front | [a1, b1) source behind it | [b1, e1) the gap that starts here | [e1, hi) source */
+        int a1 = (int)(gs0 + (cu1 - cu0) - Cl);
+        a1 = a1 < lo ? lo : (a1 > hi ? hi : a1);
+        int b1 = (int)(gs1 - Cl);
+        b1 = b1 < a1 ? a1 : (b1 > hi ? hi : b1);
+        int e1 = (cu2 - cu1) >= 16u ? 16 : b1 + (int)(cu2 - cu1);
+        e1 = e1 > hi ? hi : e1;
+        bool more = active && (int)(gs2 - Cl) < hi;
+        const u32 S32 = rc ? S_ring + (u32)S_rel - 15u : S_ring + (u32)S_rel;
+        const u32 w0 = rc ? S32 - Cl + cu1 : S32 + Cl - cu1;
+        const u32 w1 = rc ? S32 - Cl + cu2 : S32 + Cl - cu2;
+        const u32x4_a1 W0 = *(const u32x4_a1*)(ring + (w0 & (WGA_S_RING - 1u)));
+        const u32x4_a1 W1 = *(const u32x4_a1*)(ring + (w1 & (WGA_S_RING - 1u)));
+        const u32x4_a16 La = s_lm[a1], Lb = s_lm[b1], Le = s_lm[e1];
+        u32 o[4], bad[4] = {0u, 0u, 0u, 0u};
+        if (rc) {
+#pragma unroll
+          for (int d = 0; d < 4; d++) {
+            const u32 cp = comp4(bfi_b32(Lb[d], bswap32(W0[3 - d]), bswap32(W1[3 - d])), &bad[d]);
+            const u32 md = La[d] | (Le[d] & ~Lb[d]);
+            o[d] = bfi_b32(md, 0x2D2D2D2Du, cp);
+            bad[d] &= ~md;
+          }
+        } else {
+#pragma unroll
+          for (int d = 0; d < 4; d++) {
+            const u32 md = La[d] | (Le[d] & ~Lb[d]);
+            o[d] = bfi_b32(md, 0x2D2D2D2Du, bfi_b32(Lb[d], W0[d], W1[d]));
+          }
+        }
+        /* further events inside the granule: one round per event (rare: gaps are ~150 columns apart) */
+        if (__ballot(more)) {
+          u32 ie = k + 1u;
+          while (__ballot(more)) {
+            if (more) {
+              const u32 gsi = s_fifo[2u * ie], cui = s_fifo[2u * ie + 1u], gsn = s_fifo[2u * ie + 2u], cun = s_fifo[2u * ie + 3u];
+              const int b = (int)(gsi - Cl);
+              const u32 len = cun - cui;
+              const int e = len >= (u32)(hi - b) ? hi : b + (int)len;
+              const u32 w = rc ? S32 - Cl + cun : S32 + Cl - cun;
+              const u32x4_a1 W = *(const u32x4_a1*)(ring + (w & (WGA_S_RING - 1u)));
+              const u32x4_a16 Mb = s_lm[b], Me = s_lm[e];
+#pragma unroll
+              for (int d = 0; d < 4; d++) {
+                u32 x = W[d], bw = 0u;
+                if (rc) x = comp4(bswap32(W[3 - d]), &bw);
+                o[d] = bfi_b32(Mb[d], o[d], bfi_b32(Me[d], 0x2D2D2D2Du, x));
+                bad[d] = (bad[d] & Mb[d]) | (bw & ~Me[d]);
+              }
+              ie++;
+              more = (int)(gsn - Cl) < hi;
+            }
+          }
+        }
+        if (rc) { /* InvalidBase (utils.rs:97): the first offender in reversed order = the smallest slice index */
+          const bool anyb = active && (bad[0] | bad[1] | bad[2] | bad[3]) != 0u;
+          if (__ballot(anyb)) {
+            if (anyb) {
+              const i64 Kseg = (i64)s_k[0];
+              for (int j = lo; j < hi; j++) {
+                const u32 bw = j < 4 ? bad[0] : j < 8 ? bad[1] : j < 12 ? bad[2] : bad[3];
+                if (((bw >> (8 * (j & 3))) & 0xFFu) == 0u) continue;
+                const u32 cj = Cl + (u32)j;
+                u32 i = k - 1u; /* last event that starts at or before column cj */
+                while (i + 1u < nf && (int)(s_fifo[2u * (i + 1u)] - cj) <= 0) i++;
+                const u32 adj = s_fifo[2u * (i + 1u) + 1u];
+                atomicMin((u64*)&a.diag[rec].bad_base_pos, (u64)((i64)(u64)(cj - adj) + Kseg));
+              }
+            }
+          }
+        }
+        /* whole granules: one streaming store of the wave; the (at most two) partial ones: byte stores, never read-modify-write */
+        const bool whole = lo == 0 && hi == 16;
+        if (__ballot(whole)) {
+          if (whole) gstore16_nt(B, lane * 16u, o);
+          vm++;
+        }
+        if (active && !whole) {
+          u8* const p = B + lane * 16u;
+#pragma clang loop vectorize(disable) unroll(disable)
+          for (int j = lo; j < hi; j++) {
+            const u32 wj = j < 4 ? o[0] : j < 8 ? o[1] : j < 12 ? o[2] : o[3];
+            p[j] = (u8)(wj >> (8 * (j & 3)));
+          }
+        }
+        e0 += nE;
+        pos = Ce;
+      }
+      fin = false;
+    }
+
+    /* ================= a record ended: the next one starts at column C_b ================= */
+    if (bnd || !live) {
+      const bool sw = bnd; /* a switch to the next record (otherwise: a stream starts) */
+      u64 row_off, src_off, src_len, x_a, sb;
+      bool neg;
+      u32 C_a, cum_a;
+      if (bnd) {
+        const u64 bnd_op = job_lo + re;
+        u64 ren;
+        do { /* records without ops have no rows here (v1 walks past them as well) */
+          rec++;
+          ren = WGA_UNI64(a.op_off[rec + 1]);
+        } while (ren <= bnd_op);
+        re = ren - job_lo > (u64)q_end ? q_end : (u32)(ren - job_lo);
+        const wga_rec_desc* const rd = a.recs + rec;
+        row_off = WGA_UNI64(QROW ? rd->q_row_off : rd->t_row_off);
+        src_off = WGA_UNI64(QROW ? rd->q_src_off : rd->t_src_off);
+        src_len = WGA_UNI64(QROW ? rd->q_src_len : rd->t_src_len);
+        neg = (WGA_UNI64(rd->neg) & 1ull) != 0ull;
+        x_a = 0;
+        sb = 0;
+        C_a = C_b;
+        cum_a = cum_b;
+      } else {
+        /* (re)start: the next tile that is this kernel's */
+        while (t < t1 && (WGA_UNI32(a.tdesc[t].neg) & WGA_S_SKIP)) t++;
+        if (t >= t1) break;
+        const wga_tile_desc* const td = a.tdesc + t;
+        const u64 tile_start = t * WGA_TILE;
+        q = (u32)(tile_start - job_lo);
+        vm_wait(0u);
+        WGA_WAVE_SYNC();
+        C_known = cum_known = 0u;
+        pos = 0u;
+        nf = 1u;
+        e0 = 1u;
+        if (lane < 4u) {
+          s_fifo[2u * lane] = 0u;
+          s_fifo[2u * lane + 1u] = 0u;
+        }
+        rec = WGA_UNI32(td->rec);
+        const u64 ren = WGA_UNI64(td->re), rs = WGA_UNI64(td->rs);
+        re = ren - job_lo > (u64)q_end ? q_end : (u32)(ren - job_lo);
+        const bool cont = rs < tile_start; /* the record began in an earlier tile */
+        const u64 b_mx = cont ? WGA_UNI64(td->b_mx) : 0ull, b_i = cont ? WGA_UNI64(td->b_i) : 0ull,
+                  b_d = cont ? WGA_UNI64(td->b_d) : 0ull;
+        row_off = WGA_UNI64(QROW ? td->q_row_off : td->t_row_off);
+        src_off = WGA_UNI64(QROW ? td->q_src_off : td->t_src_off);
+        src_len = WGA_UNI64(QROW ? td->q_src_len : td->t_src_len);
+        neg = (WGA_UNI32(td->neg) & 1u) != 0u;
+        x_a = b_mx + b_i + b_d;
+        sb = QROW ? b_mx + b_i : b_mx + b_d;
+        C_a = cum_a = 0u;
+        { /* the first 256 ops */
+          const u64 left = a.n_ops - tile_start;
+          if (left >= 256ull || (u64)(lane * 4u) < left) lds_dma16_after_reads(a.ops + tile_start, lane * 16u, s_ops);
+          vm++;
+          vm_ops_at = vm;
+        }
+        live = true;
+      }
+      /* the segment: column C_a (cum_a gap bases in front) is column x_a of the record's row, sb bases of its slice used */
+      dst_seg = a.out + row_off + x_a - (u64)C_a;
+      rc = QROW && neg;
+      const int adv = (int)(C_a - cum_a); /* (C - cum) at the segment's start */
+      const u64 first = fa_mis + src_off + (rc ? src_len - 1ull - sb : sb); /* pool offset (from P0) of the first source byte */
+      const u64 j0 = first >> 10;
+      src0 = P0 + (j0 << 10);
+      S_ring = ((u32)j0 & (WGA_S_CHUNKS - 1u)) << 10;
+      S_rel = rc ? (int)((u32)first & 1023u) + adv : (int)((u32)first & 1023u) - adv;
+      has_src = src_len > sb;
+      {
+        const u64 last = rc ? fa_mis + src_off : fa_mis + src_off + src_len - 1ull;
+        const u64 nseq = rc ? j0 - (last >> 10) : (last >> 10) - j0;
+        seq_last = has_src ? (nseq > 0x100000ull ? 0x100000u : (u32)nseq) : 0u; /* a job never walks 2^20 chunks */
+        const i64 ha = (i64)(fa_mis & ~15ull) - (i64)(j0 << 10), hb = (i64)((fa_mis + fa_bytes + 15ull) & ~15ull) - (i64)(j0 << 10);
+        hull_a = ha < -0x40000000ll ? -0x40000000 : (int)ha;
+        hull_b = hb > 0x40000000ll ? 0x40000000 : (int)hb;
+      }
+      if (lane == 0u) s_k[0] = (u64)((i64)sb - (i64)adv);
+      vm_wait(0u); /* the old stream's chunks must not land on top of the new one's */
+      WGA_WAVE_SYNC();
+      seq_next = 0u;
+      seq_done = 0u;
+      /* the next boundary among the ops that are in (none right after a start) */
+      bnd = false;
+      if (sw && re < q_hi) {
+        const u32 kb = re - q_lo, e = kb & 3u;
+        const u32 vl = xl0 + (e > 0u ? l[0] : 0u) + (e > 1u ? l[1] : 0u) + (e > 2u ? l[2] : 0u);
+        const u32 vg = xg0 + (e > 0u ? g[0] : 0u) + (e > 1u ? g[1] : 0u) + (e > 2u ? g[2] : 0u);
+        C_b = wave_get_u32_dyn(vl, kb >> 2);
+        cum_b = wave_get_u32_dyn(vg, kb >> 2);
+        bnd = true;
+      }
+      continue;
+    }
+
+    /* ================= everything that is in has been written as far as it may: take more ops in ================= */
+    if (q >= q_end) { /* the job ends: the last, partial kilobyte */
+      if (pos != C_known) {
+        fin = true;
+        continue;
+      }
+      break;
+    }
+    if ((q & (WGA_TILE - 1u)) == 0u) { /* a tile border: is the next tile this kernel's? */
+      t = (job_lo + q) / WGA_TILE;
+      if (WGA_UNI32(a.tdesc[t].neg) & WGA_S_SKIP) { /* v1's: finish what is under way, start again behind it */
+        if (pos != C_known) {
+          fin = true;
+          continue;
+        }
+        live = false;
+        t++;
+        continue;
+      }
+    }
+    /* room for 256 more events */
+    if (e0 > 1u) { /* the FIFO's live entries (from the last gap in front of pos) move to its start */
+      const u32 from = e0 - 1u, count = nf + 3u - from;
+      for (u32 i0 = 0; i0 < count; i0 += 64u) {
+        const u32 i = i0 + lane;
+        u64 v = 0;
+        if (i < count) v = *(const u64*)(s_fifo + 2u * (from + i));
+        WGA_WAVE_SYNC();
+        if (i < count) *(u64*)(s_fifo + 2u * i) = v;
+        WGA_WAVE_SYNC();
+      }
+      nf -= from;
+      e0 = 1u;
+    }
+    if (nf + 256u > WGA_S_FIFO) { /* dense gaps: write what is known (a partial kilobyte) so that the FIFO drains */
+      fin = true;
+      if (pos != C_known) continue;
+      fin = false;
+    }
+    /* ---- take 256 ops in ---- */
+    q_lo = q;
+    q_hi = q + 256u < q_end ? q + 256u : q_end;
+    q = q_hi;
+    vm_wait((vm - vm_ops_at) & 0xFFu);
+    WGA_WAVE_SYNC();
+    const u32x4_a16 ow = *(const u32x4_a16*)(s_ops + 4u * lane);
+    WGA_WAVE_SYNC();
+    if (q_hi < q_end) { /* the next 256 travel while these are worked on */
+      const u64 qa = job_lo + q_hi, left = a.n_ops - qa;
+      if (left >= 256ull || (u64)(lane * 4u) < left) lds_dma16_after_reads(a.ops + qa, lane * 16u, s_ops);
+      vm++;
+      vm_ops_at = vm;
+    }
+    u32 sl = 0, sg = 0, sc = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const bool valid = q_lo + 4u * lane + (u32)e < q_hi;
+      const u32 len = ow[e] >> 4, cls = op_class(ow[e] & 15u);
+      l[e] = (valid && cls <= CLS_D) ? len : 0u;
+      g[e] = (valid && cls == (QROW ? CLS_D : CLS_I)) ? len : 0u;
+      sl += l[e];
+      sg += g[e];
+      sc += g[e] != 0u ? 1u : 0u;
+    }
+    const u32 il = wave_incl_scan_u32(sl), ig = wave_incl_scan_u32(sg), ic = wave_incl_scan_u32(sc);
+    xl0 = C_known + il - sl;
+    xg0 = cum_known + ig - sg;
+    {
+      u32 xl = xl0, xg = xg0, xc = nf + ic - sc;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        if (g[e] != 0u) {
+          s_fifo[2u * xc] = xl;
+          s_fifo[2u * xc + 1u] = xg;
+          xc++;
+          xg += g[e];
+        }
+        xl += l[e];
+      }
+    }
+    C_known += wave_last_u32(il);
+    cum_known += wave_last_u32(ig);
+    nf += wave_last_u32(ic);
+    if (lane < 3u) {
+      s_fifo[2u * (nf + lane)] = C_known;
+      s_fifo[2u * (nf + lane) + 1u] = cum_known;
+    }
+    WGA_WAVE_SYNC();
+    if (re < q_hi) { /* a record ends among these ops */
+      const u32 kb = re - q_lo, e = kb & 3u;
+      const u32 vl = xl0 + (e > 0u ? l[0] : 0u) + (e > 1u ? l[1] : 0u) + (e > 2u ? l[2] : 0u);
+      const u32 vg = xg0 + (e > 0u ? g[0] : 0u) + (e > 1u ? g[1] : 0u) + (e > 2u ? g[2] : 0u);
+      C_b = wave_get_u32_dyn(vl, kb >> 2);
+      cum_b = wave_get_u32_dyn(vg, kb >> 2);
+      bnd = true;
+    }
+  }
+  vm_wait(0u);
+}
+
+/* job -> XCD: blocks go to the 8 XCDs round robin; every XCD works through one contiguous eighth of the jobs (shared output
+ * lines and neighbouring source chunks meet in one L2), as v1's tiles do */
+__device__ __forceinline__ u64 xcd_job_of_block() {
+  const u32 nb = gridDim.x, b = blockIdx.x, x = b & 7u, q = nb >> 3, r = nb & 7u;
+  return (u64)(x * q + (x < r ? x : r) + (b >> 3));
+}
+
+/* one block = two waves = the target row and the query row of one job of `job_tiles` consecutive tiles */
+__device__ __forceinline__ void expand_stream(const ExpandArgs& a) {
+  __shared__ u32x4_a16 s_mem[2u * WGA_S_WAVE_BYTES / 16u];
+  const u32 lane = threadIdx.x & 63u, wave = WGA_WAVE_ID(threadIdx.x);
+  const u64 nt = (a.n_ops + WGA_TILE - 1) / WGA_TILE;
+  const u64 job = xcd_job_of_block();
+  const u64 t0 = job * a.job_tiles;
+  if (t0 >= nt) return;
+  const u64 t1 = t0 + a.job_tiles < nt ? t0 + a.job_tiles : nt;
+  u8* const lds = (u8*)s_mem + wave * WGA_S_WAVE_BYTES;
+  if (wave == 0u)
+    stream_row<false>(a, lds, lane, t0, t1);
+  else
+    stream_row<true>(a, lds, lane, t0, t1);
+}
+#ifndef WGA_S_WAVES_PER_SIMD
+#define WGA_S_WAVES_PER_SIMD 2 /* launch bound (waves per SIMD the register budget is sized for; LDS allows ~11 waves per CU) */
+#endif
+__global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_paf2maf_expand_s(ExpandArgs a) { expand_stream(a); }
+__global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_paf2maf_expand_s_alias(ExpandArgs a) { expand_stream(a); }
+
+#endif
