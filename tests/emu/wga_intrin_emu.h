@@ -23,6 +23,18 @@ __device__ __forceinline__ u32 wave_incl_scan_u32(u32 v) {
   }
   return v;
 }
+__device__ __forceinline__ u32 wave_incl_scan_max_u32(u32 v) {
+  const u32 lane = threadIdx.x & 63u;
+  for (u32 d = 1; d < 64; d <<= 1) {
+    u32 t = __shfl_up(v, d);
+    if (lane >= d && t > v) v = t;
+  }
+  return v;
+}
+__device__ __forceinline__ u32 wave_shr1_u32(u32 v, u32 fill) {
+  const u32 t = __shfl_up(v, 1u);
+  return (threadIdx.x & 63u) == 0u ? fill : t;
+}
 __device__ __forceinline__ u32 wave_last_u32(u32 incl) { return __shfl(incl, 63); }
 template <u32 K>
 __device__ __forceinline__ u64 lane_put_u64(u64 v, u64 uniform_val, u32 lane) {

@@ -51,6 +51,20 @@ __device__ __forceinline__ u32 wave_incl_scan_u32(u32 v) {
   v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); /* row_bcast:31 */
   return v;
 }
+/* the same with max instead of +, and the value of the lane in front (lane 0: `fill`): wave_shr:1 */
+__device__ __forceinline__ u32 wave_incl_scan_max_u32(u32 v) {
+  u32 t;
+  t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); v = v > t ? v : t;
+  t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false); v = v > t ? v : t;
+  t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false); v = v > t ? v : t;
+  t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); v = v > t ? v : t;
+  t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); v = v > t ? v : t;
+  t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); v = v > t ? v : t;
+  return v;
+}
+__device__ __forceinline__ u32 wave_shr1_u32(u32 v, u32 fill) {
+  return (u32)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
+}
 /* value of lane 63 of an inclusive scan = the wave total (uniform) */
 __device__ __forceinline__ u32 wave_last_u32(u32 incl) { return (u32)__builtin_amdgcn_readlane((int)incl, 63); }
 /* v with lane K's copy replaced by a wave-uniform value (v_writelane_b32 x 2; this clang has no builtin for it) */

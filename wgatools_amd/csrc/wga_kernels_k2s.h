@@ -47,7 +47,8 @@
 #define WGA_S_MAX_TILE_COLS (1ull << 24) /* wider tiles are left to v1 */
 #define WGA_S_MAX_JOB_TILES 32u          /* 32 x 2^24 columns stay below 2^31 */
 #define WGA_S_SKIP 0x100u                /* wga_tile_desc::neg: the streaming kernel leaves this tile to v1 */
-#define WGA_S_WAVE_BYTES (WGA_S_RING + 16u + 1024u + (WGA_S_FIFO + 4u) * 8u + 272u + 16u)
+#define WGA_S_U 4u /* kilobytes of a row one super-step writes: the queued granules of that many share one round of the merge code */
+#define WGA_S_WAVE_BYTES (WGA_S_RING + 16u + 1024u + (WGA_S_FIFO + 4u) * 8u + 1024u + 1024u + 272u + 16u)
 #ifndef WGA_AUTO_LONG_VARIANT
 #define WGA_AUTO_LONG_VARIANT 0 /* the row kernel of batches of long records when "expand_variant" is -1: 0 = v1, 3 = this one */
 #endif
@@ -79,13 +80,50 @@ __global__ __launch_bounds__(256) void k_stream_mark_tile(wga_tile_desc* descs, 
   }
 }
 
+/* ---- rare paths kept out of line (the kernel's hot loop has to stay small: it runs at the instruction issue rate) ---- */
+#ifdef WGA_EMU
+#define WGA_S_NOINLINE
+#else
+#define WGA_S_NOINLINE __attribute__((noinline))
+#endif
+/* bytes [lo, hi) of a granule: byte stores, never read-modify-write */
+__device__ WGA_S_NOINLINE void stream_store_bytes(u8* p, u32 o0, u32 o1, u32 o2, u32 o3, int lo, int hi) {
+#pragma clang loop vectorize(disable) unroll(disable)
+  for (int j = lo; j < hi; j++) {
+    const u32 wj = j < 4 ? o0 : j < 8 ? o1 : j < 12 ? o2 : o3;
+    p[j] = (u8)(wj >> (8 * (j & 3)));
+  }
+}
+/* InvalidBase (utils.rs:97) in bytes [lo, hi) of the granule at column Cl: the first offender in reversed order = the smallest
+ * slice index wins.  fifo == NULL: a plain granule, every byte reads the source with `adj` gap bases in front; otherwise the
+ * events from k - 1 on are walked for each flagged byte. */
+__device__ WGA_S_NOINLINE void stream_report_bad(u64* bad_base_pos, u32 b0, u32 b1, u32 b2, u32 b3, int lo, int hi, u32 Cl,
+                                                 i64 Kseg, const u32* fifo, u32 k, u32 nf, u32 adj) {
+#pragma clang loop vectorize(disable) unroll(disable)
+  for (int j = lo; j < hi; j++) {
+    const u32 bw = j < 4 ? b0 : j < 8 ? b1 : j < 12 ? b2 : b3;
+    if (((bw >> (8 * (j & 3))) & 0xFFu) == 0u) continue;
+    const u32 cj = Cl + (u32)j;
+    u32 ad = adj;
+    if (fifo) {
+      u32 i = k - 1u; /* last event that starts at or before column cj */
+      while (i + 1u < nf && (int)(fifo[2u * (i + 1u)] - cj) <= 0) i++;
+      ad = fifo[2u * (i + 1u) + 1u];
+    }
+    atomicMin(bad_base_pos, (u64)((i64)(u64)(cj - ad) + Kseg));
+  }
+}
+
 /* ---- the stream of one wave ----------------------------------------------------------------------------------------- */
 template <bool QROW>
 __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, const u32 lane, const u64 t0, const u64 t1) {
   u8* const ring = lds;                                          /* WGA_S_RING + 16 (the first 16 bytes again) */
   u32* const s_ops = (u32*)(lds + WGA_S_RING + 16u);             /* 256 ops                                   */
   u32* const s_fifo = s_ops + 256;                               /* (WGA_S_FIFO + 4) x (start column, cum)    */
-  u32x4_a16* const s_lm = (u32x4_a16*)(s_fifo + 2u * (WGA_S_FIFO + 4u)); /* bytes [0, n) of a granule, n = 0 .. 16 */
+  u32* const s_T = s_fifo + 2u * (WGA_S_FIFO + 4u);               /* 256 granules of a super-step: last event in each */
+  u32x4_a16* const s_P = (u32x4_a16*)s_T;                        /* ... later: 64 granules put together by the queue's lanes */
+  u32* const s_q = s_T + 256;                                    /* the queue: (event index, granule) of up to 256 granules */
+  u32x4_a16* const s_lm = (u32x4_a16*)(s_q + 256);               /* bytes [0, n) of a granule, n = 0 .. 16    */
   u64* const s_k = (u64*)(s_lm + 17);                            /* rarely used wave-uniform state: [0] Kseg  */
   if (lane < 17u) {
     u32x4_a16 m;
@@ -125,7 +163,7 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
   u32 l[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0}, xl0 = 0, xg0 = 0; /* the ops taken in last: lengths, gap lengths, prefixes */
 
   for (;;) {
-    /* ================= write columns: ONE site for the step ================= */
+    /* ================= write columns: ONE site for the super-step ================= */
     {
       const u32 lim = bnd ? C_b : C_known;
       const bool all = bnd || fin;
@@ -133,97 +171,166 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
         u8* const A = dst_seg + pos;
         const u32 mis = (u32)(u64)A & 1023u;
         u8* const B = A - mis;
-        const u32 room = 1024u - mis;
-        const bool fills = (lim - pos) >= room;
-        if (!all && !fills) break;
-        const u32 Cs = pos, Ce = fills ? pos + room : lim;
-        /* ---- the step: columns [Cs, Ce), all inside the kilobyte of output that starts at B ---- */
-        const u32 Cl0 = Cs - mis; /* column of lane 0's granule (wraps below zero at a stream's start) */
-        const u32 Cl = Cl0 + 16u * lane;
-        int lo = (int)(Cs - Cl), hi = (int)(Ce - Cl);
-        lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
-        hi = hi > 16 ? 16 : (hi < 0 ? 0 : hi);
-        const bool active = hi > lo;
-        /* the step's events: entry e0 + lane; k = the first event that starts in this lane's granule or behind it */
-        u32 k = e0, nE = 0, cumE0 = 0;
+        const u32 room = WGA_S_U * 1024u - mis;
+        if (!all && (lim - pos) < room) break;
+        const u32 Cs = pos, Ce = (lim - pos) < room ? lim : pos + room;
+        const u32 Cl0 = Cs - mis; /* column of the first granule of the kilobyte Cs lies in (wraps below zero at a stream's start) */
+        const u32 nu = (mis + (Ce - Cs) + 1023u) >> 10; /* kilobytes (sub-steps) this super-step touches: 1 .. WGA_S_U */
+        const u32 S32 = rc ? S_ring + (u32)S_rel - 15u : S_ring + (u32)S_rel;
+
+        /* ---- (1) the super-step's events: T[granule] = the last event that starts in it (0: none) ---- */
+        {
+          const u32x4_a16 z = {0u, 0u, 0u, 0u};
+          *(u32x4_a16*)(s_T + 4u * lane) = z;
+        }
+        WGA_WAVE_SYNC();
+        u32 nE = 0;
         {
           u32 base = e0, c;
           do {
             const u32 idx = base + lane < nf ? base + lane : nf;
-            const u64 pr = *(const u64*)(s_fifo + 2u * idx);
-            const u32 gsr = (u32)pr - Cl0; /* relative to the step's first granule */
-            if (base == e0) cumE0 = wave_get_u32((u32)(pr >> 32), 0);
-            c = (u32)__popcll(__ballot(gsr < Ce - Cl0));
-            for (u32 e = 0; e < c; e++) k += wave_get_u32_dyn(gsr, e) < 16u * lane ? 1u : 0u;
+            const u32 gsr = s_fifo[2u * idx] - Cl0;
+            const bool in = gsr < Ce - Cl0;
+            c = (u32)__popcll(__ballot(in));
+            if (in) atomicMax(&s_T[((gsr >> 4) & 63u) << 2 | (gsr >> 10)], idx); /* lane l reads its WGA_S_U granules as one vector */
             base += c;
             nE += c;
           } while (c == 64u);
         }
-        /* the source this step can touch: make sure it has landed, keep WGA_S_DEPTH chunks behind it on their way */
-        if (has_src) {
-          const int span = (int)(Ce - cumE0);
-          int need = rc ? -((S_rel - span - 16) >> 10) : (S_rel + span + 15) >> 10;
-          need = need < 0 ? 0 : (need > (int)seq_last ? (int)seq_last : need);
-          u32 lim_seq = (u32)need + WGA_S_DEPTH;
-          lim_seq = lim_seq > seq_last ? seq_last : lim_seq;
-          while (seq_next <= lim_seq) {
-            const int rel = rc ? -(int)(seq_next << 10) : (int)(seq_next << 10);
-            const u32 slot = ((S_ring >> 10) + (rc ? 0u - seq_next : seq_next)) & (WGA_S_CHUNKS - 1u);
-            const int lrel = rel + (int)(lane * 16u);
-            if (lrel >= hull_a && lrel < hull_b) lds_dma16(src0 + rel, lane * 16u, ring + slot * 1024u);
-            vm++;
-            if (slot == 0u) { /* windows that start in the last slot read across the end of the ring */
-              if (lane == 0u && rel >= hull_a && rel < hull_b) lds_dma16(src0 + rel, 0u, ring + WGA_S_RING);
-              vm++;
-            }
-            const u32 sh = 8u * (seq_next & 7u);
-            vm_at = (vm_at & ~(0xFFull << sh)) | ((u64)(vm & 0xFFu) << sh);
-            seq_next++;
-          }
-          if ((u32)need >= seq_done) {
-            vm_wait((vm - (u32)(vm_at >> (8u * ((u32)need & 7u)))) & 0xFFu);
-            seq_done = (u32)need + 1u;
-          }
-        }
         WGA_WAVE_SYNC();
-        const u32x4_a1 ea = *(const u32x4_a1*)(s_fifo + 2u * (k - 1u)); /* events k - 1, k */
-        const u32x4_a1 eb = *(const u32x4_a1*)(s_fifo + 2u * (k + 1u)); /* events k + 1, k + 2 */
-        const u32 gs0 = ea[0], cu0 = ea[1], gs1 = ea[2], cu1 = ea[3], gs2 = eb[0], cu2 = eb[1];
-        /* [lo, a1) the rest of the gap in front | [a1, b1) source behind it | [b1, e1) the gap that starts here | [e1, hi) source */
-        int a1 = (int)(gs0 + (cu1 - cu0) - Cl);
-        a1 = a1 < lo ? lo : (a1 > hi ? hi : a1);
-        int b1 = (int)(gs1 - Cl);
-        b1 = b1 < a1 ? a1 : (b1 > hi ? hi : b1);
-        int e1 = (cu2 - cu1) >= 16u ? 16 : b1 + (int)(cu2 - cu1);
-        e1 = e1 > hi ? hi : e1;
-        bool more = active && (int)(gs2 - Cl) < hi;
-        const u32 S32 = rc ? S_ring + (u32)S_rel - 15u : S_ring + (u32)S_rel;
-        const u32 w0 = rc ? S32 - Cl + cu1 : S32 + Cl - cu1;
-        const u32 w1 = rc ? S32 - Cl + cu2 : S32 + Cl - cu2;
-        const u32x4_a1 W0 = *(const u32x4_a1*)(ring + (w0 & (WGA_S_RING - 1u)));
-        const u32x4_a1 W1 = *(const u32x4_a1*)(ring + (w1 & (WGA_S_RING - 1u)));
-        const u32x4_a16 La = s_lm[a1], Lb = s_lm[b1], Le = s_lm[e1];
-        u32 o[4], bad[4] = {0u, 0u, 0u, 0u};
-        if (rc) {
+        const u32x4_a16 tv = *(const u32x4_a16*)(s_T + 4u * lane);
+        WGA_WAVE_SYNC(); /* T becomes the patch buffer below */
+
+        /* ---- (2) every lane's granule of every kilobyte: the plain case at once, the rest queued ---- */
+        u32 carry = e0 - 1u; /* the last event that starts in front of the sub-step */
+        u32 qn = 0, rpk = 0, flg = 0;
+        u32 dat[WGA_S_U][4];
 #pragma unroll
-          for (int d = 0; d < 4; d++) {
-            const u32 cp = comp4(bfi_b32(Lb[d], bswap32(W0[3 - d]), bswap32(W1[3 - d])), &bad[d]);
-            const u32 md = La[d] | (Le[d] & ~Lb[d]);
-            o[d] = bfi_b32(md, 0x2D2D2D2Du, cp);
-            bad[d] &= ~md;
-          }
-        } else {
+        for (u32 u = 0; u < WGA_S_U; u++) {
+          if (u < nu) {
+            const u32 Cu = Cl0 + 1024u * u; /* columns [Cu, Cu + 1024) ∩ [Cs, Ce) */
+            if (has_src) {
+              const u32 cumA = WGA_UNI32(s_fifo[2u * (carry + 1u) + 1u]); /* gap bases in front of the first event at / behind Cu */
+              if (u == 0u) {
+                /* Chunks travel only between super-steps: the queued granules of ALL kilobytes read the ring at the end.  What
+                 * the columns in front of Cs have consumed is exact (a gap that straddles Cs counts with its part in front). */
+                const u32 g0 = WGA_UNI32(s_fifo[2u * carry]), c0 = WGA_UNI32(s_fifo[2u * carry + 1u]);
+                const int over = (int)(g0 + (cumA - c0) - Cs);
+                const int cons = (int)(Cs - cumA) + (over > 0 ? over : 0);
+                int cs = rc ? -((S_rel - cons) >> 10) : (S_rel + cons) >> 10;
+                cs = cs < 0 ? 0 : cs;
+                u32 lim_seq = (u32)cs + WGA_S_CHUNKS - 1u;
+                lim_seq = lim_seq > seq_last ? seq_last : lim_seq;
+                while (seq_next <= lim_seq) {
+                  const int rel = rc ? -(int)(seq_next << 10) : (int)(seq_next << 10);
+                  const u32 slot = ((S_ring >> 10) + (rc ? 0u - seq_next : seq_next)) & (WGA_S_CHUNKS - 1u);
+                  const int lrel = rel + (int)(lane * 16u);
+                  if (lrel >= hull_a && lrel < hull_b) lds_dma16_after_reads(src0 + rel, lane * 16u, ring + slot * 1024u);
+                  vm++;
+                  if (slot == 0u) { /* windows that start in the last slot read across the end of the ring */
+                    if (lane == 0u && rel >= hull_a && rel < hull_b) lds_dma16(src0 + rel, 0u, ring + WGA_S_RING);
+                    vm++;
+                  }
+                  const u32 sh = 8u * (seq_next & 7u);
+                  vm_at = (vm_at & ~(0xFFull << sh)) | ((u64)(vm & 0xFFu) << sh);
+                  seq_next++;
+                }
+              }
+              /* what this kilobyte reads must have landed */
+              const u32 c_hi = (int)(Cu + 1024u - Ce) > 0 ? Ce : Cu + 1024u;
+              int need = rc ? -((S_rel - (int)(c_hi - cumA) - 16) >> 10) : (S_rel + (int)(c_hi - cumA) + 15) >> 10;
+              need = need < 0 ? 0 : (need > (int)seq_last ? (int)seq_last : need);
+              if ((u32)need >= seq_done) {
+                vm_wait((vm - (u32)(vm_at >> (8u * ((u32)need & 7u)))) & 0xFFu);
+                seq_done = (u32)need + 1u;
+              }
+              WGA_WAVE_SYNC();
+            }
+            const u32 v = tv[u];
+            const u32 inc = wave_incl_scan_max_u32(v);
+            const u32 prv = wave_shr1_u32(inc, 0u);
+            const u32 k = (prv > carry ? prv : carry) + 1u; /* the first event that starts in this granule or behind it */
+            const u32 top = wave_last_u32(inc);
+            carry = top > carry ? top : carry;
+            const u32 Cl = Cu + 16u * lane;
+            int lo = (int)(Cs - Cl), hi = (int)(Ce - Cl);
+            lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
+            hi = hi > 16 ? 16 : (hi < 0 ? 0 : hi);
+            const bool active = hi > lo, whole = lo == 0 && hi == 16;
+            const u32x4_a1 fe = *(const u32x4_a1*)(s_fifo + 2u * (k - 1u)); /* events k - 1, k: start, gap bases in front */
+            const int rel0 = (int)(fe[0] + (fe[3] - fe[1]) - Cl); /* how far the gap in front reaches into the granule */
+            const bool flagged = active && (v != 0u || (rel0 > 0 && rel0 < 16) || !whole);
+            const u32 w = rc ? S32 - Cl + fe[3] : S32 + Cl - fe[3];
+            const u32x4_a1 W = *(const u32x4_a1*)(ring + (w & (WGA_S_RING - 1u)));
+            u32 bad[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-          for (int d = 0; d < 4; d++) {
-            const u32 md = La[d] | (Le[d] & ~Lb[d]);
-            o[d] = bfi_b32(md, 0x2D2D2D2Du, bfi_b32(Lb[d], W0[d], W1[d]));
+            for (int d = 0; d < 4; d++) {
+              u32 x = W[d];
+              if (rc) x = comp4(bswap32(W[3 - d]), &bad[d]);
+              dat[u][d] = rel0 >= 16 ? 0x2D2D2D2Du : x;
+            }
+            if (rc) { /* InvalidBase in a plain granule (utils.rs:97); queued granules are checked where they are put together */
+              const bool pb = active && !flagged && rel0 < 16 && (bad[0] | bad[1] | bad[2] | bad[3]) != 0u;
+              if (__ballot(pb)) {
+                if (pb)
+                  stream_report_bad((u64*)&a.diag[rec].bad_base_pos, bad[0], bad[1], bad[2], bad[3], 0, 16, Cl, (i64)s_k[0], nullptr, 0u,
+                                    0u, fe[3]);
+              }
+            }
+            const u64 m = __ballot(flagged);
+            if (m) {
+              const u32 r = qn + lane_rank(m, lane);
+              if (flagged) {
+                s_q[r] = (k << 8) | (u << 6) | lane;
+                rpk |= r << (8u * u);
+                flg |= 1u << u;
+              }
+              qn += (u32)__popcll(m);
+            }
+            flg |= (active && whole ? 16u : 0u) << u;
+            flg |= (active && !whole ? 256u : 0u) << u;
           }
         }
-        /* further events inside the granule: one round per event (rare: gaps are ~150 columns apart) */
-        if (__ballot(more)) {
-          u32 ie = k + 1u;
-          while (__ballot(more)) {
-            if (more) {
+
+        /* ---- (3) the queued granules, 64 at a time: put together from two windows under byte masks, handed back through LDS ---- */
+        for (u32 r0 = 0; r0 < qn; r0 += 64u) {
+          WGA_WAVE_SYNC();
+          if (r0 + lane < qn) {
+            const u32 ent = s_q[r0 + lane];
+            const u32 k = ent >> 8, Cl = Cl0 + 16u * (ent & 255u);
+            int lo = (int)(Cs - Cl), hi = (int)(Ce - Cl);
+            lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
+            hi = hi > 16 ? 16 : (hi < 0 ? 0 : hi);
+            const u32x4_a1 ea = *(const u32x4_a1*)(s_fifo + 2u * (k - 1u)); /* events k - 1, k */
+            const u32x4_a1 eb = *(const u32x4_a1*)(s_fifo + 2u * (k + 1u)); /* events k + 1, k + 2 */
+            const u32 gs0 = ea[0], cu0 = ea[1], gs1 = ea[2], cu1 = ea[3], gs2 = eb[0], cu2 = eb[1];
+            /* [lo, a1) the rest of the gap in front | [a1, b1) source behind it | [b1, e1) the gap that starts here | [e1, hi) source */
+            int a1 = (int)(gs0 + (cu1 - cu0) - Cl);
+            a1 = a1 < lo ? lo : (a1 > hi ? hi : a1);
+            int b1 = (int)(gs1 - Cl);
+            b1 = b1 < a1 ? a1 : (b1 > hi ? hi : b1);
+            int e1 = (cu2 - cu1) >= 16u ? 16 : b1 + (int)(cu2 - cu1);
+            e1 = e1 > hi ? hi : e1;
+            bool more = (int)(gs2 - Cl) < hi;
+            const u32 w0 = rc ? S32 - Cl + cu1 : S32 + Cl - cu1;
+            const u32 w1 = rc ? S32 - Cl + cu2 : S32 + Cl - cu2;
+            const u32x4_a1 W0 = *(const u32x4_a1*)(ring + (w0 & (WGA_S_RING - 1u)));
+            const u32x4_a1 W1 = *(const u32x4_a1*)(ring + (w1 & (WGA_S_RING - 1u)));
+            const u32x4_a16 La = s_lm[a1], Lb = s_lm[b1], Le = s_lm[e1];
+            u32 o[4], bad[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+              u32 cp;
+              if (rc)
+                cp = comp4(bfi_b32(Lb[d], bswap32(W0[3 - d]), bswap32(W1[3 - d])), &bad[d]);
+              else
+                cp = bfi_b32(Lb[d], W0[d], W1[d]);
+              const u32 md = La[d] | (Le[d] & ~Lb[d]);
+              o[d] = bfi_b32(md, 0x2D2D2D2Du, cp);
+              bad[d] &= ~md;
+            }
+            u32 ie = k + 1u;
+            while (more) { /* further events inside the granule: one round per event (rare: gaps are ~150 columns apart) */
               const u32 gsi = s_fifo[2u * ie], cui = s_fifo[2u * ie + 1u], gsn = s_fifo[2u * ie + 2u], cun = s_fifo[2u * ie + 3u];
               const int b = (int)(gsi - Cl);
               const u32 len = cun - cui;
@@ -241,37 +348,41 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
               ie++;
               more = (int)(gsn - Cl) < hi;
             }
+            if (rc && (bad[0] | bad[1] | bad[2] | bad[3]) != 0u) /* InvalidBase */
+              stream_report_bad((u64*)&a.diag[rec].bad_base_pos, bad[0], bad[1], bad[2], bad[3], lo, hi, Cl, (i64)s_k[0], s_fifo, k, nf, 0u);
+            const u32x4_a16 ov = {o[0], o[1], o[2], o[3]};
+            s_P[lane] = ov;
           }
-        }
-        if (rc) { /* InvalidBase (utils.rs:97): the first offender in reversed order = the smallest slice index */
-          const bool anyb = active && (bad[0] | bad[1] | bad[2] | bad[3]) != 0u;
-          if (__ballot(anyb)) {
-            if (anyb) {
-              const i64 Kseg = (i64)s_k[0];
-              for (int j = lo; j < hi; j++) {
-                const u32 bw = j < 4 ? bad[0] : j < 8 ? bad[1] : j < 12 ? bad[2] : bad[3];
-                if (((bw >> (8 * (j & 3))) & 0xFFu) == 0u) continue;
-                const u32 cj = Cl + (u32)j;
-                u32 i = k - 1u; /* last event that starts at or before column cj */
-                while (i + 1u < nf && (int)(s_fifo[2u * (i + 1u)] - cj) <= 0) i++;
-                const u32 adj = s_fifo[2u * (i + 1u) + 1u];
-                atomicMin((u64*)&a.diag[rec].bad_base_pos, (u64)((i64)(u64)(cj - adj) + Kseg));
-              }
+          WGA_WAVE_SYNC();
+#pragma unroll
+          for (u32 u = 0; u < WGA_S_U; u++) {
+            const u32 r = (rpk >> (8u * u)) & 255u;
+            if (((flg >> u) & 1u) != 0u && (r >> 6) == (r0 >> 6)) {
+              const u32x4_a16 pv = s_P[r & 63u];
+              dat[u][0] = pv[0];
+              dat[u][1] = pv[1];
+              dat[u][2] = pv[2];
+              dat[u][3] = pv[3];
             }
           }
         }
-        /* whole granules: one streaming store of the wave; the (at most two) partial ones: byte stores, never read-modify-write */
-        const bool whole = lo == 0 && hi == 16;
-        if (__ballot(whole)) {
-          if (whole) gstore16_nt(B, lane * 16u, o);
-          vm++;
-        }
-        if (active && !whole) {
-          u8* const p = B + lane * 16u;
-#pragma clang loop vectorize(disable) unroll(disable)
-          for (int j = lo; j < hi; j++) {
-            const u32 wj = j < 4 ? o[0] : j < 8 ? o[1] : j < 12 ? o[2] : o[3];
-            p[j] = (u8)(wj >> (8 * (j & 3)));
+
+        /* ---- (4) whole granules: one streaming store of the wave per kilobyte; partial ones (at most two): byte stores ---- */
+#pragma unroll
+        for (u32 u = 0; u < WGA_S_U; u++) {
+          if (u < nu) {
+            const bool whole = ((flg >> (4u + u)) & 1u) != 0u;
+            if (__ballot(whole)) {
+              if (whole) gstore16_nt(B + 1024u * u, lane * 16u, dat[u]);
+              vm++;
+            }
+            if (((flg >> (8u + u)) & 1u) != 0u) {
+              const u32 Cl = Cl0 + 1024u * u + 16u * lane;
+              int lo = (int)(Cs - Cl), hi = (int)(Ce - Cl);
+              lo = lo < 0 ? 0 : lo;
+              hi = hi > 16 ? 16 : hi;
+              stream_store_bytes(B + 1024u * u + lane * 16u, dat[u][0], dat[u][1], dat[u][2], dat[u][3], lo, hi);
+            }
           }
         }
         e0 += nE;
