@@ -996,7 +996,7 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
     RT_CHECK(rt_memset(wide_counts, 0, 256, c->stream));
     RT_CHECK(rt_memset(tile_flag, 0, flag_bytes, c->stream));
     WGA_LAUNCH(k_stream_mark_rec, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, b->n, (const wga_rec_desc*)recs,
-               (const u64*)b->d_op_off, tile_flag);
+               (const u64*)b->d_op_off, (u64)t_fa_bytes, (u64)q_fa_bytes, tile_flag);
     LAUNCH_CHECK();
     WGA_LAUNCH(k_stream_mark_tile, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, tdesc, (u64)nt, (const u8*)tile_flag,
                c->expand_force_slow, wide_counts, fast_list, wide_list);

@@ -35,30 +35,28 @@
 
 #include "wga_kernels.h"
 
-#ifndef WGA_S_RING_LOG2
-#define WGA_S_RING_LOG2 13u /* the source ring of a wave: 8 chunks of 1 KB */
-#endif
-#define WGA_S_RING (1u << WGA_S_RING_LOG2)
-#define WGA_S_CHUNKS (WGA_S_RING >> 10)
-#ifndef WGA_S_DEPTH
-#define WGA_S_DEPTH (WGA_S_CHUNKS - 3u) /* chunks on their way behind the one a step needs (a step touches at most 3 chunks; at most 6: the counters of 8 chunks are kept) */
-#endif
 #define WGA_S_FIFO 320u                 /* gap events waiting for their columns to be written (256 of one intake + what is left) */
 #define WGA_S_MAX_TILE_COLS (1ull << 24) /* wider tiles are left to v1 */
 #define WGA_S_MAX_JOB_TILES 32u          /* 32 x 2^24 columns stay below 2^31 */
 #define WGA_S_SKIP 0x100u                /* wga_tile_desc::neg: the streaming kernel leaves this tile to v1 */
 #define WGA_S_U 4u /* kilobytes of a row one super-step writes: the queued granules of that many share one round of the merge code */
-#define WGA_S_WAVE_BYTES (WGA_S_RING + 16u + 1024u + (WGA_S_FIFO + 4u) * 8u + 1024u + 1024u + 272u + 16u)
+#define WGA_S_WAVE_BYTES ((WGA_S_FIFO + 4u) * 8u + 1024u + 1024u + 256u + 272u + 16u)
 #ifndef WGA_AUTO_LONG_VARIANT
 #define WGA_AUTO_LONG_VARIANT 0 /* the row kernel of batches of long records when "expand_variant" is -1: 0 = v1, 3 = this one */
 #endif
 
 /* ---- pre-pass: which tiles the streaming kernel leaves to v1 ------------------------------------------------------- */
-/* one thread per record: a record that is not clean (k_rec_desc flags 2 / 4 / 8) marks every tile it has ops in */
-__global__ __launch_bounds__(256) void k_stream_mark_rec(u32 n, const wga_rec_desc* recs, const u64* op_off, u8* tile_flag) {
+/* one thread per record: a record that is not clean (k_rec_desc flags 2 / 4 / 8), or whose slices lie within 32 bytes of an
+ * edge of their pool (the streaming kernel's sixteen-byte windows reach over a slice's ends; v1 reads such rows byte by byte),
+ * marks every tile it has ops in */
+__global__ __launch_bounds__(256) void k_stream_mark_rec(u32 n, const wga_rec_desc* recs, const u64* op_off, u64 t_fa_bytes,
+                                                         u64 q_fa_bytes, u8* tile_flag) {
   const u32 r = blockIdx.x * 256u + threadIdx.x;
   if (r >= n) return;
-  if ((recs[r].neg & 0xEull) == 0ull) return;
+  const wga_rec_desc d = recs[r];
+  const bool inside = d.t_src_off >= 32ull && d.t_src_off + d.t_src_len + 32ull <= t_fa_bytes && d.q_src_off >= 32ull &&
+                      d.q_src_off + d.q_src_len + 32ull <= q_fa_bytes;
+  if ((d.neg & 0xEull) == 0ull && inside) return;
   const u64 a = op_off[r], b = op_off[r + 1];
   if (b <= a) return;
   for (u64 t = a / WGA_TILE; t <= (b - 1) / WGA_TILE; t++) tile_flag[t] = 1;
@@ -80,12 +78,20 @@ __global__ __launch_bounds__(256) void k_stream_mark_tile(wga_tile_desc* descs, 
   }
 }
 
-/* ---- rare paths kept out of line (the kernel's hot loop has to stay small: it runs at the instruction issue rate) ---- */
-#ifdef WGA_EMU
-#define WGA_S_NOINLINE
-#else
-#define WGA_S_NOINLINE __attribute__((noinline))
-#endif
+/* comp4 (wga_kernels.h) with '-' mapped to itself, so that granules that already hold gap characters pass through unchanged;
+ * a '-' is still flagged as an invalid BASE (a plain granule only holds source bytes) */
+__device__ __forceinline__ u32 comp4s(u32 x, u32* bad) {
+  const u32 sel = x & 0x07070707u;
+  const u32 fold = byte_perm(0x474EFF54u, 0x43FF41FFu, sel);
+  const u32 comp = byte_perm(0x434E0D41u, 0x47FF54FFu, sel);
+  *bad = (x & 0xDFDFDFDFu) ^ fold;
+  return comp | (x & 0x20202020u);
+}
+
+/* ---- rare paths: small loops, never unrolled (the kernel's hot loop has to stay small: it runs at the instruction issue rate).
+ *      They are inlined all the same: a call anywhere in the loop makes the compiler wait for every outstanding memory
+ *      operation around it — each of a super-step's four stores then waited for the one in front. ---- */
+#define WGA_S_NOINLINE __forceinline__
 /* bytes [lo, hi) of a granule: byte stores, never read-modify-write */
 __device__ WGA_S_NOINLINE void stream_store_bytes(u8* p, u32 o0, u32 o1, u32 o2, u32 o3, int lo, int hi) {
 #pragma clang loop vectorize(disable) unroll(disable)
@@ -117,13 +123,11 @@ __device__ WGA_S_NOINLINE void stream_report_bad(u64* bad_base_pos, u32 b0, u32 
 /* ---- the stream of one wave ----------------------------------------------------------------------------------------- */
 template <bool QROW>
 __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, const u32 lane, const u64 t0, const u64 t1) {
-  u8* const ring = lds;                                          /* WGA_S_RING + 16 (the first 16 bytes again) */
-  u32* const s_ops = (u32*)(lds + WGA_S_RING + 16u);             /* 256 ops                                   */
-  u32* const s_fifo = s_ops + 256;                               /* (WGA_S_FIFO + 4) x (start column, cum)    */
-  u32* const s_T = s_fifo + 2u * (WGA_S_FIFO + 4u);               /* 256 granules of a super-step: last event in each */
-  u32x4_a16* const s_P = (u32x4_a16*)s_T;                        /* ... later: 64 granules put together by the queue's lanes */
-  u32* const s_q = s_T + 256;                                    /* the queue: (event index, granule) of up to 256 granules */
-  u32x4_a16* const s_lm = (u32x4_a16*)(s_q + 256);               /* bytes [0, n) of a granule, n = 0 .. 16    */
+  u32* const s_fifo = (u32*)lds;                                 /* (WGA_S_FIFO + 4) x (start column, cum)    */
+  u32x4_a16* const s_P = (u32x4_a16*)(s_fifo + 2u * (WGA_S_FIFO + 4u)); /* 64 granules put together by the queue's lanes */
+  u32* const s_q = (u32*)(s_P + 64);                             /* the queue: (event index, granule) of up to 256 granules */
+  u32* const s_T = s_q + 256;                                    /* events per granule of a super-step, a byte per kilobyte */
+  u32x4_a16* const s_lm = (u32x4_a16*)(s_T + 64);                /* bytes [0, n) of a granule, n = 0 .. 16    */
   u64* const s_k = (u64*)(s_lm + 17);                            /* rarely used wave-uniform state: [0] Kseg  */
   if (lane < 17u) {
     u32x4_a16 m;
@@ -132,15 +136,12 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
   }
   const u8* const fa = QROW ? a.q_fa : a.t_fa;
   const u64 fa_bytes = QROW ? a.q_fa_bytes : a.t_fa_bytes;
-  const u64 fa_mis = WGA_UNI64((u64)fa & 1023ull);
-  const u8* const P0 = fa - fa_mis;                              /* 1 KB-aligned: chunk j = [P0 + 1024 j, + 1024) */
   const u64 job_lo = t0 * WGA_TILE;
   const u32 q_end = WGA_UNI32((u32)((t1 * WGA_TILE < a.n_ops ? t1 * WGA_TILE : a.n_ops) - job_lo)); /* ops of the job */
+  /* the job's ops as a buffer: lanes behind the end of the op array read zeros */
+  const BufRsrc obuf = buf_make(a.ops + job_lo, (u32)(((a.n_ops - job_lo) < 0x3FFFFFFFull ? (a.n_ops - job_lo) : 0x3FFFFFFFull) * 4ull));
 
   /* ---- wave-uniform state (32-bit wherever the job's size allows) ---- */
-  u32 vm = 0;          /* counted vector memory operations issued so far (DMAs, step stores)      */
-  u32 vm_ops_at = 0;   /* vm right behind the DMA of the op chunk that is in s_ops                */
-  u64 vm_at = 0;       /* byte (seq & 7): vm right behind the DMA(s) of source chunk number seq   */
   u32 C_known = 0, cum_known = 0; /* columns / gap bases of the ops taken in                      */
   u32 nf = 1;          /* FIFO entries [0, nf), sentinels at nf .. nf + 2; entry 0 lies in front  */
   u32 e0 = 1;          /* first FIFO entry whose gap starts at or behind pos                      */
@@ -149,18 +150,16 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
   u32 q_lo = 0, q_hi = 0; /* the ops taken in last                                                */
   u32 rec = 0, re = 0; /* the record, its last op + 1 (relative to the job, saturated)            */
   u8* dst_seg = nullptr;     /* byte of column 0 (stream coordinates) of the segment's row       */
-  const u8* src0 = nullptr;  /* source chunk 0 of the segment's stream                            */
-  int S_rel = 0;       /* a non-gap column C reads source byte S_rel +/- (C - cum), relative to src0 */
-  u32 S_ring = 0;      /* ring position of src0's first byte                                      */
-  int hull_a = 0, hull_b = 0; /* the pool's 16-byte hull relative to src0                         */
-  u32 seq_next = 0, seq_last = 0, seq_done = 0; /* source chunks: next to issue, last of the slice, landed */
-  bool rc = false, has_src = false;
+  BufRsrc sbuf = buf_make(fa, 0u); /* the segment's source: the pool from a base a little in front of what the job can reach */
+  u32 S32 = 0;         /* a non-gap column C with `cum` gap bases in front reads sbuf at S32 +/- (C - cum) (rc: its window's start) */
+  bool rc = false;
   bool live = false;   /* a stream is under way                                                   */
   bool bnd = false;    /* a record ends at column C_b (gap bases cum_b in front) of the ops taken in */
-  bool fin = false;    /* write everything known, even a step that does not fill its kilobyte     */
+  bool fin = false;    /* write everything known, even a super-step that does not fill its kilobytes */
   u32 C_b = 0, cum_b = 0;
   u64 t = t0;          /* tile of op q                                                            */
   u32 l[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0}, xl0 = 0, xg0 = 0; /* the ops taken in last: lengths, gap lengths, prefixes */
+  u32 own[4] = {0, 0, 0, 0}; /* the next 256 ops, on their way */
 
   for (;;) {
     /* ================= write columns: ONE site for the super-step ================= */
@@ -173,16 +172,17 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
         u8* const B = A - mis;
         const u32 room = WGA_S_U * 1024u - mis;
         if (!all && (lim - pos) < room) break;
-        const u32 Cs = pos, Ce = (lim - pos) < room ? lim : pos + room;
+        const u32 Cs = pos;
+        u32 Ce = (lim - pos) < room ? lim : pos + room;
         const u32 Cl0 = Cs - mis; /* column of the first granule of the kilobyte Cs lies in (wraps below zero at a stream's start) */
-        const u32 nu = (mis + (Ce - Cs) + 1023u) >> 10; /* kilobytes (sub-steps) this super-step touches: 1 .. WGA_S_U */
-        const u32 S32 = rc ? S_ring + (u32)S_rel - 15u : S_ring + (u32)S_rel;
-
-        /* ---- (1) the super-step's events: T[granule] = the last event that starts in it (0: none) ---- */
-        {
-          const u32x4_a16 z = {0u, 0u, 0u, 0u};
-          *(u32x4_a16*)(s_T + 4u * lane) = z;
+        if (e0 + 255u < nf) { /* gaps every few columns: a super-step counts its events in bytes, so it ends in front of its 256th */
+          const u32 g255 = WGA_UNI32(s_fifo[2u * (e0 + 255u)]);
+          if ((int)(g255 - Ce) < 0) Ce = Cl0 + ((g255 - Cl0) & ~15u);
         }
+        const BufRsrc dbuf = buf_make(B, WGA_S_U * 1024u);
+
+        /* ---- (1) the super-step's events, counted per granule: byte u of T[l] = events that start in granule l of kilobyte u ---- */
+        s_T[lane] = 0u;
         WGA_WAVE_SYNC();
         u32 nE = 0;
         {
@@ -192,103 +192,73 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
             const u32 gsr = s_fifo[2u * idx] - Cl0;
             const bool in = gsr < Ce - Cl0;
             c = (u32)__popcll(__ballot(in));
-            if (in) atomicMax(&s_T[((gsr >> 4) & 63u) << 2 | (gsr >> 10)], idx); /* lane l reads its WGA_S_U granules as one vector */
+            if (in) atomicAdd(&s_T[(gsr >> 4) & 63u], 1u << (8u * (gsr >> 10)));
             base += c;
             nE += c;
           } while (c == 64u);
         }
         WGA_WAVE_SYNC();
-        const u32x4_a16 tv = *(const u32x4_a16*)(s_T + 4u * lane);
-        WGA_WAVE_SYNC(); /* T becomes the patch buffer below */
+        const u32 tw = s_T[lane];
+        WGA_WAVE_SYNC();
+        /* one scan for all kilobytes (no byte overflows: at most 255 events); events in front of a granule, in granule order */
+        const u32 tinc = wave_incl_scan_u32(tw);
+        const u32 texc = tinc - tw;
+        const u32 ttot = wave_last_u32(tinc);
 
-        /* ---- (2) every lane's granule of every kilobyte: the plain case at once, the rest queued ---- */
-        u32 carry = e0 - 1u; /* the last event that starts in front of the sub-step */
+        /* ---- (2) every lane's granule of every kilobyte: its window is requested at once, the ones a gap touches are queued ---- */
+        u32 kbase = e0; /* the first event of the kilobyte */
         u32 qn = 0, rpk = 0, flg = 0;
         u32 dat[WGA_S_U][4];
+        bool pl[WGA_S_U]; /* plain granules (reverse-complement rows: where an invalid base is looked for) */
+        const u32 wsp = Ce - Cs - 16u, asp = Ce - Cs + 15u; /* whole: (Cl - Cs) <= wsp; active: (Cl + 15 - Cs) < asp (unsigned) */
+        const bool any16 = (Ce - Cs) >= 16u;
 #pragma unroll
-        for (u32 u = 0; u < WGA_S_U; u++) {
-          if (u < nu) {
-            const u32 Cu = Cl0 + 1024u * u; /* columns [Cu, Cu + 1024) ∩ [Cs, Ce) */
-            if (has_src) {
-              const u32 cumA = WGA_UNI32(s_fifo[2u * (carry + 1u) + 1u]); /* gap bases in front of the first event at / behind Cu */
-              if (u == 0u) {
-                /* Chunks travel only between super-steps: the queued granules of ALL kilobytes read the ring at the end.  What
-                 * the columns in front of Cs have consumed is exact (a gap that straddles Cs counts with its part in front). */
-                const u32 g0 = WGA_UNI32(s_fifo[2u * carry]), c0 = WGA_UNI32(s_fifo[2u * carry + 1u]);
-                const int over = (int)(g0 + (cumA - c0) - Cs);
-                const int cons = (int)(Cs - cumA) + (over > 0 ? over : 0);
-                int cs = rc ? -((S_rel - cons) >> 10) : (S_rel + cons) >> 10;
-                cs = cs < 0 ? 0 : cs;
-                u32 lim_seq = (u32)cs + WGA_S_CHUNKS - 1u;
-                lim_seq = lim_seq > seq_last ? seq_last : lim_seq;
-                while (seq_next <= lim_seq) {
-                  const int rel = rc ? -(int)(seq_next << 10) : (int)(seq_next << 10);
-                  const u32 slot = ((S_ring >> 10) + (rc ? 0u - seq_next : seq_next)) & (WGA_S_CHUNKS - 1u);
-                  const int lrel = rel + (int)(lane * 16u);
-                  if (lrel >= hull_a && lrel < hull_b) lds_dma16_after_reads(src0 + rel, lane * 16u, ring + slot * 1024u);
-                  vm++;
-                  if (slot == 0u) { /* windows that start in the last slot read across the end of the ring */
-                    if (lane == 0u && rel >= hull_a && rel < hull_b) lds_dma16(src0 + rel, 0u, ring + WGA_S_RING);
-                    vm++;
-                  }
-                  const u32 sh = 8u * (seq_next & 7u);
-                  vm_at = (vm_at & ~(0xFFull << sh)) | ((u64)(vm & 0xFFu) << sh);
-                  seq_next++;
+        for (u32 u = 0; u < WGA_S_U; u++) { /* kilobytes behind the super-step's end: no lane is active, nothing is read or queued */
+          const u32 cnt = (tw >> (8u * u)) & 255u;
+          const u32 k = kbase + ((texc >> (8u * u)) & 255u); /* the first event that starts in this granule or behind it */
+          kbase += (ttot >> (8u * u)) & 255u;
+          const u32 Cl = Cl0 + 1024u * u + 16u * lane;
+          const bool whole = any16 && (Cl - Cs) <= wsp, active = (Cl + 15u - Cs) < asp;
+          const u32x4_a1 fe = *(const u32x4_a1*)(s_fifo + 2u * (k - 1u)); /* events k - 1, k: start, gap bases in front */
+          const int rel0 = (int)(fe[0] + (fe[3] - fe[1]) - Cl); /* how far the gap in front reaches into the granule */
+          const bool quiet = whole && cnt == 0u;    /* a whole granule in which no gap starts ... */
+          const bool plain = quiet && rel0 <= 0;    /* ... sixteen source bytes in a row        */
+          const bool dashes = quiet && rel0 >= 16;  /* ... sixteen gap characters               */
+          const bool flagged = active && !(plain || dashes);
+          dat[u][0] = dat[u][1] = dat[u][2] = dat[u][3] = dashes ? 0x2D2D2D2Du : 0u;
+          if (plain) buf_load16(sbuf, rc ? S32 - Cl + fe[3] : S32 + Cl - fe[3], dat[u]);
+          pl[u] = plain;
+          const u64 m = __ballot(flagged);
+          if (flagged) {
+            const u32 r = qn + lane_rank(m, lane);
+            s_q[r] = (k << 8) | (u << 6) | lane;
+            rpk |= r << (8u * u);
+            flg |= 1u << u;
+          }
+          qn += (u32)__popcll(m);
+        }
+        /* the windows arrive: reverse complement ('-' and what the queue will replace pass through) */
+        if (rc) {
+#pragma unroll
+          for (u32 u = 0; u < WGA_S_U; u++) {
+            {
+              u32 bad[4], x[4];
+#pragma unroll
+              for (int d = 0; d < 4; d++) x[d] = comp4s(bswap32(dat[u][3 - d]), &bad[d]);
+#pragma unroll
+              for (int d = 0; d < 4; d++) dat[u][d] = x[d];
+              /* InvalidBase in a plain granule (utils.rs:97); queued granules are checked where they are put together */
+              const bool pb = pl[u] && (bad[0] | bad[1] | bad[2] | bad[3]) != 0u;
+              if (__ballot(pb)) {
+                if (pb) { /* rare: the gap bases in front of the granule are looked up again */
+                  const u32 Cl = Cl0 + 1024u * u + 16u * lane;
+                  u32 i = e0 - 1u;
+                  while (i + 1u < nf && (int)(s_fifo[2u * (i + 1u)] - Cl) <= 0) i++;
+                  stream_report_bad((u64*)&a.diag[rec].bad_base_pos, bad[0], bad[1], bad[2], bad[3], 0, 16, Cl, (i64)s_k[0], nullptr, 0u, 0u,
+                                    s_fifo[2u * (i + 1u) + 1u]);
                 }
               }
-              /* what this kilobyte reads must have landed */
-              const u32 c_hi = (int)(Cu + 1024u - Ce) > 0 ? Ce : Cu + 1024u;
-              int need = rc ? -((S_rel - (int)(c_hi - cumA) - 16) >> 10) : (S_rel + (int)(c_hi - cumA) + 15) >> 10;
-              need = need < 0 ? 0 : (need > (int)seq_last ? (int)seq_last : need);
-              if ((u32)need >= seq_done) {
-                vm_wait((vm - (u32)(vm_at >> (8u * ((u32)need & 7u)))) & 0xFFu);
-                seq_done = (u32)need + 1u;
-              }
-              WGA_WAVE_SYNC();
             }
-            const u32 v = tv[u];
-            const u32 inc = wave_incl_scan_max_u32(v);
-            const u32 prv = wave_shr1_u32(inc, 0u);
-            const u32 k = (prv > carry ? prv : carry) + 1u; /* the first event that starts in this granule or behind it */
-            const u32 top = wave_last_u32(inc);
-            carry = top > carry ? top : carry;
-            const u32 Cl = Cu + 16u * lane;
-            int lo = (int)(Cs - Cl), hi = (int)(Ce - Cl);
-            lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
-            hi = hi > 16 ? 16 : (hi < 0 ? 0 : hi);
-            const bool active = hi > lo, whole = lo == 0 && hi == 16;
-            const u32x4_a1 fe = *(const u32x4_a1*)(s_fifo + 2u * (k - 1u)); /* events k - 1, k: start, gap bases in front */
-            const int rel0 = (int)(fe[0] + (fe[3] - fe[1]) - Cl); /* how far the gap in front reaches into the granule */
-            const bool flagged = active && (v != 0u || (rel0 > 0 && rel0 < 16) || !whole);
-            const u32 w = rc ? S32 - Cl + fe[3] : S32 + Cl - fe[3];
-            const u32x4_a1 W = *(const u32x4_a1*)(ring + (w & (WGA_S_RING - 1u)));
-            u32 bad[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-              u32 x = W[d];
-              if (rc) x = comp4(bswap32(W[3 - d]), &bad[d]);
-              dat[u][d] = rel0 >= 16 ? 0x2D2D2D2Du : x;
-            }
-            if (rc) { /* InvalidBase in a plain granule (utils.rs:97); queued granules are checked where they are put together */
-              const bool pb = active && !flagged && rel0 < 16 && (bad[0] | bad[1] | bad[2] | bad[3]) != 0u;
-              if (__ballot(pb)) {
-                if (pb)
-                  stream_report_bad((u64*)&a.diag[rec].bad_base_pos, bad[0], bad[1], bad[2], bad[3], 0, 16, Cl, (i64)s_k[0], nullptr, 0u,
-                                    0u, fe[3]);
-              }
-            }
-            const u64 m = __ballot(flagged);
-            if (m) {
-              const u32 r = qn + lane_rank(m, lane);
-              if (flagged) {
-                s_q[r] = (k << 8) | (u << 6) | lane;
-                rpk |= r << (8u * u);
-                flg |= 1u << u;
-              }
-              qn += (u32)__popcll(m);
-            }
-            flg |= (active && whole ? 16u : 0u) << u;
-            flg |= (active && !whole ? 256u : 0u) << u;
           }
         }
 
@@ -312,17 +282,16 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
             int e1 = (cu2 - cu1) >= 16u ? 16 : b1 + (int)(cu2 - cu1);
             e1 = e1 > hi ? hi : e1;
             bool more = (int)(gs2 - Cl) < hi;
-            const u32 w0 = rc ? S32 - Cl + cu1 : S32 + Cl - cu1;
-            const u32 w1 = rc ? S32 - Cl + cu2 : S32 + Cl - cu2;
-            const u32x4_a1 W0 = *(const u32x4_a1*)(ring + (w0 & (WGA_S_RING - 1u)));
-            const u32x4_a1 W1 = *(const u32x4_a1*)(ring + (w1 & (WGA_S_RING - 1u)));
+            u32 W0[4], W1[4];
+            buf_load16(sbuf, b1 > a1 ? (rc ? S32 - Cl + cu1 : S32 + Cl - cu1) : WGA_BUF_OOB, W0);
+            buf_load16(sbuf, hi > e1 ? (rc ? S32 - Cl + cu2 : S32 + Cl - cu2) : WGA_BUF_OOB, W1);
             const u32x4_a16 La = s_lm[a1], Lb = s_lm[b1], Le = s_lm[e1];
             u32 o[4], bad[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int d = 0; d < 4; d++) {
               u32 cp;
               if (rc)
-                cp = comp4(bfi_b32(Lb[d], bswap32(W0[3 - d]), bswap32(W1[3 - d])), &bad[d]);
+                cp = comp4s(bfi_b32(Lb[d], bswap32(W0[3 - d]), bswap32(W1[3 - d])), &bad[d]);
               else
                 cp = bfi_b32(Lb[d], W0[d], W1[d]);
               const u32 md = La[d] | (Le[d] & ~Lb[d]);
@@ -335,13 +304,13 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
               const int b = (int)(gsi - Cl);
               const u32 len = cun - cui;
               const int e = len >= (u32)(hi - b) ? hi : b + (int)len;
-              const u32 w = rc ? S32 - Cl + cun : S32 + Cl - cun;
-              const u32x4_a1 W = *(const u32x4_a1*)(ring + (w & (WGA_S_RING - 1u)));
+              u32 W[4];
+              buf_load16(sbuf, rc ? S32 - Cl + cun : S32 + Cl - cun, W);
               const u32x4_a16 Mb = s_lm[b], Me = s_lm[e];
 #pragma unroll
               for (int d = 0; d < 4; d++) {
                 u32 x = W[d], bw = 0u;
-                if (rc) x = comp4(bswap32(W[3 - d]), &bw);
+                if (rc) x = comp4s(bswap32(W[3 - d]), &bw);
                 o[d] = bfi_b32(Mb[d], o[d], bfi_b32(Me[d], 0x2D2D2D2Du, x));
                 bad[d] = (bad[d] & Mb[d]) | (bw & ~Me[d]);
               }
@@ -366,18 +335,16 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
             }
           }
         }
+        WGA_WAVE_SYNC();
 
         /* ---- (4) whole granules: one streaming store of the wave per kilobyte; partial ones (at most two): byte stores ---- */
 #pragma unroll
         for (u32 u = 0; u < WGA_S_U; u++) {
-          if (u < nu) {
-            const bool whole = ((flg >> (4u + u)) & 1u) != 0u;
-            if (__ballot(whole)) {
-              if (whole) gstore16_nt(B + 1024u * u, lane * 16u, dat[u]);
-              vm++;
-            }
-            if (((flg >> (8u + u)) & 1u) != 0u) {
-              const u32 Cl = Cl0 + 1024u * u + 16u * lane;
+          {
+            const u32 Cl = Cl0 + 1024u * u + 16u * lane;
+            const bool whole = any16 && (Cl - Cs) <= wsp;
+            buf_store16_stream(dbuf, whole ? 1024u * u + 16u * lane : WGA_BUF_OOB, dat[u]);
+            if (((flg >> u) & 1u) != 0u && !whole) {
               int lo = (int)(Cs - Cl), hi = (int)(Ce - Cl);
               lo = lo < 0 ? 0 : lo;
               hi = hi > 16 ? 16 : hi;
@@ -421,7 +388,6 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
         const wga_tile_desc* const td = a.tdesc + t;
         const u64 tile_start = t * WGA_TILE;
         q = (u32)(tile_start - job_lo);
-        vm_wait(0u);
         WGA_WAVE_SYNC();
         C_known = cum_known = 0u;
         pos = 0u;
@@ -444,37 +410,33 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
         x_a = b_mx + b_i + b_d;
         sb = QROW ? b_mx + b_i : b_mx + b_d;
         C_a = cum_a = 0u;
-        { /* the first 256 ops */
-          const u64 left = a.n_ops - tile_start;
-          if (left >= 256ull || (u64)(lane * 4u) < left) lds_dma16_after_reads(a.ops + tile_start, lane * 16u, s_ops);
-          vm++;
-          vm_ops_at = vm;
-        }
+        buf_load16(obuf, q * 4u + lane * 16u, own); /* the first 256 ops */
         live = true;
       }
-      /* the segment: column C_a (cum_a gap bases in front) is column x_a of the record's row, sb bases of its slice used */
+      /* the segment: column C_a (cum_a gap bases in front) is column x_a of the record's row, sb bases of its slice used.
+       * A non-gap column C (cum gap bases in front) reads slice index (C - cum) + Kseg, Kseg = sb - (C_a - cum_a); the job
+       * reaches at most 2^30 bases further, so the buffer starts a little in front of the first one (offsets stay 32-bit). */
       dst_seg = a.out + row_off + x_a - (u64)C_a;
       rc = QROW && neg;
-      const int adv = (int)(C_a - cum_a); /* (C - cum) at the segment's start */
-      const u64 first = fa_mis + src_off + (rc ? src_len - 1ull - sb : sb); /* pool offset (from P0) of the first source byte */
-      const u64 j0 = first >> 10;
-      src0 = P0 + (j0 << 10);
-      S_ring = ((u32)j0 & (WGA_S_CHUNKS - 1u)) << 10;
-      S_rel = rc ? (int)((u32)first & 1023u) + adv : (int)((u32)first & 1023u) - adv;
-      has_src = src_len > sb;
-      {
-        const u64 last = rc ? fa_mis + src_off : fa_mis + src_off + src_len - 1ull;
-        const u64 nseq = rc ? j0 - (last >> 10) : (last >> 10) - j0;
-        seq_last = has_src ? (nseq > 0x100000ull ? 0x100000u : (u32)nseq) : 0u; /* a job never walks 2^20 chunks */
-        const i64 ha = (i64)(fa_mis & ~15ull) - (i64)(j0 << 10), hb = (i64)((fa_mis + fa_bytes + 15ull) & ~15ull) - (i64)(j0 << 10);
-        hull_a = ha < -0x40000000ll ? -0x40000000 : (int)ha;
-        hull_b = hb > 0x40000000ll ? 0x40000000 : (int)hb;
+      const u32 adv = C_a - cum_a;
+      u64 base; /* pool offset of the buffer's first byte */
+      if (rc) { /* slice index s is pool byte src_off + src_len - 1 - s; a window of sixteen starts fifteen bytes below */
+        const u64 top = src_off + src_len; /* one behind the pool byte of slice index 0 */
+        const u64 hiB = top > sb ? top - sb : 0ull; /* one behind the first byte this segment reads */
+        base = hiB > 0x60000000ull ? hiB - 0x60000000ull : 0ull;
+        S32 = (u32)(top - base) - 16u - (u32)sb + adv; /* window start of column C: S32 - (C - cum) */
+      } else {
+        const u64 loB = src_off + sb;
+        base = loB > 64ull ? loB - 64ull : 0ull;
+        S32 = (u32)(loB - base) - adv; /* byte of column C: S32 + (C - cum) */
       }
-      if (lane == 0u) s_k[0] = (u64)((i64)sb - (i64)adv);
-      vm_wait(0u); /* the old stream's chunks must not land on top of the new one's */
+      base = base > fa_bytes ? fa_bytes : base;
+      {
+        const u64 left = fa_bytes - base;
+        sbuf = buf_make(fa + base, left > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (u32)left);
+      }
+      if (lane == 0u) s_k[0] = (u64)((i64)sb - (i64)(u64)adv);
       WGA_WAVE_SYNC();
-      seq_next = 0u;
-      seq_done = 0u;
       /* the next boundary among the ops that are in (none right after a start) */
       bnd = false;
       if (sw && re < q_hi) {
@@ -489,7 +451,7 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
     }
 
     /* ================= everything that is in has been written as far as it may: take more ops in ================= */
-    if (q >= q_end) { /* the job ends: the last, partial kilobyte */
+    if (q >= q_end) { /* the job ends: the last, partial kilobytes */
       if (pos != C_known) {
         fin = true;
         continue;
@@ -522,7 +484,7 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
       nf -= from;
       e0 = 1u;
     }
-    if (nf + 256u > WGA_S_FIFO) { /* dense gaps: write what is known (a partial kilobyte) so that the FIFO drains */
+    if (nf + 256u > WGA_S_FIFO) { /* dense gaps: write what is known (partial kilobytes) so that the FIFO drains */
       fin = true;
       if (pos != C_known) continue;
       fin = false;
@@ -531,23 +493,15 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
     q_lo = q;
     q_hi = q + 256u < q_end ? q + 256u : q_end;
     q = q_hi;
-    vm_wait((vm - vm_ops_at) & 0xFFu);
-    WGA_WAVE_SYNC();
-    const u32x4_a16 ow = *(const u32x4_a16*)(s_ops + 4u * lane);
-    WGA_WAVE_SYNC();
-    if (q_hi < q_end) { /* the next 256 travel while these are worked on */
-      const u64 qa = job_lo + q_hi, left = a.n_ops - qa;
-      if (left >= 256ull || (u64)(lane * 4u) < left) lds_dma16_after_reads(a.ops + qa, lane * 16u, s_ops);
-      vm++;
-      vm_ops_at = vm;
-    }
+    const u32 ow[4] = {own[0], own[1], own[2], own[3]};
+    buf_load16(obuf, q_hi < q_end ? q_hi * 4u + lane * 16u : WGA_BUF_OOB, own); /* the next 256 travel while these are worked on */
     u32 sl = 0, sg = 0, sc = 0;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const bool valid = q_lo + 4u * lane + (u32)e < q_hi;
-      const u32 len = ow[e] >> 4, cls = op_class(ow[e] & 15u);
-      l[e] = (valid && cls <= CLS_D) ? len : 0u;
-      g[e] = (valid && cls == (QROW ? CLS_D : CLS_I)) ? len : 0u;
+      const u32 len = valid ? ow[e] >> 4 : 0u, code = ow[e] & 15u;
+      l[e] = len & bit_mask(0x787u, code);                  /* M I D = X and the continuation codes: columns   */
+      g[e] = len & bit_mask(QROW ? 0x404u : 0x202u, code);  /* D (query row) / I (target row): this row's gaps */
       sl += l[e];
       sg += g[e];
       sc += g[e] != 0u ? 1u : 0u;
@@ -585,7 +539,6 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
       bnd = true;
     }
   }
-  vm_wait(0u);
 }
 
 /* job -> XCD: blocks go to the 8 XCDs round robin; every XCD works through one contiguous eighth of the jobs (shared output
