@@ -48,7 +48,7 @@ struct wga_ctx {
   int expand_variant = -1; /* the row kernel: -1 by the batch (records below WGA_AUTO_SHORT_OPS ops on average take the window
                               kernel of wga_kernels_k2w.h, longer ones v1), 0 v1 (wga_kernels.h), 2 the window kernel */
   int expand_variant_used = 0;
-  int expand_job_tiles = 4; /* streaming kernel: tiles per wave ("expand_job_tiles") */
+  int expand_job_tiles = 8; /* streaming kernel: tiles per wave ("expand_job_tiles") */
   const u32* stream_counts = nullptr; /* streaming kernel: the two counters of the tiles its last launch left to v1 (in the scratch arena) */
   void* expand_dbg = nullptr;
   void* scratch = nullptr;

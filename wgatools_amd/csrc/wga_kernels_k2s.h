@@ -158,7 +158,7 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
   bool fin = false;    /* write everything known, even a super-step that does not fill its kilobytes */
   u32 C_b = 0, cum_b = 0;
   u64 t = t0;          /* tile of op q                                                            */
-  u32 l[4] = {0, 0, 0, 0}, g[4] = {0, 0, 0, 0}, xl0 = 0, xg0 = 0; /* the ops taken in last: lengths, gap lengths, prefixes */
+  u32 ow[4] = {0, 0, 0, 0}, xl0 = 0, xg0 = 0; /* the ops taken in last, the columns / gap bases in front of each lane's first */
   u32 own[4] = {0, 0, 0, 0}; /* the next 256 ops, on their way */
 
   for (;;) {
@@ -179,7 +179,6 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
           const u32 g255 = WGA_UNI32(s_fifo[2u * (e0 + 255u)]);
           if ((int)(g255 - Ce) < 0) Ce = Cl0 + ((g255 - Cl0) & ~15u);
         }
-        const BufRsrc dbuf = buf_make(B, WGA_S_U * 1024u);
 
         /* ---- (1) the super-step's events, counted per granule: byte u of T[l] = events that start in granule l of kilobyte u ---- */
         s_T[lane] = 0u;
@@ -205,15 +204,15 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
         const u32 texc = tinc - tw;
         const u32 ttot = wave_last_u32(tinc);
 
-        /* ---- (2) every lane's granule of every kilobyte: its window is requested at once, the ones a gap touches are queued ---- */
+        /* ---- (2) every lane's granule of every kilobyte is classified; the ones a gap touches are queued ---- */
         u32 kbase = e0; /* the first event of the kilobyte */
-        u32 qn = 0, rpk = 0, flg = 0;
-        u32 dat[WGA_S_U][4];
-        bool pl[WGA_S_U]; /* plain granules (reverse-complement rows: where an invalid base is looked for) */
+        u32 qn = 0, rpk = 0, cls = 0; /* cls: per kilobyte u bits 4u .. 4u + 2: plain, dashes, queued */
+        u32 adjv[WGA_S_U];
         const u32 wsp = Ce - Cs - 16u, asp = Ce - Cs + 15u; /* whole: (Cl - Cs) <= wsp; active: (Cl + 15 - Cs) < asp (unsigned) */
         const bool any16 = (Ce - Cs) >= 16u;
+        u32 qcum = 0; /* queued granules of the kilobytes in front, a byte each (for kilobyte u: bits 8u ..) */
 #pragma unroll
-        for (u32 u = 0; u < WGA_S_U; u++) { /* kilobytes behind the super-step's end: no lane is active, nothing is read or queued */
+        for (u32 u = 0; u < WGA_S_U; u++) { /* kilobytes behind the super-step's end: no lane is active, nothing is queued */
           const u32 cnt = (tw >> (8u * u)) & 255u;
           const u32 k = kbase + ((texc >> (8u * u)) & 255u); /* the first event that starts in this granule or behind it */
           kbase += (ttot >> (8u * u)) & 255u;
@@ -225,133 +224,148 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
           const bool plain = quiet && rel0 <= 0;    /* ... sixteen source bytes in a row        */
           const bool dashes = quiet && rel0 >= 16;  /* ... sixteen gap characters               */
           const bool flagged = active && !(plain || dashes);
-          dat[u][0] = dat[u][1] = dat[u][2] = dat[u][3] = dashes ? 0x2D2D2D2Du : 0u;
-          if (plain) buf_load16(sbuf, rc ? S32 - Cl + fe[3] : S32 + Cl - fe[3], dat[u]);
-          pl[u] = plain;
+          adjv[u] = fe[3];
+          cls |= ((plain ? 1u : 0u) | (dashes ? 2u : 0u) | (flagged ? 4u : 0u)) << (4u * u);
           const u64 m = __ballot(flagged);
           if (flagged) {
             const u32 r = qn + lane_rank(m, lane);
-            s_q[r] = (k << 8) | (u << 6) | lane;
-            rpk |= r << (8u * u);
-            flg |= 1u << u;
+            s_q[r & 255u] = (k << 8) | (u << 6) | lane;
+            rpk |= (r & 255u) << (8u * u);
           }
+          qcum |= (qn > 255u ? 255u : qn) << (8u * u);
           qn += (u32)__popcll(m);
         }
-        /* the windows arrive: reverse complement ('-' and what the queue will replace pass through) */
-        if (rc) {
+        /* the queue's lanes put the queued granules together in ONE round: a super-step ends in front of the kilobyte with
+         * which it would queue more than 64 (a kilobyte has 64 granules, so at least one always stays) */
+        if (qn > 64u) {
+          u32 keep = 1u;
 #pragma unroll
-          for (u32 u = 0; u < WGA_S_U; u++) {
-            {
-              u32 bad[4], x[4];
-#pragma unroll
-              for (int d = 0; d < 4; d++) x[d] = comp4s(bswap32(dat[u][3 - d]), &bad[d]);
-#pragma unroll
-              for (int d = 0; d < 4; d++) dat[u][d] = x[d];
-              /* InvalidBase in a plain granule (utils.rs:97); queued granules are checked where they are put together */
-              const bool pb = pl[u] && (bad[0] | bad[1] | bad[2] | bad[3]) != 0u;
-              if (__ballot(pb)) {
-                if (pb) { /* rare: the gap bases in front of the granule are looked up again */
-                  const u32 Cl = Cl0 + 1024u * u + 16u * lane;
-                  u32 i = e0 - 1u;
-                  while (i + 1u < nf && (int)(s_fifo[2u * (i + 1u)] - Cl) <= 0) i++;
-                  stream_report_bad((u64*)&a.diag[rec].bad_base_pos, bad[0], bad[1], bad[2], bad[3], 0, 16, Cl, (i64)s_k[0], nullptr, 0u, 0u,
-                                    s_fifo[2u * (i + 1u) + 1u]);
-                }
-              }
-            }
+          for (u32 u = 2; u <= WGA_S_U; u++) { /* kilobytes [0, u) queue (qcum byte u, or qn for all of them) granules */
+            const u32 upto = u == WGA_S_U ? qn : (qcum >> (8u * u)) & 255u;
+            const bool sat = u < WGA_S_U && ((qcum >> (8u * u)) & 255u) == 255u; /* the byte saturated: more than 64 anyway */
+            if (upto <= 64u && !sat) keep = u;
           }
+          const u32 Cn = Cl0 + 1024u * keep;
+          if ((int)(Cn - Ce) < 0) Ce = Cn;
+          qn = keep == WGA_S_U ? qn : (qcum >> (8u * keep)) & 255u;
+          nE = 0;
+#pragma unroll
+          for (u32 u = 0; u < WGA_S_U; u++)
+            if (u < keep) nE += (ttot >> (8u * u)) & 255u;
         }
+        const BufRsrc dbuf = buf_make(B, WGA_S_U * 1024u);
 
-        /* ---- (3) the queued granules, 64 at a time: put together from two windows under byte masks, handed back through LDS ---- */
-        for (u32 r0 = 0; r0 < qn; r0 += 64u) {
-          WGA_WAVE_SYNC();
-          if (r0 + lane < qn) {
-            const u32 ent = s_q[r0 + lane];
-            const u32 k = ent >> 8, Cl = Cl0 + 16u * (ent & 255u);
-            int lo = (int)(Cs - Cl), hi = (int)(Ce - Cl);
-            lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
-            hi = hi > 16 ? 16 : (hi < 0 ? 0 : hi);
-            const u32x4_a1 ea = *(const u32x4_a1*)(s_fifo + 2u * (k - 1u)); /* events k - 1, k */
-            const u32x4_a1 eb = *(const u32x4_a1*)(s_fifo + 2u * (k + 1u)); /* events k + 1, k + 2 */
-            const u32 gs0 = ea[0], cu0 = ea[1], gs1 = ea[2], cu1 = ea[3], gs2 = eb[0], cu2 = eb[1];
-            /* [lo, a1) the rest of the gap in front | [a1, b1) source behind it | [b1, e1) the gap that starts here | [e1, hi) source */
-            int a1 = (int)(gs0 + (cu1 - cu0) - Cl);
-            a1 = a1 < lo ? lo : (a1 > hi ? hi : a1);
-            int b1 = (int)(gs1 - Cl);
-            b1 = b1 < a1 ? a1 : (b1 > hi ? hi : b1);
-            int e1 = (cu2 - cu1) >= 16u ? 16 : b1 + (int)(cu2 - cu1);
-            e1 = e1 > hi ? hi : e1;
-            bool more = (int)(gs2 - Cl) < hi;
-            u32 W0[4], W1[4];
-            buf_load16(sbuf, b1 > a1 ? (rc ? S32 - Cl + cu1 : S32 + Cl - cu1) : WGA_BUF_OOB, W0);
-            buf_load16(sbuf, hi > e1 ? (rc ? S32 - Cl + cu2 : S32 + Cl - cu2) : WGA_BUF_OOB, W1);
-            const u32x4_a16 La = s_lm[a1], Lb = s_lm[b1], Le = s_lm[e1];
-            u32 o[4], bad[4] = {0u, 0u, 0u, 0u};
+        /* ---- (3) the queued granules: put together from two windows under byte masks, handed back through LDS ---- */
+        WGA_WAVE_SYNC();
+        if (lane < qn) {
+          const u32 ent = s_q[lane];
+          const u32 k = ent >> 8, Cl = Cl0 + 16u * (ent & 255u);
+          int lo = (int)(Cs - Cl), hi = (int)(Ce - Cl);
+          lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
+          hi = hi > 16 ? 16 : (hi < 0 ? 0 : hi);
+          const u32x4_a1 ea = *(const u32x4_a1*)(s_fifo + 2u * (k - 1u)); /* events k - 1, k */
+          const u32x4_a1 eb = *(const u32x4_a1*)(s_fifo + 2u * (k + 1u)); /* events k + 1, k + 2 */
+          const u32 gs0 = ea[0], cu0 = ea[1], gs1 = ea[2], cu1 = ea[3], gs2 = eb[0], cu2 = eb[1];
+          /* [lo, a1) the rest of the gap in front | [a1, b1) source behind it | [b1, e1) the gap that starts here | [e1, hi) source */
+          int a1 = (int)(gs0 + (cu1 - cu0) - Cl);
+          a1 = a1 < lo ? lo : (a1 > hi ? hi : a1);
+          int b1 = (int)(gs1 - Cl);
+          b1 = b1 < a1 ? a1 : (b1 > hi ? hi : b1);
+          int e1 = (cu2 - cu1) >= 16u ? 16 : b1 + (int)(cu2 - cu1);
+          e1 = e1 > hi ? hi : e1;
+          bool more = (int)(gs2 - Cl) < hi;
+          u32 W0[4], W1[4];
+          buf_load16(sbuf, b1 > a1 ? (rc ? S32 - Cl + cu1 : S32 + Cl - cu1) : WGA_BUF_OOB, W0);
+          buf_load16(sbuf, hi > e1 ? (rc ? S32 - Cl + cu2 : S32 + Cl - cu2) : WGA_BUF_OOB, W1);
+          const u32x4_a16 La = s_lm[a1], Lb = s_lm[b1], Le = s_lm[e1];
+          u32 o[4], bad[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int d = 0; d < 4; d++) {
+            u32 cp;
+            if (rc)
+              cp = comp4s(bfi_b32(Lb[d], bswap32(W0[3 - d]), bswap32(W1[3 - d])), &bad[d]);
+            else
+              cp = bfi_b32(Lb[d], W0[d], W1[d]);
+            const u32 md = La[d] | (Le[d] & ~Lb[d]);
+            o[d] = bfi_b32(md, 0x2D2D2D2Du, cp);
+            bad[d] &= ~md;
+          }
+          u32 ie = k + 1u;
+          while (more) { /* further events inside the granule: one round per event (rare: gaps are ~150 columns apart) */
+            const u32 gsi = s_fifo[2u * ie], cui = s_fifo[2u * ie + 1u], gsn = s_fifo[2u * ie + 2u], cun = s_fifo[2u * ie + 3u];
+            const int b = (int)(gsi - Cl);
+            const u32 len = cun - cui;
+            const int e = len >= (u32)(hi - b) ? hi : b + (int)len;
+            u32 W[4];
+            buf_load16(sbuf, rc ? S32 - Cl + cun : S32 + Cl - cun, W);
+            const u32x4_a16 Mb = s_lm[b], Me = s_lm[e];
 #pragma unroll
             for (int d = 0; d < 4; d++) {
-              u32 cp;
-              if (rc)
-                cp = comp4s(bfi_b32(Lb[d], bswap32(W0[3 - d]), bswap32(W1[3 - d])), &bad[d]);
-              else
-                cp = bfi_b32(Lb[d], W0[d], W1[d]);
-              const u32 md = La[d] | (Le[d] & ~Lb[d]);
-              o[d] = bfi_b32(md, 0x2D2D2D2Du, cp);
-              bad[d] &= ~md;
+              u32 x = W[d], bw = 0u;
+              if (rc) x = comp4s(bswap32(W[3 - d]), &bw);
+              o[d] = bfi_b32(Mb[d], o[d], bfi_b32(Me[d], 0x2D2D2D2Du, x));
+              bad[d] = (bad[d] & Mb[d]) | (bw & ~Me[d]);
             }
-            u32 ie = k + 1u;
-            while (more) { /* further events inside the granule: one round per event (rare: gaps are ~150 columns apart) */
-              const u32 gsi = s_fifo[2u * ie], cui = s_fifo[2u * ie + 1u], gsn = s_fifo[2u * ie + 2u], cun = s_fifo[2u * ie + 3u];
-              const int b = (int)(gsi - Cl);
-              const u32 len = cun - cui;
-              const int e = len >= (u32)(hi - b) ? hi : b + (int)len;
-              u32 W[4];
-              buf_load16(sbuf, rc ? S32 - Cl + cun : S32 + Cl - cun, W);
-              const u32x4_a16 Mb = s_lm[b], Me = s_lm[e];
-#pragma unroll
-              for (int d = 0; d < 4; d++) {
-                u32 x = W[d], bw = 0u;
-                if (rc) x = comp4s(bswap32(W[3 - d]), &bw);
-                o[d] = bfi_b32(Mb[d], o[d], bfi_b32(Me[d], 0x2D2D2D2Du, x));
-                bad[d] = (bad[d] & Mb[d]) | (bw & ~Me[d]);
-              }
-              ie++;
-              more = (int)(gsn - Cl) < hi;
-            }
-            if (rc && (bad[0] | bad[1] | bad[2] | bad[3]) != 0u) /* InvalidBase */
-              stream_report_bad((u64*)&a.diag[rec].bad_base_pos, bad[0], bad[1], bad[2], bad[3], lo, hi, Cl, (i64)s_k[0], s_fifo, k, nf, 0u);
-            const u32x4_a16 ov = {o[0], o[1], o[2], o[3]};
-            s_P[lane] = ov;
+            ie++;
+            more = (int)(gsn - Cl) < hi;
           }
-          WGA_WAVE_SYNC();
-#pragma unroll
-          for (u32 u = 0; u < WGA_S_U; u++) {
-            const u32 r = (rpk >> (8u * u)) & 255u;
-            if (((flg >> u) & 1u) != 0u && (r >> 6) == (r0 >> 6)) {
-              const u32x4_a16 pv = s_P[r & 63u];
-              dat[u][0] = pv[0];
-              dat[u][1] = pv[1];
-              dat[u][2] = pv[2];
-              dat[u][3] = pv[3];
-            }
-          }
+          if (rc && (bad[0] | bad[1] | bad[2] | bad[3]) != 0u) /* InvalidBase */
+            stream_report_bad((u64*)&a.diag[rec].bad_base_pos, bad[0], bad[1], bad[2], bad[3], lo, hi, Cl, (i64)s_k[0], s_fifo, k, nf, 0u);
+          const u32x4_a16 ov = {o[0], o[1], o[2], o[3]};
+          s_P[lane] = ov;
         }
         WGA_WAVE_SYNC();
 
-        /* ---- (4) whole granules: one streaming store of the wave per kilobyte; partial ones (at most two): byte stores ---- */
+        /* ---- (4) the plain granules' windows, all requested at once; what the queue made replaces the queued ones; whole
+         *      granules leave in one streaming store of the wave per kilobyte, partial ones (at most two) in byte stores ---- */
+        u32 dat[WGA_S_U][4];
+        const u32 wsp2 = Ce - Cs - 16u; /* Ce may have moved */
 #pragma unroll
         for (u32 u = 0; u < WGA_S_U; u++) {
-          {
+          const u32 Cl = Cl0 + 1024u * u + 16u * lane;
+          const u32 c = (cls >> (4u * u)) & 15u;
+          dat[u][0] = dat[u][1] = dat[u][2] = dat[u][3] = (c & 2u) ? 0x2D2D2D2Du : 0u;
+          if ((c & 1u) && (int)(Cl - Ce) < 0) buf_load16(sbuf, rc ? S32 - Cl + adjv[u] : S32 + Cl - adjv[u], dat[u]);
+        }
+        if (rc) { /* the windows arrive: reverse complement ('-' and what the queue replaces pass through) */
+#pragma unroll
+          for (u32 u = 0; u < WGA_S_U; u++) {
+            u32 bad[4], x[4];
+#pragma unroll
+            for (int d = 0; d < 4; d++) x[d] = comp4s(bswap32(dat[u][3 - d]), &bad[d]);
+#pragma unroll
+            for (int d = 0; d < 4; d++) dat[u][d] = x[d];
+            /* InvalidBase in a plain granule (utils.rs:97); queued granules are checked where they are put together */
             const u32 Cl = Cl0 + 1024u * u + 16u * lane;
-            const bool whole = any16 && (Cl - Cs) <= wsp;
-            buf_store16_stream(dbuf, whole ? 1024u * u + 16u * lane : WGA_BUF_OOB, dat[u]);
-            if (((flg >> u) & 1u) != 0u && !whole) {
-              int lo = (int)(Cs - Cl), hi = (int)(Ce - Cl);
-              lo = lo < 0 ? 0 : lo;
-              hi = hi > 16 ? 16 : hi;
-              stream_store_bytes(B + 1024u * u + lane * 16u, dat[u][0], dat[u][1], dat[u][2], dat[u][3], lo, hi);
+            const bool pb = ((cls >> (4u * u)) & 1u) != 0u && (int)(Cl - Ce) < 0 && (bad[0] | bad[1] | bad[2] | bad[3]) != 0u;
+            if (__ballot(pb)) {
+              if (pb)
+                stream_report_bad((u64*)&a.diag[rec].bad_base_pos, bad[0], bad[1], bad[2], bad[3], 0, 16, Cl, (i64)s_k[0], nullptr, 0u, 0u,
+                                  adjv[u]);
             }
           }
         }
+#pragma unroll
+        for (u32 u = 0; u < WGA_S_U; u++) {
+          const u32 Cl = Cl0 + 1024u * u + 16u * lane;
+          const bool queued = ((cls >> (4u * u)) & 4u) != 0u && (int)(Cl - Ce) < 0;
+          if (queued) {
+            const u32x4_a16 pv = s_P[(rpk >> (8u * u)) & 255u];
+            dat[u][0] = pv[0];
+            dat[u][1] = pv[1];
+            dat[u][2] = pv[2];
+            dat[u][3] = pv[3];
+          }
+          const bool whole = (Ce - Cs) >= 16u && (Cl - Cs) <= wsp2;
+          buf_store16_stream(dbuf, whole ? 1024u * u + 16u * lane : WGA_BUF_OOB, dat[u]);
+          if (queued && !whole) {
+            int lo = (int)(Cs - Cl), hi = (int)(Ce - Cl);
+            lo = lo < 0 ? 0 : lo;
+            hi = hi > 16 ? 16 : hi;
+            stream_store_bytes(B + 1024u * u + lane * 16u, dat[u][0], dat[u][1], dat[u][2], dat[u][3], lo, hi);
+          }
+        }
+        WGA_WAVE_SYNC(); /* the patch buffer and the queue are rewritten by the next super-step */
         e0 += nE;
         pos = Ce;
       }
@@ -440,9 +454,15 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
       /* the next boundary among the ops that are in (none right after a start) */
       bnd = false;
       if (sw && re < q_hi) {
-        const u32 kb = re - q_lo, e = kb & 3u;
-        const u32 vl = xl0 + (e > 0u ? l[0] : 0u) + (e > 1u ? l[1] : 0u) + (e > 2u ? l[2] : 0u);
-        const u32 vg = xg0 + (e > 0u ? g[0] : 0u) + (e > 1u ? g[1] : 0u) + (e > 2u ? g[2] : 0u);
+        const u32 kb = re - q_lo, e = kb & 3u; /* the columns / gap bases in front of op kb: its lane's prefix + its ops in front */
+        u32 vl = xl0, vg = xg0;
+#pragma unroll
+        for (u32 i = 0; i < 3u; i++) {
+          const bool valid = q_lo + 4u * lane + i < q_hi && i < e;
+          const u32 len = valid ? ow[i] >> 4 : 0u, code = ow[i] & 15u;
+          vl += len & bit_mask(0x787u, code);
+          vg += len & bit_mask(QROW ? 0x404u : 0x202u, code);
+        }
         C_b = wave_get_u32_dyn(vl, kb >> 2);
         cum_b = wave_get_u32_dyn(vg, kb >> 2);
         bnd = true;
@@ -493,9 +513,9 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
     q_lo = q;
     q_hi = q + 256u < q_end ? q + 256u : q_end;
     q = q_hi;
-    const u32 ow[4] = {own[0], own[1], own[2], own[3]};
+    ow[0] = own[0], ow[1] = own[1], ow[2] = own[2], ow[3] = own[3];
     buf_load16(obuf, q_hi < q_end ? q_hi * 4u + lane * 16u : WGA_BUF_OOB, own); /* the next 256 travel while these are worked on */
-    u32 sl = 0, sg = 0, sc = 0;
+    u32 l[4], g[4], sl = 0, sg = 0, sc = 0;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const bool valid = q_lo + 4u * lane + (u32)e < q_hi;
@@ -531,9 +551,15 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
     }
     WGA_WAVE_SYNC();
     if (re < q_hi) { /* a record ends among these ops */
-      const u32 kb = re - q_lo, e = kb & 3u;
-      const u32 vl = xl0 + (e > 0u ? l[0] : 0u) + (e > 1u ? l[1] : 0u) + (e > 2u ? l[2] : 0u);
-      const u32 vg = xg0 + (e > 0u ? g[0] : 0u) + (e > 1u ? g[1] : 0u) + (e > 2u ? g[2] : 0u);
+      const u32 kb = re - q_lo, e = kb & 3u; /* the columns / gap bases in front of op kb: its lane's prefix + its ops in front */
+      u32 vl = xl0, vg = xg0;
+#pragma unroll
+      for (u32 i = 0; i < 3u; i++) {
+        const bool valid = q_lo + 4u * lane + i < q_hi && i < e;
+        const u32 len = valid ? ow[i] >> 4 : 0u, code = ow[i] & 15u;
+        vl += len & bit_mask(0x787u, code);
+        vg += len & bit_mask(QROW ? 0x404u : 0x202u, code);
+      }
       C_b = wave_get_u32_dyn(vl, kb >> 2);
       cum_b = wave_get_u32_dyn(vg, kb >> 2);
       bnd = true;
@@ -564,7 +590,7 @@ __device__ __forceinline__ void expand_stream(const ExpandArgs& a) {
     stream_row<true>(a, lds, lane, t0, t1);
 }
 #ifndef WGA_S_WAVES_PER_SIMD
-#define WGA_S_WAVES_PER_SIMD 2 /* launch bound (waves per SIMD the register budget is sized for; LDS allows ~11 waves per CU) */
+#define WGA_S_WAVES_PER_SIMD 5 /* launch bound: 96 VGPRs (the natural need is 102: two spill slots), LDS allows 31 waves per CU; 4: 6.0 ms, 5: 5.66 ms, 6 (61 spill slots): 7.4 ms */
 #endif
 __global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_paf2maf_expand_s(ExpandArgs a) { expand_stream(a); }
 __global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_paf2maf_expand_s_alias(ExpandArgs a) { expand_stream(a); }
