@@ -148,12 +148,15 @@ def test_paf2maf_stream_kernel_jobs_and_skips(emu):
 
 
 def test_expand_variant_by_the_batch(emu):
-    """expand_variant -1 (the default): short records take the window kernel, long ones v1; the bytes are the oracle's"""
+    """expand_variant -1 (the default): records of a few dozen ops take the window kernel, everything else the streaming
+    kernel; the bytes are the oracle's"""
     emu.set_param("expand_variant", -1)
-    pc.check_paf2maf(emu, synth.make_paf_batch(41, 30, 200, 30000))
+    pc.check_paf2maf(emu, synth.make_paf_batch(41, 60, 40, 30000))
     assert emu.get_param("expand_variant_used") == 2
+    pc.check_paf2maf(emu, synth.make_paf_batch(41, 30, 200, 30000))
+    assert emu.get_param("expand_variant_used") == 3
     pc.check_paf2maf(emu, synth.make_paf_batch(42, 3, 3000, 90000))
-    assert emu.get_param("expand_variant_used") == 0
+    assert emu.get_param("expand_variant_used") == 3
     emu.set_param("expand_variant", pc.DEFAULT_EXPAND_VARIANT)
 
 

@@ -42,7 +42,7 @@
 #define WGA_S_U 4u /* kilobytes of a row one super-step writes: the queued granules of that many share one round of the merge code */
 #define WGA_S_WAVE_BYTES ((WGA_S_FIFO + 4u) * 8u + 1024u + 1024u + 256u + 272u + 16u)
 #ifndef WGA_AUTO_LONG_VARIANT
-#define WGA_AUTO_LONG_VARIANT 0 /* the row kernel of batches of long records when "expand_variant" is -1: 0 = v1, 3 = this one */
+#define WGA_AUTO_LONG_VARIANT 3 /* the row kernel of every other batch when "expand_variant" is -1: this one (0 = v1, for A/B builds) */
 #endif
 
 /* ---- pre-pass: which tiles the streaming kernel leaves to v1 ------------------------------------------------------- */

@@ -45,7 +45,7 @@
 #define WGA_K2W_BLOCKS 4 /* 128 VGPRs, no scratch; five blocks (96 VGPRs) spill and lose 25 % */
 #endif
 #ifndef WGA_AUTO_SHORT_OPS
-#define WGA_AUTO_SHORT_OPS 1500ull /* batches below this many ops per record take the window kernel when "expand_variant" is -1 */
+#define WGA_AUTO_SHORT_OPS 100ull /* batches below this many ops per record take the window kernel when "expand_variant" is -1 (same buffers, round 4: 30-op records 6.1 against 7.3 ms for the streaming kernel, 60-op 7.0 / 7.4, 100-op 8.0 / 8.0, 200-op 8.1 / 6.9) */
 #endif
 
 /* The kernel's arguments for the code behind phase A: only the planner and the rare paths read them, so they are
