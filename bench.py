@@ -112,7 +112,7 @@ def kernel_source_sha():
     """the row kernel's source: roofline.traffic is only valid for the kernel it was measured on"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("wga_kernels.h", "wga_kernels_k2w.h", "wga_intrin.h"):
+    for f in ("wga_kernels.h", "wga_kernels_k2w.h", "wga_kernels_k2s.h", "wga_intrin.h"):
         h.update(open(os.path.join(ROOT, "wgatools_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -121,7 +121,7 @@ def pmc_traffic(args, job):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE and WRITE_SIZE are
     collected in their own rocprofv3 runs — scripts/gpu_pmc.sh — and corrected as MI355X_MICROARCH.md prescribes; they
     cannot be read live).  Only valid for the workload AND the kernel source they were measured on: anything else -> null."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
@@ -288,6 +288,63 @@ def north_star(args):
     eng.close()
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU, the environment the driver's
+    torch.distributed.run line would give them) and pass rank 0's line through.  Fewer than N devices: exit code 2."""
+    import subprocess
+    try:
+        import torch
+        have = torch.cuda.device_count()
+    except Exception:  # noqa: BLE001
+        have = 0
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d but %d device(s) visible\n" % (n, have))
+        raise SystemExit(2)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    raise SystemExit(rc)
+
+
+def strong_plan(args, world):
+    """The strong-scaling job: ONE global batch of --records over the targets of a 64-way all-to-all (PanSN names, human-like
+    contig sizes, records in proportion to the contig's size; or --targets equal-sized names), and who owns which target under
+    both assignment rules.  Pure host work (numpy): `--plan-only` prints it without a GPU."""
+    import numpy as np
+    from wgatools_amd import multigpu, synth
+    gseed = 0x5747415F + 2
+    n_ops_all = synth.record_lengths(gseed, args.records, args.mean_ops)
+    rng = np.random.default_rng(gseed + 1)
+    if args.targets > 0:
+        names = ["g%02d#1#chr1" % k for k in range(args.targets)]
+        p = 1.0 / np.arange(1, args.targets + 1) ** args.zipf
+        what = "%d equal-sized targets (zipf %.2f)" % (args.targets, args.zipf)
+    else:
+        names, mb = multigpu.human_like_targets(args.genomes)
+        p = mb / np.arange(1, len(names) + 1) ** args.zipf
+        what = "%d assemblies x chr1 .. chrY (PanSN names, records in proportion to the contig's size%s)" % (
+            args.genomes, ", zipf %.2f" % args.zipf if args.zipf else "")
+    tid = rng.choice(len(names), size=args.records, p=p / p.sum())
+    rec_names = [names[k] for k in tid]
+    own = {"hash": multigpu.owners(rec_names, world), "lpt": multigpu.owners_lpt(rec_names, n_ops_all, world)}
+    rep = {"targets": what, "ranks": world, "assign": args.assign}
+    for k, o in own.items():
+        per = np.bincount(o, weights=n_ops_all.astype(np.float64), minlength=world)
+        rep["ops_per_rank_" + k] = [float(x) for x in per]
+        rep["imbalance_max_over_mean_" + k] = float(per.max() / per.mean()) if per.mean() > 0 else 1.0
+    return {"owner": own[args.assign], "n_ops_all": n_ops_all, "report": rep}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -309,15 +366,24 @@ def main():
                     help="strong (default): ONE global batch of --records whatever N — the file-shaped job: every rank takes the "
                          "records fnv1a64(target_name) %% N gives it, ordered output through one all-reduce of the record sizes; "
                          "weak: --records per GPU, independently generated shards")
-    ap.add_argument("--targets", type=int, default=1600, help="strong scaling: number of target names (default: the contigs of a "
-                                                              "64-genome all-to-all, 64 x 25)")
+    ap.add_argument("--targets", type=int, default=0, help="strong scaling: number of equal-sized target names gNN#1#chr1 (0, the "
+                                                           "default: the 64 x 24 contigs of 64 human-like assemblies, chr1 .. chrY at "
+                                                           "their sizes, records in proportion to the contig's size)")
+    ap.add_argument("--genomes", type=int, default=64, help="strong scaling: assemblies of the default target set")
+    ap.add_argument("--assign", choices=["hash", "lpt"], default="hash",
+                    help="strong scaling: which rank owns a target — hash: fnv1a64(target_name) %% N, the product's rule (no table, no "
+                         "pass over the input); lpt: targets by their total ops, heaviest first, each to the lightest rank so far.  "
+                         "The line reports the imbalance of both")
+    ap.add_argument("--plan-only", action="store_true", help="print the strong-scaling partition of --gpus ranks (ops per rank and "
+                                                             "imbalance under both assignments) and exit: needs no GPU")
     ap.add_argument("--zipf", type=float, default=0.0, help="strong scaling: skew of the records over the targets "
                                                             "(P(target k) ~ 1 / (k + 1)^zipf; 0 = uniform, the default)")
-    ap.add_argument("--no-placement-probe", action="store_true", help="take the first output buffer the allocator returns instead "
-                    "of the arena the library places for the job (wga_paf2maf_expand_place, --placement-candidates)")
+    ap.add_argument("--placement-sweep", action="store_true", help="after the timed steps (which run on the FIRST output buffer the "
+                    "allocator returns: that is the headline), also let the library place the output arena among "
+                    "--placement-candidates arenas (wga_paf2maf_expand_place) and report what the best of them gives")
+    ap.add_argument("--no-placement-probe", action="store_true", help="(accepted for older command lines: the first allocation is the default now)")
     ap.add_argument("--placement-candidates", type=int, default=12,
-                    help="candidate output arenas the library places the job among (12 x 15 GB on configs[1]: the regions of HBM that are fast "
-                         "for the row kernel are about a third of them; fewer are tried when memory runs out)")
+                    help="--placement-sweep: candidate output arenas (12 x 15 GB on configs[1]; fewer are tried when memory runs out)")
     ap.add_argument("--north-star", action="store_true", help="the 10 M x 50 kop headline shape as a stream of resident batches (N = 1)")
     ap.add_argument("--ns-records", type=int, default=400_000)
     ap.add_argument("--ns-batch-records", type=int, default=40_000)
@@ -325,6 +391,10 @@ def main():
     args = ap.parse_args()
     if args.north_star:
         return north_star(args)
+    if args.plan_only:
+        return print(json.dumps(strong_plan(args, max(1, args.gpus))["report"]), flush=True)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)     # a bare `python bench.py --gpus N`: this process starts the N ranks itself
 
     import torch
     import torch.distributed as dist
@@ -333,6 +403,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    if world != args.gpus and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE %d: the line reports n_gpus = %d\n" % (args.gpus, world, world))
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d wants device %d, %d visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # --force-dist: the process group and every collective of the N > 1 path also at world size 1 (so that the RCCL branches
@@ -353,14 +427,8 @@ def main():
     if strong:
         # ONE global batch whatever N: record lengths and target names from the global seed; a rank generates the records
         # fnv1a64(target_name) % N gives it (the product's sharding rule), so the skew over targets becomes load imbalance
-        import numpy as np
-        gseed = 0x5747415F + 2
-        n_ops_all = synth.record_lengths(gseed, args.records, args.mean_ops)
-        rng = np.random.default_rng(gseed + 1)
-        p = 1.0 / np.arange(1, args.targets + 1) ** args.zipf
-        tid = rng.choice(args.targets, size=args.records, p=p / p.sum())
-        names = ["g%02d#1#chr1" % k for k in range(args.targets)]
-        owner = multigpu.owners([names[k] for k in tid], world)
+        plan = strong_plan(args, world)
+        n_ops_all, owner = plan["n_ops_all"], plan["owner"]
         mine = multigpu.my_records(owner, rank)
         tb = synth.make_paf_batch_torch(seed, len(mine), args.mean_ops, args.pool_mb * 1_000_000, dev,
                                         neg_frac=args.neg_frac, use_m=args.m_only, n_ops=n_ops_all[mine])
@@ -369,50 +437,9 @@ def main():
     else:
         tb = synth.make_paf_batch_torch(seed, args.records, args.mean_ops, args.pool_mb * 1_000_000, dev,
                                         neg_frac=args.neg_frac, use_m=args.m_only)
+    # The timed steps run on the FIRST output buffer the allocator returns: no placement policy, what any caller gets.
     placement = None
-    first_alloc_ms = None
-    if world == 1 and not args.param:
-        # what the FIRST buffer the allocator returns gives (no placement policy): five warming steps (first touch + the
-        # library's drain_min trials), then three timed launches of the row kernel; reported next to the arena's number
-        try:
-            eng.set_param("expand_alias", 1)       # these launches go under the kernel's second name (rocprofv3 --stats keeps
-            job0 = pipeline.Paf2MafStatJob(eng, tb)  # the timed steps' kernel apart from every other shape / buffer)
-            job0.bind_stream()
-            for _ in range(5):
-                job0.step()
-            torch.cuda.synchronize()
-            eng.set_param("expand_timing", 1)
-            eng.expand_timing()
-            for _ in range(3):
-                job0.expand()
-            torch.cuda.synchronize()
-            t_ms, t_n = eng.expand_timing()
-            first_alloc_ms = t_ms / max(1, t_n)
-            del job0
-        except Exception as e:  # noqa: BLE001
-            first_alloc_ms = None
-            placement = {"first_allocation_error": "%s: %s" % (type(e).__name__, e)}
-        finally:
-            eng.set_param("expand_alias", 0)
-            torch.cuda.empty_cache()
-    job = None
-    if not args.no_placement_probe:
-        # where the output arena lies in HBM sets the row kernel's level: the library places it for the
-        # job (wga_paf2maf_expand_place, the same call the `wgatools` command line makes for its row buffer) — the launches
-        # of the placement run under the kernel's second name, so that rocprofv3 --stats holds the timed steps only
-        try:
-            eng.set_param("expand_alias", 1)
-            job = pipeline.Paf2MafStatJob(eng, tb, place=args.placement_candidates)
-            job.bind_stream()
-            placement = dict(placement or {}, **job.place_output())
-        except Exception as e:  # noqa: BLE001  (the placement is a policy, not a requirement: fall back to the first allocation)
-            job = None
-            torch.cuda.empty_cache()
-            placement = dict(placement or {}, policy="first allocation (the placement call failed: %s: %s)" % (type(e).__name__, e))
-        finally:
-            eng.set_param("expand_alias", 0)
-    if job is None:
-        job = pipeline.Paf2MafStatJob(eng, tb)
+    job = pipeline.Paf2MafStatJob(eng, tb)
     job.bind_stream()
     totals = torch.zeros(11, dtype=torch.int64, device=dev)
 
@@ -467,6 +494,12 @@ def main():
     elapsed = float(el.item())
     total_ops = float(nops.item())
 
+    ranks_seen = None
+    if dist_on:   # every rank adds one: what RCCL itself saw
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+
     # the run only counts if every record came out clean
     if not args.param:
         assert bool((job.diag == -1).all()), "kernel reported per-record errors on clean synthetic input"
@@ -496,6 +529,32 @@ def main():
         k_expand_call = sum(e[2].elapsed_time(e[3]) for e in events) / args.steps   # pre-pass + kernel
         ms_sum, n_timed = eng.expand_timing()
         k_expand = ms_sum / n_timed if n_timed else k_expand_call
+        variant_used = eng.get_param("expand_variant_used")
+        kernel_name = {0: "k_paf2maf_expand", 2: "k_paf2maf_expand_w", 3: "k_paf2maf_expand_s"}.get(variant_used, "k_paf2maf_expand")
+        placed_ms = None
+        if args.placement_sweep and world == 1 and not args.param:
+            # what the best of N candidate arenas would give (the level of the row kernel follows the region of HBM its output
+            # lies in): the library's placement call, launches under the kernel's second name
+            try:
+                eng.set_param("expand_alias", 1)
+                jp = pipeline.Paf2MafStatJob(eng, tb, place=args.placement_candidates)
+                jp.bind_stream()
+                placement = jp.place_output()
+                for _ in range(3):
+                    jp.step()
+                torch.cuda.synchronize()
+                eng.expand_timing()
+                for _ in range(3):
+                    jp.expand()
+                torch.cuda.synchronize()
+                t_ms, t_n = eng.expand_timing()
+                placed_ms = t_ms / max(1, t_n)
+                del jp
+            except Exception as e:  # noqa: BLE001
+                placement = {"error": "%s: %s" % (type(e).__name__, e)}
+            finally:
+                eng.set_param("expand_alias", 0)
+                torch.cuda.empty_cache()
         ab = job.algorithmic_bytes()
         in_bytes = 4 * job.n_ops + int(tb["t_src_len"].sum()) + int(tb["q_src_len"].sum())
         ach = ab["expand"] / (k_expand * 1e-3) / 1e9
@@ -519,27 +578,27 @@ def main():
                 "records_per_gpu": args.records, "ops_per_gpu": job.n_ops,
                 "columns_per_gpu": int((tb["mx"] + tb["i"] + tb["d"]).sum()),
                 "output_bytes_per_gpu": job.out_bytes,
-                "sharding": ("one global batch of %d records over %d target names (zipf %.2f), rank = fnv1a64(target_name) %% N; "
+                "sharding": ("one global batch of %d records, a target's records on one rank (--assign %s); "
                              "per step one all-reduce of the per-record output sizes (ordered output) and one of the stat "
-                             "totals; row bytes never cross GPUs" % (args.records, args.targets, args.zipf)) if strong
+                             "totals; row bytes never cross GPUs" % (args.records, args.assign)) if strong
                             else "records, no data-path collective",
                 "ops_per_rank": per_rank_ops, "imbalance_max_over_mean": imb,
+                "partition": plan["report"] if strong else None,
+                "ranks_seen_by_rccl": ranks_seen,
             },
             "input_GBps": in_bytes * world * args.steps / elapsed / 1e9,
-            "kernel_ms": {"k_cigar_stat": k_stat, "layout_scan": k_layout, "k_paf2maf_expand": k_expand,
-                          "expand_prepass (k_rec_desc + k_tile_base)": k_expand_call - k_expand},
-            "output_placement": placement,
-            "expand_drain_min": {"used": eng.get_param("expand_drain_min"),
-                                 "autotune_settled": eng.get_param("expand_autotune_settled"),
-                                 "note": "when a wave emits its queued gap-touching chunks; tried 64 / 32 / 16 on the warm-up "
-                                         "launches, same bytes (include/wga_hip.h, wga_ctx_set_param)"},
+            "kernel_ms": {"k_cigar_stat": k_stat, "layout_scan": k_layout, kernel_name: k_expand,
+                          "expand_prepass (k_rec_desc + k_tile_base + marks)": k_expand_call - k_expand},
+            "row_kernel": {"expand_variant_used": variant_used, "name": kernel_name,
+                           "tiles_left_to_v1": eng.get_param("expand_stream_left_to_v1") if variant_used == 3 else None},
+            "output_placement": placement if placement is not None else "first allocation (the default; --placement-sweep tries more)",
             "roofline": {
-                "kernel": "k_paf2maf_expand", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                "kernel": kernel_name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args, job),
                 "algorithmic_bytes_per_launch": ab["expand"],
-                # the same kernel on the first buffer the allocator returns (no placement policy at all)
-                "frac_first_allocation": (ab["expand"] / (first_alloc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if first_alloc_ms else None,
-                "kernel_ms_first_allocation": first_alloc_ms,
+                "output_buffer": "first allocation (no placement policy)",
+                # --placement-sweep: the same kernel on the best of the candidate arenas
+                "frac_placed_best_of_%d" % args.placement_candidates: (ab["expand"] / (placed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if placed_ms else None,
                 "k_cigar_stat_GBps": ab["stat"] / (k_stat * 1e-3) / 1e9,
                 # paf2maf+stat priced both ways.  The step runs K1 and K2 as two kernels, so the packed ops
                 # are read twice (unfused); a fused walk would read them once.

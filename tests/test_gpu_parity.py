@@ -150,6 +150,7 @@ def test_paf2maf_drain_autotune_same_bytes(gpu):
     from wgatools_amd import pipeline
     gpu.set_stream(torch.cuda.current_stream().cuda_stream)
     gpu.set_param("expand_autotune", 1)
+    gpu.set_param("expand_variant", 0)      # drain_min is v1's (the row kernel of the tiles the streaming kernel leaves to it)
     job = pipeline.Paf2MafStatJob(gpu, tb)
     job.stat(); job.layout()
     sums, used = [], []
@@ -167,6 +168,7 @@ def test_paf2maf_drain_autotune_same_bytes(gpu):
     job.expand(); torch.cuda.synchronize()
     assert gpu.get_param("expand_drain_min") == 32          # 2 x 20 MB pools, no trials
     gpu.set_param("expand_autotune", 1)
+    gpu.set_param("expand_variant", pc.DEFAULT_EXPAND_VARIANT)
     gpu.reset_stream()
 
 
@@ -209,6 +211,20 @@ def test_output_arena_placed_by_the_job(gpu):
     gpu.reset_stream()
 
 
+def test_paf2maf_stream_kernel(gpu):
+    """the streaming row kernel (expand_variant 3, the default of every batch but those of tiny records) against the oracle"""
+    pc.window_kernel_cases(gpu, variant=3)
+    pc.stream_kernel_cases(gpu)
+    pc.check_paf2maf(gpu, synth.make_paf_batch(6, 500, 400, 2_000_000), variant=3)
+    pc.check_paf2maf(gpu, synth.make_paf_batch(12, 1, 300_000, 1_500_000, sigma=0.01), variant=3)   # one record over ~300 tiles
+    for seed in range(30, 40):
+        n = int(np.random.default_rng(seed).integers(1, 300))
+        mean = int(np.random.default_rng(seed + 1).integers(1, 3000))
+        b = synth.make_paf_batch(seed, n, mean, 300000, use_m=bool(seed & 1))
+        rng = np.random.default_rng(seed)
+        pc.check_paf2maf(gpu, b, pre=(rng.integers(0, 130, n), rng.integers(0, 130, n), rng.integers(0, 5, n)), variant=3)
+
+
 def test_paf2maf_window_kernel(gpu):
     pc.window_kernel_cases(gpu)
     pc.check_paf2maf(gpu, synth.make_paf_batch(6, 500, 400, 2_000_000), variant=2)
@@ -225,8 +241,8 @@ def test_paf2maf_window_kernel(gpu):
 
 
 def test_paf2maf_kernels_agree_at_size(gpu):
-    """the two row kernels over whole BASELINE-sized batches (configs[1], 500-op records, 30-op records): every byte of the
-    output text identical, on the device"""
+    """the three row kernels (v1, window, streaming) over whole BASELINE-sized batches (configs[1], 500-op records, 30-op
+    records): every byte of the output text identical, on the device"""
     import torch
     from wgatools_amd import pipeline
     dev = torch.device("cuda", 0)
@@ -234,7 +250,7 @@ def test_paf2maf_kernels_agree_at_size(gpu):
     for rec, mean, pool in [(100_000, 5000, 50), (1_000_000, 500, 50), (3_000_000, 30, 20)]:
         tb = synth.make_paf_batch_torch(0x5747415F + 2, rec, mean, pool * 1_000_000, dev)
         outs = []
-        for v in (0, 2):
+        for v in (0, 2, 3):
             gpu.set_param("expand_variant", v)
             job = pipeline.Paf2MafStatJob(gpu, tb, with_text=True)
             job.out.fill_(0x23)
@@ -244,14 +260,14 @@ def test_paf2maf_kernels_agree_at_size(gpu):
             assert bool((job.diag == -1).all()) and gpu.get_param("expand_variant_used") == v
             outs.append(job.out)
             del job
-        assert bool(torch.equal(outs[0], outs[1])), (rec, mean)
+        assert bool(torch.equal(outs[0], outs[1])) and bool(torch.equal(outs[0], outs[2])), (rec, mean)
         del outs, tb
         torch.cuda.empty_cache()
     gpu.set_param("expand_variant", pc.DEFAULT_EXPAND_VARIANT)
     gpu.reset_stream()
 
 
-@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("variant", [0, 2, 3])
 def test_paf2maf_wide_tile_auto_slow_path(gpu, variant):
     """one tile wider than 2^31 columns (9 D ops of 2^28-1) takes the u64 fallback by itself (variant 2: through the
     list of such tiles that the window kernel leaves to v1's op-serial walk)"""
@@ -998,3 +1014,40 @@ def test_fasta_pool(gpu):
 
 def test_bgzf_inflate(gpu):
     pc.check_bgzf_inflate(gpu)
+
+
+@pytest.mark.gpu
+def test_reduce_scatter_i32_on_hardware(monkeypatch):
+    """wga_reduce_scatter_i32 (pafcov --spread: the coverage merge of pafcov.rs:29-53 across devices) with its peer copies and
+    adds executed by the GPU: three contexts on the one device of this box (WGA_REDUCE_SCATTER_SAME_DEVICE lifts the
+    one-context-per-device rule for this test); slice g of buffer g = the sum over the contexts, the rest untouched"""
+    import ctypes as C
+    import torch  # noqa: F401
+    from wgatools_amd import build, _lib
+    monkeypatch.setenv("WGA_REDUCE_SCATTER_SAME_DEVICE", "1")
+    lib = _lib.load(build.HIP_LIB)
+    engs = [engine.Engine(0, lib) for _ in range(3)]
+    rng = np.random.default_rng(4)
+    try:
+        for count in (1, 7, 70001, 25_000_000):
+            host = [rng.integers(-1000, 1000, count, dtype=np.int32) for _ in range(3)]
+            bufs = [e.upload(h) for e, h in zip(engs, host)]
+            cx = (C.c_void_p * 3)(*[e.ctx for e in engs])
+            bp = (C.c_void_p * 3)(*[b.ptr for b in bufs])
+            assert lib.wga_reduce_scatter_i32(cx, 3, bp, count) == 0
+            total = host[0].astype(np.int64) + host[1] + host[2]
+            for g in range(3):
+                lo, hi = count * g // 3, count * (g + 1) // 3
+                got = bufs[g].numpy()[:count]
+                assert (got[lo:hi] == total[lo:hi]).all(), (count, g)
+                mask = np.ones(count, dtype=bool)
+                mask[lo:hi] = False
+                assert (got[mask] == host[g][mask]).all(), (count, g)
+            for b in bufs:
+                b.free()
+        dup = (C.c_void_p * 2)(engs[0].ctx, engs[0].ctx)
+        b2 = (C.c_void_p * 2)(None, None)
+        assert lib.wga_reduce_scatter_i32(dup, 2, b2, 0) == -1
+    finally:
+        for e in engs:
+            e.close()

@@ -21,7 +21,7 @@ import numpy as np
 
 from . import shard
 
-__all__ = ["owners", "my_records", "ordered_offsets", "write_ordered", "allreduce_totals", "hot_target_coverage",
+__all__ = ["owners", "owners_lpt", "human_like_targets", "my_records", "ordered_offsets", "write_ordered", "allreduce_totals", "hot_target_coverage",
            "imbalance"]
 
 
@@ -35,6 +35,43 @@ def owners(target_names, world):
             o = uniq[t] = shard.shard_of(t, world)
         out[i] = o
     return out
+
+
+def owners_lpt(target_names, weights, world):
+    """Size-aware assignment of TARGETS to ranks (every record of a target stays on one rank, as the hash rule keeps it):
+    targets sorted by their total weight (ops), heaviest first, each to the rank that is lightest so far (LPT).  The
+    hash rule needs no table and no pass over the input; this one needs the per-target totals first (one pass over the PAF's
+    first columns) and gives an imbalance near 1 when a few targets are large.  Returns the owner rank of every record."""
+    import heapq
+    names = list(target_names)
+    w = {}
+    for t, x in zip(names, weights):
+        w[t] = w.get(t, 0) + int(x)
+    heap = [(0, r) for r in range(world)]
+    heapq.heapify(heap)
+    owner_of = {}
+    for t in sorted(w, key=lambda t: (-w[t], t)):
+        load, r = heapq.heappop(heap)
+        owner_of[t] = r
+        heapq.heappush(heap, (load + w[t], r))
+    return np.fromiter((owner_of[t] for t in names), dtype=np.int32, count=len(names))
+
+
+HUMAN_CONTIG_MB = [248, 242, 198, 190, 182, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57]
+HUMAN_CONTIG_NAMES = ["chr%d" % k for k in range(1, 23)] + ["chrX", "chrY"]
+
+
+def human_like_targets(genomes=64):
+    """target names and sizes (Mb) of a pangenome of `genomes` human-like assemblies in PanSN naming (sample#hap#contig):
+    chr1 .. chrY at their GRCh38 sizes — what a 64-way all-to-all PAF holds, instead of equal-sized gNN#1#chr1 names whose
+    hashes happen to split evenly"""
+    names, sizes = [], []
+    for g in range(genomes):
+        sample = "HG%05d" % (2000 + 7 * g)
+        for c, mb in zip(HUMAN_CONTIG_NAMES, HUMAN_CONTIG_MB):
+            names.append("%s#%d#%s" % (sample, 1 + (g & 1), c))
+            sizes.append(mb)
+    return names, np.asarray(sizes, dtype=np.float64)
 
 
 def my_records(owner, rank):
