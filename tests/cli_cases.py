@@ -1219,3 +1219,73 @@ def test_maf_streaming_pieces_give_the_same_bytes(cli, tmp_path):
                 os.environ.pop("WGA_CHUNK_BYTES", None)
         assert res[0][0] == 0, (args, res[0][2])
         assert res[0][:2] == res[1][:2] == res[2][:2], args
+
+
+# ---- ties to the reference's own fixtures (the headline functions have no reference-held vector; these two
+#      round trips at least start and end on files the reference repository holds) --------------------------------------
+def test_fixture_maf_paf_maf_roundtrip(cli, tmp_path):
+    """test/test.maf -> maf2paf -> paf2maf gives back the fixture's two alignment rows byte for byte (parse_maf_seq_to_cigar
+    cigar.rs:344-432, then parse_cigar_to_insert cigar.rs:492-551 on the block's ungapped rows as the FASTA slices).  The
+    contigs are cut down to the aligned stretch (the 182 Mb around it are not in the fixture): coordinates are rebased to 0."""
+    maf = open(os.path.join(GOLDEN, "test.maf"), "rb").read().decode()
+    srows = [ln.split() for ln in maf.splitlines() if ln.startswith("s")]
+    assert len(srows) == 2
+    (_, tn, ts, tz, tstr, tsrc, trow), (_, qn, qs, qz, qstr, qsrc, qrow) = srows
+    assert tstr == "+" and qstr == "+"
+    rc, out, err = run(cli, "maf2paf", os.path.join(GOLDEN, "test.maf"))
+    assert rc == 0, err
+    f = out.decode().rstrip("\n").split("\t")
+    assert f[0] == qn and f[5] == tn and int(f[2]) == int(qs) and int(f[7]) == int(ts)
+    t_seq, q_seq = trow.replace("-", ""), qrow.replace("-", "")
+    assert len(t_seq) == int(tz) and len(q_seq) == int(qz)
+    # the same record on contigs that hold just the aligned stretch
+    f[1], f[2], f[3] = str(len(q_seq)), "0", str(len(q_seq))
+    f[6], f[7], f[8] = str(len(t_seq)), "0", str(len(t_seq))
+    paf = tmp_path / "rt.paf"
+    paf.write_text("\t".join(f) + "\n")
+    t_fa, q_fa = tmp_path / "t.fa", tmp_path / "q.fa"
+    t_fa.write_text(">%s\n%s\n" % (tn, t_seq))
+    q_fa.write_text(">%s\n%s\n" % (qn, q_seq))
+    rc, out, err = run(cli, "paf2maf", str(paf), "-g", str(t_fa), "-q", str(q_fa))
+    assert rc == 0, err
+    got = [ln.split("\t") for ln in out.decode().splitlines() if ln.startswith("s\t")]
+    assert len(got) == 2
+    assert got[0][1] == tn and got[0][3] == tz and got[0][4] == "+" and got[0][6] == trow
+    assert got[1][1] == qn and got[1][3] == qz and got[1][4] == "+" and got[1][6] == qrow
+    # ... and the MAF made from them reads back as the fixture's PAF record (the CIGAR of Appendix B.2)
+    back = tmp_path / "back.maf"
+    back.write_bytes(out)
+    rc, out2, err = run(cli, "maf2paf", str(back))
+    assert rc == 0, err
+    assert out2.decode().rstrip("\n").split("\t")[12:] == f[12:]
+
+
+def test_fixture_paf_chain_paf_roundtrip(cli, tmp_path):
+    """test/testdotplot.paf -> paf2chain -> chain2paf: coordinates (the '+' record's; the '-' record's as the reference's header
+    arithmetic leaves them), strands and the CIGAR of both records come back
+    (parse_cigar_to_chain cigar.rs:251-295 with the header math of chain.rs:103-183, then parse_chain_to_cigar
+    cigar.rs:554-627).  chain2paf recomputes the match / block columns from the chain (matches = sum of the block sizes,
+    block length = matches + D bases, chain.rs:430-452): record 1's are the fixture's, record 2's matches column is 40 where
+    the fixture says 30 — its 10M + 10M + 20M."""
+    src = open(os.path.join(GOLDEN, "testdotplot.paf")).read().splitlines()
+    rc, chain, err = run(cli, "paf2chain", os.path.join(GOLDEN, "testdotplot.paf"))
+    assert rc == 0, err
+    ch = tmp_path / "rt.chain"
+    ch.write_bytes(chain)
+    rc, out, err = run(cli, "chain2paf", str(ch))
+    assert rc == 0, err
+    got = out.decode().splitlines()
+    assert len(got) == len(src) == 2
+    for k, (g, w) in enumerate(zip(got, src)):
+        gf, wf = g.split("\t"), w.split("\t")
+        if wf[4] == "-":
+            # chain.rs:168-175 (ChainHeader from a '-' strand PafRecord): query.start = size - (end - head_ins), then
+            # query.end = size - (THAT start + tail_ins) — the reference's own arithmetic, which convert2paf hands back as it
+            # stands (chain.rs:437-440): 300 - 250 = 50, 300 - 50 = 250
+            qsz, qe = int(wf[1]), int(wf[3])
+            wf[2] = str(qsz - qe)
+            wf[3] = str(qsz - int(wf[2]))
+        assert gf[:9] == wf[:9], (k, gf, wf)                   # names, sizes, starts, ends, strand
+        assert gf[10] == wf[10]                                 # alignment block length
+        assert [x for x in gf if x.startswith("cg:Z:")] == [x for x in wf if x.startswith("cg:Z:")], k
+    assert got[0].split("\t")[9] == src[0].split("\t")[9] == "170" and got[1].split("\t")[9] == "40"

@@ -808,6 +808,36 @@ def test_maf_config3_full_size_properties(gpu):
         cstart = torch.ones_like(ccls, dtype=torch.bool)
         cstart[:, 1:] = ccls[:, 1:] != ccls[:, :-1]
         assert bool((crun[a:b] == cstart.sum(1)).all())
+    # EXACT on a 200 000-block slice: the whole run list of the caller walk — every run's start column, class and the non-gap
+    # target / query characters in front of it (what the event rules of caller.rs:444-608 read) — against torch
+    n2 = 200_000
+    off = torch.zeros(n2 + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(crun[:n2], 0)
+    nrun = int(off[-1])
+    runs = torch.zeros(3 * nrun + 3, dtype=torch.int64, device=dev)
+    gpu.maf_call_runs(n2, rows, t_off[:n2].contiguous(), q_off[:n2].contiguous(), cols[:n2].contiguous(), runs=runs, run_off=off)
+    torch.cuda.synchronize()
+    exp = torch.empty(3 * nrun, dtype=torch.int64, device=dev)
+    done = 0
+    for a in range(0, n2, 50_000):
+        b = min(n2, a + 50_000)
+        tt, qq = t[a * L:b * L].view(-1, L), q[a * L:b * L].view(-1, L)
+        eq, tg, qg = tt == qq, tt == 45, qq == 45
+        ccls = torch.where(tg & qg, 4, torch.where(tg, 1, torch.where(qg, 2, torch.where(eq, 0, 3))))
+        cstart = torch.ones_like(ccls, dtype=torch.bool)
+        cstart[:, 1:] = ccls[:, 1:] != ccls[:, :-1]
+        tb = torch.cumsum((~tg).to(torch.int64), 1) - (~tg).to(torch.int64)
+        qb = torch.cumsum((~qg).to(torch.int64), 1) - (~qg).to(torch.int64)
+        idx = cstart.flatten().nonzero().flatten()
+        k = idx.numel()
+        col = idx % L
+        e = exp[3 * done:3 * (done + k)].view(-1, 3)
+        e[:, 0] = (col << 3) | ccls.flatten()[idx]
+        e[:, 1] = tb.flatten()[idx]
+        e[:, 2] = qb.flatten()[idx]
+        done += k
+        del tt, qq, eq, tg, qg, ccls, cstart, tb, qb, idx
+    assert done == nrun and bool(torch.equal(exp, runs[:3 * nrun])), "run list differs from the torch expectation"
 
 
 def test_pafcov_config4_scaled_properties(gpu):
@@ -934,6 +964,40 @@ def test_pafcov_config4_at_stated_size(gpu):
         c = cov[int(cov_off[t]):int(cov_off[t]) + tlen]
         assert int(c.sum(dtype=torch.int64)) == int(want[t]), t
         assert int(c.min()) >= 0
+    # EXACT: every one of the 6.4e9 counters against an expectation computed with torch alone (update_cov_vec,
+    # cigar.rs:720-733: M / = ops cover [pos, pos + len) below the target's length; I / S do not move, everything else moves):
+    # +1 / -1 marks of every M / = op by index_add_, 200 000 records at a time, then a running sum per target
+    exp = torch.zeros(total + 8, dtype=torch.int32, device=dev)
+    sub = 200_000
+    for r0 in range(0, n_all, sub):
+        r1 = min(n_all, r0 + sub)
+        a, b = int(op_off[r0]), int(op_off[r1])
+        o = ops[a:b].to(torch.int64) & 0xFFFFFFFF
+        code, ln = o & 15, o >> 4
+        nper = op_off[r0 + 1:r1 + 1] - op_off[r0:r1]
+        rec = torch.repeat_interleave(torch.arange(r1 - r0, device=dev), nper)
+        stay = (code == 1) | (code == 4) | (code == 9)
+        adv = torch.where(stay, torch.zeros_like(ln), ln)
+        cs = torch.cumsum(adv, 0)
+        start_cs = torch.zeros(r1 - r0, dtype=torch.int64, device=dev)
+        first = (op_off[r0:r1] - a)
+        has = nper > 0
+        start_cs[has] = (cs - adv)[first[has]]
+        pos = t_start[r0:r1][rec] + (cs - adv) - start_cs[rec]
+        cover = (code == 0) | (code == 7)
+        base = cov_off[target_id[r0:r1].long()][rec]
+        p0, p1 = pos[cover], (pos + ln)[cover]
+        bc = base[cover]
+        m0, m1 = p0 < tlen, p1 < tlen
+        exp.index_add_(0, (bc + p0)[m0], torch.ones(int(m0.sum()), dtype=torch.int32, device=dev))
+        exp.index_add_(0, (bc + p1)[m1], torch.full((int(m1.sum()),), -1, dtype=torch.int32, device=dev))
+        del o, code, ln, rec, stay, adv, cs, pos, cover, base, p0, p1, bc, m0, m1
+    torch.cuda.empty_cache()
+    for t in range(nt):
+        lo = int(cov_off[t])
+        e = torch.cumsum(exp[lo:lo + tlen], 0, dtype=torch.int32)
+        assert bool(torch.equal(e, cov[lo:lo + tlen])), "target %d: coverage differs from the torch expectation" % t
+        del e
     gpu.reset_stream()
 
 

@@ -24,7 +24,6 @@ struct wga_ctx {
   wga_stream_t stream = nullptr;
   int expand_force_slow = 0;
   int expand_no_table = 0;
-  int expand_ablate = 0;
   unsigned expand_drain_min = 0; /* 0 = by the size of the pools, refined by trial (below) */
   bool expand_autotune = true;
   /* The cost of emitting gap-touching chunks late (lines wait half written in the L2) depends on where the output buffer
@@ -50,7 +49,6 @@ struct wga_ctx {
   int expand_variant_used = 0;
   int expand_job_tiles = 8; /* streaming kernel: tiles per wave ("expand_job_tiles") */
   const u32* stream_counts = nullptr; /* streaming kernel: the two counters of the tiles its last launch left to v1 (in the scratch arena) */
-  void* expand_dbg = nullptr;
   void* scratch = nullptr;
   size_t scratch_cap = 0;
   /* the piece table of the op walks over long records (K7, K10, K12): built by the count call of the two-call protocol and
@@ -511,10 +509,6 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
     c->expand_force_slow = value != 0;
     return WGA_OK;
   }
-  if (strcmp(name, "expand_dbg_ptr") == 0) {
-    c->expand_dbg = (void*)(uintptr_t)value;
-    return WGA_OK;
-  }
   if (strcmp(name, "expand_drain_min") == 0) { /* 0 = chosen by the size of the sequence pools (WGA_DRAIN_POOL_BYTES) */
     if (value < 0 || value > 64) return fail(WGA_E_INVALID_ARG, "expand_drain_min: 0 .. 64", nullptr);
     c->expand_drain_min = (unsigned)value;
@@ -525,10 +519,6 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
     c->tune.out = nullptr; /* what was learnt is forgotten */
     c->tune.phase = 0;
     c->tune.pending = false;
-    return WGA_OK;
-  }
-  if (strcmp(name, "expand_ablate") == 0) {
-    c->expand_ablate = (int)value;
     return WGA_OK;
   }
   if (strcmp(name, "expand_no_table") == 0) {
@@ -928,16 +918,14 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
   a.diag = d_diag;
   a.force_slow = c->expand_force_slow;
   a.no_table = c->expand_no_table;
-  a.ablate = c->expand_ablate;
   a.drain_min = 0; /* below */
-  a.dbg = (u64*)c->expand_dbg;
   a.tile_count = nullptr;
   a.tile_list = nullptr;
   a.n_rec = b->n;
   a.plan = (const u32*)((char*)ws + rec_bytes + desc_bytes + list_bytes);
   a.job_tiles = c->expand_job_tiles < 1 ? 1u : (c->expand_job_tiles > (int)WGA_S_MAX_JOB_TILES ? WGA_S_MAX_JOB_TILES : (u32)c->expand_job_tiles);
-  const bool windows = variant == 2 && !c->expand_ablate; /* the profiling knobs address v1 */
-  const bool stream = variant == 3 && !c->expand_ablate;
+  const bool windows = variant == 2;
+  const bool stream = variant == 3;
   /* when the gap-touching chunks are emitted (RowSrc::drain_min) */
   bool tune_timed = false;
   {
@@ -946,7 +934,7 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
     wga_ctx::DrainTune& T = c->tune;
     if (c->expand_drain_min) {
       dm = c->expand_drain_min;
-    } else if (c->expand_autotune && !windows && !stream && !c->expand_dbg && (u64)nt >= WGA_TUNE_MIN_TILES) {
+    } else if (c->expand_autotune && !windows && !stream && (u64)nt >= WGA_TUNE_MIN_TILES) {
       if (!T.have_ev) {
         const char* e = rt_event_create(&T.ev[0]);
         if (!e && (e = rt_event_create(&T.ev[1]))) rt_event_destroy(T.ev[0]);

@@ -483,10 +483,6 @@ __global__ __launch_bounds__(256) void k_layout_rows(ScanLayout f, u32 n, const 
   if (i >= n) return;
   u64 t = rec_off[i] + (f.pre_t ? f.pre_t[i] : 0u);
   u64 q = t + f.t_row(i) + (f.pre_q ? f.pre_q[i] : 0u);
-#ifdef WGA_HACK_ALIGN /* measurements only (wrong output): what would rows that start on a 16 / 128-byte boundary buy? */
-  t &= ~(u64)(WGA_HACK_ALIGN - 1);
-  q &= ~(u64)(WGA_HACK_ALIGN - 1);
-#endif
   t_row_off[i] = t;
   q_row_off[i] = q;
 }
@@ -514,7 +510,6 @@ struct RowSrc {
   u64 src_len;   /* slice length as fetched */
   bool rc;       /* read reversed + complemented (utils.rs:83-101) */
   bool safe;     /* every 20-byte window of this row lies inside the pool (rowsrc_prepare) */
-  int ablate;    /* profiling knob (see ExpandArgs) */
   u32 drain_min = WGA_DRAIN_MIN; /* queued complex chunks that trigger a drain before the row ends (see WGA_DRAIN_MIN) */
   const u8* win_base; /* address of slice index sbase (rc: of the mirrored window start) */
 };
@@ -564,12 +559,6 @@ struct WinRaw {
 
 __device__ __forceinline__ void win_issue(const RowSrc& src, u64 sbase, int off, int pa, int pb,
                                           WinRaw& r) {
-#ifdef WGA_PROFILE
-  if (src.ablate & 2) {
-    r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0x41414141u;
-    return;
-  }
-#endif
   if (src.safe) {
     /* pointer arithmetic only (no integer round trip): keeps this a global_load, not flat */
     const int sgn = src.rc ? -1 : 0; /* uniform */
@@ -822,13 +811,7 @@ __device__ __forceinline__ ChunkGeom chunk_geom(const RowGeom& r, u32 rel) {
   g.c_end = g.cz + g.b0;
   return g;
 }
-__device__ __forceinline__ void chunk_store(const ChunkGeom& g, const u32 o[4], int ablate = 0) {
-#ifdef WGA_PROFILE
-  if (ablate & 4) {
-    if (o[0] == 0x12345678u && o[1] == 0x9ABCDEF0u && o[3] == 7u) *(u32*)g.p = o[2];
-    return;
-  }
-#endif
+__device__ __forceinline__ void chunk_store(const ChunkGeom& g, const u32 o[4]) {
   if (g.a0 == 0u && g.b0 == 16u) {
     u32x4_a1 v = {o[0], o[1], o[2], o[3]};
     *(u32x4_a1*)g.p = v;
@@ -927,11 +910,8 @@ __device__ __forceinline__ void complex_chunk(const ChunkGeom& g, u32 rel, const
     emit_walk(o, c, c_end, cz, i, in_gap0, g0e, adj0, rd, src, bad_base_pos);
   }
   const bool whole = g.a0 == 0u && g.b0 == 16u;
-#ifdef WGA_PROFILE
-  if (src.ablate & 4) return;
-#endif
   buf_store16(rb.sbuf, whole ? rel << 4 : WGA_BUF_OOB, o);
-  if (!whole) chunk_store(g, o, 0); /* a row / tile edge: byte stores */
+  if (!whole) chunk_store(g, o); /* a row / tile edge: byte stores */
 }
 
 
@@ -955,11 +935,7 @@ __device__ __forceinline__ void emit_row_t(u8* dst, u32 N, u32 c0, const RowDesc
   const u32 n_full = rg.nchunks - lo_full - (rg.last_b0 == 16u ? 0u : 1u); /* may wrap to "none" */
   const bool any_full = rg.nchunks >= lo_full + (rg.last_b0 == 16u ? 0u : 1u) + 1u;
   const int koff = (int)(rd.gcum_a - rd.c_org); /* window offset of a chunk = cz + koff - adj */
-#ifdef WGA_PROFILE
-  const bool row_fast = src.safe && !(src.ablate & 32);
-#else
   const bool row_fast = src.safe;
-#endif
   const bool fast_ok = row_fast && any_full;
   /* buffers of the fast path: the source windows of this row relative to its first window (for
    * rc the windows walk down from it: offsets are biased by 2^31), and the row's output granules */
@@ -1014,14 +990,8 @@ __device__ __forceinline__ void emit_row_t(u8* dst, u32 N, u32 c0, const RowDesc
 #pragma unroll
       for (int d = 0; d < 4; d++) o[d] = dash[u] ? 0x2D2D2D2Du : o[d];
       const bool st_ok = cand[u] && !bad; /* an invalid base: the complex path finds and reports it */
-#ifdef WGA_PROFILE
-      if (!(src.ablate & 4))
-#endif
         buf_store16(rb.sbuf, st_ok ? rel[u] << 4 : WGA_BUF_OOB, o);
       cxs[u] = act[u] && !st_ok;
-#ifdef WGA_PROFILE
-      if (src.ablate & 16) cxs[u] = false;
-#endif
     }
     /* compact the complex chunks into the wave queue */
 #pragma unroll
@@ -1258,9 +1228,7 @@ struct ExpandArgs {
   wga_rec_diag* diag;
   int force_slow;
   int no_table; /* test knob: 256-column granules (the coarse-table path of very wide tiles) */
-  int ablate;   /* profiling knob: 1 = stop after phase A, 2 = no source loads, 4 = no stores */
   u32 drain_min; /* RowSrc::drain_min of the rows */
-  u64* dbg;     /* profiling: 8 s_memtime stamps per tile (NULL: off) */
   const u32* tile_count; /* k_paf2maf_expand_list: the blocks loop over tile_list[0 .. *tile_count) */
   const u32* tile_list;
   u32 n_rec;    /* records of the batch (op_off has n_rec + 1 entries) */
@@ -1286,10 +1254,6 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
   __shared__ u32x4_a16 s_lowmask[17];
   __shared__ u32 s_tbl[WGA_TBL_N + 2];   /* entries before each 16-column granule: I | D<<16  */
   __shared__ u32 s_queue[4 * WGA_QCAP];  /* per-wave queues of complex chunks                 */
-#ifdef WGA_LDS_PAD /* occupancy experiments: extra LDS words per block */
-  __shared__ u32 s_pad[WGA_LDS_PAD];
-  if (a.n_ops == 0xFFFFFFFFFFFFFFFFull) ((volatile u32*)s_pad)[threadIdx.x] = 1u;
-#endif
 
   const u32 tid = threadIdx.x;
   const u32 lane = tid & 63u, wave = WGA_WAVE_ID(tid);
@@ -1297,14 +1261,6 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
   const u64 tile_end = tile_start + WGA_TILE < a.n_ops ? tile_start + WGA_TILE : a.n_ops;
   const u32 nt = (u32)(tile_end - tile_start);
   build_lowmask(s_lowmask);
-#ifdef WGA_PROFILE /* s_memtime stamps per phase (scripts/gpu_stamps.py); 16 SGPRs the product build keeps free */
-  u64 stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (a.dbg) stamp[0] = WGA_CLOCK();
-#define WGA_STAMP(code) code
-#else
-#define WGA_STAMP(code)
-#endif
-
   /* lane k of every wave holds dword k of this tile's wga_tile_desc: one VGPR, no dependent
    * loads; fields are picked out with v_readlane when they are needed */
   u32 pre = 0u;
@@ -1399,13 +1355,6 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
   }
   __syncthreads();
 
-  WGA_STAMP(if (a.dbg) stamp[1] = WGA_CLOCK();)
-#ifdef WGA_PROFILE
-  if (a.ablate & 1) return;
-#endif
-#if defined(WGA_V1_ABLATE) && WGA_V1_ABLATE == 1 /* counts of phase A in an otherwise unchanged product build */
-  return;
-#endif
   /* ---- phase B: walk the record segments of this tile ------------------------------------- */
   u32 r = r0;
   u64 cur = tile_start;
@@ -1518,7 +1467,6 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
       ts.src_off = wave_get_u64(dsc, 18);
       ts.src_len = t_src_len;
       ts.rc = false;
-      ts.ablate = qs.ablate = 0;
       qs.fa = a.q_fa;
       qs.fa_bytes = a.q_fa_bytes;
       qs.src_off = wave_get_u64(dsc, 22);
@@ -1551,15 +1499,9 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
      * 2/3 = once the record ends in this tile, what the slices hold beyond the CIGAR. */
     const bool rec_ends = seg_end == re;
     const u32 rec_flags = wave_get_u32(dsc, 3);
-    WGA_STAMP(if (a.dbg && stamp[2] == 0) stamp[2] = WGA_CLOCK();)
 #pragma nounroll
     for (int job = 0; job < 4; job++) {
-      WGA_STAMP(if (a.dbg && job == 1 && stamp[3] == 0) stamp[3] = WGA_CLOCK();)
-      WGA_STAMP(if (a.dbg && job == 2 && stamp[4] == 0) stamp[4] = WGA_CLOCK();)
       const bool is_q = (job & 1) != 0, is_tail = job >= 2;
-#ifdef WGA_PROFILE
-      if (a.ablate & 8) continue;
-#endif
       if (is_tail && (!rec_ends || !(rec_flags & (is_q ? 4u : 2u)))) continue; /* no tail: nothing read, nothing computed */
       /* Ownership is static: piece p of this job goes to wave (job + 2 p + segment index) mod 4 — the two halves of
        * the two rows of a segment land on four different waves, and the rotation with the segment spreads the
@@ -1584,7 +1526,6 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
       src.src_off = wave_get_u64(dsc, 18 + q4);
       src.src_len = src_len;
       src.rc = is_q && (wave_get_u32(dsc, 3) & 1u) != 0u;
-      src.ablate = a.ablate;
       src.drain_min = a.drain_min;
 #endif
       u64 x0, nbytes;
@@ -1625,7 +1566,6 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
         src.src_off = wave_get_u64(dsc, 18 + q4);
         src.src_len = src_len;
         src.rc = is_q && (wave_get_u32(dsc, 3) & 1u) != 0u;
-        src.ablate = a.ablate;
         src.drain_min = a.drain_min;
         u8* const dst = a.out + wave_get_u64(dsc, 14 + q2) + x0;
         const u64 sb0 = is_tail ? L - gap_total : (is_q ? qb : tb);
@@ -1657,14 +1597,7 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
     r++;
     if (cur < tile_end) re = a.op_off[r + 1];
     nseg++;
-    WGA_STAMP(stamp[6] += 1;)
   }
-#ifdef WGA_PROFILE
-  if (a.dbg && tid == 0) {
-    stamp[5] = WGA_CLOCK();
-    for (int k = 0; k < 8; k++) a.dbg[g * 8 + k] = stamp[k];
-  }
-#endif
 }
 
 /* v1 of the row kernel (granules stored as they are produced: lines reach the L2 in pieces): `expand_variant` 0, one block

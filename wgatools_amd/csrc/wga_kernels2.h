@@ -890,7 +890,6 @@ __global__ __launch_bounds__(256, BASE ? WGA_K6_BLOCKS_BASE : WGA_K6_BLOCKS_SYM)
     qs.src_off = BASE ? a.q_src_off[r] : 0;
     qs.src_len = BASE ? a.q_src_len[r] : 0;
     qs.rc = a.strand_neg[r] != 0;
-    qs.ablate = 0;
     /* edited length: String::drain / insert_str semantics (cigar.rs:769-786) */
     const u64 row_len = BASE ? qs.src_len - (cs.i + cs.s) + cs.d : T_total;
     const u64 skip = a.skip[r];

@@ -358,24 +358,10 @@ __device__ __forceinline__ void span_rare(SpanW& sp, KArgP a, const u32* rec) {
 
 /* One window of a row piece: window w covers the addresses [B, B + WGA_W_BYTES), B = (dst & ~127) + w * WGA_W_BYTES.
  * `rec` = the piece's record in LDS. */
-#ifdef WGA_PROFILE /* s_memtime stamps per window phase, summed per wave (scripts/gpu_k2w_stamps.py) */
-#define WGA_WSTAMP(k)                      \
-  do {                                     \
-    const u64 _t = WGA_CLOCK();            \
-    wstamp[k] += _t - wlast;               \
-    wlast = _t;                            \
-  } while (0)
-#else
-#define WGA_WSTAMP(k)
-#endif
 template <bool RC>
 __device__ __forceinline__ void emit_window(KArgP a, const u32* rec, u32 w, const u32* s_col, const u32* s_cum,
                                             u32x4_a16* stage, const u32x4_a16* lowmask, u32 lane
-#ifdef WGA_PROFILE
-                                            , u64* wstamp, u64& wlast
-#endif
 ) {
-  WGA_WSTAMP(6); /* between windows: piece lookup, dispatch (and, before a wave's first window, the plan) */
   u32* const wt = (u32*)stage; /* the adjustment table lives in the stage until the fill starts */
   /* the piece's record: one LDS load (lane k = word k), fields by v_readlane */
   const u32 rv = rec[lane < WGA_W_SPAN_WORDS ? lane : 0u];
@@ -446,7 +432,6 @@ __device__ __forceinline__ void emit_window(KArgP a, const u32* rec, u32 w, cons
   /* a gap that starts in front of the window and reaches into it */
   const bool has_cover = e_lo > sp.ea && (int)(wave_get_u32(evw.gs, 0) + (m_lo - wave_get_u32(evw.m0, 0))) > cw0;
 
-  WGA_WSTAMP(0); /* record, search, event views */
   /* ---- per-granule source adjustment: gap bases of the events that start before the granule -------------------- */
 #pragma unroll
   for (u32 u = 0; u < WGA_W_U; u++) wt[u * 64u + lane] = 0u;
@@ -488,7 +473,6 @@ __device__ __forceinline__ void emit_window(KArgP a, const u32* rec, u32 w, cons
 #endif
   }
   WGA_WAVE_SYNC(); /* the table is dead: the stage may be written */
-  WGA_WSTAMP(1); /* table */
 
   /* ---- plain fill (every granule as if no gap touched it) with the first round of pass 1 in flight next to it ------ */
   u32 badmask = 0u; /* bit u: fill granule u * 64 + lane, bit 31: the granule of pass 1 */
@@ -508,7 +492,6 @@ __device__ __forceinline__ void emit_window(KArgP a, const u32* rec, u32 w, cons
 #pragma unroll
     for (u32 u = 0; u < WGA_W_U; u++) buf_load16(sp.lbuf, loff[u], raw[u]);
     fix1_issue<RC>(f0, sp, evw, cw0, e_lo, e_rd, act0);
-    WGA_WSTAMP(2); /* loads issued */
 #pragma unroll
     for (u32 u = 0; u < WGA_W_U; u++) {
       u32 o[4], inv[4];
@@ -525,7 +508,6 @@ __device__ __forceinline__ void emit_window(KArgP a, const u32* rec, u32 w, cons
 #if defined(WGA_W_ABLATE) && WGA_W_ABLATE == 3 /* ... + search, table, plain fill, copy-out: no fix-up passes */
   if (sp.N != 0xFFFFFFFFu) f0.own = false;
 #endif
-  WGA_WSTAMP(3); /* loads arrived, stage written */
   /* ---- fix-ups: one lane per event of the window (and the gap that reaches in from the front) ------------------- */
   if (fix1_finish<RC>(f0, sp, cw0, e_rd, stage, lowmask)) badmask |= 0x80000000u;
   const int g0_mine = f0.g0;
@@ -562,7 +544,6 @@ __device__ __forceinline__ void emit_window(KArgP a, const u32* rec, u32 w, cons
     if (badmask & 0x80000000u) rescan_granule(sr, cw0, (u32)g0_mine, vlo, vhi);
   }
 
-  WGA_WSTAMP(4); /* fix-ups */
   /* ---- copy-out: whole aligned lines; only the piece's first / last sixteen bytes can be partial ----------------- */
   const BufRsrc sbuf = buf_make(B, WGA_W_BYTES);
 #pragma unroll
@@ -584,7 +565,6 @@ __device__ __forceinline__ void emit_window(KArgP a, const u32* rec, u32 w, cons
     for (u32 j = lo; j < hi; j++) B[j] = sb[j]; /* byte stores, never read-modify-write */
   }
   WGA_WAVE_SYNC(); /* the stage is rewritten by this wave's next window */
-  WGA_WSTAMP(5); /* copy-out */
 }
 
 /* A row piece byte by byte, by one wave: a slice at a pool edge (its window loads would need bounds checks) or a record
@@ -612,7 +592,6 @@ __device__ __forceinline__ void emit_span_bytes(KArgP a, const u32* rec, const u
   src.src_off = is_q ? rp->q_src_off : rp->t_src_off;
   src.src_len = sp.src_len;
   src.rc = (flags & WSF_RC) != 0u;
-  src.ablate = 0;
   if (flags & WSF_PANIC) { /* an I (D) op whose target (query) consumption so far exceeds the fetched slice */
     bool pan = false;
     for (int i = sp.ea + (int)lane; i < sp.eb; i += 64)
@@ -875,11 +854,6 @@ __global__ __launch_bounds__(256) void k_tile_plan(const wga_tile_desc* __restri
   for (u32 k = 0; k < WGA_W_PLAN_WORDS; k++) p[k] = simple ? w[k] : 0u;
 }
 
-#ifdef WGA_PROFILE
-#define WGA_WSTAMP_ARG , wstamp, wlast
-#else
-#define WGA_WSTAMP_ARG
-#endif
 __device__ __forceinline__ void expand_tile_w(const ExpandArgs& a, const u64 g) {
   __shared__ u32 s_col[WGA_TILE + 8];  /* gap events: start column; target row from entry 0, then the query row                */
   __shared__ u32 s_cum[WGA_TILE + 8];  /*             gap bases of the row's events before                                 */
@@ -896,10 +870,6 @@ __device__ __forceinline__ void expand_tile_w(const ExpandArgs& a, const u64 g) 
   const u64 tile_start = g * WGA_TILE;
   const u64 tile_end = tile_start + WGA_TILE < a.n_ops ? tile_start + WGA_TILE : a.n_ops;
   const u32 nt = (u32)(tile_end - tile_start);
-#ifdef WGA_PROFILE
-  u64 wstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const u64 t_begin = WGA_CLOCK();
-#endif
   build_lowmask(s_lowmask);
 
   u32 pre = 0u, planv = 0u;
@@ -965,10 +935,6 @@ __device__ __forceinline__ void expand_tile_w(const ExpandArgs& a, const u64 g) 
   return;
 #endif
 
-#ifdef WGA_PROFILE
-  const u64 t_phaseA = WGA_CLOCK();
-  u64 wlast = t_phaseA;
-#endif
   /* ---- phase B: rounds of 16 record segments: wave 0 plans the pieces, the four waves take their windows round robin --- */
   u32x4_a16* const stage = s_stage[wave];
   const u32 tot_col = WGA_UNI32(s_tot[0]), tot_cnt = WGA_UNI32(s_tot[1]);
@@ -1015,23 +981,14 @@ __device__ __forceinline__ void expand_tile_w(const ExpandArgs& a, const u64 g) 
       if (flags & WSF_BYTES)
         emit_span_bytes(ka, rec, s_col, s_cum, tile_start, lane);
       else if (flags & WSF_RC)
-        emit_window<true>(ka, rec, w, s_col, s_cum, stage, s_lowmask, lane WGA_WSTAMP_ARG);
+        emit_window<true>(ka, rec, w, s_col, s_cum, stage, s_lowmask, lane);
       else
-        emit_window<false>(ka, rec, w, s_col, s_cum, stage, s_lowmask, lane WGA_WSTAMP_ARG);
+        emit_window<false>(ka, rec, w, s_col, s_cum, stage, s_lowmask, lane);
     }
 #endif
     if (!more) break;
     __syncthreads(); /* the table is rewritten by the next round */
   }
-#ifdef WGA_PROFILE
-  if (a.dbg && lane == 0u) { /* per wave: phase A, whole tile, windows' phases 0..5 */
-    u64* const d = a.dbg + (g * 4u + wave) * 8u;
-    d[0] = t_phaseA - t_begin;
-    d[1] = WGA_CLOCK() - t_begin;
-    for (int k = 0; k < 5; k++) d[2 + k] = wstamp[k];
-    d[7] = wstamp[6]; /* copy-out (wstamp[5]) = whole - phase A - the rest */
-  }
-#endif
 }
 
 __global__ __launch_bounds__(256, WGA_K2W_BLOCKS) void k_paf2maf_expand_w(ExpandArgs a) {
