@@ -606,8 +606,10 @@ int wga_arena_alloc(wga_ctx* c, size_t bytes, int candidates, void** d_out, doub
   }
   if (n == 0) return fail(WGA_E_OOM, "device allocation", "no memory for one candidate");
   rt_event_t ev[2];
+  int n_ev = 0; /* events created: only those are destroyed */
   const char* e = rt_event_create(&ev[0]);
-  if (!e && (e = rt_event_create(&ev[1]))) rt_event_destroy(ev[0]);
+  if (!e) n_ev = 1, e = rt_event_create(&ev[1]);
+  if (!e) n_ev = 2;
   int best = 0;
   double best_ms = 0.0;
   const u32 grid = (u32)(half / 256u < 65536u ? (half + 255u) / 256u : 65536u);
@@ -624,8 +626,7 @@ int wga_arena_alloc(wga_ctx* c, size_t bytes, int candidates, void** d_out, doub
     if (k == 0 || (double)ms < best_ms) best = k, best_ms = (double)ms;
   }
   if (!e) e = rt_sync(c->stream);
-  rt_event_destroy(ev[0]);
-  rt_event_destroy(ev[1]);
+  for (int k = 0; k < n_ev; k++) rt_event_destroy(ev[k]);
   for (int k = 0; k < n; k++)
     if (e || k != best) (void)rt_free(cand[k]);
   if (e) return fail(WGA_E_HIP, "arena probe", e);
@@ -1110,14 +1111,24 @@ int wga_paf2maf_expand_place(wga_ctx* c, const wga_cigar_batch* b, const wga_cig
   if (ms_by_candidate)
     for (int k = 0; k < candidates; k++) ms_by_candidate[k] = 0.0;
   if (chosen) *chosen = 0;
+  { /* the row kernel's scratch (record / tile descriptors, lists) is sized BEFORE the candidates take what is left of the
+     * memory: a trial launch that had to grow it would fail where a launch on one arena would not */
+    const u64 nt0 = n_tiles(b->n_ops);
+    void* ws0;
+    const size_t need = (((size_t)b->n * sizeof(wga_rec_desc) + 255) & ~(size_t)255) + (size_t)nt0 * sizeof(wga_tile_desc) + 256 +
+                        2 * (size_t)nt0 * sizeof(u32) + (size_t)nt0 * WGA_W_PLAN_WORDS * sizeof(u32) + (((size_t)nt0 + 255) & ~(size_t)255);
+    if ((rc = ctx_scratch(c, need, &ws0))) return rc;
+  }
   void* cand[64];
   int n = 0;
   for (; n < candidates; n++)
     if (rt_malloc(&cand[n], arena_bytes)) break; /* out of memory: fewer candidates */
   if (n == 0) return fail(WGA_E_OOM, "device allocation", "no memory for one candidate");
   rt_event_t ev[2];
+  int n_ev = 0; /* events created: only those are destroyed */
   const char* e = rt_event_create(&ev[0]);
-  if (!e && (e = rt_event_create(&ev[1]))) rt_event_destroy(ev[0]);
+  if (!e) n_ev = 1, e = rt_event_create(&ev[1]);
+  if (!e) n_ev = 2;
   /* the trials of drain_min (per output buffer) wait until the buffer is chosen; the timing ring is the caller's */
   const bool autotune = c->expand_autotune, timing = c->timing;
   c->expand_autotune = false;
@@ -1142,8 +1153,7 @@ int wga_paf2maf_expand_place(wga_ctx* c, const wga_cigar_batch* b, const wga_cig
   c->expand_autotune = autotune;
   c->timing = timing;
   if (!e && !rc) e = rt_sync(c->stream);
-  rt_event_destroy(ev[0]);
-  rt_event_destroy(ev[1]);
+  for (int k = 0; k < n_ev; k++) rt_event_destroy(ev[k]);
   for (int k = 0; k < n; k++)
     if (e || rc || k != best) (void)rt_free(cand[k]);
   if (rc) return rc;

@@ -1,34 +1,40 @@
 /*
- * wga_kernels_k2s.h — K2s, the STREAMING row kernel of paf2maf (`expand_variant` 3): the same bytes as v1 (wga_kernels.h)
- * and the window kernel (wga_kernels_k2w.h), i.e. parse_cigar_to_insert / cigar_unit_insert_seq (cigar.rs:492-551) with
- * reverse_complement (utils.rs:83-101) fused, written as a stream per wave instead of a block per tile.
+ * wga_kernels_k2s.h — K2s, the STREAMING row kernel of paf2maf (`expand_variant` 3, the default): the same bytes as v1
+ * (wga_kernels.h) and the window kernel (wga_kernels_k2w.h), i.e. parse_cigar_to_insert / cigar_unit_insert_seq
+ * (cigar.rs:492-551) with reverse_complement (utils.rs:83-101) fused, written as a stream per wave instead of a block per tile.
  *
- * Why another one.  v1 stores granules as they are produced (60 % of the 128-byte lines reach the L2 in two pieces:
- * 1.4 x the rows written) and the window kernel, which stores whole lines, pays for it with a chain of dependent global
- * loads per 4 KB window at the occupancy its 128 VGPRs allow (profiles/r03_k2w_experiments.md).  What bounds both is the
- * latency chain of a tile, not bytes.  Here nothing on a wave's critical path waits for HBM:
- *   * a wave owns ONE row kind (target or query) of a run of consecutive tiles (a "job") and walks it as a stream;
- *   * the row's source bytes are brought in by LDS-DMA (global_load_lds_dwordx4) into a per-wave ring of 1 KB chunks,
- *     several chunks ahead of the columns being written — chunk addresses depend on nothing but how far the stream is,
- *     so they are issued before the ops that will consume them are even looked at; the ops themselves arrive the same way;
- *   * output leaves in STEPS: the 64 lanes of the wave write the 64 granules of one 1 KB-aligned kilobyte of the row with
- *     one streaming store — whole 128-byte lines, once.  A lane assembles its granule in registers from two byte-unaligned
- *     16-byte LDS reads of the ring ("the source behind the gap that ended before me" | "behind the gap that starts in
- *     me") under byte masks; which gaps those are comes from a per-step 64-entry histogram of the step's gap events and a
- *     wave scan.  Granules with more events take a short per-event loop.
- * Registers: the data path needs ~20; everything that is wave-uniform (positions, ring and record bookkeeping) is scalar.
- * profiles/r04_micro_stream_dma_copy.txt: the bare mechanism (ring + unaligned reads + aligned stores) runs at the rate of a
- * plain copy of the same bytes.
+ * Why another one.  Round 4 measured what bounds the row kernels: not bytes but INSTRUCTION ISSUE.  A CU of this part retires
+ * about 1.0-1.6 wave-instructions per cycle, scalar and vector together (scripts/micro/issue_rates.hip); v1 spends 322 of them
+ * per kilobyte of row (2.9e9 VALU + 1.8e9 SALU per launch) and runs at 1.2 per cycle — it is at that ceiling, and so were the
+ * staged, planned and window kernels of rounds 2-3 (line-complete stores, but as many instructions).  This kernel spends ~210:
+ *   * a wave owns ONE row kind (target or query) of a run of consecutive tiles (a "job") and walks it as a stream: ops are
+ *     taken in 256 at a time (one 16-byte load per lane, the next 256 already on their way), three wave scans give columns,
+ *     gap bases and the row's gap events, which wait in a linear FIFO in LDS; no per-tile search, no block barriers;
+ *   * output leaves in SUPER-STEPS of four kilobytes, each kilobyte one streaming store of the wave — whole 128-byte lines,
+ *     once (v1 writes 60 % of its lines in two pieces).  The events of a super-step are counted per granule with one LDS
+ *     atomic each (a byte per kilobyte in one word per lane) and ONE packed wave scan tells every lane, for its four granules,
+ *     which event comes next.  A granule no gap touches (88 %) costs a table read, one byte-unaligned 16-byte buffer load and
+ *     its share of the store; sixteen dashes cost nothing more;
+ *   * the granules a gap touches are QUEUED, and the queue's lanes put all of a super-step's (~30) together in one round of
+ *     the merge code — two windows under byte masks, further gaps in a short loop — and hand them back through LDS to the
+ *     lanes that store them: the expensive path runs once per four kilobytes instead of once per kilobyte.  This happens
+ *     BEFORE the plain windows are requested, so that its registers are free again (96 VGPRs: five waves per SIMD);
+ *   * no calls, no barriers, every rare path inline and not unrolled.
+ * An earlier form staged the source through a per-wave LDS ring filled by LDS-DMA (global_load_lds_dwordx4, counted vmcnt;
+ * scripts/micro/stream_dma_copy.hip shows the mechanism at the rate of a plain copy): correct, but its 8-14 KB of LDS per wave
+ * left 11-13 waves per CU, and at the issue ceiling occupancy is what hides the rest (git history).
  *
  * Coordinates.  Within a stream, C counts columns (M = X I D bases) and `cum` the row's gap bases (I for the target row, D
  * for the query row) over ALL ops since the stream started, across records (u32: a job's tiles hold < 2^24 columns each).
- * A record segment maps them affinely: column C is byte dst_seg + C of the output; a non-gap column reads the source byte
- * at pool offset SF + (C - cum)  (forward)  or  SR - (C - cum)  (reverse complement).
- * The gap events of the row wait in a linear FIFO in LDS (start column, gap bases in front), three sentinels behind.
+ * A record segment maps them affinely: column C is byte dst_seg + C of the output; a non-gap column reads the segment's
+ * source buffer at S32 + (C - cum)  (forward)  or its sixteen-byte window starts at S32 - (C - cum)  (reverse complement).
+ * FIFO entries are (start column, gap bases in front); a gap's length is the next entry's second word minus its own; three
+ * sentinels stand behind the last one.
  *
  * What it does NOT do: tiles whose records are not "clean" (a slice longer or shorter than the CIGAR consumes: tails to
- * append, rows that stop early, String::insert_str panics) and tiles wider than 2^24 columns are marked by a pre-pass
- * (k_stream_mark_*) and left to v1 (k_paf2maf_expand_list), as the window kernel leaves its giant tiles there.
+ * append, rows that stop early, String::insert_str panics), records within 32 bytes of a pool's edge and tiles wider than
+ * 2^24 columns are marked by a pre-pass (k_stream_mark_*) and left to v1 (k_paf2maf_expand_list), as the window kernel
+ * leaves its giant tiles there.
  */
 #ifndef WGA_KERNELS_K2S_H
 #define WGA_KERNELS_K2S_H
