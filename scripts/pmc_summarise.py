@@ -1,5 +1,5 @@
 """Turn the rocprofv3 counter CSVs of scripts/gpu_pmc.sh into the tracked summaries under profiles/.
-usage: python scripts/pmc_summarise.py gpurun_out/pmc06 profiles/r01 <launches> <records> <mean_ops> <ops>"""
+usage: python scripts/pmc_summarise.py gpurun_out/pmc06 profiles/r01 <launches> <records> <mean_ops> <ops> [kernel]"""
 import collections
 import csv
 import glob
@@ -28,7 +28,7 @@ with open(dst + "_pmc.txt", "w") as f:
     f.write("%-6s %-28s %-24s %s\n" % ("pass", "kernel", "counter", "sum over launches"))
     for d, k, c, x in rows:
         f.write("%-6s %-28s %-24s %.6g\n" % (d, k, c, x))
-k = "k_paf2maf_expand"
+k = sys.argv[7] if len(sys.argv) > 7 else "k_paf2maf_expand_s"
 fetch_kb, write_kb = agg_all[(k, "FETCH_SIZE")], agg_all[(k, "WRITE_SIZE")]
 rd = 2.0 * fetch_kb * 1024 / launches   # gfx950: FETCH_SIZE = TCC_EA0_RDREQ x 64 B tallies 128-B requests at 64 B
 wr = write_kb * 1024 / launches
@@ -41,7 +41,7 @@ json.dump({
     "TCC_EA0_RDREQ_sum": agg_all.get((k, "TCC_EA0_RDREQ_sum")), "TCC_EA0_WRREQ_sum": agg_all.get((k, "TCC_EA0_WRREQ_sum")),
     "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
     "correction": "FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section: on gfx950 it reports half of a wide streaming "
-                  "read; cross-checked here: 2 x FETCH = 15.6 GB = the 4n + target + query bytes the kernel must read); "
+                  "read; 2 x FETCH is compared with the 4n + target + query bytes the kernel must read in DESIGN.md); "
                   "WRITE_SIZE taken as reported (= TCC_EA0_WRREQ x 64 B)",
 }, open(dst + "_pmc_traffic.json", "w"), indent=1)
 print(open(dst + "_pmc_traffic.json").read())

@@ -1289,3 +1289,77 @@ def test_fixture_paf_chain_paf_roundtrip(cli, tmp_path):
         assert gf[10] == wf[10]                                 # alignment block length
         assert [x for x in gf if x.startswith("cg:Z:")] == [x for x in wf if x.startswith("cg:Z:")], k
     assert got[0].split("\t")[9] == src[0].split("\t")[9] == "170" and got[1].split("\t")[9] == "40"
+
+
+def pafpseudo_walk_case(cli, tmp_path, n_rec, n_targets, n_queries, check_targets):
+    """BASELINE configs[4]'s all-to-all part through `pafpseudo` (symbol mode): n_rec records over n_targets x n_queries
+    (target, query) pairs in shuffled input order, with gaps, abutting records, partial overlaps (the new record's first
+    columns are trimmed, pseudomaf.rs:190-192) and contained records (dropped, :176-178); the grouping by target and query
+    (:25-42), the sorted insertion (:86-95) and the walk (:147-210) run over all of them, and the files of `check_targets`
+    targets are compared with the oracle's rows (gen_pesudo_maf_by_cigar, cigar.rs:744-804) for every record that lands
+    in them."""
+    from wgatools_amd.synth import make_ops, class_sums
+    rng = np.random.default_rng(17)
+    ops, op_off, code, length = make_ops(rng, n_rec, 12, 0.5, False)
+    cs = class_sums(code, length, op_off)
+    tspan = (cs["mx"] + cs["d"]).astype(np.int64)
+    qspan = (cs["mx"] + cs["i"]).astype(np.int64)
+    pair = rng.integers(0, n_targets * n_queries, n_rec)
+    mode = rng.integers(0, 4, n_rec)
+    jit = rng.integers(1, 60, n_rec)
+    back = rng.integers(1, 40, n_rec)
+    per_pair = n_rec // (n_targets * n_queries) + 1
+    tsize = int(per_pair * (int(tspan.mean()) + 40) * 1.3) + 1000
+    cursor = np.zeros(n_targets * n_queries, dtype=np.int64)
+    start = np.zeros(n_rec, dtype=np.int64)
+    keep = np.ones(n_rec, dtype=bool)
+    for i in range(n_rec):                          # the cursor of a pair is sequential
+        p_ = pair[i]
+        cur = cursor[p_]
+        m = mode[i]
+        st = cur + jit[i] if (m == 0 or cur == 0) else cur if m == 1 else max(0, cur - back[i]) if m == 2 else max(0, cur - tspan[i] - 5)
+        en = st + tspan[i]
+        if en > tsize:
+            keep[i] = False
+            continue
+        start[i] = st
+        if en > cur:
+            cursor[p_] = en
+    order = np.flatnonzero(keep)
+    rng.shuffle(order)                              # input order is not sorted: the sorted insertion does the work
+    tnames = ["tg%02d#1#chr%d" % (k, 1 + k % 5) for k in range(n_targets)]
+    qnames = ["qg%02d#2#ctg" % k for k in range(n_queries)]
+    texts = [None] * n_rec
+    paf = tmp_path / "walk.paf"
+    with open(paf, "wb") as f:
+        lines = []
+        for i in order:
+            t, q = tnames[pair[i] // n_queries], qnames[pair[i] % n_queries]
+            cg = orc.ops_to_text(ops[int(op_off[i]):int(op_off[i + 1])])
+            texts[i] = cg
+            lines.append(b"%s\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d\t0\t0\t60\t%s\n" % (
+                q.encode(), 10 ** 8, 1000 + i, 1000 + i + int(qspan[i]), b"+-"[i & 1:(i & 1) + 1], t.encode(), tsize, int(start[i]),
+                int(start[i] + tspan[i]), cg))
+            if len(lines) >= 50000:
+                f.write(b"".join(lines))
+                lines = []
+        f.write(b"".join(lines))
+    outdir = tmp_path / "walk_out"
+    rc, _, err = run(cli, "pafpseudo", str(paf), "-o", str(outdir))
+    assert rc == 0, err
+    assert sorted(os.listdir(outdir)) == sorted(t + ".maf" for t in set(tnames[pair[i] // n_queries] for i in order))
+    checked = 0
+    for tk in range(check_targets):
+        recs = [dict(tname=tnames[tk], qname=qnames[pair[i] % n_queries], tlen=tsize, tstart=int(start[i]), tend=int(start[i] + tspan[i]),
+                     qlen=10 ** 8, qstart=0, qend=0, strand="+", cg=texts[i].decode()) for i in order if pair[i] // n_queries == tk]
+        exp = _expected_pseudo_files(recs, {}, False)[tnames[tk]]
+        got = open(outdir / (tnames[tk] + ".maf"), "rb").read()
+        assert got.split(b"\n")[:2] == exp.split(b"\n")[:2]
+        assert sorted(got.split(b"\n")) == sorted(exp.split(b"\n")), tnames[tk]   # query rows come in HashMap order in the reference
+        checked += len(recs)
+    return len(order), checked
+
+
+def test_pafpseudo_walk_over_many_records(cli, tmp_path):
+    n, checked = pafpseudo_walk_case(cli, tmp_path, 1200, 2, 4, 2)
+    assert n > 1000 and checked == n

@@ -72,3 +72,13 @@ def test_product_does_not_touch_the_oracle():
     for binary in (build.build_hip(), build.build_cli()):
         needed = subprocess.run(["readelf", "-d", binary], stdout=subprocess.PIPE).stdout.decode()
         assert "oracle" not in needed, binary
+
+
+def test_struct_layouts_are_frozen(tmp_path):
+    """tests/abi_layout.c: _Static_assert on the size of and every offset in the structs of include/wga_hip.h — the numbers a
+    binding in another language has to reproduce (INTEGRATION.md section 2 quotes them)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["gcc", "-std=c11", "-I" + os.path.join(root, "include"), "-c", os.path.join(root, "tests", "abi_layout.c"),
+                        "-o", str(tmp_path / "abi_layout.o")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout

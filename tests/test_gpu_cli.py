@@ -44,3 +44,12 @@ def test_gpus_flag_with_the_devices_of_this_box(cli, tmp_path):
     mc.check_pafcov(cli, tmp_path, gpus, env)
     mc.check_call_paf(cli, tmp_path, gpus, env)
     mc.check_too_many(cli, env, have)
+
+
+def test_pafpseudo_walk_at_a_million_records(cli, tmp_path):
+    """BASELINE configs[4]'s all-to-all part at a size where the grouping / sorted insertion / contained-skip / overlap-trim
+    walk (pseudomaf.rs:25-42,86-95,147-210) does real work: 1.2 M records over 16 x 64 (target, query) pairs; one target's
+    file (64 query rows, ~70 000 records) is compared with the oracle's rows"""
+    from cli_cases import pafpseudo_walk_case
+    n, checked = pafpseudo_walk_case(cli, tmp_path, 1_200_000, 16, 64, 1)
+    assert n > 1_000_000 and checked > 50_000
