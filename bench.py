@@ -278,9 +278,9 @@ def north_star(args):
         "config": {"workload": "north-star shape: %d records x mean 50 kop streamed as %d on-device-generated resident batches of %d "
                                "records (2 x %d Mb pools); the full headline is 10 000 000 records" % (nb * per, nb, per, args.pool_mb),
                    "records": nb * per, "ops": tot_ops, "columns": tot_cols},
-        "roofline": {"kernel": "k_paf2maf_expand", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"kernel": {0: "k_paf2maf_expand", 2: "k_paf2maf_expand_w", 3: "k_paf2maf_expand_s"}.get(eng.get_param("expand_variant_used")),
+                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": tot_bytes},
-        "expand_drain_min": {"used": eng.get_param("expand_drain_min"), "autotune_settled": eng.get_param("expand_autotune_settled")},
         "output_placement": placement,
         "metric_scope": "kernel-only, summed over the batches, rows written into one output arena (placed for the first batch by "
                         "wga_paf2maf_expand_place); generation between batches is not timed",
@@ -387,7 +387,7 @@ def main():
     ap.add_argument("--north-star", action="store_true", help="the 10 M x 50 kop headline shape as a stream of resident batches (N = 1)")
     ap.add_argument("--ns-records", type=int, default=400_000)
     ap.add_argument("--ns-batch-records", type=int, default=40_000)
-    ap.add_argument("--ns-candidates", type=int, default=3, help="candidate arenas of the north-star stream (64 GB each)")
+    ap.add_argument("--ns-candidates", type=int, default=1, help="candidate arenas of the north-star stream (64 GB each; 1 = the first allocation)")
     args = ap.parse_args()
     if args.north_star:
         return north_star(args)

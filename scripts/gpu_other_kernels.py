@@ -42,10 +42,20 @@ dst_off[1:] = torch.cumsum(seg, 0)[:-1]
 total = int(seg.sum().item())
 out = torch.zeros(total + 64, dtype=torch.uint8, device=dev)
 skip = torch.zeros(n, dtype=torch.int64, device=dev)
-for mode in (0, 1):
+ref = None
+for mode, variant in ((0, 0), (1, 0), (1, 3)):   # base mode: one block per tile, then the streaming row kernel (the default)
+    eng.set_param("pseudo_variant", variant)
+    out.zero_()
     ms = timed(lambda: eng.pafpseudo_fill(batch, mode, tb["q_pool"], int(tb["q_pool"].numel()), tb["q_src_off"], tb["q_src_len"], skip, out, dst_off))
     rd = 4 * n_ops + (int(tb["q_src_len"].sum().item()) if mode else 0)
-    print("K6 pafpseudo %s : %.3f ms  %.0f GB/s (4 B/op%s + %d B written)" % ("base  " if mode else "symbol", ms, (rd + total) / ms / 1e6, " + query bases" if mode else "", total))
+    note = ""
+    if mode and variant == 0:
+        ref = out.clone()
+    if mode and variant == 3:
+        note = "; streaming row kernel, %d tiles left to the block kernel, same bytes as the block kernel: %s" % (
+            eng.get_param("pseudo_stream_left_to_blocks"), bool(torch.equal(ref, out)))
+        del ref
+    print("K6 pafpseudo %s : %.3f ms  %.0f GB/s (4 B/op%s + %d B written%s)" % ("base  " if mode else "symbol", ms, (rd + total) / ms / 1e6, " + query bases" if mode else "", total, note))
 # ---- K7 PAF call events -----------------------------------------------------------------------------
 for svlen, snp in ((50, 1), (0, 0)):
     cnt = torch.zeros(n, dtype=torch.int64, device=dev)

@@ -536,9 +536,17 @@ def check_pafcov(eng, b, target_id, t_start, target_len, align=4, split=False):
 # ------------------------------------------------------------------------------------------------
 # K6 pafpseudo
 # ------------------------------------------------------------------------------------------------
-def check_pafpseudo(eng, b, base_mode, skip=None, sums_call=True):
+def check_pafpseudo(eng, b, base_mode, skip=None, sums_call=True, variant=None):
     """sums_call=False: the fill without wga_cigar_class_sums in front (it then computes the tile and record sums itself
-    instead of taking what the class-sums call left in the context)"""
+    instead of taking what the class-sums call left in the context); variant: "pseudo_variant" for this call (base mode:
+    3 the streaming row kernel, 0 one block per tile)"""
+    if variant is not None:
+        before = eng.get_param("pseudo_variant")
+        eng.set_param("pseudo_variant", variant)
+        try:
+            return check_pafpseudo(eng, b, base_mode, skip=skip, sums_call=sums_call)
+        finally:
+            eng.set_param("pseudo_variant", before)
     n = len(b["strand_neg"])
     batch = eng.make_batch(b["ops"], b["op_off"], b["strand_neg"])
     sums = eng.cigar_class_sums(batch).numpy() if sums_call else {}
@@ -617,6 +625,114 @@ def check_pafpseudo(eng, b, base_mode, skip=None, sums_call=True):
         covered[int(dst_off[i]):int(dst_off[i]) + len(e)] = True
     if all_clean:
         assert (o[~covered] == 0x23).all()
+
+
+def pseudo_consumption(cigar):
+    """query bases pafpseudo's edit of a CIGAR consumes (M = X I S)"""
+    import re
+    return sum(int(n) for n, op in re.findall(r"(\d+)(\D)", cigar) if op in "M=XIS")
+
+
+def pseudo_clean(rng, b, margin=64):
+    """slices of exactly the length pafpseudo's edit consumes (M = X I S), `margin` bytes away from the pool's edges"""
+    code, length = b["ops"] & 15, (b["ops"] >> 4).astype(np.uint64)
+    v = np.where((code == 0) | (code == 7) | (code == 8) | (code == 1) | (code == 4) | (code == 9), length, 0).astype(np.uint64)
+    c = np.concatenate([np.zeros(1, np.uint64), np.cumsum(v, dtype=np.uint64)])
+    nb = dict(b)
+    n = len(b["strand_neg"])
+    nb["q_src_len"] = c[b["op_off"][1:].astype(np.int64)] - c[b["op_off"][:-1].astype(np.int64)]
+    room = len(b["q_pool"]) - 2 * margin - int(nb["q_src_len"].max())
+    if room <= 0:  # the pool grows
+        nb["q_pool"] = np.concatenate([b["q_pool"], np.frombuffer(rand_seq(rng, 2 * margin + 1 - room), dtype=np.uint8)])
+        room = 1
+    nb["q_src_off"] = (margin + rng.integers(0, room, n)).astype(np.uint64)
+    return nb
+
+
+def pseudo_stream_cases(eng):
+    """pafpseudo's base-mode rows through the streaming row kernel ("pseudo_variant" 3): every job length; S ops; heads trimmed
+    by a few columns, by whole tiles, by more than the record has; records whose slice is longer / shorter than the edit
+    consumes (left to the block kernel) between clean ones; hundreds of I / S ops in a row on one column (events without
+    columns: the FIFO's dedupe), leading and trailing clips, dense D / I; a record over many jobs; invalid bases on '-'
+    strand rows; slices at the pool's edges.  Every case also through the block kernel (variant 0)."""
+    from wgatools_amd import synth
+    before = eng.get_param("expand_job_tiles")
+    try:
+        for jt in (1, 2, 8, 32):
+            eng.set_param("expand_job_tiles", jt)
+            rng = np.random.default_rng(100 + jt)
+            b = synth.make_paf_batch(70 + jt, 9, 3000, 300_000)
+            b = sprinkle_ops(rng, b, frac=0.03, codes=(3, 4, 4, 5, 6, 11))
+            b = pseudo_clean(rng, b)
+            check_pafpseudo(eng, b, 1, variant=3)
+            assert eng.get_param("pseudo_stream_left_to_blocks") == 0
+            tot = synth.class_sums(b["ops"] & 15, b["ops"] >> 4, b["op_off"])
+            cols = (tot["mx"] + tot["d"]).astype(np.int64)
+            skip = np.array([0, 5, 1023, 1024, 4097, int(cols[5]), int(cols[6]) - 1, int(cols[7]) // 2, 17], dtype=np.int64)
+            skip = np.minimum(skip, cols)
+            for v in (3, 0):
+                check_pafpseudo(eng, b, 1, skip=skip, variant=v)
+            # records 2 and 5: leftover bases behind the CIGAR, record 6 a slice that is too short (drain panics)
+            u = dict(b)
+            ql = b["q_src_len"].copy()
+            ql[2] += 7
+            ql[5] += 300
+            ql[6] -= min(5, int(ql[6]))
+            u["q_src_len"] = ql
+            check_pafpseudo(eng, u, 1, skip=np.minimum(skip, 40), variant=3)
+            assert eng.get_param("pseudo_stream_left_to_blocks") > 0
+        eng.set_param("expand_job_tiles", 4)
+        rng = np.random.default_rng(5)
+        def dense(n):
+            out = []
+            for _ in range(n):
+                out.append("%d=" % rng.integers(1, 4))
+                out.append("%d%s" % (rng.integers(0, 3), "IDS"[int(rng.integers(0, 3))]))
+            return "".join(out) + "7="
+        cigars = ["5S" + dense(900) + "3S", "40=" + "1I" * 700 + "30=" + "2S1I" * 400 + "5=" + "1I" * 300, "1I" * 600 + "9=",
+                  "5=" + dense(300) + "9000D3=" + dense(100) + "12000I4=2000S", dense(2500), "3=1I1D1I1D2=0I0D5=" * 40 + "1=",
+                  "2000=" + "1D1I" * 500 + "1S" * 300 + "4D" + "1I" * 70 + "2000=", "7=" + "1I1S" * 160]
+        strands = [0, 1, 0, 1, 1, 0, 1, 0]
+        qs = [rand_seq(rng, pseudo_consumption(c)) for c in cigars]
+        bt = batch_from_texts(eng, cigars, strands, [b"A"] * len(cigars), qs, pad=70)
+        bt["q_pool"] = np.concatenate([np.frombuffer(b"N" * 64, np.uint8), bt["q_pool"], np.frombuffer(b"N" * 64, np.uint8)])
+        bt["q_src_off"] = bt["q_src_off"] + np.uint64(64)
+        for v in (3, 0):
+            check_pafpseudo(eng, bt, 1, variant=v)
+            check_pafpseudo(eng, bt, 1, skip=[3, 41, 0, 9100, 16, 0, 2300, 7], variant=v)
+        check_pafpseudo(eng, bt, 1, variant=3)
+        assert eng.get_param("pseudo_stream_left_to_blocks") == 0
+        # more than 255 clip / insertion ops on ONE column inside one super-step (its event counters are bytes): ten at the end
+        # of one intake of 256 ops, 255 at the start of the next, columns behind them
+        cg = ["1=1X" * 123 + "1I" * 265 + "5000=", "7=", "1=1X" * 118 + "1S" * 270 + "3D1I" + "4000="]
+        for st in ([0, 1, 1], [1, 0, 0]):
+            bt = batch_from_texts(eng, cg, st, [b"A"] * 3, [rand_seq(rng, pseudo_consumption(c)) for c in cg], pad=80)
+            bt["q_pool"] = np.concatenate([np.frombuffer(b"N" * 64, np.uint8), bt["q_pool"], np.frombuffer(b"N" * 64, np.uint8)])
+            bt["q_src_off"] = bt["q_src_off"] + np.uint64(64)
+            check_pafpseudo(eng, bt, 1, variant=3)
+            assert eng.get_param("pseudo_stream_left_to_blocks") == 0
+            check_pafpseudo(eng, bt, 1, skip=[250, 0, 236], variant=3)
+        big = synth.make_paf_batch(12, 1, 40_000, 400_000, sigma=0.01)      # one record over ~40 tiles = 10 jobs
+        big = pseudo_clean(rng, big)
+        check_pafpseudo(eng, big, 1, variant=3)
+        check_pafpseudo(eng, big, 1, skip=[30_011], variant=3)
+        assert eng.get_param("pseudo_stream_left_to_blocks") == 0
+        bad = pseudo_clean(rng, synth.make_paf_batch(13, 3, 3000, 100_000))   # invalid bases on '-' strand rows
+        bad["strand_neg"][:] = 1
+        qp = bad["q_pool"].copy()
+        for r_, f in ((0, 3), (1, 2), (1, 5)):
+            qp[int(bad["q_src_off"][r_] + bad["q_src_len"][r_] * f // 7)] = ord("R-x"[f % 3])
+        bad["q_pool"] = qp
+        for v in (3, 0):
+            check_pafpseudo(eng, bad, 1, variant=v)
+        # slices that begin at byte 0 and end at the last byte of the pool
+        cig = ["700=3I900=2D650=", "1500=1X200=4D300=2S"]
+        for st in ([0, 0], [1, 1]):
+            check_pafpseudo(eng, batch_from_texts(eng, cig, st, [b"A"] * 2, [rand_seq(rng, pseudo_consumption(c)) for c in cig], pad=0),
+                            1, variant=3)
+            assert eng.get_param("pseudo_stream_left_to_blocks") > 0
+    finally:
+        eng.set_param("expand_job_tiles", before)
 
 
 # ------------------------------------------------------------------------------------------------

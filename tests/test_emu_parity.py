@@ -266,6 +266,10 @@ def test_pafpseudo(emu, base, seed, n, mean):
     pc.check_pafpseudo(emu, b, base, skip=skip)
 
 
+def test_pafpseudo_stream_kernel(emu):
+    pc.pseudo_stream_cases(emu)
+
+
 def test_pafpseudo_symbol_runs(emu):
     """symbol mode, per-granule walk over the ops that cover it: long X / D runs, rows that start inside a granule, dense
     single-column ops, one op of 1.2 M columns, trimmed heads up to 8191 columns"""

@@ -343,6 +343,10 @@ def test_pafpseudo(gpu, base, seed, n, mean):
     pc.check_pafpseudo(gpu, b, base, skip=skip)
 
 
+def test_pafpseudo_stream_kernel(gpu):
+    pc.pseudo_stream_cases(gpu)
+
+
 def test_pafpseudo_symbol_runs(gpu):
     """symbol mode, per-granule walk over the ops that cover it: long X / D runs, rows that start inside a granule, dense
     single-column ops, one op of 1.2 M columns, trimmed heads up to 8191 columns"""
@@ -1115,3 +1119,35 @@ def test_reduce_scatter_i32_on_hardware(monkeypatch):
     finally:
         for e in engs:
             e.close()
+
+
+def test_paf2maf_stream_kernel_pools_beyond_4_gb(gpu):
+    """sequence pools of 4.6 GB: the streaming kernel addresses a record segment's source through a buffer whose base lies a
+    little in front of what the job can reach (32-bit offsets) — slices beyond 2^32 must read the same bytes as v1's 64-bit
+    pointers, on both strands; a few records against the oracle"""
+    import torch
+    from wgatools_amd import pipeline
+    dev = torch.device("cuda", 0)
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    tb = synth.make_paf_batch_torch(321, 3000, 3000, 4_600_000_000, dev)
+    assert int(tb["t_src_off"].max()) > (1 << 32) and int(tb["q_src_off"].max()) > (1 << 32)
+    outs = []
+    for v in (0, 3):
+        gpu.set_param("expand_variant", v)
+        job = pipeline.Paf2MafStatJob(gpu, tb, with_text=True)
+        job.out.fill_(0x23)
+        job.bind_stream()
+        job.step()
+        torch.cuda.synchronize()
+        assert bool((job.diag == -1).all()) and gpu.get_param("expand_variant_used") == v
+        outs.append(job.out)
+        if v == 3:
+            far = torch.nonzero((tb["q_src_off"] > (1 << 32)) & (tb["t_src_off"] > (1 << 32))).flatten()[:4].tolist()
+            for i in far:
+                et, eq = pc.oracle_rows(synth.torch_batch_record_to_numpy(tb, i), 0)
+                gt, gq = job.record_rows(i)
+                assert gt == et and gq == eq, i
+        del job
+    assert bool(torch.equal(outs[0], outs[1]))
+    gpu.set_param("expand_variant", pc.DEFAULT_EXPAND_VARIANT)
+    gpu.reset_stream()

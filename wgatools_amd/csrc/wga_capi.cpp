@@ -48,6 +48,8 @@ struct wga_ctx {
                               kernel of wga_kernels_k2w.h, longer ones v1), 0 v1 (wga_kernels.h), 2 the window kernel */
   int expand_variant_used = 0;
   int expand_job_tiles = 8; /* streaming kernel: tiles per wave ("expand_job_tiles") */
+  int pseudo_variant = 3;   /* pafpseudo's base-mode rows: 3 the streaming row kernel, 0 one block per tile ("pseudo_variant") */
+  const u32* pseudo_counts = nullptr; /* ... the two counters of the tiles its last launch left to the block kernel */
   const u32* stream_counts = nullptr; /* streaming kernel: the two counters of the tiles its last launch left to v1 (in the scratch arena) */
   void* scratch = nullptr;
   size_t scratch_cap = 0;
@@ -138,6 +140,7 @@ static int ctx_scratch(wga_ctx* c, size_t bytes, void** out) {
     if (c->scratch) RT_CHECK(rt_free(c->scratch));
     c->scratch = nullptr;
     c->stream_counts = nullptr;
+    c->pseudo_counts = nullptr;
     c->scratch_cap = 0;
     size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 2;
     RT_CHECK(rt_malloc(&c->scratch, cap));
@@ -554,6 +557,11 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
     c->expand_job_tiles = (int)value;
     return WGA_OK;
   }
+  if (strcmp(name, "pseudo_variant") == 0) { /* wga_pafpseudo_fill, base mode: 3 the streaming row kernel (default), 0 one block per tile */
+    if (value != 0 && value != 3) return fail(WGA_E_INVALID_ARG, "pseudo_variant: 0, 3", nullptr);
+    c->pseudo_variant = (int)value;
+    return WGA_OK;
+  }
   if (strcmp(name, "expand_timing") == 0) {
     if (value && !c->timing) {
       int rc = ctx_bind(c);
@@ -903,7 +911,7 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
              (const u64*)d_q_row_off, recs);
   LAUNCH_CHECK();
   WGA_LAUNCH(k_tile_base, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const u64*)b->d_op_off,
-             (u64)b->n_ops, (const wga_tile_sum*)d_tile_ws, (const wga_rec_desc*)recs, tdesc);
+             (u64)b->n_ops, (const wga_tile_sum*)d_tile_ws, (const wga_rec_desc*)recs, tdesc, 0);
   LAUNCH_CHECK();
   ExpandArgs a;
   a.ops = b->d_ops;
@@ -1068,6 +1076,25 @@ int wga_ctx_get_param(wga_ctx* c, const char* name, int64_t* value) {
       int rc = ctx_bind(c);
       if (rc) return rc;
       RT_CHECK(rt_d2h(h, c->stream_counts, sizeof(h), c->stream));
+      *value = (int64_t)h[0] + (int64_t)h[1];
+    }
+    return WGA_OK;
+  }
+  if (strcmp(name, "expand_job_tiles") == 0) {
+    *value = (int64_t)c->expand_job_tiles;
+    return WGA_OK;
+  }
+  if (strcmp(name, "pseudo_variant") == 0) {
+    *value = (int64_t)c->pseudo_variant;
+    return WGA_OK;
+  }
+  if (strcmp(name, "pseudo_stream_left_to_blocks") == 0) { /* tiles the last base-mode wga_pafpseudo_fill left to the block kernel */
+    *value = 0;
+    if (c->pseudo_counts) {
+      u32 h[2] = {0, 0};
+      int rc = ctx_bind(c);
+      if (rc) return rc;
+      RT_CHECK(rt_d2h(h, c->pseudo_counts, sizeof(h), c->stream));
       *value = (int64_t)h[0] + (int64_t)h[1];
     }
     return WGA_OK;
@@ -1804,13 +1831,23 @@ int wga_pafpseudo_fill(wga_ctx* c, const wga_cigar_batch* b, int base_mode, cons
   wga_ctx::ClassTab& t = c->class_tab;
   const bool kept = t.valid && t.ops == (const void*)b->d_ops && t.op_off == (const void*)b->d_op_off && t.n == b->n && t.n_ops == b->n_ops;
   t.valid = false; /* one shot: this fill call consumes what the class-sums call left (the sums stay where they are for this call) */
+  if (nt > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "batch too large for one launch", nullptr);
+  /* base mode: the streaming row kernel (wga_kernels_k2s.h, MODE 2) with its pre-pass; what it leaves goes to the block kernel */
+  const bool stream = base_mode && c->pseudo_variant == 3;
+  const size_t tile_bytes = kept ? 0 : ((size_t)nt * sizeof(wga_tile_sum) + 255) & ~(size_t)255;
+  const size_t sums_bytes = kept ? 0 : ((size_t)b->n * sizeof(wga_class_sums) + 255) & ~(size_t)255;
+  const size_t rec_bytes = stream ? ((size_t)b->n * sizeof(wga_rec_desc) + 255) & ~(size_t)255 : 0;
+  const size_t desc_bytes = stream ? (size_t)nt * sizeof(wga_tile_desc) : 0;
+  const size_t list_bytes = stream ? 256 + 2 * (size_t)nt * sizeof(u32) : 0;
+  const size_t flag_bytes = stream ? (((size_t)nt + 255) & ~(size_t)255) : 0;
+  void* ws = nullptr;
+  if (tile_bytes + sums_bytes + rec_bytes + desc_bytes + list_bytes + flag_bytes)
+    if ((rc = ctx_scratch(c, tile_bytes + sums_bytes + rec_bytes + desc_bytes + list_bytes + flag_bytes, &ws))) return rc;
+  c->pseudo_counts = nullptr;
   if (kept) {
     tiles = t.tiles; /* what wga_cigar_class_sums left for this batch */
     rec_sums = t.rec_sums;
   } else {
-    void* ws;
-    size_t tile_bytes = ((size_t)nt * sizeof(wga_tile_sum) + 63) & ~(size_t)63;
-    if ((rc = ctx_scratch(c, tile_bytes + (size_t)b->n * sizeof(wga_class_sums), &ws))) return rc;
     tiles = (wga_tile_sum*)ws;
     rec_sums = (wga_class_sums*)((char*)ws + tile_bytes);
     RT_CHECK(rt_memset(rec_sums, 0, (size_t)b->n * sizeof(wga_class_sums), c->stream));
@@ -1835,7 +1872,56 @@ int wga_pafpseudo_fill(wga_ctx* c, const wga_cigar_batch* b, int base_mode, cons
   a.out = d_out;
   a.dst_off = (const u64*)d_dst_off;
   a.diag = d_diag;
-  if (nt > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "batch too large for one launch", nullptr);
+  a.tile_count = nullptr;
+  a.tile_list = nullptr;
+  if (stream) {
+    char* const base = (char*)ws + tile_bytes + sums_bytes;
+    wga_rec_desc* const recs = (wga_rec_desc*)base;
+    wga_tile_desc* const tdesc = (wga_tile_desc*)(base + rec_bytes);
+    u32* const counts = (u32*)(base + rec_bytes + desc_bytes);
+    u32* const list_wide = counts + 64;
+    u32* const list_fast = list_wide + nt;
+    u8* const tile_flag = (u8*)(base + rec_bytes + desc_bytes + list_bytes);
+    RT_CHECK(rt_memset(counts, 0, 256, c->stream));
+    RT_CHECK(rt_memset(tile_flag, 0, flag_bytes, c->stream));
+    WGA_LAUNCH(k_pseudo_rec_desc, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, b->n, (const wga_class_sums*)rec_sums, b->d_strand_neg,
+               (const u64*)d_q_src_off, (const u64*)d_q_src_len, (const u64*)d_skip, (const u64*)d_dst_off, (const u64*)b->d_op_off,
+               (u64)q_fa_bytes, recs, tile_flag);
+    LAUNCH_CHECK();
+    WGA_LAUNCH(k_tile_base, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const u64*)b->d_op_off, (u64)b->n_ops,
+               (const wga_tile_sum*)tiles, (const wga_rec_desc*)recs, tdesc, 1);
+    LAUNCH_CHECK();
+    WGA_LAUNCH(k_stream_mark_tile, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, tdesc, (u64)nt, (const u8*)tile_flag, 0, counts,
+               list_fast, list_wide);
+    LAUNCH_CHECK();
+    c->pseudo_counts = counts;
+    ExpandArgs e;
+    memset(&e, 0, sizeof(e));
+    e.ops = b->d_ops;
+    e.op_off = (const u64*)b->d_op_off;
+    e.n_ops = b->n_ops;
+    e.tdesc = tdesc;
+    e.recs = recs;
+    e.q_fa = d_q_fa;
+    e.q_fa_bytes = q_fa_bytes;
+    e.out = d_out;
+    e.diag = d_diag;
+    e.n_rec = b->n;
+    e.job_tiles = c->expand_job_tiles < 1 ? 1u : (c->expand_job_tiles > (int)WGA_S_MAX_JOB_TILES ? WGA_S_MAX_JOB_TILES : (u32)c->expand_job_tiles);
+    const u64 jobs = (nt + e.job_tiles - 1) / e.job_tiles;
+    WGA_LAUNCH(k_pafpseudo_stream, (u32)((jobs + 1) / 2), 128u, c->stream, e);
+    LAUNCH_CHECK();
+    const u32 side_grid = nt < 256 ? (u32)nt : 256u;
+    a.tile_count = counts; /* tiles of records that are not clean or lie at a pool's edge, tiles beyond 2^24 bases */
+    a.tile_list = list_fast;
+    WGA_LAUNCH(k_pafpseudo_fill_list, side_grid, WGA_BLOCK, c->stream, a);
+    LAUNCH_CHECK();
+    a.tile_count = counts + 1; /* ... beyond 2^31: the block kernel decides on its op-serial walk itself */
+    a.tile_list = list_wide;
+    WGA_LAUNCH(k_pafpseudo_fill_list, side_grid, WGA_BLOCK, c->stream, a);
+    LAUNCH_CHECK();
+    return WGA_OK;
+  }
   if (base_mode)
     WGA_LAUNCH(k_pafpseudo_fill<true>, (u32)nt, WGA_BLOCK, c->stream, a);
   else

@@ -1141,9 +1141,11 @@ __global__ __launch_bounds__(256) void k_rec_desc(u32 n, const wga_cigar_counts*
  * where the record starts + totals of the tiles in between, plus everything else the expand
  * kernel wants to know up front (wga_tile_desc).  Walk-backs over more than 64 tiles (records
  * beyond 64 kop) are summed by the whole wave, one such tile at a time. */
+/* pseudo != 0 (pafpseudo's rows, wga_kernels_k2s.h): S ops count as I (both skip query bases without a column), and a tile's
+ * "columns" are everything it makes a row kernel walk (M = X I D S). */
 __global__ __launch_bounds__(256) void k_tile_base(const u64* op_off, u64 n_ops,
                                                    const wga_tile_sum* tiles,
-                                                   const wga_rec_desc* recs, wga_tile_desc* descs) {
+                                                   const wga_rec_desc* recs, wga_tile_desc* descs, int pseudo) {
   const u32 lane = threadIdx.x & 63u;
   const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
   const u64 tile_start = g * WGA_TILE;
@@ -1163,7 +1165,7 @@ __global__ __launch_bounds__(256) void k_tile_base(const u64* op_off, u64 n_ops,
       for (u64 k = g0; k < g; k++) {
         const u64* v = (k == g0) ? tiles[k].tail : tiles[k].tot;
         p_mx += v[CLS_MX];
-        p_i += v[CLS_I];
+        p_i += v[CLS_I] + (pseudo ? v[CLS_S] : 0ull);
         p_d += v[CLS_D];
       }
     } else {
@@ -1178,7 +1180,7 @@ __global__ __launch_bounds__(256) void k_tile_base(const u64* op_off, u64 n_ops,
     for (u64 k = gg0 + lane; k < gg; k += 64) {
       const u64* v = (k == gg0) ? tiles[k].tail : tiles[k].tot;
       a_mx += v[CLS_MX];
-      a_i += v[CLS_I];
+      a_i += v[CLS_I] + (pseudo ? v[CLS_S] : 0ull);
       a_d += v[CLS_D];
     }
     a_mx = wave_sum_u64(a_mx);
@@ -1194,7 +1196,7 @@ __global__ __launch_bounds__(256) void k_tile_base(const u64* op_off, u64 n_ops,
   if (!valid) return;
   const wga_rec_desc rd = recs[ts.rec];
   wga_tile_desc d;
-  d.tile_cols = ts.tot[CLS_MX] + ts.tot[CLS_I] + ts.tot[CLS_D];
+  d.tile_cols = ts.tot[CLS_MX] + ts.tot[CLS_I] + ts.tot[CLS_D] + (pseudo ? ts.tot[CLS_S] : 0ull);
   d.rec = (u32)ts.rec;
   d.neg = (u32)rd.neg;
   d.b_mx = p_mx;

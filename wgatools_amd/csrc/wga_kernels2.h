@@ -673,6 +673,8 @@ struct PseudoArgs {
   u8* out;
   const u64* dst_off;
   wga_rec_diag* diag;
+  const u32* tile_count; /* k_pafpseudo_fill_list: the blocks loop over tile_list[0 .. *tile_count) */
+  const u32* tile_list;
 };
 
 /* symbol mode: '1' for M/=, '0' for X, '-' for D, nothing for the rest (cigar.rs:760-796) */
@@ -737,7 +739,7 @@ __device__ __forceinline__ void emit_symbols(u8* dst, u32 N, u32 c0, const u32* 
 #define WGA_K6_BLOCKS_SYM 6
 #endif
 template <bool BASE>
-__global__ __launch_bounds__(256, BASE ? WGA_K6_BLOCKS_BASE : WGA_K6_BLOCKS_SYM) void k_pafpseudo_fill(PseudoArgs a) {
+__device__ __forceinline__ void pseudo_tile(const PseudoArgs& a, const u64 g) {
   /* the event lists and the chunk queue belong to the row emitter (base mode); symbol mode keeps 13 KB of LDS */
   __shared__ u32 s_col[WGA_TILE + 1];                  /* exclusive prefix of target columns (M = X D)          */
   __shared__ u32 s_ev[WGA_TILE + 1];                   /* exclusive count of event ops (D, I, S)                */
@@ -756,7 +758,6 @@ __global__ __launch_bounds__(256, BASE ? WGA_K6_BLOCKS_BASE : WGA_K6_BLOCKS_SYM)
   const u32 tid = threadIdx.x;
   build_lowmask(s_lowmask);
   const u32 lane = tid & 63u, wave = WGA_WAVE_ID(tid);
-  const u64 g = xcd_tile_of_block();
   const u64 tile_start = g * WGA_TILE;
   const u64 tile_end = tile_start + WGA_TILE < a.n_ops ? tile_start + WGA_TILE : a.n_ops;
   const u32 nt = (u32)(tile_end - tile_start);
@@ -989,6 +990,20 @@ __global__ __launch_bounds__(256, BASE ? WGA_K6_BLOCKS_BASE : WGA_K6_BLOCKS_SYM)
     }
     cur = seg_end;
     r++;
+  }
+}
+/* one block per tile of the batch: symbol mode, and base mode when the streaming row kernel is switched off ("pseudo_variant" 0) */
+template <bool BASE>
+__global__ __launch_bounds__(256, BASE ? WGA_K6_BLOCKS_BASE : WGA_K6_BLOCKS_SYM) void k_pafpseudo_fill(PseudoArgs a) {
+  pseudo_tile<BASE>(a, xcd_tile_of_block());
+}
+/* base mode, the tiles the streaming row kernel (k_pafpseudo_stream, wga_kernels_k2s.h) leaves: records whose slice is not
+ * exactly what their CIGAR consumes (leftover bases, drain / insert_str panics), slices at a pool's edge, giant tiles */
+__global__ __launch_bounds__(256, WGA_K6_BLOCKS_BASE) void k_pafpseudo_fill_list(PseudoArgs a) {
+  const u32 n_list = *a.tile_count;
+  for (u32 idx = blockIdx.x; idx < n_list; idx += gridDim.x) {
+    pseudo_tile<true>(a, a.tile_list[idx]);
+    __syncthreads(); /* the tile's LDS state is dead */
   }
 }
 

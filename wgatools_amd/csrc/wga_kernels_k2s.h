@@ -84,6 +84,38 @@ __global__ __launch_bounds__(256) void k_stream_mark_tile(wga_tile_desc* descs, 
   }
 }
 
+/* pafpseudo (MODE 2 below): the record descriptors of its base-mode rows in the row kernel's format.  The row of record r is
+ * the query slice in TARGET coordinates (M = X D columns); column x >= skip goes to out + dst_off + x - skip, so the "row
+ * offset" is dst_off - skip (it may wrap below zero: only columns >= skip are written) and skip rides in the unused t_src_len.
+ * A record is clean when its slice is exactly what the CIGAR consumes (M = X I S): no leftover bases to append, no
+ * String::drain / insert_str panic (cigar.rs:769-786); the others, and slices within 32 bytes of the pool's edges, mark their
+ * tiles for k_pafpseudo_fill_list. */
+__global__ __launch_bounds__(256) void k_pseudo_rec_desc(u32 n, const wga_class_sums* sums, const u8* strand_neg, const u64* q_src_off,
+                                                         const u64* q_src_len, const u64* skip, const u64* dst_off, const u64* op_off,
+                                                         u64 q_fa_bytes, wga_rec_desc* out, u8* tile_flag) {
+  const u32 r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= n) return;
+  const wga_class_sums cs = sums[r];
+  wga_rec_desc d;
+  d.t_row_off = 0;
+  d.q_row_off = dst_off[r] - skip[r];
+  d.t_src_off = 0;
+  d.t_src_len = skip[r];
+  d.q_src_off = q_src_off[r];
+  d.q_src_len = q_src_len[r];
+  d.I_total = cs.i + cs.s;
+  d.D_total = cs.d;
+  d.L = cs.mx + cs.d;
+  const bool clean = d.q_src_len == cs.mx + cs.i + cs.s;
+  const bool inside = d.q_src_off >= 32ull && d.q_src_off + d.q_src_len + 32ull <= q_fa_bytes;
+  d.neg = (strand_neg[r] != 0 ? 1u : 0u) | (clean ? 0u : 8u);
+  out[r] = d;
+  if (clean && inside) return;
+  const u64 a = op_off[r], b = op_off[r + 1];
+  if (b <= a) return;
+  for (u64 t = a / WGA_TILE; t <= (b - 1) / WGA_TILE; t++) tile_flag[t] = 1;
+}
+
 /* comp4 (wga_kernels.h) with '-' mapped to itself, so that granules that already hold gap characters pass through unchanged;
  * a '-' is still flagged as an invalid BASE (a plain granule only holds source bytes) */
 __device__ __forceinline__ u32 comp4s(u32 x, u32* bad) {
@@ -127,7 +159,16 @@ __device__ WGA_S_NOINLINE void stream_report_bad(u64* bad_base_pos, u32 b0, u32 
 }
 
 /* ---- the stream of one wave ----------------------------------------------------------------------------------------- */
-template <bool QROW>
+/* MODE 0: paf2maf's target row (gaps = I ops), 1: its query row (gaps = D ops), 2: pafpseudo's base-mode row (K6: the query in
+ * TARGET coordinates, gen_pesudo_maf_by_cigar cigar.rs:744-804 — D ops are gaps, I / S ops SKIP source bytes without writing a
+ * column: an event with no gap characters that lowers the adjustment; a FIFO entry's second word is then "gap bases minus
+ * skipped bases in front" and an event's gap length max(0, next - own): the sign tells the two kinds apart) */
+#define WGA_S_PSEUDO 2
+template <int MODE>
+__device__ __forceinline__ u32 stream_glen(u32 c0, u32 c1) { /* gap characters of the event between two adjustments */
+  return MODE == WGA_S_PSEUDO ? ((int)(c1 - c0) > 0 ? c1 - c0 : 0u) : c1 - c0;
+}
+template <int MODE>
 __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, const u32 lane, const u64 t0, const u64 t1) {
   u32* const s_fifo = (u32*)lds;                                 /* (WGA_S_FIFO + 4) x (start column, cum)    */
   u32x4_a16* const s_P = (u32x4_a16*)(s_fifo + 2u * (WGA_S_FIFO + 4u)); /* 64 granules put together by the queue's lanes */
@@ -140,6 +181,10 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
     for (int d = 0; d < 4; d++) m[d] = bytemask(0, (int)lane - 4 * d);
     s_lm[lane] = m;
   }
+  constexpr bool QROW = MODE != 0;
+  constexpr u32 COL_MASK = MODE == WGA_S_PSEUDO ? 0x585u : 0x787u;   /* op codes that are columns of the row: M D = X (+ I in paf2maf) */
+  constexpr u32 GAP_MASK = MODE == 0 ? 0x202u : 0x404u;              /* ... that are its gaps: I / D (and their continuation codes) */
+  constexpr u32 SKIP_MASK = MODE == WGA_S_PSEUDO ? 0x212u : 0u;      /* ... that skip source bytes: I S (pafpseudo) */
   const u8* const fa = QROW ? a.q_fa : a.t_fa;
   const u64 fa_bytes = QROW ? a.q_fa_bytes : a.t_fa_bytes;
   const u64 job_lo = t0 * WGA_TILE;
@@ -163,9 +208,39 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
   bool bnd = false;    /* a record ends at column C_b (gap bases cum_b in front) of the ops taken in */
   bool fin = false;    /* write everything known, even a super-step that does not fill its kilobytes */
   u32 C_b = 0, cum_b = 0;
+  u32 C_min = 0;       /* pafpseudo: the record's first column that is written (its overlap with the record in front is trimmed) */
   u64 t = t0;          /* tile of op q                                                            */
   u32 ow[4] = {0, 0, 0, 0}, xl0 = 0, xg0 = 0; /* the ops taken in last, the columns / gap bases in front of each lane's first */
   u32 own[4] = {0, 0, 0, 0}; /* the next 256 ops, on their way */
+
+  /* pafpseudo only: skip events are no columns, so any number of them can stand on ONE column (consecutive I / S ops) and
+   * neither the byte counters of a super-step nor the FIFO's flush get past them.  Of a run of skip events on one column only
+   * the first is needed (every entry holds the adjustment in front of it, the next entry the one behind the whole run): the
+   * others are taken out, by one lane — rare and short */
+  auto fifo_dedupe = [&]() {
+    WGA_WAVE_SYNC();
+    u32 n_new = nf;
+    if (lane == 0u) {
+      u32 w = e0;
+      for (u32 r = e0; r < nf; r++) {
+        const u32 gs = s_fifo[2u * r], cu = s_fifo[2u * r + 1u];
+        const bool dup = w > e0 && s_fifo[2u * (w - 1u)] == gs && (int)(cu - s_fifo[2u * (w - 1u) + 1u]) <= 0 &&
+                         (int)(s_fifo[2u * (r + 1u) + 1u] - cu) <= 0; /* the one kept in front is a skip on this column, and so is this */
+        if (!dup) {
+          s_fifo[2u * w] = gs;
+          s_fifo[2u * w + 1u] = cu;
+          w++;
+        }
+      }
+      for (u32 k = 0; k < 3u; k++) { /* the sentinels move up */
+        s_fifo[2u * (w + k)] = s_fifo[2u * (nf + k)];
+        s_fifo[2u * (w + k) + 1u] = s_fifo[2u * (nf + k) + 1u];
+      }
+      n_new = w;
+    }
+    nf = wave_get_u32(n_new, 0);
+    WGA_WAVE_SYNC();
+  };
 
   for (;;) {
     /* ================= write columns: ONE site for the super-step ================= */
@@ -173,6 +248,17 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
       const u32 lim = bnd ? C_b : C_known;
       const bool all = bnd || fin;
       while ((int)(lim - pos) > 0) {
+        if (MODE == WGA_S_PSEUDO && (int)(C_min - pos) > 0) { /* the record's columns in front of its first written one */
+          const u32 to = (int)(lim - C_min) > 0 ? C_min : lim;
+          u32 c;
+          do { /* e0: past the events that start in front of `to` */
+            const u32 idx = e0 + lane < nf ? e0 + lane : nf;
+            c = (u32)__popcll(__ballot(idx < nf && (int)(s_fifo[2u * idx] - to) < 0));
+            e0 += c;
+          } while (c == 64u);
+          pos = to;
+          continue;
+        }
         u8* const A = dst_seg + pos;
         const u32 mis = (u32)(u64)A & 1023u;
         u8* const B = A - mis;
@@ -184,6 +270,10 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
         if (e0 + 255u < nf) { /* gaps every few columns: a super-step counts its events in bytes, so it ends in front of its 256th */
           const u32 g255 = WGA_UNI32(s_fifo[2u * (e0 + 255u)]);
           if ((int)(g255 - Ce) < 0) Ce = Cl0 + ((g255 - Cl0) & ~15u);
+          if (MODE == WGA_S_PSEUDO && (int)(Ce - Cs) < 16) { /* hundreds of skip events on one column: made one, then again */
+            fifo_dedupe();
+            continue;
+          }
         }
 
         /* ---- (1) the super-step's events, counted per granule: byte u of T[l] = events that start in granule l of kilobyte u ---- */
@@ -225,7 +315,7 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
           const u32 Cl = Cl0 + 1024u * u + 16u * lane;
           const bool whole = any16 && (Cl - Cs) <= wsp, active = (Cl + 15u - Cs) < asp;
           const u32x4_a1 fe = *(const u32x4_a1*)(s_fifo + 2u * (k - 1u)); /* events k - 1, k: start, gap bases in front */
-          const int rel0 = (int)(fe[0] + (fe[3] - fe[1]) - Cl); /* how far the gap in front reaches into the granule */
+          const int rel0 = (int)(fe[0] + stream_glen<MODE>(fe[1], fe[3]) - Cl); /* how far the gap in front reaches into the granule */
           const bool quiet = whole && cnt == 0u;    /* a whole granule in which no gap starts ... */
           const bool plain = quiet && rel0 <= 0;    /* ... sixteen source bytes in a row        */
           const bool dashes = quiet && rel0 >= 16;  /* ... sixteen gap characters               */
@@ -273,11 +363,12 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
           const u32x4_a1 eb = *(const u32x4_a1*)(s_fifo + 2u * (k + 1u)); /* events k + 1, k + 2 */
           const u32 gs0 = ea[0], cu0 = ea[1], gs1 = ea[2], cu1 = ea[3], gs2 = eb[0], cu2 = eb[1];
           /* [lo, a1) the rest of the gap in front | [a1, b1) source behind it | [b1, e1) the gap that starts here | [e1, hi) source */
-          int a1 = (int)(gs0 + (cu1 - cu0) - Cl);
+          int a1 = (int)(gs0 + stream_glen<MODE>(cu0, cu1) - Cl);
           a1 = a1 < lo ? lo : (a1 > hi ? hi : a1);
           int b1 = (int)(gs1 - Cl);
           b1 = b1 < a1 ? a1 : (b1 > hi ? hi : b1);
-          int e1 = (cu2 - cu1) >= 16u ? 16 : b1 + (int)(cu2 - cu1);
+          const u32 gl1 = stream_glen<MODE>(cu1, cu2);
+          int e1 = gl1 >= 16u ? 16 : b1 + (int)gl1;
           e1 = e1 > hi ? hi : e1;
           bool more = (int)(gs2 - Cl) < hi;
           u32 W0[4], W1[4];
@@ -300,7 +391,7 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
           while (more) { /* further events inside the granule: one round per event (rare: gaps are ~150 columns apart) */
             const u32 gsi = s_fifo[2u * ie], cui = s_fifo[2u * ie + 1u], gsn = s_fifo[2u * ie + 2u], cun = s_fifo[2u * ie + 3u];
             const int b = (int)(gsi - Cl);
-            const u32 len = cun - cui;
+            const u32 len = stream_glen<MODE>(cui, cun);
             const int e = len >= (u32)(hi - b) ? hi : b + (int)len;
             u32 W[4];
             buf_load16(sbuf, rc ? S32 - Cl + cun : S32 + Cl - cun, W);
@@ -401,6 +492,10 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
         sb = 0;
         C_a = C_b;
         cum_a = cum_b;
+        if (MODE == WGA_S_PSEUDO) { /* the columns in front of `skip` (kept in the descriptor's unused t_src_len) are not written */
+          const u64 skip = WGA_UNI64(rd->t_src_len);
+          C_min = C_a + (u32)(skip < 0x40000000ull ? skip : 0x40000000ull);
+        }
       } else {
         /* (re)start: the next tile that is this kernel's */
         while (t < t1 && (WGA_UNI32(a.tdesc[t].neg) & WGA_S_SKIP)) t++;
@@ -427,16 +522,21 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
         src_off = WGA_UNI64(QROW ? td->q_src_off : td->t_src_off);
         src_len = WGA_UNI64(QROW ? td->q_src_len : td->t_src_len);
         neg = (WGA_UNI32(td->neg) & 1u) != 0u;
-        x_a = b_mx + b_i + b_d;
+        x_a = MODE == WGA_S_PSEUDO ? b_mx + b_d : b_mx + b_i + b_d; /* pafpseudo: I (and S, folded into b_i) are no columns */
         sb = QROW ? b_mx + b_i : b_mx + b_d;
         C_a = cum_a = 0u;
+        if (MODE == WGA_S_PSEUDO) {
+          const u64 skip = WGA_UNI64(td->t_src_len);
+          const u64 ahead = skip > x_a ? skip - x_a : 0ull;
+          C_min = (u32)(ahead < 0x40000000ull ? ahead : 0x40000000ull);
+        }
         buf_load16(obuf, q * 4u + lane * 16u, own); /* the first 256 ops */
         live = true;
       }
       /* the segment: column C_a (cum_a gap bases in front) is column x_a of the record's row, sb bases of its slice used.
        * A non-gap column C (cum gap bases in front) reads slice index (C - cum) + Kseg, Kseg = sb - (C_a - cum_a); the job
        * reaches at most 2^30 bases further, so the buffer starts a little in front of the first one (offsets stay 32-bit). */
-      dst_seg = a.out + row_off + x_a - (u64)C_a;
+      dst_seg = (u8*)((u64)a.out + row_off + x_a - (u64)C_a); /* pafpseudo: row_off may have wrapped below zero */
       rc = QROW && neg;
       const u32 adv = C_a - cum_a;
       u64 base; /* pool offset of the buffer's first byte */
@@ -466,8 +566,8 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
         for (u32 i = 0; i < 3u; i++) {
           const bool valid = q_lo + 4u * lane + i < q_hi && i < e;
           const u32 len = valid ? ow[i] >> 4 : 0u, code = ow[i] & 15u;
-          vl += len & bit_mask(0x787u, code);
-          vg += len & bit_mask(QROW ? 0x404u : 0x202u, code);
+          vl += len & bit_mask(COL_MASK, code);
+          vg += (len & bit_mask(GAP_MASK, code)) - (len & bit_mask(SKIP_MASK, code));
         }
         C_b = wave_get_u32_dyn(vl, kb >> 2);
         cum_b = wave_get_u32_dyn(vg, kb >> 2);
@@ -514,6 +614,10 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
       fin = true;
       if (pos != C_known) continue;
       fin = false;
+      if (MODE == WGA_S_PSEUDO) { /* what is left stands on the last column: runs of skip events */
+        fifo_dedupe();
+        if (nf + 256u > WGA_S_FIFO) break; /* cannot happen: a column holds at most one skip run and the gap events in front of it */
+      }
     }
     /* ---- take 256 ops in ---- */
     q_lo = q;
@@ -526,8 +630,8 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
     for (int e = 0; e < 4; e++) {
       const bool valid = q_lo + 4u * lane + (u32)e < q_hi;
       const u32 len = valid ? ow[e] >> 4 : 0u, code = ow[e] & 15u;
-      l[e] = len & bit_mask(0x787u, code);                  /* M I D = X and the continuation codes: columns   */
-      g[e] = len & bit_mask(QROW ? 0x404u : 0x202u, code);  /* D (query row) / I (target row): this row's gaps */
+      l[e] = len & bit_mask(COL_MASK, code);                                           /* columns of the row                          */
+      g[e] = (len & bit_mask(GAP_MASK, code)) - (len & bit_mask(SKIP_MASK, code));     /* its gaps (+) and skipped source bytes (-)   */
       sl += l[e];
       sg += g[e];
       sc += g[e] != 0u ? 1u : 0u;
@@ -563,8 +667,8 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
       for (u32 i = 0; i < 3u; i++) {
         const bool valid = q_lo + 4u * lane + i < q_hi && i < e;
         const u32 len = valid ? ow[i] >> 4 : 0u, code = ow[i] & 15u;
-        vl += len & bit_mask(0x787u, code);
-        vg += len & bit_mask(QROW ? 0x404u : 0x202u, code);
+        vl += len & bit_mask(COL_MASK, code);
+        vg += (len & bit_mask(GAP_MASK, code)) - (len & bit_mask(SKIP_MASK, code));
       }
       C_b = wave_get_u32_dyn(vl, kb >> 2);
       cum_b = wave_get_u32_dyn(vg, kb >> 2);
@@ -591,14 +695,25 @@ __device__ __forceinline__ void expand_stream(const ExpandArgs& a) {
   const u64 t1 = t0 + a.job_tiles < nt ? t0 + a.job_tiles : nt;
   u8* const lds = (u8*)s_mem + wave * WGA_S_WAVE_BYTES;
   if (wave == 0u)
-    stream_row<false>(a, lds, lane, t0, t1);
+    stream_row<0>(a, lds, lane, t0, t1);
   else
-    stream_row<true>(a, lds, lane, t0, t1);
+    stream_row<1>(a, lds, lane, t0, t1);
+}
+/* pafpseudo's base-mode rows (K6): every wave of the block walks a job of its own */
+__device__ __forceinline__ void pseudo_stream(const ExpandArgs& a) {
+  __shared__ u32x4_a16 s_mem[2u * WGA_S_WAVE_BYTES / 16u];
+  const u32 lane = threadIdx.x & 63u, wave = WGA_WAVE_ID(threadIdx.x);
+  const u64 nt = (a.n_ops + WGA_TILE - 1) / WGA_TILE;
+  const u64 t0 = (2u * xcd_job_of_block() + wave) * a.job_tiles;
+  if (t0 >= nt) return;
+  const u64 t1 = t0 + a.job_tiles < nt ? t0 + a.job_tiles : nt;
+  stream_row<WGA_S_PSEUDO>(a, (u8*)s_mem + wave * WGA_S_WAVE_BYTES, lane, t0, t1);
 }
 #ifndef WGA_S_WAVES_PER_SIMD
 #define WGA_S_WAVES_PER_SIMD 5 /* launch bound: 96 VGPRs (the natural need is 102: two spill slots), LDS allows 31 waves per CU; 4: 6.0 ms, 5: 5.66 ms, 6 (61 spill slots): 7.4 ms */
 #endif
 __global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_paf2maf_expand_s(ExpandArgs a) { expand_stream(a); }
 __global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_paf2maf_expand_s_alias(ExpandArgs a) { expand_stream(a); }
+__global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_pafpseudo_stream(ExpandArgs a) { pseudo_stream(a); }
 
 #endif
