@@ -9,7 +9,11 @@ nrec = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 mean_ops = int(sys.argv[2]) if len(sys.argv) > 2 else 5000     # e.g. 10000 50000: the records go through the piece kernels
 dev = torch.device("cuda", 0)
 tb = synth.make_paf_batch_torch(0x5747415F + 2, nrec, mean_ops, 50_000_000, dev)
-eng = engine.Engine(0)
+lib = None
+if os.environ.get("WGA_LIB_VARIANT"):     # an A/B build (wgatools_amd.build.build_hip_variant)
+    from wgatools_amd import _lib, build
+    lib = _lib.load(os.path.join(build.ROOT, "build_variants", "libwgahip_%s.so" % os.environ["WGA_LIB_VARIANT"]))
+eng = engine.Engine(0, lib)
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 batch = engine.Batch(tb["ops"], tb["op_off"], tb["strand_neg"], tb["n"], tb["n_ops"])
 n, n_ops = tb["n"], tb["n_ops"]
@@ -43,15 +47,15 @@ total = int(seg.sum().item())
 out = torch.zeros(total + 64, dtype=torch.uint8, device=dev)
 skip = torch.zeros(n, dtype=torch.int64, device=dev)
 ref = None
-for mode, variant in ((0, 0), (1, 0), (1, 3)):   # base mode: one block per tile, then the streaming row kernel (the default)
+for mode, variant in ((0, 0), (0, 3), (1, 0), (1, 3)):   # one block per tile, then the streaming row kernel (the default)
     eng.set_param("pseudo_variant", variant)
     out.zero_()
     ms = timed(lambda: eng.pafpseudo_fill(batch, mode, tb["q_pool"], int(tb["q_pool"].numel()), tb["q_src_off"], tb["q_src_len"], skip, out, dst_off))
     rd = 4 * n_ops + (int(tb["q_src_len"].sum().item()) if mode else 0)
     note = ""
-    if mode and variant == 0:
+    if variant == 0:
         ref = out.clone()
-    if mode and variant == 3:
+    if variant == 3:
         note = "; streaming row kernel, %d tiles left to the block kernel, same bytes as the block kernel: %s" % (
             eng.get_param("pseudo_stream_left_to_blocks"), bool(torch.equal(ref, out)))
         del ref

@@ -650,13 +650,19 @@ def pseudo_clean(rng, b, margin=64):
 
 
 def pseudo_stream_cases(eng):
-    """pafpseudo's base-mode rows through the streaming row kernel ("pseudo_variant" 3): every job length; S ops; heads trimmed
+    """pafpseudo's rows (both modes) through the streaming row kernel ("pseudo_variant" 3): every job length; S ops; heads trimmed
     by a few columns, by whole tiles, by more than the record has; records whose slice is longer / shorter than the edit
     consumes (left to the block kernel) between clean ones; hundreds of I / S ops in a row on one column (events without
     columns: the FIFO's dedupe), leading and trailing clips, dense D / I; a record over many jobs; invalid bases on '-'
     strand rows; slices at the pool's edges.  Every case also through the block kernel (variant 0)."""
     from wgatools_amd import synth
     before = eng.get_param("expand_job_tiles")
+    def chk(b, skip=None, variant=3):
+        """symbol mode (no slices: nothing is left to the block kernel but giant tiles), then base mode"""
+        check_pafpseudo(eng, b, 0, skip=skip, variant=variant)
+        if variant == 3:
+            assert eng.get_param("pseudo_stream_left_to_blocks") == 0
+        check_pafpseudo(eng, b, 1, skip=skip, variant=variant)
     try:
         for jt in (1, 2, 8, 32):
             eng.set_param("expand_job_tiles", jt)
@@ -664,14 +670,14 @@ def pseudo_stream_cases(eng):
             b = synth.make_paf_batch(70 + jt, 9, 3000, 300_000)
             b = sprinkle_ops(rng, b, frac=0.03, codes=(3, 4, 4, 5, 6, 11))
             b = pseudo_clean(rng, b)
-            check_pafpseudo(eng, b, 1, variant=3)
+            chk(b, variant=3)
             assert eng.get_param("pseudo_stream_left_to_blocks") == 0
             tot = synth.class_sums(b["ops"] & 15, b["ops"] >> 4, b["op_off"])
             cols = (tot["mx"] + tot["d"]).astype(np.int64)
             skip = np.array([0, 5, 1023, 1024, 4097, int(cols[5]), int(cols[6]) - 1, int(cols[7]) // 2, 17], dtype=np.int64)
             skip = np.minimum(skip, cols)
             for v in (3, 0):
-                check_pafpseudo(eng, b, 1, skip=skip, variant=v)
+                chk(b, skip=skip, variant=v)
             # records 2 and 5: leftover bases behind the CIGAR, record 6 a slice that is too short (drain panics)
             u = dict(b)
             ql = b["q_src_len"].copy()
@@ -679,7 +685,7 @@ def pseudo_stream_cases(eng):
             ql[5] += 300
             ql[6] -= min(5, int(ql[6]))
             u["q_src_len"] = ql
-            check_pafpseudo(eng, u, 1, skip=np.minimum(skip, 40), variant=3)
+            chk(u, skip=np.minimum(skip, 40), variant=3)
             assert eng.get_param("pseudo_stream_left_to_blocks") > 0
         eng.set_param("expand_job_tiles", 4)
         rng = np.random.default_rng(5)
@@ -698,9 +704,9 @@ def pseudo_stream_cases(eng):
         bt["q_pool"] = np.concatenate([np.frombuffer(b"N" * 64, np.uint8), bt["q_pool"], np.frombuffer(b"N" * 64, np.uint8)])
         bt["q_src_off"] = bt["q_src_off"] + np.uint64(64)
         for v in (3, 0):
-            check_pafpseudo(eng, bt, 1, variant=v)
-            check_pafpseudo(eng, bt, 1, skip=[3, 41, 0, 9100, 16, 0, 2300, 7], variant=v)
-        check_pafpseudo(eng, bt, 1, variant=3)
+            chk(bt, variant=v)
+            chk(bt, skip=[3, 41, 0, 9100, 16, 0, 2300, 7], variant=v)
+        chk(bt, variant=3)
         assert eng.get_param("pseudo_stream_left_to_blocks") == 0
         # more than 255 clip / insertion ops on ONE column inside one super-step (its event counters are bytes): ten at the end
         # of one intake of 256 ops, 255 at the start of the next, columns behind them
@@ -709,13 +715,13 @@ def pseudo_stream_cases(eng):
             bt = batch_from_texts(eng, cg, st, [b"A"] * 3, [rand_seq(rng, pseudo_consumption(c)) for c in cg], pad=80)
             bt["q_pool"] = np.concatenate([np.frombuffer(b"N" * 64, np.uint8), bt["q_pool"], np.frombuffer(b"N" * 64, np.uint8)])
             bt["q_src_off"] = bt["q_src_off"] + np.uint64(64)
-            check_pafpseudo(eng, bt, 1, variant=3)
+            chk(bt, variant=3)
             assert eng.get_param("pseudo_stream_left_to_blocks") == 0
-            check_pafpseudo(eng, bt, 1, skip=[250, 0, 236], variant=3)
+            chk(bt, skip=[250, 0, 236], variant=3)
         big = synth.make_paf_batch(12, 1, 40_000, 400_000, sigma=0.01)      # one record over ~40 tiles = 10 jobs
         big = pseudo_clean(rng, big)
-        check_pafpseudo(eng, big, 1, variant=3)
-        check_pafpseudo(eng, big, 1, skip=[30_011], variant=3)
+        chk(big, variant=3)
+        chk(big, skip=[30_011], variant=3)
         assert eng.get_param("pseudo_stream_left_to_blocks") == 0
         bad = pseudo_clean(rng, synth.make_paf_batch(13, 3, 3000, 100_000))   # invalid bases on '-' strand rows
         bad["strand_neg"][:] = 1
@@ -724,12 +730,11 @@ def pseudo_stream_cases(eng):
             qp[int(bad["q_src_off"][r_] + bad["q_src_len"][r_] * f // 7)] = ord("R-x"[f % 3])
         bad["q_pool"] = qp
         for v in (3, 0):
-            check_pafpseudo(eng, bad, 1, variant=v)
+            chk(bad, variant=v)
         # slices that begin at byte 0 and end at the last byte of the pool
         cig = ["700=3I900=2D650=", "1500=1X200=4D300=2S"]
         for st in ([0, 0], [1, 1]):
-            check_pafpseudo(eng, batch_from_texts(eng, cig, st, [b"A"] * 2, [rand_seq(rng, pseudo_consumption(c)) for c in cig], pad=0),
-                            1, variant=3)
+            chk(batch_from_texts(eng, cig, st, [b"A"] * 2, [rand_seq(rng, pseudo_consumption(c)) for c in cig], pad=0), variant=3)
             assert eng.get_param("pseudo_stream_left_to_blocks") > 0
     finally:
         eng.set_param("expand_job_tiles", before)

@@ -48,7 +48,7 @@ struct wga_ctx {
                               kernel of wga_kernels_k2w.h, longer ones v1), 0 v1 (wga_kernels.h), 2 the window kernel */
   int expand_variant_used = 0;
   int expand_job_tiles = 8; /* streaming kernel: tiles per wave ("expand_job_tiles") */
-  int pseudo_variant = 3;   /* pafpseudo's base-mode rows: 3 the streaming row kernel, 0 one block per tile ("pseudo_variant") */
+  int pseudo_variant = 3;   /* pafpseudo's rows: 3 the streaming row kernel, 0 one block per tile ("pseudo_variant") */
   const u32* pseudo_counts = nullptr; /* ... the two counters of the tiles its last launch left to the block kernel */
   const u32* stream_counts = nullptr; /* streaming kernel: the two counters of the tiles its last launch left to v1 (in the scratch arena) */
   void* scratch = nullptr;
@@ -557,7 +557,7 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
     c->expand_job_tiles = (int)value;
     return WGA_OK;
   }
-  if (strcmp(name, "pseudo_variant") == 0) { /* wga_pafpseudo_fill, base mode: 3 the streaming row kernel (default), 0 one block per tile */
+  if (strcmp(name, "pseudo_variant") == 0) { /* wga_pafpseudo_fill: 3 the streaming row kernel (default), 0 one block per tile */
     if (value != 0 && value != 3) return fail(WGA_E_INVALID_ARG, "pseudo_variant: 0, 3", nullptr);
     c->pseudo_variant = (int)value;
     return WGA_OK;
@@ -1832,8 +1832,8 @@ int wga_pafpseudo_fill(wga_ctx* c, const wga_cigar_batch* b, int base_mode, cons
   const bool kept = t.valid && t.ops == (const void*)b->d_ops && t.op_off == (const void*)b->d_op_off && t.n == b->n && t.n_ops == b->n_ops;
   t.valid = false; /* one shot: this fill call consumes what the class-sums call left (the sums stay where they are for this call) */
   if (nt > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "batch too large for one launch", nullptr);
-  /* base mode: the streaming row kernel (wga_kernels_k2s.h, MODE 2) with its pre-pass; what it leaves goes to the block kernel */
-  const bool stream = base_mode && c->pseudo_variant == 3;
+  /* the streaming row kernel (wga_kernels_k2s.h, MODE 2 / 3) with its pre-pass; what it leaves goes to the block kernel */
+  const bool stream = c->pseudo_variant == 3;
   const size_t tile_bytes = kept ? 0 : ((size_t)nt * sizeof(wga_tile_sum) + 255) & ~(size_t)255;
   const size_t sums_bytes = kept ? 0 : ((size_t)b->n * sizeof(wga_class_sums) + 255) & ~(size_t)255;
   const size_t rec_bytes = stream ? ((size_t)b->n * sizeof(wga_rec_desc) + 255) & ~(size_t)255 : 0;
@@ -1885,8 +1885,8 @@ int wga_pafpseudo_fill(wga_ctx* c, const wga_cigar_batch* b, int base_mode, cons
     RT_CHECK(rt_memset(counts, 0, 256, c->stream));
     RT_CHECK(rt_memset(tile_flag, 0, flag_bytes, c->stream));
     WGA_LAUNCH(k_pseudo_rec_desc, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, b->n, (const wga_class_sums*)rec_sums, b->d_strand_neg,
-               (const u64*)d_q_src_off, (const u64*)d_q_src_len, (const u64*)d_skip, (const u64*)d_dst_off, (const u64*)b->d_op_off,
-               (u64)q_fa_bytes, recs, tile_flag);
+               base_mode ? (const u64*)d_q_src_off : nullptr, base_mode ? (const u64*)d_q_src_len : nullptr, (const u64*)d_skip,
+               (const u64*)d_dst_off, (const u64*)b->d_op_off, (u64)q_fa_bytes, recs, tile_flag);
     LAUNCH_CHECK();
     WGA_LAUNCH(k_tile_base, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const u64*)b->d_op_off, (u64)b->n_ops,
                (const wga_tile_sum*)tiles, (const wga_rec_desc*)recs, tdesc, 1);
@@ -1902,23 +1902,32 @@ int wga_pafpseudo_fill(wga_ctx* c, const wga_cigar_batch* b, int base_mode, cons
     e.n_ops = b->n_ops;
     e.tdesc = tdesc;
     e.recs = recs;
-    e.q_fa = d_q_fa;
-    e.q_fa_bytes = q_fa_bytes;
+    e.q_fa = base_mode ? d_q_fa : nullptr;
+    e.q_fa_bytes = base_mode ? q_fa_bytes : 0;
     e.out = d_out;
     e.diag = d_diag;
     e.n_rec = b->n;
     e.job_tiles = c->expand_job_tiles < 1 ? 1u : (c->expand_job_tiles > (int)WGA_S_MAX_JOB_TILES ? WGA_S_MAX_JOB_TILES : (u32)c->expand_job_tiles);
     const u64 jobs = (nt + e.job_tiles - 1) / e.job_tiles;
-    WGA_LAUNCH(k_pafpseudo_stream, (u32)((jobs + 1) / 2), 128u, c->stream, e);
+    if (base_mode)
+      WGA_LAUNCH(k_pafpseudo_stream, (u32)((jobs + 1) / 2), 128u, c->stream, e);
+    else
+      WGA_LAUNCH(k_pafpseudo_stream_sym, (u32)((jobs + 1) / 2), 128u, c->stream, e);
     LAUNCH_CHECK();
     const u32 side_grid = nt < 256 ? (u32)nt : 256u;
     a.tile_count = counts; /* tiles of records that are not clean or lie at a pool's edge, tiles beyond 2^24 bases */
     a.tile_list = list_fast;
-    WGA_LAUNCH(k_pafpseudo_fill_list, side_grid, WGA_BLOCK, c->stream, a);
+    if (base_mode)
+      WGA_LAUNCH(k_pafpseudo_fill_list<true>, side_grid, WGA_BLOCK, c->stream, a);
+    else
+      WGA_LAUNCH(k_pafpseudo_fill_list<false>, side_grid, WGA_BLOCK, c->stream, a);
     LAUNCH_CHECK();
     a.tile_count = counts + 1; /* ... beyond 2^31: the block kernel decides on its op-serial walk itself */
     a.tile_list = list_wide;
-    WGA_LAUNCH(k_pafpseudo_fill_list, side_grid, WGA_BLOCK, c->stream, a);
+    if (base_mode)
+      WGA_LAUNCH(k_pafpseudo_fill_list<true>, side_grid, WGA_BLOCK, c->stream, a);
+    else
+      WGA_LAUNCH(k_pafpseudo_fill_list<false>, side_grid, WGA_BLOCK, c->stream, a);
     LAUNCH_CHECK();
     return WGA_OK;
   }

@@ -992,17 +992,18 @@ __device__ __forceinline__ void pseudo_tile(const PseudoArgs& a, const u64 g) {
     r++;
   }
 }
-/* one block per tile of the batch: symbol mode, and base mode when the streaming row kernel is switched off ("pseudo_variant" 0) */
+/* one block per tile of the batch: when the streaming row kernel is switched off ("pseudo_variant" 0) */
 template <bool BASE>
 __global__ __launch_bounds__(256, BASE ? WGA_K6_BLOCKS_BASE : WGA_K6_BLOCKS_SYM) void k_pafpseudo_fill(PseudoArgs a) {
   pseudo_tile<BASE>(a, xcd_tile_of_block());
 }
-/* base mode, the tiles the streaming row kernel (k_pafpseudo_stream, wga_kernels_k2s.h) leaves: records whose slice is not
- * exactly what their CIGAR consumes (leftover bases, drain / insert_str panics), slices at a pool's edge, giant tiles */
-__global__ __launch_bounds__(256, WGA_K6_BLOCKS_BASE) void k_pafpseudo_fill_list(PseudoArgs a) {
+/* the tiles the streaming row kernel (k_pafpseudo_stream / _sym, wga_kernels_k2s.h) leaves: giant tiles and, in base mode, records
+ * whose slice is not exactly what their CIGAR consumes (leftover bases, drain / insert_str panics) and slices at a pool's edge */
+template <bool BASE>
+__global__ __launch_bounds__(256, BASE ? WGA_K6_BLOCKS_BASE : WGA_K6_BLOCKS_SYM) void k_pafpseudo_fill_list(PseudoArgs a) {
   const u32 n_list = *a.tile_count;
   for (u32 idx = blockIdx.x; idx < n_list; idx += gridDim.x) {
-    pseudo_tile<true>(a, a.tile_list[idx]);
+    pseudo_tile<BASE>(a, a.tile_list[idx]);
     __syncthreads(); /* the tile's LDS state is dead */
   }
 }

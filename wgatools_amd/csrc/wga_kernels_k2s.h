@@ -101,13 +101,13 @@ __global__ __launch_bounds__(256) void k_pseudo_rec_desc(u32 n, const wga_class_
   d.q_row_off = dst_off[r] - skip[r];
   d.t_src_off = 0;
   d.t_src_len = skip[r];
-  d.q_src_off = q_src_off[r];
-  d.q_src_len = q_src_len[r];
+  d.q_src_off = q_src_off ? q_src_off[r] : 0ull; /* symbol mode: no slices, every record is clean */
+  d.q_src_len = q_src_len ? q_src_len[r] : 0ull;
   d.I_total = cs.i + cs.s;
   d.D_total = cs.d;
   d.L = cs.mx + cs.d;
-  const bool clean = d.q_src_len == cs.mx + cs.i + cs.s;
-  const bool inside = d.q_src_off >= 32ull && d.q_src_off + d.q_src_len + 32ull <= q_fa_bytes;
+  const bool clean = !q_src_len || d.q_src_len == cs.mx + cs.i + cs.s;
+  const bool inside = !q_src_off || (d.q_src_off >= 32ull && d.q_src_off + d.q_src_len + 32ull <= q_fa_bytes);
   d.neg = (strand_neg[r] != 0 ? 1u : 0u) | (clean ? 0u : 8u);
   out[r] = d;
   if (clean && inside) return;
@@ -164,10 +164,15 @@ __device__ WGA_S_NOINLINE void stream_report_bad(u64* bad_base_pos, u32 b0, u32 
  * column: an event with no gap characters that lowers the adjustment; a FIFO entry's second word is then "gap bases minus
  * skipped bases in front" and an event's gap length max(0, next - own): the sign tells the two kinds apart) */
 #define WGA_S_PSEUDO 2
+/* MODE 3: pafpseudo's symbol-mode row ('1' for M / =, '0' for X, '-' for D; cigar.rs:760-796): no source at all — the row is a
+ * background of '1' and two kinds of "gaps", X runs and D runs.  A FIFO entry's second word is then twice the gap columns in
+ * front, bit 0 = the kind of the entry's own run (1: '-'). */
+#define WGA_S_SYMBOL 3
 template <int MODE>
 __device__ __forceinline__ u32 stream_glen(u32 c0, u32 c1) { /* gap characters of the event between two adjustments */
-  return MODE == WGA_S_PSEUDO ? ((int)(c1 - c0) > 0 ? c1 - c0 : 0u) : c1 - c0;
+  return MODE == WGA_S_SYMBOL ? (c1 >> 1) - (c0 >> 1) : MODE == WGA_S_PSEUDO ? ((int)(c1 - c0) > 0 ? c1 - c0 : 0u) : c1 - c0;
 }
+__device__ __forceinline__ u32 stream_symbol(u32 cu) { return (cu & 1u) ? 0x2D2D2D2Du : 0x30303030u; } /* the run's character */
 template <int MODE>
 __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, const u32 lane, const u64 t0, const u64 t1) {
   u32* const s_fifo = (u32*)lds;                                 /* (WGA_S_FIFO + 4) x (start column, cum)    */
@@ -182,8 +187,10 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
     s_lm[lane] = m;
   }
   constexpr bool QROW = MODE != 0;
-  constexpr u32 COL_MASK = MODE == WGA_S_PSEUDO ? 0x585u : 0x787u;   /* op codes that are columns of the row: M D = X (+ I in paf2maf) */
-  constexpr u32 GAP_MASK = MODE == 0 ? 0x202u : 0x404u;              /* ... that are its gaps: I / D (and their continuation codes) */
+  constexpr bool TCOORD = MODE >= WGA_S_PSEUDO; /* pafpseudo: a row in target coordinates whose head may be trimmed */
+  constexpr bool SYM = MODE == WGA_S_SYMBOL;
+  constexpr u32 COL_MASK = TCOORD ? 0x585u : 0x787u;                 /* op codes that are columns of the row: M D = X (+ I in paf2maf) */
+  constexpr u32 GAP_MASK = MODE == 0 ? 0x202u : SYM ? 0x504u : 0x404u; /* ... that are its gaps: I / D (and their continuation codes); symbols: X D */
   constexpr u32 SKIP_MASK = MODE == WGA_S_PSEUDO ? 0x212u : 0u;      /* ... that skip source bytes: I S (pafpseudo) */
   const u8* const fa = QROW ? a.q_fa : a.t_fa;
   const u64 fa_bytes = QROW ? a.q_fa_bytes : a.t_fa_bytes;
@@ -248,7 +255,7 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
       const u32 lim = bnd ? C_b : C_known;
       const bool all = bnd || fin;
       while ((int)(lim - pos) > 0) {
-        if (MODE == WGA_S_PSEUDO && (int)(C_min - pos) > 0) { /* the record's columns in front of its first written one */
+        if (TCOORD && (int)(C_min - pos) > 0) { /* the record's columns in front of its first written one */
           const u32 to = (int)(lim - C_min) > 0 ? C_min : lim;
           u32 c;
           do { /* e0: past the events that start in front of `to` */
@@ -321,7 +328,7 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
           const bool dashes = quiet && rel0 >= 16;  /* ... sixteen gap characters               */
           const bool flagged = active && !(plain || dashes);
           adjv[u] = fe[3];
-          cls |= ((plain ? 1u : 0u) | (dashes ? 2u : 0u) | (flagged ? 4u : 0u)) << (4u * u);
+          cls |= ((plain ? 1u : 0u) | (dashes ? 2u : 0u) | (flagged ? 4u : 0u) | (SYM ? (fe[1] & 1u) << 3 : 0u)) << (4u * u);
           const u64 m = __ballot(flagged);
           if (flagged) {
             const u32 r = qn + lane_rank(m, lane);
@@ -372,12 +379,18 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
           e1 = e1 > hi ? hi : e1;
           bool more = (int)(gs2 - Cl) < hi;
           u32 W0[4], W1[4];
-          buf_load16(sbuf, b1 > a1 ? (rc ? S32 - Cl + cu1 : S32 + Cl - cu1) : WGA_BUF_OOB, W0);
-          buf_load16(sbuf, hi > e1 ? (rc ? S32 - Cl + cu2 : S32 + Cl - cu2) : WGA_BUF_OOB, W1);
+          if (!SYM) {
+            buf_load16(sbuf, b1 > a1 ? (rc ? S32 - Cl + cu1 : S32 + Cl - cu1) : WGA_BUF_OOB, W0);
+            buf_load16(sbuf, hi > e1 ? (rc ? S32 - Cl + cu2 : S32 + Cl - cu2) : WGA_BUF_OOB, W1);
+          }
           const u32x4_a16 La = s_lm[a1], Lb = s_lm[b1], Le = s_lm[e1];
           u32 o[4], bad[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
           for (int d = 0; d < 4; d++) {
+            if (SYM) { /* the run in front | '1' | the run that starts here | '1' */
+              o[d] = bfi_b32(La[d], stream_symbol(cu0), bfi_b32(Le[d] & ~Lb[d], stream_symbol(cu1), 0x31313131u));
+              continue;
+            }
             u32 cp;
             if (rc)
               cp = comp4s(bfi_b32(Lb[d], bswap32(W0[3 - d]), bswap32(W1[3 - d])), &bad[d]);
@@ -394,13 +407,19 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
             const u32 len = stream_glen<MODE>(cui, cun);
             const int e = len >= (u32)(hi - b) ? hi : b + (int)len;
             u32 W[4];
-            buf_load16(sbuf, rc ? S32 - Cl + cun : S32 + Cl - cun, W);
+            if (SYM)
+              W[0] = W[1] = W[2] = W[3] = 0x31313131u;
+            else
+              buf_load16(sbuf, rc ? S32 - Cl + cun : S32 + Cl - cun, W);
             const u32x4_a16 Mb = s_lm[b], Me = s_lm[e];
 #pragma unroll
             for (int d = 0; d < 4; d++) {
               u32 x = W[d], bw = 0u;
               if (rc) x = comp4s(bswap32(W[3 - d]), &bw);
-              o[d] = bfi_b32(Mb[d], o[d], bfi_b32(Me[d], 0x2D2D2D2Du, x));
+              if (SYM)
+                o[d] = bfi_b32(Mb[d], o[d], bfi_b32(Me[d], stream_symbol(cui), x));
+              else
+                o[d] = bfi_b32(Mb[d], o[d], bfi_b32(Me[d], 0x2D2D2D2Du, x));
               bad[d] = (bad[d] & Mb[d]) | (bw & ~Me[d]);
             }
             ie++;
@@ -421,6 +440,10 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
         for (u32 u = 0; u < WGA_S_U; u++) {
           const u32 Cl = Cl0 + 1024u * u + 16u * lane;
           const u32 c = (cls >> (4u * u)) & 15u;
+          if (SYM) { /* sixteen of the run's character, or of '1' */
+            dat[u][0] = dat[u][1] = dat[u][2] = dat[u][3] = (c & 2u) ? ((c & 8u) ? 0x2D2D2D2Du : 0x30303030u) : 0x31313131u;
+            continue;
+          }
           dat[u][0] = dat[u][1] = dat[u][2] = dat[u][3] = (c & 2u) ? 0x2D2D2D2Du : 0u;
           if ((c & 1u) && (int)(Cl - Ce) < 0) buf_load16(sbuf, rc ? S32 - Cl + adjv[u] : S32 + Cl - adjv[u], dat[u]);
         }
@@ -492,7 +515,7 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
         sb = 0;
         C_a = C_b;
         cum_a = cum_b;
-        if (MODE == WGA_S_PSEUDO) { /* the columns in front of `skip` (kept in the descriptor's unused t_src_len) are not written */
+        if (TCOORD) { /* the columns in front of `skip` (kept in the descriptor's unused t_src_len) are not written */
           const u64 skip = WGA_UNI64(rd->t_src_len);
           C_min = C_a + (u32)(skip < 0x40000000ull ? skip : 0x40000000ull);
         }
@@ -522,10 +545,10 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
         src_off = WGA_UNI64(QROW ? td->q_src_off : td->t_src_off);
         src_len = WGA_UNI64(QROW ? td->q_src_len : td->t_src_len);
         neg = (WGA_UNI32(td->neg) & 1u) != 0u;
-        x_a = MODE == WGA_S_PSEUDO ? b_mx + b_d : b_mx + b_i + b_d; /* pafpseudo: I (and S, folded into b_i) are no columns */
+        x_a = TCOORD ? b_mx + b_d : b_mx + b_i + b_d; /* pafpseudo: I (and S, folded into b_i) are no columns */
         sb = QROW ? b_mx + b_i : b_mx + b_d;
         C_a = cum_a = 0u;
-        if (MODE == WGA_S_PSEUDO) {
+        if (TCOORD) {
           const u64 skip = WGA_UNI64(td->t_src_len);
           const u64 ahead = skip > x_a ? skip - x_a : 0ull;
           C_min = (u32)(ahead < 0x40000000ull ? ahead : 0x40000000ull);
@@ -537,7 +560,7 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
        * A non-gap column C (cum gap bases in front) reads slice index (C - cum) + Kseg, Kseg = sb - (C_a - cum_a); the job
        * reaches at most 2^30 bases further, so the buffer starts a little in front of the first one (offsets stay 32-bit). */
       dst_seg = (u8*)((u64)a.out + row_off + x_a - (u64)C_a); /* pafpseudo: row_off may have wrapped below zero */
-      rc = QROW && neg;
+      rc = QROW && !SYM && neg;
       const u32 adv = C_a - cum_a;
       u64 base; /* pool offset of the buffer's first byte */
       if (rc) { /* slice index s is pool byte src_off + src_len - 1 - s; a window of sixteen starts fifteen bytes below */
@@ -645,7 +668,7 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
       for (int e = 0; e < 4; e++) {
         if (g[e] != 0u) {
           s_fifo[2u * xc] = xl;
-          s_fifo[2u * xc + 1u] = xg;
+          s_fifo[2u * xc + 1u] = SYM ? (xg << 1) | (bit_mask(0x404u, ow[e] & 15u) & 1u) : xg;
           xc++;
           xg += g[e];
         }
@@ -657,7 +680,7 @@ __device__ __forceinline__ void stream_row(const ExpandArgs& a, u8* const lds, c
     nf += wave_last_u32(ic);
     if (lane < 3u) {
       s_fifo[2u * (nf + lane)] = C_known;
-      s_fifo[2u * (nf + lane) + 1u] = cum_known;
+      s_fifo[2u * (nf + lane) + 1u] = SYM ? cum_known << 1 : cum_known;
     }
     WGA_WAVE_SYNC();
     if (re < q_hi) { /* a record ends among these ops */
@@ -699,7 +722,8 @@ __device__ __forceinline__ void expand_stream(const ExpandArgs& a) {
   else
     stream_row<1>(a, lds, lane, t0, t1);
 }
-/* pafpseudo's base-mode rows (K6): every wave of the block walks a job of its own */
+/* pafpseudo's rows (K6): every wave of the block walks a job of its own */
+template <int MODE>
 __device__ __forceinline__ void pseudo_stream(const ExpandArgs& a) {
   __shared__ u32x4_a16 s_mem[2u * WGA_S_WAVE_BYTES / 16u];
   const u32 lane = threadIdx.x & 63u, wave = WGA_WAVE_ID(threadIdx.x);
@@ -707,13 +731,17 @@ __device__ __forceinline__ void pseudo_stream(const ExpandArgs& a) {
   const u64 t0 = (2u * xcd_job_of_block() + wave) * a.job_tiles;
   if (t0 >= nt) return;
   const u64 t1 = t0 + a.job_tiles < nt ? t0 + a.job_tiles : nt;
-  stream_row<WGA_S_PSEUDO>(a, (u8*)s_mem + wave * WGA_S_WAVE_BYTES, lane, t0, t1);
+  stream_row<MODE>(a, (u8*)s_mem + wave * WGA_S_WAVE_BYTES, lane, t0, t1);
 }
 #ifndef WGA_S_WAVES_PER_SIMD
 #define WGA_S_WAVES_PER_SIMD 5 /* launch bound: 96 VGPRs (the natural need is 102: two spill slots), LDS allows 31 waves per CU; 4: 6.0 ms, 5: 5.66 ms, 6 (61 spill slots): 7.4 ms */
 #endif
 __global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_paf2maf_expand_s(ExpandArgs a) { expand_stream(a); }
 __global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_paf2maf_expand_s_alias(ExpandArgs a) { expand_stream(a); }
-__global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_pafpseudo_stream(ExpandArgs a) { pseudo_stream(a); }
+__global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_pafpseudo_stream(ExpandArgs a) { pseudo_stream<WGA_S_PSEUDO>(a); }
+#ifndef WGA_S_SYM_WAVES
+#define WGA_S_SYM_WAVES 6 /* symbol rows need no source windows: 80 VGPRs without spills */
+#endif
+__global__ __launch_bounds__(128, WGA_S_SYM_WAVES) void k_pafpseudo_stream_sym(ExpandArgs a) { pseudo_stream<WGA_S_SYMBOL>(a); }
 
 #endif
