@@ -113,3 +113,29 @@ def test_unknown_subcommand_and_overwrite_guard(cli, tmp_path):
     f.write_text("x")
     rc, _, err = run(cli, "stat", "-f", "paf", os.path.join(GOLDEN, "testdotplot.paf"), "-o", str(f))
     assert rc == 1 and "already exists, please add `-r` to rewrite it." in err
+
+
+def test_line_chunk_reader_large_file_recycled_buffers(tmp_path):
+    """LineChunkReader on a 90 MB file with 40 MB pieces: the multi-threaded pread path, the parallel line count and quote scan,
+    buffers handed back through recycle() — every byte once and in order, pieces end at line ends"""
+    import subprocess, numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "reader_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(root, "tests", "reader_check.cpp"),
+                    os.path.join(root, "wgatools_amd", "host", "wga_host.cpp"), "-o", exe, "-lz", "-lpthread"], check=True)
+    rng = np.random.default_rng(7)
+    body = rng.integers(32, 127, 90_000_000, dtype=np.uint8)
+    body[body == ord('"')] = ord("x")                     # a quote would make the reader take the rest of the file in one piece
+    body[rng.integers(0, len(body), 400_000)] = 10        # lines of ~225 bytes on average, some empty
+    body[-1] = 10
+    path = str(tmp_path / "big.txt")
+    body.tofile(path)
+    want = int((np.arange(1, len(body) + 1, dtype=np.uint64) * body.astype(np.uint64)).sum(dtype=np.uint64))   # wraps mod 2^64
+    out = subprocess.run([exe, path, str(40 << 20)], check=True, stdout=subprocess.PIPE).stdout.split()
+    pieces, nbytes, lines, h, ends_ok = (int(x) for x in out)
+    assert pieces == 3 and nbytes == len(body) and lines == int((body == 10).sum()) and ends_ok == 1
+    assert h == want
+    one = subprocess.run([exe, path, str(1 << 40)], check=True, stdout=subprocess.PIPE).stdout.split()     # the file in one piece
+    assert int(one[0]) == 1 and int(one[3]) == want and int(one[2]) == lines
+    small = subprocess.run([exe, path, str(1 << 20)], check=True, stdout=subprocess.PIPE).stdout.split()  # read(2) path, 8 MB reads
+    assert int(small[3]) == want and int(small[2]) == lines and int(small[1]) == nbytes

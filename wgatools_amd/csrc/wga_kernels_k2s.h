@@ -740,7 +740,7 @@ __global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_paf2maf_expand_s(
 __global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_paf2maf_expand_s_alias(ExpandArgs a) { expand_stream(a); }
 __global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_pafpseudo_stream(ExpandArgs a) { pseudo_stream<WGA_S_PSEUDO>(a); }
 #ifndef WGA_S_SYM_WAVES
-#define WGA_S_SYM_WAVES 6 /* symbol rows need no source windows: 80 VGPRs without spills */
+#define WGA_S_SYM_WAVES 5 /* 5: 3.87 ms, 6 (80 VGPRs, 12 spill slots): 3.97, 7: 4.34, 8: 5.80 (configs[1]'s batch) */
 #endif
 __global__ __launch_bounds__(128, WGA_S_SYM_WAVES) void k_pafpseudo_stream_sym(ExpandArgs a) { pseudo_stream<WGA_S_SYMBOL>(a); }
 

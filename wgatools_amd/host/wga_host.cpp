@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -230,17 +231,54 @@ LineChunkReader::~LineChunkReader() {
   if (gz) gzclose((gzFile)gz);
   if (fd >= 0) ::close(fd);
 }
+void LineChunkReader::recycle(std::string&& piece) {
+  if (piece.capacity() < ((size_t)8 << 20)) return;
+  std::lock_guard<std::mutex> g(spare_mx);
+  if (spares.size() < 3) spares.push_back(std::move(piece));
+}
+/* work on [0, n) shared out over a few threads (pieces of hundreds of megabytes: one core counts line ends at ~5 GB/s) */
+template <class F>
+static void in_slices(size_t n, F&& f) {
+  const unsigned T = n >= ((size_t)32 << 20) ? 8u : 1u;
+  if (T == 1u) {
+    f(0u, (size_t)0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < T; t++) th.emplace_back([&f, n, t, T] { f(t, n * t / T, n * (t + 1) / T); });
+  f(0u, (size_t)0, n / T);
+  for (auto& x : th) x.join();
+}
 bool LineChunkReader::next(std::string& piece, size_t target, size_t keep) {
   /* piece[0, keep) is the caller's own prefix (kept, not counted); the carried-over tail and fresh reads follow */
   piece.resize(keep);
-  piece += carry;
-  carry.clear();
   bytes_before = next_bytes;
   lines_before = next_lines;
   if (target == 0) target = 1;
   const size_t kRead = (size_t)8 << 20;
-  if (fd >= 0 && file_left) /* one allocation for the piece: what is left of the file, or the target plus a long line */
-    piece.reserve(piece.size() + (size_t)std::min<uint64_t>(file_left, (uint64_t)target + 2 * kRead) + kRead + 64);
+  if (fd >= 0 && file_left) { /* one allocation for the piece: what is left of the file, or the target plus a long line */
+    const size_t need = keep + carry.size() + (size_t)std::min<uint64_t>(file_left, (uint64_t)target + 2 * kRead) + kRead + 64;
+    if (piece.capacity() < need) { /* a buffer that has been through here before, if one is large enough */
+      std::lock_guard<std::mutex> g(spare_mx);
+      for (size_t k = 0; k < spares.size(); k++)
+        if (spares[k].capacity() >= need) {
+          spares[k].assign(piece.data(), keep);
+          piece.swap(spares[k]);
+          spares.erase(spares.begin() + (long)k);
+          break;
+        }
+    }
+    if (piece.capacity() < need) {
+      piece.reserve(need);
+      if (piece.capacity() >= ((size_t)8 << 20)) { /* fewer first-touch faults where transparent huge pages are on request */
+        const uintptr_t a = ((uintptr_t)piece.data() + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1);
+        const uintptr_t z = ((uintptr_t)piece.data() + piece.capacity()) & ~(((uintptr_t)2 << 20) - 1);
+        if (z > a) madvise((void*)a, (size_t)(z - a), MADV_HUGEPAGE);
+      }
+    }
+  }
+  piece += carry;
+  carry.clear();
   auto more = [&]() -> bool { /* reads straight into the end of `piece` */
     if (eof) return false;
     const size_t at = piece.size();
@@ -257,7 +295,7 @@ bool LineChunkReader::next(std::string& piece, size_t target, size_t keep) {
       const size_t want = (size_t)std::min<uint64_t>(file_left, (uint64_t)(have < target ? target - have : 0) + kRead);
       piece.resize(at + want);
       const off_t pos = lseek(fd, 0, SEEK_CUR);
-      const unsigned T = 6;
+      const unsigned T = 8;
       std::vector<size_t> got(T, 0);
       std::vector<std::thread> th;
       auto rd = [&](unsigned t) {
@@ -301,7 +339,14 @@ bool LineChunkReader::next(std::string& piece, size_t target, size_t keep) {
   size_t scanned = keep; /* bytes of `piece` already searched for a quote */
   bool whole = false;
   for (;;) {
-    if (!whole && piece.find('"', scanned) != std::string::npos) whole = true;
+    if (!whole) { /* a quote anywhere in what came in? */
+      std::atomic<bool> quote{false};
+      const char* const base = piece.data() + scanned;
+      in_slices(piece.size() - scanned, [&](unsigned, size_t a, size_t z) {
+        if (z > a && memchr(base + a, '"', z - a)) quote.store(true, std::memory_order_relaxed);
+      });
+      whole = quote.load();
+    }
     scanned = piece.size();
     if (whole) { /* a quoted field may hold line ends: no cut is safe, take the rest of the input */
       while (more()) {
@@ -320,7 +365,13 @@ bool LineChunkReader::next(std::string& piece, size_t target, size_t keep) {
   }
   if (piece.size() == keep) return false;
   next_bytes = bytes_before + (piece.size() - keep);
-  next_lines = lines_before + (uint64_t)std::count(piece.begin() + (long)keep, piece.end(), '\n');
+  {
+    uint64_t part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const char* const base = piece.data() + keep;
+    in_slices(piece.size() - keep, [&](unsigned t, size_t a, size_t z) { part[t] = (uint64_t)std::count(base + a, base + z, '\n'); });
+    next_lines = lines_before;
+    for (uint64_t v : part) next_lines += v;
+  }
   return true;
 }
 

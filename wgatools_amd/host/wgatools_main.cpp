@@ -8,6 +8,7 @@
  *   maf2paf | m2p   converter.rs:29-54        pafcov | pc    tools/pafcov.rs:13-83
  */
 #include <errno.h>
+#include <fcntl.h>
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
@@ -32,10 +33,14 @@ namespace {
 
 /* ---- device helper ---------------------------------------------------------------------------- */
 /* WGA_TIMING=1: wall time per phase of a command on stderr when it ends (profiles/r02_cli_e2e.txt) */
+static double g_warm_seconds = 0.0;   /* what the HIP start-up thread took by itself */
+static double g_reader_seconds = 0.0; /* what the read-ahead thread spent inside the reader */
 struct PhaseTimer {
   bool on = getenv("WGA_TIMING") != nullptr;
   std::vector<std::pair<std::string, double>> acc;
   double last = now();
+  double t_start = last;
+  bool printed = false;
   static double now() {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -54,13 +59,18 @@ struct PhaseTimer {
     acc.emplace_back(name, t - last);
     last = t;
   }
-  ~PhaseTimer() {
-    if (!on) return;
+  ~PhaseTimer() { print(); }
+  void print() {
+    if (!on || printed) return;
+    printed = true;
     double tot = 0;
     for (auto& a : acc) tot += a.second;
     fprintf(stderr, "[timing]");
     for (auto& a : acc) fprintf(stderr, " %s %.3f s |", a.first.c_str(), a.second);
-    fprintf(stderr, " marked total %.3f s\n", tot);
+    fprintf(stderr, " marked total %.3f s", tot);
+    if (g_warm_seconds > 0.0) fprintf(stderr, " | hip start-up thread %.3f s", g_warm_seconds);
+    if (g_reader_seconds > 0.0) fprintf(stderr, " | reader thread %.3f s", g_reader_seconds);
+    fprintf(stderr, " | since the process's static initialisers %.3f s\n", now() - t_start);
   }
 };
 static PhaseTimer g_timer;
@@ -76,6 +86,7 @@ struct GpuWarm {
   void start() {
     started = true;
     th = std::thread([this] {
+      const double t0 = PhaseTimer::now();
       rc = wga_ctx_create(0, &ctx);
       if (rc) {
         err = wga_last_error();
@@ -83,6 +94,7 @@ struct GpuWarm {
       }
       void* warm = nullptr; /* the first allocation pays for the runtime's lazy initialisation */
       if (wga_malloc(ctx, 256, &warm) == 0) wga_free(ctx, warm);
+      g_warm_seconds = PhaseTimer::now() - t0;
     });
   }
   ~GpuWarm() {
@@ -126,6 +138,11 @@ struct DevStreamer {
       if (!buf[k] && wga_host_alloc(ctx, kPiece, &buf[k])) fail(std::string("GPU engine: ") + wga_last_error());
     uint64_t pos0 = 0;
     const int fd = out.plain_fd(&pos0);
+    /* a plain file: its blocks are allocated once, up front (the system call, not posix_fallocate: no emulation by writing where
+     * a file system lacks it).  Eight threads writing the same 16 MB into a NEW file: 12.6 GB/s, 16.3 after fallocate
+     * (profiles/r04_cli_e2e.txt); with real pieces out of the pinned buffers paf2maf's 15 GB leave at 10-12 GB/s either way,
+     * and neither 12-24 writers nor handing the pieces out as eight sequential streams changed that beyond the run-to-run spread. */
+    if (fd >= 0 && n >= ((size_t)64 << 20)) (void)fallocate(fd, 0, (off_t)pos0, (off_t)n);
     std::vector<std::thread> writers;
     std::mutex mu;
     std::condition_variable cv;
@@ -622,7 +639,7 @@ PafInput load_paf(Dev& d, const std::string* input, bool want_tags) {
 struct PafChunks {
   LineChunkReader rd;
   bool want_tags;
-  size_t target = (size_t)256 << 20;
+  size_t target = (size_t)192 << 20; /* configs[1]'s 1.19 GB through `stat`: 0.25-0.27 s with 192 MB or 512 MB pieces, 0.35-0.40 s with 256 MB */
   uint64_t recs_before = 0;
   /* the next piece is read by a helper thread while the caller works on the current one (reading 1 GB takes as long as
    * every kernel of the run together): `ahead` holds it with the reader's counters for that piece */
@@ -650,8 +667,10 @@ struct PafChunks {
   void read_ahead() {
     reader = std::thread([this] {
       Ahead a;
+      const double t0 = PhaseTimer::now();
       try {
         a.ok = rd.next(a.piece, target);
+        g_reader_seconds += PhaseTimer::now() - t0; /* one reader thread at a time */
         a.lines_before = rd.lines_before;
         a.bytes_before = rd.bytes_before;
       } catch (Error& e) {
@@ -674,6 +693,8 @@ struct PafChunks {
       Ahead a = std::move(ahead);
       if (!a.err.empty()) fail(a.err);
       if (!a.ok) return false;
+      rd.recycle(std::move(in.text)); /* the piece the caller has finished with: its buffer takes a later piece */
+      in.text = std::string();
       read_ahead();
       in = paf_from_text(d, std::move(a.piece), want_tags, recs_before, a.lines_before, a.bytes_before);
       recs_before += in.recs.size();
@@ -3829,7 +3850,7 @@ void usage() {
 
 }  // namespace
 
-int main(int argc, char** argv) {
+static int run_command(int argc, char** argv) {
   try {
     std::string outfile = "-", cmd;
     bool rewrite = false;
@@ -4119,3 +4140,5 @@ int main(int argc, char** argv) {
   }
   return 0;
 }
+
+int main(int argc, char** argv) { return run_command(argc, argv); }
