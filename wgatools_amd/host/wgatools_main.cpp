@@ -1414,10 +1414,10 @@ struct MafChunks {
     if (const char* e = getenv("WGA_CHUNK_BYTES")) target = (size_t)strtoull(e, nullptr, 10);
     if (target == 0) target = 1;
   }
-  /* the next piece with at least one block, or false at the end of the input */
-  bool next(Dev& d, MafInput& in) {
+  /* reader side: the text of the next piece that holds something, or false at the end of the input */
+  bool produce(std::string& text) {
     while (!done) {
-      std::string text = first ? std::string() : std::string("#\n");
+      text = first ? std::string() : std::string("#\n");
       const size_t skip = text.size();
       text += pending;
       pending.clear();
@@ -1443,13 +1443,54 @@ struct MafChunks {
         text.resize(cut);
       }
       if (text.size() == skip) continue;
-      in = maf_from_text(d, std::move(text));
-      if (first) header = in.header;
       first = false;
+      return true;
+    }
+    return false;
+  }
+  /* the next piece is read by a helper thread while the caller works on the current one (as PafChunks does) */
+  struct Ahead {
+    bool ok = false;
+    std::string text, err;
+  } ahead;
+  std::thread reader;
+  bool started = false, first_seen = true;
+  ~MafChunks() {
+    if (reader.joinable()) reader.join();
+  }
+  void read_ahead() {
+    reader = std::thread([this] {
+      Ahead a;
+      try {
+        a.ok = produce(a.text);
+      } catch (Error& e) {
+        a.err = e.msg.empty() ? std::string("error") : e.msg;
+      } catch (std::exception& e) {
+        a.err = std::string("internal error: ") + e.what();
+      }
+      ahead = std::move(a);
+    });
+  }
+  /* the next piece with at least one block, or false at the end of the input */
+  bool next(Dev& d, MafInput& in) {
+    for (;;) {
+      if (!started) {
+        started = true;
+        read_ahead();
+      }
+      if (!reader.joinable()) return false; /* the end was seen */
+      reader.join();
+      Ahead a = std::move(ahead);
+      if (!a.err.empty()) fail(a.err);
+      if (!a.ok) return false;
+      if (in.text && in.text.use_count() == 1) rd.recycle(std::move(*in.text)); /* nobody else holds the piece the caller is done with */
+      read_ahead();
+      in = maf_from_text(d, std::move(a.text));
+      if (first_seen) header = in.header;
+      first_seen = false;
       if (!in.recs.empty()) return true;
       if (in.d_text) d.release(in.d_text);
     }
-    return false;
   }
 };
 
