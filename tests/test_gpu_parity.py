@@ -379,6 +379,8 @@ def test_maf_pair_stat(gpu):
     blk = read_maf_blocks(os.path.join(GOLDEN, "test.maf"))[0]
     pairs.append((blk[0]["seq"], blk[1]["seq"]))
     strands.append(0)
+    pairs += pc.binary_row_pairs(rng)
+    strands += [0, 1, 0, 1]
     pc.check_maf_pair(gpu, pairs, strands)
     pc.check_maf_call_runs(gpu, pairs)
 

@@ -1044,6 +1044,29 @@ struct MafWalkOut {
  * to the piece's first column, that column's index as col_bias (reported run starts are row-relative), the class of
  * the column in front of it (carry0; 0xFF at a row start) and the non-gap characters / runs of the row in front of
  * the piece (t_base0, q_base0 for the caller walk; rout already points at the piece's first run slot). */
+/* ---- sixteen columns of a lane as one bit mask: bit 8e + d = column 4d + e (dword d, byte e) ---- */
+__device__ __forceinline__ u32 maf_nonzero7(u32 x) { return ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x; } /* bit 7 of every byte that is not 0 (exact) */
+__device__ __forceinline__ u32 maf_gather_bit7(const u32 y[4]) {
+  u32 m = (y[0] >> 7) & 0x01010101u;
+  m |= (y[1] >> 6) & 0x02020202u;
+  m |= (y[2] >> 5) & 0x04040404u;
+  m |= (y[3] >> 4) & 0x08080808u;
+  return m;
+}
+/* the mask moved up by one column: column j takes column j - 1's bit, column 0 takes `first` (0 / 1) */
+__device__ __forceinline__ u32 maf_prev_cols(u32 b, u32 first) { return (b << 8) | ((b >> 23) & 0xEu) | first; }
+/* columns [0, nv) */
+__device__ __forceinline__ u32 maf_valid_mask(u32 nv) {
+  u32 v = 0u;
+#pragma unroll
+  for (u32 d = 0; d < 4u; d++) {
+    const u32 n = nv > 4u * d ? (nv - 4u * d > 4u ? 4u : nv - 4u * d) : 0u; /* valid bytes of dword d */
+    const u32 low = n >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n)) - 1u);
+    v |= (0x01010101u << d) & low;
+  }
+  return v;
+}
+
 struct MafWalkStart {
   u64 col_bias, t_base, q_base;
   u32 carry;
@@ -1097,6 +1120,7 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
   u32 carry_cls = st0.carry; /* class of the column before this step's first one */
   u64 run_base = 0, t_base = st0.t_base, q_base = st0.q_base;
   u32 steps = 0;
+  u32 acc_runs = 0, acc_t = 0, acc_q = 0; /* without a run list: this lane's run starts / non-gap characters since the last fold */
   MafStepRows nx = first;
   if (!have_first) maf_load_step(t, q, L, 0, lane, nx);
   u64 c0 = 0;
@@ -1110,109 +1134,116 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
 #pragma unroll
     for (int d = 0; d < 4; d++) tw[d] = nx.t[d], qw[d] = nx.q[d];
     if (c0 + 1024 < L) maf_load_step(t, q, L, c0 + 1024, lane, nx); /* wave-uniform: the next step's rows, behind this step's work */
-    u32 cls[4], st[4], tn[4], qn[4], vm[4];
+    /* Sixteen columns as bit masks: bit 8e + d = column 4d + e (dword d, byte e).  A class is three bit planes (b0, b1, b2:
+     * I = 001, D = 010, X = 011, W = 100, '=' = 000), every test and count below is one instruction for the lane's sixteen
+     * columns instead of one per dword and class. */
+    u32 yn[4], yt[4], yq[4];
+    const u32 any_hi = ((tw[0] | tw[1] | tw[2]) | (tw[3] | qw[0] | qw[1]) | (qw[2] | qw[3])) & 0x80808080u;
+    if (__ballot(any_hi != 0u) == 0ull) { /* wave-uniform; text: no byte has bit 7, so adding 0x7F per byte cannot carry into the next */
 #pragma unroll
-    for (int d = 0; d < 4; d++) {
-      const int lo = 4 * d;
-      vm[d] = FULL ? 0x80808080u
-                   : (nv >= (u32)lo + 4u ? 0x80808080u : (nv > (u32)lo ? (0x80808080u >> (8u * (4u - (nv - (u32)lo)))) : 0u));
-      const u32 eq = zero_bytes(tw[d] ^ qw[d]);
-      const u32 tg = zero_bytes(tw[d] ^ 0x2D2D2D2Du), qg = zero_bytes(qw[d] ^ 0x2D2D2D2Du);
-      u32 cI, cD, cX, cW = 0u;
-      if (CALLER) {
-        cW = tg & qg;
-        cI = tg & ~qg;
-        cD = qg & ~tg;
-        cX = ~(eq | tg | qg) & 0x80808080u;
-      } else {
-        cI = tg & ~eq;
-        cD = qg & ~eq;
-        cX = ~(eq | tg | qg) & 0x80808080u;
+      for (int d = 0; d < 4; d++) {
+        yn[d] = (tw[d] ^ qw[d]) + 0x7F7F7F7Fu;
+        yt[d] = (tw[d] ^ 0x2D2D2D2Du) + 0x7F7F7F7Fu;
+        yq[d] = (qw[d] ^ 0x2D2D2D2Du) + 0x7F7F7F7Fu;
       }
-      cls[d] = (cI >> 7) | (cD >> 6) | ((cX >> 7) * 3u) | (cW >> 5); /* 0..4 in every byte */
-      tn[d] = ~tg & vm[d];
-      qn[d] = ~qg & vm[d];
-      pk[1] += popc32(cI & vm[d]);
-      pk[2] += popc32(cD & vm[d]);
-      pk[3] += popc32(cX & vm[d]);
-      if (CALLER) pk[NC - 1] += popc32(cW & vm[d]);
+    } else {
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        yn[d] = maf_nonzero7(tw[d] ^ qw[d]);
+        yt[d] = maf_nonzero7(tw[d] ^ 0x2D2D2D2Du);
+        yq[d] = maf_nonzero7(qw[d] ^ 0x2D2D2D2Du);
+      }
     }
-    /* class of the column before each byte: bytes shifted up by one across the 16-byte vector */
+    constexpr u32 ALL = 0x0F0F0F0Fu;
+    const u32 V = FULL ? ALL : maf_valid_mask(nv);
+    const u32 ne = maf_gather_bit7(yn), tng = maf_gather_bit7(yt) & V, qng = maf_gather_bit7(yq) & V; /* differ; t / q hold a base */
+    const u32 tg = tng ^ V, qg = qng ^ V;
+    u32 b0, b1, b2 = 0u;
+    if (CALLER) { /* gap tests first (cigar.rs:314-328) */
+      b0 = qng & (tg | (ne & tng));
+      b1 = tng & (qg | (ne & qng));
+      b2 = tg & qg;
+    } else { /* equal bytes first (cigar.rs:298-308): two gaps are '=' */
+      b0 = ne & (tg | qng) & V;
+      b1 = ne & (qg | tng) & V;
+    }
+    const u32 cI = b0 & ~b1, cD = b1 & ~b0, cX = b0 & b1;
+    pk[1] += popc32(cI);
+    pk[2] += popc32(cD);
+    pk[3] += popc32(cX);
+    if (CALLER) pk[NC - 1] += popc32(b2);
+    /* the class of the column in front of each column: within the lane a shift of the planes, the lane's first column takes
+     * the last class of the lane below (of the step / piece in front for lane 0; 0xFF / 0xFE there match no class) */
     u32 my_last;
     if (FULL) {
-      my_last = cls[3] >> 24;
-    } else { /* no indexing of the register array by a run-time value */
-      const u32 last_dw = nv > 12u ? cls[3] : nv > 8u ? cls[2] : nv > 4u ? cls[1] : cls[0];
-      my_last = nv ? ((last_dw >> (8u * ((nv - 1u) & 3u))) & 0xFFu) : 0xFEu;
+      my_last = ((b0 >> 27) & 1u) | ((b1 >> 26) & 2u) | ((b2 >> 25) & 4u);
+    } else {
+      const u32 j = nv - 1u, pos = ((j & 3u) << 3) | (j >> 2);
+      my_last = nv ? (((b0 >> pos) & 1u) | (((b1 >> pos) & 1u) << 1) | (((b2 >> pos) & 1u) << 2)) : 0xFEu;
     }
     u32 prev_last = __shfl_up(my_last, 1u);
     if (lane == 0) prev_last = carry_cls;
-    u32 nst = 0;
+    u32 S = (b0 ^ maf_prev_cols(b0, prev_last & 1u)) | (b1 ^ maf_prev_cols(b1, (prev_last >> 1) & 1u));
+    if (CALLER)
+      S |= b2 ^ maf_prev_cols(b2, (prev_last >> 2) & 1u);
+    else
+      S |= (prev_last >> 2) & 1u; /* a row's / piece's first column after "no class" */
+    S &= V;
+    const u32 nst = popc32(S);
+    pk[1] += popc32(S & cI) << 16;
+    pk[2] += popc32(S & cD) << 16;
+    pk[3] += popc32(S & cX) << 16;
+    if (CALLER) pk[NC - 1] += popc32(S & b2) << 16;
+    /* ordered run list: wave-exclusive offsets of the per-lane start counts (the totals alone when nothing is written) */
+    u32 step_runs, t_excl = 0, q_excl = 0, t_tot = 0, q_tot = 0;
+    if (rout) {
+      const u32 incl = wave_incl_scan_u32(nst);
+      step_runs = wave_last_u32(incl);
+      if (CALLER) {
+        const u32 tnc = popc32(tng), qnc = popc32(qng);
+        const u32 ti = wave_incl_scan_u32(tnc), qi = wave_incl_scan_u32(qnc);
+        t_excl = ti - tnc;
+        q_excl = qi - qnc;
+        t_tot = wave_last_u32(ti);
+        q_tot = wave_last_u32(qi);
+      }
+      if (nst) {
+        u64 slot = run_base + (u64)(incl - nst);
+        u32 tb = 0, qb = 0; /* non-gap bytes of this lane before the dword being walked */
 #pragma unroll
-    for (int d = 0; d < 4; d++) {
-      const u32 below = d == 0 ? prev_last : (cls[d - 1] >> 24);
-      const u32 prev = (cls[d] << 8) | (below & 0xFFu);
-      st[d] = ~zero_bytes(cls[d] ^ prev) & vm[d]; /* 0x80 where a run starts */
-      nst += popc32(st[d]);
-    }
-    /* per-class run starts: a start byte's class */
-    u32 rs1 = 0, rs2 = 0, rs3 = 0, rs4 = 0; /* rs1, rs2: starts whose class has bit 0 / bit 1 set (class 3 has both) */
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-      const u32 s7 = st[d] >> 7; /* 1 in the low bit of start bytes */
-      const u32 k = cls[d];
-      const u32 b0 = s7 & k, b1 = s7 & (k >> 1);
-      rs1 += popc32(b0);
-      rs2 += popc32(b1);
-      rs3 += popc32(b0 & b1);                                              /* class 3: 011 */
-      if (CALLER) rs4 += popc32(s7 & (k >> 2));                            /* class 4: 100 */
-    }
-    rs1 -= rs3; /* class 1: 001 */
-    rs2 -= rs3; /* class 2: 010 */
-    pk[1] += rs1 << 16;
-    pk[2] += rs2 << 16;
-    pk[3] += rs3 << 16;
-    if (CALLER) pk[NC - 1] += rs4 << 16;
-    /* ordered run list: wave-exclusive offsets of the per-lane start counts */
-    const u32 incl = wave_incl_scan_u32(nst);
-    const u32 tnc = popc32(tn[0]) + popc32(tn[1]) + popc32(tn[2]) + popc32(tn[3]);
-    const u32 qnc = popc32(qn[0]) + popc32(qn[1]) + popc32(qn[2]) + popc32(qn[3]);
-    u32 t_excl = 0, q_excl = 0, t_tot = 0, q_tot = 0;
-    if (CALLER) {
-      const u32 ti = wave_incl_scan_u32(tnc), qi = wave_incl_scan_u32(qnc);
-      t_excl = ti - tnc;
-      q_excl = qi - qnc;
-      t_tot = wave_last_u32(ti);
-      q_tot = wave_last_u32(qi);
-    }
-    if (rout && nst) {
-      u64 slot = run_base + (u64)(incl - nst);
-      u32 tb = 0, qb = 0; /* non-gap bytes of this lane before the dword being walked */
-#pragma unroll
-      for (int d = 0; d < 4; d++) {
-        u32 m = st[d];
-        while (m) {
-          const u32 bit = (u32)__builtin_ctz(m); /* 7, 15, 23 or 31 */
-          const u32 j = bit >> 3;
-          const u32 k = (cls[d] >> (8u * j)) & 7u;
-          const u64 col = st0.col_bias + c + 4u * (u32)d + j;
-          if (CALLER) {
-            const u32 bm = (1u << bit) - 1u; /* bytes below j */
-            u64* e = rout + 3 * slot;
-            e[0] = (col << 3) | (u64)k;
-            e[1] = t_base + t_excl + tb + popc32(tn[d] & bm);
-            e[2] = q_base + q_excl + qb + popc32(qn[d] & bm);
-          } else {
-            rout[slot] = (col << 3) | (u64)k;
+        for (int d = 0; d < 4; d++) {
+          u32 m = (S >> d) & 0x01010101u; /* dword d's columns, byte e at bit 8e */
+          const u32 td = (tng >> d) & 0x01010101u, qd = (qng >> d) & 0x01010101u;
+          while (m) {
+            const u32 bit = (u32)__builtin_ctz(m); /* 0, 8, 16 or 24 */
+            const u32 pos = bit + (u32)d;
+            const u32 k = ((b0 >> pos) & 1u) | (((b1 >> pos) & 1u) << 1) | (((b2 >> pos) & 1u) << 2);
+            const u64 col = st0.col_bias + c + 4u * (u32)d + (bit >> 3);
+            if (CALLER) {
+              const u32 bm = (1u << bit) - 1u; /* bytes below */
+              u64* e = rout + 3 * slot;
+              e[0] = (col << 3) | (u64)k;
+              e[1] = t_base + t_excl + tb + popc32(td & bm);
+              e[2] = q_base + q_excl + qb + popc32(qd & bm);
+            } else {
+              rout[slot] = (col << 3) | (u64)k;
+            }
+            slot++;
+            m &= m - 1u;
           }
-          slot++;
-          m &= m - 1u;
+          tb += popc32(td);
+          qb += popc32(qd);
         }
-        tb += popc32(tn[d]);
-        qb += popc32(qn[d]);
+      }
+    } else { /* totals only: the lanes keep their own sums, added up when the walk ends (or before they could wrap) */
+      step_runs = 0u;
+      acc_runs += nst;
+      if (CALLER) {
+        acc_t += popc32(tng);
+        acc_q += popc32(qng);
       }
     }
-    run_base += (u64)wave_last_u32(incl);
+    run_base += (u64)step_runs;
     t_base += t_tot;
     q_base += q_tot;
     /* the last valid column of this step is in the last lane that has any */
@@ -1230,6 +1261,10 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
         Rtot[k] += wave_sum_u32(pk[k] >> 16);
         pk[k] = 0u;
       }
+      run_base += (u64)wave_sum_u32(acc_runs);
+      t_base += (u64)wave_sum_u32(acc_t);
+      q_base += (u64)wave_sum_u32(acc_q);
+      acc_runs = acc_t = acc_q = 0u;
       steps = 0;
     }
   };
@@ -1238,6 +1273,13 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
       step(std::true_type{});
     else
       step(std::false_type{});
+  }
+  if (!rout) { /* wave-uniform */
+    run_base += (u64)wave_sum_u32(acc_runs);
+    if (CALLER) {
+      t_base += (u64)wave_sum_u32(acc_t);
+      q_base += (u64)wave_sum_u32(acc_q);
+    }
   }
   /* class 0 columns / runs = all minus the others */
   u64 C[NC], R[NC];
