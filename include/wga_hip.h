@@ -123,8 +123,11 @@ int wga_ctx_reset_stream(wga_ctx*);
 /* Tunables (test knobs): "expand_force_slow" (0/1) forces the u64 op-serial fallback of the
  * expand kernel; "expand_no_table" (0/1) forces its binary-search event lookup; "expand_variant" picks the row
  * kernel — same bytes either way: -1 (default) by the batch (the window kernel, which assembles 4 KB output windows in
- * LDS and stores whole lines, for batches below 1500 ops per record, where it is 12-19 % faster; v1 for longer records,
- * where v1 is 9-18 % faster: profiles/r03_k2w_experiments.md), 0: v1, 2: the window kernel; environment: WGA_EXPAND_VARIANT; "expand_drain_min" (0 .. 64) = how many gap-touching 16-column chunks a wave
+ * LDS and stores whole lines, for batches below 100 ops per record; the streaming kernel, one wave per row kind of a run of
+ * tiles, for the others: profiles/r04_k2s_experiments.md), 0: v1 (one block per tile), 2: the window kernel, 3: the streaming
+ * kernel (environment: WGA_EXPAND_VARIANT); "expand_job_tiles" (1 .. 32, default 8): consecutive tiles one wave of the streaming kernel walks;
+ * "pseudo_variant": wga_pafpseudo_fill's rows through the streaming kernel (3, default) or one block per tile (0);
+ * "expand_drain_min" (0 .. 64, v1 only) = how many gap-touching 16-column chunks a wave
  * queues before it emits them: 0 (default) lets the library choose by the size of the two sequence pools — 64 when
  * they stay in the 256 MB Infinity Cache, 16 when they do not (the L2 then churns with source lines and half-written
  * output lines should complete at once) as the starting point — and, unless "expand_autotune" is set to 0, tries 64 / 32 /
@@ -139,7 +142,10 @@ int wga_ctx_reset_stream(wga_ctx*);
  * small values to reach those paths with small inputs. */
 int wga_ctx_set_param(wga_ctx*, const char* name, int64_t value);
 /* Read back: "expand_drain_min" = what the last wga_paf2maf_expand used, "expand_autotune_settled" (0/1),
- * "expand_variant" (the setting), "expand_variant_used" (what the last wga_paf2maf_expand ran). */
+ * "expand_variant" / "expand_job_tiles" / "pseudo_variant" (the settings), "expand_variant_used" (what the last
+ * wga_paf2maf_expand ran), "expand_stream_left_to_v1" / "pseudo_stream_left_to_blocks" (tiles the streaming kernel's last
+ * launch left to the block kernels: records whose slices do not match their CIGAR, slices at a pool's edge, giant tiles —
+ * a device read, diagnostics). */
 int wga_ctx_get_param(wga_ctx*, const char* name, int64_t* value);
 /* Measurement hook: after wga_ctx_set_param(ctx, "expand_timing", 1) every wga_paf2maf_expand
  * brackets its gap-insertion kernel (without the descriptor pre-pass) with two events on the
