@@ -1166,7 +1166,8 @@ def test_bgzipped_paf_and_maf_inputs(cli, tmp_path):
         want = runs(*cmd(paf))
         assert want[0] == 0
         assert runs(*cmd(bgz)) == want and runs(*cmd(gz)) == want, cmd("x")[0]
-        for env in ({"WGA_BGZF_DEVICE": "0"}, {"WGA_CHUNK_BYTES": "900"}):
+        for env in ({"WGA_BGZF_DEVICE": "0"}, {"WGA_CHUNK_BYTES": "900"}, {"WGA_BGZF_BATCH": "1500"},  # runs of two members each
+                    {"WGA_BGZF_BATCH": "1", "WGA_CHUNK_BYTES": "900"}):
             e = dict(os.environ)
             e.update(env)
             r = subprocess.run([cli] + cmd(bgz), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)

@@ -140,6 +140,80 @@ bool read_bgzf_image(const std::string& path, std::string& img, std::vector<Bgzf
   return true;
 }
 
+/* The member table of a BGZF file without the file in memory: every member's header names its size ("BC"), so the walk hops
+ * from header to header — one pread of the trailer in front (CRC-32, ISIZE) and the next header per member. */
+bool scan_bgzf_members(const std::string& path, std::vector<BgzfMember>& members, uint64_t* total, uint64_t* file_bytes) {
+  const int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) fail("File path `" + path + "` not exist"); /* errors.rs:13 */
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+    ::close(fd);
+    return false;
+  }
+  const uint64_t n = (uint64_t)st.st_size;
+  members.clear();
+  uint64_t p = 0, out = 0;
+  bool ok = n > 0;
+  std::vector<unsigned char> hdr(96);
+  while (ok && p < n) {
+    if (n - p < 18) {
+      ok = false;
+      break;
+    }
+    size_t want = (size_t)std::min<uint64_t>(hdr.size(), n - p);
+    if (pread(fd, hdr.data(), want, (off_t)p) != (ssize_t)want) {
+      ok = false;
+      break;
+    }
+    const unsigned char* b = hdr.data();
+    if (b[0] != 31 || b[1] != 139 || b[2] != 8 || !(b[3] & 4)) {
+      ok = false;
+      break;
+    }
+    const size_t xlen = le16(b + 10);
+    if (n - p < 12 + xlen) {
+      ok = false;
+      break;
+    }
+    if (12 + xlen > want) { /* an extra field longer than the usual six bytes */
+      hdr.resize(12 + xlen);
+      want = 12 + xlen;
+      if (pread(fd, hdr.data(), want, (off_t)p) != (ssize_t)want) {
+        ok = false;
+        break;
+      }
+      b = hdr.data();
+    }
+    size_t bsize = 0;
+    for (size_t x = 12; x + 4 <= 12 + xlen;) {
+      const size_t slen = le16(b + x + 2);
+      if (b[x] == 'B' && b[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen) bsize = le16(b + x + 4) + 1u;
+      x += 4 + slen;
+    }
+    if (bsize < 12 + xlen + 8 || bsize > n - p) {
+      ok = false;
+      break;
+    }
+    unsigned char tr[4];
+    if (pread(fd, tr, 4, (off_t)(p + bsize - 4)) != 4) {
+      ok = false;
+      break;
+    }
+    const uint64_t isize = le32(tr);
+    if (isize) members.push_back(BgzfMember{p + 12 + xlen, (uint32_t)(bsize - (12 + xlen) - 8), (uint32_t)isize, out}); /* not the EOF marker */
+    out += isize;
+    p += bsize;
+  }
+  ::close(fd);
+  if (!ok) {
+    members.clear();
+    return false;
+  }
+  *total = out;
+  if (file_bytes) *file_bytes = n;
+  return true;
+}
+
 std::string read_all_parallel(const std::string& path) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) fail("File path `" + path + "` not exist"); /* errors.rs:13 */

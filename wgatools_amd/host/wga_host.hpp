@@ -50,6 +50,9 @@ struct BgzfMember {
   uint64_t out_off;
 };
 bool read_bgzf_image(const std::string& path, std::string& img, std::vector<BgzfMember>& members, uint64_t* total);
+/* the member table alone (the file is walked header by header, nothing of it is kept): for readers that take the compressed
+ * bytes a run of members at a time */
+bool scan_bgzf_members(const std::string& path, std::vector<BgzfMember>& members, uint64_t* total, uint64_t* file_bytes);
 uint32_t gzip_crc32(const void* p, size_t n); /* the CRC-32 of a gzip member's trailer (zlib's) */
 struct Output {
   std::string path;

@@ -365,24 +365,30 @@ static void stream_out(Dev& d, Output& out, const uint8_t* d_src, size_t n) {
  * where gzread would have produced them.  The producer has a context of its own on device 0 (it runs on the reader's helper
  * thread).  WGA_BGZF_DEVICE=0, a plain gzip stream or stdin keep zlib. */
 struct BgzfDeviceSource {
-  std::string img, path;
+  std::string img, path; /* img: the compressed bytes of the run of members being inflated (never the file) */
   std::vector<BgzfMember> members;
-  uint64_t total = 0;
+  uint64_t total = 0, file_bytes = 0;
   size_t next_member = 0;
   std::string buf;
   size_t buf_at = 0;
+  int fd = -1;
+  uint64_t kBatch = 64ull << 20; /* text bytes per run of members (WGA_BGZF_BATCH: the tests reach several runs with small files) */
   Dev d;
+  ~BgzfDeviceSource() {
+    if (fd >= 0) ::close(fd);
+  }
   bool open(const std::string* p) {
     const char* e = getenv("WGA_BGZF_DEVICE");
     if (!p || (e && atoi(e) == 0)) return false;
-    if (!read_bgzf_image(*p, img, members, &total)) return false;
+    if (!scan_bgzf_members(*p, members, &total, &file_bytes)) return false;
     path = *p;
-    img.append(16, '\0');
+    fd = ::open(p->c_str(), O_RDONLY);
+    if (fd < 0) fail("File path `" + *p + "` not exist");
+    if (const char* b = getenv("WGA_BGZF_BATCH")) kBatch = std::max<uint64_t>(1, strtoull(b, nullptr, 10));
     return true;
   }
   bool refill() {
     if (next_member == members.size()) return false;
-    const uint64_t kBatch = 64ull << 20;
     const size_t m0 = next_member;
     size_t m1 = m0;
     uint64_t out_bytes = 0;
@@ -394,8 +400,18 @@ struct BgzfDeviceSource {
       k.out_off -= o0;
     }
     static_assert(sizeof(BgzfMember) == sizeof(wga_bgzf_block), "wga_bgzf_block layout");
+    { /* this run's compressed bytes, the last member's trailer and the slack the kernel's whole-vector loads reach into */
+      const size_t want = (size_t)std::min<uint64_t>(c1 - c0 + 8, file_bytes - c0);
+      img.assign((size_t)(c1 - c0) + 16, '\0');
+      size_t done = 0;
+      while (done < want) {
+        const ssize_t r = pread(fd, &img[done], want - done, (off_t)(c0 + done));
+        if (r <= 0) fail("IO error:short read of `" + path + "`");
+        done += (size_t)r;
+      }
+    }
     d.init();
-    const uint8_t* d_img = d.upload((const uint8_t*)img.data() + c0, (size_t)(c1 - c0) + 16);
+    const uint8_t* d_img = d.upload((const uint8_t*)img.data(), (size_t)(c1 - c0) + 16);
     const wga_bgzf_block* d_mem = (const wga_bgzf_block*)d.upload(part.data(), part.size());
     uint8_t* d_text = (uint8_t*)d.alloc(out_bytes + 64);
     auto* d_st = (uint32_t*)d.alloc(part.size() * 4 + 4);
@@ -414,7 +430,7 @@ struct BgzfDeviceSource {
       for (unsigned t = 0; t < T; t++)
         th.emplace_back([&, t] {
           for (size_t k = t; k < part.size(); k += T) {
-            const unsigned char* tr = (const unsigned char*)img.data() + c0 + part[k].in_off + part[k].in_len;
+            const unsigned char* tr = (const unsigned char*)img.data() + part[k].in_off + part[k].in_len;
             const uint32_t want = (uint32_t)tr[0] | (uint32_t)tr[1] << 8 | (uint32_t)tr[2] << 16 | (uint32_t)tr[3] << 24;
             if (gzip_crc32(buf.data() + part[k].out_off, part[k].out_len) != want) bad[t] = 1;
           }
