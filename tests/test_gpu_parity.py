@@ -1007,15 +1007,17 @@ def test_pafcov_config4_at_stated_size(gpu):
     gpu.reset_stream()
 
 
-def test_pafpseudo_config5_at_stated_size(gpu):
+def _pafpseudo_config5_at_stated_size(gpu):
     """10 000 records of >= 200 kop (2.5e9 ops, 3.7e10 columns) in chunks of 400: the base-mode pseudo-MAF row equals
-    paf2maf's query row minus the columns where its target row is gapped (K6 against K2), the symbol-mode row equals
-    the op symbols expanded on the device with torch"""
+    paf2maf's query row minus the columns where its target row is gapped (K6 against K2 — the rows of v1, the block kernel:
+    K6's rows come from the streaming kernel, so the two share no row code), and equals the block kernel's K6 rows
+    ("pseudo_variant" 0); the symbol-mode row equals the op symbols expanded on the device with torch"""
     import torch
     from wgatools_amd import pipeline
     dev = torch.device("cuda", 0)
     per, chunks = 400, 25
     gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    gpu.set_param("expand_variant", 0)
     sym = torch.zeros(16, dtype=torch.uint8, device=dev)
     sym[0] = sym[7] = ord("1")
     sym[8] = ord("0")
@@ -1057,6 +1059,14 @@ def test_pafpseudo_config5_at_stated_size(gpu):
         want = qrow[trow != 45]
         assert want.numel() == total and bool((want == outs[1][:total]).all()), k
         del rec, col, trow, qrow, want
+        assert gpu.get_param("pseudo_variant") == 3
+        if k % 5 == 0:   # ... and against the block kernel's rows of the same call
+            gpu.set_param("pseudo_variant", 0)
+            blk = torch.zeros(total + 64, dtype=torch.uint8, device=dev)
+            gpu.pafpseudo_fill(batch, 1, tb["q_pool"], int(tb["q_pool"].numel()), tb["q_src_off"], tb["q_src_len"], skip, blk, dst_off)
+            gpu.set_param("pseudo_variant", 3)
+            assert bool(torch.equal(blk, outs[1])), k
+            del blk
         # symbol mode against the ops expanded with torch
         code = (tb["ops"] & 15).long()
         ln = (tb["ops"] >> 4).long()
@@ -1069,7 +1079,15 @@ def test_pafpseudo_config5_at_stated_size(gpu):
           "4n + 2 x row bytes), symbol mode %.1f ms (%.0f GB/s of 4n + row bytes)" % (
               per * chunks, n_ops, out_bytes, ms[1], (4 * n_ops + 2 * out_bytes) / ms[1] / 1e6, ms[0],
               (4 * n_ops + out_bytes) / ms[0] / 1e6))
-    gpu.reset_stream()
+
+
+def test_pafpseudo_config5_at_stated_size(gpu):
+    try:
+        _pafpseudo_config5_at_stated_size(gpu)
+    finally:   # the engine is the session's
+        gpu.set_param("expand_variant", -1)
+        gpu.set_param("pseudo_variant", 3)
+        gpu.reset_stream()
 
 
 def test_fasta_pool(gpu):
