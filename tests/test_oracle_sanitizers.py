@@ -28,7 +28,7 @@ def test_oracle_under_asan_ubsan():
                         os.path.join(ROOT, "tests", "test_emu_parity.py"), "-k",
                         "(golden or oracle or readme or html or stat_random or paf2maf_edge or pafcov or pafpseudo or "
                         "maf_pair or call or tokeniser or chain or dotplot) and not (look_back or many_windows or long or "
-                        "piece or random_bytes or random_shapes or nasty or hundreds or steps or without or 2-200)"],       # the emulator-bound cases add nothing for the oracle
+                        "piece or random_bytes or random_shapes or nasty or hundreds or steps or without or 2-200 or stream_kernel)"],       # the emulator-bound cases add nothing for the oracle
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-4000:]
     assert "passed" in r.stdout and "runtime error" not in r.stdout and "AddressSanitizer" not in r.stdout, r.stdout[-4000:]
