@@ -1220,6 +1220,11 @@ def test_maf_streaming_pieces_give_the_same_bytes(cli, tmp_path):
                 os.environ.pop("WGA_CHUNK_BYTES", None)
         assert res[0][0] == 0, (args, res[0][2])
         assert res[0][:2] == res[1][:2] == res[2][:2], args
+        os.environ["WGA_MAF_FILL_MIN_BLOCKS"] = "1"   # the host records of a piece filled by eight threads (millions of blocks otherwise)
+        try:
+            assert run(cli, *args)[:2] == res[0][:2], args
+        finally:
+            os.environ.pop("WGA_MAF_FILL_MIN_BLOCKS", None)
 
 
 # ---- ties to the reference's own fixtures (the headline functions have no reference-held vector; these two

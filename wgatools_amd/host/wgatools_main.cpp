@@ -1378,26 +1378,49 @@ MafInput maf_from_text(Dev& d, std::string&& whole_text) {
       if (he == std::string::npos) he = text.size();
       if (he > 0 && text[he - 1] == '\r') he--;
       in.header.assign(text, 0, he);
-      bool open = false;
-      for (const wga_maf_line& L : lines) {
-        if (L.status != WGA_MAF_SLINE) { /* any other line ends the block in progress */
-          open = false;
+      /* a block = a maximal run of s-lines (any other line ends the block in progress); the records of a piece with millions of
+       * blocks are filled by a few threads (two or more strings per block: the allocator is what this loop costs) */
+      std::vector<std::pair<size_t, size_t>> runs_of_s; /* [first, behind the last) s-line of every block */
+      for (size_t i = 0; i < lines.size();) {
+        if (lines[i].status != WGA_MAF_SLINE) {
+          i++;
           continue;
         }
-        if (!open) {
-          in.recs.emplace_back();
-          open = true;
+        size_t j = i;
+        while (j < lines.size() && lines[j].status == WGA_MAF_SLINE) j++;
+        runs_of_s.emplace_back(i, j);
+        i = j;
+      }
+      in.recs.resize(runs_of_s.size());
+      auto fill = [&](size_t b0, size_t b1) {
+        for (size_t b = b0; b < b1; b++) {
+          MafRecord& r = in.recs[b];
+          r.slines.reserve(runs_of_s[b].second - runs_of_s[b].first);
+          for (size_t i = runs_of_s[b].first; i < runs_of_s[b].second; i++) {
+            const wga_maf_line& L = lines[i];
+            MafSLine sl;
+            sl.name.assign(text, (size_t)L.name_off, L.name_len);
+            sl.start = L.num[0];
+            sl.align_size = L.num[1];
+            sl.size = L.num[2];
+            sl.neg = L.strand_neg != 0;
+            sl.file = text.data();
+            sl.seq_off = L.seq_off;
+            sl.seq_len = L.seq_len;
+            r.slines.push_back(std::move(sl));
+          }
         }
-        MafSLine sl;
-        sl.name.assign(text, (size_t)L.name_off, L.name_len);
-        sl.start = L.num[0];
-        sl.align_size = L.num[1];
-        sl.size = L.num[2];
-        sl.neg = L.strand_neg != 0;
-        sl.file = text.data();
-        sl.seq_off = L.seq_off;
-        sl.seq_len = L.seq_len;
-        in.recs.back().slines.push_back(std::move(sl));
+      };
+      const size_t nb = runs_of_s.size();
+      static const size_t min_blocks = getenv("WGA_MAF_FILL_MIN_BLOCKS") ? (size_t)strtoull(getenv("WGA_MAF_FILL_MIN_BLOCKS"), nullptr, 10) : 50000; /* tests: 1 */
+      const unsigned T = nb >= std::max<size_t>(min_blocks, 8) ? 8u : 1u;
+      if (T == 1u) {
+        fill(0, nb);
+      } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; t++) th.emplace_back(fill, nb * t / T, nb * (t + 1) / T);
+        fill(0, nb / T);
+        for (auto& x : th) x.join();
       }
       g_timer.mark("host records");
       return in;
@@ -3810,9 +3833,14 @@ int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, c
       lo_of[g] = lo, n_of[g] = cnt;
     });
     for (uint32_t k = 0; k < n; k++) roff[k + 1] = roff[k] + cnt_all[k];
-    std::vector<uint64_t> runs(3 * roff[n]);
-    for (int g = 0; g < md.count(); g++)
-      if (n_of[g]) std::copy(runs_of[g].begin(), runs_of[g].end(), runs.begin() + 3 * roff[lo_of[g]]);
+    std::vector<uint64_t> runs;
+    if (md.count() == 1 && n_of[0] == n && lo_of[0] == 0) { /* one device: its list is the list (hundreds of megabytes per piece) */
+      runs = std::move(runs_of[0]);
+    } else {
+      runs.resize(3 * roff[n]);
+      for (int g = 0; g < md.count(); g++)
+        if (n_of[g]) std::copy(runs_of[g].begin(), runs_of[g].end(), runs.begin() + 3 * roff[lo_of[g]]);
+    }
     runs_of.clear();
     g_timer.mark("kernels + run list download");
     /* the event rules and the VCF text of a block depend on that block alone: contiguous ranges of blocks go to host
