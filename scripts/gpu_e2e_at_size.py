@@ -9,9 +9,9 @@ tmp = "/tmp/wga_e2e_size"
 os.makedirs(tmp, exist_ok=True)
 cli = build.CLI_BIN
 res = {}
-def run(name, args, outp, units, unit_name):
+def run(name, args, outp, units, unit_name, env=None):
     t0 = time.perf_counter()
-    r = subprocess.run([cli] + args + ["-o", outp, "-r"], stderr=subprocess.PIPE, env=dict(os.environ, WGA_TIMING="1"))
+    r = subprocess.run([cli] + args + ["-o", outp, "-r"], stderr=subprocess.PIPE, env=dict(os.environ, WGA_TIMING="1", **(env or {})))
     dt = time.perf_counter() - t0
     sz = os.path.getsize(outp) if os.path.exists(outp) else 0
     ph = [l for l in r.stderr.decode().splitlines() if l.startswith("[timing]")]
@@ -54,6 +54,17 @@ nb = nb0 * copies
 print("MAF: %d blocks, %.2f GB, written in %.0f s" % (nb, os.path.getsize(maf) / 1e9, time.perf_counter() - t0), flush=True)
 res["maf_input"] = {"blocks": nb, "columns": nb * cols, "bytes": os.path.getsize(maf)}
 torch.cuda.empty_cache()
+if len(sys.argv) > 1 and sys.argv[1] == "call-threads":    # how many host threads the event rules + VCF text want
+    for t in (16, 32, 64, 128):
+        run("call_maf_%d" % t, ["call", "-s", "-l", "50", maf], os.path.join(tmp, "m.vcf"), nb * cols, "columns", env={"WGA_HOST_THREADS": str(t)})
+    os.remove(maf)
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "maf-pieces":      # piece size of the MAF reader (default 1 GiB)
+    for mb in (1024, 512, 256, 128):
+        run("stat_maf_%dMB" % mb, ["stat", maf], os.path.join(tmp, "m.tsv"), nb * cols, "columns", env={"WGA_CHUNK_BYTES": str(mb << 20)})
+        run("call_maf_%dMB" % mb, ["call", "-s", "-l", "50", maf], os.path.join(tmp, "m.vcf"), nb * cols, "columns", env={"WGA_CHUNK_BYTES": str(mb << 20)})
+    os.remove(maf)
+    sys.exit(0)
 run("call_maf", ["call", "-s", "-l", "50", maf], os.path.join(tmp, "m.vcf"), nb * cols, "columns")
 run("stat_maf", ["stat", maf], os.path.join(tmp, "m.tsv"), nb * cols, "columns")
 run("maf2paf", ["maf2paf", maf], os.path.join(tmp, "m.paf"), nb * cols, "columns")
