@@ -3785,6 +3785,7 @@ int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, c
   }
   if (chunk_size == 0) fail("chunk size must be positive (the reference would never terminate)");
   MafInput min;
+  std::vector<uint64_t> runs_keep; /* one device: the run list's memory serves every piece (hundreds of megabytes; fresh pages cost more than the copy) */
   g_timer.mark("host");
   while (chunks.next(d, min)) { /* one piece of the file at a time, rows written as they are called (caller.rs:62-149) */
   g_timer.mark("read + upload + split");
@@ -3817,6 +3818,7 @@ int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, c
     /* every device walks its range of the blocks (K4: count, scan, fill); the run lists meet here in block order */
     std::vector<uint64_t> roff(n + 1, 0), cols(n), cnt_all(n);
     std::vector<std::vector<uint64_t>> runs_of(md.count());
+    if (md.count() == 1) runs_of[0] = std::move(runs_keep);
     std::vector<uint32_t> lo_of(md.count(), 0), n_of(md.count(), 0);
     md.run(min, recs, true /* total_size = target row length (:115) */, [&](int g, Dev& dg, const MafRows& p, uint32_t lo, uint32_t cnt) {
       auto* d_cnt = (uint64_t*)dg.alloc((size_t)cnt * 8);
@@ -3894,6 +3896,7 @@ int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, c
       }
     }
     g_timer.mark("write");
+    if (md.count() == 1) runs_keep = std::move(runs);
   }
   md.release_all();
   }
