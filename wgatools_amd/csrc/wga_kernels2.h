@@ -1311,10 +1311,238 @@ __device__ __forceinline__ void maf_walk(const u8* __restrict__ t, const u8* __r
   out.q_nongap = q_base;
 }
 
+#define WGA_MAF_PAIR_MAX 65000ull /* blocks the pair walk takes: every total fits sixteen bits */
+/* ... and only where one stream is fewer steps than two walks (its lanes carry a block id, two sets of totals) */
+__device__ __forceinline__ bool maf_pair_pays(u64 L0, u64 L1) {
+  if (L0 >= WGA_MAF_PAIR_MAX || L1 >= WGA_MAF_PAIR_MAX) return false;
+  const u64 P = (L0 + 15ull) & ~15ull;
+  return (L0 + 1023ull) / 1024ull + (L1 + 1023ull) / 1024ull > (P + L1 + 1023ull) / 1024ull;
+}
+/* ---- two short blocks as ONE column stream -----------------------------------------------------------------------
+ * A block of 1 500 columns is one full step and one of 476 columns — and a step costs its instructions whatever the number of
+ * lanes that hold columns.  Two blocks of a wave are therefore walked as one stream: block A's columns, padded to a multiple of
+ * sixteen (so that a lane's sixteen columns belong to ONE block), then block B's; two blocks of 1 500 columns are three steps
+ * instead of four.  A lane knows its block (`rb`), its first column in it and how many of its columns are valid; the class of
+ * the column in front of B's first lane is "none"; every lane keeps two sets of totals, A's and B's (a lane serves A in one step
+ * and B in another); with run lists, the lanes' slots and non-gap prefixes start again at B's first lane.  The step itself — masks,
+ * planes, starts, counts — is maf_walk's.  Both blocks are at most `long_cols` columns (u32 arithmetic, no folds: < 2^16 per total). */
+__device__ __forceinline__ void maf_load_lane(const u8* __restrict__ tp, const u8* __restrict__ qp, u32 nv, MafStepRows& r) {
+#pragma unroll
+  for (int d = 0; d < 4; d++) r.t[d] = r.q[d] = 0u;
+  if (nv == 16u) {
+    const u32x4_a1 a = *(const u32x4_a1*)tp, b = *(const u32x4_a1*)qp;
+#pragma unroll
+    for (int d = 0; d < 4; d++) r.t[d] = a[d], r.q[d] = b[d];
+  } else if (nv) {
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const u32 j = 4u * (u32)d + (u32)e;
+        if (j < nv) {
+          r.t[d] |= (u32)tp[j] << (8u * (u32)e);
+          r.q[d] |= (u32)qp[j] << (8u * (u32)e);
+        }
+      }
+    }
+  }
+}
+template <bool CALLER>
+__device__ __forceinline__ void maf_walk_pair(const u8* __restrict__ tA, const u8* __restrict__ qA, const u32 LA, u64* const routA,
+                                              const u8* __restrict__ tB, const u8* __restrict__ qB, const u32 LB, u64* const routB,
+                                              MafWalkOut& outA, MafWalkOut& outB) {
+  const u32 lane = threadIdx.x & 63u;
+  constexpr int NC = CALLER ? 5 : 4;
+  const bool lists = routA != nullptr; /* both or neither (wave-uniform) */
+  const u32 P = (LA + 15u) & ~15u, G = P + LB; /* B's first column in the stream, the stream's length */
+  u32 pkA[NC], pkB[NC];                        /* per class: columns in the low, run starts in the high 16 bits */
+#pragma unroll
+  for (int k = 0; k < NC; k++) pkA[k] = pkB[k] = 0u;
+  u32 accA = 0, accB = 0, acctA = 0, acctB = 0, accqA = 0, accqB = 0; /* without lists: run starts / non-gap characters of the lane */
+  u32 runA = 0, runB = 0, tbA = 0, tbB = 0, qbA = 0, qbB = 0;         /* with lists: runs / non-gap characters in front of the step */
+  u32 carry_cls = 0xFFu;
+  auto lane_of = [&](u32 g0, bool& rb, u32& crel, u32& nv) { /* this lane's sixteen columns of the step at stream column g0 */
+    const u32 gl = g0 + 16u * lane;
+    rb = gl >= P;
+    crel = rb ? gl - P : gl;
+    const u32 Lr = rb ? LB : LA;
+    nv = crel >= Lr ? 0u : (Lr - crel >= 16u ? 16u : Lr - crel);
+  };
+  MafStepRows nx;
+  {
+    bool rb;
+    u32 crel, nv;
+    lane_of(0u, rb, crel, nv);
+    maf_load_lane((rb ? tB : tA) + crel, (rb ? qB : qA) + crel, nv, nx);
+  }
+  for (u32 g0 = 0; g0 < G; g0 += 1024u) {
+    bool rb;
+    u32 crel, nv;
+    lane_of(g0, rb, crel, nv);
+    u32 tw[4], qw[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) tw[d] = nx.t[d], qw[d] = nx.q[d];
+    if (g0 + 1024u < G) { /* wave-uniform: the next step's rows, behind this step's work */
+      bool rb2;
+      u32 crel2, nv2;
+      lane_of(g0 + 1024u, rb2, crel2, nv2);
+      maf_load_lane((rb2 ? tB : tA) + crel2, (rb2 ? qB : qA) + crel2, nv2, nx);
+    }
+    u32 yn[4], yt[4], yq[4];
+    const u32 any_hi = ((tw[0] | tw[1] | tw[2]) | (tw[3] | qw[0] | qw[1]) | (qw[2] | qw[3])) & 0x80808080u;
+    if (__ballot(any_hi != 0u) == 0ull) {
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        yn[d] = (tw[d] ^ qw[d]) + 0x7F7F7F7Fu;
+        yt[d] = (tw[d] ^ 0x2D2D2D2Du) + 0x7F7F7F7Fu;
+        yq[d] = (qw[d] ^ 0x2D2D2D2Du) + 0x7F7F7F7Fu;
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        yn[d] = maf_nonzero7(tw[d] ^ qw[d]);
+        yt[d] = maf_nonzero7(tw[d] ^ 0x2D2D2D2Du);
+        yq[d] = maf_nonzero7(qw[d] ^ 0x2D2D2D2Du);
+      }
+    }
+    const u32 V = maf_valid_mask(nv);
+    const u32 ne = maf_gather_bit7(yn), tng = maf_gather_bit7(yt) & V, qng = maf_gather_bit7(yq) & V;
+    const u32 tg = tng ^ V, qg = qng ^ V;
+    u32 b0, b1, b2 = 0u;
+    if (CALLER) {
+      b0 = qng & (tg | (ne & tng));
+      b1 = tng & (qg | (ne & qng));
+      b2 = tg & qg;
+    } else {
+      b0 = ne & (tg | qng) & V;
+      b1 = ne & (qg | tng) & V;
+    }
+    const u32 cI = b0 & ~b1, cD = b1 & ~b0, cX = b0 & b1;
+    u32 my_last;
+    {
+      const u32 j = nv - 1u, pos = ((j & 3u) << 3) | (j >> 2);
+      my_last = nv ? (((b0 >> pos) & 1u) | (((b1 >> pos) & 1u) << 1) | (((b2 >> pos) & 1u) << 2)) : 0xFEu;
+    }
+    u32 prev_last = __shfl_up(my_last, 1u);
+    if (lane == 0) prev_last = carry_cls;
+    if (crel == 0u) prev_last = 0xFFu; /* a block's first column */
+    u32 S = (b0 ^ maf_prev_cols(b0, prev_last & 1u)) | (b1 ^ maf_prev_cols(b1, (prev_last >> 1) & 1u));
+    if (CALLER)
+      S |= b2 ^ maf_prev_cols(b2, (prev_last >> 2) & 1u);
+    else
+      S |= (prev_last >> 2) & 1u;
+    S &= V;
+    const u32 nst = popc32(S);
+    u32 x[NC];
+    x[0] = 0u;
+    x[1] = popc32(cI) | (popc32(S & cI) << 16);
+    x[2] = popc32(cD) | (popc32(S & cD) << 16);
+    x[3] = popc32(cX) | (popc32(S & cX) << 16);
+    if (CALLER) x[NC - 1] = popc32(b2) | (popc32(S & b2) << 16);
+#pragma unroll
+    for (int k = 1; k < NC; k++) {
+      pkA[k] += rb ? 0u : x[k];
+      pkB[k] += rb ? x[k] : 0u;
+    }
+    const u32 tnc = CALLER ? popc32(tng) : 0u, qnc = CALLER ? popc32(qng) : 0u;
+    if (lists) { /* wave-uniform */
+      /* the lanes of A in this step come first; B's slots and prefixes start again behind them */
+      const u32 nA = g0 >= P ? 0u : ((P - g0) >> 4 > 64u ? 64u : (P - g0) >> 4);
+      const u32 incl = wave_incl_scan_u32(nst);
+      const u32 runs_all = wave_last_u32(incl), runs_A = nA ? wave_get_u32_dyn(incl, nA - 1u) : 0u;
+      u32 t_excl = 0, q_excl = 0, t_all = 0, q_all = 0, t_A = 0, q_A = 0;
+      if (CALLER) {
+        const u32 ti = wave_incl_scan_u32(tnc), qi = wave_incl_scan_u32(qnc);
+        t_excl = ti - tnc;
+        q_excl = qi - qnc;
+        t_all = wave_last_u32(ti);
+        q_all = wave_last_u32(qi);
+        t_A = nA ? wave_get_u32_dyn(ti, nA - 1u) : 0u;
+        q_A = nA ? wave_get_u32_dyn(qi, nA - 1u) : 0u;
+      }
+      if (nst) {
+        u64* const rout = rb ? routB : routA;
+        u32 slot = (rb ? runB - runs_A : runA) + (incl - nst);
+        u32 tb = (rb ? tbB - t_A : tbA) + t_excl, qb = (rb ? qbB - q_A : qbA) + q_excl;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          u32 m = (S >> d) & 0x01010101u;
+          const u32 td = (tng >> d) & 0x01010101u, qd = (qng >> d) & 0x01010101u;
+          while (m) {
+            const u32 bit = (u32)__builtin_ctz(m);
+            const u32 pos = bit + (u32)d;
+            const u32 k = ((b0 >> pos) & 1u) | (((b1 >> pos) & 1u) << 1) | (((b2 >> pos) & 1u) << 2);
+            const u64 col = (u64)(crel + 4u * (u32)d + (bit >> 3));
+            if (CALLER) {
+              const u32 bm = (1u << bit) - 1u;
+              u64* e = rout + 3 * (u64)slot;
+              e[0] = (col << 3) | (u64)k;
+              e[1] = (u64)(tb + popc32(td & bm));
+              e[2] = (u64)(qb + popc32(qd & bm));
+            } else {
+              rout[slot] = (col << 3) | (u64)k;
+            }
+            slot++;
+            m &= m - 1u;
+          }
+          tb += popc32(td);
+          qb += popc32(qd);
+        }
+      }
+      runA += runs_A;
+      runB += runs_all - runs_A;
+      tbA += t_A;
+      tbB += t_all - t_A;
+      qbA += q_A;
+      qbB += q_all - q_A;
+    } else {
+      accA += rb ? 0u : nst;
+      accB += rb ? nst : 0u;
+      if (CALLER) {
+        acctA += rb ? 0u : tnc;
+        acctB += rb ? tnc : 0u;
+        accqA += rb ? 0u : qnc;
+        accqB += rb ? qnc : 0u;
+      }
+    }
+    { /* the last valid column of this step is in the last lane that has any */
+      const u64 has = __ballot(nv != 0u);
+      if (has) carry_cls = __shfl(my_last, 63 - (int)__builtin_clzll(has));
+    }
+  }
+  if (!lists) {
+    runA = wave_sum_u32(accA);
+    runB = wave_sum_u32(accB);
+    if (CALLER) {
+      tbA = wave_sum_u32(acctA);
+      tbB = wave_sum_u32(acctB);
+      qbA = wave_sum_u32(accqA);
+      qbB = wave_sum_u32(accqB);
+    }
+  }
+  u64 ocA = 0, orA = 0, ocB = 0, orB = 0;
+#pragma unroll
+  for (int k = 1; k < NC; k++) {
+    const u32 a = wave_sum_u32(pkA[k]), b = wave_sum_u32(pkB[k]); /* < 2^16 in either half: the blocks are short */
+    outA.ncol[k] = a & 0xFFFFu, outA.nrun[k] = a >> 16;
+    outB.ncol[k] = b & 0xFFFFu, outB.nrun[k] = b >> 16;
+    ocA += outA.ncol[k], orA += outA.nrun[k], ocB += outB.ncol[k], orB += outB.nrun[k];
+  }
+  outA.ncol[0] = (u64)LA - ocA, outA.nrun[0] = (u64)runA - orA;
+  outB.ncol[0] = (u64)LB - ocB, outB.nrun[0] = (u64)runB - orB;
+  if (!CALLER) outA.ncol[4] = outA.nrun[4] = outB.ncol[4] = outB.nrun[4] = 0;
+  outA.runs = runA, outB.runs = runB;
+  outA.t_nongap = tbA, outA.q_nongap = qbA, outB.t_nongap = tbB, outB.q_nongap = qbB;
+}
+
+__device__ __forceinline__ void maf_pair_store(const MafWalkOut& w, bool neg, wga_cigar_counts* cnt, u64* run_cnt, u32 lane);
 __device__ __forceinline__ void maf_pair_one(const u8* __restrict__ t, const u8* __restrict__ q, u64 L, u64* rout, bool neg,
                                              const MafStepRows& first, wga_cigar_counts* cnt, u64* run_cnt, u32 lane) {
   MafWalkOut w;
   maf_walk<false>(t, q, L, rout, w, MafWalkStart{0, 0, 0, 0xFFu}, true, first);
+  maf_pair_store(w, neg, cnt, run_cnt, lane);
+}
+__device__ __forceinline__ void maf_pair_store(const MafWalkOut& w, bool neg, wga_cigar_counts* cnt, u64* run_cnt, u32 lane) {
   /* the 11 counters leave from lanes 0..10, one field per lane (as in K1): one 88-byte store per record */
   const u64 z = 0;
   u64 v = 0;
@@ -1352,6 +1580,13 @@ __global__ __launch_bounds__(256, WGA_K3_BLOCKS) void k_maf_pair_stat(u32 n, con
   u64 *r0 = (u64*)0, *r1 = (u64*)0;
   if (runs) r0 = runs + run_off[i0], r1 = runs + run_off[i1];
   const bool do0 = L0 <= long_cols, do1 = two && L1 <= long_cols; /* a long block: walked piece by piece (k_maf_piece_walk) */
+  if (do0 && do1 && maf_pair_pays(L0, L1)) { /* wave-uniform: two short blocks as one column stream */
+    MafWalkOut wA, wB;
+    maf_walk_pair<false>(t0, q0, (u32)L0, r0, t1, q1, (u32)L1, r1, wA, wB);
+    maf_pair_store(wA, neg0, counts + i0, run_cnt ? run_cnt + i0 : (u64*)0, lane);
+    maf_pair_store(wB, neg1, counts + i1, run_cnt ? run_cnt + i1 : (u64*)0, lane);
+    return;
+  }
   MafStepRows f0, f1;
   maf_load_step(t0, q0, do0 ? L0 : 0, 0, lane, f0);
   maf_load_step(t1, q1, do1 ? L1 : 0, 0, lane, f1);
@@ -1373,6 +1608,12 @@ __global__ __launch_bounds__(256) void k_maf_call_runs(u32 n, const u8* __restri
   u64 *r0 = (u64*)0, *r1 = (u64*)0;
   if (runs) r0 = runs + 3 * run_off[i0], r1 = runs + 3 * run_off[i1];
   const bool do0 = L0 <= long_cols, do1 = two && L1 <= long_cols;
+  if (do0 && do1 && maf_pair_pays(L0, L1)) { /* wave-uniform: two short blocks as one column stream */
+    MafWalkOut wA, wB;
+    maf_walk_pair<true>(t0, q0, (u32)L0, r0, t1, q1, (u32)L1, r1, wA, wB);
+    if (lane == 0 && run_cnt) run_cnt[i0] = wA.runs, run_cnt[i1] = wB.runs;
+    return;
+  }
   MafStepRows f0, f1;
   maf_load_step(t0, q0, do0 ? L0 : 0, 0, lane, f0);
   maf_load_step(t1, q1, do1 ? L1 : 0, 0, lane, f1);
