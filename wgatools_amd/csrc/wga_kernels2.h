@@ -1783,9 +1783,14 @@ __device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, u32 lane) {
 struct PafCallState {
   u64 t, q, e;
 };
+/* POS = false: only the sums are wanted (a count pass): no prefix scans, every lane keeps its own sums and the wave adds them
+ * up once when the walk ends */
+template <bool POS>
 __device__ __forceinline__ void paf_call_walk(const u32* __restrict__ rec, u64 nops, u64 a, u64 b, u64 svlen, u32 snp,
                                               PafCallState st, u64* eout, u32 lane, PafCallState* tot, u64* bad_at) {
   u64 t_base = st.t, q_base = st.q, e_base = st.e;
+  u64 acc_t = 0, acc_q = 0; /* !POS: this lane's target / query advance ... */
+  u32 acc_e = 0;            /* ... and events */
   u32 carry_code = a ? (rec[a - 1] & 15u) : 0xFu;
   *bad_at = WGA_NONE;
   u32 wnext[4]; /* the next step's ops travel behind the work on this step's */
@@ -1829,10 +1834,17 @@ __device__ __forceinline__ void paf_call_walk(const u32* __restrict__ rec, u64 n
       qsum += qa[e];
     }
     /* lane sums are < 2^30 and their wave prefix < 2^36: scan the two 16-bit halves (DPP) and recombine */
-    const u32 tl = wave_incl_scan_u32(tsum & 0xFFFFu), th = wave_incl_scan_u32(tsum >> 16);
-    const u32 ql = wave_incl_scan_u32(qsum & 0xFFFFu), qh = wave_incl_scan_u32(qsum >> 16);
-    const u64 t_incl = ((u64)th << 16) + (u64)tl, q_incl = ((u64)qh << 16) + (u64)ql;
-    u64 tp = t_base + t_incl - (u64)tsum, qp = q_base + q_incl - (u64)qsum; /* before this lane's first op */
+    u32 tl = 0, th = 0, ql = 0, qh = 0;
+    u64 tp = 0, qp = 0;
+    if (POS) {
+      tl = wave_incl_scan_u32(tsum & 0xFFFFu), th = wave_incl_scan_u32(tsum >> 16);
+      ql = wave_incl_scan_u32(qsum & 0xFFFFu), qh = wave_incl_scan_u32(qsum >> 16);
+      const u64 t_incl = ((u64)th << 16) + (u64)tl, q_incl = ((u64)qh << 16) + (u64)ql;
+      tp = t_base + t_incl - (u64)tsum, qp = q_base + q_incl - (u64)qsum; /* before this lane's first op */
+    } else {
+      acc_t += (u64)tsum;
+      acc_q += (u64)qsum;
+    }
     u32 prev = (u32)__shfl_up((int)code[3], 1u);
     if (lane == 0) prev = carry_code;
     u32 nxt = (u32)__shfl_down((int)code[0], 1u);
@@ -1850,8 +1862,9 @@ __device__ __forceinline__ void paf_call_walk(const u32* __restrict__ rec, u64 n
       is_ev[e] = live && ((code[e] == WGA_OP_X && snp) || (head_indel && after_m && ((u64)len[e] > svlen || cont_follows)));
       nev += is_ev[e] ? 1u : 0u;
     }
-    const u32 einc = wave_incl_scan_u32(nev);
-    if (eout && nev) {
+    if (!POS) acc_e += nev;
+    const u32 einc = POS ? wave_incl_scan_u32(nev) : 0u;
+    if (POS && eout && nev) {
       u64* e_out = eout + 3 * (e_base + (u64)(einc - nev));
 #pragma unroll
       for (int e = 0; e < 4; e++) {
@@ -1865,14 +1878,21 @@ __device__ __forceinline__ void paf_call_walk(const u32* __restrict__ rec, u64 n
         qp += qa[e];
       }
     }
-    e_base += (u64)wave_last_u32(einc);
-    t_base += ((u64)wave_last_u32(th) << 16) + (u64)wave_last_u32(tl);
-    q_base += ((u64)wave_last_u32(qh) << 16) + (u64)wave_last_u32(ql);
+    if (POS) {
+      e_base += (u64)wave_last_u32(einc);
+      t_base += ((u64)wave_last_u32(th) << 16) + (u64)wave_last_u32(tl);
+      q_base += ((u64)wave_last_u32(qh) << 16) + (u64)wave_last_u32(ql);
+    }
     carry_code = (u32)__shfl((int)code[3], 63);
     if (badm) {
       *bad_at = k0 + (u64)stop;
       break;
     }
+  }
+  if (!POS) { /* the lanes' sums, added up once */
+    t_base += __shfl(wave_incl_scan_u64(acc_t, lane), 63);
+    q_base += __shfl(wave_incl_scan_u64(acc_q, lane), 63);
+    e_base += (u64)wave_sum_u32(acc_e);
   }
   tot->t = t_base - st.t;
   tot->q = q_base - st.q;
@@ -1892,7 +1912,10 @@ __global__ __launch_bounds__(256) void k_paf_call_events(u32 n, const u32* __res
   PafCallState z, tot;
   z.t = z.q = z.e = 0;
   u64 bad;
-  paf_call_walk(ops + o0, nops, 0, nops, svlen, snp, z, ev ? ev + 3 * ev_off[i] : (u64*)0, lane, &tot, &bad);
+  if (ev) /* wave-uniform */
+    paf_call_walk<true>(ops + o0, nops, 0, nops, svlen, snp, z, ev + 3 * ev_off[i], lane, &tot, &bad);
+  else
+    paf_call_walk<false>(ops + o0, nops, 0, nops, svlen, snp, z, (u64*)0, lane, &tot, &bad);
   if (lane == 0 && ev_cnt) ev_cnt[i] = tot.e;
 }
 
@@ -1935,7 +1958,7 @@ __global__ __launch_bounds__(256) void k_paf_call_pieces(u32 n, const u32* __res
     st.t = st.q = st.e = 0;
     u64 bad;
     if (MODE == 0) {
-      paf_call_walk(ops + o0, nops, a, b, svlen, snp, st, (u64*)0, lane, &tot, &bad);
+      paf_call_walk<false>(ops + o0, nops, a, b, svlen, snp, st, (u64*)0, lane, &tot, &bad);
       if (lane == 0) {
         wga_call_piece r;
         r.t = tot.t, r.q = tot.q, r.e = tot.e, r.bad = bad;
@@ -1945,7 +1968,7 @@ __global__ __launch_bounds__(256) void k_paf_call_pieces(u32 n, const u32* __res
       const wga_call_piece r = pc[p];
       if (r.bad) continue; /* behind the record's first bad op: the reference's fold skips these ops */
       st.t = r.t, st.q = r.q, st.e = r.e;
-      paf_call_walk(ops + o0, nops, a, b, svlen, snp, st, ev + 3 * ev_off[i], lane, &tot, &bad);
+      paf_call_walk<true>(ops + o0, nops, a, b, svlen, snp, st, ev + 3 * ev_off[i], lane, &tot, &bad);
     }
   }
 }
