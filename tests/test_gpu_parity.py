@@ -846,6 +846,80 @@ def test_maf_config3_full_size_properties(gpu):
     assert done == nrun and bool(torch.equal(exp, runs[:3 * nrun])), "run list differs from the torch expectation"
 
 
+def test_maf_walks_ragged_blocks_exact(gpu):
+    """150 000 MAF blocks of 1 .. 3 000 columns (2.2e8 columns; neighbours of every length mix: the walks take two short blocks
+    as one column stream where that saves a step, single walks otherwise): every counter of the stat walk, and BOTH walks' whole
+    run lists — start column, class, and for the caller walk the non-gap target / query characters in front — against torch"""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    n = 150_000
+    cols = torch.randint(1, 3001, (n,), device=dev, generator=g, dtype=torch.int64)
+    cols[::1000] = 0                                            # empty blocks between the others
+    cols[7::5000] = 1024
+    cols[9::5000] = 16
+    tot = int(cols.sum())
+    t, q, _ = _synthetic_maf_rows(dev, 1, tot, 12)
+    t[::100003] = 0xAD                                          # not text: the byte tests' exact path in those steps
+    rows = torch.cat([t, q])
+    t_off = torch.cumsum(cols, 0) - cols
+    q_off = t_off + tot
+    strand = (torch.arange(n, device=dev) % 7 == 0).to(torch.uint8)
+    blk = torch.repeat_interleave(torch.arange(n, device=dev), cols)
+    col = torch.arange(tot, device=dev) - t_off[blk]
+    eq, tg, qg = t == q, t == 45, q == 45
+    first = col == 0
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        # ---- the stat walk: counters, run counts, run list ----
+        counts = torch.zeros((n, 11), dtype=torch.int64, device=dev)
+        run_cnt = torch.zeros(n, dtype=torch.int64, device=dev)
+        gpu.maf_pair_stat(n, rows, t_off, q_off, cols, strand, counts=counts, run_cnt=run_cnt)
+        cls = torch.where(eq, 0, torch.where(tg, 1, torch.where(qg, 2, 3)))
+        start = first.clone()
+        start[1:] |= cls[1:] != cls[:-1]
+        per = lambda m: torch.bincount(blk[m], minlength=n)
+        neg = strand.bool()
+        z = torch.zeros(n, dtype=torch.int64, device=dev)
+        want = torch.stack([per(cls == 0), per(cls == 3),
+                            torch.where(neg, z, per(start & (cls == 1))), torch.where(neg, z, per(cls == 1)),
+                            torch.where(neg, z, per(start & (cls == 2))), torch.where(neg, z, per(cls == 2)),
+                            torch.where(neg, per(start & (cls == 1)), z), torch.where(neg, per(cls == 1), z),
+                            torch.where(neg, per(start & (cls == 2)), z), torch.where(neg, per(cls == 2), z),
+                            neg.to(torch.int64)], 1)
+        assert bool(torch.equal(counts, want)), "stat counters differ"
+        assert bool(torch.equal(run_cnt, per(start)))
+        off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        off[1:] = torch.cumsum(run_cnt, 0)
+        runs = torch.zeros(int(off[-1]) + 1, dtype=torch.int64, device=dev)
+        gpu.maf_pair_stat(n, rows, t_off, q_off, cols, strand, counts=counts, run_cnt=run_cnt, runs=runs, run_off=off)
+        idx = start.nonzero().flatten()
+        assert bool(torch.equal(runs[:-1], (col[idx] << 3) | cls[idx])), "stat run list differs"
+        assert bool(torch.equal(counts, want))
+        # ---- the caller walk ----
+        crun = torch.zeros(n, dtype=torch.int64, device=dev)
+        gpu.maf_call_runs(n, rows, t_off, q_off, cols, run_cnt=crun)
+        ccls = torch.where(tg & qg, 4, torch.where(tg, 1, torch.where(qg, 2, torch.where(eq, 0, 3))))
+        cstart = first.clone()
+        cstart[1:] |= ccls[1:] != ccls[:-1]
+        assert bool(torch.equal(crun, per(cstart)))
+        coff = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        coff[1:] = torch.cumsum(crun, 0)
+        cruns = torch.zeros(3 * int(coff[-1]) + 3, dtype=torch.int64, device=dev)
+        gpu.maf_call_runs(n, rows, t_off, q_off, cols, run_cnt=crun, runs=cruns, run_off=coff)
+        tn, qn = (~tg).to(torch.int64), (~qg).to(torch.int64)
+        tcs, qcs = torch.cumsum(tn, 0) - tn, torch.cumsum(qn, 0) - qn          # non-gap characters in front, over all blocks ...
+        nz = (cols > 0).nonzero().flatten()
+        tb0, qb0 = torch.zeros(n, dtype=torch.int64, device=dev), torch.zeros(n, dtype=torch.int64, device=dev)
+        tb0[nz], qb0[nz] = tcs[t_off[nz]], qcs[t_off[nz]]                        # ... minus what stands in front of the block
+        cidx = cstart.nonzero().flatten()
+        exp = torch.stack([(col[cidx] << 3) | ccls[cidx], tcs[cidx] - tb0[blk[cidx]], qcs[cidx] - qb0[blk[cidx]]], 1).flatten()
+        assert bool(torch.equal(cruns[:exp.numel()], exp)), "caller run list differs"
+    finally:
+        gpu.reset_stream()
+
+
 def test_pafcov_config4_scaled_properties(gpu):
     """config 4 shaped coverage (8 targets x 12.5 Mb here, 60 000 records): per target, the summed coverage equals
     the M/= bases K1 counts for its records; coverage is never negative nor above the number of records"""
