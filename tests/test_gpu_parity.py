@@ -1081,6 +1081,52 @@ def test_pafcov_config4_at_stated_size(gpu):
     gpu.reset_stream()
 
 
+def test_pafpseudo_stream_equals_block_kernel_at_scale(gpu):
+    """30 000 records x mean 5 kop with trimmed heads of every size (none, a few columns, thousands, the whole row): the rows of
+    the streaming kernel ("pseudo_variant" 3) and of the block kernel (0) are the same bytes in both modes, nothing is written
+    outside the segments, and the stream leaves only the records at the pool's edges to the block kernel"""
+    import torch
+    dev = torch.device("cuda", 0)
+    tb = synth.make_paf_batch_torch(77, 30_000, 5000, 50_000_000, dev)
+    n = tb["n"]
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        batch = engine.Batch(tb["ops"], tb["op_off"], tb["strand_neg"], n, tb["n_ops"])
+        seg = tb["mx"] + tb["d"]
+        g = torch.Generator(device=dev)
+        g.manual_seed(3)
+        kind = torch.randint(0, 4, (n,), device=dev, generator=g)
+        skip = torch.where(kind == 0, torch.zeros_like(seg),
+                           torch.where(kind == 1, torch.randint(1, 40, (n,), device=dev, generator=g),
+                                       torch.where(kind == 2, torch.randint(1000, 9000, (n,), device=dev, generator=g), seg)))
+        skip = torch.minimum(skip, seg)
+        left = seg - skip
+        dst_off = torch.zeros(n, dtype=torch.int64, device=dev)
+        dst_off[1:] = torch.cumsum(left + 3, 0)[:-1]                      # three bytes between the segments
+        total = int((left + 3).sum())
+        outs = {}
+        for mode in (1, 0):
+            for variant in (3, 0):
+                gpu.set_param("pseudo_variant", variant)
+                out = torch.full((total + 64,), 0x23, dtype=torch.uint8, device=dev)
+                diag = gpu.pafpseudo_fill(batch, mode, tb["q_pool"], int(tb["q_pool"].numel()), tb["q_src_off"], tb["q_src_len"], skip, out, dst_off)
+                torch.cuda.synchronize()
+                outs[(mode, variant)] = out
+                if variant == 3:
+                    leftover = gpu.get_param("pseudo_stream_left_to_blocks")
+                    assert leftover < 50 if mode else leftover == 0, (mode, leftover)
+                del diag
+            assert bool(torch.equal(outs[(mode, 3)], outs[(mode, 0)])), mode
+            covered = torch.zeros(total + 64, dtype=torch.bool, device=dev)
+            idx = torch.repeat_interleave(dst_off, left) + (torch.arange(int(left.sum()), device=dev) - torch.repeat_interleave(torch.cumsum(left, 0) - left, left))
+            covered[idx] = True
+            assert bool((outs[(mode, 3)][~covered] == 0x23).all()) and bool((outs[(mode, 3)][covered] != 0x23).all()), mode
+            del covered, idx
+    finally:
+        gpu.set_param("pseudo_variant", 3)
+        gpu.reset_stream()
+
+
 def _pafpseudo_config5_at_stated_size(gpu):
     """10 000 records of >= 200 kop (2.5e9 ops, 3.7e10 columns) in chunks of 400: the base-mode pseudo-MAF row equals
     paf2maf's query row minus the columns where its target row is gapped (K6 against K2 — the rows of v1, the block kernel:
