@@ -319,6 +319,68 @@ def test_maf_pair_stat(emu):
     pc.check_maf_call_runs(emu, pairs)
 
 
+def test_maf_walks_pairs_of_every_shape(emu):
+    """the walks take the two blocks of a wave as ONE column stream where that saves a step: every pair of lengths around the
+    sixteen-column and the 1 024-column borders (B starts at A's length rounded up to sixteen; A ends on a step's border, inside
+    it, in its last lane; empty blocks), counters and run lists of both walks"""
+    rng = np.random.default_rng(11)
+    lens = [0, 1, 15, 16, 17, 500, 1008, 1023, 1024, 1025, 1040, 2047, 2048, 2049]
+    pairs, strands = [], []
+    for la in lens:
+        for lb in lens:
+            for L in (la, lb):
+                t = pc.rand_seq(rng, L, b"ACGTacgt--N")
+                q = bytearray(pc.rand_seq(rng, L, b"ACGTacgt--N"))
+                for k in range(0, L, 3):                       # mostly equal columns, as in real blocks: longer runs
+                    if rng.random() < 0.8:
+                        q[k:k + 3] = t[k:k + 3]
+                pairs.append((t, bytes(q)))
+                strands.append(int(rng.integers(0, 2)))
+    pc.check_maf_pair(emu, pairs, strands)
+    pc.check_maf_call_runs(emu, pairs)
+
+
+def test_pafpseudo_stream_random(emu):
+    """pafpseudo's rows through the streaming kernel on random CIGARs with clips, runs of insertions and clips on one column,
+    zero-length ops and random trimmed heads, job sizes 1 and 8, both modes — against the oracle"""
+    before = emu.get_param("expand_job_tiles")
+    try:
+        for seed in range(12):
+            rng = np.random.default_rng(1000 + seed)
+            emu.set_param("expand_job_tiles", 1 if seed % 2 else 8)
+            cigars, strands = [], []
+            for _ in range(int(rng.integers(2, 7))):
+                parts = ["%d%s" % (rng.integers(0, 30), "SI"[int(rng.integers(0, 2))])] if rng.random() < 0.5 else []
+                for _ in range(int(rng.integers(1, 700))):
+                    r = rng.random()
+                    if r < 0.55:
+                        parts.append("%d%s" % (rng.integers(1, 60), "=XM"[int(rng.integers(0, 3))]))
+                    elif r < 0.70:
+                        parts.append("%dD" % rng.integers(0, 40))
+                    elif r < 0.85:
+                        parts.append("%dI" % rng.integers(0, 40))
+                    elif r < 0.90:
+                        parts.append("%dS" % rng.integers(0, 9))
+                    elif r < 0.95:
+                        parts.append("".join("%d%s" % (rng.integers(1, 4), "IS"[int(rng.integers(0, 2))]) for _ in range(int(rng.integers(2, 400)))))
+                    else:
+                        parts.append("%d%s" % (rng.integers(1, 5), "NHP"[int(rng.integers(0, 3))]))
+                parts.append("%d=" % rng.integers(1, 2000))
+                cigars.append("".join(parts))
+                strands.append(int(rng.integers(0, 2)))
+            qs = [pc.rand_seq(rng, pc.pseudo_consumption(c)) for c in cigars]
+            b = pc.batch_from_texts(emu, cigars, strands, [b"A"] * len(cigars), qs, pad=int(rng.integers(40, 90)))
+            b["q_pool"] = np.concatenate([np.frombuffer(b"N" * 64, np.uint8), b["q_pool"], np.frombuffer(b"N" * 64, np.uint8)])
+            b["q_src_off"] = b["q_src_off"] + np.uint64(64)
+            cols = [sum(int(n) for n, op in __import__("re").findall(r"(\d+)(\D)", c) if op in "M=XD") for c in cigars]
+            skip = [int(rng.integers(0, c + 1)) if rng.random() < 0.6 else 0 for c in cols]
+            for mode in (1, 0):
+                pc.check_pafpseudo(emu, b, mode, skip=skip, variant=3)
+                assert emu.get_param("pseudo_stream_left_to_blocks") == 0
+    finally:
+        emu.set_param("expand_job_tiles", before)
+
+
 def test_fast_expected_matches_oracle():
     """the numpy expectation used for long records on the GPU agrees with the C oracle"""
     b = synth.make_paf_batch(31, 25, 150, 40000)
