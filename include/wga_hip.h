@@ -125,7 +125,8 @@ int wga_ctx_reset_stream(wga_ctx*);
  * kernel — same bytes either way: -1 (default) by the batch (the window kernel, which assembles 4 KB output windows in
  * LDS and stores whole lines, for batches below 100 ops per record; the streaming kernel, one wave per row kind of a run of
  * tiles, for the others: profiles/r04_k2s_experiments.md), 0: v1 (one block per tile), 2: the window kernel, 3: the streaming
- * kernel (environment: WGA_EXPAND_VARIANT); "expand_job_tiles" (1 .. 32, default 8): consecutive tiles one wave of the streaming kernel walks;
+ * kernel (environment: WGA_EXPAND_VARIANT); "expand_job_tiles" (1 .. 32; 0, the default: 8, or 4 for batches below 200 000 tiles): consecutive tiles one wave of the
+ * streaming kernel walks;
  * "pseudo_variant": wga_pafpseudo_fill's rows through the streaming kernel (3, default) or one block per tile (0);
  * "expand_drain_min" (0 .. 64, v1 only) = how many gap-touching 16-column chunks a wave
  * queues before it emits them: 0 (default) lets the library choose by the size of the two sequence pools — 64 when

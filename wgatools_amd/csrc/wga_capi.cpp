@@ -47,7 +47,7 @@ struct wga_ctx {
   int expand_variant = -1; /* the row kernel: -1 by the batch (records below WGA_AUTO_SHORT_OPS ops on average take the window
                               kernel of wga_kernels_k2w.h, longer ones v1), 0 v1 (wga_kernels.h), 2 the window kernel */
   int expand_variant_used = 0;
-  int expand_job_tiles = 8; /* streaming kernel: tiles per wave ("expand_job_tiles") */
+  int expand_job_tiles = 0; /* streaming kernel: tiles per wave ("expand_job_tiles"); 0 = by the batch (job_tiles_for) */
   int pseudo_variant = 3;   /* pafpseudo's rows: 3 the streaming row kernel, 0 one block per tile ("pseudo_variant") */
   const u32* pseudo_counts = nullptr; /* ... the two counters of the tiles its last launch left to the block kernel */
   const u32* stream_counts = nullptr; /* streaming kernel: the two counters of the tiles its last launch left to v1 (in the scratch arena) */
@@ -553,7 +553,7 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
     return WGA_OK;
   }
   if (strcmp(name, "expand_job_tiles") == 0) { /* streaming row kernel: consecutive tiles per wave */
-    if (value < 1 || value > (int64_t)WGA_S_MAX_JOB_TILES) return fail(WGA_E_INVALID_ARG, "expand_job_tiles: 1 .. 32", nullptr);
+    if (value < 0 || value > (int64_t)WGA_S_MAX_JOB_TILES) return fail(WGA_E_INVALID_ARG, "expand_job_tiles: 0 (by the batch), 1 .. 32", nullptr);
     c->expand_job_tiles = (int)value;
     return WGA_OK;
   }
@@ -873,6 +873,13 @@ int wga_paf2maf_layout(wga_ctx* c, uint32_t n, const wga_cigar_counts* d_counts,
   return WGA_OK;
 }
 
+/* Tiles per job of the streaming row kernel: eight on a full-size batch; four when the whole grid is only a few rounds of the
+ * device's resident waves (an eighth of configs[1] — a rank's share at 8 GPUs: 0.792 against 0.810 ms; full size: the same) */
+static inline u32 job_tiles_for(int param, u64 nt) {
+  if (param >= 1) return param > (int)WGA_S_MAX_JOB_TILES ? WGA_S_MAX_JOB_TILES : (u32)param;
+  return nt < 200000ull ? 4u : 8u;
+}
+
 int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_counts* d_counts,
                        const void* d_tile_ws, const uint8_t* d_t_fa, uint64_t t_fa_bytes,
                        const uint64_t* d_t_src_off, const uint64_t* d_t_src_len,
@@ -932,7 +939,7 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
   a.tile_list = nullptr;
   a.n_rec = b->n;
   a.plan = (const u32*)((char*)ws + rec_bytes + desc_bytes + list_bytes);
-  a.job_tiles = c->expand_job_tiles < 1 ? 1u : (c->expand_job_tiles > (int)WGA_S_MAX_JOB_TILES ? WGA_S_MAX_JOB_TILES : (u32)c->expand_job_tiles);
+  a.job_tiles = job_tiles_for(c->expand_job_tiles, nt);
   const bool windows = variant == 2;
   const bool stream = variant == 3;
   /* when the gap-touching chunks are emitted (RowSrc::drain_min) */
@@ -1907,7 +1914,7 @@ int wga_pafpseudo_fill(wga_ctx* c, const wga_cigar_batch* b, int base_mode, cons
     e.out = d_out;
     e.diag = d_diag;
     e.n_rec = b->n;
-    e.job_tiles = c->expand_job_tiles < 1 ? 1u : (c->expand_job_tiles > (int)WGA_S_MAX_JOB_TILES ? WGA_S_MAX_JOB_TILES : (u32)c->expand_job_tiles);
+    e.job_tiles = job_tiles_for(c->expand_job_tiles, nt);
     const u64 jobs = (nt + e.job_tiles - 1) / e.job_tiles;
     if (base_mode)
       WGA_LAUNCH(k_pafpseudo_stream, (u32)((jobs + 1) / 2), 128u, c->stream, e);
