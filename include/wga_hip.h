@@ -486,12 +486,24 @@ int wga_fasta_pool(wga_ctx*, const uint8_t* d_text, uint64_t n_bytes, uint64_t* 
  * 256 bytes per 1024 ops of the largest batch (the pieces as the list pass writes them) and 40 bytes
  * per piece (a record segment of a tile of ops under a window of 8192 counters; 3.5 per 1024 ops on
  * configs[3]'s records).  WGA_COV_SPIN_LIMIT (environment, read by wga_ctx_create): polls of a
- * neighbouring tile's sum before a wave of the list pass adds up the ops itself (default 4096). */
+ * neighbouring tile's sum before a wave of the list pass adds up the ops itself (default 4096).
+ *
+ * accumulate_final() = accumulate() of the LAST batch + finalize() in one pass over the array: the
+ * kernel that replays the batch's marks window by window goes on to scan each window and hands its
+ * sum to the windows behind it (decoupled look-back), so the array is read and written once instead
+ * of twice more.  The targets' ranges [cov_off[t], cov_off[t] + cov_len[t]) must not overlap (any
+ * order; WGA_E_INVALID_ARG otherwise — also from finalize()); counters between them are not touched.
+ * The merge across the reference's per-thread arrays (pafcov.rs:29-53) has no counterpart: there is
+ * one array. */
 int wga_pafcov_accumulate(wga_ctx*, const wga_cigar_batch*, const uint32_t* d_target_id,
                           const uint64_t* d_t_start, const uint64_t* d_cov_off,
                           const uint64_t* d_cov_len, int32_t* d_cov, uint64_t total_cov);
 int wga_pafcov_finalize(wga_ctx*, uint32_t n_targets, const uint64_t* d_cov_off,
                         const uint64_t* d_cov_len, int32_t* d_cov);
+int wga_pafcov_accumulate_final(wga_ctx*, const wga_cigar_batch*, const uint32_t* d_target_id,
+                                const uint64_t* d_t_start, const uint64_t* d_cov_off,
+                                const uint64_t* d_cov_len, uint32_t n_targets, int32_t* d_cov,
+                                uint64_t total_cov);
 
 /* pafcov's text back end (pafcov.rs:56-60): the BED lines
  * "<name>\t<pos>\t<pos+1>\t<count>\n" for positions p0 .. p0+count-1 of one target, d_cov pointing

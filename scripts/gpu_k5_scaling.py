@@ -1,6 +1,7 @@
 """K5 (pafcov accumulate) against the size of ONE resident batch: does the time per op stay flat when the op stream grows
 from 10 GB to 100 GB?  (round 3: one call over 104 GB of ops measured 4.8 s, ten calls over 10 GB each 0.37 s.)
-usage: python scripts/gpu_k5_scaling.py [chunks ...]   (2 M records of ~1300 ops per chunk)"""
+usage: [K5_MODE=sep|fused|both] [K5_REPS=n] python scripts/gpu_k5_scaling.py [chunks ...]   (2 M records of ~1300 ops per chunk;
+10 chunks = configs[3] at its stated size)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -37,16 +38,40 @@ for chunks in [int(x) for x in (sys.argv[1:] or ["1", "2", "4", "8"])]:
         del tb
         torch.cuda.empty_cache()
     batch = engine.Batch(ops, op_off, strand, n_all, n_ops)
-    for rep in range(2):
-        cov.zero_()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        eng.pafcov_accumulate(batch, target_id, t_start, cov_off, cov_len, cov, total)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1)
-        print("chunks %d (%.1f GB of ops, %d records) rep %d: accumulate %.1f ms = %.0f GB/s of op stream" % (
-            chunks, 4 * n_ops / 1e9, n_all, rep, ms, 4 * n_ops / ms / 1e6), flush=True)
+    mode = os.environ.get("K5_MODE", "both")        # sep: accumulate + finalize; fused: accumulate_final; both
+    reps = int(os.environ.get("K5_REPS", "2"))
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    ref = None
+    for rep in range(reps):
+        if mode in ("sep", "both"):
+            cov.zero_()
+            torch.cuda.synchronize()
+            e0, e1, e2 = ev(), ev(), ev()
+            e0.record()
+            eng.pafcov_accumulate(batch, target_id, t_start, cov_off, cov_len, cov, total)
+            e1.record()
+            eng.pafcov_finalize(nt, cov_off, cov_len, cov)
+            e2.record()
+            torch.cuda.synchronize()
+            ms, msf = e0.elapsed_time(e1), e1.elapsed_time(e2)
+            print("chunks %d (%.1f GB of ops, %d records) rep %d: accumulate %.1f ms = %.0f GB/s of op stream, finalize %.1f ms, "
+                  "together %.1f ms" % (chunks, 4 * n_ops / 1e9, n_all, rep, ms, 4 * n_ops / ms / 1e6, msf, ms + msf), flush=True)
+            if mode == "both" and rep == 0:
+                ref = cov.clone()
+        if mode in ("fused", "both"):
+            cov.zero_()
+            torch.cuda.synchronize()
+            e0, e1 = ev(), ev()
+            e0.record()
+            eng.pafcov_accumulate_final(batch, target_id, t_start, cov_off, cov_len, nt, cov, total)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            alg = 4 * n_ops + 8 * nt * tlen
+            print("chunks %d rep %d: accumulate_final %.1f ms = %.0f GB/s over 4n + 8 B per counter (%.1f GB)" % (
+                chunks, rep, ms, alg / ms / 1e6, alg / 1e9), flush=True)
+            if ref is not None:
+                print("  fused == accumulate + finalize on every counter:", bool(torch.equal(ref, cov)), flush=True)
+                ref = None
     del ops, op_off, strand, t_start, target_id, batch
     torch.cuda.empty_cache()

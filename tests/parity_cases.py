@@ -459,6 +459,19 @@ def check_pafcov_long_ops(eng):
     b = dict(ops=ops, op_off=off, strand_neg=np.zeros(n, dtype=np.uint8))
     check_pafcov(eng, b, [0, 0, 1, 1, 1], [100, 8192 * 3 - 1, 0, 50000, 150000], [600000, 250000])
     check_pafcov(eng, b, [0, 0, 1, 1, 1], [100, 8192 * 3 - 1, 0, 50000, 150000], [600000, 250000], split=True)
+    # a tile that advances 2^31 bases and more (N ops of the longest packed length): the list pass measures its segments one by
+    # one in 64-bit positions, the replay walks such a piece in 64-bit positions too; the record goes on into the next tile
+    # (whose look-back brings a sum beyond 2^31) and far beyond its target's end; ordinary records in front and behind
+    big = (1 << 28) - 1
+    recs = [mk([(7, 40), (8, 1)] * 300),
+            mk([(7, 100)] + [(3, big)] * 9 + [(7, 50)] + [(7, 3), (2, 1)] * 600),
+            mk([(7, 25), (1, 2), (0, 9000)] * 40),
+            mk([(7, 5)] + [(3, big)] * 3 + [(7, 7), (2, big), (7, 1)])]       # beyond 2^30 but below 2^31: a wide piece of a narrow tile
+    ops = np.array([o for r in recs for o in r], dtype=np.uint32)
+    off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+    b = dict(ops=ops, op_off=off, strand_neg=np.zeros(len(recs), dtype=np.uint8))
+    check_pafcov(eng, b, [0, 1, 0, 1], [30, 10, 2000, 70000], [400000, 90000])
+    check_pafcov(eng, b, [0, 1, 0, 1], [30, 10, 2000, 70000], [400000, 90000], split=True)
 
 
 def check_pafcov_look_back(eng):
@@ -503,33 +516,57 @@ def check_pafcov_random(eng, seed, cases):
         check_pafcov(eng, b, list(tid), ts, tlen, align=int(rng.choice([1, 4])), split=bool(rng.integers(0, 2)))
 
 
-def check_pafcov(eng, b, target_id, t_start, target_len, align=4, split=False):
+def check_pafcov(eng, b, target_id, t_start, target_len, align=4, split=False, shuffle=None):
+    """both protocols against update_cov_vec: accumulate() per batch + finalize(), and the last batch through
+    accumulate_final() (marks and the marks -> counts scan in one pass).  The targets' ranges lie in the array in the order
+    `shuffle` gives (default: by index, or a seeded permutation for three and more targets), `align`-aligned with the gaps and
+    the array's tail holding a pattern that must still be there afterwards"""
     n = len(b["strand_neg"])
     nt = len(target_len)
+    order = list(range(nt))
+    if shuffle is None and nt >= 3:
+        np.random.default_rng(nt * 7919 + int(sum(target_len)) % 1000).shuffle(order)
+    elif shuffle is not None:
+        order = list(shuffle)
     cov_off = np.zeros(nt, dtype=np.uint64)
     p = 0
-    for t in range(nt):
+    for t in order:
         p = (p + align - 1) // align * align
         cov_off[t] = p
         p += int(target_len[t])
     total = p + 8
-    cov = eng.empty(total, np.int32).fill(0)
+    PAT = np.int32(0x5A5A5A5A)
+    init = np.full(total, PAT, dtype=np.int32)
+    for t in range(nt):
+        init[int(cov_off[t]):int(cov_off[t]) + int(target_len[t])] = 0
     d_off, d_len = eng.upload(cov_off), eng.upload(np.asarray(target_len, dtype=np.uint64))
     cuts = [0, n // 3, n] if split and n >= 3 else [0, n]      # several accumulate() calls, one finalize()
-    for lo, hi in zip(cuts[:-1], cuts[1:]):
-        a, z = int(b["op_off"][lo]), int(b["op_off"][hi])
-        batch = eng.make_batch(b["ops"][a:z], b["op_off"][lo:hi + 1] - np.uint64(a), b["strand_neg"][lo:hi])
-        eng.pafcov_accumulate(batch, eng.upload(np.asarray(target_id[lo:hi], dtype=np.uint32)),
-                              eng.upload(np.asarray(t_start[lo:hi], dtype=np.uint64)), d_off, d_len, cov, p)
-    eng.pafcov_finalize(nt, d_off, d_len, cov)
-    got = cov.numpy()
     exp = [np.zeros(int(l), dtype=np.uint64) for l in target_len]
     for i in range(n):
         orc.update_cov_vec(exp[target_id[i]], text_any(rec_ops(b, i)), int(t_start[i]))
-    for t in range(nt):
-        g = got[int(cov_off[t]):int(cov_off[t]) + int(target_len[t])]
-        assert (g.astype(np.int64) == exp[t].astype(np.int64)).all(), (
-            t, np.nonzero(g.astype(np.int64) != exp[t].astype(np.int64))[0][:5])
+    got = None
+    for fused in (False, True):
+        cov = eng.upload(init)
+        for k, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+            a, z = int(b["op_off"][lo]), int(b["op_off"][hi])
+            batch = eng.make_batch(b["ops"][a:z], b["op_off"][lo:hi + 1] - np.uint64(a), b["strand_neg"][lo:hi])
+            d_tid = eng.upload(np.asarray(target_id[lo:hi], dtype=np.uint32))
+            d_ts = eng.upload(np.asarray(t_start[lo:hi], dtype=np.uint64))
+            if fused and k == len(cuts) - 2:
+                eng.pafcov_accumulate_final(batch, d_tid, d_ts, d_off, d_len, nt, cov, p)
+            else:
+                eng.pafcov_accumulate(batch, d_tid, d_ts, d_off, d_len, cov, p)
+        if not fused:
+            eng.pafcov_finalize(nt, d_off, d_len, cov)
+        got = cov.numpy()
+        inside = np.zeros(total, dtype=bool)
+        for t in range(nt):
+            lo = int(cov_off[t])
+            g = got[lo:lo + int(target_len[t])]
+            inside[lo:lo + int(target_len[t])] = True
+            assert (g.astype(np.int64) == exp[t].astype(np.int64)).all(), (
+                fused, t, np.nonzero(g.astype(np.int64) != exp[t].astype(np.int64))[0][:5])
+        assert (got[~inside] == PAT).all(), (fused, np.nonzero(got[~inside] != PAT)[0][:5])
     return got
 
 

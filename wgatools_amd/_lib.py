@@ -83,6 +83,7 @@ PROTOTYPES = {
     "wga_bgzf_inflate": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),
     "wga_paf_call_vcf": (C.c_int, [vp, C.POINTER(CigarBatch), C.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "wga_pafcov_accumulate": (C.c_int, [vp, C.POINTER(CigarBatch), vp, vp, vp, vp, vp, C.c_uint64]),
+    "wga_pafcov_accumulate_final": (C.c_int, [vp, C.POINTER(CigarBatch), vp, vp, vp, vp, C.c_uint32, vp, C.c_uint64]),
     "wga_pafcov_format": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, C.c_uint32, vp, vp]),
     "wga_pafcov_finalize": (C.c_int, [vp, C.c_uint32, vp, vp, vp]),
     "wga_pafpseudo_fill": (C.c_int, [vp, C.POINTER(CigarBatch), C.c_int, vp, C.c_uint64, vp, vp,

@@ -7,7 +7,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "wga_kernels.h"
@@ -1613,18 +1615,56 @@ int wga_paf_call_vcf(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, const
   return WGA_OK;
 }
 
-int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_target_id,
-                          const uint64_t* d_t_start, const uint64_t* d_cov_off,
-                          const uint64_t* d_cov_len, int32_t* d_cov, uint64_t total_cov) {
-  int rc = ctx_bind(c);
-  if (rc) return rc;
-  if ((rc = check_batch(b))) return rc;
-  if (b->n == 0 || b->n_ops == 0) return WGA_OK;
-  if (!d_target_id || !d_t_start || !d_cov_off || !d_cov_len || !d_cov)
-    return fail(WGA_E_INVALID_ARG, "null array", nullptr);
-  if (total_cov == 0) return WGA_OK;
-  const u64 nt = n_tiles(b->n_ops);
-  const u64 nw = (total_cov >> WGA_COV_WIN_SHIFT) + 1;
+/* The targets' counter ranges [first, one past last] in ascending order, ranges of no counters left out: what the replay's
+ * marks -> counts part walks (k_cov_windows<true>).  Ranges that overlap are refused. */
+static int cov_ranges(wga_ctx* c, u32 n_targets, const u64* d_cov_off, const u64* d_cov_len, std::vector<u64>& lo_hi,
+                      u32* n_rng, u64* n_cov) {
+  std::vector<u64> h((size_t)n_targets * 2);
+  if (n_targets) {
+    RT_CHECK(rt_d2h(h.data(), d_cov_off, (size_t)n_targets * 8, c->stream));
+    RT_CHECK(rt_d2h(h.data() + n_targets, d_cov_len, (size_t)n_targets * 8, c->stream));
+  }
+  std::vector<std::pair<u64, u64>> r;
+  r.reserve(n_targets);
+  for (u32 t = 0; t < n_targets; t++) {
+    const u64 lo = h[t], len = h[(size_t)n_targets + t];
+    if (lo + len < lo) return fail(WGA_E_INVALID_ARG, "pafcov: a target's range wraps", nullptr);
+    if (len) r.emplace_back(lo, lo + len);
+  }
+  std::sort(r.begin(), r.end());
+  u64 top = 0;
+  for (size_t i = 0; i < r.size(); i++) {
+    if (r[i].first < top) return fail(WGA_E_INVALID_ARG, "pafcov: target ranges overlap", nullptr);
+    top = r[i].second;
+  }
+  lo_hi.resize(r.size() * 2);
+  for (size_t i = 0; i < r.size(); i++) {
+    lo_hi[i] = r[i].first;
+    lo_hi[r.size() + i] = r[i].second;
+  }
+  *n_rng = (u32)r.size();
+  *n_cov = top;
+  return WGA_OK;
+}
+
+/* accumulate (b != nullptr) and / or finalize (n_targets counter ranges): one replay over the windows does both */
+static int pafcov_run(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_target_id, const uint64_t* d_t_start,
+                      const uint64_t* d_cov_off, const uint64_t* d_cov_len, int32_t* d_cov, uint64_t total_cov, bool final,
+                      uint32_t n_targets) {
+  std::vector<u64> lo_hi;
+  u32 n_rng = 0;
+  u64 n_cov = total_cov;
+  if (final) {
+    u64 top = 0;
+    int rc = cov_ranges(c, n_targets, (const u64*)d_cov_off, (const u64*)d_cov_len, lo_hi, &n_rng, &top);
+    if (rc) return rc;
+    if (b && top > total_cov) return fail(WGA_E_INVALID_ARG, "pafcov: a target's range ends behind total_cov", nullptr);
+    if (!b) n_cov = top;
+  }
+  const bool has_ops = b && b->n != 0 && b->n_ops != 0 && total_cov != 0;
+  if (!has_ops && (!final || n_rng == 0)) return WGA_OK;
+  const u64 nt = has_ops ? n_tiles(b->n_ops) : 0;
+  const u64 nw = (n_cov >> WGA_COV_WIN_SHIFT) + 1;
   if (nw > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "coverage arrays too large for one call", nullptr);
   /* One pass lists every (tile, record segment, window) piece (see wga_kernels2.h K5): tile sums by look-back, the pieces into the
    * tile's own slots and counted under their windows; a scan of the window counts, and the pieces are taken to their windows.
@@ -1634,101 +1674,148 @@ int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* 
   const size_t b_tail = (size_t)nt * 8, b_lcnt = (size_t)WGA_COV_LISTS * 8, b_wcnt = (((size_t)nw * 4) + 15) & ~(size_t)15;
   const size_t b_woff = (((size_t)nw + 1) * 8 + ((size_t)(nw + 1023) / 1024 + 2) * 8 + 15) & ~(size_t)15;
   const size_t b_tcnt = ((size_t)nt * 4 + 15) & ~(size_t)15;
-  {
-    const size_t bytes = b_tail + b_lcnt + b_wcnt + b_woff + b_tcnt + (size_t)nt * sizeof(wga_cov_tile) +
-                         (size_t)b->n * sizeof(wga_cov_rec);
-    if ((rc = ctx_scratch(c, bytes, &ws))) return rc;
-  }
+  const size_t b_tinfo = (size_t)nt * sizeof(wga_cov_tile), b_rpos = has_ops ? (size_t)b->n * sizeof(wga_cov_rec) : 0;
+  const size_t b_state = final ? (size_t)nw * 8 : 0, b_rng = (size_t)n_rng * 16;
+  int rc;
+  if ((rc = ctx_scratch(c, b_tail + b_lcnt + b_wcnt + b_woff + b_tcnt + b_tinfo + b_rpos + b_state + b_rng + 64, &ws))) return rc;
   u64* tile_tail = (u64*)ws;
   u64* list_cnt = tile_tail + nt;
   u32* win_cnt = (u32*)(list_cnt + WGA_COV_LISTS);
   u64* win_off = (u64*)((char*)win_cnt + b_wcnt);
   u32* tile_cnt = (u32*)((char*)win_off + b_woff);
   wga_cov_tile* tile_info = (wga_cov_tile*)((char*)tile_cnt + b_tcnt);
-  wga_cov_rec* rec_pos = (wga_cov_rec*)(tile_info + nt);
-  const u32 grid = (u32)((nt + 3) / 4);
-  if (c->cov_tile_list_cap < nt) {
-    if (c->cov_tile_list) RT_CHECK(rt_free(c->cov_tile_list));
-    c->cov_tile_list = nullptr;
-    c->cov_tile_list_cap = 0;
-    RT_CHECK(rt_malloc(&c->cov_tile_list, (size_t)nt * WGA_COV_TILE_CAP * sizeof(wga_cov_piece)));
-    c->cov_tile_list_cap = nt;
-  }
-  /* what a tile's wave needs of its first two records, in one load: every record's place in the coverage index space, then the
-   * record of every tile's first op with its own and its successor's data */
-  WGA_LAUNCH(k_cov_rec_pos, (b->n + WGA_BLOCK - 1) / WGA_BLOCK, WGA_BLOCK, c->stream, b->n, d_target_id, (const u64*)d_t_start,
-             (const u64*)d_cov_off, (const u64*)d_cov_len, rec_pos);
-  LAUNCH_CHECK();
-  WGA_LAUNCH(k_cov_tile_info, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const u64*)b->d_op_off, b->n, (u64)b->n_ops,
-             (const wga_cov_rec*)rec_pos, tile_info);
-  LAUNCH_CHECK();
-  std::vector<u64> h_cnt(WGA_COV_LISTS);
-  u64 n_over = 0;
-  for (int attempt = 0;; attempt++) {
-    RT_CHECK(rt_memset(ws, 0, b_tail + b_lcnt + b_wcnt, c->stream));
-    WGA_LAUNCH(k_cov_list_pieces, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off, (u64)b->n_ops,
-               (const wga_cov_tile*)tile_info, (const wga_cov_rec*)rec_pos, tile_tail, win_cnt,
-               (wga_cov_piece*)c->cov_tile_list, tile_cnt, list_cnt, (wga_cov_piece*)c->cov_list, (u64)c->cov_list_rcap,
-               (u32)c->cov_spin_limit);
-    LAUNCH_CHECK();
-    RT_CHECK(rt_d2h(h_cnt.data(), list_cnt, b_lcnt, c->stream));
-    u64 most = 0;
-    n_over = 0;
-    for (u64 v : h_cnt) {
-      n_over += v;
-      if (v > most) most = v;
-    }
-    if (most <= c->cov_list_rcap) break;
-    if (attempt) return fail(WGA_E_HIP, "pafcov: the list regions overflow a second time", nullptr);
-    if (c->cov_list) RT_CHECK(rt_free(c->cov_list));
-    c->cov_list = nullptr;
-    c->cov_list_rcap = 0;
-    const u64 rcap = most + most / 4 + 16;
-    RT_CHECK(rt_malloc(&c->cov_list, (size_t)rcap * WGA_COV_LISTS * sizeof(wga_cov_piece)));
-    c->cov_list_rcap = rcap;
-  }
-  {
-    /* run_scan uses the context scratch itself: give it its own small buffer behind win_off */
-    ScanU32 f;
-    f.in = win_cnt;
-    u32 nb = ((u32)nw + 1023u) / 1024u;
-    u64* partial = win_off + nw + 1;
-    if (nb) {
-      WGA_LAUNCH(k_scan_partials<ScanU32>, nb, WGA_BLOCK, c->stream, f, (u32)nw, partial);
-      LAUNCH_CHECK();
-    }
-    WGA_LAUNCH(k_scan_top, 1, WGA_BLOCK, c->stream, partial, nb, win_off + nw);
-    LAUNCH_CHECK();
-    if (nb) {
-      WGA_LAUNCH(k_scan_final<ScanU32>, nb, WGA_BLOCK, c->stream, f, (u32)nw, (const u64*)partial, win_off);
-      LAUNCH_CHECK();
-    }
+  wga_cov_rec* rec_pos = (wga_cov_rec*)((char*)tile_info + b_tinfo);
+  u64* win_state = (u64*)((char*)rec_pos + b_rpos);
+  u64* rng_lo = (u64*)((char*)win_state + b_state);
+  u64* rng_hi = rng_lo + n_rng;
+  if (final) {
+    RT_CHECK(rt_memset(win_state, 0, b_state, c->stream));
+    if (n_rng) RT_CHECK(rt_h2d(rng_lo, lo_hi.data(), b_rng, c->stream));
+    RT_CHECK(rt_sync(c->stream)); /* lo_hi is a host buffer of this call */
   }
   u64 n_pieces = 0;
-  RT_CHECK(rt_d2h(&n_pieces, win_off + nw, sizeof(u64), c->stream));
-  if (n_pieces == 0) return WGA_OK;
-  if (c->cov_pieces_cap < n_pieces) {
-    if (c->cov_pieces) RT_CHECK(rt_free(c->cov_pieces));
-    c->cov_pieces = nullptr;
-    c->cov_pieces_cap = 0;
-    RT_CHECK(rt_malloc(&c->cov_pieces, (size_t)(n_pieces + n_pieces / 4) * sizeof(wga_cov_piece)));
-    c->cov_pieces_cap = n_pieces + n_pieces / 4;
+  if (has_ops) {
+    const u32 grid = (u32)((nt + 3) / 4);
+    if (c->cov_tile_list_cap < nt) {
+      if (c->cov_tile_list) RT_CHECK(rt_free(c->cov_tile_list));
+      c->cov_tile_list = nullptr;
+      c->cov_tile_list_cap = 0;
+      RT_CHECK(rt_malloc(&c->cov_tile_list, (size_t)nt * WGA_COV_TILE_CAP * sizeof(wga_cov_piece)));
+      c->cov_tile_list_cap = nt;
+    }
+    /* what a tile's wave needs of its first two records, in one load: every record's place in the coverage index space, then the
+     * record of every tile's first op with its own and its successor's data */
+    WGA_LAUNCH(k_cov_rec_pos, (b->n + WGA_BLOCK - 1) / WGA_BLOCK, WGA_BLOCK, c->stream, b->n, d_target_id, (const u64*)d_t_start,
+               (const u64*)d_cov_off, (const u64*)d_cov_len, rec_pos);
+    LAUNCH_CHECK();
+    WGA_LAUNCH(k_cov_tile_info, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const u64*)b->d_op_off, b->n, (u64)b->n_ops,
+               (const wga_cov_rec*)rec_pos, tile_info);
+    LAUNCH_CHECK();
+    std::vector<u64> h_cnt(WGA_COV_LISTS);
+    u64 n_over = 0;
+    for (int attempt = 0;; attempt++) {
+      RT_CHECK(rt_memset(ws, 0, b_tail + b_lcnt + b_wcnt, c->stream));
+      WGA_LAUNCH(k_cov_list_pieces, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off, (u64)b->n_ops,
+                 (const wga_cov_tile*)tile_info, (const wga_cov_rec*)rec_pos, tile_tail, win_cnt,
+                 (wga_cov_piece*)c->cov_tile_list, tile_cnt, list_cnt, (wga_cov_piece*)c->cov_list, (u64)c->cov_list_rcap,
+                 (u32)c->cov_spin_limit);
+      LAUNCH_CHECK();
+      RT_CHECK(rt_d2h(h_cnt.data(), list_cnt, b_lcnt, c->stream));
+      u64 most = 0;
+      n_over = 0;
+      for (u64 v : h_cnt) {
+        n_over += v;
+        if (v > most) most = v;
+      }
+      if (most <= c->cov_list_rcap) break;
+      if (attempt) return fail(WGA_E_HIP, "pafcov: the list regions overflow a second time", nullptr);
+      if (c->cov_list) RT_CHECK(rt_free(c->cov_list));
+      c->cov_list = nullptr;
+      c->cov_list_rcap = 0;
+      const u64 rcap = most + most / 4 + 16;
+      RT_CHECK(rt_malloc(&c->cov_list, (size_t)rcap * WGA_COV_LISTS * sizeof(wga_cov_piece)));
+      c->cov_list_rcap = rcap;
+    }
+    {
+      /* run_scan uses the context scratch itself: give it its own small buffer behind win_off */
+      ScanU32 f;
+      f.in = win_cnt;
+      u32 nb = ((u32)nw + 1023u) / 1024u;
+      u64* partial = win_off + nw + 1;
+      if (nb) {
+        WGA_LAUNCH(k_scan_partials<ScanU32>, nb, WGA_BLOCK, c->stream, f, (u32)nw, partial);
+        LAUNCH_CHECK();
+      }
+      WGA_LAUNCH(k_scan_top, 1, WGA_BLOCK, c->stream, partial, nb, win_off + nw);
+      LAUNCH_CHECK();
+      if (nb) {
+        WGA_LAUNCH(k_scan_final<ScanU32>, nb, WGA_BLOCK, c->stream, f, (u32)nw, (const u64*)partial, win_off);
+        LAUNCH_CHECK();
+      }
+    }
+    RT_CHECK(rt_d2h(&n_pieces, win_off + nw, sizeof(u64), c->stream));
+    if (n_pieces) {
+      if (c->cov_pieces_cap < n_pieces) {
+        if (c->cov_pieces) RT_CHECK(rt_free(c->cov_pieces));
+        c->cov_pieces = nullptr;
+        c->cov_pieces_cap = 0;
+        RT_CHECK(rt_malloc(&c->cov_pieces, (size_t)(n_pieces + n_pieces / 4) * sizeof(wga_cov_piece)));
+        c->cov_pieces_cap = n_pieces + n_pieces / 4;
+      }
+      RT_CHECK(rt_memset(win_cnt, 0, (size_t)nw * 4, c->stream)); /* now the windows' fill counters */
+      WGA_LAUNCH(k_cov_place_tiles, (u32)((nt * WGA_COV_TILE_CAP + WGA_BLOCK - 1) / WGA_BLOCK), WGA_BLOCK, c->stream, (u64)nt,
+                 (const u32*)tile_cnt, (const wga_cov_piece*)c->cov_tile_list, win_cnt, (const u64*)win_off,
+                 (wga_cov_piece*)c->cov_pieces);
+      LAUNCH_CHECK();
+      if (n_over) {
+        dim3 pgrid((u32)((c->cov_list_rcap + WGA_BLOCK - 1) / WGA_BLOCK), WGA_COV_LISTS, 1);
+        WGA_LAUNCH(k_cov_place_pieces, pgrid, WGA_BLOCK, c->stream, (const u64*)list_cnt, (const wga_cov_piece*)c->cov_list,
+                   (u64)c->cov_list_rcap, win_cnt, (const u64*)win_off, (wga_cov_piece*)c->cov_pieces);
+        LAUNCH_CHECK();
+      }
+    }
   }
-  RT_CHECK(rt_memset(win_cnt, 0, (size_t)nw * 4, c->stream)); /* now the windows' fill counters */
-  WGA_LAUNCH(k_cov_place_tiles, (u32)((nt * WGA_COV_TILE_CAP + WGA_BLOCK - 1) / WGA_BLOCK), WGA_BLOCK, c->stream, (u64)nt,
-             (const u32*)tile_cnt, (const wga_cov_piece*)c->cov_tile_list, win_cnt, (const u64*)win_off,
-             (wga_cov_piece*)c->cov_pieces);
-  LAUNCH_CHECK();
-  if (n_over) {
-    dim3 pgrid((u32)((c->cov_list_rcap + WGA_BLOCK - 1) / WGA_BLOCK), WGA_COV_LISTS, 1);
-    WGA_LAUNCH(k_cov_place_pieces, pgrid, WGA_BLOCK, c->stream, (const u64*)list_cnt, (const wga_cov_piece*)c->cov_list,
-               (u64)c->cov_list_rcap, win_cnt, (const u64*)win_off, (wga_cov_piece*)c->cov_pieces);
+  const u32* d_ops = has_ops ? b->d_ops : nullptr;
+  const u64 n_ops = has_ops ? (u64)b->n_ops : 0;
+  const u64* woff = n_pieces ? (const u64*)win_off : nullptr;
+  if (final) {
+    WGA_LAUNCH(k_cov_windows<true>, (u32)nw, WGA_COV_BLOCK, c->stream, d_ops, n_ops, (const wga_cov_piece*)c->cov_pieces, woff,
+               (int*)d_cov, (u64)n_cov, (const u64*)rng_lo, (const u64*)rng_hi, n_rng, win_state);
+    LAUNCH_CHECK();
+  } else if (n_pieces) {
+    WGA_LAUNCH(k_cov_windows<false>, (u32)nw, WGA_COV_BLOCK, c->stream, d_ops, n_ops, (const wga_cov_piece*)c->cov_pieces, woff,
+               (int*)d_cov, (u64)n_cov, (const u64*)nullptr, (const u64*)nullptr, 0u, (u64*)nullptr);
     LAUNCH_CHECK();
   }
-  WGA_LAUNCH(k_cov_windows, (u32)nw, WGA_COV_BLOCK, c->stream, b->d_ops, (u64)b->n_ops,
-             (const wga_cov_piece*)c->cov_pieces, (const u64*)win_off, (int*)d_cov, (u64)total_cov);
-  LAUNCH_CHECK();
   return WGA_OK;
+}
+
+static int pafcov_args(wga_ctx* c, const wga_cigar_batch* b, const void* d_target_id, const void* d_t_start,
+                       const void* d_cov_off, const void* d_cov_len, const void* d_cov) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if ((rc = check_batch(b))) return rc;
+  if (b->n != 0 && b->n_ops != 0 && (!d_target_id || !d_t_start || !d_cov_off || !d_cov_len || !d_cov))
+    return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  return WGA_OK;
+}
+
+int wga_pafcov_accumulate(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_target_id,
+                          const uint64_t* d_t_start, const uint64_t* d_cov_off,
+                          const uint64_t* d_cov_len, int32_t* d_cov, uint64_t total_cov) {
+  int rc = pafcov_args(c, b, d_target_id, d_t_start, d_cov_off, d_cov_len, d_cov);
+  if (rc) return rc;
+  return pafcov_run(c, b, d_target_id, d_t_start, d_cov_off, d_cov_len, d_cov, total_cov, false, 0u);
+}
+
+int wga_pafcov_accumulate_final(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_target_id,
+                                const uint64_t* d_t_start, const uint64_t* d_cov_off, const uint64_t* d_cov_len,
+                                uint32_t n_targets, int32_t* d_cov, uint64_t total_cov) {
+  int rc = pafcov_args(c, b, d_target_id, d_t_start, d_cov_off, d_cov_len, d_cov);
+  if (rc) return rc;
+  if (n_targets == 0) return WGA_OK;
+  if (!d_cov_off || !d_cov_len || !d_cov) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  return pafcov_run(c, b, d_target_id, d_t_start, d_cov_off, d_cov_len, d_cov, total_cov, true, n_targets);
 }
 
 int wga_pafcov_finalize(wga_ctx* c, uint32_t n_targets, const uint64_t* d_cov_off,
@@ -1737,42 +1824,7 @@ int wga_pafcov_finalize(wga_ctx* c, uint32_t n_targets, const uint64_t* d_cov_of
   if (rc) return rc;
   if (n_targets == 0) return WGA_OK;
   if (!d_cov_off || !d_cov_len || !d_cov) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
-  /* per target: chunk sums -> serial chunk scan (one block per target) -> chunk-local scans.
-   * The chunk grid is sized on the host from a copy of the two small per-target arrays. */
-  std::string hbuf((size_t)n_targets * 16, '\0');
-  u64* h_off = (u64*)&hbuf[0];
-  u64* h_len = h_off + n_targets;
-  RT_CHECK(rt_d2h(h_off, d_cov_off, (size_t)n_targets * 8, c->stream));
-  RT_CHECK(rt_d2h(h_len, d_cov_len, (size_t)n_targets * 8, c->stream));
-  u64 max_chunks = 0, total_chunks = 0;
-  std::string cbuf(((size_t)n_targets + 1) * 8, '\0');
-  u64* h_chunk_off = (u64*)&cbuf[0];
-  for (u32 t = 0; t < n_targets; t++) {
-    u64 nc = (h_len[t] + WGA_COV_CHUNK - 1) / WGA_COV_CHUNK;
-    h_chunk_off[t] = total_chunks;
-    total_chunks += nc;
-    if (nc > max_chunks) max_chunks = nc;
-  }
-  h_chunk_off[n_targets] = total_chunks;
-  if (total_chunks == 0) return WGA_OK;
-  if (max_chunks > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "target too long", nullptr);
-  void* ws;
-  size_t need = ((size_t)total_chunks + n_targets + 1) * 8 + 64;
-  if ((rc = ctx_scratch(c, need, &ws))) return rc;
-  u64* d_chunk_off = (u64*)ws;
-  i64* d_chunk_sum = (i64*)(d_chunk_off + n_targets + 1);
-  RT_CHECK(rt_h2d(d_chunk_off, h_chunk_off, ((size_t)n_targets + 1) * 8, c->stream));
-  RT_CHECK(rt_sync(c->stream)); /* h_chunk_off is a stack-lifetime host buffer */
-  dim3 grid((u32)max_chunks, n_targets, 1);
-  WGA_LAUNCH(k_cov_chunk_sums, grid, WGA_BLOCK, c->stream, (const u64*)d_cov_off,
-             (const u64*)d_cov_len, (const int*)d_cov, (const u64*)d_chunk_off, d_chunk_sum);
-  LAUNCH_CHECK();
-  WGA_LAUNCH(k_cov_chunk_scan, n_targets, WGA_BLOCK, c->stream, (const u64*)d_chunk_off, d_chunk_sum);
-  LAUNCH_CHECK();
-  WGA_LAUNCH(k_cov_chunk_apply, grid, WGA_BLOCK, c->stream, (const u64*)d_cov_off,
-             (const u64*)d_cov_len, (int*)d_cov, (const u64*)d_chunk_off, (const i64*)d_chunk_sum);
-  LAUNCH_CHECK();
-  return WGA_OK;
+  return pafcov_run(c, nullptr, nullptr, nullptr, d_cov_off, d_cov_len, d_cov, 0, true, n_targets);
 }
 
 /* The class sums are the count call of pafpseudo's protocol (the host sizes the row segments from them): the tile sums and the

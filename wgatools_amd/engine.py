@@ -400,6 +400,11 @@ class Engine:
                                                    _p(t_start), _p(cov_off), _p(cov_len), _p(cov),
                                                    int(total_cov)))
 
+    def pafcov_accumulate_final(self, batch, target_id, t_start, cov_off, cov_len, n_targets, cov, total_cov):
+        """the last batch's marks and the marks -> counts scan in one pass over the array"""
+        self._check(self.lib.wga_pafcov_accumulate_final(self.ctx, C.byref(batch.c), _p(target_id), _p(t_start), _p(cov_off),
+                                                         _p(cov_len), int(n_targets), _p(cov), int(total_cov)))
+
     def pafcov_finalize(self, n_targets, cov_off, cov_len, cov):
         self._check(self.lib.wga_pafcov_finalize(self.ctx, n_targets, _p(cov_off), _p(cov_len),
                                                  _p(cov)))
