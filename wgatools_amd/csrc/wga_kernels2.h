@@ -154,22 +154,20 @@ __device__ __forceinline__ u64 cov_incl_scan_u64(u64 v, u64& total) {
   return (u64)lo + ((u64)hi << 24);
 }
 
-/* 16 consecutive ops per lane of tile g, zero-filled beyond the stream */
+/* 16 consecutive ops per lane of tile g, zeros from op nt on: every 16-byte group that starts in front of nt is loaded (the group
+ * that holds the stream's last op may reach up to 12 bytes beyond it, inside the same aligned 16 bytes; the callers give what
+ * it brings from there no weight — the list pass only looks at ops inside record segments) */
 __device__ __forceinline__ void cov_load_ops(const u32* __restrict__ ops, u64 tile_start, u32 nt, u32 lane,
                                              u32 w[16]) {
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const u32 base = lane * 16u + (u32)j * 4u;
-    if (base + 3 < nt) {
-      const u32x4_a16 v = *(const u32x4_a16*)(ops + tile_start + base);
-      w[4 * j + 0] = v[0];
-      w[4 * j + 1] = v[1];
-      w[4 * j + 2] = v[2];
-      w[4 * j + 3] = v[3];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; e++) w[4 * j + e] = (base + e < nt) ? ops[tile_start + base + e] : 0u;
-    }
+    u32x4_a16 v = {0u, 0u, 0u, 0u};
+    if (base < nt) v = *(const u32x4_a16*)(ops + tile_start + base);
+    w[4 * j + 0] = v[0];
+    w[4 * j + 1] = v[1];
+    w[4 * j + 2] = v[2];
+    w[4 * j + 3] = v[3];
   }
 }
 /* an op's advance on the target: everything but I and S moves (cigar.rs:720-733) — codes 1, 4 and 9 (I, S, the rest of a split I)
@@ -216,7 +214,7 @@ __device__ __forceinline__ u64 cov_look_back(u64* tile_tail, const u32* __restri
     }
     p += mine ? (v & ~WGA_COV_READY) : 0ull;
   }
-  if (!gave_up) return wave_sum_u64(p);
+  if (!gave_up) return wave_sum_u32_wide((u32)p) + (wave_sum_u32_wide((u32)(p >> 32)) << 32); /* DPP, no LDS */
   u64 q = 0;
   for (u64 i = rs + lane; i < g * WGA_TILE; i += 64) {
     const u32 op = ops[i];
@@ -301,6 +299,10 @@ __global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
   cov_load_ops(ops, tile_start, nt, lane, w);
 #pragma unroll
   for (int e = 0; e < 16; e++) w[e] = (w[e] >> 4) & bit_mask(WGA_COV_MOVES_BITS, w[e] & 15u); /* the pass needs the ops' advance only */
+  if (nt & 3u) { /* wave-uniform, the stream's last tile: what the last 16-byte group brought from behind the stream */
+#pragma unroll
+    for (int e = 0; e < 16; e++) w[e] = lane * 16u + (u32)e < nt ? w[e] : 0u;
+  }
   const u32 region = (u32)(g % WGA_COV_LISTS);
   u64* const my_cnt = list_cnt + region;
   wga_cov_piece* const my_list = list + (u64)region * rcap;
@@ -382,37 +384,26 @@ __global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
    * real alignment) is then handled in 32-bit positions relative to each segment's start; anything else, a segment across more
    * than the slots' windows or a tile of more than WGA_COV_TILE_CAP pieces takes the general walk below, which measures every
    * segment on its own (64-bit scans, a lane-per-window search). */
-  u32 lt = 0;
+  /* w becomes the running sum inside the lane (w[e] = advance of the lane's ops 0 .. e): the advance in front of any op is then
+   * one register of one lane, read with a wave-uniform register index */
 #pragma unroll
-  for (int e = 0; e < 16; e++) lt += w[e]; /* 16 advances below 2^28 */
+  for (int e = 1; e < 16; e++) w[e] += w[e - 1]; /* 16 advances below 2^28 */
+  const u32 lt = w[15];
+  auto per_op_again = [&]() { /* the general walk measures ops one by one */
+#pragma unroll
+    for (int e = 15; e > 0; e--) w[e] -= w[e - 1];
+  };
   u64 tile_total;
   const u64 P64 = cov_incl_scan_u64((u64)lt, tile_total);
   const bool narrow = tile_total < (1ull << 31); /* wave-uniform */
   const u32 Pin = (u32)P64, Pex = Pin - lt;
   auto prefix_at = [&](u32 i) -> u32 { /* NARROW only; i <= nt, wave-uniform */
     if (i >= WGA_TILE) return (u32)tile_total;
-    const u32 li = i >> 4;
-    u32 part = 0;
-    switch (i & 15u) {
-      case 15: part += w[14]; [[fallthrough]];
-      case 14: part += w[13]; [[fallthrough]];
-      case 13: part += w[12]; [[fallthrough]];
-      case 12: part += w[11]; [[fallthrough]];
-      case 11: part += w[10]; [[fallthrough]];
-      case 10: part += w[9]; [[fallthrough]];
-      case 9: part += w[8]; [[fallthrough]];
-      case 8: part += w[7]; [[fallthrough]];
-      case 7: part += w[6]; [[fallthrough]];
-      case 6: part += w[5]; [[fallthrough]];
-      case 5: part += w[4]; [[fallthrough]];
-      case 4: part += w[3]; [[fallthrough]];
-      case 3: part += w[2]; [[fallthrough]];
-      case 2: part += w[1]; [[fallthrough]];
-      case 1: part += w[0]; [[fallthrough]];
-      default: break;
-    }
+    const u32 li = i >> 4, e = WGA_UNI32(i & 15u);
+    const u32 part = e ? w[(e - 1u) & 15u] : 0u;
     return wave_get_u32_dyn(Pex, li) + wave_get_u32_dyn(part, li);
   };
+  if (!narrow) per_op_again();
   /* Publish first, then look back, then write: the wait for the look-back's answer stands in front of the tile's first store
    * (a wait behind stores is a wait for their acknowledgements as well — a third of the pass when it was there).  The tile's
    * last segment starts where the record of the next tile's first op starts; when that record starts with the next tile, no
@@ -506,6 +497,7 @@ __global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
       if (lane == 0) tile_cnt[g] = n_p;
       return;
     }
+    per_op_again();
   }
   {
     u64 mv, inc, span;
@@ -584,7 +576,9 @@ struct ScanU32 {
  * indices in ascending order, disjoint (the host sorts them). */
 #define WGA_COV_WAVES 8u
 #define WGA_COV_BLOCK (64u * WGA_COV_WAVES)
+#ifndef WGA_COV_AHEAD
 #define WGA_COV_AHEAD 2
+#endif
 #define WGA_COVF_AGG (1ull << 62)
 #define WGA_COVF_PREFIX (2ull << 62)
 
@@ -1124,7 +1118,9 @@ __device__ __forceinline__ void pseudo_tile(const PseudoArgs& a, const u64 g) {
     qs.src_len = BASE ? a.q_src_len[r] : 0;
     qs.rc = a.strand_neg[r] != 0;
     /* edited length: String::drain / insert_str semantics (cigar.rs:769-786) */
-    const u64 row_len = BASE ? qs.src_len - (cs.i + cs.s) + cs.d : T_total;
+    /* a record whose I / S ops take more than the slice holds (String::drain panics, reported below) has no row: the
+     * difference must not wrap into a row of 2^64 bytes */
+    const u64 row_len = BASE ? (qs.src_len + cs.d >= cs.i + cs.s ? qs.src_len + cs.d - (cs.i + cs.s) : 0ull) : T_total;
     const u64 skip = a.skip[r];
     u8* const dst = a.out + a.dst_off[r];
     u64* const bad_base = (u64*)&a.diag[r].bad_base_pos;
