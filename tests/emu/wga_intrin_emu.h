@@ -75,6 +75,7 @@ __device__ __forceinline__ u64 wave_get_u64(u32 v, int k) { return (u64)__shfl(v
 __device__ __forceinline__ u32 wave_get_u32(u32 v, int k) { return __shfl(v, k); }
 __device__ __forceinline__ u32 wave_get_u32_dyn(u32 v, u32 k) { return __shfl(v, (int)k); }
 #define WGA_CLOCK() 0ull
+#define WGA_SLEEP(n) ((void)0)
 /* the emulator's lanes are fibers: a real wave barrier */
 #define WGA_WAVE_SYNC() emu::barrier_wait(emu::S().wave_bar[emu::flat_tid() >> 6])
 

@@ -745,27 +745,45 @@ def test_expand_place(emu):
 
 def test_reduce_scatter_i32(monkeypatch):
     """wga_reduce_scatter_i32 over three emulated devices: slice g of buffer g = the sum over the devices, the rest of every
-    buffer is untouched; one context is a no-op; two contexts on one device are refused"""
+    buffer is untouched; one context is a no-op; two contexts on one device are refused.  Both forms: the peers' buffers read
+    in place by one kernel per device, and ("reduce_staged") pulled into scratch first — where the emulator's streams keep the
+    book of what would be in flight together on hardware: all N - 1 pulls of a device, not one after the other"""
     import ctypes as C
     from wgatools_amd import build, _lib
     monkeypatch.setenv("WGA_EMU_DEVICES", "3")
     lib = _lib.load(build.build_emu())
     engs = [engine.Engine(g, lib) for g in range(3)]
     rng = np.random.default_rng(4)
-    for count in (0, 1, 7, 1000, 70001):
-        host = [rng.integers(-1000, 1000, max(count, 1), dtype=np.int32) for _ in range(3)]
-        bufs = [e.upload(h) for e, h in zip(engs, host)]
-        cx = (C.c_void_p * 3)(*[e.ctx for e in engs])
-        bp = (C.c_void_p * 3)(*[b.ptr for b in bufs])
-        assert lib.wga_reduce_scatter_i32(cx, 3, bp, count) == 0
-        total = host[0][:count].astype(np.int64) + host[1][:count] + host[2][:count]
-        for g in range(3):
-            lo, hi = count * g // 3, count * (g + 1) // 3
-            got = bufs[g].numpy()[:count]
-            assert (got[lo:hi] == total[lo:hi]).all(), (count, g)
-            mask = np.ones(count, dtype=bool)
-            mask[lo:hi] = False
-            assert (got[mask] == host[g][:count][mask]).all(), (count, g)
+    for staged in (0, 1):
+        for e in engs:
+            e.set_param("reduce_staged", staged)
+        for count in (0, 1, 7, 1000, 70001):
+            host = [rng.integers(-1000, 1000, max(count, 1), dtype=np.int32) for _ in range(3)]
+            bufs = [e.upload(h) for e, h in zip(engs, host)]
+            if count == 1000:       # a buffer that starts inside a 16-byte group: the kernel's counter-by-counter form
+                bufs[1] = engs[1].upload(np.concatenate([np.zeros(1, np.int32), host[1]]))
+                ptrs = [bufs[0].ptr, bufs[1].ptr + 4, bufs[2].ptr]
+            else:
+                ptrs = [b.ptr for b in bufs]
+            cx = (C.c_void_p * 3)(*[e.ctx for e in engs])
+            bp = (C.c_void_p * 3)(*ptrs)
+            lib.wga_emu_peer_copies_reset()
+            assert lib.wga_reduce_scatter_i32(cx, 3, bp, count) == 0
+            for e in engs:
+                e.sync()
+            if staged and count >= 7:
+                assert [lib.wga_emu_peer_copies_in_flight(g) for g in range(3)] == [2, 2, 2]
+            elif not staged:
+                assert [lib.wga_emu_peer_copies_in_flight(g) for g in range(3)] == [0, 0, 0]     # nothing is copied
+            total = host[0][:count].astype(np.int64) + host[1][:count] + host[2][:count]
+            for g in range(3):
+                lo, hi = count * g // 3, count * (g + 1) // 3
+                got = bufs[g].numpy()
+                got = got[1:count + 1] if (count == 1000 and g == 1) else got[:count]
+                assert (got[lo:hi] == total[lo:hi]).all(), (staged, count, g)
+                mask = np.ones(count, dtype=bool)
+                mask[lo:hi] = False
+                assert (got[mask] == host[g][:count][mask]).all(), (staged, count, g)
     one = (C.c_void_p * 1)(engs[0].ctx)
     b1 = (C.c_void_p * 1)(bufs[0].ptr)
     assert lib.wga_reduce_scatter_i32(one, 1, b1, 5) == 0

@@ -1225,34 +1225,39 @@ def test_bgzf_inflate(gpu):
 
 
 @pytest.mark.gpu
-def test_reduce_scatter_i32_on_hardware(monkeypatch):
-    """wga_reduce_scatter_i32 (pafcov --spread: the coverage merge of pafcov.rs:29-53 across devices) with its peer copies and
-    adds executed by the GPU: three contexts on the one device of this box (WGA_REDUCE_SCATTER_SAME_DEVICE lifts the
-    one-context-per-device rule for this test); slice g of buffer g = the sum over the contexts, the rest untouched"""
+def test_reduce_scatter_i32_on_hardware():
+    """wga_reduce_scatter_i32 (pafcov --spread: the coverage merge of pafcov.rs:29-53 across devices) executed by the GPU: three
+    contexts on the one device of this box ("reduce_same_device_ok" lifts the one-context-per-device rule for this test), the
+    peers' slices read in place by one kernel per context and, with "reduce_staged", pulled into scratch over two streams
+    first; nothing waits on the host inside the call (events order the three streams).  Slice g of buffer g = the sum over
+    the contexts, the rest untouched"""
     import ctypes as C
     import torch  # noqa: F401
     from wgatools_amd import build, _lib
-    monkeypatch.setenv("WGA_REDUCE_SCATTER_SAME_DEVICE", "1")
     lib = _lib.load(build.HIP_LIB)
     engs = [engine.Engine(0, lib) for _ in range(3)]
+    engs[0].set_param("reduce_same_device_ok", 1)
     rng = np.random.default_rng(4)
     try:
-        for count in (1, 7, 70001, 25_000_000):
-            host = [rng.integers(-1000, 1000, count, dtype=np.int32) for _ in range(3)]
-            bufs = [e.upload(h) for e, h in zip(engs, host)]
-            cx = (C.c_void_p * 3)(*[e.ctx for e in engs])
-            bp = (C.c_void_p * 3)(*[b.ptr for b in bufs])
-            assert lib.wga_reduce_scatter_i32(cx, 3, bp, count) == 0
-            total = host[0].astype(np.int64) + host[1] + host[2]
-            for g in range(3):
-                lo, hi = count * g // 3, count * (g + 1) // 3
-                got = bufs[g].numpy()[:count]
-                assert (got[lo:hi] == total[lo:hi]).all(), (count, g)
-                mask = np.ones(count, dtype=bool)
-                mask[lo:hi] = False
-                assert (got[mask] == host[g][mask]).all(), (count, g)
-            for b in bufs:
-                b.free()
+        for staged in (0, 1):
+            for e in engs:
+                e.set_param("reduce_staged", staged)
+            for count in (1, 7, 70001, 25_000_000):
+                host = [rng.integers(-1000, 1000, count, dtype=np.int32) for _ in range(3)]
+                bufs = [e.upload(h) for e, h in zip(engs, host)]
+                cx = (C.c_void_p * 3)(*[e.ctx for e in engs])
+                bp = (C.c_void_p * 3)(*[b.ptr for b in bufs])
+                assert lib.wga_reduce_scatter_i32(cx, 3, bp, count) == 0
+                total = host[0].astype(np.int64) + host[1] + host[2]
+                for g in range(3):
+                    lo, hi = count * g // 3, count * (g + 1) // 3
+                    got = bufs[g].numpy()[:count]          # a download on context g's stream: behind the call's events
+                    assert (got[lo:hi] == total[lo:hi]).all(), (staged, count, g)
+                    mask = np.ones(count, dtype=bool)
+                    mask[lo:hi] = False
+                    assert (got[mask] == host[g][mask]).all(), (staged, count, g)
+                for b in bufs:
+                    b.free()
         dup = (C.c_void_p * 2)(engs[0].ctx, engs[0].ctx)
         b2 = (C.c_void_p * 2)(None, None)
         assert lib.wga_reduce_scatter_i32(dup, 2, b2, 0) == -1

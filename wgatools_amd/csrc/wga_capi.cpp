@@ -101,8 +101,19 @@ struct wga_ctx {
   u64 cov_pieces_cap = 0;
   void* cov_tile_list = nullptr; /* pafcov: WGA_COV_TILE_CAP piece slots per tile of ops, grow-only */
   u64 cov_tile_list_cap = 0;     /* in tiles */
+  void* cov_order = nullptr;  /* pafcov: the order the marks -> counts replay takes the windows in, kept for the ranges it was made for */
+  u64 cov_order_cap = 0;
+  std::vector<u64> cov_order_key;
   void* cov_list = nullptr;   /* pafcov: the pieces beyond a tile's slots (WGA_COV_LISTS regions of cov_list_rcap) */
   u64 cov_list_rcap = 0;
+  /* wga_reduce_scatter_i32: events that order this context's stream against the other devices' (created at first use), a
+   * stream per staged pull, and what the two test switches say */
+  bool rs_have_ev = false;
+  rt_event_t rs_ready, rs_done;
+  std::vector<wga_stream_t> rs_streams;
+  std::vector<rt_event_t> rs_copied;
+  bool rs_same_device_ok = false; /* "reduce_same_device_ok": distinct contexts may share a device (one-GPU test boxes) */
+  bool rs_staged = false;         /* "reduce_staged": pull into scratch over N-1 streams instead of reading the peers in place */
   u32 cov_spin_limit = 1u << 12; /* polls of a tile sum (milliseconds of waiting where ten microseconds are the rule) before the
                                     look-back adds up the ops itself (WGA_COV_SPIN_LIMIT) */
   /* optional per-launch timing of the expand kernel proper (events on the launch stream) */
@@ -479,11 +490,15 @@ void wga_ctx_destroy(wga_ctx* c) {
   if (c->timing)
     for (int k = 0; k < 2 * wga_ctx::kTimingRing; k++) rt_event_destroy(c->ev[k]);
   if (c->tune.have_ev) rt_event_destroy(c->tune.ev[0]), rt_event_destroy(c->tune.ev[1]);
+  if (c->rs_have_ev) rt_event_destroy(c->rs_ready), rt_event_destroy(c->rs_done);
+  for (rt_event_t e : c->rs_copied) rt_event_destroy(e);
+  for (wga_stream_t st : c->rs_streams) rt_stream_destroy(st);
   if (c->scratch) (void)rt_free(c->scratch);
   if (c->elem_scan.mem) (void)rt_free(c->elem_scan.mem);
   if (c->class_tab.mem) (void)rt_free(c->class_tab.mem);
   if (c->cov_pieces) (void)rt_free(c->cov_pieces);
   if (c->cov_list) (void)rt_free(c->cov_list);
+  if (c->cov_order) (void)rt_free(c->cov_order);
   if (c->cov_tile_list) (void)rt_free(c->cov_tile_list);
   if (c->op_tab.mem) (void)rt_free(c->op_tab.mem);
   rt_stream_destroy(c->own_stream);
@@ -495,9 +510,14 @@ void wga_ctx_destroy(wga_ctx* c) {
 int wga_ctx_set_stream(wga_ctx* c, void* hip_stream) {
   int rc = ctx_bind(c);
   if (rc) return rc;
+#ifdef WGA_EMU
+  (void)hip_stream; /* a caller's stream handle means nothing to the emulator: everything runs in call order anyway */
+  return WGA_OK;
+#else
   if (c->stream != (wga_stream_t)hip_stream) RT_CHECK(rt_sync(c->stream));
   c->stream = (wga_stream_t)hip_stream;
   return WGA_OK;
+#endif
 }
 
 int wga_ctx_reset_stream(wga_ctx* c) {
@@ -512,6 +532,14 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return fail(WGA_E_INVALID_ARG, "null argument", nullptr);
   if (strcmp(name, "expand_force_slow") == 0) {
     c->expand_force_slow = value != 0;
+    return WGA_OK;
+  }
+  if (strcmp(name, "reduce_same_device_ok") == 0) { /* wga_reduce_scatter_i32 over contexts that share a device (tests) */
+    c->rs_same_device_ok = value != 0;
+    return WGA_OK;
+  }
+  if (strcmp(name, "reduce_staged") == 0) { /* wga_reduce_scatter_i32 by staged peer copies even where peer access exists */
+    c->rs_staged = value != 0;
     return WGA_OK;
   }
   if (strcmp(name, "expand_drain_min") == 0) { /* 0 = chosen by the size of the sequence pools (WGA_DRAIN_POOL_BYTES) */
@@ -800,45 +828,110 @@ int wga_reduce_scatter_i32(wga_ctx** ctxs, int ngpu, int32_t** d_bufs, uint64_t 
   if (!ctxs || !d_bufs || ngpu < 1) return fail(WGA_E_INVALID_ARG, "null argument", nullptr);
   for (int g = 0; g < ngpu; g++) {
     if (!ctxs[g] || (count && !d_bufs[g])) return fail(WGA_E_INVALID_ARG, "null context / buffer", nullptr);
-    /* WGA_REDUCE_SCATTER_SAME_DEVICE=1 (tests on a one-GPU box): distinct contexts may share a device, so that the peer
-     * copies and the adds of the N-device path run on hardware; the same context twice stays an error */
-    const bool same_ok = getenv("WGA_REDUCE_SCATTER_SAME_DEVICE") && atoi(getenv("WGA_REDUCE_SCATTER_SAME_DEVICE")) != 0;
     for (int h = 0; h < g; h++)
-      if (ctxs[h] == ctxs[g] || (!same_ok && ctxs[h]->device == ctxs[g]->device))
+      if (ctxs[h] == ctxs[g] || (!ctxs[0]->rs_same_device_ok && ctxs[h]->device == ctxs[g]->device))
         return fail(WGA_E_INVALID_ARG, "two contexts on one device", nullptr);
   }
   if (ngpu == 1 || count == 0) return WGA_OK;
   int rc;
-  for (int g = 0; g < ngpu; g++) { /* what the owners enqueued has happened */
-    if ((rc = ctx_bind(ctxs[g]))) return rc;
-    RT_CHECK(rt_sync(ctxs[g]->stream));
+  /* Nothing here waits on the host.  (1) every context records "my buffer is as my stream leaves it"; (2) device g's stream
+   * waits for the others' records and adds their slices g to its own — read where they lie, by ONE kernel that has a load
+   * per peer in flight in every thread (all of the device's xGMI links carry data at once), or, without peer access, pulled
+   * into scratch by N-1 copies on N-1 streams of their own (in flight together as well) and added by the same kernel;
+   * (3) every context's stream waits until the others have read its buffer.  Work enqueued behind the call on any of the
+   * contexts' streams sees the result. */
+  for (int g = 0; g < ngpu; g++) {
+    wga_ctx* c = ctxs[g];
+    if ((rc = ctx_bind(c))) return rc;
+    if (!c->rs_have_ev) {
+      RT_CHECK(rt_event_create(&c->rs_ready));
+      RT_CHECK(rt_event_create(&c->rs_done));
+      c->rs_have_ev = true;
+    }
+    RT_CHECK(rt_event_record(c->rs_ready, c->stream));
   }
-  /* every device pulls its slice from every other one into its scratch arena, then adds: the pulls of all devices are in
-   * flight together (point-to-point xGMI: every link carries one slice) */
+  bool direct = true;
+  for (int g = 0; g < ngpu && direct; g++) {
+    if (ctxs[g]->rs_staged) direct = false;
+    for (int h = 0; h < ngpu && direct; h++)
+      if (h != g && rt_peer_enable(ctxs[g]->device, ctxs[h]->device)) direct = false;
+  }
   for (int g = 0; g < ngpu; g++) {
     wga_ctx* c = ctxs[g];
     const u64 lo = count * (u64)g / (u64)ngpu, hi = count * (u64)(g + 1) / (u64)ngpu, n = hi - lo;
-    if (n == 0) continue;
     if ((rc = ctx_bind(c))) return rc;
-    void* ws;
-    if ((rc = ctx_scratch(c, (size_t)n * 4 * (size_t)(ngpu - 1), &ws))) return rc;
-    int k = 0;
-    for (int h = 0; h < ngpu; h++) {
-      if (h == g) continue;
-      int* tmp = (int*)ws + (size_t)k * n;
-      RT_CHECK(rt_peer_copy(tmp, c->device, d_bufs[h] + lo, ctxs[h]->device, (size_t)n * 4, c->stream));
-      const u32 grid = (u32)(n / 256u < 65536u ? (n + 255u) / 256u : 65536u);
-      WGA_LAUNCH(k_add_i32, grid, WGA_BLOCK, c->stream, (int*)d_bufs[g] + lo, (const int*)tmp, (u64)n);
-      LAUNCH_CHECK();
-      k++;
+    if (n) {
+      int* stage = nullptr;
+      if (!direct) {
+        void* ws;
+        if ((rc = ctx_scratch(c, (size_t)n * 4 * (size_t)(ngpu - 1), &ws))) return rc;
+        stage = (int*)ws;
+        while ((int)c->rs_streams.size() < ngpu - 1) {
+          wga_stream_t st;
+          rt_event_t ev;
+          RT_CHECK(rt_stream_create(&st));
+          c->rs_streams.push_back(st);
+          RT_CHECK(rt_event_create(&ev));
+          c->rs_copied.push_back(ev);
+        }
+      }
+      const u32 grid = (u32)(n / 1024u < 16384u ? (n + 1023u) / 1024u : 16384u);
+      int k = 0;
+      wga_peer_srcs srcs;
+      int n_src = 0;
+      auto add = [&]() {
+        WGA_LAUNCH(k_add_peers_i32, grid, WGA_BLOCK, c->stream, (int*)d_bufs[g] + lo, srcs, n_src, (u64)n);
+        n_src = 0;
+      };
+      for (int h = 0; h < ngpu; h++) {
+        if (h == g) continue;
+        if (direct) {
+          RT_CHECK(rt_stream_wait_event(c->stream, ctxs[h]->rs_ready));
+          srcs.p[n_src++] = (const int*)d_bufs[h] + lo;
+        } else { /* the scratch is this stream's: the pull starts behind what the stream had in flight, on a stream of its own */
+          wga_stream_t st = c->rs_streams[k];
+          RT_CHECK(rt_stream_wait_event(st, c->rs_ready));
+          RT_CHECK(rt_stream_wait_event(st, ctxs[h]->rs_ready));
+          RT_CHECK(rt_peer_copy(stage + (size_t)k * n, c->device, d_bufs[h] + lo, ctxs[h]->device, (size_t)n * 4, st));
+          RT_CHECK(rt_event_record(c->rs_copied[k], st));
+          srcs.p[n_src++] = stage + (size_t)k * n;
+        }
+        k++;
+        if (n_src == WGA_PEER_MAX && direct) { /* more peers than one launch takes (never on one node) */
+          add();
+          LAUNCH_CHECK();
+        }
+      }
+      if (!direct) {
+        /* every pull has been enqueued — they run side by side — and only now does the adding stream wait for them */
+        for (int j = 0; j < k; j++) RT_CHECK(rt_stream_wait_event(c->stream, c->rs_copied[j]));
+        for (int j0 = 0; j0 < k; j0 += WGA_PEER_MAX) {
+          n_src = 0;
+          for (int j = j0; j < k && j < j0 + WGA_PEER_MAX; j++) srcs.p[n_src++] = stage + (size_t)j * n;
+          add();
+          LAUNCH_CHECK();
+        }
+      } else if (n_src) {
+        add();
+        LAUNCH_CHECK();
+      }
     }
+    RT_CHECK(rt_event_record(c->rs_done, c->stream));
   }
-  for (int g = 0; g < ngpu; g++) {
-    if ((rc = ctx_bind(ctxs[g]))) return rc;
-    RT_CHECK(rt_sync(ctxs[g]->stream));
+  for (int h = 0; h < ngpu; h++) {
+    if ((rc = ctx_bind(ctxs[h]))) return rc;
+    for (int g = 0; g < ngpu; g++)
+      if (g != h) RT_CHECK(rt_stream_wait_event(ctxs[h]->stream, ctxs[g]->rs_done));
   }
   return WGA_OK;
 }
+
+#ifdef WGA_EMU
+/* test hook of the emulator build only (not part of the ABI): the most peer copies that were outstanding towards `device` at
+ * one time, as the emulator's streams keep the book (wga_rt.h) */
+int wga_emu_peer_copies_in_flight(int device) { return emu_book().most[device & 63]; }
+void wga_emu_peer_copies_reset(void) { emu_book() = emu_peer_book(); }
+#endif
 
 int wga_exclusive_scan_u64(wga_ctx* c, uint32_t n, const uint64_t* d_in, uint64_t* d_out) {
   int rc = ctx_bind(c);
@@ -1647,6 +1740,47 @@ static int cov_ranges(wga_ctx* c, u32 n_targets, const u64* d_cov_off, const u64
   return WGA_OK;
 }
 
+/* The order in which the marks -> counts replay takes the windows (k_cov_windows<true>): by depth inside their range's chain
+ * of windows, chains side by side.  A window whose first counter lies strictly inside a range needs what the window in front
+ * hands on and stands one deeper than it; every other window starts a chain.  Kept in the context for the ranges it was made
+ * for (a caller's targets do not change between calls). */
+static int cov_window_order(wga_ctx* c, const std::vector<u64>& lo_hi, u32 n_rng, u64 nw) {
+  std::vector<u64> key(lo_hi);
+  key.push_back(nw);
+  if (c->cov_order && key == c->cov_order_key) return WGA_OK;
+  std::vector<u32> depth((size_t)nw), order((size_t)nw);
+  std::vector<u32> cnt;
+  u32 t = 0;
+  for (u64 w = 0; w < nw; w++) {
+    const u64 w0 = w << WGA_COV_WIN_SHIFT;
+    while (t < n_rng && lo_hi[(size_t)n_rng + t] <= w0) t++; /* ranges that end at or in front of w0 */
+    const bool inside = t < n_rng && lo_hi[t] < w0;          /* lo < w0 < hi */
+    const u32 d = (inside && w) ? depth[(size_t)w - 1] + 1u : 0u;
+    depth[(size_t)w] = d;
+    if (d >= cnt.size()) cnt.resize((size_t)d + 1, 0u);
+    cnt[d]++;
+  }
+  u32 run = 0;
+  for (u32& x : cnt) {
+    const u32 k = x;
+    x = run;
+    run += k;
+  }
+  for (u64 w = 0; w < nw; w++) order[cnt[depth[(size_t)w]]++] = (u32)w;
+  if (c->cov_order_cap < nw) {
+    if (c->cov_order) RT_CHECK(rt_free(c->cov_order));
+    c->cov_order = nullptr;
+    c->cov_order_cap = 0;
+    RT_CHECK(rt_malloc(&c->cov_order, (size_t)nw * 4));
+    c->cov_order_cap = nw;
+  }
+  c->cov_order_key.clear();
+  RT_CHECK(rt_h2d(c->cov_order, order.data(), (size_t)nw * 4, c->stream));
+  RT_CHECK(rt_sync(c->stream)); /* `order` is a host buffer of this call */
+  c->cov_order_key.swap(key);
+  return WGA_OK;
+}
+
 /* accumulate (b != nullptr) and / or finalize (n_targets counter ranges): one replay over the windows does both */
 static int pafcov_run(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_target_id, const uint64_t* d_t_start,
                       const uint64_t* d_cov_off, const uint64_t* d_cov_len, int32_t* d_cov, uint64_t total_cov, bool final,
@@ -1689,6 +1823,7 @@ static int pafcov_run(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_ta
   u64* rng_lo = (u64*)((char*)win_state + b_state);
   u64* rng_hi = rng_lo + n_rng;
   if (final) {
+    if ((rc = cov_window_order(c, lo_hi, n_rng, nw))) return rc;
     RT_CHECK(rt_memset(win_state, 0, b_state, c->stream));
     if (n_rng) RT_CHECK(rt_h2d(rng_lo, lo_hi.data(), b_rng, c->stream));
     RT_CHECK(rt_sync(c->stream)); /* lo_hi is a host buffer of this call */
@@ -1780,11 +1915,16 @@ static int pafcov_run(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_ta
   const u64* woff = n_pieces ? (const u64*)win_off : nullptr;
   if (final) {
     WGA_LAUNCH(k_cov_windows<true>, (u32)nw, WGA_COV_BLOCK, c->stream, d_ops, n_ops, (const wga_cov_piece*)c->cov_pieces, woff,
-               (int*)d_cov, (u64)n_cov, (const u64*)rng_lo, (const u64*)rng_hi, n_rng, win_state);
+               (int*)d_cov, (u64)n_cov, (const u64*)rng_lo, (const u64*)rng_hi, n_rng, win_state,
+#ifdef WGA_COV_NO_ORDER /* A/B builds: the windows in index order */
+               (const u32*)nullptr);
+#else
+               (const u32*)c->cov_order);
+#endif
     LAUNCH_CHECK();
   } else if (n_pieces) {
     WGA_LAUNCH(k_cov_windows<false>, (u32)nw, WGA_COV_BLOCK, c->stream, d_ops, n_ops, (const wga_cov_piece*)c->cov_pieces, woff,
-               (int*)d_cov, (u64)n_cov, (const u64*)nullptr, (const u64*)nullptr, 0u, (u64*)nullptr);
+               (int*)d_cov, (u64)n_cov, (const u64*)nullptr, (const u64*)nullptr, 0u, (u64*)nullptr, (const u32*)nullptr);
     LAUNCH_CHECK();
   }
   return WGA_OK;

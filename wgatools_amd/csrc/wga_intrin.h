@@ -130,6 +130,8 @@ __device__ __forceinline__ u32 wave_get_u32(u32 v, int k) { return (u32)__builti
 /* v_readlane with a wave-uniform lane index */
 __device__ __forceinline__ u32 wave_get_u32_dyn(u32 v, u32 k) { return (u32)__builtin_amdgcn_readlane((int)v, (int)k); }
 #define WGA_CLOCK() ((u64)__builtin_amdgcn_s_memtime())
+/* a polling wave steps aside for 64 * n cycles (n a constant below 128): its loads do not crowd the ones it waits for */
+#define WGA_SLEEP(n) __builtin_amdgcn_s_sleep(n)
 /* lanes of a wave exchange data through LDS: hardware runs them in lockstep, only the compiler must not reorder */
 #define WGA_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 

@@ -72,6 +72,8 @@ typedef u32 u32x4_a16 __attribute__((vector_size(16), aligned(16)));
  * the same as aligned ones, unaligned stores ~10 % slower: scripts/micro/unaligned_copy.hip) */
 typedef u32 u32x4_a1 __attribute__((vector_size(16), aligned(1)));
 
+#include <type_traits>
+
 #include "wga_intrin.h" /* the gfx950 instructions the kernels are written with (cross-lane, buffer, uniformity) */
 
 __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
@@ -82,6 +84,9 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
 
 #ifndef WGA_K1_BLOCKS
 #define WGA_K1_BLOCKS 5 /* blocks per CU the register budget of k_cigar_stat is sized for: 94 VGPRs, no scratch.  6 (80 VGPRs + 12 B of scratch) measured 0.56 ms on one box and 0.70 ms on two others against 0.54-0.57 ms for 5 */
+#endif
+#ifndef WGA_K1_WHOLE_TILE_PATH
+#define WGA_K1_WHOLE_TILE_PATH 0 /* 1: a second copy of the class-sum loop without the range test for segments that are the whole tile (3 of 24 instructions per op less, 8 registers spilled) */
 #endif
 #ifndef WGA_K1_LANE_STORE
 #define WGA_K1_LANE_STORE 1 /* K1 writes its counters one field per lane (v_writelane) instead of from lane 0 */
@@ -197,22 +202,23 @@ __global__ __launch_bounds__(256, WGA_K1_BLOCKS) void k_cigar_stat(const u32* __
   const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
   const u32 nt = (u32)(tile_end - tile_start);
 
-  /* 16 ops per lane: op (j*64+lane)*4+e — each of the 4 loads is a fully coalesced 1 KiB */
+  /* 16 ops per lane: op (j*64+lane)*4+e — each of the 4 loads is a fully coalesced 1 KiB.  A 16-byte group is loaded when it
+   * starts in front of the stream's end (it may reach up to 12 bytes beyond it, inside the same aligned 16 bytes); what it
+   * brings from there becomes 0M, as everything behind the tile's last op */
   u32 w[16];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    u32 base = ((u32)j * 64u + lane) * 4u;
-    if (base + 3 < nt) {
-      u32x4_a16 v = *(const u32x4_a16*)(ops + tile_start + base);
-      w[4 * j + 0] = v[0];
-      w[4 * j + 1] = v[1];
-      w[4 * j + 2] = v[2];
-      w[4 * j + 3] = v[3];
-    } else {
+    const u32 base = ((u32)j * 64u + lane) * 4u;
+    u32x4_a16 v = {0u, 0u, 0u, 0u};
+    if (base < nt) v = *(const u32x4_a16*)(ops + tile_start + base);
+    w[4 * j + 0] = v[0];
+    w[4 * j + 1] = v[1];
+    w[4 * j + 2] = v[2];
+    w[4 * j + 3] = v[3];
+  }
+  if (nt & 3u) { /* wave-uniform: only the stream's last tile */
 #pragma unroll
-      for (int e = 0; e < 4; e++)
-        w[4 * j + e] = (base + e < nt) ? ops[tile_start + base + e] : 0u; /* 0M: neutral */
-    }
+    for (int k = 0; k < 16; k++) w[k] = ((u32)(k >> 2) * 256u + (u32)(k & 3) + lane * 4u < nt) ? w[k] : 0u;
   }
 
   /* the first segment's record, bounds and strand arrive with the ops (k_tile_rec); later
@@ -244,20 +250,31 @@ __global__ __launch_bounds__(256, WGA_K1_BLOCKS) void k_cigar_stat(const u32* __
     u32 ev = 0;   /* ins events | del events << 16 */
     u32 bad = 0xFFFFFFFFu;
     u32 rare = 0;
+    /* a class sum is `len & mask`, the mask one v_bfe_i32 of a 16-bit constant by the op's code (bit c set: code c belongs
+     * to the class) — 21 vector instructions per op where compares and selects on a class number took 45; a segment that is
+     * the whole tile (wave-uniform) needs no range test either */
+    constexpr u32 MX_BITS = 0x0181u, I_BITS = 0x0202u, D_BITS = 0x0404u, X_BITS = 0x0100u, RARE_BITS = 0xF878u;
+    auto class_sums = [&](auto ranged) { /* ranged: ops outside [a, b) count as 0M */
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const u32 idx = (u32)(k >> 2) * 256u + (u32)(k & 3) + lane4;
-      const u32 op = (idx - a < span) ? w[k] : 0u;
-      const u32 code = op & 15u, len = op >> 4;
-      const u32 cls = op_class(code);
-      s_mx += cls == CLS_MX ? len : 0u;
-      s_i += cls == CLS_I ? len : 0u;
-      s_d += cls == CLS_D ? len : 0u;
-      s_x += code == WGA_OP_X ? len : 0u;
-      ev += code == WGA_OP_I ? 1u : 0u;
-      ev += code == WGA_OP_D ? 0x10000u : 0u;
-      rare |= cls >= CLS_S ? 1u : 0u;
-    }
+      for (int k = 0; k < 16; k++) {
+        const u32 idx = (u32)(k >> 2) * 256u + (u32)(k & 3) + lane4;
+        const u32 op = (!decltype(ranged)::value || idx - a < span) ? w[k] : 0u;
+        const u32 code = op & 15u, len = op >> 4;
+        s_mx += len & bit_mask(MX_BITS, code);
+        s_i += len & bit_mask(I_BITS, code);
+        s_d += len & bit_mask(D_BITS, code);
+        s_x += len & bit_mask(X_BITS, code);
+        ev -= bit_mask(0x2u, code);            /* an I (not the rest of a split one): +1 */
+        ev += bit_mask(0x4u, code) & 0x10000u; /* a D */
+        rare |= bit_mask(RARE_BITS, code);
+      }
+    };
+#if WGA_K1_WHOLE_TILE_PATH
+    if (a == 0u && b == nt) /* wave-uniform */
+      class_sums(std::false_type());
+    else
+#endif
+      class_sums(std::true_type());
     const bool any_rare = __ballot(rare != 0u) != 0ull;
     if (any_rare) {
 #pragma unroll
@@ -1693,10 +1710,39 @@ __global__ __launch_bounds__(256) void k_arena_probe_fill(u32x4_a16* buf, u64 n 
   }
 }
 
-/* ---- wga_reduce_scatter_i32: a += b over n counters (16 B per thread where the pointers allow it) ------------------------ */
-__global__ __launch_bounds__(256) void k_add_i32(int* __restrict__ a, const int* __restrict__ b, u64 n) {
-  const u64 stride = (u64)gridDim.x * 256u;
-  for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) a[i] += b[i];
+/* ---- wga_reduce_scatter_i32: dst[i] += the sum of src[k][i] over up to WGA_PEER_MAX source arrays (n counters) ----------------
+ * The sources are the other devices' buffers, read where they lie (peer access over xGMI: one load per source and thread in
+ * flight, so a device's links all carry data at the same time) or, staged, copies of them in this device's scratch.  16 bytes
+ * per thread and source where the pointers share their alignment; a grid-stride loop. */
+#define WGA_PEER_MAX 15
+struct wga_peer_srcs {
+  const int* p[WGA_PEER_MAX];
+};
+__global__ __launch_bounds__(256) void k_add_peers_i32(int* __restrict__ dst, wga_peer_srcs srcs, int n_src, u64 n) {
+  const u64 tid = (u64)blockIdx.x * 256u + threadIdx.x, stride = (u64)gridDim.x * 256u;
+  bool together = true; /* dst and every source at the same offset inside their 16-byte groups */
+  for (int k = 0; k < n_src; k++) together = together && ((((u64)srcs.p[k]) ^ (u64)dst) & 15ull) == 0ull;
+  u64 head = together ? ((16ull - ((u64)dst & 15ull)) & 15ull) >> 2 : n; /* counters in front of the first whole group */
+  if (head > n) head = n;
+  const u64 groups = (n - head) >> 2, tail0 = head + (groups << 2);
+  for (u64 q = tid; q < groups; q += stride) {
+    const u64 i = head + (q << 2);
+    u32x4_a16 acc = *(const u32x4_a16*)(dst + i);
+    u32x4_a16 v[WGA_PEER_MAX];
+#pragma unroll
+    for (int k = 0; k < WGA_PEER_MAX; k++)
+      if (k < n_src) v[k] = *(const u32x4_a16*)(srcs.p[k] + i); /* all of them requested before the first is added */
+#pragma unroll
+    for (int k = 0; k < WGA_PEER_MAX; k++)
+      if (k < n_src) acc += v[k];
+    *(u32x4_a16*)(dst + i) = acc;
+  }
+  for (u64 i = tid; i < n - (groups << 2); i += stride) { /* the counters outside whole groups */
+    const u64 j = i < head ? i : tail0 + (i - head);
+    int acc = dst[j];
+    for (int k = 0; k < n_src; k++) acc += srcs.p[k][j];
+    dst[j] = acc;
+  }
 }
 
 #endif /* WGA_KERNELS_H */

@@ -627,12 +627,13 @@ __device__ __forceinline__ u32 cov_windows_in_front(u64* win_state, u64 wi, u32 
     const u64 k = wi - 1 - back - lane;
     u64 v = 0;
     u64 pref;
-    for (;;) {
+    for (u32 polls = 0;; polls++) {
       if (mine && (v >> 62) == 0ull) v = atomicAdd((unsigned long long*)&win_state[k], 0ull);
       pref = __ballot(mine && (v >> 62) == 2ull);
       const u64 empty = __ballot(mine && (v >> 62) == 0ull);
       const u64 front = pref ? ((pref & (0ull - pref)) - 1ull) : ~0ull; /* the lanes nearer than the nearest prefix */
       if (!(empty & front)) break;
+      if (polls) WGA_SLEEP(8); /* the windows waited for are still replaying: do not crowd their loads */
     }
     const u32 first = pref ? (u32)__ffsll((unsigned long long)pref) - 1u : 64u;
     acc += wave_sum_u32((mine && lane <= first) ? (u32)v : 0u);
@@ -645,14 +646,18 @@ __global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __r
                                                                const wga_cov_piece* __restrict__ pieces,
                                                                const u64* __restrict__ win_off, int* cov, u64 n_cov,
                                                                const u64* __restrict__ rng_lo, const u64* __restrict__ rng_hi,
-                                                               u32 n_rng, u64* win_state) {
+                                                               u32 n_rng, u64* win_state, const u32* __restrict__ order) {
   __shared__ int s_win[WGA_COV_WIN];
   __shared__ u32 s_ws[WGA_COV_WAVES + 1];
   __shared__ u32 s_wf[WGA_COV_WAVES];
   constexpr int D = WGA_COV_AHEAD;
   constexpr u32 PER = WGA_COV_WIN / WGA_COV_BLOCK;
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = WGA_WAVE_ID(tid);
-  const u64 wi = blockIdx.x;
+  /* FINAL: the blocks take the windows in `order` — the windows that start a range (or lie outside every range) first, then every
+   * range's second window, third ... — so that the ~1 000 windows in flight at one time are a few consecutive ones of MANY
+   * ranges instead of a thousand consecutive ones of one: a window only waits for the windows of its own range in front of it,
+   * and those were dispatched long before (the host builds the order; the window a block waits for always has a lower rank) */
+  const u64 wi = (FINAL && order) ? (u64)order[blockIdx.x] : (u64)blockIdx.x;
   const u64 p_lo = win_off ? win_off[wi] : 0ull, p_hi = win_off ? win_off[wi + 1] : 0ull;
   if (!FINAL && p_lo == p_hi) return; /* block-uniform */
   const u64 w0 = wi << WGA_COV_WIN_SHIFT;

@@ -14,9 +14,31 @@
 #include <string.h>
 
 #include "simt_emu.h"
-typedef void* wga_stream_t;
-#define WGA_LAUNCH(kernel, grid, block, stream, ...) \
-  emu::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
+/* A stream of the emulator runs everything at once, in call order; it only keeps the book that lets a test ask what WOULD be in
+ * flight together on hardware: a peer copy stays "outstanding" on its stream until that stream gets its next piece of work,
+ * is synchronised, or an event recorded behind the copy is waited for (rt_peer_stats). */
+struct emu_stream {
+  int pending_dst = -1; /* device an outstanding peer copy writes to */
+};
+typedef emu_stream* wga_stream_t;
+struct emu_peer_book {
+  int outstanding[64] = {0}, most[64] = {0};
+};
+static inline emu_peer_book& emu_book() {
+  static emu_peer_book b;
+  return b;
+}
+static inline void emu_stream_retire(wga_stream_t s) {
+  if (s && s->pending_dst >= 0) {
+    emu_book().outstanding[s->pending_dst & 63]--;
+    s->pending_dst = -1;
+  }
+}
+#define WGA_LAUNCH(kernel, grid, block, stream, ...)                         \
+  do {                                                                       \
+    emu_stream_retire(stream);                                               \
+    emu::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); });    \
+  } while (0)
 /* WGA_EMU_DEVICES=N: the emulator reports N devices (contexts are independent host-memory arenas), so that the CPU
  * test-suite can drive the host layer's multi-device paths (`wgatools --gpus N`) */
 static inline int rt_device_count() {
@@ -26,11 +48,17 @@ static inline int rt_device_count() {
 }
 static inline const char* rt_set_device(int) { return nullptr; }
 static inline const char* rt_stream_create(wga_stream_t* s) {
-  *s = nullptr;
+  *s = new emu_stream();
   return nullptr;
 }
-static inline void rt_stream_destroy(wga_stream_t) {}
-static inline const char* rt_sync(wga_stream_t) { return nullptr; }
+static inline void rt_stream_destroy(wga_stream_t s) {
+  emu_stream_retire(s);
+  delete s;
+}
+static inline const char* rt_sync(wga_stream_t s) {
+  emu_stream_retire(s);
+  return nullptr;
+}
 static inline const char* rt_malloc(void** p, size_t n) {
   *p = malloc(n + 16); /* a kernel may load the aligned 16-byte group that holds an array's last element */
   return *p ? nullptr : "malloc failed";
@@ -39,15 +67,18 @@ static inline const char* rt_free(void* p) {
   free(p);
   return nullptr;
 }
-static inline const char* rt_h2d(void* d, const void* h, size_t n, wga_stream_t) {
+static inline const char* rt_h2d(void* d, const void* h, size_t n, wga_stream_t s) {
+  emu_stream_retire(s);
   memcpy(d, h, n);
   return nullptr;
 }
-static inline const char* rt_d2h(void* h, const void* d, size_t n, wga_stream_t) {
+static inline const char* rt_d2h(void* h, const void* d, size_t n, wga_stream_t s) {
+  emu_stream_retire(s);
   memcpy(h, d, n);
   return nullptr;
 }
-static inline const char* rt_memset(void* d, int v, size_t n, wga_stream_t) {
+static inline const char* rt_memset(void* d, int v, size_t n, wga_stream_t s) {
+  emu_stream_retire(s);
   memset(d, v, n);
   return nullptr;
 }
@@ -59,22 +90,40 @@ static inline const char* rt_host_free(void* p) {
   free(p);
   return nullptr;
 }
-static inline const char* rt_d2h_async(void* h, const void* d, size_t n, wga_stream_t) {
+static inline const char* rt_d2h_async(void* h, const void* d, size_t n, wga_stream_t s) {
+  emu_stream_retire(s);
   memcpy(h, d, n);
   return nullptr;
 }
-static inline const char* rt_peer_copy(void* dst, int, const void* src, int, size_t n, wga_stream_t) {
+static inline const char* rt_peer_copy(void* dst, int dst_dev, const void* src, int, size_t n, wga_stream_t s) {
+  emu_stream_retire(s); /* a stream runs its copies one after the other */
   memcpy(dst, src, n);
+  if (s) {
+    emu_peer_book& b = emu_book();
+    s->pending_dst = dst_dev & 63;
+    if (++b.outstanding[dst_dev & 63] > b.most[dst_dev & 63]) b.most[dst_dev & 63] = b.outstanding[dst_dev & 63];
+  }
   return nullptr;
 }
+static inline const char* rt_peer_enable(int, int) { return nullptr; } /* every "device" of the emulator is host memory */
 static inline const char* rt_launch_error() { return nullptr; }
-typedef int rt_event_t;
+struct emu_event {
+  wga_stream_t on = nullptr;
+};
+typedef emu_event* rt_event_t;
 static inline const char* rt_event_create(rt_event_t* e) {
-  *e = 0;
+  *e = new emu_event();
   return nullptr;
 }
-static inline void rt_event_destroy(rt_event_t) {}
-static inline const char* rt_event_record(rt_event_t, wga_stream_t) { return nullptr; }
+static inline void rt_event_destroy(rt_event_t e) { delete e; }
+static inline const char* rt_event_record(rt_event_t e, wga_stream_t s) {
+  e->on = s;
+  return nullptr;
+}
+static inline const char* rt_stream_wait_event(wga_stream_t, rt_event_t e) {
+  emu_stream_retire(e->on); /* what was enqueued in front of the event has happened */
+  return nullptr;
+}
 static inline const char* rt_event_elapsed_ms(rt_event_t, rt_event_t, float* ms) {
   *ms = 0.0f;
   return nullptr;
@@ -117,11 +166,27 @@ static inline const char* rt_d2h_async(void* h, const void* d, size_t n, wga_str
 static inline const char* rt_peer_copy(void* dst, int dst_dev, const void* src, int src_dev, size_t n, wga_stream_t s) {
   return rt_err(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, n, s));
 }
+/* device `dev` may read `peer`'s memory from its kernels (xGMI); nullptr when it can (already enabled counts), else why not */
+static inline const char* rt_peer_enable(int dev, int peer) {
+  if (dev == peer) return nullptr;
+  int can = 0;
+  hipError_t e = hipDeviceCanAccessPeer(&can, dev, peer);
+  if (e != hipSuccess) return hipGetErrorString(e);
+  if (!can) return "no peer access between the two devices";
+  if ((e = hipSetDevice(dev)) != hipSuccess) return hipGetErrorString(e);
+  e = hipDeviceEnablePeerAccess(peer, 0);
+  if (e == hipErrorPeerAccessAlreadyEnabled) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return rt_err(e);
+}
 static inline const char* rt_launch_error() { return rt_err(hipGetLastError()); }
 typedef hipEvent_t rt_event_t;
 static inline const char* rt_event_create(rt_event_t* e) { return rt_err(hipEventCreate(e)); }
 static inline void rt_event_destroy(rt_event_t e) { (void)hipEventDestroy(e); }
 static inline const char* rt_event_record(rt_event_t e, wga_stream_t s) { return rt_err(hipEventRecord(e, s)); }
+static inline const char* rt_stream_wait_event(wga_stream_t s, rt_event_t e) { return rt_err(hipStreamWaitEvent(s, e, 0)); }
 static inline const char* rt_event_elapsed_ms(rt_event_t a, rt_event_t b, float* ms) {
   hipError_t r = hipEventSynchronize(b);
   if (r != hipSuccess) return hipGetErrorString(r);
