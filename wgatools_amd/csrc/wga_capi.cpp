@@ -101,6 +101,8 @@ struct wga_ctx {
   u64 cov_pieces_cap = 0;
   void* cov_tile_list = nullptr; /* pafcov: WGA_COV_TILE_CAP piece slots per tile of ops, grow-only */
   u64 cov_tile_list_cap = 0;     /* in tiles */
+  unsigned stat_resident = 0;     /* K1: blocks the device keeps resident (asked once) */
+  unsigned cov_list_resident = 0; /* pafcov: blocks of the list pass the device keeps resident (asked once) */
   void* cov_order = nullptr;  /* pafcov: the order the marks -> counts replay takes the windows in, kept for the ranges it was made for */
   u64 cov_order_cap = 0;
   std::vector<u64> cov_order_key;
@@ -114,7 +116,11 @@ struct wga_ctx {
   std::vector<rt_event_t> rs_copied;
   bool rs_same_device_ok = false; /* "reduce_same_device_ok": distinct contexts may share a device (one-GPU test boxes) */
   bool rs_staged = false;         /* "reduce_staged": pull into scratch over N-1 streams instead of reading the peers in place */
-  u32 cov_spin_limit = 1u << 12; /* polls of a tile sum (milliseconds of waiting where ten microseconds are the rule) before the
+#ifdef WGA_EMU
+  u32 cov_spin_limit = 64; /* the emulator runs one block at a time: a tile that is not there yet will not come while this one polls */
+#else
+  u32 cov_spin_limit = 1u << 12;
+#endif /* polls of a tile sum (milliseconds of waiting where ten microseconds are the rule) before the
                                     look-back adds up the ops itself (WGA_COV_SPIN_LIMIT) */
   /* optional per-launch timing of the expand kernel proper (events on the launch stream) */
   static const int kTimingRing = 64;
@@ -148,12 +154,15 @@ static int ctx_bind(wga_ctx* c) {
 
 /* grow-only scratch arena on the context (scan partials etc.) */
 static int ctx_scratch(wga_ctx* c, size_t bytes, void** out) {
+  /* whoever takes the scratch may overwrite the two counters the last row-kernel launch left in it: "expand_stream_left_to_v1"
+   * and "pseudo_stream_left_to_blocks" then answer "not known" instead of reading someone else's bytes (the launches that own
+   * the counters set the pointers again behind this call) */
+  c->stream_counts = nullptr;
+  c->pseudo_counts = nullptr;
   if (c->scratch_cap < bytes) {
     RT_CHECK(rt_sync(c->stream));
     if (c->scratch) RT_CHECK(rt_free(c->scratch));
     c->scratch = nullptr;
-    c->stream_counts = nullptr;
-    c->pseudo_counts = nullptr;
     c->scratch_cap = 0;
     size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 2;
     RT_CHECK(rt_malloc(&c->scratch, cap));
@@ -714,16 +723,19 @@ int wga_arena_probe(wga_ctx* c, void* d_buf, size_t bytes, int kind, double* gbp
  * then computes its own.  [lo, lo + bytes) is the range written (bytes == 0: the allocation that starts at lo). */
 static void ctx_arrays_written(wga_ctx* c, const void* lo, size_t bytes) {
   const uintptr_t a = (uintptr_t)lo, z = a + (bytes ? bytes : 1);
+  /* an array whose extent the key holds (the packed ops, the CSR offsets) is hit by a write anywhere inside it — an upload at an
+   * offset, a rewritten tail —, the others (per-record arrays of an entry point's own layout) by a write that covers their start */
   auto in = [&](const void* q) { return q && (uintptr_t)q >= a && (uintptr_t)q < z; };
+  auto hits = [&](const void* q, size_t extent) { return q && (uintptr_t)q < z && (uintptr_t)q + (extent ? extent : 1) > a; };
   const wga_ctx::OpTabKey& k = c->op_tab.key;
-  if (in(k.ops) || in(k.op_off) || in(k.x0) || in(k.x1) || in(k.x2)) c->op_tab.valid = false;
+  if (hits(k.ops, (size_t)k.n_ops * 4) || hits(k.op_off, ((size_t)k.n + 1) * 8) || in(k.x0) || in(k.x1) || in(k.x2)) c->op_tab.valid = false;
   wga_ctx::ElemScan& es = c->elem_scan;
   const void* src[sizeof(es.src) / sizeof(void*)];
   memcpy(src, es.src, sizeof(es.src));
   for (const void* q : src)
     if (in(q)) es.valid = false;
-  if (in(es.elem_off)) es.valid = false;
-  if (in(c->class_tab.ops) || in(c->class_tab.op_off)) c->class_tab.valid = false;
+  if (hits(es.elem_off, ((size_t)es.n + 1) * 8)) es.valid = false;
+  if (hits(c->class_tab.ops, (size_t)c->class_tab.n_ops * 4) || hits(c->class_tab.op_off, ((size_t)c->class_tab.n + 1) * 8)) c->class_tab.valid = false;
 }
 
 int wga_free(wga_ctx* c, void* d_ptr) {
@@ -816,7 +828,9 @@ int wga_cigar_stat(wga_ctx* c, const wga_cigar_batch* b, wga_cigar_counts* d_cou
   WGA_LAUNCH(k_tile_rec, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const u64*)b->d_op_off,
              b->d_strand_neg, b->n, (u64)b->n_ops, tile_rec);
   LAUNCH_CHECK();
-  u32 grid = (u32)((nt + 3) / 4);
+  /* a grid of resident waves, each taking every W-th tile (k_cigar_stat) */
+  if (!c->stat_resident) c->stat_resident = rt_resident_blocks(k_cigar_stat, c->device, WGA_BLOCK);
+  const u32 grid = (u32)std::min<u64>((nt + 3) / 4, (u64)c->stat_resident);
   WGA_LAUNCH(k_cigar_stat, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off,
              b->d_strand_neg, b->n, (u64)b->n_ops, (const wga_tile_rec*)tile_rec, d_counts, d_diag,
              (wga_tile_sum*)d_tile_ws);
@@ -1172,7 +1186,7 @@ int wga_ctx_get_param(wga_ctx* c, const char* name, int64_t* value) {
     return WGA_OK;
   }
   if (strcmp(name, "expand_stream_left_to_v1") == 0) { /* tiles the streaming kernel's last launch left to v1 (a device read: diagnostics) */
-    *value = 0;
+    *value = c->expand_variant_used == 3 ? -1 : 0; /* -1: the scratch that held the counters has been handed on */
     if (c->expand_variant_used == 3 && c->stream_counts) {
       u32 h[2] = {0, 0};
       int rc = ctx_bind(c);
@@ -1191,7 +1205,7 @@ int wga_ctx_get_param(wga_ctx* c, const char* name, int64_t* value) {
     return WGA_OK;
   }
   if (strcmp(name, "pseudo_stream_left_to_blocks") == 0) { /* tiles the last base-mode wga_pafpseudo_fill left to the block kernel */
-    *value = 0;
+    *value = -1; /* not known (no such launch yet, or the scratch that held the counters has been handed on) */
     if (c->pseudo_counts) {
       u32 h[2] = {0, 0};
       int rc = ctx_bind(c);
@@ -1830,7 +1844,9 @@ static int pafcov_run(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_ta
   }
   u64 n_pieces = 0;
   if (has_ops) {
-    const u32 grid = (u32)((nt + 3) / 4);
+    /* the list pass runs on a grid of resident waves (k_cov_list_pieces): what the runtime says fits, or fewer for a small batch */
+    if (!c->cov_list_resident) c->cov_list_resident = rt_resident_blocks(k_cov_list_pieces, c->device, WGA_BLOCK);
+    const u32 grid = (u32)std::min<u64>((nt + 3) / 4, (u64)c->cov_list_resident);
     if (c->cov_tile_list_cap < nt) {
       if (c->cov_tile_list) RT_CHECK(rt_free(c->cov_tile_list));
       c->cov_tile_list = nullptr;

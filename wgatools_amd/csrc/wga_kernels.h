@@ -188,38 +188,13 @@ __global__ __launch_bounds__(256) void k_tile_rec(const u64* __restrict__ op_off
   tile_rec[g] = t;
 }
 
-__global__ __launch_bounds__(256, WGA_K1_BLOCKS) void k_cigar_stat(const u32* __restrict__ ops,
-                                                    const u64* __restrict__ op_off,
-                                                    const u8* __restrict__ strand_neg, u32 n,
-                                                    u64 n_ops, const wga_tile_rec* __restrict__ tile_rec,
-                                                    wga_cigar_counts* counts,
-                                                    wga_rec_diag* diag, wga_tile_sum* tiles) {
-  const u32 lane = threadIdx.x & 63u;
-  const u32 wave = WGA_WAVE_ID(threadIdx.x);
-  const u64 g = (u64)blockIdx.x * 4 + wave;
+/* one tile of the stat walk; w = the tile's packed ops, 16 per lane: op (j*64+lane)*4+e */
+__device__ __forceinline__ void cigar_stat_tile(const u64 g, const u32 (&w)[16], const u32 lane, const u64* __restrict__ op_off,
+                                                const u8* __restrict__ strand_neg, u64 n_ops,
+                                                const wga_tile_rec* __restrict__ tile_rec, wga_cigar_counts* counts,
+                                                wga_rec_diag* diag, wga_tile_sum* tiles) {
   const u64 tile_start = g * WGA_TILE;
-  if (tile_start >= n_ops) return; /* wave-uniform; this kernel has no block barrier */
   const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
-  const u32 nt = (u32)(tile_end - tile_start);
-
-  /* 16 ops per lane: op (j*64+lane)*4+e — each of the 4 loads is a fully coalesced 1 KiB.  A 16-byte group is loaded when it
-   * starts in front of the stream's end (it may reach up to 12 bytes beyond it, inside the same aligned 16 bytes); what it
-   * brings from there becomes 0M, as everything behind the tile's last op */
-  u32 w[16];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const u32 base = ((u32)j * 64u + lane) * 4u;
-    u32x4_a16 v = {0u, 0u, 0u, 0u};
-    if (base < nt) v = *(const u32x4_a16*)(ops + tile_start + base);
-    w[4 * j + 0] = v[0];
-    w[4 * j + 1] = v[1];
-    w[4 * j + 2] = v[2];
-    w[4 * j + 3] = v[3];
-  }
-  if (nt & 3u) { /* wave-uniform: only the stream's last tile */
-#pragma unroll
-    for (int k = 0; k < 16; k++) w[k] = ((u32)(k >> 2) * 256u + (u32)(k & 3) + lane * 4u < nt) ? w[k] : 0u;
-  }
 
   /* the first segment's record, bounds and strand arrive with the ops (k_tile_rec); later
    * segments — records that start inside the tile — load theirs */
@@ -399,6 +374,53 @@ __global__ __launch_bounds__(256, WGA_K1_BLOCKS) void k_cigar_stat(const u32* __
     tiles[g] = ts;
   }
 #endif
+}
+
+/* 16 ops per lane, each of the 4 loads a fully coalesced 1 KiB.  A 16-byte group is loaded when it starts in front of the
+ * stream's end (it may reach up to 12 bytes beyond it, inside the same aligned 16 bytes); what it brings from there becomes
+ * 0M, as everything behind the tile's last op */
+__device__ __forceinline__ void stat_load_ops(const u32* __restrict__ ops, u64 n_ops, u64 g, u32 lane, u32 (&w)[16]) {
+  const u64 tile_start = g * WGA_TILE;
+  const u32 nt = tile_start + WGA_TILE < n_ops ? WGA_TILE : (u32)(n_ops - tile_start);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const u32 base = ((u32)j * 64u + lane) * 4u;
+    u32x4_a16 v = {0u, 0u, 0u, 0u};
+    if (base < nt) v = *(const u32x4_a16*)(ops + tile_start + base);
+    w[4 * j + 0] = v[0];
+    w[4 * j + 1] = v[1];
+    w[4 * j + 2] = v[2];
+    w[4 * j + 3] = v[3];
+  }
+  if (nt & 3u) { /* wave-uniform: only the stream's last tile */
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = ((u32)(k >> 2) * 256u + (u32)(k & 3) + lane * 4u < nt) ? w[k] : 0u;
+  }
+}
+
+/* A grid of resident waves (the host sizes it): wave j of W takes the tiles j, W + j, 2 W + j ... and requests the ops of its
+ * next tile before it works on the current one — with one tile per wave the kernel ran at the rate 5 waves per SIMD x 4 KB in
+ * flight allow (3.6 TB/s), whatever its instruction count. */
+__global__ __launch_bounds__(256, WGA_K1_BLOCKS) void k_cigar_stat(const u32* __restrict__ ops,
+                                                    const u64* __restrict__ op_off,
+                                                    const u8* __restrict__ strand_neg, u32 n,
+                                                    u64 n_ops, const wga_tile_rec* __restrict__ tile_rec,
+                                                    wga_cigar_counts* counts,
+                                                    wga_rec_diag* diag, wga_tile_sum* tiles) {
+  (void)n;
+  const u32 lane = threadIdx.x & 63u;
+  const u64 W = (u64)gridDim.x * 4;
+  u64 g = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
+  if (g * WGA_TILE >= n_ops) return; /* wave-uniform; this kernel has no block barrier */
+  u32 wn[16];
+  stat_load_ops(ops, n_ops, g, lane, wn);
+  for (; g * WGA_TILE < n_ops; g += W) {
+    u32 w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = wn[k];
+    if ((g + W) * WGA_TILE < n_ops) stat_load_ops(ops, n_ops, g + W, lane, wn);
+    cigar_stat_tile(g, w, lane, op_off, strand_neg, n_ops, tile_rec, counts, diag, tiles);
+  }
 }
 
 /* ============================================================================================ */

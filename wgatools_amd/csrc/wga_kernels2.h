@@ -281,22 +281,18 @@ __global__ __launch_bounds__(256) void k_cov_tile_info(const u64* __restrict__ o
  * segments need of their records comes with the tile's ops in one load (k_cov_tile_info), a further segment's record data
  * (op_off, k_cov_rec_pos's pair) is fetched a segment ahead.  With `rcap` = 0 the pieces beyond the slots are only counted. */
 #ifndef WGA_K5_LIST_WAVES
-#define WGA_K5_LIST_WAVES 1 /* waves per SIMD the register allocation aims at (8: 62 VGPRs and 12 bytes of scratch) */
+#define WGA_K5_LIST_WAVES 5 /* waves per SIMD the register allocation aims at (5: 96 VGPRs and 12 bytes of scratch with the next tile's ops in registers; 6: 80 and 20) */
 #endif
-__global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
-    const u32* __restrict__ ops, const u64* __restrict__ op_off, u64 n_ops, const wga_cov_tile* __restrict__ tile_info,
-    const wga_cov_rec* __restrict__ rec_pos, u64* tile_tail, u32* win_cnt, wga_cov_piece* tile_list, u32* tile_cnt, u64* list_cnt,
-    wga_cov_piece* list, u64 rcap, u32 spin_limit) {
-  const u32 lane = threadIdx.x & 63u;
-  const u64 g = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
+/* one tile of the list pass; w = the tile's 16 packed ops per lane */
+__device__ __forceinline__ void cov_list_tile(
+    const u64 g, u32 (&w)[16], const u32 lane, const u32* __restrict__ ops, const u64* __restrict__ op_off, u64 n_ops,
+    const wga_cov_tile* __restrict__ tile_info, const wga_cov_rec* __restrict__ rec_pos, u64* tile_tail, u32* win_cnt,
+    wga_cov_piece* tile_list, u32* tile_cnt, u64* list_cnt, wga_cov_piece* list, u64 rcap, u32 spin_limit) {
   const u64 tile_start = g * WGA_TILE;
-  if (tile_start >= n_ops) return;
   const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
   const u32 nt = (u32)(tile_end - tile_start);
   const wga_cov_tile tr = tile_info[g];
   const u64 rs_next = tile_end < n_ops ? tile_info[g + 1].rs : ~0ull; /* where the record of the next tile's first op starts */
-  u32 w[16];
-  cov_load_ops(ops, tile_start, nt, lane, w);
 #pragma unroll
   for (int e = 0; e < 16; e++) w[e] = (w[e] >> 4) & bit_mask(WGA_COV_MOVES_BITS, w[e] & 15u); /* the pass needs the ops' advance only */
   if (nt & 3u) { /* wave-uniform, the stream's last tile: what the last 16-byte group brought from behind the stream */
@@ -529,6 +525,34 @@ __global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
     r++;
   }
   if (lane == 0) tile_cnt[g] = n_mine < (u64)WGA_COV_TILE_CAP ? (u32)n_mine : WGA_COV_TILE_CAP;
+}
+
+/* A grid of RESIDENT waves (the host sizes it by the occupancy the runtime reports): wave j of W takes the tiles j, W + j,
+ * 2 W + j ... and requests the ops of its next tile before it works on the current one.  What bounded the pass with one tile
+ * per wave was the time a wave spends waiting for its 4 KB of ops with nothing else to do (7 waves per SIMD x 4 KB in flight),
+ * not instructions and not HBM.  A tile looks back at the tile in front of it, which belongs to the wave in front in the same
+ * round (wave 0: to the last wave's round before) and is published at the start of that wave's round: the waves move through
+ * the rounds side by side.  Should a wave it waits for not be running (a grid larger than what is resident, the emulator's one
+ * block at a time), the look-back's poll limit ends the wait and the wave adds up the ops itself. */
+__global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
+    const u32* __restrict__ ops, const u64* __restrict__ op_off, u64 n_ops, const wga_cov_tile* __restrict__ tile_info,
+    const wga_cov_rec* __restrict__ rec_pos, u64* tile_tail, u32* win_cnt, wga_cov_piece* tile_list, u32* tile_cnt, u64* list_cnt,
+    wga_cov_piece* list, u64 rcap, u32 spin_limit) {
+  const u32 lane = threadIdx.x & 63u;
+  const u64 W = (u64)gridDim.x * 4;
+  u64 g = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
+  if (g * WGA_TILE >= n_ops) return;
+  auto tile_ops = [&](u64 k) { return k * WGA_TILE + WGA_TILE < n_ops ? WGA_TILE : (u32)(n_ops - k * WGA_TILE); };
+  u32 wn[16];
+  cov_load_ops(ops, g * WGA_TILE, tile_ops(g), lane, wn);
+  for (; g * WGA_TILE < n_ops; g += W) { /* wave-uniform */
+    u32 w[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) w[e] = wn[e];
+    if ((g + W) * WGA_TILE < n_ops) cov_load_ops(ops, (g + W) * WGA_TILE, tile_ops(g + W), lane, wn);
+    cov_list_tile(g, w, lane, ops, op_off, n_ops, tile_info, rec_pos, tile_tail, win_cnt, tile_list, tile_cnt, list_cnt, list, rcap,
+                  spin_limit);
+  }
 }
 
 /* the listed pieces go to their windows: a piece takes the next place of its window (win_fill, zero before) — an atomic with an

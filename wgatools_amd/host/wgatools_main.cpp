@@ -142,7 +142,9 @@ struct DevStreamer {
      * a file system lacks it).  Eight threads writing the same 16 MB into a NEW file: 12.6 GB/s, 16.3 after fallocate
      * (profiles/r04_cli_e2e.txt); with real pieces out of the pinned buffers paf2maf's 15 GB leave at 10-12 GB/s either way,
      * and neither 12-24 writers nor handing the pieces out as eight sequential streams changed that beyond the run-to-run spread. */
-    if (fd >= 0 && n >= ((size_t)64 << 20)) (void)fallocate(fd, 0, (off_t)pos0, (off_t)n);
+    /* FALLOC_FL_KEEP_SIZE: the blocks are reserved, the file's length still ends behind the last byte written — a run that fails
+     * or is killed half way leaves no zero-filled tail that looks like output. */
+    if (fd >= 0 && n >= ((size_t)64 << 20)) (void)fallocate(fd, FALLOC_FL_KEEP_SIZE, (off_t)pos0, (off_t)n);
     std::vector<std::thread> writers;
     std::mutex mu;
     std::condition_variable cv;
@@ -459,6 +461,11 @@ struct BgzfDeviceSource {
  * a slice.  Commands that need bases on the host (VCF REF / ALT text, a target row of pafpseudo, the offending base of
  * an error message) read them back from the device.  WGA_FASTA_READER=host keeps the host line stripper (A/B, tests). */
 struct DevFasta {
+  /* The pool the kernels see has kPad bytes of 'N' in front of the first contig and behind the last one: the streaming row
+   * kernel reads 16-byte windows that may reach over a slice's ends and leaves slices within 32 bytes of a pool edge to the
+   * block kernels (include/wga_hip.h) — with the padding no slice of a real contig is such a slice.  Offsets handed out by
+   * fetch() count from the padded pool's start. */
+  static constexpr uint64_t kPad = 32;
   Faidx idx;
   uint8_t* d_pool = nullptr;
   uint64_t bytes = 0;
@@ -467,6 +474,8 @@ struct DevFasta {
     const char* mode = getenv("WGA_FASTA_READER");
     if (mode && strcmp(mode, "host") == 0) {
       idx.load(path);
+      idx.pool.insert(0, (size_t)kPad, 'N');
+      idx.pool.append((size_t)kPad, 'N');
       bytes = idx.pool.size();
       d_pool = d.upload((const uint8_t*)idx.pool.data(), idx.pool.size());
       have_host = true;
@@ -507,9 +516,11 @@ struct DevFasta {
     }
     uint64_t nc = 0, nb = 0;
     d.check(wga_fasta_pool(d.ctx, d_text, n_text, &nc, &nb, nullptr, nullptr));
-    d_pool = (uint8_t*)d.alloc(nb + 64);
+    d_pool = (uint8_t*)d.alloc(nb + 2 * kPad + 64);
+    d.check(wga_memset(d.ctx, d_pool, 'N', kPad));
+    d.check(wga_memset(d.ctx, d_pool + kPad + nb, 'N', kPad + 64));
     auto* d_tab = (wga_fa_contig*)d.alloc((nc + 1) * sizeof(wga_fa_contig));
-    d.check(wga_fasta_pool(d.ctx, d_text, n_text, &nc, &nb, d_pool, d_tab));
+    d.check(wga_fasta_pool(d.ctx, d_text, n_text, &nc, &nb, d_pool + kPad, d_tab));
     std::vector<wga_fa_contig> tab(nc);
     if (nc) d.download(tab.data(), (const wga_fa_contig*)d_tab, nc);
     static_assert(sizeof(wga_fa_contig) == 4 * sizeof(uint64_t), "wga_fa_contig layout");
@@ -529,12 +540,13 @@ struct DevFasta {
     } else {
       idx.set_table(text, (const uint64_t*)tab.data(), nc);
     }
-    bytes = nb;
+    bytes = nb + 2 * kPad;
     d.release(d_tab);
     d.release(d_text);
   }
   void fetch(const std::string& name, uint64_t beg, uint64_t end_incl, uint64_t* off, uint64_t* len) const {
     idx.fetch(name, beg, end_incl, off, len);
+    *off += kPad;
   }
   /* the whole pool on the host (downloaded once) */
   const std::string& host_pool(Dev& d) {
