@@ -141,7 +141,7 @@ def extra_shape(eng, synth, pipeline, torch, dev, seed, records, mean_ops, pool_
     tb = synth.make_paf_batch_torch(seed, records, mean_ops, pool_mb * 1_000_000, dev)
     job = pipeline.Paf2MafStatJob(eng, tb)
     job.bind_stream()
-    for _ in range(5):    # first touch of the output buffer + the library's drain_min trials (wga_hip.h)
+    for _ in range(3):    # first touch of the output buffer
         job.step()
     torch.cuda.synchronize()
     eng.expand_timing()   # drop what the warm-up recorded
@@ -238,24 +238,22 @@ def north_star(args):
     nb = (args.ns_records + per - 1) // per
     tot_ops = tot_cols = tot_bytes = 0
     ms_step = ms_k2 = 0.0
-    arena = keep = placement = None
+    arena = None
     for b in range(nb):
         tb = synth.make_paf_batch_torch(0x5747415F + 1000 + b, per, 50_000, args.pool_mb * 1_000_000, dev)
         need = int((tb["t_src_len"] + tb["i"]).sum() + (tb["q_src_len"] + tb["d"]).sum()) + 64
-        if arena is None or arena.numel() < need:   # one output arena for the whole stream, as a long-lived caller keeps:
-            arena = keep = None                      # placed by the library for the first batch that needs it
+        fresh = arena is None or arena.numel() < need
+        if fresh:                       # one output arena for the whole stream, as a long-lived caller keeps: the first
+            arena = None                # buffer the allocator returns
             torch.cuda.empty_cache()
-            job = pipeline.Paf2MafStatJob(eng, tb, place=args.ns_candidates)
-            job.bind_stream()
-            placement = job.place_output(arena_bytes=int(need * 1.08))
-            arena, keep = job.arena_view, job.arena
-            for _ in range(4):              # warm-up: the library's drain_min trials on the kept arena
+            arena = torch.empty(int(need * 1.08), dtype=torch.uint8, device=dev)
+        job = pipeline.Paf2MafStatJob(eng, tb, out=arena)
+        job.bind_stream()
+        if fresh:
+            for _ in range(2):          # first touch of the arena
                 job.step()
             torch.cuda.synchronize()
             eng.expand_timing()
-        else:
-            job = pipeline.Paf2MafStatJob(eng, tb, out=arena)
-            job.bind_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         job.step()
@@ -281,9 +279,9 @@ def north_star(args):
         "roofline": {"kernel": {0: "k_paf2maf_expand", 2: "k_paf2maf_expand_w", 3: "k_paf2maf_expand_s"}.get(eng.get_param("expand_variant_used")),
                      "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": tot_bytes},
-        "output_placement": placement,
-        "metric_scope": "kernel-only, summed over the batches, rows written into one output arena (placed for the first batch by "
-                        "wga_paf2maf_expand_place); generation between batches is not timed",
+        "output_placement": "first allocation",
+        "metric_scope": "kernel-only, summed over the batches, rows written into one output arena (the first buffer the allocator "
+                        "returns); generation between batches is not timed",
     }), flush=True)
     eng.close()
 
@@ -349,7 +347,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5, help="untimed steps; the library's drain_min trials take the first five launches on a new output buffer")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed steps (the first launch touches the output buffer for the first time)")
     ap.add_argument("--records", type=int, default=100_000)
     ap.add_argument("--mean-ops", type=int, default=5000)
     ap.add_argument("--pool-mb", type=int, default=50)
@@ -378,16 +376,10 @@ def main():
                                                              "imbalance under both assignments) and exit: needs no GPU")
     ap.add_argument("--zipf", type=float, default=0.0, help="strong scaling: skew of the records over the targets "
                                                             "(P(target k) ~ 1 / (k + 1)^zipf; 0 = uniform, the default)")
-    ap.add_argument("--placement-sweep", action="store_true", help="after the timed steps (which run on the FIRST output buffer the "
-                    "allocator returns: that is the headline), also let the library place the output arena among "
-                    "--placement-candidates arenas (wga_paf2maf_expand_place) and report what the best of them gives")
-    ap.add_argument("--no-placement-probe", action="store_true", help="(accepted for older command lines: the first allocation is the default now)")
-    ap.add_argument("--placement-candidates", type=int, default=12,
-                    help="--placement-sweep: candidate output arenas (12 x 15 GB on configs[1]; fewer are tried when memory runs out)")
+    ap.add_argument("--no-placement-probe", action="store_true", help="(accepted for older command lines: the output buffer is the first allocation)")
     ap.add_argument("--north-star", action="store_true", help="the 10 M x 50 kop headline shape as a stream of resident batches (N = 1)")
     ap.add_argument("--ns-records", type=int, default=400_000)
     ap.add_argument("--ns-batch-records", type=int, default=40_000)
-    ap.add_argument("--ns-candidates", type=int, default=1, help="candidate arenas of the north-star stream (64 GB each; 1 = the first allocation)")
     args = ap.parse_args()
     if args.north_star:
         return north_star(args)
@@ -437,8 +429,7 @@ def main():
     else:
         tb = synth.make_paf_batch_torch(seed, args.records, args.mean_ops, args.pool_mb * 1_000_000, dev,
                                         neg_frac=args.neg_frac, use_m=args.m_only)
-    # The timed steps run on the FIRST output buffer the allocator returns: no placement policy, what any caller gets.
-    placement = None
+    # The timed steps run on the FIRST output buffer the allocator returns: what any caller gets.
     job = pipeline.Paf2MafStatJob(eng, tb)
     job.bind_stream()
     totals = torch.zeros(11, dtype=torch.int64, device=dev)
@@ -467,11 +458,9 @@ def main():
         if dist_on:
             dist.all_reduce(totals)                          # RCCL over xGMI: 88 bytes
 
-    eng.set_param("expand_alias", 1)   # warm-up launches (first touch, the library's trials) under the kernel's second name:
-    for _ in range(args.warmup):       # rocprofv3 --stats of this command then holds exactly the timed launches under the first
+    for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    eng.set_param("expand_alias", 0)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -531,30 +520,6 @@ def main():
         k_expand = ms_sum / n_timed if n_timed else k_expand_call
         variant_used = eng.get_param("expand_variant_used")
         kernel_name = {0: "k_paf2maf_expand", 2: "k_paf2maf_expand_w", 3: "k_paf2maf_expand_s"}.get(variant_used, "k_paf2maf_expand")
-        placed_ms = None
-        if args.placement_sweep and world == 1 and not args.param:
-            # what the best of N candidate arenas would give (the level of the row kernel follows the region of HBM its output
-            # lies in): the library's placement call, launches under the kernel's second name
-            try:
-                eng.set_param("expand_alias", 1)
-                jp = pipeline.Paf2MafStatJob(eng, tb, place=args.placement_candidates)
-                jp.bind_stream()
-                placement = jp.place_output()
-                for _ in range(3):
-                    jp.step()
-                torch.cuda.synchronize()
-                eng.expand_timing()
-                for _ in range(3):
-                    jp.expand()
-                torch.cuda.synchronize()
-                t_ms, t_n = eng.expand_timing()
-                placed_ms = t_ms / max(1, t_n)
-                del jp
-            except Exception as e:  # noqa: BLE001
-                placement = {"error": "%s: %s" % (type(e).__name__, e)}
-            finally:
-                eng.set_param("expand_alias", 0)
-                torch.cuda.empty_cache()
         ab = job.algorithmic_bytes()
         in_bytes = 4 * job.n_ops + int(tb["t_src_len"].sum()) + int(tb["q_src_len"].sum())
         ach = ab["expand"] / (k_expand * 1e-3) / 1e9
@@ -591,14 +556,12 @@ def main():
                           "expand_prepass (k_rec_desc + k_tile_base + marks)": k_expand_call - k_expand},
             "row_kernel": {"expand_variant_used": variant_used, "name": kernel_name,
                            "tiles_left_to_v1": eng.get_param("expand_stream_left_to_v1") if variant_used == 3 else None},
-            "output_placement": placement if placement is not None else "first allocation (the default; --placement-sweep tries more)",
+            "output_placement": "first allocation",
             "roofline": {
                 "kernel": kernel_name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args, job),
                 "algorithmic_bytes_per_launch": ab["expand"],
                 "output_buffer": "first allocation (no placement policy)",
-                # --placement-sweep: the same kernel on the best of the candidate arenas
-                "frac_placed_best_of_%d" % args.placement_candidates: (ab["expand"] / (placed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if placed_ms else None,
                 "k_cigar_stat_GBps": ab["stat"] / (k_stat * 1e-3) / 1e9,
                 # paf2maf+stat priced both ways.  The step runs K1 and K2 as two kernels, so the packed ops
                 # are read twice (unfused); a fused walk would read them once.
@@ -637,7 +600,6 @@ def main():
             try:   # additional information: never at the price of the headline line
                 del job
                 torch.cuda.empty_cache()
-                eng.set_param("expand_alias", 1)   # other shapes run under the kernel's second name (rocprofv3 --stats)
                 ms_g, frac_g = extra_shape(eng, synth, pipeline, torch, dev, seed, args.records, args.mean_ops, 1000)
                 ms_l, frac_l = extra_shape(eng, synth, pipeline, torch, dev, seed + 100, 10_000, 50_000, args.pool_mb)
                 ms_lg, frac_lg = extra_shape(eng, synth, pipeline, torch, dev, seed + 100, 10_000, 50_000, 1000)

@@ -31,8 +31,12 @@ extern "C" {
 /* 2: what a count call leaves in the context for its fill call (wga_maf_runs_* / wga_chain_lines_*, the op walks
  *    wga_paf_call_events / wga_cigar_chain / wga_cigar_dotplot over long records, wga_cigar_class_sums -> wga_pafpseudo_fill)
  *    is ONE-SHOT — the first fill call that takes it consumes it — and is dropped when one of the arrays it was made from is
- *    written through wga_memcpy_h2d / wga_memset or freed; "expand_variant" takes -1, 0, 2, 3. */
-#define WGA_ABI_VERSION 2
+ *    written through wga_memcpy_h2d / wga_memset or freed; "expand_variant" takes -1, 0, 2, 3.
+ * 3: the output-placement calls (wga_paf2maf_expand_place, wga_arena_alloc, wga_arena_probe) and the parameters
+ *    "expand_autotune" / "expand_alias" are gone — the streaming row kernel made them unnecessary —; new:
+ *    wga_pafcov_accumulate_final; wga_reduce_scatter_i32 no longer waits on the host (its result is ordered on the contexts'
+ *    streams) and wga_pafcov_finalize refuses overlapping target ranges.  No struct layout changed. */
+#define WGA_ABI_VERSION 3
 
 /* ---- status codes (call level) ------------------------------------------------------------ */
 enum wga_status {
@@ -129,24 +133,20 @@ int wga_ctx_reset_stream(wga_ctx*);
  * streaming kernel walks;
  * "pseudo_variant": wga_pafpseudo_fill's rows through the streaming kernel (3, default) or one block per tile (0);
  * "expand_drain_min" (0 .. 64, v1 only) = how many gap-touching 16-column chunks a wave
- * queues before it emits them: 0 (default) lets the library choose by the size of the two sequence pools — 64 when
- * they stay in the 256 MB Infinity Cache, 16 when they do not (the L2 then churns with source lines and half-written
- * output lines should complete at once) as the starting point — and, unless "expand_autotune" is set to 0, tries 64 / 32 /
- * 16 on the first launches of >= 8192 tiles that write to a given output buffer and keeps the fastest per tile (what
- * late emission costs depends on where the output buffer lies in HBM; the bytes written do not depend on it).  A caller
- * that keeps its output arena pays three slightly slower launches once.  Environment: WGA_EXPAND_DRAIN_MIN,
- * WGA_EXPAND_AUTOTUNE.  "expand_alias" (0/1): launch the row kernel under its second name (k_paf2maf_expand_alias) —
- * a harness that runs several shapes in one process keeps its per-kernel profiler statistics apart that way.
+ * queues before it emits them: 0 (default) lets the library choose by the size of the two sequence pools — 32 when
+ * they stay in the 256 MB Infinity Cache, 16 when they do not (environment: WGA_EXPAND_DRAIN_MIN).
+ * "reduce_same_device_ok" / "reduce_staged" (0/1): wga_reduce_scatter_i32 over contexts that share a device, and by staged
+ * peer copies where peer access exists (tests on one-GPU boxes).
  * "op_long_ops" (default 16384) / "op_piece_ops" (8192, a multiple of 256): the op walks with one wave per record (call
  * events, chain lines, dotplot segments) cut records beyond the first into pieces of at most the second and walk the pieces
  * over the whole chip; "maf_long_cols" (32768) / "maf_piece_cols" (16384): the same for the MAF column walks.  The tests set
  * small values to reach those paths with small inputs. */
 int wga_ctx_set_param(wga_ctx*, const char* name, int64_t value);
-/* Read back: "expand_drain_min" = what the last wga_paf2maf_expand used, "expand_autotune_settled" (0/1),
+/* Read back: "expand_drain_min" = what the last wga_paf2maf_expand used,
  * "expand_variant" / "expand_job_tiles" / "pseudo_variant" (the settings), "expand_variant_used" (what the last
  * wga_paf2maf_expand ran), "expand_stream_left_to_v1" / "pseudo_stream_left_to_blocks" (tiles the streaming kernel's last
  * launch left to the block kernels: records whose slices do not match their CIGAR, slices at a pool's edge, giant tiles —
- * a device read, diagnostics). */
+ * a device read, diagnostics; -1 once another call has taken the scratch arena the two counters lay in). */
 int wga_ctx_get_param(wga_ctx*, const char* name, int64_t* value);
 /* Measurement hook: after wga_ctx_set_param(ctx, "expand_timing", 1) every wga_paf2maf_expand
  * brackets its gap-insertion kernel (without the descriptor pre-pass) with two events on the
@@ -156,21 +156,6 @@ int wga_ctx_expand_timing(wga_ctx*, double* ms_sum, uint32_t* launches);
 int wga_sync(wga_ctx*);
 int wga_malloc(wga_ctx*, size_t bytes, void** d_out);
 int wga_free(wga_ctx*, void* d_ptr);
-/* Placement policy for a large, long-lived output arena (the MAF rows of converter.rs:237-262, which the reference
- * keeps in two `String`s per record).  The rate a write-heavy kernel reaches depends on the REGION of HBM its output lies
- * in (profiles/r02_k2_experiments.md sections 7, 10: the same row kernel at 6.65 / 6.81 / 7.21 ms by region, and a plain
- * copy moves with it), and nothing in the allocation API says which region a buffer got.  wga_arena_alloc allocates up to
- * `candidates` buffers of `bytes`, times a plain streaming copy inside each (one warming pass = first touch, two timed
- * ones; HIP events on the context's stream), keeps the fastest and frees the others.  `gbps_by_candidate` (optional,
- * `candidates` entries; 0 for candidates that were not allocated) receives the probe's copy rate per candidate, `chosen`
- * (optional) the index kept.  candidates <= 1 is wga_malloc.  Free the arena with wga_free.  Synchronises. */
-int wga_arena_alloc(wga_ctx*, size_t bytes, int candidates, void** d_out, double* gbps_by_candidate, int* chosen);
-/* The probe by itself on a caller's buffer (>= 4 KiB, 16-byte aligned; its contents are overwritten): GB/s of pattern
- * `kind` — 0 the streaming copy wga_arena_alloc ranks its candidates by, 1 a streaming fill, 2 / 3 the fill with every
- * 128-byte line written in eight pieces that arrive 1 MiB / 64 KiB of other writes apart, 4 / 5 whole 4 KiB / 64 KiB
- * chunks written at scattered places.  For measurements of a
- * placement (profiles/), not needed by a caller of wga_arena_alloc. */
-int wga_arena_probe(wga_ctx*, void* d_buf, size_t bytes, int kind, double* gbps);
 int wga_memcpy_h2d(wga_ctx*, void* d_dst, const void* h_src, size_t bytes);
 int wga_memcpy_d2h(wga_ctx*, void* h_dst, const void* d_src, size_t bytes); /* synchronises */
 int wga_memset(wga_ctx*, void* d_dst, int byte, size_t bytes);
@@ -240,24 +225,6 @@ int wga_paf2maf_expand(wga_ctx*, const wga_cigar_batch*, const wga_cigar_counts*
                        const uint8_t* d_q_fa, uint64_t q_fa_bytes, const uint64_t* d_q_src_off,
                        const uint64_t* d_q_src_len, uint8_t* d_out, const uint64_t* d_t_row_off,
                        const uint64_t* d_q_row_off, wga_rec_diag* d_diag);
-
-/* The same call with the output arena placed BY THE JOB: the level the row kernel runs at depends on the physical region of
- * HBM its output lies in (regions differ by 20 % in what they give a streaming write and the kernel runs at that rate;
- * plain probe patterns rank the regions only partly as the kernel does: profiles/r03_arena_probe_kinds.txt).  `candidates`
- * buffers of `arena_bytes` (>= the rows of this batch; a caller that keeps the arena for later batches asks for more) are
- * allocated, the rows of THIS batch are written into each — one launch that touches the buffer, two timed — and the
- * buffer the kernel was fastest on comes back in *d_out, holding the batch's rows; the others are freed (free *d_out with
- * wga_free).  Fewer candidates are tried when memory runs out; candidates <= 1 is wga_malloc + wga_paf2maf_expand.
- * ms_by_candidate (optional, `candidates` entries): the timed launches' mean per candidate, 0 where none ran.
- * The per-buffer trials of "expand_drain_min" start with the first later launch on the chosen buffer.
- * A long-lived caller does this once for its first batch and keeps the arena (the `wgatools` command line does). */
-int wga_paf2maf_expand_place(wga_ctx*, const wga_cigar_batch*, const wga_cigar_counts* d_counts,
-                             const void* d_tile_ws, const uint8_t* d_t_fa, uint64_t t_fa_bytes,
-                             const uint64_t* d_t_src_off, const uint64_t* d_t_src_len,
-                             const uint8_t* d_q_fa, uint64_t q_fa_bytes, const uint64_t* d_q_src_off,
-                             const uint64_t* d_q_src_len, const uint64_t* d_t_row_off,
-                             const uint64_t* d_q_row_off, wga_rec_diag* d_diag, size_t arena_bytes, int candidates,
-                             void** d_out, double* ms_by_candidate, int* chosen);
 
 /* Copy n variable-length byte snippets: d_dst[d_dst_off[i] ..) = d_src[d_src_off[i] .. d_src_off[i+1])
  * (used to drop the "a score=…" / "s\tname\t…" line text between the rows, maf.rs:566-581). */

@@ -8,7 +8,7 @@
 #include <stddef.h>
 #include "wga_hip.h"
 
-_Static_assert(WGA_ABI_VERSION == 2, "ABI version");
+_Static_assert(WGA_ABI_VERSION == 3, "ABI version");
 _Static_assert(sizeof(wga_rec_diag) == 24, "wga_rec_diag");
 _Static_assert(offsetof(wga_rec_diag, bad_op_idx) == 0, "wga_rec_diag.bad_op_idx");
 _Static_assert(offsetof(wga_rec_diag, panic_op_idx) == 8, "wga_rec_diag.panic_op_idx");

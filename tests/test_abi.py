@@ -26,7 +26,7 @@ def test_library_exports_every_symbol():
     for name in header_functions():
         assert hasattr(h, name), name
     h.wga_abi_version.restype = ctypes.c_int
-    assert h.wga_abi_version() == 2
+    assert h.wga_abi_version() == 3
 
 
 def test_no_gpu_fails_loudly():

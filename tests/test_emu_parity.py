@@ -470,43 +470,6 @@ def test_paf2maf_drain_min_settings(emu):
     pc.check_drain_min_settings(emu, synth.make_paf_batch(21, 6, 900, 200_000))
 
 
-def test_paf2maf_drain_trials_state_machine(emu):
-    """the emulator build starts the trials at 2 tiles: on one output buffer the launches use the default, then 64 / 32 / 16,
-    then the winner (the emulator's events read 0 ms, so the first candidate stays); a new buffer starts over; every
-    launch writes the same bytes"""
-    b = synth.make_paf_batch(33, 5, 1500, 300_000)
-    n = len(b["strand_neg"])
-    batch = emu.make_batch(b["ops"], b["op_off"], b["strand_neg"])
-    counts, diag, tws = emu.cigar_stat(batch)
-    tl, ql = emu.upload(b["t_src_len"]), emu.upload(b["q_src_len"])
-    to, qo = emu.upload(b["t_src_off"]), emu.upload(b["q_src_off"])
-    tro, qro, reco = emu.paf2maf_layout(n, counts, tl, ql)
-    total = int(reco.numpy()[-1])
-    tp, qp = emu.upload(b["t_pool"]), emu.upload(b["q_pool"])
-    assert emu.get_param("expand_variant") == pc.DEFAULT_EXPAND_VARIANT
-    emu.set_param("expand_variant", 0)           # the trials belong to v1 (the window kernel has no queue to drain)
-    emu.set_param("expand_autotune", 1)          # forget what earlier tests' buffers (maybe at this address) taught
-    ref, alive = None, []
-    for buf in range(2):
-        out = emu.empty(total + 64, np.uint8)
-        alive.append(out)                          # two buffers, two addresses
-        used = []
-        for k in range(6):
-            out.fill(0x23)
-            emu.paf2maf_expand(batch, counts, tws, tp, len(b["t_pool"]), to, tl, qp, len(b["q_pool"]), qo, ql, out, tro, qro, diag)
-            used.append(emu.get_param("expand_drain_min"))
-            got = out.numpy().copy()
-            ref = got if ref is None else ref
-            assert (got == ref).all(), (buf, k)
-        assert used == [32, 64, 32, 16, 64, 64], used
-        assert emu.get_param("expand_autotune_settled") == 1
-    emu.set_param("expand_autotune", 0)
-    emu.paf2maf_expand(batch, counts, tws, tp, len(b["t_pool"]), to, tl, qp, len(b["q_pool"]), qo, ql, out, tro, qro, diag)
-    assert emu.get_param("expand_drain_min") == 32 and emu.get_param("expand_autotune_settled") == 0
-    emu.set_param("expand_autotune", 1)
-    emu.set_param("expand_variant", pc.DEFAULT_EXPAND_VARIANT)
-
-
 def test_cigar_chain(emu):
     b = synth.make_paf_batch(57, 12, 300, 400000)
     pc.check_cigar_chain(emu, b["ops"], b["op_off"])
@@ -700,47 +663,6 @@ def test_maf_long_blocks_piecewise(emu):
     finally:
         emu.set_param("maf_long_cols", 32768)
         emu.set_param("maf_piece_cols", 16384)
-
-
-def test_arena_alloc(emu):
-    """wga_arena_alloc on the emulator: the probe's copies run (events read 0 ms: the first candidate stays), the arena
-    is a plain allocation of the asked size, candidates <= 1 is wga_malloc"""
-    a, rates, chosen = emu.arena_alloc(10000, 3)
-    assert a.ptr and len(rates) == 3 and chosen == 0 and a.nbytes == 10000
-    a.fill(0x41)
-    assert bytes(a.numpy()[:4]) == b"AAAA" and a.numpy()[-1] == 0x41
-    a.free()
-    b, rates, chosen = emu.arena_alloc(64, 1)
-    assert b.ptr and chosen == 0
-    b.free()
-    c = emu.empty(1 << 16, np.uint8)
-    for kind in range(14):                     # the measurement patterns write inside the buffer, all of it
-        c.fill(0)
-        emu.arena_probe(c, (1 << 16) - 48, kind)
-        h = c.numpy()
-        assert (h[(1 << 16) - 48:] == 0).all(), kind
-    c.free()
-
-
-def test_expand_place(emu):
-    """wga_paf2maf_expand_place on the emulator (events read 0 ms: the first candidate stays): the arena comes back holding
-    the batch's rows — the bytes the plain call writes"""
-    b = synth.make_paf_batch(21, 30, 200, 50000)
-    n = len(b["strand_neg"])
-    batch = emu.make_batch(b["ops"], b["op_off"], b["strand_neg"])
-    counts, diag, tile_ws = emu.cigar_stat(batch)
-    up = lambda k: emu.upload(np.ascontiguousarray(b[k]))
-    tp, qp = up("t_pool"), up("q_pool")
-    to, tl, qo, ql = up("t_src_off"), up("t_src_len"), up("q_src_off"), up("q_src_len")
-    tro, qro, rec = emu.paf2maf_layout(n, counts, tl, ql)
-    total = int(rec.numpy()[-1])
-    plain = emu.empty(total + 64, np.uint8).fill(0x23)
-    emu.paf2maf_expand(batch, counts, tile_ws, tp, b["t_pool"].size, to, tl, qp, b["q_pool"].size, qo, ql, plain, tro, qro, diag)
-    arena, ms, chosen = emu.paf2maf_expand_place(batch, counts, tile_ws, tp, b["t_pool"].size, to, tl, qp, b["q_pool"].size, qo,
-                                                 ql, tro, qro, diag, total + 64, 3)
-    assert len(ms) == 3 and chosen == 0 and arena.nbytes == total + 64
-    assert (arena.numpy()[:total] == plain.numpy()[:total]).all()
-    arena.free()
 
 
 def test_reduce_scatter_i32(monkeypatch):

@@ -140,71 +140,23 @@ def test_paf2maf_drain_min_settings(gpu):
     pc.check_drain_min_settings(gpu, synth.make_paf_batch(21, 200, 900, 2_000_000))
 
 
-def test_paf2maf_drain_autotune_same_bytes(gpu):
-    """launches of >= 8192 tiles on one output buffer: a warming launch, three trials (drain_min 64 / 32 / 16 on live
-    work), then the fastest stays; the rows are the same bytes in every launch"""
-    import torch
-    dev = torch.device("cuda", 0)
-    tb = synth.make_paf_batch_torch(77, 3000, 4000, 20_000_000, dev)
-    assert tb["n_ops"] >= 8192 * 1024
-    from wgatools_amd import pipeline
-    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
-    gpu.set_param("expand_autotune", 1)
-    gpu.set_param("expand_variant", 0)      # drain_min is v1's (the row kernel of the tiles the streaming kernel leaves to it)
-    job = pipeline.Paf2MafStatJob(gpu, tb)
-    job.stat(); job.layout()
-    sums, used = [], []
-    for k in range(7):
-        job.out.fill_(0x23)
-        job.expand()
-        torch.cuda.synchronize()
-        used.append(gpu.get_param("expand_drain_min"))
-        sums.append((int(job.out[:job.out_bytes].to(torch.int64).sum()), int((job.out[:job.out_bytes:4097].to(torch.int64) * 31).sum())))
-    assert used[1:4] == [64, 32, 16] and used[4] in (64, 32, 16) and used[5] == used[4] == used[6], used
-    assert gpu.get_param("expand_autotune_settled") == 1
-    assert len(set(sums)) == 1, sums
-    assert bool((job.diag == -1).all())
-    gpu.set_param("expand_autotune", 0)
-    job.expand(); torch.cuda.synchronize()
-    assert gpu.get_param("expand_drain_min") == 32          # 2 x 20 MB pools, no trials
-    gpu.set_param("expand_autotune", 1)
-    gpu.set_param("expand_variant", pc.DEFAULT_EXPAND_VARIANT)
-    gpu.reset_stream()
-
-
-def test_output_arena_placed_by_the_job(gpu):
-    """wga_paf2maf_expand_place (the library's placement policy for a long-lived caller's output arena): the batch's rows are
-    written into every candidate, the one the row kernel was fastest on comes back holding them — the rows of any other
-    buffer; wga_arena_alloc / wga_arena_probe (plain patterns, measurements) answer too"""
+def test_caller_owned_output_buffer(gpu):
+    """the rows go where the caller says: a buffer of its own gives the bytes of a library-side allocation, a buffer that is
+    too small is refused by the driver class before any launch"""
     import torch
     from wgatools_amd import pipeline
     dev = torch.device("cuda", 0)
     tb = synth.make_paf_batch_torch(78, 600, 3000, 5_000_000, dev)
     gpu.set_stream(torch.cuda.current_stream().cuda_stream)
-    a = pipeline.Paf2MafStatJob(gpu, tb, place=3)
-    assert a.out is None
-    info = a.place_output()
-    ms = info["k2_ms_by_candidate"]
-    assert len(ms) == 3 and all(m > 0 for m in ms) and 0 <= info["chosen"] < 3 and ms[info["chosen"]] == min(ms)
-    assert a.out.data_ptr() == a.arena.ptr and a.out.numel() == a.out_bytes + 64
     b = pipeline.Paf2MafStatJob(gpu, tb)
     b.out.fill_(0x23)
     b.step()
-    torch.cuda.synchronize()
-    assert bool((a.out[:a.out_bytes] == b.out[:b.out_bytes]).all()) and bool((a.diag == -1).all())
-    a.out.fill_(0x23)          # a later batch into the kept arena: the plain call
+    arena = torch.full((b.out_bytes * 2,), 0x23, dtype=torch.uint8, device=dev)
+    a = pipeline.Paf2MafStatJob(gpu, tb, out=arena)
     a.step()
     torch.cuda.synchronize()
-    assert bool((a.out[:a.out_bytes] == b.out[:b.out_bytes]).all())
-    one = pipeline.Paf2MafStatJob(gpu, tb, place=1)     # candidates <= 1: an allocation and the plain call
-    assert one.place_output()["chosen"] == 0
-    torch.cuda.synchronize()
-    assert bool((one.out[:one.out_bytes] == b.out[:b.out_bytes]).all())
-    arena, rates, chosen = gpu.arena_alloc(1 << 24, 3)
-    assert len(rates) == 3 and all(r > 0 for r in rates) and rates[chosen] == max(rates)
-    for kind in (0, 1, 3, 5, 6):
-        assert gpu.arena_probe(arena, 1 << 24, kind) > 0
-    arena.free()
+    assert a.out.data_ptr() == arena.data_ptr()
+    assert bool((a.out[:a.out_bytes] == b.out[:b.out_bytes]).all()) and bool((a.diag == -1).all())
     small = torch.empty(16, dtype=torch.uint8, device=dev)
     with pytest.raises(ValueError):
         pipeline.Paf2MafStatJob(gpu, tb, out=small)

@@ -42,8 +42,6 @@ PROTOTYPES = {
     "wga_ctx_expand_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "wga_sync": (C.c_int, [vp]),
     "wga_malloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
-    "wga_arena_alloc": (C.c_int, [vp, C.c_size_t, C.c_int, C.POINTER(vp), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
-    "wga_arena_probe": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "wga_free": (C.c_int, [vp, vp]),
     "wga_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "wga_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
@@ -58,9 +56,6 @@ PROTOTYPES = {
     "wga_paf2maf_layout": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "wga_paf2maf_expand": (C.c_int, [vp, C.POINTER(CigarBatch), vp, vp, vp, C.c_uint64, vp, vp,
                                      vp, C.c_uint64, vp, vp, vp, vp, vp, vp]),
-    "wga_paf2maf_expand_place": (C.c_int, [vp, C.POINTER(CigarBatch), vp, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp,
-                                           vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(vp), C.POINTER(C.c_double),
-                                           C.POINTER(C.c_int)]),
     "wga_scatter_bytes": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp]),
     "wga_maf_pair_stat": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "wga_maf_call_runs": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp]),

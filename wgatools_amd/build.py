@@ -88,7 +88,7 @@ def build_hip(force=False, verbose=False):
         raise RuntimeError("hipcc not found: libwgahip.so cannot be built here")
     objs = []
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall"] + STAGE2
-    flags += os.environ.get("WGA_EXTRA_FLAGS", "").split()  # e.g. -DWGA_PROFILE (ablation knobs)
+    flags += os.environ.get("WGA_EXTRA_FLAGS", "").split()  # A/B builds (see build_hip_variant)
     for src, xflag in (("wga_capi.cpp", ["-x", "hip"]), ("wga_pack.cpp", [])):
         obj = os.path.join(CSRC, src.replace(".cpp", ".o"))
         out = _run([hipcc] + flags + xflag + ["-c", os.path.join(CSRC, src), "-o", obj])
@@ -126,8 +126,7 @@ def build_emu(force=False):
     if not force and not _newer(EMU_LIB, srcs):
         return EMU_LIB
     # -DWGA_MAF_FOLD_STEPS: fold the MAF walks' 16-bit lane counters every 3 steps, so that small test rows reach that path
-    # -DWGA_TUNE_MIN_TILES: the drain_min trials of wga_paf2maf_expand start at 2 tiles, so that test batches run them
-    _run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DWGA_EMU", "-DWGA_MAF_FOLD_STEPS=3u", "-DWGA_TUNE_MIN_TILES=2ull", "-Wall",
+    _run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DWGA_EMU", "-DWGA_MAF_FOLD_STEPS=3u", "-Wall",
           "-Wno-unknown-pragmas", "-I" + os.path.join(ROOT, "tests", "emu")] + STAGE2
          + [os.path.join(CSRC, "wga_capi.cpp"), os.path.join(CSRC, "wga_pack.cpp"), "-o", EMU_LIB])
     return EMU_LIB

@@ -26,26 +26,12 @@ struct wga_ctx {
   wga_stream_t stream = nullptr;
   int expand_force_slow = 0;
   int expand_no_table = 0;
-  unsigned expand_drain_min = 0; /* 0 = by the size of the pools, refined by trial (below) */
-  bool expand_autotune = true;
-  /* The cost of emitting gap-touching chunks late (lines wait half written in the L2) depends on where the output buffer
-   * lies in HBM: on one and the same buffer drain_min 64 / 32 / 16 measure 6.46 / 6.67 / 6.92 ms, on the next one 7.19 /
-   * 6.87 / 6.92 (profiles/r02_k2_experiments.md, section 8).  The bytes written do not depend on it, so the first
-   * launches on an output buffer try the candidates on live work and the fastest per tile stays. */
-  struct DrainTune {
-    const void* out = nullptr;
-    int phase = 0; /* 0: the next launch warms the buffer; 1..3: trials; 4: read the last trial; 5: settled */
-    bool pending = false, have_ev = false;
-    unsigned cur = 0, best = 0, last = 0;
-    double best_ms = 0.0;
-    uint64_t tiles = 0;
-    rt_event_t ev[2];
-  } tune;
+  unsigned expand_drain_min = 0; /* v1 only: 0 = by the size of the pools (WGA_DRAIN_POOL_BYTES: 32, 16 for genome-sized pools) */
+  unsigned expand_drain_min_used = 0;
   uint64_t op_long_ops = 16384;  /* op walks with one wave per record (K7 call events, K12 dotplot segments): records beyond this many ops ... */
   uint64_t op_piece_ops = 8192;  /* ... are walked in pieces of this many (a multiple of 256), one wave each (test knobs: "op_long_ops", "op_piece_ops") */
   uint64_t maf_long_cols = 32768;  /* MAF blocks beyond this many columns are walked piece by piece ... */
   uint64_t maf_piece_cols = 16384; /* ... of this many columns, one wave each (test knobs: "maf_long_cols", "maf_piece_cols") */
-  int expand_alias = 0;   /* 1: launch the row kernel under its second name (k_paf2maf_expand_alias) */
   int expand_variant = -1; /* the row kernel: -1 by the batch (records below WGA_AUTO_SHORT_OPS ops on average take the window
                               kernel of wga_kernels_k2w.h, longer ones v1), 0 v1 (wga_kernels.h), 2 the window kernel */
   int expand_variant_used = 0;
@@ -483,7 +469,6 @@ int wga_ctx_create(int device, wga_ctx** out) {
   /* A/B switch for measurements: WGA_EXPAND_VARIANT=0 selects v1 of the paf2maf row kernel (wga_ctx_set_param overrides) */
   if (const char* v = getenv("WGA_EXPAND_VARIANT")) c->expand_variant = (atoi(v) == 0 || atoi(v) == 2 || atoi(v) == 3) ? atoi(v) : -1;
   if (const char* v = getenv("WGA_COV_SPIN_LIMIT")) c->cov_spin_limit = (u32)strtoul(v, nullptr, 10);
-  if (const char* v = getenv("WGA_EXPAND_AUTOTUNE")) c->expand_autotune = atoi(v) != 0;
   if (const char* v = getenv("WGA_EXPAND_DRAIN_MIN")) {
     const int d = atoi(v);
     if (d >= 0 && d <= 64) c->expand_drain_min = (unsigned)d;
@@ -498,7 +483,6 @@ void wga_ctx_destroy(wga_ctx* c) {
   (void)rt_sync(c->stream);
   if (c->timing)
     for (int k = 0; k < 2 * wga_ctx::kTimingRing; k++) rt_event_destroy(c->ev[k]);
-  if (c->tune.have_ev) rt_event_destroy(c->tune.ev[0]), rt_event_destroy(c->tune.ev[1]);
   if (c->rs_have_ev) rt_event_destroy(c->rs_ready), rt_event_destroy(c->rs_done);
   for (rt_event_t e : c->rs_copied) rt_event_destroy(e);
   for (wga_stream_t st : c->rs_streams) rt_stream_destroy(st);
@@ -556,13 +540,6 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
     c->expand_drain_min = (unsigned)value;
     return WGA_OK;
   }
-  if (strcmp(name, "expand_autotune") == 0) {
-    c->expand_autotune = value != 0;
-    c->tune.out = nullptr; /* what was learnt is forgotten */
-    c->tune.phase = 0;
-    c->tune.pending = false;
-    return WGA_OK;
-  }
   if (strcmp(name, "expand_no_table") == 0) {
     c->expand_no_table = value != 0;
     return WGA_OK;
@@ -585,10 +562,6 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
   if (strcmp(name, "expand_variant") == 0) {
     if (value != -1 && value != 0 && value != 2 && value != 3) return fail(WGA_E_INVALID_ARG, "expand_variant: -1 (by the batch), 0, 2, 3", nullptr);
     c->expand_variant = (int)value;
-    return WGA_OK;
-  }
-  if (strcmp(name, "expand_alias") == 0) {
-    c->expand_alias = value != 0;
     return WGA_OK;
   }
   if (strcmp(name, "expand_job_tiles") == 0) { /* streaming row kernel: consecutive tiles per wave */
@@ -636,88 +609,6 @@ int wga_malloc(wga_ctx* c, size_t bytes, void** d_out) {
   if (e) return fail(WGA_E_OOM, "device allocation", e);
   return WGA_OK;
 }
-int wga_arena_alloc(wga_ctx* c, size_t bytes, int candidates, void** d_out, double* gbps_by_candidate, int* chosen) {
-  int rc = ctx_bind(c);
-  if (rc) return rc;
-  if (!d_out) return fail(WGA_E_INVALID_ARG, "d_out is null", nullptr);
-  if (candidates > 64) candidates = 64;
-  if (gbps_by_candidate)
-    for (int k = 0; k < candidates; k++) gbps_by_candidate[k] = 0.0;
-  if (chosen) *chosen = 0;
-  const u64 half = (u64)bytes / 32u; /* granules per half */
-  if (candidates <= 1 || half == 0) return wga_malloc(c, bytes, d_out);
-  void* cand[64];
-  int n = 0;
-  for (; n < candidates; n++) {
-    if (rt_malloc(&cand[n], bytes)) break; /* out of memory: fewer candidates */
-  }
-  if (n == 0) return fail(WGA_E_OOM, "device allocation", "no memory for one candidate");
-  rt_event_t ev[2];
-  int n_ev = 0; /* events created: only those are destroyed */
-  const char* e = rt_event_create(&ev[0]);
-  if (!e) n_ev = 1, e = rt_event_create(&ev[1]);
-  if (!e) n_ev = 2;
-  int best = 0;
-  double best_ms = 0.0;
-  const u32 grid = (u32)(half / 256u < 65536u ? (half + 255u) / 256u : 65536u);
-  for (int k = 0; k < n && !e; k++) {
-    WGA_LAUNCH(k_arena_probe, grid, WGA_BLOCK, c->stream, (u32x4_a16*)cand[k], half, 0); /* first touch */
-    if ((e = rt_event_record(ev[0], c->stream))) break;
-    WGA_LAUNCH(k_arena_probe, grid, WGA_BLOCK, c->stream, (u32x4_a16*)cand[k], half, 1);
-    WGA_LAUNCH(k_arena_probe, grid, WGA_BLOCK, c->stream, (u32x4_a16*)cand[k], half, 0);
-    if ((e = rt_event_record(ev[1], c->stream))) break;
-    float ms = 0.0f;
-    if ((e = rt_event_elapsed_ms(ev[0], ev[1], &ms))) break;
-    if ((e = rt_launch_error())) break;
-    if (gbps_by_candidate) gbps_by_candidate[k] = ms > 0.0f ? 4.0 * 16.0 * (double)half / ((double)ms * 1e6) : 0.0;
-    if (k == 0 || (double)ms < best_ms) best = k, best_ms = (double)ms;
-  }
-  if (!e) e = rt_sync(c->stream);
-  for (int k = 0; k < n_ev; k++) rt_event_destroy(ev[k]);
-  for (int k = 0; k < n; k++)
-    if (e || k != best) (void)rt_free(cand[k]);
-  if (e) return fail(WGA_E_HIP, "arena probe", e);
-  *d_out = cand[best];
-  if (chosen) *chosen = best;
-  return WGA_OK;
-}
-int wga_arena_probe(wga_ctx* c, void* d_buf, size_t bytes, int kind, double* gbps) {
-  int rc = ctx_bind(c);
-  if (rc) return rc;
-  if (!d_buf || !gbps || kind < 0 || kind > 13 || bytes < 4096 || ((uintptr_t)d_buf & 15u))
-    return fail(WGA_E_INVALID_ARG, "buffer, rate or kind", nullptr);
-  *gbps = 0.0;
-  rt_event_t ev[2];
-  const char* e = rt_event_create(&ev[0]);
-  if (!e && (e = rt_event_create(&ev[1]))) rt_event_destroy(ev[0]);
-  if (e) return fail(WGA_E_HIP, "arena probe", e);
-  const u64 n = (u64)bytes / 16u, half = n / 2u;
-  const u64 per_xcd = ((n >> 3) + 255u) / 256u; /* kinds >= 6: blocks per XCD, a multiple of 8 in all */
-  const u32 grid = kind >= 6 ? 8u * (u32)(per_xcd < 8192u ? (per_xcd ? per_xcd : 1u) : 8192u)
-                             : (u32)(half / 256u < 65536u ? (half + 255u) / 256u : 65536u);
-  double moved = 0.0;
-  for (int pass = 0; pass < 3 && !e; pass++) { /* pass 0: first touch */
-    if (pass == 1) e = rt_event_record(ev[0], c->stream);
-    if (e) break;
-    if (kind == 0) {
-      WGA_LAUNCH(k_arena_probe, grid, WGA_BLOCK, c->stream, (u32x4_a16*)d_buf, half, pass & 1);
-      if (pass) moved += 32.0 * (double)half;
-    } else {
-      WGA_LAUNCH(k_arena_probe_fill, grid, WGA_BLOCK, c->stream, (u32x4_a16*)d_buf, n,
-                 kind == 1 ? 0u : kind == 2 ? 16u : kind == 3 ? 12u : kind == 4 ? 40u : kind == 5 ? 44u : 64u + (u32)(kind - 6), (u32)pass);
-      if (pass) moved += 16.0 * (double)n;
-    }
-    e = rt_launch_error();
-  }
-  if (!e) e = rt_event_record(ev[1], c->stream);
-  float ms = 0.0f;
-  if (!e) e = rt_event_elapsed_ms(ev[0], ev[1], &ms);
-  rt_event_destroy(ev[0]);
-  rt_event_destroy(ev[1]);
-  if (e) return fail(WGA_E_HIP, "arena probe", e);
-  *gbps = ms > 0.0f ? moved / ((double)ms * 1e6) : 0.0;
-  return WGA_OK;
-}
 /* What a count call left for its fill call (the K11 scan, the piece table of K7 / K10 / K12, pafpseudo's class sums) is keyed
  * by the arrays it was made from.  Writing into one of those arrays through the library, or freeing it, drops it: a fill call
  * then computes its own.  [lo, lo + bytes) is the range written (bytes == 0: the allocation that starts at lo). */
@@ -741,12 +632,6 @@ static void ctx_arrays_written(wga_ctx* c, const void* lo, size_t bytes) {
 int wga_free(wga_ctx* c, void* d_ptr) {
   int rc = ctx_bind(c);
   if (rc) return rc;
-  if (d_ptr && d_ptr == c->tune.out) { /* a later buffer at the same address learns for itself */
-    if (c->tune.pending) (void)rt_sync(c->stream);
-    c->tune.out = nullptr;
-    c->tune.phase = 0;
-    c->tune.pending = false;
-  }
   if (d_ptr) ctx_arrays_written(c, d_ptr, 0); /* what a count call left for its fill call does not outlive the arrays it was made from */
   if (d_ptr) RT_CHECK(rt_free(d_ptr));
   return WGA_OK;
@@ -1052,52 +937,9 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
   const bool windows = variant == 2;
   const bool stream = variant == 3;
   /* when the gap-touching chunks are emitted (RowSrc::drain_min) */
-  bool tune_timed = false;
-  {
-    const unsigned dflt = (u64)t_fa_bytes + (u64)q_fa_bytes > WGA_DRAIN_POOL_BYTES ? 16u : 32u;
-    unsigned dm = dflt;
-    wga_ctx::DrainTune& T = c->tune;
-    if (c->expand_drain_min) {
-      dm = c->expand_drain_min;
-    } else if (c->expand_autotune && !windows && !stream && (u64)nt >= WGA_TUNE_MIN_TILES) {
-      if (!T.have_ev) {
-        const char* e = rt_event_create(&T.ev[0]);
-        if (!e && (e = rt_event_create(&T.ev[1]))) rt_event_destroy(T.ev[0]);
-        if (e) return fail(WGA_E_HIP, "rt_event_create", e);
-        T.have_ev = true;
-      }
-      /* what was learnt belongs to one buffer and one size of work: another pointer, or a launch of less than half / more
-       * than twice the tiles the trials ran on, starts over (a buffer freed through wga_free is forgotten there) */
-      const bool resized = T.phase > 1 && T.tiles && ((uint64_t)nt > 2 * T.tiles || 2 * (uint64_t)nt < T.tiles);
-      if (T.out != (const void*)d_out || resized) {
-        T.out = (const void*)d_out;
-        T.phase = 0;
-        T.pending = false;
-      }
-      if (T.pending) { /* the trial launched by the previous call */
-        float ms = 0.0f;
-        RT_CHECK(rt_event_elapsed_ms(T.ev[0], T.ev[1], &ms));
-        const double per_tile = (double)ms / (double)T.tiles;
-        if (T.best == 0u || per_tile < T.best_ms) T.best_ms = per_tile, T.best = T.cur;
-        T.pending = false;
-      }
-      static const unsigned cand[3] = {64u, 32u, 16u};
-      if (T.phase == 0) { /* first touch of the buffer: not timed */
-        T.best = 0u;
-        T.phase = 1;
-      } else if (T.phase <= 3) {
-        dm = T.cur = cand[T.phase - 1];
-        T.tiles = (uint64_t)nt;
-        T.phase++;
-        tune_timed = true;
-      } else {
-        dm = T.best ? T.best : dflt;
-        T.phase = 5;
-      }
-    }
-    T.last = dm;
-    a.drain_min = dm;
-  }
+  /* when v1's waves emit their queued gap-touching chunks (RowSrc::drain_min) */
+  a.drain_min = c->expand_drain_min ? c->expand_drain_min : ((u64)t_fa_bytes + (u64)q_fa_bytes > WGA_DRAIN_POOL_BYTES ? 16u : 32u);
+  c->expand_drain_min_used = a.drain_min;
   if (windows) { /* part of the pre-pass: the tiles for the op-serial walk, the prepared pieces of one-segment tiles */
     RT_CHECK(rt_memset(wide_counts, 0, 256, c->stream));
     WGA_LAUNCH(k_list_slow_tiles, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const wga_tile_desc*)tdesc, (u64)nt,
@@ -1124,10 +966,7 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
   if (c->timing) RT_CHECK(rt_event_record(c->ev[2 * slot], c->stream));
   if (stream) {
     const u64 jobs = (nt + a.job_tiles - 1) / a.job_tiles;
-    if (c->expand_alias)
-      WGA_LAUNCH(k_paf2maf_expand_s_alias, (u32)jobs, 128u, c->stream, a);
-    else
-      WGA_LAUNCH(k_paf2maf_expand_s, (u32)jobs, 128u, c->stream, a);
+    WGA_LAUNCH(k_paf2maf_expand_s, (u32)jobs, 128u, c->stream, a);
     LAUNCH_CHECK();
     const u32 side_grid = nt < 256 ? (u32)nt : 256u;
     a.tile_count = wide_counts; /* tiles of records that are not clean, tiles beyond 2^24 columns: v1's row emitters */
@@ -1141,10 +980,7 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
     LAUNCH_CHECK();
   } else if (windows) {
     /* the window kernel; tiles beyond 2^31 columns (and every tile under "expand_force_slow") are listed for v1's op-serial walk */
-    if (c->expand_alias)
-      WGA_LAUNCH(k_paf2maf_expand_w_alias, (u32)nt, WGA_BLOCK, c->stream, a);
-    else
-      WGA_LAUNCH(k_paf2maf_expand_w, (u32)nt, WGA_BLOCK, c->stream, a);
+    WGA_LAUNCH(k_paf2maf_expand_w, (u32)nt, WGA_BLOCK, c->stream, a);
     LAUNCH_CHECK();
     a.force_slow = 1;
     a.tile_count = wide_counts;
@@ -1153,16 +989,8 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
     WGA_LAUNCH(k_paf2maf_expand_list, side_grid, WGA_BLOCK, c->stream, a);
     LAUNCH_CHECK();
   } else {
-    if (tune_timed) RT_CHECK(rt_event_record(c->tune.ev[0], c->stream));
-    if (c->expand_alias)
-      WGA_LAUNCH(k_paf2maf_expand_alias, (u32)nt, WGA_BLOCK, c->stream, a);
-    else
-      WGA_LAUNCH(k_paf2maf_expand, (u32)nt, WGA_BLOCK, c->stream, a);
+    WGA_LAUNCH(k_paf2maf_expand, (u32)nt, WGA_BLOCK, c->stream, a);
     LAUNCH_CHECK();
-    if (tune_timed) {
-      RT_CHECK(rt_event_record(c->tune.ev[1], c->stream));
-      c->tune.pending = true;
-    }
   }
   if (c->timing) {
     RT_CHECK(rt_event_record(c->ev[2 * slot + 1], c->stream));
@@ -1174,11 +1002,7 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
 int wga_ctx_get_param(wga_ctx* c, const char* name, int64_t* value) {
   if (!c || !name || !value) return fail(WGA_E_INVALID_ARG, "null argument", nullptr);
   if (strcmp(name, "expand_drain_min") == 0) { /* what the last wga_paf2maf_expand used */
-    *value = (int64_t)c->tune.last;
-    return WGA_OK;
-  }
-  if (strcmp(name, "expand_autotune_settled") == 0) {
-    *value = c->tune.phase == 5 ? 1 : 0;
+    *value = (int64_t)c->expand_drain_min_used;
     return WGA_OK;
   }
   if (strcmp(name, "expand_variant") == 0) {
@@ -1237,72 +1061,6 @@ int wga_ctx_expand_timing(wga_ctx* c, double* ms_sum, uint32_t* launches) {
   }
   *launches = n;
   c->ev_n = 0;
-  return WGA_OK;
-}
-
-int wga_paf2maf_expand_place(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_counts* d_counts, const void* d_tile_ws,
-                             const uint8_t* d_t_fa, uint64_t t_fa_bytes, const uint64_t* d_t_src_off,
-                             const uint64_t* d_t_src_len, const uint8_t* d_q_fa, uint64_t q_fa_bytes,
-                             const uint64_t* d_q_src_off, const uint64_t* d_q_src_len, const uint64_t* d_t_row_off,
-                             const uint64_t* d_q_row_off, wga_rec_diag* d_diag, size_t arena_bytes, int candidates,
-                             void** d_out, double* ms_by_candidate, int* chosen) {
-  int rc = ctx_bind(c);
-  if (rc) return rc;
-  if (!d_out || arena_bytes == 0) return fail(WGA_E_INVALID_ARG, "d_out is null or the arena is empty", nullptr);
-  if (candidates < 1) candidates = 1;
-  if (candidates > 64) candidates = 64;
-  if (ms_by_candidate)
-    for (int k = 0; k < candidates; k++) ms_by_candidate[k] = 0.0;
-  if (chosen) *chosen = 0;
-  { /* the row kernel's scratch (record / tile descriptors, lists) is sized BEFORE the candidates take what is left of the
-     * memory: a trial launch that had to grow it would fail where a launch on one arena would not */
-    const u64 nt0 = n_tiles(b->n_ops);
-    void* ws0;
-    const size_t need = (((size_t)b->n * sizeof(wga_rec_desc) + 255) & ~(size_t)255) + (size_t)nt0 * sizeof(wga_tile_desc) + 256 +
-                        2 * (size_t)nt0 * sizeof(u32) + (size_t)nt0 * WGA_W_PLAN_WORDS * sizeof(u32) + (((size_t)nt0 + 255) & ~(size_t)255);
-    if ((rc = ctx_scratch(c, need, &ws0))) return rc;
-  }
-  void* cand[64];
-  int n = 0;
-  for (; n < candidates; n++)
-    if (rt_malloc(&cand[n], arena_bytes)) break; /* out of memory: fewer candidates */
-  if (n == 0) return fail(WGA_E_OOM, "device allocation", "no memory for one candidate");
-  rt_event_t ev[2];
-  int n_ev = 0; /* events created: only those are destroyed */
-  const char* e = rt_event_create(&ev[0]);
-  if (!e) n_ev = 1, e = rt_event_create(&ev[1]);
-  if (!e) n_ev = 2;
-  /* the trials of drain_min (per output buffer) wait until the buffer is chosen; the timing ring is the caller's */
-  const bool autotune = c->expand_autotune, timing = c->timing;
-  c->expand_autotune = false;
-  c->timing = false;
-  int best = 0;
-  double best_ms = 0.0;
-  for (int k = 0; k < n && !e && !rc; k++) {
-    const int launches = n > 1 ? 3 : 1; /* the first one touches the buffer */
-    for (int l = 0; l < launches && !rc && !e; l++) {
-      if (l == 1) e = rt_event_record(ev[0], c->stream);
-      if (!e)
-        rc = wga_paf2maf_expand(c, b, d_counts, d_tile_ws, d_t_fa, t_fa_bytes, d_t_src_off, d_t_src_len, d_q_fa, q_fa_bytes,
-                                d_q_src_off, d_q_src_len, (uint8_t*)cand[k], d_t_row_off, d_q_row_off, d_diag);
-    }
-    if (rc || e || n == 1) break;
-    if ((e = rt_event_record(ev[1], c->stream))) break;
-    float ms = 0.0f;
-    if ((e = rt_event_elapsed_ms(ev[0], ev[1], &ms))) break;
-    if (ms_by_candidate) ms_by_candidate[k] = (double)ms / 2.0;
-    if (k == 0 || (double)ms < best_ms) best = k, best_ms = (double)ms;
-  }
-  c->expand_autotune = autotune;
-  c->timing = timing;
-  if (!e && !rc) e = rt_sync(c->stream);
-  for (int k = 0; k < n_ev; k++) rt_event_destroy(ev[k]);
-  for (int k = 0; k < n; k++)
-    if (e || rc || k != best) (void)rt_free(cand[k]);
-  if (rc) return rc;
-  if (e) return fail(WGA_E_HIP, "output placement", e);
-  *d_out = cand[best];
-  if (chosen) *chosen = best;
   return WGA_OK;
 }
 

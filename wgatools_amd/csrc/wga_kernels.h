@@ -301,7 +301,11 @@ __device__ __forceinline__ void cigar_stat_tile(const u64 g, const u32 (&w)[16],
         if (whole)
           f[lane] = v; /* the record lives in this tile only: plain stores */
         else if (v)
+#ifdef WGA_K1_NO_ATOMICS /* A/B builds only (wrong counts for records across tiles): what the atomics cost */
+          f[lane] = v;
+#else
           atomicAdd(f + lane, v); /* record spans tiles: counts were zeroed by the launcher */
+#endif
       }
       if (lane == 0 && BAD != 0xFFFFFFFFu) atomicMin((u64*)&diag[r].bad_op_idx, tile_start + BAD - rs);
     }
@@ -535,9 +539,6 @@ __global__ __launch_bounds__(256) void k_layout_rows(ScanLayout f, u32 n, const 
                              instructions) but lets the lines its chunks belong to wait half written in the L2; 16 completes them
                              at once.  Same buffers, one process (scripts/gpu_k2_same_buffers.py): with 2 x 50 MB pools 64 / 32 /
                              16 = 6.19 / 6.44 / 6.66 ms, with 2 x 1 GB pools (the L2 churns with source lines) 8.65 / 8.07 / 7.85 */
-#endif
-#ifndef WGA_TUNE_MIN_TILES
-#define WGA_TUNE_MIN_TILES 8192ull /* launches below this (8 M ops) are too short to compare drain_min settings on */
 #endif
 #ifndef WGA_DRAIN_POOL_BYTES
 #define WGA_DRAIN_POOL_BYTES (192ull << 20) /* sequence pools beyond this (together) do not stay in the 256 MB Infinity Cache */
@@ -1663,11 +1664,6 @@ __global__ __launch_bounds__(256, WGA_K2_BLOCKS) void k_paf2maf_expand(ExpandArg
   expand_tile_v1(a, xcd_tile_of_block());
 }
 
-/* the same kernel under a second name ("expand_alias"): a harness that also runs other shapes / buffers in the process
- * launches those here, so that per-kernel profiler statistics of k_paf2maf_expand hold the measured workload only */
-__global__ __launch_bounds__(256, WGA_K2_BLOCKS) void k_paf2maf_expand_alias(ExpandArgs a) {
-  expand_tile_v1(a, xcd_tile_of_block());
-}
 
 __global__ __launch_bounds__(256, 4) void k_paf2maf_expand_list(ExpandArgs a) {
   const u32 n_list = *a.tile_count;
@@ -1686,50 +1682,6 @@ __global__ __launch_bounds__(256) void k_scatter_bytes(u32 n, const u8* src, con
   if (i >= n) return;
   const u64 s0 = src_off[i], s1 = src_off[i + 1], d0 = dst_off[i];
   for (u64 k = s0 + lane; k < s1; k += 64) dst[d0 + (k - s0)] = src[k];
-}
-
-/* ---- wga_arena_alloc: a plain streaming copy inside a candidate buffer (16 B per thread, coalesced) ----------- */
-__global__ __launch_bounds__(256) void k_arena_probe(u32x4_a16* buf, u64 half /* granules */, int dir) {
-  const u32x4_a16* src = dir ? buf + half : buf;
-  u32x4_a16* dst = dir ? buf : buf + half;
-  const u64 stride = (u64)gridDim.x * 256u;
-  for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < half; i += stride) dst[i] = src[i];
-}
-/* ---- wga_arena_probe, kinds 1 .. 3: write-only patterns (measurements: which plain pattern ranks buffers as the row kernel
- *      does).  1: a streaming fill.  2 / 3: the fill with every 128-byte line written in eight 16-byte pieces that arrive
- *      `lines` x 16 bytes of other writes apart (lines = 65536 / 4096): lines wait partly written, as the rows' lines do
- *      when a gap-touching chunk is emitted late.  4 / 5: whole 4 KiB / 64 KiB chunks at scattered places (many pages in flight). */
-__global__ __launch_bounds__(256) void k_arena_probe_fill(u32x4_a16* buf, u64 n /* granules */, u32 lines_log2, u32 seed) {
-  const u64 stride = (u64)gridDim.x * 256u;
-  u32x4_a16 v;
-  v[0] = v[1] = v[2] = v[3] = seed;
-  if (lines_log2 == 0u) {
-    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) buf[i] = v;
-    return;
-  }
-  if (lines_log2 >= 64u) { /* every XCD (block b runs on XCD b % 8) streams through one eighth of the buffer, as the row kernel's
-                              tiles do; eighth = (XCD + rot) % 8 */
-    const u32 rot = lines_log2 - 64u, x = ((blockIdx.x & 7u) + rot) & 7u;
-    const u64 region = n >> 3, per = (u64)(gridDim.x >> 3) * 256u;
-    u32x4_a16* const dst = buf + (u64)x * region;
-    for (u64 i = (u64)(blockIdx.x >> 3) * 256u + threadIdx.x; i < region; i += per) dst[i] = v;
-    return;
-  }
-  if (lines_log2 >= 32u) { /* whole chunks of 2^(lines_log2 - 32) granules, scattered over the buffer (a prime stride) */
-    const u32 cl = lines_log2 - 32u;
-    const u64 nch = n >> cl;
-    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < (nch << cl); i += stride) {
-      const u64 c = i >> cl;
-      buf[(((c * 2654435761ull) % nch) << cl) | (i & ((1ull << cl) - 1u))] = v;
-    }
-    return;
-  }
-  const u64 L = 1ull << lines_log2, W = 8ull * L; /* granules per window */
-  for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += stride) {
-    const u64 w = i / W, r = i - w * W;
-    const u64 g = w * W + (r & (L - 1u)) * 8u + (r >> lines_log2); /* piece r / L of line r % L */
-    if (g < n) buf[g] = v;
-  }
 }
 
 /* ---- wga_reduce_scatter_i32: dst[i] += the sum of src[k][i] over up to WGA_PEER_MAX source arrays (n counters) ----------------

@@ -737,7 +737,6 @@ __device__ __forceinline__ void pseudo_stream(const ExpandArgs& a) {
 #define WGA_S_WAVES_PER_SIMD 5 /* launch bound: 96 VGPRs (the natural need is 102: two spill slots), LDS allows 31 waves per CU; 4: 6.0 ms, 5: 5.66 ms, 6 (61 spill slots): 7.4 ms */
 #endif
 __global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_paf2maf_expand_s(ExpandArgs a) { expand_stream(a); }
-__global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_paf2maf_expand_s_alias(ExpandArgs a) { expand_stream(a); }
 __global__ __launch_bounds__(128, WGA_S_WAVES_PER_SIMD) void k_pafpseudo_stream(ExpandArgs a) { pseudo_stream<WGA_S_PSEUDO>(a); }
 #ifndef WGA_S_SYM_WAVES
 #define WGA_S_SYM_WAVES 5 /* 5: 3.87 ms, 6 (80 VGPRs, 12 spill slots): 3.97, 7: 4.34, 8: 5.80 (configs[1]'s batch) */

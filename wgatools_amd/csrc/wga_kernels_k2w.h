@@ -505,16 +505,11 @@ __device__ __forceinline__ void emit_window(KArgP a, const u32* rec, u32 w, cons
   }
   WGA_WAVE_SYNC();
 
-#if defined(WGA_W_ABLATE) && WGA_W_ABLATE == 3 /* ... + search, table, plain fill, copy-out: no fix-up passes */
-  if (sp.N != 0xFFFFFFFFu) f0.own = false;
-#endif
   /* ---- fix-ups: one lane per event of the window (and the gap that reaches in from the front) ------------------- */
   if (fix1_finish<RC>(f0, sp, cw0, e_rd, stage, lowmask)) badmask |= 0x80000000u;
   const int g0_mine = f0.g0;
   WGA_WAVE_SYNC();
-#if !(defined(WGA_W_ABLATE) && WGA_W_ABLATE == 3)
   fix23(evw, cw0, (bool)((int)act0 | (int)cover0), cover0, stage, lowmask, lane);
-#endif
   WGA_WAVE_SYNC();
   for (int e0 = e_lo + 63; e0 < e_hi; e0 += 64) { /* more than 63 events in one window: indel-dense stretches */
     const int e = e0 + (int)lane;
@@ -931,9 +926,6 @@ __device__ __forceinline__ void expand_tile_w(const ExpandArgs& a, const u64 g) 
     }
   }
   __syncthreads();
-#if defined(WGA_W_ABLATE) && WGA_W_ABLATE == 1 /* instruction counts of phase A alone (measurements only: wrong output) */
-  return;
-#endif
 
   /* ---- phase B: rounds of 16 record segments: wave 0 plans the pieces, the four waves take their windows round robin --- */
   u32x4_a16* const stage = s_stage[wave];
@@ -971,7 +963,6 @@ __device__ __forceinline__ void expand_tile_w(const ExpandArgs& a, const u64 g) 
       nwin_all = WGA_UNI32(s_plan[1]);
       more = WGA_UNI32(s_plan[2]);
     }
-#if !(defined(WGA_W_ABLATE) && WGA_W_ABLATE == 2)
     u32 k = 0u; /* the piece that holds window wi */
     for (u32 wi = wave; wi < nwin_all; wi += 4u) {
       while (k + 1u < nspan && WGA_UNI32(s_span[(k + 1u) * WGA_W_SPAN_WORDS + WSP_W0]) <= wi) k++;
@@ -985,17 +976,12 @@ __device__ __forceinline__ void expand_tile_w(const ExpandArgs& a, const u64 g) 
       else
         emit_window<false>(ka, rec, w, s_col, s_cum, stage, s_lowmask, lane);
     }
-#endif
     if (!more) break;
     __syncthreads(); /* the table is rewritten by the next round */
   }
 }
 
 __global__ __launch_bounds__(256, WGA_K2W_BLOCKS) void k_paf2maf_expand_w(ExpandArgs a) {
-  expand_tile_w(a, xcd_tile_of_block());
-}
-
-__global__ __launch_bounds__(256, WGA_K2W_BLOCKS) void k_paf2maf_expand_w_alias(ExpandArgs a) { /* see k_paf2maf_expand_alias */
   expand_tile_w(a, xcd_tile_of_block());
 }
 

@@ -136,21 +136,6 @@ class Engine:
         self._check(self.lib.wga_malloc(self.ctx, max(n * dt.itemsize, 16), C.byref(ptr)))
         return DeviceArray(self, ptr.value, shape, dt)
 
-    def arena_alloc(self, nbytes, candidates=8):
-        """a large output arena placed by the library's probe (wga_arena_alloc: the fastest of `candidates` buffers for
-        a plain streaming copy) -> (DeviceArray u8, [probe GB/s per candidate], index kept)"""
-        ptr = C.c_void_p()
-        rates = (C.c_double * max(1, candidates))()
-        chosen = C.c_int(0)
-        self._check(self.lib.wga_arena_alloc(self.ctx, int(nbytes), int(candidates), C.byref(ptr), rates, C.byref(chosen)))
-        return DeviceArray(self, ptr.value, (int(nbytes),), np.uint8), [float(x) for x in rates][:max(1, candidates)], chosen.value
-
-    def arena_probe(self, buf, nbytes, kind=0):
-        """GB/s of probe pattern `kind` (wga_arena_probe) on a device buffer; its contents are overwritten"""
-        g = C.c_double(0.0)
-        self._check(self.lib.wga_arena_probe(self.ctx, _p(buf), int(nbytes), int(kind), C.byref(g)))
-        return g.value
-
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)
         d = self.empty(arr.shape, arr.dtype)
@@ -255,20 +240,6 @@ class Engine:
             self.ctx, C.byref(batch.c), _p(counts), _p(tile_ws), _p(t_fa), int(t_fa_bytes),
             _p(t_src_off), _p(t_src_len), _p(q_fa), int(q_fa_bytes), _p(q_src_off), _p(q_src_len),
             _p(out), _p(t_row_off), _p(q_row_off), _p(diag)))
-
-    def paf2maf_expand_place(self, batch, counts, tile_ws, t_fa, t_fa_bytes, t_src_off, t_src_len, q_fa, q_fa_bytes,
-                             q_src_off, q_src_len, t_row_off, q_row_off, diag, arena_bytes, candidates=8):
-        """the rows of the batch, written into the fastest of `candidates` output arenas for THIS job
-        (wga_paf2maf_expand_place) -> (DeviceArray u8 that owns the arena, [K2 ms per candidate], index kept)"""
-        ptr = C.c_void_p()
-        ms = (C.c_double * max(1, candidates))()
-        chosen = C.c_int(0)
-        self._check(self.lib.wga_paf2maf_expand_place(
-            self.ctx, C.byref(batch.c), _p(counts), _p(tile_ws), _p(t_fa), int(t_fa_bytes), _p(t_src_off), _p(t_src_len),
-            _p(q_fa), int(q_fa_bytes), _p(q_src_off), _p(q_src_len), _p(t_row_off), _p(q_row_off), _p(diag),
-            int(arena_bytes), int(candidates), C.byref(ptr), ms, C.byref(chosen)))
-        return (DeviceArray(self, ptr.value, (int(arena_bytes),), np.uint8), [float(x) for x in ms][:max(1, candidates)],
-                chosen.value)
 
     def bgzf_inflate(self, d_in, in_bytes, n_blocks, blocks, out, status):
         """BGZF members inflated on the device (wga_bgzf_inflate); blocks: n x (in_off u64, in_len u32, out_len u32, out_off u64)"""

@@ -304,30 +304,22 @@ struct Dev {
   T* upload(const std::vector<T>& v) { return upload(v.data(), v.size()); }
   template <typename T>
   void download(T* h, const T* d, size_t n) { check(wga_memcpy_d2h(ctx, h, d, n * sizeof(T))); }
-  /* The rows of paf2maf go into ONE device buffer for the whole run (it grows when a piece needs more): the row kernel's
-   * time depends on where its output lies in HBM and the library learns on the first launches that write to a buffer when
-   * to emit its queued chunks (include/wga_hip.h, "expand_drain_min") — a buffer per piece would start over every time. */
+  /* The rows of paf2maf go into ONE device buffer for the whole run (it grows when a piece needs more): a buffer per piece
+   * would pay the allocation and the first touch of gigabytes every time. */
   void* out_arena = nullptr;
   size_t out_arena_cap = 0;
-  /* true when the arena must be (re)allocated for `bytes`: the caller then lets the library place it for its job
-   * (wga_paf2maf_expand_place: the batch's rows are written into a few candidate arenas and the one the row kernel is
-   * fastest on stays); WGA_ARENA_CANDIDATES=1 takes the first allocation */
-  bool out_arena_needs(size_t bytes, size_t* cap, int* cand) {
-    if (bytes <= out_arena_cap) return false;
+  void out_arena_for(size_t bytes) {
+    if (bytes <= out_arena_cap) return;
     if (out_arena) {
       check(wga_sync(ctx));
       wga_free(ctx, out_arena);
       out_arena = nullptr;
       out_arena_cap = 0;
     }
-    *cap = bytes + bytes / 4;
-    /* four candidates cost about a dozen launches of the row kernel and save a few per cent of every later one: worth it
-     * from some hundred batches on (a file-to-file run is bound by its I/O long before) */
-    *cand = out_batches_ahead >= 128 ? 4 : 1;
-    if (const char* v = getenv("WGA_ARENA_CANDIDATES")) *cand = atoi(v);
-    return true;
+    const size_t cap = bytes + bytes / 4;
+    check(wga_malloc(ctx, cap, &out_arena));
+    out_arena_cap = cap;
   }
-  uint64_t out_batches_ahead = 0; /* set by the caller that knows how much work follows */
   void release(void* p) {
     auto it = std::find(owned.begin(), owned.end(), p);
     if (it != owned.end()) owned.erase(it);
@@ -941,16 +933,9 @@ uint32_t expand_batch(Dev& d, const wga_cigar_batch& cb, const ExpandJob& j, con
   d.download(qro.data(), d_qro, n);
   std::vector<wga_cigar_counts> counts(n);
   d.download(counts.data(), d_counts, n);
-  size_t arena_cap = 0;
-  int arena_cand = 1;
-  if (d.out_arena_needs(rec_off[n] + 64, &arena_cap, &arena_cand)) {
-    d.check(wga_paf2maf_expand_place(d.ctx, &cb, d_counts, d_tiles, d_tpool, t_bytes, d_to, d_tl, d_qpool, q_bytes, d_qo, d_ql,
-                                     d_tro, d_qro, d_diag, arena_cap, arena_cand, &d.out_arena, nullptr, nullptr));
-    d.out_arena_cap = arena_cap;
-  } else {
-    d.check(wga_paf2maf_expand(d.ctx, &cb, d_counts, d_tiles, d_tpool, t_bytes, d_to, d_tl, d_qpool, q_bytes, d_qo, d_ql,
-                               (uint8_t*)d.out_arena, d_tro, d_qro, d_diag));
-  }
+  d.out_arena_for(rec_off[n] + 64);
+  d.check(wga_paf2maf_expand(d.ctx, &cb, d_counts, d_tiles, d_tpool, t_bytes, d_to, d_tl, d_qpool, q_bytes, d_qo, d_ql,
+                             (uint8_t*)d.out_arena, d_tro, d_qro, d_diag));
   auto* d_out = (uint8_t*)d.out_arena;
   /* the MAF line text around the rows: three snippets per record */
   std::vector<uint64_t> dst(3 * (size_t)n);
@@ -1027,11 +1012,6 @@ size_t p2m_run(Dev& d, DevFasta& tf, DevFasta& qf, const PafInput& in, const siz
   const uint64_t kMaxBytes = 6ull << 30;
   const uint64_t kMaxText = 160ull << 20; /* ~64 M ops */
   const size_t keep = d.owned.size();
-  {
-    uint64_t text_ahead = 0;
-    for (size_t k = 0; k < n_which; k++) text_ahead += in.cigar_bytes(which ? which[k] : k);
-    d.out_batches_ahead = std::max(d.out_batches_ahead, text_ahead / kMaxText);
-  }
   size_t i0 = 0;
   while (i0 < n_which && err.empty()) {
     ExpandJob job;

@@ -12,10 +12,8 @@ from . import engine
 class Paf2MafStatJob:
     """stat (K1) -> row layout (scan) -> gap insertion (K2) over one resident batch."""
 
-    def __init__(self, eng, tb, with_text=False, out=None, place=0):
-        """out: a caller-owned output buffer (uint8, at least the rows' bytes + 64), e.g. one reserved at process start.
-        place = N > 0: no buffer yet — place_output() lets the library put the arena where this job's row kernel is
-        fastest among N candidates (wga_paf2maf_expand_place)."""
+    def __init__(self, eng, tb, with_text=False, out=None):
+        """out: a caller-owned output buffer (uint8, at least the rows' bytes + 64), e.g. one reserved at process start."""
         import torch
         self.torch = torch
         self.eng = eng
@@ -40,29 +38,7 @@ class Paf2MafStatJob:
         self.out_bytes = rows
         if out is not None and out.numel() < rows + 64:
             raise ValueError("output buffer too small: %d < %d" % (out.numel(), rows + 64))
-        self.place = int(place)
-        self.arena = None
-        if self.place > 0:
-            self.out = None
-        else:
-            self.out = out[: rows + 64] if out is not None else torch.empty(rows + 64, dtype=torch.uint8, device=dev)
-
-    def place_output(self, arena_bytes=None):
-        """stat + layout, then the rows of this batch into the fastest of `place` candidate arenas (the library's policy for
-        a long-lived caller's output arena, also used by the `wgatools` command line) -> {K2 ms per candidate, index kept}.
-        arena_bytes: size of the arena when it is to serve later, larger batches as well (default: this batch's rows)."""
-        tb = self.tb
-        self.stat()
-        self.layout()
-        self.arena, ms, chosen = self.eng.paf2maf_expand_place(
-            self.batch, self.counts, self.tile_ws, tb["t_pool"], tb["t_pool"].numel(), tb["t_src_off"], tb["t_src_len"],
-            tb["q_pool"], tb["q_pool"].numel(), tb["q_src_off"], tb["q_src_len"], self.t_row_off, self.q_row_off, self.diag,
-            max(self.out_bytes + 64, int(arena_bytes or 0)), self.place)
-        self.arena_view = self.arena.torch(tb["ops"].device)
-        self.out = self.arena_view[: self.out_bytes + 64]
-        return {"policy": "wga_paf2maf_expand_place: the batch's rows written into each of %d candidate arenas, the one the "
-                          "row kernel was fastest on kept" % self.place,
-                "k2_ms_by_candidate": [round(x, 3) for x in ms], "chosen": chosen}
+        self.out = out[: rows + 64] if out is not None else torch.empty(rows + 64, dtype=torch.uint8, device=dev)
 
     def bind_stream(self):
         self.eng.set_stream(self.torch.cuda.current_stream().cuda_stream)
