@@ -992,6 +992,20 @@ def test_pafcov_config4_at_stated_size(gpu):
     print("\nconfig 4 at size: %d records, %.3g ops, %d x %d counters: ONE accumulate call %.1f ms (%.0f GB/s of op stream), "
           "finalize %.1f ms (%.0f GB/s over 8 B per counter)" % (n_all, n_ops, nt, tlen, ms_acc, 4 * n_ops / ms_acc / 1e6,
                                                                 ms_fin, 8.0 * nt * tlen / ms_fin / 1e6))
+    # the same job as ONE call (marks and the marks -> counts scan in one pass over the array): every counter as above
+    cov_f = torch.zeros(total + 8, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+    e0.record()
+    gpu.pafcov_accumulate_final(batch, target_id, t_start, cov_off, cov_len, nt, cov_f, total)
+    e1.record()
+    torch.cuda.synchronize()
+    ms_one = e0.elapsed_time(e1)
+    print("config 4 at size: accumulate_final %.1f ms = %.0f GB/s over 4 B per op + 8 B per counter" % (
+        ms_one, (4.0 * n_ops + 8.0 * nt * tlen) / ms_one / 1e6))
+    assert bool(torch.equal(cov, cov_f)), "accumulate_final differs from accumulate + finalize"
+    del cov_f
+    torch.cuda.empty_cache()
     for t in range(nt):
         c = cov[int(cov_off[t]):int(cov_off[t]) + tlen]
         assert int(c.sum(dtype=torch.int64)) == int(want[t]), t

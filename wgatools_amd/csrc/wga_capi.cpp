@@ -87,8 +87,6 @@ struct wga_ctx {
   u64 cov_pieces_cap = 0;
   void* cov_tile_list = nullptr; /* pafcov: WGA_COV_TILE_CAP piece slots per tile of ops, grow-only */
   u64 cov_tile_list_cap = 0;     /* in tiles */
-  unsigned stat_resident = 0;     /* K1: blocks the device keeps resident (asked once) */
-  unsigned cov_list_resident = 0; /* pafcov: blocks of the list pass the device keeps resident (asked once) */
   void* cov_order = nullptr;  /* pafcov: the order the marks -> counts replay takes the windows in, kept for the ranges it was made for */
   u64 cov_order_cap = 0;
   std::vector<u64> cov_order_key;
@@ -102,11 +100,7 @@ struct wga_ctx {
   std::vector<rt_event_t> rs_copied;
   bool rs_same_device_ok = false; /* "reduce_same_device_ok": distinct contexts may share a device (one-GPU test boxes) */
   bool rs_staged = false;         /* "reduce_staged": pull into scratch over N-1 streams instead of reading the peers in place */
-#ifdef WGA_EMU
-  u32 cov_spin_limit = 64; /* the emulator runs one block at a time: a tile that is not there yet will not come while this one polls */
-#else
-  u32 cov_spin_limit = 1u << 12;
-#endif /* polls of a tile sum (milliseconds of waiting where ten microseconds are the rule) before the
+  u32 cov_spin_limit = 1u << 12; /* polls of a tile sum (milliseconds of waiting where ten microseconds are the rule) before the
                                     look-back adds up the ops itself (WGA_COV_SPIN_LIMIT) */
   /* optional per-launch timing of the expand kernel proper (events on the launch stream) */
   static const int kTimingRing = 64;
@@ -713,9 +707,7 @@ int wga_cigar_stat(wga_ctx* c, const wga_cigar_batch* b, wga_cigar_counts* d_cou
   WGA_LAUNCH(k_tile_rec, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const u64*)b->d_op_off,
              b->d_strand_neg, b->n, (u64)b->n_ops, tile_rec);
   LAUNCH_CHECK();
-  /* a grid of resident waves, each taking every W-th tile (k_cigar_stat) */
-  if (!c->stat_resident) c->stat_resident = rt_resident_blocks(k_cigar_stat, c->device, WGA_BLOCK);
-  const u32 grid = (u32)std::min<u64>((nt + 3) / 4, (u64)c->stat_resident);
+  const u32 grid = (u32)((nt + 3) / 4);
   WGA_LAUNCH(k_cigar_stat, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off,
              b->d_strand_neg, b->n, (u64)b->n_ops, (const wga_tile_rec*)tile_rec, d_counts, d_diag,
              (wga_tile_sum*)d_tile_ws);
@@ -1602,9 +1594,7 @@ static int pafcov_run(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_ta
   }
   u64 n_pieces = 0;
   if (has_ops) {
-    /* the list pass runs on a grid of resident waves (k_cov_list_pieces): what the runtime says fits, or fewer for a small batch */
-    if (!c->cov_list_resident) c->cov_list_resident = rt_resident_blocks(k_cov_list_pieces, c->device, WGA_BLOCK);
-    const u32 grid = (u32)std::min<u64>((nt + 3) / 4, (u64)c->cov_list_resident);
+    const u32 grid = (u32)((nt + 3) / 4);
     if (c->cov_tile_list_cap < nt) {
       if (c->cov_tile_list) RT_CHECK(rt_free(c->cov_tile_list));
       c->cov_tile_list = nullptr;

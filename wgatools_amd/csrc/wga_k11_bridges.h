@@ -1,0 +1,194 @@
+/*
+ * wga_k11_bridges.h — K11: bridges between run / data-line lists and packed ops / CIGAR text.
+ * One of the parts of wga_kernels2.h, which includes them in dependency order (a part uses helpers of the parts in front of it).
+ */
+#ifndef WGA_K11_BRIDGES_H
+#define WGA_K11_BRIDGES_H
+
+#include "wga_kernels.h"
+
+/* ============================================================================================ */
+/* K11: bridges between the run / data-line lists and the packed-op and CIGAR-text forms        */
+/*      (maf2chain, chain2paf, chain2maf, maf2paf's cg:Z: text)      */
+/* ============================================================================================ */
+/* All four share one skeleton: element x (a K3 run, or a chain data line) of record r produces
+ * src.size(x, r) output units (packed ops or text bytes); an exclusive scan over the elements
+ * gives every element its place inside its record's output, which starts at out_off[r].  One
+ * thread per element; its record is found by bisection in the CSR offsets. */
+__device__ __forceinline__ u32 csr_find_rec(const u64* __restrict__ off, u32 n, u64 x) {
+  u32 lo = 0, hi = n; /* largest r < n with off[r] <= x (records without elements are skipped) */
+  while (hi - lo > 1u) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if (off[mid] <= x) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ u32 split_pieces(u64 len) { /* pieces of at most WGA_OP_MAX_LEN, none for 0 */
+  return (u32)((len + (u64)WGA_OP_MAX_LEN - 1ull) / (u64)WGA_OP_MAX_LEN);
+}
+__device__ __forceinline__ u32* put_split(u32* p, u64 len, u32 code, u32 cont) {
+  bool first = true;
+  while (len) {
+    const u64 piece = len > (u64)WGA_OP_MAX_LEN ? (u64)WGA_OP_MAX_LEN : len;
+    *p++ = ((u32)piece << 4) | (first ? code : cont);
+    len -= piece;
+    first = false;
+  }
+  return p;
+}
+__device__ __forceinline__ u8* put_len_op(u8* p, u64 len, u8 op) {
+  const u32 nd = dec_digits(len);
+  dec_write(p, len, nd);
+  p[nd] = op;
+  return p + nd + 1u;
+}
+
+/* K3 runs (start_column << 3 | class, class 0 '=' 1 I 2 D 3 X) of MAF column pairs */
+struct MafRunSrc {
+  const u64* runs;
+  const u64* run_off;
+  const u64* cols;
+  __device__ u64 len(u64 x, u32 r) const {
+    const u64 start = runs[x] >> 3;
+    const u64 end = x + 1 < run_off[r + 1] ? runs[x + 1] >> 3 : cols[r];
+    return end - start;
+  }
+  __device__ u32 cls(u64 x) const { return (u32)(runs[x] & 7ull); }
+};
+/* -> packed ops: '=' 7, I 1, D 2, X 8; a run of 2^28 columns or more is split like the PAF packer
+ * splits a length (continuation codes for I / D), so every consumer of a wga_cigar_batch applies */
+struct MafRunOps {
+  typedef u32 out_t;
+  MafRunSrc s;
+  __device__ u64 size(u64 x, u32 r) const { return split_pieces(s.len(x, r)); }
+  __device__ void write(u64 x, u32 r, u32* p) const {
+    const u32 c = s.cls(x);
+    const u32 code = c == 0u ? (u32)WGA_OP_EQ : c == 1u ? (u32)WGA_OP_I : c == 2u ? (u32)WGA_OP_D : (u32)WGA_OP_X;
+    const u32 cont = c == 1u ? (u32)WGA_OP_I_CONT : c == 2u ? (u32)WGA_OP_D_CONT : code;
+    put_split(p, s.len(x, r), code, cont);
+  }
+};
+/* -> the cg:Z: text of maf2paf, "<len><=|I|D|X>" per run (maf.rs:484-520, cigar.rs:400-401) */
+struct MafRunText {
+  typedef u8 out_t;
+  MafRunSrc s;
+  __device__ u64 size(u64 x, u32 r) const { return dec_digits(s.len(x, r)) + 1u; }
+  __device__ void write(u64 x, u32 r, u8* p) const {
+    const u32 c = s.cls(x);
+    put_len_op(p, s.len(x, r), c == 0u ? (u8)'=' : c == 1u ? (u8)'I' : c == 2u ? (u8)'D' : (u8)'X');
+  }
+};
+/* chain data lines, three u64 each: size, 2nd column (bases only in the target: D), 3rd column
+ * (bases only in the query: I) — chain.rs:330-348 reads them in this order */
+struct ChainLineSrc {
+  const u64* lines;
+  __device__ u64 size_(u64 x) const { return lines[3 * x]; }
+  __device__ u64 del_(u64 x) const { return lines[3 * x + 1]; }
+  __device__ u64 ins_(u64 x) const { return lines[3 * x + 2]; }
+};
+/* -> packed ops in the order parse_chain_to_cigar / parse_chain_to_insert walk a line
+ * (cigar.rs:576-606, converter.rs:360-388): M size, I 3rd column, D 2nd column; zero lengths
+ * have no effect on rows or counts and are left out */
+struct ChainLineOps {
+  typedef u32 out_t;
+  ChainLineSrc s;
+  __device__ u64 size(u64 x, u32) const {
+    return (u64)split_pieces(s.size_(x)) + split_pieces(s.ins_(x)) + split_pieces(s.del_(x));
+  }
+  __device__ void write(u64 x, u32, u32* p) const {
+    p = put_split(p, s.size_(x), (u32)WGA_OP_M, (u32)WGA_OP_M);
+    p = put_split(p, s.ins_(x), (u32)WGA_OP_I, (u32)WGA_OP_I_CONT);
+    put_split(p, s.del_(x), (u32)WGA_OP_D, (u32)WGA_OP_D_CONT);
+  }
+};
+/* -> chain2paf's CIGAR text: "<size>M" always, "<n>I" / "<n>D" when non-zero (cigar.rs:576-606) */
+struct ChainLineText {
+  typedef u8 out_t;
+  ChainLineSrc s;
+  __device__ u64 size(u64 x, u32) const {
+    const u64 i = s.ins_(x), d = s.del_(x);
+    return (u64)dec_digits(s.size_(x)) + 1u + (i ? dec_digits(i) + 1u : 0u) + (d ? dec_digits(d) + 1u : 0u);
+  }
+  __device__ void write(u64 x, u32, u8* p) const {
+    const u64 i = s.ins_(x), d = s.del_(x);
+    p = put_len_op(p, s.size_(x), (u8)'M');
+    if (i) p = put_len_op(p, i, (u8)'I');
+    if (d) put_len_op(p, d, (u8)'D');
+  }
+};
+
+template <typename F>
+struct ScanElem { /* scan functor: output units of element x */
+  F f;
+  const u64* elem_off;
+  u32 n;
+  __device__ u64 operator()(u32 x) const { return f.size((u64)x, csr_find_rec(elem_off, n, (u64)x)); }
+};
+__global__ __launch_bounds__(256) void k_elem_rec_totals(u32 n, const u64* __restrict__ elem_off,
+                                                         const u64* __restrict__ esc, u64* __restrict__ cnt) {
+  const u32 r = blockIdx.x * 256u + threadIdx.x;
+  if (r < n) cnt[r] = esc[elem_off[r + 1]] - esc[elem_off[r]];
+}
+/* bytes [a, a + total) of an LDS text buffer go to gb + a (gb 16-byte aligned: the buffer mirrors the output's position
+ * inside its 16-byte group): whole groups with 16-byte stores, the ragged head and tail (< 16 bytes each) by bytes.
+ * `nthr` threads share the work (a wave or a block; the caller synchronises around the call). */
+__device__ __forceinline__ void lds_text_flush(const u8* tbuf, u32 a, u32 total, u8* gb, u32 tid, u32 nthr) {
+  const u32 end = a + total;
+  const u32 g_lo = (a + 15u) >> 4, g_hi = end >> 4; /* whole 16-byte groups [g_lo, g_hi) */
+  for (u32 g = g_lo + tid; g < g_hi; g += nthr) *(u32x4_a16*)(gb + 16u * g) = *(const u32x4_a16*)(tbuf + 16u * g);
+  const u32 head_end = 16u * g_lo < end ? 16u * g_lo : end;           /* [a, head_end) */
+  const u32 tail_beg = 16u * g_hi > head_end ? 16u * g_hi : head_end; /* [tail_beg, end) */
+  if (tid < 16u) {
+    const u32 x = a + tid;
+    if (x < head_end) gb[x] = tbuf[x];
+  } else if (tid < 32u) {
+    const u32 x = tail_beg + (tid - 16u);
+    if (x < end) gb[x] = tbuf[x];
+  }
+}
+
+/* One thread per element, 256 consecutive elements per block.  The records of the block's first and last element are
+ * found once (two wave-wide searches per block); every thread then looks inside that window — one record in nearly every block.
+ * A block whose elements belong to ONE record writes one contiguous stretch of that record's output: its threads put
+ * their units into an LDS buffer that mirrors the stretch's position inside its 16-byte group, and the stretch goes out
+ * in 16-byte stores.  Blocks across a record border, or with more output than the buffer holds, write directly. */
+#define WGA_ELEM_STAGE 16384u
+template <typename F>
+__global__ __launch_bounds__(256) void k_elem_fill(F f, u32 n, u32 ne, const u64* __restrict__ elem_off,
+                                                   const u64* __restrict__ esc, typename F::out_t* out,
+                                                   const u64* __restrict__ out_off) {
+  typedef typename F::out_t out_t;
+  __shared__ u32x4_a16 s_buf[(WGA_ELEM_STAGE + 32u) / 16u];
+  __shared__ u32 s_r[2];
+  const u32 tid = threadIdx.x;
+  const u32 x0 = blockIdx.x * 256u, x1 = x0 + 256u < ne ? x0 + 256u : ne;
+  /* two waves search, 64 probes a step (three steps for 10^5 records where one thread's bisection takes seventeen) */
+  if (tid < 128u) { /* wave-uniform */
+    const u32 r = wga_find_rec(elem_off, n, tid < 64u ? (u64)x0 : (u64)(x1 - 1u));
+    if ((tid & 63u) == 0u) s_r[tid >> 6] = r;
+  }
+  __syncthreads();
+  const u32 r_lo = WGA_UNI32(s_r[0]), r_hi = WGA_UNI32(s_r[1]);
+  const u32 x = x0 + tid;
+  const u64 e0 = esc[x0], e1 = esc[x1]; /* units in front of the block, and behind it */
+  const bool staged = r_lo == r_hi && (e1 - e0) * sizeof(out_t) <= (u64)WGA_ELEM_STAGE;
+  if (staged) { /* block-uniform */
+    out_t* const g0 = out + out_off[r_lo] + (e0 - esc[elem_off[r_lo]]);
+    const u32 a = (u32)((uintptr_t)g0 & 15u);
+    u8* const tbuf = (u8*)s_buf;
+    if (x < x1) f.write((u64)x, r_lo, (out_t*)(tbuf + a) + (esc[x] - e0));
+    __syncthreads();
+    lds_text_flush(tbuf, a, (u32)((e1 - e0) * sizeof(out_t)), (u8*)g0 - a, tid, 256u);
+    return;
+  }
+  if (x >= x1) return;
+  u32 lo = r_lo, hi = r_hi + 1u; /* largest r in [r_lo, r_hi] with elem_off[r] <= x */
+  while (hi - lo > 1u) {
+    const u32 mid = lo + ((hi - lo) >> 1);
+    if (elem_off[mid] <= (u64)x) lo = mid; else hi = mid;
+  }
+  f.write((u64)x, lo, out + out_off[lo] + (esc[x] - esc[elem_off[lo]]));
+}
+
+#endif /* WGA_K11_BRIDGES_H */

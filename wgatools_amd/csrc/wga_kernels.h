@@ -402,9 +402,10 @@ __device__ __forceinline__ void stat_load_ops(const u32* __restrict__ ops, u64 n
   }
 }
 
-/* A grid of resident waves (the host sizes it): wave j of W takes the tiles j, W + j, 2 W + j ... and requests the ops of its
- * next tile before it works on the current one — with one tile per wave the kernel ran at the rate 5 waves per SIMD x 4 KB in
- * flight allow (3.6 TB/s), whatever its instruction count. */
+/* One wave per tile.  The kernel is bound by the instructions it issues: 626 vector + 161 scalar per tile at 1.16 per cycle and
+ * CU (profiles/r05_k1_k5_counters.txt), the ceiling scripts/micro/issue_rates.hip measures for such a mix — not by its loads (a
+ * plain read of the same 2 GB runs at 6.5 TB/s, scripts/micro/read_only.hip; a grid of resident waves that requested the next
+ * tile's ops early: 0.586 against 0.555 ms) and not by the atomics of records that span tiles (without them: the same time). */
 __global__ __launch_bounds__(256, WGA_K1_BLOCKS) void k_cigar_stat(const u32* __restrict__ ops,
                                                     const u64* __restrict__ op_off,
                                                     const u8* __restrict__ strand_neg, u32 n,
@@ -413,18 +414,11 @@ __global__ __launch_bounds__(256, WGA_K1_BLOCKS) void k_cigar_stat(const u32* __
                                                     wga_rec_diag* diag, wga_tile_sum* tiles) {
   (void)n;
   const u32 lane = threadIdx.x & 63u;
-  const u64 W = (u64)gridDim.x * 4;
-  u64 g = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
+  const u64 g = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
   if (g * WGA_TILE >= n_ops) return; /* wave-uniform; this kernel has no block barrier */
-  u32 wn[16];
-  stat_load_ops(ops, n_ops, g, lane, wn);
-  for (; g * WGA_TILE < n_ops; g += W) {
-    u32 w[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) w[k] = wn[k];
-    if ((g + W) * WGA_TILE < n_ops) stat_load_ops(ops, n_ops, g + W, lane, wn);
-    cigar_stat_tile(g, w, lane, op_off, strand_neg, n_ops, tile_rec, counts, diag, tiles);
-  }
+  u32 w[16];
+  stat_load_ops(ops, n_ops, g, lane, w);
+  cigar_stat_tile(g, w, lane, op_off, strand_neg, n_ops, tile_rec, counts, diag, tiles);
 }
 
 /* ============================================================================================ */

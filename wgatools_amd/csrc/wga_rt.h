@@ -106,12 +106,6 @@ static inline const char* rt_peer_copy(void* dst, int dst_dev, const void* src, 
   return nullptr;
 }
 static inline const char* rt_peer_enable(int, int) { return nullptr; } /* every "device" of the emulator is host memory */
-/* blocks of `kernel` a device keeps resident at one time (grids of persistent waves); the emulator runs one block at a time and
- * answers 3, so that small test batches go through several rounds */
-template <typename K>
-static inline unsigned rt_resident_blocks(K, int, unsigned) {
-  return 3u;
-}
 static inline const char* rt_launch_error() { return nullptr; }
 struct emu_event {
   wga_stream_t on = nullptr;
@@ -186,14 +180,6 @@ static inline const char* rt_peer_enable(int dev, int peer) {
     return nullptr;
   }
   return rt_err(e);
-}
-template <typename K>
-static inline unsigned rt_resident_blocks(K kernel, int device, unsigned block_threads) {
-  int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)block_threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 1;
-  (void)hipGetLastError();
-  return (unsigned)per_cu * (unsigned)cus;
 }
 static inline const char* rt_launch_error() { return rt_err(hipGetLastError()); }
 typedef hipEvent_t rt_event_t;

@@ -9,6 +9,8 @@
  */
 #include <errno.h>
 #include <fcntl.h>
+
+#include <atomic>
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
@@ -3840,7 +3842,7 @@ int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, c
     /* the event rules and the VCF text of a block depend on that block alone: contiguous ranges of blocks go to host
      * threads, their text is written in block order (rows in front of a failing block are written, then the error) */
     unsigned nthr = std::thread::hardware_concurrency();
-    nthr = std::max(1u, std::min({nthr, 32u, n / 256u + 1u}));
+    nthr = std::max(1u, std::min({nthr, 96u, n / 256u + 1u})); /* rows are short strings: the work scales with the cores */
     if (const char* e = getenv("WGA_HOST_THREADS")) nthr = std::max(1u, std::min((unsigned)atoi(e), n)); /* tests */
     std::vector<std::string> parts(nthr), errs(nthr);
     auto work = [&](unsigned t) {
@@ -3876,16 +3878,46 @@ int cmd_call_maf(const std::string* input, bool snp, bool inv, uint64_t svlen, c
       for (auto& x : th) x.join();
     }
     g_timer.mark("host event rules + VCF text");
-    for (unsigned t = 0; t < nthr; t++) {
-      text += parts[t];
-      if (!errs[t].empty()) {
-        out.write(text);
-        fail(errs[t]);
+    {
+      /* the threads' texts leave in block order: what was collected before, then part 0, 1 ...; up to the first part that
+       * holds an error (its rows in front of the failing block are written, then the error is raised).  Into a plain file
+       * the parts are written side by side at their places (no copy into one string, no single writer). */
+      unsigned good = 0;
+      while (good < nthr && errs[good].empty()) good++;
+      const unsigned upto = good < nthr ? good + 1 : nthr; /* parts written */
+      out.write(text);
+      text.clear();
+      uint64_t pos0 = 0;
+      const int fd = nthr > 1 ? out.plain_fd(&pos0) : -1;
+      if (fd >= 0) {
+        std::vector<uint64_t> at(upto + 1, pos0);
+        for (unsigned t = 0; t < upto; t++) at[t + 1] = at[t] + parts[t].size();
+        std::atomic<bool> bad(false);
+        auto put = [&](unsigned t) {
+          size_t w = 0;
+          while (w < parts[t].size()) {
+            const ssize_t r2 = pwrite(fd, parts[t].data() + w, parts[t].size() - w, (off_t)(at[t] + w));
+            if (r2 <= 0) {
+              bad = true;
+              return;
+            }
+            w += (size_t)r2;
+          }
+        };
+        std::vector<std::thread> th;
+        const unsigned nw = std::min(upto, 8u);
+        for (unsigned k = 1; k < nw; k++)
+          th.emplace_back([&, k] {
+            for (unsigned t = k; t < upto; t += nw) put(t);
+          });
+        for (unsigned t = 0; t < upto; t += nw) put(t);
+        for (auto& x : th) x.join();
+        if (bad) fail("write error on the output file");
+        out.advance(at[upto] - pos0);
+      } else {
+        for (unsigned t = 0; t < upto; t++) out.write(parts[t]);
       }
-      if (text.size() > (1u << 24)) {
-        out.write(text);
-        text.clear();
-      }
+      if (good < nthr) fail(errs[good]);
     }
     g_timer.mark("write");
     if (md.count() == 1) runs_keep = std::move(runs);
