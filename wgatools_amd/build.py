@@ -140,8 +140,9 @@ def build_cli(force=False):
     """the `wgatools` drop-in command line (C++ host layer over the C-ABI)"""
     hdir = os.path.join(ROOT, "wgatools_amd", "host")
     srcs = [os.path.join(hdir, f) for f in ("wgatools_main.cpp", "wga_host.cpp", "wga_host.hpp")]
+    parts = [os.path.join(hdir, f) for f in sorted(os.listdir(hdir)) if f.endswith(".inc")]   # the commands, included by wgatools_main.cpp
     lib = build_hip()
-    if not force and not _newer(CLI_BIN, srcs + [lib]):
+    if not force and not _newer(CLI_BIN, srcs + parts + [lib]):
         return CLI_BIN
     os.makedirs(os.path.dirname(CLI_BIN), exist_ok=True)
     _run(["g++", "-O2", "-g", "-std=c++17", "-Wall", srcs[0], srcs[1], "-o", CLI_BIN,
@@ -155,8 +156,8 @@ def build_cli_emu(force=False):
     """tests/emu/wgatools_emu — the CLI host code linked against the emulator build of the kernels.
     Test infrastructure: lets the CPU suite exercise the host logic end to end without a GPU."""
     lib = build_emu(force)
-    srcs = [os.path.join(ROOT, "wgatools_amd", "host", "wgatools_main.cpp"), os.path.join(ROOT, "wgatools_amd", "host", "wga_host.cpp"),
-            os.path.join(ROOT, "wgatools_amd", "host", "wga_host.hpp"), lib]
+    hdir = os.path.join(ROOT, "wgatools_amd", "host")
+    srcs = [os.path.join(hdir, f) for f in sorted(os.listdir(hdir)) if f.endswith((".cpp", ".hpp", ".inc"))] + [lib]
     if not force and not _newer(CLI_EMU_BIN, srcs):
         return CLI_EMU_BIN
     _run(["g++", "-O1", "-g", "-std=c++17", "-Wall", os.path.join(ROOT, "wgatools_amd", "host", "wgatools_main.cpp"),

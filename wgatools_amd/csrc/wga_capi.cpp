@@ -1561,7 +1561,7 @@ static int pafcov_run(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_ta
   }
   const bool has_ops = b && b->n != 0 && b->n_ops != 0 && total_cov != 0;
   if (!has_ops && (!final || n_rng == 0)) return WGA_OK;
-  const u64 nt = has_ops ? n_tiles(b->n_ops) : 0;
+  const u64 nt = has_ops ? ((u64)b->n_ops + WGA_COV_TILE - 1) / WGA_COV_TILE : 0; /* K5 cuts the ops into tiles of its own size */
   const u64 nw = (n_cov >> WGA_COV_WIN_SHIFT) + 1;
   if (nw > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "coverage arrays too large for one call", nullptr);
   /* One pass lists every (tile, record segment, window) piece (see wga_kernels2.h K5): tile sums by look-back, the pieces into the

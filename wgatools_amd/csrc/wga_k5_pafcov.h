@@ -24,11 +24,20 @@
  * atomics and adds the window to memory with plain stores — it is the only writer. */
 #define WGA_COV_WIN_SHIFT 13u
 #define WGA_COV_WIN (1u << WGA_COV_WIN_SHIFT)
+/* K5's own tile: WGA_COV_TILE ops per wave, WGA_COV_LO consecutive ones per lane.  1 024 (16 per lane) as everywhere else;
+ * 2 048 (-DWGA_COV_TILE_SHIFT=11u: 32 per lane, 128 VGPRs) was measured at configs[3]'s size — the list pass 31.8 ms against
+ * 28.0, the replay 34.0 against 35.0 (fewer, longer pieces), 74.8 against 74.2 ms in all (profiles/r05_k5_stated_run5.log). */
+#ifndef WGA_COV_TILE_SHIFT
+#define WGA_COV_TILE_SHIFT 10u
+#endif
+#define WGA_COV_TILE (1u << WGA_COV_TILE_SHIFT)
+#define WGA_COV_LO (WGA_COV_TILE / 64u)       /* ops per lane */
+#define WGA_COV_LO_SHIFT (WGA_COV_TILE_SHIFT - 6u)
 
 struct __attribute__((aligned(16))) wga_cov_piece {
   u32 g;       /* tile */
-  u32 ab;      /* first op | end op << 16, tile-relative (<= 1024): the ops of the record segment whose marks can lie in the
-                  window the piece is listed under (whole lanes of 16 ops) */
+  u32 ab;      /* first op | end op << 16, tile-relative (<= WGA_COV_TILE): the ops of the record segment whose marks can lie in
+                  the window the piece is listed under (whole lanes of WGA_COV_LO ops) */
   u64 pos0;    /* coverage index (cov_off + target position) in front of op `first` */
   u64 limit;   /* coverage index one past the target's last counter */
   u32 wi;      /* window the piece is listed under */
@@ -38,7 +47,7 @@ struct __attribute__((aligned(16))) wga_cov_piece {
 /* The list pass writes a tile's first WGA_COV_TILE_CAP pieces into the tile's own slots — no atomic with an answer to wait for —
  * and further ones where WGA_COV_LISTS counters hand out places (tile g uses counter g mod WGA_COV_LISTS: one counter for all
  * tiles would take every such segment of the batch through one address), each over a region of `rcap` pieces. */
-#define WGA_COV_TILE_CAP 8u
+#define WGA_COV_TILE_CAP (WGA_COV_LO / 2u) /* 8 slots per 1 024 ops */
 #define WGA_COV_LISTS 4096u
 #define WGA_COV_READY (1ull << 63)
 /* inclusive scan over the lanes of a value below 2^40 (a lane's 16 ops advance less than 16 x 2^28), and the wave's total: two
@@ -49,14 +58,14 @@ __device__ __forceinline__ u64 cov_incl_scan_u64(u64 v, u64& total) {
   return (u64)lo + ((u64)hi << 24);
 }
 
-/* 16 consecutive ops per lane of tile g, zeros from op nt on: every 16-byte group that starts in front of nt is loaded (the group
+/* WGA_COV_LO consecutive ops per lane of tile g, zeros from op nt on: every 16-byte group that starts in front of nt is loaded (the group
  * that holds the stream's last op may reach up to 12 bytes beyond it, inside the same aligned 16 bytes; the callers give what
  * it brings from there no weight — the list pass only looks at ops inside record segments) */
 __device__ __forceinline__ void cov_load_ops(const u32* __restrict__ ops, u64 tile_start, u32 nt, u32 lane,
-                                             u32 w[16]) {
+                                             u32 w[WGA_COV_LO]) {
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const u32 base = lane * 16u + (u32)j * 4u;
+  for (u32 j = 0; j < WGA_COV_LO / 4u; j++) {
+    const u32 base = lane * WGA_COV_LO + j * 4u;
     u32x4_a16 v = {0u, 0u, 0u, 0u};
     if (base < nt) v = *(const u32x4_a16*)(ops + tile_start + base);
     w[4 * j + 0] = v[0];
@@ -70,28 +79,28 @@ __device__ __forceinline__ void cov_load_ops(const u32* __restrict__ ops, u64 ti
 __device__ __forceinline__ bool cov_op_moves(u32 code) { return ((0x212u >> code) & 1u) == 0u; }
 #define WGA_COV_MOVES_BITS 0xFDEDu  /* bit c set: an op of code c moves on the target (the same as a mask for v_bfe_i32) */
 #define WGA_COV_NOTCNT_BITS 0xFF7Eu /* bit c set: an op of code c is not counted (all but M and =) */
-/* target advance of this lane's ops inside [a, b); mvl[e] = the advance of op e (16 lengths below 2^28: the sum fits 32 bits) */
-__device__ __forceinline__ u64 cov_lane_moves(const u32 mvl[16], u32 lane, u32 a, u32 b) {
-  u32 mv = 0;
-  const u32 t = lane * 16u - a, n = b - a;
+/* target advance of this lane's ops inside [a, b); mvl[e] = the advance of op e */
+__device__ __forceinline__ u64 cov_lane_moves(const u32 mvl[WGA_COV_LO], u32 lane, u32 a, u32 b) {
+  u64 mv = 0; /* 32 lengths below 2^28 do not fit 32 bits */
+  const u32 t = lane * WGA_COV_LO - a, n = b - a;
 #pragma unroll
-  for (int e = 0; e < 16; e++) mv += (t + (u32)e < n) ? mvl[e] : 0u;
-  return (u64)mv;
+  for (u32 e = 0; e < WGA_COV_LO; e++) mv += (t + e < n) ? mvl[e] : 0u;
+  return mv;
 }
 
-/* Target advance of record r's ops in front of tile g (the record starts at op rs, in tile g0 = rs / WGA_TILE): the tail sums the
+/* Target advance of record r's ops in front of tile g (the record starts at op rs, in tile g0 = rs / WGA_COV_TILE): the tail sums the
  * tiles g0 .. g-1 published (every one of them ends inside the record, so its last segment is the record's part of it).  Lane L
  * takes tile g-1-L (and 64 further back per round); `early` is what a first poll of round 0 — sent before the tile's other
  * segments were worked on — brought back (cov_poll_early).  Those tiles belong to blocks of the same launch with lower
  * indices, which were dispatched before this one; should one of them not have published after `spin_limit` polls (or with a
  * limit of 0: at once), the ops themselves are added up — the pass ends whatever the dispatch order is. */
 __device__ __forceinline__ u64 cov_poll_early(u64* tile_tail, u64 rs, u64 g, u32 lane) {
-  const u64 g0 = rs / WGA_TILE;
+  const u64 g0 = rs >> WGA_COV_TILE_SHIFT;
   return (g - g0 > (u64)lane) ? (u64)atomicAdd((unsigned long long*)&tile_tail[g - 1 - lane], 0ull) : 0ull;
 }
 __device__ __forceinline__ u64 cov_look_back(u64* tile_tail, const u32* __restrict__ ops, u64 rs, u64 g, u32 lane,
                                              u32 spin_limit, u64 early) {
-  const u64 g0 = rs / WGA_TILE;
+  const u64 g0 = rs >> WGA_COV_TILE_SHIFT;
   u64 p = 0;
   bool gave_up = spin_limit == 0; /* wave-uniform */
   for (u64 back = 0; back < g - g0 && !gave_up; back += 64) {
@@ -111,7 +120,7 @@ __device__ __forceinline__ u64 cov_look_back(u64* tile_tail, const u32* __restri
   }
   if (!gave_up) return wave_sum_u32_wide((u32)p) + (wave_sum_u32_wide((u32)(p >> 32)) << 32); /* DPP, no LDS */
   u64 q = 0;
-  for (u64 i = rs + lane; i < g * WGA_TILE; i += 64) {
+  for (u64 i = rs + lane; i < (g << WGA_COV_TILE_SHIFT); i += 64) {
     const u32 op = ops[i];
     q += cov_op_moves(op & 15u) ? (u64)(op >> 4) : 0ull;
   }
@@ -146,7 +155,7 @@ struct __attribute__((aligned(16))) wga_cov_tile {
 __global__ __launch_bounds__(256) void k_cov_tile_info(const u64* __restrict__ op_off, u32 n, u64 n_ops,
                                                        const wga_cov_rec* __restrict__ rec_pos, wga_cov_tile* __restrict__ info) {
   const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
-  const u64 x = g * WGA_TILE;
+  const u64 x = g << WGA_COV_TILE_SHIFT;
   if (x >= n_ops) return;
   u32 lo = 0, hi = n; /* last r with op_off[r] <= x; op_off[0] == 0, op_off[n] == n_ops > x */
   while (hi - lo > 1u) {
@@ -176,24 +185,28 @@ __global__ __launch_bounds__(256) void k_cov_tile_info(const u64* __restrict__ o
  * segments need of their records comes with the tile's ops in one load (k_cov_tile_info), a further segment's record data
  * (op_off, k_cov_rec_pos's pair) is fetched a segment ahead.  With `rcap` = 0 the pieces beyond the slots are only counted. */
 #ifndef WGA_K5_LIST_WAVES
-#define WGA_K5_LIST_WAVES 1 /* waves per SIMD the register allocation aims at (1: as many registers as it likes — 72, seven waves) */
+#define WGA_K5_LIST_WAVES 1 /* waves per SIMD the register allocation aims at (1: as many registers as it likes — 72, seven waves; with 32 ops per lane 4: 128 VGPRs) */
 #endif
-/* one tile of the list pass; w = the tile's 16 packed ops per lane */
+/* one tile of the list pass; w = the tile's packed ops, WGA_COV_LO consecutive ones per lane */
 __device__ __forceinline__ void cov_list_tile(
-    const u64 g, u32 (&w)[16], const u32 lane, const u32* __restrict__ ops, const u64* __restrict__ op_off, u64 n_ops,
+    const u64 g, u32 (&w)[WGA_COV_LO], const u32 lane, const u32* __restrict__ ops, const u64* __restrict__ op_off, u64 n_ops,
     const wga_cov_tile* __restrict__ tile_info, const wga_cov_rec* __restrict__ rec_pos, u64* tile_tail, u32* win_cnt,
     wga_cov_piece* tile_list, u32* tile_cnt, u64* list_cnt, wga_cov_piece* list, u64 rcap, u32 spin_limit) {
-  const u64 tile_start = g * WGA_TILE;
-  const u64 tile_end = tile_start + WGA_TILE < n_ops ? tile_start + WGA_TILE : n_ops;
+  const u64 tile_start = g << WGA_COV_TILE_SHIFT;
+  const u64 tile_end = tile_start + WGA_COV_TILE < n_ops ? tile_start + WGA_COV_TILE : n_ops;
   const u32 nt = (u32)(tile_end - tile_start);
   const wga_cov_tile tr = tile_info[g];
   const u64 rs_next = tile_end < n_ops ? tile_info[g + 1].rs : ~0ull; /* where the record of the next tile's first op starts */
 #pragma unroll
-  for (int e = 0; e < 16; e++) w[e] = (w[e] >> 4) & bit_mask(WGA_COV_MOVES_BITS, w[e] & 15u); /* the pass needs the ops' advance only */
+  for (u32 e = 0; e < WGA_COV_LO; e++) w[e] = (w[e] >> 4) & bit_mask(WGA_COV_MOVES_BITS, w[e] & 15u); /* the pass needs the ops' advance only */
   if (nt & 3u) { /* wave-uniform, the stream's last tile: what the last 16-byte group brought from behind the stream */
 #pragma unroll
-    for (int e = 0; e < 16; e++) w[e] = lane * 16u + (u32)e < nt ? w[e] : 0u;
+    for (u32 e = 0; e < WGA_COV_LO; e++) w[e] = lane * WGA_COV_LO + e < nt ? w[e] : 0u;
   }
+  u32 any = 0; /* a lane's running sums stay below 2^31 when none of its ops advances 2^26 bases or more */
+#pragma unroll
+  for (u32 e = 0; e < WGA_COV_LO; e++) any |= w[e];
+  const bool small_ops = __ballot(any >= (1u << 26)) == 0ull; /* wave-uniform */
   const u32 region = (u32)(g % WGA_COV_LISTS);
   u64* const my_cnt = list_cnt + region;
   wga_cov_piece* const my_list = list + (u64)region * rcap;
@@ -242,7 +255,7 @@ __device__ __forceinline__ void cov_list_tile(
       }
       c2 += __shfl(l_start, (int)c2) <= hi ? 1u : 0u;
       const u32 l1 = c1, l2 = c2 ? c2 - 1u : 0u;
-      const u32 a2 = a > 16u * l1 ? a : 16u * l1, b2 = b < 16u * (l2 + 1u) ? b : 16u * (l2 + 1u);
+      const u32 a2 = a > WGA_COV_LO * l1 ? a : WGA_COV_LO * l1, b2 = b < WGA_COV_LO * (l2 + 1u) ? b : WGA_COV_LO * (l2 + 1u);
       const u64 pos_a2 = __shfl(l_start, (int)l1);
       if (on) {
         atomicAdd(&win_cnt[wi], 1u);
@@ -278,20 +291,20 @@ __device__ __forceinline__ void cov_list_tile(
   /* w becomes the running sum inside the lane (w[e] = advance of the lane's ops 0 .. e): the advance in front of any op is then
    * one register of one lane, read with a wave-uniform register index */
 #pragma unroll
-  for (int e = 1; e < 16; e++) w[e] += w[e - 1]; /* 16 advances below 2^28 */
-  const u32 lt = w[15];
+  for (u32 e = 1; e < WGA_COV_LO; e++) w[e] += w[e - 1]; /* modulo 2^32: exact when small_ops, and exactly undone below otherwise */
+  const u32 lt = w[WGA_COV_LO - 1u];
   auto per_op_again = [&]() { /* the general walk measures ops one by one */
 #pragma unroll
-    for (int e = 15; e > 0; e--) w[e] -= w[e - 1];
+    for (u32 e = WGA_COV_LO - 1u; e > 0u; e--) w[e] -= w[e - 1];
   };
   u64 tile_total;
   const u64 P64 = cov_incl_scan_u64((u64)lt, tile_total);
-  const bool narrow = tile_total < (1ull << 31); /* wave-uniform */
+  const bool narrow = small_ops && tile_total < (1ull << 31); /* wave-uniform */
   const u32 Pin = (u32)P64, Pex = Pin - lt;
   auto prefix_at = [&](u32 i) -> u32 { /* NARROW only; i <= nt, wave-uniform */
-    if (i >= WGA_TILE) return (u32)tile_total;
-    const u32 li = i >> 4, e = WGA_UNI32(i & 15u);
-    const u32 part = e ? w[(e - 1u) & 15u] : 0u;
+    if (i >= WGA_COV_TILE) return (u32)tile_total;
+    const u32 li = i >> WGA_COV_LO_SHIFT, e = WGA_UNI32(i & (WGA_COV_LO - 1u));
+    const u32 part = e ? w[(e - 1u) & (WGA_COV_LO - 1u)] : 0u;
     return wave_get_u32_dyn(Pex, li) + wave_get_u32_dyn(part, li);
   };
   if (!narrow) per_op_again();
@@ -335,7 +348,7 @@ __device__ __forceinline__ void cov_list_tile(
         l1 = l1 < 63u ? l1 : 63u;
         const u32 c2 = (u32)__popcll(__ballot(wf <= j)); /* lanes that start inside or in front of it */
         const u32 l2 = c2 ? c2 - 1u : 0u;
-        const u32 a2 = a > 16u * l1 ? a : 16u * l1, b2 = b < 16u * (l2 + 1u) ? b : 16u * (l2 + 1u);
+        const u32 a2 = a > WGA_COV_LO * l1 ? a : WGA_COV_LO * l1, b2 = b < WGA_COV_LO * (l2 + 1u) ? b : WGA_COV_LO * (l2 + 1u);
         const u64 pos_a2 = pos + (u64)wave_get_u32_dyn(cs, l1);
         const bool me = lane == n_p + j;
         pc_ab = me ? (a2 | (b2 << 16)) : pc_ab;
@@ -432,9 +445,10 @@ __global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
     wga_cov_piece* list, u64 rcap, u32 spin_limit) {
   const u32 lane = threadIdx.x & 63u;
   const u64 g = (u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x);
-  if (g * WGA_TILE >= n_ops) return;
-  u32 w[16];
-  cov_load_ops(ops, g * WGA_TILE, g * WGA_TILE + WGA_TILE < n_ops ? WGA_TILE : (u32)(n_ops - g * WGA_TILE), lane, w);
+  const u64 tile_start = g << WGA_COV_TILE_SHIFT;
+  if (tile_start >= n_ops) return;
+  u32 w[WGA_COV_LO];
+  cov_load_ops(ops, tile_start, tile_start + WGA_COV_TILE < n_ops ? WGA_COV_TILE : (u32)(n_ops - tile_start), lane, w);
   cov_list_tile(g, w, lane, ops, op_off, n_ops, tile_info, rec_pos, tile_tail, win_cnt, tile_list, tile_cnt, list_cnt, list, rcap,
                 spin_limit);
 }
@@ -501,15 +515,15 @@ __device__ __forceinline__ void cov_load4(const u32* __restrict__ ops, u64 tile_
 }
 /* where a piece's loads end: its last op rounded up to whole 16-byte groups, inside the tile */
 __device__ __forceinline__ u32 cov_piece_lim(u64 n_ops, const wga_cov_piece& pc) {
-  const u64 tile_start = (u64)pc.g * WGA_TILE;
-  const u32 nt = tile_start + WGA_TILE < n_ops ? WGA_TILE : (u32)(n_ops - tile_start);
+  const u64 tile_start = (u64)pc.g << WGA_COV_TILE_SHIFT;
+  const u32 nt = tile_start + WGA_COV_TILE < n_ops ? WGA_COV_TILE : (u32)(n_ops - tile_start);
   const u32 b4 = ((pc.ab >> 16) + 3u) & ~3u;
   return b4 < nt ? b4 : nt;
 }
 /* the four ops of this lane in the first 256-op step of a piece */
 __device__ __forceinline__ void cov_step_ops(const u32* __restrict__ ops, u64 n_ops, const wga_cov_piece& pc, u32 lane,
                                              u32 (&w)[4]) {
-  cov_load4(ops, (u64)pc.g * WGA_TILE, cov_piece_lim(n_ops, pc), ((pc.ab & 0xFFFFu) & ~3u) + lane * 4u, w);
+  cov_load4(ops, (u64)pc.g << WGA_COV_TILE_SHIFT, cov_piece_lim(n_ops, pc), ((pc.ab & 0xFFFFu) & ~3u) + lane * 4u, w);
 }
 
 /* the last range that starts at or in front of counter k (n when none does) */
@@ -606,7 +620,7 @@ __global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __r
       }
       if (p + (u64)(2 * D + 1) * WGA_COV_WAVES < p_hi) dq[2 * D] = pieces[p + (u64)(2 * D + 1) * WGA_COV_WAVES];
       if (p + (u64)(D + 1) * WGA_COV_WAVES < p_hi) cov_step_ops(ops, n_ops, dq[D], lane, wq[D]);
-      const u64 tile_start = (u64)pc.g * WGA_TILE;
+      const u64 tile_start = (u64)pc.g << WGA_COV_TILE_SHIFT;
       const u32 lim = cov_piece_lim(n_ops, pc);
       const u32 a = pc.ab & 0xFFFFu, b = pc.ab >> 16;
       if (pc.pad & WGA_COV_NARROW) { /* wave-uniform */
