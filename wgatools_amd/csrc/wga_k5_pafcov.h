@@ -435,10 +435,13 @@ __device__ __forceinline__ void cov_list_tile(
   if (lane == 0) tile_cnt[g] = n_mine < (u64)WGA_COV_TILE_CAP ? (u32)n_mine : WGA_COV_TILE_CAP;
 }
 
-/* One wave per tile.  (A grid of resident waves that took every W-th tile and requested the next tile's ops before working on the
- * current one was measured and was 5 % slower, 29.4 against 28.0 ms at configs[3]'s size: the pass is bound by the instructions
- * it issues — 400 vector + 280 scalar per tile at 0.97 per cycle and CU, profiles/r05_k1_k5_counters.txt — not by the wait for
- * its 4 KB of ops.) */
+/* One wave per tile.  Measured against it at configs[3]'s size, all within 1 ms of its 28 ms or slower: a grid of resident waves
+ * that take every W-th tile, with the next tile's ops requested early (29.4 ms at five waves per SIMD) and without (28.0 at
+ * seven, 28.9 at five); tiles of 2 048 ops (31.8); a third fewer vector instructions per tile (646 -> 403, same time).  What the
+ * r04 ablations showed still holds: the pass waits on its small memory operations — per tile one published sum (an atomic),
+ * one or two polls of the neighbour's, 3.5 window counts (atomics), the piece store and the slot count — not on its 4 KB of ops,
+ * not on instruction issue (0.97 per cycle and CU) and not on a wave's lifetime (profiles/r05_k1_k5_counters.txt,
+ * r05_k5_stated_run4 ... run6). */
 __global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
     const u32* __restrict__ ops, const u64* __restrict__ op_off, u64 n_ops, const wga_cov_tile* __restrict__ tile_info,
     const wga_cov_rec* __restrict__ rec_pos, u64* tile_tail, u32* win_cnt, wga_cov_piece* tile_list, u32* tile_cnt, u64* list_cnt,
