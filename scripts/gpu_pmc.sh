@@ -6,8 +6,6 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-# the library would spend these three launches on its drain_min trials (64 / 32 / 16): fix the value it settles on for this shape
-export WGA_EXPAND_DRAIN_MIN=${WGA_EXPAND_DRAIN_MIN:-64}
 BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-e2e --no-placement-probe --check 0"
 # another command's kernels (e.g. K5: WGA_PMC_CMD="python $R/scripts/gpu_k5_scaling.py 1" bash scripts/gpu_pmc.sh k5pmc "sq1 sq2 sq3 tcc")
 BENCH=${WGA_PMC_CMD:-$BENCH}
