@@ -225,7 +225,7 @@ def test_pafcov_segments_across_hundreds_of_windows(emu):
 
 
 def test_pafcov_random_shapes(emu):
-    pc.check_pafcov_random(emu, 11, 8)
+    pc.check_pafcov_random(emu, 11, 5)
 
 
 def test_pafcov_look_back(emu, monkeypatch):
