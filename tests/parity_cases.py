@@ -516,6 +516,27 @@ def check_pafcov_random(eng, seed, cases):
         check_pafcov(eng, b, list(tid), ts, tlen, align=int(rng.choice([1, 4])), split=bool(rng.integers(0, 2)))
 
 
+def check_pafcov_many_small_targets(eng, seed=5, nt=400):
+    """hundreds of targets shorter than a window (8 192 counters), a few of no bases at all, packed without alignment: a
+    window of the counting replay holds dozens of range borders (its counter-by-counter walk, every range a chain of its
+    own), and records that start in one target's counters run over its end"""
+    rng = np.random.default_rng(seed)
+    tlen = [int(x) for x in rng.choice([0, 1, 2, 7, 30, 100, 300, 1000, 9000], nt)]
+    n = 3 * nt
+    tid = [int(x) for x in rng.integers(0, nt, n)]
+    codes = np.array([7, 7, 0, 8, 1, 2, 3], dtype=np.uint32)
+    recs, lens = [], []
+    for _ in range(n):
+        m = int(rng.integers(1, 12))
+        recs.append((rng.integers(0, 60, m).astype(np.uint32) << 4) | rng.choice(codes, m))
+        lens.append(m)
+    b = dict(ops=np.concatenate(recs).astype(np.uint32), op_off=np.cumsum([0] + lens).astype(np.uint64),
+             strand_neg=np.zeros(n, dtype=np.uint8))
+    ts = [int(rng.integers(0, tlen[t] + 3)) for t in tid]
+    check_pafcov(eng, b, tid, ts, tlen, align=1)
+    check_pafcov(eng, b, tid, ts, tlen, align=1, split=True)
+
+
 def check_pafcov(eng, b, target_id, t_start, target_len, align=4, split=False, shuffle=None):
     """both protocols against update_cov_vec: accumulate() per batch + finalize(), and the last batch through
     accumulate_final() (marks and the marks -> counts scan in one pass).  The targets' ranges lie in the array in the order

@@ -224,6 +224,10 @@ def test_pafcov_segments_across_hundreds_of_windows(emu):
     pc.check_pafcov(emu, b, [0, 1, 0], [100, 8191, 4_300_000], [4_400_000, 1_000_000])
 
 
+def test_pafcov_many_small_targets(emu):
+    pc.check_pafcov_many_small_targets(emu, nt=120)
+
+
 def test_pafcov_random_shapes(emu):
     pc.check_pafcov_random(emu, 11, 5)
 

@@ -931,6 +931,54 @@ def test_pafpseudo_config5_long_cigar_cross_check(gpu):
         assert want.numel() == got.numel() and bool((want == got).all()), i
 
 
+def test_pafcov_many_small_targets(gpu):
+    pc.check_pafcov_many_small_targets(gpu, nt=400)
+    pc.check_pafcov_many_small_targets(gpu, seed=6, nt=3000)
+
+
+def test_pafcov_one_long_target_both_protocols(gpu):
+    """ONE target of 2e9 counters (244 141 windows): in the counting replay every window hangs on the window in front of it — the
+    longest chain the look-back can meet, a thousand consecutive windows of it in flight at a time — and the array lies beyond
+    2^31 bytes.  2 000 000 records; accumulate + finalize and accumulate_final give the same counters, and those are the
+    running sum of torch's +1 / -1 marks"""
+    import torch
+    dev = torch.device("cuda", 0)
+    tlen, n = 2_000_000_000, 2_000_000
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    tb = synth.make_paf_batch_torch(431, n, 1300, tlen, dev)
+    batch = engine.Batch(tb["ops"], tb["op_off"], tb["strand_neg"], n, tb["n_ops"])
+    cov_off = torch.tensor([3], dtype=torch.int64, device=dev)          # not aligned to anything
+    cov_len = torch.tensor([tlen], dtype=torch.int64, device=dev)
+    total = tlen + 3
+    tid = torch.zeros(n, dtype=torch.int32, device=dev)
+    cov = torch.zeros(total + 8, dtype=torch.int32, device=dev)
+    gpu.pafcov_accumulate(batch, tid, tb["t_src_off"], cov_off, cov_len, cov, total)
+    gpu.pafcov_finalize(1, cov_off, cov_len, cov)
+    one = torch.zeros(total + 8, dtype=torch.int32, device=dev)
+    gpu.pafcov_accumulate_final(batch, tid, tb["t_src_off"], cov_off, cov_len, 1, one, total)
+    torch.cuda.synchronize()
+    assert bool(torch.equal(cov, one))
+    del one
+    o = tb["ops"].to(torch.int64) & 0xFFFFFFFF
+    code, ln = o & 15, o >> 4
+    nper = tb["op_off"][1:] - tb["op_off"][:-1]
+    rec = torch.repeat_interleave(torch.arange(n, device=dev), nper)
+    adv = torch.where((code == 1) | (code == 4) | (code == 9), torch.zeros_like(ln), ln)
+    cs = torch.cumsum(adv, 0)
+    start_cs = (cs - adv)[tb["op_off"][:-1]]
+    pos = tb["t_src_off"][rec] + (cs - adv) - start_cs[rec]
+    cover = (code == 0) | (code == 7)
+    p0, p1 = pos[cover], (pos + ln)[cover]
+    del o, code, ln, rec, adv, cs, pos, cover
+    exp = torch.zeros(total + 8, dtype=torch.int32, device=dev)
+    m0, m1 = p0 < tlen, p1 < tlen
+    exp.index_add_(0, 3 + p0[m0], torch.ones(int(m0.sum()), dtype=torch.int32, device=dev))
+    exp.index_add_(0, 3 + p1[m1], torch.full((int(m1.sum()),), -1, dtype=torch.int32, device=dev))
+    e = torch.cumsum(exp[3:3 + tlen], 0, dtype=torch.int32)
+    assert bool(torch.equal(e, cov[3:3 + tlen])) and int(cov[:3].abs().sum()) == 0 and int(cov[3 + tlen:].abs().sum()) == 0
+    gpu.reset_stream()
+
+
 def test_pafcov_config4_at_stated_size(gpu):
     """BASELINE configs[3] at its stated size: 64 targets x 100 Mb = 6.4e9 int32 counters (25.6 GB), 20 M records of ~1300
     ops generated on the device in ten chunks and gathered into ONE resident batch (2.6e10 ops, 104 GB), accumulated into
