@@ -959,21 +959,25 @@ def test_pafcov_one_long_target_both_protocols(gpu):
     torch.cuda.synchronize()
     assert bool(torch.equal(cov, one))
     del one
-    o = tb["ops"].to(torch.int64) & 0xFFFFFFFF
-    code, ln = o & 15, o >> 4
-    nper = tb["op_off"][1:] - tb["op_off"][:-1]
-    rec = torch.repeat_interleave(torch.arange(n, device=dev), nper)
-    adv = torch.where((code == 1) | (code == 4) | (code == 9), torch.zeros_like(ln), ln)
-    cs = torch.cumsum(adv, 0)
-    start_cs = (cs - adv)[tb["op_off"][:-1]]
-    pos = tb["t_src_off"][rec] + (cs - adv) - start_cs[rec]
-    cover = (code == 0) | (code == 7)
-    p0, p1 = pos[cover], (pos + ln)[cover]
-    del o, code, ln, rec, adv, cs, pos, cover
     exp = torch.zeros(total + 8, dtype=torch.int32, device=dev)
-    m0, m1 = p0 < tlen, p1 < tlen
-    exp.index_add_(0, 3 + p0[m0], torch.ones(int(m0.sum()), dtype=torch.int32, device=dev))
-    exp.index_add_(0, 3 + p1[m1], torch.full((int(m1.sum()),), -1, dtype=torch.int32, device=dev))
+    op_off, sub = tb["op_off"], 200_000
+    for r0 in range(0, n, sub):                     # 200 000 records at a time (the whole op stream as int64 would not fit)
+        r1 = min(n, r0 + sub)
+        a, b = int(op_off[r0]), int(op_off[r1])
+        o = tb["ops"][a:b].to(torch.int64) & 0xFFFFFFFF
+        code, ln = o & 15, o >> 4
+        nper = op_off[r0 + 1:r1 + 1] - op_off[r0:r1]
+        rec = torch.repeat_interleave(torch.arange(r1 - r0, device=dev), nper)
+        adv = torch.where((code == 1) | (code == 4) | (code == 9), torch.zeros_like(ln), ln)
+        cs = torch.cumsum(adv, 0)
+        start_cs = (cs - adv)[op_off[r0:r1] - a]
+        pos = tb["t_src_off"][r0:r1][rec] + (cs - adv) - start_cs[rec]
+        cover = (code == 0) | (code == 7)
+        p0, p1 = pos[cover], (pos + ln)[cover]
+        m0, m1 = p0 < tlen, p1 < tlen
+        exp.index_add_(0, 3 + p0[m0], torch.ones(int(m0.sum()), dtype=torch.int32, device=dev))
+        exp.index_add_(0, 3 + p1[m1], torch.full((int(m1.sum()),), -1, dtype=torch.int32, device=dev))
+        del o, code, ln, rec, adv, cs, pos, cover, p0, p1, m0, m1
     e = torch.cumsum(exp[3:3 + tlen], 0, dtype=torch.int32)
     assert bool(torch.equal(e, cov[3:3 + tlen])) and int(cov[:3].abs().sum()) == 0 and int(cov[3 + tlen:].abs().sum()) == 0
     gpu.reset_stream()
