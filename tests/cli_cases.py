@@ -553,6 +553,17 @@ def test_call_query_selection(cli, tmp_path):
     assert out.decode() == _expected_vcf(blocks, "sample", True, False, 0, 1000000)
     rc, out, err = run(cli, "c", str(maf), "-s", "-l0", "--query-name", "absent")
     assert rc == 0 and out.decode() == VCF_HEADER % "sample"
+    # Rust `regex` syntax the host's std::regex does not speak is mapped: a leading (?i), named groups, \A / \z, \x{..}
+    for pat in (r"(?i)QRY\.[0-9]", r"(?P<name>qry)\.(?<d>\d)", r"\Aqry\x{2e}\d\z", r"qry\.(?:\d|zz)", r"[q][[:alpha:]]{2}\.\d+?"):
+        rc, out, err = run(cli, "c", str(maf), "-s", "-l0", "--query-regex", pat)
+        assert rc == 0, (pat, err)
+        assert out.decode() == _expected_vcf(blocks, "sample", True, False, 0, 1000000), pat
+    rc, out, err = run(cli, "c", str(maf), "-s", "-l0", "--query-regex", r"(?i)QRY\.0")
+    assert rc == 0 and out.decode() == want0
+    # ... and what the crate refuses at parse time is refused: look-around, back-references, an unbalanced pattern
+    for pat in (r"qry(?=\.)", r"(q)\1", r"qry\.(\d", r"(?s)qry.0", r"\p{L}+"):
+        rc, out, err = run(cli, "c", str(maf), "-s", "-l0", "--query-regex", pat)
+        assert rc != 0 and "regex parse error" in (err if isinstance(err, str) else err.decode()) and out == b"", (pat, rc, err)
 
 
 # ---- call (PAF) ------------------------------------------------------------------------------------
