@@ -100,7 +100,11 @@ struct wga_ctx {
   std::vector<rt_event_t> rs_copied;
   bool rs_same_device_ok = false; /* "reduce_same_device_ok": distinct contexts may share a device (one-GPU test boxes) */
   bool rs_staged = false;         /* "reduce_staged": pull into scratch over N-1 streams instead of reading the peers in place */
-  u32 cov_spin_limit = 1u << 12; /* polls of a tile sum (milliseconds of waiting where ten microseconds are the rule) before the
+#ifdef WGA_EMU
+  u32 cov_spin_limit = 64; /* the emulator runs one block at a time: a tile that is not there yet will not come while this one polls */
+#else
+  u32 cov_spin_limit = 1u << 12;
+#endif /* polls of a tile sum (milliseconds of waiting where ten microseconds are the rule) before the
                                     look-back adds up the ops itself (WGA_COV_SPIN_LIMIT) */
   /* optional per-launch timing of the expand kernel proper (events on the launch stream) */
   static const int kTimingRing = 64;
