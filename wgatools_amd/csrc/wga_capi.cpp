@@ -1598,7 +1598,7 @@ static int pafcov_run(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_ta
   }
   u64 n_pieces = 0;
   if (has_ops) {
-    const u32 grid = (u32)((nt + 3) / 4);
+    const u32 grid = (u32)((nt + WGA_K5_LIST_BW - 1) / WGA_K5_LIST_BW);
     if (c->cov_tile_list_cap < nt) {
       if (c->cov_tile_list) RT_CHECK(rt_free(c->cov_tile_list));
       c->cov_tile_list = nullptr;
@@ -1618,7 +1618,7 @@ static int pafcov_run(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_ta
     u64 n_over = 0;
     for (int attempt = 0;; attempt++) {
       RT_CHECK(rt_memset(ws, 0, b_tail + b_lcnt + b_wcnt, c->stream));
-      WGA_LAUNCH(k_cov_list_pieces, grid, WGA_BLOCK, c->stream, b->d_ops, (const u64*)b->d_op_off, (u64)b->n_ops,
+      WGA_LAUNCH(k_cov_list_pieces, grid, 64u * WGA_K5_LIST_BW, c->stream, b->d_ops, (const u64*)b->d_op_off, (u64)b->n_ops,
                  (const wga_cov_tile*)tile_info, (const wga_cov_rec*)rec_pos, tile_tail, win_cnt,
                  (wga_cov_piece*)c->cov_tile_list, tile_cnt, list_cnt, (wga_cov_piece*)c->cov_list, (u64)c->cov_list_rcap,
                  (u32)c->cov_spin_limit);

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_cov_tile_info(const u64* __restrict__ o
 #endif
 /* one tile of the list pass; w = the tile's packed ops, WGA_COV_LO consecutive ones per lane */
 __device__ __forceinline__ void cov_list_tile(
-    const u64 g, u32 (&w)[WGA_COV_LO], const u32 (&pv)[WGA_COV_LO], const u32 lane, const u32* __restrict__ ops,
+    const u64 g, u32 (&w)[WGA_COV_LO], u64* const s_tail, const u32 lane, const u32* __restrict__ ops,
     const u64* __restrict__ op_off, u64 n_ops,
     const wga_cov_tile* __restrict__ tile_info, const wga_cov_rec* __restrict__ rec_pos, u64* tile_tail, u32* win_cnt,
     wga_cov_piece* tile_list, u32* tile_cnt, u64* list_cnt, wga_cov_piece* list, u64 rcap, u32 spin_limit) {
@@ -282,24 +282,14 @@ __device__ __forceinline__ void cov_list_tile(
   const u32 b0 = (u32)(end0 - tile_start);
   const wga_cov_rec rp0 = tr.rp0;
   /* The first segment's record began in a tile in front.  NEAR — in the tile right in front, four tiles of five on configs[3]'s
-   * records — the wave adds up that tile's ops behind the record's start itself: it asked for them together with its own (pv; the
-   * wave next door reads the same lines, they come from the L1 / this XCD's L2), so nothing is waited for.  Only a record that
-   * began further back goes through the published sums of the tiles in front (a round trip or two through memory per poll:
-   * the look-back was 7.4 of the pass's 28 ms, profiles/r05_k5_list_pass_ablations.txt). */
+   * records — and that tile is another wave's of THIS block: its published sum comes through LDS behind a block barrier
+   * (hundreds of cycles) instead of through memory (a poll is a round trip or two of microseconds: the look-back was 7.4 of the
+   * pass's 28 ms, profiles/r05_k5_list_pass_ablations.txt).  The block's first wave, and records that began further back, go
+   * through the published sums of the tiles in front as before. */
+  const u32 wave = WGA_WAVE_ID(threadIdx.x);
   const bool waits = rs0 < tile_start;
-  const bool near = waits && tile_start - rs0 <= (u64)WGA_COV_TILE;
-  const u64 early = waits && !near ? cov_poll_early(tile_tail, rs0, g, lane) : 0ull;
-  u64 near_sum = 0;
-  if (near) { /* wave-uniform */
-    const u32 from = (u32)(rs0 - (tile_start - WGA_COV_TILE)); /* the record's first op, relative to the tile in front */
-    u64 sl = 0;
-#pragma unroll
-    for (u32 e = 0; e < WGA_COV_LO; e++)
-      sl += lane * WGA_COV_LO + e >= from ? (u64)((pv[e] >> 4) & bit_mask(WGA_COV_MOVES_BITS, pv[e] & 15u)) : 0ull;
-    u64 tot;
-    (void)cov_incl_scan_u64(sl, tot);
-    near_sum = tot;
-  }
+  const bool near_lds = waits && wave != 0u && tile_start - rs0 <= (u64)WGA_COV_TILE;
+  const u64 early = waits && !near_lds ? cov_poll_early(tile_tail, rs0, g, lane) : 0ull;
   /* ONE scan serves every segment of the tile: the lanes' advance summed over all 1 024 ops, whatever records they belong to.
    * The advance in front of op i (wave-uniform i) is the sum of the lanes in front of i's lane plus that lane's ops in front of
    * i: a handful of adds in every lane and two v_readlane.  A tile that advances less than 2^31 bases (NARROW: every tile of a
@@ -342,8 +332,10 @@ __device__ __forceinline__ void cov_list_tile(
       }
     }
     publish(span_last);
+    if (lane == 0) s_tail[wave] = span_last;
   }
-  const u64 base0 = near ? near_sum : waits ? cov_look_back(tile_tail, ops, rs0, g, lane, spin_limit, early) : 0ull;
+  __syncthreads(); /* every wave of the block comes here (k_cov_list_pieces): the waves' sums are in LDS */
+  const u64 base0 = near_lds ? WGA_UNI64(s_tail[wave - 1u]) : waits ? cov_look_back(tile_tail, ops, rs0, g, lane, spin_limit, early) : 0ull;
   if (narrow) {
     u32 n_p = 0; /* pieces so far; lane q keeps piece q until the walk is through (nothing is written before) */
     u32 pc_ab = 0, pc_wi = 0, pc_pad = 0;
@@ -453,27 +445,37 @@ __device__ __forceinline__ void cov_list_tile(
   if (lane == 0) tile_cnt[g] = n_mine < (u64)WGA_COV_TILE_CAP ? (u32)n_mine : WGA_COV_TILE_CAP;
 }
 
-/* One wave per tile; a block's four waves take four consecutive tiles, and the blocks of one XCD (every eighth block) take one
- * contiguous eighth of the tiles: the tile in front of a wave's own — whose ops it reads as well, for the advance of a record
- * that began there — was read a moment ago by the wave next door or by the block in front on the SAME XCD (its L2), and the
- * published sums a far record's look-back polls were written on this XCD too.
- * Measured against one wave per tile at configs[3]'s size, all within 1 ms of it or slower: a grid of resident waves that take
- * every W-th tile, with the next tile's ops requested early (29.4 ms at five waves per SIMD) and without (28.0 at seven, 28.9
- * at five); tiles of 2 048 ops (31.8); a third fewer vector instructions per tile (646 -> 403, same time).  The ablations of
- * round 5 (profiles/r05_k5_list_pass_ablations.txt: 27.95 ms as it was; without the window counts 27.2, without the piece store
- * 26.3, WITHOUT THE LOOK-BACK 20.5) say where the time went. */
-__global__ __launch_bounds__(256, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
+/* One wave per tile; a block's WGA_K5_LIST_BW waves take consecutive tiles, so that a wave finds the sum of the tile in front
+ * of its own in LDS (cov_list_tile).
+ * Measured against one wave per tile with every look-back through memory, at configs[3]'s size, all within 1 ms of its 28 ms or
+ * slower: a grid of resident waves that take every W-th tile, with the next tile's ops requested early (29.4 ms at five waves
+ * per SIMD) and without (28.0 at seven, 28.9 at five); tiles of 2 048 ops (31.8); a third fewer vector instructions per tile
+ * (646 -> 403, same time); the wave reading the tile in front again to add up a near record's ops itself (38.4 ms: the second
+ * read of a line another wave of the same CU has just asked for goes to HBM again).  The ablations of round 5
+ * (profiles/r05_k5_list_pass_ablations.txt: 27.95 ms as it was; without the window counts 27.2, without the piece store 26.3,
+ * WITHOUT THE LOOK-BACK 20.5) say where the time went. */
+#ifndef WGA_K5_LIST_BW
+#define WGA_K5_LIST_BW 4u /* waves per block */
+#endif
+#ifndef WGA_K5_LIST_XCD
+#define WGA_K5_LIST_XCD 0 /* 1: the blocks of one XCD take one contiguous eighth of the tiles */
+#endif
+__global__ __launch_bounds__(64 * WGA_K5_LIST_BW, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
     const u32* __restrict__ ops, const u64* __restrict__ op_off, u64 n_ops, const wga_cov_tile* __restrict__ tile_info,
     const wga_cov_rec* __restrict__ rec_pos, u64* tile_tail, u32* win_cnt, wga_cov_piece* tile_list, u32* tile_cnt, u64* list_cnt,
     wga_cov_piece* list, u64 rcap, u32 spin_limit) {
+  __shared__ u64 s_tail[WGA_K5_LIST_BW];
   const u32 lane = threadIdx.x & 63u;
-  const u64 g = xcd_tile_of_block() * 4 + WGA_WAVE_ID(threadIdx.x);
+  const u64 blk = WGA_K5_LIST_XCD ? xcd_tile_of_block() : (u64)blockIdx.x;
+  const u64 g = blk * WGA_K5_LIST_BW + WGA_WAVE_ID(threadIdx.x);
   const u64 tile_start = g << WGA_COV_TILE_SHIFT;
-  if (tile_start >= n_ops) return;
-  u32 w[WGA_COV_LO], pv[WGA_COV_LO];
+  if (tile_start >= n_ops) { /* the waves behind the stream's last tile only keep the block's barrier company */
+    __syncthreads();
+    return;
+  }
+  u32 w[WGA_COV_LO];
   cov_load_ops(ops, tile_start, tile_start + WGA_COV_TILE < n_ops ? WGA_COV_TILE : (u32)(n_ops - tile_start), lane, w);
-  cov_load_ops(ops, g ? tile_start - WGA_COV_TILE : 0ull, g ? WGA_COV_TILE : 0u, lane, pv); /* the tile in front, whole */
-  cov_list_tile(g, w, pv, lane, ops, op_off, n_ops, tile_info, rec_pos, tile_tail, win_cnt, tile_list, tile_cnt, list_cnt, list, rcap,
+  cov_list_tile(g, w, s_tail, lane, ops, op_off, n_ops, tile_info, rec_pos, tile_tail, win_cnt, tile_list, tile_cnt, list_cnt, list, rcap,
                 spin_limit);
 }
 
