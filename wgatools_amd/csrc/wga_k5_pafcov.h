@@ -446,19 +446,18 @@ __device__ __forceinline__ void cov_list_tile(
 }
 
 /* One wave per tile; a block's WGA_K5_LIST_BW waves take consecutive tiles, so that a wave finds the sum of the tile in front
- * of its own in LDS (cov_list_tile).
- * Measured against one wave per tile with every look-back through memory, at configs[3]'s size, all within 1 ms of its 28 ms or
- * slower: a grid of resident waves that take every W-th tile, with the next tile's ops requested early (29.4 ms at five waves
- * per SIMD) and without (28.0 at seven, 28.9 at five); tiles of 2 048 ops (31.8); a third fewer vector instructions per tile
- * (646 -> 403, same time); the wave reading the tile in front again to add up a near record's ops itself (38.4 ms: the second
- * read of a line another wave of the same CU has just asked for goes to HBM again).  The ablations of round 5
+ * of its own in LDS (cov_list_tile): 27.95 -> 23.3 ms at configs[3]'s size with four waves per block (eight: 28.9 ms, sixteen:
+ * 39.0 — the barrier holds more waves; four with the blocks of one XCD on one contiguous eighth of the tiles: 33.0;
+ * profiles/r05_k5_stated_run8_lds_handover_variants.txt).
+ * Measured against one wave per tile with every look-back through memory, all within 1 ms of its 28 ms or slower: a grid of
+ * resident waves that take every W-th tile, with the next tile's ops requested early (29.4 ms at five waves per SIMD) and
+ * without (28.0 at seven, 28.9 at five); tiles of 2 048 ops (31.8); a third fewer vector instructions per tile (646 -> 403,
+ * same time); the wave reading the tile in front again to add up a near record's ops itself (38.4 ms: the second read of a
+ * line another wave of the same CU has just asked for goes to HBM again).  The ablations of round 5
  * (profiles/r05_k5_list_pass_ablations.txt: 27.95 ms as it was; without the window counts 27.2, without the piece store 26.3,
- * WITHOUT THE LOOK-BACK 20.5) say where the time went. */
+ * WITHOUT THE LOOK-BACK 20.5) said where the time went. */
 #ifndef WGA_K5_LIST_BW
 #define WGA_K5_LIST_BW 4u /* waves per block */
-#endif
-#ifndef WGA_K5_LIST_XCD
-#define WGA_K5_LIST_XCD 0 /* 1: the blocks of one XCD take one contiguous eighth of the tiles */
 #endif
 __global__ __launch_bounds__(64 * WGA_K5_LIST_BW, WGA_K5_LIST_WAVES) void k_cov_list_pieces(
     const u32* __restrict__ ops, const u64* __restrict__ op_off, u64 n_ops, const wga_cov_tile* __restrict__ tile_info,
@@ -466,8 +465,7 @@ __global__ __launch_bounds__(64 * WGA_K5_LIST_BW, WGA_K5_LIST_WAVES) void k_cov_
     wga_cov_piece* list, u64 rcap, u32 spin_limit) {
   __shared__ u64 s_tail[WGA_K5_LIST_BW];
   const u32 lane = threadIdx.x & 63u;
-  const u64 blk = WGA_K5_LIST_XCD ? xcd_tile_of_block() : (u64)blockIdx.x;
-  const u64 g = blk * WGA_K5_LIST_BW + WGA_WAVE_ID(threadIdx.x);
+  const u64 g = (u64)blockIdx.x * WGA_K5_LIST_BW + WGA_WAVE_ID(threadIdx.x);
   const u64 tile_start = g << WGA_COV_TILE_SHIFT;
   if (tile_start >= n_ops) { /* the waves behind the stream's last tile only keep the block's barrier company */
     __syncthreads();
