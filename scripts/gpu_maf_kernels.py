@@ -36,7 +36,11 @@ cols = torch.full((n,), L, dtype=torch.int64, device=dev)
 t_off = (torch.arange(n, device=dev) * L).to(torch.int64)
 q_off = t_off + tot
 strand = (torch.rand(n, device=dev, generator=g) < 0.1).to(torch.uint8)
-eng = engine.Engine(0)
+lib = None
+if os.environ.get("WGA_LIB"):     # an A/B build (wgatools_amd.build.build_hip_variant)
+    from wgatools_amd import _lib
+    lib = _lib.load(os.environ["WGA_LIB"])
+eng = engine.Engine(0, lib)
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 counts = torch.zeros((n, 11), dtype=torch.int64, device=dev)
 run_cnt = torch.zeros(n, dtype=torch.int64, device=dev)

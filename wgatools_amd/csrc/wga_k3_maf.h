@@ -560,25 +560,46 @@ __device__ __forceinline__ void maf_pair_store(const MafWalkOut& w, bool neg, wg
   if (lane == 0 && run_cnt) *run_cnt = w.runs;
 }
 
+/* what a wave needs of its two blocks before their rows can be asked for: wave-uniform, scalar loads */
+struct MafPairIn {
+  u64 L0, L1, to0, qo0, to1, qo1, ro0, ro1;
+  u32 neg0, neg1;
+  bool two;
+};
+__device__ __forceinline__ MafPairIn maf_pair_in(u64 i0, u32 n, const u64* __restrict__ t_off, const u64* __restrict__ q_off,
+                                                 const u64* __restrict__ cols, const u8* __restrict__ strand_neg,
+                                                 const u64* __restrict__ run_off) {
+  MafPairIn p;
+  p.two = i0 + 1u < n;
+  const u64 i1 = p.two ? i0 + 1u : i0;
+  /* told to be wave-uniform: the values live in scalar registers across the walk (a resident wave holds the next pair's) */
+  p.L0 = WGA_UNI64(cols[i0]), p.L1 = WGA_UNI64(cols[i1]);
+  p.to0 = WGA_UNI64(t_off[i0]), p.qo0 = WGA_UNI64(q_off[i0]), p.to1 = WGA_UNI64(t_off[i1]), p.qo1 = WGA_UNI64(q_off[i1]);
+  p.neg0 = strand_neg ? WGA_UNI32(strand_neg[i0] != 0 ? 1u : 0u) : 0u;
+  p.neg1 = strand_neg ? WGA_UNI32(strand_neg[i1] != 0 ? 1u : 0u) : 0u;
+  p.ro0 = run_off ? WGA_UNI64(run_off[i0]) : 0ull;
+  p.ro1 = run_off ? WGA_UNI64(run_off[i1]) : 0ull;
+  return p;
+}
+
 /* Two consecutive records per wave: the offsets of both are fetched together and the second record's first rows travel while
  * the first record is walked — three dependent round trips (offsets, rows, every further step) stood in front of the work
- * of a 1 500-column block, the step loop above and this pairing leave one. */
-__global__ __launch_bounds__(256, WGA_K3_BLOCKS) void k_maf_pair_stat(u32 n, const u8* __restrict__ rows,
-                                                       const u64* t_off, const u64* q_off,
-                                                       const u64* cols, const u8* strand_neg,
-                                                       wga_cigar_counts* counts, u64* run_cnt,
-                                                       u64* runs, const u64* run_off, u64 long_cols) {
-  const u32 lane = threadIdx.x & 63u;
-  const u64 i0 = ((u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x)) * 2u;
-  if (i0 >= n) return;
-  const bool two = i0 + 1u < n;
-  const u64 i1 = two ? i0 + 1u : i0;
-  const u64 L0 = cols[i0], L1 = cols[i1];
-  const u8 *t0 = rows + t_off[i0], *q0 = rows + q_off[i0], *t1 = rows + t_off[i1], *q1 = rows + q_off[i1];
-  const bool neg0 = strand_neg[i0] != 0, neg1 = strand_neg[i1] != 0;
+ * of a 1 500-column block, the step loop above and this pairing leave one.
+ * WGA_MAF_PERSIST (round 5): a grid of resident waves; wave j of W takes the pairs j, W + j ... and asks for the NEXT pair's
+ * offsets (scalar registers only) before it walks the current one, so that the round trip for the offsets is off the path as
+ * well. */
+#ifndef WGA_MAF_PERSIST
+#define WGA_MAF_PERSIST 1
+#endif
+__device__ __forceinline__ void maf_pair_stat_body(const MafPairIn& p, u64 i0, const u8* __restrict__ rows, wga_cigar_counts* counts,
+                                                   u64* run_cnt, u64* runs, u64 long_cols, u32 lane) {
+  const u64 i1 = p.two ? i0 + 1u : i0;
+  const u8 *t0 = rows + p.to0, *q0 = rows + p.qo0, *t1 = rows + p.to1, *q1 = rows + p.qo1;
+  const bool neg0 = p.neg0 != 0u, neg1 = p.neg1 != 0u;
   u64 *r0 = (u64*)0, *r1 = (u64*)0;
-  if (runs) r0 = runs + run_off[i0], r1 = runs + run_off[i1];
-  const bool do0 = L0 <= long_cols, do1 = two && L1 <= long_cols; /* a long block: walked piece by piece (k_maf_piece_walk) */
+  if (runs) r0 = runs + p.ro0, r1 = runs + p.ro1;
+  const u64 L0 = p.L0, L1 = p.L1;
+  const bool do0 = L0 <= long_cols, do1 = p.two && L1 <= long_cols; /* a long block: walked piece by piece (k_maf_piece_walk) */
   if (do0 && do1 && maf_pair_pays(L0, L1)) { /* wave-uniform: two short blocks as one column stream */
     MafWalkOut wA, wB;
     maf_walk_pair<false>(t0, q0, (u32)L0, r0, t1, q1, (u32)L1, r1, wA, wB);
@@ -592,21 +613,39 @@ __global__ __launch_bounds__(256, WGA_K3_BLOCKS) void k_maf_pair_stat(u32 n, con
   if (do0) maf_pair_one(t0, q0, L0, r0, neg0, f0, counts + i0, run_cnt ? run_cnt + i0 : (u64*)0, lane); /* wave-uniform */
   if (do1) maf_pair_one(t1, q1, L1, r1, neg1, f1, counts + i1, run_cnt ? run_cnt + i1 : (u64*)0, lane);
 }
-
-__global__ __launch_bounds__(256) void k_maf_call_runs(u32 n, const u8* __restrict__ rows,
+__global__ __launch_bounds__(256, WGA_K3_BLOCKS) void k_maf_pair_stat(u32 n, const u8* __restrict__ rows,
                                                        const u64* t_off, const u64* q_off,
-                                                       const u64* cols, u64* run_cnt, u64* runs,
-                                                       const u64* run_off, u64 long_cols) {
+                                                       const u64* cols, const u8* strand_neg,
+                                                       wga_cigar_counts* counts, u64* run_cnt,
+                                                       u64* runs, const u64* run_off, u64 long_cols) {
   const u32 lane = threadIdx.x & 63u;
-  const u64 i0 = ((u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x)) * 2u;
+  u64 i0 = ((u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x)) * 2u;
   if (i0 >= n) return;
-  const bool two = i0 + 1u < n;
-  const u64 i1 = two ? i0 + 1u : i0;
-  const u64 L0 = cols[i0], L1 = cols[i1];
-  const u8 *t0 = rows + t_off[i0], *q0 = rows + q_off[i0], *t1 = rows + t_off[i1], *q1 = rows + q_off[i1];
+  MafPairIn p = maf_pair_in(i0, n, t_off, q_off, cols, strand_neg, runs ? run_off : (const u64*)0);
+#if WGA_MAF_PERSIST
+  const u64 stride = (u64)gridDim.x * 8u;
+  for (;;) {
+    const u64 in = i0 + stride;
+    MafPairIn pn = p;
+    if (in < n) pn = maf_pair_in(in, n, t_off, q_off, cols, strand_neg, runs ? run_off : (const u64*)0); /* behind the walk below */
+    maf_pair_stat_body(p, i0, rows, counts, run_cnt, runs, long_cols, lane);
+    if (in >= n) break;
+    i0 = in;
+    p = pn;
+  }
+#else
+  maf_pair_stat_body(p, i0, rows, counts, run_cnt, runs, long_cols, lane);
+#endif
+}
+
+__device__ __forceinline__ void maf_call_runs_body(const MafPairIn& p, u64 i0, const u8* __restrict__ rows, u64* run_cnt, u64* runs,
+                                                   u64 long_cols, u32 lane) {
+  const u64 i1 = p.two ? i0 + 1u : i0;
+  const u8 *t0 = rows + p.to0, *q0 = rows + p.qo0, *t1 = rows + p.to1, *q1 = rows + p.qo1;
   u64 *r0 = (u64*)0, *r1 = (u64*)0;
-  if (runs) r0 = runs + 3 * run_off[i0], r1 = runs + 3 * run_off[i1];
-  const bool do0 = L0 <= long_cols, do1 = two && L1 <= long_cols;
+  if (runs) r0 = runs + 3 * p.ro0, r1 = runs + 3 * p.ro1;
+  const u64 L0 = p.L0, L1 = p.L1;
+  const bool do0 = L0 <= long_cols, do1 = p.two && L1 <= long_cols;
   if (do0 && do1 && maf_pair_pays(L0, L1)) { /* wave-uniform: two short blocks as one column stream */
     MafWalkOut wA, wB;
     maf_walk_pair<true>(t0, q0, (u32)L0, r0, t1, q1, (u32)L1, r1, wA, wB);
@@ -626,6 +665,29 @@ __global__ __launch_bounds__(256) void k_maf_call_runs(u32 n, const u8* __restri
     maf_walk<true>(t1, q1, L1, r1, w, MafWalkStart{0, 0, 0, 0xFFu}, true, f1);
     if (lane == 0 && run_cnt) run_cnt[i1] = w.runs;
   }
+}
+__global__ __launch_bounds__(256) void k_maf_call_runs(u32 n, const u8* __restrict__ rows,
+                                                       const u64* t_off, const u64* q_off,
+                                                       const u64* cols, u64* run_cnt, u64* runs,
+                                                       const u64* run_off, u64 long_cols) {
+  const u32 lane = threadIdx.x & 63u;
+  u64 i0 = ((u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x)) * 2u;
+  if (i0 >= n) return;
+  MafPairIn p = maf_pair_in(i0, n, t_off, q_off, cols, (const u8*)0, runs ? run_off : (const u64*)0);
+#if WGA_MAF_PERSIST
+  const u64 stride = (u64)gridDim.x * 8u;
+  for (;;) {
+    const u64 in = i0 + stride;
+    MafPairIn pn = p;
+    if (in < n) pn = maf_pair_in(in, n, t_off, q_off, cols, (const u8*)0, runs ? run_off : (const u64*)0);
+    maf_call_runs_body(p, i0, rows, run_cnt, runs, long_cols, lane);
+    if (in >= n) break;
+    i0 = in;
+    p = pn;
+  }
+#else
+  maf_call_runs_body(p, i0, rows, run_cnt, runs, long_cols, lane);
+#endif
 }
 
 template <bool CALLER>
