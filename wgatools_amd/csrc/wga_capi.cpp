@@ -1076,25 +1076,6 @@ int wga_scatter_bytes(wga_ctx* c, uint32_t n, const uint8_t* d_src, const uint64
 /* ------------------------------------------------------------------------------------------ */
 /* K3 / K5 / K6 launchers (kernels in wga_kernels2.h)                                          */
 /* ------------------------------------------------------------------------------------------ */
-/* blocks of the two MAF walks: one wave per pair of blocks, or (WGA_MAF_PERSIST) what the device keeps resident */
-static u32 maf_pair_grid(wga_ctx* c, const void* kernel, u32 n) {
-  const u32 all = (n + 7u) / 8u;
-#if WGA_MAF_PERSIST && !defined(WGA_EMU)
-  int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)WGA_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < 1) cus = 1;
-  (void)hipGetLastError();
-  const u32 res = (u32)per_cu * (u32)cus;
-  return all < res ? all : res;
-#elif WGA_MAF_PERSIST
-  (void)c, (void)kernel;
-  return all < 3u ? all : 3u; /* the emulator: a few blocks, several rounds each */
-#else
-  (void)c, (void)kernel;
-  return all;
-#endif
-}
-
 int wga_maf_pair_stat(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint64_t* d_t_off,
                       const uint64_t* d_q_off, const uint64_t* d_cols,
                       const uint8_t* d_strand_neg, wga_cigar_counts* d_counts,
@@ -1105,7 +1086,7 @@ int wga_maf_pair_stat(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint6
   if (!d_rows || !d_t_off || !d_q_off || !d_cols || !d_strand_neg || !d_counts)
     return fail(WGA_E_INVALID_ARG, "null array", nullptr);
   if (d_runs && !d_run_off) return fail(WGA_E_INVALID_ARG, "d_run_off null", nullptr);
-  WGA_LAUNCH(k_maf_pair_stat, maf_pair_grid(c, (const void*)k_maf_pair_stat, n), WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off,
+  WGA_LAUNCH(k_maf_pair_stat, (n + 7u) / 8u, WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off,
              (const u64*)d_q_off, (const u64*)d_cols, d_strand_neg, d_counts, (u64*)d_run_cnt,
              (u64*)d_runs, (const u64*)d_run_off, (u64)c->maf_long_cols);
   LAUNCH_CHECK();
@@ -1121,7 +1102,7 @@ int wga_maf_call_runs(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint6
   if (n == 0) return WGA_OK;
   if (!d_rows || !d_t_off || !d_q_off || !d_cols) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
   if (d_runs && !d_run_off) return fail(WGA_E_INVALID_ARG, "d_run_off null", nullptr);
-  WGA_LAUNCH(k_maf_call_runs, maf_pair_grid(c, (const void*)k_maf_call_runs, n), WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off,
+  WGA_LAUNCH(k_maf_call_runs, (n + 7u) / 8u, WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off,
              (const u64*)d_q_off, (const u64*)d_cols, (u64*)d_run_cnt, (u64*)d_runs,
              (const u64*)d_run_off, (u64)c->maf_long_cols);
   LAUNCH_CHECK();

@@ -572,7 +572,7 @@ __device__ __forceinline__ MafPairIn maf_pair_in(u64 i0, u32 n, const u64* __res
   MafPairIn p;
   p.two = i0 + 1u < n;
   const u64 i1 = p.two ? i0 + 1u : i0;
-  /* told to be wave-uniform: the values live in scalar registers across the walk (a resident wave holds the next pair's) */
+  /* told to be wave-uniform: the values live in scalar registers across the walk */
   p.L0 = WGA_UNI64(cols[i0]), p.L1 = WGA_UNI64(cols[i1]);
   p.to0 = WGA_UNI64(t_off[i0]), p.qo0 = WGA_UNI64(q_off[i0]), p.to1 = WGA_UNI64(t_off[i1]), p.qo1 = WGA_UNI64(q_off[i1]);
   p.neg0 = strand_neg ? WGA_UNI32(strand_neg[i0] != 0 ? 1u : 0u) : 0u;
@@ -585,12 +585,9 @@ __device__ __forceinline__ MafPairIn maf_pair_in(u64 i0, u32 n, const u64* __res
 /* Two consecutive records per wave: the offsets of both are fetched together and the second record's first rows travel while
  * the first record is walked — three dependent round trips (offsets, rows, every further step) stood in front of the work
  * of a 1 500-column block, the step loop above and this pairing leave one.
- * WGA_MAF_PERSIST (round 5): a grid of resident waves; wave j of W takes the pairs j, W + j ... and asks for the NEXT pair's
- * offsets (scalar registers only) before it walks the current one, so that the round trip for the offsets is off the path as
- * well. */
-#ifndef WGA_MAF_PERSIST
-#define WGA_MAF_PERSIST 1
-#endif
+ * (Round 5 measured a grid of resident waves that ask for the NEXT pair's offsets — scalar registers only — before they walk
+ * the current pair: K3 0.344 against 0.247 ms, K4 0.249 against 0.224 on 200 000 blocks of 1 500 columns,
+ * profiles/r05_maf_resident_waves_variants.txt: one wave per pair, launched by the hardware as slots free up, overlaps better.) */
 __device__ __forceinline__ void maf_pair_stat_body(const MafPairIn& p, u64 i0, const u8* __restrict__ rows, wga_cigar_counts* counts,
                                                    u64* run_cnt, u64* runs, u64 long_cols, u32 lane) {
   const u64 i1 = p.two ? i0 + 1u : i0;
@@ -619,23 +616,10 @@ __global__ __launch_bounds__(256, WGA_K3_BLOCKS) void k_maf_pair_stat(u32 n, con
                                                        wga_cigar_counts* counts, u64* run_cnt,
                                                        u64* runs, const u64* run_off, u64 long_cols) {
   const u32 lane = threadIdx.x & 63u;
-  u64 i0 = ((u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x)) * 2u;
+  const u64 i0 = ((u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x)) * 2u;
   if (i0 >= n) return;
-  MafPairIn p = maf_pair_in(i0, n, t_off, q_off, cols, strand_neg, runs ? run_off : (const u64*)0);
-#if WGA_MAF_PERSIST
-  const u64 stride = (u64)gridDim.x * 8u;
-  for (;;) {
-    const u64 in = i0 + stride;
-    MafPairIn pn = p;
-    if (in < n) pn = maf_pair_in(in, n, t_off, q_off, cols, strand_neg, runs ? run_off : (const u64*)0); /* behind the walk below */
-    maf_pair_stat_body(p, i0, rows, counts, run_cnt, runs, long_cols, lane);
-    if (in >= n) break;
-    i0 = in;
-    p = pn;
-  }
-#else
+  const MafPairIn p = maf_pair_in(i0, n, t_off, q_off, cols, strand_neg, runs ? run_off : (const u64*)0);
   maf_pair_stat_body(p, i0, rows, counts, run_cnt, runs, long_cols, lane);
-#endif
 }
 
 __device__ __forceinline__ void maf_call_runs_body(const MafPairIn& p, u64 i0, const u8* __restrict__ rows, u64* run_cnt, u64* runs,
@@ -671,23 +655,10 @@ __global__ __launch_bounds__(256) void k_maf_call_runs(u32 n, const u8* __restri
                                                        const u64* cols, u64* run_cnt, u64* runs,
                                                        const u64* run_off, u64 long_cols) {
   const u32 lane = threadIdx.x & 63u;
-  u64 i0 = ((u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x)) * 2u;
+  const u64 i0 = ((u64)blockIdx.x * 4 + WGA_WAVE_ID(threadIdx.x)) * 2u;
   if (i0 >= n) return;
-  MafPairIn p = maf_pair_in(i0, n, t_off, q_off, cols, (const u8*)0, runs ? run_off : (const u64*)0);
-#if WGA_MAF_PERSIST
-  const u64 stride = (u64)gridDim.x * 8u;
-  for (;;) {
-    const u64 in = i0 + stride;
-    MafPairIn pn = p;
-    if (in < n) pn = maf_pair_in(in, n, t_off, q_off, cols, (const u8*)0, runs ? run_off : (const u64*)0);
-    maf_call_runs_body(p, i0, rows, run_cnt, runs, long_cols, lane);
-    if (in >= n) break;
-    i0 = in;
-    p = pn;
-  }
-#else
+  const MafPairIn p = maf_pair_in(i0, n, t_off, q_off, cols, (const u8*)0, runs ? run_off : (const u64*)0);
   maf_call_runs_body(p, i0, rows, run_cnt, runs, long_cols, lane);
-#endif
 }
 
 template <bool CALLER>
