@@ -121,9 +121,10 @@ def pmc_traffic(args, job):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE and WRITE_SIZE are
     collected in their own rocprofv3 runs — scripts/gpu_pmc.sh — and corrected as MI355X_MICROARCH.md prescribes; they
     cannot be read live).  Only valid for the workload AND the kernel source they were measured on: anything else -> null."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")), reverse=True):  # newest round first
         try:
-            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+            t = json.load(open(path))
         except Exception:
             continue
         w = t.get("workload", {})
@@ -171,7 +172,7 @@ def e2e_leg(tb, synth, torch, check=2):
     tmp = tempfile.mkdtemp(prefix="wga_e2e_", dir="/tmp")
     try:
         free = shutil.disk_usage(tmp).free
-        if free < rows_bytes * 1.2 + 4e9:
+        if free < rows_bytes * 1.6 + 4e9:
             return {"skipped": "%.0f GB free under /tmp, the MAF alone is %.0f GB" % (free / 1e9, rows_bytes / 1e9)}
         t_fa, q_fa, paf = (os.path.join(tmp, f) for f in ("t.fa", "q.fa", "in.paf"))
         for path, name, pool in ((t_fa, b"tchr", tb["t_pool"]), (q_fa, b"qchr", tb["q_pool"])):
@@ -193,7 +194,8 @@ def e2e_leg(tb, synth, torch, check=2):
                if not (k.startswith("ROCPROF") or k.startswith("ROCP_") or k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE"))}
         env["WGA_TIMING"] = "1"
         for name, argv, outp in (("stat", ["stat", "-f", "paf", paf], os.path.join(tmp, "out.tsv")),
-                                 ("paf2maf", ["paf2maf", paf, "-g", t_fa, "-q", q_fa], os.path.join(tmp, "out.maf"))):
+                                 ("paf2maf", ["paf2maf", paf, "-g", t_fa, "-q", q_fa], os.path.join(tmp, "out.maf")),
+                                 ("paf2maf_gz", ["paf2maf", paf, "-g", t_fa, "-q", q_fa], os.path.join(tmp, "out.maf.gz"))):
             t0 = time.perf_counter()
             r = subprocess.run([cli] + argv + ["-o", outp, "-r"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env,
                                timeout=900)
@@ -217,6 +219,28 @@ def e2e_leg(tb, synth, torch, check=2):
                 et, eq = pc.oracle_rows(synth.torch_batch_record_to_numpy(tb, i), 0)
                 assert srows[0].split(b"\t")[-1] == et and srows[1].split(b"\t")[-1] == eq, "MAF block %d differs from the oracle" % i
             out["paf2maf"]["parity_spot_check"] = "first %d MAF blocks bit-identical to oracle rows" % check
+        if "wall_s" in out.get("paf2maf_gz", {}) and "wall_s" in out.get("paf2maf", {}):
+            # `-o out.maf.gz` (utils.rs:201-209): BGZF members deflated on the device (K18).  Every member's ISIZE is added up
+            # against the plain file's size; the first 64 members are inflated by zlib and compared with the plain file's head.
+            import mmap, struct, zlib
+            g = out["paf2maf_gz"]
+            with open(os.path.join(tmp, "out.maf.gz"), "rb") as f, open(os.path.join(tmp, "out.maf"), "rb") as fp:
+                mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+                p, total, members, head = 0, 0, 0, []
+                while p < len(mm):
+                    bsize = struct.unpack_from("<H", mm, p + 16)[0] + 1
+                    total += struct.unpack_from("<I", mm, p + bsize - 4)[0]
+                    if members < 64:
+                        head.append(zlib.decompress(mm[p + 18:p + bsize - 8], -15))
+                    members += 1
+                    p += bsize
+                head = b"".join(head)
+                ok = p == len(mm) and total == out["paf2maf"]["output_bytes"] and fp.read(len(head)) == head
+                mm.close()
+            g["members"] = members
+            g["ratio"] = g["output_bytes"] / out["paf2maf"]["output_bytes"]
+            g["check"] = ("ISIZE of all members adds up to the plain MAF's size; the first 64 members inflate (zlib) to its head" if ok
+                          else "MISMATCH against the plain MAF")
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -472,6 +472,21 @@ int wga_pafcov_accumulate_final(wga_ctx*, const wga_cigar_batch*, const uint32_t
                                 const uint64_t* d_cov_len, uint32_t n_targets, int32_t* d_cov,
                                 uint64_t total_cov);
 
+/* K18 — output bytes in HBM -> BGZF: what `-o out.maf.gz` stands for in the reference (utils.rs:181-228 wraps the output
+ * file in flate2's GzEncoder, level 6, when the name ends in `.gz`; converter.rs / pafcov.rs / pseudomaf.rs write through
+ * that writer).  The promise to a reader is a gzip stream that inflates to the plain output; this entry keeps it with the
+ * text still on the device, so the compressed bytes are what crosses PCIe.  The stream is a sequence of complete gzip
+ * members of at most 32 768 input bytes, each with the BGZF `BC` extra field (members are independent: seekable by
+ * htslib-style readers, concatenable; any gzip reader takes the whole), each one deflate block of literals under the
+ * member's own Huffman code, or a stored block where that is not smaller.  Calls on consecutive pieces of an output
+ * concatenate into one valid stream; eof_marker != 0 appends BGZF's 28-byte empty member behind the last piece.
+ *   wga_bgzf_bound(n)      what d_out must hold for n input bytes in the worst case (stored members + marker)
+ *   wga_bgzf_compress(..)  d_in[n_bytes] -> d_out[*out_bytes]; synchronises once (the size); d_in, d_out any alignment.
+ *                          WGA_E_INVALID_ARG with *out_bytes set when out_cap is too small (nothing written). */
+uint64_t wga_bgzf_bound(uint64_t n_bytes);
+int wga_bgzf_compress(wga_ctx*, const uint8_t* d_in, uint64_t n_bytes, uint8_t* d_out, uint64_t out_cap, uint64_t* out_bytes,
+                      int eof_marker);
+
 /* pafcov's text back end (pafcov.rs:56-60): the BED lines
  * "<name>\t<pos>\t<pos+1>\t<count>\n" for positions p0 .. p0+count-1 of one target, d_cov pointing
  * at the counter of p0.  Two calls: with d_out == NULL it fills d_line_off[count+1] (exclusive

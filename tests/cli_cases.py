@@ -112,6 +112,12 @@ def test_paf2maf_end_to_end(cli, tmp_path):
     rc, _, err = run(cli, "p2m", paf, "-g", t_fa, "-q", q_fa, "-o", gz)
     import gzip
     assert rc == 0 and gzip.open(gz, "rb").read() == _expected_maf(b, mapq, t_fa, q_fa, 60)
+    # the .gz file is BGZF: the header line as a host (zlib) member, the rows as members deflated on the device, the empty member at the end
+    img = open(gz, "rb").read()
+    n_members = pc.bgzf_check_stream(img, _expected_maf(b, mapq, t_fa, q_fa, 60), True, one_call=False)
+    assert n_members >= 2 and len(img) < 0.45 * len(_expected_maf(b, mapq, t_fa, q_fa, 60))
+    rc, _, err = run(cli, "p2m", paf, "-g", t_fa, "-q", q_fa, "-o", gz)        # an existing .gz is refused without -r like any output
+    assert rc != 0 and "already exists" in (err if isinstance(err, str) else err.decode())
 
 
 def _bgzf_write(path, data, block=0xFF00):
@@ -1380,3 +1386,41 @@ def pafpseudo_walk_case(cli, tmp_path, n_rec, n_targets, n_queries, check_target
 def test_pafpseudo_walk_over_many_records(cli, tmp_path):
     n, checked = pafpseudo_walk_case(cli, tmp_path, 1200, 2, 4, 2)
     assert n > 1000 and checked == n
+
+
+def test_gz_outputs_of_host_text_go_through_the_device_deflate(cli, tmp_path):
+    """`-o x.gz` (utils.rs:201-209) for text the host makes: a few lines leave as a zlib member, megabytes are handed to the
+    device's deflate (members of 32 768 input bytes are its mark; a host member holds up to 65 280) — either way the file is
+    BGZF and inflates to what the plain output holds."""
+    import gzip
+    rng = np.random.default_rng(5)
+    n = 9500
+    maf = str(tmp_path / "many.maf")
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    with open(maf, "wb") as f:
+        f.write(b"##maf version=1\n")
+        for k in range(n):
+            row = alpha[rng.integers(0, 4, 24)].tobytes()
+            f.write(b"a score=1\ns\tthe.target.contig.%05d\t%d\t24\t+\t900000\t%s\ns\tthe.query.contig.%05d\t%d\t24\t+\t800000\t%s\n\n"
+                    % (k % 977, 7 * k, row, k % 881, 5 * k, row[:11] + b"T" + row[12:]))
+    plain, gz = str(tmp_path / "many.paf"), str(tmp_path / "many.paf.gz")
+    rc, _, err = run(cli, "maf2paf", maf, "-o", plain)
+    assert rc == 0, err
+    want = open(plain, "rb").read()
+    assert len(want) > (1 << 20) and want.count(b"\n") == n
+    rc, _, err = run(cli, "maf2paf", maf, "-o", gz)
+    assert rc == 0, err
+    img = open(gz, "rb").read()
+    assert gzip.decompress(img) == want
+    pc.bgzf_check_stream(img, want, True, one_call=False)
+    tab, _ = pc.bgzf_table(img)
+    assert (tab["out_len"] == 32768).sum() >= len(want) // 32768 - 1          # the device's members
+    # a small output: one host member and the closing one
+    small = str(tmp_path / "few.paf.gz")
+    few = str(tmp_path / "few.maf")
+    open(few, "wb").write(b"\n\n".join(open(maf, "rb").read().split(b"\n\n")[:3]) + b"\n\n")
+    rc, _, err = run(cli, "maf2paf", few, "-o", small)
+    assert rc == 0, err
+    img = open(small, "rb").read()
+    tab, _ = pc.bgzf_table(img)
+    assert len(tab) == 2 and tab["out_len"][1] == 0 and gzip.decompress(img).count(b"\n") == 3

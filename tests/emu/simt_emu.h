@@ -246,6 +246,17 @@ static inline T atomicAdd(T* p, T v) {
   return old;
 }
 template <typename T>
+static inline T atomicOr(T* p, T v) {
+  T old = *p;
+  *p = old | v;
+  return old;
+}
+static inline unsigned __brev(unsigned v) {
+  unsigned r = 0;
+  for (int k = 0; k < 32; k++) r |= ((v >> k) & 1u) << (31 - k);
+  return r;
+}
+template <typename T>
 static inline T atomicMin(T* p, T v) {
   T old = *p;
   if (v < old) *p = v;

@@ -1986,3 +1986,95 @@ def check_bgzf_inflate(eng):
         if k not in (0, 1, 2, 4, 6):
             a, n = int(tab["out_off"][k]), int(tab["out_len"][k])
             assert st[k] == 0 and got[a:a + n].tobytes() == want[a:a + n], k
+
+
+# ------------------------------------------------------------------------------------------------
+# K18 BGZF deflate on the device: zlib is the judge (the stream must inflate to the input), the member
+# structure is read by bgzf_table, and the device inflate (K17) must take it back as well
+# ------------------------------------------------------------------------------------------------
+def bgzf_check_stream(img, want, eof_marker, one_call=True):
+    """img is a valid BGZF stream of `want`: gzip inflates it to the input; every member carries the BC field with its own size,
+    its CRC-32 and ISIZE, holds at most 32 768 input bytes and inflates alone; the 28-byte marker closes it when asked for"""
+    import gzip, struct, zlib
+    assert gzip.decompress(img) == want if img else want == b""
+    p, got, sizes = 0, 0, []
+    while p < len(img):
+        assert img[p:p + 4] == b"\x1f\x8b\x08\x04" and img[p + 10:p + 16] == b"\x06\x00BC\x02\x00", p
+        bsize = struct.unpack_from("<H", img, p + 16)[0] + 1
+        crc, isize = struct.unpack_from("<II", img, p + bsize - 8)
+        raw = zlib.decompressobj(-15)
+        data = raw.decompress(img[p + 18:p + bsize - 8])
+        assert raw.eof and raw.unused_data == b"" and len(data) == isize and isize <= 32768
+        assert data == want[got:got + isize] and zlib.crc32(data) & 0xFFFFFFFF == crc
+        sizes.append(isize)
+        got += isize
+        p += bsize
+    assert p == len(img) and got == len(want)
+    if eof_marker:
+        assert sizes and sizes[-1] == 0 and img[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+        sizes = sizes[:-1]
+    assert all(s > 0 for s in sizes) and (not one_call or all(s == 32768 for s in sizes[:-1]))   # one call: full members but the last
+    return len(sizes)
+
+
+def bgzf_deflate_inputs():
+    rng = np.random.default_rng(18)
+    dna = bytes(rng.choice(list(b"ACGT-acgtN\n"), 200000, p=[.2, .2, .2, .2, .1, .02, .02, .02, .02, .01, .01]).astype(np.uint8))
+    maf = (b"##maf version=1\n" + b"".join(b"a score=0\ns chr%d %d 700 + 100000 " % (k, 13 * k) + dna[700 * k:700 * k + 700] +
+                                          b"\ns qry%d 5 700 - 9000 " % k + dna[700 * k + 350:700 * k + 1050] + b"\n\n" for k in range(120)))
+    skew = bytes(rng.choice(256, 70000, p=np.r_[0.97, np.full(255, 0.03 / 255)]).astype(np.uint8))   # one symbol nearly alone: 1-bit code
+    fib = [1, 1]
+    while sum(fib) + fib[-1] + fib[-2] <= 32768:
+        fib.append(fib[-1] + fib[-2])
+    deep = b"".join(bytes([65 + i]) * c for i, c in enumerate(fib))            # Fibonacci counts: a tree deeper than 15 before the halving
+    return [("maf", maf), ("dna", dna), ("empty", b""), ("one byte", b"x"), ("two symbols", b"ab" * 5000),
+            ("one symbol", b"N" * 40000), ("a member exactly", dna[:32768]), ("two members exactly", dna[:65536]),
+            ("one over", dna[:32769]), ("random bytes (stored)", bytes(rng.integers(0, 256, 50000, dtype=np.uint8))),
+            ("all 256 symbols, skewed", skew), ("deep tree", deep + dna[:1000]), ("127 bytes", dna[:127]), ("129 bytes", dna[:129])]
+
+
+def check_bgzf_deflate(eng, inflate_too=True):
+    """wga_bgzf_compress on every kind of input (see bgzf_deflate_inputs) at every alignment of input and output; pieces
+    compressed by separate calls concatenate into one stream; a buffer that is too small is refused with the size it needs"""
+    from wgatools_amd import _lib
+    for k, (name, data) in enumerate(bgzf_deflate_inputs()):
+        ia, oa = k % 4, (k * 3 + 1) % 4
+        d_in = eng.upload(np.frombuffer(b"\xAA" * ia + data + b"\xBB" * 8, dtype=np.uint8))
+        cap = int(eng.lib.wga_bgzf_bound(len(data)))
+        out = eng.empty(oa + cap + 8, np.uint8).fill(0x23)
+        marker = k % 3 != 1
+        _, used = eng.bgzf_compress(d_in, len(data), out=out, eof_marker=marker, in_offset=ia, out_offset=oa)
+        got = out.numpy()
+        assert used <= cap and (got[:oa] == 0x23).all() and (got[oa + used:] == 0x23).all(), name
+        img = got[oa:oa + used].tobytes()
+        n_members = bgzf_check_stream(img, data, marker)
+        assert n_members == (len(data) + 32767) // 32768, name
+        if name in ("maf", "dna", "one symbol", "all 256 symbols, skewed"):
+            assert used < len(data) * 0.45, (name, used, len(data))        # literals under their own code: four bases -> about 2.3 bits
+        if name == "random bytes (stored)":
+            assert used == len(data) + n_members * 31 + (28 if marker else 0)
+        if inflate_too and data:
+            tab, total = bgzf_table(img)
+            back = eng.empty(total + 16, np.uint8).fill(0x23)
+            status = eng.empty(len(tab), np.uint32).fill(0xFF)
+            eng.bgzf_inflate(eng.upload(np.frombuffer(img + b"\0" * 16, dtype=np.uint8)), len(img), len(tab), eng.upload(tab.view(np.uint8)), back, status)
+            assert (status.numpy() == 0).all() and back.numpy()[:total].tobytes() == data, name
+    # pieces: three calls into one buffer make one stream; the last one closes it
+    data = bgzf_deflate_inputs()[0][1]
+    cuts = [0, 40001, 40001 + 32768, len(data)]
+    d_in = eng.upload(np.frombuffer(data, dtype=np.uint8))
+    out = eng.empty(int(eng.lib.wga_bgzf_bound(len(data))) + 200, np.uint8).fill(0)
+    at = 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        _, used = eng.bgzf_compress(d_in, b - a, out=out, eof_marker=b == len(data), in_offset=a, out_offset=at)
+        at += used
+    import gzip
+    assert gzip.decompress(out.numpy()[:at].tobytes()) == data
+    # too small a buffer: refused, the size reported, nothing written
+    import ctypes as C
+    small = eng.empty(1000, np.uint8).fill(0x23)
+    need = C.c_uint64(0)
+    rc = eng.lib.wga_bgzf_compress(eng.ctx, d_in.ptr, len(data), small.ptr, 1000, C.byref(need), 1)
+    _, whole = eng.bgzf_compress(d_in, len(data))
+    assert rc != 0 and need.value == whole and (small.numpy() == 0x23).all()
+    assert b"wga_bgzf_bound" in eng.lib.wga_last_error()

@@ -45,3 +45,32 @@ def test_lpt_keeps_a_target_on_one_rank():
 def test_gpus_n_without_a_launcher_refuses_missing_devices():
     r = _bench("--gpus", "2")
     assert r.returncode == 2 and "device(s) visible" in r.stderr
+
+
+def test_traffic_comes_from_the_newest_rounds_counter_passes():
+    """roofline.traffic is read from the committed PMC summary of the newest round whose workload and row-kernel source both
+    match what bench.py is about to time; anything else must give null, never an older round's figure."""
+    import glob
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    assert files, "no committed counter passes"
+    newest = json.load(open(files[-1]))
+
+    class Args:
+        records = newest["workload"]["records"]
+        mean_ops = newest["workload"]["mean_ops"]
+
+    class Job:
+        n_ops = newest["workload"]["ops"]
+
+    got = bench.pmc_traffic(Args, Job)
+    if newest["kernel_source_sha"] == bench.kernel_source_sha():
+        assert got == newest["hbm_bytes_per_launch"]
+        assert 1.0 <= got / (4 * Job.n_ops) < 20.0
+    else:
+        assert got is None or got != newest["hbm_bytes_per_launch"]
+    Job.n_ops += 1
+    assert bench.pmc_traffic(Args, Job) is None

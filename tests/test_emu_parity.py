@@ -722,3 +722,7 @@ def test_reduce_scatter_i32(monkeypatch):
 
 def test_bgzf_inflate(emu):
     pc.check_bgzf_inflate(emu)
+
+
+def test_bgzf_deflate(emu):
+    pc.check_bgzf_deflate(emu)

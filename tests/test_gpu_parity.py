@@ -1242,6 +1242,70 @@ def test_bgzf_inflate(gpu):
     pc.check_bgzf_inflate(gpu)
 
 
+def test_bgzf_deflate(gpu):
+    pc.check_bgzf_deflate(gpu)
+
+
+def test_bgzf_deflate_at_size_round_trip(gpu):
+    """K18 on 2 GB of alignment-row-like text made in HBM (61 035 full members and a ragged one, unaligned input and output):
+    every member is taken back by the device inflate (K17) and the bytes are the input's; zlib inflates a sample of members
+    and checks their CRC-32 and ISIZE; the stream is about a third of the input."""
+    import struct
+    import time
+    import zlib
+    import torch
+    dev = torch.device("cuda", 0)
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    n = 2_000_000_123
+    g = torch.Generator(device=dev)
+    g.manual_seed(18)
+    alphabet = torch.tensor(list(b"ACGTACGTACGTACGTACGTACGT----acgtN\n"), dtype=torch.uint8, device=dev)
+    text = torch.empty(n + 5 + 16, dtype=torch.uint8, device=dev)
+    for a in range(0, n, 1 << 28):
+        m = min(1 << 28, n - a)
+        text[5 + a:5 + a + m] = alphabet[torch.randint(0, len(alphabet), (m,), device=dev, generator=g)]
+    cap = int(gpu.lib.wga_bgzf_bound(n))
+    out = torch.full((cap + 64,), 0x23, dtype=torch.uint8, device=dev)
+    _, used = gpu.bgzf_compress(text, n, out=engine.DeviceArray(gpu, out.data_ptr(), (cap + 64,), np.uint8, owner=False), eof_marker=True,
+                                in_offset=5, out_offset=3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, used2 = gpu.bgzf_compress(text, n, out=engine.DeviceArray(gpu, out.data_ptr(), (cap + 64,), np.uint8, owner=False), eof_marker=True,
+                                 in_offset=5, out_offset=3)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert used2 == used and 0.25 * n < used < 0.40 * n
+    assert bool((out[:3] == 0x23).all()) and bool((out[3 + used:] == 0x23).all())
+    img = out[3:3 + used].cpu().numpy()
+    n_members = (n + 32767) // 32768
+    rows = np.zeros(n_members, dtype=[("in_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"), ("out_off", "<u8")])
+    p = 0
+    for k in range(n_members):
+        assert img[p] == 0x1f and img[p + 1] == 0x8b and img[p + 12] == 0x42 and img[p + 13] == 0x43
+        bsize = int(img[p + 16]) + 256 * int(img[p + 17]) + 1
+        isize = struct.unpack_from("<I", img, p + bsize - 4)[0]
+        assert isize == (32768 if k + 1 < n_members else n - 32768 * (n_members - 1))
+        rows[k] = (p + 18, bsize - 26, isize, 32768 * k)
+        p += bsize
+    assert p + 28 == used and img[p:].tobytes() == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    for k in list(range(0, n_members, 4099)) + [n_members - 1]:             # zlib on a sample of members
+        a, ln = int(rows["in_off"][k]), int(rows["in_len"][k])
+        data = zlib.decompress(img[a:a + ln].tobytes(), -15)
+        crc, isize = struct.unpack_from("<II", img, a + ln)
+        want = text[5 + 32768 * k:5 + 32768 * k + isize].cpu().numpy().tobytes()
+        assert data == want and zlib.crc32(data) & 0xFFFFFFFF == crc
+    back = torch.full((n + 64,), 0x23, dtype=torch.uint8, device=dev)
+    status = torch.full((n_members,), 0xFF, dtype=torch.int32, device=dev)
+    d_rows = torch.from_numpy(rows.view(np.uint8).copy()).to(dev)
+    gpu.bgzf_inflate(out[3:], used, n_members, d_rows, back, status)
+    torch.cuda.synchronize()
+    assert int(status.abs().sum()) == 0
+    assert torch.equal(back[:n], text[5:5 + n]) and bool((back[n:] == 0x23).all())
+    print("\nK18 at size: %.2e bytes -> %.2e (%.3f) in %.1f ms = %.0f GB/s of input (plan + scan + emit + the size's trip to the host)"
+          % (n, used, used / n, dt * 1e3, n / dt / 1e9))
+    gpu.reset_stream()
+
+
 @pytest.mark.gpu
 def test_reduce_scatter_i32_on_hardware():
     """wga_reduce_scatter_i32 (pafcov --spread: the coverage merge of pafcov.rs:29-53 across devices) executed by the GPU: three

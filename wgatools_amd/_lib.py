@@ -76,6 +76,8 @@ PROTOTYPES = {
     "wga_fasta_pool": (C.c_int, [vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp, vp]),
     "wga_paf_call_events": (C.c_int, [vp, C.POINTER(CigarBatch), C.c_uint64, C.c_int, vp, vp, vp]),
     "wga_bgzf_inflate": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),
+    "wga_bgzf_bound": (C.c_uint64, [C.c_uint64]),
+    "wga_bgzf_compress": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]),
     "wga_paf_call_vcf": (C.c_int, [vp, C.POINTER(CigarBatch), C.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "wga_pafcov_accumulate": (C.c_int, [vp, C.POINTER(CigarBatch), vp, vp, vp, vp, vp, C.c_uint64]),
     "wga_pafcov_accumulate_final": (C.c_int, [vp, C.POINTER(CigarBatch), vp, vp, vp, vp, C.c_uint32, vp, C.c_uint64]),

@@ -1225,6 +1225,58 @@ int wga_fasta_pool(wga_ctx* c, const uint8_t* d_text, uint64_t n_bytes, uint64_t
   return WGA_OK;
 }
 
+/* K18: bytes in HBM -> BGZF members (wga_k18_bgzf_deflate.h) */
+static const uint8_t k_bgzf_eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43,
+                                       0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+uint64_t wga_bgzf_bound(uint64_t n_bytes) {
+  const uint64_t members = (n_bytes + WGA_BGZF_IN - 1u) / WGA_BGZF_IN;
+  return n_bytes + members * (uint64_t)(WGA_BGZF_HDR + 5u + WGA_BGZF_TRAILER) + sizeof k_bgzf_eof;
+}
+int wga_bgzf_compress(wga_ctx* c, const uint8_t* d_in, uint64_t n_bytes, uint8_t* d_out, uint64_t out_cap,
+                      uint64_t* out_bytes, int eof_marker) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (!out_bytes) return fail(WGA_E_INVALID_ARG, "out_bytes null", nullptr);
+  if (n_bytes && !d_in) return fail(WGA_E_INVALID_ARG, "d_in null", nullptr);
+  const u64 nb64 = (n_bytes + WGA_BGZF_IN - 1u) / WGA_BGZF_IN;
+  if (nb64 > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "more than 2^31 members in one call", nullptr);
+  const u32 nb = (u32)nb64;
+  const u64 tail = eof_marker ? sizeof k_bgzf_eof : 0u;
+  u64 total = 0;
+  if (nb) {
+    /* scratch: member sizes | their exclusive scan (+ total) | scan partials | crc + kind per member | code lengths */
+    void* ws;
+    const size_t words = (size_t)nb * 2 + 2 + (size_t)nb / 1024 + 4;
+    const size_t head = words * sizeof(u64);
+    const size_t need = head + (size_t)nb * sizeof(wga_bgzf_member) + (size_t)nb * WGA_BGZF_LENS;
+    if ((rc = ctx_scratch(c, need, &ws))) return rc;
+    u64* sizes = (u64*)ws;
+    u64* offs = sizes + nb;
+    u64* partial = offs + nb + 1;
+    wga_bgzf_member* members = (wga_bgzf_member*)((char*)ws + head);
+    u8* lens = (u8*)(members + nb);
+    WGA_LAUNCH(k_bgzf_plan, nb, WGA_BLOCK, c->stream, d_in, (u64)n_bytes, sizes, members, lens);
+    LAUNCH_CHECK();
+    ScanPlain sp;
+    sp.in = sizes;
+    if ((rc = run_scan_ws(c, sp, nb, offs, partial))) return rc;
+    RT_CHECK(rt_d2h(&total, offs + nb, sizeof total, c->stream));
+    *out_bytes = total + tail;
+    if (total + tail > out_cap) return fail(WGA_E_INVALID_ARG, "output buffer smaller than the compressed stream (wga_bgzf_bound)", nullptr);
+    if (!d_out) return fail(WGA_E_INVALID_ARG, "d_out null", nullptr);
+    WGA_LAUNCH(k_bgzf_emit, nb, WGA_BLOCK, c->stream, d_in, (u64)n_bytes, (const u64*)offs, (const wga_bgzf_member*)members,
+               (const u8*)lens, d_out);
+    LAUNCH_CHECK();
+  }
+  *out_bytes = total + tail;
+  if (tail) {
+    if (total + tail > out_cap) return fail(WGA_E_INVALID_ARG, "output buffer smaller than the compressed stream (wga_bgzf_bound)", nullptr);
+    if (!d_out) return fail(WGA_E_INVALID_ARG, "d_out null", nullptr);
+    RT_CHECK(rt_h2d(d_out + total, k_bgzf_eof, sizeof k_bgzf_eof, c->stream));
+  }
+  return WGA_OK;
+}
+
 int wga_pafcov_format(wga_ctx* c, const uint8_t* d_name, uint32_t name_len, const int32_t* d_cov,
                       uint64_t p0, uint32_t count, uint64_t* d_line_off, uint8_t* d_out) {
   int rc = ctx_bind(c);

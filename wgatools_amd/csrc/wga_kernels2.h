@@ -20,5 +20,6 @@
 #include "wga_k12_dotplot.h"
 #include "wga_k13_splitters.h"
 #include "wga_k15_fasta.h"
+#include "wga_k18_bgzf_deflate.h"
 
 #endif /* WGA_KERNELS2_H */

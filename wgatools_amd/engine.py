@@ -245,6 +245,19 @@ class Engine:
         """BGZF members inflated on the device (wga_bgzf_inflate); blocks: n x (in_off u64, in_len u32, out_len u32, out_off u64)"""
         self._check(self.lib.wga_bgzf_inflate(self.ctx, _p(d_in), int(in_bytes), int(n_blocks), _p(blocks), _p(out), _p(status)))
 
+    def bgzf_compress(self, d_in, n_bytes, out=None, eof_marker=True, in_offset=0, out_offset=0):
+        """bytes in HBM -> BGZF members (wga_bgzf_compress, K18); returns (DeviceArray of the worst-case size, bytes used).
+        in_offset / out_offset: byte offsets into d_in / out (any alignment)."""
+        cap = int(self.lib.wga_bgzf_bound(int(n_bytes)))
+        if out is None:
+            out = self.empty(cap + int(out_offset), np.uint8)
+        used = C.c_uint64(0)
+        src = _p(d_in)
+        self._check(self.lib.wga_bgzf_compress(self.ctx, (src + int(in_offset)) if src else None, int(n_bytes),
+                                               _p(out) + int(out_offset), out.nbytes - int(out_offset) if isinstance(out, DeviceArray) else cap,
+                                               C.byref(used), 1 if eof_marker else 0))
+        return out, int(used.value)
+
     def scatter_bytes(self, n, src, src_off, dst, dst_off):
         self._check(self.lib.wga_scatter_bytes(self.ctx, n, _p(src), _p(src_off), _p(dst),
                                                _p(dst_off)))

@@ -454,6 +454,8 @@ static bool ends_with(const std::string& s, const char* suf) {
   return s.size() >= n && memcmp(s.data() + s.size() - n, suf, n) == 0;
 }
 
+bool (*Output::big_text)(Output&, const char*, size_t) = nullptr;
+
 void Output::open(const std::string& p, bool rewrite) {
   path = p;
   if (p == "-") {
@@ -465,29 +467,84 @@ void Output::open(const std::string& p, bool rewrite) {
     fail("File `" + p + "` already exists, please add `-r` to rewrite it."); /* errors.rs:25 */
   if (ends_with(p, ".bz2") || ends_with(p, ".xz"))
     fail("IO error:bz2 / xz output is not built into this engine (plain or .gz only)");
-  if (ends_with(p, ".gz")) {
-    gz = gzopen(p.c_str(), "wb6");
-    if (!gz) fail("IO error:cannot create `" + p + "`");
-  } else {
-    fp = fopen(p.c_str(), "wb");
-    if (!fp) fail("IO error:cannot create `" + p + "`");
+  bgzf = ends_with(p, ".gz");
+  fp = fopen(p.c_str(), "wb");
+  if (!fp) fail("IO error:cannot create `" + p + "`");
+}
+
+/* one BGZF member of n <= 0xff00 bytes by zlib (level 6: the reference's, utils.rs:192; stored blocks where deflate would not
+ * fit the 64 KiB a member may have) */
+static void bgzf_member_host(FILE* fp, const char* p, size_t n) {
+  static const size_t kCap = 65536;
+  unsigned char buf[kCap];
+  size_t pay = 0;
+  for (int level : {6, 0}) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) fail("IO error:zlib deflateInit2 failed");
+    zs.next_in = (Bytef*)p;
+    zs.avail_in = (uInt)n;
+    zs.next_out = buf + 18;
+    zs.avail_out = (uInt)(kCap - 18 - 8);
+    const int r = deflate(&zs, Z_FINISH);
+    pay = zs.total_out;
+    deflateEnd(&zs);
+    if (r == Z_STREAM_END) break;
+    if (level == 0) fail("IO error:zlib deflate failed");
   }
+  static const unsigned char head[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0};
+  memcpy(buf, head, 16);
+  const uint32_t bsize = (uint32_t)(18 + pay + 8 - 1), crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)p, (uInt)n), isize = (uint32_t)n;
+  buf[16] = (unsigned char)(bsize & 0xff);
+  buf[17] = (unsigned char)(bsize >> 8);
+  unsigned char* t = buf + 18 + pay;
+  for (int k = 0; k < 4; k++) t[k] = (unsigned char)(crc >> (8 * k));
+  for (int k = 0; k < 4; k++) t[4 + k] = (unsigned char)(isize >> (8 * k));
+  if (fwrite(buf, 1, 18 + pay + 8, fp) != 18 + pay + 8) fail("IO error:write failed");
+}
+void Output::host_members(const char* p, size_t n) {
+  static const size_t kIn = 0xff00;
+  if (!pend.empty()) { /* top the waiting text up to a member first */
+    const size_t take = std::min(n, kIn - pend.size());
+    pend.append(p, take);
+    p += take;
+    n -= take;
+    if (pend.size() < kIn) return;
+    bgzf_member_host(fp, pend.data(), pend.size());
+    pend.clear();
+  }
+  while (n >= kIn) {
+    bgzf_member_host(fp, p, kIn);
+    p += kIn;
+    n -= kIn;
+  }
+  pend.append(p, n);
+}
+void Output::flush_pend() {
+  if (pend.empty()) return;
+  bgzf_member_host(fp, pend.data(), pend.size());
+  pend.clear();
 }
 void Output::write(const char* p, size_t n) {
   if (!n) return;
-  if (gz) {
-    while (n) {
-      unsigned k = n > (1u << 30) ? (1u << 30) : (unsigned)n;
-      if (gzwrite((gzFile)gz, p, k) <= 0) fail("IO error:write failed");
-      p += k;
-      n -= k;
-    }
+  if (bgzf) {
+    if (n >= kBigText && big_text && big_text(*this, p, n)) return;
+    host_members(p, n);
   } else if (fwrite(p, 1, n, fp) != n) {
     fail("IO error:write failed");
   }
 }
 int Output::plain_fd(uint64_t* pos) {
-  if (gz || !fp || fp == stdout) return -1;
+  if (bgzf || !fp || fp == stdout) return -1;
+  fflush(fp);
+  const long at = ftell(fp);
+  if (at < 0) return -1;
+  *pos = (uint64_t)at;
+  return fileno(fp);
+}
+int Output::raw_fd(uint64_t* pos) {
+  if (!bgzf || !fp) return -1;
+  flush_pend();
   fflush(fp);
   const long at = ftell(fp);
   if (at < 0) return -1;
@@ -498,10 +555,17 @@ void Output::advance(uint64_t n) {
   if (fp && fp != stdout && fseek(fp, (long)n, SEEK_CUR) != 0) fail("IO error:seek failed");
 }
 void Output::close() {
-  if (gz) gzclose((gzFile)gz);
-  if (fp && fp != stdout) fclose(fp);
+  if (bgzf && fp) {
+    flush_pend();
+    static const unsigned char eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43,
+                                          0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (fwrite(eof, 1, sizeof eof, fp) != sizeof eof) fail("IO error:write failed");
+  }
+  if (fp && fp != stdout && fclose(fp) != 0) {
+    fp = nullptr;
+    fail("IO error:write failed");
+  }
   if (fp == stdout) fflush(stdout);
-  gz = nullptr;
   fp = nullptr;
 }
 

@@ -56,7 +56,13 @@ bool scan_bgzf_members(const std::string& path, std::vector<BgzfMember>& members
 uint32_t gzip_crc32(const void* p, size_t n); /* the CRC-32 of a gzip member's trailer (zlib's) */
 struct Output {
   std::string path;
-  void* gz = nullptr;
+  /* `.gz` (utils.rs:201-209: the reference wraps the file in a gzip encoder): the file is a sequence of BGZF members — complete
+   * gzip members of at most 64 KiB with the `BC` field — closed by BGZF's empty member.  Text that is already in HBM comes
+   * compressed from the device (K18, wga_bgzf_compress) and is appended as it is (raw_fd); host text is collected in `pend`
+   * and leaves as zlib level-6 members; host text of megabytes goes through the device as well once a command has one
+   * (big_text, set by Dev::init).  Any gzip reader inflates the file to the bytes the plain output would hold. */
+  bool bgzf = false;
+  std::string pend;
   FILE* fp = nullptr;
   void open(const std::string& path, bool rewrite);
   void write(const char* p, size_t n);
@@ -65,7 +71,16 @@ struct Output {
   /* a plain file (not stdout, not .gz): positional writes from several threads are possible.  Returns the file
    * descriptor after flushing what stdio holds and the offset where the next byte belongs, or -1. */
   int plain_fd(uint64_t* pos);
-  void advance(uint64_t n); /* the caller wrote n bytes at the position plain_fd reported */
+  /* the same for finished BGZF members going into a `.gz` file (host text waiting in `pend` leaves first); -1 for anything else */
+  int raw_fd(uint64_t* pos);
+  void advance(uint64_t n); /* the caller wrote n bytes at the position plain_fd / raw_fd reported */
+  /* (out, text, bytes) -> true when the text went out through the device's deflate */
+  static bool (*big_text)(Output&, const char*, size_t);
+  static const size_t kBigText = (size_t)1 << 20; /* zlib takes 10-20 ms for this much; the trip through the device about one */
+
+ private:
+  void host_members(const char* p, size_t n); /* whole members of 0xff00 bytes, the rest into pend */
+  void flush_pend();
 };
 
 /* ---- PAF ------------------------------------------------------------------------------------ */

@@ -77,6 +77,19 @@ struct PhaseTimer {
 };
 static PhaseTimer g_timer;
 
+/* A command whose outputs are closed leaves the process at once. Returning through the destructors unmapped a multi-gigabyte
+ * input, handed gigabytes of pinned memory back and took the HIP runtime down page by page: 0.3-0.5 s of a 1.4-2 s run
+ * (profiles/r05_e2e_at_size.json: `stat -f maf` 0.88 s of marked phases in a 1.36 s process) for memory the kernel reclaims
+ * anyway. Every output of every command goes through Output::close() (fclose / gzclose) before this is reached; the streams
+ * the process was given are flushed here. The error paths still unwind normally. */
+static int leave(int rc) {
+  g_timer.mark("teardown before leaving");
+  g_timer.print();
+  fflush(stdout);
+  fflush(stderr);
+  _exit(rc);
+}
+
 /* The HIP runtime takes ~0.1 s to come up: main() starts it on a second thread while the command opens and reads its
  * input; the first Dev::init() picks the context up (one context per process: the commands use one Dev). */
 struct GpuWarm {
@@ -122,7 +135,8 @@ struct DevStreamer {
     for (int k = 0; k < kBufs; k++)
       if (buf[k]) wga_host_free(ctx, buf[k]);
   }
-  void run(Output& out, const uint8_t* d_src, size_t n) {
+  /* raw: d_src holds finished BGZF members for a `.gz` file (Output::raw_fd) */
+  void run(Output& out, const uint8_t* d_src, size_t n, bool raw = false) {
     if (n == 0) return;
     const size_t np = (n + kPiece - 1) / kPiece;
     /* writers: memcpy into the page cache is what bounds a large output (one thread moves 2-3 GB/s), the copy engine delivers
@@ -130,7 +144,7 @@ struct DevStreamer {
     int nthreads = 1;
     {
       uint64_t pos_probe = 0;
-      if (out.plain_fd(&pos_probe) >= 0) {
+      if ((raw ? out.raw_fd(&pos_probe) : out.plain_fd(&pos_probe)) >= 0) {
         nthreads = 8; /* 16 / 24 / 32 measured slower at 15 GB (scripts/gpu_write_threads.py: 2.6 / 2.9 / 3.0 s against 2.5) */
         if (const char* e = getenv("WGA_WRITE_THREADS")) nthreads = std::max(1, std::min(32, atoi(e)));
       }
@@ -139,7 +153,8 @@ struct DevStreamer {
     for (int k = 0; k < nbuf; k++)
       if (!buf[k] && wga_host_alloc(ctx, kPiece, &buf[k])) fail(std::string("GPU engine: ") + wga_last_error());
     uint64_t pos0 = 0;
-    const int fd = out.plain_fd(&pos0);
+    const int fd = raw ? out.raw_fd(&pos0) : out.plain_fd(&pos0);
+    if (raw && fd < 0) fail("internal error: BGZF members for something that is not a .gz file");
     /* a plain file: its blocks are allocated once, up front (the system call, not posix_fallocate: no emulation by writing where
      * a file system lacks it).  Eight threads writing the same 16 MB into a NEW file: 12.6 GB/s, 16.3 after fallocate
      * (profiles/r04_cli_e2e.txt); with real pieces out of the pinned buffers paf2maf's 15 GB leave at 10-12 GB/s either way,
@@ -257,6 +272,10 @@ struct DevStreamer {
 static int g_gpus = 1;
 static bool g_spread = false; /* `--spread` (with --gpus N, pafcov): deal the records out round robin and sum the coverage over the devices */
 
+struct Dev;
+static Dev* g_gz_dev = nullptr; /* the device host text for a `.gz` file is deflated on (Output::big_text) */
+static bool big_text_through_device(Output& out, const char* p, size_t n);
+
 struct Dev {
   wga_ctx* ctx = nullptr;
   bool own_ctx = true; /* false: the context is another Dev's (the reader's, lent to device 0's worker) */
@@ -268,6 +287,10 @@ struct Dev {
   void init() {
     if (ctx) return;
     g_timer.mark("host");
+    if (device == 0 && !g_gz_dev) {
+      g_gz_dev = this;
+      Output::big_text = big_text_through_device;
+    }
     if (device != 0) { /* the workers' devices: a context each */
       int rc = wga_ctx_create(device, &ctx);
       if (rc) fail(std::string("GPU engine: ") + wga_last_error());
@@ -322,6 +345,20 @@ struct Dev {
     check(wga_malloc(ctx, cap, &out_arena));
     out_arena_cap = cap;
   }
+  /* the BGZF members of a piece of `.gz` output (K18) wait here for the copy out */
+  void* gz_arena = nullptr;
+  size_t gz_arena_cap = 0;
+  void gz_arena_for(size_t bytes) {
+    if (bytes <= gz_arena_cap) return;
+    if (gz_arena) {
+      check(wga_sync(ctx));
+      wga_free(ctx, gz_arena);
+      gz_arena = nullptr;
+      gz_arena_cap = 0;
+    }
+    check(wga_malloc(ctx, bytes, &gz_arena));
+    gz_arena_cap = bytes;
+  }
   void release(void* p) {
     auto it = std::find(owned.begin(), owned.end(), p);
     if (it != owned.end()) owned.erase(it);
@@ -340,9 +377,11 @@ struct Dev {
     }
   }
   ~Dev() {
+    if (g_gz_dev == this) g_gz_dev = nullptr;
     if (ctx) {
       streamer.reset();
       if (out_arena) wga_free(ctx, out_arena);
+      if (gz_arena) wga_free(ctx, gz_arena);
       for (void* p : owned) wga_free(ctx, p);
       if (own_ctx) wga_ctx_destroy(ctx);
     }
@@ -352,8 +391,40 @@ static void stream_out(Dev& d, Output& out, const uint8_t* d_src, size_t n) {
   if (!d.streamer) d.streamer.reset(new DevStreamer(d.ctx));
   d.check(wga_sync(d.ctx));
   g_timer.mark("kernels + host tables");
+  if (out.bgzf) {
+    /* `.gz`: the text is deflated where it is (K18) and the members are what crosses PCIe and reaches the file; slabs keep
+     * the buffer of members bounded whatever the piece */
+    const size_t kSlab = (size_t)1 << 30;
+    for (size_t a = 0; a < n; a += kSlab) {
+      const size_t len = std::min(kSlab, n - a);
+      const uint64_t cap = wga_bgzf_bound(len);
+      d.gz_arena_for((size_t)cap);
+      uint64_t used = 0;
+      d.check(wga_bgzf_compress(d.ctx, d_src + a, len, (uint8_t*)d.gz_arena, cap, &used, 0));
+      g_timer.mark("device deflate");
+      d.streamer->run(out, (const uint8_t*)d.gz_arena, (size_t)used, true);
+      g_timer.mark("copy out + write");
+    }
+    return;
+  }
   d.streamer->run(out, d_src, n);
   g_timer.mark("copy out + write");
+}
+/* host text of megabytes for a `.gz` file (Output::big_text): up, through the same deflate, out */
+static bool big_text_through_device(Output& out, const char* p, size_t n) {
+  Dev* d = g_gz_dev;
+  if (!d || !d->ctx) return false;
+  const size_t kSlab = (size_t)1 << 30;
+  for (size_t a = 0; a < n; a += kSlab) {
+    const size_t len = std::min(kSlab, n - a);
+    void* d_txt = nullptr;
+    d->check(wga_malloc(d->ctx, len + 16, &d_txt));
+    d->check(wga_memcpy_h2d(d->ctx, d_txt, p + a, len));
+    stream_out(*d, out, (const uint8_t*)d_txt, len);
+    d->check(wga_sync(d->ctx));
+    wga_free(d->ctx, d_txt);
+  }
+  return true;
 }
 
 /* A bgzipped PAF / MAF through the device inflate (K17, wga_bgzf_inflate): the compressed file stays on the host, a run of
