@@ -51,7 +51,8 @@ struct wga_bgzf_member {
 /* CRC-32 (reflected 0xEDB88320) tables made at compile time: the byte table, and x^(2^k) mod P for the zero-feeding
  * products that fold partial CRCs (the same arithmetic as zlib's crc32_combine) */
 struct wga_crc_tables {
-  u32 byte[256];
+  u32 byte[256];    /* the byte table */
+  u32 by4[3][256];  /* its three companions for four bytes at a time (slicing-by-4: by4[k][i] = byte i followed by k + 1 zero bytes) */
   u32 x2n[32];
   static constexpr u32 mul(u32 a, u32 b) {
     u32 m = 1u << 31, p = 0;
@@ -65,11 +66,15 @@ struct wga_crc_tables {
     }
     return p;
   }
-  constexpr wga_crc_tables() : byte{}, x2n{} {
+  constexpr wga_crc_tables() : byte{}, by4{}, x2n{} {
     for (u32 i = 0; i < 256u; i++) {
       u32 c = i;
       for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
       byte[i] = c;
+    }
+    for (u32 i = 0; i < 256u; i++) {
+      u32 c = byte[i];
+      for (int k = 0; k < 3; k++) by4[k][i] = c = byte[c & 0xFFu] ^ (c >> 8);
     }
     u32 p = 1u << 30; /* x^1 */
     x2n[0] = p;
@@ -167,14 +172,13 @@ __global__ __launch_bounds__(256) void k_bgzf_plan(const u8* __restrict__ in, u6
                                                    wga_bgzf_member* __restrict__ members, u8* __restrict__ lens) {
   __shared__ u32 s_in[WGA_BGZF_IN / 4u];
   __shared__ u32 s_rep[WGA_BGZF_REP * WGA_BGZF_REP_STRIDE];
-  __shared__ u32 s_crc_t[256];
+  __shared__ u32 s_crc_t[4][256];
   __shared__ u32 s_cnt[260];   /* the member's histogram; [256] = the end-of-block symbol */
   __shared__ u32 s_wt[260];    /* the weights the code is built on (the counts, halved while a length passes 15) */
   __shared__ u32 s_leaf[260];  /* weights of the used symbols in rank order */
-  __shared__ u16 s_sorted[260];
   __shared__ u32 s_node[260];  /* weights of the internal nodes in the order they are made */
+  __shared__ u32 s_key[260];   /* (weight << 9) | symbol of the used symbols, in symbol order */
   __shared__ u16 s_par[520];   /* parent (index among the internal nodes) of leaf i, of internal node n + j */
-  __shared__ u16 s_dep[260];
   __shared__ u8 s_len[260];
   __shared__ u32 s_fold[4];
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = WGA_WAVE_ID(tid);
@@ -184,7 +188,8 @@ __global__ __launch_bounds__(256) void k_bgzf_plan(const u8* __restrict__ in, u6
   const u32 n = left < (u64)WGA_BGZF_IN ? (u32)left : WGA_BGZF_IN;
 
   for (u32 i = tid; i < WGA_BGZF_REP * WGA_BGZF_REP_STRIDE; i += 256u) s_rep[i] = 0u;
-  s_crc_t[tid] = k_crc_tables.byte[tid];
+  s_crc_t[0][tid] = k_crc_tables.byte[tid];
+  for (int k = 0; k < 3; k++) s_crc_t[k + 1][tid] = k_crc_tables.by4[k][tid];
   __syncthreads();
   /* stage and count: word i of the member by thread i mod 256 */
   {
@@ -215,10 +220,19 @@ __global__ __launch_bounds__(256) void k_bgzf_plan(const u8* __restrict__ in, u6
   u32 crc = 0;
   {
     const i32 start = (i32)n - 128 * (i32)(256u - tid);
-    const u8* bytes = (const u8*)s_in;
-    for (i32 j = 0; j < 128; j++) {
-      const i32 p = start + j;
-      if (p >= 0) crc = s_crc_t[(crc ^ (u32)bytes[p]) & 0xFFu] ^ (crc >> 8);
+    if ((n & 3u) == 0u) { /* four bytes a step (every member but a ragged last one) */
+      for (i32 j = 0; j < 32; j++) {
+        const i32 wi = (start >> 2) + j;
+        if (wi < 0) continue;
+        const u32 x = crc ^ s_in[wi];
+        crc = s_crc_t[3][x & 0xFFu] ^ s_crc_t[2][(x >> 8) & 0xFFu] ^ s_crc_t[1][(x >> 16) & 0xFFu] ^ s_crc_t[0][x >> 24];
+      }
+    } else {
+      const u8* bytes = (const u8*)s_in;
+      for (i32 j = 0; j < 128; j++) {
+        const i32 p = start + j;
+        if (p >= 0) crc = s_crc_t[0][(crc ^ (u32)bytes[p]) & 0xFFu] ^ (crc >> 8);
+      }
     }
   }
   /* fold: (a, b) -> a x^(8 |b|) + b, |b| = 128, 256, ... bytes */
@@ -240,58 +254,65 @@ __global__ __launch_bounds__(256) void k_bgzf_plan(const u8* __restrict__ in, u6
     for (;;) {
       /* rank of every used symbol by (weight, symbol) */
       u32 key[5], rank[5];
+      u32 n_used = 0;
 #pragma unroll
       for (int k = 0; k < 5; k++) {
         const u32 s = (u32)k * 64u + lane;
         const u32 wv = s <= 256u ? s_wt[s] : 0u;
         key[k] = wv ? (wv << 9) | s : 0u;
         rank[k] = 0;
+        const u64 m = __ballot(key[k] != 0u);
+        if (key[k]) s_key[n_used + lane_rank(m, lane)] = key[k];
+        n_used += (u32)__popcll(m);
       }
-      u32 n_used = 0;
-      for (u32 o = 0; o <= 256u; o++) {
-        const u32 wv = s_wt[o];
-        if (!wv) continue;
-        const u32 ko = (wv << 9) | o;
-        n_used++;
+      WGA_WAVE_SYNC();
+      for (u32 o = 0; o < n_used; o++) {
+        const u32 ko = s_key[o];
 #pragma unroll
         for (int k = 0; k < 5; k++) rank[k] += ko < key[k] ? 1u : 0u;
       }
 #pragma unroll
       for (int k = 0; k < 5; k++)
-        if (key[k]) {
-          s_sorted[rank[k]] = (u16)(key[k] & 0x1FFu);
-          s_leaf[rank[k]] = key[k] >> 9;
-        }
+        if (key[k]) s_leaf[rank[k]] = key[k] >> 9;
       WGA_WAVE_SYNC();
       /* two queues: the leaves in rank order, the internal nodes in the order they were made (their weights never go
        * down); a leaf wins a tie, which keeps the tree as shallow as the weights allow */
       if (lane == 0u) {
         u32 a = 0, q = 0;
+        u32 la = s_leaf[0], nq = 0xFFFFFFFFu; /* the two fronts; all ones: that queue has nothing to give right now */
         for (u32 j = 0; j + 1u < n_used; j++) {
           u32 wsum = 0;
           for (int pick = 0; pick < 2; pick++) {
-            const bool leaf = a < n_used && (q >= j || s_leaf[a] <= s_node[q]);
-            if (leaf) {
-              wsum += s_leaf[a];
+            if (la <= nq) {
+              wsum += la;
               s_par[a++] = (u16)j;
+              la = a < n_used ? s_leaf[a] : 0xFFFFFFFFu;
             } else {
-              wsum += s_node[q];
+              wsum += nq;
               s_par[n_used + q++] = (u16)j;
+              nq = q < j ? s_node[q] : 0xFFFFFFFFu;
             }
           }
           s_node[j] = wsum;
+          if (q == j) nq = wsum; /* the node just made is the internal queue's front */
         }
-        s_dep[n_used - 2u] = 0;
-        for (i32 j = (i32)n_used - 3; j >= 0; j--) s_dep[j] = (u16)(s_dep[s_par[n_used + (u32)j]] + 1u);
       }
       WGA_WAVE_SYNC();
+      /* a leaf's length = the nodes on its way up to the root (internal node n_used - 2) */
       u32 deepest = 0;
 #pragma unroll
       for (int k = 0; k < 5; k++) {
         const u32 s = (u32)k * 64u + lane;
         if (s > 256u) continue;
         u32 l = 0;
-        if (key[k]) l = (u32)s_dep[s_par[rank[k]]] + 1u;
+        if (key[k]) {
+          u32 p = s_par[rank[k]];
+          l = 1;
+          while (p != n_used - 2u) {
+            p = s_par[n_used + p];
+            l++;
+          }
+        }
         s_len[s] = (u8)(l > 255u ? 255u : l);
         deepest = l > deepest ? l : deepest;
       }
@@ -390,8 +411,14 @@ __global__ __launch_bounds__(256) void k_bgzf_emit(const u8* __restrict__ in, u6
     /* literals: thread t packs bytes 128 t .. 128 t + 127 */
     const u32 c0 = 128u * tid;
     const u32 cnt = c0 < n ? (n - c0 < 128u ? n - c0 : 128u) : 0u;
+    const u32 full = cnt >> 2; /* whole words of the chunk; a ragged member's last bytes go one by one */
+    const u32* words = s_in + 32u * tid;
     u32 my_bits = 0;
-    for (u32 j = 0; j < cnt; j++) my_bits += s_code[bytes[c0 + j]] & 15u;
+    for (u32 j = 0; j < full; j++) {
+      const u32 x = words[j];
+      my_bits += (s_code[x & 0xFFu] & 15u) + (s_code[(x >> 8) & 0xFFu] & 15u) + (s_code[(x >> 16) & 0xFFu] & 15u) + (s_code[x >> 24] & 15u);
+    }
+    for (u32 j = 4u * full; j < cnt; j++) my_bits += s_code[bytes[c0 + j]] & 15u;
     u64 total;
     const u32 ex = (u32)block_excl_scan_u64((u64)my_bits, s_w, &total);
     {
@@ -399,13 +426,10 @@ __global__ __launch_bounds__(256) void k_bgzf_emit(const u8* __restrict__ in, u6
       u32 w = pos >> 5, nb = pos & 31u;
       u64 acc = 0;
       bool first = true;
-      for (u32 j = 0; j < cnt; j++) {
-        const u32 e = s_code[bytes[c0 + j]];
-        acc |= (u64)(e >> 4) << nb;
-        nb += e & 15u;
+      auto flush = [&]() { /* a full word leaves: the first one shares its word with whoever is in front */
         if (nb >= 32u) {
           if (first)
-            atomicOr(&s_out[w], (u32)acc); /* shares the word with whoever is in front */
+            atomicOr(&s_out[w], (u32)acc);
           else
             s_out[w] = (u32)acc;
           first = false;
@@ -413,6 +437,24 @@ __global__ __launch_bounds__(256) void k_bgzf_emit(const u8* __restrict__ in, u6
           acc >>= 32;
           nb -= 32u;
         }
+      };
+      auto put = [&](u32 e) {
+        acc |= (u64)(e >> 4) << nb;
+        nb += e & 15u;
+      };
+      for (u32 j = 0; j < full; j++) {
+        const u32 x = words[j];
+        const u32 e0 = s_code[x & 0xFFu], e1 = s_code[(x >> 8) & 0xFFu], e2 = s_code[(x >> 16) & 0xFFu], e3 = s_code[x >> 24];
+        put(e0); /* two codes are at most 30 bits: 31 + 30 still fit the accumulator */
+        put(e1);
+        flush();
+        put(e2);
+        put(e3);
+        flush();
+      }
+      for (u32 j = 4u * full; j < cnt; j++) {
+        put(s_code[bytes[c0 + j]]);
+        flush();
       }
       if (cnt && (nb != 0u || first)) atomicOr(&s_out[w], (u32)acc);
     }
