@@ -1424,3 +1424,27 @@ def test_gz_outputs_of_host_text_go_through_the_device_deflate(cli, tmp_path):
     img = open(small, "rb").read()
     tab, _ = pc.bgzf_table(img)
     assert len(tab) == 2 and tab["out_len"][1] == 0 and gzip.decompress(img).count(b"\n") == 3
+
+
+def test_every_command_writes_the_same_bytes_into_a_gz(cli, tmp_path):
+    """utils.rs:181-228: the writer is chosen by the output's extension, whatever the command.  For each command of the path: the
+    `.gz` file is a closed BGZF stream (every member checked) that inflates to exactly what the command writes to stdout;
+    `.bz2` / `.xz` are refused with a message, an existing file without `-r` as well."""
+    maf, paf = os.path.join(GOLDEN, "test.maf"), os.path.join(GOLDEN, "testdotplot.paf")
+    cases = [("stat", maf), ("stat", "-f", "paf", paf), ("maf2paf", maf), ("maf2chain", maf), ("paf2chain", paf),
+             ("call", maf, "-s", "-l0"), ("pafcov", paf), ("dotplot", "-f", "paf", paf, "--out-format", "csv"), ("dotplot", maf, "--out-format", "csv", "-m", "overview"), ("validate", paf)]
+    for k, argv in enumerate(cases):
+        rc, want, err = run(cli, *argv)
+        assert rc == 0 and want, (argv, err)
+        gz = str(tmp_path / ("out%d.txt.gz" % k))
+        rc, out, err = run(cli, *argv, "-o", gz)
+        assert rc == 0 and out == b"", (argv, err)
+        img = open(gz, "rb").read()
+        pc.bgzf_check_stream(img, want, True, one_call=False)
+        rc, _, err = run(cli, *argv, "-o", gz)
+        assert rc != 0 and "already exists" in err, argv
+        rc, _, err = run(cli, *argv, "-o", gz, "-r")
+        assert rc == 0 and open(gz, "rb").read() == img, argv          # the same command, the same bytes
+    for ext in (".bz2", ".xz"):
+        rc, _, err = run(cli, "stat", maf, "-o", str(tmp_path / ("o" + ext)))
+        assert rc != 0 and "not built into this engine" in err

@@ -726,3 +726,35 @@ def test_bgzf_inflate(emu):
 
 def test_bgzf_deflate(emu):
     pc.check_bgzf_deflate(emu)
+
+
+def test_bgzf_deflate_random_inputs(emu):
+    """K18 on whatever bytes: alphabets of 1 to 256 symbols with flat, skewed and geometric frequencies (a geometric one is what
+    drives a Huffman tree past 15 levels), lengths around the member and chunk borders, every alignment — the stream is valid BGZF
+    and inflates to the input"""
+    from hypothesis import given, settings, strategies as st
+    sizes = st.one_of(st.integers(0, 600), st.sampled_from([32767, 32768, 32769, 65535, 65536, 65537, 128 * 255, 128 * 255 + 3]),
+                      st.integers(0, 140000))
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(0, 2 ** 31), sizes, st.integers(1, 256), st.sampled_from(["flat", "skewed", "geometric"]), st.integers(0, 3), st.integers(0, 3),
+           st.booleans())
+    def run(seed, n, k, shape, ia, oa, marker):
+        rng = np.random.default_rng(seed)
+        alphabet = rng.permutation(256)[:k]
+        if shape == "flat":
+            p = np.ones(k)
+        elif shape == "skewed":
+            p = rng.random(k) ** 6 + 1e-9
+        else:
+            p = 0.62 ** np.arange(k) + 1e-12
+        data = alphabet[rng.choice(k, n, p=p / p.sum())].astype(np.uint8).tobytes()
+        d_in = emu.upload(np.frombuffer(b"\x55" * ia + data + b"\x66" * 8, dtype=np.uint8))
+        cap = int(emu.lib.wga_bgzf_bound(n))
+        out = emu.empty(oa + cap + 8, np.uint8).fill(0x23)
+        _, used = emu.bgzf_compress(d_in, n, out=out, eof_marker=marker, in_offset=ia, out_offset=oa)
+        got = out.numpy()
+        assert used <= cap and (got[:oa] == 0x23).all() and (got[oa + used:] == 0x23).all()
+        assert pc.bgzf_check_stream(got[oa:oa + used].tobytes(), data, marker) == (n + 32767) // 32768
+
+    run()
