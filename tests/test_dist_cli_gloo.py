@@ -29,3 +29,11 @@ def test_totals_allreduce(libs, tmp_path):
 
 def test_bad_cigar_ends_every_rank(libs, tmp_path):
     dc.check_bad_cigar_ends_every_rank(tmp_path, libs[0], (1, 2), 29660)
+
+
+def test_compressed_output_names_are_refused(libs, tmp_path):
+    """the ranks write records at their offsets in the plain output: a `.gz` name is refused before anything starts (the
+    single-process command line is the one that deflates, on the device)"""
+    gz = str(tmp_path / "out.maf.gz")
+    r = dc.launch(1, libs[0], 29670, "paf2maf", "nothing.paf", "-g", "t.fa", "-q", "q.fa", "-o", gz, expect_rc=1)
+    assert "plain offsets" in r.stderr and not (tmp_path / "out.maf.gz").exists()

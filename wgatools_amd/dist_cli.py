@@ -497,6 +497,13 @@ def main(argv=None):
     p.add_argument("input")
     p.add_argument("--chunk-bytes", type=int, default=64 << 20)
     args = ap.parse_args(argv)
+    out = getattr(args, "output", None)
+    if out and out.endswith((".gz", ".bz2", ".xz")):
+        # every rank writes its records at their offsets in the PLAIN output; a compressed stream has no such offsets.  The
+        # single-process command line deflates `.gz` outputs on the device (wga_bgzf_compress).
+        sys.stderr.write("ERROR IO error:the multi-rank writer places records at their plain offsets: `%s` would not be a "
+                         "compressed file; write a plain file here, or a .gz with the wgatools command line\n" % out)
+        return 1
     R = Ranks(args.lib)
     try:
         rc = {"paf2maf": run_paf2maf, "pafcov": run_pafcov, "totals": run_totals}[args.cmd](R, args)
