@@ -482,6 +482,8 @@ int wga_pafcov_accumulate_final(wga_ctx*, const wga_cigar_batch*, const uint32_t
  * concatenate into one valid stream; eof_marker != 0 appends BGZF's 28-byte empty member behind the last piece.
  *   wga_bgzf_bound(n)      what d_out must hold for n input bytes in the worst case (stored members + marker)
  *   wga_bgzf_compress(..)  d_in[n_bytes] -> d_out[*out_bytes]; synchronises once (the size); d_in, d_out any alignment.
+ *                          d_out == NULL: the count call — *out_bytes is the exact size of the stream, nothing is written
+ *                          (a caller that cannot spare wga_bgzf_bound's worst case allocates by it and calls again).
  *                          WGA_E_INVALID_ARG with *out_bytes set when out_cap is too small (nothing written). */
 uint64_t wga_bgzf_bound(uint64_t n_bytes);
 int wga_bgzf_compress(wga_ctx*, const uint8_t* d_in, uint64_t n_bytes, uint8_t* d_out, uint64_t out_cap, uint64_t* out_bytes,

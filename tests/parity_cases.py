@@ -2076,5 +2076,9 @@ def check_bgzf_deflate(eng, inflate_too=True):
     need = C.c_uint64(0)
     rc = eng.lib.wga_bgzf_compress(eng.ctx, d_in.ptr, len(data), small.ptr, 1000, C.byref(need), 1)
     _, whole = eng.bgzf_compress(d_in, len(data))
+    exact = C.c_uint64(0)                                      # the count call: the exact size, nothing written
+    assert eng.lib.wga_bgzf_compress(eng.ctx, d_in.ptr, len(data), None, 0, C.byref(exact), 1) == 0 and exact.value == whole
+    assert eng.lib.wga_bgzf_compress(eng.ctx, None, 0, None, 0, C.byref(exact), 1) == 0 and exact.value == 28
+    assert eng.lib.wga_bgzf_compress(eng.ctx, None, 0, None, 0, C.byref(exact), 0) == 0 and exact.value == 0
     assert rc != 0 and need.value == whole and (small.numpy() == 0x23).all()
     assert b"wga_bgzf_bound" in eng.lib.wga_last_error()

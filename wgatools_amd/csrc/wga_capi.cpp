@@ -1262,16 +1262,15 @@ int wga_bgzf_compress(wga_ctx* c, const uint8_t* d_in, uint64_t n_bytes, uint8_t
     if ((rc = run_scan_ws(c, sp, nb, offs, partial))) return rc;
     RT_CHECK(rt_d2h(&total, offs + nb, sizeof total, c->stream));
     *out_bytes = total + tail;
+    if (!d_out) return WGA_OK; /* the count call */
     if (total + tail > out_cap) return fail(WGA_E_INVALID_ARG, "output buffer smaller than the compressed stream (wga_bgzf_bound)", nullptr);
-    if (!d_out) return fail(WGA_E_INVALID_ARG, "d_out null", nullptr);
     WGA_LAUNCH(k_bgzf_emit, nb, WGA_BLOCK, c->stream, d_in, (u64)n_bytes, (const u64*)offs, (const wga_bgzf_member*)members,
                (const u8*)lens, d_out);
     LAUNCH_CHECK();
   }
   *out_bytes = total + tail;
-  if (tail) {
+  if (tail && d_out) {
     if (total + tail > out_cap) return fail(WGA_E_INVALID_ARG, "output buffer smaller than the compressed stream (wga_bgzf_bound)", nullptr);
-    if (!d_out) return fail(WGA_E_INVALID_ARG, "d_out null", nullptr);
     RT_CHECK(rt_h2d(d_out + total, k_bgzf_eof, sizeof k_bgzf_eof, c->stream));
   }
   return WGA_OK;
