@@ -116,6 +116,10 @@ def test_paf2maf_end_to_end(cli, tmp_path):
     img = open(gz, "rb").read()
     n_members = pc.bgzf_check_stream(img, _expected_maf(b, mapq, t_fa, q_fa, 60), True, one_call=False)
     assert n_members >= 2 and len(img) < 0.45 * len(_expected_maf(b, mapq, t_fa, q_fa, 60))
+    # and the engine's own readers take it back (BGZF members through the device inflate, K17): the same PAF as from the plain file
+    rc, a, err = run(cli, "maf2paf", gz)
+    rc2, b_, err2 = run(cli, "maf2paf", outp)
+    assert rc == 0 and rc2 == 0 and a == b_ and a.count(b"\n") == 60, (err, err2)
     rc, _, err = run(cli, "p2m", paf, "-g", t_fa, "-q", q_fa, "-o", gz)        # an existing .gz is refused without -r like any output
     assert rc != 0 and "already exists" in (err if isinstance(err, str) else err.decode())
 
