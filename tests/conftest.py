@@ -14,6 +14,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (`-m "not gpu"`: the kernels on the SIMT emulator, the oracle under sanitizers, gloo ranks) is fifteen minutes
+    on one core and four on six: when pytest-xdist is installed and the caller did not choose (`-n ...`), it runs over up to six
+    worker processes.  Nothing is shared between tests but the built libraries (the build functions take a file lock) and fixed,
+    distinct rendezvous ports.  The GPU suite (`-m gpu`) is never split: its tests at stated size each want the device to
+    themselves.  WGA_TEST_PROCS=<n> overrides (1: one process)."""
+    if os.environ.get("PYTEST_XDIST_WORKER") or not config.pluginmanager.hasplugin("xdist"):
+        return None
+    if (config.getoption("markexpr", "") or "").strip() != "not gpu" or config.getoption("numprocesses", None) is not None:
+        return None
+    want = os.environ.get("WGA_TEST_PROCS")
+    procs = int(want) if want and want.isdigit() else min(6, os.cpu_count() or 1)
+    if procs > 1:
+        config.option.numprocesses = procs
+    return None
+
+
 def pytest_collection_modifyitems(config, items):
     """a plain `pytest tests` on a box without an MI355X skips the GPU tests instead of failing them one by one
     (`-m gpu` on such a box still fails loudly: the product has no CPU fallback)"""
