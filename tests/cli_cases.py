@@ -1419,6 +1419,17 @@ def test_gz_outputs_of_host_text_go_through_the_device_deflate(cli, tmp_path):
     pc.bgzf_check_stream(img, want, True, one_call=False)
     tab, _ = pc.bgzf_table(img)
     assert (tab["out_len"] == 32768).sum() >= len(want) // 32768 - 1          # the device's members
+    # a middling output (below the 1 MiB that is worth the trip to the device): zlib members of 65 280 input bytes from the host
+    mid, midmaf = str(tmp_path / "mid.paf.gz"), str(tmp_path / "mid.maf")
+    open(midmaf, "wb").write(b"\n\n".join(open(maf, "rb").read().split(b"\n\n")[:2500]) + b"\n\n")
+    rc, want_mid, err = run(cli, "maf2paf", midmaf)
+    assert rc == 0 and 3 * 65280 < len(want_mid) < (1 << 20), err
+    rc, _, err = run(cli, "maf2paf", midmaf, "-o", mid)
+    assert rc == 0, err
+    img = open(mid, "rb").read()
+    pc.bgzf_check_stream(img, want_mid, True, one_call=False)
+    tab, _ = pc.bgzf_table(img)
+    assert (tab["out_len"][:-2] == 65280).all() and len(tab) == len(want_mid) // 65280 + 2 and len(img) < 0.5 * len(want_mid)
     # a small output: one host member and the closing one
     small = str(tmp_path / "few.paf.gz")
     few = str(tmp_path / "few.maf")

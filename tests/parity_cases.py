@@ -2004,7 +2004,7 @@ def bgzf_check_stream(img, want, eof_marker, one_call=True):
         crc, isize = struct.unpack_from("<II", img, p + bsize - 8)
         raw = zlib.decompressobj(-15)
         data = raw.decompress(img[p + 18:p + bsize - 8])
-        assert raw.eof and raw.unused_data == b"" and len(data) == isize and isize <= 32768
+        assert raw.eof and raw.unused_data == b"" and len(data) == isize and isize <= (32768 if one_call else 65280)   # the host's zlib members hold up to 0xff00
         assert data == want[got:got + isize] and zlib.crc32(data) & 0xFFFFFFFF == crc
         sizes.append(isize)
         got += isize
