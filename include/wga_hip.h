@@ -137,12 +137,13 @@ int wga_ctx_reset_stream(wga_ctx*);
  * they stay in the 256 MB Infinity Cache, 16 when they do not (environment: WGA_EXPAND_DRAIN_MIN).
  * "reduce_same_device_ok" / "reduce_staged" (0/1): wga_reduce_scatter_i32 over contexts that share a device, and by staged
  * peer copies where peer access exists (tests on one-GPU boxes).
+ * "cov_spin_limit" (default 4096): wga_pafcov_accumulate's list pass polls a tile sum this often before it adds up the ops itself.
  * "op_long_ops" (default 16384) / "op_piece_ops" (8192, a multiple of 256): the op walks with one wave per record (call
  * events, chain lines, dotplot segments) cut records beyond the first into pieces of at most the second and walk the pieces
  * over the whole chip; "maf_long_cols" (32768) / "maf_piece_cols" (16384): the same for the MAF column walks.  The tests set
  * small values to reach those paths with small inputs. */
 int wga_ctx_set_param(wga_ctx*, const char* name, int64_t value);
-/* Read back: "expand_drain_min" = what the last wga_paf2maf_expand used,
+/* Read back: "cov_spin_limit" (the setting), "expand_drain_min" = what the last wga_paf2maf_expand used,
  * "expand_variant" / "expand_job_tiles" / "pseudo_variant" (the settings), "expand_variant_used" (what the last
  * wga_paf2maf_expand ran), "expand_stream_left_to_v1" / "pseudo_stream_left_to_blocks" (tiles the streaming kernel's last
  * launch left to the block kernels: records whose slices do not match their CIGAR, slices at a pool's edge, giant tiles —
@@ -452,8 +453,8 @@ int wga_fasta_pool(wga_ctx*, const uint8_t* d_text, uint64_t n_bytes, uint64_t* 
  * counts back to size its work lists).  The context keeps its work lists between calls, grow-only:
  * 256 bytes per 1024 ops of the largest batch (the pieces as the list pass writes them) and 40 bytes
  * per piece (a record segment of a tile of ops under a window of 8192 counters; 3.5 per 1024 ops on
- * configs[3]'s records).  WGA_COV_SPIN_LIMIT (environment, read by wga_ctx_create): polls of a
- * neighbouring tile's sum before a wave of the list pass adds up the ops itself (default 4096).
+ * configs[3]'s records).  Context parameter "cov_spin_limit": polls of a neighbouring tile's sum
+ * before a wave of the list pass adds up the ops itself (default 4096; 0: always adds them up).
  *
  * accumulate_final() = accumulate() of the LAST batch + finalize() in one pass over the array: the
  * kernel that replays the batch's marks window by window goes on to scan each window and hands its

@@ -237,13 +237,12 @@ def test_pafcov_look_back(emu, monkeypatch):
     records across 2 .. 70 tiles (more than one round of 64 lanes), tiles that end exactly with a record, and the same with the
     look-back told to add up the ops itself (what it does when a tile in front has not published in time)"""
     pc.check_pafcov_look_back(emu)
-    monkeypatch.setenv("WGA_COV_SPIN_LIMIT", "0")
-    from conftest import _emu_engine
-    eng = _emu_engine()
+    keep = emu.get_param("cov_spin_limit")
+    emu.set_param("cov_spin_limit", 0)
     try:
-        pc.check_pafcov_look_back(eng)
+        pc.check_pafcov_look_back(emu)
     finally:
-        eng.close()
+        emu.set_param("cov_spin_limit", keep)
 
 
 @pytest.mark.parametrize("base", [0, 1])

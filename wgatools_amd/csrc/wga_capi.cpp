@@ -105,7 +105,7 @@ struct wga_ctx {
 #else
   u32 cov_spin_limit = 1u << 12;
 #endif /* polls of a tile sum (milliseconds of waiting where ten microseconds are the rule) before the
-                                    look-back adds up the ops itself (WGA_COV_SPIN_LIMIT) */
+                                    look-back adds up the ops itself (parameter "cov_spin_limit") */
   /* optional per-launch timing of the expand kernel proper (events on the launch stream) */
   static const int kTimingRing = 64;
   bool timing = false;
@@ -466,7 +466,6 @@ int wga_ctx_create(int device, wga_ctx** out) {
   c->stream = c->own_stream;
   /* A/B switch for measurements: WGA_EXPAND_VARIANT=0 selects v1 of the paf2maf row kernel (wga_ctx_set_param overrides) */
   if (const char* v = getenv("WGA_EXPAND_VARIANT")) c->expand_variant = (atoi(v) == 0 || atoi(v) == 2 || atoi(v) == 3) ? atoi(v) : -1;
-  if (const char* v = getenv("WGA_COV_SPIN_LIMIT")) c->cov_spin_limit = (u32)strtoul(v, nullptr, 10);
   if (const char* v = getenv("WGA_EXPAND_DRAIN_MIN")) {
     const int d = atoi(v);
     if (d >= 0 && d <= 64) c->expand_drain_min = (unsigned)d;
@@ -527,6 +526,11 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
   }
   if (strcmp(name, "reduce_same_device_ok") == 0) { /* wga_reduce_scatter_i32 over contexts that share a device (tests) */
     c->rs_same_device_ok = value != 0;
+    return WGA_OK;
+  }
+  if (strcmp(name, "cov_spin_limit") == 0) { /* K5's list pass: polls of a tile sum before the look-back adds up the ops itself */
+    if (value < 0 || value > 0x7FFFFFFF) return fail(WGA_E_INVALID_ARG, "cov_spin_limit: 0 .. 2^31 - 1", nullptr);
+    c->cov_spin_limit = (u32)value;
     return WGA_OK;
   }
   if (strcmp(name, "reduce_staged") == 0) { /* wga_reduce_scatter_i32 by staged peer copies even where peer access exists */
@@ -997,6 +1001,10 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
 
 int wga_ctx_get_param(wga_ctx* c, const char* name, int64_t* value) {
   if (!c || !name || !value) return fail(WGA_E_INVALID_ARG, "null argument", nullptr);
+  if (strcmp(name, "cov_spin_limit") == 0) {
+    *value = (int64_t)c->cov_spin_limit;
+    return WGA_OK;
+  }
   if (strcmp(name, "expand_drain_min") == 0) { /* what the last wga_paf2maf_expand used */
     *value = (int64_t)c->expand_drain_min_used;
     return WGA_OK;
