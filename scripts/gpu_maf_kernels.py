@@ -42,6 +42,8 @@ if os.environ.get("WGA_LIB"):     # an A/B build (wgatools_amd.build.build_hip_v
     lib = _lib.load(os.environ["WGA_LIB"])
 eng = engine.Engine(0, lib)
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
+if os.environ.get("WGA_MAF_GROUP"):
+    eng.set_param("maf_group", int(os.environ["WGA_MAF_GROUP"]))     # blocks per wave of the stream kernels (0: by the batch)
 counts = torch.zeros((n, 11), dtype=torch.int64, device=dev)
 run_cnt = torch.zeros(n, dtype=torch.int64, device=dev)
 run_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)

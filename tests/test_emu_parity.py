@@ -323,11 +323,12 @@ def test_maf_pair_stat(emu):
 
 
 def test_maf_walks_pairs_of_every_shape(emu):
-    """the walks take the two blocks of a wave as ONE column stream where that saves a step: every pair of lengths around the
-    sixteen-column and the 1 024-column borders (B starts at A's length rounded up to sixteen; A ends on a step's border, inside
-    it, in its last lane; empty blocks), counters and run lists of both walks"""
+    """the walks take up to eight consecutive blocks of a wave as ONE column stream (`maf_group`; a lane holds 32 columns of one
+    block, a block's last lane its last 32 bytes): every pair of lengths around the 32-column and the 2 048-column borders
+    (a block ends on a step's border, inside it, in its last lane; empty and tiny blocks in between), groups of 1, 3 and 8,
+    counters and run lists of both walks"""
     rng = np.random.default_rng(11)
-    lens = [0, 1, 15, 16, 17, 500, 1008, 1023, 1024, 1025, 1040, 2047, 2048, 2049]
+    lens = [0, 1, 31, 32, 33, 63, 64, 65, 500, 2016, 2047, 2048, 2049, 2080, 4095, 4096, 4097]
     pairs, strands = [], []
     for la in lens:
         for lb in lens:
@@ -339,8 +340,38 @@ def test_maf_walks_pairs_of_every_shape(emu):
                         q[k:k + 3] = t[k:k + 3]
                 pairs.append((t, bytes(q)))
                 strands.append(int(rng.integers(0, 2)))
-    pc.check_maf_pair(emu, pairs, strands)
-    pc.check_maf_call_runs(emu, pairs)
+    try:
+        for g in (1, 3, 8):
+            emu.set_param("maf_group", g)
+            pc.check_maf_pair(emu, pairs[g::2] if g == 3 else pairs, strands[g::2] if g == 3 else strands)
+            pc.check_maf_call_runs(emu, pairs[g::2] if g == 3 else pairs)
+    finally:
+        emu.set_param("maf_group", 0)
+
+
+def test_maf_stream_groups_with_long_and_binary_blocks(emu):
+    """a group of eight whose blocks are of every kind at once — long (left to the piece walk, whose packed totals are folded
+    every three steps in this build), tiny, empty, rows that are not text — and a long block whose last piece is tiny"""
+    rng = np.random.default_rng(12)
+    pairs, strands = [], []
+    for L in (7000, 5, 0, 300, 64 * 100 + 3, 40, 31, 9000, 2048, 1, 33, 6500):
+        t = pc.rand_seq(rng, L, b"ACGTacgt--N")
+        q = pc.rand_seq(rng, L + int(rng.integers(0, 3)), b"ACGTacgt--N")
+        pairs.append((t, q))
+        strands.append(L & 1)
+    pairs += pc.binary_row_pairs(rng)
+    strands += [0, 1, 0, 1]
+    try:
+        for g, long_cols, piece_cols in ((8, 6000, 64), (8, 6000, 2048), (5, 32768, 16384), (8, 300, 100), (8, 3000, 7000)):
+            emu.set_param("maf_group", g)
+            emu.set_param("maf_long_cols", long_cols)
+            emu.set_param("maf_piece_cols", piece_cols)
+            pc.check_maf_pair(emu, pairs, strands)
+            pc.check_maf_call_runs(emu, pairs)
+    finally:
+        emu.set_param("maf_group", 0)
+        emu.set_param("maf_long_cols", 32768)
+        emu.set_param("maf_piece_cols", 16384)
 
 
 def test_pafpseudo_stream_random(emu):

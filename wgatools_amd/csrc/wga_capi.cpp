@@ -32,6 +32,10 @@ struct wga_ctx {
   uint64_t op_piece_ops = 8192;  /* ... are walked in pieces of this many (a multiple of 256), one wave each (test knobs: "op_long_ops", "op_piece_ops") */
   uint64_t maf_long_cols = 32768;  /* MAF blocks beyond this many columns are walked piece by piece ... */
   uint64_t maf_piece_cols = 16384; /* ... of this many columns, one wave each (test knobs: "maf_long_cols", "maf_piece_cols") */
+  unsigned maf_group = 0;          /* blocks per wave of the MAF stream kernels, 1 .. 8 ("maf_group"; 0 = by the number of blocks) */
+  void* maf_tab = nullptr;         /* K3 / K4: the table of a call's long blocks (header, list, pieces), grow-only */
+  size_t maf_tab_cap = 0;
+  bool maf_hdr_clean = false;      /* the header's append counters are zero (the plan kernel leaves them so) */
   int expand_variant = -1; /* the row kernel: -1 by the batch (records below WGA_AUTO_SHORT_OPS ops on average take the window
                               kernel of wga_kernels_k2w.h, longer ones v1), 0 v1 (wga_kernels.h), 2 the window kernel */
   int expand_variant_used = 0;
@@ -315,70 +319,64 @@ static int split_lines(wga_ctx* c, const uint8_t* d_text, uint64_t n_bytes, uint
   return WGA_OK;
 }
 
-/* the long blocks of a MAF walk call, piece by piece (see k_maf_piece_walk); returns at once when there are none */
+/* K3 / K4: the stream kernel over every block that is not long, then the long blocks piece by piece (wga_k3_maf.h).  Five
+ * launches at most, all of them queued whatever the data holds: the table of long blocks is built and sized on the device (its
+ * bounds — n list entries, 32 768 + n pieces — are known here), nothing is read back. */
+#ifdef WGA_EMU
+#define WGA_MAF_PIECE_GRID 3u /* the emulator makes 256 fibers per block, empty or not */
+#else
+#define WGA_MAF_PIECE_GRID 2048u
+#endif
 template <bool CALLER>
-static int maf_long_blocks(wga_ctx* c, u32 n, const u8* d_rows, const u64* d_t_off, const u64* d_q_off, const u64* d_cols,
-                           const u8* d_strand_neg, wga_cigar_counts* d_counts, u64* d_run_cnt, u64* d_runs,
-                           const u64* d_run_off) {
-  int rc;
-  void* ws;
-  const size_t head = ((size_t)n * 2 + 2 + (size_t)n / 1024 + 4) * sizeof(u64);
-  if ((rc = ctx_scratch(c, head, &ws))) return rc;
-  u64* npieces = (u64*)ws;
-  u64* piece_off = npieces + n;
-  u64* partial = piece_off + n + 1;
-  /* the fill call must not clear what the count call left in the caller's arrays */
-  WGA_LAUNCH(k_maf_piece_counts, (n + 255u) / 256u, WGA_BLOCK, c->stream, n, d_cols, (u64)c->maf_long_cols,
-             (u64)c->maf_piece_cols, npieces, d_runs ? (wga_cigar_counts*)nullptr : d_counts,
-             d_runs ? (u64*)nullptr : d_run_cnt);
-  LAUNCH_CHECK();
-  ScanPlain sp;
-  sp.in = npieces;
-  if ((rc = run_scan_ws(c, sp, n, piece_off, partial))) return rc;
-  u64 total = 0;
-  RT_CHECK(rt_d2h(&total, piece_off + n, sizeof total, c->stream));
-  if (total == 0) return WGA_OK;
-  if (total > 0xFFFFFFF0ull) return fail(WGA_E_INVALID_ARG, "too many pieces for one call", nullptr);
-  const u32 np = (u32)total;
-  /* the piece arrays go behind the record arrays; regrowing the arena frees it, so the head is rebuilt */
-  const size_t piece_bytes = (size_t)np * sizeof(wga_maf_piece_tot) + 3 * ((size_t)np + 1) * sizeof(u64) +
-                             ((size_t)np / 1024 + 4) * sizeof(u64) + 256;
-  if (c->scratch_cap < head + piece_bytes) {
-    if ((rc = ctx_scratch(c, head + piece_bytes, &ws))) return rc;
-    npieces = (u64*)ws;
-    piece_off = npieces + n;
-    partial = piece_off + n + 1;
-    WGA_LAUNCH(k_maf_piece_counts, (n + 255u) / 256u, WGA_BLOCK, c->stream, n, d_cols, (u64)c->maf_long_cols,
-               (u64)c->maf_piece_cols, npieces, (wga_cigar_counts*)nullptr, (u64*)nullptr);
-    LAUNCH_CHECK();
-    sp.in = npieces;
-    if ((rc = run_scan_ws(c, sp, n, piece_off, partial))) return rc;
+static int maf_walk_call(wga_ctx* c, u32 n, const u8* d_rows, const u64* d_t_off, const u64* d_q_off, const u64* d_cols,
+                         const u8* d_strand_neg, wga_cigar_counts* d_counts, u64* d_run_cnt, u64* d_runs,
+                         const u64* d_run_off) {
+  const size_t cap = (size_t)n + WGA_MAF_PIECE_BUDGET + 1;
+  const size_t o_list = 64, o_off = o_list + (((size_t)n * 4 + 63) & ~(size_t)63), o_ptot = o_off + ((((size_t)n + 1) * 4 + 63) & ~(size_t)63),
+               o_ex = o_ptot + cap * sizeof(wga_maf_piece_tot), need = o_ex + (cap + 1) * sizeof(wga_maf_piece_tot);
+  if (c->maf_tab_cap < need) {
+    RT_CHECK(rt_sync(c->stream));
+    if (c->maf_tab) RT_CHECK(rt_free(c->maf_tab));
+    c->maf_tab = nullptr;
+    c->maf_tab_cap = 0;
+    RT_CHECK(rt_malloc(&c->maf_tab, need + need / 4));
+    c->maf_tab_cap = need + need / 4;
+    c->maf_hdr_clean = false;
   }
-  char* base = (char*)ws + ((head + 63) & ~(size_t)63);
-  wga_maf_piece_tot* ptot = (wga_maf_piece_tot*)base;
-  u64* ex_runs = (u64*)(ptot + np);
-  u64* ex_t = ex_runs + np + 1;
-  u64* ex_q = ex_t + np + 1;
-  u64* ppartial = ex_q + np + 1;
-  const u32 grid = np < 4u * 2048u ? (np + 3u) / 4u : 2048u;
-  WGA_LAUNCH((k_maf_piece_walk<CALLER, 0>), grid, WGA_BLOCK, c->stream, n, d_rows, d_t_off, d_q_off, d_cols, d_strand_neg,
-             (const u64*)piece_off, (u64)c->maf_piece_cols, ptot, (const u64*)nullptr, (const u64*)nullptr,
-             (const u64*)nullptr, d_runs ? (wga_cigar_counts*)nullptr : d_counts, d_runs ? (u64*)nullptr : d_run_cnt,
-             (u64*)nullptr, (const u64*)nullptr);
+  if (!c->maf_hdr_clean) { /* a fresh table, or a call that did not get as far as its plan */
+    RT_CHECK(rt_memset(c->maf_tab, 0, 64, c->stream));
+    c->maf_hdr_clean = true;
+  }
+  char* const base = (char*)c->maf_tab;
+  wga_maf_long_hdr* const hdr = (wga_maf_long_hdr*)base;
+  u32* const long_list = (u32*)(base + o_list);
+  u32* const list_off = (u32*)(base + o_off);
+  wga_maf_piece_tot* const ptot = (wga_maf_piece_tot*)(base + o_ptot);
+  wga_maf_piece_tot* const ex = (wga_maf_piece_tot*)(base + o_ex);
+  u32 G = c->maf_group ? c->maf_group : n / 24576u; /* eight blocks per wave where that still leaves every CU a few rounds of waves */
+  G = G < 1u ? 1u : G > WGA_MAF_G ? WGA_MAF_G : G;
+  const u32 grid = (u32)(((u64)n + 4ull * G - 1ull) / (4ull * G));
+  c->maf_hdr_clean = false; /* until the plan has cleared the appends */
+  if (d_runs)
+    WGA_LAUNCH((k_maf_stream<CALLER, true>), grid, WGA_BLOCK, c->stream, n, G, d_rows, d_t_off, d_q_off, d_cols, d_strand_neg, d_counts,
+               d_run_cnt, d_runs, d_run_off, (u64)c->maf_long_cols, hdr, long_list);
+  else
+    WGA_LAUNCH((k_maf_stream<CALLER, false>), grid, WGA_BLOCK, c->stream, n, G, d_rows, d_t_off, d_q_off, d_cols, d_strand_neg, d_counts,
+               d_run_cnt, d_runs, d_run_off, (u64)c->maf_long_cols, hdr, long_list);
+  LAUNCH_CHECK();
+  WGA_LAUNCH(k_maf_long_plan, 1, 1024, c->stream, hdr, (const u32*)long_list, list_off, d_cols, (u64)c->maf_piece_cols);
+  LAUNCH_CHECK();
+  c->maf_hdr_clean = true;
+  /* the fill call must not add to what the count call left in the caller's arrays */
+  WGA_LAUNCH((k_maf_piece_walk<CALLER, 0>), WGA_MAF_PIECE_GRID, WGA_BLOCK, c->stream, d_rows, d_t_off, d_q_off, d_cols, d_strand_neg,
+             (const wga_maf_long_hdr*)hdr, (const u32*)long_list, (const u32*)list_off, ptot, (const wga_maf_piece_tot*)nullptr,
+             d_runs ? (wga_cigar_counts*)nullptr : d_counts, d_runs ? (u64*)nullptr : d_run_cnt, (u64*)nullptr, (const u64*)nullptr);
   LAUNCH_CHECK();
   if (!d_runs) return WGA_OK;
-  ScanPieceTot st;
-  st.in = ptot;
-  st.field = 0;
-  if ((rc = run_scan_ws(c, st, np, ex_runs, ppartial))) return rc;
-  if (CALLER) {
-    st.field = 1;
-    if ((rc = run_scan_ws(c, st, np, ex_t, ppartial))) return rc;
-    st.field = 2;
-    if ((rc = run_scan_ws(c, st, np, ex_q, ppartial))) return rc;
-  }
-  WGA_LAUNCH((k_maf_piece_walk<CALLER, 1>), grid, WGA_BLOCK, c->stream, n, d_rows, d_t_off, d_q_off, d_cols, d_strand_neg,
-             (const u64*)piece_off, (u64)c->maf_piece_cols, ptot, (const u64*)ex_runs, (const u64*)ex_t, (const u64*)ex_q,
+  WGA_LAUNCH(k_maf_piece_scan, 1, 1024, c->stream, (const wga_maf_long_hdr*)hdr, (const wga_maf_piece_tot*)ptot, ex);
+  LAUNCH_CHECK();
+  WGA_LAUNCH((k_maf_piece_walk<CALLER, 1>), WGA_MAF_PIECE_GRID, WGA_BLOCK, c->stream, d_rows, d_t_off, d_q_off, d_cols, d_strand_neg,
+             (const wga_maf_long_hdr*)hdr, (const u32*)long_list, (const u32*)list_off, ptot, (const wga_maf_piece_tot*)ex,
              (wga_cigar_counts*)nullptr, (u64*)nullptr, d_runs, d_run_off);
   LAUNCH_CHECK();
   return WGA_OK;
@@ -491,6 +489,7 @@ void wga_ctx_destroy(wga_ctx* c) {
   if (c->cov_order) (void)rt_free(c->cov_order);
   if (c->cov_tile_list) (void)rt_free(c->cov_tile_list);
   if (c->op_tab.mem) (void)rt_free(c->op_tab.mem);
+  if (c->maf_tab) (void)rt_free(c->maf_tab);
   rt_stream_destroy(c->own_stream);
   delete c;
 }
@@ -559,6 +558,11 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
   if (strcmp(name, "maf_long_cols") == 0 || strcmp(name, "maf_piece_cols") == 0) {
     if (value < 1) return fail(WGA_E_INVALID_ARG, "must be positive", name);
     (name[4] == 'l' ? c->maf_long_cols : c->maf_piece_cols) = (uint64_t)value;
+    return WGA_OK;
+  }
+  if (strcmp(name, "maf_group") == 0) {
+    if (value < 0 || value > (long long)WGA_MAF_G) return fail(WGA_E_INVALID_ARG, "maf_group: 0 (by the batch) .. 8", nullptr);
+    c->maf_group = (unsigned)value;
     return WGA_OK;
   }
   if (strcmp(name, "expand_variant") == 0) {
@@ -1094,12 +1098,8 @@ int wga_maf_pair_stat(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint6
   if (!d_rows || !d_t_off || !d_q_off || !d_cols || !d_strand_neg || !d_counts)
     return fail(WGA_E_INVALID_ARG, "null array", nullptr);
   if (d_runs && !d_run_off) return fail(WGA_E_INVALID_ARG, "d_run_off null", nullptr);
-  WGA_LAUNCH(k_maf_pair_stat, (n + 7u) / 8u, WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off,
-             (const u64*)d_q_off, (const u64*)d_cols, d_strand_neg, d_counts, (u64*)d_run_cnt,
-             (u64*)d_runs, (const u64*)d_run_off, (u64)c->maf_long_cols);
-  LAUNCH_CHECK();
-  return maf_long_blocks<false>(c, n, d_rows, (const u64*)d_t_off, (const u64*)d_q_off, (const u64*)d_cols, d_strand_neg,
-                                d_counts, (u64*)d_run_cnt, (u64*)d_runs, (const u64*)d_run_off);
+  return maf_walk_call<false>(c, n, d_rows, (const u64*)d_t_off, (const u64*)d_q_off, (const u64*)d_cols, d_strand_neg, d_counts,
+                              (u64*)d_run_cnt, (u64*)d_runs, (const u64*)d_run_off);
 }
 
 int wga_maf_call_runs(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint64_t* d_t_off,
@@ -1110,13 +1110,8 @@ int wga_maf_call_runs(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint6
   if (n == 0) return WGA_OK;
   if (!d_rows || !d_t_off || !d_q_off || !d_cols) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
   if (d_runs && !d_run_off) return fail(WGA_E_INVALID_ARG, "d_run_off null", nullptr);
-  WGA_LAUNCH(k_maf_call_runs, (n + 7u) / 8u, WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off,
-             (const u64*)d_q_off, (const u64*)d_cols, (u64*)d_run_cnt, (u64*)d_runs,
-             (const u64*)d_run_off, (u64)c->maf_long_cols);
-  LAUNCH_CHECK();
-  return maf_long_blocks<true>(c, n, d_rows, (const u64*)d_t_off, (const u64*)d_q_off, (const u64*)d_cols,
-                               (const u8*)nullptr, (wga_cigar_counts*)nullptr, (u64*)d_run_cnt, (u64*)d_runs,
-                               (const u64*)d_run_off);
+  return maf_walk_call<true>(c, n, d_rows, (const u64*)d_t_off, (const u64*)d_q_off, (const u64*)d_cols, (const u8*)nullptr,
+                             (wga_cigar_counts*)nullptr, (u64*)d_run_cnt, (u64*)d_runs, (const u64*)d_run_off);
 }
 
 int wga_cigar_tokenise(wga_ctx* c, uint32_t n, const uint8_t* d_text, const uint64_t* d_text_off,
