@@ -298,6 +298,28 @@ int wga_paf_call_vcf(wga_ctx*, const wga_cigar_batch*, uint64_t svlen, const uin
                      const uint8_t* d_q_pool, uint64_t* d_nbytes, wga_vcf_err* d_err, uint8_t* d_out,
                      const uint64_t* d_out_off);
 
+/* ---- call on MAF: chunk cuts, event rules and VCF rows on the run list (replaces find_safe_chunk_boundary
+ *      caller.rs:159-219, create_chunk_record :221-265 and the fold + record building of call_within_var :388-608;
+ *      text layout of noodles-vcf 0.43, README.md:323-343) ---------------------------------------------------------
+ * d_rows / d_t_off / d_q_off / d_cols / d_runs / d_run_off: the arrays of wga_maf_call_runs (cols = the target row's
+ * length, caller.rs:115) and the run list it wrote.  d_recs: per block its names (offsets into d_names), the two s lines'
+ * start fields, the query's source size and strand (maf.rs:65-73).  Block i's text = the rows of its chunks in order: the
+ * <INV> row of a '-' block's chunk (`inv`, :423-440), one row per column of an X run (`snp`, :570-603), one row per I / D
+ * run longer than `svlen` that follows an '=' / X run (:464-569).  Two calls as wga_paf_call_vcf: d_out == NULL ->
+ * d_nbytes[n], d_err[n] (item == ~0: clean; kind 2 = a REF / ALT base outside ACGTN in any case, ch = the byte:
+ * noodles-vcf's parse error); then d_out_off = exclusive scan of d_nbytes and the call again with d_out.  A block's text
+ * ends in front of the chunk that holds its first bad base (a chunk's records are collected before any is written, :137-141). */
+typedef struct {
+  uint64_t t_name_off, q_name_off;
+  uint32_t t_name_len, q_name_len;
+  uint64_t t_start, q_start, q_size;
+  uint32_t q_neg, pad;
+} wga_maf_vcf_rec;
+int wga_maf_call_vcf(wga_ctx*, uint32_t n, const uint8_t* d_rows, const uint64_t* d_t_off, const uint64_t* d_q_off,
+                     const uint64_t* d_cols, const uint64_t* d_runs, const uint64_t* d_run_off, const wga_maf_vcf_rec* d_recs,
+                     const uint8_t* d_names, int snp, int inv, uint64_t svlen, uint64_t chunk_size, uint64_t* d_nbytes,
+                     wga_vcf_err* d_err, uint8_t* d_out, const uint64_t* d_out_off);
+
 /* ---- BGZF inflate on the device (the reference opens bgzipped FASTA through htslib's faidx,
  *      converter.rs:183-184, paf.rs:221-237, pseudomaf.rs:214-237) -------------------------------------------------
  * d_in: the compressed file as it is; d_blocks[n]: per BGZF member the place of its raw DEFLATE stream (behind the gzip

@@ -66,6 +66,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "maf-pieces":      # piece size of the M
     os.remove(maf)
     sys.exit(0)
 run("call_maf", ["call", "-s", "-l", "50", maf], os.path.join(tmp, "m.vcf"), nb * cols, "columns")
+run("call_maf_again", ["call", "-s", "-l", "50", maf], os.path.join(tmp, "m.vcf"), nb * cols, "columns")
+if len(sys.argv) > 1 and sys.argv[1] == "maf-only":
+    run("stat_maf", ["stat", maf], os.path.join(tmp, "m.tsv"), nb * cols, "columns")
+    os.remove(maf)
+    print(json.dumps(res))
+    sys.exit(0)
 run("stat_maf", ["stat", maf], os.path.join(tmp, "m.tsv"), nb * cols, "columns")
 run("maf2paf", ["maf2paf", maf], os.path.join(tmp, "m.paf"), nb * cols, "columns")
 os.remove(maf)

@@ -48,6 +48,15 @@ _Static_assert(offsetof(wga_vcf_rec, t_off) == 56, "wga_vcf_rec.t_off");
 _Static_assert(offsetof(wga_vcf_rec, t_len) == 64, "wga_vcf_rec.t_len");
 _Static_assert(offsetof(wga_vcf_rec, q_off) == 72, "wga_vcf_rec.q_off");
 _Static_assert(offsetof(wga_vcf_rec, q_len) == 80, "wga_vcf_rec.q_len");
+_Static_assert(sizeof(wga_maf_vcf_rec) == 56, "wga_maf_vcf_rec");
+_Static_assert(offsetof(wga_maf_vcf_rec, t_name_off) == 0, "wga_maf_vcf_rec.t_name_off");
+_Static_assert(offsetof(wga_maf_vcf_rec, q_name_off) == 8, "wga_maf_vcf_rec.q_name_off");
+_Static_assert(offsetof(wga_maf_vcf_rec, t_name_len) == 16, "wga_maf_vcf_rec.t_name_len");
+_Static_assert(offsetof(wga_maf_vcf_rec, q_name_len) == 20, "wga_maf_vcf_rec.q_name_len");
+_Static_assert(offsetof(wga_maf_vcf_rec, t_start) == 24, "wga_maf_vcf_rec.t_start");
+_Static_assert(offsetof(wga_maf_vcf_rec, q_start) == 32, "wga_maf_vcf_rec.q_start");
+_Static_assert(offsetof(wga_maf_vcf_rec, q_size) == 40, "wga_maf_vcf_rec.q_size");
+_Static_assert(offsetof(wga_maf_vcf_rec, q_neg) == 48, "wga_maf_vcf_rec.q_neg");
 _Static_assert(sizeof(wga_vcf_err) == 16, "wga_vcf_err");
 _Static_assert(offsetof(wga_vcf_err, item) == 0, "wga_vcf_err.item");
 _Static_assert(offsetof(wga_vcf_err, kind) == 8, "wga_vcf_err.kind");

@@ -534,19 +534,33 @@ def test_call_and_maf2paf_on_a_long_block(cli, tmp_path):
         assert ln.split("\t")[-1] == "cg:Z:" + txt
 
 
-def test_call_blocks_over_host_threads(cli, tmp_path):
-    """the event rules / VCF text of the blocks are worked out by several host threads: same bytes, block order kept"""
-    blocks = _synth_maf_blocks(31, 23, 900)
+def test_call_maf_bad_base_ends_in_front_of_its_chunk(cli, tmp_path):
+    """a REF / ALT character outside ACGTN is noodles-vcf's parse error (caller.rs:480-501): the rows of the blocks and of the
+    block's chunks in front of the failing chunk are written (a chunk's records are collected before any is written,
+    :137-141), then the command fails with the character; the rules and the rows are made on the device (wga_maf_call_vcf)"""
+    blocks = _synth_maf_blocks(31, 5, 900)
+    b = blocks[3]
+    t, q = bytearray(b["t"]), bytearray(b["q"])
+    col = next(k for k in range(450, 900) if t[k] != 45 and q[k] != 45)
+    t[col], q[col] = ord("R"), ord("A")                      # an X column whose REF is no base: a SNP row's REF
+    b["t"], b["q"] = bytes(t), bytes(q)
     maf = tmp_path / "in.maf"
     _write_maf(maf, blocks)
-    want = _expected_vcf(blocks, "smp", True, True, 2, 500)
-    for thr in ("1", "3", "8", "64"):
-        os.environ["WGA_HOST_THREADS"] = thr
-        try:
-            rc, out, err = run(cli, "call", str(maf), "-s", "-i", "-l", "2", "-c", "500", "-n", "smp")
-        finally:
-            del os.environ["WGA_HOST_THREADS"]
-        assert rc == 0 and out.decode() == want, (thr, err)
+    rc, out, err = run(cli, "call", str(maf), "-s", "-i", "-l", "2", "-c", "300", "-n", "smp")
+    assert rc == 1 and "invalid reference/alternate base `R`" in err, err
+    # what the reference has written by then: every block in front, and this block's chunks in front of the failing one
+    good = _expected_vcf(blocks[:3], "smp", True, True, 2, 300)
+    assert out.decode().startswith(good)
+    rest = out.decode()[len(good):]
+    b_ok = dict(b)
+    t2 = bytearray(b["t"]); t2[col] = ord("C" if q[col] != ord("C") else "G")
+    b_ok["t"] = bytes(t2)
+    full = "".join(orc.call_var_maf_record(b_ok["t_name"], b_ok["q_name"], b_ok["t"], b_ok["q"], b_ok["t_start"], b_ok["q_start"],
+                                           b_ok["q_align"], b_ok["q_size"], b_ok["neg"], True, True, 2, 300))
+    assert full.startswith(rest) and len(rest) < len(full)
+    pos = [int(ln.split("\t")[1]) for ln in rest.splitlines()]
+    t_before = b["t_start"] + sum(1 for ch in b["t"][:col] if ch != 45)
+    assert all(p <= t_before + 1 for p in pos)              # nothing at or behind the bad column's chunk end is there
 
 
 def test_call_query_selection(cli, tmp_path):

@@ -694,6 +694,22 @@ def test_maf_long_blocks_piecewise(emu):
             emu.set_param("maf_piece_cols", piece_cols)
             pc.check_maf_pair(emu, pairs, strands)
             pc.check_maf_call_runs(emu, pairs)
+        # a fill call that does not find its count call's table (here: the piece size changed in between) lists and walks
+        # the long blocks itself
+        emu.set_param("maf_long_cols", 100)
+        scan = emu.exclusive_scan_u64
+
+        def scan_and_change(*a, **k):
+            emu.set_param("maf_piece_cols", 96)
+            return scan(*a, **k)
+        emu.exclusive_scan_u64 = scan_and_change
+        try:
+            emu.set_param("maf_piece_cols", 64)
+            pc.check_maf_pair(emu, pairs, strands)
+            emu.set_param("maf_piece_cols", 64)
+            pc.check_maf_call_runs(emu, pairs)
+        finally:
+            del emu.exclusive_scan_u64
     finally:
         emu.set_param("maf_long_cols", 32768)
         emu.set_param("maf_piece_cols", 16384)

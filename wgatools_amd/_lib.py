@@ -79,6 +79,8 @@ PROTOTYPES = {
     "wga_bgzf_bound": (C.c_uint64, [C.c_uint64]),
     "wga_bgzf_compress": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_uint64), C.c_int]),
     "wga_paf_call_vcf": (C.c_int, [vp, C.POINTER(CigarBatch), C.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "wga_maf_call_vcf": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                   vp, vp, vp, vp]),
     "wga_pafcov_accumulate": (C.c_int, [vp, C.POINTER(CigarBatch), vp, vp, vp, vp, vp, C.c_uint64]),
     "wga_pafcov_accumulate_final": (C.c_int, [vp, C.POINTER(CigarBatch), vp, vp, vp, vp, C.c_uint32, vp, C.c_uint64]),
     "wga_pafcov_format": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, C.c_uint32, vp, vp]),

@@ -18,6 +18,7 @@
 #ifdef WGA_STAGE2
 #include "wga_kernels2.h"
 #include "wga_kernels3.h"
+#include "wga_k19_maf_call.h"
 #endif
 
 struct wga_ctx {
@@ -36,6 +37,16 @@ struct wga_ctx {
   void* maf_tab = nullptr;         /* K3 / K4: the table of a call's long blocks (header, list, pieces), grow-only */
   size_t maf_tab_cap = 0;
   bool maf_hdr_clean = false;      /* the header's append counters are zero (the plan kernel leaves them so) */
+  struct MafKey { /* what the table was built from: a count call leaves it for the fill call on the same arrays (one shot) */
+    bool valid = false, caller = false;
+    uint32_t n = 0;
+    const void *rows = nullptr, *t_off = nullptr, *q_off = nullptr, *cols = nullptr;
+    uint64_t long_cols = 0, piece_cols = 0;
+    bool same(const MafKey& o) const {
+      return caller == o.caller && n == o.n && rows == o.rows && t_off == o.t_off && q_off == o.q_off && cols == o.cols &&
+             long_cols == o.long_cols && piece_cols == o.piece_cols;
+    }
+  } maf_key;
   int expand_variant = -1; /* the row kernel: -1 by the batch (records below WGA_AUTO_SHORT_OPS ops on average take the window
                               kernel of wga_kernels_k2w.h, longer ones v1), 0 v1 (wga_kernels.h), 2 the window kernel */
   int expand_variant_used = 0;
@@ -325,7 +336,7 @@ static int split_lines(wga_ctx* c, const uint8_t* d_text, uint64_t n_bytes, uint
 #ifdef WGA_EMU
 #define WGA_MAF_PIECE_GRID 3u /* the emulator makes 256 fibers per block, empty or not */
 #else
-#define WGA_MAF_PIECE_GRID 2048u
+#define WGA_MAF_PIECE_GRID 1024u /* 4 096 resident waves: a wave takes two pieces of a 10^8-column block and adds their counters up before it touches memory */
 #endif
 template <bool CALLER>
 static int maf_walk_call(wga_ctx* c, u32 n, const u8* d_rows, const u64* d_t_off, const u64* d_q_off, const u64* d_cols,
@@ -356,22 +367,36 @@ static int maf_walk_call(wga_ctx* c, u32 n, const u8* d_rows, const u64* d_t_off
   u32 G = c->maf_group ? c->maf_group : n / 24576u; /* eight blocks per wave where that still leaves every CU a few rounds of waves */
   G = G < 1u ? 1u : G > WGA_MAF_G ? WGA_MAF_G : G;
   const u32 grid = (u32)(((u64)n + 4ull * G - 1ull) / (4ull * G));
-  c->maf_hdr_clean = false; /* until the plan has cleared the appends */
+  /* the fill call of the two-call protocol finds the table its count call built (the long blocks, their pieces and the pieces'
+   * totals): it neither lists the long blocks again nor walks them a second time for their totals */
+  wga_ctx::MafKey key;
+  key.caller = CALLER, key.n = n, key.rows = d_rows, key.t_off = d_t_off, key.q_off = d_q_off, key.cols = d_cols;
+  key.long_cols = c->maf_long_cols, key.piece_cols = c->maf_piece_cols;
+  const bool hit = d_runs && c->maf_key.valid && c->maf_key.same(key);
+  c->maf_key.valid = false;
+  if (!hit) c->maf_hdr_clean = false; /* until the plan has cleared the appends */
   if (d_runs)
     WGA_LAUNCH((k_maf_stream<CALLER, true>), grid, WGA_BLOCK, c->stream, n, G, d_rows, d_t_off, d_q_off, d_cols, d_strand_neg, d_counts,
-               d_run_cnt, d_runs, d_run_off, (u64)c->maf_long_cols, hdr, long_list);
+               d_run_cnt, d_runs, d_run_off, (u64)c->maf_long_cols, hit ? (wga_maf_long_hdr*)nullptr : hdr, long_list);
   else
     WGA_LAUNCH((k_maf_stream<CALLER, false>), grid, WGA_BLOCK, c->stream, n, G, d_rows, d_t_off, d_q_off, d_cols, d_strand_neg, d_counts,
                d_run_cnt, d_runs, d_run_off, (u64)c->maf_long_cols, hdr, long_list);
   LAUNCH_CHECK();
-  WGA_LAUNCH(k_maf_long_plan, 1, 1024, c->stream, hdr, (const u32*)long_list, list_off, d_cols, (u64)c->maf_piece_cols);
-  LAUNCH_CHECK();
-  c->maf_hdr_clean = true;
-  /* the fill call must not add to what the count call left in the caller's arrays */
-  WGA_LAUNCH((k_maf_piece_walk<CALLER, 0>), WGA_MAF_PIECE_GRID, WGA_BLOCK, c->stream, d_rows, d_t_off, d_q_off, d_cols, d_strand_neg,
-             (const wga_maf_long_hdr*)hdr, (const u32*)long_list, (const u32*)list_off, ptot, (const wga_maf_piece_tot*)nullptr,
-             d_runs ? (wga_cigar_counts*)nullptr : d_counts, d_runs ? (u64*)nullptr : d_run_cnt, (u64*)nullptr, (const u64*)nullptr);
-  LAUNCH_CHECK();
+  if (!hit) {
+    WGA_LAUNCH(k_maf_long_plan, 1, 1024, c->stream, hdr, (const u32*)long_list, list_off, d_cols, (u64)c->maf_piece_cols);
+    LAUNCH_CHECK();
+    c->maf_hdr_clean = true;
+    /* the fill call must not add to what the count call left in the caller's arrays */
+    WGA_LAUNCH((k_maf_piece_walk<CALLER, 0>), WGA_MAF_PIECE_GRID, WGA_BLOCK, c->stream, d_rows, d_t_off, d_q_off, d_cols, d_strand_neg,
+               (const wga_maf_long_hdr*)hdr, (const u32*)long_list, (const u32*)list_off, ptot, (const wga_maf_piece_tot*)nullptr,
+               d_runs ? (wga_cigar_counts*)nullptr : d_counts, d_runs ? (u64*)nullptr : d_run_cnt, (u64*)nullptr, (const u64*)nullptr);
+    LAUNCH_CHECK();
+  }
+  if (!d_runs) {
+    c->maf_key = key;
+    c->maf_key.valid = true;
+    return WGA_OK;
+  }
   if (!d_runs) return WGA_OK;
   WGA_LAUNCH(k_maf_piece_scan, 1, 1024, c->stream, (const wga_maf_long_hdr*)hdr, (const wga_maf_piece_tot*)ptot, ex);
   LAUNCH_CHECK();
@@ -632,6 +657,8 @@ static void ctx_arrays_written(wga_ctx* c, const void* lo, size_t bytes) {
   for (const void* q : src)
     if (in(q)) es.valid = false;
   if (hits(es.elem_off, ((size_t)es.n + 1) * 8)) es.valid = false;
+  const wga_ctx::MafKey& mk = c->maf_key;
+  if (in(mk.rows) || hits(mk.t_off, (size_t)mk.n * 8) || hits(mk.q_off, (size_t)mk.n * 8) || hits(mk.cols, (size_t)mk.n * 8)) c->maf_key.valid = false;
   if (hits(c->class_tab.ops, (size_t)c->class_tab.n_ops * 4) || hits(c->class_tab.op_off, ((size_t)c->class_tab.n + 1) * 8)) c->class_tab.valid = false;
 }
 
@@ -1525,6 +1552,34 @@ int wga_paf_call_vcf(wga_ctx* c, const wga_cigar_batch* b, uint64_t svlen, const
     WGA_LAUNCH(k_paf_call_vcf<true>, (b->n + 3u) / 4u, WGA_BLOCK, c->stream, b->n, b->d_ops, (const u64*)b->d_op_off,
                b->d_strand_neg, (u64)svlen, (const u64*)d_ev, (const u64*)d_ev_off, (const wga_vcf_rec_dev*)d_recs, d_names,
                d_t_pool, d_q_pool, (u64*)nullptr, (wga_vcf_err_dev*)nullptr, d_out, (const u64*)d_out_off);
+  }
+  LAUNCH_CHECK();
+  return WGA_OK;
+}
+
+int wga_maf_call_vcf(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint64_t* d_t_off, const uint64_t* d_q_off,
+                     const uint64_t* d_cols, const uint64_t* d_runs, const uint64_t* d_run_off, const wga_maf_vcf_rec* d_recs,
+                     const uint8_t* d_names, int snp, int inv, uint64_t svlen, uint64_t chunk_size, uint64_t* d_nbytes,
+                     wga_vcf_err* d_err, uint8_t* d_out, const uint64_t* d_out_off) {
+  int rc = ctx_bind(c);
+  if (rc) return rc;
+  if (n == 0) return WGA_OK;
+  static_assert(sizeof(wga_maf_vcf_rec) == sizeof(wga_maf_vcf_rec_dev) && sizeof(wga_maf_vcf_rec) == 56, "wga_maf_vcf_rec layout");
+  if (!d_rows || !d_t_off || !d_q_off || !d_cols || !d_runs || !d_run_off || !d_recs || !d_names)
+    return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+  if (chunk_size == 0) return fail(WGA_E_INVALID_ARG, "chunk_size must be positive", nullptr);
+  if (!d_out) {
+    if (!d_nbytes || !d_err) return fail(WGA_E_INVALID_ARG, "null array", nullptr);
+    WGA_LAUNCH(k_maf_call_vcf<false>, (n + 3u) / 4u, WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off, (const u64*)d_q_off,
+               (const u64*)d_cols, (const u64*)d_runs, (const u64*)d_run_off, (const wga_maf_vcf_rec_dev*)d_recs, d_names,
+               (u32)(snp != 0), (u32)(inv != 0), (u64)svlen, (u64)chunk_size, (u64*)d_nbytes, (wga_vcf_err_dev*)d_err, (u8*)nullptr,
+               (const u64*)nullptr);
+  } else {
+    if (!d_out_off) return fail(WGA_E_INVALID_ARG, "d_out_off null", nullptr);
+    WGA_LAUNCH(k_maf_call_vcf<true>, (n + 3u) / 4u, WGA_BLOCK, c->stream, n, d_rows, (const u64*)d_t_off, (const u64*)d_q_off,
+               (const u64*)d_cols, (const u64*)d_runs, (const u64*)d_run_off, (const wga_maf_vcf_rec_dev*)d_recs, d_names,
+               (u32)(snp != 0), (u32)(inv != 0), (u64)svlen, (u64)chunk_size, (u64*)nullptr, (wga_vcf_err_dev*)nullptr, d_out,
+               (const u64*)d_out_off);
   }
   LAUNCH_CHECK();
   return WGA_OK;

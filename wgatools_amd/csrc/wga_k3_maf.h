@@ -374,9 +374,11 @@ __global__ __launch_bounds__(256, WGA_MAF_BLOCKS) void k_maf_stream(u32 n, u32 G
     if (!CALLER && strand_neg[i] != 0) fl |= MAF_SEG_NEG;
     if (ck > long_cols || ck > (u64)WGA_MAF_SHORT_MAX) {
       fl |= MAF_SEG_LONG;
-      const u32 slot = atomicAdd(&hdr->live_n, 1u);
-      long_list[slot] = (u32)i;
-      atomicAdd((unsigned long long*)&hdr->live_cols, (unsigned long long)ck);
+      if (hdr) { /* null: the table of the count call on these arrays is still there */
+        const u32 slot = atomicAdd(&hdr->live_n, 1u);
+        long_list[slot] = (u32)i;
+        atomicAdd((unsigned long long*)&hdr->live_cols, (unsigned long long)ck);
+      }
     } else if (ck < 32u) {
       if (ck) fl |= MAF_SEG_TINY;
     } else {
@@ -431,24 +433,25 @@ __global__ __launch_bounds__(256, WGA_MAF_BLOCKS) void k_maf_stream(u32 n, u32 G
 /* ---- long blocks ---------------------------------------------------------------------------------------------------------
  * The plan: one block of 1 024 threads; thread x owns a strip of the list.  Pieces per long block at the piece size the
  * total asks for, their exclusive scan, the counts the walks read; the live counters are cleared for the next call. */
-__device__ __forceinline__ u64 block_scan_1024(u64 v, u64* s /*[1024]*/, u64* total) {
-  const u32 x = threadIdx.x;
-  s[x] = v;
+/* exclusive scan of one value per thread over a block of 1 024 threads: a wave scan, the sixteen wave totals through LDS */
+__device__ __forceinline__ u64 block_scan_1024(u64 v, u64* s /*[16]*/, u64* total) {
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const u64 inc = wave_incl_scan_u64(v, lane);
+  __syncthreads(); /* s may still be read from the scan in front */
+  if (lane == 63u) s[wave] = inc;
   __syncthreads();
-  for (u32 d = 1; d < 1024u; d <<= 1) {
-    const u64 a = x >= d ? s[x - d] : 0ull;
-    __syncthreads();
-    s[x] += a;
-    __syncthreads();
+  u64 before = 0, all = 0;
+  for (u32 w = 0; w < 16u; w++) {
+    const u64 x = s[w];
+    if (w < wave) before += x;
+    all += x;
   }
-  *total = s[1023];
-  const u64 ex = s[x] - v;
-  __syncthreads();
-  return ex;
+  *total = all;
+  return before + inc - v;
 }
 __global__ __launch_bounds__(1024) void k_maf_long_plan(wga_maf_long_hdr* hdr, const u32* __restrict__ long_list,
                                                         u32* list_off, const u64* __restrict__ cols, u64 cfg_piece_cols) {
-  __shared__ u64 s[1024];
+  __shared__ u64 s[16];
   const u32 x = threadIdx.x;
   const u32 nl = hdr->live_n;
   const u64 lc = hdr->live_cols;
@@ -478,16 +481,34 @@ __global__ __launch_bounds__(1024) void k_maf_long_plan(wga_maf_long_hdr* hdr, c
 /* exclusive scan of the pieces' totals (np + 1 entries), one block */
 __global__ __launch_bounds__(1024) void k_maf_piece_scan(const wga_maf_long_hdr* hdr, const wga_maf_piece_tot* __restrict__ ptot,
                                                          wga_maf_piece_tot* ex) {
-  __shared__ u64 s[1024];
+  __shared__ u64 s[16];
   const u32 x = threadIdx.x;
   const u32 np = hdr->np;
   if (np == 0u) return;
   const u32 per = (np + 1023u) / 1024u, p0 = x * per, p1 = p0 + per < np ? p0 + per : np;
-  wga_maf_piece_tot mine;
+  wga_maf_piece_tot mine, at;
   mine.runs = mine.t_nongap = mine.q_nongap = 0;
-  for (u32 p = p0; p < p1; p++) mine.runs += ptot[p].runs, mine.t_nongap += ptot[p].t_nongap, mine.q_nongap += ptot[p].q_nongap;
   u64 total;
-  wga_maf_piece_tot at;
+  if (per <= 8u) { /* block-uniform: the strip in registers, its loads all in flight together (8 192 pieces: one 10^8-column block has 6 104) */
+    wga_maf_piece_tot v[8];
+#pragma unroll
+    for (u32 k = 0; k < 8u; k++) {
+      v[k].runs = v[k].t_nongap = v[k].q_nongap = 0;
+      if (p0 + k < p1) v[k] = ptot[p0 + k];
+    }
+#pragma unroll
+    for (u32 k = 0; k < 8u; k++) mine.runs += v[k].runs, mine.t_nongap += v[k].t_nongap, mine.q_nongap += v[k].q_nongap;
+    at.runs = block_scan_1024(mine.runs, s, &total);
+    at.t_nongap = block_scan_1024(mine.t_nongap, s, &total);
+    at.q_nongap = block_scan_1024(mine.q_nongap, s, &total);
+#pragma unroll
+    for (u32 k = 0; k < 8u; k++) {
+      if (p0 + k < p1) ex[p0 + k] = at;
+      at.runs += v[k].runs, at.t_nongap += v[k].t_nongap, at.q_nongap += v[k].q_nongap;
+    }
+    return;
+  }
+  for (u32 p = p0; p < p1; p++) mine.runs += ptot[p].runs, mine.t_nongap += ptot[p].t_nongap, mine.q_nongap += ptot[p].q_nongap;
   at.runs = block_scan_1024(mine.runs, s, &total);
   at.t_nongap = block_scan_1024(mine.t_nongap, s, &total);
   at.q_nongap = block_scan_1024(mine.q_nongap, s, &total);
@@ -497,6 +518,13 @@ __global__ __launch_bounds__(1024) void k_maf_piece_scan(const wga_maf_long_hdr*
   }
 }
 
+__device__ __forceinline__ void maf_piece_flush(wga_cigar_counts* counts, u64* run_cnt, u32 rec, u32 lane, u64 v) {
+  if (lane < 11u) {
+    if (counts) atomicAdd((unsigned long long*)((u64*)(counts + rec) + lane), (unsigned long long)v);
+  } else if (run_cnt) {
+    atomicAdd((unsigned long long*)(run_cnt + rec), (unsigned long long)v);
+  }
+}
 /* MODE 0: count (piece totals; K3 also adds the piece's counters to its block; run_cnt[i] += runs).
  * MODE 1: fill (runs written at the piece's slot; ex = exclusive scan of the piece totals). */
 template <bool CALLER, int MODE>
@@ -512,7 +540,11 @@ __global__ __launch_bounds__(256, WGA_MAF_BLOCKS) void k_maf_piece_walk(const u8
   __shared__ MafSeg s_seg[4];
   __shared__ MafTot s_tot[4];
   __shared__ u64 s_big[4][6];
+  __shared__ u64 s_acc[4][12]; /* MODE 0: fields 0 .. 10 of the block the wave is on, its run count */
+  __shared__ u32 s_rec[4];
   const u32 lane = threadIdx.x & 63u, wave = WGA_WAVE_ID(threadIdx.x);
+  u64* const acc = s_acc[wave];
+  u32 acc_rec = 0xFFFFFFFFu; /* wave-uniform */
   const u32 np = hdr->np, nl = hdr->n_long;
   const u64 piece_cols = hdr->piece_cols;
   const u32 n_waves = gridDim.x * 4u;
@@ -570,14 +602,43 @@ __global__ __launch_bounds__(256, WGA_MAF_BLOCKS) void k_maf_piece_walk(const u8
         wga_maf_piece_tot pt;
         pt.runs = nruns, pt.t_nongap = (u64)ng_t, pt.q_nongap = (u64)ng_q;
         ptot[p] = pt;
-        if (run_cnt) atomicAdd((unsigned long long*)(run_cnt + i), (unsigned long long)nruns);
       }
-      if (!CALLER && counts && lane < 11u) {
-        const u64 A = tot->A, B = tot->B;
-        const u64 v = maf_count_field(lane, (u64)L, big[0] + (A & 0xFFFFull), big[1] + ((A >> 16) & 0xFFFFull),
-                                      big[2] + ((A >> 32) & 0xFFFFull), big[3] + (B & 0xFFFFull), big[4] + ((B >> 16) & 0xFFFFull),
-                                      big[5] + ((B >> 32) & 0xFFFFull), strand_neg[i] != 0, p == pfirst ? 1ull : 0ull);
-        if (v) atomicAdd((unsigned long long*)((u64*)(counts + i) + lane), (unsigned long long)v);
+      /* the block's counters and run count: kept per wave across its pieces (LDS), added to memory when the wave moves on to
+       * another block and once per workgroup at the end — a global atomic per piece on ONE address costs 8 ns each and they
+       * all come at the same time (6 104 pieces of one 10^8-column block: 50 us behind a 40 us walk) */
+      if (counts || run_cnt) { /* wave-uniform */
+        if (acc_rec != i) {
+          if (acc_rec != 0xFFFFFFFFu && lane < 12u && acc[lane]) maf_piece_flush(counts, run_cnt, acc_rec, lane, acc[lane]);
+          WGA_WAVE_SYNC();
+          if (lane < 12u) acc[lane] = 0ull;
+          acc_rec = i;
+        }
+        if (lane < 12u) {
+          u64 v = nruns;
+          if (lane < 11u) {
+            const u64 A = tot->A, B = tot->B;
+            v = CALLER ? 0ull
+                       : maf_count_field(lane, (u64)L, big[0] + (A & 0xFFFFull), big[1] + ((A >> 16) & 0xFFFFull),
+                                         big[2] + ((A >> 32) & 0xFFFFull), big[3] + (B & 0xFFFFull), big[4] + ((B >> 16) & 0xFFFFull),
+                                         big[5] + ((B >> 32) & 0xFFFFull), strand_neg[i] != 0, p == pfirst ? 1ull : 0ull);
+          }
+          acc[lane] += v;
+        }
+      }
+    }
+  }
+  if (MODE == 0 && (counts || run_cnt)) { /* the waves of a workgroup that ended on the same block add up first: the lowest of them speaks */
+    if (lane == 0u) s_rec[wave] = acc_rec;
+    __syncthreads();
+    if (acc_rec != 0xFFFFFFFFu && lane < 12u) {
+      bool leader = true;
+      for (u32 w = 0; w < wave; w++)
+        if (s_rec[w] == acc_rec) leader = false;
+      if (leader) {
+        u64 v = acc[lane];
+        for (u32 w = wave + 1u; w < 4u; w++)
+          if (s_rec[w] == acc_rec) v += s_acc[w][lane];
+        if (v) maf_piece_flush(counts, run_cnt, acc_rec, lane, v);
       }
     }
   }

@@ -19,14 +19,6 @@
  * A length >= 2^28 is packed as a head op plus continuation pieces (codes 9 / 10): the head is
  * flagged when `len > svlen` or a continuation follows; the host applies the cutoff to the sum.
  * Event entry = 3 u64: op index in the record, target advance before it, query advance before it. */
-__device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, u32 lane) {
-#pragma unroll
-  for (u32 d = 1; d < 64; d <<= 1) {
-    const u64 o = __shfl_up(v, d);
-    if (lane >= d) v += o;
-  }
-  return v;
-}
 
 /* The walk of ops [a, b) of one record by one wave, 4 consecutive ops per lane and 256 per step (a is a multiple of 256): running
  * target / query positions and event count start from `st`, the op in front of a gives `after_m`, the op behind a step

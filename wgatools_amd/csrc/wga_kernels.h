@@ -101,6 +101,15 @@ __device__ __forceinline__ u64 wave_sum_u32_wide(u32 v) {
   return ((u64)hi << 16) + (u64)lo;
 }
 __device__ __forceinline__ u32 wave_sum_u32(u32 v) { return wave_last_u32(wave_incl_scan_u32(v)); }
+/* inclusive scan of a u64 over the 64 lanes */
+__device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, u32 lane) {
+#pragma unroll
+  for (u32 d = 1; d < 64; d <<= 1) {
+    const u64 o = __shfl_up(v, d);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
 __device__ __forceinline__ u32 wave_min_u32(u32 v) {
   for (int m = 32; m >= 1; m >>= 1) {
     u32 o = __shfl_xor(v, m);
