@@ -63,12 +63,20 @@ def test_product_does_not_touch_the_oracle():
     knows how to compile it for the tests), and neither product binary depends on it"""
     import subprocess
     pkg = os.path.join(ROOT, "wgatools_amd")
-    for dirpath, _, files in os.walk(pkg):
-        for f in files:
-            if not f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")) or f == "build.py":
-                continue
-            txt = open(os.path.join(dirpath, f), errors="replace").read()
-            assert not re.search(r"oracle_py|liboracle|\borc_", txt), os.path.join(dirpath, f)
+    seen = 0
+    for where in (pkg, os.path.join(ROOT, "include")):
+        for dirpath, dirs, files in os.walk(where):
+            dirs[:] = [d for d in dirs if d != "__pycache__"]
+            for f in files:
+                path = os.path.join(dirpath, f)
+                if f == "build.py" or f.endswith((".so", ".o", ".a", ".pyc", ".hsaco", ".co")) or os.path.dirname(path).endswith("bin"):
+                    continue                      # built artefacts are checked through their dynamic sections below
+                raw = open(path, "rb").read()
+                if b"\0" in raw[:4096]:
+                    continue                      # some other binary
+                seen += 1
+                assert not re.search(r"oracle_py|liboracle|\borc_|oracle/", raw.decode(errors="replace")), path
+    assert seen > 40                              # every source of the package, whatever its extension (.inc, .hip, ...)
     for binary in (build.build_hip(), build.build_cli()):
         needed = subprocess.run(["readelf", "-d", binary], stdout=subprocess.PIPE).stdout.decode()
         assert "oracle" not in needed, binary
