@@ -112,7 +112,7 @@ def kernel_source_sha():
     """the row kernel's source: roofline.traffic is only valid for the kernel it was measured on"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("wga_kernels.h", "wga_kernels_k2w.h", "wga_kernels_k2s.h", "wga_intrin.h"):
+    for f in ("wga_kernels.h", "wga_kernels_k2s.h", "wga_intrin.h"):
         h.update(open(os.path.join(ROOT, "wgatools_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -300,7 +300,7 @@ def north_star(args):
         "config": {"workload": "north-star shape: %d records x mean 50 kop streamed as %d on-device-generated resident batches of %d "
                                "records (2 x %d Mb pools); the full headline is 10 000 000 records" % (nb * per, nb, per, args.pool_mb),
                    "records": nb * per, "ops": tot_ops, "columns": tot_cols},
-        "roofline": {"kernel": {0: "k_paf2maf_expand", 2: "k_paf2maf_expand_w", 3: "k_paf2maf_expand_s"}.get(eng.get_param("expand_variant_used")),
+        "roofline": {"kernel": {0: "k_paf2maf_expand", 3: "k_paf2maf_expand_s"}.get(eng.get_param("expand_variant_used")),
                      "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": tot_bytes},
         "output_placement": "first allocation",
@@ -543,7 +543,7 @@ def main():
         ms_sum, n_timed = eng.expand_timing()
         k_expand = ms_sum / n_timed if n_timed else k_expand_call
         variant_used = eng.get_param("expand_variant_used")
-        kernel_name = {0: "k_paf2maf_expand", 2: "k_paf2maf_expand_w", 3: "k_paf2maf_expand_s"}.get(variant_used, "k_paf2maf_expand")
+        kernel_name = {0: "k_paf2maf_expand", 3: "k_paf2maf_expand_s"}.get(variant_used, "k_paf2maf_expand")
         ab = job.algorithmic_bytes()
         in_bytes = 4 * job.n_ops + int(tb["t_src_len"].sum()) + int(tb["q_src_len"].sum())
         ach = ab["expand"] / (k_expand * 1e-3) / 1e9

@@ -126,9 +126,9 @@ int wga_ctx_set_stream(wga_ctx*, void* hip_stream);
 int wga_ctx_reset_stream(wga_ctx*);
 /* Tunables (test knobs): "expand_force_slow" (0/1) forces the u64 op-serial fallback of the
  * expand kernel; "expand_no_table" (0/1) forces its binary-search event lookup; "expand_variant" picks the row
- * kernel — same bytes either way: -1 (default) by the batch (the window kernel, which assembles 4 KB output windows in
- * LDS and stores whole lines, for batches below 100 ops per record; the streaming kernel, one wave per row kind of a run of
- * tiles, for the others: profiles/r04_k2s_experiments.md), 0: v1 (one block per tile), 2: the window kernel, 3: the streaming
+ * kernel — same bytes either way: -1 (default) or 3: the streaming kernel, one wave per row kind of a run of tiles
+ * (profiles/r04_k2s_experiments.md), 0: v1 (one block per tile; also the kernel of the tiles the streaming kernel leaves).  The
+ * window kernel of rounds 3-5 (2) was retired in round 6: it was ahead only for batches below 100 ops per record
  * kernel (environment: WGA_EXPAND_VARIANT); "expand_job_tiles" (1 .. 32; 0, the default: 8, or 4 for batches below 200 000 tiles): consecutive tiles one wave of the
  * streaming kernel walks;
  * "pseudo_variant": wga_pafpseudo_fill's rows through the streaming kernel (3, default) or one block per tile (0);

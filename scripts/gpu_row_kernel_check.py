@@ -1,4 +1,4 @@
-"""A row kernel (expand_variant 2 = the window kernel, 3 = the streaming kernel; argv[1], default 2) on the GPU: the oracle
+"""A row kernel (expand_variant 3 = the streaming kernel; argv[1]) on the GPU: the oracle
 battery, and the whole output of BASELINE configs[1] / 50-kop / 500-op batches byte for byte against v1 (expand_variant 0)
 on the device.  Further arguments: context parameters name=value (e.g. expand_job_tiles=8)."""
 import os, sys, time

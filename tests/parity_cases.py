@@ -56,12 +56,12 @@ def check_stat(eng, b, sample=None):
 # ------------------------------------------------------------------------------------------------
 # K2
 # ------------------------------------------------------------------------------------------------
-DEFAULT_EXPAND_VARIANT = {"0": 0, "2": 2, "3": 3}.get(os.environ.get("WGA_EXPAND_VARIANT", ""), -1)   # -1: the library picks by the batch
+DEFAULT_EXPAND_VARIANT = {"0": 0, "3": 3}.get(os.environ.get("WGA_EXPAND_VARIANT", ""), -1)   # -1: the library picks by the batch
 
 
 def run_paf2maf(eng, b, pre=None, force_slow=0, fill=0x23, no_table=0, variant=None):
-    """stat -> layout -> expand; returns host copies.  variant: 0 = v1 of the row kernel, 2 = the window kernel
-    (wga_kernels_k2w.h); None = whatever the context runs by default (it picks by the batch)"""
+    """stat -> layout -> expand; returns host copies.  variant: 0 = v1 of the row kernel, 3 = the streaming kernel; None =
+    whatever the context runs by default"""
     n = len(b["strand_neg"])
     batch = eng.make_batch(b["ops"], b["op_off"], b["strand_neg"])
     eng.set_param("expand_force_slow", force_slow)
@@ -331,8 +331,8 @@ def wide_tile_batch(eng, seed=3):
     return batch_from_texts(eng, cigars, strands, t_seqs, q_seqs)
 
 
-def window_kernel_cases(eng, variant=2):
-    """the window row kernel (expand_variant 2) against the oracle: random mixtures, edge cases with odd row alignments,
+def window_kernel_cases(eng, variant=3):
+    """a row kernel (expand_variant 3 = the streaming kernel, 0 = v1) against the oracle: random mixtures, edge cases with odd row alignments,
     records over many tiles, many records per tile (more than 16 and more than 64 record segments in a tile), wide tiles,
     the op-serial walk behind it"""
     from wgatools_amd import synth

@@ -107,28 +107,29 @@ def test_paf2maf_long_record_many_tiles(emu):
     pc.check_paf2maf(emu, nb)
 
 
-def test_paf2maf_window_kernel(emu):
-    pc.window_kernel_cases(emu)
+def test_paf2maf_v1_kernel(emu):
+    """the battery of the row kernels on v1 (expand_variant 0: the kernel of the tiles the streaming kernel leaves)"""
+    pc.window_kernel_cases(emu, variant=0)
 
 
-def test_paf2maf_window_kernel_dense_indels(emu):
+def test_paf2maf_row_kernels_dense_indels(emu):
     b = pc.dense_indel_batch(emu)
-    pc.check_paf2maf(emu, b, variant=2)
+    pc.check_paf2maf(emu, b, variant=3)
     pc.check_paf2maf(emu, b, variant=0)
 
 
-def test_paf2maf_window_kernel_errors_and_long_record(emu):
+def test_paf2maf_row_kernels_errors_and_long_record(emu):
     cigars = ["10=", "10=", "6M1I", "3=1D", "4=2N4="]
     strands = [1, 1, 0, 0, 0]
     t = [b"ACGTACGTAC", b"ACGTACGTAC", b"ACGT", b"ACGT", b"ACGTACGT"]
     q = [b"ACGTRCGYAC", b"ACGTACGTAC", b"ACGTACG", b"AC", b"ACGTACGT"]
-    r = pc.check_paf2maf(emu, pc.batch_from_texts(emu, cigars, strands, t, q), variant=2)
+    r = pc.check_paf2maf(emu, pc.batch_from_texts(emu, cigars, strands, t, q), variant=3)
     d = r["diag"]
     assert int(d["bad_base_pos"][0]) == 2 and int(d["bad_base_pos"][1]) == int(engine.NONE)
     assert int(d["panic_op_idx"][2]) == 1 and int(d["panic_op_idx"][3]) == 1
     assert int(d["bad_op_idx"][4]) == 1
     big = synth.make_paf_batch(12, 1, 40_000, 400_000, sigma=0.01)  # one record over ~40 tiles
-    pc.check_paf2maf(emu, big, variant=2)
+    pc.check_paf2maf(emu, big, variant=3)
     # an invalid base in the middle of a long '-' strand record whose slice overlaps another record's
     bad = synth.make_paf_batch(13, 2, 3000, 100_000)
     bad["strand_neg"][:] = 1
@@ -136,7 +137,7 @@ def test_paf2maf_window_kernel_errors_and_long_record(emu):
     k = int(bad["q_src_off"][1] + bad["q_src_len"][1] // 2)
     qp[k] = ord("R")
     bad["q_pool"] = qp
-    pc.check_paf2maf(emu, bad, variant=2)
+    pc.check_paf2maf(emu, bad, variant=3)
 
 
 def test_paf2maf_stream_kernel(emu):
@@ -147,16 +148,15 @@ def test_paf2maf_stream_kernel_jobs_and_skips(emu):
     pc.stream_kernel_cases(emu)
 
 
-def test_expand_variant_by_the_batch(emu):
-    """expand_variant -1 (the default): records of a few dozen ops take the window kernel, everything else the streaming
-    kernel; the bytes are the oracle's"""
+def test_expand_variant_default(emu):
+    """expand_variant -1 (the default) is the streaming kernel whatever the batch (the window kernel that took records of a few
+    dozen ops was retired in round 6); 2 is refused; the bytes are the oracle's"""
     emu.set_param("expand_variant", -1)
-    pc.check_paf2maf(emu, synth.make_paf_batch(41, 60, 40, 30000))
-    assert emu.get_param("expand_variant_used") == 2
-    pc.check_paf2maf(emu, synth.make_paf_batch(41, 30, 200, 30000))
-    assert emu.get_param("expand_variant_used") == 3
-    pc.check_paf2maf(emu, synth.make_paf_batch(42, 3, 3000, 90000))
-    assert emu.get_param("expand_variant_used") == 3
+    for b in (synth.make_paf_batch(41, 60, 40, 30000), synth.make_paf_batch(41, 30, 200, 30000), synth.make_paf_batch(42, 3, 3000, 90000)):
+        pc.check_paf2maf(emu, b)
+        assert emu.get_param("expand_variant_used") == 3
+    with pytest.raises(Exception):
+        emu.set_param("expand_variant", 2)
     emu.set_param("expand_variant", pc.DEFAULT_EXPAND_VARIANT)
 
 

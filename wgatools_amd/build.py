@@ -17,7 +17,6 @@ HIP_LIB = os.path.join(ROOT, "wgatools_amd", "libwgahip.so")
 EMU_LIB = os.path.join(ROOT, "tests", "emu", "libwgaemu.so")
 CLI_EMU_BIN = os.path.join(ROOT, "tests", "emu", "wgatools_emu")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "liboracle.so")
-STAGE2 = ["-DWGA_STAGE2"] if os.path.exists(os.path.join(CSRC, "wga_kernels2.h")) else []
 
 
 def _newer(target, sources):
@@ -87,7 +86,7 @@ def build_hip(force=False, verbose=False):
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libwgahip.so cannot be built here")
     objs = []
-    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall"] + STAGE2
+    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall"]
     flags += os.environ.get("WGA_EXTRA_FLAGS", "").split()  # A/B builds (see build_hip_variant)
     for src, xflag in (("wga_capi.cpp", ["-x", "hip"]), ("wga_pack.cpp", [])):
         obj = os.path.join(CSRC, src.replace(".cpp", ".o"))
@@ -107,7 +106,7 @@ def build_hip_variant(name, extra_flags):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     vdir = os.path.join(ROOT, "build_variants")
     os.makedirs(vdir, exist_ok=True)
-    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall"] + STAGE2 + list(extra_flags)
+    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall"] + list(extra_flags)
     objs = []
     for src, xflag in (("wga_capi.cpp", ["-x", "hip"]), ("wga_pack.cpp", [])):
         obj = os.path.join(vdir, "%s_%s" % (name, src.replace(".cpp", ".o")))
@@ -127,7 +126,7 @@ def build_emu(force=False):
         return EMU_LIB
     # -DWGA_MAF_FOLD_STEPS: fold the MAF walks' 16-bit lane counters every 3 steps, so that small test rows reach that path
     _run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DWGA_EMU", "-DWGA_MAF_FOLD_STEPS=3u", "-Wall",
-          "-Wno-unknown-pragmas", "-I" + os.path.join(ROOT, "tests", "emu")] + STAGE2
+          "-Wno-unknown-pragmas", "-I" + os.path.join(ROOT, "tests", "emu")]
          + [os.path.join(CSRC, "wga_capi.cpp"), os.path.join(CSRC, "wga_pack.cpp"), "-o", EMU_LIB])
     return EMU_LIB
 

@@ -12,14 +12,27 @@
 #include <utility>
 #include <vector>
 
-#include "wga_kernels.h"
-#include "wga_kernels_k2w.h"
-#include "wga_kernels_k2s.h"
-#ifdef WGA_STAGE2
-#include "wga_kernels2.h"
-#include "wga_kernels3.h"
-#include "wga_k19_maf_call.h"
-#endif
+/* the kernels, one header per family (each names the reference code it replaces), in dependency order: a header may use helpers
+ * of the ones in front of it */
+#include <type_traits>
+
+#include "wga_kernels.h"       /* K1 stat, v1 of the row kernel, scans, layout */
+#include "wga_kernels_k2s.h"   /* K2s: the streaming row kernel (paf2maf, pafpseudo's rows) */
+#include "wga_k_class.h"
+#include "wga_k5_pafcov.h"
+#include "wga_k6_pafpseudo.h"
+#include "wga_k3_maf.h"        /* K3 / K4: the MAF walks */
+#include "wga_k7_paf_call.h"
+#include "wga_k8_tokenise.h"
+#include "wga_k9_bed.h"
+#include "wga_k10_chain.h"
+#include "wga_k11_bridges.h"
+#include "wga_k12_dotplot.h"
+#include "wga_k13_splitters.h"
+#include "wga_k15_fasta.h"
+#include "wga_k18_bgzf_deflate.h"
+#include "wga_kernels3.h"      /* K16 VCF rows of call on PAF, K17 BGZF inflate */
+#include "wga_k19_maf_call.h"  /* K19: rules and VCF rows of call on MAF */
 
 struct wga_ctx {
   int device = 0;
@@ -47,8 +60,9 @@ struct wga_ctx {
              long_cols == o.long_cols && piece_cols == o.piece_cols;
     }
   } maf_key;
-  int expand_variant = -1; /* the row kernel: -1 by the batch (records below WGA_AUTO_SHORT_OPS ops on average take the window
-                              kernel of wga_kernels_k2w.h, longer ones v1), 0 v1 (wga_kernels.h), 2 the window kernel */
+  int expand_variant = -1; /* the row kernel: -1 / 3 the streaming kernel (wga_kernels_k2s.h), 0 v1 (wga_kernels.h: what the
+                              streaming kernel leaves is v1's in either case).  The window kernel of rounds 3-5 (2) is gone: it was
+                              ahead only below 100 ops per record (30-op records 6.1 against 7.3 ms) */
   int expand_variant_used = 0;
   int expand_job_tiles = 0; /* streaming kernel: tiles per wave ("expand_job_tiles"); 0 = by the batch (job_tiles_for) */
   int pseudo_variant = 3;   /* pafpseudo's rows: 3 the streaming row kernel, 0 one block per tile ("pseudo_variant") */
@@ -488,7 +502,7 @@ int wga_ctx_create(int device, wga_ctx** out) {
   }
   c->stream = c->own_stream;
   /* A/B switch for measurements: WGA_EXPAND_VARIANT=0 selects v1 of the paf2maf row kernel (wga_ctx_set_param overrides) */
-  if (const char* v = getenv("WGA_EXPAND_VARIANT")) c->expand_variant = (atoi(v) == 0 || atoi(v) == 2 || atoi(v) == 3) ? atoi(v) : -1;
+  if (const char* v = getenv("WGA_EXPAND_VARIANT")) c->expand_variant = (atoi(v) == 0 || atoi(v) == 3) ? atoi(v) : -1;
   if (const char* v = getenv("WGA_EXPAND_DRAIN_MIN")) {
     const int d = atoi(v);
     if (d >= 0 && d <= 64) c->expand_drain_min = (unsigned)d;
@@ -591,7 +605,7 @@ int wga_ctx_set_param(wga_ctx* c, const char* name, int64_t value) {
     return WGA_OK;
   }
   if (strcmp(name, "expand_variant") == 0) {
-    if (value != -1 && value != 0 && value != 2 && value != 3) return fail(WGA_E_INVALID_ARG, "expand_variant: -1 (by the batch), 0, 2, 3", nullptr);
+    if (value != -1 && value != 0 && value != 3) return fail(WGA_E_INVALID_ARG, "expand_variant: -1 (the library's choice), 0, 3", nullptr);
     c->expand_variant = (int)value;
     return WGA_OK;
   }
@@ -926,11 +940,9 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
   size_t rec_bytes = ((size_t)b->n * sizeof(wga_rec_desc) + 255) & ~(size_t)255;
   const size_t desc_bytes = (size_t)nt * sizeof(wga_tile_desc);
   const size_t list_bytes = 256 + 2 * (size_t)nt * sizeof(u32); /* two counters + the lists of wide / huge tiles */
-  /* which row kernel: the window kernel wins on short records (many row pieces per tile: -12 .. -19 % at 500 ops per record),
-   * v1 on long ones (+7 % at 5 kop, profiles/r03_k2w_experiments.md) */
-  const int variant = c->expand_variant >= 0 ? c->expand_variant : (b->n_ops / (u64)b->n < WGA_AUTO_SHORT_OPS ? 2 : WGA_AUTO_LONG_VARIANT);
+  const int variant = c->expand_variant >= 0 ? c->expand_variant : WGA_AUTO_LONG_VARIANT;
   c->expand_variant_used = variant;
-  const size_t plan_bytes = variant == 2 ? (size_t)nt * WGA_W_PLAN_WORDS * sizeof(u32) : 0;
+  const size_t plan_bytes = 0;
   const size_t flag_bytes = variant == 3 ? (((size_t)nt + 255) & ~(size_t)255) : 0; /* streaming kernel: one byte per tile */
   if ((rc = ctx_scratch(c, rec_bytes + desc_bytes + list_bytes + plan_bytes + flag_bytes, &ws))) return rc;
   wga_rec_desc* recs = (wga_rec_desc*)ws;
@@ -963,23 +975,12 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
   a.tile_count = nullptr;
   a.tile_list = nullptr;
   a.n_rec = b->n;
-  a.plan = (const u32*)((char*)ws + rec_bytes + desc_bytes + list_bytes);
   a.job_tiles = job_tiles_for(c->expand_job_tiles, nt);
-  const bool windows = variant == 2;
   const bool stream = variant == 3;
   /* when the gap-touching chunks are emitted (RowSrc::drain_min) */
   /* when v1's waves emit their queued gap-touching chunks (RowSrc::drain_min) */
   a.drain_min = c->expand_drain_min ? c->expand_drain_min : ((u64)t_fa_bytes + (u64)q_fa_bytes > WGA_DRAIN_POOL_BYTES ? 16u : 32u);
   c->expand_drain_min_used = a.drain_min;
-  if (windows) { /* part of the pre-pass: the tiles for the op-serial walk, the prepared pieces of one-segment tiles */
-    RT_CHECK(rt_memset(wide_counts, 0, 256, c->stream));
-    WGA_LAUNCH(k_list_slow_tiles, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const wga_tile_desc*)tdesc, (u64)nt,
-               c->expand_force_slow, wide_counts, wide_list);
-    LAUNCH_CHECK();
-    WGA_LAUNCH(k_tile_plan, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const wga_tile_desc*)tdesc, (u64)b->n_ops, d_out, d_t_fa,
-               (u64)t_fa_bytes, d_q_fa, (u64)q_fa_bytes, (u32*)a.plan);
-    LAUNCH_CHECK();
-  }
   u32* const fast_list = wide_list + nt; /* the second half of the list area: tiles for v1's row emitters */
   if (stream) { /* part of the pre-pass: the tiles the streaming kernel leaves to v1 (records that are not clean, giant tiles) */
     u8* const tile_flag = (u8*)ws + rec_bytes + desc_bytes + list_bytes + plan_bytes;
@@ -1007,16 +1008,6 @@ int wga_paf2maf_expand(wga_ctx* c, const wga_cigar_batch* b, const wga_cigar_cou
     a.force_slow = 1; /* beyond 2^31 columns (and everything under "expand_force_slow"): the op-serial walk */
     a.tile_count = wide_counts + 1;
     a.tile_list = wide_list;
-    WGA_LAUNCH(k_paf2maf_expand_list, side_grid, WGA_BLOCK, c->stream, a);
-    LAUNCH_CHECK();
-  } else if (windows) {
-    /* the window kernel; tiles beyond 2^31 columns (and every tile under "expand_force_slow") are listed for v1's op-serial walk */
-    WGA_LAUNCH(k_paf2maf_expand_w, (u32)nt, WGA_BLOCK, c->stream, a);
-    LAUNCH_CHECK();
-    a.force_slow = 1;
-    a.tile_count = wide_counts;
-    a.tile_list = wide_list;
-    const u32 side_grid = nt < 256 ? (u32)nt : 256u;
     WGA_LAUNCH(k_paf2maf_expand_list, side_grid, WGA_BLOCK, c->stream, a);
     LAUNCH_CHECK();
   } else {
@@ -1111,9 +1102,8 @@ int wga_scatter_bytes(wga_ctx* c, uint32_t n, const uint8_t* d_src, const uint64
   return WGA_OK;
 }
 
-#ifdef WGA_STAGE2
 /* ------------------------------------------------------------------------------------------ */
-/* K3 / K5 / K6 launchers (kernels in wga_kernels2.h)                                          */
+/* K3 / K5 / K6 launchers                                                                      */
 /* ------------------------------------------------------------------------------------------ */
 int wga_maf_pair_stat(wga_ctx* c, uint32_t n, const uint8_t* d_rows, const uint64_t* d_t_off,
                       const uint64_t* d_q_off, const uint64_t* d_cols,
@@ -1677,7 +1667,7 @@ static int pafcov_run(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_ta
   const u64 nt = has_ops ? ((u64)b->n_ops + WGA_COV_TILE - 1) / WGA_COV_TILE : 0; /* K5 cuts the ops into tiles of its own size */
   const u64 nw = (n_cov >> WGA_COV_WIN_SHIFT) + 1;
   if (nw > 0x7FFFFFFFull) return fail(WGA_E_INVALID_ARG, "coverage arrays too large for one call", nullptr);
-  /* One pass lists every (tile, record segment, window) piece (see wga_kernels2.h K5): tile sums by look-back, the pieces into the
+  /* One pass lists every (tile, record segment, window) piece (see wga_k5_pafcov.h): tile sums by look-back, the pieces into the
    * tile's own slots and counted under their windows; a scan of the window counts, and the pieces are taken to their windows.
    * Pieces beyond a tile's slots go to one of WGA_COV_LISTS list regions, as large as the last call needed them (+ 25 %): a call
    * that overflows one is run again. */
@@ -2014,6 +2004,5 @@ int wga_pafpseudo_fill(wga_ctx* c, const wga_cigar_batch* b, int base_mode, cons
   LAUNCH_CHECK();
   return WGA_OK;
 }
-#endif /* WGA_STAGE2 */
 
 } /* extern "C" */

@@ -1,6 +1,6 @@
 /*
  * wga_k10_chain.h — K10: paf2chain data lines and header trims (cigar.rs:202-295,460-490).
- * One of the parts of wga_kernels2.h, which includes them in dependency order (a part uses helpers of the parts in front of it).
+ * One header per kernel family; wga_capi.cpp includes them in dependency order (a header may use helpers of the ones in front of it).
  */
 #ifndef WGA_K10_CHAIN_H
 #define WGA_K10_CHAIN_H

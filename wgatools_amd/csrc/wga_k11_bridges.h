@@ -1,6 +1,6 @@
 /*
  * wga_k11_bridges.h — K11: bridges between run / data-line lists and packed ops / CIGAR text.
- * One of the parts of wga_kernels2.h, which includes them in dependency order (a part uses helpers of the parts in front of it).
+ * One header per kernel family; wga_capi.cpp includes them in dependency order (a header may use helpers of the ones in front of it).
  */
 #ifndef WGA_K11_BRIDGES_H
 #define WGA_K11_BRIDGES_H

@@ -1,6 +1,6 @@
 /*
  * wga_k12_dotplot.h — K12: dotplot base-level segments (emit_baseplotdatas, cigar.rs:815-914).
- * One of the parts of wga_kernels2.h, which includes them in dependency order (a part uses helpers of the parts in front of it).
+ * One header per kernel family; wga_capi.cpp includes them in dependency order (a header may use helpers of the ones in front of it).
  */
 #ifndef WGA_K12_DOTPLOT_H
 #define WGA_K12_DOTPLOT_H

@@ -1,6 +1,6 @@
 /*
  * wga_k13_splitters.h — K13 / K14: the PAF and MAF line splitters (paf.rs:24-30,50-78; maf.rs:25-36,138-211).
- * One of the parts of wga_kernels2.h, which includes them in dependency order (a part uses helpers of the parts in front of it).
+ * One header per kernel family; wga_capi.cpp includes them in dependency order (a header may use helpers of the ones in front of it).
  */
 #ifndef WGA_K13_SPLITTERS_H
 #define WGA_K13_SPLITTERS_H

@@ -1,6 +1,6 @@
 /*
  * wga_k15_fasta.h — K15: FASTA text in HBM -> line-stripped sequence pool + contig table.
- * One of the parts of wga_kernels2.h, which includes them in dependency order (a part uses helpers of the parts in front of it).
+ * One header per kernel family; wga_capi.cpp includes them in dependency order (a header may use helpers of the ones in front of it).
  */
 #ifndef WGA_K15_FASTA_H
 #define WGA_K15_FASTA_H

@@ -1,6 +1,6 @@
 /*
  * wga_k18_bgzf_deflate.h — K18: output bytes in HBM -> BGZF (blocked gzip) members, compressed on the device.
- * One of the parts of wga_kernels2.h, which includes them in dependency order (a part uses helpers of the parts in front of it).
+ * One header per kernel family; wga_capi.cpp includes them in dependency order (a header may use helpers of the ones in front of it).
  */
 #ifndef WGA_K18_BGZF_DEFLATE_H
 #define WGA_K18_BGZF_DEFLATE_H

@@ -1,6 +1,6 @@
 /*
  * wga_k5_pafcov.h — K5: pafcov — difference-array coverage marks (update_cov_vec, cigar.rs:710-741) and the marks -> counts replay.
- * One of the parts of wga_kernels2.h, which includes them in dependency order (a part uses helpers of the parts in front of it).
+ * One header per kernel family; wga_capi.cpp includes them in dependency order (a header may use helpers of the ones in front of it).
  */
 #ifndef WGA_K5_PAFCOV_H
 #define WGA_K5_PAFCOV_H

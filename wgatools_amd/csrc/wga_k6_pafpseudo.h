@@ -1,6 +1,6 @@
 /*
  * wga_k6_pafpseudo.h — K6: pafpseudo — target-coordinate pseudo-MAF segments, block kernel (gen_pesudo_maf_by_cigar, cigar.rs:744-804).
- * One of the parts of wga_kernels2.h, which includes them in dependency order (a part uses helpers of the parts in front of it).
+ * One header per kernel family; wga_capi.cpp includes them in dependency order (a header may use helpers of the ones in front of it).
  */
 #ifndef WGA_K6_PAFPSEUDO_H
 #define WGA_K6_PAFPSEUDO_H

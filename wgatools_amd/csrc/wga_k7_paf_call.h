@@ -1,6 +1,6 @@
 /*
  * wga_k7_paf_call.h — K7: the op walk of call on PAF (call_within_var_paf, caller.rs:610-822) and the piece table of the op walks.
- * One of the parts of wga_kernels2.h, which includes them in dependency order (a part uses helpers of the parts in front of it).
+ * One header per kernel family; wga_capi.cpp includes them in dependency order (a header may use helpers of the ones in front of it).
  */
 #ifndef WGA_K7_PAF_CALL_H
 #define WGA_K7_PAF_CALL_H

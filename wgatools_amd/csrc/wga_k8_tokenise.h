@@ -1,6 +1,6 @@
 /*
  * wga_k8_tokenise.h — K8: CIGAR text -> packed ops on the device (cigar.rs:43-75).
- * One of the parts of wga_kernels2.h, which includes them in dependency order (a part uses helpers of the parts in front of it).
+ * One header per kernel family; wga_capi.cpp includes them in dependency order (a header may use helpers of the ones in front of it).
  */
 #ifndef WGA_K8_TOKENISE_H
 #define WGA_K8_TOKENISE_H

@@ -1,6 +1,6 @@
 /*
  * wga_k9_bed.h — K9: pafcov BED text (pafcov.rs:56-60).
- * One of the parts of wga_kernels2.h, which includes them in dependency order (a part uses helpers of the parts in front of it).
+ * One header per kernel family; wga_capi.cpp includes them in dependency order (a header may use helpers of the ones in front of it).
  */
 #ifndef WGA_K9_BED_H
 #define WGA_K9_BED_H

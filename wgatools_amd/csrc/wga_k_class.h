@@ -1,6 +1,6 @@
 /*
  * wga_k_class.h — class sums of the op stream per tile and per record (shared first pass of pafcov and pafpseudo), the stat totals.
- * One of the parts of wga_kernels2.h, which includes them in dependency order (a part uses helpers of the parts in front of it).
+ * One header per kernel family; wga_capi.cpp includes them in dependency order (a header may use helpers of the ones in front of it).
  */
 #ifndef WGA_K_CLASS_H
 #define WGA_K_CLASS_H

@@ -1277,7 +1277,6 @@ struct ExpandArgs {
   const u32* tile_count; /* k_paf2maf_expand_list: the blocks loop over tile_list[0 .. *tile_count) */
   const u32* tile_list;
   u32 n_rec;    /* records of the batch (op_off has n_rec + 1 entries) */
-  const u32* plan; /* window kernel: the prepared pieces of one-segment tiles (k_tile_plan) */
   u32 job_tiles;   /* streaming kernel: consecutive tiles one wave walks as one stream */
 };
 
@@ -1646,8 +1645,8 @@ __device__ __forceinline__ void expand_tile_v1(const ExpandArgs& a, const u64 g)
 }
 
 /* v1 of the row kernel (granules stored as they are produced: lines reach the L2 in pieces): `expand_variant` 0, one block
- * per tile of the batch; the default for batches of long records (the window kernel of wga_kernels_k2w.h takes the short
- * ones) and — as k_paf2maf_expand_list — the op-serial u64 walk of the tiles beyond 2^31 columns under either kernel. */
+ * per tile of the batch — and, as k_paf2maf_expand_list, the kernel of the tiles the streaming kernel (wga_kernels_k2s.h, the
+ * default) leaves: records that are not clean, pool edges, tiles beyond 2^24 columns, the op-serial u64 walk beyond 2^31. */
 /* Blocks go to the 8 XCDs round robin (block b runs on XCD b % 8), each with its own L2.  Every XCD gets one contiguous
  * eighth of the tiles, in order: the ~190 tiles an XCD has in flight are then neighbours — the output lines two tiles
  * share and the source windows of one record's tiles meet in one L2.  Measured (profiles/r02_k2_experiments.md):

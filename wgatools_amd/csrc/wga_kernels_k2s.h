@@ -1,6 +1,6 @@
 /*
  * wga_kernels_k2s.h — K2s, the STREAMING row kernel of paf2maf (`expand_variant` 3, the default): the same bytes as v1
- * (wga_kernels.h) and the window kernel (wga_kernels_k2w.h), i.e. parse_cigar_to_insert / cigar_unit_insert_seq
+ * (wga_kernels.h; the window kernel of rounds 3-5 was retired in round 6), i.e. parse_cigar_to_insert / cigar_unit_insert_seq
  * (cigar.rs:492-551) with reverse_complement (utils.rs:83-101) fused, written as a stream per wave instead of a block per tile.
  *
  * Why another one.  Round 4 measured what bounds the row kernels: not bytes but INSTRUCTION ISSUE.  A CU of this part retires
