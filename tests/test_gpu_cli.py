@@ -26,6 +26,20 @@ def test_dist_cli_one_rank_writes_the_command_lines_bytes(cli, tmp_path):
     dc.check_totals(tmp_path, None, (1,), 29740)
 
 
+def test_dist_cli_two_ranks_over_rccl(cli, tmp_path):
+    """the multi-rank driver with TWO ranks, one per GPU, over RCCL (backend "nccl"): the size all-reduce that orders the
+    output, the totals all-reduce and the reduce-scatter of a spread pafcov target cross xGMI.  Skips on a one-GPU box; the
+    same cases run with two ranks over gloo on the emulator build (test_dist_cli_gloo.py)"""
+    import ctypes
+    import torch  # noqa: F401
+    import dist_cli_cases as dc
+    if ctypes.CDLL(build.HIP_LIB).wga_device_count() < 2:
+        pytest.skip("one device on this box: two ranks over RCCL need two")
+    dc.check_paf2maf(tmp_path, None, cli, (2,), 29800)
+    dc.check_pafcov(tmp_path, None, cli, (2,), 29820)
+    dc.check_totals(tmp_path, None, (2,), 29840)
+
+
 def test_gpus_flag_with_the_devices_of_this_box(cli, tmp_path):
     """`wgatools --gpus N` (C++ worker threads, one context per device) with every device this box has — one on the
     driver's boxes, where the sharded path then runs with a single worker: the same bytes as the plain command line and

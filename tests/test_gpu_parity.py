@@ -1349,6 +1349,57 @@ def test_reduce_scatter_i32_on_hardware():
             e.close()
 
 
+def test_reduce_scatter_i32_across_devices():
+    """the same call over the REAL devices of the box (no "reduce_same_device_ok"): one context per device, up to eight — the
+    peers' slices cross xGMI, read in place by one kernel per device, or pulled over N - 1 streams with "reduce_staged".  Skips
+    on a one-GPU box (the driver's pool has those); on a multi-GPU lease it is the first evidence of bytes over the links, and
+    it prints the rate of the 400 MB case"""
+    import ctypes as C
+    import time
+    import torch  # noqa: F401
+    from wgatools_amd import build, _lib
+    lib = _lib.load(build.HIP_LIB)
+    have = int(lib.wga_device_count())
+    if have < 2:
+        pytest.skip("one device on this box: the cross-device reduce needs two")
+    ng = min(have, 8)
+    engs = [engine.Engine(g, lib) for g in range(ng)]
+    rng = np.random.default_rng(14)
+    try:
+        for staged in (0, 1):
+            for e in engs:
+                e.set_param("reduce_staged", staged)
+            for count in (1, 70001, 100_000_000):
+                host = [rng.integers(-1000, 1000, count, dtype=np.int32) for _ in range(ng)]
+                bufs = [e.upload(h) for e, h in zip(engs, host)]
+                cx = (C.c_void_p * ng)(*[e.ctx for e in engs])
+                bp = (C.c_void_p * ng)(*[b.ptr for b in bufs])
+                for e in engs:
+                    e.sync()
+                t0 = time.perf_counter()
+                assert lib.wga_reduce_scatter_i32(cx, ng, bp, count) == 0
+                for e in engs:
+                    e.sync()
+                dt = time.perf_counter() - t0
+                total = np.sum(np.stack(host).astype(np.int64), axis=0)
+                for g in range(ng):
+                    lo, hi = count * g // ng, count * (g + 1) // ng
+                    got = bufs[g].numpy()[:count]
+                    assert (got[lo:hi] == total[lo:hi]).all(), (staged, count, g)
+                    mask = np.ones(count, dtype=bool)
+                    mask[lo:hi] = False
+                    assert (got[mask] == host[g][mask]).all(), (staged, count, g)
+                if count == 100_000_000:
+                    moved = 4.0 * count * (ng - 1) / ng        # bytes every device reads from its peers
+                    print("\nreduce_scatter_i32 over %d devices (%s): %.2f ms, %.1f GB/s into each device" % (
+                        ng, "staged" if staged else "peer reads", dt * 1e3, moved / dt / 1e9))
+                for b in bufs:
+                    b.free()
+    finally:
+        for e in engs:
+            e.close()
+
+
 def test_paf2maf_stream_kernel_pools_beyond_4_gb(gpu):
     """sequence pools of 4.6 GB: the streaming kernel addresses a record segment's source through a buffer whose base lies a
     little in front of what the job can reach (32-bit offsets) — slices beyond 2^32 must read the same bytes as v1's 64-bit
