@@ -159,6 +159,40 @@ def extra_shape(eng, synth, pipeline, torch, dev, seed, records, mean_ops, pool_
     return ms, frac
 
 
+def allocation_spread(eng, pipeline, torch, tb, first_ms, n_alloc=4, steps=3):
+    """The row kernel on further FRESH output allocations of this process, all held at once (so they are different memory):
+    the kernel's time depends on where the 15 GB of rows land (+- 5 % from box to box and from allocation to allocation:
+    VERDICT r05), so the line carries min / median / max over `1 + n_alloc` allocations beside the first one's number.
+    first_ms: the timed steps' per-launch time on the first allocation."""
+    import statistics
+    outs, ms = [], [first_ms]
+    rows = pipeline.output_bytes(tb)
+    for _ in range(n_alloc):
+        outs.append(torch.empty(rows + 64, dtype=torch.uint8, device=tb["ops"].device))
+    for out in outs:
+        job = pipeline.Paf2MafStatJob(eng, tb, out=out)
+        job.bind_stream()
+        for _ in range(2):    # first touch of this buffer
+            job.step()
+        torch.cuda.synchronize()
+        eng.expand_timing()
+        for _ in range(steps):
+            job.step()
+        torch.cuda.synchronize()
+        ms_sum, n_timed = eng.expand_timing()
+        assert bool((job.diag == -1).all())
+        ms.append(ms_sum / max(1, n_timed))
+        ab = job.algorithmic_bytes()["expand"]
+        del job
+    del outs
+    torch.cuda.empty_cache()
+    fr = lambda t: ab / (t * 1e-3) / 1e9 / HBM_PEAK_GBS
+    return {"allocations": len(ms), "k_ms_by_allocation": ms, "k_ms_min": min(ms), "k_ms_median": statistics.median(ms),
+            "k_ms_max": max(ms), "frac_min": fr(max(ms)), "frac_median": fr(statistics.median(ms)), "frac_max": fr(min(ms)),
+            "note": "allocation 0 = the timed steps' buffer (the headline); the others are fresh buffers held side by side, "
+                    "3 timed launches each; rocprofv3's average over one run of this command covers all of them"}
+
+
 def e2e_leg(tb, synth, torch, check=2):
     """file to file on the same batch ("input GB/s is reported on the text size as well"): the records as a PAF
     file and the pools as two FASTA files under /tmp, then the `wgatools` command line (the C++ host layer over the C-ABI)
@@ -401,6 +435,8 @@ def main():
     ap.add_argument("--zipf", type=float, default=0.0, help="strong scaling: skew of the records over the targets "
                                                             "(P(target k) ~ 1 / (k + 1)^zipf; 0 = uniform, the default)")
     ap.add_argument("--no-placement-probe", action="store_true", help="(accepted for older command lines: the output buffer is the first allocation)")
+    ap.add_argument("--no-spread", action="store_true", help="skip the row kernel's times on four further fresh output allocations "
+                                                             "(roofline.allocation_spread)")
     ap.add_argument("--north-star", action="store_true", help="the 10 M x 50 kop headline shape as a stream of resident batches (N = 1)")
     ap.add_argument("--ns-records", type=int, default=400_000)
     ap.add_argument("--ns-batch-records", type=int, default=40_000)
@@ -618,6 +654,11 @@ def main():
                     gt, gq = job.record_rows(i)
                     assert gt == et and gq == eq, "record %d differs from the oracle" % i
                 result["cpu_baseline"]["parity_spot_check"] = "%d records bit-identical to oracle rows" % len(step_idx)
+        if world == 1 and not args.no_spread and not args.param:
+            try:   # additional information: never at the price of the headline line
+                result["roofline"]["allocation_spread"] = allocation_spread(eng, pipeline, torch, tb, k_expand)
+            except Exception as e:  # noqa: BLE001
+                result["roofline"]["allocation_spread"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_extras and not args.param and args.records == 100_000 and args.mean_ops == 5000:
             # the same kernel where the default shape flatters it: pools beyond the Infinity Cache, and the
             # north-star record length

@@ -837,8 +837,7 @@ int wga_reduce_scatter_i32(wga_ctx** ctxs, int ngpu, int32_t** d_bufs, uint64_t 
           RT_CHECK(rt_stream_wait_event(st, c->rs_ready));
           RT_CHECK(rt_stream_wait_event(st, ctxs[h]->rs_ready));
           RT_CHECK(rt_peer_copy(stage + (size_t)k * n, c->device, d_bufs[h] + lo, ctxs[h]->device, (size_t)n * 4, st));
-          RT_CHECK(rt_event_record(c->rs_copied[k], st));
-          srcs.p[n_src++] = stage + (size_t)k * n;
+          RT_CHECK(rt_event_record(c->rs_copied[k], st)); /* the staged pieces are named below, WGA_PEER_MAX per launch */
         }
         k++;
         if (n_src == WGA_PEER_MAX && direct) { /* more peers than one launch takes (never on one node) */

@@ -580,6 +580,11 @@ __device__ __forceinline__ u32 cov_windows_in_front(u64* win_state, u64 wi, u32 
       const u64 front = pref ? ((pref & (0ull - pref)) - 1ull) : ~0ull; /* the lanes nearer than the nearest prefix */
       if (!(empty & front)) break;
       if (polls) WGA_SLEEP(8); /* the windows waited for are still replaying: do not crowd their loads */
+      /* Forward progress rests on the launch's order: the window a block waits for has a lower rank in `order` (or a lower
+       * index without one) and blocks are dispatched in blockIdx order, so it is running or done.  Should that ever not hold (a
+       * partitioned or preempted device, a launch order that changes), the wait ends after ~4 s of polls in a trap — the call
+       * then FAILS at the stream's next synchronisation instead of hanging the device. */
+      if (polls > (1u << 24)) __builtin_trap();
     }
     const u32 first = pref ? (u32)__ffsll((unsigned long long)pref) - 1u : 64u;
     acc += wave_sum_u32((mine && lane <= first) ? (u32)v : 0u);

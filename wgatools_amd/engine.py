@@ -245,17 +245,27 @@ class Engine:
         """BGZF members inflated on the device (wga_bgzf_inflate); blocks: n x (in_off u64, in_len u32, out_len u32, out_off u64)"""
         self._check(self.lib.wga_bgzf_inflate(self.ctx, _p(d_in), int(in_bytes), int(n_blocks), _p(blocks), _p(out), _p(status)))
 
-    def bgzf_compress(self, d_in, n_bytes, out=None, eof_marker=True, in_offset=0, out_offset=0):
+    def bgzf_compress(self, d_in, n_bytes, out=None, eof_marker=True, in_offset=0, out_offset=0, out_cap=None):
         """bytes in HBM -> BGZF members (wga_bgzf_compress, K18); returns (DeviceArray of the worst-case size, bytes used).
-        in_offset / out_offset: byte offsets into d_in / out (any alignment)."""
+        in_offset / out_offset: byte offsets into d_in / out (any alignment).  The capacity handed to the library is what `out`
+        really holds behind out_offset (a DeviceArray's or a tensor's own size; out_cap for a raw pointer): the library's
+        own check then refuses a buffer that is too small instead of writing past it."""
         cap = int(self.lib.wga_bgzf_bound(int(n_bytes)))
         if out is None:
             out = self.empty(cap + int(out_offset), np.uint8)
+        if out_cap is None:
+            if isinstance(out, DeviceArray):
+                out_cap = out.nbytes - int(out_offset)
+            elif hasattr(out, "numel") and hasattr(out, "element_size"):
+                out_cap = out.numel() * out.element_size() - int(out_offset)
+            else:
+                raise ValueError("bgzf_compress: out_cap is required when `out` is a raw pointer")
+        if out_cap < 0:
+            raise ValueError("bgzf_compress: out_offset lies behind the end of `out`")
         used = C.c_uint64(0)
         src = _p(d_in)
         self._check(self.lib.wga_bgzf_compress(self.ctx, (src + int(in_offset)) if src else None, int(n_bytes),
-                                               _p(out) + int(out_offset), out.nbytes - int(out_offset) if isinstance(out, DeviceArray) else cap,
-                                               C.byref(used), 1 if eof_marker else 0))
+                                               _p(out) + int(out_offset), int(out_cap), C.byref(used), 1 if eof_marker else 0))
         return out, int(used.value)
 
     def scatter_bytes(self, n, src, src_off, dst, dst_off):

@@ -280,17 +280,21 @@ struct Dev {
   wga_ctx* ctx = nullptr;
   bool own_ctx = true; /* false: the context is another Dev's (the reader's, lent to device 0's worker) */
   int device = 0;
+  bool helper = false; /* a reader's own context, used on its helper thread (BgzfDeviceSource): never the one host text is deflated on */
   std::vector<void*> owned;
   std::unique_ptr<DevStreamer> streamer; /* pinned buffers, allocated once per process */
   Dev() {}
   explicit Dev(int dev) : device(dev) {}
   void init() {
-    if (ctx) return;
-    g_timer.mark("host");
-    if (device == 0 && !g_gz_dev) {
+    /* the device big host text for a `.gz` file goes through (Output::big_text): a COMMAND's context on device 0, registered by the
+     * thread that runs the command — never a helper thread's (a wga_ctx serves one thread), and again whenever the slot is empty
+     * (a reader that came and went leaves it so) */
+    if (!helper && device == 0 && !g_gz_dev) {
       g_gz_dev = this;
       Output::big_text = big_text_through_device;
     }
+    if (ctx) return;
+    g_timer.mark("host");
     if (device != 0) { /* the workers' devices: a context each */
       int rc = wga_ctx_create(device, &ctx);
       if (rc) fail(std::string("GPU engine: ") + wga_last_error());
@@ -445,6 +449,7 @@ struct BgzfDeviceSource {
     if (fd >= 0) ::close(fd);
   }
   bool open(const std::string* p) {
+    d.helper = true; /* refill() runs on the reader's helper thread: this context is no one else's */
     const char* e = getenv("WGA_BGZF_DEVICE");
     if (!p || (e && atoi(e) == 0)) return false;
     if (!scan_bgzf_members(*p, members, &total, &file_bytes)) return false;
