@@ -1,4 +1,4 @@
-"""The multi-rank driver (wgatools_amd/dist_cli.py: torch.distributed over gloo, the emulator build of the kernels, two and three ranks)
+"""The multi-rank driver (tests/dist_cli.py: torch.distributed over gloo, the emulator build of the kernels, two and three ranks)
 on random inputs: its files against the oracle's expectation and the single-process command line:
 python scripts/emu_campaign_dist_cli.py <first seed> <seconds> <first port>.  CPU only; results: profiles/r05_emu_campaign.txt."""
 import os, pathlib, shutil, subprocess, sys, tempfile, time, traceback

@@ -1,11 +1,14 @@
-"""One process per GPU over a PAF file: the multi-GPU driver of the hot path (north_star: "records
-shard naturally by hash(target_name) across the 8 GPUs of one node with an RCCL reduce over xGMI only for the global
-stat / pafcov totals").
+"""TEST HARNESS (round 6: it lived in the package as wgatools_amd/dist_cli.py until the multi-GPU drivers were reduced to one).
+One process per GPU over a PAF file, the collectives of wgatools_amd/multigpu.py (torch.distributed: "nccl" = RCCL on the GPU
+box, gloo on the emulator build) around the single-GPU calls of the C-ABI: it checks that the partition rule and the
+collectives bench.py --gpus N measures give the bytes of the product's own multi-GPU driver, `wgatools --gpus N`
+(north_star: "records shard naturally by hash(target_name) across the 8 GPUs of one node with an RCCL
+reduce over xGMI only for the global stat / pafcov totals").
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        -m wgatools_amd.dist_cli paf2maf  in.paf -g target.fa -q query.fa -o out.maf
-        -m wgatools_amd.dist_cli pafcov   in.paf -o out.bed [--spread]
-        -m wgatools_amd.dist_cli totals   in.paf                      (the 11 global stat counters, one JSON line)
+        tests/dist_cli.py paf2maf  in.paf -g target.fa -q query.fa -o out.maf
+        tests/dist_cli.py pafcov   in.paf -o out.bed [--spread]
+        tests/dist_cli.py totals   in.paf                      (the 11 global stat counters, one JSON line)
 
 Every rank reads the whole PAF (host parsing is the same work on every rank; the kernels are not), keeps the records
 `fnv1a64(target_name) % N` gives it and runs the single-GPU calls of the C-ABI on them (`wgatools_amd.engine`); the bytes
@@ -37,7 +40,8 @@ import sys
 
 import numpy as np
 
-from . import _lib, engine, multigpu
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wgatools_amd import _lib, engine, multigpu  # noqa: E402
 
 NONE = 0xFFFFFFFFFFFFFFFF
 
@@ -479,7 +483,7 @@ def run_totals(R, args):
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser(prog="python -m wgatools_amd.dist_cli", description=__doc__.split("\n\n")[0])
+    ap = argparse.ArgumentParser(prog="python tests/dist_cli.py", description=__doc__.split("\n\n")[0])
     ap.add_argument("--lib", default=None, help="library to bind instead of the in-tree libwgahip.so (tests: the emulator build; runs over gloo)")
     sub = ap.add_subparsers(dest="cmd", required=True)
     p = sub.add_parser("paf2maf")

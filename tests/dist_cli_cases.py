@@ -1,4 +1,4 @@
-"""Cases for the multi-rank driver (wgatools_amd/dist_cli.py): its files must be the bytes the single-GPU `wgatools`
+"""Cases for the multi-rank harness (tests/dist_cli.py over wgatools_amd/multigpu.py): its files must be the bytes the single-GPU `wgatools`
 command line writes, whatever the number of ranks.  test_dist_cli_gloo.py runs them on CPU (emulator build of the kernels,
 1 and 2 ranks over gloo), test_gpu_cli.py on the GPU box (one rank, libwgahip.so)."""
 import json
@@ -75,7 +75,7 @@ def launch(world, lib, port, *args, expect_rc=0):
     if world > 1:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
                 "--master-port", str(port)]
-    cmd += ["-m", "wgatools_amd.dist_cli"] + (["--lib", lib] if lib else []) + list(args)
+    cmd += [os.path.join(ROOT, "tests", "dist_cli.py")] + (["--lib", lib] if lib else []) + list(args)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PYTHONPATH=ROOT)
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == expect_rc or (world > 1 and expect_rc and r.returncode != 0), (r.returncode, r.stdout[-2000:], r.stderr[-3000:])

@@ -12,7 +12,7 @@ WORKER = r'''
 import os, sys
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, torch, torch.distributed as dist
-from wgatools_amd import build, engine, _lib, synth, shard
+from wgatools_amd import build, engine, _lib, synth, shard, multigpu
 import parity_cases as pc, oracle_py as orc
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -27,7 +27,7 @@ counts, _, _ = eng.cigar_stat(batch)
 c = counts.numpy()
 tot = torch.tensor([int(c[k].sum()) for k in engine.COUNTS_DTYPE.names], dtype=torch.int64)
 n_mine = torch.tensor([len(mine)], dtype=torch.int64)
-shard.allreduce_totals(tot, dist)
+multigpu.allreduce_totals(tot, dist)
 dist.all_reduce(n_mine)
 if rank == 0:
     exp = np.zeros(11, dtype=np.int64)

@@ -130,7 +130,9 @@ def write_ordered(path, local_bytes, local_off, local_len, global_off, total=Non
 
 def allreduce_totals(totals, dist=None):
     """sum the 11 stat counters over ranks (in place on a torch tensor): RCCL over xGMI, 88 bytes"""
-    return shard.allreduce_totals(totals, dist)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(totals)
+    return totals
 
 
 def hot_target_coverage(cov, dist=None):

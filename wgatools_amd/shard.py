@@ -37,10 +37,3 @@ def select_batch(b, idx):
     for k in ("strand_neg", "t_src_off", "t_src_len", "q_src_off", "q_src_len"):
         out[k] = b[k][idx]
     return out
-
-
-def allreduce_totals(totals, dist=None):
-    """sum the 11 stat counters over ranks (in place on a torch tensor)"""
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(totals)
-    return totals
