@@ -391,10 +391,11 @@ struct Dev {
     }
   }
 };
-static void stream_out(Dev& d, Output& out, const uint8_t* d_src, size_t n) {
+/* marks: the phase timer is the main thread's; a helper thread that streams a piece out while the next one is worked on passes false */
+static void stream_out(Dev& d, Output& out, const uint8_t* d_src, size_t n, bool marks = true) {
   if (!d.streamer) d.streamer.reset(new DevStreamer(d.ctx));
   d.check(wga_sync(d.ctx));
-  g_timer.mark("kernels + host tables");
+  if (marks) g_timer.mark("kernels + host tables");
   if (out.bgzf) {
     /* `.gz`: the text is deflated where it is (K18) and the members are what crosses PCIe and reaches the file; slabs keep
      * the buffer of members bounded whatever the piece */
@@ -405,14 +406,14 @@ static void stream_out(Dev& d, Output& out, const uint8_t* d_src, size_t n) {
       d.gz_arena_for((size_t)cap);
       uint64_t used = 0;
       d.check(wga_bgzf_compress(d.ctx, d_src + a, len, (uint8_t*)d.gz_arena, cap, &used, 0));
-      g_timer.mark("device deflate");
+      if (marks) g_timer.mark("device deflate");
       d.streamer->run(out, (const uint8_t*)d.gz_arena, (size_t)used, true);
-      g_timer.mark("copy out + write");
+      if (marks) g_timer.mark("copy out + write");
     }
     return;
   }
   d.streamer->run(out, d_src, n);
-  g_timer.mark("copy out + write");
+  if (marks) g_timer.mark("copy out + write");
 }
 /* host text of megabytes for a `.gz` file (Output::big_text): up, through the same deflate, out */
 static bool big_text_through_device(Output& out, const char* p, size_t n) {
