@@ -42,6 +42,19 @@ for chunks in [int(x) for x in (sys.argv[1:] or ["1", "2", "4", "8"])]:
     reps = int(os.environ.get("K5_REPS", "2"))
     ev = lambda: torch.cuda.Event(enable_timing=True)
     ref = None
+    if os.environ.get("K5_COLD"):   # what the first call's 4.7 s are made of: the library's work buffers through hipMalloc (tile slots
+        import time                 # nt x 8 x 32 B, scratch, pieces: ~12 GB at this size), timed here on allocations of those sizes
+        import numpy as np
+        nt_tiles = (n_ops + 1023) // 1024
+        for name, nbytes in (("tile slots", nt_tiles * 8 * 32), ("scratch", nt_tiles * 84 + n_all * 16), ("pieces", int(nt_tiles * 2.8 * 1.25) * 32)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            x = eng.empty(int(nbytes), np.uint8)
+            eng.sync()
+            t1 = time.perf_counter()
+            x.free()
+            eng.sync()
+            print("hipMalloc of %.2f GB (%s): %.0f ms, free %.0f ms" % (nbytes / 1e9, name, (t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3), flush=True)
     for rep in range(reps):
         if mode in ("sep", "both"):
             cov.zero_()

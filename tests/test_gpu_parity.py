@@ -799,6 +799,94 @@ def test_maf_config3_full_size_properties(gpu):
     assert done == nrun and bool(torch.equal(exp, runs[:3 * nrun])), "run list differs from the torch expectation"
 
 
+def test_maf_call_vcf_at_size(gpu):
+    """`call -s -i -l 2` on 200 000 MAF blocks x 1 500 columns through K4 + K19 (wga_maf_call_vcf: chunk cuts, after_m rules,
+    rows): the number of rows of every kind against what torch derives from the same rows on the device (a SNP row per X
+    column; an INS / DEL row per target- / query-gap run longer than the cutoff whose nearest earlier run that is not
+    both-gap is '=' or X; an <INV> row per '-' block), every row's 8 tab-separated columns in place, and a sample of blocks
+    byte for byte against the oracle (orc_call_var_maf_record: caller.rs:115-265,388-608)"""
+    import torch
+    dev = torch.device("cuda", 0)
+    L, n, svlen = 1500, 200_000, 2
+    t, q, n = _synthetic_maf_rows(dev, n, L, 23)
+    rows = torch.cat([t, q])
+    tot = n * L
+    cols = torch.full((n,), L, dtype=torch.int64, device=dev)
+    t_off = torch.arange(n, device=dev, dtype=torch.int64) * L
+    q_off = t_off + tot
+    neg = (torch.arange(n, device=dev) % 10 == 0)
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    crun = torch.zeros(n, dtype=torch.int64, device=dev)
+    gpu.maf_call_runs(n, rows, t_off, q_off, cols, run_cnt=crun)
+    off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(crun, 0)
+    nrun = int(off[-1])
+    runs = torch.zeros(3 * nrun + 3, dtype=torch.int64, device=dev)
+    gpu.maf_call_runs(n, rows, t_off, q_off, cols, run_cnt=crun, runs=runs, run_off=off)
+    names = b"ref.chr1qry.chr1\0"
+    recs = np.zeros(n, dtype=engine.MAF_VCF_REC_DTYPE)
+    recs["t_name_off"], recs["t_name_len"], recs["q_name_off"], recs["q_name_len"] = 0, 8, 8, 8
+    recs["t_start"] = 1600 * np.arange(n, dtype=np.uint64)
+    recs["q_start"] = 1700 * np.arange(n, dtype=np.uint64)
+    recs["q_size"] = 4_000_000_000
+    recs["q_neg"] = neg.cpu().numpy().astype(np.uint32)
+    d_recs = torch.from_numpy(recs.view(np.uint8).reshape(n, -1).copy()).to(dev)
+    d_names = torch.tensor(list(names), dtype=torch.uint8, device=dev)
+    nb = torch.zeros(n, dtype=torch.int64, device=dev)
+    err = torch.zeros((n, 2), dtype=torch.int64, device=dev)
+    gpu.maf_call_vcf(n, rows, t_off, q_off, cols, runs, off, d_recs, d_names, True, True, svlen, 1_000_000, nbytes=nb, err=err)
+    torch.cuda.synchronize()
+    assert bool((err[:, 0] == -1).all())
+    toff = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    toff[1:] = torch.cumsum(nb, 0)
+    n_text = int(toff[-1])
+    text = torch.zeros(n_text + 64, dtype=torch.uint8, device=dev)
+    gpu.maf_call_vcf(n, rows, t_off, q_off, cols, runs, off, d_recs, d_names, True, True, svlen, 1_000_000, out=text, out_off=toff)
+    torch.cuda.synchronize()
+    text = text[:n_text]
+    # rows of every kind, from the columns themselves
+    tt, qq = t.view(n, L), q.view(n, L)
+    tg, qg = tt == 45, qq == 45
+    cls = torch.where(tg & qg, 4, torch.where(tg, 1, torch.where(qg, 2, torch.where(tt == qq, 0, 3))))
+    n_snp = int((cls == 3).sum())
+    r3 = runs[:3 * nrun].view(nrun, 3)
+    rcls = r3[:, 0] & 7
+    rstart = r3[:, 0] >> 3
+    blk = torch.repeat_interleave(torch.arange(n, device=dev), crun)
+    rend = torch.empty_like(rstart)
+    rend[:-1] = rstart[1:]
+    last = torch.zeros(nrun, dtype=torch.bool, device=dev)
+    last[off[1:] - 1] = True
+    rend[last] = L
+    rlen = rend - rstart
+    # the nearest earlier run that is not both-gap, inside the block: a running maximum over the indices of such runs
+    idx = torch.arange(nrun, device=dev)
+    nonw = torch.where(rcls != 4, idx, torch.full_like(idx, -1))
+    prev = torch.cummax(nonw, 0).values
+    prev_excl = torch.empty_like(prev)
+    prev_excl[0] = -1
+    prev_excl[1:] = prev[:-1]
+    ok_prev = (prev_excl >= 0) & (blk[prev_excl.clamp(min=0)] == blk) & ((rcls[prev_excl.clamp(min=0)] == 0) | (rcls[prev_excl.clamp(min=0)] == 3))
+    n_sv = int((((rcls == 1) | (rcls == 2)) & (rlen > svlen) & ok_prev).sum())
+    n_negb = int((neg & ((~tg).sum(1) > 0)).sum())
+    nl = int((text == 10).sum())
+    assert int((text == 9).sum()) == 9 * nl                      # ten columns a row
+    host = text.cpu().numpy().tobytes()
+    # an <INV> row per chunk of a '-' block that holds a target base: a block is cut behind its last gap segment of `svlen`
+    # columns (caller.rs:186-216), so one or two per block — the sample below pins the cuts exactly
+    n_inv = host.count(b"SVTYPE=INV")
+    assert n_negb <= n_inv <= 2 * n_negb
+    assert host.count(b"SVTYPE=INS") + host.count(b"SVTYPE=DEL") == n_sv and n_sv > 1000
+    assert nl == n_snp + n_sv + n_inv, (nl, n_snp, n_sv, n_inv)
+    th, qh, tof = t.cpu().numpy(), q.cpu().numpy(), toff.cpu().numpy()
+    for i in list(range(0, n, n // 150)) + [n - 1]:
+        want = orc.call_var_maf_record("ref.chr1", "qry.chr1", th[i * L:(i + 1) * L].tobytes(), qh[i * L:(i + 1) * L].tobytes(),
+                                       int(recs["t_start"][i]), int(recs["q_start"][i]), int((qh[i * L:(i + 1) * L] != 45).sum()),
+                                       4_000_000_000, bool(recs["q_neg"][i]), True, True, svlen, 1_000_000)
+        assert host[int(tof[i]):int(tof[i + 1])].decode() == want, i
+    gpu.reset_stream()
+
+
 def test_maf_walks_ragged_blocks_exact(gpu):
     """150 000 MAF blocks of 1 .. 3 000 columns (2.2e8 columns; neighbours of every length mix: the walks take two short blocks
     as one column stream where that saves a step, single walks otherwise): every counter of the stat walk, and BOTH walks' whole

@@ -108,6 +108,11 @@ class Batch:
         self.c = _lib.CigarBatch(_p(ops), _p(op_off), _p(strand_neg), self.n_ops, self.n)
 
 
+VCF_ERR_DTYPE = np.dtype([("item", "<u8"), ("kind", "<u4"), ("ch", "<u4")])
+MAF_VCF_REC_DTYPE = np.dtype([("t_name_off", "<u8"), ("q_name_off", "<u8"), ("t_name_len", "<u4"), ("q_name_len", "<u4"),
+                              ("t_start", "<u8"), ("q_start", "<u8"), ("q_size", "<u8"), ("q_neg", "<u4"), ("pad", "<u4")])
+
+
 class Engine:
     def __init__(self, device=0, lib=None):
         self.lib = lib if lib is not None else _lib.load()
@@ -291,6 +296,19 @@ class Engine:
         self._check(self.lib.wga_maf_call_runs(self.ctx, n, _p(rows), _p(t_off), _p(q_off), _p(cols),
                                                _p(run_cnt), _p(runs), _p(run_off)))
         return run_cnt
+
+    def maf_call_vcf(self, n, rows, t_off, q_off, cols, runs, run_off, recs, names, snp, inv, svlen, chunk_size,
+                     nbytes=None, err=None, out=None, out_off=None):
+        """the rules and VCF rows of `call` on MAF (wga_maf_call_vcf, K19) on K4's run list: count pass when out is None
+        (returns nbytes, err), fill pass otherwise.  recs: n x MAF_VCF_REC_DTYPE"""
+        if out is None:
+            nbytes = nbytes if nbytes is not None else self.empty(n, np.uint64)
+            err = err if err is not None else self.empty(n, VCF_ERR_DTYPE)
+        self._check(self.lib.wga_maf_call_vcf(self.ctx, n, _p(rows), _p(t_off), _p(q_off), _p(cols), _p(runs), _p(run_off),
+                                              _p(recs), _p(names), 1 if snp else 0, 1 if inv else 0, int(svlen), int(chunk_size),
+                                              _p(nbytes) if out is None else None, _p(err) if out is None else None,
+                                              _p(out), _p(out_off)))
+        return nbytes, err
 
     def cigar_tokenise(self, n, text, text_off, op_cnt=None, err=None, ops=None, op_off=None):
         """device tokeniser (wga_cigar_tokenise): count pass when ops is None, fill pass otherwise"""
