@@ -52,9 +52,17 @@ for chunks in [int(x) for x in (sys.argv[1:] or ["1", "2", "4", "8"])]:
             x = eng.empty(int(nbytes), np.uint8)
             eng.sync()
             t1 = time.perf_counter()
-            x.free()
+            keep = os.environ["K5_COLD"] == "2"       # 2: the three stay allocated side by side (fresh memory every time), freed at the end
+            if keep:
+                held = globals().setdefault("_held", [])
+                held.append(x)
+            else:
+                x.free()
             eng.sync()
-            print("hipMalloc of %.2f GB (%s): %.0f ms, free %.0f ms" % (nbytes / 1e9, name, (t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3), flush=True)
+            print("hipMalloc of %.2f GB (%s): %.0f ms%s" % (nbytes / 1e9, name, (t1 - t0) * 1e3, "" if keep else ", free %.0f ms" % ((time.perf_counter() - t1) * 1e3)), flush=True)
+        for x in globals().get("_held", []):
+            x.free()
+        globals()["_held"] = []
     for rep in range(reps):
         if mode in ("sep", "both"):
             cov.zero_()

@@ -870,7 +870,7 @@ def test_maf_call_vcf_at_size(gpu):
     n_sv = int((((rcls == 1) | (rcls == 2)) & (rlen > svlen) & ok_prev).sum())
     n_negb = int((neg & ((~tg).sum(1) > 0)).sum())
     nl = int((text == 10).sum())
-    assert int((text == 9).sum()) == 9 * nl                      # ten columns a row
+    assert int((text == 9).sum()) == 9 * nl, (int((text == 9).sum()), nl, n_text)   # ten columns a row
     host = text.cpu().numpy().tobytes()
     # an <INV> row per chunk of a '-' block that holds a target base: a block is cut behind its last gap segment of `svlen`
     # columns (caller.rs:186-216), so one or two per block — the sample below pins the cuts exactly

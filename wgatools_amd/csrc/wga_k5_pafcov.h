@@ -520,7 +520,6 @@ struct ScanU32 {
  * look-back: window i waits for the SUMS of the windows in front of it, which they publish as soon as their own replay is
  * done, not for their look-backs), and writes counts.  `rng_lo` / `rng_hi` are the targets' [first, one past last] counter
  * indices in ascending order, disjoint (the host sorts them). */
-#define WGA_COV_SW(i) ((i) + ((i) >> 5)) /* a counter's place in the padded LDS window */
 #define WGA_COV_WAVES 8u
 #define WGA_COV_BLOCK (64u * WGA_COV_WAVES)
 #ifndef WGA_COV_AHEAD
@@ -599,9 +598,10 @@ __global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __r
                                                                const u64* __restrict__ win_off, int* cov, u64 n_cov,
                                                                const u64* __restrict__ rng_lo, const u64* __restrict__ rng_hi,
                                                                u32 n_rng, u64* win_state, const u32* __restrict__ order) {
-  /* one pad word per 32 counters (WGA_COV_SW): the marks -> counts scan gives a thread 16 consecutive counters, and thread t's first
-   * one would otherwise lie in bank 0 or 16 for every t — 43 % of that pass's LDS cycles were bank conflicts (profiles/r05_k1_k5_counters.txt) */
-  __shared__ int s_win[WGA_COV_WIN + WGA_COV_WIN / 32u];
+  /* (round 6: one pad word per 32 counters against the count pass's bank conflicts — 43 % of its LDS cycles,
+   * profiles/r05_k1_k5_counters.txt — measured at configs[3]'s stated size: 70.7 ms against 69.3-69.6 without.  LDS is not what the
+   * pass waits for; the padding was taken out again) */
+  __shared__ int s_win[WGA_COV_WIN];
   __shared__ u32 s_ws[WGA_COV_WAVES + 1];
   __shared__ u32 s_wf[WGA_COV_WAVES];
   constexpr int D = WGA_COV_AHEAD;
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __r
   }
   /* the marks are added to zeros (and only counters with a mark are written) or, when counts are made, to what the array held */
 #pragma unroll
-  for (u32 j = 0; j < PER; j++) s_win[WGA_COV_SW(tid + j * WGA_COV_BLOCK)] = FINAL ? old[j] : 0;
+  for (u32 j = 0; j < PER; j++) s_win[tid + j * WGA_COV_BLOCK] = FINAL ? old[j] : 0;
   __syncthreads();
   /* a wave's pieces one after the other: dq[k] / wq[k] = descriptor / first ops of the piece k rounds behind the current one */
   const u64 p0 = p_lo + wave;
@@ -680,8 +680,8 @@ __global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __r
           for (int e = 0; e < 4; e++) {
             const u32 nc = bit_mask(WGA_COV_NOTCNT_BITS, w[e] & 15u);
             const u32 ku = r | nc, kd = (r + (w[e] >> 4)) | nc;
-            if (ku < Lc) atomicAdd(&s_win[WGA_COV_SW(ku)], 1);
-            if (kd < Lc) atomicAdd(&s_win[WGA_COV_SW(kd)], -1);
+            if (ku < Lc) atomicAdd(&s_win[ku], 1);
+            if (kd < Lc) atomicAdd(&s_win[kd], -1);
             r += lm[e];
           }
           rb += wave_last_u32(inc);
@@ -716,8 +716,8 @@ __global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __r
             const u64 pe = pos + len;
             const bool up = counts && pos - w0 < (u64)WGA_COV_WIN;
             const bool down = counts && pe < pc.limit && pe - w0 < (u64)WGA_COV_WIN;
-            if (up) atomicAdd(&s_win[WGA_COV_SW((u32)(pos - w0))], 1);
-            if (down) atomicAdd(&s_win[WGA_COV_SW((u32)(pe - w0))], -1);
+            if (up) atomicAdd(&s_win[(u32)(pos - w0)], 1);
+            if (down) atomicAdd(&s_win[(u32)(pe - w0)], -1);
             pos += (in && cov_op_moves(code)) ? len : 0ull;
           }
           pos_base += step_moves;
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __r
     /* the window goes to memory; counters without a mark are not touched */
 #pragma unroll
     for (u32 j = 0; j < PER; j++) {
-      const int v = s_win[WGA_COV_SW(tid + j * WGA_COV_BLOCK)];
+      const int v = s_win[tid + j * WGA_COV_BLOCK];
       if (v) cov[w0 + tid + j * WGA_COV_BLOCK] = old[j] + v;
     }
     return;
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __r
   if (plain) {
 #pragma unroll
     for (u32 e = 0; e < PER; e++) {
-      run += (u32)s_win[WGA_COV_SW(c0 + e)];
+      run += (u32)s_win[c0 + e];
       v[e] = run;
     }
   } else {
@@ -777,8 +777,8 @@ __global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __r
         run = 0;
       }
       if (inside) {
-        run += (u32)s_win[WGA_COV_SW(c0 + e)];
-        s_win[WGA_COV_SW(c0 + e)] = (int)run;
+        run += (u32)s_win[c0 + e];
+        s_win[c0 + e] = (int)run;
         inmask |= 1u << e;
       }
     }
@@ -827,14 +827,14 @@ __global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __r
   const u32 add = ps + (pf ? 0u : s_ws[WGA_COV_WAVES]);
   if (plain) { /* whole lines through LDS */
 #pragma unroll
-    for (u32 e = 0; e < PER; e++) s_win[WGA_COV_SW(c0 + e)] = (int)(v[e] + add);
+    for (u32 e = 0; e < PER; e++) s_win[c0 + e] = (int)(v[e] + add);
     __syncthreads();
 #pragma unroll
-    for (u32 j = 0; j < PER; j++) cov[w0 + tid + j * WGA_COV_BLOCK] = s_win[WGA_COV_SW(tid + j * WGA_COV_BLOCK)];
+    for (u32 j = 0; j < PER; j++) cov[w0 + tid + j * WGA_COV_BLOCK] = s_win[tid + j * WGA_COV_BLOCK];
   } else { /* counters between the ranges stay as they are */
 #pragma unroll 1
     for (u32 e = 0; e < PER; e++)
-      if ((inmask >> e) & 1u) cov[w0 + c0 + e] = (int)((u32)s_win[WGA_COV_SW(c0 + e)] + (e < lead ? add : 0u));
+      if ((inmask >> e) & 1u) cov[w0 + c0 + e] = (int)((u32)s_win[c0 + e] + (e < lead ? add : 0u));
   }
 }
 
