@@ -50,7 +50,7 @@
 #define WGA_MAF_FOLD_STEPS 28u /* a piece folds its packed totals every 28 steps (57 344 columns); the emulator build of the tests every few */
 #endif
 #ifndef WGA_MAF_BLOCKS
-#define WGA_MAF_BLOCKS 6 /* blocks per CU the register budget of the stream kernels is sized for */
+#define WGA_MAF_BLOCKS 5 /* blocks per CU the register budget of the stream kernels is sized for: 96 VGPRs, no scratch.  Measured at 200 000 x 1 500 (profiles/r06_maf_blocks_per_cu.txt): 4: K3 0.116 ms, 5: 0.119, 6 (80 VGPRs, a few spilled): 0.131-0.134, 8 (64, spills in the loop): 0.220 */
 #endif
 
 __device__ __forceinline__ u32 popc32(u32 x) { return (u32)__builtin_popcount(x); }
