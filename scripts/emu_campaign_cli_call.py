@@ -1,5 +1,5 @@
 """`wgatools call` and `maf2paf` of the emulator build on random MAF blocks with random flags against the oracle's VCF / cg:Z: text:
-python scripts/emu_campaign_cli_call.py <first seed> <seconds>.  CPU only; results: profiles/r05_emu_campaign.txt."""
+python scripts/emu_campaign_cli_call.py <first seed> <seconds>.  CPU only; results: profiles/r06_emu_campaign.txt."""
 import os, sys, tempfile, time, traceback
 sys.path[:0] = ['/root/repo', '/root/repo/tests', '/root/repo/oracle']
 import numpy as np

@@ -1,5 +1,5 @@
 """MAF walks, call events, chain text, dotplot and pafpseudo on the emulator with seeds the suite does not use:
-python scripts/emu_campaign_walks.py <first seed> <seconds>.  CPU only; results: profiles/r05_emu_campaign.txt."""
+python scripts/emu_campaign_walks.py <first seed> <seconds>.  CPU only; results: profiles/r06_emu_campaign.txt."""
 import sys, time, traceback
 sys.path[:0] = ['/root/repo', '/root/repo/tests', '/root/repo/oracle']
 import numpy as np
@@ -31,8 +31,13 @@ while time.time() - t0 < budget:
                 if rng.random() < 0.85:
                     q[j:j + 4] = t[j:j + 4]
         pairs.append((t, bytes(q[:max(len(q), 0)]))); strands.append(int(rng.integers(0, 2)))
-    attempt("maf_pair %d" % s, lambda: pc.check_maf_pair(eng, pairs, strands))
-    attempt("maf_call %d" % s, lambda: pc.check_maf_call_runs(eng, pairs))
+    # round 6: the stream walks' knobs at random — blocks per wave, where a block counts as long, the piece size (tiny pieces,
+    # pieces of a few steps: the packed totals are folded every three steps in this build)
+    grp, lng, pcs = int(rng.integers(0, 9)), int(rng.choice([32768, 100, 500, 2100])), int(rng.choice([16384, 17, 64, 1000, 2048, 7000]))
+    eng.set_param("maf_group", grp); eng.set_param("maf_long_cols", lng); eng.set_param("maf_piece_cols", pcs)
+    attempt("maf_pair %d (group %d long %d piece %d)" % (s, grp, lng, pcs), lambda: pc.check_maf_pair(eng, pairs, strands))
+    attempt("maf_call %d (group %d long %d piece %d)" % (s, grp, lng, pcs), lambda: pc.check_maf_call_runs(eng, pairs))
+    eng.set_param("maf_group", 0); eng.set_param("maf_long_cols", 32768); eng.set_param("maf_piece_cols", 16384)
     attempt("dotplot_maf %d" % s, lambda: pc.check_dotplot_maf(eng, pairs, strands, int(rng.integers(0, 50))))
     n = int(rng.integers(1, 40)); mean = int(rng.choice([3, 30, 200, 900]))
     b = synth.make_paf_batch(s, n, mean, 60000, use_m=bool(rng.integers(0, 2)))
