@@ -1303,6 +1303,46 @@ def test_fixture_maf_paf_maf_roundtrip(cli, tmp_path):
     assert out2.decode().rstrip("\n").split("\t")[12:] == f[12:]
 
 
+def test_call_paf_readme_golden_through_maf2paf(cli, tmp_path):
+    """README.md:317-343 shows ONE VCF for `call test/test.maf -s -l0` and for the same call on the PAF with the two FASTA files
+    (`-f paf`).  The repository holds neither test.paf nor the FASTA files, but both follow from the fixture: `maf2paf` makes
+    the record (K3's runs as cg:Z: text), the block's gap-stripped rows are the contigs' aligned stretches.  Contigs that hold
+    just those stretches move every coordinate by the s lines' start fields — the golden rows are moved by the same amounts —
+    and then `call -f paf` (K7 + K16: caller.rs:610-822) must print the README's rows: a reference-held vector for maf2paf's
+    CIGAR and for the PAF caller (SNP rows: the first 8 columns, the README predates their QI field)"""
+    maf = open(os.path.join(GOLDEN, "test.maf"), "rb").read().decode()
+    (_, tn, ts, tz, _, _, trow), (_, qn, qs, qz, _, _, qrow) = [ln.split() for ln in maf.splitlines() if ln.startswith("s")]
+    ts, qs = int(ts), int(qs)
+    rc, out, err = run(cli, "maf2paf", os.path.join(GOLDEN, "test.maf"))
+    assert rc == 0, err
+    f = out.decode().rstrip("\n").split("\t")
+    t_seq, q_seq = trow.replace("-", ""), qrow.replace("-", "")
+    f[1], f[2], f[3] = str(len(q_seq)), "0", str(len(q_seq))
+    f[6], f[7], f[8] = str(len(t_seq)), "0", str(len(t_seq))
+    paf = tmp_path / "t.paf"
+    paf.write_text("\t".join(f) + "\n")
+    t_fa, q_fa = tmp_path / "t.fa", tmp_path / "q.fa"
+    t_fa.write_text(">%s\n%s\n" % (tn, t_seq))
+    q_fa.write_text(">%s\n%s\n" % (qn, q_seq))
+    rc, out, err = run(cli, "call", "-f", "paf", str(paf), "--target", str(t_fa), "-q", str(q_fa), "-s", "-l0")
+    assert rc == 0, err
+    got = [ln for ln in out.decode().splitlines() if not ln.startswith("#")]
+    golden = [ln for ln in open(os.path.join(GOLDEN, "readme_call_test_maf_s_l0.vcf")).read().splitlines() if not ln.startswith("#")]
+    assert len(got) == len(golden) == 11
+    for g, w in zip(got, golden):
+        gc, wc = g.split("\t"), w.split("\t")
+        wc[1] = str(int(wc[1]) - ts)                                      # POS on the cut-down contig
+        if wc[7] != ".":
+            info = dict(kv.split("=") for kv in wc[7].split(";"))
+            info["END"] = str(int(info["END"]) - ts)
+            wc[7] = ";".join("%s=%s" % (k, info[k]) for k in [kv.split("=")[0] for kv in w.split("\t")[7].split(";")])
+            name, a, b, strand = wc[9].split(":")[1].split("@")        # 1|1:<query>@<a>@<b>@P
+            wc[9] = "1|1:%s@%d@%d@%s" % (name, int(a) - qs, int(b) - qs, strand)
+            assert gc == wc, (g, w)
+        else:
+            assert gc[:8] == wc[:8] and gc[8] == "GT:QI", (g, w)
+
+
 def test_fixture_paf_chain_paf_roundtrip(cli, tmp_path):
     """test/testdotplot.paf -> paf2chain -> chain2paf: coordinates (the '+' record's; the '-' record's as the reference's header
     arithmetic leaves them), strands and the CIGAR of both records come back

@@ -45,6 +45,28 @@ def test_readme_vcf_golden(test_maf):
             assert gc[8] == "GT:QI" and gc[9].startswith("1|1:query.chr8@") and gc[9].endswith("@P")
 
 
+def test_readme_vcf_golden_through_the_paf_caller(test_maf):
+    """README.md:317-343 gives ONE output for `call test/test.maf -s -l0` and for `call test/test.paf -s -l0 --target .. --query ..
+    -f paf`: the PAF flavour of the caller (caller.rs:610-822) on the CIGAR parse_maf_seq_to_cigar (cigar.rs:344-432) makes of
+    the fixture's rows must print the same rows.  That ties two more restatements to a vector the reference holds: the VCF's
+    nine SNP, one INS and one DEL positions determine every run length of the CIGAR (109=1D243=1X12=...: eight X ops over nine
+    columns, one D, one I), so a wrong CIGAR or a wrong fold would move a row"""
+    t, q = test_maf
+    golden = [l.rstrip("\n") for l in open(os.path.join(GOLDEN, "readme_call_test_maf_s_l0.vcf")) if not l.startswith("#")]
+    _, cg = orc.parse_maf_seq_to_cigar(t["seq"], q["seq"], q["strand"] == "-")
+    assert cg == "109=1D243=1X12=1X138=1X177=1X31=1X133=8I18=1X100=2X7=1X22="
+    tseq, qseq = t["seq"].replace(b"-", b""), q["seq"].replace(b"-", b"")
+    # paf.rs:221-237 fetches [start, end] inclusive: one base behind the aligned stretch
+    got = orc.call_within_var_paf(t["name"], q["name"], "cg:Z:" + cg, tseq + b"A", qseq + b"A", t["start"], t["start"] + t["align"],
+                                  q["start"], q["start"] + q["align"], q["strand"] == "-", True, 0).splitlines()
+    assert len(got) == len(golden) == 11
+    for g, e in zip(got, golden):
+        gc, ec = g.split("\t"), e.split("\t")
+        assert gc[:8] == ec[:8]
+        if ec[7] != ".":
+            assert gc[8:] == ec[8:]
+
+
 def test_snp_query_positions(test_maf):
     """Appendix B.5: QI positions of the nine SNP rows"""
     qpos = [int(l.split("\t")[9].split("@")[1]) for l in _call(test_maf, True, 0).splitlines()
