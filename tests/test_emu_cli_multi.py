@@ -62,6 +62,7 @@ def test_maf_commands_blocks_per_device(cli, tmp_path, monkeypatch, gpus):
     cc.test_call_readme_golden(cli)
     cc.test_call_synthetic_blocks(cli, tmp_path, True, False, 3, 64)
     cc.test_call_query_selection(cli, tmp_path)
+    cc.test_call_maf_bad_base_ends_in_front_of_its_chunk(cli, tmp_path)
     if gpus == "2":
         cc.test_call_and_maf2paf_on_a_long_block(cli, tmp_path)
         cc.test_maf_streaming_pieces_give_the_same_bytes(cli, tmp_path)

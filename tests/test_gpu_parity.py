@@ -767,6 +767,14 @@ def test_maf_config3_full_size_properties(gpu):
         cstart = torch.ones_like(ccls, dtype=torch.bool)
         cstart[:, 1:] = ccls[:, 1:] != ccls[:, :-1]
         assert bool((crun[a:b] == cstart.sum(1)).all())
+    # ... and against the ORACLE itself on a sample of the 2 000 000 blocks (orc_parse_maf_seq_to_cigar, cigar.rs:344-432: the
+    # eleven counters and the run count of the cg:Z: text), so that the at-size check does not rest on torch expectations alone
+    ch, rh = counts.cpu().numpy(), run_cnt.cpu().numpy()
+    for i in list(range(0, n, n // 120)) + [n - 1]:
+        tb_, qb_ = t[(i % 200_000) * L:(i % 200_000 + 1) * L].cpu().numpy().tobytes(), q[(i % 200_000) * L:(i % 200_000 + 1) * L].cpu().numpy().tobytes()
+        exp_counts, exp_txt = orc.parse_maf_seq_to_cigar(tb_, qb_, int(strand[i]))
+        assert tuple(int(x) for x in ch[i]) == exp_counts, i
+        assert int(rh[i]) == sum(1 for c in exp_txt if not c.isdigit()), i
     # EXACT on a 200 000-block slice: the whole run list of the caller walk — every run's start column, class and the non-gap
     # target / query characters in front of it (what the event rules of caller.rs:444-608 read) — against torch
     n2 = 200_000
