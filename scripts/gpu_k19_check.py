@@ -8,6 +8,7 @@ import oracle_py as orc
 import test_gpu_parity as tg
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 svlen = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
 dev = torch.device("cuda", 0)
 eng = engine.Engine(0)
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -29,20 +30,20 @@ recs["q_size"] = 4_000_000_000; recs["q_neg"] = (np.arange(n) % 10 == 0).astype(
 d_recs = torch.from_numpy(recs.view(np.uint8).reshape(n, -1).copy()).to(dev)
 d_names = torch.tensor(list(b"ref.chr1qry.chr1\0"), dtype=torch.uint8, device=dev)
 nb = torch.zeros(n, dtype=torch.int64, device=dev); err = torch.zeros((n, 2), dtype=torch.int64, device=dev)
-eng.maf_call_vcf(n, rows, t_off, q_off, cols, runs, off, d_recs, d_names, True, True, svlen, 1_000_000, nbytes=nb, err=err)
+eng.maf_call_vcf(n, rows, t_off, q_off, cols, runs, off, d_recs, d_names, True, True, svlen, chunk, nbytes=nb, err=err)
 torch.cuda.synchronize()
 print("errors:", int((err[:, 0] != -1).sum()))
 toff = torch.zeros(n + 1, dtype=torch.int64, device=dev); toff[1:] = torch.cumsum(nb, 0)
 ntext = int(toff[-1])
 text = torch.zeros(ntext + 64, dtype=torch.uint8, device=dev)
-eng.maf_call_vcf(n, rows, t_off, q_off, cols, runs, off, d_recs, d_names, True, True, svlen, 1_000_000, out=text, out_off=toff)
+eng.maf_call_vcf(n, rows, t_off, q_off, cols, runs, off, d_recs, d_names, True, True, svlen, chunk, out=text, out_off=toff)
 torch.cuda.synchronize()
 host = text[:ntext].cpu().numpy().tobytes()
 print("rows", host.count(b"\n"), "tabs", host.count(b"\t"), "zeros", host.count(b"\0"), "bytes", ntext)
 th, qh, tof = t.cpu().numpy(), q.cpu().numpy(), toff.cpu().numpy()
 bad = 0
 for i in range(n):
-    want = orc.call_var_maf_record("ref.chr1", "qry.chr1", th[i*L:(i+1)*L].tobytes(), qh[i*L:(i+1)*L].tobytes(), int(recs["t_start"][i]), int(recs["q_start"][i]), int((qh[i*L:(i+1)*L] != 45).sum()), 4_000_000_000, bool(recs["q_neg"][i]), True, True, svlen, 1_000_000)
+    want = orc.call_var_maf_record("ref.chr1", "qry.chr1", th[i*L:(i+1)*L].tobytes(), qh[i*L:(i+1)*L].tobytes(), int(recs["t_start"][i]), int(recs["q_start"][i]), int((qh[i*L:(i+1)*L] != 45).sum()), 4_000_000_000, bool(recs["q_neg"][i]), True, True, svlen, chunk)
     got = host[int(tof[i]):int(tof[i+1])]
     if got != want.encode():
         bad += 1
@@ -53,4 +54,4 @@ for i in range(n):
                 a = w[k] if k < len(w) else None; b = g[k] if k < len(g) else None
                 if a != b:
                     print("  row", k, "\n   want", a, "\n   got ", b); break
-print("bad blocks", bad, "of", n)
+print("bad blocks", bad, "of", n, "(svlen %d, chunk %d)" % (svlen, chunk))
