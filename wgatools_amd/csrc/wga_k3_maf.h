@@ -460,9 +460,9 @@ __global__ __launch_bounds__(1024) void k_maf_long_plan(wga_maf_long_hdr* hdr, c
     if (x == 0u) hdr->n_long = 0u, hdr->np = 0u;
     return;
   }
+  /* the configured piece size, unless that would make more than WGA_MAF_PIECE_BUDGET pieces (beyond one per block): then whole steps */
   u64 piece = (lc + WGA_MAF_PIECE_BUDGET - 1u) / WGA_MAF_PIECE_BUDGET;
-  piece = (piece + WGA_MAF_STEP - 1u) / WGA_MAF_STEP * WGA_MAF_STEP;
-  if (piece < cfg_piece_cols) piece = cfg_piece_cols;
+  piece = piece <= cfg_piece_cols ? cfg_piece_cols : (piece + WGA_MAF_STEP - 1u) / WGA_MAF_STEP * WGA_MAF_STEP;
   const u32 per = (nl + 1023u) / 1024u, e0 = x * per, e1 = e0 + per < nl ? e0 + per : nl;
   u64 mine = 0;
   for (u32 e = e0; e < e1; e++) mine += (cols[long_list[e]] + piece - 1u) / piece;
