@@ -140,8 +140,12 @@ int wga_ctx_reset_stream(wga_ctx*);
  * "cov_spin_limit" (default 4096): wga_pafcov_accumulate's list pass polls a tile sum this often before it adds up the ops itself.
  * "op_long_ops" (default 16384) / "op_piece_ops" (8192, a multiple of 256): the op walks with one wave per record (call
  * events, chain lines, dotplot segments) cut records beyond the first into pieces of at most the second and walk the pieces
- * over the whole chip; "maf_long_cols" (32768) / "maf_piece_cols" (16384): the same for the MAF column walks.  The tests set
- * small values to reach those paths with small inputs. */
+ * over the whole chip; "maf_long_cols" (32768; 61440 at most: longer blocks are long whatever it says) / "maf_piece_cols"
+ * (16384): the same for the MAF column walks — a long block is listed, planned and walked in pieces on the device (no
+ * read-back); when the configured piece size would make more than 32 768 pieces beyond one per long block, the piece grows
+ * to whole steps of 2 048 columns that stay inside that budget.  "maf_group" (0 .. 8, default 0 = by the number of blocks:
+ * n / 24 576, at least 1, at most 8): consecutive MAF blocks one wave walks as one column stream.  The tests set small values
+ * to reach those paths with small inputs. */
 int wga_ctx_set_param(wga_ctx*, const char* name, int64_t value);
 /* Read back: "cov_spin_limit" (the setting), "expand_drain_min" = what the last wga_paf2maf_expand used,
  * "expand_variant" / "expand_job_tiles" / "pseudo_variant" (the settings), "expand_variant_used" (what the last
