@@ -563,6 +563,25 @@ def test_call_maf_bad_base_ends_in_front_of_its_chunk(cli, tmp_path):
     assert all(p <= t_before + 1 for p in pos)              # nothing at or behind the bad column's chunk end is there
 
 
+def test_call_maf_gz_output_in_pieces(cli, tmp_path):
+    """`call -o out.vcf.gz` over a MAF read in many pieces: every piece's rows are deflated where they lie (K18) and leave on the
+    helper thread while the next piece is walked; the members inflate to the plain file's bytes = the oracle's"""
+    import gzip
+    blocks = _synth_maf_blocks(77, 40, 1200)
+    maf = tmp_path / "in.maf"
+    _write_maf(maf, blocks)
+    os.environ["WGA_CHUNK_BYTES"] = "20000"
+    try:
+        rc1, _, err1 = run(cli, "call", str(maf), "-s", "-i", "-l", "3", "-o", str(tmp_path / "plain.vcf"), "-r")
+        rc2, _, err2 = run(cli, "call", str(maf), "-s", "-i", "-l", "3", "-o", str(tmp_path / "z.vcf.gz"), "-r")
+    finally:
+        os.environ.pop("WGA_CHUNK_BYTES", None)
+    assert rc1 == 0 and rc2 == 0, (err1, err2)
+    plain = open(tmp_path / "plain.vcf", "rb").read()
+    assert gzip.open(tmp_path / "z.vcf.gz", "rb").read() == plain
+    assert plain.decode() == _expected_vcf(blocks, "sample", True, True, 3, 1000000)
+
+
 def test_call_query_selection(cli, tmp_path):
     """caller.rs:62-108: --query-name / --query-regex pick the query s-line; blocks without it are skipped"""
     blocks = _synth_maf_blocks(5, 4, 400)
