@@ -159,7 +159,7 @@ def extra_shape(eng, synth, pipeline, torch, dev, seed, records, mean_ops, pool_
     return ms, frac
 
 
-def allocation_spread(eng, pipeline, torch, tb, first_ms, n_alloc=4, steps=3):
+def allocation_spread(eng, pipeline, torch, tb, first_ms, n_alloc=4, steps=3, warm=2):
     """The row kernel on further FRESH output allocations of this process, all held at once (so they are different memory):
     the kernel's time depends on where the 15 GB of rows land (+- 5 % from box to box and from allocation to allocation:
     VERDICT r05), so the line carries min / median / max over `1 + n_alloc` allocations beside the first one's number.
@@ -172,7 +172,7 @@ def allocation_spread(eng, pipeline, torch, tb, first_ms, n_alloc=4, steps=3):
     for out in outs:
         job = pipeline.Paf2MafStatJob(eng, tb, out=out)
         job.bind_stream()
-        for _ in range(2):    # first touch of this buffer
+        for _ in range(max(2, warm)):    # first touch of this buffer
             job.step()
         torch.cuda.synchronize()
         eng.expand_timing()
@@ -189,8 +189,10 @@ def allocation_spread(eng, pipeline, torch, tb, first_ms, n_alloc=4, steps=3):
     fr = lambda t: ab / (t * 1e-3) / 1e9 / HBM_PEAK_GBS
     return {"allocations": len(ms), "k_ms_by_allocation": ms, "k_ms_min": min(ms), "k_ms_median": statistics.median(ms),
             "k_ms_max": max(ms), "frac_min": fr(max(ms)), "frac_median": fr(statistics.median(ms)), "frac_max": fr(min(ms)),
-            "note": "allocation 0 = the timed steps' buffer (the headline); the others are fresh buffers held side by side, "
-                    "3 timed launches each; rocprofv3's average over one run of this command covers all of them"}
+            "launches_per_allocation": max(2, warm) + steps,
+            "note": "allocation 0 = the timed steps' buffer (the headline); the others are fresh buffers held side by side, with as "
+                    "many warm-up and timed launches each as the headline: rocprofv3's average over one run of this command weighs "
+                    "the five allocations equally"}
 
 
 def e2e_leg(tb, synth, torch, check=2):
@@ -656,7 +658,8 @@ def main():
                 result["cpu_baseline"]["parity_spot_check"] = "%d records bit-identical to oracle rows" % len(step_idx)
         if world == 1 and not args.no_spread and not args.param:
             try:   # additional information: never at the price of the headline line
-                result["roofline"]["allocation_spread"] = allocation_spread(eng, pipeline, torch, tb, k_expand)
+                result["roofline"]["allocation_spread"] = allocation_spread(eng, pipeline, torch, tb, k_expand, steps=args.steps,
+                                                                            warm=args.warmup)
             except Exception as e:  # noqa: BLE001
                 result["roofline"]["allocation_spread"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if world == 1 and not args.no_extras and not args.param and args.records == 100_000 and args.mean_ops == 5000:
