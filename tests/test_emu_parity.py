@@ -478,6 +478,8 @@ def test_pafcov_format(emu):
     pc.check_pafcov_format(emu, b"huge", [7, 8], 18_446_744_073_709_551_000)
     pc.check_pafcov_format(emu, b"", [5], 41)
     pc.check_pafcov_format(emu, b"none", [], 0)
+    pc.check_pafcov_format(emu, b"a_target_name_longer_than_the_staging_buffer_takes_512_lines_of", rng.integers(0, 500, 1100), 7)
+    pc.check_pafcov_format(emu, b"c", rng.integers(0, 9, 512 * 3), 999_999_000)   # exactly three blocks, a digit roll-over inside
 
 
 def test_device_tokeniser_random_bytes(emu):

@@ -409,6 +409,9 @@ def test_pafcov_format(gpu):
     pc.check_pafcov_format(gpu, b"big", rng.integers(0, 70000, 30), 9_999_999_990)
     pc.check_pafcov_format(gpu, b"huge", [7, 8], 18_446_744_073_709_551_000)
     pc.check_pafcov_format(gpu, b"", [5], 41)
+    pc.check_pafcov_format(gpu, b"a_target_name_longer_than_the_staging_buffer_takes_512_lines_of", rng.integers(0, 500, 1100), 7)
+    pc.check_pafcov_format(gpu, b"c", rng.integers(0, 9, 512 * 3), 999_999_000)   # exactly three blocks, a digit roll-over inside
+    pc.check_pafcov_format(gpu, b"chr12", rng.integers(0, 300, 2_000_001), 99_000_000)
     pc.check_pafcov_format(gpu, b"none", [], 0)
 
 

@@ -1306,7 +1306,7 @@ int wga_pafcov_format(wga_ctx* c, const uint8_t* d_name, uint32_t name_len, cons
   f.name_len = name_len;
   if (!d_out) return run_scan(c, f, count, (u64*)d_line_off);
   if (count == 0) return WGA_OK;
-  WGA_LAUNCH(k_pafcov_format, (count + 255u) / 256u, WGA_BLOCK, c->stream, f, count, d_name,
+  WGA_LAUNCH(k_pafcov_format, (count + WGA_BED_LINES - 1u) / WGA_BED_LINES, WGA_BLOCK, c->stream, f, count, d_name,
              (const u64*)d_line_off, d_out);
   LAUNCH_CHECK();
   return WGA_OK;

@@ -5,7 +5,7 @@
 #ifndef WGA_K11_BRIDGES_H
 #define WGA_K11_BRIDGES_H
 
-#include "wga_kernels.h"
+#include "wga_k9_bed.h" /* dec_digits, dec_write, lds_text_flush */
 
 /* ============================================================================================ */
 /* K11: bridges between the run / data-line lists and the packed-op and CIGAR-text forms        */
@@ -130,24 +130,6 @@ __global__ __launch_bounds__(256) void k_elem_rec_totals(u32 n, const u64* __res
   const u32 r = blockIdx.x * 256u + threadIdx.x;
   if (r < n) cnt[r] = esc[elem_off[r + 1]] - esc[elem_off[r]];
 }
-/* bytes [a, a + total) of an LDS text buffer go to gb + a (gb 16-byte aligned: the buffer mirrors the output's position
- * inside its 16-byte group): whole groups with 16-byte stores, the ragged head and tail (< 16 bytes each) by bytes.
- * `nthr` threads share the work (a wave or a block; the caller synchronises around the call). */
-__device__ __forceinline__ void lds_text_flush(const u8* tbuf, u32 a, u32 total, u8* gb, u32 tid, u32 nthr) {
-  const u32 end = a + total;
-  const u32 g_lo = (a + 15u) >> 4, g_hi = end >> 4; /* whole 16-byte groups [g_lo, g_hi) */
-  for (u32 g = g_lo + tid; g < g_hi; g += nthr) *(u32x4_a16*)(gb + 16u * g) = *(const u32x4_a16*)(tbuf + 16u * g);
-  const u32 head_end = 16u * g_lo < end ? 16u * g_lo : end;           /* [a, head_end) */
-  const u32 tail_beg = 16u * g_hi > head_end ? 16u * g_hi : head_end; /* [tail_beg, end) */
-  if (tid < 16u) {
-    const u32 x = a + tid;
-    if (x < head_end) gb[x] = tbuf[x];
-  } else if (tid < 32u) {
-    const u32 x = tail_beg + (tid - 16u);
-    if (x < end) gb[x] = tbuf[x];
-  }
-}
-
 /* One thread per element, 256 consecutive elements per block.  The records of the block's first and last element are
  * found once (two wave-wide searches per block); every thread then looks inside that window — one record in nearly every block.
  * A block whose elements belong to ONE record writes one contiguous stretch of that record's output: its threads put

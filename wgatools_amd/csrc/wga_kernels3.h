@@ -22,8 +22,8 @@
 #ifndef WGA_KERNELS3_H
 #define WGA_KERNELS3_H
 
-#include "wga_k11_bridges.h" /* lds_text_flush */
-#include "wga_k10_chain.h"   /* dec_digits, dec_write */
+#include "wga_k11_bridges.h"
+#include "wga_k10_chain.h"
 
 struct wga_vcf_rec_dev { /* = wga_vcf_rec (wga_hip.h) */
   u64 t_name_off, q_name_off; /* into `names` */
