@@ -83,3 +83,17 @@ def k4_fill():
 ms2 = timed(lambda: (k4_count(), k4_fill())) - ms
 print("K4 run list         : %.3f ms  %.0f GB/s (2 B/column + 24 B/run, %d runs)" % (ms2, (2 * tot + 24 * ncr) / ms2 / 1e6, ncr))
 print("blocks %d x %d columns = %.2e columns; strand- %.1f %%" % (n, L, tot, 100 * float(strand.float().mean())))
+if os.environ.get("WGA_MAF_K11", "1") != "0":      # maf2paf's cg:Z: text and maf2chain's ops from the K3 run list (K11)
+    tcnt = torch.zeros(n, dtype=torch.int64, device=dev)
+    def k11_count():
+        eng.maf_runs_cigar_text(n, nruns, runs, run_off, cols, cnt=tcnt)
+    ms = timed(k11_count)
+    toff = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    eng.exclusive_scan_u64(n, tcnt, toff)
+    nbytes = int(toff[-1].item())
+    text = torch.zeros(nbytes + 64, dtype=torch.uint8, device=dev)
+    def k11_fill():
+        eng.maf_runs_cigar_text(n, nruns, runs, run_off, cols, out=text, out_off=toff)
+    ms2 = timed(lambda: (k11_count(), k11_fill())) - ms
+    print("K11 runs -> cg:Z: text: count %.3f ms, fill %.3f ms  %.0f GB/s (8 B/run + %d B of text)" % (
+        ms, ms2, (8 * nruns + nbytes) / ms2 / 1e6, nbytes))

@@ -273,8 +273,14 @@ static int run_elems(wga_ctx* c, int kind, F f, u32 n, uint64_t n_elems, const u
                (const u64*)esc, (u64*)d_cnt);
     LAUNCH_CHECK();
   } else if (ne) {
-    WGA_LAUNCH(k_elem_fill<F>, (ne + 255u) / 256u, WGA_BLOCK, c->stream, f, n, ne, (const u64*)d_elem_off,
-               (const u64*)esc, d_out, (const u64*)d_out_off);
+    const u32 nb = (ne + 255u) / 256u;
+    void* ws;
+    if ((rc = ctx_scratch(c, (size_t)nb * sizeof(wga_elem_block), &ws))) return rc;
+    WGA_LAUNCH(k_elem_blocks, (nb + 255u) / 256u, WGA_BLOCK, c->stream, n, ne, (const u64*)d_elem_off, (const u64*)esc,
+               (const u64*)d_out_off, (wga_elem_block*)ws);
+    LAUNCH_CHECK();
+    WGA_LAUNCH(k_elem_fill<F>, nb, WGA_BLOCK, c->stream, f, n, ne, (const u64*)d_elem_off, (const u64*)esc, d_out,
+               (const u64*)d_out_off, (const wga_elem_block*)ws);
     LAUNCH_CHECK();
   }
   return WGA_OK;

@@ -130,8 +130,28 @@ __global__ __launch_bounds__(256) void k_elem_rec_totals(u32 n, const u64* __res
   const u32 r = blockIdx.x * 256u + threadIdx.x;
   if (r < n) cnt[r] = esc[elem_off[r + 1]] - esc[elem_off[r]];
 }
-/* One thread per element, 256 consecutive elements per block.  The records of the block's first and last element are
- * found once (two wave-wide searches per block); every thread then looks inside that window — one record in nearly every block.
+/* What a block of the fill needs to know before it can start, found once per block by a small kernel in front of the fill
+ * (one thread per block, two bisections): the records of its first and last element and, in units of the output, where the
+ * block's first unit goes when the block lies inside one record.  The fill's blocks used to search for their records themselves
+ * — two wave-wide searches of three dependent probes each, then out_off[r] and esc[elem_off[r]] behind them: five dependent
+ * round trips in front of the first useful load of a block that lives for a few microseconds (round 6). */
+struct __attribute__((aligned(16))) wga_elem_block {
+  u32 r_lo, r_hi;
+  u64 base; /* out_off[r_lo] + (units of r_lo's elements in front of the block) */
+};
+__global__ __launch_bounds__(256) void k_elem_blocks(u32 n, u32 ne, const u64* __restrict__ elem_off, const u64* __restrict__ esc,
+                                                     const u64* __restrict__ out_off, wga_elem_block* __restrict__ blocks) {
+  const u32 b = blockIdx.x * 256u + threadIdx.x;
+  const u64 x0 = (u64)b * 256u;
+  if (x0 >= (u64)ne) return;
+  const u64 x1 = x0 + 256u < (u64)ne ? x0 + 256u : (u64)ne;
+  wga_elem_block e;
+  e.r_lo = csr_find_rec(elem_off, n, x0);
+  e.r_hi = csr_find_rec(elem_off, n, x1 - 1u);
+  e.base = out_off[e.r_lo] + (esc[x0] - esc[elem_off[e.r_lo]]);
+  blocks[b] = e;
+}
+/* One thread per element, 256 consecutive elements per block (k_elem_blocks tells the block where it stands).
  * A block whose elements belong to ONE record writes one contiguous stretch of that record's output: its threads put
  * their units into an LDS buffer that mirrors the stretch's position inside its 16-byte group, and the stretch goes out
  * in 16-byte stores.  Blocks across a record border, or with more output than the buffer holds, write directly. */
@@ -139,24 +159,18 @@ __global__ __launch_bounds__(256) void k_elem_rec_totals(u32 n, const u64* __res
 template <typename F>
 __global__ __launch_bounds__(256) void k_elem_fill(F f, u32 n, u32 ne, const u64* __restrict__ elem_off,
                                                    const u64* __restrict__ esc, typename F::out_t* out,
-                                                   const u64* __restrict__ out_off) {
+                                                   const u64* __restrict__ out_off, const wga_elem_block* __restrict__ blocks) {
   typedef typename F::out_t out_t;
   __shared__ u32x4_a16 s_buf[(WGA_ELEM_STAGE + 32u) / 16u];
-  __shared__ u32 s_r[2];
   const u32 tid = threadIdx.x;
   const u32 x0 = blockIdx.x * 256u, x1 = x0 + 256u < ne ? x0 + 256u : ne;
-  /* two waves search, 64 probes a step (three steps for 10^5 records where one thread's bisection takes seventeen) */
-  if (tid < 128u) { /* wave-uniform */
-    const u32 r = wga_find_rec(elem_off, n, tid < 64u ? (u64)x0 : (u64)(x1 - 1u));
-    if ((tid & 63u) == 0u) s_r[tid >> 6] = r;
-  }
-  __syncthreads();
-  const u32 r_lo = WGA_UNI32(s_r[0]), r_hi = WGA_UNI32(s_r[1]);
+  const wga_elem_block eb = blocks[blockIdx.x];
+  const u32 r_lo = eb.r_lo, r_hi = eb.r_hi;
   const u32 x = x0 + tid;
   const u64 e0 = esc[x0], e1 = esc[x1]; /* units in front of the block, and behind it */
   const bool staged = r_lo == r_hi && (e1 - e0) * sizeof(out_t) <= (u64)WGA_ELEM_STAGE;
   if (staged) { /* block-uniform */
-    out_t* const g0 = out + out_off[r_lo] + (e0 - esc[elem_off[r_lo]]);
+    out_t* const g0 = out + eb.base;
     const u32 a = (u32)((uintptr_t)g0 & 15u);
     u8* const tbuf = (u8*)s_buf;
     if (x < x1) f.write((u64)x, r_lo, (out_t*)(tbuf + a) + (esc[x] - e0));
