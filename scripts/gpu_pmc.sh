@@ -39,3 +39,4 @@ for d in ("sq1","sq2","sq3","fetch","write","tcc"):
 PY
 # keep only the small per-kernel counter files
 find $OUT -name '*kernel_trace.csv' -size +5M -delete
+find $OUT -name '*counter_collection.csv' -size +8M -delete   # (gpurun copies back at most 64 MiB)

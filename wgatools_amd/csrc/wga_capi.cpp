@@ -112,7 +112,7 @@ struct wga_ctx {
     uint32_t n = 0, ne = 0;
     unsigned char src[32] = {0}; /* the entry point's source arrays (its functor) */
   } elem_scan;
-  void* cov_pieces = nullptr; /* pafcov: (window, piece) list, grow-only */
+  void* cov_pieces = nullptr; /* pafcov: the pieces' descriptors (wga_cov_desc) in window order, grow-only */
   u64 cov_pieces_cap = 0;
   void* cov_tile_list = nullptr; /* pafcov: WGA_COV_TILE_CAP piece slots per tile of ops, grow-only */
   u64 cov_tile_list_cap = 0;     /* in tiles */
@@ -1715,7 +1715,7 @@ static int pafcov_run(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_ta
     WGA_LAUNCH(k_cov_rec_pos, (b->n + WGA_BLOCK - 1) / WGA_BLOCK, WGA_BLOCK, c->stream, b->n, d_target_id, (const u64*)d_t_start,
                (const u64*)d_cov_off, (const u64*)d_cov_len, rec_pos);
     LAUNCH_CHECK();
-    WGA_LAUNCH(k_cov_tile_info, (u32)((nt + 255) / 256), WGA_BLOCK, c->stream, (const u64*)b->d_op_off, b->n, (u64)b->n_ops,
+    WGA_LAUNCH(k_cov_tile_info, (b->n + 255u) / 256u, WGA_BLOCK, c->stream, (const u64*)b->d_op_off, b->n, (u64)b->n_ops,
                (const wga_cov_rec*)rec_pos, tile_info);
     LAUNCH_CHECK();
     std::vector<u64> h_cnt(WGA_COV_LISTS);
@@ -1766,18 +1766,18 @@ static int pafcov_run(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_ta
         if (c->cov_pieces) RT_CHECK(rt_free(c->cov_pieces));
         c->cov_pieces = nullptr;
         c->cov_pieces_cap = 0;
-        RT_CHECK(rt_malloc(&c->cov_pieces, (size_t)(n_pieces + n_pieces / 4) * sizeof(wga_cov_piece)));
+        RT_CHECK(rt_malloc(&c->cov_pieces, (size_t)(n_pieces + n_pieces / 4) * sizeof(wga_cov_desc)));
         c->cov_pieces_cap = n_pieces + n_pieces / 4;
       }
       RT_CHECK(rt_memset(win_cnt, 0, (size_t)nw * 4, c->stream)); /* now the windows' fill counters */
       WGA_LAUNCH(k_cov_place_tiles, (u32)((nt * WGA_COV_TILE_CAP + WGA_BLOCK - 1) / WGA_BLOCK), WGA_BLOCK, c->stream, (u64)nt,
-                 (const u32*)tile_cnt, (const wga_cov_piece*)c->cov_tile_list, win_cnt, (const u64*)win_off,
-                 (wga_cov_piece*)c->cov_pieces);
+                 (u64)b->n_ops, (const u32*)tile_cnt, (const wga_cov_piece*)c->cov_tile_list, win_cnt, (const u64*)win_off,
+                 (wga_cov_desc*)c->cov_pieces);
       LAUNCH_CHECK();
       if (n_over) {
         dim3 pgrid((u32)((c->cov_list_rcap + WGA_BLOCK - 1) / WGA_BLOCK), WGA_COV_LISTS, 1);
-        WGA_LAUNCH(k_cov_place_pieces, pgrid, WGA_BLOCK, c->stream, (const u64*)list_cnt, (const wga_cov_piece*)c->cov_list,
-                   (u64)c->cov_list_rcap, win_cnt, (const u64*)win_off, (wga_cov_piece*)c->cov_pieces);
+        WGA_LAUNCH(k_cov_place_pieces, pgrid, WGA_BLOCK, c->stream, (u64)b->n_ops, (const u64*)list_cnt,
+                   (const wga_cov_piece*)c->cov_list, (u64)c->cov_list_rcap, win_cnt, (const u64*)win_off, (wga_cov_desc*)c->cov_pieces);
         LAUNCH_CHECK();
       }
     }
@@ -1786,7 +1786,8 @@ static int pafcov_run(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_ta
   const u64 n_ops = has_ops ? (u64)b->n_ops : 0;
   const u64* woff = n_pieces ? (const u64*)win_off : nullptr;
   if (final) {
-    WGA_LAUNCH(k_cov_windows<true>, (u32)nw, WGA_COV_BLOCK, c->stream, d_ops, n_ops, (const wga_cov_piece*)c->cov_pieces, woff,
+    WGA_LAUNCH(k_cov_windows<true>, (u32)nw, WGA_COV_BLOCK, c->stream, d_ops, n_ops, (const wga_cov_desc*)c->cov_pieces,
+               (const wga_cov_piece*)c->cov_tile_list, (const wga_cov_piece*)c->cov_list, woff,
                (int*)d_cov, (u64)n_cov, (const u64*)rng_lo, (const u64*)rng_hi, n_rng, win_state,
 #ifdef WGA_COV_NO_ORDER /* A/B builds: the windows in index order */
                (const u32*)nullptr);
@@ -1795,7 +1796,8 @@ static int pafcov_run(wga_ctx* c, const wga_cigar_batch* b, const uint32_t* d_ta
 #endif
     LAUNCH_CHECK();
   } else if (n_pieces) {
-    WGA_LAUNCH(k_cov_windows<false>, (u32)nw, WGA_COV_BLOCK, c->stream, d_ops, n_ops, (const wga_cov_piece*)c->cov_pieces, woff,
+    WGA_LAUNCH(k_cov_windows<false>, (u32)nw, WGA_COV_BLOCK, c->stream, d_ops, n_ops, (const wga_cov_desc*)c->cov_pieces,
+               (const wga_cov_piece*)c->cov_tile_list, (const wga_cov_piece*)c->cov_list, woff,
                (int*)d_cov, (u64)n_cov, (const u64*)nullptr, (const u64*)nullptr, 0u, (u64*)nullptr, (const u32*)nullptr);
     LAUNCH_CHECK();
   }

@@ -5,6 +5,8 @@
 #ifndef WGA_K5_PAFCOV_H
 #define WGA_K5_PAFCOV_H
 
+#include <type_traits>
+
 #include "wga_kernels.h"
 
 /* ============================================================================================ */
@@ -22,7 +24,9 @@
  * (k_cov_list_pieces in ONE pass over the ops: tile sums by look-back, the pieces into the tile's own slots; then a scan of the
  * window counts and k_cov_place_*), and one block per window replays its pieces with LDS
  * atomics and adds the window to memory with plain stores — it is the only writer. */
-#define WGA_COV_WIN_SHIFT 13u
+#ifndef WGA_COV_WIN_SHIFT
+#define WGA_COV_WIN_SHIFT 14u /* 64 KB of counters per block, two blocks per CU: pieces are as long as windows let them be (round 6: 13 -> 14) */
+#endif
 #define WGA_COV_WIN (1u << WGA_COV_WIN_SHIFT)
 /* K5's own tile: WGA_COV_TILE ops per wave, WGA_COV_LO consecutive ones per lane.  1 024 (16 per lane) as everywhere else;
  * 2 048 (-DWGA_COV_TILE_SHIFT=11u: 32 per lane, 128 VGPRs) was measured at configs[3]'s size — the list pass 31.8 ms against
@@ -41,9 +45,22 @@ struct __attribute__((aligned(16))) wga_cov_piece {
   u64 pos0;    /* coverage index (cov_off + target position) in front of op `first` */
   u64 limit;   /* coverage index one past the target's last counter */
   u32 wi;      /* window the piece is listed under */
-  u32 pad;     /* WGA_COV_NARROW: the segment advances less than 2^30 bases inside its tile */
+  u32 pad;     /* WGA_COV_NARROW: the segment advances less than 2^27 bases inside its tile */
 };
 #define WGA_COV_NARROW 1u
+#define WGA_COV_NARROW_BITS 27u /* the replay walks such a piece in 32-bit BYTE offsets into its window's counters: 4 x (2^27 in front
+                                   + the window + 2^27 + an op's 2^27) stays below 2^31 */
+/* What the replay reads per piece, 16 bytes, made from the list pass's piece where it is taken to its window (k_cov_place_*):
+ * everything that is the same for all lanes and steps is worked out there, once, by a thread that waits for an atomic anyway,
+ * instead of by every replaying wave's scalar unit (round 6: the replay is bound by instruction issue — 1.34 per cycle and CU at
+ * configs[3]'s size, a quarter of them per-piece bookkeeping; profiles/r06_k5_counters.txt). */
+struct __attribute__((aligned(16))) wga_cov_desc {
+  u32 g;  /* tile */
+  u32 ab; /* first op | end op << 12 | (where the loads end - end op) << 24 | WGA_COV_WIDE */
+  u32 rb; /* 4 x (coverage index in front of op `first` - window start), two's complement; WIDE: the piece's index, low half */
+  u32 lc; /* 4 x min(limit - window start, WGA_COV_WIN); WIDE: the index's high half | bit 31: in the list regions, not the tile slots */
+};
+#define WGA_COV_WIDE (1u << 31)
 /* The list pass writes a tile's first WGA_COV_TILE_CAP pieces into the tile's own slots — no atomic with an answer to wait for —
  * and further ones where WGA_COV_LISTS counters hand out places (tile g uses counter g mod WGA_COV_LISTS: one counter for all
  * tiles would take every such segment of the batch through one address), each over a region of `rcap` pieces. */
@@ -77,8 +94,11 @@ __device__ __forceinline__ void cov_load_ops(const u32* __restrict__ ops, u64 ti
 /* an op's advance on the target: everything but I and S moves (cigar.rs:720-733) — codes 1, 4 and 9 (I, S, the rest of a split I)
  * do not */
 __device__ __forceinline__ bool cov_op_moves(u32 code) { return ((0x212u >> code) & 1u) == 0u; }
-#define WGA_COV_MOVES_BITS 0xFDEDu  /* bit c set: an op of code c moves on the target (the same as a mask for v_bfe_i32) */
-#define WGA_COV_NOTCNT_BITS 0xFF7Eu /* bit c set: an op of code c is not counted (all but M and =) */
+/* bit c set: an op of code c moves on the target / is not counted (all but M and =).  The 16 bits stand twice in the word: v_bfe_i32
+ * takes its bit index from the low FIVE bits of the operand, so bit_mask(BITS, op) works on the packed op itself — bit 4 is the
+ * length's lowest bit and picks one copy or the other — without an instruction to cut the code out first */
+#define WGA_COV_MOVES_BITS 0xFDEDFDEDu
+#define WGA_COV_NOTCNT_BITS 0xFF7EFF7Eu
 /* target advance of this lane's ops inside [a, b); mvl[e] = the advance of op e */
 __device__ __forceinline__ u64 cov_lane_moves(const u32 mvl[WGA_COV_LO], u32 lane, u32 a, u32 b) {
   u64 mv = 0; /* 32 lengths below 2^28 do not fit 32 bits */
@@ -152,29 +172,44 @@ struct __attribute__((aligned(16))) wga_cov_tile {
   wga_cov_rec rp1; /* the place of record rec + 1 */
   u32 rec, pad;
 };
+/* One thread per record: the tiles whose first op the record holds get the record's data (a record of 1 300 ops holds 1.3 tiles'
+ * first ops; one without ops none).  A record that holds more than 16 has the whole wave write them.  (Until round 6 a thread per
+ * tile looked its record up by bisection: 25 dependent loads each, 1.04 ms at configs[3]'s size.) */
 __global__ __launch_bounds__(256) void k_cov_tile_info(const u64* __restrict__ op_off, u32 n, u64 n_ops,
                                                        const wga_cov_rec* __restrict__ rec_pos, wga_cov_tile* __restrict__ info) {
-  const u64 g = (u64)blockIdx.x * 256 + threadIdx.x;
-  const u64 x = g << WGA_COV_TILE_SHIFT;
-  if (x >= n_ops) return;
-  u32 lo = 0, hi = n; /* last r with op_off[r] <= x; op_off[0] == 0, op_off[n] == n_ops > x */
-  while (hi - lo > 1u) {
-    const u32 mid = lo + ((hi - lo) >> 1);
-    if (op_off[mid] <= x)
-      lo = mid;
-    else
-      hi = mid;
-  }
+  const u32 r = blockIdx.x * 256u + threadIdx.x;
+  const u32 lane = threadIdx.x & 63u;
   wga_cov_tile t;
-  t.rec = lo;
-  t.pad = 0;
-  t.rs = op_off[lo];
-  t.re = op_off[lo + 1];
-  t.rp0 = rec_pos[lo];
-  const bool more = lo + 1u < n;
-  t.re1 = more ? op_off[lo + 2] : 0ull;
-  t.rp1 = rec_pos[more ? lo + 1u : lo];
-  info[g] = t;
+  t.rec = r, t.pad = 0, t.rs = 0, t.re = 0, t.re1 = 0;
+  t.rp0.pos0 = t.rp0.limit = t.rp1.pos0 = t.rp1.limit = 0;
+  u64 g0 = 1, g1 = 0;
+  if (r < n) {
+    t.rs = op_off[r];
+    t.re = op_off[r + 1];
+    if (t.re > t.rs) { /* the tiles g with rs <= g * WGA_COV_TILE < re */
+      g0 = (t.rs + (u64)(WGA_COV_TILE - 1u)) >> WGA_COV_TILE_SHIFT;
+      g1 = (t.re - 1ull) >> WGA_COV_TILE_SHIFT;
+    }
+    if (g0 <= g1) {
+      const bool more = r + 1u < n;
+      t.rp0 = rec_pos[r];
+      t.re1 = more ? op_off[r + 2] : 0ull;
+      t.rp1 = rec_pos[more ? r + 1u : r];
+    }
+  }
+  const u64 cnt = g0 <= g1 ? g1 - g0 + 1ull : 0ull;
+  if (cnt <= 16ull)
+    for (u64 g = g0; g <= g1; g++) info[g] = t;
+  for (u64 big = __ballot(cnt > 16ull); big; big &= big - 1ull) { /* wave-uniform */
+    const int src = __ffsll((unsigned long long)big) - 1;
+    wga_cov_tile b;
+    b.rs = __shfl(t.rs, src), b.re = __shfl(t.re, src), b.re1 = __shfl(t.re1, src);
+    b.rp0.pos0 = __shfl(t.rp0.pos0, src), b.rp0.limit = __shfl(t.rp0.limit, src);
+    b.rp1.pos0 = __shfl(t.rp1.pos0, src), b.rp1.limit = __shfl(t.rp1.limit, src);
+    b.rec = __shfl(t.rec, src), b.pad = 0;
+    const u64 f = __shfl(g0, src), l = __shfl(g1, src);
+    for (u64 g = f + lane; g <= l; g += 64) info[g] = b;
+  }
 }
 
 /* The list pass: one wave per tile of 1024 ops.  Every record segment of the tile is measured (target advance per lane, scanned),
@@ -199,10 +234,10 @@ __device__ __forceinline__ void cov_list_tile(
   const wga_cov_tile tr = tile_info[g];
   const u64 rs_next = tile_end < n_ops ? tile_info[g + 1].rs : ~0ull; /* where the record of the next tile's first op starts */
 #pragma unroll
-  for (u32 e = 0; e < WGA_COV_LO; e++) w[e] = (w[e] >> 4) & bit_mask(WGA_COV_MOVES_BITS, w[e] & 15u); /* the pass needs the ops' advance only */
+  for (u32 e = 0; e < WGA_COV_LO; e++) w[e] = (w[e] >> 4) & bit_mask(WGA_COV_MOVES_BITS, w[e]); /* the pass needs the ops' advance only */
   if (nt & 3u) { /* wave-uniform, the stream's last tile: what the last 16-byte group brought from behind the stream */
 #pragma unroll
-    for (u32 e = 0; e < WGA_COV_LO; e++) w[e] = lane * WGA_COV_LO + e < nt ? w[e] : 0u;
+    for (u32 e = 0; e < WGA_COV_LO; e++) w[e] = (int)e < (int)(nt - lane * WGA_COV_LO) ? w[e] : 0u;
   }
   u32 any = 0; /* a lane's running sums stay below 2^31 when none of its ops advances 2^26 bases or more */
 #pragma unroll
@@ -266,7 +301,7 @@ __device__ __forceinline__ void cov_list_tile(
         pc.pos0 = pos_a2;
         pc.limit = rp.limit;
         pc.wi = (u32)wi;
-        pc.pad = span < (1ull << 30) ? WGA_COV_NARROW : 0u; /* the replay may walk it in 32-bit window positions */
+        pc.pad = span < (1ull << WGA_COV_NARROW_BITS) ? WGA_COV_NARROW : 0u; /* the replay may walk it in 32-bit window positions */
         const u64 idx = n_mine + j0 + lane;
         if (idx < (u64)WGA_COV_TILE_CAP)
           my_slots[idx] = pc;
@@ -305,10 +340,17 @@ __device__ __forceinline__ void cov_list_tile(
 #pragma unroll
     for (u32 e = WGA_COV_LO - 1u; e > 0u; e--) w[e] -= w[e - 1];
   };
+  /* one 32-bit scan when no lane's ops advance 2^25 bases (64 lanes stay below 2^31: every tile of a real alignment) */
   u64 tile_total;
-  const u64 P64 = cov_incl_scan_u64((u64)lt, tile_total);
+  u32 Pin;
+  if (small_ops && __ballot(lt >= (1u << 25)) == 0ull) { /* wave-uniform */
+    Pin = wave_incl_scan_u32(lt);
+    tile_total = (u64)wave_last_u32(Pin);
+  } else {
+    Pin = (u32)cov_incl_scan_u64((u64)lt, tile_total);
+  }
   const bool narrow = small_ops && tile_total < (1ull << 31); /* wave-uniform */
-  const u32 Pin = (u32)P64, Pex = Pin - lt;
+  const u32 Pex = Pin - lt;
   auto prefix_at = [&](u32 i) -> u32 { /* NARROW only; i <= nt, wave-uniform */
     if (i >= WGA_COV_TILE) return (u32)tile_total;
     const u32 li = i >> WGA_COV_LO_SHIFT, e = WGA_UNI32(i & (WGA_COV_LO - 1u));
@@ -352,7 +394,7 @@ __device__ __forceinline__ void cov_list_tile(
       const u32 lo_c = Pex > Ca ? Pex : Ca, hi_c = Pin > Ca ? Pin : Ca;
       const u32 cs = (lo_c < Cb ? lo_c : Cb) - Ca, ce = (hi_c < Cb ? hi_c : Cb) - Ca;
       const u32 wf = (q0 + cs) >> WGA_COV_WIN_SHIFT, wl = (q0 + ce) >> WGA_COV_WIN_SHIFT; /* its first and last window */
-      const u32 pad = span < (1u << 30) ? WGA_COV_NARROW : 0u;
+      const u32 pad = span < (1u << WGA_COV_NARROW_BITS) ? WGA_COV_NARROW : 0u;
       for (u32 j = 0; j < np; j++) { /* a window replays only the lanes that can mark inside it */
         u32 l1 = (u32)__popcll(__ballot(wl < j)); /* lanes that end in front of the window */
         l1 = l1 < 63u ? l1 : 63u;
@@ -477,27 +519,6 @@ __global__ __launch_bounds__(64 * WGA_K5_LIST_BW, WGA_K5_LIST_WAVES) void k_cov_
                 spin_limit);
 }
 
-/* the listed pieces go to their windows: a piece takes the next place of its window (win_fill, zero before) — an atomic with an
- * answer per piece, but of threads that have nothing else to wait for */
-__global__ __launch_bounds__(256) void k_cov_place_tiles(u64 n_tiles, const u32* __restrict__ tile_cnt,
-                                                         const wga_cov_piece* __restrict__ tile_list, u32* win_fill,
-                                                         const u64* __restrict__ win_off, wga_cov_piece* pieces) {
-  const u64 t = (u64)blockIdx.x * WGA_BLOCK + threadIdx.x;
-  const u64 g = t / WGA_COV_TILE_CAP;
-  if (g >= n_tiles || (u32)(t % WGA_COV_TILE_CAP) >= tile_cnt[g]) return;
-  const wga_cov_piece pc = tile_list[t];
-  pieces[win_off[pc.wi] + atomicAdd(&win_fill[pc.wi], 1u)] = pc;
-}
-__global__ __launch_bounds__(256) void k_cov_place_pieces(const u64* __restrict__ list_cnt, const wga_cov_piece* __restrict__ list,
-                                                          u64 rcap, u32* win_fill, const u64* __restrict__ win_off,
-                                                          wga_cov_piece* pieces) {
-  const u32 region = blockIdx.y;
-  const u64 i = (u64)blockIdx.x * WGA_BLOCK + threadIdx.x;
-  if (i >= list_cnt[region]) return;
-  const wga_cov_piece pc = list[(u64)region * rcap + i];
-  pieces[win_off[pc.wi] + atomicAdd(&win_fill[pc.wi], 1u)] = pc;
-}
-
 struct ScanU32 {
   const u32* in;
   __device__ u64 operator()(u32 i) const { return (u64)in[i]; }
@@ -520,10 +541,12 @@ struct ScanU32 {
  * look-back: window i waits for the SUMS of the windows in front of it, which they publish as soon as their own replay is
  * done, not for their look-backs), and writes counts.  `rng_lo` / `rng_hi` are the targets' [first, one past last] counter
  * indices in ascending order, disjoint (the host sorts them). */
-#define WGA_COV_WAVES 8u
+#ifndef WGA_COV_WAVES
+#define WGA_COV_WAVES 16u
+#endif
 #define WGA_COV_BLOCK (64u * WGA_COV_WAVES)
 #ifndef WGA_COV_AHEAD
-#define WGA_COV_AHEAD 2
+#define WGA_COV_AHEAD 1
 #endif
 #define WGA_COVF_AGG (1ull << 62)
 #define WGA_COVF_PREFIX (2ull << 62)
@@ -544,10 +567,49 @@ __device__ __forceinline__ u32 cov_piece_lim(u64 n_ops, const wga_cov_piece& pc)
   const u32 b4 = ((pc.ab >> 16) + 3u) & ~3u;
   return b4 < nt ? b4 : nt;
 }
+/* the replay's descriptor of a listed piece; `idx` / `in_list` say where the piece itself stands (a WIDE one is read from there) */
+__device__ __forceinline__ wga_cov_desc cov_make_desc(const wga_cov_piece& pc, u64 n_ops, u64 idx, bool in_list) {
+  static_assert(WGA_COV_TILE < 4096u, "12-bit op indices");
+  const u32 a = pc.ab & 0xFFFFu, b = pc.ab >> 16;
+  wga_cov_desc d;
+  d.g = pc.g;
+  d.ab = a | (b << 12) | ((cov_piece_lim(n_ops, pc) - b) << 24);
+  if (pc.pad & WGA_COV_NARROW) {
+    const u64 w0 = (u64)pc.wi << WGA_COV_WIN_SHIFT;
+    const u64 room = pc.limit - w0; /* the piece is listed under this window: limit > w0 */
+    d.rb = (u32)(pc.pos0 - w0) << 2;
+    d.lc = (room < (u64)WGA_COV_WIN ? (u32)room : WGA_COV_WIN) << 2;
+  } else {
+    d.ab |= WGA_COV_WIDE;
+    d.rb = (u32)idx;
+    d.lc = (u32)(idx >> 32) | (in_list ? 1u << 31 : 0u);
+  }
+  return d;
+}
+/* the listed pieces go to their windows: a piece takes the next place of its window (win_fill, zero before) — an atomic with an
+ * answer per piece, but of threads that have nothing else to wait for — and leaves its descriptor there */
+__global__ __launch_bounds__(256) void k_cov_place_tiles(u64 n_tiles, u64 n_ops, const u32* __restrict__ tile_cnt,
+                                                         const wga_cov_piece* __restrict__ tile_list, u32* win_fill,
+                                                         const u64* __restrict__ win_off, wga_cov_desc* descs) {
+  const u64 t = (u64)blockIdx.x * WGA_BLOCK + threadIdx.x;
+  const u64 g = t / WGA_COV_TILE_CAP;
+  if (g >= n_tiles || (u32)(t % WGA_COV_TILE_CAP) >= tile_cnt[g]) return;
+  const wga_cov_piece pc = tile_list[t];
+  descs[win_off[pc.wi] + atomicAdd(&win_fill[pc.wi], 1u)] = cov_make_desc(pc, n_ops, t, false);
+}
+__global__ __launch_bounds__(256) void k_cov_place_pieces(u64 n_ops, const u64* __restrict__ list_cnt,
+                                                          const wga_cov_piece* __restrict__ list, u64 rcap, u32* win_fill,
+                                                          const u64* __restrict__ win_off, wga_cov_desc* descs) {
+  const u32 region = blockIdx.y;
+  const u64 i = (u64)blockIdx.x * WGA_BLOCK + threadIdx.x;
+  if (i >= list_cnt[region]) return;
+  const wga_cov_piece pc = list[(u64)region * rcap + i];
+  descs[win_off[pc.wi] + atomicAdd(&win_fill[pc.wi], 1u)] = cov_make_desc(pc, n_ops, (u64)region * rcap + i, true);
+}
 /* the four ops of this lane in the first 256-op step of a piece */
-__device__ __forceinline__ void cov_step_ops(const u32* __restrict__ ops, u64 n_ops, const wga_cov_piece& pc, u32 lane,
-                                             u32 (&w)[4]) {
-  cov_load4(ops, (u64)pc.g << WGA_COV_TILE_SHIFT, cov_piece_lim(n_ops, pc), ((pc.ab & 0xFFFFu) & ~3u) + lane * 4u, w);
+__device__ __forceinline__ void cov_step_ops(const u32* __restrict__ ops, const wga_cov_desc& d, u32 lane, u32 (&w)[4]) {
+  const u32 b = (d.ab >> 12) & 0xFFFu;
+  cov_load4(ops, (u64)d.g << WGA_COV_TILE_SHIFT, b + ((d.ab >> 24) & 3u), ((d.ab & 0xFFFu) & ~3u) + lane * 4u, w);
 }
 
 /* the last range that starts at or in front of counter k (n when none does) */
@@ -594,22 +656,27 @@ __device__ __forceinline__ u32 cov_windows_in_front(u64* win_state, u64 wi, u32 
 
 template <bool FINAL>
 __global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __restrict__ ops, u64 n_ops,
-                                                               const wga_cov_piece* __restrict__ pieces,
+                                                               const wga_cov_desc* __restrict__ descs,
+                                                               const wga_cov_piece* __restrict__ tile_list,
+                                                               const wga_cov_piece* __restrict__ list,
                                                                const u64* __restrict__ win_off, int* cov, u64 n_cov,
                                                                const u64* __restrict__ rng_lo, const u64* __restrict__ rng_hi,
                                                                u32 n_rng, u64* win_state, const u32* __restrict__ order) {
   /* (round 6: one pad word per 32 counters against the count pass's bank conflicts — 43 % of its LDS cycles,
    * profiles/r05_k1_k5_counters.txt — measured at configs[3]'s stated size: 70.7 ms against 69.3-69.6 without.  LDS is not what the
-   * pass waits for; the padding was taken out again) */
-  __shared__ int s_win[WGA_COV_WIN];
+   * pass waits for; the padding was taken out again.)
+   * Behind the window's counters stands one word per lane: a mark that does not count (an op that is not M / =, a position
+   * outside the window or beyond the target) is added THERE — every lane its own word, no conflict — instead of being
+   * branched around: a compare, a select and the LDS add per mark where the exec-masked form spent seven instructions. */
+  __shared__ int s_win[WGA_COV_WIN + 64u];
   __shared__ u32 s_ws[WGA_COV_WAVES + 1];
   __shared__ u32 s_wf[WGA_COV_WAVES];
   constexpr int D = WGA_COV_AHEAD;
   constexpr u32 PER = WGA_COV_WIN / WGA_COV_BLOCK;
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = WGA_WAVE_ID(tid);
   /* FINAL: the blocks take the windows in `order` — the windows that start a range (or lie outside every range) first, then every
-   * range's second window, third ... — so that the ~1 000 windows in flight at one time are a few consecutive ones of MANY
-   * ranges instead of a thousand consecutive ones of one: a window only waits for the windows of its own range in front of it,
+   * range's second window, third ... — so that the windows in flight at one time are a few consecutive ones of MANY
+   * ranges instead of hundreds of consecutive ones of one: a window only waits for the windows of its own range in front of it,
    * and those were dispatched long before (the host builds the order; the window a block waits for always has a lower rank) */
   const u64 wi = (FINAL && order) ? (u64)order[blockIdx.x] : (u64)blockIdx.x;
   const u64 p_lo = win_off ? win_off[wi] : 0ull, p_hi = win_off ? win_off[wi + 1] : 0ull;
@@ -628,20 +695,21 @@ __global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __r
   /* a wave's pieces one after the other: dq[k] / wq[k] = descriptor / first ops of the piece k rounds behind the current one */
   const u64 p0 = p_lo + wave;
   if (p0 < p_hi) { /* wave-uniform */
-    wga_cov_piece dq[2 * D + 1];
+    wga_cov_desc dq[2 * D + 1];
     u32 wq[D + 1][4];
 #pragma unroll
     for (int k = 0; k <= 2 * D; k++) {
       const u64 q = p0 + (u64)k * WGA_COV_WAVES;
-      dq[k] = pieces[q < p_hi ? q : p_lo];
+      dq[k] = descs[q < p_hi ? q : p_lo];
     }
 #pragma unroll
     for (int k = 0; k <= D; k++) {
       wq[k][0] = wq[k][1] = wq[k][2] = wq[k][3] = 0u;
-      if (p0 + (u64)k * WGA_COV_WAVES < p_hi) cov_step_ops(ops, n_ops, dq[k], lane, wq[k]);
+      if (p0 + (u64)k * WGA_COV_WAVES < p_hi) cov_step_ops(ops, dq[k], lane, wq[k]);
     }
+    const u32 dummy = (WGA_COV_WIN + lane) << 2;
     for (u64 p = p0; p < p_hi; p += WGA_COV_WAVES) {
-      const wga_cov_piece pc = dq[0];
+      const wga_cov_desc pd = dq[0];
       u32 w[4] = {wq[0][0], wq[0][1], wq[0][2], wq[0][3]};
 #pragma unroll
       for (int k = 0; k < 2 * D; k++) dq[k] = dq[k + 1];
@@ -650,45 +718,58 @@ __global__ __launch_bounds__(WGA_COV_BLOCK, 8) void k_cov_windows(const u32* __r
 #pragma unroll
         for (int e = 0; e < 4; e++) wq[k][e] = wq[k + 1][e];
       }
-      if (p + (u64)(2 * D + 1) * WGA_COV_WAVES < p_hi) dq[2 * D] = pieces[p + (u64)(2 * D + 1) * WGA_COV_WAVES];
-      if (p + (u64)(D + 1) * WGA_COV_WAVES < p_hi) cov_step_ops(ops, n_ops, dq[D], lane, wq[D]);
-      const u64 tile_start = (u64)pc.g << WGA_COV_TILE_SHIFT;
-      const u32 lim = cov_piece_lim(n_ops, pc);
-      const u32 a = pc.ab & 0xFFFFu, b = pc.ab >> 16;
-      if (pc.pad & WGA_COV_NARROW) { /* wave-uniform */
-        const u64 room = pc.limit - w0; /* the piece is listed under this window: limit > w0 */
-        const u32 Lc = room < (u64)WGA_COV_WIN ? (u32)room : WGA_COV_WIN;
-        u32 rb = (u32)(pc.pos0 - w0); /* two's complement: a position in front of the window compares above Lc */
-        for (u32 s0 = a & ~3u; s0 < b; s0 += 256u) {
-          const u32 i0 = s0 + lane * 4u;
-          const bool more = s0 + 256u < b; /* wave-uniform: a further step's ops travel behind this one's work */
-          u32 wn[4] = {0u, 0u, 0u, 0u};
-          if (more) cov_load4(ops, tile_start, lim, i0 + 256u, wn);
-          if (s0 < a || s0 + 256u > b) { /* wave-uniform: ops outside the piece become an I of no bases */
+      if (p + (u64)(2 * D + 1) * WGA_COV_WAVES < p_hi) dq[2 * D] = descs[p + (u64)(2 * D + 1) * WGA_COV_WAVES];
+      if (p + (u64)(D + 1) * WGA_COV_WAVES < p_hi) cov_step_ops(ops, dq[D], lane, wq[D]);
+      const u64 tile_start = (u64)pd.g << WGA_COV_TILE_SHIFT;
+      const u32 a = pd.ab & 0xFFFu, b = (pd.ab >> 12) & 0xFFFu;
+      const u32 lim = b + ((pd.ab >> 24) & 3u);
+      if (!(pd.ab & WGA_COV_WIDE)) { /* wave-uniform */
+        const u32 Lc = pd.lc; /* byte offsets: a position in front of the window compares above Lc (two's complement) */
+        /* FULLW: the target goes on behind the window (nearly every piece) — whatever lies at or beyond the window's end goes to
+         * the dummy words with ONE v_min (it may land in another lane's word: they hold nothing) */
+        auto walk = [&](auto fullw) {
+          constexpr bool FULLW = decltype(fullw)::value;
+          u32 rb = pd.rb;
+          for (u32 s0 = a & ~3u; s0 < b; s0 += 256u) {
+            const u32 i0 = s0 + lane * 4u;
+            const bool more = s0 + 256u < b; /* wave-uniform: a further step's ops travel behind this one's work */
+            u32 wn[4] = {0u, 0u, 0u, 0u};
+            if (more) cov_load4(ops, tile_start, lim, i0 + 256u, wn);
+            if (s0 < a || s0 + 256u > b) { /* wave-uniform: ops outside the piece become an I of no bases */
 #pragma unroll
-            for (int e = 0; e < 4; e++) w[e] = (i0 + (u32)e - a < b - a) ? w[e] : 1u;
+              for (int e = 0; e < 4; e++) w[e] = (i0 + (u32)e - a < b - a) ? w[e] : 1u;
+            }
+            u32 lm[4], mv = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { /* 4 x the op's advance: the length stands at bit 4 */
+              lm[e] = (w[e] >> 2) & (bit_mask(WGA_COV_MOVES_BITS, w[e]) << 2);
+              mv += lm[e];
+            }
+            const u32 inc = wave_incl_scan_u32(mv);
+            u32 r = rb + (inc - mv);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const u32 nc = bit_mask(WGA_COV_NOTCNT_BITS, w[e]);
+              const u32 ku = r | nc;
+              r += lm[e]; /* an op that counts moves */
+              const u32 kd = r | nc;
+              const u32 iu = FULLW ? (ku < dummy ? ku : dummy) : (ku < Lc ? ku : dummy);
+              const u32 id = FULLW ? (kd < dummy ? kd : dummy) : (kd < Lc ? kd : dummy);
+              atomicAdd((int*)((char*)s_win + iu), 1);
+              atomicAdd((int*)((char*)s_win + id), -1);
+            }
+            rb += wave_last_u32(inc);
+#pragma unroll
+            for (int e = 0; e < 4; e++) w[e] = wn[e];
           }
-          u32 lm[4], mv = 0;
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            lm[e] = (w[e] >> 4) & bit_mask(WGA_COV_MOVES_BITS, w[e] & 15u);
-            mv += lm[e];
-          }
-          const u32 inc = wave_incl_scan_u32(mv);
-          u32 r = rb + (inc - mv);
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const u32 nc = bit_mask(WGA_COV_NOTCNT_BITS, w[e] & 15u);
-            const u32 ku = r | nc, kd = (r + (w[e] >> 4)) | nc;
-            if (ku < Lc) atomicAdd(&s_win[ku], 1);
-            if (kd < Lc) atomicAdd(&s_win[kd], -1);
-            r += lm[e];
-          }
-          rb += wave_last_u32(inc);
-#pragma unroll
-          for (int e = 0; e < 4; e++) w[e] = wn[e];
-        }
+        };
+        if (Lc == (WGA_COV_WIN << 2))
+          walk(std::true_type());
+        else
+          walk(std::false_type());
       } else {
+        const u64 src = (u64)pd.rb | ((u64)(pd.lc & 0x7FFFFFFFu) << 32);
+        const wga_cov_piece pc = (pd.lc >> 31) ? list[src] : tile_list[src];
         u64 pos_base = pc.pos0;
         /* the piece's ops, 4 consecutive ones per lane and 256 per step (a is a multiple of 16 or the segment's first op) */
         for (u32 s0 = a & ~3u; s0 < b; s0 += 256u) {
