@@ -497,7 +497,12 @@ __device__ __forceinline__ void cov_list_tile(
  * same time); the wave reading the tile in front again to add up a near record's ops itself (38.4 ms: the second read of a
  * line another wave of the same CU has just asked for goes to HBM again).  The ablations of round 5
  * (profiles/r05_k5_list_pass_ablations.txt: 27.95 ms as it was; without the window counts 27.2, without the piece store 26.3,
- * WITHOUT THE LOOK-BACK 20.5) said where the time went. */
+ * WITHOUT THE LOOK-BACK 20.5) said where the time went.
+ * Round 6, on the tree with 16 K windows (22.6 ms as it stands, gpurun_out/r06lds): the barrier replaced by a word per wave in LDS
+ * that the next wave polls (cleared behind a barrier at the block's start) 24.0 ms, with eight waves per block 30.3, sixteen 38.7
+ * — larger blocks lose to the CU's 28 wave slots (one block of sixteen fits), not to the barrier; eight waves per SIMD (63
+ * registers, 14 scalar spills) 24.7; tiles of 2 048 ops 28.7-31.5; a fifth fewer vector instructions (v_bfe_i32 on the packed
+ * op, one scan instead of two) 0.4 ms.  The pass moves 116 GB at 5.0 TB/s. */
 #ifndef WGA_K5_LIST_BW
 #define WGA_K5_LIST_BW 4u /* waves per block */
 #endif
