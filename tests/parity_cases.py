@@ -443,22 +443,13 @@ def text_any(ops_slice):
 
 
 def check_pafcov_long_ops(eng):
-    """K5: a window (8 192 counters) replays only the lanes of a record segment whose ops can mark inside it.  Ops far longer
-    than a window (a segment across 60+ windows, windows without any mark inside), ops ending exactly on window borders,
-    zero-length ops, a record that runs past its target's end, two targets back to back in the coverage array"""
-    W = 8192
+    """K5: a window (16 384 counters since round 6, 8 192 before: both sizes' borders are hit) replays only the lanes of a record
+    segment whose ops can mark inside it.  Ops far longer than a window (a segment across 60+ windows, windows without any mark
+    inside), ops ending exactly on window borders, zero-length ops, a record that runs past its target's end, two targets back
+    to back in the coverage array"""
     mk = lambda p: [(int(ln) << 4) | int(c) for c, ln in p]
-    recs = [mk([(7, 300000), (2, 5), (0, 200001), (8, 1), (1, 7), (7, 9)]),
-            mk([(7, W), (7, W), (2, W), (7, 1), (8, W - 1), (7, 0), (0, 3 * W)]),
-            mk([(7, 3), (1, 2)] * 700 + [(7, 100000)] + [(8, 1), (7, 2)] * 300),
-            mk([(7, 5000), (3, 40000), (7, 5000), (2, 70000), (7, 20000)]),      # N and D move without counting
-            mk([(7, 60000)] * 3)]                                                   # runs past the end of its target
-    ops = np.array([o for r in recs for o in r], dtype=np.uint32)
-    off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
-    n = len(recs)
-    b = dict(ops=ops, op_off=off, strand_neg=np.zeros(n, dtype=np.uint8))
-    check_pafcov(eng, b, [0, 0, 1, 1, 1], [100, 8192 * 3 - 1, 0, 50000, 150000], [600000, 250000])
-    check_pafcov(eng, b, [0, 0, 1, 1, 1], [100, 8192 * 3 - 1, 0, 50000, 150000], [600000, 250000], split=True)
+    for W in (8192, 16384):
+        _check_pafcov_window_borders(eng, W, mk)
     # a tile that advances 2^31 bases and more (N ops of the longest packed length): the list pass measures its segments one by
     # one in 64-bit positions, the replay walks such a piece in 64-bit positions too; the record goes on into the next tile
     # (whose look-back brings a sum beyond 2^31) and far beyond its target's end; ordinary records in front and behind
@@ -472,6 +463,34 @@ def check_pafcov_long_ops(eng):
     b = dict(ops=ops, op_off=off, strand_neg=np.zeros(len(recs), dtype=np.uint8))
     check_pafcov(eng, b, [0, 1, 0, 1], [30, 10, 2000, 70000], [400000, 90000])
     check_pafcov(eng, b, [0, 1, 0, 1], [30, 10, 2000, 70000], [400000, 90000], split=True)
+    # WIDE pieces (a segment that advances 2^27 bases or more: the replay reads the piece itself through its descriptor) in a
+    # tile of more pieces than its eight slots hold, so that some of them stand in the list regions: forty records of three ops in
+    # one tile, each with an N op of 2^28 - 1 or 2^27 bases behind five counted ones, over targets of a few windows; around them
+    # ordinary records whose pieces are narrow
+    recs = [mk([(7, 9), (8, 1)] * 20)]
+    recs += [mk([(7, 5 + k), (3, big if k % 3 else 1 << 27), (7, 5)]) for k in range(40)]
+    recs += [mk([(7, 30), (2, 4), (0, 17)] * 50)]
+    ops = np.array([o for r in recs for o in r], dtype=np.uint32)
+    off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+    b = dict(ops=ops, op_off=off, strand_neg=np.zeros(len(recs), dtype=np.uint8))
+    tid = [0] + [k % 2 for k in range(40)] + [1]
+    ts = [77] + [(k * 2711) % 60000 for k in range(40)] + [123]
+    check_pafcov(eng, b, tid, ts, [70000, 100000])
+    check_pafcov(eng, b, tid, ts, [70000, 100000], split=True)
+
+
+def _check_pafcov_window_borders(eng, W, mk):
+    recs = [mk([(7, 300000), (2, 5), (0, 200001), (8, 1), (1, 7), (7, 9)]),
+            mk([(7, W), (7, W), (2, W), (7, 1), (8, W - 1), (7, 0), (0, 3 * W)]),
+            mk([(7, 3), (1, 2)] * 700 + [(7, 100000)] + [(8, 1), (7, 2)] * 300),
+            mk([(7, 5000), (3, 40000), (7, 5000), (2, 70000), (7, 20000)]),      # N and D move without counting
+            mk([(7, 60000)] * 3)]                                                   # runs past the end of its target
+    ops = np.array([o for r in recs for o in r], dtype=np.uint32)
+    off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+    n = len(recs)
+    b = dict(ops=ops, op_off=off, strand_neg=np.zeros(n, dtype=np.uint8))
+    check_pafcov(eng, b, [0, 0, 1, 1, 1], [100, W * 3 - 1, 0, 50000, 150000], [600000, 250000])
+    check_pafcov(eng, b, [0, 0, 1, 1, 1], [100, W * 3 - 1, 0, 50000, 150000], [600000, 250000], split=True)
 
 
 def check_pafcov_look_back(eng):
