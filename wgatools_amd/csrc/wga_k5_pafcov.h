@@ -316,14 +316,16 @@ __device__ __forceinline__ void cov_list_tile(
   const u64 rs0 = tr.rs, end0 = tr.re < tile_end ? tr.re : tile_end;
   const u32 b0 = (u32)(end0 - tile_start);
   const wga_cov_rec rp0 = tr.rp0;
-  /* The first segment's record began in a tile in front.  NEAR — in the tile right in front, four tiles of five on configs[3]'s
-   * records — and that tile is another wave's of THIS block: its published sum comes through LDS behind a block barrier
+  /* The first segment's record began in a tile in front.  NEAR — in a tile of THIS block (the tile right in front, four tiles of
+   * five on configs[3]'s records; since round 6 also two or three tiles in front, a quarter of its records: the tiles between
+   * belong to the record from end to end, so their published sums are whole-tile sums) — its sum comes through LDS behind a block barrier
    * (hundreds of cycles) instead of through memory (a poll is a round trip or two of microseconds: the look-back was 7.4 of the
    * pass's 28 ms, profiles/r05_k5_list_pass_ablations.txt).  The block's first wave, and records that began further back, go
    * through the published sums of the tiles in front as before. */
   const u32 wave = WGA_WAVE_ID(threadIdx.x);
   const bool waits = rs0 < tile_start;
-  const bool near_lds = waits && wave != 0u && tile_start - rs0 <= (u64)WGA_COV_TILE;
+  const u64 back = g - (rs0 >> WGA_COV_TILE_SHIFT); /* the record began that many tiles in front (waits: >= 1) */
+  const bool near_lds = waits && back <= (u64)wave; /* ... in a tile of this block: every tile between is the record's from end to end */
   const u64 early = waits && !near_lds ? cov_poll_early(tile_tail, rs0, g, lane) : 0ull;
   /* ONE scan serves every segment of the tile: the lanes' advance summed over all 1 024 ops, whatever records they belong to.
    * The advance in front of op i (wave-uniform i) is the sum of the lanes in front of i's lane plus that lane's ops in front of
@@ -377,7 +379,12 @@ __device__ __forceinline__ void cov_list_tile(
     if (lane == 0) s_tail[wave] = span_last;
   }
   __syncthreads(); /* every wave of the block comes here (k_cov_list_pieces): the waves' sums are in LDS */
-  const u64 base0 = near_lds ? WGA_UNI64(s_tail[wave - 1u]) : waits ? cov_look_back(tile_tail, ops, rs0, g, lane, spin_limit, early) : 0ull;
+  u64 base0 = 0;
+  if (near_lds) { /* wave-uniform: the sums of the block's tiles from the record's first one on */
+    for (u32 k = 1; k <= (u32)back; k++) base0 += WGA_UNI64(s_tail[wave - k]);
+  } else if (waits) {
+    base0 = cov_look_back(tile_tail, ops, rs0, g, lane, spin_limit, early);
+  }
   if (narrow) {
     u32 n_p = 0; /* pieces so far; lane q keeps piece q until the walk is through (nothing is written before) */
     u32 pc_ab = 0, pc_wi = 0, pc_pad = 0;
@@ -502,7 +509,12 @@ __device__ __forceinline__ void cov_list_tile(
  * that the next wave polls (cleared behind a barrier at the block's start) 24.0 ms, with eight waves per block 30.3, sixteen 38.7
  * — larger blocks lose to the CU's 28 wave slots (one block of sixteen fits), not to the barrier; eight waves per SIMD (63
  * registers, 14 scalar spills) 24.7; tiles of 2 048 ops 28.7-31.5; a fifth fewer vector instructions (v_bfe_i32 on the packed
- * op, one scan instead of two) 0.4 ms.  The pass moves 116 GB at 5.0 TB/s. */
+ * op, one scan instead of two) 0.4 ms.  The pass moves 116 GB at 5.0 TB/s.
+ * Timing-only builds with parts left out (gpurun_out/k5abl, k5abl2; 22.8 ms as it stood): without the look-back through memory
+ * 20.2; nothing but loads, scan and barrier 19.8-20.3; the same with every load one contiguous kilobyte instead of a lane's own
+ * sixteen ops 16.4 — but the real pass with contiguous loads turned into the lane layout through LDS (swizzled, conflict-free)
+ * ran 24.4 against 22.1: the round trip through LDS stands in every wave's critical path.  Kept from that series: a record
+ * that began two or three tiles in front INSIDE the block takes its position from LDS as well (22.8 -> 22.3). */
 #ifndef WGA_K5_LIST_BW
 #define WGA_K5_LIST_BW 4u /* waves per block */
 #endif
