@@ -84,6 +84,7 @@ __device__ __forceinline__ u32 lane_rank(u64 m, u32 lane) { return (u32)__popcll
 __device__ __forceinline__ u32x4_a16 ops_load16(const u32* p) { return *(const u32x4_a16*)p; }
 
 __device__ __forceinline__ u32 bit_mask(u32 bits, u32 idx) { return 0u - ((bits >> (idx & 31u)) & 1u); }
+__device__ __forceinline__ u32 bit_test(u32 bits, u32 idx) { return (bits >> (idx & 31u)) & 1u; }
 
 #define WGA_KARG_SPACE
 #define WGA_KARG_SEGMENT(T, a) (&(a))

@@ -159,6 +159,9 @@ __device__ __forceinline__ u32x4_a16 ops_load16(const u32* p) {
 
 /* all ones when bit idx of bits is set (v_bfe_i32) */
 __device__ __forceinline__ u32 bit_mask(u32 bits, u32 idx) { return (u32)__builtin_amdgcn_sbfe((int)bits, idx, 1u); }
+/* ... and 1 (v_bfe_u32).  Both take the index from the low FIVE bits of idx: with a 16-bit class constant standing twice in
+ * `bits` they work on a packed op as it is (bit 4, the length's lowest bit, picks one copy or the other) */
+__device__ __forceinline__ u32 bit_test(u32 bits, u32 idx) { return __builtin_amdgcn_ubfe(bits, idx, 1u); }
 
 /* kernel arguments read where they are used, from the kernarg segment (scalar loads), instead of occupying SGPRs for the
  * whole kernel: the pointer type's address space, the segment pointer, and a fence that keeps loads through it behind a point */

@@ -229,32 +229,34 @@ __device__ __forceinline__ void cigar_stat_tile(const u64 g, const u32 (&w)[16],
      * segments alike; S / other ops and the first bad op are only worked out when a wave vote
      * says the segment holds any (they end the run with an error anyway). */
     const u32 span = b - a, lane4 = lane * 4u;
-    u32 s_mx = 0, s_i = 0, s_d = 0, s_s = 0, s_o = 0;
+    u32 s_mx = 0, s_i = 0, s_t = 0, s_s = 0, s_o = 0; /* s_t: every op's length — the D bases are what the other classes leave of it */
     u32 s_x = 0;  /* X only: match = s_mx - s_x */
     u32 ev = 0;   /* ins events | del events << 16 */
     u32 bad = 0xFFFFFFFFu;
     u32 rare = 0;
-    /* a class sum is `len & mask`, the mask one v_bfe_i32 of a 16-bit constant by the op's code (bit c set: code c belongs
-     * to the class) — 21 vector instructions per op where compares and selects on a class number took 45; a segment that is
-     * the whole tile (wave-uniform) needs no range test either */
-    constexpr u32 MX_BITS = 0x0181u, I_BITS = 0x0202u, D_BITS = 0x0404u, X_BITS = 0x0100u, RARE_BITS = 0xF878u;
+    /* a class sum is `len & mask`, the mask one v_bfe_i32 of a class constant by the packed op itself (bit c set: code c belongs
+     * to the class; the 16 bits stand twice, so that the length's lowest bit — bit 4 of the op — picks either copy) — 17 vector
+     * instructions per op (round 5: 21 with the code cut out first and the D bases summed on their own; compares and selects on
+     * a class number took 45) */
+    constexpr u32 MX_BITS = 0x01810181u, I_BITS = 0x02020202u, X_BITS = 0x01000100u, RARE_BITS = 0xF878F878u;
+    constexpr u32 IEV_BITS = 0x00020002u, DEV_BITS = 0x00040004u; /* an I (not the rest of a split one), a D */
     auto class_sums = [&](auto ranged) { /* ranged: ops outside [a, b) count as 0M */
 #pragma unroll
       for (int k = 0; k < 16; k++) {
         const u32 idx = (u32)(k >> 2) * 256u + (u32)(k & 3) + lane4;
         const u32 op = (!decltype(ranged)::value || idx - a < span) ? w[k] : 0u;
-        const u32 code = op & 15u, len = op >> 4;
-        s_mx += len & bit_mask(MX_BITS, code);
-        s_i += len & bit_mask(I_BITS, code);
-        s_d += len & bit_mask(D_BITS, code);
-        s_x += len & bit_mask(X_BITS, code);
-        ev -= bit_mask(0x2u, code);            /* an I (not the rest of a split one): +1 */
-        ev += bit_mask(0x4u, code) & 0x10000u; /* a D */
-        rare |= bit_mask(RARE_BITS, code);
+        const u32 len = op >> 4;
+        s_mx += len & bit_mask(MX_BITS, op);
+        s_i += len & bit_mask(I_BITS, op);
+        s_t += len;
+        s_x += len & bit_mask(X_BITS, op);
+        ev += bit_test(IEV_BITS, op);
+        ev += bit_test(DEV_BITS, op) << 16;
+        rare |= bit_mask(RARE_BITS, op);
       }
     };
 #if WGA_K1_WHOLE_TILE_PATH
-    if (a == 0u && b == nt) /* wave-uniform */
+    if (a == 0u && b == (u32)(tile_end - tile_start)) /* wave-uniform (what stands behind the stream's end is 0M already) */
       class_sums(std::false_type());
     else
 #endif
@@ -272,14 +274,28 @@ __device__ __forceinline__ void cigar_stat_tile(const u64 g, const u32 (&w)[16],
         bad = (cls >= CLS_S && idx < bad) ? idx : bad;
       }
     }
-    u64 S[5];
-    S[0] = wave_sum_u32_wide(s_mx);
-    S[1] = wave_sum_u32_wide(s_i);
-    S[2] = wave_sum_u32_wide(s_d);
-    const u64 Sx = wave_sum_u32_wide(s_x);
-    const u32 EV = wave_sum_u32(ev);
-    S[3] = any_rare ? wave_sum_u32_wide(s_s) : 0ull;
-    S[4] = any_rare ? wave_sum_u32_wide(s_o) : 0ull;
+    /* the wave's sums: one 32-bit reduction each when no lane's lengths add up to 2^26 (64 lanes stay below 2^32: every tile of a
+     * real alignment), else two 16-bit halves each */
+    u64 S[5], Sx, St;
+    u32 EV;
+    if (__ballot(s_t >= (1u << 26)) == 0ull) { /* wave-uniform */
+      S[0] = wave_sum_u32(s_mx);
+      S[1] = wave_sum_u32(s_i);
+      St = wave_sum_u32(s_t);
+      Sx = wave_sum_u32(s_x);
+      EV = wave_sum_u32(ev);
+      S[3] = any_rare ? (u64)wave_sum_u32(s_s) : 0ull;
+      S[4] = any_rare ? (u64)wave_sum_u32(s_o) : 0ull;
+    } else {
+      S[0] = wave_sum_u32_wide(s_mx);
+      S[1] = wave_sum_u32_wide(s_i);
+      St = wave_sum_u32_wide(s_t);
+      Sx = wave_sum_u32_wide(s_x);
+      EV = wave_sum_u32(ev);
+      S[3] = any_rare ? wave_sum_u32_wide(s_s) : 0ull;
+      S[4] = any_rare ? wave_sum_u32_wide(s_o) : 0ull;
+    }
+    S[2] = St - S[0] - S[1] - S[3] - S[4]; /* every op is M-like, I, D, S or other */
     const u32 BAD = any_rare ? wave_min_u32(bad) : 0xFFFFFFFFu;
     const u64 Smatch = S[0] - Sx;
 
