@@ -427,8 +427,8 @@ __device__ __forceinline__ void stat_load_ops(const u32* __restrict__ ops, u64 n
   }
 }
 
-/* One wave per tile.  The kernel is bound by the instructions it issues: 626 vector + 161 scalar per tile at 1.16 per cycle and
- * CU (profiles/r05_k1_k5_counters.txt), the ceiling scripts/micro/issue_rates.hip measures for such a mix — not by its loads (a
+/* One wave per tile.  The kernel is bound by its VECTOR instructions — a CU retires one per cycle, and 511 per tile (626 until
+ * round 6: profiles/r06_pmc.txt, r05_k1_k5_counters.txt) x 487 536 tiles / 256 CUs is 0.41 of its 0.48 ms — not by its loads (a
  * plain read of the same 2 GB runs at 6.5 TB/s, scripts/micro/read_only.hip; a grid of resident waves that requested the next
  * tile's ops early: 0.586 against 0.555 ms) and not by the atomics of records that span tiles (without them: the same time). */
 __global__ __launch_bounds__(256, WGA_K1_BLOCKS) void k_cigar_stat(const u32* __restrict__ ops,
