@@ -213,6 +213,48 @@ __device__ __forceinline__ void cigar_stat_tile(const u64 g, const u32 (&w)[16],
   u64 cur = tile_start;
   u64 tot[5] = {0, 0, 0, 0, 0}, tail[5] = {0, 0, 0, 0, 0};
   u64 re = WGA_UNI64(tr.re);
+  /* a class sum is `len & mask`, the mask one v_bfe_i32 of a class constant by the packed op itself (bit c set: code c belongs
+   * to the class; the 16 bits stand twice, so that the length's lowest bit — bit 4 of the op — picks either copy) — 17 vector
+   * instructions per op (round 5: 21 with the code cut out first and the D bases summed on their own; compares and selects on
+   * a class number took 45), 20 with the range test of a segment that is not the whole tile */
+  constexpr u32 MX_BITS = 0x01810181u, I_BITS = 0x02020202u, X_BITS = 0x01000100u, RARE_BITS = 0xF878F878u;
+  constexpr u32 IEV_BITS = 0x00020002u, DEV_BITS = 0x00040004u; /* an I (not the rest of a split one), a D */
+  const u32 lane4 = lane * 4u;
+  /* the wave's sums: one 32-bit reduction each when no lane's lengths add up to 2^26 (64 lanes stay below 2^32: every tile of a
+   * real alignment), else two 16-bit halves each */
+  auto wave_sums = [&](u32 s_mx, u32 s_i, u32 s_t, u32 s_x, u32 ev, u64& Smx, u64& Si, u64& St, u64& Sx, u32& EV) {
+    if (__ballot(s_t >= (1u << 26)) == 0ull) { /* wave-uniform */
+      Smx = wave_sum_u32(s_mx), Si = wave_sum_u32(s_i), St = wave_sum_u32(s_t), Sx = wave_sum_u32(s_x);
+    } else {
+      Smx = wave_sum_u32_wide(s_mx), Si = wave_sum_u32_wide(s_i), St = wave_sum_u32_wide(s_t), Sx = wave_sum_u32_wide(s_x);
+    }
+    EV = wave_sum_u32(ev);
+  };
+  /* The WHOLE tile first, without a range test: a tile's last segment (its only one, in four tiles of five on 5-kop records) is
+   * what the segments in front leave of these sums, so only segments that end inside the tile pay the three instructions per op
+   * of the test — unless the tile holds an op outside M = X I D (an error for the run: every segment is then measured on its own,
+   * with its first bad op). */
+  u64 Wmx, Wi, Wt, Wx;
+  u32 Wev;
+  bool rare_tile;
+  {
+    u32 s_mx = 0, s_i = 0, s_t = 0, s_x = 0, ev = 0, rare = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const u32 op = w[k], len = op >> 4;
+      s_mx += len & bit_mask(MX_BITS, op);
+      s_i += len & bit_mask(I_BITS, op);
+      s_t += len;
+      s_x += len & bit_mask(X_BITS, op);
+      ev += bit_test(IEV_BITS, op);
+      ev += bit_test(DEV_BITS, op) << 16;
+      rare |= bit_mask(RARE_BITS, op);
+    }
+    rare_tile = __ballot(rare != 0u) != 0ull;
+    wave_sums(s_mx, s_i, s_t, s_x, ev, Wmx, Wi, Wt, Wx, Wev);
+  }
+  u64 Amx = 0, Ai = 0, At = 0, Ax = 0; /* the tile's segments so far */
+  u32 Aev = 0;
   while (cur < tile_end) {
     while (re <= cur) { /* skip empty records */
       r++;
@@ -225,26 +267,25 @@ __device__ __forceinline__ void cigar_stat_tile(const u64 g, const u32 (&w)[16],
     const u32 a = (u32)(cur - tile_start), b = (u32)(seg_end - tile_start);
 
     /* per-lane partials: 16 ops * (2^28-1) < 2^32, so u32 is exact.  Ops outside the segment are
-     * turned into 0M (neutral) on the fly, so that ONE short loop serves whole-tile and partial
-     * segments alike; S / other ops and the first bad op are only worked out when a wave vote
+     * turned into 0M (neutral) on the fly; S / other ops and the first bad op are only worked out when a wave vote
      * says the segment holds any (they end the run with an error anyway). */
-    const u32 span = b - a, lane4 = lane * 4u;
-    u32 s_mx = 0, s_i = 0, s_t = 0, s_s = 0, s_o = 0; /* s_t: every op's length — the D bases are what the other classes leave of it */
-    u32 s_x = 0;  /* X only: match = s_mx - s_x */
-    u32 ev = 0;   /* ins events | del events << 16 */
-    u32 bad = 0xFFFFFFFFu;
-    u32 rare = 0;
-    /* a class sum is `len & mask`, the mask one v_bfe_i32 of a class constant by the packed op itself (bit c set: code c belongs
-     * to the class; the 16 bits stand twice, so that the length's lowest bit — bit 4 of the op — picks either copy) — 17 vector
-     * instructions per op (round 5: 21 with the code cut out first and the D bases summed on their own; compares and selects on
-     * a class number took 45) */
-    constexpr u32 MX_BITS = 0x01810181u, I_BITS = 0x02020202u, X_BITS = 0x01000100u, RARE_BITS = 0xF878F878u;
-    constexpr u32 IEV_BITS = 0x00020002u, DEV_BITS = 0x00040004u; /* an I (not the rest of a split one), a D */
-    auto class_sums = [&](auto ranged) { /* ranged: ops outside [a, b) count as 0M */
+    u64 S[5], Sx, St;
+    u32 EV, BAD = 0xFFFFFFFFu;
+    S[3] = S[4] = 0ull;
+    if (!rare_tile && seg_end == tile_end) { /* wave-uniform: what the segments in front leave of the tile */
+      S[0] = Wmx - Amx, S[1] = Wi - Ai, St = Wt - At, Sx = Wx - Ax;
+      EV = Wev - Aev; /* both counts of the tile are at least those of its first segments: no borrow between the halves */
+    } else {
+      const u32 span = b - a;
+      u32 s_mx = 0, s_i = 0, s_t = 0, s_s = 0, s_o = 0; /* s_t: every op's length — the D bases are what the other classes leave of it */
+      u32 s_x = 0;  /* X only: match = s_mx - s_x */
+      u32 ev = 0;   /* ins events | del events << 16 */
+      u32 bad = 0xFFFFFFFFu;
+      u32 rare = 0;
 #pragma unroll
       for (int k = 0; k < 16; k++) {
         const u32 idx = (u32)(k >> 2) * 256u + (u32)(k & 3) + lane4;
-        const u32 op = (!decltype(ranged)::value || idx - a < span) ? w[k] : 0u;
+        const u32 op = (idx - a < span) ? w[k] : 0u;
         const u32 len = op >> 4;
         s_mx += len & bit_mask(MX_BITS, op);
         s_i += len & bit_mask(I_BITS, op);
@@ -254,49 +295,28 @@ __device__ __forceinline__ void cigar_stat_tile(const u64 g, const u32 (&w)[16],
         ev += bit_test(DEV_BITS, op) << 16;
         rare |= bit_mask(RARE_BITS, op);
       }
-    };
-#if WGA_K1_WHOLE_TILE_PATH
-    if (a == 0u && b == (u32)(tile_end - tile_start)) /* wave-uniform (what stands behind the stream's end is 0M already) */
-      class_sums(std::false_type());
-    else
-#endif
-      class_sums(std::true_type());
-    const bool any_rare = __ballot(rare != 0u) != 0ull;
-    if (any_rare) {
+      const bool any_rare = rare_tile && __ballot(rare != 0u) != 0ull;
+      if (any_rare) {
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
-        const u32 idx = (u32)(k >> 2) * 256u + (u32)(k & 3) + lane4;
-        u32 op = (idx - a < span) ? w[k] : 0u;
-        WGA_PIN(op); /* opaque: no sharing of compare masks with the loop above */
-        const u32 cls = op_class(op & 15u), len = op >> 4;
-        s_s += cls == CLS_S ? len : 0u;
-        s_o += cls == CLS_O ? len : 0u;
-        bad = (cls >= CLS_S && idx < bad) ? idx : bad;
+        for (int k = 0; k < 16; k++) {
+          const u32 idx = (u32)(k >> 2) * 256u + (u32)(k & 3) + lane4;
+          u32 op = (idx - a < span) ? w[k] : 0u;
+          WGA_PIN(op); /* opaque: no sharing of compare masks with the loop above */
+          const u32 cls = op_class(op & 15u), len = op >> 4;
+          s_s += cls == CLS_S ? len : 0u;
+          s_o += cls == CLS_O ? len : 0u;
+          bad = (cls >= CLS_S && idx < bad) ? idx : bad;
+        }
       }
-    }
-    /* the wave's sums: one 32-bit reduction each when no lane's lengths add up to 2^26 (64 lanes stay below 2^32: every tile of a
-     * real alignment), else two 16-bit halves each */
-    u64 S[5], Sx, St;
-    u32 EV;
-    if (__ballot(s_t >= (1u << 26)) == 0ull) { /* wave-uniform */
-      S[0] = wave_sum_u32(s_mx);
-      S[1] = wave_sum_u32(s_i);
-      St = wave_sum_u32(s_t);
-      Sx = wave_sum_u32(s_x);
-      EV = wave_sum_u32(ev);
-      S[3] = any_rare ? (u64)wave_sum_u32(s_s) : 0ull;
-      S[4] = any_rare ? (u64)wave_sum_u32(s_o) : 0ull;
-    } else {
-      S[0] = wave_sum_u32_wide(s_mx);
-      S[1] = wave_sum_u32_wide(s_i);
-      St = wave_sum_u32_wide(s_t);
-      Sx = wave_sum_u32_wide(s_x);
-      EV = wave_sum_u32(ev);
-      S[3] = any_rare ? wave_sum_u32_wide(s_s) : 0ull;
-      S[4] = any_rare ? wave_sum_u32_wide(s_o) : 0ull;
+      wave_sums(s_mx, s_i, s_t, s_x, ev, S[0], S[1], St, Sx, EV);
+      if (any_rare) {
+        S[3] = wave_sum_u32_wide(s_s);
+        S[4] = wave_sum_u32_wide(s_o);
+        BAD = wave_min_u32(bad);
+      }
+      Amx += S[0], Ai += S[1], At += St, Ax += Sx, Aev += EV;
     }
     S[2] = St - S[0] - S[1] - S[3] - S[4]; /* every op is M-like, I, D, S or other */
-    const u32 BAD = any_rare ? wave_min_u32(bad) : 0xFFFFFFFFu;
     const u64 Smatch = S[0] - Sx;
 
 #if WGA_K1_LANE_STORE
@@ -427,8 +447,8 @@ __device__ __forceinline__ void stat_load_ops(const u32* __restrict__ ops, u64 n
   }
 }
 
-/* One wave per tile.  The kernel is bound by its VECTOR instructions — a CU retires one per cycle, and 511 per tile (626 until
- * round 6: profiles/r06_pmc.txt, r05_k1_k5_counters.txt) x 487 536 tiles / 256 CUs is 0.41 of its 0.48 ms — not by its loads (a
+/* One wave per tile.  The kernel is bound by its VECTOR instructions — a CU retires one per cycle, and 443 per tile (626 until
+ * round 6: profiles/r06_pmc.txt, r05_k1_k5_counters.txt) x 487 536 tiles / 256 CUs is 0.35 of its 0.42 ms — not by its loads (a
  * plain read of the same 2 GB runs at 6.5 TB/s, scripts/micro/read_only.hip; a grid of resident waves that requested the next
  * tile's ops early: 0.586 against 0.555 ms) and not by the atomics of records that span tiles (without them: the same time). */
 __global__ __launch_bounds__(256, WGA_K1_BLOCKS) void k_cigar_stat(const u32* __restrict__ ops,
