@@ -40,6 +40,39 @@ __global__ __launch_bounds__(256) void k_class_tiles(const u32* __restrict__ ops
   const u32 r_first = r;
   u64 cur = tile_start;
   u64 tot[5] = {0, 0, 0, 0, 0}, tail[5] = {0, 0, 0, 0, 0};
+  /* The sums as K1 makes them since round 6 (wga_kernels.h): a class sum is `len & mask`, the mask one v_bfe_i32 of a class
+   * constant (its 16 bits standing twice) by the packed op itself; the fifth class is what the four others leave of the sum of
+   * all lengths; the whole tile is summed first, without a range test, and a tile's last segment is what the segments in front
+   * leave of it; one 32-bit reduction per sum when no lane's lengths reach 2^26.  14 vector instructions per op (17 with the
+   * range test) where the class number, five compares and five selects took 45 (0.67 -> 0.3x ms on configs[1]'s batch). */
+  constexpr u32 MX_BITS = 0x01810181u, I_BITS = 0x02020202u, D_BITS = 0x04040404u, S_BITS = 0x00100010u;
+  auto wave_sums = [&](const u32 (&p)[5], u64 (&S)[5]) { /* p[4]: every op's length */
+    u64 T;
+    if (__ballot(p[4] >= (1u << 26)) == 0ull) { /* wave-uniform */
+#pragma unroll
+      for (int c = 0; c < 4; c++) S[c] = wave_sum_u32(p[c]);
+      T = wave_sum_u32(p[4]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; c++) S[c] = wave_sum_u32_wide(p[c]);
+      T = wave_sum_u32_wide(p[4]);
+    }
+    S[4] = T - S[0] - S[1] - S[2] - S[3]; /* every op is M-like, I, D, S or other */
+  };
+  u64 W[5], A[5] = {0, 0, 0, 0, 0}; /* the whole tile; its segments so far */
+  {
+    u32 p[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const u32 op = w[k], len = op >> 4;
+      p[0] += len & bit_mask(MX_BITS, op);
+      p[1] += len & bit_mask(I_BITS, op);
+      p[2] += len & bit_mask(D_BITS, op);
+      p[3] += len & bit_mask(S_BITS, op);
+      p[4] += len;
+    }
+    wave_sums(p, W);
+  }
   while (cur < tile_end) {
     u64 re = op_off[r + 1];
     while (re <= cur) {
@@ -49,25 +82,28 @@ __global__ __launch_bounds__(256) void k_class_tiles(const u32* __restrict__ ops
     const u64 rs = op_off[r];
     const u64 seg_end = re < tile_end ? re : tile_end;
     const u32 a = (u32)(cur - tile_start), b = (u32)(seg_end - tile_start);
-    u32 s[5] = {0, 0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        u32 idx = ((u32)j * 64u + lane) * 4u + (u32)e;
-        u32 op = w[4 * j + e];
-        u32 cls = op_class(op & 15u);
-        u32 l = (idx >= a && idx < b) ? (op >> 4) : 0u;
-        s[0] += cls == CLS_MX ? l : 0u;
-        s[1] += cls == CLS_I ? l : 0u;
-        s[2] += cls == CLS_D ? l : 0u;
-        s[3] += cls == CLS_S ? l : 0u;
-        s[4] += cls == CLS_O ? l : 0u;
-      }
-    }
     u64 S[5];
+    if (seg_end == tile_end) { /* wave-uniform */
 #pragma unroll
-    for (int c = 0; c < 5; c++) S[c] = wave_sum_u32_wide(s[c]); /* DPP scans on 16-bit halves: exact (a lane's sum < 2^32) */
+      for (int c = 0; c < 5; c++) S[c] = W[c] - A[c];
+    } else {
+      const u32 span = b - a;
+      u32 p[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const u32 idx = ((u32)(k >> 2) * 64u + lane) * 4u + (u32)(k & 3);
+        const u32 op = (idx - a < span) ? w[k] : 0u;
+        const u32 len = op >> 4;
+        p[0] += len & bit_mask(MX_BITS, op);
+        p[1] += len & bit_mask(I_BITS, op);
+        p[2] += len & bit_mask(D_BITS, op);
+        p[3] += len & bit_mask(S_BITS, op);
+        p[4] += len;
+      }
+      wave_sums(p, S);
+#pragma unroll
+      for (int c = 0; c < 5; c++) A[c] += S[c];
+    }
     if (rec_sums && lane == 0) {
       u64* f = (u64*)(rec_sums + r);
       if (rs >= tile_start && re <= tile_end) {
