@@ -64,7 +64,9 @@ struct __attribute__((aligned(16))) wga_cov_desc {
 /* The list pass writes a tile's first WGA_COV_TILE_CAP pieces into the tile's own slots — no atomic with an answer to wait for —
  * and further ones where WGA_COV_LISTS counters hand out places (tile g uses counter g mod WGA_COV_LISTS: one counter for all
  * tiles would take every such segment of the batch through one address), each over a region of `rcap` pieces. */
+#ifndef WGA_COV_TILE_CAP
 #define WGA_COV_TILE_CAP (WGA_COV_LO / 2u) /* 8 slots per 1 024 ops */
+#endif
 #define WGA_COV_LISTS 4096u
 #define WGA_COV_READY (1ull << 63)
 /* inclusive scan over the lanes of a value below 2^40 (a lane's 16 ops advance less than 16 x 2^28), and the wave's total: two
